@@ -1,0 +1,159 @@
+"""Parity cases shared by the golden generator (reference side), the oracle tests and the
+GPU tests: deterministic inputs (hashfill) and the oracle call for every case.
+
+Per-op cases are tiny (outputs are stored in full in the fixtures); the end-to-end
+cases use the real channel counts with small spatial sizes / point counts.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
+from oracle import cmr_oracle as O  # noqa: E402
+
+
+def u(name, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(hashfill.uniform("case/" + name, shape, lo, hi).astype(np.float32))
+
+
+def _nearest(xyz_b3n, node_b3m):
+    d = ((xyz_b3n[:, :, :, None] - node_b3m[:, :, None, :]) ** 2).sum(1)
+    return d.argmin(dim=2)
+
+
+# ---------------------------------------------------------------------------------------------
+# per-op cases: name -> (inputs(), oracle(sd, inputs))
+# ---------------------------------------------------------------------------------------------
+
+def _gpt_inputs():
+    xyz = u("gpt/xyz", (2, 3, 300), -5, 5)
+    node = xyz[:, :, :40].clone()
+    return dict(xyz=xyz, feat=u("gpt/feat", (2, 64, 300)), node=node, node_feat=u("gpt/nf", (2, 64, 40)),
+                idx=_nearest(xyz, node))
+
+
+def _pnu_inputs():
+    xyz = u("pnu/xyz", (2, 500, 3), -1, 1)
+    return dict(xyz=xyz, points=u("pnu/pts", (2, 500, 8)), start=torch.tensor([3, 77]))
+
+
+OP_CASES = {
+    "resblock_3_64_s1": dict(inputs=lambda: dict(x=u("rb0", (2, 3, 16, 32), 0, 1)),
+                             oracle=lambda sd, i: dict(y=O.residual_block(O.Weights(sd), i["x"], 1))),
+    "resblock_64_64_s1": dict(inputs=lambda: dict(x=u("rb1", (2, 64, 12, 20))),
+                              oracle=lambda sd, i: dict(y=O.residual_block(O.Weights(sd), i["x"], 1))),
+    "resblock_64_64_s2": dict(inputs=lambda: dict(x=u("rb2", (2, 64, 12, 20))),
+                              oracle=lambda sd, i: dict(y=O.residual_block(O.Weights(sd), i["x"], 2))),
+    "resblock_128_64_s1": dict(inputs=lambda: dict(x=u("rb3", (1, 128, 9, 13))),
+                               oracle=lambda sd, i: dict(y=O.residual_block(O.Weights(sd), i["x"], 1))),
+    "mini_pointnet_3_64": dict(inputs=lambda: dict(x=u("mp0", (2, 3, 200), -5, 5)),
+                               oracle=lambda sd, i: dict(y=O.mini_pointnet(O.Weights(sd), i["x"]))),
+    "mini_pointnet_128_64": dict(inputs=lambda: dict(x=u("mp1", (2, 128, 100))),
+                                 oracle=lambda sd, i: dict(y=O.mini_pointnet(O.Weights(sd), i["x"]))),
+    "cbr1d_128_64": dict(inputs=lambda: dict(x=u("cb0", (2, 128, 150))),
+                         oracle=lambda sd, i: dict(y=O.conv_bn_relu_res1d(O.Weights(sd), i["x"]))),
+    "cbr1d_64_64": dict(inputs=lambda: dict(x=u("cb1", (2, 64, 150))),
+                        oracle=lambda sd, i: dict(y=O.conv_bn_relu_res1d(O.Weights(sd), i["x"]))),
+    "cbr1d_5_64": dict(inputs=lambda: dict(x=u("cb2", (2, 5, 150))),
+                       oracle=lambda sd, i: dict(y=O.conv_bn_relu_res1d(O.Weights(sd), i["x"]))),
+    "group_point_transformer": dict(
+        inputs=_gpt_inputs,
+        oracle=lambda sd, i: dict(y=O.group_point_transformer(O.Weights(sd), i["xyz"], i["feat"], i["node"],
+                                                              i["node_feat"], i["idx"]))),
+    "knn_point_transformer": dict(
+        inputs=lambda: dict(xyz=u("knn/xyz", (2, 3, 100), -5, 5), feat=u("knn/feat", (2, 64, 100))),
+        oracle=lambda sd, i: dict(y=O.knn_point_transformer(O.Weights(sd), i["xyz"], i["feat"], 16),
+                                  knn=O.knn_indices(i["xyz"].permute(0, 2, 1), 16))),
+    "vit_self_block": dict(inputs=lambda: dict(x=u("vs/x", (2, 50, 64))),
+                           oracle=lambda sd, i: dict(y=O.vit_block(O.Weights(sd), i["x"], None, 8))),
+    "vit_cross_block": dict(inputs=lambda: dict(x=u("vc/x", (2, 50, 64)), y=u("vc/y", (2, 30, 64))),
+                            oracle=lambda sd, i: dict(y=O.vit_block(O.Weights(sd), i["x"], i["y"], 8))),
+    "linear_attention": dict(inputs=lambda: dict(x=u("la/x", (2, 70, 64)), y=u("la/y", (2, 45, 64))),
+                             oracle=lambda sd, i: dict(y=O.linear_attention(O.Weights(sd), i["x"], i["y"], 8))),
+    "posenc_sine_2d": dict(inputs=lambda: dict(x=u("pe/x", (1, 64, 24, 32))),
+                           oracle=lambda sd, i: dict(y=i["x"] + O.position_encoding_sine_2d(64, 24, 32))),
+    "pointnet_util": dict(
+        inputs=_pnu_inputs,
+        oracle=lambda sd, i: _pnu_oracle(i)),
+    "set_abstraction": dict(
+        inputs=_pnu_inputs,
+        oracle=lambda sd, i: dict(zip(("new_xyz", "new_points"),
+                                      O.set_abstraction(O.Weights(sd), i["xyz"], i["points"], 32, 0.4, 16, i["start"])))),
+    "set_abstraction_msg": dict(
+        inputs=_pnu_inputs,
+        oracle=lambda sd, i: dict(zip(("new_xyz", "new_points"),
+                                      O.set_abstraction_msg(O.Weights(sd), i["xyz"], i["points"], 32, [0.3, 0.6],
+                                                            [8, 16], i["start"])))),
+    "feature_propagation": dict(
+        inputs=lambda: dict(xyz1=u("fp/x1", (2, 3, 200)), xyz2=u("fp/x2", (2, 3, 40)), p1=u("fp/p1", (2, 8, 200)),
+                            p2=u("fp/p2", (2, 16, 40))),
+        oracle=lambda sd, i: dict(y=O.feature_propagation(O.Weights(sd), i["xyz1"], i["xyz2"], i["p1"], i["p2"]))),
+}
+
+
+def _pnu_oracle(i):
+    xyz, pts = i["xyz"], i["points"]
+    fps = O.farthest_point_sample(xyz, 64, i["start"])
+    new_xyz = O.index_points(xyz, fps)
+    ball = O.query_ball_point(0.4, 16, xyz, new_xyz)
+    sq = O.square_distance(new_xyz, xyz)
+    nx, g, _, _ = O.sample_and_group(32, 0.4, 16, xyz, pts, i["start"])
+    return dict(fps=fps, new_xyz=new_xyz, ball=ball, sqdist=sq, sg_xyz=nx, sg_points=g,
+                gathered=O.index_points(pts, ball))
+
+
+# ---------------------------------------------------------------------------------------------
+# end-to-end cases
+# ---------------------------------------------------------------------------------------------
+
+E2E_CASES = {
+    # reference-native map size (the only one the unmodified reference accepts)
+    "e2e_native": dict(B=2, N=4096, H=160, W=512, M=1280, Q=256, steps=10, n_circle=128),
+    # small, with odd tile counts: h x w = 24 x 40, T = 15
+    "e2e_small": dict(B=2, N=1024, H=96, W=160, M=320, Q=256, steps=3, n_circle=64),
+}
+
+
+def e2e_config(case):
+    from cmr_agent_amd.config import KittiConfiguration
+    c = E2E_CASES[case]
+    return KittiConfiguration(cropped_img_H=c["H"], cropped_img_W=c["W"], num_pt=c["N"], device="cpu",
+                              num_node=c["M"], num_proxy=c["Q"], action_num=c["steps"])
+
+
+def e2e_batch(case):
+    c = E2E_CASES[case]
+    return synthetic.make_batch(c["B"], c["N"], c["H"], c["W"], c["M"], O.dataset_fps, O.nearest_node,
+                                seed=2023, n_circle=c["n_circle"])
+
+
+GEO_TAG, AGENT_TAG = "geo4/", "agent/"      # fill tags probed to give a non-degenerate overlap prediction
+
+
+def e2e_state_dicts(spec):
+    """spec = json-loaded {'geo': {key: shape}, 'agent': {key: shape}}."""
+    return (hashfill.make_state_dict(spec["geo"], GEO_TAG), hashfill.make_state_dict(spec["agent"], AGENT_TAG))
+
+
+GEO_KEYS = ("img_feat_2", "node2proxy", "pt_feat", "node_feat", "img_proxy", "pt_proxy", "vis_feat",
+            "fused_img_feat", "fused_node_feat", "pc_overlap_logits", "img_overlap_logits", "pc_geo_feat",
+            "img_geo_feat", "pc_overlap_pred", "pc_is_in_cam_scores", "img_overlap_pred")
+
+
+def e2e_oracle(case, geo_sd, agent_sd, batch=None):
+    cfg = e2e_config(case)
+    batch = e2e_batch(case) if batch is None else batch
+    pose, trace, out = O.registration_iteration(geo_sd, agent_sd, batch, cfg)
+    named = {k: out[k] for k in GEO_KEYS}
+    for s, t in enumerate(trace):
+        for k in ("r_logits", "t_logits", "value", "action_r", "action_t", "pose"):
+            named["step%d/%s" % (s, k)] = t[k]
+    named["final_pose"] = pose
+    return named

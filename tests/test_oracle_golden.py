@@ -1,0 +1,48 @@
+"""CPU tier: the oracle (oracle/cmr_oracle.py) reproduces every committed golden fixture.
+
+The fixtures were produced by running the reference itself (tests/golden/make_golden.py);
+there the oracle matched the reference's full tensors to <= 5e-7 (see
+tests/golden/oracle_vs_reference.json), so tolerances here are tight.
+"""
+import json
+import os
+
+import pytest
+import torch
+
+import cases as C
+import golden_util as G
+from cmr_agent_amd.utils import hashfill
+
+torch.set_grad_enabled(False)
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+
+
+@pytest.mark.parametrize("name", sorted(C.OP_CASES))
+def test_op_case(name):
+    case = C.OP_CASES[name]
+    sd = hashfill.make_state_dict(SPECS[name], name + "/")
+    out = case["oracle"](sd, case["inputs"]())
+    G.assert_case(name, out, atol=2e-6, rtol=2e-6)
+
+
+def test_dataset_ops():
+    from oracle import cmr_oracle as O
+    pc = hashfill.uniform("case/ds/pc", (3, 3000), -30, 30)
+    nodes, idx = O.dataset_fps(pc[:, :1200], 100, 2)
+    G.assert_case("dataset_ops", dict(fps_idx=idx, nodes=nodes, pt2node=O.nearest_node(pc, nodes)), 0, 0)
+
+
+@pytest.mark.parametrize("case", sorted(C.E2E_CASES))
+def test_e2e_case(case):
+    geo_sd, agent_sd = C.e2e_state_dicts(SPECS)
+    named = C.e2e_oracle(case, geo_sd, agent_sd)
+    G.assert_case(case, named, atol=1e-5, rtol=1e-5)
+
+
+def test_fixture_documents_reference_agreement():
+    rep = json.load(open(os.path.join(G.GOLDEN_DIR, "oracle_vs_reference.json")))
+    for case, d in rep.items():
+        for k, v in d.items():
+            if not k.startswith("_"):
+                assert v <= 1e-6, (case, k, v)
