@@ -1,0 +1,187 @@
+// Attention kernels of the coarse (softmax) and fine (linear) matchers.
+//
+// cmr_mha_f32        softmax(Q K^T / sqrt(dh)) V for 8 heads x 8 dims on <= ~2k tokens
+//                    (ImageViT.py:81-108, PointViT.py:117-140, IMGPCEncoder.py:36-58).  Head dim 8 and
+//                    T <= 1400 make this a latency problem, not an MFMA one: K/V of one head live in
+//                    LDS (broadcast b128 reads), one query per lane, two passes (max, then exp/sum).
+// cmr_la_reduce_f32  KV[h,d,v] = sum_s K~[s,h,d] * V[s,h,v] / S  and  Ksum[h,d] = sum_s K~[s,h,d]
+// cmr_la_apply_f32   msg[l,h,v] = (Q~[l,h,:] . KV[h,:,v]) * S / (Q~[l,h,:] . Ksum[h,:] + eps)
+//                    (LinearAttention.py:53-60; K~,Q~ = elu+1 are produced by the projection epilogue).
+#include "cmr_common.h"
+
+namespace {
+
+constexpr int DH = 8, NH = 8, CH = 64;
+
+__global__ __launch_bounds__(64) void mha_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                 int64_t ldk, const float* __restrict__ v, int64_t ldv,
+                                                 float* __restrict__ o, int64_t ldo, int Tq, int Tk, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tk][8] then V_h [Tk][8]
+  float* ks = kv;
+  float* vs = kv + (size_t)Tk * DH;
+  const int head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const float* kb = k + (int64_t)b * Tk * ldk + head * DH;
+  const float* vb = v + (int64_t)b * Tk * ldv + head * DH;
+  for (int e = lane; e < Tk * 2; e += 64) {
+    const int t = e >> 1, half = (e & 1) * 4;
+    *reinterpret_cast<f32x4*>(&ks[t * DH + half]) = *reinterpret_cast<const f32x4*>(kb + (int64_t)t * ldk + half);
+    *reinterpret_cast<f32x4*>(&vs[t * DH + half]) = *reinterpret_cast<const f32x4*>(vb + (int64_t)t * ldv + half);
+  }
+  __syncthreads();
+  const int tq = blockIdx.x * 64 + lane;
+  if (tq >= Tq) return;
+  const float* qp = q + ((int64_t)b * Tq + tq) * ldq + head * DH;
+  const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
+  auto score = [&](int t) {
+    const f32x4 k0 = *reinterpret_cast<const f32x4*>(&ks[t * DH]);
+    const f32x4 k1 = *reinterpret_cast<const f32x4*>(&ks[t * DH + 4]);
+    float s = q0[0] * k0[0];
+    s += q0[1] * k0[1]; s += q0[2] * k0[2]; s += q0[3] * k0[3];
+    s += q1[0] * k1[0]; s += q1[1] * k1[1]; s += q1[2] * k1[2]; s += q1[3] * k1[3];
+    return s * scale;
+  };
+  float m = -INFINITY;
+  for (int t = 0; t < Tk; ++t) m = fmaxf(m, score(t));
+  float l = 0.f;
+  float acc[DH] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < Tk; ++t) {
+    const float p = expf(score(t) - m);
+    l += p;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(&vs[t * DH]);
+    const f32x4 v1 = *reinterpret_cast<const f32x4*>(&vs[t * DH + 4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] += p * v0[i]; acc[4 + i] += p * v1[i]; }
+  }
+  const float inv = 1.f / l;
+  float* op = o + ((int64_t)b * Tq + tq) * ldo + head * DH;
+  f32x4 o0 = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+  f32x4 o1 = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
+  *reinterpret_cast<f32x4*>(op) = o0;
+  *reinterpret_cast<f32x4*>(op + 4) = o1;
+}
+
+// partial sums over a slab of TS tokens: thread (h,d,v) accumulates K[s,h,d]*V[s,h,v]/S; threads with
+// v == 0 also accumulate Ksum.  part layout: [B][nslab][576]  (512 KV entries then 64 Ksum entries)
+constexpr int LA_TS = 32;
+__global__ __launch_bounds__(512) void la_reduce_partial_kernel(const float* __restrict__ kf, int64_t ldk,
+                                                                const float* __restrict__ v, int64_t ldv,
+                                                                float* __restrict__ part, int S, int slab_tokens) {
+  __shared__ __attribute__((aligned(16))) float ks[LA_TS * CH];
+  __shared__ __attribute__((aligned(16))) float vs[LA_TS * CH];
+  const int b = blockIdx.y, slab = blockIdx.x, tid = threadIdx.x;
+  const int hh = tid >> 6, d = (tid >> 3) & 7, vv = tid & 7;
+  const int s_begin = slab * slab_tokens;
+  const int s_end = min(S, s_begin + slab_tokens);
+  const float invS = (float)S;
+  float acc = 0.f, ksum = 0.f;
+  for (int s0 = s_begin; s0 < s_end; s0 += LA_TS) {
+    __syncthreads();
+    {  // 32 tokens x 16 float4 = 512 float4 per tensor: one per thread
+      const int t = tid >> 4, c = (tid & 15) * 4;
+      f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = {0.f, 0.f, 0.f, 0.f};
+      if (s0 + t < s_end) {
+        a = *reinterpret_cast<const f32x4*>(kf + ((int64_t)b * S + s0 + t) * ldk + c);
+        bq = *reinterpret_cast<const f32x4*>(v + ((int64_t)b * S + s0 + t) * ldv + c);
+        bq[0] = bq[0] / invS; bq[1] = bq[1] / invS; bq[2] = bq[2] / invS; bq[3] = bq[3] / invS;  // value / v_length
+      }
+      *reinterpret_cast<f32x4*>(&ks[t * CH + c]) = a;
+      *reinterpret_cast<f32x4*>(&vs[t * CH + c]) = bq;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int t = 0; t < LA_TS; ++t) {
+      const float kk = ks[t * CH + hh * 8 + d];
+      acc += kk * vs[t * CH + hh * 8 + vv];
+      ksum += kk;
+    }
+  }
+  float* p = part + ((int64_t)b * gridDim.x + slab) * 576;
+  p[tid] = acc;
+  if (vv == 0) p[512 + hh * 8 + d] = ksum;
+}
+
+__global__ __launch_bounds__(576) void la_reduce_final_kernel(const float* __restrict__ part, float* __restrict__ kvsum,
+                                                              int nslab) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = 0; i < nslab; ++i) s += part[((int64_t)b * nslab + i) * 576 + tid];
+  kvsum[(int64_t)b * 576 + tid] = s;
+}
+
+// one wave per token group; lane = output channel c = h*8+v
+__global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__ qf, int64_t ldq,
+                                                       const float* __restrict__ kvsum, float* __restrict__ msg,
+                                                       int64_t ldm, int L, int S, float eps, int tokens_per_wave) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hh = lane >> 3, vv = lane & 7;
+  const float* kvb = kvsum + (int64_t)b * 576;
+  float kvr[8], ksr[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    kvr[d] = kvb[hh * 64 + d * 8 + vv];
+    ksr[d] = kvb[512 + hh * 8 + d];
+  }
+  const float fs = (float)S;
+  const int l0 = (blockIdx.x * 4 + wave) * tokens_per_wave;
+  const int l1 = min(L, l0 + tokens_per_wave);
+  for (int l = l0; l < l1; ++l) {
+    const float qv = qf[((int64_t)b * L + l) * ldq + lane];
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      const float qd = __shfl(qv, hh * 8 + d);
+      num += qd * kvr[d];
+      den += qd * ksr[d];
+    }
+    const float z = 1.f / (den + eps);
+    msg[((int64_t)b * L + l) * ldm + lane] = num * z * fs;
+  }
+}
+
+}  // namespace
+
+extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                           float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
+  CMR_REQUIRE(q && k && v && o && B > 0 && B <= 65535 && Tq > 0 && Tk > 0);
+  CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
+  CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(o));
+  const size_t smem = (size_t)Tk * DH * 2 * sizeof(float);
+  CMR_REQUIRE(smem <= 160 * 1024);
+  if (smem > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mha_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return CMR_ELAUNCH;
+  }
+  dim3 grid((Tq + 63) / 64, NH, B);
+  hipLaunchKernelGGL(mha_kernel, grid, dim3(64), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
+                     0.35355339059327373f);
+  return cmr_launch_status();
+}
+
+extern "C" int64_t cmr_la_reduce_workspace_bytes(int B, int S) {
+  const int slab_tokens = 512;
+  const int nslab = (S + slab_tokens - 1) / slab_tokens;
+  return (int64_t)B * nslab * 576 * sizeof(float);
+}
+
+extern "C" int cmr_la_reduce_f32(const float* kf, int64_t ldk, const float* v, int64_t ldv, float* kvsum,
+                                 void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
+  CMR_REQUIRE(kf && v && kvsum && workspace && B > 0 && B <= 65535 && S > 0);
+  CMR_REQUIRE(ldk % 4 == 0 && ldv % 4 == 0 && cmr_aligned16(kf) && cmr_aligned16(v));
+  CMR_REQUIRE(workspace_bytes >= cmr_la_reduce_workspace_bytes(B, S));
+  const int slab_tokens = 512;
+  const int nslab = (S + slab_tokens - 1) / slab_tokens;
+  hipLaunchKernelGGL(la_reduce_partial_kernel, dim3(nslab, B), dim3(512), 0, stream, kf, ldk, v, ldv,
+                     (float*)workspace, S, slab_tokens);
+  hipLaunchKernelGGL(la_reduce_final_kernel, dim3(B), dim3(576), 0, stream, (const float*)workspace, kvsum, nslab);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* msg, int64_t ldm, int B, int L,
+                                int S, float eps, hipStream_t stream) {
+  CMR_REQUIRE(qf && kvsum && msg && B > 0 && B <= 65535 && L > 0 && S > 0);
+  const int tokens_per_wave = 16;
+  dim3 grid((L + 4 * tokens_per_wave - 1) / (4 * tokens_per_wave), B);
+  hipLaunchKernelGGL(la_apply_kernel, grid, dim3(256), 0, stream, qf, ldq, kvsum, msg, ldm, L, S, eps, tokens_per_wave);
+  return cmr_launch_status();
+}

@@ -1,0 +1,41 @@
+// Shared device/host helpers for libcmr_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CMR_OK 0
+#define CMR_EINVAL -1   // bad argument (shape / alignment / null pointer)
+#define CMR_ELAUNCH -2  // hipGetLastError() after the launch was not hipSuccess
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CMR_REQUIRE(cond) \
+  do {                    \
+    if (!(cond)) return CMR_EINVAL; \
+  } while (0)
+
+static inline int cmr_launch_status() { return hipGetLastError() == hipSuccess ? CMR_OK : CMR_ELAUNCH; }
+
+static inline bool cmr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// activation codes shared by the GEMM / conv epilogues
+enum { CMR_ACT_NONE = 0, CMR_ACT_RELU = 1, CMR_ACT_LRELU = 2, CMR_ACT_GELU = 3, CMR_ACT_ELU1 = 4 };
+
+__device__ __forceinline__ float cmr_act(float v, int act, float p) {
+  switch (act) {
+    case CMR_ACT_RELU: return v > 0.f ? v : 0.f;
+    case CMR_ACT_LRELU: return v > 0.f ? v : v * p;
+    case CMR_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case CMR_ACT_ELU1: return v > 0.f ? v + 1.f : expf(v);  // elu(v) + 1
+    default: return v;
+  }
+}
+
+// 32x32x2 fp32 MFMA: D[i][j] += sum_k A[i][k] B[k][j];  lane l supplies A[i=l&31][k=l>>5] and
+// B[k=l>>5][j=l&31]; D register r of lane l is D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+__device__ __forceinline__ f32x16 cmr_mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int cmr_mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }

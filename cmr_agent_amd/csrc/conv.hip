@@ -1,0 +1,370 @@
+// NHWC image-side kernels: 3x3 convolution as an implicit GEMM on fp32 MFMA with fused
+// (folded-BN) bias + residual + LeakyReLU + positional table, the 3-channel stem of
+// MiniResNet, pooling, the x8 nearest up-sample + concat, and the 8x8 patch gather.
+//
+// Reference: ResidualBlock / MiniResNet (models/ImageResNet.py:5-65), the fuse / head
+// ResidualBlocks (IMGPCEnDecoder.py:49-54,85-94; MultiHeadModel.py:41-47,133-139) and
+// CMRAgent.state_2d_embed (CMRAgent.py:34-60).  BatchNorm is inference-mode and folded into
+// the conv weights/bias on the host when the module is prepared.
+//
+// conv3x3 data flow per workgroup (256 threads = 4 waves):
+//   output tile  TH x 32 pixels x 64 output channels (grid.z walks batch x Cout/64)
+//   K loop       input channels in chunks of KC; per chunk the (TH-1)*S+3 x 31*S+3 halo tile is
+//                staged ONCE in LDS ([pixel][KC+4] floats) and reused by all 9 taps; per tap a
+//                [64 cout][KC+4] weight slab is double-buffered in LDS, prefetched through
+//                registers while the previous tap's MFMAs run.
+//   math         v_mfma_f32_32x32x2_f32: M = 32 consecutive output pixels of one row, N = 32 couts.
+#include "cmr_common.h"
+
+namespace {
+
+struct ConvArgs {
+  const float* x; int B, H, W, Cin;
+  const float* w;      // [9][Cout][Cin]
+  const float* bias;   // [Cout] or null
+  const float* res;    // [B,Ho,Wo,Cout] or null (added before the activation)
+  const float* post;   // [Ho,Wo,Cout] or null  (added after the activation)
+  float* y; int Ho, Wo, Cout;
+  float slope;         // LeakyReLU slope; 1.0f = identity
+};
+
+template <int S, int MT, int KC>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
+  constexpr int TH = 4 * MT, TW = 32;
+  constexpr int HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
+  constexpr int LDP = KC + 4;              // floats per halo pixel / weight row in LDS
+  constexpr int C4 = KC / 4;               // float4 per pixel per chunk
+  constexpr int HALO_F4 = HR * HC * C4;
+  constexpr int WSLAB_F4 = 64 * C4;
+  constexpr int WL = (WSLAB_F4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;                      // [HR*HC][LDP]
+  float* wbuf = smem + HR * HC * LDP;      // [2][64][LDP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nco = a.Cout / 64;
+  const int b = blockIdx.z / nco, co0 = (blockIdx.z % nco) * 64;
+  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+  const int nchunk = a.Cin / KC;
+  const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
+
+  f32x4 wr[WL];
+  auto load_slab = [&](int chunk, int tap) {   // weights for (tap, chunk) -> registers
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      int e = tid + 256 * i;
+      if (WSLAB_F4 % 256 == 0 || e < WSLAB_F4) {
+        int n = e / C4, c = e % C4;
+        wr[i] = *reinterpret_cast<const f32x4*>(a.w + ((int64_t)tap * a.Cout + co0 + n) * a.Cin + chunk * KC + c * 4);
+      }
+    }
+  };
+  auto store_slab = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WL; ++i) {
+      int e = tid + 256 * i;
+      if (WSLAB_F4 % 256 == 0 || e < WSLAB_F4) {
+        int n = e / C4, c = e % C4;
+        *reinterpret_cast<f32x4*>(&wbuf[(buf * 64 + n) * LDP + c * 4]) = wr[i];
+      }
+    }
+  };
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // LDS float offset of this lane's A rows (tap (0,0), k-group 0)
+  int abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) abase[m] = (((wave * MT + m) * S) * HC + l31 * S) * LDP + 4 * h;
+  const int bbase = l31 * LDP + 4 * h;
+
+  load_slab(0, 0);
+  int cur = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    __syncthreads();   // every wave is done with the previous chunk's halo
+    for (int e = tid; e < HALO_F4; e += 256) {
+      int p = e / C4, c = e % C4;
+      int py = p / HC, px = p % HC;
+      int iy = iy0 + py, ix = ix0 + px;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+        v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)iy * a.W + ix) * a.Cin + chunk * KC + c * 4);
+      *reinterpret_cast<f32x4*>(&halo[p * LDP + c * 4]) = v;
+    }
+    for (int tap = 0; tap < 9; ++tap) {
+      store_slab(cur);
+      __syncthreads();  // slab `cur` (and on tap 0 the halo) visible; tap-1 compute finished everywhere
+      if (tap < 8) load_slab(chunk, tap + 1);
+      else if (chunk + 1 < nchunk) load_slab(chunk + 1, 0);
+      const int toff = ((tap / 3) * HC + (tap % 3)) * LDP;
+      const float* wb = wbuf + cur * 64 * LDP;
+#pragma unroll
+      for (int kg = 0; kg < KC / 8; ++kg) {
+        f32x4 av[MT], bv[2];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(&halo[abase[m] + toff + kg * 8]);
+        bv[0] = *reinterpret_cast<const f32x4*>(&wb[bbase + kg * 8]);
+        bv[1] = *reinterpret_cast<const f32x4*>(&wb[bbase + 32 * LDP + kg * 8]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            acc[m][0] = cmr_mfma32(av[m][j], bv[0][j], acc[m][0]);
+            acc[m][1] = cmr_mfma32(av[m][j], bv[1][j], acc[m][1]);
+          }
+      }
+      cur ^= 1;
+    }
+  }
+
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int oy = oy0 + wave * MT + m;
+    if (oy >= a.Ho) continue;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int co = co0 + n * 32 + l31;
+      const float bsv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ox = ox0 + cmr_mfma_row(r, lane);
+        if (ox < a.Wo) {
+          const int64_t pix = (int64_t)oy * a.Wo + ox;
+          const int64_t o = ((int64_t)b * a.Ho * a.Wo + pix) * a.Cout + co;
+          float v = acc[m][n][r] + bsv;
+          if (a.res) v += a.res[o];
+          v = v > 0.f ? v : v * a.slope;
+          if (a.post) v += a.post[pix * a.Cout + co];
+          a.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int S, int MT, int KC>
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+  constexpr int TH = 4 * MT, HR = (TH - 1) * S + 3, HC = 31 * S + 3, LDP = KC + 4;
+  constexpr size_t smem = (size_t)(HR * HC * LDP + 2 * 64 * LDP) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<S, MT, KC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return CMR_ELAUNCH;
+    attr_set = true;
+  }
+  dim3 grid((a.Wo + 31) / 32, (a.Ho + TH - 1) / TH, a.B * (a.Cout / 64));
+  hipLaunchKernelGGL((conv3x3_kernel<S, MT, KC>), grid, dim3(256), smem, stream, a);
+  return cmr_launch_status();
+}
+
+// ---- MiniResNet block 0 (3 input channels), direct VALU convolutions -------------------------
+// stem_a: t = LReLU(conv3x3(3->3)(x) + b)      NCHW [B,3,H,W] -> NCHW [B,3,H,W]
+__global__ __launch_bounds__(256) void stem_a_kernel(const float* __restrict__ x, const float* __restrict__ w /*[3][3][3][3]*/,
+                                                     const float* __restrict__ bias, float* __restrict__ t, int B, int H,
+                                                     int W, float slope) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t hw = (int64_t)H * W;
+  if (p >= B * hw) return;
+  const int b = (int)(p / hw);
+  const int yy = (int)((p % hw) / W), xx = (int)(p % W);
+  float o[3] = {bias[0], bias[1], bias[2]};
+  for (int ci = 0; ci < 3; ++ci)
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = yy + ky - 1;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = xx + kx - 1;
+        if (ix < 0 || ix >= W) continue;
+        const float v = x[((int64_t)b * 3 + ci) * hw + (int64_t)iy * W + ix];
+#pragma unroll
+        for (int co = 0; co < 3; ++co) o[co] += v * w[((co * 3 + ci) * 3 + ky) * 3 + kx];
+      }
+    }
+#pragma unroll
+  for (int co = 0; co < 3; ++co) {
+    const float v = o[co];
+    t[((int64_t)b * 3 + co) * hw + (int64_t)yy * W + xx] = v > 0.f ? v : v * slope;
+  }
+}
+
+// stem_b: y = LReLU(conv3x3(3->C)(t) + conv1x1(3->C)(x) + b)   NCHW x2 -> NHWC [B,H,W,C], C = 64
+// one wave per 4 consecutive pixels, lane = output channel (coalesced 256-B rows)
+__global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t, const float* __restrict__ x,
+                                                     const float* __restrict__ w3 /*[27][64] (ci,ky,kx major)*/,
+                                                     const float* __restrict__ w1 /*[3][64]*/,
+                                                     const float* __restrict__ bias /*[64] (both BN shifts)*/,
+                                                     float* __restrict__ y, int B, int H, int W, float slope) {
+  __shared__ float sw[30 * 64];
+  for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[i] = w3[i];
+  for (int i = threadIdx.x; i < 3 * 64; i += 256) sw[27 * 64 + i] = w1[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw;
+  const float bs = bias[lane];
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
+  for (int q = 0; q < 4; ++q) {
+    const int64_t p = p0 + q;
+    if (p >= total) break;
+    const int b = (int)(p / hw);
+    const int yy = (int)((p % hw) / W), xx = (int)(p % W);
+    float o = bs;
+    for (int ci = 0; ci < 3; ++ci) {
+      const float* tp = t + ((int64_t)b * 3 + ci) * hw;
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = yy + ky - 1;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = xx + kx - 1;
+          if (ix < 0 || ix >= W) continue;
+          o += tp[(int64_t)iy * W + ix] * sw[((ci * 3 + ky) * 3 + kx) * 64 + lane];
+        }
+      }
+      o += x[((int64_t)b * 3 + ci) * hw + (int64_t)yy * W + xx] * sw[(27 + ci) * 64 + lane];
+    }
+    y[p * 64 + lane] = o > 0.f ? o : o * slope;
+  }
+}
+
+// ---- pooling / resampling ---------------------------------------------------------------------
+// AvgPool2d(k, stride k) on NHWC with floor semantics; (kh,kw)=(H,W) gives the global pool.
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H,
+                                                      int W, int C, int kh, int kw, int Ho, int Wo) {
+  const int c4n = C / 4;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * Ho * Wo * c4n) return;
+  const int c = (int)(e % c4n) * 4;
+  const int64_t p = e / c4n;
+  const int ox = (int)(p % Wo), oy = (int)((p / Wo) % Ho), b = (int)(p / ((int64_t)Wo * Ho));
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int dy = 0; dy < kh; ++dy)
+    for (int dx = 0; dx < kw; ++dx) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + oy * kh + dy) * W + ox * kw + dx) * C + c);
+      s += v;
+    }
+  const float inv = 1.f / (float)(kh * kw);
+  s[0] *= inv; s[1] *= inv; s[2] *= inv; s[3] *= inv;
+  *reinterpret_cast<f32x4*>(y + p * C + c) = s;
+}
+
+// out[b,y,x,:] = [ f[b,y,x,:C1] | proxy[b, (y/s)*(W/s) + x/s, :C2] ]   (IMGPCEnDecoder.py:85-89)
+__global__ __launch_bounds__(256) void upsample_concat_kernel(const float* __restrict__ f, const float* __restrict__ proxy,
+                                                              float* __restrict__ out, int B, int H, int W, int C1, int C2,
+                                                              int s) {
+  const int c4n = (C1 + C2) / 4;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * H * W * c4n) return;
+  const int c = (int)(e % c4n) * 4;
+  const int64_t p = e / c4n;
+  const int xx = (int)(p % W), yy = (int)((p / W) % H), b = (int)(p / ((int64_t)W * H));
+  f32x4 v;
+  if (c < C1) v = *reinterpret_cast<const f32x4*>(f + p * C1 + c);
+  else {
+    const int64_t t = (int64_t)b * (H / s) * (W / s) + (int64_t)(yy / s) * (W / s) + xx / s;
+    v = *reinterpret_cast<const f32x4*>(proxy + t * C2 + (c - C1));
+  }
+  *reinterpret_cast<f32x4*>(out + p * (C1 + C2) + c) = v;
+}
+
+// patches[b*T + ty*Wp + tx, (ky*P + kx)*C + c] = x[b, ty*P+ky, tx*P+kx, c]   (ImageViT.py:19-22, stride = kernel)
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int H,
+                                                       int W, int C, int P) {
+  const int c4n = C / 4, Hp = H / P, Wp = W / P;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * Hp * Wp * P * P * c4n) return;
+  const int c = (int)(e % c4n) * 4;
+  int64_t q = e / c4n;
+  const int kx = (int)(q % P); q /= P;
+  const int ky = (int)(q % P); q /= P;
+  const int tx = (int)(q % Wp); q /= Wp;
+  const int ty = (int)(q % Hp);
+  const int b = (int)(q / Hp);
+  *reinterpret_cast<f32x4*>(out + e * 4) =
+      *reinterpret_cast<const f32x4*>(x + (((int64_t)b * H + ty * P + ky) * W + tx * P + kx) * C + c);
+}
+
+// generic [B,C,L] <-> [B,L,C] transposes through a 32x33 LDS tile (API-boundary layout changes)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int Cn) {
+  // x: [batch][R][Cn] -> y: [batch][Cn][R]
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const float* xb = x + (int64_t)b * R * Cn;
+  float* yb = y + (int64_t)b * R * Cn;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < Cn) tile[i][tx] = xb[(int64_t)(r0 + i) * Cn + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < Cn && r0 + tx < R) yb[(int64_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+}  // namespace
+
+extern "C" int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
+                                    const float* res, const float* post, float* y, int Cout, int stride, float slope,
+                                    hipStream_t stream) {
+  CMR_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0);
+  CMR_REQUIRE(Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0 && Cout >= 64 && (stride == 1 || stride == 2));
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w));
+  ConvArgs a{x, B, H, W, Cin, w, bias, res, post, y, (H - 1) / stride + 1, (W - 1) / stride + 1, Cout, slope};
+  CMR_REQUIRE((int64_t)B * (Cout / 64) <= 65535);
+  if (stride == 1) return launch_conv<1, 2, 32>(a, stream);
+  return launch_conv<2, 1, 16>(a, stream);
+}
+
+extern "C" int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,
+                                  const float* b_b, float* tmp_nchw, float* y_nhwc, int B, int H, int W, float slope,
+                                  hipStream_t stream) {
+  CMR_REQUIRE(x_nchw && w_a && b_a && w3 && w1 && b_b && tmp_nchw && y_nhwc && B > 0 && H > 0 && W > 0);
+  const int64_t total = (int64_t)B * H * W;
+  hipLaunchKernelGGL(stem_a_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x_nchw, w_a, b_a,
+                     tmp_nchw, B, H, W, slope);
+  hipLaunchKernelGGL(stem_b_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, tmp_nchw, x_nchw, w3, w1,
+                     b_b, y_nhwc, B, H, W, slope);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int kh, int kw,
+                                    hipStream_t stream) {
+  CMR_REQUIRE(x && y && B > 0 && C % 4 == 0 && kh > 0 && kw > 0 && kh <= H && kw <= W && cmr_aligned16(x) &&
+              cmr_aligned16(y));
+  const int Ho = H / kh, Wo = W / kw;
+  const int64_t n = (int64_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(avgpool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, B, H, W, C, kh, kw,
+                     Ho, Wo);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_upsample_concat_f32(const float* f, const float* proxy, float* out, int B, int H, int W, int C1,
+                                       int C2, int scale, hipStream_t stream) {
+  CMR_REQUIRE(f && proxy && out && B > 0 && C1 % 4 == 0 && C2 % 4 == 0 && scale > 0 && H % scale == 0 &&
+              W % scale == 0);
+  const int64_t n = (int64_t)B * H * W * ((C1 + C2) / 4);
+  hipLaunchKernelGGL(upsample_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, f, proxy, out, B,
+                     H, W, C1, C2, scale);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_patchify_nhwc_f32(const float* x, float* out, int B, int H, int W, int C, int P, hipStream_t stream) {
+  CMR_REQUIRE(x && out && B > 0 && C % 4 == 0 && P > 0 && H >= P && W >= P);
+  const int64_t n = (int64_t)B * (H / P) * (W / P) * P * P * (C / 4);
+  hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, out, B, H, W, C, P);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_transpose_f32(const float* x, float* y, int batch, int R, int Cn, hipStream_t stream) {
+  CMR_REQUIRE(x && y && batch > 0 && batch <= 65535 && R > 0 && Cn > 0);
+  dim3 grid((Cn + 31) / 32, (R + 31) / 32, batch);
+  CMR_REQUIRE(grid.y <= 65535);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, x, y, R, Cn);
+  return cmr_launch_status();
+}

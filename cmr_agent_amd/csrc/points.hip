@@ -1,0 +1,529 @@
+// Point-cloud side kernels (all HBM / latency bound -- no MFMA here on purpose):
+//   layout      planar [B,3,N] xyz -> row-major [B*N,4]; int64 per-batch indices -> int32 global rows
+//   grouping    CSR of "points of each node" (stable, deterministic), kNN-16 on the nodes,
+//               nearest row (node->proxy, point->node)
+//   attention   vector-attention glue of GroupPointTransformer / KnnPointTransformer
+//               (PointNN.py:149-185, 209-232): t = q[.] - k[.] + pos ; vp = v[.] + pos ; then the
+//               per-segment, per-channel softmax + weighted sum (replaces 3 torch_scatter calls +
+//               4 gathers per layer)
+//   pointnet_util  farthest point sampling, ball query, square distance, index_points
+//               (models/pointnet_util.py:19-93) with the module's exact arithmetic order
+//   reductions  per-batch channel max / mean
+// Distances use explicit __fmul_rn/__fadd_rn so that no FMA contraction changes the rounding
+// relative to torch's sum((a-b)**2, -1): index results are then bit-identical except on exact ties.
+#include "cmr_common.h"
+
+namespace {
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---- layout ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void planar_to_rows4_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                              int C, int N) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= (int64_t)B * N) return;
+  const int b = (int)(r / N), n = (int)(r % N);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C && c < 4; ++c) v[c] = x[((int64_t)b * C + c) * N + n];
+  *reinterpret_cast<f32x4*>(y + r * 4) = v;
+}
+
+__global__ __launch_bounds__(256) void index_to_global_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ out,
+                                                              int B, int N, int M) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= (int64_t)B * N) return;
+  out[r] = (int32_t)(idx[r] + (r / N) * M);
+}
+
+// ---- CSR (segments = destination rows, members listed in ascending source order) ------------
+// One wave per segment scans the `n_per_batch` keys of its batch.  Deterministic and stable.
+__global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restrict__ key, int32_t* __restrict__ count,
+                                                        int n_per_batch, int seg_per_batch, int total_seg) {
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (seg >= total_seg) return;
+  const int b = seg / seg_per_batch;
+  const int32_t* kb = key + (int64_t)b * n_per_batch;
+  int c = 0;
+  for (int i = lane; i < n_per_batch; i += 64) c += (kb[i] == seg);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
+  if (lane == 0) count[seg] = c;
+}
+
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t* __restrict__ count,
+                                                              int32_t* __restrict__ offsets, int n) {
+  // single block; offsets has n+1 entries
+  __shared__ int32_t sums[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = tid * per, hi = min(n, lo + per);
+  int s = 0;
+  for (int i = lo; i < hi; ++i) s += count[i];
+  sums[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = tid >= off ? sums[tid - off] : 0;
+    __syncthreads();
+    sums[tid] += v;
+    __syncthreads();
+  }
+  int run = sums[tid] - s;
+  for (int i = lo; i < hi; ++i) { offsets[i] = run; run += count[i]; }
+  if (tid == 1023) offsets[n] = sums[1023];
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ key, const int32_t* __restrict__ offsets,
+                                                       int32_t* __restrict__ order, int n_per_batch, int seg_per_batch,
+                                                       int total_seg) {
+  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (seg >= total_seg) return;
+  const int b = seg / seg_per_batch;
+  const int32_t* kb = key + (int64_t)b * n_per_batch;
+  int pos = offsets[seg];
+  for (int i0 = 0; i0 < n_per_batch; i0 += 64) {
+    const int i = i0 + lane;
+    const bool hit = i < n_per_batch && kb[i] == seg;
+    const unsigned long long mask = __ballot(hit);
+    if (hit) order[pos + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)((int64_t)b * n_per_batch + i);
+    pos += __popcll(mask);
+  }
+}
+
+// ---- kNN (k = 16) among the rows of each batch: one thread per query, candidates in LDS ------
+template <int K>
+__global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz4, int32_t* __restrict__ out, int M) {
+  extern __shared__ __attribute__((aligned(16))) float cand[];  // [M][4]
+  const int b = blockIdx.y;
+  const float* xb = xyz4 + (int64_t)b * M * 4;
+  for (int i = threadIdx.x; i < M; i += 256)
+    *reinterpret_cast<f32x4*>(&cand[i * 4]) = *reinterpret_cast<const f32x4*>(xb + (int64_t)i * 4);
+  __syncthreads();
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  if (qi >= M) return;
+  const f32x4 qp = *reinterpret_cast<const f32x4*>(&cand[qi * 4]);
+  float bd[K];
+  int bi[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) { bd[j] = INFINITY; bi[j] = 0x7fffffff; }
+  for (int c = 0; c < M; ++c) {
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(&cand[c * 4]);
+    float d = sqdist3(qp[0], qp[1], qp[2], cp[0], cp[1], cp[2]);
+    if (d < bd[K - 1]) {     // strict: on ties the smaller index (seen first) stays ahead
+      int id = c;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const bool sw = d < bd[j];
+        const float td = sw ? bd[j] : d; const int ti = sw ? bi[j] : id;
+        bd[j] = sw ? d : bd[j]; bi[j] = sw ? id : bi[j];
+        d = td; id = ti;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) out[((int64_t)b * M + qi) * K + j] = (int32_t)((int64_t)b * M + bi[j]);
+}
+
+// nearest candidate row for every query row (first index on ties); candidates tiled through LDS
+__global__ __launch_bounds__(256) void nearest_kernel(const float* __restrict__ q4, const float* __restrict__ c4,
+                                                      int32_t* __restrict__ out_global, int64_t* __restrict__ out_local,
+                                                      int Nq, int Nc) {
+  __shared__ __attribute__((aligned(16))) float tile[1024 * 4];
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  f32x4 qp = {0.f, 0.f, 0.f, 0.f};
+  if (qi < Nq) qp = *reinterpret_cast<const f32x4*>(q4 + ((int64_t)b * Nq + qi) * 4);
+  float best = INFINITY;
+  int besti = 0;
+  for (int c0 = 0; c0 < Nc; c0 += 1024) {
+    const int n = min(1024, Nc - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+      *reinterpret_cast<f32x4*>(&tile[i * 4]) = *reinterpret_cast<const f32x4*>(c4 + ((int64_t)b * Nc + c0 + i) * 4);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const f32x4 cp = *reinterpret_cast<const f32x4*>(&tile[i * 4]);
+      const float d = sqdist3(qp[0], qp[1], qp[2], cp[0], cp[1], cp[2]);
+      if (d < best) { best = d; besti = c0 + i; }
+    }
+  }
+  if (qi < Nq) {
+    if (out_global) out_global[(int64_t)b * Nq + qi] = (int32_t)((int64_t)b * Nc + besti);
+    if (out_local) out_local[(int64_t)b * Nq + qi] = besti;
+  }
+}
+
+// ---- row gathers ------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t map_row(const int32_t* idx, int64_t div, int64_t r) {
+  return idx ? (int64_t)idx[r] : (div > 1 ? r / div : r);
+}
+
+// out[r, :4] = a[map_a(r)] - b[map_b(r)]         (relative positions; 4th lane stays 0)
+__global__ __launch_bounds__(256) void rel_pos_kernel(const float* __restrict__ a, const int32_t* __restrict__ ia,
+                                                      int64_t diva, const float* __restrict__ b,
+                                                      const int32_t* __restrict__ ib, int64_t divb, float* __restrict__ out,
+                                                      int64_t rows) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= rows) return;
+  const f32x4 av = *reinterpret_cast<const f32x4*>(a + map_row(ia, diva, r) * 4);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(b + map_row(ib, divb, r) * 4);
+  f32x4 o = {av[0] - bv[0], av[1] - bv[1], av[2] - bv[2], 0.f};
+  *reinterpret_cast<f32x4*>(out + r * 4) = o;
+}
+
+// t[r] = q[map_q(r)] - k[map_k(r)] + pos[r];  vp[r] = v[map_k(r)] + pos[r]      (64 channels)
+__global__ __launch_bounds__(256) void vecattn_prep_kernel(const float* __restrict__ q, int64_t ldq,
+                                                           const int32_t* __restrict__ iq, int64_t divq,
+                                                           const float* __restrict__ k, int64_t ldk,
+                                                           const float* __restrict__ v, int64_t ldv,
+                                                           const int32_t* __restrict__ ik, const float* __restrict__ pos,
+                                                           float* __restrict__ t, float* __restrict__ vp, int64_t rows) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = e >> 4;
+  if (r >= rows) return;
+  const int c = (int)(e & 15) * 4;
+  const int64_t rq = map_row(iq, divq, r), rk = ik ? (int64_t)ik[r] : r;
+  const f32x4 qv = *reinterpret_cast<const f32x4*>(q + rq * ldq + c);
+  const f32x4 kv = *reinterpret_cast<const f32x4*>(k + rk * ldk + c);
+  const f32x4 vv = *reinterpret_cast<const f32x4*>(v + rk * ldv + c);
+  const f32x4 pv = *reinterpret_cast<const f32x4*>(pos + r * 64 + c);
+  f32x4 to, vo;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { to[i] = qv[i] - kv[i] + pv[i]; vo[i] = vv[i] + pv[i]; }
+  *reinterpret_cast<f32x4*>(t + r * 64 + c) = to;
+  *reinterpret_cast<f32x4*>(vp + r * 64 + c) = vo;
+}
+
+// out[s, c] = sum_i softmax_i(attn[row_i, c] * scale) * vp[row_i, c] over the rows of segment s
+// one wave per segment, lane = channel (64)
+__global__ __launch_bounds__(256) void segment_softmax_kernel(const float* __restrict__ attn, const float* __restrict__ vp,
+                                                              const int32_t* __restrict__ order,
+                                                              const int32_t* __restrict__ offsets, int fixed_len,
+                                                              float scale, float* __restrict__ out, int64_t nseg) {
+  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (seg >= nseg) return;
+  const int64_t lo = offsets ? offsets[seg] : seg * fixed_len;
+  const int64_t hi = offsets ? offsets[seg + 1] : lo + fixed_len;
+  float m = -INFINITY;
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t r = order ? order[i] : i;
+    m = fmaxf(m, attn[r * 64 + lane] * scale);
+  }
+  float l = 0.f, acc = 0.f;
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t r = order ? order[i] : i;
+    const float p = expf(attn[r * 64 + lane] * scale - m);
+    l += p;
+    acc += p * vp[r * 64 + lane];
+  }
+  out[seg * 64 + lane] = hi > lo ? acc / l : 0.f;
+}
+
+// out[r, :C] = src[idx[r], :C]      (pointnet_util.index_points / torch.gather of rows)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                          const int32_t* __restrict__ idx, float* __restrict__ out,
+                                                          int64_t ldo, int64_t rows, int C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = e / C;
+  if (r >= rows) return;
+  const int c = (int)(e % C);
+  out[r * ldo + c] = src[(int64_t)idx[r] * lds + c];
+}
+
+// ---- pointnet_util --------------------------------------------------------------------------
+// Farthest point sampling: one workgroup (1024 threads) per cloud, running min-distance in
+// registers, argmax by wave shuffle + LDS across the 16 waves (lowest index wins ties, like
+// torch.max).  xyz4 [B,N,4]; start [B]; out [B,npoint] int64 (local indices).
+constexpr int FPS_T = 1024;
+template <int PER, bool CACHE>
+__global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz4, const int64_t* __restrict__ start,
+                                                    int64_t* __restrict__ out, int N, int npoint) {
+  __shared__ float red_d[16];
+  __shared__ int red_i[16];
+  __shared__ int far_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = xyz4 + (int64_t)b * N * 4;
+  // coordinates stay in registers for clouds up to 16K points; larger clouds re-read them (L2)
+  constexpr int PC = CACHE ? PER : 1;
+  float px[PC], py[PC], pz[PC], dist[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid + j * FPS_T;
+    dist[j] = i < N ? 1e10f : -1.f;
+    if (CACHE) {
+      f32x4 p = {0.f, 0.f, 0.f, 0.f};
+      if (i < N) p = *reinterpret_cast<const f32x4*>(xb + (int64_t)i * 4);
+      px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+    }
+  }
+  int far = (int)start[b];
+  for (int it = 0; it < npoint; ++it) {
+    if (tid == 0) out[(int64_t)b * npoint + it] = far;
+    const f32x4 c = *reinterpret_cast<const f32x4*>(xb + (int64_t)far * 4);
+    float bd = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = tid + j * FPS_T;
+      if (i < N) {
+        float qx, qy, qz;
+        if (CACHE) { qx = px[j]; qy = py[j]; qz = pz[j]; }
+        else { const f32x4 p = *reinterpret_cast<const f32x4*>(xb + (int64_t)i * 4); qx = p[0]; qy = p[1]; qz = p[2]; }
+        const float d = sqdist3(qx, qy, qz, c[0], c[1], c[2]);
+        dist[j] = fminf(dist[j], d);
+        if (dist[j] > bd) { bd = dist[j]; bi = i; }   // ascending i within a thread: first max kept
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float od = __shfl_xor(bd, m);
+      const int oi = __shfl_xor(bi, m);
+      if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (lane == 0) { red_d[wave] = bd; red_i[wave] = bi; }
+    __syncthreads();
+    if (wave == 0) {
+      float d2 = lane < 16 ? red_d[lane] : -2.f;
+      int i2 = lane < 16 ? red_i[lane] : 0x7fffffff;
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) {
+        const float od = __shfl_xor(d2, m);
+        const int oi = __shfl_xor(i2, m);
+        if (od > d2 || (od == d2 && oi < i2)) { d2 = od; i2 = oi; }
+      }
+      if (lane == 0) far_s = i2;
+    }
+    __syncthreads();
+    far = far_s;
+  }
+}
+
+// ball query: one wave per query; ascending scan, first `nsample` hits with d2 <= r2, padded
+// with the first hit (pointnet_util.py:86-92).  A query with no hit yields N (as the reference).
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz4, const float* __restrict__ new4,
+                                                         int64_t* __restrict__ out, int N, int S, int nsample, float r2) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (s >= S) return;
+  const f32x4 qp = *reinterpret_cast<const f32x4*>(new4 + ((int64_t)b * S + s) * 4);
+  const float* xb = xyz4 + (int64_t)b * N * 4;
+  int64_t* ob = out + ((int64_t)b * S + s) * nsample;
+  int cnt = 0, first = N;
+  for (int i0 = 0; i0 < N && cnt < nsample; i0 += 64) {
+    const int i = i0 + lane;
+    bool hit = false;
+    if (i < N) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xb + (int64_t)i * 4);
+      hit = !(sqdist3(qp[0], qp[1], qp[2], p[0], p[1], p[2]) > r2);
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (mask) {
+      if (cnt == 0) first = i0 + __ffsll((long long)mask) - 1;
+      const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (hit && slot < nsample) ob[slot] = i;
+      cnt += __popcll(mask);
+    }
+  }
+  if (cnt > nsample) cnt = nsample;
+  for (int j = cnt + lane; j < nsample; j += 64) ob[j] = first;
+}
+
+// square_distance: [B,N,4] x [B,M,4] -> [B,N,M]
+__global__ __launch_bounds__(256) void square_distance_kernel(const float* __restrict__ a4, const float* __restrict__ b4,
+                                                              float* __restrict__ out, int N, int M) {
+  const int b = blockIdx.z;
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (j >= M) return;
+  const f32x4 p = *reinterpret_cast<const f32x4*>(a4 + ((int64_t)b * N + i) * 4);
+  const f32x4 q = *reinterpret_cast<const f32x4*>(b4 + ((int64_t)b * M + j) * 4);
+  out[((int64_t)b * N + i) * M + j] = sqdist3(p[0], p[1], p[2], q[0], q[1], q[2]);
+}
+
+// ---- per-batch channel reductions over rows: partial [B][nslab][C] then final [B][C] --------
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void colreduce_partial_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                float* __restrict__ part, int N, int C, int slab_rows) {
+  // block (C/4 float4 columns x rows-in-flight): thread -> column group c4, row phase rp
+  const int b = blockIdx.y, slab = blockIdx.x;
+  const int c4n = C / 4, rows_par = 256 / c4n;
+  const int c = (threadIdx.x % c4n) * 4, rp = threadIdx.x / c4n;
+  const int lo = slab * slab_rows, hi = min(N, lo + slab_rows);
+  f32x4 acc;
+  const float init = IS_MAX ? -INFINITY : 0.f;
+  acc[0] = acc[1] = acc[2] = acc[3] = init;
+  if (rp < rows_par)
+    for (int r = lo + rp; r < hi; r += rows_par) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + ((int64_t)b * N + r) * ldx + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = IS_MAX ? fmaxf(acc[i], v[i]) : acc[i] + v[i];
+    }
+  __shared__ __attribute__((aligned(16))) float sm[256 * 4];
+  *reinterpret_cast<f32x4*>(&sm[threadIdx.x * 4]) = acc;
+  __syncthreads();
+  if (rp == 0) {
+    for (int p = 1; p < rows_par; ++p) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&sm[(p * c4n + threadIdx.x) * 4]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = IS_MAX ? fmaxf(acc[i], v[i]) : acc[i] + v[i];
+    }
+    *reinterpret_cast<f32x4*>(part + ((int64_t)b * gridDim.x + slab) * C + c) = acc;
+  }
+}
+
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int nslab, int C, float mul) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float acc = IS_MAX ? -INFINITY : 0.f;
+    for (int s = 0; s < nslab; ++s) {
+      const float v = part[((int64_t)b * nslab + s) * C + c];
+      acc = IS_MAX ? fmaxf(acc, v) : acc + v;
+    }
+    out[(int64_t)b * C + c] = IS_MAX ? acc : acc * mul;
+  }
+}
+
+}  // namespace
+
+#define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
+
+extern "C" int cmr_planar_to_rows4_f32(const float* x, float* y, int B, int C, int N, hipStream_t stream) {
+  CMR_REQUIRE(x && y && B > 0 && C >= 1 && C <= 4 && N > 0 && cmr_aligned16(y));
+  hipLaunchKernelGGL(planar_to_rows4_kernel, GRID1D((int64_t)B * N), dim3(256), 0, stream, x, y, B, C, N);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_index_to_global_i32(const int64_t* idx, int32_t* out, int B, int N, int M, hipStream_t stream) {
+  CMR_REQUIRE(idx && out && B > 0 && N > 0 && M > 0 && (int64_t)B * M < 2147483647LL && (int64_t)B * N < 2147483647LL);
+  hipLaunchKernelGGL(index_to_global_kernel, GRID1D((int64_t)B * N), dim3(256), 0, stream, idx, out, B, N, M);
+  return cmr_launch_status();
+}
+
+// key [B*n_per_batch] global segment ids; count/offsets: [B*seg_per_batch (+1)]; order [B*n_per_batch]
+extern "C" int cmr_csr_build_i32(const int32_t* key, int32_t* count, int32_t* offsets, int32_t* order, int B,
+                                 int n_per_batch, int seg_per_batch, hipStream_t stream) {
+  CMR_REQUIRE(key && count && offsets && order && B > 0 && n_per_batch > 0 && seg_per_batch > 0);
+  const int total = B * seg_per_batch;
+  hipLaunchKernelGGL(csr_count_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, key, count, n_per_batch,
+                     seg_per_batch, total);
+  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, count, offsets, total);
+  hipLaunchKernelGGL(csr_fill_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, key, offsets, order, n_per_batch,
+                     seg_per_batch, total);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_knn16_f32(const float* xyz4, int32_t* out, int B, int M, hipStream_t stream) {
+  CMR_REQUIRE(xyz4 && out && B > 0 && B <= 65535 && M >= 16 && cmr_aligned16(xyz4));
+  const size_t smem = (size_t)M * 4 * sizeof(float);
+  CMR_REQUIRE(smem <= 160 * 1024);
+  if (smem > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem) != hipSuccess)
+    return CMR_ELAUNCH;
+  hipLaunchKernelGGL(knn_kernel<16>, dim3((M + 255) / 256, B), dim3(256), smem, stream, xyz4, out, M);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_nearest_f32(const float* q4, const float* c4, int32_t* out_global, int64_t* out_local, int B, int Nq,
+                               int Nc, hipStream_t stream) {
+  CMR_REQUIRE(q4 && c4 && (out_global || out_local) && B > 0 && B <= 65535 && Nq > 0 && Nc > 0);
+  hipLaunchKernelGGL(nearest_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, q4, c4, out_global, out_local, Nq,
+                     Nc);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_rel_pos_f32(const float* a, const int32_t* ia, int64_t diva, const float* b, const int32_t* ib,
+                               int64_t divb, float* out, int64_t rows, hipStream_t stream) {
+  CMR_REQUIRE(a && b && out && rows > 0 && cmr_aligned16(a) && cmr_aligned16(b) && cmr_aligned16(out));
+  hipLaunchKernelGGL(rel_pos_kernel, GRID1D(rows), dim3(256), 0, stream, a, ia, diva, b, ib, divb, out, rows);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_vecattn_prep_f32(const float* q, int64_t ldq, const int32_t* iq, int64_t divq, const float* k,
+                                    int64_t ldk, const float* v, int64_t ldv, const int32_t* ik, const float* pos,
+                                    float* t, float* vp, int64_t rows, hipStream_t stream) {
+  CMR_REQUIRE(q && k && v && pos && t && vp && rows > 0 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0);
+  hipLaunchKernelGGL(vecattn_prep_kernel, GRID1D(rows * 16), dim3(256), 0, stream, q, ldq, iq, divq, k, ldk, v, ldv, ik,
+                     pos, t, vp, rows);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_segment_softmax_f32(const float* attn, const float* vp, const int32_t* order, const int32_t* offsets,
+                                       int fixed_len, float scale, float* out, int64_t nseg, hipStream_t stream) {
+  CMR_REQUIRE(attn && vp && out && nseg > 0 && (offsets || fixed_len > 0));
+  hipLaunchKernelGGL(segment_softmax_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, stream, attn, vp, order,
+                     offsets, fixed_len, scale, out, nseg);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo,
+                                   int64_t rows, int C, hipStream_t stream) {
+  CMR_REQUIRE(src && idx && out && rows > 0 && C > 0);
+  hipLaunchKernelGGL(gather_rows_kernel, GRID1D(rows * C), dim3(256), 0, stream, src, lds, idx, out, ldo, rows, C);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint,
+                           hipStream_t stream) {
+  CMR_REQUIRE(xyz4 && start && out && B > 0 && N > 0 && npoint > 0 && cmr_aligned16(xyz4));
+  const int per = (N + FPS_T - 1) / FPS_T;
+  CMR_REQUIRE(per <= 64);                                       // N <= 65536
+#define FPS_CASE(P, C) \
+  hipLaunchKernelGGL((fps_kernel<P, C>), dim3(B), dim3(FPS_T), 0, stream, xyz4, start, out, N, npoint)
+  if (per <= 1) FPS_CASE(1, true);
+  else if (per <= 4) FPS_CASE(4, true);
+  else if (per <= 16) FPS_CASE(16, true);
+  else if (per <= 40) FPS_CASE(40, false);
+  else FPS_CASE(64, false);
+#undef FPS_CASE
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_ball_query_f32(const float* xyz4, const float* new4, int64_t* out, int B, int N, int S, int nsample,
+                                  float radius2, hipStream_t stream) {
+  CMR_REQUIRE(xyz4 && new4 && out && B > 0 && B <= 65535 && N > 0 && S > 0 && nsample > 0);
+  hipLaunchKernelGGL(ball_query_kernel, dim3((S + 3) / 4, B), dim3(256), 0, stream, xyz4, new4, out, N, S, nsample,
+                     radius2);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_square_distance_f32(const float* a4, const float* b4, float* out, int B, int N, int M,
+                                       hipStream_t stream) {
+  CMR_REQUIRE(a4 && b4 && out && B > 0 && B <= 65535 && N > 0 && N <= 65535 && M > 0);
+  hipLaunchKernelGGL(square_distance_kernel, dim3((M + 255) / 256, N, B), dim3(256), 0, stream, a4, b4, out, N, M);
+  return cmr_launch_status();
+}
+
+static int colreduce(bool is_max, const float* x, int64_t ldx, float* out, float* ws, int64_t ws_bytes, int B, int N,
+                     int C, float mul, hipStream_t stream) {
+  CMR_REQUIRE(x && out && ws && B > 0 && B <= 65535 && N > 0 && C % 4 == 0 && C >= 4 && C <= 1024 && ldx % 4 == 0);
+  const int slab_rows = 256;
+  const int nslab = (N + slab_rows - 1) / slab_rows;
+  CMR_REQUIRE(ws_bytes >= (int64_t)B * nslab * C * (int64_t)sizeof(float));
+  if (is_max) {
+    hipLaunchKernelGGL(colreduce_partial_kernel<true>, dim3(nslab, B), dim3(256), 0, stream, x, ldx, ws, N, C, slab_rows);
+    hipLaunchKernelGGL(colreduce_final_kernel<true>, dim3(B), dim3(256), 0, stream, ws, out, nslab, C, mul);
+  } else {
+    hipLaunchKernelGGL(colreduce_partial_kernel<false>, dim3(nslab, B), dim3(256), 0, stream, x, ldx, ws, N, C, slab_rows);
+    hipLaunchKernelGGL(colreduce_final_kernel<false>, dim3(B), dim3(256), 0, stream, ws, out, nslab, C, mul);
+  }
+  return cmr_launch_status();
+}
+
+extern "C" int64_t cmr_colreduce_workspace_bytes(int B, int N, int C) {
+  return (int64_t)B * ((N + 255) / 256) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int cmr_colmax_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C,
+                              hipStream_t stream) {
+  return colreduce(true, x, ldx, out, (float*)ws, ws_bytes, B, N, C, 1.f, stream);
+}
+
+extern "C" int cmr_colmean_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C,
+                               hipStream_t stream) {
+  return colreduce(false, x, ldx, out, (float*)ws, ws_bytes, B, N, C, 1.f / (float)N, stream);
+}

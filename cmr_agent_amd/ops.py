@@ -1,0 +1,298 @@
+"""Tensor-level wrappers over the C ABI (include/cmr_hip.h).  PyTorch is used for device
+memory and the current HIP stream only; every computation is a HIP kernel.  Arguments are
+2-D row views ([rows, C], unit inner stride, arbitrary row stride) unless stated otherwise."""
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_ELU1 = 0, 1, 2, 3, 4
+f32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _rows(t, name="tensor"):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != f32 or not t.is_cuda:
+        raise ValueError("%s must be a 2-D float32 device tensor with unit inner stride, got %s %s %s" % (
+            name, tuple(t.shape), t.stride(), t.dtype))
+    return t
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _i32(t):
+    if t is not None and (t.dtype != torch.int32 or not t.is_contiguous()):
+        raise ValueError("row-id tensors must be contiguous int32")
+    return t
+
+
+def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, act=ACT_NONE, act_param=0.0, out=None):
+    _rows(x1, "x1")
+    rows, k1 = x1.shape
+    n_out, kw = w.shape
+    k2 = 0
+    if x2 is not None:
+        _rows(x2, "x2")
+        k2 = x2.shape[1]
+    if kw != k1 + k2 or not w.is_contiguous():
+        raise ValueError("weight shape %s does not match k1+k2=%d" % (tuple(w.shape), k1 + k2))
+    if out is None:
+        out = torch.empty((rows, n_out), dtype=f32, device=x1.device)
+    _rows(out, "out")
+    if res is not None:
+        _rows(res, "res")
+    _lib.call("cmr_linear_f32", _p(x1), _ld(x1), k1, _p(x2), _ld(x2) if x2 is not None else 0, k2, _p(_i32(idx2)),
+              int(div2), _p(w), kw, _p(bias), _p(res), _ld(res) if res is not None else 0, int(res_mod), _p(out),
+              _ld(out), rows, n_out, act, float(act_param), _stream())
+    return out
+
+
+def layernorm64(x, gamma, beta, eps, res=None, out=None):
+    _rows(x, "x")
+    if out is None:
+        out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
+    _lib.call("cmr_layernorm64_f32", _p(x), _ld(x), _p(gamma), _p(beta), float(eps), _p(res),
+              _ld(res) if res is not None else 0, _p(out), _ld(out), x.shape[0], _stream())
+    return out
+
+
+def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None):
+    """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout]."""
+    B, H, W, cin = x.shape
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
+        raise ValueError("conv3x3: bad operand layout")
+    if out is None:
+        out = torch.empty((B, ho, wo, cout), dtype=f32, device=x.device)
+    _lib.call("cmr_conv3x3_nhwc_f32", _p(x), B, H, W, cin, _p(w9), _p(bias), _p(res), _p(post), _p(out), cout, stride,
+              float(slope), _stream())
+    return out
+
+
+def stem_block(img_nchw, w_a, b_a, w3, w1, b_b, slope):
+    B, c, H, W = img_nchw.shape
+    if c != 3 or not img_nchw.is_contiguous():
+        raise ValueError("stem expects a contiguous [B,3,H,W] image")
+    tmp = torch.empty_like(img_nchw)
+    out = torch.empty((B, H, W, 64), dtype=f32, device=img_nchw.device)
+    _lib.call("cmr_stem_block_f32", _p(img_nchw), _p(w_a), _p(b_a), _p(w3), _p(w1), _p(b_b), _p(tmp), _p(out), B, H, W,
+              float(slope), _stream())
+    return out
+
+
+def avgpool(x, kh, kw):
+    B, H, W, C = x.shape
+    out = torch.empty((B, H // kh, W // kw, C), dtype=f32, device=x.device)
+    _lib.call("cmr_avgpool_nhwc_f32", _p(x), _p(out), B, H, W, C, kh, kw, _stream())
+    return out
+
+
+def upsample_concat(f, proxy_rows, scale):
+    B, H, W, c1 = f.shape
+    c2 = proxy_rows.shape[1]
+    out = torch.empty((B, H, W, c1 + c2), dtype=f32, device=f.device)
+    _lib.call("cmr_upsample_concat_f32", _p(f), _p(proxy_rows), _p(out), B, H, W, c1, c2, scale, _stream())
+    return out
+
+
+def patchify(x, P):
+    B, H, W, C = x.shape
+    out = torch.empty((B * (H // P) * (W // P), P * P * C), dtype=f32, device=x.device)
+    _lib.call("cmr_patchify_nhwc_f32", _p(x), _p(out), B, H, W, C, P, _stream())
+    return out
+
+
+def transpose(x):
+    """[batch, R, C] contiguous -> [batch, C, R] contiguous."""
+    b, r, c = x.shape
+    if not x.is_contiguous():
+        raise ValueError("transpose expects a contiguous tensor")
+    out = torch.empty((b, c, r), dtype=f32, device=x.device)
+    _lib.call("cmr_transpose_f32", _p(x), _p(out), b, r, c, _stream())
+    return out
+
+
+def mha(q, k, v, B, Tq, Tk, out=None):
+    if out is None:
+        out = torch.empty((B * Tq, 64), dtype=f32, device=q.device)
+    _lib.call("cmr_mha_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(out), _ld(out), B, Tq,
+              Tk, _stream())
+    return out
+
+
+def la_reduce(kf, v, B, S):
+    ws_bytes = _lib.load().cmr_la_reduce_workspace_bytes(B, S)
+    ws = torch.empty((ws_bytes // 4,), dtype=f32, device=kf.device)
+    kvsum = torch.empty((B, 576), dtype=f32, device=kf.device)
+    _lib.call("cmr_la_reduce_f32", _p(_rows(kf)), _ld(kf), _p(_rows(v)), _ld(v), _p(kvsum), _p(ws), ws_bytes, B, S,
+              _stream())
+    return kvsum
+
+
+def la_apply(qf, kvsum, B, L, S, eps, out=None):
+    if out is None:
+        out = torch.empty((B * L, 64), dtype=f32, device=qf.device)
+    _lib.call("cmr_la_apply_f32", _p(_rows(qf)), _ld(qf), _p(kvsum), _p(out), _ld(out), B, L, S, float(eps), _stream())
+    return out
+
+
+def planar_to_rows4(x):
+    """[B,C<=4,N] -> [B*N,4] (zero padded)."""
+    B, C, N = x.shape
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out = torch.empty((B * N, 4), dtype=f32, device=x.device)
+    _lib.call("cmr_planar_to_rows4_f32", _p(x), _p(out), B, C, N, _stream())
+    return out
+
+
+def index_to_global(idx, M):
+    """int64 [B,N] per-batch ids in [0,M) -> int32 [B*N] global row ids."""
+    B, N = idx.shape
+    if idx.dtype != torch.int64 or not idx.is_contiguous():
+        raise ValueError("index tensor must be contiguous int64")
+    out = torch.empty((B * N,), dtype=torch.int32, device=idx.device)
+    _lib.call("cmr_index_to_global_i32", _p(idx), _p(out), B, N, M, _stream())
+    return out
+
+
+def csr_build(key, B, n_per_batch, seg_per_batch):
+    total = B * seg_per_batch
+    count = torch.empty((total,), dtype=torch.int32, device=key.device)
+    offsets = torch.empty((total + 1,), dtype=torch.int32, device=key.device)
+    order = torch.empty((B * n_per_batch,), dtype=torch.int32, device=key.device)
+    _lib.call("cmr_csr_build_i32", _p(_i32(key)), _p(count), _p(offsets), _p(order), B, n_per_batch, seg_per_batch,
+              _stream())
+    return offsets, order
+
+
+def knn16(xyz4, B, M):
+    out = torch.empty((B * M, 16), dtype=torch.int32, device=xyz4.device)
+    _lib.call("cmr_knn16_f32", _p(xyz4), _p(out), B, M, _stream())
+    return out
+
+
+def nearest(q4, c4, B, Nq, Nc, want_local=True, want_global=True):
+    og = torch.empty((B * Nq,), dtype=torch.int32, device=q4.device) if want_global else None
+    ol = torch.empty((B, Nq), dtype=torch.int64, device=q4.device) if want_local else None
+    _lib.call("cmr_nearest_f32", _p(q4), _p(c4), _p(og), _p(ol), B, Nq, Nc, _stream())
+    return og, ol
+
+
+def rel_pos(a, b, rows, ia=None, diva=1, ib=None, divb=1):
+    out = torch.empty((rows, 4), dtype=f32, device=a.device)
+    _lib.call("cmr_rel_pos_f32", _p(a), _p(_i32(ia)), int(diva), _p(b), _p(_i32(ib)), int(divb), _p(out), rows, _stream())
+    return out
+
+
+def vecattn_prep(q, k, v, pos, rows, iq=None, divq=1, ik=None):
+    t = torch.empty((rows, 64), dtype=f32, device=q.device)
+    vp = torch.empty((rows, 64), dtype=f32, device=q.device)
+    _lib.call("cmr_vecattn_prep_f32", _p(_rows(q)), _ld(q), _p(_i32(iq)), int(divq), _p(_rows(k)), _ld(k), _p(_rows(v)),
+              _ld(v), _p(_i32(ik)), _p(pos), _p(t), _p(vp), rows, _stream())
+    return t, vp
+
+
+def segment_softmax(attn, vp, nseg, scale, order=None, offsets=None, fixed_len=0):
+    out = torch.empty((nseg, 64), dtype=f32, device=attn.device)
+    _lib.call("cmr_segment_softmax_f32", _p(attn), _p(vp), _p(_i32(order)), _p(_i32(offsets)), fixed_len, float(scale),
+              _p(out), nseg, _stream())
+    return out
+
+
+def gather_rows(src, idx, C=None, out=None):
+    _rows(src)
+    C = src.shape[1] if C is None else C
+    rows = idx.numel()
+    if out is None:
+        out = torch.empty((rows, C), dtype=f32, device=src.device)
+    _lib.call("cmr_gather_rows_f32", _p(src), _ld(src), _p(_i32(idx)), _p(out), _ld(out), rows, C, _stream())
+    return out
+
+
+def fps(xyz4, start, B, N, npoint):
+    out = torch.empty((B, npoint), dtype=torch.int64, device=xyz4.device)
+    _lib.call("cmr_fps_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _stream())
+    return out
+
+
+def ball_query(xyz4, new4, B, N, S, nsample, radius):
+    out = torch.empty((B, S, nsample), dtype=torch.int64, device=xyz4.device)
+    r2 = torch.tensor(float(radius) ** 2, dtype=f32).item()      # the scalar the reference compares against
+    _lib.call("cmr_ball_query_f32", _p(xyz4), _p(new4), _p(out), B, N, S, nsample, r2, _stream())
+    return out
+
+
+def square_distance(a4, b4, B, N, M):
+    out = torch.empty((B, N, M), dtype=f32, device=a4.device)
+    _lib.call("cmr_square_distance_f32", _p(a4), _p(b4), _p(out), B, N, M, _stream())
+    return out
+
+
+def _colreduce(name, x, B, N):
+    _rows(x)
+    C = x.shape[1]
+    ws_bytes = _lib.load().cmr_colreduce_workspace_bytes(B, N, C)
+    ws = torch.empty((max(ws_bytes // 4, 1),), dtype=f32, device=x.device)
+    out = torch.empty((B, C), dtype=f32, device=x.device)
+    _lib.call(name, _p(x), _ld(x), _p(out), _p(ws), ws_bytes, B, N, C, _stream())
+    return out
+
+
+def colmax(x, B, N):
+    return _colreduce("cmr_colmax_f32", x, B, N)
+
+
+def colmean(x, B, N):
+    return _colreduce("cmr_colmean_f32", x, B, N)
+
+
+def project_scatter(pc4, feat, overlap_u8, pose, K, mean4, B, N, h, w, acc, cnt, state3d):
+    _lib.call("cmr_project_scatter_f32", _p(pc4), _p(feat), _p(overlap_u8), _p(pose), _p(K), _p(mean4), _p(acc), _p(cnt),
+              _p(state3d), B, N, h, w, _stream())
+
+
+def observation_finalize(img_feat, acc, cnt, state2d, B, h, w, write_img):
+    _lib.call("cmr_observation_finalize_f32", _p(img_feat), _p(acc), _p(cnt), _p(state2d), B, h, w, int(write_img),
+              _stream())
+
+
+def pose_step(pose, act_r, act_t, r_steps, t_steps, six_dof):
+    _lib.call("cmr_pose_step_f32", _p(pose), _p(act_r), _p(act_t), _p(r_steps), _p(t_steps), pose.shape[0], int(six_dof),
+              _stream())
+
+
+def to_disentangled(pose, mean4):
+    _lib.call("cmr_to_disentangled_f32", _p(pose), _p(mean4), pose.shape[0], _stream())
+
+
+def argmax_rows(x, rows, n):
+    out = torch.empty((rows,), dtype=torch.int64, device=x.device)
+    _lib.call("cmr_argmax_rows_f32", _p(x), _p(out), rows, n, _stream())
+    return out
+
+
+def softmax2(logits, thr_lo=0.5, thr_hi=0.8):
+    _rows(logits)
+    rows = logits.shape[0]
+    prob = torch.empty((rows,), dtype=f32, device=logits.device)
+    lo = torch.empty((rows,), dtype=torch.uint8, device=logits.device)
+    hi = torch.empty((rows,), dtype=torch.uint8, device=logits.device)
+    _lib.call("cmr_softmax2_f32", _p(logits), _ld(logits), _p(prob), _p(lo), _p(hi), thr_lo, thr_hi, rows, _stream())
+    return prob, lo, hi
+
+
+def l2norm64(x, out=None):
+    _rows(x)
+    if out is None:
+        out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
+    _lib.call("cmr_l2norm64_f32", _p(x), _ld(x), _p(out), _ld(out), x.shape[0], _stream())
+    return out

@@ -1,0 +1,162 @@
+/* libcmr_hip.so -- C ABI of the MI355X (gfx950) kernels behind CMR-Agent's hot path.
+ *
+ * The reference (y2w-oc/CMR-Agent) has NO FFI: its hot path is PyTorch op sequences inside
+ * models/*.py and environment/environment.py plus the third-party torch_scatter extension.  Each
+ * entry point below therefore cites the reference op sequence (file:line) it replaces; the
+ * Python host layer (cmr_agent_amd/models, cmr_agent_amd/environment) keeps the reference's
+ * nn.Module / function API on top of these calls (see INTEGRATION.md for the binding).
+ *
+ * Conventions
+ *   - every function returns 0 (CMR_OK), -1 (bad argument) or -2 (launch failure); none throws,
+ *     allocates or synchronises; all work is enqueued on `stream` (graph-capturable);
+ *   - the caller owns every buffer, including workspaces (sizes from the *_workspace_bytes helpers);
+ *   - tensors are fp32, row-major "channels-last": images [B,H,W,C], point/token sets [B*L, C];
+ *     `ld*` arguments are row strides in floats; float4-accessed buffers must be 16-byte aligned;
+ *   - index tensors handed over by the reference API are int64; internal row ids are int32 GLOBAL
+ *     row numbers (batch offset already added, cmr_index_to_global_i32).
+ */
+#ifndef CMR_HIP_H
+#define CMR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* hipStream_t;
+
+#define CMR_OK 0
+#define CMR_EINVAL -1
+#define CMR_ELAUNCH -2
+
+enum { CMR_ACT_NONE = 0, CMR_ACT_RELU = 1, CMR_ACT_LRELU = 2, CMR_ACT_GELU = 3, CMR_ACT_ELU1 = 4 };
+
+/* ---- dense contractions (fp32 MFMA) -------------------------------------------------------- */
+
+/* Y[r,:n_out] = act([X1[r,:k1] | X2[map(r),:k2]] W^T + bias + RES[r % res_mod]),  W = [n_out][k1+k2].
+ * map(r) = idx2[r] if idx2 else r / div2.  Replaces nn.Linear / Conv1d(k=1) / Conv2d(k=1) (+ folded
+ * BatchNorm, + activation, + residual) and the cat/gather feeding them: PointNN.py:96-123,149-156,
+ * 209-226,260-282; PointViT.py:66-73; ImageViT.py:81-133; IMGPCEncoder.py:36-102;
+ * LinearAttention.py:46-48,63,68; IMGPCEnDecoder.py:77-81; MultiHeadModel.py:34-39,61-67,126-131,
+ * 227-233; CMRAgent.py:57-59,70-86,92-101. */
+int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_t ld2, int k2, const int32_t* idx2,
+                   int64_t div2, const float* w, int64_t ldw, const float* bias, const float* res, int64_t ldres,
+                   int64_t res_mod, float* y, int64_t ldy, int64_t rows, int n_out, int act, float act_param,
+                   hipStream_t stream);
+
+/* y = LayerNorm_64(x) * gamma + beta (+ res).  ImageViT.py:139-140, IMGPCEncoder.py:86-87 (eps 1e-6),
+ * LinearAttention.py:33-34,64,69,71 (eps 1e-5, residual x + norm2(.)). */
+int cmr_layernorm64_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const float* res,
+                        int64_t ldres, float* y, int64_t ldy, int64_t rows, hipStream_t stream);
+
+/* 3x3 convolution, pad 1, stride 1|2, NHWC, w = [9][Cout][Cin] (BN folded), y = lrelu(conv + bias + res) + post.
+ * ImageResNet.py:9-14,24-36 (ResidualBlock convs + strided shortcut), IMGPCEnDecoder.py:90-94 (post = 2-D
+ * sine table, utils/positional_embedding_2d.py:35-40), MultiHeadModel.py:70-72,236-238, CMRAgent.py:34-56. */
+int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
+                         const float* res, const float* post, float* y, int Cout, int stride, float slope,
+                         hipStream_t stream);
+
+/* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.
+ * ImageResNet.py:50 with :9-23. */
+int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,
+                       const float* b_b, float* tmp_nchw, float* y_nhwc, int B, int H, int W, float slope,
+                       hipStream_t stream);
+
+/* AvgPool2d((kh,kw), stride=(kh,kw)) on NHWC; (kh,kw)=(H,W) is the global pool.  CMRAgent.py:39,45,51,56. */
+int cmr_avgpool_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, int kh, int kw, hipStream_t stream);
+
+/* out = cat([f, nearest_upsample(proxy, scale)], channel).  IMGPCEnDecoder.py:85-89. */
+int cmr_upsample_concat_f32(const float* f, const float* proxy, float* out, int B, int H, int W, int C1, int C2,
+                            int scale, hipStream_t stream);
+
+/* non-overlapping PxP patches as rows [(ky,kx,c)] for the stride-P patch conv.  ImageViT.py:19-22,51. */
+int cmr_patchify_nhwc_f32(const float* x, float* out, int B, int H, int W, int C, int P, hipStream_t stream);
+
+/* [batch][R][C] -> [batch][C][R]: layout changes at the nn.Module boundary (NCHW <-> NHWC). */
+int cmr_transpose_f32(const float* x, float* y, int batch, int R, int Cn, hipStream_t stream);
+
+/* ---- attention ----------------------------------------------------------------------------- */
+
+/* softmax(Q K^T / sqrt(8)) V, 8 heads x 8 dims.  ImageViT.py:93-104, IMGPCEncoder.py:45-53. */
+int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,
+                int64_t ldo, int B, int Tq, int Tk, hipStream_t stream);
+
+/* kvsum[b] = { KV[h][d][v] = sum_s K~ V / S (512), Ksum[h][d] (64) }.  LinearAttention.py:55-58. */
+int64_t cmr_la_reduce_workspace_bytes(int B, int S);
+int cmr_la_reduce_f32(const float* kf, int64_t ldk, const float* v, int64_t ldv, float* kvsum, void* workspace,
+                      int64_t workspace_bytes, int B, int S, hipStream_t stream);
+/* msg = (Q~ KV) * S / (Q~ Ksum + eps).  LinearAttention.py:59-60. */
+int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* msg, int64_t ldm, int B, int L, int S,
+                     float eps, hipStream_t stream);
+
+/* ---- point-cloud ops ----------------------------------------------------------------------- */
+
+int cmr_planar_to_rows4_f32(const float* x, float* y, int B, int C, int N, hipStream_t stream);
+int cmr_index_to_global_i32(const int64_t* idx, int32_t* out, int B, int N, int M, hipStream_t stream);
+
+/* CSR of the points owned by each node (replaces the expanded-index torch_scatter calls,
+ * PointNN.py:171,175,182; third-party torch_scatter, version unpinned in the reference). */
+int cmr_csr_build_i32(const int32_t* key, int32_t* count, int32_t* offsets, int32_t* order, int B, int n_per_batch,
+                      int seg_per_batch, hipStream_t stream);
+
+/* 16 nearest nodes of every node, ascending distance.  PointNN.py:215-216 (square_distance + argsort). */
+int cmr_knn16_f32(const float* xyz4, int32_t* out, int B, int M, hipStream_t stream);
+
+/* nearest candidate per query.  PointViT.py:85-87 (node -> proxy), dataset/KittiDataset.py:366-367 (point -> node). */
+int cmr_nearest_f32(const float* q4, const float* c4, int32_t* out_global, int64_t* out_local, int B, int Nq, int Nc,
+                    hipStream_t stream);
+
+/* out[r] = a[map_a(r)] - b[map_b(r)] (xyz rows).  PointNN.py:164-166, :223. */
+int cmr_rel_pos_f32(const float* a, const int32_t* ia, int64_t diva, const float* b, const int32_t* ib, int64_t divb,
+                    float* out, int64_t rows, hipStream_t stream);
+
+/* t = q[map_q] - k[map_k] + pos ; vp = v[map_k] + pos.  PointNN.py:162,168,179 and :220,225,228. */
+int cmr_vecattn_prep_f32(const float* q, int64_t ldq, const int32_t* iq, int64_t divq, const float* k, int64_t ldk,
+                         const float* v, int64_t ldv, const int32_t* ik, const float* pos, float* t, float* vp,
+                         int64_t rows, hipStream_t stream);
+
+/* per-segment, per-channel softmax(attn*scale) weighted sum of vp.  PointNN.py:170-182 and :226-228. */
+int cmr_segment_softmax_f32(const float* attn, const float* vp, const int32_t* order, const int32_t* offsets,
+                            int fixed_len, float scale, float* out, int64_t nseg, hipStream_t stream);
+
+/* out[r,:C] = src[idx[r],:C].  pointnet_util.py:36-47 (index_points), torch.gather of feature rows. */
+int cmr_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t rows, int C,
+                        hipStream_t stream);
+
+/* pointnet_util.py:50-70 (start index explicit), :73-93, :19-33. */
+int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, hipStream_t stream);
+int cmr_ball_query_f32(const float* xyz4, const float* new4, int64_t* out, int B, int N, int S, int nsample,
+                       float radius2, hipStream_t stream);
+int cmr_square_distance_f32(const float* a4, const float* b4, float* out, int B, int N, int M, hipStream_t stream);
+
+/* per-batch max / mean over rows.  CMRAgent.py:95 (torch.max over points), environment.py:46,88 (pc.mean). */
+int64_t cmr_colreduce_workspace_bytes(int B, int N, int C);
+int cmr_colmax_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C,
+                   hipStream_t stream);
+int cmr_colmean_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C,
+                    hipStream_t stream);
+
+/* ---- agent iteration ------------------------------------------------------------------------ */
+
+/* environment.py:24-126: projection, in-frustum test, scatter-mean numerator/denominator, state_3d. */
+int cmr_project_scatter_f32(const float* pc4, const float* feat, const uint8_t* overlap, const float* pose,
+                            const float* Kmat, const float* mean4, float* acc, float* cnt, float* state3d, int B, int N,
+                            int h, int w, hipStream_t stream);
+int cmr_observation_finalize_f32(const float* img_feat, const float* acc, const float* cnt, float* state2d, int B, int h,
+                                 int w, int write_img, hipStream_t stream);
+/* environment.py:179-260 (step + euler_angles_to_matrix 'XYZ'), :14-21 (to_disentangled). */
+int cmr_pose_step_f32(float* pose, const int64_t* act_r, const int64_t* act_t, const double* r_steps,
+                      const double* t_steps, int B, int six_dof, hipStream_t stream);
+int cmr_to_disentangled_f32(float* pose, const float* mean4, int B, hipStream_t stream);
+/* CMRAgent.py:118-127 (deterministic action = argmax). */
+int cmr_argmax_rows_f32(const float* x, int64_t* out, int rows, int n, hipStream_t stream);
+/* MultiHeadModel.py:330-341 (softmax over 2 classes, thresholds .5/.8). */
+int cmr_softmax2_f32(const float* logits, int64_t ld, float* prob, uint8_t* pred_lo, uint8_t* pred_hi, float thr_lo,
+                     float thr_hi, int64_t rows, hipStream_t stream);
+/* MultiHeadModel.py:233,241 (F.normalize over channels). */
+int cmr_l2norm64_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CMR_HIP_H */

@@ -1,0 +1,316 @@
+"""GPU tier, op level: every entry point of libcmr_hip.so (called through the C ABI via
+cmr_agent_amd.ops) against a plain torch-CPU / oracle computation of the same op.
+Tolerances: fp32 kernels vs fp32/fp64 CPU, rtol 1e-4 of the output scale (stated per test);
+index-valued ops must match exactly."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cmr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cmr_agent_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def close(got, ref, rtol=1e-4, name=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= rtol * scale, "%s: max|d| %.3e vs scale %.3e" % (name, err, scale)
+
+
+ACTS = {0: lambda v, p: v, 1: lambda v, p: F.relu(v), 2: lambda v, p: F.leaky_relu(v, p), 3: lambda v, p: F.gelu(v),
+        4: lambda v, p: F.elu(v) + 1}
+
+
+@pytest.mark.parametrize("rows,k1,n_out,act", [(1, 64, 64, 0), (130, 64, 64, 2), (300, 128, 64, 1), (77, 8, 64, 2),
+                                               (500, 4, 64, 1), (257, 64, 1024, 3), (64, 1024, 64, 0), (40000, 64, 64, 4),
+                                               (20000, 64, 32, 2), (333, 32, 2, 0), (8, 256, 11, 2), (3344, 4096, 64, 0)])
+def test_linear_basic(ops, rows, k1, n_out, act):
+    x, w, b = rnd(rows, k1, seed=1), rnd(n_out, k1, seed=2) / math.sqrt(k1), rnd(n_out, seed=3)
+    ref = ACTS[act](x.double() @ w.double().t() + b.double(), 0.2)
+    got = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act, act_param=0.2)
+    close(got, ref, 2e-5 if k1 <= 1024 else 5e-5, "linear")
+
+
+def test_linear_two_sources_gather_residual(ops):
+    rows, m = 5000, 37
+    x1, x2 = rnd(rows, 64, seed=4), rnd(m, 64, seed=5)
+    idx = torch.randint(0, m, (rows,), generator=torch.Generator().manual_seed(0)).int()
+    w, b, res = rnd(64, 128, seed=6) / 8, rnd(64, seed=7), rnd(rows, 64, seed=8)
+    ref = F.leaky_relu(torch.cat([x1, x2[idx.long()]], 1).double() @ w.double().t() + b.double() + res.double(), 0.2)
+    got = ops.linear(x1.to(DEV), w.to(DEV), b.to(DEV), x2=x2.to(DEV), idx2=idx.to(DEV), res=res.to(DEV), act=2,
+                     act_param=0.2)
+    close(got, ref, 2e-5, "linear2")
+    # broadcast second source (row r -> r // div2) and strided output / input views
+    x2b = rnd(rows // 1000, 64, seed=9)
+    ref = torch.cat([x1, x2b.repeat_interleave(1000, 0)], 1).double() @ w.double().t()
+    buf = torch.zeros(rows, 192, device=DEV)
+    xin = torch.zeros(rows, 96, device=DEV)
+    xin[:, 32:] = x1.to(DEV)
+    ops.linear(xin[:, 32:], w.to(DEV), None, x2=x2b.to(DEV), div2=1000, out=buf[:, 64:128])
+    close(buf[:, 64:128], ref, 2e-5, "linear2-bcast")
+    assert float(buf[:, :64].abs().max()) == 0 and float(buf[:, 128:].abs().max()) == 0
+
+
+def test_linear_res_mod(ops):
+    rows, t = 6 * 15, 15
+    x, w, tab = rnd(rows, 64, seed=10), rnd(64, 64, seed=11) / 8, rnd(t, 64, seed=12)
+    ref = x.double() @ w.double().t() + tab.double().repeat(6, 1)
+    close(ops.linear(x.to(DEV), w.to(DEV), None, res=tab.to(DEV), res_mod=t), ref, 2e-5, "res_mod")
+
+
+@pytest.mark.parametrize("rows,eps", [(1, 1e-6), (1000, 1e-5), (26752, 1e-6)])
+def test_layernorm64(ops, rows, eps):
+    x, g, b, r = rnd(rows, 64, seed=13, lo=-3, hi=5), rnd(64, seed=14), rnd(64, seed=15), rnd(rows, 64, seed=16)
+    ref = F.layer_norm(x.double(), (64,), g.double(), b.double(), eps)
+    close(ops.layernorm64(x.to(DEV), g.to(DEV), b.to(DEV), eps), ref, 2e-5, "ln")
+    close(ops.layernorm64(x.to(DEV), g.to(DEV), b.to(DEV), eps, res=r.to(DEV)), ref + r.double(), 2e-5, "ln+res")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,stride", [(2, 12, 20, 64, 64, 1), (1, 40, 70, 64, 64, 1), (2, 9, 13, 128, 64, 1),
+                                                   (1, 11, 38, 128, 128, 1), (2, 12, 20, 64, 64, 2), (1, 33, 71, 64, 64, 2),
+                                                   (1, 64, 96, 64, 64, 1)])
+def test_conv3x3(ops, B, H, W, cin, cout, stride):
+    x, w, b = rnd(B, cin, H, W, seed=17), rnd(cout, cin, 3, 3, seed=18) / math.sqrt(9 * cin), rnd(cout, seed=19)
+    y = F.conv2d(x.double(), w.double(), b.double(), stride, 1)
+    res, post = rnd(*y.shape, seed=20), rnd(cout, y.shape[2], y.shape[3], seed=21)
+    ref = F.leaky_relu(y + res.double(), 0.2) + post.double()
+    w9 = w.permute(2, 3, 0, 1).reshape(9, cout, cin).contiguous()
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w9.to(DEV), b.to(DEV), cout, stride, 0.2,
+                      res=res.permute(0, 2, 3, 1).contiguous().to(DEV), post=post.permute(1, 2, 0).contiguous().to(DEV))
+    close(got.permute(0, 3, 1, 2), ref, 2e-5, "conv3x3")
+    got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w9.to(DEV), None, cout, stride, 1.0)
+    close(got.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, stride, 1), 2e-5, "conv3x3-plain")
+
+
+def test_stem_block(ops):
+    B, H, W = 2, 16, 35
+    x = rnd(B, 3, H, W, seed=22, lo=0)
+    wa, ba = rnd(3, 3, 3, 3, seed=23) / 5, rnd(3, seed=24)
+    w3, w1, bb = rnd(64, 3, 3, 3, seed=25) / 5, rnd(64, 3, 1, 1, seed=26), rnd(64, seed=27)
+    t = F.leaky_relu(F.conv2d(x.double(), wa.double(), ba.double(), 1, 1), 0.2)
+    ref = F.leaky_relu(F.conv2d(t, w3.double(), None, 1, 1) + F.conv2d(x.double(), w1.double()) + bb.double().view(1, -1, 1, 1), 0.2)
+    got = ops.stem_block(x.to(DEV), wa.contiguous().to(DEV), ba.to(DEV), w3.reshape(64, 27).t().contiguous().to(DEV),
+                         w1.reshape(64, 3).t().contiguous().to(DEV), bb.to(DEV), 0.2)
+    close(got.permute(0, 3, 1, 2), ref, 2e-5, "stem")
+
+
+def test_pool_upsample_patchify_transpose(ops):
+    x = rnd(2, 11, 38, 128, seed=28)
+    close(ops.avgpool(x.to(DEV), 2, 2).permute(0, 3, 1, 2), F.avg_pool2d(x.permute(0, 3, 1, 2), 2, 2), 1e-6, "pool2")
+    close(ops.avgpool(x.to(DEV), 11, 38).permute(0, 3, 1, 2), F.avg_pool2d(x.permute(0, 3, 1, 2), (11, 38), 1), 1e-5, "gpool")
+    f, p = rnd(2, 16, 24, 64, seed=29), rnd(2 * 2 * 3, 64, seed=30)
+    up = F.interpolate(p.view(2, 2, 3, 64).permute(0, 3, 1, 2), scale_factor=8, mode="nearest")
+    ref = torch.cat([f.permute(0, 3, 1, 2), up], 1)
+    close(ops.upsample_concat(f.to(DEV), p.to(DEV), 8).permute(0, 3, 1, 2), ref, 0, "upcat")
+    w = rnd(64, 64, 8, 8, seed=31) / 64
+    ref = F.conv2d(f.permute(0, 3, 1, 2).double(), w.double(), None, 8).flatten(2).transpose(1, 2).reshape(-1, 64)
+    pat = ops.patchify(f.to(DEV), 8)
+    got = ops.linear(pat, w.permute(0, 2, 3, 1).reshape(64, -1).contiguous().to(DEV))
+    close(got, ref, 5e-5, "patch-embed")
+    t = rnd(3, 70, 45, seed=32)
+    close(ops.transpose(t.to(DEV)), t.transpose(1, 2), 0, "transpose")
+
+
+@pytest.mark.parametrize("B,Tq,Tk", [(2, 50, 30), (1, 418, 256), (2, 256, 418), (1, 70, 1400)])
+def test_mha(ops, B, Tq, Tk):
+    q, k, v = rnd(B * Tq, 64, seed=33, lo=-3, hi=3), rnd(B * Tk, 64, seed=34, lo=-3, hi=3), rnd(B * Tk, 64, seed=35)
+    qh = q.view(B, Tq, 8, 8).permute(0, 2, 1, 3).double()
+    kh = k.view(B, Tk, 8, 8).permute(0, 2, 1, 3).double()
+    vh = v.view(B, Tk, 8, 8).permute(0, 2, 1, 3).double()
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(8), -1) @ vh).permute(0, 2, 1, 3).reshape(B * Tq, 64)
+    kv = torch.cat([k, v], 1).to(DEV)                      # fused [K|V] buffer, ld = 128
+    got = ops.mha(q.to(DEV), kv[:, :64], kv[:, 64:], B, Tq, Tk)
+    close(got, ref, 2e-5, "mha")
+
+
+@pytest.mark.parametrize("B,L,S", [(2, 70, 45), (1, 1280, 3000), (2, 2000, 1280)])
+def test_linear_attention_core(ops, B, L, S):
+    q, k, v = rnd(B * L, 64, seed=36, lo=0.1, hi=2), rnd(B * S, 64, seed=37, lo=0.1, hi=2), rnd(B * S, 64, seed=38)
+    Q, K, V = q.view(B, L, 8, 8).double(), k.view(B, S, 8, 8).double(), v.view(B, S, 8, 8).double() / S
+    KV = torch.einsum("nshd,nshv->nhdv", K, V)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + 1e-6)
+    ref = (torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * S).reshape(B * L, 64)
+    kvsum = ops.la_reduce(k.to(DEV), v.to(DEV), B, S)
+    close(kvsum[:, :512], KV.reshape(B, 512), 2e-5, "la-kv")
+    close(kvsum[:, 512:], K.sum(1).reshape(B, 64), 2e-5, "la-ksum")
+    close(ops.la_apply(q.to(DEV), kvsum, B, L, S, 1e-6), ref, 5e-5, "la-apply")
+
+
+def _cloud(B, N, seed):
+    return rnd(B, 3, N, seed=seed, lo=-20, hi=20)
+
+
+def test_layout_and_csr(ops):
+    B, N, M = 3, 1000, 37
+    pc = _cloud(B, N, 39)
+    rows4 = ops.planar_to_rows4(pc.to(DEV)).cpu()
+    assert torch.equal(rows4[:, :3], pc.permute(0, 2, 1).reshape(-1, 3)) and float(rows4[:, 3].abs().max()) == 0
+    idx = torch.randint(0, M, (B, N), generator=torch.Generator().manual_seed(1))
+    idx[:, :M] = torch.arange(M)                     # every node owns at least one point
+    g = ops.index_to_global(idx.to(DEV), M)
+    gref = (idx + torch.arange(B).view(B, 1) * M).reshape(-1)
+    assert torch.equal(g.cpu().long(), gref)
+    offsets, order = ops.csr_build(g, B, N, M)
+    cnt = torch.bincount(gref, minlength=B * M)
+    assert torch.equal(offsets.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
+    assert torch.equal(order.cpu().long(), torch.sort(gref, stable=True)[1])
+
+
+def test_knn_and_nearest(ops):
+    B, M = 2, 1280
+    nodes = _cloud(B, M, 40)
+    n4 = ops.planar_to_rows4(nodes.to(DEV))
+    got = ops.knn16(n4, B, M).cpu().long().view(B, M, 16)
+    xyz = nodes.permute(0, 2, 1)
+    ref = O.square_distance(xyz, xyz).argsort()[:, :, :16] + torch.arange(B).view(B, 1, 1) * M
+    assert float((got == ref).float().mean()) == 1.0
+    pc = _cloud(B, 5000, 41)
+    p4 = ops.planar_to_rows4(pc.to(DEV))
+    og, ol = ops.nearest(p4, n4, B, 5000, M)
+    d = O.square_distance(pc.permute(0, 2, 1), xyz)
+    assert torch.equal(ol.cpu(), d.argmin(2))
+    assert torch.equal(og.cpu().long().view(B, -1), d.argmin(2) + torch.arange(B).view(B, 1) * M)
+    sq = ops.square_distance(n4, p4, B, M, 5000)
+    assert torch.equal(sq.cpu(), O.square_distance(xyz, pc.permute(0, 2, 1)))
+
+
+def test_vector_attention_pieces(ops):
+    rows, m = 3000, 70
+    a4, b4 = rnd(rows, 4, seed=42), rnd(m, 4, seed=43)
+    a4[:, 3] = 0
+    b4[:, 3] = 0
+    idx = torch.randint(0, m, (rows,), generator=torch.Generator().manual_seed(2)).int()
+    got = ops.rel_pos(a4.to(DEV), b4.to(DEV), rows, ib=idx.to(DEV))
+    close(got, a4 - b4[idx.long()], 0, "rel_pos")
+    got = ops.rel_pos(b4.to(DEV), a4.to(DEV), m * 16, diva=16, ib=idx[:m * 16].to(DEV))
+    close(got, b4.repeat_interleave(16, 0) - a4[idx[:m * 16].long()], 0, "rel_pos-div")
+    q, k, v, pos = rnd(m, 64, seed=44), rnd(rows, 64, seed=45), rnd(rows, 64, seed=46), rnd(rows, 64, seed=47)
+    t, vp = ops.vecattn_prep(q.to(DEV), k.to(DEV), v.to(DEV), pos.to(DEV), rows, iq=idx.to(DEV))
+    close(t, q[idx.long()] - k + pos, 1e-6, "prep-t")
+    close(vp, v + pos, 1e-6, "prep-vp")
+    ik = torch.randint(0, rows, (m * 16,), generator=torch.Generator().manual_seed(3)).int()
+    t, vp = ops.vecattn_prep(q.to(DEV), k.to(DEV), v.to(DEV), pos[:m * 16].contiguous().to(DEV), m * 16, divq=16,
+                             ik=ik.to(DEV))
+    close(t, q.repeat_interleave(16, 0) - k[ik.long()] + pos[:m * 16], 1e-6, "prep-t-knn")
+    close(vp, v[ik.long()] + pos[:m * 16], 1e-6, "prep-vp-knn")
+    # segment softmax against the scatter formulation (PointNN.py:170-182)
+    attn, val = rnd(rows, 64, seed=48, lo=-30, hi=30), rnd(rows, 64, seed=49)
+    seg = idx.long()
+    seg[:m] = torch.arange(m)
+    gi = seg.view(1, 1, rows).expand(1, 64, rows)
+    a = attn.t().unsqueeze(0).double() / 8
+    a = (a - torch.gather(O.scatter_max(a, gi, 2, m), 2, gi)).exp()
+    a = a / torch.gather(O.scatter_sum(a, gi, 2, m), 2, gi)
+    ref = O.scatter_sum(a * val.t().unsqueeze(0).double(), gi, 2, m)[0].t()
+    offsets, order = ops.csr_build(seg.int().to(DEV), 1, rows, m)
+    got = ops.segment_softmax(attn.to(DEV), val.to(DEV), m, 0.125, order=order, offsets=offsets)
+    close(got, ref, 2e-5, "segsoftmax")
+    ref16 = (torch.softmax(attn[:m * 16].view(m, 16, 64).double() / 8, 1) * val[:m * 16].view(m, 16, 64).double()).sum(1)
+    got = ops.segment_softmax(attn[:m * 16].contiguous().to(DEV), val[:m * 16].contiguous().to(DEV), m, 0.125, fixed_len=16)
+    close(got, ref16, 2e-5, "segsoftmax-fixed")
+    got = ops.gather_rows(val.to(DEV), idx.to(DEV))
+    close(got, val[idx.long()], 0, "gather_rows")
+
+
+@pytest.mark.parametrize("B,N,npoint", [(2, 500, 64), (2, 4096, 256), (1, 10240, 1280), (1, 20000, 128)])
+def test_fps_matches_pointnet_util(ops, B, N, npoint):
+    xyz = _cloud(B, N, 50).permute(0, 2, 1).contiguous()
+    start = torch.tensor([3, 77][:B])
+    ref = O.farthest_point_sample(xyz, npoint, start)
+    x4 = ops.planar_to_rows4(xyz.permute(0, 2, 1).contiguous().to(DEV))
+    got = ops.fps(x4, start.to(DEV), B, N, npoint)
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_ball_query_matches_pointnet_util(ops):
+    B, N, S = 2, 3000, 128
+    xyz = _cloud(B, N, 51).permute(0, 2, 1).contiguous()
+    new_xyz = xyz[:, ::23][:, :S].contiguous() + 0.01
+    x4 = ops.planar_to_rows4(xyz.permute(0, 2, 1).contiguous().to(DEV))
+    n4 = ops.planar_to_rows4(new_xyz.permute(0, 2, 1).contiguous().to(DEV))
+    for radius, ns in ((4.0, 16), (9.0, 32), (0.001, 8)):
+        ref = O.query_ball_point(radius, ns, xyz, new_xyz)
+        got = ops.ball_query(x4, n4, B, N, S, ns, radius)
+        assert torch.equal(got.cpu(), ref), radius
+
+
+def test_col_reductions(ops):
+    B, N = 3, 5000
+    x = rnd(B * N, 64, seed=52, lo=-5, hi=5)
+    close(ops.colmax(x.to(DEV), B, N), x.view(B, N, 64).max(1)[0], 0, "colmax")
+    x4 = rnd(B * N, 4, seed=53, lo=-40, hi=40)
+    close(ops.colmean(x4.to(DEV), B, N), x4.view(B, N, 4).double().mean(1), 1e-5, "colmean")
+    x128 = rnd(B * 700, 128, seed=54)
+    close(ops.colmax(x128.to(DEV), B, 700), x128.view(B, 700, 128).max(1)[0], 0, "colmax128")
+
+
+def test_observation_and_pose(ops):
+    B, N, h, w = 2, 4000, 24, 40
+    pc = torch.stack([rnd(B, N, seed=55, lo=-30, hi=30), rnd(B, N, seed=56, lo=-2, hi=2), rnd(B, N, seed=57, lo=1, hi=60)], 1)
+    feat = F.normalize(rnd(B, 64, N, seed=58), dim=1)
+    imf = rnd(B, 64, h, w, seed=59)
+    ov = rnd(B, N, seed=60) > 0.3
+    K = torch.tensor([[0.6 * w, 0, w / 2.0], [0, 0.6 * w, h / 2.0], [0, 0, 1]]).repeat(B, 1, 1)
+    pose = torch.eye(4).repeat(B, 1, 1)
+    r_steps = torch.tensor([-62.5, -12.5, -2.5, -0.5, -0.1, 0.0, 0.1, 0.5, 2.5, 12.5, 62.5], dtype=torch.float64) * math.pi / 180
+    t_steps = torch.tensor([-8.1, -2.7, -0.9, -0.3, -0.1, 0.0, 0.1, 0.3, 0.9, 2.7, 8.1], dtype=torch.float64)
+    ar, at = torch.tensor([[8], [2]]), torch.tensor([[7, 3], [9, 1]])
+    pose_ref = O.env_step(ar, at, pose.clone(), r_steps, t_steps)
+    pose_ref = O.env_step(ar, at, pose_ref, r_steps, t_steps)
+    pose_g = pose.clone().to(DEV)
+    for _ in range(2):
+        ops.pose_step(pose_g, ar.to(DEV), at.to(DEV), r_steps.to(DEV), t_steps.to(DEV), False)
+    close(pose_g, pose_ref, 1e-6, "pose_step")
+    data = dict(K=K, pc=pc, pc_overlap_pred=ov, pc_geo_feat=feat, img_geo_feat=imf)
+    s2, s3 = O.observation_from_a_pose(data, pose_ref)
+    pc4 = ops.planar_to_rows4(pc.to(DEV))
+    mean4 = ops.colmean(pc4, B, N)
+    acc = torch.empty(B * h * w, 64, device=DEV)
+    cnt = torch.empty(B * h * w, device=DEV)
+    st3 = torch.empty(B * N, 8, device=DEV)
+    st2 = torch.empty(B, h, w, 128, device=DEV)
+    ops.project_scatter(pc4, feat.permute(0, 2, 1).reshape(-1, 64).contiguous().to(DEV), ov.to(torch.uint8).reshape(-1).to(DEV),
+                        pose_g, K.to(DEV), mean4, B, N, h, w, acc, cnt, st3)
+    ops.observation_finalize(imf.permute(0, 2, 3, 1).contiguous().to(DEV), acc, cnt, st2, B, h, w, True)
+    got3 = st3.view(B, N, 8).permute(0, 2, 1).cpu()
+    assert float((got3[:, :5] == s3).float().mean()) > 0.9995 and float(got3[:, 5:].abs().max()) == 0
+    got2 = st2.permute(0, 3, 1, 2).cpu()
+    bad = ((got2 - s2).abs() > 1e-5).float().mean()
+    assert float(bad) < 2e-3, float(bad)      # a point within 1 ulp of a pixel boundary may land next door
+    # to_disentangled
+    p2 = pose_ref.clone()
+    ref = O.to_disentangled(p2, pc)
+    pg = pose_ref.clone().to(DEV)
+    ops.to_disentangled(pg, mean4)
+    close(pg, ref, 1e-5, "to_disentangled")
+
+
+def test_small_heads(ops):
+    logits = rnd(5000, 2, seed=61, lo=-4, hi=4)
+    prob, lo, hi = ops.softmax2(logits.to(DEV))
+    ref = torch.softmax(logits.double(), 1)[:, 1]
+    close(prob, ref, 1e-6, "softmax2")
+    safe = ((ref - 0.5).abs() > 1e-5) & ((ref - 0.8).abs() > 1e-5)
+    assert torch.equal(lo.cpu().bool()[safe], (ref > 0.5)[safe]) and torch.equal(hi.cpu().bool()[safe], (ref > 0.8)[safe])
+    x = rnd(3000, 64, seed=62)
+    close(ops.l2norm64(x.to(DEV)), F.normalize(x.double(), dim=1), 1e-6, "l2norm")
+    lg = rnd(24, 11, seed=63)
+    assert torch.equal(ops.argmax_rows(lg.to(DEV), 24, 11).cpu(), lg.argmax(1))
