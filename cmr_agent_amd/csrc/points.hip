@@ -13,6 +13,10 @@
 // relative to torch's sum((a-b)**2, -1): index results are then bit-identical except on exact ties.
 #include "cmr_common.h"
 
+// hipcc contracts a*b+c into fma by default (also through __fmul_rn/__fadd_rn, which are plain
+// operators in the HIP headers); distances must round like torch's separate mul / add.
+#pragma clang fp contract(off)
+
 namespace {
 
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
@@ -21,14 +25,37 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 }
 
 // ---- layout ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void planar_to_rows4_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
-                                                              int C, int N) {
+// planar [B,C,N] -> rows [B*N, CP] (CP = 4 or 8, zero padded)
+__global__ __launch_bounds__(256) void planar_to_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                             int C, int N, int CP) {
   const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (r >= (int64_t)B * N) return;
   const int b = (int)(r / N), n = (int)(r % N);
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  for (int c = 0; c < C && c < 4; ++c) v[c] = x[((int64_t)b * C + c) * N + n];
-  *reinterpret_cast<f32x4*>(y + r * 4) = v;
+  for (int c0 = 0; c0 < CP; c0 += 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < 4; ++c)
+      if (c0 + c < C) v[c] = x[((int64_t)b * C + c0 + c) * N + n];
+    *reinterpret_cast<f32x4*>(y + r * CP + c0) = v;
+  }
+}
+
+// out[r] = [ x1[r, :C1] | x2[map(r), :C2] ]   (materialised torch.cat, only where a consumer needs it)
+__global__ __launch_bounds__(256) void concat_rows_kernel(const float* __restrict__ x1, int64_t ld1, int C1,
+                                                          const float* __restrict__ x2, int64_t ld2, int C2,
+                                                          const int32_t* __restrict__ idx2, int64_t div2,
+                                                          float* __restrict__ out, int64_t rows) {
+  const int c4n = (C1 + C2) / 4;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = e / c4n;
+  if (r >= rows) return;
+  const int c = (int)(e % c4n) * 4;
+  f32x4 v;
+  if (c < C1) v = *reinterpret_cast<const f32x4*>(x1 + r * ld1 + c);
+  else {
+    const int64_t s = idx2 ? (int64_t)idx2[r] : (div2 > 1 ? r / div2 : r);
+    v = *reinterpret_cast<const f32x4*>(x2 + s * ld2 + (c - C1));
+  }
+  *reinterpret_cast<f32x4*>(out + r * (C1 + C2) + c) = v;
 }
 
 __global__ __launch_bounds__(256) void index_to_global_kernel(const int64_t* __restrict__ idx, int32_t* __restrict__ out,
@@ -391,9 +418,18 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(const float* __res
 
 #define GRID1D(n) dim3((unsigned)(((n) + 255) / 256))
 
-extern "C" int cmr_planar_to_rows4_f32(const float* x, float* y, int B, int C, int N, hipStream_t stream) {
-  CMR_REQUIRE(x && y && B > 0 && C >= 1 && C <= 4 && N > 0 && cmr_aligned16(y));
-  hipLaunchKernelGGL(planar_to_rows4_kernel, GRID1D((int64_t)B * N), dim3(256), 0, stream, x, y, B, C, N);
+extern "C" int cmr_planar_to_rows_f32(const float* x, float* y, int B, int C, int N, int Cpad, hipStream_t stream) {
+  CMR_REQUIRE(x && y && B > 0 && C >= 1 && (Cpad == 4 || Cpad == 8) && C <= Cpad && N > 0 && cmr_aligned16(y));
+  hipLaunchKernelGGL(planar_to_rows_kernel, GRID1D((int64_t)B * N), dim3(256), 0, stream, x, y, B, C, N, Cpad);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_concat_rows_f32(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2,
+                                   const int32_t* idx2, int64_t div2, float* out, int64_t rows, hipStream_t stream) {
+  CMR_REQUIRE(x1 && x2 && out && rows > 0 && C1 > 0 && C2 > 0 && C1 % 4 == 0 && C2 % 4 == 0 && ld1 % 4 == 0 &&
+              ld2 % 4 == 0 && cmr_aligned16(x1) && cmr_aligned16(x2) && cmr_aligned16(out));
+  hipLaunchKernelGGL(concat_rows_kernel, GRID1D(rows * ((C1 + C2) / 4)), dim3(256), 0, stream, x1, ld1, C1, x2, ld2, C2,
+                     idx2, div2, out, rows);
   return cmr_launch_status();
 }
 

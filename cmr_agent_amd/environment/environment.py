@@ -1,0 +1,95 @@
+"""Pose-conditioned observation and pose update on HIP kernels.  Function-level mirror of the
+reference's environment/environment.py: init :129-140, to_disentangled :14-21,
+observation_from_a_pose :24-126, step :179-207 (+ euler_angles_to_matrix :210-260 inside the
+kernel).  `expert` / `reward` (:143-176, :263-302) are training-side host logic.
+
+The geo model leaves its row-layout buffers in data['_cmr']; the observation is then two kernel
+launches + two memsets per agent step, with no per-sample Python loop and no host sync.  A
+sample with zero predicted-overlap points yields an all-zero projected half instead of the
+reference's crash (environment.py:74-82)."""
+import torch
+
+from .. import ops
+from ..models.ImageResNet import to_nhwc
+from ..models.PointNN import rows_from_bcl
+
+
+class _ObsContext:
+    """Per-batch constants of the agent loop + the reusable scatter / state buffers."""
+
+    def __init__(self, data):
+        cl = data.get('_cmr')
+        pc = data['pc']
+        self.B, _, self.N = pc.shape
+        dev = pc.device
+        if cl is not None and 'geo' in cl and cl['geo'].pc4.device == dev:
+            self.pc4 = cl['geo'].pc4
+        else:
+            self.pc4 = ops.planar_to_rows(pc.contiguous(), 4)
+        self.feat = cl['pc_geo_feat'] if cl is not None and 'pc_geo_feat' in cl else rows_from_bcl(data['pc_geo_feat'])
+        ov = data['pc_overlap_pred']
+        self.overlap = ov.contiguous().view(torch.uint8).view(-1) if ov.dtype == torch.bool else ov.to(torch.uint8).view(-1)
+        self.overlap_src = ov
+        self.img = cl['img_geo_feat'] if cl is not None and 'img_geo_feat' in cl else to_nhwc(data['img_geo_feat'])
+        _, self.h, self.w, c = self.img.shape
+        if c != 64:
+            raise ValueError("observation kernels are instantiated for 64-d geometric features")
+        self.K = data['K'].to(dev).contiguous()
+        self.mean4 = ops.colmean(self.pc4, self.B, self.N)
+        cells = self.B * self.h * self.w
+        self.acc = torch.empty((cells, 64), dtype=torch.float32, device=dev)
+        self.cnt = torch.empty((cells,), dtype=torch.float32, device=dev)
+        self.first = True
+
+
+def _context(data):
+    ctx = data.get('_cmr_obs')
+    if ctx is None or ctx.overlap_src is not data['pc_overlap_pred'] or ctx.pc4.device != data['pc'].device:
+        ctx = _ObsContext(data)
+        data['_cmr_obs'] = ctx
+    return ctx
+
+
+@torch.no_grad()
+def to_disentangled(poses, pcd):
+    """t <- t - mu + R mu with mu the centroid of the cloud; mutates and returns `poses`."""
+    B, _, N = pcd.shape
+    pc4 = ops.planar_to_rows(pcd[:, 0:3, :].contiguous(), 4)
+    ops.to_disentangled(poses, ops.colmean(pc4, B, N))
+    return poses
+
+
+@torch.no_grad()
+def observation_from_a_pose(data, RT):
+    """-> (state_2d [B,128,h,w], state_3d [B,5,N]) as views of channels-last / row storage.
+    New storage is returned on every call (the reference's replay buffer keeps them)."""
+    ctx = _context(data)
+    B, N, h, w = ctx.B, ctx.N, ctx.h, ctx.w
+    dev = ctx.pc4.device
+    state3d = torch.empty((B * N, 8), dtype=torch.float32, device=dev)
+    state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev)
+    ops.project_scatter(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.acc, ctx.cnt,
+                        state3d)
+    ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, B, h, w, True)
+    obs2d = state2d.permute(0, 3, 1, 2)
+    obs3d = state3d.view(B, N, 8)[:, :, :5].permute(0, 2, 1)
+    return obs2d, obs3d
+
+
+def init(data):
+    """Identity start pose and the ground-truth pose (for the expert)."""
+    dev = data['pc'].device
+    B = data['pc'].shape[0]
+    pose_target = data['P'].to(dev)
+    pose_source = torch.eye(4, device=dev).repeat(B, 1, 1)
+    return pose_source, pose_target
+
+
+def step(action_r, action_t, pose_source, config):
+    """pose <- [E_xyz(delta_r) R | t + delta_t]; mutates and returns pose_source."""
+    dev = pose_source.device
+    r_steps, t_steps = config.r_steps, config.t_steps
+    if r_steps.device != dev:
+        r_steps, t_steps = r_steps.to(dev), t_steps.to(dev)
+    ops.pose_step(pose_source, action_r.contiguous(), action_t.contiguous(), r_steps, t_steps, config.is_6_DoF)
+    return pose_source

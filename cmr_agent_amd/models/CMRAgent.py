@@ -1,0 +1,121 @@
+"""Stage-2 actor-critic policy.  API / state_dict mirror of the reference's models/CMRAgent.py
+(:17-144).  2-D branch: 8 x conv3x3(128->128) (+BN on the odd ones) with LeakyReLU(0.01), three
+2x2 average pools and a global pool, two 1x1 convs; 3-D branch: 4 x ConvBNReLURes1D with a global
+max-pool whose result is broadcast-concatenated to every point (never materialised: it enters the
+next layer as the second GEMM source); heads: three small MLPs on the 256-d state."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import _pack
+from ._pack import Planned
+from .ImageResNet import to_nhwc
+from .PointNN import ConvBNReLURes1D
+
+SLOPE = 0.01          # nn.LeakyReLU default (CMRAgent.py:36)
+
+
+def _mlp(sizes):
+    layers = []
+    for i in range(len(sizes) - 1):
+        layers.append(nn.Linear(sizes[i], sizes[i + 1]))
+        if i < len(sizes) - 2:
+            layers.append(nn.LeakyReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class CMRAgent(Planned):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        f = config.embed_dim
+        self.state_3d_embed = nn.ModuleList([ConvBNReLURes1D(5, f), ConvBNReLURes1D(2 * f, f),
+                                             ConvBNReLURes1D(2 * f, f), ConvBNReLURes1D(2 * f, 2 * f)])
+        H, W = config.image_H // 8, config.image_W // 8
+        c = 2 * f
+        conv = lambda: nn.Conv2d(c, c, kernel_size=(3, 3), padding=(1, 1), stride=1)
+        seq = []
+        for stage in range(4):
+            seq += [conv(), nn.BatchNorm2d(c), nn.LeakyReLU(inplace=True), conv(), nn.LeakyReLU(inplace=True),
+                    nn.AvgPool2d((2, 2), stride=(2, 2)) if stage < 3 else nn.AvgPool2d((H, W), stride=1)]
+        seq += [nn.Conv2d(c, c, kernel_size=(1, 1), padding=(0, 0), stride=1), nn.LeakyReLU(inplace=True),
+                nn.Conv2d(c, c, kernel_size=(1, 1), padding=(0, 0), stride=1)]
+        self.state_2d_embed = nn.Sequential(*seq)
+        self.degree_r, self.degree_t = (3, 3) if config.is_6_DoF else (1, 2)
+        self.policy_r = _mlp([4 * f, 4 * f, 4 * f, self.degree_r * config.num_steps])
+        self.policy_t = _mlp([4 * f, 4 * f, 4 * f, self.degree_t * config.num_steps])
+        self.value = _mlp([4 * f, f, f, 1])
+
+    def _build_plan(self):
+        e = self.state_2d_embed
+        p = {"convs": []}
+        for stage in range(4):
+            b = stage * 6
+            p["convs"].append((_pack.conv9(e[b], e[b + 1]), _pack.conv9(e[b + 3])))
+        p["c24"], p["c26"] = _pack.lin(e[24]), _pack.lin(e[26])
+        for name in ("policy_r", "policy_t", "value"):
+            m = getattr(self, name)
+            p[name] = [_pack.lin(m[0]), _pack.lin(m[2]), _pack.lin(m[4])]
+        return p
+
+    # ------------------------------------------------------------------------------------------
+    def forward_cl(self, state2d, state3d_rows, B, N):
+        """state2d NHWC [B,h,w,128]; state3d rows [B*N,8] = (x,y,z,overlap,in_cam,0,0,0)."""
+        self._require_eval()
+        p = self.plan()
+        c = 2 * self.config.embed_dim
+        x = state2d
+        for stage, ((wa, ba), (wb, bb)) in enumerate(p["convs"]):
+            x = ops.conv3x3(x, wa, ba, c, 1, SLOPE)
+            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE)
+            if stage < 3:
+                x = ops.avgpool(x, 2, 2)
+            else:
+                kh, kw = self.config.image_H // 8, self.config.image_W // 8
+                if (x.shape[1], x.shape[2]) != (kh, kw):
+                    raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (x.shape[1], x.shape[2], kh, kw))
+                x = ops.avgpool(x, kh, kw)
+        e2d = ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
+        layers = self.state_3d_embed
+        feat = layers[0].rows(state3d_rows)
+        for i in (1, 2, 3):
+            g = ops.colmax(feat, B, N)                       # torch.max over points, broadcast back (:95-99)
+            feat = layers[i].rows(feat, x2=g, div2=N)
+        e3d = ops.colmax(feat, B, N)
+        out = []
+        for name in ("policy_r", "policy_t", "value"):
+            l0, l1, l2 = p[name]
+            hcur = ops.linear(e2d, *l0, x2=e3d, act=ops.ACT_LRELU, act_param=SLOPE)      # cat([embed_2d, embed_3d])
+            hcur = ops.linear(hcur, *l1, act=ops.ACT_LRELU, act_param=SLOPE)
+            out.append(ops.linear(hcur, *l2))
+        S = self.config.num_steps
+        return out[0].view(B, self.degree_r, S), out[1].view(B, self.degree_t, S), out[2].view(B, 1, 1)
+
+    def forward(self, state_2d, state_3d):
+        """state_2d [B,128,h,w], state_3d [B,5,N] (reference layout; the views produced by
+        cmr_agent_amd.environment are consumed without a copy)."""
+        B, _, N = state_3d.shape
+        s2 = to_nhwc(state_2d)
+        if state_3d.stride(1) == 1 and state_3d.stride(2) == 8 and state_3d.stride(0) == 8 * N:
+            s3 = torch.as_strided(state_3d, (B * N, 8), (8, 1))            # view of the env's [B*N,8] rows
+        else:
+            s3 = ops.planar_to_rows(state_3d.contiguous(), 8)
+        return self.forward_cl(s2, s3, B, N)
+
+    @staticmethod
+    def action_from_logits(r_logits, t_logits, deterministic=False):
+        """CMRAgent.py:118-127.  deterministic: argmax (of the Categorical probs = of the logits)."""
+        if deterministic:
+            ar = ops.argmax_rows(r_logits.contiguous(), r_logits.shape[0] * r_logits.shape[1], r_logits.shape[2])
+            at = ops.argmax_rows(t_logits.contiguous(), t_logits.shape[0] * t_logits.shape[1], t_logits.shape[2])
+            return ar.view(r_logits.shape[:2]), at.view(t_logits.shape[:2])
+        from torch.distributions import Categorical
+        return Categorical(logits=r_logits).sample(), Categorical(logits=t_logits).sample()
+
+    @staticmethod
+    def action_logprob_and_entropy(r_logits, t_logits, action_r, action_t):
+        """CMRAgent.py:129-144 (training-side bookkeeping; plain torch)."""
+        from torch.distributions import Categorical
+        dr, dt = Categorical(logits=r_logits), Categorical(logits=t_logits)
+        return (torch.cat([dr.log_prob(action_r), dt.log_prob(action_t)], dim=1),
+                torch.cat([dr.entropy(), dt.entropy()], dim=1))

@@ -1,0 +1,66 @@
+"""Coarse matcher: both towers, then 6 x [image<-point CA, point<-image CA, image SA, point SA]
+on T image proxies x Q point proxies.  API / state_dict mirror of the reference's
+models/IMGPCEncoder.py (:105-164).  Inputs stay on the device of the module's parameters
+(the reference hard-codes .cuda(), :130-134)."""
+import torch.nn as nn
+
+from ._pack import Planned, device_of
+from ._vit import Attention, Block, Mlp  # noqa: F401
+from .ImageViT import ImageTransformer
+from .PointNN import bcl_from_rows
+from .PointViT import PointGeometry, PointTransformer
+
+
+class IMGPCEncoder(Planned):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.pt_transformer = PointTransformer(config)
+        self.img_transformer = ImageTransformer(config)
+        n = config.num_ca_layer_coarse
+        self.i2p_ca_layers = nn.ModuleList([Block(config) for _ in range(n)])
+        self.p2i_ca_layers = nn.ModuleList([Block(config) for _ in range(n)])
+        self.pt_sa_layers = nn.ModuleList([Block(config) for _ in range(n)])
+        self.img_sa_layers = nn.ModuleList([Block(config) for _ in range(n)])
+
+    def _build_plan(self):
+        return {}
+
+    def forward_cl(self, data_batch):
+        """Runs the encoder and returns the row-layout context (dict) used by the decoder / heads."""
+        dev = device_of(self)
+        img = data_batch['img'].to(dev).contiguous()
+        pc = data_batch['pc'].to(dev)
+        node = data_batch['node'].to(dev)
+        idx = data_batch['pt2node'].to(dev)
+        geo = PointGeometry(pc, node, idx)
+        B, Q = geo.B, self.config.num_proxy
+        img_proxy, T, f2, f1, f0 = self.img_transformer.forward_cl(img)
+        pt_proxy, n2p, n2p_global, pt_feat, node_feat = self.pt_transformer.forward_cl(geo)
+        for i in range(self.config.num_ca_layer_coarse):
+            img_proxy = self.p2i_ca_layers[i].rows(img_proxy, pt_proxy, B, T, Q)
+            pt_proxy = self.i2p_ca_layers[i].rows(pt_proxy, img_proxy, B, Q, T)
+            img_proxy = self.img_sa_layers[i].rows(img_proxy, None, B, T, T)
+            pt_proxy = self.pt_sa_layers[i].rows(pt_proxy, None, B, Q, Q)
+        return dict(geo=geo, B=B, T=T, Q=Q, pc=pc, f2=f2, f1=f1, f0=f0, img_proxy=img_proxy, pt_proxy=pt_proxy,
+                    node2proxy=n2p, node2proxy_global=n2p_global, pt_feat=pt_feat, node_feat=node_feat)
+
+    @staticmethod
+    def publish(data_batch, cl):
+        """Write the reference's batch-dict keys (IMGPCEncoder.py:132-162) as reference-shaped views."""
+        B = cl["B"]
+        nchw = lambda f: f.permute(0, 3, 1, 2)
+        data_batch['pc_i'] = cl["pc"]
+        data_batch['img_feat_2'], data_batch['img_feat_1'], data_batch['img_feat_0'] = nchw(cl["f2"]), nchw(cl["f1"]), nchw(cl["f0"])
+        data_batch['node2proxy'] = cl["node2proxy"]
+        data_batch['pt_feat'] = bcl_from_rows(cl["pt_feat"], B)
+        data_batch['node_feat'] = bcl_from_rows(cl["node_feat"], B)
+        data_batch['img_proxy'] = cl["img_proxy"].view(B, cl["T"], -1)
+        data_batch['pt_proxy'] = cl["pt_proxy"].view(B, cl["Q"], -1)
+        data_batch['pc'] = cl["pc"]
+
+    def forward(self, data_batch):
+        cl = self.forward_cl(data_batch)
+        self.publish(data_batch, cl)
+        data_batch['_cmr'] = cl
+        return 0

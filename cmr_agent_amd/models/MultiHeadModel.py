@@ -1,0 +1,121 @@
+"""Stage-1 "geo model": encoder/decoder + overlap head + geometric-feature head.  API /
+state_dict / batch-dict mirror of the reference's models/MultiHeadModel.py (OverlapDetectionHead
+:24-109, GeometricDistanceHead :112-272, MultiHeadModel :275-353).
+
+`forward(data_batch)` returns 0 and mutates the dict like the reference.  All published tensors
+have the reference's shapes; feature maps are views of channels-last storage.  The row-layout
+buffers the agent loop consumes are kept under data_batch['_cmr'].
+
+Losses (focal / circle, MultiHeadModel.py:49-50,141-178) are training-side; in this inference
+build `loss` entries are only produced by cmr_agent_amd.models.losses when asked for."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import _pack
+from ._pack import Planned
+from .ImageResNet import ResidualBlock
+from .IMGPCEnDecoder import IMGPCEnDecoder
+from .PointNN import ConvBNReLURes1D, bcl_from_rows
+
+HEAD_SLOPE = 0.2
+
+
+class _Head(Planned):
+    """Shared trunk of the two heads: gather node->point, 3 x ConvBNReLURes1D on points, 2 x
+    ResidualBlock on pixels, then a two-layer 1x1 head on each side."""
+
+    def __init__(self, config, pc_out, img_out, pc_name, img_name, pc_mid, img_mid):
+        super().__init__()
+        self.config = config
+        f = config.embed_dim
+        self.point_fuse_convs = nn.ModuleList([ConvBNReLURes1D(2 * f, f)] +
+                                              [ConvBNReLURes1D(f, f) for _ in range(config.pt_head_res_num - 1)])
+        setattr(self, pc_name, nn.Sequential(nn.Conv1d(f, pc_mid, kernel_size=1, stride=1, padding=0),
+                                             nn.LeakyReLU(HEAD_SLOPE, inplace=True),
+                                             nn.Conv1d(pc_mid, pc_out, kernel_size=1, stride=1, padding=0)))
+        self.img_res_convs = nn.ModuleList([ResidualBlock(f, f) for _ in range(config.img_fuse_res_num)])
+        setattr(self, img_name, nn.Sequential(nn.Conv2d(f, img_mid, 1, 1, 0), nn.LeakyReLU(HEAD_SLOPE, inplace=True),
+                                              nn.Conv2d(img_mid, img_out, 1, 1, 0)))
+        self._pc_name, self._img_name = pc_name, img_name
+
+    def _build_plan(self):
+        pc, im = getattr(self, self._pc_name), getattr(self, self._img_name)
+        return dict(pc0=_pack.lin(pc[0]), pc2=_pack.lin(pc[2]), im0=_pack.lin(im[0]), im2=_pack.lin(im[2]))
+
+    def trunk_cl(self, cl):
+        """-> (point rows [B*N, pc_out], pixel rows [B*h*w, img_out])"""
+        self._require_eval()
+        p = self.plan()
+        geo = cl["geo"]
+        x = self.point_fuse_convs[0].rows(cl["pt_feat"], x2=cl["fused_node_feat"], idx2=geo.gidx)
+        for layer in list(self.point_fuse_convs)[1:]:
+            x = layer.rows(x)
+        pts = ops.linear(ops.linear(x, *p["pc0"], act=ops.ACT_LRELU, act_param=HEAD_SLOPE), *p["pc2"])
+        y = cl["fused_img_feat"]
+        for layer in self.img_res_convs:
+            y = layer.forward_cl(y)
+        B, h, w, f = y.shape
+        pix = ops.linear(ops.linear(y.view(B * h * w, f), *p["im0"], act=ops.ACT_LRELU, act_param=HEAD_SLOPE), *p["im2"])
+        return pts, pix
+
+
+class OverlapDetectionHead(_Head):
+    def __init__(self, config):
+        super().__init__(config, 2, 2, "pc_overlap_head", "img_overlap_head", 32, 32)
+
+    def forward_cl(self, cl):
+        cl["pc_overlap_logits"], cl["img_overlap_logits"] = self.trunk_cl(cl)
+        return cl
+
+
+class GeometricDistanceHead(_Head):
+    def __init__(self, config):
+        f = config.embed_dim
+        super().__init__(config, f, f, "pc_geo_head", "img_geo_head", f, f)
+        self.dist_thres, self.pos_margin, self.neg_margin, self.lambda_geo = 1, 0.1, 1.4, 1
+
+    def forward_cl(self, cl):
+        pts, pix = self.trunk_cl(cl)
+        cl["pc_geo_feat"] = ops.l2norm64(pts)                       # F.normalize(dim=1), :233
+        cl["img_geo_feat"] = ops.l2norm64(pix).view(cl["B"], cl["h"], cl["w"], -1)
+        return cl
+
+
+class MultiHeadModel(Planned):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.encoder_decoder = IMGPCEnDecoder(config)
+        self.overlap_head = OverlapDetectionHead(config)
+        self.geo_head = GeometricDistanceHead(config)
+
+    def _build_plan(self):
+        return {}
+
+    def forward_cl(self, data_batch):
+        cl = self.encoder_decoder.forward_cl(data_batch)
+        self.overlap_head.forward_cl(cl)
+        self.geo_head.forward_cl(cl)
+        prob, lo, hi = ops.softmax2(cl["pc_overlap_logits"], 0.5, 0.8)       # :330-335
+        cl["pc_prob"], cl["pc_overlap_u8"], cl["pc_overlap_hi_u8"] = prob, lo, hi
+        cl["img_prob"], _, _ = ops.softmax2(cl["img_overlap_logits"], 0.5, 0.8)
+        return cl
+
+    def forward(self, data_batch):
+        cl = self.forward_cl(data_batch)
+        B, N, h, w = cl["B"], cl["geo"].N, cl["h"], cl["w"]
+        IMGPCEnDecoder.publish(data_batch, cl)
+        data_batch['loss'] = 0.
+        data_batch['pc_overlap_logits'] = bcl_from_rows(cl["pc_overlap_logits"], B)
+        data_batch['img_overlap_logits'] = bcl_from_rows(cl["img_overlap_logits"], B)
+        data_batch['pc_geo_feat'] = bcl_from_rows(cl["pc_geo_feat"], B)
+        data_batch['img_geo_feat'] = cl["img_geo_feat"].permute(0, 3, 1, 2)
+        data_batch['pc_overlap_pred'] = cl["pc_overlap_u8"].view(B, N).view(torch.bool)
+        data_batch['pc_overlap_pred_standby'] = cl["pc_overlap_hi_u8"].view(B, N).view(torch.bool)
+        data_batch['pc_is_in_cam_scores'] = cl["pc_prob"].view(B, N)
+        data_batch['img_overlap_pred'] = cl["img_prob"].view(B, h, w)            # reference: view(B, 40, 128), :340
+        data_batch['inlier_mask_in_cam_i'] = data_batch['pc_overlap_pred_standby']
+        data_batch['matrix_accumulated'] = torch.eye(4, device=cl["pc"].device).unsqueeze(0)
+        data_batch['_cmr'] = cl
+        return 0

@@ -1,0 +1,107 @@
+"""One-time weight preparation for the HIP kernels (not on the timed path): inference-mode
+BatchNorm folding, repacking into the kernels' operand layouts and K padding to float4.
+
+Every module of cmr_agent_amd.models keeps the reference's parameters (same state_dict keys)
+in ordinary torch containers and derives a cached "plan" of packed device buffers from them;
+the plan is dropped whenever parameters may have changed (load_state_dict / .to() / train())."""
+import torch
+import torch.nn as nn
+
+
+def bn_scale_shift(bn):
+    scale = bn.weight.detach() / torch.sqrt(bn.running_var.detach() + bn.eps)
+    shift = bn.bias.detach() - bn.running_mean.detach() * scale
+    return scale, shift
+
+
+def folded(conv, bn=None):
+    """(weight, bias) of `conv` with an optional inference-mode BatchNorm folded in."""
+    w = conv.weight.detach()
+    b = conv.bias.detach() if conv.bias is not None else torch.zeros(w.shape[0], dtype=w.dtype, device=w.device)
+    if bn is not None:
+        s, t = bn_scale_shift(bn)
+        w = w * s.view(-1, *([1] * (w.dim() - 1)))
+        b = b * s + t
+    return w, b
+
+
+def pad_k(w2d, mult=4):
+    """[n_out, k] -> contiguous [n_out, ceil(k/mult)*mult] (zero padded columns)."""
+    n, k = w2d.shape
+    kp = (k + mult - 1) // mult * mult
+    if kp == k:
+        return w2d.contiguous()
+    out = torch.zeros((n, kp), dtype=w2d.dtype, device=w2d.device)
+    out[:, :k] = w2d
+    return out
+
+
+def pad_rows(w2d, b, mult=4):
+    """pad the OUTPUT dim of a layer feeding a padded-K layer (zero rows / zero bias)."""
+    n, k = w2d.shape
+    npad = (n + mult - 1) // mult * mult
+    if npad == n:
+        return w2d.contiguous(), b.contiguous()
+    w = torch.zeros((npad, k), dtype=w2d.dtype, device=w2d.device)
+    w[:n] = w2d
+    bb = torch.zeros((npad,), dtype=b.dtype, device=b.device)
+    bb[:n] = b
+    return w, bb
+
+
+def lin(layer, bn=None):
+    """Linear / Conv1d(k=1) / Conv2d(k=1) -> (W [n_out, k_pad4], bias [n_out])."""
+    w, b = folded(layer, bn)
+    return pad_k(w.reshape(w.shape[0], -1)), b.contiguous()
+
+
+def conv9(conv, bn=None):
+    """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout])."""
+    w, b = folded(conv, bn)
+    co, ci = w.shape[0], w.shape[1]
+    return w.permute(2, 3, 0, 1).reshape(9, co, ci).contiguous(), b.contiguous()
+
+
+class Planned(nn.Module):
+    """Base class: lazily built, invalidated plan of packed weights."""
+
+    def __init__(self):
+        super().__init__()
+        self._plan = None
+
+    def _build_plan(self):
+        raise NotImplementedError
+
+    def plan(self):
+        if self._plan is None:
+            with torch.no_grad():
+                self._plan = self._build_plan()
+        return self._plan
+
+    def invalidate(self):
+        for m in self.modules():
+            if isinstance(m, Planned):
+                m._plan = None
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate()
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.invalidate()
+        return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        self.invalidate()
+        return super().train(mode)
+
+    def _require_eval(self):
+        if self.training:
+            raise NotImplementedError(
+                "%s: the HIP path implements inference (eval-mode BatchNorm / no dropout); training-mode forward "
+                "(batch statistics, dropout, backward kernels) is SURVEY.md 8(f1) and not built yet -- call .eval()"
+                % type(self).__name__)
+
+
+def device_of(module):
+    return next(module.parameters()).device

@@ -1,0 +1,97 @@
+"""Pre-LN transformer block shared by the image tower (ImageViT.py:61-158), the point tower
+(PointViT.py:96-183) and the coarse cross-attention matcher (IMGPCEncoder.py:14-102) -- the
+reference carries three copies of the same code.  Tokens are rows [B*T, 64]."""
+import torch.nn as nn
+
+from .. import ops
+from . import _pack
+from ._pack import Planned
+
+
+class Attention(Planned):
+    def __init__(self, config):
+        super().__init__()
+        self.num_attention_heads = config.num_head
+        self.attention_head_size = int(config.embed_dim / self.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        if (self.num_attention_heads, self.attention_head_size) != (8, 8):
+            raise NotImplementedError("the attention kernel is instantiated for 8 heads x 8 dims")
+        self.query = nn.Linear(config.embed_dim, self.all_head_size)
+        self.key = nn.Linear(config.embed_dim, self.all_head_size)
+        self.value = nn.Linear(config.embed_dim, self.all_head_size)
+        self.out = nn.Linear(config.embed_dim, config.embed_dim)
+        self.attn_dropout = nn.Dropout(config.attention_dropout)
+        self.proj_dropout = nn.Dropout(config.attention_dropout)
+
+    def _build_plan(self):
+        import torch
+        wq, bq = _pack.lin(self.query)
+        wk, bk = _pack.lin(self.key)
+        wv, bv = _pack.lin(self.value)
+        return dict(q=(wq, bq), kv=(torch.cat([wk, wv], 0).contiguous(), torch.cat([bk, bv], 0).contiguous()),
+                    qkv=(torch.cat([wq, wk, wv], 0).contiguous(), torch.cat([bq, bk, bv], 0).contiguous()),
+                    out=_pack.lin(self.out))
+
+    def rows(self, xn, yn, B, tx, ty, residual):
+        """out-projection(softmax-attention(xn, yn)) + residual; yn is None for self-attention."""
+        p = self.plan()
+        if yn is None:
+            qkv = ops.linear(xn, *p["qkv"])
+            ctx = ops.mha(qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192], B, tx, tx)
+        else:
+            q = ops.linear(xn, *p["q"])
+            kv = ops.linear(yn, *p["kv"])
+            ctx = ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, tx, ty)
+        return ops.linear(ctx, *p["out"], res=residual)
+
+
+class Mlp(Planned):
+    def __init__(self, config):
+        super().__init__()
+        self.fc1 = nn.Linear(config.embed_dim, config.mlp_dim)
+        self.fc2 = nn.Linear(config.mlp_dim, config.embed_dim)
+        self.dropout = nn.Dropout(config.mlp_dropout)
+        nn.init.xavier_uniform_(self.fc1.weight)
+        nn.init.xavier_uniform_(self.fc2.weight)
+        nn.init.normal_(self.fc1.bias, std=1e-6)
+        nn.init.normal_(self.fc2.bias, std=1e-6)
+
+    def _build_plan(self):
+        return dict(fc1=_pack.lin(self.fc1), fc2=_pack.lin(self.fc2))
+
+    def rows(self, xn, residual):
+        p = self.plan()
+        return ops.linear(ops.linear(xn, *p["fc1"], act=ops.ACT_GELU), *p["fc2"], res=residual)
+
+
+class Block(Planned):
+    """forward(x) is the self-attention block, forward(x, y) the cross block in which x and y
+    pass through the SAME attention_norm (IMGPCEncoder.py:93-94)."""
+    LN_EPS = 1e-6
+
+    def __init__(self, config):
+        super().__init__()
+        self.attention_norm = nn.LayerNorm(config.embed_dim, eps=self.LN_EPS)
+        self.ffn_norm = nn.LayerNorm(config.embed_dim, eps=self.LN_EPS)
+        self.ffn = Mlp(config)
+        self.attn = Attention(config)
+
+    def _build_plan(self):
+        g = lambda ln: (ln.weight.detach().contiguous(), ln.bias.detach().contiguous())
+        return dict(n1=g(self.attention_norm), n2=g(self.ffn_norm))
+
+    def rows(self, x, y, B, tx, ty):
+        self._require_eval()
+        p = self.plan()
+        xn = ops.layernorm64(x, *p["n1"], self.LN_EPS)
+        yn = None if (y is None or y is x) else ops.layernorm64(y, *p["n1"], self.LN_EPS)
+        x = self.attn.rows(xn, yn, B, tx, ty, residual=x)
+        return self.ffn.rows(ops.layernorm64(x, *p["n2"], self.LN_EPS), residual=x)
+
+    def forward(self, x, y=None):
+        B, tx, c = x.shape
+        xr = x.contiguous().view(B * tx, c)
+        if y is None or y is x:
+            return self.rows(xr, None, B, tx, tx).view(B, tx, c)
+        ty = y.shape[1]
+        return self.rows(xr, y.contiguous().view(B * ty, c), B, tx, ty).view(B, tx, c)

@@ -144,13 +144,26 @@ def la_apply(qf, kvsum, B, L, S, eps, out=None):
     return out
 
 
-def planar_to_rows4(x):
-    """[B,C<=4,N] -> [B*N,4] (zero padded)."""
+def planar_to_rows(x, cpad=4):
+    """contiguous [B,C,N] -> [B*N,cpad] (zero padded), cpad in {4, 8}."""
     B, C, N = x.shape
-    if not x.is_contiguous():
-        x = x.contiguous()
-    out = torch.empty((B * N, 4), dtype=f32, device=x.device)
-    _lib.call("cmr_planar_to_rows4_f32", _p(x), _p(out), B, C, N, _stream())
+    if not x.is_contiguous() or x.dtype != f32:
+        raise ValueError("planar_to_rows expects a contiguous float32 [B,C,N] tensor")
+    out = torch.empty((B * N, cpad), dtype=f32, device=x.device)
+    _lib.call("cmr_planar_to_rows_f32", _p(x), _p(out), B, C, N, cpad, _stream())
+    return out
+
+
+def planar_to_rows4(x):
+    return planar_to_rows(x, 4)
+
+
+def concat_rows(x1, x2, idx2=None, div2=1):
+    _rows(x1), _rows(x2)
+    rows = x1.shape[0]
+    out = torch.empty((rows, x1.shape[1] + x2.shape[1]), dtype=f32, device=x1.device)
+    _lib.call("cmr_concat_rows_f32", _p(x1), _ld(x1), x1.shape[1], _p(x2), _ld(x2), x2.shape[1], _p(_i32(idx2)),
+              int(div2), _p(out), rows, _stream())
     return out
 
 

@@ -91,7 +91,12 @@ int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* ms
 
 /* ---- point-cloud ops ----------------------------------------------------------------------- */
 
-int cmr_planar_to_rows4_f32(const float* x, float* y, int B, int C, int N, hipStream_t stream);
+/* planar [B,C,N] (the reference's point layout) -> rows [B*N, Cpad], Cpad in {4, 8}, zero padded. */
+int cmr_planar_to_rows_f32(const float* x, float* y, int B, int C, int N, int Cpad, hipStream_t stream);
+/* out[r] = [x1[r] | x2[map(r)]]: a materialised torch.cat for the one consumer that needs it as a
+ * residual (CMRAgent.py:97-99 feeding the identity shortcut of state_3d_embed[3]). */
+int cmr_concat_rows_f32(const float* x1, int64_t ld1, int C1, const float* x2, int64_t ld2, int C2, const int32_t* idx2,
+                        int64_t div2, float* out, int64_t rows, hipStream_t stream);
 int cmr_index_to_global_i32(const int64_t* idx, int32_t* out, int B, int N, int M, hipStream_t stream);
 
 /* CSR of the points owned by each node (replaces the expanded-index torch_scatter calls,

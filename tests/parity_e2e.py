@@ -1,0 +1,120 @@
+"""End-to-end parity helper (used by tests/test_e2e_gpu.py and __graft_entry__.smoke()):
+one registration iteration (Test_Agent.py:150-170 loop body) through the HIP product vs the CPU
+oracle and vs the committed golden fixture generated from the reference.
+
+Stated tolerances (fp32 GPU vs fp32 CPU): unit-norm geometric features and
+probabilities atol 2e-3; other features / logits atol 2e-3 * max|ref|; discrete outputs (node2proxy,
+overlap mask, actions) must agree except where the reference itself is within rounding of a tie."""
+import json
+import os
+
+import torch
+
+import cases as C
+import golden_util as G
+
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+
+
+def build_models(cfg, device="cuda"):
+    from cmr_agent_amd.models import CMRAgent, MultiHeadModel
+    geo_sd, agent_sd = C.e2e_state_dicts(SPECS)
+    geo, agent = MultiHeadModel(cfg), CMRAgent(cfg)
+    # position_embeddings is image-size specific and skipped by the fill (strict=False for that key only)
+    missing, unexpected = geo.load_state_dict(geo_sd, strict=False)
+    assert not unexpected and all(k.endswith(("position_embeddings", "num_batches_tracked")) for k in missing), missing
+    missing, unexpected = agent.load_state_dict(agent_sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), missing
+    return geo.to(device).eval(), agent.to(device).eval(), geo_sd, agent_sd
+
+
+def run_product(case, geo, agent, batch, cfg, device="cuda"):
+    from cmr_agent_amd.environment import environment as env
+    data = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    with torch.no_grad():
+        geo(data)
+        named = {k: data[k] for k in C.GEO_KEYS}
+        pose, target = env.init(data)
+        target = env.to_disentangled(target, data['pc'])
+        for s in range(cfg.action_num):
+            s2, s3 = env.observation_from_a_pose(data, pose)
+            r, t, v = agent(s2, s3)
+            ar, at = agent.action_from_logits(r, t, deterministic=True)
+            pose = env.step(ar, at, pose, cfg)
+            if s == 0:
+                named["step0/state_2d"], named["step0/state_3d"] = s2, s3
+            for k, val in (("r_logits", r), ("t_logits", t), ("value", v), ("action_r", ar), ("action_t", at),
+                           ("pose", pose.clone())):
+                named["step%d/%s" % (s, k)] = val
+        named["final_pose"] = pose
+        named["pose_target_disentangled"] = target
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu() for k, v in named.items()}
+
+
+UNIT = ("pc_geo_feat", "img_geo_feat", "pc_is_in_cam_scores", "img_overlap_pred")
+DISCRETE = ("node2proxy", "pc_overlap_pred")
+
+
+def compare(named, ref, verbose=False, atol=2e-3):
+    """named / ref: dict name -> cpu tensor.  Returns list of error strings."""
+    errs = []
+    for k, r in ref.items():
+        if k not in named:
+            continue
+        g = named[k]
+        if tuple(g.shape) != tuple(r.shape):
+            errs.append("%s: shape %s vs %s" % (k, tuple(g.shape), tuple(r.shape)))
+            continue
+        if r.dtype in (torch.bool, torch.int64, torch.int32, torch.uint8):
+            frac = float((g.long() == r.long()).float().mean())
+            need = 0.999 if k == "pc_overlap_pred" else 1.0
+            if verbose:
+                print("  %-28s equal fraction %.6f" % (k, frac))
+            if frac < need:
+                errs.append("%s: only %.6f equal" % (k, frac))
+            continue
+        scale = 1.0 if (k in UNIT or k.startswith("step0/state")) else max(float(r.abs().max()), 1.0)
+        d = (g.double() - r.double()).abs()
+        if k.startswith("step0/state"):
+            bad = float((d > atol).float().mean())       # a boundary point may land in the next pixel
+            if verbose:
+                print("  %-28s frac(|d|>%.0e) %.2e" % (k, atol, bad))
+            if bad > 2e-3:
+                errs.append("%s: %.3e of entries differ" % (k, bad))
+            continue
+        err = float(d.max())
+        if verbose:
+            print("  %-28s max|d| %.3e (tol %.3e)" % (k, err, atol * scale))
+        if err > atol * scale:
+            errs.append("%s: max|d| %.3e > %.3e" % (k, err, atol * scale))
+    return errs
+
+
+def run_case(case, check_golden=True, verbose=False):
+    cfg = C.e2e_config(case)
+    geo, agent, geo_sd, agent_sd = build_models(cfg)
+    batch = C.e2e_batch(case)
+    got = run_product(case, geo, agent, batch, cfg)
+    ref = C.e2e_oracle(case, geo_sd, agent_sd, batch)
+    if verbose:
+        print("product vs oracle (%s)" % case)
+    errs = compare(got, ref, verbose)
+    assert not errs, "HIP path vs oracle:\n  " + "\n  ".join(errs)
+    if check_golden:
+        fx = G.load_case(case)
+        gerrs = []
+        for k, t in got.items():
+            if k not in fx:
+                continue
+            if fx[k]["sample"].dtype.kind in "iub":
+                e = G.compare(k, t, fx[k], 0, 0, 0.999 if k == "pc_overlap_pred" else 1.0)
+            elif k.startswith("step0/state"):
+                continue
+            else:
+                scale = 1.0 if k in UNIT else max(float(abs(fx[k]["sample"]).max()), 1.0)
+                e = G.compare(k, t, fx[k], 2e-3 * scale, 0)
+            if e:
+                gerrs.append(e)
+        assert not gerrs, "HIP path vs golden fixture:\n  " + "\n  ".join(gerrs)
+    return got

@@ -1,0 +1,92 @@
+"""GPU tier, module level: the product's nn.Modules (reference API, reference-layout tensors in
+and out) against the golden fixtures generated from the reference's own modules, plus the
+pointnet_util device ops (index-valued results must be exact)."""
+import json
+import os
+
+import pytest
+import torch
+
+import cases as C
+import golden_util as G
+from cmr_agent_amd.utils import hashfill
+
+pytestmark = pytest.mark.gpu
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+DEV = "cuda"
+
+
+def _module(name):
+    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.models import ImageResNet as R, PointNN as P, LinearAttention as LA, _vit
+    cfg = KittiConfiguration(device="cpu")
+    table = {
+        "resblock_3_64_s1": lambda: R.ResidualBlock(3, 64, 1), "resblock_64_64_s1": lambda: R.ResidualBlock(64, 64, 1),
+        "resblock_64_64_s2": lambda: R.ResidualBlock(64, 64, 2), "resblock_128_64_s1": lambda: R.ResidualBlock(128, 64, 1),
+        "mini_pointnet_3_64": lambda: P.MiniPointNet(3, 64), "mini_pointnet_128_64": lambda: P.MiniPointNet(128, 64),
+        "cbr1d_128_64": lambda: P.ConvBNReLURes1D(128, 64), "cbr1d_64_64": lambda: P.ConvBNReLURes1D(64, 64),
+        "cbr1d_5_64": lambda: P.ConvBNReLURes1D(5, 64), "group_point_transformer": lambda: P.GroupPointTransformer(64, 64),
+        "knn_point_transformer": lambda: P.KnnPointTransformer(64, 64, 16), "vit_self_block": lambda: _vit.Block(cfg),
+        "vit_cross_block": lambda: _vit.Block(cfg), "linear_attention": lambda: LA.LinearAttention(64, 8),
+    }
+    m = table[name]()
+    sd = hashfill.make_state_dict(SPECS[name], name + "/")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    return m.to(DEV).eval()
+
+
+CALLS = {
+    "group_point_transformer": lambda m, i: m(i["xyz"], i["feat"], i["node"], i["node_feat"], i["idx"]),
+    "knn_point_transformer": lambda m, i: m(i["xyz"], i["feat"]),
+    "vit_cross_block": lambda m, i: m(i["x"], i["y"]),
+    "linear_attention": lambda m, i: m(i["x"], i["y"]),
+}
+
+
+@pytest.mark.parametrize("name", ["resblock_3_64_s1", "resblock_64_64_s1", "resblock_64_64_s2", "resblock_128_64_s1",
+                                  "mini_pointnet_3_64", "mini_pointnet_128_64", "cbr1d_128_64", "cbr1d_64_64", "cbr1d_5_64",
+                                  "group_point_transformer", "knn_point_transformer", "vit_self_block", "vit_cross_block",
+                                  "linear_attention"])
+def test_module_vs_golden(name):
+    m = _module(name)
+    inp = {k: v.to(DEV) for k, v in C.OP_CASES[name]["inputs"]().items()}
+    with torch.no_grad():
+        y = CALLS.get(name, lambda mod, i: mod(i["x"]))(m, inp)
+    # per-op tolerance: rtol 1e-4, atol 1e-5 on O(1) activations
+    G.assert_case(name, {"y": y}, atol=2e-5, rtol=1e-4, only={"y"})
+
+
+def test_pointnet_util_ops_vs_golden():
+    from cmr_agent_amd.models import pointnet_util as U
+    i = {k: v.to(DEV) for k, v in C.OP_CASES["pointnet_util"]["inputs"]().items()}
+    xyz, pts = i["xyz"], i["points"]
+    fps = U.farthest_point_sample(xyz, 64, i["start"])
+    new_xyz = U.index_points(xyz, fps)
+    ball = U.query_ball_point(0.4, 16, xyz, new_xyz)
+    nx, g = U.sample_and_group(32, 0.4, 16, xyz, pts, start_idx=i["start"])
+    out = dict(fps=fps, new_xyz=new_xyz, ball=ball, sqdist=U.square_distance(new_xyz, xyz), sg_xyz=nx, sg_points=g,
+               gathered=U.index_points(pts, ball))
+    G.assert_case("pointnet_util", out, atol=0, rtol=0)          # bit exact, indices and floats alike
+
+
+def test_posenc_table_vs_golden():
+    from cmr_agent_amd.models.IMGPCEnDecoder import position_encoding_sine_2d
+    x = C.OP_CASES["posenc_sine_2d"]["inputs"]()["x"]
+    y = x + position_encoding_sine_2d(64, 24, 32).permute(2, 0, 1).unsqueeze(0)
+    G.assert_case("posenc_sine_2d", {"y": y}, atol=0, rtol=0)
+
+
+def test_dataset_side_ops_on_device():
+    """FPS of the nodes + nearest-node assignment (dataset/KittiDataset.py:107-126, 359-367) as device ops:
+    fp32 on device vs the float64 fixture -> identical indices on this well-separated cloud."""
+    from cmr_agent_amd import ops
+    pc = torch.from_numpy(hashfill.uniform("case/ds/pc", (3, 3000), -30, 30)).float()
+    sub4 = ops.planar_to_rows(pc[:, :1200].unsqueeze(0).contiguous().to(DEV), 4)
+    idx = ops.fps(sub4, torch.tensor([2], device=DEV), 1, 1200, 100)
+    fx = G.load_case("dataset_ops")
+    assert (idx.cpu().numpy()[0] == fx["fps_idx"]["sample"]).mean() == 1.0
+    nodes4 = ops.gather_rows(sub4, idx.view(-1).int())
+    pc4 = ops.planar_to_rows(pc.unsqueeze(0).contiguous().to(DEV), 4)
+    _, local = ops.nearest(pc4, nodes4, 1, 3000, 100)
+    assert (local.cpu().numpy()[0] == fx["pt2node"]["sample"]).mean() > 0.999
