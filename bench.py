@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: registration iterations / s on KITTI-shaped synthetic input.
+
+One STEP = the loop body of the reference's Test_Agent.py:150-170 for one batch: geo model forward
+once + action_num x [observation_from_a_pose -> CMRAgent -> argmax action -> env.step], final pose
+copied to the host.  Workload = BASELINE.json configs[1]: KittiConfig, batch 8 per GPU, 16384
+points, 352x1216 image, 10 agent steps, fp32.  Inputs are resident in HBM before the timed region.
+
+  python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (stride-1 3x3 NHWC convolution on
+fp32 MFMA): algorithmic FLOPs of its launches / their HIP-event time inside the timed region, against
+the 157.3 TFLOP/s fp32 matrix peak.  `cpu_baseline` = the oracle (CPU restatement pinned to the
+reference) on a bounded sample of the same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cmr_agent_amd import ops  # noqa: E402
+from cmr_agent_amd.config import KittiConfiguration  # noqa: E402
+from cmr_agent_amd.environment import environment as env  # noqa: E402
+from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
+from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
+
+WORKLOAD = dict(B=8, N=16384, H=352, W=1216, M=1280, steps=10)
+GEO_TAG, AGENT_TAG = "geo4/", "agent/"
+FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def hip_fps(dev):
+    def fn(pts_3n, k, init_idx):
+        x = torch.from_numpy(np.ascontiguousarray(pts_3n, dtype=np.float32)).unsqueeze(0).to(dev)
+        rows = ops.planar_to_rows(x, 4)
+        idx = ops.fps(rows, torch.tensor([init_idx], device=dev), 1, x.shape[2], k)
+        i = idx[0].cpu().numpy()
+        return pts_3n[:, i], i
+    return fn
+
+
+def hip_nearest(dev):
+    def fn(pc_3n, node_3m):
+        p = ops.planar_to_rows(torch.from_numpy(np.ascontiguousarray(pc_3n, dtype=np.float32)).unsqueeze(0).to(dev), 4)
+        n = ops.planar_to_rows(torch.from_numpy(np.ascontiguousarray(node_3m, dtype=np.float32)).unsqueeze(0).to(dev), 4)
+        _, local = ops.nearest(p, n, 1, pc_3n.shape[1], node_3m.shape[1], want_global=False)
+        return local[0].cpu().numpy()
+    return fn
+
+
+def load_models(cfg, dev):
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
+    geo, agent = MultiHeadModel(cfg), CMRAgent(cfg)
+    geo.load_state_dict(hashfill.make_state_dict(spec["geo"], GEO_TAG), strict=False)
+    agent.load_state_dict(hashfill.make_state_dict(spec["agent"], AGENT_TAG), strict=False)
+    return geo.to(dev).eval(), agent.to(dev).eval(), spec
+
+
+def registration_step(geo, agent, cfg, batch):
+    """Test_Agent.py:150-187 for one batch (inputs already on the device)."""
+    data = dict(batch)
+    geo(data)
+    pose, target = env.init(data)
+    target = env.to_disentangled(target, data['pc'])
+    for _ in range(cfg.action_num):
+        s2, s3 = env.observation_from_a_pose(data, pose)
+        r, t, _ = agent(s2, s3)
+        ar, at = agent.action_from_logits(r, t, deterministic=True)
+        pose = env.step(ar, at, pose, cfg)
+    return pose.cpu()                                   # final pose D2H (Test_Agent.py:185)
+
+
+class ConvTimer:
+    """HIP-event timing of every stride-1 conv3x3 launch on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []
+        self._orig = ops.conv3x3
+
+    def __enter__(self):
+        def timed(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None):
+            if stride != 1:
+                return self._orig(x, w9, bias, cout, stride, slope, res, post, out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = self._orig(x, w9, bias, cout, stride, slope, res, post, out)
+            e1.record()
+            B, H, W, cin = x.shape
+            flops = 2.0 * 9 * cin * cout * B * H * W
+            # algorithmic bytes: input once, output once, residual/table once, weights once
+            nbytes = 4.0 * (B * H * W * (cin + cout * (2 if res is not None else 1)) + 9 * cin * cout)
+            self.records.append((e0, e1, flops, nbytes))
+            return y
+        ops.conv3x3 = timed
+        return self
+
+    def __exit__(self, *a):
+        ops.conv3x3 = self._orig
+
+    def summary(self):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+        fl = sum(r[2] for r in self.records)
+        by = sum(r[3] for r in self.records)
+        return dict(launches=len(self.records), ms=ms, flops=fl, bytes=by)
+
+
+def cpu_baseline(spec, budget_s=20.0):
+    """The oracle on ONE sample of the workload shape (B=1), repeated while the budget lasts."""
+    from oracle import cmr_oracle as O
+    w = WORKLOAD
+    cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device="cpu",
+                             action_num=w["steps"])
+    geo_sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
+    agent_sd = hashfill.make_state_dict(spec["agent"], AGENT_TAG)
+    batch = synthetic.make_batch(1, w["N"], w["H"], w["W"], w["M"], O.dataset_fps, O.nearest_node, seed=2023, n_circle=16)
+    n, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            O.registration_iteration(geo_sd, agent_sd, batch, cfg)
+            n += 1
+            if time.perf_counter() - t0 > budget_s or n >= 16:
+                break
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="registration iters/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d x (1 sample: 1 geo forward + %d agent steps, %dx%d image, %d points) through oracle/cmr_oracle.py, "
+                       "torch CPU fp32" % (n, w["steps"], w["H"], w["W"], w["N"]))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    w = WORKLOAD
+    cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
+    geo, agent, spec = load_models(cfg, dev)
+    # the path shards by batch: every rank registers its own B pairs, no data-path collective
+    batch = synthetic.make_batch(w["B"], w["N"], w["H"], w["W"], w["M"], hip_fps(dev), hip_nearest(dev), seed=2023 + rank,
+                                 n_circle=16, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            registration_step(geo, agent, cfg, batch)
+        barrier()
+        with ConvTimer() as ct:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pose = registration_step(geo, agent, cfg, batch)
+            barrier()
+            elapsed = time.perf_counter() - t0
+    assert torch.isfinite(pose).all()
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        conv = ct.summary()
+        achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
+        iters = world * w["B"] * args.steps
+        line = {
+            "metric": "registration iters/sec (KITTI 352x1216 img + 16384 pts, 1 geo forward + 10 agent steps)",
+            "value": iters / elapsed, "unit": "registration iters/s", "per_gpu": iters / elapsed / world,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: KittiConfig, batch 8 per GPU, 16384 pts, 352x1216 image, "
+                                   "10 agent steps, fp32, hash-filled weights", "batch_per_gpu": w["B"],
+                       "parallelism": "batch sharding, no data-path collective"},
+            "agent_steps_per_s": iters * w["steps"] / elapsed,
+            "roofline": {"kernel": "conv3x3_kernel<1,2,32> (NHWC 3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+                         "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches_per_step": conv["launches"] / args.steps,
+                         "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
+                         "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9,
+                         "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
+                         "share_of_step_time": conv["ms"] * 1e-3 / elapsed},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(spec)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

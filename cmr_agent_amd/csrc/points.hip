@@ -20,8 +20,11 @@
 namespace {
 
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
-  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+  // plain operators on purpose: the __f*_rn helpers are header functions compiled with the default
+  // contract(fast) and get fused after inlining; these expressions are under this file's contract(off)
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + yy) + zz;
 }
 
 // ---- layout ---------------------------------------------------------------------------------
