@@ -30,6 +30,7 @@ from cmr_agent_amd.config import KittiConfiguration  # noqa: E402
 from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
+from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
 
 WORKLOAD = dict(B=8, N=16384, H=352, W=1216, M=1280, steps=10)
 GEO_TAG, AGENT_TAG = "geo4/", "agent/"
@@ -115,6 +116,7 @@ def cpu_baseline(spec, budget_s=20.0):
     """The oracle on ONE sample of the workload shape (B=1), repeated while the budget lasts."""
     from oracle import cmr_oracle as O
     w = WORKLOAD
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # past ~32 threads torch's small CPU ops only get slower
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device="cpu",
                              action_num=w["steps"])
     geo_sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
@@ -141,30 +143,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+    ranks = Ranks(backend="nccl", device=dev)          # RCCL: timing barrier / MAX only, no data-path collective
+    rank = ranks.rank
 
     w = WORKLOAD
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
     geo, agent, spec = load_models(cfg, dev)
     # the path shards by batch: every rank registers its own B pairs, no data-path collective
-    batch = synthetic.make_batch(w["B"], w["N"], w["H"], w["W"], w["M"], hip_fps(dev), hip_nearest(dev), seed=2023 + rank,
+    batch = synthetic.make_batch(w["B"], w["N"], w["H"], w["W"], w["M"], hip_fps(dev), hip_nearest(dev),
+                                 seed=ranks.shard_seed(cfg.seed),
                                  n_circle=16, device=dev)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    barrier = ranks.barrier
 
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -177,10 +173,7 @@ def main():
             barrier()
             elapsed = time.perf_counter() - t0
     assert torch.isfinite(pose).all()
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = ranks.max_over_ranks(elapsed)
 
     if rank == 0:
         conv = ct.summary()
@@ -188,7 +181,7 @@ def main():
         iters = world * w["B"] * args.steps
         line = {
             "metric": "registration iters/sec (KITTI 352x1216 img + 16384 pts, 1 geo forward + 10 agent steps)",
-            "value": iters / elapsed, "unit": "registration iters/s", "per_gpu": iters / elapsed / world,
+            "value": ranks.aggregate_rate(w["B"] * args.steps, elapsed), "unit": "registration iters/s", "per_gpu": iters / elapsed / world,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[1]: KittiConfig, batch 8 per GPU, 16384 pts, 352x1216 image, "
@@ -207,9 +200,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ranks.close()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark at the shapes of BASELINE configs[1] (B=8): HIP-event timing of
+single entry points, reported against the fp32 MFMA peak / HBM bandwidth.  Development tool."""
+import argparse
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cmr_agent_amd import ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def bench_conv(B, H, W, cin, cout, stride, reps):
+    x = torch.randn(B, H, W, cin, device=DEV)
+    w = torch.randn(9, cout, cin, device=DEV) / math.sqrt(9 * cin)
+    b = torch.randn(cout, device=DEV)
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = torch.randn(B, ho, wo, cout, device=DEV)
+    out = torch.empty(B, ho, wo, cout, device=DEV)
+    us = timeit(lambda: ops.conv3x3(x, w, b, cout, stride, 0.2, res=res, out=out), reps)
+    fl = 2.0 * 9 * cin * cout * B * ho * wo
+    by = 4.0 * (x.numel() + 2 * out.numel())
+    print("conv3x3 %4dx%-4d %3d->%-3d s%d : %8.1f us  %6.1f TFLOP/s  (%5.2f TB/s algorithmic)" % (
+        H, W, cin, cout, stride, us, fl / us / 1e6, by / us / 1e6))
+
+
+def bench_linear(rows, k1, n_out, k2=0, gather=False, act=0, reps=20):
+    x1 = torch.randn(rows, k1, device=DEV)
+    w = torch.randn(n_out, k1 + k2, device=DEV) / math.sqrt(k1 + k2)
+    b = torch.randn(n_out, device=DEV)
+    x2 = idx = None
+    if k2:
+        m = max(rows // 13, 1)
+        x2 = torch.randn(m if gather else rows, k2, device=DEV)
+        if gather:
+            idx = torch.randint(0, m, (rows,), device=DEV, dtype=torch.int32)
+    out = torch.empty(rows, n_out, device=DEV)
+    us = timeit(lambda: ops.linear(x1, w, b, x2=x2, idx2=idx, act=act, act_param=0.2, out=out), reps)
+    fl = 2.0 * rows * (k1 + k2) * n_out
+    by = 4.0 * rows * (k1 + k2 + n_out)
+    print("linear %7d x (%4d%s) -> %-4d act%d : %8.1f us  %6.1f TFLOP/s  %5.2f TB/s" % (
+        rows, k1, "+%d%s" % (k2, "g" if gather else "") if k2 else "", n_out, act, us, fl / us / 1e6, by / us / 1e6))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="conv,linear")
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    B = 8
+    if "conv" in a.what:
+        for (H, W, ci, co, s) in [(352, 1216, 64, 64, 1), (176, 608, 64, 64, 1), (88, 304, 64, 64, 1), (88, 304, 128, 128, 1),
+                                  (88, 304, 128, 64, 1), (44, 152, 128, 128, 1), (22, 76, 128, 128, 1), (11, 38, 128, 128, 1),
+                                  (352, 1216, 64, 64, 2), (176, 608, 64, 64, 2)]:
+            bench_conv(B, H, W, ci, co, s, a.reps)
+    if "linear" in a.what:
+        N, P4, M, T = 8 * 16384, 8 * 26752, 8 * 1280, 8 * 418
+        for args in [(N, 64, 64), (N, 64, 64, 64, True), (N, 64, 128), (N, 64, 128, 64, True), (N, 128, 64), (N, 4, 64), (N, 8, 8),
+                     (N, 64, 32), (N, 32, 2), (P4, 64, 64), (P4, 64, 128, 64, False), (P4, 128, 64), (M, 64, 64), (M, 64, 192),
+                     (T, 64, 192), (T, 64, 1024), (T, 1024, 64), (T, 4096, 64), (8, 256, 256), (8, 128, 128)]:
+            bench_linear(*args, reps=a.reps)
+
+
+if __name__ == "__main__":
+    main()
