@@ -124,14 +124,16 @@ __global__ void to_disentangled_kernel(float* __restrict__ pose, const float* __
   }
 }
 
-// argmax over the last dim (first index on ties): logits [rows, n] -> int64 [rows]
-__global__ void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int rows, int n) {
+// argmax over the last dim (first index on ties): logits x[o*so + i*si + 0..n) -> int64 out[o*inner + i]
+__global__ void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int outer, int inner, int n,
+                                   int64_t so, int64_t si) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  float best = x[(int64_t)r * n];
+  if (r >= outer * inner) return;
+  const float* p = x + (r / inner) * so + (r % inner) * si;
+  float best = p[0];
   int bi = 0;
   for (int i = 1; i < n; ++i) {
-    const float v = x[(int64_t)r * n + i];
+    const float v = p[i];
     if (v > best) { best = v; bi = i; }
   }
   out[r] = bi;
@@ -208,9 +210,11 @@ extern "C" int cmr_to_disentangled_f32(float* pose, const float* mean4, int B, h
   return cmr_launch_status();
 }
 
-extern "C" int cmr_argmax_rows_f32(const float* x, int64_t* out, int rows, int n, hipStream_t stream) {
-  CMR_REQUIRE(x && out && rows > 0 && n > 0);
-  hipLaunchKernelGGL(argmax_rows_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, x, out, rows, n);
+extern "C" int cmr_argmax_rows_f32(const float* x, int64_t* out, int outer, int inner, int n, int64_t stride_outer,
+                                   int64_t stride_inner, hipStream_t stream) {
+  CMR_REQUIRE(x && out && outer > 0 && inner > 0 && n > 0);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((outer * inner + 63) / 64), dim3(64), 0, stream, x, out, outer, inner, n,
+                     stride_outer, stride_inner);
   return cmr_launch_status();
 }
 

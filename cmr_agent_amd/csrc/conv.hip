@@ -29,7 +29,8 @@ struct ConvArgs {
 };
 
 template <int S, int MT, int KC>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a, const int tiles_x, const int tiles_y,
+                                                      const int ntiles) {
   constexpr int TH = 4 * MT, TW = 32;
   constexpr int HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
   constexpr int LDP = KC + 4;              // floats per halo pixel / weight row in LDS
@@ -44,109 +45,169 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int nco = a.Cout / 64;
-  const int b = blockIdx.z / nco, co0 = (blockIdx.z % nco) * 64;
-  const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
-  const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
   const int nchunk = a.Cin / KC;
-  const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
 
+  struct Tile { int b, co0, oy0, ox0; };
+  auto decode = [&](int t) {
+    Tile r;
+    r.ox0 = (t % tiles_x) * TW; t /= tiles_x;
+    r.oy0 = (t % tiles_y) * TH; t /= tiles_y;
+    r.b = t / nco; r.co0 = (t % nco) * 64;
+    return r;
+  };
+
+  // ---- register-staged prefetch: weight slab of the next tap, halo of the next chunk / tile ----
   f32x4 wr[WL];
-  auto load_slab = [&](int chunk, int tap) {   // weights for (tap, chunk) -> registers
+  auto load_slab = [&](int co0, int chunk, int tap) {
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
       int e = tid + 256 * i;
-      if (WSLAB_F4 % 256 == 0 || e < WSLAB_F4) {
-        int n = e / C4, c = e % C4;
-        wr[i] = *reinterpret_cast<const f32x4*>(a.w + ((int64_t)tap * a.Cout + co0 + n) * a.Cin + chunk * KC + c * 4);
-      }
+      if (WSLAB_F4 % 256 != 0 && e >= WSLAB_F4) e = WSLAB_F4 - 1;
+      const int n = e / C4, c = e % C4;
+      wr[i] = *reinterpret_cast<const f32x4*>(a.w + ((int64_t)tap * a.Cout + co0 + n) * a.Cin + chunk * KC + c * 4);
     }
   };
   auto store_slab = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WL; ++i) {
-      int e = tid + 256 * i;
+      const int e = tid + 256 * i;
       if (WSLAB_F4 % 256 == 0 || e < WSLAB_F4) {
-        int n = e / C4, c = e % C4;
+        const int n = e / C4, c = e % C4;
         *reinterpret_cast<f32x4*>(&wbuf[(buf * 64 + n) * LDP + c * 4]) = wr[i];
       }
     }
   };
-
-  f32x16 acc[MT][2];
+  // All loads of a halo chunk are issued back to back, branch-free (clamped addresses); the zero
+  // padding is applied when the registers are written to LDS.  Thread (px = tid / C4, c = tid % C4)
+  // copies one float4 of every halo row (row addresses differ by a wave-uniform stride); the last
+  // EXC columns of all rows are one extra float4 for the first HR*EXC*C4 threads.
+  constexpr int PXM = 256 / C4;            // halo columns covered by the main pattern (32 or 64)
+  constexpr int EXC = HC - PXM;            // remaining columns (2 for stride 1, 1 for stride 2)
+  static_assert(EXC >= 0 && HR * EXC * C4 <= 256, "halo extra columns must fit one pass");
+  const int hpx = tid / C4, hc = tid % C4;
+  const int epy = tid / (EXC * C4), epx = PXM + (tid % (EXC * C4)) / C4;     // extra-column element
+  const bool ehas = tid < HR * EXC * C4;
+  f32x4 hv[HR + 1];
+  auto load_halo = [&](const Tile& t, int chunk) {
+    const float* xb = a.x + (int64_t)t.b * a.H * a.W * a.Cin + chunk * KC + hc * 4;
+    const int iy0 = t.oy0 * S - 1, ix0 = t.ox0 * S - 1;
+    int ix = ix0 + hpx;
+    ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  // LDS float offset of this lane's A rows (tap (0,0), k-group 0)
-  int abase[MT];
-#pragma unroll
-  for (int m = 0; m < MT; ++m) abase[m] = (((wave * MT + m) * S) * HC + l31 * S) * LDP + 4 * h;
-  const int bbase = l31 * LDP + 4 * h;
-
-  load_slab(0, 0);
-  int cur = 0;
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    __syncthreads();   // every wave is done with the previous chunk's halo
-    for (int e = tid; e < HALO_F4; e += 256) {
-      int p = e / C4, c = e % C4;
-      int py = p / HC, px = p % HC;
-      int iy = iy0 + py, ix = ix0 + px;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-        v = *reinterpret_cast<const f32x4*>(xb + ((int64_t)iy * a.W + ix) * a.Cin + chunk * KC + c * 4);
-      *reinterpret_cast<f32x4*>(&halo[p * LDP + c * 4]) = v;
+    for (int i = 0; i < HR; ++i) {
+      int iy = iy0 + i;
+      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      hv[i] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)iy * a.W + ix) * a.Cin);
     }
-    for (int tap = 0; tap < 9; ++tap) {
-      store_slab(cur);
-      __syncthreads();  // slab `cur` (and on tap 0 the halo) visible; tap-1 compute finished everywhere
-      if (tap < 8) load_slab(chunk, tap + 1);
-      else if (chunk + 1 < nchunk) load_slab(chunk + 1, 0);
-      const int toff = ((tap / 3) * HC + (tap % 3)) * LDP;
-      const float* wb = wbuf + cur * 64 * LDP;
+    int ey = iy0 + (ehas ? epy : 0), ex = ix0 + epx;
+    ey = ey < 0 ? 0 : (ey >= a.H ? a.H - 1 : ey);
+    ex = ex < 0 ? 0 : (ex >= a.W ? a.W - 1 : ex);
+    hv[HR] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)ey * a.W + ex) * a.Cin);
+  };
+  auto store_halo = [&](const Tile& t) {
+    const int iy0 = t.oy0 * S - 1, ix0 = t.ox0 * S - 1;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const bool xin = ix0 + hpx >= 0 && ix0 + hpx < a.W;
 #pragma unroll
-      for (int kg = 0; kg < KC / 8; ++kg) {
-        f32x4 av[MT], bv[2];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) av[m] = *reinterpret_cast<const f32x4*>(&halo[abase[m] + toff + kg * 8]);
-        bv[0] = *reinterpret_cast<const f32x4*>(&wb[bbase + kg * 8]);
-        bv[1] = *reinterpret_cast<const f32x4*>(&wb[bbase + 32 * LDP + kg * 8]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            acc[m][0] = cmr_mfma32(av[m][j], bv[0][j], acc[m][0]);
-            acc[m][1] = cmr_mfma32(av[m][j], bv[1][j], acc[m][1]);
-          }
-      }
-      cur ^= 1;
+    for (int i = 0; i < HR; ++i) {
+      const bool inb = xin && iy0 + i >= 0 && iy0 + i < a.H;
+      *reinterpret_cast<f32x4*>(&halo[(i * HC + hpx) * LDP + hc * 4]) = inb ? hv[i] : zero;
     }
-  }
+    if (ehas) {
+      const bool inb = iy0 + epy >= 0 && iy0 + epy < a.H && ix0 + epx >= 0 && ix0 + epx < a.W;
+      *reinterpret_cast<f32x4*>(&halo[(epy * HC + epx) * LDP + hc * 4]) = inb ? hv[HR] : zero;
+    }
+  };
 
+  // LDS float offset of this lane's pixel rows (tap (0,0), k-group 0) and weight rows
+  int pbase[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) {
-    const int oy = oy0 + wave * MT + m;
-    if (oy >= a.Ho) continue;
+  for (int m = 0; m < MT; ++m) pbase[m] = (((wave * MT + m) * S) * HC + l31 * S) * LDP + 4 * h;
+  const int wbase = l31 * LDP + 4 * h;
+
+  int t_cur = blockIdx.x;
+  if (t_cur >= ntiles) return;
+  Tile cur = decode(t_cur);
+  load_slab(cur.co0, 0, 0);
+  int buf = 0;
+  for (;;) {
+    const int t_nxt = t_cur + gridDim.x;
+    const bool has_next = t_nxt < ntiles;
+    const Tile nxt = decode(has_next ? t_nxt : t_cur);
+
+    // D'[cout][pixel]: weights are the MFMA A operand, pixels the B operand -> a lane owns ONE pixel and
+    // its accumulator registers are 4 x 4 consecutive output channels (float4 epilogue)
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      const int co = co0 + n * 32 + l31;
-      const float bsv = a.bias ? a.bias[co] : 0.f;
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + cmr_mfma_row(r, lane);
-        if (ox < a.Wo) {
-          const int64_t pix = (int64_t)oy * a.Wo + ox;
-          const int64_t o = ((int64_t)b * a.Ho * a.Wo + pix) * a.Cout + co;
-          float v = acc[m][n][r] + bsv;
-          if (a.res) v += a.res[o];
-          v = v > 0.f ? v : v * a.slope;
-          if (a.post) v += a.post[pix * a.Cout + co];
-          a.y[o] = v;
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    for (int chunk = 0; chunk < nchunk; ++chunk) {
+      load_halo(cur, chunk);   // all HR+1 loads in flight at once (the old per-element loop serialised them)
+      __syncthreads();         // every wave is done reading the previous halo
+      store_halo(cur);
+      for (int tap = 0; tap < 9; ++tap) {
+        store_slab(buf);
+        __syncthreads();  // slab `buf` (and on tap 0 the halo) visible; tap-1 compute finished everywhere
+        if (tap < 8) load_slab(cur.co0, chunk, tap + 1);
+        else if (chunk + 1 < nchunk) load_slab(cur.co0, chunk + 1, 0);
+        else if (has_next) load_slab(nxt.co0, 0, 0);
+        const int toff = ((tap / 3) * HC + (tap % 3)) * LDP;
+        const float* wb = wbuf + buf * 64 * LDP;
+#pragma unroll
+        for (int kg = 0; kg < KC / 8; ++kg) {
+          f32x4 pv[MT], wv[2];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) pv[m] = *reinterpret_cast<const f32x4*>(&halo[pbase[m] + toff + kg * 8]);
+          wv[0] = *reinterpret_cast<const f32x4*>(&wb[wbase + kg * 8]);
+          wv[1] = *reinterpret_cast<const f32x4*>(&wb[wbase + 32 * LDP + kg * 8]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+              acc[m][0] = cmr_mfma32(wv[0][j], pv[m][j], acc[m][0]);
+              acc[m][1] = cmr_mfma32(wv[1][j], pv[m][j], acc[m][1]);
+            }
         }
+        buf ^= 1;
       }
     }
+
+    // ---- epilogue: lane = pixel (oy, ox0 + l31); register quad q of tile n = couts n*32 + 8q + 4h .. +3
+    const int ox = cur.ox0 + l31;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oy = cur.oy0 + wave * MT + m;
+      const bool valid = oy < a.Ho && ox < a.Wo;
+      const int64_t pix = (int64_t)(oy < a.Ho ? oy : a.Ho - 1) * a.Wo + (ox < a.Wo ? ox : a.Wo - 1);
+      const int64_t o = ((int64_t)cur.b * a.Ho * a.Wo + pix) * a.Cout + cur.co0 + 4 * h;
+      f32x4 r4[2][4];
+      if (a.res) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r4[n][q] = *reinterpret_cast<const f32x4*>(a.res + o + n * 32 + 8 * q);
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = n * 32 + 8 * q;
+          f32x4 v = {acc[m][n][4 * q], acc[m][n][4 * q + 1], acc[m][n][4 * q + 2], acc[m][n][4 * q + 3]};
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + cur.co0 + 4 * h + c);
+          if (a.res) v += r4[n][q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+          if (a.post) v += *reinterpret_cast<const f32x4*>(a.post + pix * a.Cout + cur.co0 + 4 * h + c);
+          if (valid) *reinterpret_cast<f32x4*>(a.y + o + c) = v;
+        }
+    }
+    if (!has_next) break;
+    t_cur = t_nxt;
+    cur = nxt;
   }
 }
 
@@ -161,8 +222,12 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
       return CMR_ELAUNCH;
     attr_set = true;
   }
-  dim3 grid((a.Wo + 31) / 32, (a.Ho + TH - 1) / TH, a.B * (a.Cout / 64));
-  hipLaunchKernelGGL((conv3x3_kernel<S, MT, KC>), grid, dim3(256), smem, stream, a);
+  const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + TH - 1) / TH;
+  const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B * (a.Cout / 64);
+  if (ntiles > 0x7fffffff) return CMR_EINVAL;
+  // persistent workgroups: 2 resident per CU (LDS bound), each walks its tiles with stride gridDim.x
+  const int grid = (int)(ntiles < 512 ? ntiles : 512);
+  hipLaunchKernelGGL((conv3x3_kernel<S, MT, KC>), dim3(grid), dim3(256), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
   return cmr_launch_status();
 }
 
@@ -316,7 +381,8 @@ extern "C" int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin
   CMR_REQUIRE(Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0 && Cout >= 64 && (stride == 1 || stride == 2));
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w));
   ConvArgs a{x, B, H, W, Cin, w, bias, res, post, y, (H - 1) / stride + 1, (W - 1) / stride + 1, Cout, slope};
-  CMR_REQUIRE((int64_t)B * (Cout / 64) <= 65535);
+  CMR_REQUIRE(cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
+              (!post || cmr_aligned16(post)));
   if (stride == 1) return launch_conv<1, 2, 32>(a, stream);
   return launch_conv<2, 1, 16>(a, stream);
 }

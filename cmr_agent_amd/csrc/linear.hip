@@ -55,30 +55,30 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
   }
 
   f32x4 ra[AL], rb[2];
-  auto load_chunk = [&](int c) {
+  auto load_chunk = [&](int c) {   // branch-free (clamped addresses, masked afterwards): all loads in flight together
     const bool second = c >= nch1;
     const int kofs = (second ? c - nch1 : c) * KC;
     const int kvalid = (second ? a.k2 : a.k1) - kofs;
     const bool kin = c4 * 4 < kvalid;
     const float* xs = second ? a.x2 : a.x1;
     const int64_t ld = second ? a.ld2 : a.ld1;
+    const int kcol = kin ? kofs + c4 * 4 : 0;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < AL; ++i) {
-      int64_t r = row_base + r0 + 32 * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kin && r < a.rows) {
-        int64_t s = second ? srow2[i] : r;
-        v = *reinterpret_cast<const f32x4*>(xs + s * ld + kofs + c4 * 4);
-      }
-      ra[i] = v;
+      const int64_t r = row_base + r0 + 32 * i;
+      const bool ok = kin && r < a.rows;
+      const int64_t s = ok ? (second ? srow2[i] : r) : 0;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xs + s * ld + kcol);
+      ra[i] = ok ? v : zero;
     }
-    const int kw = (second ? a.k1 : 0) + kofs;
+    const int kw = kin ? (second ? a.k1 : 0) + kofs + c4 * 4 : 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int n = col_base + r0 + 32 * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (kin && n < a.n_out) v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)n * a.ldw + kw + c4 * 4);
-      rb[i] = v;
+      const int n = col_base + r0 + 32 * i;
+      const bool ok = kin && n < a.n_out;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (int64_t)(ok ? n : 0) * a.ldw + kw);
+      rb[i] = ok ? v : zero;
     }
   };
 
@@ -142,6 +142,160 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
   }
 }
 
+// Weight-stationary, barrier-free variant for K = k1 + k2 <= 128 (every hot-path GEMM except the two
+// K = 1024 / 4096 ones), computed TRANSPOSED: D'[cout][row] = W . X^T.
+//   * the [32*NT couts][K] weight block is loaded into LDS once per workgroup and is the MFMA A operand;
+//   * X rows are the B operand and come straight from global memory in operand layout (lane (row, h)
+//     reads the 16 B at k = 8g + 4h of ITS row; every row is read exactly once, nothing to share), the
+//     next 64-deep K segment / next tile is prefetched into registers while the current one is multiplied;
+//   * there is no __syncthreads in the loop: waves stream 32-row tiles independently;
+//   * in the transposed product a lane owns one output row and its 16 accumulator registers are 4 x 4
+//     consecutive output channels, so bias / residual / store are float4 accesses (and the registers
+//     of one layer are directly the B operand of the next -- the hook for chained layers).
+// Rows are HBM-bound at these shapes ((K + Nout) * 4 bytes vs 2*K*Nout flops per row).
+__device__ __attribute__((aligned(16))) const float cmr_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// NT = 32-wide cout tiles per workgroup (1, 2, 4); G = k-groups (of 8) per register segment (1, 2, 4, 8).
+// kpad = nseg * 8 * G >= k1 + k2 (weights beyond k1 + k2 are zero in LDS, X loads beyond it read zeros).
+// AC = activation class: 0 -> v > 0 ? v : v * slope (none / ReLU / LeakyReLU with slope 1 / 0 / p), 1 -> erf-GELU, 2 -> elu+1
+template <int AC>
+__device__ __forceinline__ float ws_act(float v, float slope) {
+  if (AC == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (AC == 2) return v > 0.f ? v + 1.f : expf(v);
+  return v > 0.f ? v : v * slope;
+}
+
+template <int NT, int G, int AC>
+__global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a, const int nseg) {
+  extern __shared__ __attribute__((aligned(16))) float Ws[];   // [32*NT][kpad + 4]
+  const int kpad = nseg * 8 * G;
+  const int ldws = kpad + 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int col_base = blockIdx.y * 32 * NT;
+  const int ktot = a.k1 + a.k2;
+  const int64_t ntiles = (a.rows + 31) / 32;
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+
+  // No load is conditional and no loaded value is touched before its MFMA: masked elements (rows past
+  // the end, k past k1 + k2) read a 16-byte zero page instead, so a whole segment stays in flight.
+  auto load_seg = [&](int64_t tile, int seg, f32x4 (&dst)[G]) {
+    int64_t row = tile * 32 + l31;
+    const bool valid = tile < ntiles && row < a.rows;
+    if (!valid) row = 0;
+    const float* p1 = a.x1 + row * a.ld1;
+    const float* p2 = p1;
+    if (a.x2) p2 = a.x2 + (a.idx2 ? (int64_t)a.idx2[row] : row / a.div2) * a.ld2;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int kk = (seg * G + i) * 8 + 4 * h;
+      const float* p = kk < a.k1 ? p1 + kk : p2 + (kk - a.k1);
+      if (!valid || kk >= ktot) p = cmr_zero16;
+      dst[i] = *reinterpret_cast<const f32x4*>(p);
+    }
+  };
+
+  f32x4 xcur[G], xnxt[G];
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  load_seg(tile, 0, xcur);                 // in flight while the weights are staged
+  {
+    const int c4n = kpad / 4;
+    for (int e = tid; e < 32 * NT * c4n; e += 256) {
+      const int n = e / c4n, c = (e % c4n) * 4;
+      const bool ok = col_base + n < a.n_out && c < ktot;
+      const float* p = ok ? a.w + (int64_t)(col_base + n) * a.ldw + c : cmr_zero16;
+      *reinterpret_cast<f32x4*>(&Ws[n * ldws + c]) = *reinterpret_cast<const f32x4*>(p);
+    }
+  }
+  __syncthreads();
+
+  for (; tile < ntiles; tile += tstride) {
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int seg = 0; seg < nseg; ++seg) {
+      if (seg + 1 < nseg) load_seg(tile, seg + 1, xnxt);
+      else load_seg(tile + tstride, 0, xnxt);            // next tile of this wave (zero page past the end)
+      const float* wrow = Ws + l31 * ldws + seg * G * 8 + 4 * h;
+#pragma unroll
+      for (int i = 0; i < G; ++i) {
+        f32x4 wv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wv[n] = *reinterpret_cast<const f32x4*>(wrow + n * 32 * ldws + i * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = cmr_mfma32(wv[n][j], xcur[i][j], acc[n]);
+      }
+#pragma unroll
+      for (int i = 0; i < G; ++i) xcur[i] = xnxt[i];
+    }
+    // epilogue: this lane's row, 4 consecutive couts per register quad
+    const int64_t row = tile * 32 + l31;
+    if (row < a.rows) {
+      const int64_t rr = a.res ? (a.res_mod > 0 ? row % a.res_mod : row) : 0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 r4[4];
+        if (a.res) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c0 = col_base + n * 32 + 8 * q + 4 * h;
+            r4[q] = *reinterpret_cast<const f32x4*>(c0 < a.n_out ? a.res + rr * a.ldres + c0 : cmr_zero16);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = col_base + n * 32 + 8 * q + 4 * h;
+          f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(c0 < a.n_out ? a.bias + c0 : cmr_zero16);
+          if (a.res) v += r4[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ws_act<AC>(v[e], a.act_param);
+          if (c0 < a.n_out) *reinterpret_cast<f32x4*>(a.y + row * a.ldy + c0) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT, int G, int AC>
+int launch_linear_ws_ga(LinearArgs a, int nseg, hipStream_t stream) {
+  const size_t smem = (size_t)32 * NT * (nseg * 8 * G + 4) * sizeof(float);
+  static size_t attr_set = 0;
+  if (smem > 64 * 1024 && smem > attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_ws_kernel<NT, G, AC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return CMR_ELAUNCH;
+    attr_set = smem;
+  }
+  if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
+  const int64_t ntiles = (a.rows + 31) / 32;
+  int64_t gx = (ntiles + 3) / 4;
+  if (gx > 512) gx = 512;                   // 2 resident workgroups per CU; each wave walks its tiles with stride
+  dim3 grid((unsigned)gx, (unsigned)((a.n_out + 32 * NT - 1) / (32 * NT)));
+  hipLaunchKernelGGL((linear_ws_kernel<NT, G, AC>), grid, dim3(256), smem, stream, a, nseg);
+  return cmr_launch_status();
+}
+
+template <int NT, int G>
+int launch_linear_ws_g(const LinearArgs& a, int nseg, hipStream_t stream) {
+  if (a.act == CMR_ACT_GELU) return launch_linear_ws_ga<NT, G, 1>(a, nseg, stream);
+  if (a.act == CMR_ACT_ELU1) return launch_linear_ws_ga<NT, G, 2>(a, nseg, stream);
+  return launch_linear_ws_ga<NT, G, 0>(a, nseg, stream);
+}
+
+template <int NT>
+int launch_linear_ws(const LinearArgs& a, hipStream_t stream) {
+  const int ng = (a.k1 + a.k2 + 7) / 8;     // k-groups of 8
+  if (ng >= 5 && NT < 4) return launch_linear_ws_g<NT, 8>(a, (ng + 7) / 8, stream);
+  if (ng >= 3) return launch_linear_ws_g<NT, 4>(a, (ng + 3) / 4, stream);     // NT = 4 keeps 4-group segments (registers)
+  if (ng == 2) return launch_linear_ws_g<NT, 2>(a, 1, stream);
+  return launch_linear_ws_g<NT, 1>(a, 1, stream);
+}
+
 // LayerNorm over exactly 64 channels; 16 lanes per row (float4 each).  y = LN(x)*g + b (+ res)
 __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restrict__ x, int64_t ldx,
                                                           const float* __restrict__ g, const float* __restrict__ b,
@@ -191,6 +345,14 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   if (rows == 0) return CMR_OK;
   LinearArgs a{x1, ld1, k1, x2, ld2, x2 ? k2 : 0, idx2, div2 < 1 ? 1 : div2, w, ldw, bias, res, ldres, res_mod,
                y, ldy, rows, n_out, act, act_param};
+  // float4 epilogue needs 4-aligned output channels (the host layer pads the few odd heads)
+  const bool vec_ok = (n_out % 4 == 0) && (ldy % 4 == 0) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) &&
+                      (!res || (ldres % 4 == 0 && cmr_aligned16(res)));
+  if (a.k1 + a.k2 <= 128 && vec_ok) {       // weights fit in LDS: weight-stationary streaming kernel
+    if (n_out <= 32 || (n_out > 64 && n_out <= 96)) return launch_linear_ws<1>(a, stream);
+    if (n_out % 128 == 0) return launch_linear_ws<4>(a, stream);
+    return launch_linear_ws<2>(a, stream);
+  }
   const unsigned gy = (unsigned)((n_out + 63) / 64);
   if (rows >= 16384) {
     dim3 grid((unsigned)((rows + 255) / 256), gy);

@@ -88,8 +88,9 @@ class CMRAgent(Planned):
             hcur = ops.linear(e2d, *l0, x2=e3d, act=ops.ACT_LRELU, act_param=SLOPE)      # cat([embed_2d, embed_3d])
             hcur = ops.linear(hcur, *l1, act=ops.ACT_LRELU, act_param=SLOPE)
             out.append(ops.linear(hcur, *l2))
-        S = self.config.num_steps
-        return out[0].view(B, self.degree_r, S), out[1].view(B, self.degree_t, S), out[2].view(B, 1, 1)
+        S = self.config.num_steps          # head widths are padded to a multiple of 4: slice, then split
+        return (out[0][:, :self.degree_r * S].view(B, self.degree_r, S), out[1][:, :self.degree_t * S].view(B, self.degree_t, S),
+                out[2][:, :1].view(B, 1, 1))
 
     def forward(self, state_2d, state_3d):
         """state_2d [B,128,h,w], state_3d [B,5,N] (reference layout; the views produced by
@@ -106,9 +107,7 @@ class CMRAgent(Planned):
     def action_from_logits(r_logits, t_logits, deterministic=False):
         """CMRAgent.py:118-127.  deterministic: argmax (of the Categorical probs = of the logits)."""
         if deterministic:
-            ar = ops.argmax_rows(r_logits.contiguous(), r_logits.shape[0] * r_logits.shape[1], r_logits.shape[2])
-            at = ops.argmax_rows(t_logits.contiguous(), t_logits.shape[0] * t_logits.shape[1], t_logits.shape[2])
-            return ar.view(r_logits.shape[:2]), at.view(t_logits.shape[:2])
+            return ops.argmax_rows(r_logits), ops.argmax_rows(t_logits)
         from torch.distributions import Categorical
         return Categorical(logits=r_logits).sample(), Categorical(logits=t_logits).sample()
 

@@ -38,6 +38,7 @@ class _Head(Planned):
         setattr(self, img_name, nn.Sequential(nn.Conv2d(f, img_mid, 1, 1, 0), nn.LeakyReLU(HEAD_SLOPE, inplace=True),
                                               nn.Conv2d(img_mid, img_out, 1, 1, 0)))
         self._pc_name, self._img_name = pc_name, img_name
+        self._pc_out, self._img_out = pc_out, img_out
 
     def _build_plan(self):
         pc, im = getattr(self, self._pc_name), getattr(self, self._img_name)
@@ -57,7 +58,7 @@ class _Head(Planned):
             y = layer.forward_cl(y)
         B, h, w, f = y.shape
         pix = ops.linear(ops.linear(y.view(B * h * w, f), *p["im0"], act=ops.ACT_LRELU, act_param=HEAD_SLOPE), *p["im2"])
-        return pts, pix
+        return pts[:, :self._pc_out], pix[:, :self._img_out]      # widths are padded to 4 in the plan
 
 
 class OverlapDetectionHead(_Head):

@@ -50,9 +50,11 @@ def pad_rows(w2d, b, mult=4):
 
 
 def lin(layer, bn=None):
-    """Linear / Conv1d(k=1) / Conv2d(k=1) -> (W [n_out, k_pad4], bias [n_out])."""
+    """Linear / Conv1d(k=1) / Conv2d(k=1) -> (W [n_pad4, k_pad4], bias [n_pad4]).  Output channels are
+    padded to a multiple of 4 with zero rows (float4 epilogue of the streaming GEMM); the few layers
+    with an odd width (2, 11, 22, 1) slice the result."""
     w, b = folded(layer, bn)
-    return pad_k(w.reshape(w.shape[0], -1)), b.contiguous()
+    return pad_rows(pad_k(w.reshape(w.shape[0], -1)), b.contiguous())
 
 
 def conv9(conv, bn=None):

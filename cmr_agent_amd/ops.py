@@ -287,9 +287,13 @@ def to_disentangled(pose, mean4):
     _lib.call("cmr_to_disentangled_f32", _p(pose), _p(mean4), pose.shape[0], _stream())
 
 
-def argmax_rows(x, rows, n):
-    out = torch.empty((rows,), dtype=torch.int64, device=x.device)
-    _lib.call("cmr_argmax_rows_f32", _p(x), _p(out), rows, n, _stream())
+def argmax_rows(x):
+    """x [outer, inner, n] (unit stride on the last dim) -> int64 [outer, inner]."""
+    outer, inner, n = x.shape
+    if x.stride(2) != 1:
+        raise ValueError("argmax_rows needs unit stride on the last dim")
+    out = torch.empty((outer, inner), dtype=torch.int64, device=x.device)
+    _lib.call("cmr_argmax_rows_f32", _p(x), _p(out), outer, inner, n, x.stride(0), x.stride(1), _stream())
     return out
 
 

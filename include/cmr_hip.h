@@ -154,7 +154,8 @@ int cmr_pose_step_f32(float* pose, const int64_t* act_r, const int64_t* act_t, c
                       const double* t_steps, int B, int six_dof, hipStream_t stream);
 int cmr_to_disentangled_f32(float* pose, const float* mean4, int B, hipStream_t stream);
 /* CMRAgent.py:118-127 (deterministic action = argmax). */
-int cmr_argmax_rows_f32(const float* x, int64_t* out, int rows, int n, hipStream_t stream);
+int cmr_argmax_rows_f32(const float* x, int64_t* out, int outer, int inner, int n, int64_t stride_outer,
+                        int64_t stride_inner, hipStream_t stream);
 /* MultiHeadModel.py:330-341 (softmax over 2 classes, thresholds .5/.8). */
 int cmr_softmax2_f32(const float* logits, int64_t ld, float* prob, uint8_t* pred_lo, uint8_t* pred_hi, float thr_lo,
                      float thr_hi, int64_t rows, hipStream_t stream);

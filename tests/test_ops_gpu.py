@@ -313,4 +313,7 @@ def test_small_heads(ops):
     x = rnd(3000, 64, seed=62)
     close(ops.l2norm64(x.to(DEV)), F.normalize(x.double(), dim=1), 1e-6, "l2norm")
     lg = rnd(24, 11, seed=63)
-    assert torch.equal(ops.argmax_rows(lg.to(DEV), 24, 11).cpu(), lg.argmax(1))
+    assert torch.equal(ops.argmax_rows(lg.to(DEV).view(8, 3, 11)).cpu(), lg.argmax(1).view(8, 3))
+    pad = torch.zeros(8, 24, device=DEV)
+    pad[:, :22] = lg[:16].reshape(8, 22).to(DEV)
+    assert torch.equal(ops.argmax_rows(pad[:, :22].view(8, 2, 11)).cpu(), lg[:16].argmax(1).view(8, 2))

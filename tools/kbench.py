@@ -15,13 +15,20 @@ DEV = "cuda"
 
 
 def timeit(fn, reps=20, warm=3):
+    """GPU time per call: the calls are captured into one HIP graph and replayed, so host-side
+    launch cost (ctypes + torch, ~10 us per call) does not mask short kernels."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3      # us
