@@ -67,11 +67,18 @@ def prototypes():
     return _protos
 
 
-_ERR = {-1: "invalid argument (shape / alignment / null pointer)", -2: "kernel launch failed"}
+_ERR = {-1: "invalid argument (shape / alignment / null pointer)", -2: "kernel launch failed",
+        -3: "not served by this entry point"}
 
 
-def call(name, *args):
-    """Invoke an int-returning entry point; raises CmrError on a non-zero status."""
+UNSUPPORTED = -3
+
+
+def call(name, *args, allow_unsupported=False):
+    """Invoke an int-returning entry point; raises CmrError on a non-zero status
+    (returns UNSUPPORTED instead of raising when the caller has a fallback entry point)."""
     rc = getattr(load(), name)(*args)
+    if rc == UNSUPPORTED and allow_unsupported:
+        return rc
     if rc != 0:
         raise CmrError("%s failed: %s (rc=%d)" % (name, _ERR.get(rc, "?"), rc))

@@ -6,6 +6,7 @@
 #define CMR_OK 0
 #define CMR_EINVAL -1   // bad argument (shape / alignment / null pointer)
 #define CMR_ELAUNCH -2  // hipGetLastError() after the launch was not hipSuccess
+#define CMR_EUNSUPPORTED -3  // valid request that this build serves through another entry point (caller falls back)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -26,6 +26,7 @@ struct ConvArgs {
   const float* post;   // [Ho,Wo,Cout] or null  (added after the activation)
   float* y; int Ho, Wo, Cout;
   float slope;         // LeakyReLU slope; 1.0f = identity
+  int pool;            // 1 = none, 2 = fused AvgPool2d(2,2) of the activated output (y is [B,Ho/2,Wo/2,Cout])
 };
 
 template <int S, int MT, int KC>
@@ -178,6 +179,32 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const ConvArgs a, const in
 
     // ---- epilogue: lane = pixel (oy, ox0 + l31); register quad q of tile n = couts n*32 + 8q + 4h .. +3
     const int ox = cur.ox0 + l31;
+    if (MT == 2 && a.pool == 2) {
+      // fused AvgPool2d(2,2) (CMRAgent.py:39,45,51): the wave's two rows and the neighbouring lane
+      const int py = (cur.oy0 + wave * 2) >> 1, px = ox >> 1;
+      const int hp = a.Ho >> 1, wp = a.Wo >> 1;
+      const bool pvalid = (l31 & 1) == 0 && py < hp && px < wp;
+      const int64_t o = (((int64_t)cur.b * hp + (py < hp ? py : 0)) * wp + (px < wp ? px : 0)) * a.Cout + cur.co0 + 4 * h;
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = n * 32 + 8 * q;
+          f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias) bs = *reinterpret_cast<const f32x4*>(a.bias + cur.co0 + 4 * h + c);
+          f32x4 sum;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v0 = acc[0][n][4 * q + e] + bs[e], v1 = acc[MT - 1][n][4 * q + e] + bs[e];
+            v0 = v0 > 0.f ? v0 : v0 * a.slope;
+            v1 = v1 > 0.f ? v1 : v1 * a.slope;
+            float t2 = v0 + v1;
+            t2 += __shfl_xor(t2, 1);
+            sum[e] = 0.25f * t2;
+          }
+          if (pvalid) *reinterpret_cast<f32x4*>(a.y + o + c) = sum;
+        }
+    } else
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int oy = cur.oy0 + wave * MT + m;
@@ -261,41 +288,223 @@ __global__ __launch_bounds__(256) void stem_a_kernel(const float* __restrict__ x
   }
 }
 
-// stem_b: y = LReLU(conv3x3(3->C)(t) + conv1x1(3->C)(x) + b)   NCHW x2 -> NHWC [B,H,W,C], C = 64
-// one wave per 4 consecutive pixels, lane = output channel (coalesced 256-B rows)
+// ---- direct (LDS-free) 3x3 convolution for small maps ------------------------------------------
+// When the map is so small that 8x32 tiles cannot fill 256 CUs (22x76, 11x38 at the end of the agent's
+// 2-D branch), every wave takes 32 flattened output pixels x NT*32 output channels and gathers both
+// MFMA operands straight from global memory (the whole input and the weights are L2 resident): pixel
+// fragments through per-lane neighbour pointers (a zero page stands in for the padding), weight
+// fragments as in the streaming GEMM.  Both are prefetched one 32-channel segment ahead.
+__device__ __attribute__((aligned(16))) const float cmr_conv_zero_page[1024] = {0.f};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv3x3_direct_kernel(const ConvArgs a, const int64_t npix, const int mtiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int co0 = blockIdx.y * 32 * NT;
+  const int nseg = a.Cin / 32;                       // 32-channel segments per tap (4 k-groups each)
+  const int nit = 9 * nseg;
+  const int64_t hwo = (int64_t)a.Ho * a.Wo;
+  for (int mt = blockIdx.x * 4 + wave; mt < mtiles; mt += gridDim.x * 4) {
+    int64_t p = (int64_t)mt * 32 + l31;
+    const bool valid = p < npix;
+    if (!valid) p = 0;
+    const int b = (int)(p / hwo);
+    const int rem = (int)(p - (int64_t)b * hwo);
+    const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+    const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin + 4 * h;
+    const float* wb = a.w + (int64_t)(co0 + l31) * a.Cin + 4 * h;
+
+    auto xptr = [&](int it) {      // pixel-operand pointer of iteration it = tap * nseg + seg
+      const int tap = it / nseg, seg = it - tap * nseg;
+      const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+      const bool in = valid && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      return in ? xb + ((int64_t)iy * a.W + ix) * a.Cin + seg * 32 : cmr_conv_zero_page + 4 * h;
+    };
+    auto wptr = [&](int it) {
+      const int tap = it / nseg, seg = it - tap * nseg;
+      return wb + (int64_t)tap * a.Cout * a.Cin + seg * 32;
+    };
+    f32x4 xc[4], xn[4], wc[NT][4], wn[NT][4];
+    {
+      const float* xp = xptr(0);
+      const float* wp = wptr(0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xc[g] = *reinterpret_cast<const f32x4*>(xp + g * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wc[n][g] = *reinterpret_cast<const f32x4*>(wp + (int64_t)n * 32 * a.Cin + g * 8);
+      }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    for (int it = 0; it < nit; ++it) {
+      const int itn = it + 1 < nit ? it + 1 : it;
+      const float* xp = xptr(itn);
+      const float* wp = wptr(itn);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xn[g] = *reinterpret_cast<const f32x4*>(xp + g * 8);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wn[n][g] = *reinterpret_cast<const f32x4*>(wp + (int64_t)n * 32 * a.Cin + g * 8);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[n] = cmr_mfma32(wc[n][g][j], xc[g][j], acc[n]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xc[g] = xn[g];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wc[n][g] = wn[n][g];
+      }
+    }
+    if (valid) {
+      const int64_t pix = (int64_t)oy * a.Wo + ox;
+      const int64_t o = ((int64_t)b * hwo + pix) * a.Cout + co0 + 4 * h;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x4 r4[4];
+        if (a.res) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) r4[q] = *reinterpret_cast<const f32x4*>(a.res + o + n * 32 + 8 * q);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = n * 32 + 8 * q;
+          f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+          if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + co0 + 4 * h + c);
+          if (a.res) v += r4[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+          if (a.post) v += *reinterpret_cast<const f32x4*>(a.post + pix * a.Cout + co0 + 4 * h + c);
+          *reinterpret_cast<f32x4*>(a.y + o + c) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int NT>
+int launch_conv_direct(const ConvArgs& a, hipStream_t stream) {
+  const int64_t npix = (int64_t)a.B * a.Ho * a.Wo;
+  const int mtiles = (int)((npix + 31) / 32);
+  const int gx = (mtiles + 3) / 4 < 1024 ? (mtiles + 3) / 4 : 1024;
+  hipLaunchKernelGGL(conv3x3_direct_kernel<NT>, dim3(gx, a.Cout / (32 * NT)), dim3(256), 0, stream, a, npix, mtiles);
+  return cmr_launch_status();
+}
+
+__device__ __attribute__((aligned(16))) const float cmr_conv_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// stem_b: y = LReLU(conv3x3(3->64)(t) + conv1x1(3->64)(x) + b)   NCHW t, x -> NHWC [B,H,W,64]
+// as a K = 32 GEMM on fp32 MFMA (27 taps of t, 3 channels of x, 2 zero pads).  Each wave owns tiles of
+// 32 consecutive (flattened) pixels: the pixel operand is gathered with scalar loads that are coalesced
+// across lanes (planar input), the [64][32] weight block lives in registers for the whole kernel, and
+// the next tile's 16 loads are in flight while the current tile is multiplied.  Output-bound (256 B/pixel).
 __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t, const float* __restrict__ x,
                                                      const float* __restrict__ w3 /*[27][64] (ci,ky,kx major)*/,
                                                      const float* __restrict__ w1 /*[3][64]*/,
                                                      const float* __restrict__ bias /*[64] (both BN shifts)*/,
                                                      float* __restrict__ y, int B, int H, int W, float slope) {
-  __shared__ float sw[30 * 64];
-  for (int i = threadIdx.x; i < 27 * 64; i += 256) sw[i] = w3[i];
-  for (int i = threadIdx.x; i < 3 * 64; i += 256) sw[27 * 64 + i] = w1[i];
+  __shared__ __attribute__((aligned(16))) float ws[64 * 36];
+  for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+    const int c = e >> 5, k = e & 31;
+    ws[c * 36 + k] = k < 27 ? w3[k * 64 + c] : (k < 30 ? w1[(k - 27) * 64 + c] : 0.f);
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  f32x4 wf[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) wf[n][g] = *reinterpret_cast<const f32x4*>(&ws[(n * 32 + l31) * 36 + g * 8 + 4 * h]);
+
   const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw;
-  const float bs = bias[lane];
-  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * 4;
-  for (int q = 0; q < 4; ++q) {
-    const int64_t p = p0 + q;
-    if (p >= total) break;
-    const int b = (int)(p / hw);
-    const int yy = (int)((p % hw) / W), xx = (int)(p % W);
-    float o = bs;
-    for (int ci = 0; ci < 3; ++ci) {
-      const float* tp = t + ((int64_t)b * 3 + ci) * hw;
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = yy + ky - 1;
-        if (iy < 0 || iy >= H) continue;
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = xx + kx - 1;
-          if (ix < 0 || ix >= W) continue;
-          o += tp[(int64_t)iy * W + ix] * sw[((ci * 3 + ky) * 3 + kx) * 64 + lane];
-        }
-      }
-      o += x[((int64_t)b * 3 + ci) * hw + (int64_t)yy * W + xx] * sw[(27 + ci) * 64 + lane];
+  // per-lane description of its 16 K entries: k = 8g + 4h + e
+  int off[16], code[16];           // code: 0..8 = (dy+1)*3+(dx+1) tap of t, 9 = centre of x, 10 = zero pad
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = 8 * (i >> 2) + 4 * h + (i & 3);
+    if (k < 27) {
+      const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
+      off[i] = (int)(ci * hw) + (ky - 1) * W + (kx - 1);
+      code[i] = ky * 3 + kx;
+    } else if (k < 30) {
+      off[i] = (int)((k - 27) * hw);
+      code[i] = 9;
+    } else {
+      off[i] = 0;
+      code[i] = 10;
     }
-    y[p * 64 + lane] = o > 0.f ? o : o * slope;
+  }
+  auto gather = [&](int64_t tile, float (&dst)[16]) {
+    int64_t p = tile * 32 + l31;
+    const bool valid = p < total;
+    if (!valid) p = 0;
+    const int b = (int)(p / hw);
+    const int rem = (int)(p - (int64_t)b * hw);
+    const int yy = rem / W, xx = rem - yy * W;
+    // bit (dy+1)*3+(dx+1) set when that neighbour is inside the image; bit 9 always; bit 10 never
+    unsigned m = 0;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const bool in = yy + dy >= 0 && yy + dy < H && xx + dx >= 0 && xx + dx < W;
+        m |= (in ? 1u : 0u) << ((dy + 1) * 3 + dx + 1);
+      }
+    m |= 1u << 9;
+    if (!valid) m = 0;
+    const float* tp = t + (int64_t)b * 3 * hw + rem;
+    const float* xp = x + (int64_t)b * 3 * hw + rem;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float* q = (code[i] == 9 ? xp : tp) + off[i];
+      if (!((m >> code[i]) & 1u)) q = cmr_conv_zero16;
+      dst[i] = *q;
+    }
+  };
+
+  const int64_t ntiles = (total + 31) / 32;
+  const int64_t tstride = (int64_t)gridDim.x * 4;
+  float xc[16], xn[16];
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  gather(tile < ntiles ? tile : 0, xc);
+  for (; tile < ntiles; tile += tstride) {
+    gather(tile + tstride < ntiles ? tile + tstride : tile, xn);
+    f32x16 acc[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0] = cmr_mfma32(wf[0][g][j], xc[g * 4 + j], acc[0]);
+        acc[1] = cmr_mfma32(wf[1][g][j], xc[g * 4 + j], acc[1]);
+      }
+    const int64_t p = tile * 32 + l31;
+    if (p < total) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = n * 32 + 8 * q + 4 * h;
+          f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+          v += *reinterpret_cast<const f32x4*>(bias + c0);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+          *reinterpret_cast<f32x4*>(y + p * 64 + c0) = v;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xc[i] = xn[i];
   }
 }
 
@@ -376,14 +585,23 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 extern "C" int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
                                     const float* res, const float* post, float* y, int Cout, int stride, float slope,
-                                    hipStream_t stream) {
+                                    int pool, hipStream_t stream) {
   CMR_REQUIRE(x && w && y && B > 0 && H > 0 && W > 0);
   CMR_REQUIRE(Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0 && Cout >= 64 && (stride == 1 || stride == 2));
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w));
-  ConvArgs a{x, B, H, W, Cin, w, bias, res, post, y, (H - 1) / stride + 1, (W - 1) / stride + 1, Cout, slope};
+  CMR_REQUIRE(pool == 1 || (pool == 2 && stride == 1 && !res && !post));
+  ConvArgs a{x, B, H, W, Cin, w, bias, res, post, y, (H - 1) / stride + 1, (W - 1) / stride + 1, Cout, slope, pool};
   CMR_REQUIRE(cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
               (!post || cmr_aligned16(post)));
-  if (stride == 1) return launch_conv<1, 2, 32>(a, stream);
+  if (stride == 1) {
+    const int64_t tiles = (int64_t)((a.Wo + 31) / 32) * ((a.Ho + 7) / 8) * B * (Cout / 64);
+    if (tiles < 256) {               // too few 8x32 tiles for 256 CUs: per-wave direct convolution
+      if (pool != 1) return CMR_EUNSUPPORTED;   // caller pools separately (tiny maps)
+      const int64_t mtiles = ((int64_t)B * a.Ho * a.Wo + 31) / 32;
+      return mtiles * (Cout / 64) < 512 ? launch_conv_direct<1>(a, stream) : launch_conv_direct<2>(a, stream);
+    }
+    return launch_conv<1, 2, 32>(a, stream);
+  }
   return launch_conv<2, 1, 16>(a, stream);
 }
 
@@ -394,8 +612,10 @@ extern "C" int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const f
   const int64_t total = (int64_t)B * H * W;
   hipLaunchKernelGGL(stem_a_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x_nchw, w_a, b_a,
                      tmp_nchw, B, H, W, slope);
-  hipLaunchKernelGGL(stem_b_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, tmp_nchw, x_nchw, w3, w1,
-                     b_b, y_nhwc, B, H, W, slope);
+  CMR_REQUIRE((int64_t)3 * H * W < 0x7fffffff && cmr_aligned16(b_b) && cmr_aligned16(y_nhwc));
+  const int64_t stiles = (total + 31) / 32;
+  const unsigned sgrid = (unsigned)(stiles + 3) / 4 < 1024u ? (unsigned)((stiles + 3) / 4) : 1024u;
+  hipLaunchKernelGGL(stem_b_kernel, dim3(sgrid), dim3(256), 0, stream, tmp_nchw, x_nchw, w3, w1, b_b, y_nhwc, B, H, W, slope);
   return cmr_launch_status();
 }
 

@@ -153,6 +153,77 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
 //     consecutive output channels, so bias / residual / store are float4 accesses (and the registers
 //     of one layer are directly the B operand of the next -- the hook for chained layers).
 // Rows are HBM-bound at these shapes ((K + Nout) * 4 bytes vs 2*K*Nout flops per row).
+// Skinny GEMM for <= 16 rows (the agent's per-sample heads: 8 rows x K = 128..256).  A wave owns 4
+// output channels: its 64 lanes read a weight row as one coalesced 1-KiB float4 load per 256 k,
+// multiply with the input rows held in LDS and finish with a wave reduction.  Replaces 128-row
+// MFMA tiles that would be > 90 % padding; latency-bound by construction (a few microseconds).
+constexpr int SK_ROWS = 16;
+template <int R>
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const LinearArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];   // [R][ktot], rows past a.rows are zero
+  const int ktot = a.k1 + a.k2;
+  const int rows = (int)a.rows;
+  for (int e = threadIdx.x; e < R * (ktot / 4); e += 256) {
+    const int r = e / (ktot / 4), c = (e % (ktot / 4)) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+      const float* p = c < a.k1 ? a.x1 + (int64_t)r * a.ld1 + c
+                                : a.x2 + (a.idx2 ? (int64_t)a.idx2[r] : (int64_t)r / a.div2) * a.ld2 + (c - a.k1);
+      v = *reinterpret_cast<const f32x4*>(p);
+    }
+    *reinterpret_cast<f32x4*>(&xs[r * ktot + c]) = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  float acc[4][R];
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[o][r] = 0.f;
+  for (int kc = 0; kc < ktot; kc += 256) {
+    const int k = kc + lane * 4;
+    const bool kin = k < ktot;
+    f32x4 wv[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int n = n0 + o < a.n_out ? n0 + o : 0;
+      wv[o] = *reinterpret_cast<const f32x4*>(a.w + (int64_t)n * a.ldw + (kin ? k : 0));
+    }
+    if (kin) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(&xs[r * ktot + k]);
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o][r] += wv[o][0] * xv[0] + wv[o][1] * xv[1] + wv[o][2] * xv[2] + wv[o][3] * xv[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float v = acc[o][r];
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+      acc[o][r] = v;
+    }
+  if (lane < 4 * R) {                         // lane -> (o, r); every lane holds all sums after the xor reduction
+    const int o = lane / R, r = lane % R;
+    const int n = n0 + o;
+    if (n < a.n_out && r < rows) {
+      float v = 0.f;
+#pragma unroll
+      for (int oo = 0; oo < 4; ++oo)
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) v = (oo == o && rr == r) ? acc[oo][rr] : v;
+      v += a.bias ? a.bias[n] : 0.f;
+      if (a.res) v += a.res[(a.res_mod > 0 ? r % a.res_mod : r) * a.ldres + n];
+      a.y[(int64_t)r * a.ldy + n] = cmr_act(v, a.act, a.act_param);
+    }
+  }
+}
+
 __device__ __attribute__((aligned(16))) const float cmr_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 // NT = 32-wide cout tiles per workgroup (1, 2, 4); G = k-groups (of 8) per register segment (1, 2, 4, 8).
@@ -345,6 +416,14 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   if (rows == 0) return CMR_OK;
   LinearArgs a{x1, ld1, k1, x2, ld2, x2 ? k2 : 0, idx2, div2 < 1 ? 1 : div2, w, ldw, bias, res, ldres, res_mod,
                y, ldy, rows, n_out, act, act_param};
+  if (rows <= SK_ROWS && (size_t)SK_ROWS * (a.k1 + a.k2) * sizeof(float) <= 64 * 1024) {
+    const dim3 grid((unsigned)((n_out + 15) / 16));
+    if (rows <= 8)
+      hipLaunchKernelGGL(linear_skinny_kernel<8>, grid, dim3(256), (size_t)8 * (a.k1 + a.k2) * sizeof(float), stream, a);
+    else
+      hipLaunchKernelGGL(linear_skinny_kernel<16>, grid, dim3(256), (size_t)16 * (a.k1 + a.k2) * sizeof(float), stream, a);
+    return cmr_launch_status();
+  }
   // float4 epilogue needs 4-aligned output channels (the host layer pads the few odd heads)
   const bool vec_ok = (n_out % 4 == 0) && (ldy % 4 == 0) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) &&
                       (!res || (ldres % 4 == 0 && cmr_aligned16(res)));

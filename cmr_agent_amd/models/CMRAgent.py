@@ -67,10 +67,8 @@ class CMRAgent(Planned):
         x = state2d
         for stage, ((wa, ba), (wb, bb)) in enumerate(p["convs"]):
             x = ops.conv3x3(x, wa, ba, c, 1, SLOPE)
-            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE)
-            if stage < 3:
-                x = ops.avgpool(x, 2, 2)
-            else:
+            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE, pool=2 if stage < 3 else 1)     # AvgPool2d(2,2) in the epilogue
+            if stage == 3:
                 kh, kw = self.config.image_H // 8, self.config.image_W // 8
                 if (x.shape[1], x.shape[2]) != (kh, kw):
                     raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (x.shape[1], x.shape[2], kh, kw))

@@ -64,16 +64,24 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
     return out
 
 
-def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None):
-    """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout]."""
+def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1):
+    """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout] (or the 2x2 average-pooled
+    map when pool=2: fused into the conv epilogue where the tiled kernel runs, a second kernel otherwise)."""
     B, H, W, cin = x.shape
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
         raise ValueError("conv3x3: bad operand layout")
+    if pool == 2:
+        y = torch.empty((B, ho // 2, wo // 2, cout), dtype=f32, device=x.device)
+        rc = _lib.call("cmr_conv3x3_nhwc_f32", _p(x), B, H, W, cin, _p(w9), _p(bias), None, None, _p(y), cout, stride,
+                       float(slope), 2, _stream(), allow_unsupported=True)
+        if rc == _lib.UNSUPPORTED:
+            return avgpool(conv3x3(x, w9, bias, cout, stride, slope), 2, 2)
+        return y
     if out is None:
         out = torch.empty((B, ho, wo, cout), dtype=f32, device=x.device)
     _lib.call("cmr_conv3x3_nhwc_f32", _p(x), B, H, W, cin, _p(w9), _p(bias), _p(res), _p(post), _p(out), cout, stride,
-              float(slope), _stream())
+              float(slope), 1, _stream())
     return out
 
 

@@ -28,6 +28,7 @@ typedef struct ihipStream_t* hipStream_t;
 #define CMR_OK 0
 #define CMR_EINVAL -1
 #define CMR_ELAUNCH -2
+#define CMR_EUNSUPPORTED -3
 
 enum { CMR_ACT_NONE = 0, CMR_ACT_RELU = 1, CMR_ACT_LRELU = 2, CMR_ACT_GELU = 3, CMR_ACT_ELU1 = 4 };
 
@@ -51,9 +52,11 @@ int cmr_layernorm64_f32(const float* x, int64_t ldx, const float* gamma, const f
 
 /* 3x3 convolution, pad 1, stride 1|2, NHWC, w = [9][Cout][Cin] (BN folded), y = lrelu(conv + bias + res) + post.
  * ImageResNet.py:9-14,24-36 (ResidualBlock convs + strided shortcut), IMGPCEnDecoder.py:90-94 (post = 2-D
- * sine table, utils/positional_embedding_2d.py:35-40), MultiHeadModel.py:70-72,236-238, CMRAgent.py:34-56. */
+ * sine table, utils/positional_embedding_2d.py:35-40), MultiHeadModel.py:70-72,236-238, CMRAgent.py:34-56.
+ * pool = 2 fuses the following AvgPool2d(2,2) (CMRAgent.py:39,45,51; y is then [B,Ho/2,Wo/2,Cout]); returns
+ * CMR_EUNSUPPORTED (-3) for maps too small for the tiled kernel: the caller then pools with cmr_avgpool_nhwc_f32. */
 int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* w, const float* bias,
-                         const float* res, const float* post, float* y, int Cout, int stride, float slope,
+                         const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                          hipStream_t stream);
 
 /* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.

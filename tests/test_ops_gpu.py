@@ -86,7 +86,8 @@ def test_layernorm64(ops, rows, eps):
 
 @pytest.mark.parametrize("B,H,W,cin,cout,stride", [(2, 12, 20, 64, 64, 1), (1, 40, 70, 64, 64, 1), (2, 9, 13, 128, 64, 1),
                                                    (1, 11, 38, 128, 128, 1), (2, 12, 20, 64, 64, 2), (1, 33, 71, 64, 64, 2),
-                                                   (1, 64, 96, 64, 64, 1)])
+                                                   (1, 64, 96, 64, 64, 1), (4, 96, 320, 64, 64, 1), (2, 88, 304, 128, 128, 1),
+                                                   (8, 11, 38, 128, 128, 1), (2, 50, 330, 64, 64, 2)])
 def test_conv3x3(ops, B, H, W, cin, cout, stride):
     x, w, b = rnd(B, cin, H, W, seed=17), rnd(cout, cin, 3, 3, seed=18) / math.sqrt(9 * cin), rnd(cout, seed=19)
     y = F.conv2d(x.double(), w.double(), b.double(), stride, 1)
@@ -98,6 +99,9 @@ def test_conv3x3(ops, B, H, W, cin, cout, stride):
     close(got.permute(0, 3, 1, 2), ref, 2e-5, "conv3x3")
     got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w9.to(DEV), None, cout, stride, 1.0)
     close(got.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, stride, 1), 2e-5, "conv3x3-plain")
+    if stride == 1:      # AvgPool2d(2,2) fused into the epilogue (or the two-kernel fallback on tiny maps)
+        got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w9.to(DEV), b.to(DEV), cout, 1, 0.01, pool=2)
+        close(got.permute(0, 3, 1, 2), F.avg_pool2d(F.leaky_relu(y, 0.01), 2, 2), 2e-5, "conv3x3-pool")
 
 
 def test_stem_block(ops):
