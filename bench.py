@@ -191,6 +191,14 @@ def main():
 
     if rank == 0:
         conv = ct.summary()
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if "conv3x3_kernel<1, 2, 32>" in k)
+        except Exception:
+            pass
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
         iters = world * w["B"] * args.steps
         line = {
@@ -204,7 +212,9 @@ def main():
             "agent_steps_per_s": iters * w["steps"] / elapsed,
             "roofline": {"kernel": "conv3x3_kernel<1,2,32> (NHWC 3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
+                         "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                          "launches_per_step": conv["launches"] / args.steps,
                          "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                          "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9,

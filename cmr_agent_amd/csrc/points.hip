@@ -185,6 +185,59 @@ __global__ __launch_bounds__(256) void nearest_kernel(const float* __restrict__ 
   }
 }
 
+// three nearest candidates per query (ascending distance) + normalised inverse-distance weights
+// (PointNetFeaturePropagation, pointnet_util.py:287-295): idx int32 GLOBAL rows [B*Nq,3], w [B*Nq,3]
+__global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__ q4, const float* __restrict__ c4,
+                                                       int32_t* __restrict__ idx, float* __restrict__ wgt, int Nq, int Nc) {
+  __shared__ __attribute__((aligned(16))) float tile[1024 * 4];
+  const int b = blockIdx.y;
+  const int qi = blockIdx.x * 256 + threadIdx.x;
+  f32x4 qp = {0.f, 0.f, 0.f, 0.f};
+  if (qi < Nq) qp = *reinterpret_cast<const f32x4*>(q4 + ((int64_t)b * Nq + qi) * 4);
+  float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+  int i0 = 0, i1 = 0, i2 = 0;
+  for (int c0 = 0; c0 < Nc; c0 += 1024) {
+    const int n = min(1024, Nc - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+      *reinterpret_cast<f32x4*>(&tile[i * 4]) = *reinterpret_cast<const f32x4*>(c4 + ((int64_t)b * Nc + c0 + i) * 4);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const f32x4 cp = *reinterpret_cast<const f32x4*>(&tile[i * 4]);
+      const float d = sqdist3(qp[0], qp[1], qp[2], cp[0], cp[1], cp[2]);
+      const int id = c0 + i;
+      if (d < d2) {
+        if (d < d1) {
+          d2 = d1; i2 = i1;
+          if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = id; }
+          else { d1 = d; i1 = id; }
+        } else { d2 = d; i2 = id; }
+      }
+    }
+  }
+  if (qi < Nq) {
+    const float r0 = 1.0f / (d0 + 1e-8f), r1 = 1.0f / (d1 + 1e-8f), r2 = 1.0f / (d2 + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    const int64_t o = ((int64_t)b * Nq + qi) * 3;
+    idx[o] = (int32_t)((int64_t)b * Nc + i0); idx[o + 1] = (int32_t)((int64_t)b * Nc + i1); idx[o + 2] = (int32_t)((int64_t)b * Nc + i2);
+    wgt[o] = r0 / norm; wgt[o + 1] = r1 / norm; wgt[o + 2] = r2 / norm;
+  }
+}
+
+// out[r, c] = sum_j w[r, j] * src[idx[r, j], c], j = 0..2
+__global__ __launch_bounds__(256) void weighted_gather3_kernel(const float* __restrict__ src, int64_t lds,
+                                                               const int32_t* __restrict__ idx, const float* __restrict__ wgt,
+                                                               float* __restrict__ out, int64_t ldo, int64_t rows, int C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = e / C;
+  if (r >= rows) return;
+  const int c = (int)(e % C);
+  const float a0 = src[(int64_t)idx[r * 3] * lds + c] * wgt[r * 3];
+  const float a1 = src[(int64_t)idx[r * 3 + 1] * lds + c] * wgt[r * 3 + 1];
+  const float a2 = src[(int64_t)idx[r * 3 + 2] * lds + c] * wgt[r * 3 + 2];
+  out[r * ldo + c] = (a0 + a1) + a2;
+}
+
 // ---- row gathers ------------------------------------------------------------------------------
 __device__ __forceinline__ int64_t map_row(const int32_t* idx, int64_t div, int64_t r) {
   return idx ? (int64_t)idx[r] : (div > 1 ? r / div : r);
@@ -472,6 +525,20 @@ extern "C" int cmr_nearest_f32(const float* q4, const float* c4, int32_t* out_gl
   CMR_REQUIRE(q4 && c4 && (out_global || out_local) && B > 0 && B <= 65535 && Nq > 0 && Nc > 0);
   hipLaunchKernelGGL(nearest_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, q4, c4, out_global, out_local, Nq,
                      Nc);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_three_nn_f32(const float* q4, const float* c4, int32_t* idx, float* wgt, int B, int Nq, int Nc,
+                                hipStream_t stream) {
+  CMR_REQUIRE(q4 && c4 && idx && wgt && B > 0 && B <= 65535 && Nq > 0 && Nc >= 3);
+  hipLaunchKernelGGL(three_nn_kernel, dim3((Nq + 255) / 256, B), dim3(256), 0, stream, q4, c4, idx, wgt, Nq, Nc);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_weighted_gather3_f32(const float* src, int64_t lds, const int32_t* idx, const float* wgt, float* out,
+                                        int64_t ldo, int64_t rows, int C, hipStream_t stream) {
+  CMR_REQUIRE(src && idx && wgt && out && rows > 0 && C > 0);
+  hipLaunchKernelGGL(weighted_gather3_kernel, GRID1D(rows * C), dim3(256), 0, stream, src, lds, idx, wgt, out, ldo, rows, C);
   return cmr_launch_status();
 }
 

@@ -239,6 +239,21 @@ def gather_rows(src, idx, C=None, out=None):
     return out
 
 
+def three_nn(q4, c4, B, Nq, Nc):
+    idx = torch.empty((B * Nq, 3), dtype=torch.int32, device=q4.device)
+    wgt = torch.empty((B * Nq, 3), dtype=f32, device=q4.device)
+    _lib.call("cmr_three_nn_f32", _p(q4), _p(c4), _p(idx), _p(wgt), B, Nq, Nc, _stream())
+    return idx, wgt
+
+
+def weighted_gather3(src, idx, wgt):
+    _rows(src)
+    rows, C = idx.shape[0], src.shape[1]
+    out = torch.empty((rows, C), dtype=f32, device=src.device)
+    _lib.call("cmr_weighted_gather3_f32", _p(src), _ld(src), _p(idx), _p(wgt), _p(out), C, rows, C, _stream())
+    return out
+
+
 def fps(xyz4, start, B, N, npoint):
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz4.device)
     _lib.call("cmr_fps_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _stream())

@@ -137,6 +137,13 @@ int cmr_ball_query_f32(const float* xyz4, const float* new4, int64_t* out, int B
                        float radius2, hipStream_t stream);
 int cmr_square_distance_f32(const float* a4, const float* b4, float* out, int B, int N, int M, hipStream_t stream);
 
+/* pointnet_util.py:287-296 (PointNetFeaturePropagation): 3 nearest of xyz2 + inverse-distance weights, then
+ * the weighted sum of their feature rows. */
+int cmr_three_nn_f32(const float* q4, const float* c4, int32_t* idx, float* wgt, int B, int Nq, int Nc,
+                     hipStream_t stream);
+int cmr_weighted_gather3_f32(const float* src, int64_t lds, const int32_t* idx, const float* wgt, float* out, int64_t ldo,
+                             int64_t rows, int C, hipStream_t stream);
+
 /* per-batch max / mean over rows.  CMRAgent.py:95 (torch.max over points), environment.py:46,88 (pc.mean). */
 int64_t cmr_colreduce_workspace_bytes(int B, int N, int C);
 int cmr_colmax_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C,

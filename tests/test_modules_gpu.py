@@ -90,3 +90,25 @@ def test_dataset_side_ops_on_device():
     pc4 = ops.planar_to_rows(pc.unsqueeze(0).contiguous().to(DEV), 4)
     _, local = ops.nearest(pc4, nodes4, 1, 3000, 100)
     assert (local.cpu().numpy()[0] == fx["pt2node"]["sample"]).mean() > 0.999
+
+
+@pytest.mark.parametrize("name", ["set_abstraction", "set_abstraction_msg", "feature_propagation"])
+def test_pointnet2_modules_vs_golden(name):
+    """PointNetSetAbstraction / ...Msg / FeaturePropagation (pointnet_util.py:156-308) on the device ops."""
+    from cmr_agent_amd.models import pointnet_util as U
+    ctor = {"set_abstraction": lambda: U.PointNetSetAbstraction(32, 0.4, 16, 3 + 8, [16, 32], False),
+            "set_abstraction_msg": lambda: U.PointNetSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]]),
+            "feature_propagation": lambda: U.PointNetFeaturePropagation(8 + 16, [32, 16])}[name]
+    m = ctor()
+    sd = hashfill.make_state_dict(SPECS[name], name + "/")
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    m = m.to(DEV).eval()
+    i = {k: v.to(DEV) for k, v in C.OP_CASES[name]["inputs"]().items()}
+    with torch.no_grad():
+        if name == "feature_propagation":
+            out = {"y": m(i["xyz1"], i["xyz2"], i["p1"], i["p2"])}
+        else:
+            a, b = m(i["xyz"], i["points"], start_idx=i["start"])
+            out = {"new_xyz": a, "new_points": b}
+    G.assert_case(name, out, atol=2e-5, rtol=1e-4)
