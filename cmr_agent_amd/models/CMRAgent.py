@@ -56,7 +56,44 @@ class CMRAgent(Planned):
         for name in ("policy_r", "policy_t", "value"):
             m = getattr(self, name)
             p[name] = [_pack.lin(m[0]), _pack.lin(m[2]), _pack.lin(m[4])]
+        # 3-D branch, layers 1..3: the input is cat([feat, broadcast(global max)]) (CMRAgent.py:95-99).  Split every
+        # weight that multiplies it into the streamed half (feat) and the per-sample half (max), which becomes a
+        # per-batch bias computed by a skinny GEMM each step.
+        f = self.config.embed_dim
+        p["s3d"] = []
+        for i in (1, 2, 3):
+            q = self.state_3d_embed[i].plan()
+            w1, b1 = q["l1"]
+            ent = dict(w1a=w1[:, :f].contiguous(), w1b=w1[:, f:].contiguous(), b1=b1, w2=q["l2"][0])
+            if q["sc"] is not None:
+                ent.update(wsca=q["sc"][0][:, :f].contiguous(), wscb=q["sc"][0][:, f:].contiguous(), b2=q["b2f"])
+            else:   # identity shortcut: the max half of the residual is per-sample too -> selection matrix [0; I]
+                e = torch.zeros((2 * f, f), dtype=w1.dtype, device=w1.device)
+                e[f:, :] = torch.eye(f, dtype=w1.dtype, device=w1.device)
+                ent.update(wsca=None, wscb=e, b2=q["b2f"])
+            p["s3d"].append(ent)
         return p
+
+    def _embed_3d(self, state3d_rows, B, N):
+        """-> [B, 2f] global max of the last block, one fused kernel per ConvBNReLURes1D block."""
+        p = self.plan()
+        layers = self.state_3d_embed
+        q0 = layers[0].plan()
+        r = ops.cbr_block(state3d_rows, q0["l1"][0], q0["l1"][1], q0["l2"][0], q0["b2f"], q0["sc"][0], 0.2,
+                          rows_per_batch=N, want_colmax=True)
+        if r is None:
+            return None
+        feat, g = r
+        for i, ent in enumerate(p["s3d"]):
+            b1b = ops.linear(g, ent["w1b"], ent["b1"])                   # [B, 2f] per-sample hidden bias
+            b2b = ops.linear(g, ent["wscb"], ent["b2"])                  # [B, co] per-sample output bias
+            last = i == 2
+            r = ops.cbr_block(feat, ent["w1a"], b1b, ent["w2"], b2b, ent["wsca"], 0.2, rows_per_batch=N,
+                              want_y=not last, want_colmax=True)
+            if r is None:
+                return None
+            feat, g = r
+        return g
 
     # ------------------------------------------------------------------------------------------
     def forward_cl(self, state2d, state3d_rows, B, N):
@@ -74,12 +111,14 @@ class CMRAgent(Planned):
                     raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (x.shape[1], x.shape[2], kh, kw))
                 x = ops.avgpool(x, kh, kw)
         e2d = ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
-        layers = self.state_3d_embed
-        feat = layers[0].rows(state3d_rows)
-        for i in (1, 2, 3):
-            g = ops.colmax(feat, B, N)                       # torch.max over points, broadcast back (:95-99)
-            feat = layers[i].rows(feat, x2=g, div2=N)
-        e3d = ops.colmax(feat, B, N)
+        e3d = self._embed_3d(state3d_rows, B, N)
+        if e3d is None:                                      # shapes the fused block kernel is not built for
+            layers = self.state_3d_embed
+            feat = layers[0].rows(state3d_rows)
+            for i in (1, 2, 3):
+                g = ops.colmax(feat, B, N)                   # torch.max over points, broadcast back (:95-99)
+                feat = layers[i].rows(feat, x2=g, div2=N)
+            e3d = ops.colmax(feat, B, N)
         out = []
         for name in ("policy_r", "policy_t", "value"):
             l0, l1, l2 = p[name]

@@ -78,13 +78,19 @@ class ConvBNReLURes1D(Planned):
         w1, b1 = _pack.pad_rows(w1, b1)                      # hidden width padded to 4 (extra units are 0)
         w2, b2 = _pack.lin(self.net[3], self.net[4])         # [cout, cin_pad]
         sc = None if isinstance(self.shortcut, nn.Identity) else _pack.lin(self.shortcut[0], self.shortcut[1])
-        return dict(l1=(w1, b1), l2=(w2, b2), sc=sc)
+        b2f = b2 if sc is None else (b2 + sc[1]).contiguous()          # both BN shifts, for the fused block kernel
+        return dict(l1=(w1, b1), l2=(w2, b2), sc=sc, b2f=b2f)
 
     def rows(self, x1, x2=None, idx2=None, div2=1, res_rows=None):
         """LReLU(net(x) + shortcut(x)) with x = [x1 | x2[map]] never materialised.  With an identity
         shortcut and two sources the caller supplies the concatenated rows as `res_rows`."""
         self._require_eval()
         p = self.plan()
+        # one kernel for the whole block when the shape is instantiated (hidden activations never leave registers)
+        fused = ops.cbr_block(x1, p["l1"][0], p["l1"][1], p["l2"][0], p["b2f"], None if p["sc"] is None else p["sc"][0],
+                              self.SLOPE, x2=x2, idx2=idx2, div2=div2)
+        if fused is not None:
+            return fused[0]
         hid = ops.linear(x1, *p["l1"], x2=x2, idx2=idx2, div2=div2, act=ops.ACT_LRELU, act_param=self.SLOPE)
         if p["sc"] is not None:
             res = ops.linear(x1, *p["sc"], x2=x2, idx2=idx2, div2=div2)

@@ -55,6 +55,37 @@ def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, ac
     return out
 
 
+def cbr_block(x1, w1, b1, w2, b2, wsc, slope, x2=None, idx2=None, div2=1, rows_per_batch=None, want_y=True,
+              want_colmax=False):
+    """Fused ConvBNReLURes1D block.  b1 / b2: [C] shared or [B, C] per batch.  Returns (y or None,
+    colmax [B, co] or None), or None when the shape is not instantiated (caller composes linears)."""
+    _rows(x1, "x1")
+    rows, k1 = x1.shape
+    kx = k1 + (x2.shape[1] if x2 is not None else 0)
+    ch, co = w1.shape[0], w2.shape[0]
+    if w1.shape[1] != kx or w2.shape[1] != ch or (wsc is not None and tuple(wsc.shape) != (co, kx)):
+        raise ValueError("cbr_block: inconsistent weight shapes")
+    rpb = rows if rows_per_batch is None else rows_per_batch
+    B = rows // rpb
+    if want_colmax and (rpb % 32 or rows % rpb):
+        return None
+    y = torch.empty((rows, co), dtype=f32, device=x1.device) if want_y else None
+    ntiles = (rows + 31) // 32
+    part = torch.empty((ntiles, co), dtype=f32, device=x1.device) if want_colmax else None
+    s1 = b1.stride(0) if b1.dim() == 2 else 0
+    s2 = b2.stride(0) if b2.dim() == 2 else 0
+    rc = _lib.call("cmr_cbr_block_f32", _p(x1), _ld(x1), k1, _p(x2), _ld(x2) if x2 is not None else 0, _p(_i32(idx2)),
+                   int(div2), kx, ch, co, _p(w1), _p(b1), s1, _p(w2), _p(b2), s2, _p(wsc), _p(y), co, _p(part), rows, rpb,
+                   float(slope), _stream(), allow_unsupported=True)
+    if rc == _lib.UNSUPPORTED:
+        return None
+    cm = None
+    if want_colmax:
+        cm = torch.empty((B, co), dtype=f32, device=x1.device)
+        _lib.call("cmr_colmax_partials_f32", _p(part), _p(cm), B, rpb // 32, co, _stream())
+    return y, cm
+
+
 def layernorm64(x, gamma, beta, eps, res=None, out=None):
     _rows(x, "x")
     if out is None:

@@ -45,6 +45,19 @@ int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_
                    int64_t res_mod, float* y, int64_t ldy, int64_t rows, int n_out, int act, float act_param,
                    hipStream_t stream);
 
+/* Whole ConvBNReLURes1D block in one kernel (PointNN.py:260-282 with BN folded):
+ *   hid = lrelu(W1 x + b1);  y = lrelu(W2 hid + b2 + (Wsc x | x)),  x = [x1[:, :k1] | x2[map][:, :kx-k1]].
+ * The hidden activations stay in MFMA accumulator registers (transposed GEMM: accumulators of layer 1 are the
+ * B-operand fragments of layer 2).  b1 / b2 may be per-batch rows (stride > 0: the broadcast global max-pool
+ * concatenation of CMRAgent.py:95-99 folded into the bias); colmax_part receives per-32-row-tile channel maxima
+ * of y (CMRAgent.py:95) and is reduced by cmr_colmax_partials_f32.  (kx, ch, co, shortcut) must be one of the
+ * instantiated shapes, otherwise CMR_EUNSUPPORTED is returned and the caller composes cmr_linear_f32 calls. */
+int cmr_cbr_block_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_t ld2, const int32_t* idx2,
+                      int64_t div2, int kx, int ch, int co, const float* w1, const float* b1, int64_t b1_stride,
+                      const float* w2, const float* b2, int64_t b2_stride, const float* wsc, float* y, int64_t ldy,
+                      float* colmax_part, int64_t rows, int64_t rows_per_batch, float slope, hipStream_t stream);
+int cmr_colmax_partials_f32(const float* part, float* out, int B, int tiles_per_batch, int C, hipStream_t stream);
+
 /* y = LayerNorm_64(x) * gamma + beta (+ res).  ImageViT.py:139-140, IMGPCEncoder.py:86-87 (eps 1e-6),
  * LinearAttention.py:33-34,64,69,71 (eps 1e-5, residual x + norm2(.)). */
 int cmr_layernorm64_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, const float* res,
