@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void project_scatter_kernel(const float* __res
 __global__ __launch_bounds__(256) void observation_finalize_kernel(const float* __restrict__ img_feat,
                                                                    const float* __restrict__ acc,
                                                                    const float* __restrict__ cnt, float* __restrict__ state2d,
-                                                                   int64_t cells, int write_img) {
+                                                                   float* __restrict__ proj, int64_t cells, int write_img) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t cell = e >> 4;
   if (cell >= cells) return;
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void observation_finalize_kernel(const float* 
   f32x4 a = *reinterpret_cast<const f32x4*>(acc + cell * 64 + c);
   a[0] /= n; a[1] /= n; a[2] /= n; a[3] /= n;
   *reinterpret_cast<f32x4*>(state2d + cell * 128 + 64 + c) = a;
+  if (proj) *reinterpret_cast<f32x4*>(proj + cell * 64 + c) = a;
   if (write_img) *reinterpret_cast<f32x4*>(state2d + cell * 128 + c) = *reinterpret_cast<const f32x4*>(img_feat + cell * 64 + c);
 }
 
@@ -187,12 +188,12 @@ extern "C" int cmr_project_scatter_f32(const float* pc4, const float* feat, cons
   return cmr_launch_status();
 }
 
-extern "C" int cmr_observation_finalize_f32(const float* img_feat, const float* acc, const float* cnt, float* state2d, int B,
-                                            int h, int w, int write_img, hipStream_t stream) {
+extern "C" int cmr_observation_finalize_f32(const float* img_feat, const float* acc, const float* cnt, float* state2d,
+                                            float* proj, int B, int h, int w, int write_img, hipStream_t stream) {
   CMR_REQUIRE(img_feat && acc && cnt && state2d && B > 0 && h > 0 && w > 0);
   const int64_t cells = (int64_t)B * h * w;
   hipLaunchKernelGGL(observation_finalize_kernel, dim3((unsigned)((cells * 16 + 255) / 256)), dim3(256), 0, stream,
-                     img_feat, acc, cnt, state2d, cells, write_img);
+                     img_feat, acc, cnt, state2d, proj, cells, write_img);
   return cmr_launch_status();
 }
 

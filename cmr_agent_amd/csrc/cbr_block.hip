@@ -191,18 +191,21 @@ __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
 }
 
 // out[b][c] = max over the tiles of batch b of part[tile][c]  (tiles_per_batch consecutive tiles per batch)
-__global__ __launch_bounds__(256) void colmax_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int tiles_per_batch, int C) {
-  __shared__ float sm[256];
+__global__ __launch_bounds__(1024) void colmax_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               int tiles_per_batch, int C) {
+  __shared__ float sm[1024];
   const int b = blockIdx.x, cblk = blockIdx.y * 64;
-  const int c = cblk + (threadIdx.x & 63), grp = threadIdx.x >> 6;        // 4 row groups x 64 channels
+  const int c = cblk + (threadIdx.x & 63), grp = threadIdx.x >> 6;        // 16 tile groups x 64 channels
   float m = -INFINITY;
   if (c < C)
-    for (int t = grp; t < tiles_per_batch; t += 4) m = fmaxf(m, part[((int64_t)b * tiles_per_batch + t) * C + c]);
+    for (int t = grp; t < tiles_per_batch; t += 16) m = fmaxf(m, part[((int64_t)b * tiles_per_batch + t) * C + c]);
   sm[threadIdx.x] = m;
   __syncthreads();
-  if (grp == 0 && c < C) out[(int64_t)b * C + c] = fmaxf(fmaxf(sm[threadIdx.x], sm[threadIdx.x + 64]),
-                                                          fmaxf(sm[threadIdx.x + 128], sm[threadIdx.x + 192]));
+  if (grp == 0 && c < C) {
+#pragma unroll
+    for (int g = 1; g < 16; ++g) m = fmaxf(m, sm[threadIdx.x + 64 * g]);
+    out[(int64_t)b * C + c] = m;
+  }
 }
 
 template <int KX, int CH, int CO, bool CONV_SC>
@@ -254,6 +257,6 @@ extern "C" int cmr_cbr_block_f32(const float* x1, int64_t ld1, int k1, const flo
 extern "C" int cmr_colmax_partials_f32(const float* part, float* out, int B, int tiles_per_batch, int C,
                                        hipStream_t stream) {
   CMR_REQUIRE(part && out && B > 0 && B <= 65535 && tiles_per_batch > 0 && C > 0);
-  hipLaunchKernelGGL(colmax_partials_kernel, dim3(B, (C + 63) / 64), dim3(256), 0, stream, part, out, tiles_per_batch, C);
+  hipLaunchKernelGGL(colmax_partials_kernel, dim3(B, (C + 63) / 64), dim3(1024), 0, stream, part, out, tiles_per_batch, C);
   return cmr_launch_status();
 }

@@ -68,10 +68,14 @@ def observation_from_a_pose(data, RT):
     dev = ctx.pc4.device
     state3d = torch.empty((B * N, 8), dtype=torch.float32, device=dev)
     state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev)
+    proj = torch.empty((B, h, w, 64), dtype=torch.float32, device=dev)
     ops.project_scatter(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.acc, ctx.cnt,
                         state3d)
-    ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, B, h, w, True)
+    ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, proj, B, h, w, True)
     obs2d = state2d.permute(0, 3, 1, 2)
+    # the agent's first conv is linear in its input: hand it the two halves separately so that the image half
+    # (constant over the steps of one registration) is convolved once (CMRAgent.forward_cl)
+    obs2d._cmr_split = (ctx.img, proj)
     obs3d = state3d.view(B, N, 8)[:, :, :5].permute(0, 2, 1)
     return obs2d, obs3d
 

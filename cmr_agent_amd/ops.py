@@ -327,9 +327,9 @@ def project_scatter(pc4, feat, overlap_u8, pose, K, mean4, B, N, h, w, acc, cnt,
               _p(state3d), B, N, h, w, _stream())
 
 
-def observation_finalize(img_feat, acc, cnt, state2d, B, h, w, write_img):
-    _lib.call("cmr_observation_finalize_f32", _p(img_feat), _p(acc), _p(cnt), _p(state2d), B, h, w, int(write_img),
-              _stream())
+def observation_finalize(img_feat, acc, cnt, state2d, proj, B, h, w, write_img):
+    _lib.call("cmr_observation_finalize_f32", _p(img_feat), _p(acc), _p(cnt), _p(state2d), _p(proj), B, h, w,
+              int(write_img), _stream())
 
 
 def pose_step(pose, act_r, act_t, r_steps, t_steps, six_dof):

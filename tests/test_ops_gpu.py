@@ -293,7 +293,9 @@ def test_observation_and_pose(ops):
     st2 = torch.empty(B, h, w, 128, device=DEV)
     ops.project_scatter(pc4, feat.permute(0, 2, 1).reshape(-1, 64).contiguous().to(DEV), ov.to(torch.uint8).reshape(-1).to(DEV),
                         pose_g, K.to(DEV), mean4, B, N, h, w, acc, cnt, st3)
-    ops.observation_finalize(imf.permute(0, 2, 3, 1).contiguous().to(DEV), acc, cnt, st2, B, h, w, True)
+    proj = torch.empty(B, h, w, 64, device=DEV)
+    ops.observation_finalize(imf.permute(0, 2, 3, 1).contiguous().to(DEV), acc, cnt, st2, proj, B, h, w, True)
+    assert torch.equal(proj, st2[..., 64:])
     got3 = st3.view(B, N, 8).permute(0, 2, 1).cpu()
     assert float((got3[:, :5] == s3).float().mean()) > 0.9995 and float(got3[:, 5:].abs().max()) == 0
     got2 = st2.permute(0, 3, 1, 2).cpu()
