@@ -13,23 +13,28 @@ namespace {
 
 constexpr int DH = 8, NH = 8, CH = 64;
 
-__global__ __launch_bounds__(64) void mha_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
-                                                 int64_t ldk, const float* __restrict__ v, int64_t ldv,
-                                                 float* __restrict__ o, int64_t ldo, int Tq, int Tk, float scale) {
+// 256 threads = 64 queries of one (batch, head) x 4 lanes; lane `sub` of a query takes keys sub, sub+4, ...
+// and the four partial (max, sum, weighted value) states are merged with two xor-shuffles each.
+constexpr int MHA_Q = 64, MHA_SPLIT = 4;
+__global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
+                                                  int64_t ldk, const float* __restrict__ v, int64_t ldv,
+                                                  float* __restrict__ o, int64_t ldo, int Tq, int Tk, float scale) {
   extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tk][8] then V_h [Tk][8]
   float* ks = kv;
   float* vs = kv + (size_t)Tk * DH;
-  const int head = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z;
   const float* kb = k + (int64_t)b * Tk * ldk + head * DH;
   const float* vb = v + (int64_t)b * Tk * ldv + head * DH;
-  for (int e = lane; e < Tk * 2; e += 64) {
+  for (int e = threadIdx.x; e < Tk * 2; e += 256) {
     const int t = e >> 1, half = (e & 1) * 4;
     *reinterpret_cast<f32x4*>(&ks[t * DH + half]) = *reinterpret_cast<const f32x4*>(kb + (int64_t)t * ldk + half);
     *reinterpret_cast<f32x4*>(&vs[t * DH + half]) = *reinterpret_cast<const f32x4*>(vb + (int64_t)t * ldv + half);
   }
   __syncthreads();
-  const int tq = blockIdx.x * 64 + lane;
-  if (tq >= Tq) return;
+  const int sub = threadIdx.x & (MHA_SPLIT - 1);
+  int tq = blockIdx.x * MHA_Q + (threadIdx.x >> 2);
+  const bool qvalid = tq < Tq;
+  if (!qvalid) tq = Tq - 1;                       // keep the lane alive for the shuffles
   const float* qp = q + ((int64_t)b * Tq + tq) * ldq + head * DH;
   const f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
   auto score = [&](int t) {
@@ -41,10 +46,12 @@ __global__ __launch_bounds__(64) void mha_kernel(const float* __restrict__ q, in
     return s * scale;
   };
   float m = -INFINITY;
-  for (int t = 0; t < Tk; ++t) m = fmaxf(m, score(t));
+  for (int t = sub; t < Tk; t += MHA_SPLIT) m = fmaxf(m, score(t));
+  m = fmaxf(m, __shfl_xor(m, 1));
+  m = fmaxf(m, __shfl_xor(m, 2));
   float l = 0.f;
   float acc[DH] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < Tk; ++t) {
+  for (int t = sub; t < Tk; t += MHA_SPLIT) {
     const float p = expf(score(t) - m);
     l += p;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(&vs[t * DH]);
@@ -52,6 +59,14 @@ __global__ __launch_bounds__(64) void mha_kernel(const float* __restrict__ q, in
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i] += p * v0[i]; acc[4 + i] += p * v1[i]; }
   }
+  l += __shfl_xor(l, 1);
+  l += __shfl_xor(l, 2);
+#pragma unroll
+  for (int i = 0; i < DH; ++i) {
+    acc[i] += __shfl_xor(acc[i], 1);
+    acc[i] += __shfl_xor(acc[i], 2);
+  }
+  if (!qvalid || sub != 0) return;
   const float inv = 1.f / l;
   float* op = o + ((int64_t)b * Tq + tq) * ldo + head * DH;
   f32x4 o0 = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
@@ -153,7 +168,7 @@ extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t 
       return CMR_ELAUNCH;
   }
   dim3 grid((Tq + 63) / 64, NH, B);
-  hipLaunchKernelGGL(mha_kernel, grid, dim3(64), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
+  hipLaunchKernelGGL(mha_kernel, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
                      0.35355339059327373f);
   return cmr_launch_status();
 }

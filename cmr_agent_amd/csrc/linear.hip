@@ -332,6 +332,89 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a, cons
   }
 }
 
+// Split-K variant: one workgroup = one 32-row tile x 64 output channels, its 8 waves each take 1/8 of K
+// (operands straight from global / L2 in fragment layout, 4 k-groups prefetched ahead), partial
+// accumulators are summed through LDS and wave 0 runs the float4 epilogue.
+__global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[7 * 32 * 64];      // partial tiles of waves 1..7
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int col_base = blockIdx.y * 64;
+  const int64_t row0 = (int64_t)blockIdx.x * 32;
+  int64_t row = row0 + l31;
+  const bool valid = row < a.rows;
+  if (!valid) row = 0;
+  const int kper = a.k1 / 8;                          // multiple of 8 (k1 % 64 == 0)
+  const float* xp = a.x1 + row * a.ld1 + wave * kper + 4 * h;
+  const int c0n = col_base + l31, c1n = col_base + 32 + l31;
+  const float* w0 = a.w + (int64_t)(c0n < a.n_out ? c0n : 0) * a.ldw + wave * kper + 4 * h;
+  const float* w1 = a.w + (int64_t)(c1n < a.n_out ? c1n : 0) * a.ldw + wave * kper + 4 * h;
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+  const int ng = kper / 8;
+  f32x4 xc[4], wc0[4], wc1[4], xn[4], wn0[4], wn1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = i < ng ? i : 0;
+    xc[i] = *reinterpret_cast<const f32x4*>(xp + g * 8);
+    wc0[i] = *reinterpret_cast<const f32x4*>(w0 + g * 8);
+    wc1[i] = *reinterpret_cast<const f32x4*>(w1 + g * 8);
+  }
+  for (int g0 = 0; g0 < ng; g0 += 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = g0 + 4 + i < ng ? g0 + 4 + i : 0;
+      xn[i] = *reinterpret_cast<const f32x4*>(xp + g * 8);
+      wn0[i] = *reinterpret_cast<const f32x4*>(w0 + g * 8);
+      wn1[i] = *reinterpret_cast<const f32x4*>(w1 + g * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (g0 + i < ng) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[0] = cmr_mfma32(wc0[i][j], xc[i][j], acc[0]);
+          acc[1] = cmr_mfma32(wc1[i][j], xc[i][j], acc[1]);
+        }
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xc[i] = xn[i]; wc0[i] = wn0[i]; wc1[i] = wn1[i]; }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave - 1) * 32 + n * 16 + r) * 64 + lane] = acc[n][r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int w = 0; w < 7; ++w) acc[n][r] += red[(w * 32 + n * 16 + r) * 64 + lane];
+  if (!valid) return;
+  row = row0 + l31;
+  const int64_t rr = a.res ? (a.res_mod > 0 ? row % a.res_mod : row) : 0;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c0 = col_base + n * 32 + 8 * q + 4 * h;
+      if (c0 >= a.n_out) continue;
+      f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+      if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + c0);
+      if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + rr * a.ldres + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = cmr_act(v[e], a.act, a.act_param);
+      *reinterpret_cast<f32x4*>(a.y + row * a.ldy + c0) = v;
+    }
+}
+
 template <int NT, int G, int AC>
 int launch_linear_ws_ga(LinearArgs a, int nseg, hipStream_t stream) {
   const size_t smem = (size_t)32 * NT * (nseg * 8 * G + 4) * sizeof(float);
@@ -431,6 +514,13 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
     if (n_out <= 32 || (n_out > 64 && n_out <= 96)) return launch_linear_ws<1>(a, stream);
     if (n_out % 128 == 0) return launch_linear_ws<4>(a, stream);
     return launch_linear_ws<2>(a, stream);
+  }
+  // big K on few rows (ViT MLP fc2: K = 1024, patch embedding: K = 4096, a few thousand token rows): split K over
+  // the 8 waves of a workgroup so that a 32-row tile is not one wave's serial chain of K/2 MFMAs
+  if (vec_ok && !a.x2 && a.k1 % 64 == 0 && a.k1 >= 512 && rows <= 65536) {
+    dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((n_out + 63) / 64));
+    hipLaunchKernelGGL(linear_splitk_kernel, grid, dim3(512), 0, stream, a);
+    return cmr_launch_status();
   }
   const unsigned gy = (unsigned)((n_out + 63) / 64);
   if (rows >= 16384) {
