@@ -87,14 +87,15 @@ class ConvTimer:
         self._orig = ops.conv3x3
 
     def __enter__(self):
-        def timed(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1):
+        def timed(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None):
             B, H, W, cin = x.shape
-            tiled = stride == 1 and ((W + 31) // 32) * ((H + 7) // 8) * B * (cout // 64) >= 256
-            if not tiled:      # stride-2 and tiny-map launches run other kernels (conv.hip dispatch)
-                return self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool)
+            wino = (ops.WINOGRAD and u is not None and stride == 1 and out is None
+                    and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= 512)      # ops.conv3x3 dispatch
+            if not wino:       # stride-2 and small-map launches run the other conv kernels
+                return self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool, u)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            y = self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool)
+            y = self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool, u)
             e1.record()
             flops = 2.0 * 9 * cin * cout * B * H * W
             # algorithmic bytes: input once, output once, residual/table once, weights once
@@ -196,7 +197,7 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if "conv3x3_kernel<1, 2, 32>" in k)
+            traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if "conv3x3_wino_kernel" in k)
         except Exception:
             pass
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
@@ -210,9 +211,13 @@ def main():
                                    "10 agent steps, fp32, hash-filled weights", "batch_per_gpu": w["B"],
                        "parallelism": "batch sharding, no data-path collective"},
             "agent_steps_per_s": iters * w["steps"] / elapsed,
-            "roofline": {"kernel": "conv3x3_kernel<1,2,32> (NHWC 3x3 stride-1 implicit GEMM, v_mfma_f32_32x32x2_f32)",
+            "roofline": {"kernel": "conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
                          "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         # `achieved` counts the ALGORITHMIC work of the convolution (2*9*Cin*Cout flop per output pixel);
+                         # Winograd issues 16/36 of those multiplies on the matrix cores, which is how frac can pass 1
+                         "mfma_executed": achieved * 16.0 / 36.0, "mfma_executed_frac": achieved * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                          "launches_per_step": conv["launches"] / args.steps,

@@ -1,0 +1,250 @@
+// Stride-1 3x3 convolution by Winograd F(2x2, 3x3) on fp32 MFMA, fully fused (input transform, the 16
+// position GEMMs, output transform, bias / residual / LeakyReLU / table / optional 2x2 average pool).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A        16 multiplies per 2x2 outputs instead of 36
+//
+// The direct implicit-GEMM kernel (conv.hip) runs at ~75 % of the fp32 MFMA peak, so the remaining lever
+// is the multiply count itself.  U = G g G^T is precomputed per layer ([16][Cout][Cin], host side).
+//
+// Workgroup = 256 threads = 4 waves; output tile 8 rows x 16 cols = 4 x 8 Winograd tiles = ONE 32-wide
+// MFMA dimension (lane = Winograd tile); 64 output channels per workgroup (2 x 32).
+// Per 32-channel chunk of the input:
+//   1. the 10 x 18 pixel halo chunk goes global -> registers -> LDS (double buffered: the next chunk's
+//      loads are in flight during this chunk's GEMMs; ONE barrier per chunk);
+//   2. wave w multiplies the 4 positions (w, 0..3).  It never materialises V = B^T d B: per k-group a lane
+//      reads the two input rows its position row needs (8 x ds_read_b128 of ITS tile's patch), forms the 4
+//      transformed fragments with 8 float4 adds, and feeds 32 MFMAs.  A operand = U fragments straight
+//      from global / L2, prefetched one k-group ahead.
+// Epilogue: T[w][b] = sum_j M[w][j] A[j][b] in registers, exchanged through LDS, then wave q finishes
+// Y[a][b] = sum_i A^T[a][i] T[i][b] for register quad q (4 consecutive channels -> float4 stores).
+#include "cmr_common.h"
+
+namespace {
+
+struct WinoArgs {
+  const float* x; int B, H, W, Cin;
+  const float* u;      // [16][Cout][Cin]  (G g G^T, BN folded)
+  const float* bias; const float* res; const float* post;
+  float* y; int Cout; float slope; int pool;
+};
+
+constexpr int WT_TH = 8, WT_TW = 16;          // output tile
+constexpr int WT_HR = 10, WT_HC = 18;         // halo
+constexpr int WT_KC = 32, WT_LDP = 36;        // channels per chunk, padded LDS row (floats)
+constexpr int WT_C4 = WT_KC / 4;
+constexpr int WT_HALO_F4 = WT_HR * WT_HC * WT_C4;                 // 1440
+constexpr int WT_HL = (WT_HALO_F4 + 255) / 256;                   // 6
+constexpr int WT_HALO_FLOATS = WT_HR * WT_HC * WT_LDP;            // 6480
+constexpr int WT_SMEM_FLOATS = 16384;         // 64 KB: two halo buffers (12960) in the K loop, T (16384) after it
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, const int tiles_x, const int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int nco = a.Cout / 64;
+  int t = blockIdx.x;
+  const int ox0 = (t % tiles_x) * WT_TW; t /= tiles_x;
+  const int oy0 = (t % tiles_y) * WT_TH; t /= tiles_y;
+  const int b = t / nco, co0 = (t % nco) * 64;
+  const int iy0 = oy0 - 1, ix0 = ox0 - 1;
+  const int nchunk = a.Cin / WT_KC;
+  const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
+
+  f32x16 acc[4][2];                                 // [position column j][cout tile]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+
+  // halo chunk: global -> registers (batched, clamped addresses) -> LDS (zero padding applied there)
+  f32x4 hv[WT_HL];
+  auto load_halo = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < WT_HL; ++i) {
+      int e = tid + 256 * i;
+      if (e >= WT_HALO_F4) e = WT_HALO_F4 - 1;
+      const int p = e / WT_C4, c = e % WT_C4;
+      int iy = iy0 + p / WT_HC, ix = ix0 + p % WT_HC;
+      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      hv[i] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)iy * a.W + ix) * a.Cin + chunk * WT_KC + c * 4);
+    }
+  };
+  auto store_halo = [&](float* halo) {
+#pragma unroll
+    for (int i = 0; i < WT_HL; ++i) {
+      const int e = tid + 256 * i;
+      if (e < WT_HALO_F4) {
+        const int p = e / WT_C4, c = e % WT_C4;
+        const int iy = iy0 + p / WT_HC, ix = ix0 + p % WT_HC;
+        const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        *reinterpret_cast<f32x4*>(&halo[p * WT_LDP + c * 4]) = inb ? hv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+
+  // This wave multiplies the 4 positions (i = wave, j = 0..3).  Row i of B^T d needs two input rows:
+  //   i=0: d0 - d2   i=1: d1 + d2   i=2: d2 - d1   i=3: d1 - d3       (ra, rb, sign below)
+  const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+  const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+  const float sgn = wave == 1 ? 1.f : -1.f;
+  const int ty = l31 >> 3, tx = l31 & 7;
+  const int pa = ((2 * ty + ra) * WT_HC + 2 * tx) * WT_LDP + 4 * h;     // LDS float offsets of the two patch rows
+  const int pb = ((2 * ty + rb) * WT_HC + 2 * tx) * WT_LDP + 4 * h;
+  const float* ub = a.u + ((int64_t)(4 * wave) * a.Cout + co0 + l31) * a.Cin + 4 * h;   // position (wave, 0), cout l31
+  const int64_t upos = (int64_t)a.Cout * a.Cin;     // stride between positions
+
+  load_halo(0);
+  int buf = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    float* halo = smem + buf * WT_HALO_FLOATS;
+    store_halo(halo);
+    __syncthreads();                                // halo[buf] visible; everybody is past the GEMMs that read halo[buf] two chunks ago
+    if (chunk + 1 < nchunk) load_halo(chunk + 1);   // in flight during this chunk's GEMMs
+    const float* uc = ub + chunk * WT_KC;
+    f32x4 wc[4][2], wn[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) wc[j][n] = *reinterpret_cast<const f32x4*>(uc + j * upos + (int64_t)n * 32 * a.Cin);
+#pragma unroll
+    for (int kg = 0; kg < WT_KC / 8; ++kg) {
+      if (kg + 1 < WT_KC / 8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            wn[j][n] = *reinterpret_cast<const f32x4*>(uc + j * upos + (int64_t)n * 32 * a.Cin + (kg + 1) * 8);
+      }
+      // on-the-fly input transform of this lane's tile: t[c] = d[ra][c] +- d[rb][c], then the 4 columns j
+      f32x4 tc[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 da = *reinterpret_cast<const f32x4*>(&halo[pa + c * WT_LDP + kg * 8]);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(&halo[pb + c * WT_LDP + kg * 8]);
+        tc[c] = da + sgn * db;
+      }
+      f32x4 vf[4];
+      vf[0] = tc[0] - tc[2];
+      vf[1] = tc[1] + tc[2];
+      vf[2] = tc[2] - tc[1];
+      vf[3] = tc[1] - tc[3];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[j][0] = cmr_mfma32(wc[j][0][e], vf[j][e], acc[j][0]);
+          acc[j][1] = cmr_mfma32(wc[j][1][e], vf[j][e], acc[j][1]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) wc[j][n] = wn[j][n];
+    }
+    buf ^= 1;
+  }
+  __syncthreads();                                  // all waves done with the halo buffers before they are reused for T
+
+  // ---- output transform, stage 1 (registers): T[w][b] = sum_j M[w][j] A[j][b]
+  float* Ts = smem;                                 // [(w*2 + b)*2 + n][16][64]
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float t0 = (acc[0][n][r] + acc[1][n][r]) + acc[2][n][r];
+      const float t1 = (acc[1][n][r] - acc[2][n][r]) - acc[3][n][r];
+      Ts[(((wave * 2 + 0) * 2 + n) * 16 + r) * 64 + lane] = t0;
+      Ts[(((wave * 2 + 1) * 2 + n) * 16 + r) * 64 + lane] = t1;
+    }
+  __syncthreads();
+  // ---- stage 2: wave q finishes the 4 outputs (a, b) of register quad q of both cout tiles
+  const int q = wave;
+  const int Ho = a.H, Wo = a.W;
+  f32x4 yv[2][2][2];                                // [n][a][b]
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      f32x4 tw[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tw[w][e] = Ts[(((w * 2 + bb) * 2 + n) * 16 + 4 * q + e) * 64 + lane];
+      yv[n][0][bb] = (tw[0] + tw[1]) + tw[2];
+      yv[n][1][bb] = (tw[1] - tw[2]) - tw[3];
+    }
+  if (a.pool == 2) {
+    const int py = (oy0 >> 1) + ty, px = (ox0 >> 1) + tx;
+    const int hp2 = Ho >> 1, wp2 = Wo >> 1;
+    if (py < hp2 && px < wp2) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int c = co0 + n * 32 + 8 * q + 4 * h;
+        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bs = *reinterpret_cast<const f32x4*>(a.bias + c);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = yv[n][aa][bb][e] + bs[e];
+              s[e] += v > 0.f ? v : v * a.slope;
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] *= 0.25f;
+        *reinterpret_cast<f32x4*>(a.y + (((int64_t)b * hp2 + py) * wp2 + px) * a.Cout + c) = s;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int oy = oy0 + 2 * ty + aa, ox = ox0 + 2 * tx + bb;
+      if (oy >= Ho || ox >= Wo) continue;
+      const int64_t pix = (int64_t)oy * Wo + ox;
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int c = co0 + n * 32 + 8 * q + 4 * h;
+        const int64_t o = ((int64_t)b * Ho * Wo + pix) * a.Cout + c;
+        f32x4 v = yv[n][aa][bb];
+        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + c);
+        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+        if (a.post) v += *reinterpret_cast<const f32x4*>(a.post + pix * a.Cout + c);
+        *reinterpret_cast<f32x4*>(a.y + o) = v;
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
+                                         const float* res, const float* post, float* y, int Cout, float slope, int pool,
+                                         hipStream_t stream) {
+  CMR_REQUIRE(x && u && y && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0 && Cout >= 64);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(u) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) &&
+              (!res || cmr_aligned16(res)) && (!post || cmr_aligned16(post)));
+  CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post));
+  const int tiles_x = (W + WT_TW - 1) / WT_TW, tiles_y = (H + WT_TH - 1) / WT_TH;
+  const int64_t ntiles = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
+  CMR_REQUIRE(ntiles < 0x7fffffff);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            WT_SMEM_FLOATS * (int)sizeof(float)) != hipSuccess)
+      return CMR_ELAUNCH;
+    attr_set = true;
+  }
+  const WinoArgs a{x, B, H, W, Cin, u, bias, res, post, y, Cout, slope, pool};
+  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)ntiles), dim3(256), WT_SMEM_FLOATS * sizeof(float), stream, a,
+                     tiles_x, tiles_y);
+  return cmr_launch_status();
+}

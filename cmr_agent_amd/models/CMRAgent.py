@@ -55,9 +55,8 @@ class CMRAgent(Planned):
         # conv(W, [img | proj]) = conv(W[:, :f], img) + conv(W[:, f:], proj): the image half of the observation
         # does not change over the action_num steps of one registration
         f = self.config.embed_dim
-        w0, b0 = p["convs"][0][0]
-        p["conv0_img"] = (w0[:, :, :f].contiguous(), b0)
-        p["conv0_proj"] = w0[:, :, f:].contiguous()
+        p["conv0_img"] = _pack.conv9(e[0], e[1], cin_slice=slice(0, f))
+        p["conv0_proj"] = _pack.conv9(e[0], e[1], cin_slice=slice(f, 2 * f))
         p["img_cache"] = {}
         p["c24"], p["c26"] = _pack.lin(e[24]), _pack.lin(e[26])
         for name in ("policy_r", "policy_t", "value"):
@@ -111,18 +110,20 @@ class CMRAgent(Planned):
         p = self.plan()
         c = 2 * self.config.embed_dim
         x = state2d
-        for stage, ((wa, ba), (wb, bb)) in enumerate(p["convs"]):
+        for stage, ((wa, ba, ua), (wb, bb, ub)) in enumerate(p["convs"]):
             if stage == 0 and split is not None:
                 img_src, proj = split
                 key = (img_src.data_ptr(), img_src._version, tuple(img_src.shape))
                 cache = p["img_cache"]
                 if cache.get("key") != key:          # first step of a registration: image half of conv 0 (+ bias)
                     cache["key"] = key
-                    cache["val"] = ops.conv3x3(img_src, p["conv0_img"][0], p["conv0_img"][1], c, 1, 1.0)
-                x = ops.conv3x3(proj, p["conv0_proj"], None, c, 1, SLOPE, res=cache["val"])
+                    wi, bi, ui = p["conv0_img"]
+                    cache["val"] = ops.conv3x3(img_src, wi, bi, c, 1, 1.0, u=ui)
+                wp, _, up = p["conv0_proj"]
+                x = ops.conv3x3(proj, wp, None, c, 1, SLOPE, res=cache["val"], u=up)
             else:
-                x = ops.conv3x3(x, wa, ba, c, 1, SLOPE)
-            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE, pool=2 if stage < 3 else 1)     # AvgPool2d(2,2) in the epilogue
+                x = ops.conv3x3(x, wa, ba, c, 1, SLOPE, u=ua)
+            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE, pool=2 if stage < 3 else 1, u=ub)     # AvgPool2d(2,2) in the epilogue
             if stage == 3:
                 kh, kw = self.config.image_H // 8, self.config.image_W // 8
                 if (x.shape[1], x.shape[2]) != (kh, kw):

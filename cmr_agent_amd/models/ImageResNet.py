@@ -68,7 +68,7 @@ class ResidualBlock(Planned):
         if p["stem"]:
             assert post is None
             return ops.stem_block(x, p["wa"], p["ba"], p["w3"], p["w1"], p["bb"], self.SLOPE)
-        t = ops.conv3x3(x, p["a"][0], p["a"][1], self.inchannel, self.stride, self.SLOPE)
+        t = ops.conv3x3(x, p["a"][0], p["a"][1], self.inchannel, self.stride, self.SLOPE, u=p["a"][2])
         sc = p["sc"]
         if sc is None:
             res = x
@@ -77,7 +77,7 @@ class ResidualBlock(Planned):
             res = ops.linear(x.view(B * H * W, c), sc[1], sc[2]).view(B, H, W, self.outchannel)
         else:
             res = ops.conv3x3(x, sc[1], sc[2], self.outchannel, 2, 1.0)
-        return ops.conv3x3(t, p["b"][0], p["b"][1], self.outchannel, 1, self.SLOPE, res=res, post=post)
+        return ops.conv3x3(t, p["b"][0], p["b"][1], self.outchannel, 1, self.SLOPE, res=res, post=post, u=p["b"][2])
 
     def forward(self, x):
         if self.inchannel == 3:

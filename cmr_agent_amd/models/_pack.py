@@ -57,11 +57,24 @@ def lin(layer, bn=None):
     return pad_rows(pad_k(w.reshape(w.shape[0], -1)), b.contiguous())
 
 
-def conv9(conv, bn=None):
-    """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout])."""
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def winograd_u(w):
+    """[Cout, Cin, 3, 3] -> U = G g G^T as [16, Cout, Cin] (Winograd F(2x2,3x3) weight transform)."""
+    g = torch.tensor(_WINO_G, dtype=w.dtype, device=w.device)
+    u = torch.einsum("ik,ockl,jl->ijoc", g, w, g)
+    return u.reshape(16, w.shape[0], w.shape[1]).contiguous()
+
+
+def conv9(conv, bn=None, cin_slice=None):
+    """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout], U [16, Cout, Cin] for the Winograd kernel).
+    cin_slice restricts the input channels (the agent's image / projection halves)."""
     w, b = folded(conv, bn)
+    if cin_slice is not None:
+        w = w[:, cin_slice]
     co, ci = w.shape[0], w.shape[1]
-    return w.permute(2, 3, 0, 1).reshape(9, co, ci).contiguous(), b.contiguous()
+    return w.permute(2, 3, 0, 1).reshape(9, co, ci).contiguous(), b.contiguous(), winograd_u(w)
 
 
 class Planned(nn.Module):

@@ -95,13 +95,32 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
     return out
 
 
-def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1):
+WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
+
+
+def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
+    """Stride-1 3x3 convolution through the fused Winograd F(2x2,3x3) kernel; u [16,Cout,Cin] = G g G^T."""
+    B, H, W, cin = x.shape
+    if not x.is_contiguous() or tuple(u.shape) != (16, cout, cin):
+        raise ValueError("conv3x3_wino: bad operand layout")
+    hp, wp = (H // 2, W // 2) if pool == 2 else (H, W)
+    y = torch.empty((B, hp, wp, cout), dtype=f32, device=x.device)
+    _lib.call("cmr_conv3x3_wino_nhwc_f32", _p(x), B, H, W, cin, _p(u), _p(bias), _p(res), _p(post), _p(y), cout,
+              float(slope), pool, _stream())
+    return y
+
+
+def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None):
     """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout] (or the 2x2 average-pooled
-    map when pool=2: fused into the conv epilogue where the tiled kernel runs, a second kernel otherwise)."""
+    map when pool=2: fused into the conv epilogue where the tiled kernel runs, a second kernel otherwise).
+    u [16,Cout,Cin] (= G g G^T) enables the Winograd kernel for stride 1."""
     B, H, W, cin = x.shape
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
         raise ValueError("conv3x3: bad operand layout")
+    if (WINOGRAD and u is not None and stride == 1 and out is None
+            and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= 512):
+        return conv3x3_wino(x, u, bias, cout, slope, res, post, pool)
     if pool == 2:
         y = torch.empty((B, ho // 2, wo // 2, cout), dtype=f32, device=x.device)
         rc = _lib.call("cmr_conv3x3_nhwc_f32", _p(x), B, H, W, cin, _p(w9), _p(bias), None, None, _p(y), cout, stride,

@@ -72,6 +72,13 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
                          const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                          hipStream_t stream);
 
+/* Same convolution (stride 1) by Winograd F(2x2,3x3): u = G g G^T as [16][Cout][Cin] (host-side transform of the
+ * folded weights); input / output transforms, the 16 position GEMMs and the epilogue of cmr_conv3x3_nhwc_f32
+ * (bias, residual, LeakyReLU, table, optional 2x2 average pool) are fused in one kernel. */
+int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
+                              const float* res, const float* post, float* y, int Cout, float slope, int pool,
+                              hipStream_t stream);
+
 /* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.
  * ImageResNet.py:50 with :9-23. */
 int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,

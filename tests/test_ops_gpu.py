@@ -99,6 +99,15 @@ def test_conv3x3(ops, B, H, W, cin, cout, stride):
     close(got.permute(0, 3, 1, 2), ref, 2e-5, "conv3x3")
     got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w9.to(DEV), None, cout, stride, 1.0)
     close(got.permute(0, 3, 1, 2), F.conv2d(x.double(), w.double(), None, stride, 1), 2e-5, "conv3x3-plain")
+    if stride == 1:      # Winograd F(2x2,3x3) kernel: same results within fp32 rounding of the transforms
+        from cmr_agent_amd.models._pack import winograd_u
+        u = winograd_u(w.to(DEV))
+        xg = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        got = ops.conv3x3_wino(xg, u, b.to(DEV), cout, 0.2, res=res.permute(0, 2, 3, 1).contiguous().to(DEV),
+                               post=post.permute(1, 2, 0).contiguous().to(DEV))
+        close(got.permute(0, 3, 1, 2), ref, 5e-5, "conv3x3-winograd")
+        got = ops.conv3x3_wino(xg, u, b.to(DEV), cout, 0.01, pool=2)
+        close(got.permute(0, 3, 1, 2), F.avg_pool2d(F.leaky_relu(y, 0.01), 2, 2), 5e-5, "conv3x3-winograd-pool")
     if stride == 1:      # AvgPool2d(2,2) fused into the epilogue (or the two-kernel fallback on tiny maps)
         got = ops.conv3x3(x.permute(0, 2, 3, 1).contiguous().to(DEV), w9.to(DEV), b.to(DEV), cout, 1, 0.01, pool=2)
         close(got.permute(0, 3, 1, 2), F.avg_pool2d(F.leaky_relu(y, 0.01), 2, 2), 2e-5, "conv3x3-pool")

@@ -44,8 +44,13 @@ def bench_conv(B, H, W, cin, cout, stride, reps):
     us = timeit(lambda: ops.conv3x3(x, w, b, cout, stride, 0.2, res=res, out=out), reps)
     fl = 2.0 * 9 * cin * cout * B * ho * wo
     by = 4.0 * (x.numel() + 2 * out.numel())
-    print("conv3x3 %4dx%-4d %3d->%-3d s%d : %8.1f us  %6.1f TFLOP/s  (%5.2f TB/s algorithmic)" % (
-        H, W, cin, cout, stride, us, fl / us / 1e6, by / us / 1e6))
+    line = "conv3x3 %4dx%-4d %3d->%-3d s%d : %8.1f us  %6.1f TFLOP/s  (%5.2f TB/s algorithmic)" % (
+        H, W, cin, cout, stride, us, fl / us / 1e6, by / us / 1e6)
+    if stride == 1:
+        u = torch.randn(16, cout, cin, device=DEV) / math.sqrt(9 * cin)
+        us2 = timeit(lambda: ops.conv3x3(x, w, b, cout, 1, 0.2, res=res, u=u), reps)
+        line += "   | winograd %8.1f us  %6.1f algorithmic TFLOP/s" % (us2, fl / us2 / 1e6)
+    print(line)
 
 
 def bench_linear(rows, k1, n_out, k2=0, gather=False, act=0, reps=20):
