@@ -90,7 +90,7 @@ class ConvTimer:
         def timed(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None):
             B, H, W, cin = x.shape
             wino = (ops.WINOGRAD and u is not None and stride == 1 and out is None
-                    and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= 512)      # ops.conv3x3 dispatch
+                    and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= ops.WINO_MIN_TILES)      # ops.conv3x3 dispatch
             if not wino:       # stride-2 and small-map launches run the other conv kernels
                 return self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool, u)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -96,6 +96,7 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
 
 
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
+WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
 
 
 def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
@@ -119,7 +120,7 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
     if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
         raise ValueError("conv3x3: bad operand layout")
     if (WINOGRAD and u is not None and stride == 1 and out is None
-            and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= 512):
+            and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= WINO_MIN_TILES):
         return conv3x3_wino(x, u, bias, cout, slope, res, post, pool)
     if pool == 2:
         y = torch.empty((B, ho // 2, wo // 2, cout), dtype=f32, device=x.device)
