@@ -305,6 +305,29 @@ __global__ __launch_bounds__(256) void segment_softmax_kernel(const float* __res
   out[seg * 64 + lane] = hi > lo ? acc / l : 0.f;
 }
 
+// torch_scatter semantics over CSR segments: out[s, c] = reduce_i src[row_i, c] over the rows of segment s
+// (mode 0 sum, 1 max, 2 mean = sum / max(count, 1); empty segments give 0, like torch_scatter's zero-filled
+// output).  One wave per segment, lanes stride over channels.
+__global__ __launch_bounds__(256) void segment_reduce_kernel(const float* __restrict__ src, int64_t lds,
+                                                             const int32_t* __restrict__ order,
+                                                             const int32_t* __restrict__ offsets, float* __restrict__ out,
+                                                             int64_t ldo, int64_t nseg, int C, int mode) {
+  const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (seg >= nseg) return;
+  const int64_t lo = offsets[seg], hi = offsets[seg + 1];
+  for (int c = lane; c < C; c += 64) {
+    float acc = mode == 1 ? -INFINITY : 0.f;
+    for (int64_t i = lo; i < hi; ++i) {
+      const float v = src[(int64_t)order[i] * lds + c];
+      acc = mode == 1 ? fmaxf(acc, v) : acc + v;
+    }
+    if (hi == lo) acc = 0.f;
+    else if (mode == 2) acc = acc / (float)(hi - lo);
+    out[seg * ldo + c] = acc;
+  }
+}
+
 // out[r, :C] = src[idx[r], :C]      (pointnet_util.index_points / torch.gather of rows)
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds,
                                                           const int32_t* __restrict__ idx, float* __restrict__ out,
@@ -563,6 +586,14 @@ extern "C" int cmr_segment_softmax_f32(const float* attn, const float* vp, const
   CMR_REQUIRE(attn && vp && out && nseg > 0 && (offsets || fixed_len > 0));
   hipLaunchKernelGGL(segment_softmax_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, stream, attn, vp, order,
                      offsets, fixed_len, scale, out, nseg);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_segment_reduce_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets,
+                                      float* out, int64_t ldo, int64_t nseg, int C, int mode, hipStream_t stream) {
+  CMR_REQUIRE(src && order && offsets && out && nseg > 0 && C > 0 && mode >= 0 && mode <= 2);
+  hipLaunchKernelGGL(segment_reduce_kernel, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, stream, src, lds, order, offsets,
+                     out, ldo, nseg, C, mode);
   return cmr_launch_status();
 }
 

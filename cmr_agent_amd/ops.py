@@ -280,6 +280,16 @@ def segment_softmax(attn, vp, nseg, scale, order=None, offsets=None, fixed_len=0
     return out
 
 
+def segment_reduce(src, order, offsets, nseg, mode):
+    """mode 'sum' | 'max' | 'mean' over the CSR segments (offsets, order) of the rows of src [R, C] -> [nseg, C]."""
+    _rows(src)
+    C = src.shape[1]
+    out = torch.empty((nseg, C), dtype=f32, device=src.device)
+    _lib.call("cmr_segment_reduce_f32", _p(src), _ld(src), _p(_i32(order)), _p(_i32(offsets)), _p(out), C, nseg, C,
+              {"sum": 0, "max": 1, "mean": 2}[mode], _stream())
+    return out
+
+
 def gather_rows(src, idx, C=None, out=None):
     _rows(src)
     C = src.shape[1] if C is None else C

@@ -147,6 +147,11 @@ int cmr_vecattn_prep_f32(const float* q, int64_t ldq, const int32_t* iq, int64_t
 int cmr_segment_softmax_f32(const float* attn, const float* vp, const int32_t* order, const int32_t* offsets,
                             int fixed_len, float scale, float* out, int64_t nseg, hipStream_t stream);
 
+/* torch_scatter.scatter_{sum,max,mean} over CSR segments (mode 0 / 1 / 2; empty segments -> 0): the op API of the
+ * third-party extension the reference calls at PointNN.py:171-182 and environment.py:79. */
+int cmr_segment_reduce_f32(const float* src, int64_t lds, const int32_t* order, const int32_t* offsets, float* out,
+                           int64_t ldo, int64_t nseg, int C, int mode, hipStream_t stream);
+
 /* out[r,:C] = src[idx[r],:C].  pointnet_util.py:36-47 (index_points), torch.gather of feature rows. */
 int cmr_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t rows, int C,
                         hipStream_t stream);
