@@ -6,6 +6,10 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  -- MUST be imported before libcmr_hip.so is loaded: both link libamdhip64, and the HIP
+#                            runtime copy that torch ships has to be the one in the process (loading ours first made
+#                            every later kernel launch fail with hipErrorInvalidDeviceFunction-class errors)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libcmr_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "cmr_hip.h")

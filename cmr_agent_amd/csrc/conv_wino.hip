@@ -23,7 +23,7 @@ namespace {
 
 struct WinoArgs {
   const float* x; int B, H, W, Cin;
-  const float* u;      // [16][Cout][Cin]  (G g G^T, BN folded)
+  const float* u;      // G g G^T (BN folded) as A fragments [16][Cout/32][Cin/8][64][4]
   const float* bias; const float* res; const float* post;
   float* y; int Cout; float slope; int pool;
 };
@@ -34,12 +34,19 @@ constexpr int WT_KC = 32, WT_LDP = 36;        // channels per chunk, padded LDS 
 constexpr int WT_C4 = WT_KC / 4;
 constexpr int WT_HALO_F4 = WT_HR * WT_HC * WT_C4;                 // 1440
 constexpr int WT_HL = (WT_HALO_F4 + 255) / 256;                   // 6
-constexpr int WT_HALO_FLOATS = WT_HR * WT_HC * WT_LDP;            // 6480
-constexpr int WT_SMEM_FLOATS = 16384;         // 64 KB: two halo buffers (12960) in the K loop, T (16384) after it
+// LDS image of the halo: row pitch 20 pixels, columns de-interleaved by parity (pixel x sits at (x&1)*10 + x/2).
+// The Winograd tiles of a wave start at even columns (stride 2); with the plain [row][col] image every
+// ds_read_b128 of the patch was a 4-way bank conflict (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.56).  In
+// this image lane tx reads pixel slot tx + const, i.e. a stride of one 36-float slot: conflict free.
+constexpr int WT_PITCH = 20;
+constexpr int WT_HALO_FLOATS = WT_HR * WT_PITCH * WT_LDP;         // 7200
+constexpr int WT_SMEM_FLOATS = 16384;         // 64 KB: two halo buffers (14400) in the K loop, T (16384) after it
+__device__ __forceinline__ int wt_slot(int py, int px) { return py * WT_PITCH + (px & 1) * (WT_PITCH / 2) + (px >> 1); }
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, const int tiles_x, const int tiles_y) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: lets the U bases live in SGPRs
   const int h = lane >> 5, l31 = lane & 31;
   const int nco = a.Cout / 64;
   int t = blockIdx.x;
@@ -59,18 +66,23 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
       for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
 
   // halo chunk: global -> registers (batched, clamped addresses) -> LDS (zero padding applied there)
+  // (per-lane 32-bit offsets from uniform bases: the loads take the saddr + voffset form, one VGPR per address)
   f32x4 hv[WT_HL];
-  auto load_halo = [&](int chunk) {
+  unsigned hoff[WT_HL];
 #pragma unroll
-    for (int i = 0; i < WT_HL; ++i) {
-      int e = tid + 256 * i;
-      if (e >= WT_HALO_F4) e = WT_HALO_F4 - 1;
-      const int p = e / WT_C4, c = e % WT_C4;
-      int iy = iy0 + p / WT_HC, ix = ix0 + p % WT_HC;
-      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
-      ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
-      hv[i] = *reinterpret_cast<const f32x4*>(xb + ((int64_t)iy * a.W + ix) * a.Cin + chunk * WT_KC + c * 4);
-    }
+  for (int i = 0; i < WT_HL; ++i) {
+    int e = tid + 256 * i;
+    if (e >= WT_HALO_F4) e = WT_HALO_F4 - 1;
+    const int p = e / WT_C4, c = e % WT_C4;
+    int iy = iy0 + p / WT_HC, ix = ix0 + p % WT_HC;
+    iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+    ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+    hoff[i] = (unsigned)((iy * a.W + ix) * a.Cin + c * 4);
+  }
+  auto load_halo = [&](int chunk) {
+    const float* xc = xb + chunk * WT_KC;
+#pragma unroll
+    for (int i = 0; i < WT_HL; ++i) hv[i] = *reinterpret_cast<const f32x4*>(xc + hoff[i]);
   };
   auto store_halo = [&](float* halo) {
 #pragma unroll
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
         const int p = e / WT_C4, c = e % WT_C4;
         const int iy = iy0 + p / WT_HC, ix = ix0 + p % WT_HC;
         const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        *reinterpret_cast<f32x4*>(&halo[p * WT_LDP + c * 4]) = inb ? hv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(&halo[wt_slot(p / WT_HC, p % WT_HC) * WT_LDP + c * 4]) = inb ? hv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   };
@@ -91,39 +103,45 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
   const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
   const float sgn = wave == 1 ? 1.f : -1.f;
   const int ty = l31 >> 3, tx = l31 & 7;
-  const int pa = ((2 * ty + ra) * WT_HC + 2 * tx) * WT_LDP + 4 * h;     // LDS float offsets of the two patch rows
-  const int pb = ((2 * ty + rb) * WT_HC + 2 * tx) * WT_LDP + 4 * h;
-  const float* ub = a.u + ((int64_t)(4 * wave) * a.Cout + co0 + l31) * a.Cin + 4 * h;   // position (wave, 0), cout l31
+  const int pa = ((2 * ty + ra) * WT_PITCH + tx) * WT_LDP + 4 * h;      // LDS float offsets of the two patch rows (column 2*tx)
+  const int pb = ((2 * ty + rb) * WT_PITCH + tx) * WT_LDP + 4 * h;
+  // U is stored as ready-made A fragments [pos][Cout/32][Cin/8][64 lanes][4]: a wave load is 1 KB contiguous
+  const int64_t utile = (int64_t)(a.Cin / 8) * 256; // stride between cout tiles
   const int64_t upos = (int64_t)a.Cout * a.Cin;     // stride between positions
+  const float* ub = a.u + (int64_t)(4 * wave) * upos + (co0 / 32) * utile;   // position (wave, 0), first cout tile (uniform)
+  const unsigned uoff = (unsigned)(lane * 4);
 
+  // Loads retire in order (vmcnt), so a U fragment queued behind a halo load waits for HBM.  Order of issue per
+  // chunk: U(kg1) | U(kg2) | U(kg3), halo(next chunk) | U(next chunk, kg0): every wait on U only has older U
+  // loads ahead of it, and the halo has two k-groups of MFMAs (plus the barrier) to arrive.
   load_halo(0);
+  f32x4 wc[4][2], wn[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) wc[j][n] = *reinterpret_cast<const f32x4*>(ub + j * upos + n * utile + uoff);
   int buf = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     float* halo = smem + buf * WT_HALO_FLOATS;
     store_halo(halo);
     __syncthreads();                                // halo[buf] visible; everybody is past the GEMMs that read halo[buf] two chunks ago
-    if (chunk + 1 < nchunk) load_halo(chunk + 1);   // in flight during this chunk's GEMMs
-    const float* uc = ub + chunk * WT_KC;
-    f32x4 wc[4][2], wn[4][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) wc[j][n] = *reinterpret_cast<const f32x4*>(uc + j * upos + (int64_t)n * 32 * a.Cin);
+    const float* uc = ub + chunk * (WT_KC / 8) * 256;
+    const float* un = ub + (chunk + 1 < nchunk ? chunk + 1 : 0) * (WT_KC / 8) * 256;   // last chunk: a harmless in-bounds re-read
 #pragma unroll
     for (int kg = 0; kg < WT_KC / 8; ++kg) {
-      if (kg + 1 < WT_KC / 8) {
+      const float* up = kg + 1 < WT_KC / 8 ? uc + (kg + 1) * 256 : un;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
-            wn[j][n] = *reinterpret_cast<const f32x4*>(uc + j * upos + (int64_t)n * 32 * a.Cin + (kg + 1) * 8);
-      }
+        for (int n = 0; n < 2; ++n) wn[j][n] = *reinterpret_cast<const f32x4*>(up + j * upos + n * utile + uoff);
+      if (kg == WT_KC / 8 - 2 && chunk + 1 < nchunk) load_halo(chunk + 1);
       // on-the-fly input transform of this lane's tile: t[c] = d[ra][c] +- d[rb][c], then the 4 columns j
       f32x4 tc[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const f32x4 da = *reinterpret_cast<const f32x4*>(&halo[pa + c * WT_LDP + kg * 8]);
-        const f32x4 db = *reinterpret_cast<const f32x4*>(&halo[pb + c * WT_LDP + kg * 8]);
+        constexpr int WT_COFS[4] = {0, (WT_PITCH / 2) * WT_LDP, WT_LDP, (WT_PITCH / 2 + 1) * WT_LDP};   // column 2*tx + c
+        const f32x4 da = *reinterpret_cast<const f32x4*>(&halo[pa + WT_COFS[c] + kg * 8]);
+        const f32x4 db = *reinterpret_cast<const f32x4*>(&halo[pb + WT_COFS[c] + kg * 8]);
         tc[c] = da + sgn * db;
       }
       f32x4 vf[4];
@@ -159,10 +177,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
       Ts[(((wave * 2 + 0) * 2 + n) * 16 + r) * 64 + lane] = t0;
       Ts[(((wave * 2 + 1) * 2 + n) * 16 + r) * 64 + lane] = t1;
     }
-  __syncthreads();
-  // ---- stage 2: wave q finishes the 4 outputs (a, b) of register quad q of both cout tiles
+  // ---- stage 2: wave q finishes the 4 outputs (a, b) of register quad q of both cout tiles.
+  // Every epilogue operand (bias / residual / table) is requested HERE, before the barrier, in one batch of
+  // branch-free loads (absent operands read a valid dummy address and are masked after the wait): a
+  // conditional load per use costs one exposed L2/HBM round trip each, ~20 of them per workgroup.
   const int q = wave;
   const int Ho = a.H, Wo = a.W;
+  const int cq = co0 + 8 * q + 4 * h;               // + 32 n
+  f32x4 bs[2], rs[2][2][2], ps[2][2][2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bs[n] = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq + 32 * n : a.u);
+  if (a.pool == 1) {
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        int oy = oy0 + 2 * ty + aa, ox = ox0 + 2 * tx + bb;
+        oy = oy < Ho ? oy : Ho - 1;
+        ox = ox < Wo ? ox : Wo - 1;
+        const int64_t pix = (int64_t)oy * Wo + ox;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          rs[n][aa][bb] = *reinterpret_cast<const f32x4*>(a.res ? a.res + ((int64_t)b * Ho * Wo + pix) * a.Cout + cq + 32 * n : a.u);
+          ps[n][aa][bb] = *reinterpret_cast<const f32x4*>(a.post ? a.post + pix * a.Cout + cq + 32 * n : a.u);
+        }
+      }
+  }
+  __syncthreads();
   f32x4 yv[2][2][2];                                // [n][a][b]
 #pragma unroll
   for (int n = 0; n < 2; ++n)
@@ -176,28 +217,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
       yv[n][0][bb] = (tw[0] + tw[1]) + tw[2];
       yv[n][1][bb] = (tw[1] - tw[2]) - tw[3];
     }
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int n = 0; n < 2; ++n) bs[n] = a.bias ? bs[n] : zero4;
   if (a.pool == 2) {
     const int py = (oy0 >> 1) + ty, px = (ox0 >> 1) + tx;
     const int hp2 = Ho >> 1, wp2 = Wo >> 1;
     if (py < hp2 && px < wp2) {
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const int c = co0 + n * 32 + 8 * q + 4 * h;
-        f32x4 bs = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) bs = *reinterpret_cast<const f32x4*>(a.bias + c);
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s = zero4;
 #pragma unroll
         for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
           for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = yv[n][aa][bb][e] + bs[e];
+              const float v = yv[n][aa][bb][e] + bs[n][e];
               s[e] += v > 0.f ? v : v * a.slope;
             }
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[e] *= 0.25f;
-        *reinterpret_cast<f32x4*>(a.y + (((int64_t)b * hp2 + py) * wp2 + px) * a.Cout + c) = s;
+        *reinterpret_cast<f32x4*>(a.y + (((int64_t)b * hp2 + py) * wp2 + px) * a.Cout + cq + 32 * n) = s;
       }
     }
     return;
@@ -207,19 +248,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
 #pragma unroll
     for (int bb = 0; bb < 2; ++bb) {
       const int oy = oy0 + 2 * ty + aa, ox = ox0 + 2 * tx + bb;
-      if (oy >= Ho || ox >= Wo) continue;
+      const bool inb = oy < Ho && ox < Wo;
       const int64_t pix = (int64_t)oy * Wo + ox;
 #pragma unroll
       for (int n = 0; n < 2; ++n) {
-        const int c = co0 + n * 32 + 8 * q + 4 * h;
-        const int64_t o = ((int64_t)b * Ho * Wo + pix) * a.Cout + c;
-        f32x4 v = yv[n][aa][bb];
-        if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + c);
-        if (a.res) v += *reinterpret_cast<const f32x4*>(a.res + o);
+        f32x4 v = yv[n][aa][bb] + bs[n];
+        if (a.res) v += rs[n][aa][bb];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
-        if (a.post) v += *reinterpret_cast<const f32x4*>(a.post + pix * a.Cout + c);
-        *reinterpret_cast<f32x4*>(a.y + o) = v;
+        if (a.post) v += ps[n][aa][bb];
+        if (inb) *reinterpret_cast<f32x4*>(a.y + ((int64_t)b * Ho * Wo + pix) * a.Cout + cq + 32 * n) = v;
       }
     }
 }

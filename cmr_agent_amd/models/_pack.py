@@ -61,14 +61,18 @@ _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
 def winograd_u(w):
-    """[Cout, Cin, 3, 3] -> U = G g G^T as [16, Cout, Cin] (Winograd F(2x2,3x3) weight transform)."""
+    """[Cout, Cin, 3, 3] -> U = G g G^T (Winograd F(2x2,3x3) weight transform), stored as the MFMA A fragments the
+    kernel consumes: [16 positions][Cout/32 tiles][Cin/8 k-groups][64 lanes][4], lane = 32 h + l holding
+    U[pos][32 tile + l][8 kgroup + 4 h .. + 3].  One wave load of a fragment is then 1 KB contiguous (8 full cache
+    lines) instead of 32 B out of each of 32 lines (include/cmr_hip.h: cmr_conv3x3_wino_nhwc_f32)."""
     g = torch.tensor(_WINO_G, dtype=w.dtype, device=w.device)
-    u = torch.einsum("ik,ockl,jl->ijoc", g, w, g)
-    return u.reshape(16, w.shape[0], w.shape[1]).contiguous()
+    co, ci = w.shape[0], w.shape[1]
+    u = torch.einsum("ik,ockl,jl->ijoc", g, w, g).reshape(16, co // 32, 32, ci // 8, 2, 4)   # [p][t][l][kg][h][e]
+    return u.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(16, co, ci)
 
 
 def conv9(conv, bn=None, cin_slice=None):
-    """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout], U [16, Cout, Cin] for the Winograd kernel).
+    """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout], U fragments (16*Cout*Cin floats) for the Winograd kernel).
     cin_slice restricts the input channels (the agent's image / projection halves)."""
     w, b = folded(conv, bn)
     if cin_slice is not None:

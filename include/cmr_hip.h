@@ -72,8 +72,9 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
                          const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                          hipStream_t stream);
 
-/* Same convolution (stride 1) by Winograd F(2x2,3x3): u = G g G^T as [16][Cout][Cin] (host-side transform of the
- * folded weights); input / output transforms, the 16 position GEMMs and the epilogue of cmr_conv3x3_nhwc_f32
+/* Same convolution (stride 1) by Winograd F(2x2,3x3): u = G g G^T of the folded weights, transformed host-side and
+ * stored as MFMA A fragments [16 positions][Cout/32][Cin/8][64 lanes][4] with lane 32h+l holding
+ * U[pos][32 tile + l][8 kgroup + 4h .. +3] (16*Cout*Cin floats; cmr_agent_amd/models/_pack.py:winograd_u); input / output transforms, the 16 position GEMMs and the epilogue of cmr_conv3x3_nhwc_f32
  * (bias, residual, LeakyReLU, table, optional 2x2 average pool) are fused in one kernel. */
 int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,

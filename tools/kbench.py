@@ -75,7 +75,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="conv,linear")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--lib", default=None, help="A/B: load this build of libcmr_hip.so instead of the in-tree one")
     a = ap.parse_args()
+    if a.lib:
+        from cmr_agent_amd import _lib
+        _lib.LIB_PATH = os.path.abspath(a.lib)
     B = 8
     if "conv" in a.what:
         for (H, W, ci, co, s) in [(352, 1216, 64, 64, 1), (176, 608, 64, 64, 1), (88, 304, 64, 64, 1), (88, 304, 128, 128, 1),
