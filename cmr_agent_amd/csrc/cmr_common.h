@@ -35,6 +35,12 @@ __device__ __forceinline__ float cmr_act(float v, int act, float p) {
 
 // 32x32x2 fp32 MFMA: D[i][j] += sum_k A[i][k] B[k][j];  lane l supplies A[i=l&31][k=l>>5] and
 // B[k=l>>5][j=l&31]; D register r of lane l is D[row=(r&3)+8*(r>>2)+4*(l>>5)][col=l&31].
+// Pins a value in registers at this point of the program.  Epilogues compute every output first, pin it, and
+// only then enter the predicated stores: hipcc otherwise sinks "acc + loaded operand" into each predicated
+// block, where its waitcnt bookkeeping degrades to s_waitcnt vmcnt(0) -- every store then waits for the
+// previous store (stores count in vmcnt on gfx9) and for the next tile's prefetch.
+__device__ __forceinline__ void cmr_pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ f32x16 cmr_mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

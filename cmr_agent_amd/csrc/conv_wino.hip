@@ -38,6 +38,7 @@ constexpr int WT_HL = (WT_HALO_F4 + 255) / 256;                   // 6
 // The Winograd tiles of a wave start at even columns (stride 2); with the plain [row][col] image every
 // ds_read_b128 of the patch was a 4-way bank conflict (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.56).  In
 // this image lane tx reads pixel slot tx + const, i.e. a stride of one 36-float slot: conflict free.
+constexpr int WT_NUM_CU = 256;
 constexpr int WT_PITCH = 20;
 constexpr int WT_HALO_FLOATS = WT_HR * WT_PITCH * WT_LDP;         // 7200
 constexpr int WT_SMEM_FLOATS = 16384;         // 64 KB: two halo buffers (14400) in the K loop, T (16384) after it
@@ -114,6 +115,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
   // Loads retire in order (vmcnt), so a U fragment queued behind a halo load waits for HBM.  Order of issue per
   // chunk: U(kg1) | U(kg2) | U(kg3), halo(next chunk) | U(next chunk, kg0): every wait on U only has older U
   // loads ahead of it, and the halo has two k-groups of MFMAs (plus the barrier) to arrive.
+  // Two workgroups share a CU (one wave of each per SIMD).  Launched together they stay in lock step -- both in
+  // the load prologue, both in the MFMA loop, both in the epilogue -- and the MFMA pipe idles for every non-MFMA
+  // phase.  The first generation of workgroups on odd wave slots starts half a period late; equal-length
+  // workgroups preserve that offset, so one wave's loads / epilogue run under the other's MFMAs from then on.
+  if (blockIdx.x < 2 * WT_NUM_CU && (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1)) {     // HW_ID.WAVE_ID bit 0
+    for (int i = 0; i < 1 + nchunk; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   load_halo(0);
   f32x4 wc[4][2], wn[4][2];
 #pragma unroll

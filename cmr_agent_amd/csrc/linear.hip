@@ -224,11 +224,17 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const LinearArgs a) 
   }
 }
 
-__device__ __attribute__((aligned(16))) const float cmr_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float cmr_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // NOT const: hipcc folds loads of a const zero page into predicated loads + 0
 
-// NT = 32-wide cout tiles per workgroup (1, 2, 4); G = k-groups (of 8) per register segment (1, 2, 4, 8).
-// kpad = nseg * 8 * G >= k1 + k2 (weights beyond k1 + k2 are zero in LDS, X loads beyond it read zeros).
-// AC = activation class: 0 -> v > 0 ? v : v * slope (none / ReLU / LeakyReLU with slope 1 / 0 / p), 1 -> erf-GELU, 2 -> elu+1
+// NT = 32-wide cout tiles per workgroup (1, 2, 4); G = k-groups (of 8) per register segment (1, 2, 4, 8); NSEG
+// segments cover K: KPAD = NSEG * 8 * G >= k1 + k2 (weights beyond k1 + k2 are zero in LDS, X loads beyond it read
+// zeros).  AC = activation class: 0 -> v > 0 ? v : v * slope (none / ReLU / LeakyReLU with slope 1 / 0 / p),
+// 1 -> erf-GELU, 2 -> elu+1.
+//
+// The tile loop is written so that hipcc sees ONE straight-line body (segments unrolled, no conditional load, no
+// 64-bit division, gather indices fetched a tile ahead): its s_waitcnt bookkeeping is exact only then, and with any
+// branch around a load it falls back to vmcnt(0), which serialises the X prefetch of the next tile, the residual
+// loads and every store (stores count in vmcnt on gfx9) behind each other.
 template <int AC>
 __device__ __forceinline__ float ws_act(float v, float slope) {
   if (AC == 1) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
@@ -236,65 +242,101 @@ __device__ __forceinline__ float ws_act(float v, float slope) {
   return v > 0.f ? v : v * slope;
 }
 
-template <int NT, int G, int AC>
-__global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a, const int nseg) {
-  extern __shared__ __attribute__((aligned(16))) float Ws[];   // [32*NT][kpad + 4]
-  const int kpad = nseg * 8 * G;
-  const int ldws = kpad + 4;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+template <int NT, int G, int NSEG, int AC>
+__global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a) {
+  constexpr int KPAD = NSEG * 8 * G, LDWS = KPAD + 4;
+  constexpr bool RES_EARLY = NT < 4;       // residual rows requested before the tile's MFMAs (registers permitting)
+  extern __shared__ __attribute__((aligned(16))) float Ws[];   // [32*NT][KPAD + 4] weights, then [32*NT] bias
+  float* Bs = Ws + 32 * NT * LDWS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   const int col_base = blockIdx.y * 32 * NT;
   const int ktot = a.k1 + a.k2;
-  const int64_t ntiles = (a.rows + 31) / 32;
-  const int64_t tstride = (int64_t)gridDim.x * 4;
+  const uint32_t rows = (uint32_t)a.rows;  // < 2^31 (dispatch)
+  const uint32_t ntiles = (rows + 31) / 32;
+  const uint32_t tstride = gridDim.x * 4;
+  const float* x2 = a.x2 ? a.x2 : a.x1;
 
-  // No load is conditional and no loaded value is touched before its MFMA: masked elements (rows past
-  // the end, k past k1 + k2) read a 16-byte zero page instead, so a whole segment stays in flight.
-  auto load_seg = [&](int64_t tile, int seg, f32x4 (&dst)[G]) {
-    int64_t row = tile * 32 + l31;
-    const bool valid = tile < ntiles && row < a.rows;
-    if (!valid) row = 0;
-    const float* p1 = a.x1 + row * a.ld1;
-    const float* p2 = p1;
-    if (a.x2) p2 = a.x2 + (a.idx2 ? (int64_t)a.idx2[row] : row / a.div2) * a.ld2;
+  struct TileRows { const float* p1; const float* p2; bool valid; };
+  auto load_idx = [&](uint32_t tile) -> int32_t {            // gather index of this lane's row (zero page when unused)
+    const uint32_t row = tile * 32 + l31;
+    const int32_t* p = (a.idx2 && tile < ntiles && row < rows) ? a.idx2 + row : reinterpret_cast<const int32_t*>(cmr_zero16);
+    return *p;
+  };
+  auto tile_rows = [&](uint32_t tile, int32_t idxv) -> TileRows {
+    uint32_t row = tile * 32 + l31;
+    const bool valid = tile < ntiles && row < rows;
+    row = valid ? row : 0;
+    const int64_t r2 = a.idx2 ? (int64_t)idxv : (int64_t)(row / (uint32_t)a.div2);
+    return {a.x1 + (int64_t)row * a.ld1, x2 + r2 * a.ld2, valid};
+  };
+  auto load_seg = [&](const TileRows& r, int seg, f32x4 (&dst)[G]) {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int kk = (seg * G + i) * 8 + 4 * h;
-      const float* p = kk < a.k1 ? p1 + kk : p2 + (kk - a.k1);
-      if (!valid || kk >= ktot) p = cmr_zero16;
+      const float* p = kk < a.k1 ? r.p1 + kk : r.p2 + (kk - a.k1);
+      p = (r.valid && kk < ktot) ? p : cmr_zero16;
       dst[i] = *reinterpret_cast<const f32x4*>(p);
     }
   };
+  // residual rows: unconditional loads at clamped indices (rows / couts past the end re-read a valid element and
+  // are never stored); without a residual the base is the zero page with stride 0.  Index clamps stay selects,
+  // pointer selects on a per-lane condition are turned back into branches by hipcc.
+  const float* resb = a.res ? a.res : cmr_zero16;
+  const int64_t res_ld = a.res ? a.ldres : 0;
+  const int res_cmax = a.res ? a.n_out - 4 : 0;
+  auto load_res = [&](uint32_t tile, f32x4 (&r4)[NT][4]) {
+    uint32_t row = tile * 32 + l31;
+    row = row < rows ? row : 0;
+    const uint32_t rr = a.res_mod > 0 ? row % (uint32_t)a.res_mod : row;
+    const float* rp = resb + (int64_t)rr * res_ld;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = col_base + n * 32 + 8 * q + 4 * h;
+        r4[n][q] = *reinterpret_cast<const f32x4*>(rp + (c < res_cmax ? c : res_cmax));
+      }
+  };
 
   f32x4 xcur[G], xnxt[G];
-  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  load_seg(tile, 0, xcur);                 // in flight while the weights are staged
+  uint32_t tile = blockIdx.x * 4 + wave;
+  TileRows rc = tile_rows(tile, load_idx(tile));
+  load_seg(rc, 0, xcur);                   // in flight while the weights are staged
+  int32_t idn = load_idx(tile + tstride);
   {
-    const int c4n = kpad / 4;
-    for (int e = tid; e < 32 * NT * c4n; e += 256) {
-      const int n = e / c4n, c = (e % c4n) * 4;
+    constexpr int C4N = KPAD / 4;
+    for (int e = tid; e < 32 * NT * C4N; e += 256) {
+      const int n = e / C4N, c = (e % C4N) * 4;
       const bool ok = col_base + n < a.n_out && c < ktot;
       const float* p = ok ? a.w + (int64_t)(col_base + n) * a.ldw + c : cmr_zero16;
-      *reinterpret_cast<f32x4*>(&Ws[n * ldws + c]) = *reinterpret_cast<const f32x4*>(p);
+      *reinterpret_cast<f32x4*>(&Ws[n * LDWS + c]) = *reinterpret_cast<const f32x4*>(p);
     }
+    if (tid < 32 * NT) Bs[tid] = (a.bias && col_base + tid < a.n_out) ? a.bias[col_base + tid] : 0.f;
   }
   __syncthreads();
 
   for (; tile < ntiles; tile += tstride) {
+    f32x4 r4[NT][4];
+    if (RES_EARLY) load_res(tile, r4);
+    const TileRows rn = tile_rows(tile + tstride, idn);      // idn was requested one tile ago
+    idn = load_idx(tile + 2 * tstride);
     f32x16 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
-    for (int seg = 0; seg < nseg; ++seg) {
-      if (seg + 1 < nseg) load_seg(tile, seg + 1, xnxt);
-      else load_seg(tile + tstride, 0, xnxt);            // next tile of this wave (zero page past the end)
-      const float* wrow = Ws + l31 * ldws + seg * G * 8 + 4 * h;
+#pragma unroll
+    for (int seg = 0; seg < NSEG; ++seg) {
+      if (seg + 1 < NSEG) load_seg(rc, seg + 1, xnxt);
+      else load_seg(rn, 0, xnxt);                            // next tile of this wave (zero page past the end)
+      const float* wrow = Ws + l31 * LDWS + seg * G * 8 + 4 * h;
 #pragma unroll
       for (int i = 0; i < G; ++i) {
         f32x4 wv[NT];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) wv[n] = *reinterpret_cast<const f32x4*>(wrow + n * 32 * ldws + i * 8);
+        for (int n = 0; n < NT; ++n) wv[n] = *reinterpret_cast<const f32x4*>(wrow + n * 32 * LDWS + i * 8);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -303,31 +345,33 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a, cons
 #pragma unroll
       for (int i = 0; i < G; ++i) xcur[i] = xnxt[i];
     }
-    // epilogue: this lane's row, 4 consecutive couts per register quad
-    const int64_t row = tile * 32 + l31;
-    if (row < a.rows) {
-      const int64_t rr = a.res ? (a.res_mod > 0 ? row % a.res_mod : row) : 0;
+    rc = rn;
+    if (!RES_EARLY) load_res(tile, r4);
+    // epilogue: this lane's row, 4 consecutive couts per register quad.  All values first, then the stores.
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        f32x4 r4[4];
-        if (a.res) {
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c0 = col_base + n * 32 + 8 * q + 4 * h;
-            r4[q] = *reinterpret_cast<const f32x4*>(c0 < a.n_out ? a.res + rr * a.ldres + c0 : cmr_zero16);
-          }
-        }
+      for (int q = 0; q < 4; ++q) {
+        const int cl = n * 32 + 8 * q + 4 * h;
+        f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+        v += *reinterpret_cast<const f32x4*>(&Bs[cl]);
+        v += r4[n][q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c0 = col_base + n * 32 + 8 * q + 4 * h;
-          f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
-          if (a.bias) v += *reinterpret_cast<const f32x4*>(c0 < a.n_out ? a.bias + c0 : cmr_zero16);
-          if (a.res) v += r4[q];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ws_act<AC>(v[e], a.act_param);
-          if (c0 < a.n_out) *reinterpret_cast<f32x4*>(a.y + row * a.ldy + c0) = v;
-        }
+        for (int e = 0; e < 4; ++e) v[e] = ws_act<AC>(v[e], a.act_param);
+        r4[n][q] = v;
       }
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cmr_pin(r4[n][q]);
+    const uint32_t row = tile * 32 + l31;
+    if (row < rows) {
+      float* yp = a.y + (int64_t)row * a.ldy + col_base + 4 * h;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (col_base + n * 32 + 8 * q + 4 * h < a.n_out) *reinterpret_cast<f32x4*>(yp + n * 32 + 8 * q) = r4[n][q];
     }
   }
 }
@@ -415,39 +459,46 @@ __global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) 
     }
 }
 
-template <int NT, int G, int AC>
-int launch_linear_ws_ga(LinearArgs a, int nseg, hipStream_t stream) {
-  const size_t smem = (size_t)32 * NT * (nseg * 8 * G + 4) * sizeof(float);
-  static size_t attr_set = 0;
-  if (smem > 64 * 1024 && smem > attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_ws_kernel<NT, G, AC>),
+template <int NT, int G, int NSEG, int AC>
+int launch_linear_ws_ga(LinearArgs a, hipStream_t stream) {
+  const size_t smem = (size_t)32 * NT * (NSEG * 8 * G + 4 + 1) * sizeof(float);      // weights + bias
+  static bool attr_set = false;
+  if (smem > 64 * 1024 && !attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_ws_kernel<NT, G, NSEG, AC>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
       return CMR_ELAUNCH;
-    attr_set = smem;
+    attr_set = true;
   }
   if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
   const int64_t ntiles = (a.rows + 31) / 32;
   int64_t gx = (ntiles + 3) / 4;
   if (gx > 512) gx = 512;                   // 2 resident workgroups per CU; each wave walks its tiles with stride
   dim3 grid((unsigned)gx, (unsigned)((a.n_out + 32 * NT - 1) / (32 * NT)));
-  hipLaunchKernelGGL((linear_ws_kernel<NT, G, AC>), grid, dim3(256), smem, stream, a, nseg);
+  hipLaunchKernelGGL((linear_ws_kernel<NT, G, NSEG, AC>), grid, dim3(256), smem, stream, a);
   return cmr_launch_status();
 }
 
-template <int NT, int G>
-int launch_linear_ws_g(const LinearArgs& a, int nseg, hipStream_t stream) {
-  if (a.act == CMR_ACT_GELU) return launch_linear_ws_ga<NT, G, 1>(a, nseg, stream);
-  if (a.act == CMR_ACT_ELU1) return launch_linear_ws_ga<NT, G, 2>(a, nseg, stream);
-  return launch_linear_ws_ga<NT, G, 0>(a, nseg, stream);
+template <int NT, int G, int NSEG>
+int launch_linear_ws_g(const LinearArgs& a, hipStream_t stream) {
+  if (a.act == CMR_ACT_GELU) return launch_linear_ws_ga<NT, G, NSEG, 1>(a, stream);
+  if (a.act == CMR_ACT_ELU1) return launch_linear_ws_ga<NT, G, NSEG, 2>(a, stream);
+  return launch_linear_ws_ga<NT, G, NSEG, 0>(a, stream);
 }
 
 template <int NT>
 int launch_linear_ws(const LinearArgs& a, hipStream_t stream) {
-  const int ng = (a.k1 + a.k2 + 7) / 8;     // k-groups of 8
-  if (ng >= 5 && NT < 4) return launch_linear_ws_g<NT, 8>(a, (ng + 7) / 8, stream);
-  if (ng >= 3) return launch_linear_ws_g<NT, 4>(a, (ng + 3) / 4, stream);     // NT = 4 keeps 4-group segments (registers)
-  if (ng == 2) return launch_linear_ws_g<NT, 2>(a, 1, stream);
-  return launch_linear_ws_g<NT, 1>(a, 1, stream);
+  const int ng = (a.k1 + a.k2 + 7) / 8;     // k-groups of 8 (<= 16)
+  if (NT < 4) {
+    if (ng > 8) return launch_linear_ws_g<NT, 8, 2>(a, stream);
+    if (ng > 4) return launch_linear_ws_g<NT, 8, 1>(a, stream);
+  } else {                                  // NT = 4 keeps 4-group segments (registers)
+    if (ng > 12) return launch_linear_ws_g<NT, 4, 4>(a, stream);
+    if (ng > 8) return launch_linear_ws_g<NT, 4, 3>(a, stream);
+    if (ng > 4) return launch_linear_ws_g<NT, 4, 2>(a, stream);
+  }
+  if (ng > 2) return launch_linear_ws_g<NT, 4, 1>(a, stream);
+  if (ng == 2) return launch_linear_ws_g<NT, 2, 1>(a, stream);
+  return launch_linear_ws_g<NT, 1, 1>(a, stream);
 }
 
 // LayerNorm over exactly 64 channels; 16 lanes per row (float4 each).  y = LN(x)*g + b (+ res)
@@ -510,7 +561,7 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   // float4 epilogue needs 4-aligned output channels (the host layer pads the few odd heads)
   const bool vec_ok = (n_out % 4 == 0) && (ldy % 4 == 0) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) &&
                       (!res || (ldres % 4 == 0 && cmr_aligned16(res)));
-  if (a.k1 + a.k2 <= 128 && vec_ok) {       // weights fit in LDS: weight-stationary streaming kernel
+  if (a.k1 + a.k2 <= 128 && vec_ok && rows < (int64_t)0x7fffffc0) {       // weights fit in LDS: weight-stationary streaming kernel
     if (n_out <= 32 || (n_out > 64 && n_out <= 96)) return launch_linear_ws<1>(a, stream);
     if (n_out % 128 == 0) return launch_linear_ws<4>(a, stream);
     return launch_linear_ws<2>(a, stream);
