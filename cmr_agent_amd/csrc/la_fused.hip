@@ -1,0 +1,405 @@
+// Fused linear-attention layer of the fine matcher (reference models/LinearAttention.py:38-73), two kernels:
+//
+//   cmr_la_kv_state_f32    y rows -> K = elu(Wk y)+1, V = (Wv y)/S -> per (batch, head) state  KV = K^T V, Ksum
+//   cmr_la_query_layer_f32 x rows -> Q = elu(Wq x)+1 -> message = Q KV / (Q.Ksum + eps) * S -> merge -> LayerNorm
+//                          -> mlp(cat[x, message]) (128 -> 128 ReLU -> 64) -> LayerNorm -> x + .
+//
+// The unfused path makes 11 passes over the token rows per layer (each projection, the state reduction, the
+// application, both LayerNorms and the MLP read and write [rows][64..128] arrays); here the source rows are
+// read once and the query rows are read once and written once.  Every GEMM runs on v_mfma_f32_32x32x2_f32 with
+// the weights resident in LDS; the query kernel computes TRANSPOSED (D'[channel][row], weights = A operand), so
+// a lane owns one row, accumulator register 4q+e of tile t is channel 32t + 8q + 4h + e, and the accumulators of
+// one GEMM are the B fragments (k-group 4t+q) of the next: the whole chain stays in registers.  A head is one
+// k-group (8 channels, 4 in each lane half), so the 8x8 state product and the LayerNorm statistics need a single
+// exchange with the partner lane (lane ^ 32).
+#include "cmr_common.h"
+
+namespace {
+
+constexpr int LA_D = 64, LA_HID = 128, LA_STATE = 576;    // 8 heads x (8x8 KV + 8 Ksum)
+constexpr int LA_LD64 = LA_D + 4, LA_LD128 = LA_HID + 4;  // padded LDS weight rows (conflict-free b128 reads)
+
+__device__ __forceinline__ float la_elu1(float v) { return v > 0.f ? v + 1.f : expf(v); }   // F.elu(v) + 1
+__device__ __forceinline__ float la_xhalf(float v) { return __shfl_xor(v, 32); }            // partner lane (other 4 dims of the head)
+
+// acc[t] += W[32t + l31][8kg + 4h + j] * bfrag(kg, j)   for kg < KG, j < 4   (weights software-pipelined one
+// k-group ahead from LDS; the scheduling barrier keeps hipcc from hoisting every LDS read of the unrolled loop)
+template <int T, int KG, int LD, typename BF>
+__device__ __forceinline__ void la_gemm(const float* __restrict__ Ws, int l31, int h, f32x16 (&acc)[T], BF bfrag) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* wrow = Ws + l31 * LD + 4 * h;
+  f32x4 wc[T], wn[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) wc[t] = *reinterpret_cast<const f32x4*>(wrow + t * 32 * LD);
+#pragma unroll
+  for (int kg = 0; kg < KG; ++kg) {
+    if (kg + 1 < KG) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) wn[t] = *reinterpret_cast<const f32x4*>(wrow + t * 32 * LD + (kg + 1) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = bfrag(kg, j);
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = cmr_mfma32(wc[t][j], b, acc[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) wc[t] = wn[t];
+  }
+}
+
+// LayerNorm over the 64 channels of this lane's row (32 here, 32 in the partner lane), in place
+__device__ __forceinline__ void la_layernorm(f32x16 (&v)[2], const float* __restrict__ gs, const float* __restrict__ bs,
+                                             int h, float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += v[t][r];
+  s += la_xhalf(s);
+  const float mean = s * (1.f / 64.f);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float d = v[t][r] - mean;
+      v[t][r] = d;
+      q += d * d;
+    }
+  q += la_xhalf(q);
+  const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + eps);
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gs + 32 * t + 8 * qd + 4 * h);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bs + 32 * t + 8 * qd + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[t][4 * qd + e] = v[t][4 * qd + e] * rstd * g[e] + b[e];
+    }
+}
+
+struct LaQueryArgs {
+  const float* x; int64_t ldx;
+  const float* kv;                     // [B][576]
+  const float *wq, *wm, *w0, *w3;      // [64][64], [64][64], [128][128], [64][128]  (PyTorch [out][in])
+  const float *g1, *b1, *g2, *b2;      // LayerNorm 1 / 2
+  float* out; int64_t ldo;
+  uint32_t rows, L; int B;
+  float s, eps, ln_eps;
+};
+
+__global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Wq = smem;                              // [64][68]
+  float* Wm = Wq + LA_D * LA_LD64;               // [64][68]
+  float* W0 = Wm + LA_D * LA_LD64;               // [128][132]
+  float* W3 = W0 + LA_HID * LA_LD128;            // [64][132]
+  float* Ln = W3 + LA_D * LA_LD128;              // g1 | b1 | g2 | b2
+  float* Kv = Ln + 4 * LA_D;                     // [B][576]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  {
+    // all 16 weight loads of a thread are issued before the first LDS store (one memory round trip, not 16)
+    f32x4 wq4[2], wm4[2], w04[8], w34[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      wq4[i] = *reinterpret_cast<const f32x4*>(a.wq + (tid + 512 * i) * 4);
+      wm4[i] = *reinterpret_cast<const f32x4*>(a.wm + (tid + 512 * i) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w04[i] = *reinterpret_cast<const f32x4*>(a.w0 + (tid + 512 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w34[i] = *reinterpret_cast<const f32x4*>(a.w3 + (tid + 512 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + 512 * i, n = e / (LA_D / 4), c = (e % (LA_D / 4)) * 4;
+      *reinterpret_cast<f32x4*>(&Wq[n * LA_LD64 + c]) = wq4[i];
+      *reinterpret_cast<f32x4*>(&Wm[n * LA_LD64 + c]) = wm4[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 512 * i, n = e / (LA_HID / 4), c = (e % (LA_HID / 4)) * 4;
+      *reinterpret_cast<f32x4*>(&W0[n * LA_LD128 + c]) = w04[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 512 * i, n = e / (LA_HID / 4), c = (e % (LA_HID / 4)) * 4;
+      *reinterpret_cast<f32x4*>(&W3[n * LA_LD128 + c]) = w34[i];
+    }
+  }
+  if (tid < LA_D) {
+    Ln[tid] = a.g1[tid]; Ln[LA_D + tid] = a.b1[tid]; Ln[2 * LA_D + tid] = a.g2[tid]; Ln[3 * LA_D + tid] = a.b2[tid];
+  }
+  for (int e = tid; e < a.B * (LA_STATE / 4); e += 512)
+    *reinterpret_cast<f32x4*>(&Kv[e * 4]) = *reinterpret_cast<const f32x4*>(a.kv + e * 4);
+  __syncthreads();
+
+  const uint32_t ntiles = (a.rows + 31) / 32;
+  for (uint32_t tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+    const uint32_t row = tile * 32 + l31;
+    const bool valid = row < a.rows;
+    const uint32_t rowc = valid ? row : 0;       // rows past the end recompute row 0 and are not stored
+    // ---- input fragments: B operand of the q projection and of the MLP's first half, and the residual
+    const float* xp = a.x + (int64_t)rowc * a.ldx + 4 * h;
+    f32x4 xf[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) xf[kg] = *reinterpret_cast<const f32x4*>(xp + kg * 8);
+    const float* kvb = Kv + (rowc / a.L) * LA_STATE + 4 * h;
+
+    // ---- Q = elu(Wq x) + 1 ; message = Q KV / (Q . Ksum + eps) * S, head by head (head = tile t, quad qd)
+    f32x16 msg[2];
+    la_gemm<2, 8, LA_LD64>(Wq, l31, h, msg, [&](int kg, int j) { return xf[kg][j]; });
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const int hd = 4 * t + qd;
+        float qo[4], qp[4];                      // this lane's 4 dims of the head (4h..4h+3), the partner's 4
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qo[e] = la_elu1(msg[t][4 * qd + e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qp[e] = la_xhalf(qo[e]);
+        // dims in natural order d = 0..7: lane half 0 owns 0..3, half 1 owns 4..7
+        float qd8[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          qd8[e] = h == 0 ? qo[e] : qp[e];
+          qd8[4 + e] = h == 0 ? qp[e] : qo[e];
+        }
+        const f32x4 ks0 = *reinterpret_cast<const f32x4*>(kvb - 4 * h + 512 + hd * 8);
+        const f32x4 ks1 = *reinterpret_cast<const f32x4*>(kvb - 4 * h + 512 + hd * 8 + 4);
+        float den = 0.f;
+        f32x4 num = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          const f32x4 kvr = *reinterpret_cast<const f32x4*>(kvb + hd * 64 + d * 8);     // KV[hd][d][4h .. 4h+3]
+          den += qd8[d] * (d < 4 ? ks0[d] : ks1[d - 4]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) num[e] += qd8[d] * kvr[e];
+        }
+        const float z = 1.f / (den + a.eps);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) msg[t][4 * qd + e] = num[e] * z * a.s;
+      }
+
+    // ---- merge + LayerNorm 1
+    f32x16 mrg[2];
+    la_gemm<2, 8, LA_LD64>(Wm, l31, h, mrg, [&](int kg, int j) { return msg[kg / 4][4 * (kg % 4) + j]; });
+    la_layernorm(mrg, Ln, Ln + LA_D, h, a.ln_eps);
+
+    // ---- mlp: 128 -> 128 (ReLU) -> 64 on cat[x, message], LayerNorm 2, residual
+    f32x16 hid[4];
+    la_gemm<4, 16, LA_LD128>(W0, l31, h, hid, [&](int kg, int j) {
+      return kg < 8 ? xf[kg & 7][j] : mrg[(kg - 8) / 4 & 1][4 * ((kg - 8) % 4 & 3) + j];
+    });
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hid[t][r] = hid[t][r] > 0.f ? hid[t][r] : 0.f;
+    f32x16 o[2];
+    la_gemm<2, 16, LA_LD128>(W3, l31, h, o, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
+    la_layernorm(o, Ln + 2 * LA_D, Ln + 3 * LA_D, h, a.ln_eps);
+
+    f32x4 ov[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[kg][e] = xf[kg][e] + o[kg / 4][4 * (kg % 4) + e];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) cmr_pin(ov[kg]);
+    if (valid) {
+      float* yp = a.out + (int64_t)row * a.ldo + 4 * h;
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) *reinterpret_cast<f32x4*>(yp + kg * 8) = ov[kg];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// State kernel.  Standard orientation (D[row][channel]: rows = A operand, weights = B operand): a lane owns one
+// output CHANNEL and accumulator register r is row (r&3) + 8(r>>2) + 4h of the tile -- which is the operand layout of
+// a second MFMA that contracts over the ROWS:  KV_tile[i][j] += sum_rows K[row][i] V[row][j]  (A = K registers,
+// B = V registers, 16 MFMAs per 32-channel tile).  Only the 8x8 diagonal blocks (one per head) of that 32x32
+// product are kept.  Workgroup (slab, b): wave w reduces tiles [(8 slab + w) TPW, + TPW) of batch b into registers
+// and writes ONE partial state; la_state_final sums the partials in a fixed order (deterministic, no atomics).
+struct LaStateArgs {
+  const float* y; int64_t ldy;
+  const float *wk, *wv;                // [64][64]
+  float* part;                         // [B][nslab * 8][576]
+  uint32_t S; int tiles_per_wave; float s;
+};
+
+__global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs a) {
+  __shared__ __attribute__((aligned(16))) float Wk[LA_D * LA_LD64];
+  __shared__ __attribute__((aligned(16))) float Wv[LA_D * LA_LD64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  for (int e = tid; e < LA_D * (LA_D / 4); e += 512) {
+    const int n = e / (LA_D / 4), c = (e % (LA_D / 4)) * 4;
+    *reinterpret_cast<f32x4*>(&Wk[n * LA_LD64 + c]) = *reinterpret_cast<const f32x4*>(a.wk + n * LA_D + c);
+    *reinterpret_cast<f32x4*>(&Wv[n * LA_LD64 + c]) = *reinterpret_cast<const f32x4*>(a.wv + n * LA_D + c);
+  }
+  __syncthreads();
+  const int b = blockIdx.y;
+  const uint32_t tiles_b = (a.S + 31) / 32;
+  const uint32_t t0 = (blockIdx.x * 8 + wave) * a.tiles_per_wave;
+  const float* yb = a.y + (int64_t)b * a.S * a.ldy;
+
+  f32x16 kv[2];                                  // kv[t]: 32x32 product of channel tile t with itself
+  float ksum[2] = {0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kv[t][r] = 0.f;
+
+  for (int it = 0; it < a.tiles_per_wave; ++it) {
+    const uint32_t tile = t0 + it;
+    if (tile >= tiles_b) break;
+    const uint32_t row = tile * 32 + l31;
+    const uint32_t rowc = row < a.S ? row : 0;
+    const float* yp = yb + (int64_t)rowc * a.ldy + 4 * h;
+    f32x4 yf[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) yf[kg] = *reinterpret_cast<const f32x4*>(yp + kg * 8);
+    f32x16 kk[2], vv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { kk[t][r] = 0.f; vv[t][r] = 0.f; }
+    const float* wkr = Wk + l31 * LA_LD64 + 4 * h;
+    const float* wvr = Wv + l31 * LA_LD64 + 4 * h;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      f32x4 wk4[2], wv4[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        wk4[t] = *reinterpret_cast<const f32x4*>(wkr + t * 32 * LA_LD64 + kg * 8);
+        wv4[t] = *reinterpret_cast<const f32x4*>(wvr + t * 32 * LA_LD64 + kg * 8);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          kk[t] = cmr_mfma32(yf[kg][j], wk4[t][j], kk[t]);      // D[row][channel 32t + l31]
+          vv[t] = cmr_mfma32(yf[kg][j], wv4[t][j], vv[t]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // K = elu + 1 (rows past the end contribute nothing), V = v / S
+    const bool partial = tile * 32 + 32 > a.S;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float k = la_elu1(kk[t][r]);
+        if (partial && tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.S) k = 0.f;
+        kk[t][r] = k;
+        ksum[t] += k;
+        vv[t][r] = vv[t][r] / a.s;
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) kv[t] = cmr_mfma32(kk[t][r], vv[t][r], kv[t]);   // contracts rows {r-th of h=0, r-th of h=1}
+  }
+  // partial state of this wave: KV[hd][d][v] from the diagonal 8x8 blocks, Ksum[hd][d]
+  float* p = a.part + ((int64_t)b * gridDim.x * 8 + blockIdx.x * 8 + wave) * LA_STATE;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const float ks = ksum[t] + la_xhalf(ksum[t]);
+    if (h == 0) p[512 + 32 * t + l31] = ks;                      // channel 32t + l31 = hd*8 + d
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * h;              // K channel (within tile t) of this register
+      if ((i >> 3) == (l31 >> 3)) p[(4 * t + (i >> 3)) * 64 + (i & 7) * 8 + (l31 & 7)] = kv[t][r];
+    }
+  }
+}
+
+// kvsum[b][c] = sum over the partial states, fixed order: 16 interleaved groups of partials per column, then
+// the 16 group sums in sequence.  grid (9 column blocks of 64, B), 1024 threads = 16 groups x 64 columns.
+__global__ __launch_bounds__(1024) void la_state_final_kernel(const float* __restrict__ part, float* __restrict__ kvsum,
+                                                              int npart) {
+  __shared__ float red[16][64];
+  const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
+  const float* p = part + (int64_t)b * npart * LA_STATE + col;
+  float s = 0.f;
+  for (int i = grp; i < npart; i += 16) s += p[(int64_t)i * LA_STATE];
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+    kvsum[(int64_t)b * LA_STATE + col] = t;
+  }
+}
+
+// The partition of a batch element's tiles into partial sums depends on S ONLY: a sample's result must not change
+// with the batch it is in (ranks shard the batch, tests/test_fullsize_gpu.py checks independence).
+int la_state_tiles_per_wave(int S) {
+  const int tiles_b = (S + 31) / 32;
+  int tpw = 1;
+  while (tpw < 64 && (tiles_b + 8 * tpw - 1) / (8 * tpw) > 64) tpw *= 2;     // at most 64 workgroups per batch element
+  return tpw;
+}
+int la_state_nslab(int S) {
+  const int tiles_b = (S + 31) / 32, tpw = la_state_tiles_per_wave(S);
+  return (tiles_b + 8 * tpw - 1) / (8 * tpw);
+}
+
+}  // namespace
+
+extern "C" int64_t cmr_la_kv_state_workspace_bytes(int B, int S) {
+  if (B <= 0 || S <= 0) return 0;
+  return (int64_t)B * la_state_nslab(S) * 8 * LA_STATE * sizeof(float);
+}
+
+extern "C" int cmr_la_kv_state_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum,
+                                   void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
+  CMR_REQUIRE(y && wk && wv && kvsum && workspace && B > 0 && B <= 65535 && S > 0);
+  CMR_REQUIRE(ldy % 4 == 0 && cmr_aligned16(y) && cmr_aligned16(wk) && cmr_aligned16(wv));
+  CMR_REQUIRE(workspace_bytes >= cmr_la_kv_state_workspace_bytes(B, S));
+  const int nslab = la_state_nslab(S);
+  const LaStateArgs a{y, ldy, wk, wv, (float*)workspace, (uint32_t)S, la_state_tiles_per_wave(S), (float)S};
+  hipLaunchKernelGGL(la_state_partial_kernel, dim3(nslab, B), dim3(512), 0, stream, a);
+  hipLaunchKernelGGL(la_state_final_kernel, dim3(LA_STATE / 64, B), dim3(1024), 0, stream, (const float*)workspace, kvsum,
+                     nslab * 8);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,
+                                      const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
+                                      const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, int B, int L, int S,
+                                      float eps, float ln_eps, hipStream_t stream) {
+  CMR_REQUIRE(x && kvsum && wq && wmerge && ln1_g && ln1_b && w_mlp0 && w_mlp3 && ln2_g && ln2_b && out);
+  CMR_REQUIRE(B > 0 && L > 0 && S > 0 && (int64_t)B * L < (int64_t)0x7fffffc0);
+  CMR_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && cmr_aligned16(x) && cmr_aligned16(out) && cmr_aligned16(kvsum) &&
+              cmr_aligned16(wq) && cmr_aligned16(wmerge) && cmr_aligned16(w_mlp0) && cmr_aligned16(w_mlp3));
+  const size_t smem = (size_t)(2 * LA_D * LA_LD64 + LA_HID * LA_LD128 + LA_D * LA_LD128 + 4 * LA_D + (size_t)B * LA_STATE) *
+                      sizeof(float);
+  if (smem > 160 * 1024) return CMR_EUNSUPPORTED;          // the per-batch states no longer fit beside the weights
+  static size_t attr_set = 0;
+  if (smem > attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(la_query_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)smem) != hipSuccess)
+      return CMR_ELAUNCH;
+    attr_set = smem;
+  }
+  const uint32_t rows = (uint32_t)((int64_t)B * L);
+  const uint32_t ntiles = (rows + 31) / 32;
+  uint32_t grid = (ntiles + 7) / 8;
+  if (grid > 256) grid = 256;                              // one persistent workgroup per CU (LDS bound)
+  const LaQueryArgs a{x, ldx, kvsum, wq, wmerge, w_mlp0, w_mlp3, ln1_g, ln1_b, ln2_g, ln2_b, out, ldo, rows, (uint32_t)L, B,
+                      (float)S, eps, ln_eps};
+  hipLaunchKernelGGL(la_query_layer_kernel, dim3(grid), dim3(512), smem, stream, a);
+  return cmr_launch_status();
+}

@@ -33,10 +33,17 @@ class LinearAttention(Planned):
         return dict(q=w(self.q_proj), k=w(self.k_proj), v=w(self.v_proj), merge=w(self.merge), m0=w(self.mlp[0]),
                     m3=w(self.mlp[3]), n1=g(self.norm1), n2=g(self.norm2))
 
+    FUSED = True      # two-kernel layer (ops.la_kv_state + ops.la_query_layer); False = one kernel per reference op
+
     def rows(self, x, y, B, L, S):
         """x rows [B*L,64] attends to y rows [B*S,64] (y may be x)."""
         self._require_eval()
         p = self.plan()
+        if self.FUSED:
+            out = ops.la_query_layer(x, ops.la_kv_state(y, p["k"], p["v"], B, S), p["q"], p["merge"], p["n1"], p["m0"],
+                                     p["m3"], p["n2"], B, L, S, self.eps, self.LN_EPS)
+            if out is not None:
+                return out
         qf = ops.linear(x, p["q"], act=ops.ACT_ELU1)
         kf = ops.linear(y, p["k"], act=ops.ACT_ELU1)
         v = ops.linear(y, p["v"])

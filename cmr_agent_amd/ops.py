@@ -203,6 +203,26 @@ def la_apply(qf, kvsum, B, L, S, eps, out=None):
     return out
 
 
+def la_kv_state(y, wk, wv, B, S):
+    """Fused k/v projections + per-(batch, head) state of one linear-attention layer: y [B*S,64] -> [B,576]."""
+    ws_bytes = _lib.load().cmr_la_kv_state_workspace_bytes(B, S)
+    ws = torch.empty((ws_bytes // 4,), dtype=f32, device=y.device)
+    kvsum = torch.empty((B, 576), dtype=f32, device=y.device)
+    _lib.call("cmr_la_kv_state_f32", _p(_rows(y)), _ld(y), _p(wk), _p(wv), _p(kvsum), _p(ws), ws_bytes, B, S, _stream())
+    return kvsum
+
+
+def la_query_layer(x, kvsum, wq, wmerge, ln1, w0, w3, ln2, B, L, S, eps, ln_eps, out=None):
+    """Fused query side of a linear-attention layer (q projection .. residual).  Returns None when the library
+    does not serve the shape (too many batch states for LDS) so that the caller can take the unfused path."""
+    if out is None:
+        out = torch.empty((B * L, 64), dtype=f32, device=x.device)
+    rc = _lib.call("cmr_la_query_layer_f32", _p(_rows(x)), _ld(x), _p(kvsum), _p(wq), _p(wmerge), _p(ln1[0]), _p(ln1[1]),
+                   _p(w0), _p(w3), _p(ln2[0]), _p(ln2[1]), _p(out), _ld(out), B, L, S, float(eps), float(ln_eps),
+                   _stream(), allow_unsupported=True)
+    return None if rc == _lib.UNSUPPORTED else out
+
+
 def planar_to_rows(x, cpad=4):
     """contiguous [B,C,N] -> [B*N,cpad] (zero padded), cpad in {4, 8}."""
     B, C, N = x.shape

@@ -113,6 +113,23 @@ int cmr_la_reduce_f32(const float* kf, int64_t ldk, const float* v, int64_t ldv,
 int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* msg, int64_t ldm, int B, int L, int S,
                      float eps, hipStream_t stream);
 
+/* Fused linear-attention layer (LinearAttention.py:38-73) in two kernels; the unfused entry points above stay for
+ * callers that need the intermediates.
+ *   cmr_la_kv_state_f32:    y [B*S, 64] -> K = elu(Wk y)+1 (:45-46,52), V = (Wv y)/S (:47,57) -> kvsum [B][576] in the
+ *                           layout of cmr_la_reduce_f32 (KV[h][d][v] at h*64 + d*8 + v, Ksum[h][d] at 512 + h*8 + d).
+ *                           Deterministic (per-wave partials in `workspace`, summed in a fixed order).
+ *   cmr_la_query_layer_f32: x [B*L, 64] -> Q = elu(Wq x)+1 -> message (:58-60) -> merge -> LayerNorm (:63-64)
+ *                           -> mlp(cat[x, message]): 128 -> 128 ReLU -> 64 (:67) -> LayerNorm (:68) -> x + . (:70).
+ *                           Weights are the PyTorch [out][in] matrices (no bias, as in the reference).
+ *                           CMR_EUNSUPPORTED when the B states do not fit in LDS beside the weights (B > 11). */
+int64_t cmr_la_kv_state_workspace_bytes(int B, int S);
+int cmr_la_kv_state_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, void* workspace,
+                        int64_t workspace_bytes, int B, int S, hipStream_t stream);
+int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,
+                           const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
+                           const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, int B, int L, int S, float eps,
+                           float ln_eps, hipStream_t stream);
+
 /* ---- point-cloud ops ----------------------------------------------------------------------- */
 
 /* planar [B,C,N] (the reference's point layout) -> rows [B*N, Cpad], Cpad in {4, 8}, zero padded. */

@@ -167,6 +167,33 @@ def test_linear_attention_core(ops, B, L, S):
     close(ops.la_apply(q.to(DEV), kvsum, B, L, S, 1e-6), ref, 5e-5, "la-apply")
 
 
+@pytest.mark.parametrize("B,L,S", [(2, 70, 45), (1, 1280, 3000), (2, 2016, 1280), (3, 33, 64), (8, 960, 320)])
+def test_linear_attention_fused_layer(ops, B, L, S):
+    """cmr_la_kv_state_f32 + cmr_la_query_layer_f32 against the oracle's restatement of LinearAttention.forward
+    (ragged L / S: tiles that straddle batch elements and partial last tiles)."""
+    names = {"q_proj.weight": (64, 64), "k_proj.weight": (64, 64), "v_proj.weight": (64, 64), "merge.weight": (64, 64),
+             "mlp.0.weight": (128, 128), "mlp.3.weight": (64, 128), "norm1.weight": (64,), "norm1.bias": (64,),
+             "norm2.weight": (64,), "norm2.bias": (64,)}
+    sd = {k: rnd(*shp, seed=90 + i, lo=-0.3, hi=0.3) for i, (k, shp) in enumerate(names.items())}
+    sd["norm1.weight"] += 1.0
+    sd["norm2.weight"] += 1.0
+    x, y = rnd(B, L, 64, seed=80), rnd(B, S, 64, seed=81)
+    ref = O.linear_attention(O.Weights({k: v.double() for k, v in sd.items()}), x.double(), y.double())
+    d = {k: v.to(DEV).contiguous() for k, v in sd.items()}
+    xr, yr = x.to(DEV).view(B * L, 64), y.to(DEV).view(B * S, 64)
+    kv = ops.la_kv_state(yr, d["k_proj.weight"], d["v_proj.weight"], B, S)
+    K = F.elu(y.double() @ sd["k_proj.weight"].double().T) + 1
+    V = (y.double() @ sd["v_proj.weight"].double().T) / S
+    close(kv[:, :512], torch.einsum("nshd,nshv->nhdv", K.view(B, S, 8, 8), V.view(B, S, 8, 8)).reshape(B, 512), 2e-5, "kv")
+    close(kv[:, 512:], K.sum(1), 2e-5, "ksum")
+    got = ops.la_query_layer(xr, kv, d["q_proj.weight"], d["merge.weight"], (d["norm1.weight"], d["norm1.bias"]),
+                             d["mlp.0.weight"], d["mlp.3.weight"], (d["norm2.weight"], d["norm2.bias"]), B, L, S, 1e-6, 1e-5)
+    assert got is not None
+    close(got.view(B, L, 64), ref, 1e-4, "la-layer")
+    kv2 = ops.la_kv_state(yr, d["k_proj.weight"], d["v_proj.weight"], B, S)
+    assert torch.equal(kv, kv2), "state reduction must be deterministic"
+
+
 def _cloud(B, N, seed):
     return rnd(B, 3, N, seed=seed, lo=-20, hi=20)
 
