@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils.streams import fork_join
 from . import _pack
 from ._pack import Planned
 from .ImageResNet import to_nhwc
@@ -101,12 +102,7 @@ class CMRAgent(Planned):
             feat, g = r
         return g
 
-    # ------------------------------------------------------------------------------------------
-    def forward_cl(self, state2d, state3d_rows, B, N, split=None):
-        """state2d NHWC [B,h,w,128]; state3d rows [B*N,8] = (x,y,z,overlap,in_cam,0,0,0).
-        split = (img_geo_feat NHWC [B,h,w,64], projected half NHWC [B,h,w,64]) when the observation comes from
-        cmr_agent_amd.environment: the two halves of state2d as separate tensors."""
-        self._require_eval()
+    def _embed_2d(self, state2d, B, split):
         p = self.plan()
         c = 2 * self.config.embed_dim
         x = state2d
@@ -129,7 +125,9 @@ class CMRAgent(Planned):
                 if (x.shape[1], x.shape[2]) != (kh, kw):
                     raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (x.shape[1], x.shape[2], kh, kw))
                 x = ops.colmean(x.view(B * kh * kw, c), B, kh * kw)        # AvgPool2d((H, W)) = per-sample channel mean
-        e2d = ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
+        return ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
+
+    def _embed_3d_any(self, state3d_rows, B, N):
         e3d = self._embed_3d(state3d_rows, B, N)
         if e3d is None:                                      # shapes the fused block kernel is not built for
             layers = self.state_3d_embed
@@ -138,6 +136,17 @@ class CMRAgent(Planned):
                 g = ops.colmax(feat, B, N)                   # torch.max over points, broadcast back (:95-99)
                 feat = layers[i].rows(feat, x2=g, div2=N)
             e3d = ops.colmax(feat, B, N)
+        return e3d
+
+    # ------------------------------------------------------------------------------------------
+    def forward_cl(self, state2d, state3d_rows, B, N, split=None):
+        """state2d NHWC [B,h,w,128]; state3d rows [B*N,8] = (x,y,z,overlap,in_cam,0,0,0).
+        split = (img_geo_feat NHWC [B,h,w,64], projected half NHWC [B,h,w,64]) when the observation comes from
+        cmr_agent_amd.environment: the two halves of state2d as separate tensors."""
+        self._require_eval()
+        # the 3-D branch (4 fused blocks on B*N points) runs on a side stream underneath the 2-D convolutions
+        e3d, e2d = fork_join(lambda: self._embed_3d_any(state3d_rows, B, N), lambda: self._embed_2d(state2d, B, split), tag="agent")
+        p = self.plan()
         out = []
         for name in ("policy_r", "policy_t", "value"):
             l0, l1, l2 = p[name]

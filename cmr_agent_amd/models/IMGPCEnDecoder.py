@@ -8,6 +8,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils.streams import fork_join
 from ._pack import Planned
 from .ImageResNet import ResidualBlock
 from .IMGPCEncoder import IMGPCEncoder
@@ -62,23 +63,30 @@ class IMGPCEnDecoder(Planned):
         B, geo, f2 = cl["B"], cl["geo"], cl["f2"]
         _, h, w, f = f2.shape
         P = self.config.patch_size
-        # proxies -> nodes: cat([node_feat, pt_proxy[node2proxy]]) feeds the first fuse conv un-materialised
-        nod = self.node_fuse_convs[0].rows(cl["node_feat"], x2=cl["pt_proxy"], idx2=cl["node2proxy_global"])
-        for layer in list(self.node_fuse_convs)[1:-1]:
-            nod = layer.rows(nod)
-        # proxies -> pixels
-        x = ops.upsample_concat(f2, cl["img_proxy"], P)
-        convs = list(self.img_fuse_convs)[:-1]
-        for i, layer in enumerate(convs):
-            x = layer.forward_cl(x, post=self._pos_table(h, w, x.device) if i == 0 else None)
+        def fuse_nodes():
+            # proxies -> nodes: cat([node_feat, pt_proxy[node2proxy]]) feeds the first fuse conv un-materialised
+            nod = self.node_fuse_convs[0].rows(cl["node_feat"], x2=cl["pt_proxy"], idx2=cl["node2proxy_global"])
+            for layer in list(self.node_fuse_convs)[1:-1]:
+                nod = layer.rows(nod)
+            return nod
+
+        def fuse_pixels():
+            # proxies -> pixels
+            x = ops.upsample_concat(f2, cl["img_proxy"], P)
+            for i, layer in enumerate(list(self.img_fuse_convs)[:-1]):
+                x = layer.forward_cl(x, post=self._pos_table(h, w, x.device) if i == 0 else None)
+            return x
+
+        nod, x = fork_join(fuse_nodes, fuse_pixels, tag="fuse")
         cl["vis_feat"] = x
         pix = x.view(B * h * w, f)
         M, L = geo.M, h * w
         for i in range(self.config.linear_attention_num):
             nod = self.pixel_to_node_LA[i].rows(nod, pix, B, M, L)
             pix = self.node_to_pixel_LA[i].rows(pix, nod, B, L, M)
-            nod = self.node_self_LA[i].rows(nod, nod, B, M, M)
-            pix = self.pixel_self_LA[i].rows(pix, pix, B, L, L)
+            n0, p0 = nod, pix
+            nod, pix = fork_join(lambda: self.node_self_LA[i].rows(n0, n0, B, M, M),
+                                 lambda: self.pixel_self_LA[i].rows(p0, p0, B, L, L), tag="fine_sa")
         cl["fused_img_feat"] = pix.view(B, h, w, f)
         cl["fused_node_feat"] = nod
         cl["h"], cl["w"] = h, w

@@ -4,6 +4,7 @@ models/IMGPCEncoder.py (:105-164).  Inputs stay on the device of the module's pa
 (the reference hard-codes .cuda(), :130-134)."""
 import torch.nn as nn
 
+from ..utils.streams import fork_join
 from ._pack import Planned, device_of
 from ._vit import Attention, Block, Mlp  # noqa: F401
 from .ImageViT import ImageTransformer
@@ -33,15 +34,22 @@ class IMGPCEncoder(Planned):
         pc = data_batch['pc'].to(dev)
         node = data_batch['node'].to(dev)
         idx = data_batch['pt2node'].to(dev)
-        geo = PointGeometry(pc, node, idx)
-        B, Q = geo.B, self.config.num_proxy
-        img_proxy, T, f2, f1, f0 = self.img_transformer.forward_cl(img)
-        pt_proxy, n2p, n2p_global, pt_feat, node_feat = self.pt_transformer.forward_cl(geo)
+        B, Q = pc.shape[0], self.config.num_proxy
+
+        def point_tower():
+            geo = PointGeometry(pc, node, idx)
+            return (geo,) + tuple(self.pt_transformer.forward_cl(geo))
+
+        # the two towers are independent: the point tower (kNN, grouping, small GEMMs) runs on a side stream
+        # underneath the image tower's convolutions; so do the two self-attention blocks of every coarse layer
+        (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat), (img_proxy, T, f2, f1, f0) = fork_join(
+            point_tower, lambda: self.img_transformer.forward_cl(img), tag="towers")
         for i in range(self.config.num_ca_layer_coarse):
             img_proxy = self.p2i_ca_layers[i].rows(img_proxy, pt_proxy, B, T, Q)
             pt_proxy = self.i2p_ca_layers[i].rows(pt_proxy, img_proxy, B, Q, T)
-            img_proxy = self.img_sa_layers[i].rows(img_proxy, None, B, T, T)
-            pt_proxy = self.pt_sa_layers[i].rows(pt_proxy, None, B, Q, Q)
+            ip, pp = img_proxy, pt_proxy
+            pt_proxy, img_proxy = fork_join(lambda: self.pt_sa_layers[i].rows(pp, None, B, Q, Q),
+                                            lambda: self.img_sa_layers[i].rows(ip, None, B, T, T), tag="coarse_sa")
         return dict(geo=geo, B=B, T=T, Q=Q, pc=pc, f2=f2, f1=f1, f0=f0, img_proxy=img_proxy, pt_proxy=pt_proxy,
                     node2proxy=n2p, node2proxy_global=n2p_global, pt_feat=pt_feat, node_feat=node_feat)
 

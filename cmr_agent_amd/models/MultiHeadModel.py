@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils.streams import fork_join
 from . import _pack
 from ._pack import Planned
 from .ImageResNet import ResidualBlock
@@ -44,30 +45,42 @@ class _Head(Planned):
         pc, im = getattr(self, self._pc_name), getattr(self, self._img_name)
         return dict(pc0=_pack.lin(pc[0]), pc2=_pack.lin(pc[2]), im0=_pack.lin(im[0]), im2=_pack.lin(im[2]))
 
-    def trunk_cl(self, cl):
-        """-> (point rows [B*N, pc_out], pixel rows [B*h*w, img_out])"""
+    def points_cl(self, cl):
+        """-> point rows [B*N, pc_out]"""
         self._require_eval()
         p = self.plan()
-        geo = cl["geo"]
-        x = self.point_fuse_convs[0].rows(cl["pt_feat"], x2=cl["fused_node_feat"], idx2=geo.gidx)
+        x = self.point_fuse_convs[0].rows(cl["pt_feat"], x2=cl["fused_node_feat"], idx2=cl["geo"].gidx)
         for layer in list(self.point_fuse_convs)[1:]:
             x = layer.rows(x)
         pts = ops.linear(ops.linear(x, *p["pc0"], act=ops.ACT_LRELU, act_param=HEAD_SLOPE), *p["pc2"])
+        return pts[:, :self._pc_out]                              # widths are padded to 4 in the plan
+
+    def pixels_cl(self, cl):
+        """-> pixel rows [B*h*w, img_out]"""
+        self._require_eval()
+        p = self.plan()
         y = cl["fused_img_feat"]
         for layer in self.img_res_convs:
             y = layer.forward_cl(y)
         B, h, w, f = y.shape
         pix = ops.linear(ops.linear(y.view(B * h * w, f), *p["im0"], act=ops.ACT_LRELU, act_param=HEAD_SLOPE), *p["im2"])
-        return pts[:, :self._pc_out], pix[:, :self._img_out]      # widths are padded to 4 in the plan
+        return pix[:, :self._img_out]
+
+    def trunk_cl(self, cl):
+        """-> (point rows [B*N, pc_out], pixel rows [B*h*w, img_out]); the two branches are independent"""
+        return fork_join(lambda: self.points_cl(cl), lambda: self.pixels_cl(cl), tag="trunk")
 
 
 class OverlapDetectionHead(_Head):
     def __init__(self, config):
         super().__init__(config, 2, 2, "pc_overlap_head", "img_overlap_head", 32, 32)
 
-    def forward_cl(self, cl):
-        cl["pc_overlap_logits"], cl["img_overlap_logits"] = self.trunk_cl(cl)
+    def finish_cl(self, cl, pts, pix):
+        cl["pc_overlap_logits"], cl["img_overlap_logits"] = pts, pix
         return cl
+
+    def forward_cl(self, cl):
+        return self.finish_cl(cl, *self.trunk_cl(cl))
 
 
 class GeometricDistanceHead(_Head):
@@ -76,11 +89,13 @@ class GeometricDistanceHead(_Head):
         super().__init__(config, f, f, "pc_geo_head", "img_geo_head", f, f)
         self.dist_thres, self.pos_margin, self.neg_margin, self.lambda_geo = 1, 0.1, 1.4, 1
 
-    def forward_cl(self, cl):
-        pts, pix = self.trunk_cl(cl)
+    def finish_cl(self, cl, pts, pix):
         cl["pc_geo_feat"] = ops.l2norm64(pts)                       # F.normalize(dim=1), :233
         cl["img_geo_feat"] = ops.l2norm64(pix).view(cl["B"], cl["h"], cl["w"], -1)
         return cl
+
+    def forward_cl(self, cl):
+        return self.finish_cl(cl, *self.trunk_cl(cl))
 
 
 class MultiHeadModel(Planned):
@@ -96,8 +111,13 @@ class MultiHeadModel(Planned):
 
     def forward_cl(self, data_batch):
         cl = self.encoder_decoder.forward_cl(data_batch)
-        self.overlap_head.forward_cl(cl)
-        self.geo_head.forward_cl(cl)
+        # four independent branches (2 heads x {points, pixels}): one flat fork, the pixel convolutions of the
+        # geometric head stay on the main stream
+        oh, gh = self.overlap_head, self.geo_head
+        op, ox, gp, gx = fork_join(lambda: oh.points_cl(cl), lambda: oh.pixels_cl(cl), lambda: gh.points_cl(cl),
+                                   lambda: gh.pixels_cl(cl), tag="heads")
+        oh.finish_cl(cl, op, ox)
+        gh.finish_cl(cl, gp, gx)
         prob, lo, hi = ops.softmax2(cl["pc_overlap_logits"], 0.5, 0.8)       # :330-335
         cl["pc_prob"], cl["pc_overlap_u8"], cl["pc_overlap_hi_u8"] = prob, lo, hi
         cl["img_prob"], _, _ = ops.softmax2(cl["img_overlap_logits"], 0.5, 0.8)

@@ -1,0 +1,55 @@
+"""Fork / join of independent branches on HIP streams.
+
+The reference's forward passes are sequential Python, but many of their sub-graphs are independent (image tower
+vs point tower, the agent's 2-D vs 3-D state embedding, the self-attention layers of the two modalities, ...).
+Most kernels of the smaller branch are latency-bound launches that fill a fraction of the 256 CUs; issued on a
+second stream they run underneath the MFMA-bound convolutions of the other branch.  Under hipGraph capture the
+event dependencies recorded here become the edges of the graph, so the replayed iteration keeps the overlap.
+
+Memory rules that make this safe with torch's stream-aware caching allocator (no record_stream needed):
+  * the side branch starts with side.wait_stream(main): every block it allocates or reuses is ordered after all
+    work queued on the main stream so far;
+  * the caller keeps the inputs of both branches alive until fork_join returns (the closures hold them);
+  * results of the side branch are first used on the main stream after main.wait_stream(side)."""
+import os
+
+import torch
+
+ENABLED = os.environ.get("CMR_STREAMS", "1") != "0"
+_pool = {}
+_depth = 0
+
+
+def _side_stream(device, depth):
+    key = (device, depth)
+    if key not in _pool:
+        _pool[key] = torch.cuda.Stream(device=device)
+    return _pool[key]
+
+
+_ONLY = set(t for t in os.environ.get("CMR_STREAMS_ONLY", "").split(",") if t)      # debugging: fork only these tags
+
+
+def fork_join(*fns, tag=""):
+    """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn on the current stream and
+    returns all results (in argument order) after joining.  Sequential on CPU / when disabled / when called from
+    inside another fork (nested forks crash hipGraph capture on ROCm 7.2: use one flat n-way fork instead)."""
+    global _depth
+    if not ENABLED or not torch.cuda.is_available() or _depth > 0 or (_ONLY and tag not in _ONLY):
+        return tuple(f() for f in fns)
+    main = torch.cuda.current_stream()
+    sides = [_side_stream(main.device, i) for i in range(len(fns) - 1)]
+    for s in sides:
+        s.wait_stream(main)
+    _depth += 1
+    try:
+        out = []
+        for s, f in zip(sides, fns[:-1]):
+            with torch.cuda.stream(s):
+                out.append(f())
+        out.append(fns[-1]())
+    finally:
+        _depth -= 1
+    for s in sides:
+        main.wait_stream(s)
+    return tuple(out)
