@@ -1,0 +1,251 @@
+// Pre-LN transformer block (reference models/ImageViT.py:61-158, PointViT.py:96-183, IMGPCEncoder.py:14-102) in three
+// launches instead of seven to nine:
+//
+//   cmr_ln64_linear_f32      LayerNorm(64) + projection for up to two row sets in ONE launch
+//                            (self block: x -> [q|k|v];  cross block: x -> q and y -> [k|v], same norm)
+//   cmr_mha_f32              (attention.hip, unchanged)
+//   cmr_vit_out_ffn_f32      x1 = ctx Wo + bo + x ;  out = x1 + W2 gelu(W1 LN(x1) + b1) + b2
+//
+// The token counts of this path are small (B*T = 3 344 image proxies, B*Q = 2 048 point proxies): the unfused block
+// is a chain of launch-latency-bound kernels, each filling a fraction of the chip.  Weights are passed as MFMA A
+// fragments ([n_out/32][k/8][64 lanes][4], cmr_agent_amd/models/_pack.py:frag_pack) and read straight from L2 with
+// 1 KB coalesced wave loads; everything is computed transposed (D'[channel][row]: a lane owns one row, accumulator
+// register 4q+e of tile t is channel 32t + 8q + 4h + e = B fragment k-group 4t+q of the next GEMM).
+// The MLP kernel gives one 32-row tile to a workgroup of 8 waves: every wave redoes the small out-projection and
+// LayerNorm, takes 128 of the 1024 hidden units through fc1 / GELU / its K-slice of fc2, and the 8 partial outputs
+// are summed through LDS in a fixed order.
+#include "cmr_common.h"
+
+namespace {
+
+__device__ __forceinline__ float vf_xhalf(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ float vf_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+// LayerNorm over the 64 channels of a row held as 8 fragments (32 channels here, 32 in lane ^ 32), in place
+__device__ __forceinline__ void vf_layernorm(f32x4 (&v)[8], const float* __restrict__ g, const float* __restrict__ b, int h,
+                                             float eps) {
+  float s = 0.f;
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) s += (v[kg][0] + v[kg][1]) + (v[kg][2] + v[kg][3]);
+  s += vf_xhalf(s);
+  const float mean = s * (1.f / 64.f);
+  float q = 0.f;
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[kg][e] - mean;
+      v[kg][e] = d;
+      q += d * d;
+    }
+  q += vf_xhalf(q);
+  const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + eps);
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 8 * kg + 4 * h);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(b + 8 * kg + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[kg][e] = v[kg][e] * rstd * gv[e] + bv[e];
+  }
+}
+
+// acc[t] = sum_kg sum_j Wf[tile0 + t][kg0 + kg][lane][j] * bfrag(kg, j)   (fragments prefetched one k-group ahead)
+template <int T, int KG, typename BF>
+__device__ __forceinline__ void vf_gemm(const float* __restrict__ wf, int kg_total, int tile0, int kg0, int lane,
+                                        f32x16 (&acc)[T], BF bfrag) {
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float* wp = wf + ((int64_t)tile0 * kg_total + kg0) * 256 + lane * 4;
+  const int64_t tstride = (int64_t)kg_total * 256;
+  f32x4 wc[T], wn[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) wc[t] = *reinterpret_cast<const f32x4*>(wp + t * tstride);
+#pragma unroll
+  for (int kg = 0; kg < KG; ++kg) {
+    if (kg + 1 < KG) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) wn[t] = *reinterpret_cast<const f32x4*>(wp + t * tstride + (kg + 1) * 256);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = bfrag(kg, j);
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = cmr_mfma32(wc[t][j], b, acc[t]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < T; ++t) wc[t] = wn[t];
+  }
+}
+
+struct LnLinProblem {
+  const float* x; int64_t ldx; uint32_t rows;
+  const float* wf; const float* bias; int npair;       // n_out = 64 * npair
+  float* y; int64_t ldy;
+};
+struct LnLinArgs {
+  LnLinProblem p[2];
+  uint32_t tiles0, tiles;                              // tiles of problem 0, total tiles
+  const float* g; const float* b; float eps;
+};
+
+__global__ __launch_bounds__(256) void ln64_linear_kernel(const LnLinArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const uint32_t gt = blockIdx.x * 4 + wave;
+  if (gt >= a.tiles) return;
+  const LnLinProblem& P = gt < a.tiles0 ? a.p[0] : a.p[1];
+  const uint32_t tile = gt < a.tiles0 ? gt : gt - a.tiles0;
+  const uint32_t row = tile * 32 + l31;
+  const bool valid = row < P.rows;
+  const float* xp = P.x + (int64_t)(valid ? row : 0) * P.ldx + 4 * h;
+  f32x4 xf[8];
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) xf[kg] = *reinterpret_cast<const f32x4*>(xp + kg * 8);
+  vf_layernorm(xf, a.g, a.b, h, a.eps);
+  for (int pr = 0; pr < P.npair; ++pr) {               // 64 output channels per pass
+    f32x16 acc[2];
+    vf_gemm<2, 8>(P.wf, 8, 2 * pr, 0, lane, acc, [&](int kg, int j) { return xf[kg][j]; });
+    f32x4 ov[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(P.bias + 64 * pr + 32 * t + 8 * qd + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ov[4 * t + qd][e] = acc[t][4 * qd + e] + bv[e];
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cmr_pin(ov[i]);
+    if (valid) {
+      float* yp = P.y + (int64_t)row * P.ldy + 64 * pr + 4 * h;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(yp + 8 * i) = ov[i];
+    }
+  }
+}
+
+struct OutFfnArgs {
+  const float* ctx; int64_t ldc;
+  const float* x; int64_t ldx;                         // residual stream
+  const float* wo_f; const float* bo;                  // [2][8][64][4], [64]
+  const float* g2; const float* b2n; float eps;        // ffn_norm
+  const float* w1_f; const float* b1;                  // [32][8][64][4], [1024]
+  const float* w2_f; const float* b2;                  // [2][128][64][4], [64]
+  float* out; int64_t ldo; uint32_t rows;
+};
+
+__global__ __launch_bounds__(512) void vit_out_ffn_kernel(const OutFfnArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[7 * 8 * 64 * 4];     // partial outputs of waves 1..7: [w][frag][lane][4]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const uint32_t row = blockIdx.x * 32 + l31;
+  const bool valid = row < a.rows;
+  const uint32_t rowc = valid ? row : 0;
+  const float* cp = a.ctx + (int64_t)rowc * a.ldc + 4 * h;
+  const float* xp = a.x + (int64_t)rowc * a.ldx + 4 * h;
+  f32x4 cf[8], x1[8];
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) {
+    cf[kg] = *reinterpret_cast<const f32x4*>(cp + kg * 8);
+    x1[kg] = *reinterpret_cast<const f32x4*>(xp + kg * 8);
+  }
+  // ---- x1 = ctx Wo + bo + x     (every wave: 64 MFMAs, cheaper than a broadcast through LDS)
+  {
+    f32x16 acc[2];
+    vf_gemm<2, 8>(a.wo_f, 8, 0, 0, lane, acc, [&](int kg, int j) { return cf[kg][j]; });
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + 8 * kg + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x1[kg][e] = (acc[kg / 4][4 * (kg % 4) + e] + bv[e]) + x1[kg][e];
+    }
+  }
+  f32x4 xn[8];
+#pragma unroll
+  for (int kg = 0; kg < 8; ++kg) xn[kg] = x1[kg];
+  vf_layernorm(xn, a.g2, a.b2n, h, a.eps);
+  // ---- this wave's 128 hidden units: fc1 + GELU, then its K-slice of fc2
+  f32x16 hid[4];
+  vf_gemm<4, 8>(a.w1_f, 8, 4 * wave, 0, lane, hid, [&](int kg, int j) { return xn[kg][j]; });
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + 128 * wave + 32 * t + 8 * qd + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) hid[t][4 * qd + e] = vf_gelu(hid[t][4 * qd + e] + bv[e]);
+    }
+  f32x16 part[2];
+  vf_gemm<2, 16>(a.w2_f, 128, 0, 16 * wave, lane, part, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 v = {part[i / 4][4 * (i % 4)], part[i / 4][4 * (i % 4) + 1], part[i / 4][4 * (i % 4) + 2], part[i / 4][4 * (i % 4) + 3]};
+      *reinterpret_cast<f32x4*>(&red[(((wave - 1) * 8 + i) * 64 + lane) * 4]) = v;
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  f32x4 ov[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f32x4 s = {part[i / 4][4 * (i % 4)], part[i / 4][4 * (i % 4) + 1], part[i / 4][4 * (i % 4) + 2], part[i / 4][4 * (i % 4) + 3]};
+#pragma unroll
+    for (int w = 0; w < 7; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * 8 + i) * 64 + lane) * 4]);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + 8 * i + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[i][e] = (s[e] + bv[e]) + x1[i][e];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) cmr_pin(ov[i]);
+  if (valid) {
+    float* yp = a.out + (int64_t)row * a.ldo + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(yp + 8 * i) = ov[i];
+  }
+}
+
+}  // namespace
+
+extern "C" int cmr_ln64_linear_f32(const float* x, int64_t ldx, int64_t rows_x, const float* wf_x, const float* bias_x,
+                                   int n_out_x, float* out_x, int64_t ldo_x, const float* y, int64_t ldy, int64_t rows_y,
+                                   const float* wf_y, const float* bias_y, int n_out_y, float* out_y, int64_t ldo_y,
+                                   const float* gamma, const float* beta, float eps, hipStream_t stream) {
+  CMR_REQUIRE(x && wf_x && bias_x && out_x && gamma && beta && rows_x > 0 && rows_x < (int64_t)0x7fffffc0);
+  CMR_REQUIRE(n_out_x > 0 && n_out_x % 64 == 0 && ldx % 4 == 0 && ldo_x % 4 == 0 && cmr_aligned16(x) && cmr_aligned16(wf_x) &&
+              cmr_aligned16(bias_x) && cmr_aligned16(out_x) && cmr_aligned16(gamma) && cmr_aligned16(beta));
+  LnLinArgs a{};
+  a.p[0] = LnLinProblem{x, ldx, (uint32_t)rows_x, wf_x, bias_x, n_out_x / 64, out_x, ldo_x};
+  a.tiles0 = (uint32_t)((rows_x + 31) / 32);
+  a.tiles = a.tiles0;
+  if (y) {
+    CMR_REQUIRE(wf_y && bias_y && out_y && rows_y > 0 && rows_y < (int64_t)0x7fffffc0 && n_out_y > 0 && n_out_y % 64 == 0);
+    CMR_REQUIRE(ldy % 4 == 0 && ldo_y % 4 == 0 && cmr_aligned16(y) && cmr_aligned16(wf_y) && cmr_aligned16(bias_y) &&
+                cmr_aligned16(out_y));
+    a.p[1] = LnLinProblem{y, ldy, (uint32_t)rows_y, wf_y, bias_y, n_out_y / 64, out_y, ldo_y};
+    a.tiles += (uint32_t)((rows_y + 31) / 32);
+  } else {
+    a.p[1] = a.p[0];
+  }
+  a.g = gamma; a.b = beta; a.eps = eps;
+  hipLaunchKernelGGL(ln64_linear_kernel, dim3((a.tiles + 3) / 4), dim3(256), 0, stream, a);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_vit_out_ffn_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f,
+                                   const float* bo, const float* ln_g, const float* ln_b, float eps, const float* w1_f,
+                                   const float* b1, const float* w2_f, const float* b2, float* out, int64_t ldo, int64_t rows,
+                                   hipStream_t stream) {
+  CMR_REQUIRE(ctx && x && wo_f && bo && ln_g && ln_b && w1_f && b1 && w2_f && b2 && out && rows > 0 && rows < (int64_t)0x7fffffc0);
+  CMR_REQUIRE(ldc % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && cmr_aligned16(ctx) && cmr_aligned16(x) && cmr_aligned16(out) &&
+              cmr_aligned16(wo_f) && cmr_aligned16(w1_f) && cmr_aligned16(w2_f) && cmr_aligned16(bo) && cmr_aligned16(b1) &&
+              cmr_aligned16(b2) && cmr_aligned16(ln_g) && cmr_aligned16(ln_b));
+  const OutFfnArgs a{ctx, ldc, x, ldx, wo_f, bo, ln_g, ln_b, eps, w1_f, b1, w2_f, b2, out, ldo, (uint32_t)rows};
+  hipLaunchKernelGGL(vit_out_ffn_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(512), 0, stream, a);
+  return cmr_launch_status();
+}

@@ -57,6 +57,13 @@ def lin(layer, bn=None):
     return pad_rows(pad_k(w.reshape(w.shape[0], -1)), b.contiguous())
 
 
+def frag_pack(w):
+    """W [n_out, k] (n_out % 32 == 0, k % 8 == 0) -> MFMA A fragments [n_out/32][k/8][64 lanes][4] (flat), lane = 32 h + l
+    holding W[32 tile + l][8 kgroup + 4 h .. + 3]: a wave reads one fragment as 1 KB of contiguous memory."""
+    n, k = w.shape
+    return w.reshape(n // 32, 32, k // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 

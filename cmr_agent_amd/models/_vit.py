@@ -28,9 +28,12 @@ class Attention(Planned):
         wq, bq = _pack.lin(self.query)
         wk, bk = _pack.lin(self.key)
         wv, bv = _pack.lin(self.value)
-        return dict(q=(wq, bq), kv=(torch.cat([wk, wv], 0).contiguous(), torch.cat([bk, bv], 0).contiguous()),
-                    qkv=(torch.cat([wq, wk, wv], 0).contiguous(), torch.cat([bq, bk, bv], 0).contiguous()),
-                    out=_pack.lin(self.out))
+        kv = (torch.cat([wk, wv], 0).contiguous(), torch.cat([bk, bv], 0).contiguous())
+        qkv = (torch.cat([wq, wk, wv], 0).contiguous(), torch.cat([bq, bk, bv], 0).contiguous())
+        wo, bo = _pack.lin(self.out)
+        f = _pack.frag_pack
+        return dict(q=(wq, bq), kv=kv, qkv=qkv, out=(wo, bo),
+                    q_f=(f(wq), bq), kv_f=(f(kv[0]), kv[1]), qkv_f=(f(qkv[0]), qkv[1]), out_f=(f(wo), bo))
 
     def rows(self, xn, yn, B, tx, ty, residual):
         """out-projection(softmax-attention(xn, yn)) + residual; yn is None for self-attention."""
@@ -57,7 +60,8 @@ class Mlp(Planned):
         nn.init.normal_(self.fc2.bias, std=1e-6)
 
     def _build_plan(self):
-        return dict(fc1=_pack.lin(self.fc1), fc2=_pack.lin(self.fc2))
+        fc1, fc2 = _pack.lin(self.fc1), _pack.lin(self.fc2)
+        return dict(fc1=fc1, fc2=fc2, fc1_f=(_pack.frag_pack(fc1[0]), fc1[1]), fc2_f=(_pack.frag_pack(fc2[0]), fc2[1]))
 
     def rows(self, xn, residual):
         p = self.plan()
@@ -80,9 +84,20 @@ class Block(Planned):
         g = lambda ln: (ln.weight.detach().contiguous(), ln.bias.detach().contiguous())
         return dict(n1=g(self.attention_norm), n2=g(self.ffn_norm))
 
+    FUSED = True      # three launches per block (ops.ln64_linear, ops.mha, ops.vit_out_ffn); False = one per reference op
+
     def rows(self, x, y, B, tx, ty):
         self._require_eval()
         p = self.plan()
+        if self.FUSED and self.ffn.fc1.out_features == 1024:
+            a, m = self.attn.plan(), self.ffn.plan()
+            if y is None or y is x:
+                qkv = ops.ln64_linear(x, *a["qkv_f"], *p["n1"], self.LN_EPS)
+                ctx = ops.mha(qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192], B, tx, tx)
+            else:
+                q, kv = ops.ln64_linear(x, *a["q_f"], *p["n1"], self.LN_EPS, y, *a["kv_f"])
+                ctx = ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, tx, ty)
+            return ops.vit_out_ffn(ctx, x, *a["out_f"], p["n2"], self.LN_EPS, *m["fc1_f"], *m["fc2_f"])
         xn = ops.layernorm64(x, *p["n1"], self.LN_EPS)
         yn = None if (y is None or y is x) else ops.layernorm64(y, *p["n1"], self.LN_EPS)
         x = self.attn.rows(xn, yn, B, tx, ty, residual=x)

@@ -203,6 +203,32 @@ def la_apply(qf, kvsum, B, L, S, eps, out=None):
     return out
 
 
+def ln64_linear(x, wf_x, bias_x, gamma, beta, eps, y=None, wf_y=None, bias_y=None):
+    """LayerNorm(64) + projection of x rows (and, with the same norm, of y rows) in one launch; weights are
+    fragment-packed (_pack.frag_pack).  Returns out_x [rows_x, n_x] (and out_y [rows_y, n_y])."""
+    nx = bias_x.numel()
+    ox = torch.empty((x.shape[0], nx), dtype=f32, device=x.device)
+    if y is None:
+        _lib.call("cmr_ln64_linear_f32", _p(_rows(x)), _ld(x), x.shape[0], _p(wf_x), _p(bias_x), nx, _p(ox), _ld(ox), None, 0, 0,
+                  None, None, 0, None, 0, _p(gamma), _p(beta), float(eps), _stream())
+        return ox
+    ny = bias_y.numel()
+    oy = torch.empty((y.shape[0], ny), dtype=f32, device=y.device)
+    _lib.call("cmr_ln64_linear_f32", _p(_rows(x)), _ld(x), x.shape[0], _p(wf_x), _p(bias_x), nx, _p(ox), _ld(ox), _p(_rows(y)),
+              _ld(y), y.shape[0], _p(wf_y), _p(bias_y), ny, _p(oy), _ld(oy), _p(gamma), _p(beta), float(eps), _stream())
+    return ox, oy
+
+
+def vit_out_ffn(ctx, x, wo_f, bo, ln, eps, w1_f, b1, w2_f, b2):
+    """attention out-projection + residual, then the pre-LN MLP (64 -> 1024 -> 64, erf GELU) + residual."""
+    if b1.numel() != 1024 or bo.numel() != 64:
+        raise ValueError("vit_out_ffn is instantiated for embed_dim 64 / mlp_dim 1024")
+    out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
+    _lib.call("cmr_vit_out_ffn_f32", _p(_rows(ctx)), _ld(ctx), _p(_rows(x)), _ld(x), _p(wo_f), _p(bo), _p(ln[0]), _p(ln[1]),
+              float(eps), _p(w1_f), _p(b1), _p(w2_f), _p(b2), _p(out), _ld(out), x.shape[0], _stream())
+    return out
+
+
 def la_kv_state(y, wk, wv, B, S):
     """Fused k/v projections + per-(batch, head) state of one linear-attention layer: y [B*S,64] -> [B,576]."""
     ws_bytes = _lib.load().cmr_la_kv_state_workspace_bytes(B, S)

@@ -113,6 +113,21 @@ int cmr_la_reduce_f32(const float* kf, int64_t ldk, const float* v, int64_t ldv,
 int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* msg, int64_t ldm, int B, int L, int S,
                      float eps, hipStream_t stream);
 
+/* Pre-LN transformer block (ImageViT.py:61-158 = PointViT.py:96-183 = IMGPCEncoder.py:14-102) in three launches.
+ * Weights marked _f are MFMA A fragments: W [n_out][k] stored as [n_out/32][k/8][64 lanes][4] with lane 32h+l holding
+ * W[32 tile + l][8 kgroup + 4h .. +3] (cmr_agent_amd/models/_pack.py:frag_pack).
+ *   cmr_ln64_linear_f32: out_x = LN(x) Wx^T + bx and (y != NULL) out_y = LN(y) Wy^T + by with the SAME LayerNorm
+ *                        (attention_norm feeds query and key/value, IMGPCEncoder.py:93-94); n_out multiples of 64.
+ *   cmr_vit_out_ffn_f32: x1 = ctx Wo^T + bo + x (attn.out + residual); out = x1 + fc2(gelu(fc1(LN(x1))))
+ *                        (ffn_norm, Mlp 64 -> 1024 -> 64, exact erf GELU). */
+int cmr_ln64_linear_f32(const float* x, int64_t ldx, int64_t rows_x, const float* wf_x, const float* bias_x, int n_out_x,
+                        float* out_x, int64_t ldo_x, const float* y, int64_t ldy, int64_t rows_y, const float* wf_y,
+                        const float* bias_y, int n_out_y, float* out_y, int64_t ldo_y, const float* gamma, const float* beta,
+                        float eps, hipStream_t stream);
+int cmr_vit_out_ffn_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f, const float* bo,
+                        const float* ln_g, const float* ln_b, float eps, const float* w1_f, const float* b1, const float* w2_f,
+                        const float* b2, float* out, int64_t ldo, int64_t rows, hipStream_t stream);
+
 /* Fused linear-attention layer (LinearAttention.py:38-73) in two kernels; the unfused entry points above stay for
  * callers that need the intermediates.
  *   cmr_la_kv_state_f32:    y [B*S, 64] -> K = elu(Wk y)+1 (:45-46,52), V = (Wv y)/S (:47,57) -> kvsum [B][576] in the

@@ -194,6 +194,35 @@ def test_linear_attention_fused_layer(ops, B, L, S):
     assert torch.equal(kv, kv2), "state reduction must be deterministic"
 
 
+@pytest.mark.parametrize("rows_x,rows_y", [(3344, 2048), (70, 33), (1, 0), (418, 0)])
+def test_vit_block_fused_pieces(ops, rows_x, rows_y):
+    """cmr_ln64_linear_f32 (one or two row sets) and cmr_vit_out_ffn_f32 against torch fp64."""
+    from cmr_agent_amd.models._pack import frag_pack
+    g, b = rnd(64, seed=1, lo=0.5, hi=1.5), rnd(64, seed=2)
+    wq, bq = rnd(64, 64, seed=3, lo=-0.3, hi=0.3), rnd(64, seed=4)
+    wkv, bkv = rnd(128, 64, seed=5, lo=-0.3, hi=0.3), rnd(128, seed=6)
+    x = rnd(rows_x, 64, seed=7, lo=-2, hi=2)
+    ln = lambda t: F.layer_norm(t.double(), (64,), g.double(), b.double(), 1e-6)
+    d = lambda t: t.to(DEV).contiguous()
+    if rows_y:
+        y = rnd(rows_y, 64, seed=8, lo=-2, hi=2)
+        oq, okv = ops.ln64_linear(d(x), d(frag_pack(wq)), d(bq), d(g), d(b), 1e-6, d(y), d(frag_pack(wkv)), d(bkv))
+        close(oq, ln(x) @ wq.double().T + bq.double(), 2e-5, "ln-q")
+        close(okv, ln(y) @ wkv.double().T + bkv.double(), 2e-5, "ln-kv")
+    else:
+        wqkv, bqkv = torch.cat([wq, wkv], 0), torch.cat([bq, bkv], 0)
+        o = ops.ln64_linear(d(x), d(frag_pack(wqkv)), d(bqkv), d(g), d(b), 1e-6)
+        close(o, ln(x) @ wqkv.double().T + bqkv.double(), 2e-5, "ln-qkv")
+    ctx = rnd(rows_x, 64, seed=9)
+    wo, bo = rnd(64, 64, seed=10, lo=-0.3, hi=0.3), rnd(64, seed=11)
+    w1, b1 = rnd(1024, 64, seed=12, lo=-0.2, hi=0.2), rnd(1024, seed=13)
+    w2, b2 = rnd(64, 1024, seed=14, lo=-0.1, hi=0.1), rnd(64, seed=15)
+    x1 = ctx.double() @ wo.double().T + bo.double() + x.double()
+    ref = x1 + F.gelu(ln(x1) @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
+    got = ops.vit_out_ffn(d(ctx), d(x), d(frag_pack(wo)), d(bo), (d(g), d(b)), 1e-6, d(frag_pack(w1)), d(b1), d(frag_pack(w2)), d(b2))
+    close(got, ref, 2e-5, "out-ffn")
+
+
 def _cloud(B, N, seed):
     return rnd(B, 3, N, seed=seed, lo=-20, hi=20)
 
