@@ -1,0 +1,133 @@
+// Tail of the CMRAgent forward (reference models/CMRAgent.py:52-56,59-86,101-116) in ONE launch:
+//   global average pool of the last 2-D feature map -> conv1x1 + LeakyReLU -> conv1x1        (embed_2d, 128)
+//   cat([embed_2d, embed_3d])                                                                (state, 256)
+//   policy_r / policy_t / value: three 3-layer MLPs with LeakyReLU                           (logits, value)
+// All of it is 8-row (one row per sample) matrix-vector work: as thirteen separate launches it is pure launch
+// latency (~90 us per agent step).  One workgroup per sample; a wave produces one output channel at a time
+// (lanes split the input vector in float4 pieces, one coalesced row read, xor-shuffle reduction); the three heads
+// advance layer by layer together so that every layer is a single pass over 16 waves.
+#include "cmr_common.h"
+
+namespace {
+
+constexpr int AH_THREADS = 1024, AH_WAVES = AH_THREADS / 64;
+constexpr int AH_C = 128, AH_STATE = 256, AH_MAXW = 256;      // 2-D channels, state width, widest hidden layer
+
+struct AhHead { const float *w0, *b0, *w1, *b1, *w2, *b2; int n0, n1, n2; float* out; int ldo; };
+struct AhArgs {
+  const float* x; int npix;              // [B][npix][128] last feature map (already activated)
+  const float *w24, *b24, *w26, *b26;    // conv1x1 128 -> 128 (LeakyReLU), conv1x1 128 -> 128
+  const float* e3d;                      // [B][128]
+  AhHead h[3];
+  float slope;
+};
+
+// y[n] = act(b[n] + sum_k W[n][k] x[k]) for the outputs n = wave, wave + 16, ...; x in LDS, k % 4 == 0, k <= 256.
+// Eight weight rows per wave are in flight at once (branch-free: out-of-range rows / columns re-read a valid
+// element, lanes past k multiply by the zero x they hold), so a layer costs about one memory round trip.
+__device__ __forceinline__ void ah_gemv(const float* __restrict__ W, const float* __restrict__ bias, const float* xin, int k, int n_out,
+                                        float* yout, bool lrelu, float slope, int wave, int lane) {
+  constexpr int R = 8;
+  const int c = lane * 4;
+  const int cc = c < k ? c : 0;
+  f32x4 xv = *reinterpret_cast<const f32x4*>(xin + cc);
+  if (c >= k) xv = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int n0 = wave; n0 < n_out; n0 += R * AH_WAVES) {
+    f32x4 wv[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int n = n0 + i * AH_WAVES;
+      wv[i] = *reinterpret_cast<const f32x4*>(W + (int64_t)(n < n_out ? n : n_out - 1) * k + cc);
+    }
+    float s[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) s[i] = (wv[i][0] * xv[0] + wv[i][1] * xv[1]) + (wv[i][2] * xv[2] + wv[i][3] * xv[3]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int i = 0; i < R; ++i) s[i] += __shfl_xor(s[i], m);
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int n = n0 + i * AH_WAVES;
+      if (lane == 0 && n < n_out) {
+        const float v = s[i] + bias[n];
+        yout[n] = lrelu ? (v > 0.f ? v : v * slope) : v;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[8][AH_C];
+  __shared__ __attribute__((aligned(16))) float va[AH_C], vb[AH_C], state[AH_STATE];
+  __shared__ __attribute__((aligned(16))) float h0[3][AH_MAXW], h1[3][AH_MAXW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- AvgPool2d((H, W)): per-sample channel mean, 8 pixel groups x 128 channels, fixed summation order
+  {
+    const int c = tid & (AH_C - 1), g = tid >> 7;
+    const float* xp = a.x + (int64_t)b * a.npix * AH_C + c;
+    float s = 0.f;
+    int p = g;
+    for (; p + 56 < a.npix; p += 64) {                        // 8 loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = xp[(int64_t)(p + 8 * i) * AH_C];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; p < a.npix; p += 8) s += xp[(int64_t)p * AH_C];
+    red[g][c] = s;
+    __syncthreads();
+    if (tid < AH_C) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t += red[i][tid];
+      va[tid] = t / (float)a.npix;
+    }
+    if (tid >= AH_C && tid < 2 * AH_C) state[tid] = a.e3d[(int64_t)b * AH_C + tid - AH_C];
+    __syncthreads();
+  }
+  ah_gemv(a.w24, a.b24, va, AH_C, AH_C, vb, true, a.slope, wave, lane);
+  __syncthreads();
+  ah_gemv(a.w26, a.b26, vb, AH_C, AH_C, state, false, a.slope, wave, lane);
+  __syncthreads();
+  // ---- the three heads, layer by layer
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ah_gemv(a.h[i].w0, a.h[i].b0, state, AH_STATE, a.h[i].n0, h0[i], true, a.slope, wave, lane);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i) ah_gemv(a.h[i].w1, a.h[i].b1, h0[i], a.h[i].n0, a.h[i].n1, h1[i], true, a.slope, wave, lane);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    ah_gemv(a.h[i].w2, a.h[i].b2, h1[i], a.h[i].n1, a.h[i].n2, a.h[i].out + (int64_t)b * a.h[i].ldo, false, a.slope, wave, lane);
+}
+
+}  // namespace
+
+extern "C" int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const float* b24, const float* w26,
+                                   const float* b26, const float* e3d,
+                                   const float* r_w0, const float* r_b0, const float* r_w1, const float* r_b1, const float* r_w2, const float* r_b2,
+                                   int r_n0, int r_n1, int r_n2, float* r_out, int r_ldo,
+                                   const float* t_w0, const float* t_b0, const float* t_w1, const float* t_b1, const float* t_w2, const float* t_b2,
+                                   int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
+                                   const float* v_w0, const float* v_b0, const float* v_w1, const float* v_b1, const float* v_w2, const float* v_b2,
+                                   int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                                   float slope, hipStream_t stream) {
+  CMR_REQUIRE(x && w24 && b24 && w26 && b26 && e3d && B > 0 && npix > 0);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w24) && cmr_aligned16(w26));
+  AhArgs a{};
+  a.x = x; a.npix = npix; a.w24 = w24; a.b24 = b24; a.w26 = w26; a.b26 = b26; a.e3d = e3d; a.slope = slope;
+  a.h[0] = AhHead{r_w0, r_b0, r_w1, r_b1, r_w2, r_b2, r_n0, r_n1, r_n2, r_out, r_ldo};
+  a.h[1] = AhHead{t_w0, t_b0, t_w1, t_b1, t_w2, t_b2, t_n0, t_n1, t_n2, t_out, t_ldo};
+  a.h[2] = AhHead{v_w0, v_b0, v_w1, v_b1, v_w2, v_b2, v_n0, v_n1, v_n2, v_out, v_ldo};
+  for (int i = 0; i < 3; ++i) {
+    const AhHead& h = a.h[i];
+    CMR_REQUIRE(h.w0 && h.w1 && h.w2 && h.b0 && h.b1 && h.b2 && h.out && h.n2 > 0 && h.ldo >= h.n2);
+    CMR_REQUIRE(h.n0 > 0 && h.n0 <= AH_MAXW && h.n0 % 4 == 0 && h.n1 > 0 && h.n1 <= AH_MAXW && h.n1 % 4 == 0);
+    CMR_REQUIRE(cmr_aligned16(h.w0) && cmr_aligned16(h.w1) && cmr_aligned16(h.w2));
+  }
+  hipLaunchKernelGGL(agent_heads_kernel, dim3(B), dim3(AH_THREADS), 0, stream, a);
+  return cmr_launch_status();
+}

@@ -49,34 +49,37 @@ __device__ __forceinline__ void vf_layernorm(f32x4 (&v)[8], const float* __restr
   }
 }
 
-// acc[t] = sum_kg sum_j Wf[tile0 + t][kg0 + kg][lane][j] * bfrag(kg, j)   (fragments prefetched one k-group ahead)
-template <int T, int KG, typename BF>
+// acc[t] = sum_kg sum_j Wf[tile0 + t][kg0 + kg][lane][j] * bfrag(kg, j).  The fragments come straight from L2
+// (~1-2 us under load) and a k-group is only T*4 MFMAs (0.25-0.5 us), so they are requested D k-groups ahead
+// through a register ring; with one k-group of lookahead every step of the chain was an exposed L2 round trip.
+template <int T, int KG, int D, typename BF>
 __device__ __forceinline__ void vf_gemm(const float* __restrict__ wf, int kg_total, int tile0, int kg0, int lane,
                                         f32x16 (&acc)[T], BF bfrag) {
+  static_assert(D >= 1 && D <= KG, "prefetch depth");
 #pragma unroll
   for (int t = 0; t < T; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const float* wp = wf + ((int64_t)tile0 * kg_total + kg0) * 256 + lane * 4;
   const int64_t tstride = (int64_t)kg_total * 256;
-  f32x4 wc[T], wn[T];
+  f32x4 ring[D][T];
 #pragma unroll
-  for (int t = 0; t < T; ++t) wc[t] = *reinterpret_cast<const f32x4*>(wp + t * tstride);
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int t = 0; t < T; ++t) ring[d][t] = *reinterpret_cast<const f32x4*>(wp + t * tstride + d * 256);
 #pragma unroll
   for (int kg = 0; kg < KG; ++kg) {
-    if (kg + 1 < KG) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) wn[t] = *reinterpret_cast<const f32x4*>(wp + t * tstride + (kg + 1) * 256);
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float b = bfrag(kg, j);
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = cmr_mfma32(wc[t][j], b, acc[t]);
+      for (int t = 0; t < T; ++t) acc[t] = cmr_mfma32(ring[kg % D][t][j], b, acc[t]);
+    }
+    if (kg + D < KG) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) ring[kg % D][t] = *reinterpret_cast<const f32x4*>(wp + t * tstride + (kg + D) * 256);
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < T; ++t) wc[t] = wn[t];
   }
 }
 
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void ln64_linear_kernel(const LnLinArgs a) {
   vf_layernorm(xf, a.g, a.b, h, a.eps);
   for (int pr = 0; pr < P.npair; ++pr) {               // 64 output channels per pass
     f32x16 acc[2];
-    vf_gemm<2, 8>(P.wf, 8, 2 * pr, 0, lane, acc, [&](int kg, int j) { return xf[kg][j]; });
+    vf_gemm<2, 8, 8>(P.wf, 8, 2 * pr, 0, lane, acc, [&](int kg, int j) { return xf[kg][j]; });
     f32x4 ov[8];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(512) void vit_out_ffn_kernel(const OutFfnArgs a) {
   // ---- x1 = ctx Wo + bo + x     (every wave: 64 MFMAs, cheaper than a broadcast through LDS)
   {
     f32x16 acc[2];
-    vf_gemm<2, 8>(a.wo_f, 8, 0, 0, lane, acc, [&](int kg, int j) { return cf[kg][j]; });
+    vf_gemm<2, 8, 8>(a.wo_f, 8, 0, 0, lane, acc, [&](int kg, int j) { return cf[kg][j]; });
 #pragma unroll
     for (int kg = 0; kg < 8; ++kg) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + 8 * kg + 4 * h);
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(512) void vit_out_ffn_kernel(const OutFfnArgs a) {
   vf_layernorm(xn, a.g2, a.b2n, h, a.eps);
   // ---- this wave's 128 hidden units: fc1 + GELU, then its K-slice of fc2
   f32x16 hid[4];
-  vf_gemm<4, 8>(a.w1_f, 8, 4 * wave, 0, lane, hid, [&](int kg, int j) { return xn[kg][j]; });
+  vf_gemm<4, 8, 4>(a.w1_f, 8, 4 * wave, 0, lane, hid, [&](int kg, int j) { return xn[kg][j]; });
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(512) void vit_out_ffn_kernel(const OutFfnArgs a) {
       for (int e = 0; e < 4; ++e) hid[t][4 * qd + e] = vf_gelu(hid[t][4 * qd + e] + bv[e]);
     }
   f32x16 part[2];
-  vf_gemm<2, 16>(a.w2_f, 128, 0, 16 * wave, lane, part, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
+  vf_gemm<2, 16, 8>(a.w2_f, 128, 0, 16 * wave, lane, part, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
   if (wave > 0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

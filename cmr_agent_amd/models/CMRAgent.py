@@ -102,6 +102,8 @@ class CMRAgent(Planned):
             feat, g = r
         return g
 
+    FUSED_TAIL = True
+
     def _embed_2d(self, state2d, B, split):
         p = self.plan()
         c = 2 * self.config.embed_dim
@@ -124,8 +126,7 @@ class CMRAgent(Planned):
                 kh, kw = self.config.image_H // 8, self.config.image_W // 8
                 if (x.shape[1], x.shape[2]) != (kh, kw):
                     raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (x.shape[1], x.shape[2], kh, kw))
-                x = ops.colmean(x.view(B * kh * kw, c), B, kh * kw)        # AvgPool2d((H, W)) = per-sample channel mean
-        return ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
+        return x                                             # [B, kh, kw, c]: global pool + 1x1 convs live in _tail
 
     def _embed_3d_any(self, state3d_rows, B, N):
         e3d = self._embed_3d(state3d_rows, B, N)
@@ -147,12 +148,20 @@ class CMRAgent(Planned):
         # the 3-D branch (4 fused blocks on B*N points) runs on a side stream underneath the 2-D convolutions
         e3d, e2d = fork_join(lambda: self._embed_3d_any(state3d_rows, B, N), lambda: self._embed_2d(state2d, B, split), tag="agent")
         p = self.plan()
-        out = []
-        for name in ("policy_r", "policy_t", "value"):
-            l0, l1, l2 = p[name]
-            hcur = ops.linear(e2d, *l0, x2=e3d, act=ops.ACT_LRELU, act_param=SLOPE)      # cat([embed_2d, embed_3d])
-            hcur = ops.linear(hcur, *l1, act=ops.ACT_LRELU, act_param=SLOPE)
-            out.append(ops.linear(hcur, *l2))
+        _, kh, kw, c = e2d.shape
+        xr = e2d.view(B * kh * kw, c)
+        heads = [p[name] for name in ("policy_r", "policy_t", "value")]
+        if self.FUSED_TAIL and e3d.is_contiguous():
+            # AvgPool2d((H, W)) + the two 1x1 convs + the three heads: one launch (13 otherwise)
+            out = ops.agent_heads(xr, B, kh * kw, p["c24"], p["c26"], e3d, heads, SLOPE)
+        else:
+            x = ops.colmean(xr, B, kh * kw)                  # AvgPool2d((H, W)) = per-sample channel mean
+            e2 = ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
+            out = []
+            for l0, l1, l2 in heads:
+                hcur = ops.linear(e2, *l0, x2=e3d, act=ops.ACT_LRELU, act_param=SLOPE)   # cat([embed_2d, embed_3d])
+                hcur = ops.linear(hcur, *l1, act=ops.ACT_LRELU, act_param=SLOPE)
+                out.append(ops.linear(hcur, *l2))
         S = self.config.num_steps          # head widths are padded to a multiple of 4: slice, then split
         return (out[0][:, :self.degree_r * S].view(B, self.degree_r, S), out[1][:, :self.degree_t * S].view(B, self.degree_t, S),
                 out[2][:, :1].view(B, 1, 1))

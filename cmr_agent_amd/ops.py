@@ -203,6 +203,19 @@ def la_apply(qf, kvsum, B, L, S, eps, out=None):
     return out
 
 
+def agent_heads(x, B, npix, c24, c26, e3d, heads, slope):
+    """x [B*npix,128] (last 2-D feature map) -> global mean -> two 1x1 convs -> cat with e3d [B,128] -> the three
+    MLP heads.  c24 / c26 / heads[i][j] are (W [out,in], bias) pairs; returns the three logit tensors [B, n2_i]."""
+    outs, args = [], []
+    for (w0, b0), (w1, b1), (w2, b2) in heads:
+        o = torch.empty((B, w2.shape[0]), dtype=f32, device=x.device)
+        outs.append(o)
+        args += [_p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), w0.shape[0], w1.shape[0], w2.shape[0], _p(o), o.stride(0)]
+    _lib.call("cmr_agent_heads_f32", _p(_rows(x)), B, npix, _p(c24[0]), _p(c24[1]), _p(c26[0]), _p(c26[1]), _p(e3d), *args,
+              float(slope), _stream())
+    return outs
+
+
 def ln64_linear(x, wf_x, bias_x, gamma, beta, eps, y=None, wf_y=None, bias_y=None):
     """LayerNorm(64) + projection of x rows (and, with the same norm, of y rows) in one launch; weights are
     fragment-packed (_pack.frag_pack).  Returns out_x [rows_x, n_x] (and out_y [rows_y, n_y])."""

@@ -113,6 +113,20 @@ int cmr_la_reduce_f32(const float* kf, int64_t ldk, const float* v, int64_t ldv,
 int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* msg, int64_t ldm, int B, int L, int S,
                      float eps, hipStream_t stream);
 
+/* Tail of CMRAgent.forward (CMRAgent.py:52-56 global pool + two 1x1 convs, :101-116 the three MLP heads on
+ * cat([embed_2d, embed_3d])) in one launch, one workgroup per sample.  x [B][npix][128] is the activated output of the
+ * last 3x3 conv; weights are the PyTorch [out][in] matrices; head i: 256 -> n0 -> n1 -> n2 with LeakyReLU(slope)
+ * between, logits written to out[b * ldo + 0..n2). */
+int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const float* b24, const float* w26,
+                        const float* b26, const float* e3d,
+                        const float* r_w0, const float* r_b0, const float* r_w1, const float* r_b1, const float* r_w2, const float* r_b2,
+                        int r_n0, int r_n1, int r_n2, float* r_out, int r_ldo,
+                        const float* t_w0, const float* t_b0, const float* t_w1, const float* t_b1, const float* t_w2, const float* t_b2,
+                        int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
+                        const float* v_w0, const float* v_b0, const float* v_w1, const float* v_b1, const float* v_w2, const float* v_b2,
+                        int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                        float slope, hipStream_t stream);
+
 /* Pre-LN transformer block (ImageViT.py:61-158 = PointViT.py:96-183 = IMGPCEncoder.py:14-102) in three launches.
  * Weights marked _f are MFMA A fragments: W [n_out][k] stored as [n_out/32][k/8][64 lanes][4] with lane 32h+l holding
  * W[32 tile + l][8 kgroup + 4h .. +3] (cmr_agent_amd/models/_pack.py:frag_pack).

@@ -223,6 +223,25 @@ def test_vit_block_fused_pieces(ops, rows_x, rows_y):
     close(got, ref, 2e-5, "out-ffn")
 
 
+@pytest.mark.parametrize("B,npix", [(8, 418), (2, 60), (1, 7)])
+def test_agent_heads_fused_tail(ops, B, npix):
+    """cmr_agent_heads_f32: global mean -> 1x1 convs -> three MLP heads, against torch fp64."""
+    x, e3d = rnd(B, npix, 128, seed=21), rnd(B, 128, seed=22)
+    lin = lambda n, k, sd: (rnd(n, k, seed=sd, lo=-0.2, hi=0.2), rnd(n, seed=sd + 1))
+    c24, c26 = lin(128, 128, 23), lin(128, 128, 25)
+    heads = [[lin(256, 256, 30), lin(256, 256, 32), lin(36, 256, 34)], [lin(256, 256, 40), lin(256, 256, 42), lin(24, 256, 44)],
+             [lin(64, 256, 50), lin(64, 64, 52), lin(4, 64, 54)]]
+    f = lambda t, wb: t @ wb[0].double().T + wb[1].double()
+    e2 = f(F.leaky_relu(f(x.double().mean(1), c24), 0.01), c26)
+    st = torch.cat([e2, e3d.double()], 1)
+    d = lambda t: t.to(DEV).contiguous()
+    dd = lambda wb: (d(wb[0]), d(wb[1]))
+    got = ops.agent_heads(d(x).view(B * npix, 128), B, npix, dd(c24), dd(c26), d(e3d), [[dd(l) for l in h] for h in heads], 0.01)
+    for g, h in zip(got, heads):
+        ref = f(F.leaky_relu(f(F.leaky_relu(f(st, h[0]), 0.01), h[1]), 0.01), h[2])
+        close(g, ref, 2e-5, "head")
+
+
 def _cloud(B, N, seed):
     return rnd(B, 3, N, seed=seed, lo=-20, hi=20)
 

@@ -1,7 +1,8 @@
 """Timeline analysis of one replayed registration iteration from a rocprofv3 kernel trace: wall time, time with
 exactly one kernel type resident (where that kernel alone is on the critical path), idle time."""
 import csv, glob, collections, re, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')

@@ -71,6 +71,23 @@ def bench_linear(rows, k1, n_out, k2=0, gather=False, act=0, reps=20):
         rows, k1, "+%d%s" % (k2, "g" if gather else "") if k2 else "", n_out, act, us, fl / us / 1e6, by / us / 1e6))
 
 
+def bench_vit(rows_x, rows_y, B, reps):
+    from cmr_agent_amd.models._pack import frag_pack
+    r = lambda *shape: torch.randn(*shape, device=DEV) * 0.1
+    x, y = r(rows_x, 64), r(rows_y, 64)
+    g, b = r(64) + 1, r(64)
+    wq, wkv, wqkv = frag_pack(r(64, 64)), frag_pack(r(128, 64)), frag_pack(r(192, 64))
+    bq, bkv, bqkv = r(64), r(128), r(192)
+    wo, w1, w2 = frag_pack(r(64, 64)), frag_pack(r(1024, 64)), frag_pack(r(64, 1024))
+    bo, b1, b2 = r(64), r(1024), r(64)
+    t1 = timeit(lambda: ops.ln64_linear(x, wqkv, bqkv, g, b, 1e-6), reps)
+    t2 = timeit(lambda: ops.ln64_linear(x, wq, bq, g, b, 1e-6, y, wkv, bkv), reps)
+    q, kv = ops.ln64_linear(x, wq, bq, g, b, 1e-6, y, wkv, bkv)
+    t3 = timeit(lambda: ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, rows_x // B, rows_y // B), reps)
+    t4 = timeit(lambda: ops.vit_out_ffn(q, x, wo, bo, (g, b), 1e-6, w1, b1, w2, b2), reps)
+    print("vit block rows %d / %d: ln+qkv %.1f us  ln+q,kv %.1f us  mha %.1f us  out+ffn %.1f us" % (rows_x, rows_y, t1, t2, t3, t4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--what", default="conv,linear")
@@ -86,6 +103,25 @@ def main():
                                   (88, 304, 128, 64, 1), (44, 152, 128, 128, 1), (22, 76, 128, 128, 1), (11, 38, 128, 128, 1),
                                   (352, 1216, 64, 64, 2), (176, 608, 64, 64, 2)]:
             bench_conv(B, H, W, ci, co, s, a.reps)
+    if "latency" in a.what:      # dependent-launch floor inside a hipGraph: a chain of tiny kernels
+        x = torch.randn(32, 64, device=DEV); g = torch.ones(64, device=DEV); b = torch.zeros(64, device=DEV)
+        y = torch.empty_like(x)
+        def chain():
+            ops.layernorm64(x, g, b, 1e-5, out=y); ops.layernorm64(y, g, b, 1e-5, out=x)
+        print("dependent tiny-kernel chain in a graph: %.2f us per kernel" % (timeit(chain, 200) / 2))
+        xs = [torch.randn(32, 64, device=DEV) for _ in range(8)]; ys = [torch.empty_like(x) for _ in range(8)]
+        def indep():
+            for i in range(8): ops.layernorm64(xs[i], g, b, 1e-5, out=ys[i])
+        print("independent tiny kernels (same stream) in a graph: %.2f us per kernel" % (timeit(indep, 50) / 8))
+    if "heads" in a.what:
+        r = lambda *shape: torch.randn(*shape, device=DEV) * 0.1
+        x, e3d = r(8 * 418, 128), r(8, 128)
+        c24, c26 = (r(128, 128), r(128)), (r(128, 128), r(128))
+        heads = [[(r(256, 256), r(256)), (r(256, 256), r(256)), (r(36, 256), r(36))] for _ in range(2)] + [[(r(64, 256), r(64)), (r(64, 64), r(64)), (r(4, 64), r(4))]]
+        print("agent_heads: %.1f us" % timeit(lambda: ops.agent_heads(x, 8, 418, c24, c26, e3d, heads, 0.01), a.reps))
+    if "vit" in a.what:
+        bench_vit(8 * 418, 8 * 256, 8, a.reps)
+        bench_vit(8 * 256, 8 * 418, 8, a.reps)
     if "linear" in a.what:
         N, P4, M, T = 8 * 16384, 8 * 26752, 8 * 1280, 8 * 418
         for args in [(N, 64, 64), (N, 64, 64, 64, True), (N, 64, 128), (N, 64, 128, 64, True), (N, 128, 64), (N, 4, 64), (N, 8, 8),

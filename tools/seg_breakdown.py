@@ -1,7 +1,8 @@
 """Per-segment kernel breakdown of a rocprofv3 kernel trace of bench.py: one agent step and the geo forward
 (the span between the last pose_step of one iteration and the first of the next)."""
 import csv, glob, collections, re, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+import os
+f = max(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'), key=os.path.getmtime)
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r['Start_Timestamp']))
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
