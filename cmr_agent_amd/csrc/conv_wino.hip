@@ -45,7 +45,8 @@ constexpr int WT_SLOTS = WT_HR * WT_PITCH;                        // 200
 constexpr int WT_HALO_FLOATS = WT_SLOTS * WT_KC;                  // 6400
 constexpr int WT_DMA = WT_SLOTS / 8;                              // 25 wave-wide LDS-DMA blocks of 8 slots (1 KB)
 constexpr int WT_DMA_PER_WAVE = (WT_DMA + 3) / 4;                 // 7
-constexpr int WT_SMEM_FLOATS = 16384;         // 64 KB: two halo buffers (12800) in the K loop, T (16384) after it
+// LDS: two halo buffers (12800 floats) in the K loop, T (8192 floats per 32-cout tile) after it
+template <int NT> constexpr int wt_smem_floats() { return 8192 * NT > 2 * WT_HALO_FLOATS ? 8192 * NT : 2 * WT_HALO_FLOATS; }
 __device__ __attribute__((aligned(16))) float wt_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // NOT const (hipcc would fold the loads into branches)
 // Re-materialises a thread-index-derived value at its point of use: the persistent tile loop would otherwise
 // hoist every per-lane address / predicate of the prologue and epilogue out of the loop and keep ~100 of them
@@ -54,12 +55,15 @@ __device__ __forceinline__ int wt_fresh(int v) { asm volatile("" : "+v"(v)); ret
 __device__ __forceinline__ int wt_slot(int py, int px) { return py * WT_PITCH + (px & 1) * (WT_PITCH / 2) + (px >> 1); }
 __device__ __forceinline__ int wt_lds(int slot, int c) { return slot * WT_KC + 4 * (c ^ (slot & 7)); }   // float offset of piece c
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, const int tiles_x, const int tiles_y) {
+// NT = 32-cout tiles per workgroup.  NT = 2: 248 VGPRs, 64 KB LDS, 2 workgroups / CU.  NT = 1: half the accumulators
+// (<= 168 VGPRs, 51 KB), 3 workgroups / CU and twice the workgroups -- for maps too small to fill the chip.
+template <int NT>
+__global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(const WinoArgs a, const int tiles_x, const int tiles_y) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // uniform: lets the U bases live in SGPRs
   const int h = lane >> 5, l31 = lane & 31;
-  const int nco = a.Cout / 64;
+  const int nco = a.Cout / (32 * NT);
   const int nchunk = a.Cin / WT_KC;
 
   struct Tile { int b, co0, oy0, ox0; };
@@ -67,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
     Tile r;
     r.ox0 = (t % tiles_x) * WT_TW; t /= tiles_x;
     r.oy0 = (t % tiles_y) * WT_TH; t /= tiles_y;
-    r.b = t / nco; r.co0 = (t % nco) * 64;
+    r.b = t / nco; r.co0 = (t % nco) * 32 * NT;
     return r;
   };
 
@@ -143,19 +147,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
   const int Ho = a.H, Wo = a.W;
 
   const Tile cur = decode(blockIdx.x);
-  f32x4 wc[4][2], wn[4][2];
+  f32x4 wc[4][NT], wn[4][NT];
   load_halo(cur);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) wc[j][n] = *reinterpret_cast<const f32x4*>(uw + (cur.co0 / 32 + n) * utile + j * upos);
+    for (int n = 0; n < NT; ++n) wc[j][n] = *reinterpret_cast<const f32x4*>(uw + (cur.co0 / 32 + n) * utile + j * upos);
 
   {
-    f32x16 acc[4][2];                               // [position column j][cout tile]
+    f32x16 acc[4][NT];                               // [position column j][cout tile]
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
     const float* ub = uw + (cur.co0 / 32) * utile;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) wn[j][n] = *reinterpret_cast<const f32x4*>(up + j * upos + n * utile);
+          for (int n = 0; n < NT; ++n) wn[j][n] = *reinterpret_cast<const f32x4*>(up + j * upos + n * utile);
         if (kg == WT_KC / 8 - 2 && chunk + 1 < nchunk) dma_halo(cur, chunk + 1, smem + (buf ^ 1) * WT_HALO_FLOATS);
         // on-the-fly input transform of this lane's tile: t[c] = d[ra][c] +- d[rb][c], then the 4 columns j
         f32x4 tc[4];
@@ -195,14 +199,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
         for (int j = 0; j < 4; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            acc[j][0] = cmr_mfma32(wc[j][0][e], vf[j][e], acc[j][0]);
-            acc[j][1] = cmr_mfma32(wc[j][1][e], vf[j][e], acc[j][1]);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], acc[j][n]);
           }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) wc[j][n] = wn[j][n];
+          for (int n = 0; n < NT; ++n) wc[j][n] = wn[j][n];
       }
       buf ^= 1;
     }
@@ -211,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
     // ---- output transform, stage 1 (registers): T[w][b] = sum_j M[w][j] A[j][b]
     float* Ts = smem;                               // [(w*2 + b)*2 + n][register quad][lane][4]: b128 both ways
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int rq = 0; rq < 4; ++rq) {
         f32x4 t0, t1;
@@ -221,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
           t0[e] = (acc[0][n][r] + acc[1][n][r]) + acc[2][n][r];
           t1[e] = (acc[1][n][r] - acc[2][n][r]) - acc[3][n][r];
         }
-        *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 0) * 2 + n) * 4 + rq) * 64 + lane) * 4]) = t0;
-        *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 1) * 2 + n) * 4 + rq) * 64 + lane) * 4]) = t1;
+        *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 0) * NT + n) * 4 + rq) * 64 + lane) * 4]) = t0;
+        *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 1) * NT + n) * 4 + rq) * 64 + lane) * 4]) = t1;
       }
 
     __syncthreads();
@@ -232,12 +236,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
     const int lf = wt_fresh(lane);
     const int tyf = (lf & 31) >> 3, txf = lf & 7;
     const int cq = cur.co0 + 8 * q + 4 * (lf >> 5); // + 32 n
-    f32x4 bs[2], rs[2][2][2];
+    f32x4 bs[NT], rs[NT][2][2];
     {
       const float* bp = a.bias ? a.bias + cq : wt_zero16;
       const int bst = a.bias ? 32 : 0;
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bs[n] = *reinterpret_cast<const f32x4*>(bp + bst * n);
+      for (int n = 0; n < NT; ++n) bs[n] = *reinterpret_cast<const f32x4*>(bp + bst * n);
       const float* rp = a.res ? a.res + (int64_t)cur.b * Ho * Wo * a.Cout + cq : wt_zero16;
       const int rst = a.res ? a.Cout : 0, rn = a.res ? 32 : 0;
       if (a.pool == 1) {
@@ -250,18 +254,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
             ox = ox < Wo ? ox : Wo - 1;
             const int pix = oy * Wo + ox;
 #pragma unroll
-            for (int n = 0; n < 2; ++n) rs[n][aa][bb] = *reinterpret_cast<const f32x4*>(rp + (int64_t)pix * rst + rn * n);
+            for (int n = 0; n < NT; ++n) rs[n][aa][bb] = *reinterpret_cast<const f32x4*>(rp + (int64_t)pix * rst + rn * n);
           }
       }
     }
-    f32x4 yv[2][2][2];                              // [n][a][b]
+    f32x4 yv[NT][2][2];                              // [n][a][b]
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) {
         f32x4 tw[4];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) tw[w] = *reinterpret_cast<const f32x4*>(&Ts[((((w * 2 + bb) * 2 + n) * 4 + q) * 64 + lane) * 4]);
+        for (int w = 0; w < 4; ++w) tw[w] = *reinterpret_cast<const f32x4*>(&Ts[((((w * 2 + bb) * NT + n) * 4 + q) * 64 + lane) * 4]);
         yv[n][0][bb] = (tw[0] + tw[1]) + tw[2];
         yv[n][1][bb] = (tw[1] - tw[2]) - tw[3];
         __builtin_amdgcn_sched_barrier(0);          // keeps the 64 T reads from being hoisted into one 64-register burst
@@ -269,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
     if (a.pool == 2) {
       const int py = (cur.oy0 >> 1) + tyf, px = (cur.ox0 >> 1) + txf;
       const int hp2 = Ho >> 1, wp2 = Wo >> 1;
-      f32x4 sv[2];
+      f32x4 sv[NT];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
+      for (int n = 0; n < NT; ++n) {
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int aa = 0; aa < 2; ++aa)
@@ -286,12 +290,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
         for (int e = 0; e < 4; ++e) s[e] *= 0.25f;
         sv[n] = s;
       }
-      cmr_pin(sv[0]);
-      cmr_pin(sv[1]);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) cmr_pin(sv[n]);
       if (py < hp2 && px < wp2) {
         float* yp = a.y + (((int64_t)cur.b * hp2 + py) * wp2 + px) * a.Cout + cq;
-        *reinterpret_cast<f32x4*>(yp) = sv[0];
-        *reinterpret_cast<f32x4*>(yp + 32) = sv[1];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(yp + 32 * n) = sv[n];
       }
     } else {
 #pragma unroll
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) {
+          for (int n = 0; n < NT; ++n) {
             f32x4 v = yv[n][aa][bb] + bs[n];
             v += rs[n][aa][bb];
 #pragma unroll
@@ -315,8 +319,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
             oy = oy < Ho ? oy : Ho - 1;
             ox = ox < Wo ? ox : Wo - 1;
             const float* pp = a.post + (int64_t)(oy * Wo + ox) * a.Cout + cq;
-            yv[0][aa][bb] += *reinterpret_cast<const f32x4*>(pp);
-            yv[1][aa][bb] += *reinterpret_cast<const f32x4*>(pp + 32);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) yv[n][aa][bb] += *reinterpret_cast<const f32x4*>(pp + 32 * n);
           }
       }
 #pragma unroll
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) cmr_pin(yv[n][aa][bb]);
+          for (int n = 0; n < NT; ++n) cmr_pin(yv[n][aa][bb]);
 #pragma unroll
       for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
@@ -332,12 +336,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs a, 
           const int oy = cur.oy0 + 2 * tyf + aa, ox = cur.ox0 + 2 * txf + bb;
           if (oy < Ho && ox < Wo) {
             float* yp = a.y + (((int64_t)cur.b * Ho + oy) * Wo + ox) * a.Cout + cq;
-            *reinterpret_cast<f32x4*>(yp) = yv[0][aa][bb];
-            *reinterpret_cast<f32x4*>(yp + 32) = yv[1][aa][bb];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(yp + 32 * n) = yv[n][aa][bb];
           }
         }
     }
   }
+}
+
+template <int NT>
+int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
+  constexpr int smem = wt_smem_floats<NT>() * (int)sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            smem) != hipSuccess)
+      return CMR_ELAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3x3_wino_kernel<NT>, dim3((unsigned)ntiles), dim3(256), smem, stream, a, tiles_x, tiles_y);
+  return cmr_launch_status();
 }
 
 }  // namespace
@@ -350,17 +368,11 @@ extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, in
               (!res || cmr_aligned16(res)) && (!post || cmr_aligned16(post)));
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post));
   const int tiles_x = (W + WT_TW - 1) / WT_TW, tiles_y = (H + WT_TH - 1) / WT_TH;
-  const int64_t ntiles = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
-  CMR_REQUIRE(ntiles < 0x7fffffff);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            WT_SMEM_FLOATS * (int)sizeof(float)) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = true;
-  }
   const WinoArgs a{x, B, H, W, Cin, u, bias, res, post, y, Cout, slope, pool};
-  hipLaunchKernelGGL(conv3x3_wino_kernel, dim3((unsigned)ntiles), dim3(256), WT_SMEM_FLOATS * sizeof(float), stream, a,
-                     tiles_x, tiles_y);
-  return cmr_launch_status();
+  // 64 couts per workgroup unless that leaves the chip under-filled (2 x 256 resident workgroups): small maps
+  // take 32-cout workgroups, twice as many and three per CU
+  const int64_t ntiles64 = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
+  CMR_REQUIRE(2 * ntiles64 < 0x7fffffff);
+  if (ntiles64 >= 512) return launch_wino<2>(a, tiles_x, tiles_y, ntiles64, stream);
+  return launch_wino<1>(a, tiles_x, tiles_y, 2 * ntiles64, stream);
 }

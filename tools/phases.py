@@ -44,6 +44,18 @@ def main():
     tg, _ = graph_time(geo_fn)
     ta, _ = graph_time(agent_fn)
     print("geo forward %.2f ms   agent loop (%d steps) %.2f ms   sum %.2f ms" % (tg, cfg.action_num, ta, tg + ta))
+    if len(sys.argv) > 1:     # sub-phases of one agent step
+        pose, target = env.init(data)
+        s2, s3 = env.observation_from_a_pose(data, pose)
+        B, N = s3.shape[0], s3.shape[2]
+        from cmr_agent_amd.models.ImageResNet import to_nhwc
+        s3r = torch.as_strided(s3, (B * N, 8), (8, 1)) if s3.stride(1) == 1 else None
+        split = getattr(s2, "_cmr_split", None)
+        to, _ = graph_time(lambda: env.observation_from_a_pose(data, pose), 20)
+        t2, _ = graph_time(lambda: agent._embed_2d(to_nhwc(s2), B, split), 20)
+        t3, _ = graph_time(lambda: agent._embed_3d_any(s3r, B, N), 20)
+        tf, _ = graph_time(lambda: agent(s2, s3), 20)
+        print("agent step: observation %.3f   2-D embed %.3f   3-D embed %.3f   full forward %.3f ms" % (to, t2, t3, tf))
     if len(sys.argv) > 1:     # sub-phases of the geo forward
         ed = geo.encoder_decoder; enc = ed.encoder
         img = batch['img'].contiguous()
@@ -53,6 +65,22 @@ def main():
         t3, _ = graph_time(lambda: enc.forward_cl(dict(batch)))
         t4, _ = graph_time(lambda: ed.forward_cl(dict(batch)))
         print("image tower %.2f   point tower %.2f   encoder %.2f   encoder+decoder %.2f   full geo %.2f" % (t1, t2, t3, t4, tg))
+        with torch.no_grad():
+            cl = enc.forward_cl(dict(batch))
+        B, T, Q = cl["B"], cl["T"], cl["Q"]
+        ip0, pp0 = cl["img_proxy"].clone(), cl["pt_proxy"].clone()
+        from cmr_agent_amd.utils.streams import fork_join
+        def coarse():
+            ip, pp = ip0, pp0
+            for i in range(cfg.num_ca_layer_coarse):
+                ip = enc.p2i_ca_layers[i].rows(ip, pp, B, T, Q)
+                pp = enc.i2p_ca_layers[i].rows(pp, ip, B, Q, T)
+                a, b = ip, pp
+                pp, ip = fork_join(lambda: enc.pt_sa_layers[i].rows(b, None, B, Q, Q), lambda: enc.img_sa_layers[i].rows(a, None, B, T, T))
+            return ip, pp
+        t5, _ = graph_time(coarse, 10)
+        t6, _ = graph_time(lambda: enc.p2i_ca_layers[0].rows(ip0, pp0, B, T, Q), 20)
+        print("coarse matcher (6 layers) %.2f ms; one cross block %.3f ms" % (t5, t6))
 
 if __name__ == "__main__":
     main()
