@@ -18,7 +18,7 @@
 
 namespace {
 
-__device__ __attribute__((aligned(16))) const float cbr_zero[256] = {0.f};
+__device__ __attribute__((aligned(16))) float cbr_zero[256] = {0.f};   // NOT const: hipcc folds loads of a const zero page into branches
 
 struct CbrArgs {
   const float* x1; int64_t ld1;
@@ -32,17 +32,30 @@ struct CbrArgs {
   int64_t rows; int64_t rows_per_batch; float slope;
 };
 
+constexpr int CBR_MAXB = 16;     // distinct per-batch bias rows staged in LDS
+
+// The tile loop follows the rules of linear_ws_kernel (csrc/linear.hip): one straight-line body, no conditional load,
+// 32-bit index math, gather indices and input fragments fetched a tile ahead, biases read from LDS, outputs pinned
+// before the predicated stores.  (The first version loaded every bias float4 under a branch: 24 serialised global
+// round trips per 32-row tile, 3 x the MFMA time of the tile.)
 template <int KX, int CH, int CO, bool CONV_SC>
 __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
   constexpr int LDX = KX + 4, LDH = CH + 4;
   constexpr int GX = KX / 8, GH = CH / 8;      // k-groups of the two GEMMs
   constexpr int T1 = (CH + 31) / 32, T2 = CO / 32;
+  constexpr int CHP = 32 * T1;                 // hidden width padded to whole tiles
+  constexpr bool PREFETCH = KX <= 64;          // next tile's input fragments in registers during this tile (KX = 128: no room)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* W1s = smem;                            // [32*T1][LDX]   (rows >= CH are zero)
   float* W2s = W1s + 32 * T1 * LDX;             // [CO][LDH]
   float* Wss = W2s + CO * LDH;                  // [CO][LDX]      (only if CONV_SC)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* B1s = Wss + (CONV_SC ? CO * LDX : 0);  // [nb][CHP]
+  float* B2s = B1s + CBR_MAXB * CHP;            // [nb][CO]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
+  const uint32_t rows = (uint32_t)a.rows, rpb = (uint32_t)a.rows_per_batch;
+  const int nb1 = a.b1_stride > 0 ? (int)((rows + rpb - 1) / rpb) : 1, nb2 = a.b2_stride > 0 ? (int)((rows + rpb - 1) / rpb) : 1;
   for (int e = tid; e < 32 * T1 * (KX / 4); e += 512) {
     const int n = e / (KX / 4), c = (e % (KX / 4)) * 4;
     *reinterpret_cast<f32x4*>(&W1s[n * LDX + c]) = *reinterpret_cast<const f32x4*>(n < CH ? a.w1 + (int64_t)n * KX + c : cbr_zero);
@@ -56,24 +69,45 @@ __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
       const int n = e / (KX / 4), c = (e % (KX / 4)) * 4;
       *reinterpret_cast<f32x4*>(&Wss[n * LDX + c]) = *reinterpret_cast<const f32x4*>(a.wsc + (int64_t)n * KX + c);
     }
+  for (int e = tid; e < nb1 * CHP; e += 512) B1s[e] = (e % CHP) < CH ? a.b1[(int64_t)(e / CHP) * a.b1_stride + e % CHP] : 0.f;
+  for (int e = tid; e < nb2 * CO; e += 512) B2s[e] = a.b2[(int64_t)(e / CO) * a.b2_stride + e % CO];
   __syncthreads();
 
-  const int64_t ntiles = (a.rows + 31) / 32;
-  for (int64_t tile = (int64_t)blockIdx.x * 8 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 8) {
-    int64_t row = tile * 32 + l31;
-    const bool valid = row < a.rows;
-    if (!valid) row = 0;
-    const int64_t batch = row / a.rows_per_batch;
-    // ---- input fragments (B operand of GEMM 1 and of the shortcut; also the identity residual)
-    const float* p1 = a.x1 + row * a.ld1 + 4 * h;
-    const float* p2 = p1;
-    if (a.x2) p2 = a.x2 + (a.idx2 ? (int64_t)a.idx2[row] : row / a.div2) * a.ld2 + 4 * h;
-    f32x4 xf[GX];
+  const uint32_t ntiles = (rows + 31) / 32, tstride = gridDim.x * 8;
+  const float* x2b = a.x2 ? a.x2 : a.x1;
+  const int32_t* izero = reinterpret_cast<const int32_t*>(cbr_zero);
+  auto load_idx = [&](uint32_t tile) -> int32_t {      // gather index of this lane's row one tile ahead (zero page when unused)
+    const uint32_t row = tile * 32 + l31;
+    const uint32_t ok = (a.idx2 != nullptr && tile < ntiles && row < rows) ? 1u : 0u;
+    return (a.idx2 ? a.idx2 : izero)[ok * row];
+  };
+  auto load_x = [&](uint32_t tile, int32_t idxv, f32x4 (&xf)[GX]) {
+    uint32_t row = tile * 32 + l31;
+    row = (tile < ntiles && row < rows) ? row : 0;       // rows past the end recompute row 0 and are not stored
+    const int64_t r2 = a.idx2 ? (int64_t)idxv : (int64_t)(row / (uint32_t)a.div2);
+    const float* p1 = a.x1 + (int64_t)row * a.ld1 + 4 * h;
+    const float* p2 = x2b + r2 * a.ld2 + 4 * h - a.k1;
 #pragma unroll
-    for (int g = 0; g < GX; ++g) {
-      const int kk = g * 8;                    // + 4h is already in the pointers
-      const float* p = kk + 4 * h < a.k1 ? p1 + kk : p2 + (kk - a.k1);
-      xf[g] = *reinterpret_cast<const f32x4*>(p);
+    for (int g = 0; g < GX; ++g) xf[g] = *reinterpret_cast<const f32x4*>((g * 8 + 4 * h < a.k1 ? p1 : p2) + g * 8);
+  };
+
+  uint32_t tile = blockIdx.x * 8 + wave;
+  f32x4 xf[GX], xn[PREFETCH ? GX : 1];
+  int32_t idn = load_idx(tile);
+  if (PREFETCH) {
+    load_x(tile, idn, xf);
+    idn = load_idx(tile + tstride);
+  }
+  for (; tile < ntiles; tile += tstride) {
+    const uint32_t row = tile * 32 + l31;
+    const bool valid = row < rows;
+    const uint32_t batch = (valid ? row : 0) / rpb;
+    if constexpr (PREFETCH) {
+      load_x(tile + tstride, idn, xn);                   // next tile's fragments fly under this tile's GEMMs
+      idn = load_idx(tile + 2 * tstride);
+    } else {
+      load_x(tile, idn, xf);
+      idn = load_idx(tile + tstride);
     }
     // ---- GEMM 1: hid'[c1][row]
     f32x16 hid[T1];
@@ -104,7 +138,7 @@ __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
     }
     // bias + LeakyReLU on the hidden activations, in place (register 4q+e <-> channel 32t + 8q + 4h + e)
     {
-      const float* b1 = a.b1 + batch * a.b1_stride + 4 * h;
+      const float* b1 = B1s + (a.b1_stride > 0 ? batch : 0) * CHP + 4 * h;
 #pragma unroll
       for (int g = 0; g < GH; ++g) {
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b1 + g * 8);
@@ -159,24 +193,39 @@ __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
         for (int n = 0; n < T2; ++n) wc[n] = wn[n];
       }
     }
-    // ---- epilogue
-    const float* b2 = a.b2 + batch * a.b2_stride + 4 * h;
-    float* yrow = a.y ? a.y + (tile * 32 + l31) * a.ldy + 4 * h : nullptr;
+    // ---- epilogue: all values first (bias from LDS), pinned, then the predicated stores / the column maxima
+    const float* b2 = B2s + (a.b2_stride > 0 ? batch : 0) * CO + 4 * h;
+    f32x4 ov[T2][4];
 #pragma unroll
     for (int n = 0; n < T2; ++n)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int c = n * 32 + q * 8;
         const f32x4 bv = *reinterpret_cast<const f32x4*>(b2 + c);
-        f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float s = acc[n][4 * q + e] + bv[e];
           if (!CONV_SC && c < KX) s += xf[(c / 8)][e];          // identity shortcut: channel c+4h+e of x
-          v[e] = s > 0.f ? s : s * a.slope;
+          ov[n][q][e] = s > 0.f ? s : s * a.slope;
         }
-        if (yrow && valid) *reinterpret_cast<f32x4*>(yrow + c) = v;
-        if (a.colmax_part) {
+      }
+#pragma unroll
+    for (int n = 0; n < T2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cmr_pin(ov[n][q]);
+    if (a.y && valid) {
+      float* yrow = a.y + (int64_t)row * a.ldy + 4 * h;
+#pragma unroll
+      for (int n = 0; n < T2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yrow + n * 32 + q * 8) = ov[n][q];
+    }
+    if (a.colmax_part) {
+#pragma unroll
+      for (int n = 0; n < T2; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 v = ov[n][q];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float m = valid ? v[e] : -INFINITY;
@@ -184,9 +233,13 @@ __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
             for (int s = 1; s < 32; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
             v[e] = m;
           }
-          if (l31 == 0) *reinterpret_cast<f32x4*>(a.colmax_part + tile * CO + c + 4 * h) = v;
+          if (l31 == 0) *reinterpret_cast<f32x4*>(a.colmax_part + (int64_t)tile * CO + n * 32 + q * 8 + 4 * h) = v;
         }
-      }
+    }
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int g = 0; g < GX; ++g) xf[g] = xn[g];
+    }
   }
 }
 
@@ -211,7 +264,8 @@ __global__ __launch_bounds__(1024) void colmax_partials_kernel(const float* __re
 template <int KX, int CH, int CO, bool CONV_SC>
 int launch_cbr(const CbrArgs& a, hipStream_t stream) {
   constexpr int T1 = (CH + 31) / 32;
-  constexpr size_t smem = (size_t)(32 * T1 * (KX + 4) + CO * (CH + 4) + (CONV_SC ? CO * (KX + 4) : 0)) * sizeof(float);
+  constexpr size_t smem = (size_t)(32 * T1 * (KX + 4) + CO * (CH + 4) + (CONV_SC ? CO * (KX + 4) : 0) + CBR_MAXB * (32 * T1 + CO)) *
+                          sizeof(float);      // weights + staged bias rows
   static_assert(smem <= 160 * 1024, "weights must fit in LDS");
   static bool attr_set = false;
   if (!attr_set && smem > 64 * 1024) {
@@ -246,6 +300,8 @@ extern "C" int cmr_cbr_block_f32(const float* x1, int64_t ld1, int k1, const flo
   const CbrArgs a{x1, ld1, x2, ld2, idx2, div2 < 1 ? 1 : div2, k1, w1, b1, b1_stride, w2, b2, b2_stride, wsc, y, ldy,
                   colmax_part, rows, rows_per_batch, slope};
   const bool conv = wsc != nullptr;
+  if (rows >= (int64_t)0x7fffffc0 || ((b1_stride > 0 || b2_stride > 0) && (rows + rows_per_batch - 1) / rows_per_batch > CBR_MAXB))
+    return CMR_EUNSUPPORTED;                 // the unfused path (cmr_linear_f32 per layer) serves these
   if (kx == 64 && ch == 64 && co == 64 && !conv) return launch_cbr<64, 64, 64, false>(a, stream);
   if (kx == 128 && ch == 128 && co == 64 && conv) return launch_cbr<128, 128, 64, true>(a, stream);
   if (kx == 64 && ch == 128 && co == 64 && conv) return launch_cbr<64, 128, 64, true>(a, stream);

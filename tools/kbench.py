@@ -113,6 +113,18 @@ def main():
         def indep():
             for i in range(8): ops.layernorm64(xs[i], g, b, 1e-5, out=ys[i])
         print("independent tiny kernels (same stream) in a graph: %.2f us per kernel" % (timeit(indep, 50) / 8))
+    if "cbr" in a.what:
+        r = lambda *shape: torch.randn(*shape, device=DEV) * 0.1
+        rows, B = 8 * 16384, 8
+        for (kx, ch, co, conv, perb) in [(64, 128, 64, True, True), (64, 128, 128, False, True), (8, 8, 64, True, False), (64, 64, 64, False, False), (128, 128, 64, True, False)]:
+            x = r(rows, kx)
+            w1, w2 = r(ch, kx), r(co, ch)
+            b1 = r(B, ch) if perb else r(ch)
+            b2 = r(B, co) if perb else r(co)
+            wsc = r(co, kx) if conv else None
+            t = timeit(lambda: ops.cbr_block(x, w1, b1, w2, b2, wsc, 0.2, rows_per_batch=rows // B, want_colmax=True), a.reps)
+            fl = 2.0 * rows * (kx * ch + ch * co + (kx * co if conv else 0))
+            print("cbr_block %3d->%3d->%3d sc=%d: %7.1f us (incl. colmax pass)  %5.1f TFLOP/s" % (kx, ch, co, conv, t, fl / t / 1e6))
     if "heads" in a.what:
         r = lambda *shape: torch.randn(*shape, device=DEV) * 0.1
         x, e3d = r(8 * 418, 128), r(8, 128)
