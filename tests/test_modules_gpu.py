@@ -57,6 +57,16 @@ def test_module_vs_golden(name):
     G.assert_case(name, {"y": y}, atol=2e-5, rtol=1e-4, only={"y"})
 
 
+@pytest.mark.parametrize("name", ["vit_self_block", "vit_cross_block", "linear_attention"])
+def test_op_level_composition_vs_golden(name, monkeypatch):
+    """The layer-level kernels are the default; the one-kernel-per-reference-op composition they replace is held
+    to the same golden vectors."""
+    from cmr_agent_amd.models import LinearAttention as LA, _vit
+    monkeypatch.setattr(LA.LinearAttention, "FUSED", False)
+    monkeypatch.setattr(_vit.Block, "FUSED", False)
+    test_module_vs_golden(name)
+
+
 def test_pointnet_util_ops_vs_golden():
     from cmr_agent_amd.models import pointnet_util as U
     i = {k: v.to(DEV) for k, v in C.OP_CASES["pointnet_util"]["inputs"]().items()}
