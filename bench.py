@@ -224,8 +224,8 @@ def main():
                          "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                          "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9,
                          "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
-                         "share_of_step_time": conv["ms"] * 1e-3 / elapsed,
-                         "timed_in": "separate eager pass of the same %d steps (HIP events on the launch stream)" % args.steps},
+                         "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the "
+                                     "side-stream branches of the forward run concurrently, as in the replayed graph)" % args.steps},
             "launch_mode": "eager" if args.eager else "hipGraph replay",
         }
         if world == 1 and not args.no_cpu_baseline:
