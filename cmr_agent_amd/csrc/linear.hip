@@ -142,18 +142,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const LinearArgs a) {
   }
 }
 
-// Weight-stationary, barrier-free variant for K = k1 + k2 <= 128 (every hot-path GEMM except the two
-// K = 1024 / 4096 ones), computed TRANSPOSED: D'[cout][row] = W . X^T.
-//   * the [32*NT couts][K] weight block is loaded into LDS once per workgroup and is the MFMA A operand;
-//   * X rows are the B operand and come straight from global memory in operand layout (lane (row, h)
-//     reads the 16 B at k = 8g + 4h of ITS row; every row is read exactly once, nothing to share), the
-//     next 64-deep K segment / next tile is prefetched into registers while the current one is multiplied;
-//   * there is no __syncthreads in the loop: waves stream 32-row tiles independently;
-//   * in the transposed product a lane owns one output row and its 16 accumulator registers are 4 x 4
-//     consecutive output channels, so bias / residual / store are float4 accesses (and the registers
-//     of one layer are directly the B operand of the next -- the hook for chained layers).
-// Rows are HBM-bound at these shapes ((K + Nout) * 4 bytes vs 2*K*Nout flops per row).
-// Skinny GEMM for <= 16 rows (the agent's per-sample heads: 8 rows x K = 128..256).  A wave owns 4
+// Skinny GEMM for <= 16 rows (per-sample vectors: 8 rows x K = 128..256).  A wave owns 4
 // output channels: its 64 lanes read a weight row as one coalesced 1-KiB float4 load per 256 k,
 // multiply with the input rows held in LDS and finish with a wave reduction.  Replaces 128-row
 // MFMA tiles that would be > 90 % padding; latency-bound by construction (a few microseconds).
@@ -226,6 +215,17 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const LinearArgs a) 
 
 __device__ __attribute__((aligned(16))) float cmr_zero16[4] = {0.f, 0.f, 0.f, 0.f};   // NOT const: hipcc folds loads of a const zero page into predicated loads + 0
 
+// Weight-stationary, barrier-free variant for K = k1 + k2 <= 128 (every hot-path GEMM except the two
+// K = 1024 / 4096 ones), computed TRANSPOSED: D'[cout][row] = W . X^T.
+//   * the [32*NT couts][K] weight block is loaded into LDS once per workgroup and is the MFMA A operand;
+//   * X rows are the B operand and come straight from global memory in operand layout (lane (row, h)
+//     reads the 16 B at k = 8g + 4h of ITS row; every row is read exactly once, nothing to share), the
+//     next 64-deep K segment / next tile is prefetched into registers while the current one is multiplied;
+//   * there is no __syncthreads in the loop: waves stream 32-row tiles independently;
+//   * in the transposed product a lane owns one output row and its 16 accumulator registers are 4 x 4
+//     consecutive output channels, so bias / residual / store are float4 accesses (and the registers
+//     of one layer are directly the B operand of the next -- the hook for chained layers).
+// Rows are HBM-bound at these shapes ((K + Nout) * 4 bytes vs 2*K*Nout flops per row).
 // NT = 32-wide cout tiles per workgroup (1, 2, 4); G = k-groups (of 8) per register segment (1, 2, 4, 8); NSEG
 // segments cover K: KPAD = NSEG * 8 * G >= k1 + k2 (weights beyond k1 + k2 are zero in LDS, X loads beyond it read
 // zeros).  AC = activation class: 0 -> v > 0 ? v : v * slope (none / ReLU / LeakyReLU with slope 1 / 0 / p),
