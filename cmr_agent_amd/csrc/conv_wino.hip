@@ -53,7 +53,10 @@ __device__ __attribute__((aligned(16))) float wt_zero16[4] = {0.f, 0.f, 0.f, 0.f
 // live (spilled) across the MFMA loop.
 __device__ __forceinline__ int wt_fresh(int v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ int wt_slot(int py, int px) { return py * WT_PITCH + (px & 1) * (WT_PITCH / 2) + (px >> 1); }
-__device__ __forceinline__ int wt_lds(int slot, int c) { return slot * WT_KC + 4 * (c ^ (slot & 7)); }   // float offset of piece c
+// piece c of slot s lives at piece c ^ key(s); bit 0 of the key also flips with the row pair, because the two tile rows a
+// 16-lane ds_read_b128 pass covers are 2 rows = 40 slots = 0 (mod 8) apart and would otherwise share banks
+__device__ __forceinline__ int wt_key(int slot) { return (slot & 7) ^ (((slot / WT_PITCH) >> 1) & 1); }
+__device__ __forceinline__ int wt_lds(int slot, int c) { return slot * WT_KC + 4 * (c ^ wt_key(slot)); }   // float offset of piece c
 
 // NT = 32-cout tiles per workgroup.  NT = 2: 248 VGPRs, 64 KB LDS, 2 workgroups / CU.  NT = 1: half the accumulators
 // (<= 168 VGPRs, 51 KB), 3 workgroups / CU and twice the workgroups -- for maps too small to fill the chip.
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(cons
   // w, w+4, ... (clamped to the last block: a duplicate, identical write instead of a branch).
   auto dma_halo = [&](const Tile& t, int chunk, float* halo) {
     const int lf = wt_fresh(lane);
-    const float* xc = a.x + (int64_t)t.b * a.H * a.W * a.Cin + chunk * WT_KC + ((lf & 7) ^ (lf >> 3)) * 4;
+    const float* xc = a.x + (int64_t)t.b * a.H * a.W * a.Cin + chunk * WT_KC;
 #pragma unroll
     for (int i = 0; i < WT_DMA_PER_WAVE; ++i) {
       int k = wave + 4 * i;
@@ -119,7 +122,7 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(cons
       const int px = r < WT_PITCH / 2 ? 2 * r : 2 * r - (WT_PITCH - 1);
       const int iy = t.oy0 - 1 + py, ix = t.ox0 - 1 + px;
       const bool inb = px < WT_HC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      const float* src = inb ? xc + (unsigned)((iy * a.W + ix) * a.Cin) : wt_zero16;
+      const float* src = inb ? xc + (unsigned)((iy * a.W + ix) * a.Cin + ((lf & 7) ^ wt_key(slot)) * 4) : wt_zero16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(halo + k * 256), 16, 0, 0);
     }
