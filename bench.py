@@ -197,7 +197,8 @@ def main():
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = next(v["hbm_bytes_per_launch"] for k, v in pmc.items() if "conv3x3_wino_kernel" in k)
+            wino = [v for k, v in pmc.items() if "conv3x3_wino_kernel" in k]       # both template instances, launch-weighted
+            traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in wino) / sum(v["launches"] for v in wino)
         except Exception:
             pass
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12

@@ -1,10 +1,11 @@
 """gpurun_out/prof_r/{fetch,write}/**/counter_collection.csv -> per-kernel HBM bytes per launch (JSON on stdout).
 FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled on gfx950 (128-B requests tallied at 64 B, MI355X_MICROARCH.md)."""
-import csv, glob, json, collections, re, sys
+import csv, glob, json, collections, os, re, sys
 root = sys.argv[1]
 def collect(sub, counter):
     acc = collections.defaultdict(lambda: [set(), 0.0])
-    for f in glob.glob(root + "/" + sub + "/**/*counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(root + "/" + sub + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:                                  # gpurun merges runs into the same directory: newest only
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
