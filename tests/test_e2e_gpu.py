@@ -10,6 +10,12 @@ def test_registration_iteration(case):
     parity_e2e.run_case(case, check_golden=True, verbose=True)
 
 
+def test_registration_iteration_baseline_config0():
+    """BASELINE.json configs[0] sizes (batch 1, 4096 points, 176x608 -> 192x608, 1 agent step) against the oracle."""
+    import parity_e2e
+    parity_e2e.run_case("e2e_config0", check_golden=False, verbose=True)
+
+
 def test_registration_iteration_op_level_paths(monkeypatch):
     """Same iteration with every layer-level fusion and the side streams switched off: the op-level composition
     must meet the same oracle / golden bars."""
