@@ -192,3 +192,26 @@ def test_nuscenes_shape_runs():
     data, pose, acts = _iteration(geo, agent, cfg, _hip_batch(1, 32768, 896, 1600))
     assert data["img_proxy"].shape == (1, 28 * 50, 64) and data["img_geo_feat"].shape == (1, 64, 224, 400)
     assert torch.isfinite(pose).all() and acts.shape == (1, 2, 3)
+
+
+def test_geo_forward_at_65536_points():
+    """BASELINE configs[4] size of the geometric model (65 536 points, the PointNN grouping / kNN stress shape):
+    runs through the HIP path; outputs are finite, unit-norm where the reference normalises, and a sample's
+    result does not depend on its batch mate."""
+    from cmr_agent_amd.config import KittiConfiguration
+    cfg = KittiConfiguration(cropped_img_H=160, cropped_img_W=512, num_pt=65536, device=DEV)
+    geo, _ = _models(cfg)
+    batch = _hip_batch(2, 65536, 160, 512)
+    data = dict(batch)
+    with torch.no_grad():
+        geo(data)
+    torch.cuda.synchronize()
+    assert data["pc_geo_feat"].shape == (2, 64, 65536) and data["pc_overlap_logits"].shape == (2, 2, 65536)
+    for k in ("pc_geo_feat", "img_geo_feat", "pc_overlap_logits", "fused_node_feat"):
+        assert torch.isfinite(data[k]).all(), k
+    assert float((data["pc_geo_feat"].norm(dim=1) - 1).abs().max()) < 1e-4
+    one = {k: (v[1:2].contiguous() if torch.is_tensor(v) and v.shape[0] == 2 else v) for k, v in batch.items()}
+    with torch.no_grad():
+        geo(one)
+    assert float((one["pc_geo_feat"] - data["pc_geo_feat"][1:2]).abs().max()) < 1e-5
+    assert torch.equal(one["pc_overlap_pred"], data["pc_overlap_pred"][1:2])
