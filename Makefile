@@ -8,7 +8,7 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Icmr_agent_amd/csrc
 
 all: $(LIB)
 
-build/%.o: cmr_agent_amd/csrc/%.hip cmr_agent_amd/csrc/cmr_common.h
+build/%.o: cmr_agent_amd/csrc/%.hip cmr_agent_amd/csrc/cmr_common.h cmr_agent_amd/csrc/cmr_chain.h
 	@mkdir -p build
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

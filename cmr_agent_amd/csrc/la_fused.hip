@@ -12,7 +12,7 @@
 // one GEMM are the B fragments (k-group 4t+q) of the next: the whole chain stays in registers.  A head is one
 // k-group (8 channels, 4 in each lane half), so the 8x8 state product and the LayerNorm statistics need a single
 // exchange with the partner lane (lane ^ 32).
-#include "cmr_common.h"
+#include "cmr_chain.h"
 
 namespace {
 
@@ -21,36 +21,6 @@ constexpr int LA_LD64 = LA_D + 4, LA_LD128 = LA_HID + 4;  // padded LDS weight r
 
 __device__ __forceinline__ float la_elu1(float v) { return v > 0.f ? v + 1.f : expf(v); }   // F.elu(v) + 1
 __device__ __forceinline__ float la_xhalf(float v) { return __shfl_xor(v, 32); }            // partner lane (other 4 dims of the head)
-
-// acc[t] += W[32t + l31][8kg + 4h + j] * bfrag(kg, j)   for kg < KG, j < 4   (weights software-pipelined one
-// k-group ahead from LDS; the scheduling barrier keeps hipcc from hoisting every LDS read of the unrolled loop)
-template <int T, int KG, int LD, typename BF>
-__device__ __forceinline__ void la_gemm(const float* __restrict__ Ws, int l31, int h, f32x16 (&acc)[T], BF bfrag) {
-#pragma unroll
-  for (int t = 0; t < T; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const float* wrow = Ws + l31 * LD + 4 * h;
-  f32x4 wc[T], wn[T];
-#pragma unroll
-  for (int t = 0; t < T; ++t) wc[t] = *reinterpret_cast<const f32x4*>(wrow + t * 32 * LD);
-#pragma unroll
-  for (int kg = 0; kg < KG; ++kg) {
-    if (kg + 1 < KG) {
-#pragma unroll
-      for (int t = 0; t < T; ++t) wn[t] = *reinterpret_cast<const f32x4*>(wrow + t * 32 * LD + (kg + 1) * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float b = bfrag(kg, j);
-#pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = cmr_mfma32(wc[t][j], b, acc[t]);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < T; ++t) wc[t] = wn[t];
-  }
-}
 
 // LayerNorm over the 64 channels of this lane's row (32 here, 32 in the partner lane), in place
 __device__ __forceinline__ void la_layernorm(f32x16 (&v)[2], const float* __restrict__ gs, const float* __restrict__ bs,
@@ -155,7 +125,7 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
 
     // ---- Q = elu(Wq x) + 1 ; message = Q KV / (Q . Ksum + eps) * S, head by head (head = tile t, quad qd)
     f32x16 msg[2];
-    la_gemm<2, 8, LA_LD64>(Wq, l31, h, msg, [&](int kg, int j) { return xf[kg][j]; });
+    cmr_chain_gemm<2, 8, LA_LD64>(Wq, l31, h, msg, [&](int kg, int j) { return xf[kg][j]; });
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -191,12 +161,12 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
 
     // ---- merge + LayerNorm 1
     f32x16 mrg[2];
-    la_gemm<2, 8, LA_LD64>(Wm, l31, h, mrg, [&](int kg, int j) { return msg[kg / 4][4 * (kg % 4) + j]; });
+    cmr_chain_gemm<2, 8, LA_LD64>(Wm, l31, h, mrg, [&](int kg, int j) { return msg[kg / 4][4 * (kg % 4) + j]; });
     la_layernorm(mrg, Ln, Ln + LA_D, h, a.ln_eps);
 
     // ---- mlp: 128 -> 128 (ReLU) -> 64 on cat[x, message], LayerNorm 2, residual
     f32x16 hid[4];
-    la_gemm<4, 16, LA_LD128>(W0, l31, h, hid, [&](int kg, int j) {
+    cmr_chain_gemm<4, 16, LA_LD128>(W0, l31, h, hid, [&](int kg, int j) {
       return kg < 8 ? xf[kg & 7][j] : mrg[(kg - 8) / 4 & 1][4 * ((kg - 8) % 4 & 3) + j];
     });
 #pragma unroll
@@ -204,7 +174,7 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
 #pragma unroll
       for (int r = 0; r < 16; ++r) hid[t][r] = hid[t][r] > 0.f ? hid[t][r] : 0.f;
     f32x16 o[2];
-    la_gemm<2, 16, LA_LD128>(W3, l31, h, o, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
+    cmr_chain_gemm<2, 16, LA_LD128>(W3, l31, h, o, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
     la_layernorm(o, Ln + 2 * LA_D, Ln + 3 * LA_D, h, a.ln_eps);
 
     f32x4 ov[8];

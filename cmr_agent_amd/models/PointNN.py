@@ -106,6 +106,9 @@ class ConvBNReLURes1D(Planned):
         return bcl_from_rows(self.rows(r), B)
 
 
+FUSED_FRONT = True     # one launch for the per-row front of the vector attention (ops.vecattn_front); False = op by op
+
+
 def _vector_attention(p, q, k, v, rel, rows, nseg, iq, divq, ik, order, offsets, fixed_len):
     """Shared tail of the two point transformers: pos = fc_delta(rel); a = fc_gamma(q - k + pos);
     per-channel softmax of a / sqrt(64) over each segment; sum of a * (v + pos)."""
@@ -140,10 +143,15 @@ class GroupPointTransformer(Planned):
         self._require_eval()
         p = self.plan()
         R, S = feat.shape[0], node_feat.shape[0]
-        kv = ops.linear(ops.linear(feat, *p["fc1_0"]), p["wkv"])
         q = ops.linear(ops.linear(node_feat, *p["fc1_1"]), p["wq"])
-        rel = ops.rel_pos(xyz4, node4, R, ib=gidx)
-        res = _vector_attention(p, q, kv[:, 0:64], kv[:, 64:128], rel, R, S, gidx, 1, None, order, offsets, 0)
+        if FUSED_FRONT and p["d0"][0].shape == (64, 4):
+            a, vp = ops.vecattn_front(q, xyz4, node4, gidx, p["d0"], p["d2"], p["g0"], p["g2"], R, iq=gidx, feat=feat,
+                                      fc1=p["fc1_0"], wkv=p["wkv"])
+            res = ops.segment_softmax(a, vp, S, 0.125, order=order, offsets=offsets, fixed_len=0)
+        else:
+            kv = ops.linear(ops.linear(feat, *p["fc1_0"]), p["wkv"])
+            rel = ops.rel_pos(xyz4, node4, R, ib=gidx)
+            res = _vector_attention(p, q, kv[:, 0:64], kv[:, 64:128], rel, R, S, gidx, 1, None, order, offsets, 0)
         return ops.linear(res, *p["fc2"], res=node_feat)
 
     def forward(self, xyz, xyz_features, node, node_features, idx):
@@ -180,9 +188,14 @@ class KnnPointTransformer(Planned):
         p = self.plan()
         S = feat.shape[0]
         qkv = ops.linear(ops.linear(feat, *p["fc1"]), p["wqkv"])
-        rel = ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn)               # centre - neighbour
-        res = _vector_attention(p, qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192], rel, S * 16, S, None, 16, knn, None,
-                                None, 16)
+        if FUSED_FRONT and p["d0"][0].shape == (64, 4):
+            a, vp = ops.vecattn_front(qkv[:, 0:64], node4, node4, knn, p["d0"], p["d2"], p["g0"], p["g2"], S * 16, divq=16,
+                                      diva=16, kv=qkv[:, 64:192], ik=knn)                 # centre - neighbour
+            res = ops.segment_softmax(a, vp, S, 0.125, fixed_len=16)
+        else:
+            rel = ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn)               # centre - neighbour
+            res = _vector_attention(p, qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192], rel, S * 16, S, None, 16, knn, None,
+                                    None, 16)
         return ops.linear(res, *p["fc2"], res=feat)
 
     def forward(self, xyz, features):

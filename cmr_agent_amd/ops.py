@@ -332,6 +332,22 @@ def vecattn_prep(q, k, v, pos, rows, iq=None, divq=1, ik=None):
     return t, vp
 
 
+def vecattn_front(q, pa4, pb4, ib, d0, d2, g0, g2, rows, iq=None, divq=1, ia=None, diva=1, feat=None, fc1=None, wkv=None,
+                  kv=None, ik=None):
+    """Per-row front of the vector attention (see cmr_vecattn_front_f32): returns (a, vp), both [rows, 64].
+    Either feat + fc1 (W, b) + wkv ([128, 64]) or a precomputed kv table [*, >=128] (+ ik) supplies k / v."""
+    a = torch.empty((rows, 64), dtype=f32, device=q.device)
+    vp = torch.empty((rows, 64), dtype=f32, device=q.device)
+    if feat is not None:
+        src = (_p(_rows(feat)), _ld(feat), _p(fc1[0]), _p(fc1[1]), _p(wkv), None, 0, None)
+    else:
+        src = (None, 0, None, None, None, _p(_rows(kv)), _ld(kv), _p(_i32(ik)))
+    _lib.call("cmr_vecattn_front_f32", *src, _p(_rows(q)), _ld(q), _p(_i32(iq)), int(divq), _p(pa4), _p(_i32(ia)), int(diva),
+              _p(pb4), _p(_i32(ib)), _p(d0[0]), _p(d0[1]), _p(d2[0]), _p(d2[1]), _p(g0[0]), _p(g0[1]), _p(g2[0]), _p(g2[1]),
+              _p(a), _p(vp), rows, _stream())
+    return a, vp
+
+
 def segment_softmax(attn, vp, nseg, scale, order=None, offsets=None, fixed_len=0):
     out = torch.empty((nseg, 64), dtype=f32, device=attn.device)
     _lib.call("cmr_segment_softmax_f32", _p(attn), _p(vp), _p(_i32(order)), _p(_i32(offsets)), fixed_len, float(scale),

@@ -159,6 +159,21 @@ int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* kvsum, cons
                            const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, int B, int L, int S, float eps,
                            float ln_eps, hipStream_t stream);
 
+/* Front half of the vector attention of GroupPointTransformer / KnnPointTransformer (PointNN.py:151-170, 219-226) in one
+ * launch, per row r (a (point, owning node) or (node, neighbour) pair):
+ *   k, v = [Wk | Wv] (W10 feat[r] + b10)           when feat != NULL   (group transformer)
+ *        = kv[ik ? ik[r] : r][0:64], [64:128]      when feat == NULL   (kNN transformer: precomputed table)
+ *   pos = Wd2 relu(Wd0 (pa4[ia ? ia[r] : r / diva] - pb4[ib[r]]) + bd0) + bd2        (Wd0: [64][4], 3 columns used)
+ *   a_out[r] = Wg2 relu(Wg0 (q[iq ? iq[r] : r / divq] - k + pos) + bg0) + bg2 ;  vp_out[r] = v + pos
+ * a_out / vp_out are [rows][64] and feed cmr_segment_softmax_f32.  Replaces cmr_rel_pos_f32 + cmr_vecattn_prep_f32 +
+ * six cmr_linear_f32 launches. */
+int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float* w10, const float* b10, const float* wkv, const float* kv,
+                          int64_t ldkv, const int32_t* ik, const float* q, int64_t ldq, const int32_t* iq, int64_t divq,
+                          const float* pa4, const int32_t* ia, int64_t diva, const float* pb4, const int32_t* ib,
+                          const float* wd0, const float* bd0, const float* wd2, const float* bd2, const float* wg0,
+                          const float* bg0, const float* wg2, const float* bg2, float* a_out, float* vp_out, int64_t rows,
+                          hipStream_t stream);
+
 /* ---- point-cloud ops ----------------------------------------------------------------------- */
 
 /* planar [B,C,N] (the reference's point layout) -> rows [B*N, Cpad], Cpad in {4, 8}, zero padded. */

@@ -57,11 +57,13 @@ def test_module_vs_golden(name):
     G.assert_case(name, {"y": y}, atol=2e-5, rtol=1e-4, only={"y"})
 
 
-@pytest.mark.parametrize("name", ["vit_self_block", "vit_cross_block", "linear_attention"])
+@pytest.mark.parametrize("name", ["vit_self_block", "vit_cross_block", "linear_attention", "group_point_transformer",
+                                  "knn_point_transformer"])
 def test_op_level_composition_vs_golden(name, monkeypatch):
     """The layer-level kernels are the default; the one-kernel-per-reference-op composition they replace is held
     to the same golden vectors."""
-    from cmr_agent_amd.models import LinearAttention as LA, _vit
+    from cmr_agent_amd.models import LinearAttention as LA, PointNN, _vit
+    monkeypatch.setattr(PointNN, "FUSED_FRONT", False)
     monkeypatch.setattr(LA.LinearAttention, "FUSED", False)
     monkeypatch.setattr(_vit.Block, "FUSED", False)
     test_module_vs_golden(name)

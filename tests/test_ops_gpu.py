@@ -242,6 +242,44 @@ def test_agent_heads_fused_tail(ops, B, npix):
         close(g, ref, 2e-5, "head")
 
 
+@pytest.mark.parametrize("mode", ["group", "knn"])
+def test_vector_attention_front_fused(ops, mode):
+    """cmr_vecattn_front_f32 against torch fp64 (both k/v sources, ragged row counts)."""
+    lin = lambda n, k, sd: (rnd(n, k, seed=sd, lo=-0.3, hi=0.3), rnd(n, seed=sd + 1))
+    d0w, d0b = lin(64, 3, 60)
+    d0 = (torch.cat([d0w, torch.zeros(64, 1)], 1), d0b)            # K padded to 4 as _pack.lin does
+    d2, g0, g2 = lin(64, 64, 62), lin(64, 64, 64), lin(64, 64, 66)
+    dd = lambda wb: (wb[0].to(DEV).contiguous(), wb[1].to(DEV).contiguous())
+    f = lambda t, wb: t @ wb[0].double().T + wb[1].double()
+    if mode == "group":
+        R, S = 1000, 37
+        feat, q = rnd(R, 64, seed=70), rnd(S, 64, seed=71)
+        pa, pb = rnd(R, 4, seed=72, lo=-5, hi=5), rnd(S, 4, seed=73, lo=-5, hi=5)
+        gidx = torch.randint(0, S, (R,), generator=torch.Generator().manual_seed(5), dtype=torch.int32)
+        fc1, wkv = lin(64, 64, 74), rnd(128, 64, seed=76, lo=-0.3, hi=0.3)
+        x = f(feat.double(), fc1)
+        k, v = x @ wkv[:64].double().T, x @ wkv[64:].double().T
+        rel = (pa.double() - pb.double()[gidx.long()])[:, :3]
+        qq = q.double()[gidx.long()]
+        a, vp = ops.vecattn_front(q.to(DEV), pa.to(DEV), pb.to(DEV), gidx.to(DEV), dd(d0), dd(d2), dd(g0), dd(g2), R,
+                                  iq=gidx.to(DEV), feat=feat.to(DEV), fc1=dd(fc1), wkv=wkv.to(DEV))
+    else:
+        S = 77
+        R = S * 16
+        qkv = rnd(S, 192, seed=80)
+        node = rnd(S, 4, seed=81, lo=-5, hi=5)
+        knn = torch.randint(0, S, (R,), generator=torch.Generator().manual_seed(6), dtype=torch.int32)
+        k, v = qkv.double()[knn.long(), 64:128], qkv.double()[knn.long(), 128:192]
+        qq = qkv.double()[:, :64].repeat_interleave(16, 0)
+        rel = (node.double().repeat_interleave(16, 0) - node.double()[knn.long()])[:, :3]
+        dq = qkv.to(DEV)
+        a, vp = ops.vecattn_front(dq[:, 0:64], node.to(DEV), node.to(DEV), knn.to(DEV), dd(d0), dd(d2), dd(g0), dd(g2), R,
+                                  divq=16, diva=16, kv=dq[:, 64:192], ik=knn.to(DEV))
+    pos = f(F.relu(rel @ d0w.double().T + d0b.double()), d2)
+    close(a, f(F.relu(f(qq - k + pos, g0)), g2), 2e-5, "a")
+    close(vp, v + pos, 2e-5, "vp")
+
+
 def _cloud(B, N, seed):
     return rnd(B, 3, N, seed=seed, lo=-20, hi=20)
 
