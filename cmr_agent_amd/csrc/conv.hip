@@ -426,19 +426,20 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
 
   const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw;
   // per-lane description of its 16 K entries: k = 8g + 4h + e
-  int off[16], code[16];           // code: 0..8 = (dy+1)*3+(dx+1) tap of t, 9 = centre of x, 10 = zero pad
+  int off[16], offc[16], code[16];  // code: 0..8 = (dy+1)*3+(dx+1) tap of t, 9 = centre of x, 10 = zero pad; offc = centre of the channel
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = 8 * (i >> 2) + 4 * h + (i & 3);
     if (k < 27) {
       const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
       off[i] = (int)(ci * hw) + (ky - 1) * W + (kx - 1);
+      offc[i] = (int)(ci * hw);
       code[i] = ky * 3 + kx;
     } else if (k < 30) {
-      off[i] = (int)((k - 27) * hw);
+      off[i] = offc[i] = (int)((k - 27) * hw);
       code[i] = 9;
     } else {
-      off[i] = 0;
+      off[i] = offc[i] = 0;
       code[i] = 10;
     }
   }
@@ -462,14 +463,19 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
     if (!valid) m = 0;
     const float* tp = t + (int64_t)b * 3 * hw + rem;
     const float* xp = x + (int64_t)b * 3 * hw + rem;
+    // branch-free: an out-of-image tap re-reads the (always valid) centre pixel of its channel and is masked after
+    // the load -- a conditional load or a pointer select is compiled to a branch + s_waitcnt vmcnt(0) per tap
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const float* q = (code[i] == 9 ? xp : tp) + off[i];
-      if (!((m >> code[i]) & 1u)) q = cmr_conv_zero16;
-      dst[i] = *q;
+      const bool ok = (m >> code[i]) & 1u;
+      const float v = (code[i] == 9 ? xp : tp)[ok ? off[i] : offc[i]];
+      dst[i] = ok ? v : 0.f;
     }
   };
 
+  f32x4 bv[8];                      // bias of this lane's 8 channel quads, loaded once
+#pragma unroll
+  for (int i = 0; i < 8; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + 8 * i + 4 * h);
   const int64_t ntiles = (total + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * 4;
   float xc[16], xn[16];
@@ -477,6 +483,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
   gather(tile < ntiles ? tile : 0, xc);
   for (; tile < ntiles; tile += tstride) {
     gather(tile + tstride < ntiles ? tile + tstride : tile, xn);
+    __builtin_amdgcn_sched_barrier(0);           // the next tile's 16 loads are issued BEFORE this tile's MFMAs, not after
     f32x16 acc[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -490,18 +497,23 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
         acc[1] = cmr_mfma32(wf[1][g][j], xc[g * 4 + j], acc[1]);
       }
     const int64_t p = tile * 32 + l31;
+    f32x4 ov[8];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+        v += bv[4 * n + q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        ov[4 * n + q] = v;
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cmr_pin(ov[i]);
     if (p < total) {
+      float* yp = y + p * 64 + 4 * h;
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c0 = n * 32 + 8 * q + 4 * h;
-          f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
-          v += *reinterpret_cast<const f32x4*>(bias + c0);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
-          *reinterpret_cast<f32x4*>(y + p * 64 + c0) = v;
-        }
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(yp + 8 * i) = ov[i];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xc[i] = xn[i];
