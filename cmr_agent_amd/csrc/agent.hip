@@ -55,16 +55,23 @@ __global__ __launch_bounds__(256) void project_scatter_kernel(const float* __res
 }
 
 // state2d[b,y,x,0:64] = img_feat ; state2d[b,y,x,64:128] = acc / max(cnt,1)
+// clear: the cells that received points are zeroed again after they have been read (16 lanes share a cell; lane 0 of the
+// 16 resets the counter after all of them have read it), so the next scatter needs no 55 MB memset.
 __global__ __launch_bounds__(256) void observation_finalize_kernel(const float* __restrict__ img_feat,
-                                                                   const float* __restrict__ acc,
-                                                                   const float* __restrict__ cnt, float* __restrict__ state2d,
-                                                                   float* __restrict__ proj, int64_t cells, int write_img) {
+                                                                   float* __restrict__ acc,
+                                                                   float* __restrict__ cnt, float* __restrict__ state2d,
+                                                                   float* __restrict__ proj, int64_t cells, int write_img, int clear) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t cell = e >> 4;
   if (cell >= cells) return;
   const int c = (int)(e & 15) * 4;
-  const float n = fmaxf(cnt[cell], 1.f);
+  const float nraw = cnt[cell];
+  const float n = fmaxf(nraw, 1.f);
   f32x4 a = *reinterpret_cast<const f32x4*>(acc + cell * 64 + c);
+  if (clear && nraw > 0.f) {
+    *reinterpret_cast<f32x4*>(acc + cell * 64 + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if ((threadIdx.x & 15) == 0) cnt[cell] = 0.f;      // the cell's 16 lanes sit in one wave and have all loaded the count above
+  }
   a[0] /= n; a[1] /= n; a[2] /= n; a[3] /= n;
   *reinterpret_cast<f32x4*>(state2d + cell * 128 + 64 + c) = a;
   if (proj) *reinterpret_cast<f32x4*>(proj + cell * 64 + c) = a;
@@ -177,23 +184,25 @@ __global__ __launch_bounds__(256) void l2norm64_kernel(const float* __restrict__
 
 extern "C" int cmr_project_scatter_f32(const float* pc4, const float* feat, const uint8_t* overlap, const float* pose,
                                        const float* Kmat, const float* mean4, float* acc, float* cnt, float* state3d,
-                                       int B, int N, int h, int w, hipStream_t stream) {
+                                       int B, int N, int h, int w, int zero_first, hipStream_t stream) {
   CMR_REQUIRE(pc4 && feat && overlap && pose && Kmat && mean4 && acc && cnt && state3d && B > 0 && N > 0 && h > 0 && w > 0);
   const int64_t cells = (int64_t)B * h * w;
-  if (hipMemsetAsync(acc, 0, cells * 64 * sizeof(float), stream) != hipSuccess) return CMR_ELAUNCH;
-  if (hipMemsetAsync(cnt, 0, cells * sizeof(float), stream) != hipSuccess) return CMR_ELAUNCH;
+  if (zero_first) {      // otherwise the caller guarantees zeroed accumulators (cmr_observation_finalize_f32 with clear = 1 leaves them so)
+    if (hipMemsetAsync(acc, 0, cells * 64 * sizeof(float), stream) != hipSuccess) return CMR_ELAUNCH;
+    if (hipMemsetAsync(cnt, 0, cells * sizeof(float), stream) != hipSuccess) return CMR_ELAUNCH;
+  }
   const int64_t total = (int64_t)B * N;
   hipLaunchKernelGGL(project_scatter_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, pc4, feat, overlap,
                      pose, Kmat, mean4, acc, cnt, state3d, B, N, h, w);
   return cmr_launch_status();
 }
 
-extern "C" int cmr_observation_finalize_f32(const float* img_feat, const float* acc, const float* cnt, float* state2d,
-                                            float* proj, int B, int h, int w, int write_img, hipStream_t stream) {
+extern "C" int cmr_observation_finalize_f32(const float* img_feat, float* acc, float* cnt, float* state2d,
+                                            float* proj, int B, int h, int w, int write_img, int clear, hipStream_t stream) {
   CMR_REQUIRE(img_feat && acc && cnt && state2d && B > 0 && h > 0 && w > 0);
   const int64_t cells = (int64_t)B * h * w;
   hipLaunchKernelGGL(observation_finalize_kernel, dim3((unsigned)((cells * 16 + 255) / 256)), dim3(256), 0, stream,
-                     img_feat, acc, cnt, state2d, proj, cells, write_img);
+                     img_feat, acc, cnt, state2d, proj, cells, write_img, clear);
   return cmr_launch_status();
 }
 

@@ -37,8 +37,9 @@ class _ObsContext:
         self.K = data['K'].to(dev).contiguous()
         self.mean4 = ops.colmean(self.pc4, self.B, self.N)
         cells = self.B * self.h * self.w
-        self.acc = torch.empty((cells, 64), dtype=torch.float32, device=dev)
-        self.cnt = torch.empty((cells,), dtype=torch.float32, device=dev)
+        # scatter-mean accumulators: zeroed once here, re-zeroed sparsely by every observation_finalize(clear=True)
+        self.acc = torch.zeros((cells, 64), dtype=torch.float32, device=dev)
+        self.cnt = torch.zeros((cells,), dtype=torch.float32, device=dev)
         self.first = True
 
 
@@ -70,8 +71,8 @@ def observation_from_a_pose(data, RT):
     state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev)
     proj = torch.empty((B, h, w, 64), dtype=torch.float32, device=dev)
     ops.project_scatter(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.acc, ctx.cnt,
-                        state3d)
-    ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, proj, B, h, w, True)
+                        state3d, zero_first=False)
+    ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, proj, B, h, w, True, clear=True)
     obs2d = state2d.permute(0, 3, 1, 2)
     # the agent's first conv is linear in its input: hand it the two halves separately so that the image half
     # (constant over the steps of one registration) is convolved once (CMRAgent.forward_cl)

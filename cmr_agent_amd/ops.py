@@ -427,14 +427,15 @@ def colmean(x, B, N):
     return _colreduce("cmr_colmean_f32", x, B, N)
 
 
-def project_scatter(pc4, feat, overlap_u8, pose, K, mean4, B, N, h, w, acc, cnt, state3d):
+def project_scatter(pc4, feat, overlap_u8, pose, K, mean4, B, N, h, w, acc, cnt, state3d, zero_first=True):
+    """acc / cnt must be zero on entry; zero_first=False when the previous observation_finalize(clear=True) left them so."""
     _lib.call("cmr_project_scatter_f32", _p(pc4), _p(feat), _p(overlap_u8), _p(pose), _p(K), _p(mean4), _p(acc), _p(cnt),
-              _p(state3d), B, N, h, w, _stream())
+              _p(state3d), B, N, h, w, int(zero_first), _stream())
 
 
-def observation_finalize(img_feat, acc, cnt, state2d, proj, B, h, w, write_img):
+def observation_finalize(img_feat, acc, cnt, state2d, proj, B, h, w, write_img, clear=False):
     _lib.call("cmr_observation_finalize_f32", _p(img_feat), _p(acc), _p(cnt), _p(state2d), _p(proj), B, h, w,
-              int(write_img), _stream())
+              int(write_img), int(clear), _stream())
 
 
 def pose_step(pose, act_r, act_t, r_steps, t_steps, six_dof):

@@ -240,13 +240,16 @@ int cmr_colmean_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t w
 
 /* ---- agent iteration ------------------------------------------------------------------------ */
 
-/* environment.py:24-126: projection, in-frustum test, scatter-mean numerator/denominator, state_3d. */
+/* environment.py:24-126: projection, in-frustum test, scatter-mean numerator/denominator, state_3d.  acc [B*h*w][64] and
+ * cnt [B*h*w] must be zero on entry: zero_first = 1 clears them here (two memsets), zero_first = 0 relies on the caller
+ * (cmr_observation_finalize_f32 with clear = 1 re-zeroes exactly the cells that were hit). */
 int cmr_project_scatter_f32(const float* pc4, const float* feat, const uint8_t* overlap, const float* pose,
                             const float* Kmat, const float* mean4, float* acc, float* cnt, float* state3d, int B, int N,
-                            int h, int w, hipStream_t stream);
-/* state2d = [img_feat | acc / max(cnt,1)]; proj (optional) receives the second half alone as [B,h,w,64]. */
-int cmr_observation_finalize_f32(const float* img_feat, const float* acc, const float* cnt, float* state2d, float* proj,
-                                 int B, int h, int w, int write_img, hipStream_t stream);
+                            int h, int w, int zero_first, hipStream_t stream);
+/* state2d = [img_feat | acc / max(cnt,1)]; proj (optional) receives the second half alone as [B,h,w,64].
+ * clear = 1: cells with cnt > 0 are reset to zero after they have been read. */
+int cmr_observation_finalize_f32(const float* img_feat, float* acc, float* cnt, float* state2d, float* proj,
+                                 int B, int h, int w, int write_img, int clear, hipStream_t stream);
 /* environment.py:179-260 (step + euler_angles_to_matrix 'XYZ'), :14-21 (to_disentangled). */
 int cmr_pose_step_f32(float* pose, const int64_t* act_r, const int64_t* act_t, const double* r_steps,
                       const double* t_steps, int B, int six_dof, hipStream_t stream);

@@ -418,6 +418,17 @@ def test_observation_and_pose(ops):
     proj = torch.empty(B, h, w, 64, device=DEV)
     ops.observation_finalize(imf.permute(0, 2, 3, 1).contiguous().to(DEV), acc, cnt, st2, proj, B, h, w, True)
     assert torch.equal(proj, st2[..., 64:])
+    # the self-cleaning protocol of the environment: finalize(clear=True) leaves the accumulators zeroed, so the next
+    # scatter needs no memset (zero_first=False) and reproduces the same observation bit for bit
+    st2b, projb = torch.empty_like(st2), torch.empty_like(proj)
+    ops.project_scatter(pc4, feat.permute(0, 2, 1).reshape(-1, 64).contiguous().to(DEV), ov.to(torch.uint8).reshape(-1).to(DEV),
+                        pose_g, K.to(DEV), mean4, B, N, h, w, acc, cnt, st3)
+    ops.observation_finalize(imf.permute(0, 2, 3, 1).contiguous().to(DEV), acc, cnt, st2b, projb, B, h, w, True, clear=True)
+    assert float(acc.abs().max()) == 0 and float(cnt.abs().max()) == 0
+    ops.project_scatter(pc4, feat.permute(0, 2, 1).reshape(-1, 64).contiguous().to(DEV), ov.to(torch.uint8).reshape(-1).to(DEV),
+                        pose_g, K.to(DEV), mean4, B, N, h, w, acc, cnt, st3, zero_first=False)
+    ops.observation_finalize(imf.permute(0, 2, 3, 1).contiguous().to(DEV), acc, cnt, st2b, projb, B, h, w, True, clear=True)
+    assert float((projb - proj).abs().max()) < 1e-5          # float atomics: summation order may differ in the last bit
     got3 = st3.view(B, N, 8).permute(0, 2, 1).cpu()
     assert float((got3[:, :5] == s3).float().mean()) > 0.9995 and float(got3[:, 5:].abs().max()) == 0
     got2 = st2.permute(0, 3, 1, 2).cpu()
