@@ -98,3 +98,27 @@ def step(action_r, action_t, pose_source, config):
         r_steps, t_steps = r_steps.to(dev), t_steps.to(dev)
     ops.pose_step(pose_source, action_r.contiguous(), action_t.contiguous(), r_steps, t_steps, config.is_6_DoF)
     return pose_source
+
+
+@torch.no_grad()
+def expert(pose_source, targets, config, data=None):
+    """Expert action of the current state (reference environment.py:143-176), on the device: the reference leaves the
+    GPU for scipy's Euler decomposition at every step.  Returns (action_r, action_t) int64 like the reference."""
+    dev = pose_source.device
+    r_steps, t_steps = config.r_steps, config.t_steps
+    if r_steps.device != dev:
+        r_steps, t_steps = r_steps.to(dev), t_steps.to(dev)
+    return ops.expert_action(pose_source.contiguous(), targets.to(dev).contiguous(), r_steps, t_steps, config.is_6_DoF)
+
+
+@torch.no_grad()
+def reward(RT, data, prev_distance=None):
+    """Dense step reward (reference environment.py:263-302).  RT is accepted and ignored exactly as in the reference
+    (the transformed cloud is commented out there, :276).  Returns (reward [B,1,1], p2p_distance [B,1,1])."""
+    pc = data['pc']
+    dev = pc.device
+    cam = data['pc_in_cam_space'].to(dev).contiguous()
+    mask = data['pc_mask'].to(dev).to(torch.int64).contiguous()
+    prev = None if prev_distance is None else prev_distance.to(dev).reshape(-1).contiguous()
+    rew, dist = ops.reward(pc.contiguous(), cam, mask, prev)
+    return rew.view(-1, 1, 1), dist.view(-1, 1, 1)

@@ -447,6 +447,35 @@ def to_disentangled(pose, mean4):
     _lib.call("cmr_to_disentangled_f32", _p(pose), _p(mean4), pose.shape[0], _stream())
 
 
+def expert_action(pose_source, pose_target, r_steps, t_steps, six_dof):
+    """-> (action_r int64 [B, 1|3], action_t int64 [B, 2|3]); the step tables are float64 device tensors."""
+    B = pose_source.shape[0]
+    ar = torch.empty((B, 3 if six_dof else 1), dtype=torch.int64, device=pose_source.device)
+    at = torch.empty((B, 3 if six_dof else 2), dtype=torch.int64, device=pose_source.device)
+    _lib.call("cmr_expert_action_f32", _p(pose_source), _p(pose_target), _p(r_steps), _p(t_steps), r_steps.numel(), int(six_dof),
+              _p(ar), _p(at), B, _stream())
+    return ar, at
+
+
+def reward(pc, pc_in_cam, mask_i64, prev_distance=None):
+    """planar clouds [B,3,N], mask int64 [B,N] -> (reward [B], distance [B])."""
+    B, _, N = pc.shape
+    dist = torch.empty((B,), dtype=f32, device=pc.device)
+    rew = torch.empty((B,), dtype=f32, device=pc.device)
+    _lib.call("cmr_reward_f32", _p(pc), _p(pc_in_cam), _p(mask_i64), _p(prev_distance), _p(dist), _p(rew), B, N, _stream())
+    return rew, dist
+
+
+def discounted(vals, gamma):
+    """Reverse discounted cumulative sum along the last axis of a contiguous float32 tensor."""
+    if not vals.is_contiguous() or vals.dtype != f32:
+        raise ValueError("discounted expects a contiguous float32 tensor")
+    out = torch.empty_like(vals)
+    T = vals.shape[-1]
+    _lib.call("cmr_discounted_f32", _p(vals), _p(out), float(gamma), vals.numel() // T, T, _stream())
+    return out
+
+
 def argmax_rows(x):
     """x [outer, inner, n] (unit stride on the last dim) -> int64 [outer, inner]."""
     outer, inner, n = x.shape

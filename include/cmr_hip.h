@@ -174,6 +174,20 @@ int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float* w10, cons
                           const float* bg0, const float* wg2, const float* bg2, float* a_out, float* vp_out, int64_t rows,
                           hipStream_t stream);
 
+/* ---- rollout ops of the training loop ---------------------------------------- */
+
+/* environment.py:143-176 (expert): residual pose target * source^-1 -> extrinsic-xyz Euler angles (folded back when the
+ * x angle exceeds 3 rad) and translation -> nearest entries of the float64 step tables.  act_r int64 [B,1] / act_t [B,2]
+ * (six_dof = 0: y rotation, x / z translation) or [B,3] each. */
+int cmr_expert_action_f32(const float* pose_source, const float* pose_target, const double* r_steps, const double* t_steps,
+                          int num_steps, int six_dof, int64_t* act_r, int64_t* act_t, int B, hipStream_t stream);
+/* environment.py:263-302 (reward): distance[b] = mean over mask[b] != 0 of |pc_in_cam - (pc - centroid(pc))|^2 on planar
+ * [B,3,N] clouds; reward[b] = +0.5 / -0.5 / 0 against prev_distance[b] (0 when prev_distance is NULL). */
+int cmr_reward_f32(const float* pc, const float* pc_in_cam, const int64_t* mask, const float* prev_distance, float* distance,
+                   float* reward, int B, int N, hipStream_t stream);
+/* buffer.py:24-33 (discounted): out[r][i] = vals[r][i] + gamma * out[r][i+1] over rows of length T. */
+int cmr_discounted_f32(const float* vals, float* out, float gamma, int64_t rows, int T, hipStream_t stream);
+
 /* ---- point-cloud ops ----------------------------------------------------------------------- */
 
 /* planar [B,C,N] (the reference's point layout) -> rows [B*N, Cpad], Cpad in {4, 8}, zero padded. */

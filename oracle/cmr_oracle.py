@@ -659,6 +659,72 @@ def registration_iteration(geo_sd, agent_sd, data, cfg):
 
 
 # ----------------------------------------------------------------------------------------------
+# rollout ops of the training loop: environment/environment.py:143-176, 263-302,
+# environment/buffer.py:24-51.  `expert` goes through scipy.spatial.transform.Rotation exactly as the
+# reference does (a third-party dependency of the reference, present in this image: scipy 1.15).
+# ----------------------------------------------------------------------------------------------
+
+def env_expert(pose_source, targets, r_steps, t_steps, is_6dof=False):
+    """environment.py:143-176: nearest step-table entries to the residual rotation (extrinsic xyz Euler angles of
+    R_target R_source^T, folded back when the x angle exceeds 3 rad) and translation."""
+    from scipy.spatial.transform import Rotation
+    delta_t = targets[:, :3, 3] - pose_source[:, :3, 3]
+    delta_R = targets[:, :3, :3] @ pose_source[:, :3, :3].transpose(2, 1)
+    delta_r = Rotation.from_matrix(delta_R.cpu().numpy()).as_euler('xyz')
+    mask = delta_r[:, 0] > 3
+    delta_r[mask, 0] = 0
+    delta_r[mask, 2] = 0
+    mask_p = delta_r[:, 1] > 0
+    delta_r[mask & mask_p, 1] = math.pi - delta_r[mask & mask_p, 1]
+    mask_n = delta_r[:, 1] < 0
+    delta_r[mask & mask_n, 1] = -1 * math.pi - delta_r[mask & mask_n, 1]
+    delta_r = torch.from_numpy(delta_r)
+    action_r = torch.abs(delta_r.unsqueeze(-1) - r_steps.cpu().unsqueeze(0).unsqueeze(0)).argmin(dim=2)
+    action_t = torch.abs(delta_t.unsqueeze(-1) - t_steps.cpu().unsqueeze(0).unsqueeze(0)).argmin(dim=2)
+    if not is_6dof:
+        action_r = action_r[:, 1:2]
+        action_t = torch.cat([action_t[:, 0:1], action_t[:, 2:3]], dim=1)
+    return action_r, action_t
+
+
+def env_reward(data, prev_distance=None):
+    """environment.py:263-302: mean squared distance between the masked camera-frame points and the centred cloud
+    (the pose argument of the reference is unused there: the transformed cloud is commented out, :276), and the
+    +-0.5 step reward against the previous distance."""
+    cam, mask, pc = data['pc_in_cam_space'], data['pc_mask'].bool(), data['pc']
+    pc = pc - pc.mean(dim=2, keepdim=True)
+    dist = torch.zeros(pc.shape[0])
+    for i in range(pc.shape[0]):
+        d = cam[i][:, mask[i]] - pc[i][:, mask[i]]
+        dist[i] = (d * d).sum(dim=0).mean()
+    dist = dist.unsqueeze(-1).unsqueeze(-1)
+    if prev_distance is None:
+        return torch.zeros_like(dist), dist
+    better = (dist < prev_distance).float() * 0.5
+    worse = (dist > prev_distance).float() * 0.5
+    return better - worse, dist
+
+
+def discounted(vals, gamma=0.99):
+    """buffer.py:24-33: reverse cumulative discounted sum along the last axis."""
+    g = 0
+    out = torch.zeros_like(vals)
+    for i in range(vals.shape[-1] - 1, -1, -1):
+        g = vals[..., i] + gamma * g
+        out[..., i] = g
+    return out
+
+
+def advantage(rewards, values, gamma=0.99, gae_lambda=0.0):
+    """buffer.py:36-51: returns - values, or GAE(lambda) with a zero bootstrap value."""
+    if gae_lambda == 0:
+        return discounted(rewards, gamma) - values
+    values = torch.cat([values, torch.zeros((values.shape[0], 1, 1))], dim=2)
+    deltas = rewards + gamma * values[..., 1:] - values[..., :-1]
+    return discounted(deltas, gamma * gae_lambda)
+
+
+# ----------------------------------------------------------------------------------------------
 # pointnet_util ops (models/pointnet_util.py) + dataset-side sampler (dataset/KittiDataset.py)
 # ----------------------------------------------------------------------------------------------
 

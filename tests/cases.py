@@ -8,6 +8,8 @@ import os
 import sys
 import types
 
+import math
+
 import numpy as np
 import torch
 
@@ -170,3 +172,43 @@ def e2e_oracle(case, geo_sd, agent_sd, batch=None):
             named["step%d/%s" % (s, k)] = t[k]
     named["final_pose"] = pose
     return named
+
+
+# ----------------------------------------------------------------------------------------------
+# rollout ops of the training loop (environment.expert / reward, buffer.discounted / advantage)
+# ----------------------------------------------------------------------------------------------
+def rollout_inputs(seed=7):
+    """Deterministic inputs: B = 12 pose pairs covering small / large yaw errors (incl. |yaw| > 90 deg, where the
+    reference folds the Euler decomposition back), translations inside and outside the step table, and a masked cloud."""
+    g = torch.Generator().manual_seed(seed)
+    B, N, T = 12, 2000, 10
+    u = lambda *s, lo=-1.0, hi=1.0: torch.rand(*s, generator=g) * (hi - lo) + lo
+
+    def rot(ax, ay, az):
+        cx, sx, cy, sy, cz, sz = math.cos(ax), math.sin(ax), math.cos(ay), math.sin(ay), math.cos(az), math.sin(az)
+        rx = torch.tensor([[1, 0, 0], [0, cx, -sx], [0, sx, cx]], dtype=torch.float64)
+        ry = torch.tensor([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], dtype=torch.float64)
+        rz = torch.tensor([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]], dtype=torch.float64)
+        return rz @ ry @ rx
+
+    def pose(ax, ay, az, t):
+        p = torch.eye(4, dtype=torch.float64)
+        p[:3, :3] = rot(ax, ay, az)
+        p[:3, 3] = torch.tensor(t, dtype=torch.float64)
+        return p.float()
+
+    yaw_t = [0.3, -2.9, 1.2, 2.6, -0.05, 3.0, -1.7, 0.0, 0.9, -3.1, 2.0, 0.02]
+    src, tgt = [], []
+    for b in range(B):
+        small = 0.02 if b % 3 else 0.0                       # a little roll / pitch on some samples (6-DoF branch)
+        tgt.append(pose(small * float(u(1)), yaw_t[b], small * float(u(1)), [float(u(1, lo=-9, hi=9)), 0.0, float(u(1, lo=-9, hi=9))]))
+        src.append(pose(0.0, float(u(1, lo=-0.4, hi=0.4)), 0.0, [float(u(1, lo=-1, hi=1)), 0.0, float(u(1, lo=-1, hi=1))]))
+    pc = u(B, 3, N, lo=-20, hi=20)
+    cam = pc - pc.mean(dim=2, keepdim=True) + 0.3 * u(B, 3, N)
+    mask = (u(B, N) > 0.2).long()
+    mask[3] = 0
+    mask[3, :5] = 1                                          # nearly empty mask
+    rewards = (torch.randint(0, 3, (B, 1, T), generator=g).float() - 1) * 0.5
+    values = u(B, 1, T)
+    return dict(pose_source=torch.stack(src), pose_target=torch.stack(tgt), pc=pc, pc_in_cam_space=cam, pc_mask=mask,
+                rewards=rewards, values=values)

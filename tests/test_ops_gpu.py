@@ -456,3 +456,51 @@ def test_small_heads(ops):
     pad = torch.zeros(8, 24, device=DEV)
     pad[:, :22] = lg[:16].reshape(8, 22).to(DEV)
     assert torch.equal(ops.argmax_rows(pad[:, :22].view(8, 2, 11)).cpu(), lg[:16].argmax(1).view(8, 2))
+
+
+def test_rollout_ops_on_device():
+    """cmr_expert_action_f32 / cmr_reward_f32 / cmr_discounted_f32 through the env / buffer API against the oracle and
+    the fixture generated from the reference (actions must be identical)."""
+    import cases as C
+    import golden_util as G
+    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.environment import environment as env, buffer as buf
+    inp = {k: v.to(DEV) for k, v in C.rollout_inputs().items()}
+    named = {}
+    for six in (False, True):
+        cfg = KittiConfiguration(device=DEV)
+        cfg.is_6_DoF = six
+        ar, at = env.expert(inp["pose_source"], inp["pose_target"], cfg, None)
+        oar, oat = O.env_expert(inp["pose_source"].cpu(), inp["pose_target"].cpu(), cfg.r_steps, cfg.t_steps, six)
+        assert torch.equal(ar.cpu(), oar) and torch.equal(at.cpu(), oat)
+        tag = "6dof" if six else "3dof"
+        named["expert_r_" + tag], named["expert_t_" + tag] = ar, at
+    data = dict(pc=inp["pc"], pc_in_cam_space=inp["pc_in_cam_space"], pc_mask=inp["pc_mask"])
+    r0, d0 = env.reward(None, data)
+    shift = torch.tensor([0.5, -0.5, 0.0] * 4, device=DEV).view(-1, 1, 1)
+    _, dref = O.env_reward({k: v.cpu() for k, v in data.items()})
+    r1, _ = env.reward(None, data, prev_distance=dref.to(DEV) + shift)
+    named.update(reward_first=r0, distance=d0, reward_next=r1, returns=buf.discounted(inp["rewards"], 0.99),
+                 advantage_plain=buf.advantage(inp["rewards"], inp["values"], 0.99, 0),
+                 advantage_gae=buf.advantage(inp["rewards"], inp["values"], 0.99, 0.95))
+    G.assert_case("rollout_ops", named, atol=1e-5, rtol=1e-5, only=set(named) - {"reward_next"})
+    # the third of every triple sits exactly on the previous distance in the fixture; on the device the distance differs
+    # in the last bits, so only the +-0.5 cases are compared
+    fx = G.load_case("rollout_ops")["reward_next"]["sample"].reshape(-1)
+    got = r1.reshape(-1).cpu().numpy()
+    for i in range(12):
+        if i % 3 != 2:
+            assert got[i] == fx[i], (i, got[i], fx[i])
+    # Buffer API round trip
+    cfg = KittiConfiguration(device=DEV)
+    b = buf.Buffer(cfg)
+    b.start_trajectory()
+    for t in range(3):
+        z = torch.zeros(4, 1, 1, device=DEV)
+        b.log_step(z, z, z + t, z + 0.5, z.long(), z.long(), z.long(), z.long(), z)
+    ret, adv = b.get_returns_and_advantages()
+    assert len(b) == 1 and ret[0].shape == (4, 3, 1) and adv[0].shape == (4, 3, 1)
+    close(ret[0][:, :, 0], O.discounted(torch.full((4, 1, 3), 0.5), cfg.GAMMA)[:, 0], 1e-6, "buffer returns")
+    assert len(b.get_samples()) == 10
+    b.clear()
+    assert len(b) == 0

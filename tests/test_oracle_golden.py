@@ -46,3 +46,23 @@ def test_fixture_documents_reference_agreement():
         for k, v in d.items():
             if not k.startswith("_"):
                 assert v <= 1e-6, (case, k, v)
+
+
+def test_rollout_ops():
+    """environment.expert / reward and buffer.discounted / advantage restatements vs the fixture made from the reference."""
+    from cmr_agent_amd.config import KittiConfiguration
+    from oracle import cmr_oracle as O
+    inp = C.rollout_inputs()
+    named = {}
+    for six in (False, True):
+        cfg = KittiConfiguration(device="cpu")
+        ar, at = O.env_expert(inp["pose_source"], inp["pose_target"], cfg.r_steps, cfg.t_steps, six)
+        tag = "6dof" if six else "3dof"
+        named["expert_r_" + tag], named["expert_t_" + tag] = ar, at
+    data = dict(pc=inp["pc"], pc_in_cam_space=inp["pc_in_cam_space"], pc_mask=inp["pc_mask"])
+    r0, d0 = O.env_reward(data)
+    r1, _ = O.env_reward(data, prev_distance=d0 + torch.tensor([0.5, -0.5, 0.0] * 4).view(-1, 1, 1))
+    named.update(reward_first=r0, distance=d0, reward_next=r1, returns=O.discounted(inp["rewards"], 0.99),
+                 advantage_plain=O.advantage(inp["rewards"], inp["values"], 0.99, 0),
+                 advantage_gae=O.advantage(inp["rewards"], inp["values"], 0.99, 0.95))
+    G.assert_case("rollout_ops", named, atol=1e-6, rtol=1e-6)
