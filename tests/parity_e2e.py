@@ -2,9 +2,11 @@
 one registration iteration (Test_Agent.py:150-170 loop body) through the HIP product vs the CPU
 oracle and vs the committed golden fixture generated from the reference.
 
-Stated tolerances (fp32 GPU vs fp32 CPU): unit-norm geometric features and
-probabilities atol 2e-3; other features / logits atol 2e-3 * max|ref|; discrete outputs (node2proxy,
-overlap mask, actions) must agree except where the reference itself is within rounding of a tie."""
+Stated tolerances (fp32 GPU vs fp32 CPU; SURVEY.md 8c allows 2e-3, the path is held to 20x tighter): unit-norm
+geometric features and probabilities atol 1e-4; other features / logits atol 1e-4 * max|ref|; discrete outputs
+(node2proxy, overlap mask, actions) must agree except where the reference itself is within rounding of a tie.
+Observed at the reference-native size: 2e-6 on unit-norm features, 2e-6 * max|ref| on logits, every discrete
+output equal."""
 import json
 import os
 
@@ -56,7 +58,7 @@ UNIT = ("pc_geo_feat", "img_geo_feat", "pc_is_in_cam_scores", "img_overlap_pred"
 DISCRETE = ("node2proxy", "pc_overlap_pred")
 
 
-def compare(named, ref, verbose=False, atol=2e-3):
+def compare(named, ref, verbose=False, atol=1e-4):
     """named / ref: dict name -> cpu tensor.  Returns list of error strings."""
     errs = []
     for k, r in ref.items():
@@ -113,7 +115,7 @@ def run_case(case, check_golden=True, verbose=False):
                 continue
             else:
                 scale = 1.0 if k in UNIT else max(float(abs(fx[k]["sample"]).max()), 1.0)
-                e = G.compare(k, t, fx[k], 2e-3 * scale, 0)
+                e = G.compare(k, t, fx[k], 1e-4 * scale, 0)
             if e:
                 gerrs.append(e)
         assert not gerrs, "HIP path vs golden fixture:\n  " + "\n  ".join(gerrs)
