@@ -162,11 +162,8 @@ extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t 
   CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(o));
   const size_t smem = (size_t)Tk * DH * 2 * sizeof(float);
   CMR_REQUIRE(smem <= 160 * 1024);
-  if (smem > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mha_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
-      return CMR_ELAUNCH;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   dim3 grid((Tq + 63) / 64, NH, B);
   hipLaunchKernelGGL(mha_kernel, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
                      0.35355339059327373f);

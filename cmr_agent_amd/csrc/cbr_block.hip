@@ -267,13 +267,8 @@ int launch_cbr(const CbrArgs& a, hipStream_t stream) {
   constexpr size_t smem = (size_t)(32 * T1 * (KX + 4) + CO * (CH + 4) + (CONV_SC ? CO * (KX + 4) : 0) + CBR_MAXB * (32 * T1 + CO)) *
                           sizeof(float);      // weights + staged bias rows
   static_assert(smem <= 160 * 1024, "weights must fit in LDS");
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(cbr_block_kernel<KX, CH, CO, CONV_SC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = true;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(cbr_block_kernel<KX, CH, CO, CONV_SC>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   const int64_t ntiles = (a.rows + 31) / 32;
   const int per_cu = smem > 80 * 1024 ? 1 : 2;
   int64_t grid = (ntiles + 7) / 8;

@@ -18,6 +18,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cmr_launch_status() { return hipGetLastError() == hipSuccess ? CMR_OK : CMR_ELAUNCH; }
 
+// Raises a kernel's dynamic-LDS limit (needed above 64 KB), once per (kernel, device): `cache` is a per-kernel array of
+// the sizes already granted, indexed by device, so a process that drives several GPUs sets it on each of them.
+constexpr int CMR_MAX_DEVICES = 16;
+struct CmrSmemCache { size_t granted[CMR_MAX_DEVICES]; };
+static inline int cmr_grant_smem(const void* kernel, size_t bytes, CmrSmemCache& cache) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return CMR_ELAUNCH;
+  dev = dev < 0 || dev >= CMR_MAX_DEVICES ? 0 : dev;
+  if (bytes <= 64 * 1024 || bytes <= cache.granted[dev]) return CMR_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return CMR_ELAUNCH;
+  cache.granted[dev] = bytes;
+  return CMR_OK;
+}
+
 static inline bool cmr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // activation codes shared by the GEMM / conv epilogues

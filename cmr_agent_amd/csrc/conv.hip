@@ -242,13 +242,8 @@ template <int S, int MT, int KC>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
   constexpr int TH = 4 * MT, HR = (TH - 1) * S + 3, HC = 31 * S + 3, LDP = KC + 4;
   constexpr size_t smem = (size_t)(HR * HC * LDP + 2 * 64 * LDP) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_kernel<S, MT, KC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = true;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_kernel<S, MT, KC>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   const int tiles_x = (a.Wo + 31) / 32, tiles_y = (a.Ho + TH - 1) / TH;
   const int64_t ntiles = (int64_t)tiles_x * tiles_y * a.B * (a.Cout / 64);
   if (ntiles > 0x7fffffff) return CMR_EINVAL;

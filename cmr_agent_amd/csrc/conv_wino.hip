@@ -350,13 +350,8 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(cons
 template <int NT>
 int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
   constexpr int smem = wt_smem_floats<NT>() * (int)sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wino_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            smem) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = true;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_kernel<NT>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   hipLaunchKernelGGL(conv3x3_wino_kernel<NT>, dim3((unsigned)ntiles), dim3(256), smem, stream, a, tiles_x, tiles_y);
   return cmr_launch_status();
 }

@@ -357,13 +357,8 @@ extern "C" int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* 
   const size_t smem = (size_t)(2 * LA_D * LA_LD64 + LA_HID * LA_LD128 + LA_D * LA_LD128 + 4 * LA_D + (size_t)B * LA_STATE) *
                       sizeof(float);
   if (smem > 160 * 1024) return CMR_EUNSUPPORTED;          // the per-batch states no longer fit beside the weights
-  static size_t attr_set = 0;
-  if (smem > attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(la_query_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = smem;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(la_query_layer_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   const uint32_t rows = (uint32_t)((int64_t)B * L);
   const uint32_t ntiles = (rows + 31) / 32;
   uint32_t grid = (ntiles + 7) / 8;

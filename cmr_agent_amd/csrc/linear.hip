@@ -462,13 +462,8 @@ __global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) 
 template <int NT, int G, int NSEG, int AC>
 int launch_linear_ws_ga(LinearArgs a, hipStream_t stream) {
   const size_t smem = (size_t)32 * NT * (NSEG * 8 * G + 4 + 1) * sizeof(float);      // weights + bias
-  static bool attr_set = false;
-  if (smem > 64 * 1024 && !attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_ws_kernel<NT, G, NSEG, AC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = true;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(linear_ws_kernel<NT, G, NSEG, AC>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
   const int64_t ntiles = (a.rows + 31) / 32;
   int64_t gx = (ntiles + 3) / 4;

@@ -565,10 +565,8 @@ extern "C" int cmr_knn16_f32(const float* xyz4, int32_t* out, int B, int M, hipS
   CMR_REQUIRE(xyz4 && out && B > 0 && B <= 65535 && M >= 16 && cmr_aligned16(xyz4));
   const size_t smem = (size_t)M * 4 * sizeof(float);
   CMR_REQUIRE(smem <= 160 * 1024);
-  if (smem > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(knn_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)smem) != hipSuccess)
-    return CMR_ELAUNCH;
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(knn_kernel<16>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   constexpr int QPW = 256 / KNN_SPLIT;          // queries per workgroup
   hipLaunchKernelGGL(knn_kernel<16>, dim3((M + QPW - 1) / QPW, B), dim3(256), smem, stream, xyz4, out, M);
   return cmr_launch_status();

@@ -148,13 +148,8 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
 template <bool COMPUTE_KV>
 int launch_va(const VaArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)(64 * VA_LD8 + 3 * 64 * VA_LD + 5 * 64 + (COMPUTE_KV ? 192 * VA_LD : 0)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && smem > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(vecattn_front_kernel<COMPUTE_KV>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return CMR_ELAUNCH;
-    attr_set = true;
-  }
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(vecattn_front_kernel<COMPUTE_KV>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   const uint32_t ntiles = (a.rows + 31) / 32;
   uint32_t grid = (ntiles + 7) / 8;
   const uint32_t cap = COMPUTE_KV ? 256 : 512;          // persistent: 1 (109 KB) or 2 (57 KB) workgroups per CU
