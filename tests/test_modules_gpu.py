@@ -69,6 +69,21 @@ def test_op_level_composition_vs_golden(name, monkeypatch):
     test_module_vs_golden(name)
 
 
+def test_linear_attention_many_batch_elements_falls_back():
+    """More batch elements than per-batch states fit in LDS beside the weights (B > 11): the layer-level kernel declines
+    (CMR_EUNSUPPORTED) and the module composes the op-level kernels; same numbers either way."""
+    from oracle import cmr_oracle as O
+    m = _module("linear_attention")
+    sd = {k: v.double().cpu() for k, v in m.state_dict().items()}
+    B, L, S = 13, 96, 40
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.rand(B, L, 64, generator=g) - 0.5, torch.rand(B, S, 64, generator=g) - 0.5
+    ref = O.linear_attention(O.Weights(sd), x.double(), y.double())
+    with torch.no_grad():
+        got = m(x.to(DEV), y.to(DEV))
+    assert float((got.cpu().double() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_pointnet_util_ops_vs_golden():
     from cmr_agent_amd.models import pointnet_util as U
     i = {k: v.to(DEV) for k, v in C.OP_CASES["pointnet_util"]["inputs"]().items()}
