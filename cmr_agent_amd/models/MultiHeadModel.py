@@ -123,11 +123,34 @@ class MultiHeadModel(Planned):
         cl["img_prob"], _, _ = ops.softmax2(cl["img_overlap_logits"], 0.5, 0.8)
         return cl
 
+    LABEL_KEYS = ("pc_mask", "img_mask", "pc_idx_for_circle_loss", "pc_xy_int_for_circle_loss", "pc_xy_float_for_circle_loss")
+
+    def _losses(self, data_batch, cl):
+        """The loss values and overlap metrics the reference's heads compute in every forward (MultiHeadModel.py:68-108,
+        240-268), when the batch carries the dataset's labels; forward values only (this build does not train)."""
+        B, N, h, w = cl["B"], cl["geo"].N, cl["h"], cl["w"]
+        dev = cl["pc_overlap_logits"].device
+        lab = lambda k: data_batch[k].to(dev).contiguous()
+        pc = ops.focal_metrics(cl["pc_overlap_logits"], lab("pc_mask").view(-1), 0.75, B)
+        im = ops.focal_metrics(cl["img_overlap_logits"], lab("img_mask").view(-1), 0.5, B)
+        gh = self.geo_head
+        geo = ops.circle_loss(cl["pc_geo_feat"], cl["img_geo_feat"], lab("pc_idx_for_circle_loss"),
+                              lab("pc_xy_int_for_circle_loss"), lab("pc_xy_float_for_circle_loss").float(), B, N, gh.dist_thres,
+                              gh.pos_margin, gh.neg_margin, 10, gh.lambda_geo)
+        out = {"pc_overlap_loss": pc[0], "img_overlap_loss": im[0], "geometric_loss": geo[0]}
+        for tag, v in (("pc", pc), ("img", im)):
+            out[tag + "_overlap_precision"], out[tag + "_overlap_recall"], out[tag + "_overlap_accuracy"] = v[1], v[2], v[3]
+        out["loss"] = (pc[0] + im[0]) + geo[0]                 # data['loss'] = 0. += overlap losses += geometric loss (:101-102, 269)
+        return out
+
     def forward(self, data_batch):
         cl = self.forward_cl(data_batch)
         B, N, h, w = cl["B"], cl["geo"].N, cl["h"], cl["w"]
         IMGPCEnDecoder.publish(data_batch, cl)
-        data_batch['loss'] = 0.
+        if all(k in data_batch for k in self.LABEL_KEYS):
+            data_batch.update(self._losses(data_batch, cl))
+        else:
+            data_batch['loss'] = 0.                              # label-free batch: nothing to score
         data_batch['pc_overlap_logits'] = bcl_from_rows(cl["pc_overlap_logits"], B)
         data_batch['img_overlap_logits'] = bcl_from_rows(cl["img_overlap_logits"], B)
         data_batch['pc_geo_feat'] = bcl_from_rows(cl["pc_geo_feat"], B)

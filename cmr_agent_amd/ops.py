@@ -447,6 +447,31 @@ def to_disentangled(pose, mean4):
     _lib.call("cmr_to_disentangled_f32", _p(pose), _p(mean4), pose.shape[0], _stream())
 
 
+def focal_metrics(logits_rows, label_i64, alpha, B):
+    """2-class logits rows [R, >=2] + int64 labels [R] -> float32 [4] = (focal loss, precision, recall, accuracy)."""
+    R = logits_rows.shape[0]
+    ws_bytes = _lib.load().cmr_focal_metrics_workspace_bytes(R)
+    ws = torch.empty((max(ws_bytes // 4, 1),), dtype=f32, device=logits_rows.device)
+    out = torch.empty((4,), dtype=f32, device=logits_rows.device)
+    _lib.call("cmr_focal_metrics_f32", _p(logits_rows), logits_rows.stride(0), _p(label_i64), float(alpha), R, B, _p(out), _p(ws),
+              ws_bytes, _stream())
+    return out
+
+
+def circle_loss(pc_feat_rows, img_feat_nhwc, pc_idx, xy_int, xy_float, B, N, dist_thres, pos_margin, neg_margin, log_scale, lam):
+    """Circle loss over the sampled (point, pixel) pairs: pc_feat rows [B*N,64], img_feat [B,h,w,64], pc_idx int64 [B,n],
+    xy_int int64 [B,2,n], xy_float [B,2,n] -> float32 [1]."""
+    _, h, w, _ = img_feat_nhwc.shape
+    n = pc_idx.shape[1]
+    ws_bytes = _lib.load().cmr_circle_loss_workspace_bytes(B, n)
+    ws = torch.empty((ws_bytes // 4,), dtype=f32, device=pc_feat_rows.device)
+    out = torch.empty((1,), dtype=f32, device=pc_feat_rows.device)
+    _lib.call("cmr_circle_loss_f32", _p(_rows(pc_feat_rows)), _p(img_feat_nhwc), _p(pc_idx), _p(xy_int), _p(xy_float), B, N, h, w, n,
+              float(dist_thres), float(pos_margin), float(neg_margin), float(log_scale), float(lam), _p(out), _p(ws), ws_bytes,
+              _stream())
+    return out
+
+
 def expert_action(pose_source, pose_target, r_steps, t_steps, six_dof):
     """-> (action_r int64 [B, 1|3], action_t int64 [B, 2|3]); the step tables are float64 device tensors."""
     B = pose_source.shape[0]

@@ -174,6 +174,22 @@ int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float* w10, cons
                           const float* bg0, const float* wg2, const float* bg2, float* a_out, float* vp_out, int64_t rows,
                           hipStream_t stream);
 
+/* ---- loss / metric values of the heads (forward only) ---------------------------------------- */
+
+/* MultiHeadModel.py:68-97 on 2-class logits rows [rows][ld >= 2] with int64 labels: out4 = {focal loss (focal_loss.py:55-110,
+ * gamma 2, mean), precision, recall, accuracy}; rows = B * n (accuracy is (correct / B) / n as in the reference). */
+int64_t cmr_focal_metrics_workspace_bytes(int64_t rows);
+int cmr_focal_metrics_f32(const float* logits, int64_t ld, const int64_t* label, float alpha, int64_t rows, int B, float* out4,
+                          void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* MultiHeadModel.py:141-178, 240-268: circle loss over the n sampled (point, pixel) pairs of every sample.  pc_feat rows
+ * [B*N][64], img_feat NHWC [B][h][w][64], pc_idx int64 [B][n], xy_int int64 [B][2][n] (x, y), xy_float [B][2][n];
+ * out[0] = lambda * mean. */
+int64_t cmr_circle_loss_workspace_bytes(int B, int n);
+int cmr_circle_loss_f32(const float* pc_feat, const float* img_feat, const int64_t* pc_idx, const int64_t* xy_int,
+                        const float* xy_float, int B, int N, int h, int w, int n, float dist_thres, float pos_margin,
+                        float neg_margin, float log_scale, float lambda, float* out, void* workspace, int64_t workspace_bytes,
+                        hipStream_t stream);
+
 /* ---- rollout ops of the training loop ---------------------------------------- */
 
 /* environment.py:143-176 (expert): residual pose target * source^-1 -> extrinsic-xyz Euler angles (folded back when the

@@ -426,8 +426,9 @@ def _head2(fn, w, x, slope=0.2):
     return fn(F.leaky_relu(fn(x, w.sub("0")), slope), w.sub("2"))
 
 
-def focal_loss(logits, target, alpha, gamma=2.0, eps=1e-8):
-    """focal_loss.py:55-110 with reduction='mean' (one-hot is +1e-6 everywhere, :52)."""
+def focal_loss(logits, target, alpha, gamma=2.0, eps=1e-6):
+    """models/focal_loss.py:55-110 with reduction='mean' (one-hot is +1e-6 everywhere, :52); the FocalLoss module
+    passes its own eps = 1e-6 for the softmax offset (:160, 166), not the function default 1e-8."""
     soft = F.softmax(logits, dim=1) + eps
     one_hot = torch.zeros_like(logits).scatter_(1, target.unsqueeze(1), 1.0) + 1e-6
     focal = -alpha * torch.pow(-soft + 1.0, gamma) * torch.log(soft)
@@ -489,6 +490,13 @@ def multi_head_model(sd, data, cfg, with_loss=False):
         dmap = torch.sqrt(torch.sum(torch.square(xy_f.unsqueeze(-1) - xy_i.unsqueeze(-2)), dim=1))
         geo = circle_loss(pix, pts, dmap)
         out.update(pc_overlap_loss=pcl, img_overlap_loss=iml, geometric_loss=geo, loss=pcl + iml + geo)
+        # MultiHeadModel.py:84-95: precision / recall / accuracy of the arg-max predictions
+        for tag, logits, lab in (("pc", pc_logits, data["pc_mask"]), ("img", img_logits, data["img_mask"].view(b, -1))):
+            pred = logits.argmax(1)
+            n = pred.shape[1]
+            out[tag + "_overlap_precision"] = (lab[pred == 1]).sum() / pred.sum()
+            out[tag + "_overlap_recall"] = (pred[lab == 1]).sum() / lab.sum()
+            out[tag + "_overlap_accuracy"] = (pred == lab).sum() / b / n
     prob = torch.softmax(pc_logits, dim=1)[:, 1, :]
     out["pc_overlap_pred"] = prob > 0.5
     out["pc_overlap_pred_standby"] = prob > 0.8
@@ -640,10 +648,10 @@ def env_step(action_r, action_t, pose, r_steps, t_steps, is_6dof=False):
     return pose
 
 
-def registration_iteration(geo_sd, agent_sd, data, cfg):
+def registration_iteration(geo_sd, agent_sd, data, cfg, with_loss=False):
     """Loop body of Test_Agent.py:150-170 (geo forward + action_num agent steps).
     Returns (final pose, per-step logits/actions, geo outputs)."""
-    out = multi_head_model(geo_sd, data, cfg)
+    out = multi_head_model(geo_sd, data, cfg, with_loss=with_loss)
     d = dict(data)
     d.update(out)
     pose, target = env_init(d)

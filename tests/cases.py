@@ -162,11 +162,18 @@ GEO_KEYS = ("img_feat_2", "node2proxy", "pt_feat", "node_feat", "img_proxy", "pt
             "img_geo_feat", "pc_overlap_pred", "pc_is_in_cam_scores", "img_overlap_pred")
 
 
+LOSS_KEYS = ("loss", "pc_overlap_loss", "img_overlap_loss", "geometric_loss")
+METRIC_KEYS = ("pc_overlap_precision", "pc_overlap_recall", "pc_overlap_accuracy", "img_overlap_precision",
+               "img_overlap_recall", "img_overlap_accuracy")
+
+
 def e2e_oracle(case, geo_sd, agent_sd, batch=None):
     cfg = e2e_config(case)
     batch = e2e_batch(case) if batch is None else batch
-    pose, trace, out = O.registration_iteration(geo_sd, agent_sd, batch, cfg)
+    pose, trace, out = O.registration_iteration(geo_sd, agent_sd, batch, cfg, with_loss=True)
     named = {k: out[k] for k in GEO_KEYS}
+    for k in LOSS_KEYS + METRIC_KEYS:
+        named[k] = torch.as_tensor(out[k]).reshape(1).float()
     for s, t in enumerate(trace):
         for k in ("r_logits", "t_logits", "value", "action_r", "action_t", "pose"):
             named["step%d/%s" % (s, k)] = t[k]

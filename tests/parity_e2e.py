@@ -36,6 +36,8 @@ def run_product(case, geo, agent, batch, cfg, device="cuda"):
     with torch.no_grad():
         geo(data)
         named = {k: data[k] for k in C.GEO_KEYS}
+        for k in C.LOSS_KEYS + C.METRIC_KEYS:               # loss values / overlap metrics the heads add to the batch dict
+            named[k] = torch.as_tensor(data[k]).reshape(1).float()
         pose, target = env.init(data)
         target = env.to_disentangled(target, data['pc'])
         for s in range(cfg.action_num):
@@ -116,6 +118,11 @@ def run_case(case, check_golden=True, verbose=False):
             else:
                 scale = 1.0 if k in UNIT else max(float(abs(fx[k]["sample"]).max()), 1.0)
                 e = G.compare(k, t, fx[k], 1e-4 * scale, 0)
+            if e:
+                gerrs.append(e)
+        fm = G.load_case(case + "_metrics")                  # losses + precision / recall / accuracy from the reference's heads
+        for k in C.LOSS_KEYS + C.METRIC_KEYS:
+            e = G.compare(k, got[k], fm[k], 1e-4 * max(float(abs(fm[k]["sample"]).max()), 1.0), 0)
             if e:
                 gerrs.append(e)
         assert not gerrs, "HIP path vs golden fixture:\n  " + "\n  ".join(gerrs)

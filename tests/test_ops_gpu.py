@@ -504,3 +504,37 @@ def test_rollout_ops_on_device():
     assert len(b.get_samples()) == 10
     b.clear()
     assert len(b) == 0
+
+
+def test_head_losses_and_metrics(ops):
+    """cmr_focal_metrics_f32 / cmr_circle_loss_f32 against the oracle's restatement of the reference's heads."""
+    B, n_pts = 3, 5000
+    logits = rnd(B, 2, n_pts, seed=91, lo=-3, hi=3)
+    label = (rnd(B, n_pts, seed=92) > 0.3).long()
+    rows = torch.zeros(B * n_pts, 4)
+    rows[:, :2] = logits.permute(0, 2, 1).reshape(-1, 2)
+    got = ops.focal_metrics(rows.to(DEV)[:, :2], label.view(-1).to(DEV), 0.75, B).cpu()
+    pred = logits.argmax(1)
+    ref = torch.stack([O.focal_loss(logits, label, 0.75), (label[pred == 1]).sum() / pred.sum(), (pred[label == 1]).sum() / label.sum(),
+                       (pred == label).sum() / B / n_pts])
+    close(got, ref, 1e-5, "focal+metrics")
+    # nothing predicted positive: precision is 0 / 0 = NaN in the reference as well
+    neg = rows.clone(); neg[:, 0] = 5.0; neg[:, 1] = -5.0
+    g2 = ops.focal_metrics(neg.to(DEV)[:, :2], label.view(-1).to(DEV), 0.5, B).cpu()
+    assert torch.isnan(g2[1]) and float(g2[2]) == 0.0
+    # circle loss on n = 512 sampled pairs (the reference's size) and a ragged n
+    for n in (512, 37):
+        N, h, w = 3000, 24, 40
+        pc_feat = F.normalize(rnd(B, 64, N, seed=93), dim=1)
+        img_feat = F.normalize(rnd(B, 64, h, w, seed=94), dim=1)
+        g = torch.Generator().manual_seed(n)
+        pc_idx = torch.randint(0, N, (B, n), generator=g)
+        xy_int = torch.stack([torch.randint(0, w, (B, n), generator=g), torch.randint(0, h, (B, n), generator=g)], 1)
+        xy_float = xy_int.float() + (torch.rand(B, 2, n, generator=g) - 0.5) * 3
+        pix = torch.stack([img_feat[i][:, xy_int[i][1], xy_int[i][0]] for i in range(B)], 0)
+        pts = torch.stack([pc_feat[i][:, pc_idx[i]] for i in range(B)], 0)
+        dmap = torch.sqrt(torch.sum(torch.square(xy_float.unsqueeze(-1) - xy_int.unsqueeze(-2)), dim=1))
+        ref = O.circle_loss(pix, pts, dmap)
+        got = ops.circle_loss(pc_feat.permute(0, 2, 1).reshape(-1, 64).contiguous().to(DEV), img_feat.permute(0, 2, 3, 1).contiguous().to(DEV),
+                              pc_idx.to(DEV), xy_int.to(DEV), xy_float.to(DEV), B, N, 1, 0.1, 1.4, 10, 1).cpu()
+        close(got, ref.reshape(1), 2e-5, "circle loss n=%d" % n)

@@ -37,7 +37,10 @@ def test_dataset_ops():
 def test_e2e_case(case):
     geo_sd, agent_sd = C.e2e_state_dicts(SPECS)
     named = C.e2e_oracle(case, geo_sd, agent_sd)
+    metrics = {k: named.pop(k) for k in C.METRIC_KEYS}            # live in <case>_metrics.npz (with the losses again)
     G.assert_case(case, named, atol=1e-5, rtol=1e-5)
+    metrics.update({k: named[k] for k in C.LOSS_KEYS})
+    G.assert_case(case + "_metrics", metrics, atol=1e-6, rtol=1e-6)
 
 
 def test_fixture_documents_reference_agreement():
