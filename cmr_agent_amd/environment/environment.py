@@ -41,6 +41,7 @@ class _ObsContext:
         self.acc = torch.zeros((cells, 64), dtype=torch.float32, device=dev)
         self.cnt = torch.zeros((cells,), dtype=torch.float32, device=dev)
         self.first = True
+        self.dirty = False        # True between a scatter and its finalize: an interrupted call must not leak accumulators
 
 
 def _context(data):
@@ -70,9 +71,11 @@ def observation_from_a_pose(data, RT):
     state3d = torch.empty((B * N, 8), dtype=torch.float32, device=dev)
     state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev)
     proj = torch.empty((B, h, w, 64), dtype=torch.float32, device=dev)
+    zero_first, ctx.dirty = ctx.dirty, True
     ops.project_scatter(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.acc, ctx.cnt,
-                        state3d, zero_first=False)
+                        state3d, zero_first=zero_first)
     ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, proj, B, h, w, True, clear=True)
+    ctx.dirty = False
     obs2d = state2d.permute(0, 3, 1, 2)
     # the agent's first conv is linear in its input: hand it the two halves separately so that the image half
     # (constant over the steps of one registration) is convolved once (CMRAgent.forward_cl)
