@@ -22,6 +22,7 @@ from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # no
 from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
+from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
 
 
 def get_P_diff(P_pred, P_gt):
@@ -44,10 +45,8 @@ def main():
     config = Cfg(num_pt=args.num_pt, device=dev)
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
     geo_model, agent = MultiHeadModel(config), CMRAgent(config)
-    geo_model.load_state_dict(torch.load(args.geo_ckpt) if args.geo_ckpt else hashfill.make_state_dict(spec["geo"], "geo4/"),
-                              strict=False)
-    agent.load_state_dict(torch.load(args.agent_ckpt) if args.agent_ckpt else hashfill.make_state_dict(spec["agent"], "agent/"),
-                          strict=False)
+    load_checked(geo_model, torch.load(args.geo_ckpt) if args.geo_ckpt else hashfill.make_state_dict(spec["geo"], "geo4/"))
+    load_checked(agent, torch.load(args.agent_ckpt) if args.agent_ckpt else hashfill.make_state_dict(spec["agent"], "agent/"))
     geo_model, agent = geo_model.to(dev).eval(), agent.to(dev).eval()
 
     rte, rre = [], []

@@ -31,6 +31,7 @@ from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
 from cmr_agent_amd.runtime import RegistrationGraph  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
+from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
 from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
 
 WORKLOAD = dict(B=8, N=16384, H=352, W=1216, M=1280, steps=10)
@@ -60,8 +61,8 @@ def hip_nearest(dev):
 def load_models(cfg, dev):
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
     geo, agent = MultiHeadModel(cfg), CMRAgent(cfg)
-    geo.load_state_dict(hashfill.make_state_dict(spec["geo"], GEO_TAG), strict=False)
-    agent.load_state_dict(hashfill.make_state_dict(spec["agent"], AGENT_TAG), strict=False)
+    load_checked(geo, hashfill.make_state_dict(spec["geo"], GEO_TAG))
+    load_checked(agent, hashfill.make_state_dict(spec["agent"], AGENT_TAG))
     return geo.to(dev).eval(), agent.to(dev).eval(), spec
 
 

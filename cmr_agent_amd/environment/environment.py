@@ -41,6 +41,7 @@ class _ObsContext:
         self.acc = torch.zeros((cells, 64), dtype=torch.float32, device=dev)
         self.cnt = torch.zeros((cells,), dtype=torch.float32, device=dev)
         self.first = True
+        self.agent_cache = {}     # CMRAgent keeps the image half of its first conv here (constant over the steps of THIS registration)
         self.dirty = False        # True between a scatter and its finalize: an interrupted call must not leak accumulators
 
 
@@ -79,7 +80,7 @@ def observation_from_a_pose(data, RT):
     obs2d = state2d.permute(0, 3, 1, 2)
     # the agent's first conv is linear in its input: hand it the two halves separately so that the image half
     # (constant over the steps of one registration) is convolved once (CMRAgent.forward_cl)
-    obs2d._cmr_split = (ctx.img, proj)
+    obs2d._cmr_split = (ctx.img, proj, ctx.agent_cache)
     obs3d = state3d.view(B, N, 8)[:, :, :5].permute(0, 2, 1)
     return obs2d, obs3d
 

@@ -58,7 +58,6 @@ class CMRAgent(Planned):
         f = self.config.embed_dim
         p["conv0_img"] = _pack.conv9(e[0], e[1], cin_slice=slice(0, f))
         p["conv0_proj"] = _pack.conv9(e[0], e[1], cin_slice=slice(f, 2 * f))
-        p["img_cache"] = {}
         p["c24"], p["c26"] = _pack.lin(e[24]), _pack.lin(e[26])
         for name in ("policy_r", "policy_t", "value"):
             m = getattr(self, name)
@@ -110,13 +109,16 @@ class CMRAgent(Planned):
         x = state2d
         for stage, ((wa, ba, ua), (wb, bb, ub)) in enumerate(p["convs"]):
             if stage == 0 and split is not None:
-                img_src, proj = split
-                key = (img_src.data_ptr(), img_src._version, tuple(img_src.shape))
-                cache = p["img_cache"]
-                if cache.get("key") != key:          # first step of a registration: image half of conv 0 (+ bias)
-                    cache["key"] = key
+                # split = (image half, projected half, per-registration cache): the cache dict belongs to the
+                # observation context of ONE registration (environment._ObsContext), so the image half of conv 0
+                # (+ bias) is computed on the first step of that registration and can never be confused with
+                # another batch whose buffer happens to land at the same address
+                img_src, proj, cache = split
+                tag = (id(self), id(p))
+                if cache.get("tag") != tag:
                     wi, bi, ui = p["conv0_img"]
                     cache["val"] = ops.conv3x3(img_src, wi, bi, c, 1, 1.0, u=ui)
+                    cache["tag"] = tag
                 wp, _, up = p["conv0_proj"]
                 x = ops.conv3x3(proj, wp, None, c, 1, SLOPE, res=cache["val"], u=up)
             else:
@@ -142,8 +144,8 @@ class CMRAgent(Planned):
     # ------------------------------------------------------------------------------------------
     def forward_cl(self, state2d, state3d_rows, B, N, split=None):
         """state2d NHWC [B,h,w,128]; state3d rows [B*N,8] = (x,y,z,overlap,in_cam,0,0,0).
-        split = (img_geo_feat NHWC [B,h,w,64], projected half NHWC [B,h,w,64]) when the observation comes from
-        cmr_agent_amd.environment: the two halves of state2d as separate tensors."""
+        split = (img_geo_feat NHWC [B,h,w,64], projected half NHWC [B,h,w,64], cache dict of this registration) when
+        the observation comes from cmr_agent_amd.environment: the two halves of state2d as separate tensors."""
         self._require_eval()
         # the 3-D branch (4 fused blocks on B*N points) runs on a side stream underneath the 2-D convolutions
         e3d, e2d = fork_join(lambda: self._embed_3d_any(state3d_rows, B, N), lambda: self._embed_2d(state2d, B, split), tag="agent")

@@ -102,6 +102,8 @@ WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct k
 def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     """Stride-1 3x3 convolution through the fused Winograd F(2x2,3x3) kernel; u [16,Cout,Cin] = G g G^T."""
     B, H, W, cin = x.shape
+    if pool == 2 and (res is not None or post is not None):
+        raise ValueError("conv3x3: pool=2 cannot be combined with res / post")
     if not x.is_contiguous() or tuple(u.shape) != (16, cout, cin):
         raise ValueError("conv3x3_wino: bad operand layout")
     hp, wp = (H // 2, W // 2) if pool == 2 else (H, W)
@@ -123,6 +125,9 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
             and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= WINO_MIN_TILES):
         return conv3x3_wino(x, u, bias, cout, slope, res, post, pool)
     if pool == 2:
+        if res is not None or post is not None or out is not None:
+            raise ValueError("conv3x3: pool=2 cannot be combined with res / post / out (the fused-pool epilogue has none; "
+                             "the Winograd entry point rejects the same combination)")
         y = torch.empty((B, ho // 2, wo // 2, cout), dtype=f32, device=x.device)
         rc = _lib.call("cmr_conv3x3_nhwc_f32", _p(x), B, H, W, cin, _p(w9), _p(bias), None, None, _p(y), cout, stride,
                        float(slope), 2, _stream(), allow_unsupported=True)

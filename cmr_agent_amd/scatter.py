@@ -3,7 +3,9 @@
 [B, N] map expanded over the channels.  The hot path itself does not go through these (it keeps the CSR
 and fuses the group softmax); they exist so that code written against torch_scatter's op API keeps
 working.  Semantics as documented by torch_scatter: sum; max (empty groups -> 0, argmax not returned);
-mean = sum / max(count, 1); output length = dim_size or index.max() + 1."""
+mean = sum / max(count, 1); output length = dim_size or index.max() + 1.  Cost: the CSR build counts with
+one pass per segment block (O(segments x N / 64 lanes) per batch), fine for the M <= 1280 groups of the towers,
+slow for the environment-style M = h*w + 1; that caller has its own kernel (cmr_project_scatter_f32)."""
 import torch
 
 from . import ops
@@ -18,7 +20,12 @@ def _reduce(src, index, dim, dim_size, mode):
     idx = idx.contiguous()
     if idx.dtype != torch.int64:
         idx = idx.long()
-    M = int(idx.max()) + 1 if dim_size is None else int(dim_size)
+    lo, hi = int(idx.min()), int(idx.max())          # host sync: this API is off the hot path (module docstring)
+    M = hi + 1 if dim_size is None else int(dim_size)
+    if lo < 0 or hi >= M:
+        # torch_scatter raises here too; without the check index_to_global would map the id into the next batch's
+        # segments (or past the end of the CSR for the last batch)
+        raise IndexError("scatter index out of range: [%d, %d] for dim_size %d" % (lo, hi, M))
     g = ops.index_to_global(idx, M)
     offsets, order = ops.csr_build(g, B, N, M)
     out = ops.segment_reduce(rows_from_bcl(src), order, offsets, B * M, mode)

@@ -20,8 +20,14 @@ _pool = {}
 _depth = 0
 
 
-def _side_stream(device, depth):
-    key = (device, depth)
+def _side_stream(device, depth, i):
+    """One stream per (nesting depth, branch index).  Round 1 keyed the pool by the branch index alone, so a fork issued
+    from inside branch 0 of another fork was handed the very stream it was already running on as its "side" stream:
+    `side.wait_stream(main)` then recorded an event on that stream and made the same stream wait for it, and both
+    branches ran on one stream.  Under hipGraph capture that self-dependency is what failed (it had been blamed on
+    ROCm 7.2 and papered over by refusing nested forks).  With the depth in the key a nested fork can never receive the
+    stream it runs on; tests/test_ops_gpu.py::test_nested_fork_join_under_graph_capture captures and replays one."""
+    key = (device, depth, i)
     if key not in _pool:
         _pool[key] = torch.cuda.Stream(device=device)
     return _pool[key]
@@ -32,13 +38,15 @@ _ONLY = set(t for t in os.environ.get("CMR_STREAMS_ONLY", "").split(",") if t)  
 
 def fork_join(*fns, tag=""):
     """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn on the current stream and
-    returns all results (in argument order) after joining.  Sequential on CPU / when disabled / when called from
-    inside another fork (nested forks crash hipGraph capture on ROCm 7.2: use one flat n-way fork instead)."""
+    returns all results (in argument order) after joining.  Sequential on CPU / when disabled.  Forks may nest: the
+    side streams of depth d are distinct from those of every other depth (see _side_stream)."""
     global _depth
-    if not ENABLED or not torch.cuda.is_available() or _depth > 0 or (_ONLY and tag not in _ONLY):
+    if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY):
         return tuple(f() for f in fns)
     main = torch.cuda.current_stream()
-    sides = [_side_stream(main.device, i) for i in range(len(fns) - 1)]
+    sides = [_side_stream(main.device, _depth, i) for i in range(len(fns) - 1)]
+    if any(s == main for s in sides):
+        raise RuntimeError("fork_join: a side stream equals the current stream (called from a foreign stream pool?)")
     for s in sides:
         s.wait_stream(main)
     _depth += 1

@@ -129,6 +129,11 @@ E2E_CASES = {
 # nearest size it can.
 ORACLE_ONLY_E2E_CASES = {
     "e2e_config0": dict(B=1, N=4096, H=192, W=608, M=1280, Q=256, steps=1, n_circle=128),
+    # BASELINE.json configs[1], the headline shape (352x1216 image, 16 384 points, 10 agent steps) at B = 2: T = 418
+    # patches, 88x304 maps, both Winograd instances (64- and 32-cout workgroups) and the 10-step loop together
+    "e2e_config1": dict(B=2, N=16384, H=352, W=1216, M=1280, Q=256, steps=10, n_circle=128),
+    # BASELINE.json configs[3] shape: NuScenesConfig, 32 768 points, 900x1600 -> 896x1600 (multiples of 32 only), B = 1
+    "e2e_config3": dict(B=1, N=32768, H=896, W=1600, M=1280, Q=256, steps=2, n_circle=128, dataset="nuscenes"),
 }
 
 
@@ -137,9 +142,10 @@ def _case(case):
 
 
 def e2e_config(case):
-    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration
     c = _case(case)
-    return KittiConfiguration(cropped_img_H=c["H"], cropped_img_W=c["W"], num_pt=c["N"], device="cpu",
+    Cfg = NuScenesConfiguration if c.get("dataset") == "nuscenes" else KittiConfiguration
+    return Cfg(cropped_img_H=c["H"], cropped_img_W=c["W"], num_pt=c["N"], device="cpu",
                               num_node=c["M"], num_proxy=c["Q"], action_num=c["steps"])
 
 

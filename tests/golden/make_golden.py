@@ -190,7 +190,8 @@ def run_e2e(ns, specs, case):
     # oracle cross-check on the full tensors
     geo_sd, agent_sd = C.e2e_state_dicts(specs)
     ora = C.e2e_oracle(case, geo_sd, agent_sd)
-    REPORT[case] = {k: _maxdiff(named[k], ora[k]) for k in ora}
+    REPORT[case] = {k: _maxdiff(named[k], ora[k]) for k in ora if k in named}   # the oracle also returns the
+    # overlap metrics (cases.METRIC_KEYS); their fixtures come from make_golden_metrics.py
     REPORT[case]["_overlap_fraction"] = float(data["pc_overlap_pred"].float().mean())
     REPORT[case]["_min_top2_logit_gap"] = min(gaps)
     G.save_case(case, named)
@@ -229,10 +230,13 @@ def main():
     run_dataset_ops(ns)
     for case in C.E2E_CASES:
         run_e2e(ns, specs, case)
-    with open(os.path.join(HERE, "specs.json"), "w") as f:
+    with open(os.path.join(G.OUT_DIR, "specs.json"), "w") as f:
         json.dump(specs, f, indent=0, sort_keys=True)
-    with open(os.path.join(HERE, "oracle_vs_reference.json"), "w") as f:
-        json.dump(REPORT, f, indent=1, sort_keys=True)
+    rp = os.path.join(G.OUT_DIR, "oracle_vs_reference.json")      # shared with make_golden_metrics / _rollout / _train: merge
+    rep = json.load(open(rp)) if os.path.exists(rp) else {}
+    rep.update(REPORT)
+    with open(rp, "w") as f:
+        json.dump(rep, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

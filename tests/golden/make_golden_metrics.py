@@ -27,7 +27,7 @@ torch.set_grad_enabled(False)
 def main():
     ns = ref_harness.load_reference()
     specs = json.load(open(os.path.join(HERE, "specs.json")))
-    rp = os.path.join(HERE, "oracle_vs_reference.json")
+    rp = os.path.join(G.OUT_DIR, "oracle_vs_reference.json")
     rep = json.load(open(rp))
     for case, c in C.E2E_CASES.items():
         cfg = ns.config.KittiConfiguration()

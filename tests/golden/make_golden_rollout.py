@@ -51,7 +51,7 @@ def main():
                         float((O.advantage(inp["rewards"], inp["values"], 0.99, 0.95) - named["advantage_gae"]).abs().max())]
     G.save_case("rollout_ops", named)
     print(json.dumps(report, indent=1))
-    rp = os.path.join(HERE, "oracle_vs_reference.json")
+    rp = os.path.join(G.OUT_DIR, "oracle_vs_reference.json")
     rep = json.load(open(rp))
     rep["rollout_ops"] = {"%s_%d" % (k, i): v for k, vs in report.items() for i, v in enumerate(vs)}   # flat: max |oracle - reference|
     json.dump(rep, open(rp, "w"), indent=1, sort_keys=True)

@@ -10,6 +10,9 @@ import numpy as np
 import torch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# the generators write here; tests/test_golden_recipe.py points it at a scratch directory to check that the committed
+# recipe still reproduces the committed fixtures
+OUT_DIR = os.environ.get("CMR_GOLDEN_OUT", GOLDEN_DIR)
 MAX_SAMPLES = 4096
 
 
@@ -41,7 +44,7 @@ def pack(named):
 
 
 def save_case(case, named):
-    np.savez_compressed(os.path.join(GOLDEN_DIR, case + ".npz"), **pack(named))
+    np.savez_compressed(os.path.join(OUT_DIR, case + ".npz"), **pack(named))
 
 
 def load_case(case):

@@ -1,5 +1,6 @@
 """GPU tier, end to end: geo model + agent loop through the HIP path vs oracle and golden."""
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 
@@ -16,6 +17,21 @@ def test_registration_iteration_baseline_config0():
     parity_e2e.run_case("e2e_config0", check_golden=False, verbose=True)
 
 
+def test_registration_iteration_headline_config1():
+    """BASELINE.json configs[1] -- the shape the bench line is quoted on (352x1216, 16 384 points, 10 agent steps) --
+    at B = 2 against the oracle, same tolerances as the small cases (parity_e2e.compare).  The oracle needs a few
+    seconds per sample on the host."""
+    import parity_e2e
+    parity_e2e.run_case("e2e_config1", check_golden=False, verbose=True)
+
+
+def test_registration_iteration_nuscenes_config3_shape():
+    """BASELINE.json configs[3] shape (896x1600 next to 900x1600, 32 768 points; NuScenesConfig), B = 1, 2 agent steps,
+    against the oracle."""
+    import parity_e2e
+    parity_e2e.run_case("e2e_config3", check_golden=False, verbose=True)
+
+
 def test_registration_iteration_op_level_paths(monkeypatch):
     """Same iteration with every layer-level fusion and the side streams switched off: the op-level composition
     must meet the same oracle / golden bars."""
@@ -28,3 +44,38 @@ def test_registration_iteration_op_level_paths(monkeypatch):
     monkeypatch.setattr(CMRAgent, "FUSED_TAIL", False)
     monkeypatch.setattr(streams, "ENABLED", False)
     parity_e2e.run_case("e2e_small", check_golden=True, verbose=False)
+
+
+def test_agent_image_half_cache_is_per_registration():
+    """the image half of the agent's first convolution used to be cached under (data_ptr, version,
+    shape) of img_geo_feat; a second registration whose buffer landed at the same address reused the previous pair's
+    result.  Two same-shape, different-content batches through ONE agent, first data dict dropped in between, must give
+    what a fresh agent gives."""
+    import gc
+    import parity_e2e
+    import cases as C
+    from cmr_agent_amd.environment import environment as env
+    cfg = C.e2e_config("e2e_small")
+    geo, agent, _, _ = parity_e2e.build_models(cfg)
+    _, agent2, _, _ = parity_e2e.build_models(cfg)
+    b1 = C.e2e_batch("e2e_small")
+    b2 = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b1.items()}
+    b2["img"] = b1["img"].flip(0).contiguous() * 0.7 + 0.1                   # same shapes, other content
+
+    def logits(ag, batch):
+        data = {k: (v.to("cuda") if torch.is_tensor(v) else v) for k, v in batch.items()}
+        with torch.no_grad():
+            geo(data)
+            pose, _ = env.init(data)
+            s2, s3 = env.observation_from_a_pose(data, pose)
+            r, t, v = ag(s2, s3)
+        return torch.cat([r.flatten(), t.flatten(), v.flatten()]).cpu()
+
+    l1 = logits(agent, b1)
+    gc.collect()                                                             # frees data dict 1: its buffers return to the allocator
+    l2 = logits(agent, b2)
+    want = logits(agent2, b2)
+    scale = float(want.abs().max())
+    assert float((l1 - l2).abs().max()) > 1e-2 * scale                       # the two batches really differ
+    # not bit-exact: the projection scatter-mean accumulates with float atomics
+    assert float((l2 - want).abs().max()) < 1e-5 * scale, float((l2 - want).abs().max())

@@ -18,6 +18,7 @@ import torch
 import cases as C
 import golden_util as G
 from cmr_agent_amd.utils import hashfill, synthetic
+from cmr_agent_amd.utils.checkpoint import load_checked
 from oracle import cmr_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -29,8 +30,8 @@ def _models(cfg):
     from cmr_agent_amd.models import CMRAgent, MultiHeadModel
     geo_sd, agent_sd = C.e2e_state_dicts(SPECS)
     geo, agent = MultiHeadModel(cfg), CMRAgent(cfg)
-    geo.load_state_dict(geo_sd, strict=False)
-    agent.load_state_dict(agent_sd, strict=False)
+    load_checked(geo, geo_sd)
+    load_checked(agent, agent_sd)
     return geo.to(DEV).eval(), agent.to(DEV).eval()
 
 

@@ -1,0 +1,53 @@
+"""The committed fixture recipe must keep working: where the reference tree is present (the authoring container),
+re-run the three generators into a scratch directory and require bit-identical fixtures and the same case lists as
+tests/cases.py.  (Round 1 shipped a make_golden.py that crashed at HEAD without any test noticing.)  Each generator
+imports the reference, which patches torch.Tensor.cuda and takes over the top-level module names `models`, `config`,
+`environment`, so they run in child processes.  Skipped on the GPU box, where /root/reference does not exist."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases as C
+import golden_util as G
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference tree not present")
+
+GENERATORS = ("make_golden.py", "make_golden_metrics.py", "make_golden_rollout.py", "make_golden_train.py")
+
+
+@pytest.fixture(scope="module")
+def regenerated(tmp_path_factory):
+    out = tmp_path_factory.mktemp("golden")
+    for f in ("specs.json", "oracle_vs_reference.json"):
+        shutil.copy(os.path.join(G.GOLDEN_DIR, f), out / f)
+    env = dict(os.environ, CMR_GOLDEN_OUT=str(out), OMP_NUM_THREADS="8")
+    for gen in GENERATORS:
+        r = subprocess.run([sys.executable, os.path.join(G.GOLDEN_DIR, gen)], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, "%s failed:\n%s" % (gen, r.stderr[-3000:])
+    return out
+
+
+def test_generators_reproduce_committed_fixtures(regenerated):
+    made = sorted(f for f in os.listdir(regenerated) if f.endswith(".npz"))
+    committed = sorted(f for f in os.listdir(G.GOLDEN_DIR) if f.endswith(".npz"))
+    assert made == committed, (set(made) ^ set(committed))
+    for f in made:
+        a, b = np.load(regenerated / f), np.load(os.path.join(G.GOLDEN_DIR, f))
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), (f, k)
+    assert json.load(open(regenerated / "specs.json")) == json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+
+
+def test_case_lists_match_cases_py(regenerated):
+    made = {f[:-4] for f in os.listdir(regenerated) if f.endswith(".npz")}
+    want = set(C.OP_CASES) | set(C.E2E_CASES) | {c + "_metrics" for c in C.E2E_CASES} | {"dataset_ops", "rollout_ops"} | set(C.TRAIN_FIXTURES)
+    assert made == want, (made ^ want)
+    rep = json.load(open(regenerated / "oracle_vs_reference.json"))
+    assert set(C.OP_CASES) | set(C.E2E_CASES) <= set(rep)

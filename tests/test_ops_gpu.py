@@ -538,3 +538,57 @@ def test_head_losses_and_metrics(ops):
         got = ops.circle_loss(pc_feat.permute(0, 2, 1).reshape(-1, 64).contiguous().to(DEV), img_feat.permute(0, 2, 3, 1).contiguous().to(DEV),
                               pc_idx.to(DEV), xy_int.to(DEV), xy_float.to(DEV), B, N, 1, 0.1, 1.4, 10, 1).cpu()
         close(got, ref.reshape(1), 2e-5, "circle loss n=%d" % n)
+
+
+def test_nested_fork_join_under_graph_capture(ops):
+    """utils/streams.py: a fork issued inside a branch of another fork gets side streams of its own nesting depth (round 1
+    handed it the stream it was running on, which is what failed under capture).  Capture a nested fork, replay it
+    twice, compare with the sequential result."""
+    from cmr_agent_amd.utils import streams
+    x = rnd(4096, 64, seed=5).to(DEV)
+    w = [rnd(64, 64, seed=10 + i).to(DEV) for i in range(4)]
+
+    def work():
+        def inner():
+            a, b = streams.fork_join(lambda: ops.linear(x, w[0]), lambda: ops.linear(x, w[1]), tag="t_inner")
+            return a + b
+        c, d, e = streams.fork_join(inner, lambda: ops.linear(x, w[2]), lambda: ops.linear(x, w[3]), tag="t_outer")
+        return c + d + e
+
+    ref = sum(ops.linear(x, wi) for wi in w)
+    eager = work()
+    torch.cuda.synchronize()
+    assert torch.equal(eager, ref)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        work()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = work()
+    for _ in range(2):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
+    assert len({streams._side_stream(x.device, 0, 0), streams._side_stream(x.device, 1, 0), torch.cuda.current_stream()}) == 3
+
+
+def test_argument_guards(ops):
+    """conv3x3(pool=2) with a residual / table / out buffer must raise on BOTH dispatch paths; scatter ops
+    validate their index range like torch_scatter."""
+    from cmr_agent_amd import scatter
+    x = rnd(1, 8, 16, 64, seed=1).to(DEV)
+    w9 = rnd(9, 64, 64, seed=2).to(DEV)
+    with pytest.raises(ValueError):
+        ops.conv3x3(x, w9, None, 64, 1, 1.0, res=x, pool=2)
+    with pytest.raises(ValueError):
+        ops.conv3x3(x, w9, None, 64, 1, 1.0, out=torch.empty(1, 4, 8, 64, device=DEV), pool=2)
+    src = rnd(2, 64, 100, seed=3).to(DEV)
+    idx = torch.randint(0, 10, (2, 100)).to(DEV)
+    with pytest.raises(IndexError):
+        scatter.scatter_sum(src, idx.unsqueeze(1).expand(2, 64, 100), dim=2, dim_size=5)
+    with pytest.raises(IndexError):
+        scatter.scatter_sum(src, (idx - 1).unsqueeze(1).expand(2, 64, 100), dim=2, dim_size=10)
