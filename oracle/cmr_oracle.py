@@ -55,8 +55,14 @@ class Weights:
 # generic layers
 # ----------------------------------------------------------------------------------------------
 
+BN_TRAINING = False      # oracle/train_oracle.py sets this while restating `agent.train()` forwards (Train_Agent.py:256)
+
+
 def _bn(x, w):
-    """Inference-mode BatchNorm (running statistics), torch default eps."""
+    """BatchNorm, torch default eps.  Inference mode (running statistics) unless BN_TRAINING: then batch statistics,
+    and the running statistics in the state dict are updated in place with momentum 0.1 (nn.BatchNorm default)."""
+    if BN_TRAINING:
+        return F.batch_norm(x, w["running_mean"], w["running_var"], w["weight"], w["bias"], True, 0.1, BN_EPS)
     return F.batch_norm(x, w["running_mean"], w["running_var"], w["weight"], w["bias"], False, 0.0, BN_EPS)
 
 

@@ -225,3 +225,60 @@ def rollout_inputs(seed=7):
     values = u(B, 1, T)
     return dict(pose_source=torch.stack(src), pose_target=torch.stack(tgt), pc=pc, pc_in_cam_space=cam, pc_mask=mask,
                 rewards=rewards, values=values)
+
+
+# ----------------------------------------------------------------------------------------------
+# agent training step (Train_Agent.py:263-305) and replay-buffer ordering (buffer.py:127-143)
+# ----------------------------------------------------------------------------------------------
+TRAIN_CASES = {
+    # two minibatches of 4 samples, 16x24 observation maps (global pool 2x3), 320 points
+    "agent_train_small": dict(B=4, h=16, w=24, N=320, nbatch=2),
+}
+TRAIN_FIXTURES = ("agent_train_small_trainbn", "agent_train_small_evalbn", "buffer_order")
+
+
+def train_config(case, device="cpu"):
+    from cmr_agent_amd.config import KittiConfiguration
+    c = TRAIN_CASES[case]
+    return KittiConfiguration(cropped_img_H=4 * c["h"], cropped_img_W=4 * c["w"], num_pt=c["N"], device=device)
+
+
+def train_inputs(case, cfg=None):
+    """-> list of `nbatch` minibatch dicts in the layout of the reference's TensorDataset (Train_Agent.py:258-266)."""
+    c = TRAIN_CASES[case]
+    B, h, w, N = c["B"], c["h"], c["w"], c["N"]
+    S = 11
+    out = []
+    for i in range(c["nbatch"]):
+        t = "train/%s/%d/" % (case, i)
+        s3 = torch.cat([u(t + "xyz", (B, 3, N), -40, 40), (u(t + "ov", (B, 1, N), 0, 1) > 0.6).float(),
+                        (u(t + "cam", (B, 1, N), 0, 1) > 0.5).float()], dim=1)
+        ints = lambda name, shape: (u(t + name, shape, 0, 1) * S).long().clamp(max=S - 1)
+        out.append(dict(
+            states_2d=u(t + "s2", (B, 128, h, w), -0.3, 0.3), states_3d=s3,
+            state_values=u(t + "v0", (B, 1), -1, 1),
+            expert_actions_r=ints("er", (B, 1)), expert_actions_t=ints("et", (B, 2)),
+            action_r=ints("ar", (B, 1)), action_t=ints("at", (B, 2)),
+            # old log-probabilities spread around log(1/11) so that the probability ratio leaves the clip range both ways
+            action_logprob=u(t + "lp", (B, 3), -3.6, -1.2),
+            state_value_ref=u(t + "ret", (B, 1), -1, 1), advantages=u(t + "adv", (B, 1), -1, 1)))
+    return out
+
+
+def buffer_inputs():
+    """2 trajectories x 3 steps x B = 2 of distinguishable values for the nine fields of Buffer.log_step."""
+    B, T, ntraj = 2, 3, 2
+    trajs = []
+    for j in range(ntraj):
+        steps = []
+        for s in range(T):
+            tag = 100 * j + 10 * s
+            base = torch.arange(B, dtype=torch.float32) + tag
+            steps.append(dict(
+                state_2d=base.view(B, 1, 1, 1).expand(B, 4, 2, 3).clone(), state_3d=(base + 0.5).view(B, 1, 1).expand(B, 5, 7).clone(),
+                state_value=(base * 0.01).view(B, 1, 1), reward=((base % 3) - 1).view(B, 1, 1) * 0.5,
+                expert_action_r=base.long().view(B, 1), expert_action_t=base.long().view(B, 1).repeat(1, 2) + 1,
+                action_r=base.long().view(B, 1) + 2, action_t=base.long().view(B, 1).repeat(1, 2) + 3,
+                action_logprob=-base.view(B, 1).repeat(1, 3) * 0.001))
+        trajs.append(steps)
+    return trajs

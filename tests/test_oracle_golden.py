@@ -69,3 +69,45 @@ def test_rollout_ops():
                  advantage_plain=O.advantage(inp["rewards"], inp["values"], 0.99, 0),
                  advantage_gae=O.advantage(inp["rewards"], inp["values"], 0.99, 0.95))
     G.assert_case("rollout_ops", named, atol=1e-6, rtol=1e-6)
+
+
+def _packed(prefix, sd, named, nsamples=256):
+    keys = sorted(sd)
+    named[prefix + "norms"] = torch.stack([sd[k].double().norm() for k in keys]).float()
+    named[prefix + "samples"] = torch.cat([sd[k].reshape(-1)[::max(1, -(-sd[k].numel() // nsamples))] for k in keys]).float()
+
+
+@pytest.mark.parametrize("bn_training", [True, False])
+def test_agent_training_step(bn_training):
+    """oracle/train_oracle.py (train-mode CMRAgent forward, BC + PPO loss, autograd, Adam) vs the fixture produced by the
+    reference's CMRAgent module + torch.optim.Adam (tests/golden/make_golden_train.py): logits, every loss term of two
+    steps, every parameter gradient, parameters and BatchNorm running statistics after two optimizer steps."""
+    from oracle import train_oracle as TO
+    case = "agent_train_small"
+    cfg = C.train_config(case)
+    sd0 = hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG)
+    sd0 = {k: v for k, v in sd0.items() if not k.endswith("num_batches_tracked")}
+    batches = C.train_inputs(case)
+    with torch.enable_grad():
+        _, grads, (r, t, v) = TO.agent_forward_backward({k: x.clone() for k, x in sd0.items()}, batches[0], cfg, bn_training)
+        final, hist = TO.adam_train(sd0, batches, cfg, bn_training)
+    named = dict(r_logits=r, t_logits=t, value=v)
+    _packed("grad_", grads, named)
+    _packed("final_", final, named)
+    for i, h in enumerate(hist):
+        for k, x in h.items():
+            named["step%d/%s" % (i, k)] = x.reshape(1)
+    G.assert_case(case + ("_trainbn" if bn_training else "_evalbn"), named, atol=1e-6, rtol=1e-5)
+
+
+def test_buffer_ordering_quirk():
+    """Buffer.get_samples(): logged fields step-major, returns / advantages batch-major (buffer.py:127-143)."""
+    from cmr_agent_amd.config import KittiConfiguration
+    from oracle import train_oracle as TO
+    cfg = KittiConfiguration(device="cpu")
+    out = TO.buffer_samples(C.buffer_inputs(), cfg.GAMMA, cfg.GAE_LAMBDA)
+    names = ("states_2d", "states_3d", "state_values", "expert_actions_r", "expert_actions_t", "actions_r", "actions_t",
+             "actions_logprob", "returns", "advantages")
+    G.assert_case("buffer_order", dict(zip(names, out)), atol=1e-6, rtol=1e-6)
+    # the quirk itself: sample i of the states is (step i // B, batch i % B) but return i is (batch i // T, step i % T)
+    assert float(out[0][1, 0, 0, 0]) == 1.0 and float(out[0][2, 0, 0, 0]) == 10.0
