@@ -1,0 +1,626 @@
+// Training-side kernels of the agent update (reference Train_Agent.py:263-305 = forward of CMRAgent in
+// train() mode, loss.backward(), Adam.step()).  Everything here is HBM- or latency-bound streaming work over row maps
+// [rows, C] (channels-last): batch-statistics BatchNorm forward / backward, activation and pooling backward, per-batch
+// column reductions with arg-max, the small-batch linear backward of the heads, the BC + PPO loss with its gradient
+// w.r.t. the logits, and the fused Adam step over the flat parameter bucket.  The MFMA-class backward contractions
+// (conv3x3 wgrad, linear wgrad) live in wgrad.hip; data-gradient contractions reuse the forward kernels with
+// transposed weights (cmr_pack_conv3x3_f32).
+//
+// Reductions are two-stage and deterministic: fixed partition of the rows over workgroups, fp32 partials, partials
+// combined in double in a fixed order (so a result never depends on scheduling, and the data-parallel ranks of
+// utils/flatbucket.py stay bit-identical after the all-reduce).
+#include "cmr_common.h"
+
+namespace {
+
+constexpr int RED_THREADS = 256;
+constexpr int MAX_C = 256;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+inline int red_blocks(int64_t rows, int C) {
+  // enough workgroups to fill 256 CUs twice, at least 64 rows per row-group pass
+  const int rg = RED_THREADS / (C / 4);
+  int64_t nb = (rows + (int64_t)rg * 16 - 1) / ((int64_t)rg * 16);
+  if (nb > 512) nb = 512;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm, training mode: statistics
+// ------------------------------------------------------------------------------------------------------------------
+// part[blk][0][c] = sum (x - pivot_c), part[blk][1][c] = sum (x - pivot_c)^2 over the block's rows; pivot = row 0 (keeps the
+// E[x^2] - E[x]^2 cancellation mild whatever the channel mean is).
+__global__ __launch_bounds__(RED_THREADS) void bn_stats_partial_kernel(const float* __restrict__ x, int64_t ldx, int64_t rows,
+                                                                       int C, float* __restrict__ part) {
+  __shared__ float sm[2 * 4 * RED_THREADS];   // RG * 2 * C = (256 / (C/4)) * 2 * C = 2048 floats whatever C is
+  const int q = C >> 2, tid = threadIdx.x;
+  const int cq = tid % q, rg = tid / q, RG = RED_THREADS / q;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  const f32x4 pivot = ld4(x + 4 * cq);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + rg; r < r1; r += RG) {
+    const f32x4 v = ld4(x + r * ldx + 4 * cq) - pivot;
+    s += v;
+    ss += v * v;
+  }
+  st4(&sm[(rg * 2 + 0) * C + 4 * cq], s);
+  st4(&sm[(rg * 2 + 1) * C + 4 * cq], ss);
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += RED_THREADS) {
+    float a = 0.f;
+    for (int g = 0; g < RG; ++g) a += sm[g * 2 * C + i];
+    part[(int64_t)blockIdx.x * 2 * C + i] = a;
+  }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ part, int nblk, int64_t rows, int C,
+                                      float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ stat) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)part[(int64_t)b * 2 * C + c];
+    ss += (double)part[(int64_t)b * 2 * C + C + c];
+  }
+  const double n = (double)rows;
+  const double pm = s / n;
+  double var = ss / n - pm * pm;
+  var = var > 0.0 ? var : 0.0;
+  const double mean = (double)x[c] + pm;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float scale = g * rstd;
+  stat[c] = (float)mean;
+  stat[C + c] = rstd;
+  stat[2 * C + c] = scale;
+  stat[3 * C + c] = bt - (float)mean * scale;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// y = lrelu(x * scale + shift + [res * rscale + rshift | res]).  scale / shift null -> identity on x.
+__global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const float* __restrict__ res, int64_t ldres,
+                                                         const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                         float* __restrict__ y, int64_t ldy, int64_t rows, int C, float slope) {
+  const int q = C >> 2;
+  const int64_t total = rows * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    f32x4 v = ld4(x + r * ldx + c);
+    if (scale) v = v * ld4(scale + c) + ld4(shift + c);
+    if (res) {
+      f32x4 t = ld4(res + r * ldres + c);
+      if (rscale) t = t * ld4(rscale + c) + ld4(rshift + c);
+      v += t;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+    st4(y + r * ldy + c, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BatchNorm, training mode: backward
+// ------------------------------------------------------------------------------------------------------------------
+// dy = dz * act'(z) (z = activation output, null -> dy = dz);  part[blk][0][c] = sum dy,  [1][c] = sum dy * xhat
+__global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ z,
+                                                                     int64_t ldz, float slope, const float* __restrict__ x, int64_t ldx,
+                                                                     const float* __restrict__ stat, int64_t rows, int C,
+                                                                     float* __restrict__ part) {
+  __shared__ float sm[2 * 4 * RED_THREADS];
+  const int q = C >> 2, tid = threadIdx.x;
+  const int cq = tid % q, rg = tid / q, RG = RED_THREADS / q;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
+  const f32x4 mean = ld4(stat + 4 * cq), rstd = ld4(stat + C + 4 * cq);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0 + rg; r < r1; r += RG) {
+    f32x4 d = ld4(dz + r * lddz + 4 * cq);
+    if (z) {
+      const f32x4 a = ld4(z + r * ldz + 4 * cq);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : d[e] * slope;
+    }
+    const f32x4 xh = (ld4(x + r * ldx + 4 * cq) - mean) * rstd;
+    s += d;
+    sx += d * xh;
+  }
+  st4(&sm[(rg * 2 + 0) * C + 4 * cq], s);
+  st4(&sm[(rg * 2 + 1) * C + 4 * cq], sx);
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += RED_THREADS) {
+    float a = 0.f;
+    for (int g = 0; g < RG; ++g) a += sm[g * 2 * C + i];
+    part[(int64_t)blockIdx.x * 2 * C + i] = a;
+  }
+}
+
+// coef[0][c] = sum dy / n, coef[1][c] = sum dy xhat / n;  dgamma / dbeta written (or accumulated) into the gradient bucket
+__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int64_t rows, int C, float* __restrict__ coef,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, sx = 0.0;
+  for (int b = 0; b < nblk; ++b) {
+    s += (double)part[(int64_t)b * 2 * C + c];
+    sx += (double)part[(int64_t)b * 2 * C + C + c];
+  }
+  coef[c] = (float)(s / (double)rows);
+  coef[C + c] = (float)(sx / (double)rows);
+  if (dbeta) dbeta[c] = (float)s;
+  if (dgamma) dgamma[c] = (float)sx;
+}
+
+// dx = scale * (dy - c1 - xhat * c2) (+ add),  scale = gamma * rstd = stat[2]
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ z, int64_t ldz,
+                                                           float slope, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stat,
+                                                           const float* __restrict__ coef, const float* __restrict__ add, int64_t ldadd,
+                                                           float* __restrict__ dx, int64_t lddx, int64_t rows, int C) {
+  const int q = C >> 2;
+  const int64_t total = rows * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    f32x4 d = ld4(dz + r * lddz + c);
+    if (z) {
+      const f32x4 a = ld4(z + r * ldz + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : d[e] * slope;
+    }
+    const f32x4 xh = (ld4(x + r * ldx + c) - ld4(stat + c)) * ld4(stat + C + c);
+    f32x4 g = ld4(stat + 2 * C + c) * (d - ld4(coef + c) - xh * ld4(coef + C + c));
+    if (add) g += ld4(add + r * ldadd + c);
+    st4(dx + r * lddx + c, g);
+  }
+}
+
+// dy = dz * act'(z) (+ add): activation backward without a BatchNorm (identity shortcut of ConvBNReLURes1D)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ z, int64_t ldz,
+                                                      float slope, const float* __restrict__ add, int64_t ldadd, float* __restrict__ dy,
+                                                      int64_t lddy, int64_t rows, int C) {
+  const int q = C >> 2;
+  const int64_t total = rows * q;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / q;
+    const int c = (int)(i - r * q) * 4;
+    f32x4 d = ld4(dz + r * lddz + c);
+    const f32x4 a = ld4(z + r * ldz + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : d[e] * slope;
+    if (add) d += ld4(add + r * ldadd + c);
+    st4(dy + r * lddy + c, d);
+  }
+}
+
+// AvgPool2d(ph, pw) backward fused with the backward of the activation that precedes the pool:
+// dc[b,y,x,:] = g[b, y / ph, x / pw, :] / (ph pw) * act'(d[b,y,x,:])
+__global__ __launch_bounds__(256) void pool_act_bwd_kernel(const float* __restrict__ g, const float* __restrict__ d, float* __restrict__ dc,
+                                                           int B, int H, int W, int C, int ph, int pw, float slope) {
+  const int q = C >> 2;
+  const int64_t total = (int64_t)B * H * W * q;
+  const int Hp = H / ph, Wp = W / pw;
+  const float inv = 1.f / (float)(ph * pw);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % q) * 4;
+    int64_t p = i / q;
+    const int xx = (int)(p % W);
+    p /= W;
+    const int yy = (int)(p % H);
+    const int b = (int)(p / H);
+    const f32x4 gv = ld4(g + (((int64_t)b * Hp + yy / ph) * Wp + xx / pw) * C + c);
+    const f32x4 a = ld4(d + (i / q) * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = gv[e] * inv * (a[e] > 0.f ? 1.f : slope);
+    st4(dc + (i / q) * C + c, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// per-batch column reductions: sum, and max with arg-max (first index on ties, like torch.max(dim))
+// ------------------------------------------------------------------------------------------------------------------
+template <bool MAXARG>
+__global__ __launch_bounds__(RED_THREADS) void col_partial_kernel(const float* __restrict__ x, int64_t ldx, int N, int C, float* __restrict__ pv,
+                                                                  int32_t* __restrict__ pi) {
+  __shared__ float sv[4 * RED_THREADS];             // RG * C = 1024 floats
+  __shared__ int32_t si[MAXARG ? 4 * RED_THREADS : 1];
+  const int q = C >> 2, tid = threadIdx.x;
+  const int cq = tid % q, rg = tid / q, RG = RED_THREADS / q;
+  const int b = blockIdx.y;
+  const int per = (N + gridDim.x - 1) / gridDim.x;
+  const int n0 = blockIdx.x * per, n1 = n0 + per < N ? n0 + per : N;
+  f32x4 acc;
+  int idx[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] = MAXARG ? -INFINITY : 0.f;
+  for (int n = n0 + rg; n < n1; n += RG) {
+    const f32x4 v = ld4(x + ((int64_t)b * N + n) * ldx + 4 * cq);
+    if (MAXARG) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (v[e] > acc[e]) { acc[e] = v[e]; idx[e] = n; }
+    } else {
+      acc += v;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sv[rg * C + 4 * cq + e] = acc[e];
+    if (MAXARG) si[rg * C + 4 * cq + e] = idx[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += RED_THREADS) {
+    float a = sv[c];
+    int ia = MAXARG ? si[c] : 0;
+    for (int g = 1; g < RG; ++g) {
+      const float v = sv[g * C + c];
+      if (MAXARG) {
+        const int iv = si[g * C + c];
+        if (v > a || (v == a && iv < ia)) { a = v; ia = iv; }
+      } else {
+        a += v;
+      }
+    }
+    const int64_t o = ((int64_t)b * gridDim.x + blockIdx.x) * C + c;
+    pv[o] = a;
+    if (MAXARG) pi[o] = ia;
+  }
+}
+
+template <bool MAXARG>
+__global__ void col_final_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int nblk, int C, float* __restrict__ out,
+                                 int32_t* __restrict__ arg) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  if (MAXARG) {
+    float a = -INFINITY;
+    int ia = 0x7fffffff;
+    for (int k = 0; k < nblk; ++k) {
+      const float v = pv[((int64_t)b * nblk + k) * C + c];
+      const int iv = pi[((int64_t)b * nblk + k) * C + c];
+      if (v > a || (v == a && iv < ia)) { a = v; ia = iv; }
+    }
+    out[(int64_t)b * C + c] = a;
+    arg[(int64_t)b * C + c] = ia;
+  } else {
+    double a = 0.0;
+    for (int k = 0; k < nblk; ++k) a += (double)pv[((int64_t)b * nblk + k) * C + c];
+    out[(int64_t)b * C + c] = (float)a;
+  }
+}
+
+// backward of the per-batch max: dx[b, arg[b,c], c] += g[b,c]
+__global__ void add_at_arg_kernel(float* __restrict__ dx, int64_t lddx, const int32_t* __restrict__ arg, const float* __restrict__ g, int64_t ldg,
+                                  int B, int N, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i - b * C;
+  dx[((int64_t)b * N + arg[i]) * lddx + c] += g[(int64_t)b * ldg + c];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// linear layer backward on a handful of rows (the 1x1 convs after the global pool and the three heads: rows = minibatch)
+//   dYe = dY * act'(Y);  dW[n][k] = sum_r dYe[r][n] X[r][k];  db[n] = sum_r dYe[r][n];  dX[r][k] (+)= sum_n dYe[r][n] W[n][k]
+// X = [X1 | X2] (the heads read cat([embed_2d, embed_3d]))
+// ------------------------------------------------------------------------------------------------------------------
+struct SmallBwd {
+  const float *x1, *x2, *y, *dy, *w;
+  float *dw, *db, *dx1, *dx2;
+  int64_t ldx1, ldx2, ldy, lddy, ldw, lddw, lddx1, lddx2;
+  int rows, n, k1, k2, acc_dx;
+  float slope;
+};
+
+__global__ __launch_bounds__(256) void linear_bwd_small_kernel(const SmallBwd a) {
+  const int K = a.k1 + a.k2;
+  const int64_t nw = (int64_t)a.n * K;
+  const int64_t nx = (a.dx1 || a.dx2) ? (int64_t)a.rows * K : 0;
+  const int64_t total = nw + a.n + nx;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < nw + a.n) {
+      const bool isb = i >= nw;
+      const int n = isb ? (int)(i - nw) : (int)(i / K);
+      const int k = isb ? 0 : (int)(i - (int64_t)n * K);
+      float s = 0.f;
+      for (int r = 0; r < a.rows; ++r) {
+        float d = a.dy[(int64_t)r * a.lddy + n];
+        if (a.y) d = a.y[(int64_t)r * a.ldy + n] > 0.f ? d : d * a.slope;
+        const float xv = isb ? 1.f : (k < a.k1 ? a.x1[(int64_t)r * a.ldx1 + k] : a.x2[(int64_t)r * a.ldx2 + k - a.k1]);
+        s += d * xv;
+      }
+      if (isb) {
+        if (a.db) a.db[n] = s;
+      } else if (a.dw) {
+        a.dw[(int64_t)n * a.lddw + k] = s;
+      }
+    } else {
+      const int64_t j = i - nw - a.n;
+      const int r = (int)(j / K), k = (int)(j - (int64_t)r * K);
+      float s = 0.f;
+      for (int n = 0; n < a.n; ++n) {
+        float d = a.dy[(int64_t)r * a.lddy + n];
+        if (a.y) d = a.y[(int64_t)r * a.ldy + n] > 0.f ? d : d * a.slope;
+        s += d * a.w[(int64_t)n * a.ldw + k];
+      }
+      float* dst = k < a.k1 ? (a.dx1 ? a.dx1 + (int64_t)r * a.lddx1 + k : nullptr) : (a.dx2 ? a.dx2 + (int64_t)r * a.lddx2 + k - a.k1 : nullptr);
+      if (dst) *dst = a.acc_dx ? *dst + s : s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// BC + PPO loss of one minibatch and its gradient w.r.t. the logits / value (Train_Agent.py:268-302, CMRAgent.py:129-144)
+// one thread per (sample, degree of freedom) row of S logits; single workgroup (minibatch = 10 samples in the reference)
+// ------------------------------------------------------------------------------------------------------------------
+struct LossArgs {
+  const float *r_logits, *t_logits, *value;
+  int64_t ldr, ldt, ldv;
+  const int64_t *expert_r, *expert_t, *act_r, *act_t;
+  const float *old_logprob, *returns, *adv;
+  float *d_r, *d_t, *d_v;
+  int64_t lddr, lddt, lddv;
+  float* out;     // [8]: loss, clone, policy, value, entropy, ppo, 0, 0
+  int B, dr, dt, S;
+  float alpha, clip_eps, w_value, w_entropy, grad_scale;
+};
+
+__global__ __launch_bounds__(256) void agent_loss_kernel(const LossArgs a) {
+  __shared__ float red[5][256];
+  const int tid = threadIdx.x;
+  const int D = a.dr + a.dt;
+  float ce_r = 0.f, ce_t = 0.f, pol = 0.f, ent = 0.f, val = 0.f;
+  for (int i = tid; i < a.B * D; i += blockDim.x) {
+    const int b = i / D, j = i - b * D;
+    const bool isr = j < a.dr;
+    const int jj = isr ? j : j - a.dr;
+    const float* lg = isr ? a.r_logits + (int64_t)b * a.ldr + jj * a.S : a.t_logits + (int64_t)b * a.ldt + jj * a.S;
+    float* dl = isr ? a.d_r + (int64_t)b * a.lddr + jj * a.S : a.d_t + (int64_t)b * a.lddt + jj * a.S;
+    const int64_t ex = isr ? a.expert_r[(int64_t)b * a.dr + jj] : a.expert_t[(int64_t)b * a.dt + jj];
+    const int64_t ac = isr ? a.act_r[(int64_t)b * a.dr + jj] : a.act_t[(int64_t)b * a.dt + jj];
+    float m = -INFINITY;
+    for (int s = 0; s < a.S; ++s) m = fmaxf(m, lg[s]);
+    float sum = 0.f;
+    for (int s = 0; s < a.S; ++s) sum += expf(lg[s] - m);
+    const float lse = m + logf(sum);
+    float H = 0.f;
+    for (int s = 0; s < a.S; ++s) {
+      const float lp = lg[s] - lse;
+      H -= expf(lp) * lp;
+    }
+    const float lp_ex = lg[ex] - lse, lp_ac = lg[ac] - lse;
+    const float n_ce = 1.f / (float)(a.B * (isr ? a.dr : a.dt));     // CrossEntropyLoss mean over the rows of its own call
+    if (isr) ce_r += -lp_ex * n_ce; else ce_t += -lp_ex * n_ce;
+    float w_lp = 0.f;                                                   // d loss / d logprob(action)
+    const float n_pd = 1.f / (float)(a.B * D);
+    if (a.alpha > 0.f) {
+      const float A = a.adv[b];
+      const float ratio = expf(lp_ac - a.old_logprob[(int64_t)b * D + j]);
+      const float clipped = fminf(fmaxf(ratio, 1.f - a.clip_eps), 1.f + a.clip_eps);
+      const float s1 = ratio * A, s2 = clipped * A;
+      pol += -fminf(s1, s2) * n_pd;
+      ent += H * n_pd;
+      // torch.min(a, b) backward: gradient to the smaller one, split in halves on ties; clamp passes the gradient inside
+      // [lo, hi] (bounds included)
+      const bool inside = ratio >= 1.f - a.clip_eps && ratio <= 1.f + a.clip_eps;
+      float ga = s1 < s2 ? 1.f : (s1 == s2 ? 0.5f : 0.f);
+      float gb = s2 < s1 ? 1.f : (s1 == s2 ? 0.5f : 0.f);
+      const float dratio = ga * A + (inside ? gb * A : 0.f);
+      w_lp = -a.alpha * n_pd * dratio * ratio;
+    }
+    for (int s = 0; s < a.S; ++s) {
+      const float lp = lg[s] - lse, p = expf(lp);
+      float g = n_ce * (p - (s == ex ? 1.f : 0.f));                     // behaviour cloning
+      g += w_lp * ((s == ac ? 1.f : 0.f) - p);                          // PPO policy term through log pi(action)
+      if (a.alpha > 0.f) g += a.alpha * a.w_entropy * n_pd * p * (lp + H);   // - w_entropy * mean(H): dH/dz_s = -p (lp + H)
+      dl[s] = g * a.grad_scale;
+    }
+  }
+  for (int b = tid; b < a.B; b += blockDim.x) {
+    const float v = a.value[(int64_t)b * a.ldv];
+    if (a.alpha > 0.f) {
+      const float d = v - a.returns[b];
+      val += d * d / (float)a.B;
+      a.d_v[(int64_t)b * a.lddv] = a.alpha * a.w_value * 2.f * d / (float)a.B * a.grad_scale;
+    } else {
+      a.d_v[(int64_t)b * a.lddv] = 0.f;
+    }
+  }
+  red[0][tid] = ce_r; red[1][tid] = ce_t; red[2][tid] = pol; red[3][tid] = ent; red[4][tid] = val;
+  __syncthreads();
+  if (tid == 0) {
+    float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 5; ++k)
+      for (int i = 0; i < (int)blockDim.x; ++i) t[k] += red[k][i];
+    const float clone = t[0] + t[1];
+    const float ppo = t[2] + t[4] * a.w_value - t[3] * a.w_entropy;
+    a.out[0] = a.alpha > 0.f ? clone + ppo * a.alpha : clone;
+    a.out[1] = clone; a.out[2] = t[2]; a.out[3] = t[4]; a.out[4] = t[3]; a.out[5] = ppo; a.out[6] = 0.f; a.out[7] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// fused Adam over the flat bucket (torch.optim.Adam semantics, Train_Agent.py:121-127: L2 weight decay added to the
+// gradient, bias-corrected moments).  g is scaled by gscale first (1 / world size after the sum all-reduce).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n4, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
+                                                   float gscale) {
+  const float step = lr / bc1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pv = ld4(p + 4 * i), gv = ld4(g + 4 * i) * gscale, mv = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = gv[e] + wd * pv[e];
+      mv[e] = mv[e] + (gg - mv[e]) * (1.f - b1);               // exp_avg.lerp_(grad, 1 - beta1)
+      vv[e] = vv[e] * b2 + (1.f - b2) * gg * gg;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+      const float denom = sqrtf(vv[e]) / sqrt_bc2 + eps;        // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
+      pv[e] = pv[e] - step * (mv[e] / denom);
+    }
+    st4(p + 4 * i, pv);
+    st4(m + 4 * i, mv);
+    st4(v + 4 * i, vv);
+  }
+}
+
+inline unsigned ew_grid(int64_t items) {
+  int64_t g = (items + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+inline bool chan_ok(int C) { return C == 8 || C == 16 || C == 32 || C == 64 || C == 128 || C == 256; }
+
+}  // namespace
+
+extern "C" int64_t cmr_bn_workspace_bytes(int64_t rows, int C) { return (int64_t)red_blocks(rows, C) * 2 * C * sizeof(float); }
+
+extern "C" int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C, float eps, float momentum, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float* stat, void* ws, int64_t ws_bytes,
+                                hipStream_t stream) {
+  CMR_REQUIRE(x && stat && ws && rows > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));
+  CMR_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  const int nb = red_blocks(rows, C);
+  CMR_REQUIRE(ws_bytes >= (int64_t)nb * 2 * C * (int64_t)sizeof(float));
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, stream, x, ldx, rows, C, (float*)ws);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, x, (const float*)ws, nb, rows, C, eps, momentum,
+                     gamma, beta, running_mean, running_var, stat);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const float* shift, const float* res, int64_t ldres,
+                                  const float* rscale, const float* rshift, float* y, int64_t ldy, int64_t rows, int C, float slope,
+                                  hipStream_t stream) {
+  CMR_REQUIRE(x && y && rows >= 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && cmr_aligned16(x) && cmr_aligned16(y));
+  CMR_REQUIRE((scale == nullptr) == (shift == nullptr) && (rscale == nullptr) == (rshift == nullptr));
+  if (res) CMR_REQUIRE(ldres % 4 == 0 && cmr_aligned16(res));
+  if (rows == 0) return CMR_OK;
+  hipLaunchKernelGGL(affine_act_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, x, ldx, scale, shift, res, ldres, rscale,
+                     rshift, y, ldy, rows, C, slope);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
+                              const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                              int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(dz && x && stat && dx && ws && rows > 0 && chan_ok(C));
+  CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x) && cmr_aligned16(dx));
+  if (z) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z));
+  if (add) CMR_REQUIRE(ldadd % 4 == 0 && cmr_aligned16(add));
+  const int nb = red_blocks(rows, C);
+  CMR_REQUIRE(ws_bytes >= (int64_t)(nb + 1) * 2 * C * (int64_t)sizeof(float));
+  float* part = (float*)ws;
+  float* coef = part + (int64_t)nb * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat, rows, C, part);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)part, nb, rows, C, coef, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat,
+                     (const float*)coef, add, ldadd, dx, lddx, rows, C);
+  return cmr_launch_status();
+}
+
+extern "C" int64_t cmr_bn_bwd_workspace_bytes(int64_t rows, int C) {
+  return (int64_t)(red_blocks(rows, C) + 1) * 2 * C * sizeof(float);
+}
+
+extern "C" int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,
+                               float* dy, int64_t lddy, int64_t rows, int C, hipStream_t stream) {
+  CMR_REQUIRE(dz && z && dy && rows >= 0 && C > 0 && C % 4 == 0 && lddz % 4 == 0 && ldz % 4 == 0 && lddy % 4 == 0);
+  CMR_REQUIRE(cmr_aligned16(dz) && cmr_aligned16(z) && cmr_aligned16(dy));
+  if (add) CMR_REQUIRE(ldadd % 4 == 0 && cmr_aligned16(add));
+  if (rows == 0) return CMR_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, dz, lddz, z, ldz, slope, add, ldadd, dy, lddy,
+                     rows, C);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_pool_act_bwd_f32(const float* g, const float* d, float* dc, int B, int H, int W, int C, int ph, int pw, float slope,
+                                    hipStream_t stream) {
+  CMR_REQUIRE(g && d && dc && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && ph > 0 && pw > 0 && H % ph == 0 && W % pw == 0);
+  CMR_REQUIRE(cmr_aligned16(g) && cmr_aligned16(d) && cmr_aligned16(dc));
+  hipLaunchKernelGGL(pool_act_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * (C / 4))), dim3(256), 0, stream, g, d, dc, B, H, W, C, ph, pw,
+                     slope);
+  return cmr_launch_status();
+}
+
+static inline int col_blocks(int N, int C) {
+  const int rg = RED_THREADS / (C / 4);
+  int nb = (N + rg * 16 - 1) / (rg * 16);
+  return nb > 128 ? 128 : (nb < 1 ? 1 : nb);
+}
+
+extern "C" int64_t cmr_colarg_workspace_bytes(int B, int N, int C) { return (int64_t)B * col_blocks(N, C) * C * 8; }
+
+extern "C" int cmr_colsum_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C, hipStream_t stream) {
+  CMR_REQUIRE(x && out && ws && B > 0 && N > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));
+  const int nb = col_blocks(N, C);
+  CMR_REQUIRE(ws_bytes >= (int64_t)B * nb * C * 4);
+  hipLaunchKernelGGL(col_partial_kernel<false>, dim3(nb, B), dim3(RED_THREADS), 0, stream, x, ldx, N, C, (float*)ws, (int32_t*)nullptr);
+  hipLaunchKernelGGL(col_final_kernel<false>, dim3((C + 63) / 64, B), dim3(64), 0, stream, (const float*)ws, (const int32_t*)nullptr, nb, C,
+                     out, (int32_t*)nullptr);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_colmax_arg_f32(const float* x, int64_t ldx, float* out, int32_t* arg, void* ws, int64_t ws_bytes, int B, int N, int C,
+                                  hipStream_t stream) {
+  CMR_REQUIRE(x && out && arg && ws && B > 0 && N > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));
+  const int nb = col_blocks(N, C);
+  CMR_REQUIRE(ws_bytes >= (int64_t)B * nb * C * 8);
+  float* pv = (float*)ws;
+  int32_t* pi = (int32_t*)(pv + (int64_t)B * nb * C);
+  hipLaunchKernelGGL(col_partial_kernel<true>, dim3(nb, B), dim3(RED_THREADS), 0, stream, x, ldx, N, C, pv, pi);
+  hipLaunchKernelGGL(col_final_kernel<true>, dim3((C + 63) / 64, B), dim3(64), 0, stream, (const float*)pv, (const int32_t*)pi, nb, C, out,
+                     arg);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_add_at_arg_f32(float* dx, int64_t lddx, const int32_t* arg, const float* g, int64_t ldg, int B, int N, int C,
+                                  hipStream_t stream) {
+  CMR_REQUIRE(dx && arg && g && B > 0 && N > 0 && C > 0);
+  hipLaunchKernelGGL(add_at_arg_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, dx, lddx, arg, g, ldg, B, N, C);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_linear_bwd_small_f32(const float* x1, int64_t ldx1, int k1, const float* x2, int64_t ldx2, int k2, const float* y,
+                                        int64_t ldy, float slope, const float* dy, int64_t lddy, const float* w, int64_t ldw, float* dw,
+                                        int64_t lddw, float* db, float* dx1, int64_t lddx1, float* dx2, int64_t lddx2, int acc_dx, int rows,
+                                        int n, hipStream_t stream) {
+  CMR_REQUIRE(x1 && dy && w && rows > 0 && rows <= 1024 && n > 0 && k1 > 0 && k2 >= 0 && (k2 == 0 || x2));
+  SmallBwd a{x1, x2, y, dy, w, dw, db, dx1, dx2, ldx1, ldx2, ldy, lddy, ldw, lddw, lddx1, lddx2, rows, n, k1, k2, acc_dx, slope};
+  const int64_t total = (int64_t)n * (k1 + k2) + n + (int64_t)rows * (k1 + k2);
+  hipLaunchKernelGGL(linear_bwd_small_kernel, dim3(ew_grid(total)), dim3(256), 0, stream, a);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_agent_loss_f32(const float* r_logits, int64_t ldr, const float* t_logits, int64_t ldt, const float* value, int64_t ldv,
+                                  const int64_t* expert_r, const int64_t* expert_t, const int64_t* act_r, const int64_t* act_t,
+                                  const float* old_logprob, const float* returns, const float* adv, float* d_r, int64_t lddr, float* d_t,
+                                  int64_t lddt, float* d_v, int64_t lddv, float* out, int B, int dr, int dt, int S, float alpha,
+                                  float clip_eps, float w_value, float w_entropy, float grad_scale, hipStream_t stream) {
+  CMR_REQUIRE(r_logits && t_logits && value && expert_r && expert_t && act_r && act_t && d_r && d_t && d_v && out);
+  CMR_REQUIRE(B > 0 && dr > 0 && dt > 0 && S > 0 && S <= 64);
+  if (alpha > 0.f) CMR_REQUIRE(old_logprob && returns && adv);
+  LossArgs a{r_logits, t_logits, value, ldr, ldt, ldv, expert_r, expert_t, act_r, act_t, old_logprob, returns, adv, d_r, d_t, d_v,
+             lddr, lddt, lddv, out, B, dr, dt, S, alpha, clip_eps, w_value, w_entropy, grad_scale};
+  hipLaunchKernelGGL(agent_loss_kernel, dim3(1), dim3(256), 0, stream, a);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, hipStream_t stream) {
+  CMR_REQUIRE(p && g && m && v && n >= 0 && n % 4 == 0 && cmr_aligned16(p) && cmr_aligned16(g) && cmr_aligned16(m) && cmr_aligned16(v));
+  CMR_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f);
+  if (n == 0) return CMR_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, lr, beta1, beta2, eps, weight_decay,
+                     bias_correction1, sqrtf(bias_correction2), grad_scale);
+  return cmr_launch_status();
+}

@@ -1,0 +1,329 @@
+// Weight-gradient contractions of the agent update (reference Train_Agent.py:304 `loss.backward()` through
+// the nn.Conv2d / nn.Conv1d / nn.Linear layers of CMRAgent.py:25-86) on the fp32 matrix cores, and the per-step weight
+// repacking that lets the data-gradient convolutions reuse the forward kernels.
+//
+// A weight gradient contracts over the PIXELS / ROWS of the minibatch (K = 10^5 .. 10^6) into a tiny output
+// (Cout x Cin x 9 or n x k): every wave keeps its output tiles in MFMA accumulators for the whole launch and streams its
+// slice of the rows through v_mfma_f32_32x32x2_f32 (A = dY^T: lane l supplies dY[row k = l>>5][channel i = l&31],
+// B = X: X[row k][channel j = l&31]; both are 128-byte coalesced dword loads per half wave, no LDS, no barrier);
+// per-wave partial outputs go to a workspace and a second kernel sums them in a fixed order (deterministic: the
+// data-parallel ranks must produce bit-identical buckets from identical inputs).
+#include "cmr_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3x3 (stride 1, pad 1, NHWC) weight gradient:  dW[co][ci][ky][kx] = sum_{b,y,x} dY[b,y,x,co] X[b,y+ky-1,x+kx-1,ci]
+// grid (slices, Cout/32); workgroup = 4 waves; wave = (ci tile, pixel sub-slice); 9 accumulator tiles (one per tap).
+// One MFMA step consumes the pixels (2q, 2q+1) of the flattened [B*H*W] map (each lane tracks the coordinates of its own
+// pixel, so a pair may straddle a row or an image).  Loads of step q+1 are issued before the MFMAs
+// of step q (straight-line, clamped addresses, masks applied afterwards: see DESIGN.md "hipcc rules").
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCI>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                                                int Cin, int Cout, float* __restrict__ part) {
+  constexpr int NSPLIT = 4 / NCI;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ci_t = wave % NCI, split = wave / NCI;
+  const int co_t = blockIdx.y;
+  const int npix = B * H * W;
+  const int npairs = (npix + 1) / 2;
+  const int per_blk = (npairs + gridDim.x - 1) / gridDim.x;
+  const int q0 = min((int)blockIdx.x * per_blk, npairs), q1 = min(q0 + per_blk, npairs);
+  const int per_w = (q1 - q0 + NSPLIT - 1) / NSPLIT;
+  const int w0 = min(q0 + split * per_w, q1), w1 = min(w0 + per_w, q1);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* xb = x + ci_t * 32 + l31;
+  const float* db = dy + co_t * 32 + l31;
+  const int last_pix = B * H * W - 1;
+
+  // coordinates of this lane's pixel of pair q
+  int p = 2 * w0 + h;
+  int xx = p % W, t_ = p / W, yy = t_ % H, bb = t_ / H;
+
+  float a_cur, v_cur[9], a_nxt = 0.f, v_nxt[9];
+  auto load = [&](float& a, float (&v)[9], int bq, int yq, int xq) {
+    const int base = (bq * H + yq) * W + xq;
+    a = db[(int64_t)min(base, last_pix) * Cout];
+    a = base <= last_pix ? a : 0.f;               // odd pixel count: the second lane half of the last pair
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int y2 = yq + ky - 1, x2 = xq + kx - 1;
+        const int yc = min(max(y2, 0), H - 1), xc = min(max(x2, 0), W - 1);
+        const int pix = min((bq * H + yc) * W + xc, last_pix);
+        v[ky * 3 + kx] = xb[(int64_t)pix * Cin];
+      }
+  };
+  auto mask = [&](float (&v)[9], int yq, int xq) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bool ok = (unsigned)(yq + ky - 1) < (unsigned)H && (unsigned)(xq + kx - 1) < (unsigned)W;
+        v[ky * 3 + kx] = ok ? v[ky * 3 + kx] : 0.f;
+      }
+  };
+
+  if (w0 < w1) {
+    load(a_cur, v_cur, bb, yy, xx);
+    mask(v_cur, yy, xx);
+  }
+  for (int q = w0; q < w1; ++q) {
+    int xn = xx + 2, yn = yy, bn = bb;
+    if (xn >= W) { xn -= W; ++yn; }              // W >= 2: one wrap per step
+    if (yn >= H) { yn -= H; ++bn; }
+    load(a_nxt, v_nxt, bn, yn, xn);          // past the end of the slice this reads a valid, unused address
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = cmr_mfma32(a_cur, v_cur[t], acc[t]);
+    mask(v_nxt, yn, xn);
+    a_cur = a_nxt;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v_cur[t] = v_nxt[t];
+    xx = xn; yy = yn; bb = bn;
+  }
+
+  float* out = part + ((int64_t)(blockIdx.x * NSPLIT + split) * 9) * Cout * Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = cmr_mfma_row(r, lane);
+      out[((int64_t)t * Cout + co_t * 32 + row) * Cin + ci_t * 32 + l31] = acc[t][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ part, int nslices, int Cout, int Cin,
+                                                                   float* __restrict__ dw) {
+  const int total = 9 * Cout * Cin;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
+  double s = 0.0;
+  for (int k = 0; k < nslices; ++k) s += (double)part[(int64_t)k * total + i];
+  dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// linear / conv1d(k=1) weight gradient over a row map:  dW[n][k] = sum_r dY[r][n] X[r][k]      (n, k <= 128)
+// grid (slices); workgroup = 4 waves; wave = (n tile, row sub-slice); KT accumulator tiles (all of k).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int KT>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, int64_t lddy, int n, const float* __restrict__ x,
+                                                           int64_t ldx, int k, int64_t rows, float* __restrict__ part) {
+  constexpr int NSPLIT = 4 / NT;
+  constexpr int UNR = 4;                       // row pairs per step: (1 + KT) * UNR loads in flight
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int n_t = wave % NT, split = wave / NT;
+  const int64_t nsteps = (rows + 2 * UNR - 1) / (2 * UNR);
+  const int64_t per_blk = (nsteps + gridDim.x - 1) / gridDim.x;
+  const int64_t s0 = min((int64_t)blockIdx.x * per_blk, nsteps), s1 = min(s0 + per_blk, nsteps);
+  const int64_t per_w = (s1 - s0 + NSPLIT - 1) / NSPLIT;
+  const int64_t w0 = min(s0 + split * per_w, s1), w1 = min(w0 + per_w, s1);
+
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int ncol = n_t * 32 + l31;
+  const bool n_ok = ncol < n;
+  const float* dcol = dy + (n_ok ? ncol : 0);
+  bool k_ok[KT];
+  const float* xcol[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    k_ok[t] = t * 32 + l31 < k;
+    xcol[t] = x + (k_ok[t] ? t * 32 + l31 : 0);
+  }
+
+  float a_cur[UNR], v_cur[UNR][KT], a_nxt[UNR], v_nxt[UNR][KT];
+  auto load = [&](float (&a)[UNR], float (&v)[UNR][KT], int64_t step) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t r = (step * UNR + u) * 2 + h;
+      const int64_t rc = r < rows ? r : rows - 1;
+      a[u] = dcol[rc * lddy];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) v[u][t] = xcol[t][rc * ldx];
+    }
+  };
+  auto mask = [&](float (&a)[UNR], float (&v)[UNR][KT], int64_t step) {
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      const bool ok = (step * UNR + u) * 2 + h < rows;
+      a[u] = ok && n_ok ? a[u] : 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) v[u][t] = k_ok[t] ? v[u][t] : 0.f;
+    }
+  };
+  if (w0 < w1) {
+    load(a_cur, v_cur, w0);
+    mask(a_cur, v_cur, w0);
+  }
+  for (int64_t s = w0; s < w1; ++s) {
+    const int64_t sn = s + 1 < nsteps ? s + 1 : s;
+    load(a_nxt, v_nxt, sn);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int t = 0; t < KT; ++t) acc[t] = cmr_mfma32(a_cur[u], v_cur[u][t], acc[t]);
+    mask(a_nxt, v_nxt, sn);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      a_cur[u] = a_nxt[u];
+#pragma unroll
+      for (int t = 0; t < KT; ++t) v_cur[u][t] = v_nxt[u][t];
+    }
+  }
+  float* out = part + (int64_t)(blockIdx.x * NSPLIT + split) * (NT * 32) * (KT * 32);
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = cmr_mfma_row(r, lane);
+      out[(int64_t)(n_t * 32 + row) * (KT * 32) + t * 32 + l31] = acc[t][r];
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, int nslices, int npad, int kpad, int n, int k,
+                                                                  float* __restrict__ dw, int64_t lddw, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * k) return;
+  const int row = i / k, col = i - row * k;
+  double s = 0.0;
+  for (int j = 0; j < nslices; ++j) s += (double)part[((int64_t)j * npad + row) * kpad + col];
+  float* d = dw + (int64_t)row * lddw + col;
+  *d = accumulate ? *d + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3x3 weights [Co][Ci][3][3] (the nn.Conv2d parameter, read straight from the flat bucket) -> the operand layouts
+// of the forward kernels: w9 [9][Co'][Ci'] and Winograd U = G g G^T as MFMA A fragments [16][Co'/32][Ci'/8][64][4].
+// transpose != 0 gives the data-gradient convolution: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx].
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int transpose, float* __restrict__ w9,
+                                                           float* __restrict__ ufrag) {
+  const int Cop = transpose ? Ci : Co, Cip = transpose ? Co : Ci;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cop * Cip) return;
+  const int o = i / Cip, c = i - o * Cip;
+  float g[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      g[ky][kx] = transpose ? w[((int64_t)c * Ci + o) * 9 + (2 - ky) * 3 + (2 - kx)] : w[((int64_t)o * Ci + c) * 9 + ky * 3 + kx];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) w9[((int64_t)t * Cop + o) * Cip + c] = g[t / 3][t % 3];
+  if (!ufrag) return;
+  // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+  float gg[4][3];
+#pragma unroll
+  for (int l = 0; l < 3; ++l) {
+    gg[0][l] = g[0][l];
+    gg[1][l] = 0.5f * g[0][l] + 0.5f * g[1][l] + 0.5f * g[2][l];
+    gg[2][l] = 0.5f * g[0][l] - 0.5f * g[1][l] + 0.5f * g[2][l];
+    gg[3][l] = g[2][l];
+  }
+  const int t32 = o >> 5, l = o & 31, kg = c >> 3, hh = (c >> 2) & 1, e = c & 3;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const float u0 = gg[a][0];
+    const float u1 = 0.5f * gg[a][0] + 0.5f * gg[a][1] + 0.5f * gg[a][2];
+    const float u2 = 0.5f * gg[a][0] - 0.5f * gg[a][1] + 0.5f * gg[a][2];
+    const float u3 = gg[a][2];
+    const float uu[4] = {u0, u1, u2, u3};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int pos = a * 4 + b;
+      ufrag[((((int64_t)(pos * (Cop / 32) + t32) * (Cip / 8) + kg) * 2 + hh) * 32 + l) * 4 + e] = uu[b];
+    }
+  }
+}
+
+inline int wgrad_slices(int64_t work_items) {
+  int64_t s = work_items / 64;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+}  // namespace
+
+extern "C" int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+  const int nci = Cin / 32;
+  const int nsplit = nci > 0 && nci <= 4 ? 4 / nci : 1;
+  const int slices = wgrad_slices(((int64_t)B * H * W + 1) / 2);
+  return (int64_t)slices * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float);
+}
+
+extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
+                                     int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W >= 2);
+  CMR_REQUIRE(Cout % 32 == 0 && (Cin == 32 || Cin == 64 || Cin == 128));
+  CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff * 16);
+  CMR_REQUIRE((int64_t)B * H * W < 0x7fffffff);
+  const int nci = Cin / 32, nsplit = 4 / nci;
+  const int slices = wgrad_slices(((int64_t)B * H * W + 1) / 2);
+  CMR_REQUIRE(ws_bytes >= (int64_t)slices * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float));
+  dim3 grid(slices, Cout / 32);
+  float* part = (float*)ws;
+  if (nci == 4)
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
+  else if (nci == 2)
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
+  else
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + 255) / 256), dim3(256), 0, stream, (const float*)part,
+                     slices * nsplit, Cout, Cin, dw);
+  return cmr_launch_status();
+}
+
+extern "C" int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k) {
+  const int nt = (n + 31) / 32, kt = (k + 31) / 32;
+  const int ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4), ktp = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+  return (int64_t)wgrad_slices(rows / 8) * (4 / ntp) * (ntp * 32) * (ktp * 32) * (int64_t)sizeof(float);
+}
+
+extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
+                                    int64_t lddw, int accumulate, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(dy && x && dw && ws && rows > 0 && n > 0 && n <= 128 && k > 0 && k <= 128);
+  const int nt = (n + 31) / 32, kt = (k + 31) / 32;
+  const int ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4), ktp = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+  const int slices = wgrad_slices(rows / 8);
+  CMR_REQUIRE(ws_bytes >= (int64_t)slices * (4 / ntp) * (ntp * 32) * (ktp * 32) * (int64_t)sizeof(float));
+  float* part = (float*)ws;
+#define CMR_LW(NT, KT)                                                                                                      \
+  hipLaunchKernelGGL((linear_wgrad_kernel<NT, KT>), dim3(slices), dim3(256), 0, stream, dy, lddy, n, x, ldx, k, rows, part)
+  if (ntp == 1 && ktp == 1) CMR_LW(1, 1);
+  else if (ntp == 1 && ktp == 2) CMR_LW(1, 2);
+  else if (ntp == 1 && ktp == 4) CMR_LW(1, 4);
+  else if (ntp == 2 && ktp == 1) CMR_LW(2, 1);
+  else if (ntp == 2 && ktp == 2) CMR_LW(2, 2);
+  else if (ntp == 2 && ktp == 4) CMR_LW(2, 4);
+  else if (ntp == 4 && ktp == 1) CMR_LW(4, 1);
+  else if (ntp == 4 && ktp == 2) CMR_LW(4, 2);
+  else CMR_LW(4, 4);
+#undef CMR_LW
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(256), 0, stream, (const float*)part, slices * (4 / ntp),
+                     ntp * 32, ktp * 32, n, k, dw, lddw, accumulate);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, hipStream_t stream) {
+  CMR_REQUIRE(w && w9 && Cout > 0 && Cin > 0);
+  if (ufrag) CMR_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0);
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, stream, w, Cout, Cin, transpose, w9, ufrag);
+  return cmr_launch_status();
+}

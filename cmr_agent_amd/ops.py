@@ -532,3 +532,156 @@ def l2norm64(x, out=None):
         out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
     _lib.call("cmr_l2norm64_f32", _p(x), _ld(x), _p(out), _ld(out), x.shape[0], _stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# agent update: training-mode BatchNorm, backward pieces, loss, optimizer -- see include/cmr_hip.h
+# ----------------------------------------------------------------------------------------------------------------------
+def _ws(nbytes, dev):
+    return torch.empty((max(int(nbytes) // 4, 1),), dtype=f32, device=dev)
+
+
+def bn_stats(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """x [rows, C] -> stat [4, C] = (mean, rstd, scale, shift); updates the running statistics in place when given."""
+    _rows(x)
+    rows, C = x.shape
+    stat = torch.empty((4, C), dtype=f32, device=x.device)
+    nb = _lib.load().cmr_bn_workspace_bytes(rows, C)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_bn_stats_f32", _p(x), _ld(x), rows, C, float(eps), float(momentum), _p(gamma), _p(beta), _p(running_mean),
+              _p(running_var), _p(stat), _p(ws), nb, _stream())
+    return stat
+
+
+def affine_act(x, scale=None, shift=None, res=None, rscale=None, rshift=None, slope=1.0, out=None):
+    _rows(x)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=f32, device=x.device)
+    _lib.call("cmr_affine_act_f32", _p(x), _ld(x), _p(scale), _p(shift), _p(res), _ld(res) if res is not None else 0, _p(rscale),
+              _p(rshift), _p(out), _ld(out), rows, C, float(slope), _stream())
+    return out
+
+
+def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None):
+    """Backward of [BatchNorm(train) -> LeakyReLU(slope)] (z None: no activation) -> dx [rows, C]."""
+    _rows(dz), _rows(x)
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=f32, device=x.device)
+    nb = _lib.load().cmr_bn_bwd_workspace_bytes(rows, C)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_bn_bwd_f32", _p(dz), _ld(dz), _p(z), _ld(z) if z is not None else 0, float(slope), _p(x), _ld(x), _p(stat), _p(add),
+              _ld(add) if add is not None else 0, _p(out), _ld(out), _p(dgamma), _p(dbeta), rows, C, _p(ws), nb, _stream())
+    return out
+
+
+def act_bwd(dz, z, slope, add=None, out=None):
+    _rows(dz), _rows(z)
+    rows, C = z.shape
+    if out is None:
+        out = torch.empty((rows, C), dtype=f32, device=z.device)
+    _lib.call("cmr_act_bwd_f32", _p(dz), _ld(dz), _p(z), _ld(z), float(slope), _p(add), _ld(add) if add is not None else 0, _p(out),
+              _ld(out), rows, C, _stream())
+    return out
+
+
+def pool_act_bwd(g, d, ph, pw, slope):
+    """g [B,H/ph,W/pw,C] (contiguous), d [B,H,W,C] activation output -> gradient w.r.t. the pre-activation [B,H,W,C]."""
+    B, H, W, C = d.shape
+    if not (g.is_contiguous() and d.is_contiguous()) or g.numel() != B * (H // ph) * (W // pw) * C:
+        raise ValueError("pool_act_bwd: bad operand layout")
+    out = torch.empty_like(d)
+    _lib.call("cmr_pool_act_bwd_f32", _p(g), _p(d), _p(out), B, H, W, C, ph, pw, float(slope), _stream())
+    return out
+
+
+def colsum(x, B, N, out=None):
+    _rows(x)
+    C = x.shape[1]
+    nb = _lib.load().cmr_colarg_workspace_bytes(B, N, C)
+    ws = _ws(nb, x.device)
+    if out is None:
+        out = torch.empty((B, C), dtype=f32, device=x.device)
+    _lib.call("cmr_colsum_f32", _p(x), _ld(x), _p(out), _p(ws), nb, B, N, C, _stream())
+    return out
+
+
+def colmax_arg(x, B, N):
+    _rows(x)
+    C = x.shape[1]
+    nb = _lib.load().cmr_colarg_workspace_bytes(B, N, C)
+    ws = _ws(nb, x.device)
+    out = torch.empty((B, C), dtype=f32, device=x.device)
+    arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
+    _lib.call("cmr_colmax_arg_f32", _p(x), _ld(x), _p(out), _p(arg), _p(ws), nb, B, N, C, _stream())
+    return out, arg
+
+
+def add_at_arg(dx, arg, g, B, N):
+    _rows(dx)
+    C = g.shape[1]
+    _lib.call("cmr_add_at_arg_f32", _p(dx), _ld(dx), _p(_i32(arg)), _p(g), g.stride(0), B, N, C, _stream())
+    return dx
+
+
+def linear_bwd_small(x1, dy, w, ldw, n, y=None, slope=1.0, x2=None, dw=None, lddw=0, db=None, dx1=None, dx2=None, acc_dx=False):
+    """Backward of a Linear on <= 1024 rows; w / dw are raw views (pointer + row stride) into the flat buckets."""
+    rows, k1 = x1.shape
+    k2 = x2.shape[1] if x2 is not None else 0
+    _lib.call("cmr_linear_bwd_small_f32", _p(x1), x1.stride(0), k1, _p(x2), x2.stride(0) if x2 is not None else 0, k2, _p(y),
+              y.stride(0) if y is not None else 0, float(slope), _p(dy), dy.stride(0), _p(w), int(ldw), _p(dw), int(lddw), _p(db), _p(dx1),
+              dx1.stride(0) if dx1 is not None else 0, _p(dx2), dx2.stride(0) if dx2 is not None else 0, int(acc_dx), rows, int(n),
+              _stream())
+
+
+def agent_loss(r_logits, t_logits, value, expert_r, expert_t, act_r, act_t, old_logprob, returns, adv, dr, dt, S, alpha, clip_eps,
+               w_value, w_entropy, grad_scale=1.0):
+    """-> (losses float32 [8], d_r_logits, d_t_logits, d_value) with the gradient buffers shaped like the (padded) inputs."""
+    B = r_logits.shape[0]
+    d_r, d_t, d_v = torch.zeros_like(r_logits), torch.zeros_like(t_logits), torch.zeros_like(value)
+    out = torch.empty((8,), dtype=f32, device=r_logits.device)
+    for t in (expert_r, expert_t, act_r, act_t):
+        if t.dtype != torch.int64 or not t.is_contiguous():
+            raise ValueError("agent_loss: actions must be contiguous int64")
+    _lib.call("cmr_agent_loss_f32", _p(r_logits), r_logits.stride(0), _p(t_logits), t_logits.stride(0), _p(value), value.stride(0),
+              _p(expert_r), _p(expert_t), _p(act_r), _p(act_t), _p(old_logprob), _p(returns), _p(adv), _p(d_r), d_r.stride(0), _p(d_t),
+              d_t.stride(0), _p(d_v), d_v.stride(0), _p(out), B, dr, dt, S, float(alpha), float(clip_eps), float(w_value),
+              float(w_entropy), float(grad_scale), _stream())
+    return out, d_r, d_t, d_v
+
+
+def adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _lib.call("cmr_adam_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+              float(weight_decay), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), _stream())
+
+
+def conv3x3_wgrad(x, dy, dw):
+    """x [B,H,W,Cin], dy [B,H,W,Cout] (contiguous NHWC) -> dw (flat view of [Cout,Cin,3,3] in the gradient bucket)."""
+    B, H, W, cin = x.shape
+    cout = dy.shape[3]
+    if not (x.is_contiguous() and dy.is_contiguous()) or dw.numel() != cout * cin * 9:
+        raise ValueError("conv3x3_wgrad: bad operand layout")
+    nb = _lib.load().cmr_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_conv3x3_wgrad_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
+
+
+def linear_wgrad(dy, x, dw, lddw, n=None, k=None, accumulate=False):
+    """dw[n][k] (+)= dy^T x over the rows; dw is a raw view (pointer + row stride)."""
+    _rows(dy), _rows(x)
+    rows = dy.shape[0]
+    n = dy.shape[1] if n is None else n
+    k = x.shape[1] if k is None else k
+    nb = _lib.load().cmr_linear_wgrad_workspace_bytes(rows, n, k)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_linear_wgrad_f32", _p(dy), _ld(dy), n, _p(x), _ld(x), k, rows, _p(dw), int(lddw), int(accumulate), _p(ws), nb, _stream())
+
+
+def pack_conv3x3(w, cout, cin, transpose=False, want_u=True):
+    """nn.Conv2d weight (flat [Cout,Cin,3,3]) -> (w9 [9,Co',Ci'], U fragments [16,Co',Ci'] or None) for the forward kernels."""
+    co, ci = (cin, cout) if transpose else (cout, cin)
+    w9 = torch.empty((9, co, ci), dtype=f32, device=w.device)
+    u = torch.empty((16, co, ci), dtype=f32, device=w.device) if want_u and co % 32 == 0 and ci % 32 == 0 else None
+    _lib.call("cmr_pack_conv3x3_f32", _p(w), cout, cin, int(transpose), _p(w9), _p(u), _stream())
+    return w9, u

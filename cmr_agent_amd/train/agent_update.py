@@ -1,0 +1,297 @@
+"""One minibatch update of CMRAgent on the HIP path: the `agent.train(); ... loss.backward(); optimizer.step()` of the
+reference's Train_Agent.py:256-305, as an explicit schedule of kernel launches instead of torch autograd.
+
+Forward (train mode = batch statistics in every BatchNorm, CMRAgent.py:88-115) keeps the tensors the backward needs;
+the backward walks the network once in reverse and writes every parameter gradient straight into its slice of the flat
+gradient bucket (FlatBucket); then ONE all-reduce of that bucket over the data-parallel ranks (the only collective of
+the path) and ONE fused Adam launch over the flat parameter bucket.
+
+Contractions run on the fp32 matrix cores: forward / data-gradient 3x3 convolutions on the Winograd kernel (the data
+gradient is the same convolution with the weights transposed and flipped, packed per step by cmr_pack_conv3x3_f32),
+weight gradients on the row-streaming kernels of csrc/wgrad.hip, 1x1 layers on the streaming GEMM.  BatchNorm
+statistics / backward, pooling and activation backward, the per-sample max with arg-max, the loss and Adam are the
+streaming kernels of csrc/train.hip.  There is no CPU path."""
+import torch
+
+from .. import ops
+from ..models.ImageResNet import to_nhwc
+from .flatbucket import FlatBucket
+
+SLOPE2D = 0.01     # nn.LeakyReLU() default in state_2d_embed and the heads (CMRAgent.py:36)
+SLOPE3D = 0.2      # ConvBNReLURes1D (PointNN.py:267)
+LOSS_NAMES = ("loss", "clone_loss", "policy_loss", "value_loss", "entropy_loss", "ppo_loss")
+
+
+def _pad_running(bn, cpad):
+    """running statistics of a BatchNorm whose width is not a multiple of 4 (the 5-channel first block), zero padded."""
+    c = bn.running_mean.numel()
+    if c == cpad:
+        return bn.running_mean, bn.running_var, None
+    rm = torch.zeros(cpad, dtype=torch.float32, device=bn.running_mean.device)
+    rv = torch.ones(cpad, dtype=torch.float32, device=bn.running_mean.device)
+    rm[:c] = bn.running_mean
+    rv[:c] = bn.running_var
+    return rm, rv, c
+
+
+class AgentUpdate:
+    """agent: cmr_agent_amd.models.CMRAgent already on its device.  dist: torch.distributed (or None) for data parallelism."""
+
+    def __init__(self, agent, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None):
+        self.agent, self.cfg, self.dist = agent, config, dist
+        self.bucket = FlatBucket(agent)
+        n = self.bucket.numel
+        dev = self.bucket.params.device
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.lr = config.lr if lr is None else lr
+        self.betas, self.eps = betas, eps
+        self.weight_decay = config.weight_decay if weight_decay is None else weight_decay
+        self.t = 0
+        self.last_allreduce_ms = None
+        f = config.embed_dim
+        self.f = f
+        self.dims3d = [(5, f), (2 * f, f), (2 * f, f), (2 * f, 2 * f)]
+
+    # ---------------------------------------------------------------------------------------------------------- helpers
+    def _bn(self, x, bn, prefix):
+        """BatchNorm statistics of the row map x for module `bn` (parameters `prefix`.weight / .bias in the bucket)."""
+        C = x.shape[1]
+        gamma, beta = self.bucket.w(prefix + ".weight"), self.bucket.w(prefix + ".bias")
+        rm, rv, c = _pad_running(bn, C)
+        stat = ops.bn_stats(x, gamma, beta, rm, rv, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
+        if c is not None:
+            bn.running_mean.copy_(rm[:c])
+            bn.running_var.copy_(rv[:c])
+        return stat
+
+    def _bn_bwd(self, dz, z, slope, x, stat, prefix, add=None):
+        return ops.bn_bwd(dz, z, slope, x, stat, self.bucket.g(prefix + ".weight"), self.bucket.g(prefix + ".bias"), add=add)
+
+    def _wT(self, name):
+        """transposed copy of a stored weight matrix [n4, k4] -> [k4, n4] (data-gradient GEMM operand)."""
+        w = self.bucket.w(name)
+        return ops.transpose(w.view(1, *w.shape))[0]
+
+    # ---------------------------------------------------------------------------------------------------------- forward
+    def _forward(self, s2, s3, B, N):
+        bk, ag = self.bucket, self.agent
+        e = ag.state_2d_embed
+        c = 2 * self.f
+        T = {}                                                     # tape
+        # ---- 2-D branch: 4 x [conv3x3 + BN + LReLU, conv3x3 + LReLU, pool]
+        x = s2
+        T["stages"] = []
+        for s in range(4):
+            ia, ib = 6 * s, 6 * s + 3
+            na, nb = "state_2d_embed.%d" % ia, "state_2d_embed.%d" % ib
+            w9a, ua = ops.pack_conv3x3(bk.w(na + ".weight"), c, c)
+            w9b, ub = ops.pack_conv3x3(bk.w(nb + ".weight"), c, c)
+            a = ops.conv3x3(x, w9a, bk.w(na + ".bias"), c, 1, 1.0, u=ua)
+            Bq, H, W, _ = a.shape
+            ar = a.view(-1, c)
+            stat = self._bn(ar, e[ia + 1], "state_2d_embed.%d" % (ia + 1))
+            z = ops.affine_act(ar, stat[2], stat[3], slope=SLOPE2D).view(Bq, H, W, c)
+            d = ops.conv3x3(z, w9b, bk.w(nb + ".bias"), c, 1, SLOPE2D, u=ub)
+            T["stages"].append(dict(xin=x, a=a, z=z, d=d, stat=stat, na=na, nb=nb, nbn="state_2d_embed.%d" % (ia + 1), H=H, W=W))
+            if s < 3:
+                x = ops.avgpool(d, 2, 2)
+            else:
+                kh, kw = self.cfg.image_H // 8, self.cfg.image_W // 8
+                if (H, W) != (kh, kw):
+                    raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (H, W, kh, kw))
+                pooled = ops.colmean(d.view(-1, c), B, H * W)                                        # AvgPool2d((H, W))
+        T["pooled"] = pooled
+        T["t1"] = ops.linear(pooled, bk.w("state_2d_embed.24.weight"), bk.w("state_2d_embed.24.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
+        T["e2d"] = ops.linear(T["t1"], bk.w("state_2d_embed.26.weight"), bk.w("state_2d_embed.26.bias"))
+        # ---- 3-D branch: 4 x ConvBNReLURes1D + per-sample max, broadcast-concatenated to every point (never materialised
+        # in front of a GEMM: it is the second source x2[r / N])
+        L3 = []
+        feat, g = s3, None
+        for i, (cin, cout) in enumerate(self.dims3d):
+            p = "state_3d_embed.%d." % i
+            m = ag.state_3d_embed[i]
+            src = dict(x2=g, div2=N) if g is not None else {}
+            h1raw = ops.linear(feat, bk.w(p + "net.0.weight"), bk.w(p + "net.0.bias"), **src)
+            st1 = self._bn(h1raw, m.net[1], p + "net.1")
+            h1 = ops.affine_act(h1raw, st1[2], st1[3], slope=SLOPE3D)
+            h2raw = ops.linear(h1, bk.w(p + "net.3.weight"), bk.w(p + "net.3.bias"))
+            st2 = self._bn(h2raw, m.net[4], p + "net.4")
+            rec = dict(x=feat, g=g, h1raw=h1raw, st1=st1, h1=h1, h2raw=h2raw, st2=st2, cin=cin, cout=cout, p=p)
+            if cin != cout:
+                scraw = ops.linear(feat, bk.w(p + "shortcut.0.weight"), bk.w(p + "shortcut.0.bias"), **src)
+                stsc = self._bn(scraw, m.shortcut[1], p + "shortcut.1")
+                out = ops.affine_act(h2raw, st2[2], st2[3], res=scraw, rscale=stsc[2], rshift=stsc[3], slope=SLOPE3D)
+                rec.update(scraw=scraw, stsc=stsc)
+            else:
+                xcat = ops.concat_rows(feat, g, None, N)                                           # identity shortcut on cat([feat, max])
+                out = ops.affine_act(h2raw, st2[2], st2[3], res=xcat, slope=SLOPE3D)
+            gmax, arg = ops.colmax_arg(out, B, N)
+            rec.update(out=out, gmax=gmax, arg=arg)
+            L3.append(rec)
+            feat, g = out, gmax
+        T["L3"] = L3
+        T["e3d"] = g
+        # ---- heads on cat([embed_2d, embed_3d])
+        T["heads"] = {}
+        outs = []
+        for name in ("policy_r", "policy_t", "value"):
+            h1 = ops.linear(T["e2d"], bk.w(name + ".0.weight"), bk.w(name + ".0.bias"), x2=T["e3d"], act=ops.ACT_LRELU, act_param=SLOPE2D)
+            h2 = ops.linear(h1, bk.w(name + ".2.weight"), bk.w(name + ".2.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
+            o = ops.linear(h2, bk.w(name + ".4.weight"), bk.w(name + ".4.bias"))
+            T["heads"][name] = (h1, h2, o)
+            outs.append(o)
+        return T, outs
+
+    # --------------------------------------------------------------------------------------------------------- backward
+    def _lin_small_bwd(self, name, x1, dy, y=None, x2=None, dx1=None, dx2=None, acc=False):
+        bk = self.bucket
+        w, gw = bk.w(name + ".weight"), bk.g(name + ".weight")
+        ops.linear_bwd_small(x1, dy, w, w.shape[1], w.shape[0], y=y, slope=SLOPE2D, x2=x2, dw=gw, lddw=gw.shape[1], db=bk.g(name + ".bias"),
+                             dx1=dx1, dx2=dx2, acc_dx=acc)
+
+    def _backward(self, T, d_outs, B, N):
+        bk = self.bucket
+        dev = bk.params.device
+        c, f = 2 * self.f, self.f
+        de2d = torch.empty((B, c), dtype=torch.float32, device=dev)
+        de3d = torch.empty((B, c), dtype=torch.float32, device=dev)
+        for i, name in enumerate(("policy_r", "policy_t", "value")):
+            h1, h2, o = T["heads"][name]
+            dh2 = torch.empty_like(h2)
+            dh1 = torch.empty_like(h1)
+            self._lin_small_bwd(name + ".4", h2, d_outs[i], dx1=dh2)
+            self._lin_small_bwd(name + ".2", h1, dh2, y=h2, dx1=dh1)
+            self._lin_small_bwd(name + ".0", T["e2d"], dh1, y=h1, x2=T["e3d"], dx1=de2d, dx2=de3d, acc=i > 0)
+        # ---- 2-D tail and tower
+        dt1 = torch.empty_like(T["t1"])
+        dpooled = torch.empty_like(T["pooled"])
+        self._lin_small_bwd("state_2d_embed.26", T["t1"], de2d, dx1=dt1)
+        self._lin_small_bwd("state_2d_embed.24", T["pooled"], dt1, y=T["t1"], dx1=dpooled)
+        g = dpooled
+        for s in (3, 2, 1, 0):
+            st = T["stages"][s]
+            H, W = st["H"], st["W"]
+            ph, pw = (2, 2) if s < 3 else (H, W)
+            dc = ops.pool_act_bwd(g.contiguous(), st["d"], ph, pw, SLOPE2D)                 # through the pool and conv b's LeakyReLU
+            ops.conv3x3_wgrad(st["z"], dc, bk.g(st["nb"] + ".weight"))
+            ops.colsum(dc.view(-1, c), 1, B * H * W, out=bk.g(st["nb"] + ".bias").view(1, c))
+            w9t, ut = ops.pack_conv3x3(bk.w(st["nb"] + ".weight"), c, c, transpose=True)
+            dz = ops.conv3x3(dc, w9t, None, c, 1, 1.0, u=ut)
+            da = self._bn_bwd(dz.view(-1, c), st["z"].view(-1, c), SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
+            ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"))
+            ops.colsum(da.view(-1, c), 1, B * H * W, out=bk.g(st["na"] + ".bias").view(1, c))
+            if s > 0:
+                w9t, ut = ops.pack_conv3x3(bk.w(st["na"] + ".weight"), c, c, transpose=True)
+                g = ops.conv3x3(da, w9t, None, c, 1, 1.0, u=ut)
+        # ---- 3-D branch
+        R = B * N
+        dg = de3d                                                   # gradient w.r.t. the per-sample max of the current block
+        dfeat = None                                                # gradient w.r.t. the block output rows from the NEXT block
+        for i in (3, 2, 1, 0):
+            r = T["L3"][i]
+            p, cin, cout = r["p"], r["cin"], r["cout"]
+            if dfeat is None:
+                dfeat = torch.zeros((R, cout), dtype=torch.float32, device=dev)
+            ops.add_at_arg(dfeat, r["arg"], dg, B, N)                                         # backward of torch.max(dim=2)
+            dsum = ops.act_bwd(dfeat, r["out"], SLOPE3D)                                      # final LeakyReLU
+            dh2raw = self._bn_bwd(dsum, None, 1.0, r["h2raw"], r["st2"], p + "net.4")
+            gw2 = bk.g(p + "net.3.weight")
+            ops.linear_wgrad(dh2raw, r["h1"], gw2, gw2.shape[1])
+            ops.colsum(dh2raw, 1, R, out=bk.g(p + "net.3.bias").view(1, -1))
+            dh1 = ops.linear(dh2raw, self._wT(p + "net.3.weight"))
+            dh1raw = self._bn_bwd(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], p + "net.1")
+            w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
+            if i == 0:
+                ops.linear_wgrad(dh1raw, r["x"], gw1, gw1.shape[1])
+                ops.colsum(dh1raw, 1, R, out=bk.g(p + "net.0.bias").view(1, -1))
+                dsc = self._bn_bwd(dsum, None, 1.0, r["scraw"], r["stsc"], p + "shortcut.1")
+                gws = bk.g(p + "shortcut.0.weight")
+                ops.linear_wgrad(dsc, r["x"], gws, gws.shape[1])
+                ops.colsum(dsc, 1, R, out=bk.g(p + "shortcut.0.bias").view(1, -1))
+                break
+            # input of this block = cat([feat_prev (f), broadcast max_prev (f)]): streamed half -> row GEMMs, broadcast half ->
+            # per-sample column sums through the small-rows kernel
+            fprev, gprev = r["x"], r["g"]
+            ops.linear_wgrad(dh1raw, fprev, gw1, gw1.shape[1], k=f)                           # dW1[:, :f]
+            cs1 = ops.colsum(dh1raw, B, N)
+            dgprev = torch.empty((B, f), dtype=torch.float32, device=dev)
+            ident = cin == cout
+            if ident:       # identity shortcut on the concatenation: the broadcast half of d cat = dsum, summed per sample
+                ops.colsum(dsum[:, f:], B, N, out=dgprev)
+            ops.linear_bwd_small(gprev, cs1, w1[:, f:], w1.shape[1], w1.shape[0], dw=gw1[:, f:], lddw=gw1.shape[1],
+                                 db=bk.g(p + "net.0.bias"), dx1=dgprev, acc_dx=ident)         # dW1[:, f:], db1, d max_prev
+            w1t = self._wT(p + "net.0.weight")                                                # [cin4, cin4]; rows :f = W1[:, :f]^T
+            if cin != cout:
+                dsc = self._bn_bwd(dsum, None, 1.0, r["scraw"], r["stsc"], p + "shortcut.1")
+                ws, gws = bk.w(p + "shortcut.0.weight"), bk.g(p + "shortcut.0.weight")
+                ops.linear_wgrad(dsc, fprev, gws, gws.shape[1], k=f)
+                cs2 = ops.colsum(dsc, B, N)
+                ops.linear_bwd_small(gprev, cs2, ws[:, f:], ws.shape[1], ws.shape[0], dw=gws[:, f:], lddw=gws.shape[1],
+                                     db=bk.g(p + "shortcut.0.bias"), dx1=dgprev, acc_dx=True)
+                dprev = ops.linear(dh1raw, w1t[:f])
+                dprev = ops.linear(dsc, self._wT(p + "shortcut.0.weight")[:f], res=dprev)
+            else:
+                # identity shortcut: the streamed half of d cat = dsum goes to the rows as the residual of the GEMM
+                dprev = ops.linear(dh1raw, w1t[:f], res=dsum[:, :f])
+            dfeat, dg = dprev, dgprev
+
+    # ------------------------------------------------------------------------------------------------------------- API
+    def forward_backward(self, batch, grad_scale=1.0):
+        """batch: dict with the ten tensors of the reference's TensorDataset (Train_Agent.py:264-266; names as in
+        oracle/train_oracle.py / tests/cases.py:train_inputs).  Fills the gradient bucket; returns (losses [8] device
+        tensor, (r_logits, t_logits, value))."""
+        ag, cfg = self.agent, self.cfg
+        self.bucket.check_attached()
+        s2 = to_nhwc(batch["states_2d"])
+        st3 = batch["states_3d"]
+        B, _, N = st3.shape
+        if st3.stride(1) == 1 and st3.stride(2) == 8 and st3.stride(0) == 8 * N:
+            s3 = torch.as_strided(st3, (B * N, 8), (8, 1))
+        else:
+            s3 = ops.planar_to_rows(st3.contiguous(), 8)
+        T, (o_r, o_t, o_v) = self._forward(s2.contiguous(), s3, B, N)
+        S, dr, dt = cfg.num_steps, ag.degree_r, ag.degree_t
+        i64 = lambda t: t.to(torch.int64).contiguous()
+        alpha = float(cfg.alpha)
+        f32c = lambda t, n: t.reshape(B, n).float().contiguous()
+        losses, d_r, d_t, d_v = ops.agent_loss(
+            o_r, o_t, o_v, i64(batch["expert_actions_r"]), i64(batch["expert_actions_t"]), i64(batch["action_r"]), i64(batch["action_t"]),
+            f32c(batch["action_logprob"], dr + dt) if alpha > 0 else None, f32c(batch["state_value_ref"], 1) if alpha > 0 else None,
+            f32c(batch["advantages"], 1) if alpha > 0 else None, dr, dt, S, alpha, cfg.CLIP_EPS, cfg.W_VALUE, cfg.W_ENTROPY, grad_scale)
+        self._backward(T, (d_r, d_t, d_v), B, N)
+        return losses, (o_r[:, :dr * S].view(B, dr, S), o_t[:, :dt * S].view(B, dt, S), o_v[:, :1].view(B, 1, 1))
+
+    def optimizer_step(self):
+        """all-reduce (sum) of the gradient bucket over the ranks, then the fused Adam launch (mean folded into grad_scale)."""
+        world = 1
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            dev = self.bucket.grads.device
+            if dev.type == "cuda":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                world = self.bucket.all_reduce(self.dist)
+                e1.record()
+                self._ar_events = (e0, e1)
+            else:
+                world = self.bucket.all_reduce(self.dist)
+        self.t += 1
+        ops.adam(self.bucket.params, self.bucket.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                 self.weight_decay, self.t, grad_scale=1.0 / world)
+        self.agent.invalidate()                                     # inference plans (folded BN, packed weights) are stale now
+
+    def allreduce_ms(self):
+        ev = getattr(self, "_ar_events", None)
+        if ev is None:
+            return 0.0
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
+
+    def step(self, batch):
+        """One optimizer step on one minibatch (Train_Agent.py:263-305).  Returns the loss vector (device tensor [8])."""
+        losses, _ = self.forward_backward(batch)
+        self.optimizer_step()
+        return losses
+
+    def set_lr(self, lr):
+        self.lr = lr

@@ -26,7 +26,15 @@ def _side_stream(device, depth, i):
     `side.wait_stream(main)` then recorded an event on that stream and made the same stream wait for it, and both
     branches ran on one stream.  Under hipGraph capture that self-dependency is what failed (it had been blamed on
     ROCm 7.2 and papered over by refusing nested forks).  With the depth in the key a nested fork can never receive the
-    stream it runs on; tests/test_ops_gpu.py::test_nested_fork_join_under_graph_capture captures and replays one."""
+    stream it runs on, and nested forks run concurrently in eager mode.
+
+    Under hipGraph capture a nested fork still fails on ROCm 7.2 -- with distinct streams at every depth and every side
+    stream joined back before the capture ends, hipStreamEndCapture itself dies with SIGSEGV (python frame:
+    torch/cuda/graphs.py capture_end <- CUDAGraph.__exit__; reproduced in round 2 by
+    tests/test_ops_gpu.py::test_nested_fork_join before the guard below went back in; the eager run of the same nested
+    pattern was correct).  That is a runtime defect, not an ordering bug of fork_join, so while a capture is in progress
+    an inner fork runs its branches sequentially on the stream it is on (flat n-way forks capture fine and are what the
+    models use)."""
     key = (device, depth, i)
     if key not in _pool:
         _pool[key] = torch.cuda.Stream(device=device)
@@ -38,10 +46,13 @@ _ONLY = set(t for t in os.environ.get("CMR_STREAMS_ONLY", "").split(",") if t)  
 
 def fork_join(*fns, tag=""):
     """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn on the current stream and
-    returns all results (in argument order) after joining.  Sequential on CPU / when disabled.  Forks may nest: the
-    side streams of depth d are distinct from those of every other depth (see _side_stream)."""
+    returns all results (in argument order) after joining.  Sequential on CPU / when disabled.  Forks may nest in eager
+    mode (the side streams of depth d are distinct from those of every other depth); during hipGraph capture an inner
+    fork is sequential (see _side_stream for the recorded failure)."""
     global _depth
     if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY):
+        return tuple(f() for f in fns)
+    if _depth > 0 and torch.cuda.is_current_stream_capturing():
         return tuple(f() for f in fns)
     main = torch.cuda.current_stream()
     sides = [_side_stream(main.device, _depth, i) for i in range(len(fns) - 1)]

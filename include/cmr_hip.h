@@ -293,6 +293,78 @@ int cmr_softmax2_f32(const float* logits, int64_t ld, float* prob, uint8_t* pred
 /* MultiHeadModel.py:233,241 (F.normalize over channels). */
 int cmr_l2norm64_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, hipStream_t stream);
 
+/* ---- agent update: training-mode forward, backward, optimizer ------------------ */
+/* The reference trains CMRAgent with `agent.train(); loss.backward(); optimizer.step()` on minibatches of 10 buffered
+ * samples (Train_Agent.py:256-305).  There is no FFI to mirror; these entry points are what the Python host layer
+ * (cmr_agent_amd/train/agent_update.py) calls in place of torch autograd.  Data-gradient contractions reuse the forward
+ * entry points (cmr_conv3x3_wino_nhwc_f32 / cmr_conv3x3_nhwc_f32 / cmr_linear_f32) with transposed weights. */
+
+/* nn.BatchNorm2d / nn.BatchNorm1d in train() mode (CMRAgent.py:35,41,47,53; PointNN.py:265,268,277 via CMRAgent.py:25-29)
+ * over a row map x [rows, C]: batch mean / biased variance per channel; stat [4][C] = (mean, rstd, gamma*rstd,
+ * beta - mean*gamma*rstd); running_mean / running_var (optional) are updated with `momentum` and the unbiased variance. */
+int64_t cmr_bn_workspace_bytes(int64_t rows, int C);
+int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C, float eps, float momentum, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float* stat, void* ws, int64_t ws_bytes,
+                     hipStream_t stream);
+/* y = LeakyReLU_slope(x * scale + shift + (res * rscale + rshift | res)): BatchNorm application + activation, and the
+ * `final_relu(net(x) + shortcut(x))` of ConvBNReLURes1D (PointNN.py:282).  Null scale / rscale = identity; slope 1 = none. */
+int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const float* shift, const float* res, int64_t ldres,
+                       const float* rscale, const float* rshift, float* y, int64_t ldy, int64_t rows, int C, float slope,
+                       hipStream_t stream);
+/* Backward of [BatchNorm(train) -> LeakyReLU]: dz = gradient w.r.t. the activation output z (z null: no activation),
+ * x = the BatchNorm input, stat from cmr_bn_stats_f32.  dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add),
+ * dgamma = sum dy xhat, dbeta = sum dy (written when non-null). */
+int64_t cmr_bn_bwd_workspace_bytes(int64_t rows, int C);
+int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
+                   const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                   int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream);
+/* dy = dz * LeakyReLU'(z) (+ add): activation backward where no BatchNorm sits in front (identity shortcut, PointNN.py:271). */
+int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,
+                    float* dy, int64_t lddy, int64_t rows, int C, hipStream_t stream);
+/* Backward of [LeakyReLU -> AvgPool2d(ph, pw)] (CMRAgent.py:38-39,44-45,50-51,56-57): g [B,H/ph,W/pw,C] -> dc [B,H,W,C]
+ * with d = the activation output. */
+int cmr_pool_act_bwd_f32(const float* g, const float* d, float* dc, int B, int H, int W, int C, int ph, int pw, float slope,
+                         hipStream_t stream);
+/* per-batch column sum; per-batch column max with the arg-max row (first index on ties, as torch.max(dim) on the CPU);
+ * backward of the max: dx[b, arg[b,c], c] += g[b,c]   (CMRAgent.py:95). */
+int64_t cmr_colarg_workspace_bytes(int B, int N, int C);
+int cmr_colsum_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C, hipStream_t stream);
+int cmr_colmax_arg_f32(const float* x, int64_t ldx, float* out, int32_t* arg, void* ws, int64_t ws_bytes, int B, int N, int C,
+                       hipStream_t stream);
+int cmr_add_at_arg_f32(float* dx, int64_t lddx, const int32_t* arg, const float* g, int64_t ldg, int B, int N, int C,
+                       hipStream_t stream);
+/* nn.Linear / 1x1 conv backward on a handful of rows (<= 1024; the layers after the global pools, CMRAgent.py:57-59,70-86):
+ * dYe = dY * LeakyReLU'(Y) (Y null: none); dW = dYe^T [X1|X2]; db = sum dYe; dX1 / dX2 (+)= dYe W. */
+int cmr_linear_bwd_small_f32(const float* x1, int64_t ldx1, int k1, const float* x2, int64_t ldx2, int k2, const float* y,
+                             int64_t ldy, float slope, const float* dy, int64_t lddy, const float* w, int64_t ldw, float* dw,
+                             int64_t lddw, float* db, float* dx1, int64_t lddx1, float* dx2, int64_t lddx2, int acc_dx, int rows,
+                             int n, hipStream_t stream);
+/* Loss of one minibatch and its gradient w.r.t. logits / value (Train_Agent.py:268-302 with CMRAgent.py:129-144):
+ * cross-entropy against the expert + alpha (PPO clip + w_value MSE - w_entropy entropy).  logits rows [B, d*S]; actions
+ * int64 [B,d]; old_logprob [B, dr+dt]; returns / adv [B]; out [8] = (loss, clone, policy, value, entropy, ppo, 0, 0);
+ * gradients are multiplied by grad_scale. */
+int cmr_agent_loss_f32(const float* r_logits, int64_t ldr, const float* t_logits, int64_t ldt, const float* value, int64_t ldv,
+                       const int64_t* expert_r, const int64_t* expert_t, const int64_t* act_r, const int64_t* act_t,
+                       const float* old_logprob, const float* returns, const float* adv, float* d_r, int64_t lddr, float* d_t,
+                       int64_t lddt, float* d_v, int64_t lddv, float* out, int B, int dr, int dt, int S, float alpha,
+                       float clip_eps, float w_value, float w_entropy, float grad_scale, hipStream_t stream);
+/* torch.optim.Adam step (Train_Agent.py:121-127, :305) over the flat parameter bucket: g <- grad_scale * g + wd * p;
+ * m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).  n % 4 == 0 (the bucket pads every tensor). */
+int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, hipStream_t stream);
+/* nn.Conv2d(3x3, stride 1, pad 1) weight gradient on the matrix cores: dw [Cout][Cin][3][3] = sum over the minibatch
+ * pixels of dy (x) shifted x (NHWC maps, W >= 2, Cin in {32,64,128}, Cout % 32 == 0). */
+int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
+                          int64_t ws_bytes, hipStream_t stream);
+/* nn.Conv1d(k=1) / nn.Linear weight gradient over a row map: dw [n][k] (+)= dy^T x  (n, k <= 128). */
+int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k);
+int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
+                         int64_t lddw, int accumulate, void* ws, int64_t ws_bytes, hipStream_t stream);
+/* nn.Conv2d weight [Cout][Cin][3][3] -> operand layouts of the forward kernels (w9 [9][Co'][Ci'] and the Winograd
+ * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]. */
+int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -540,17 +540,22 @@ def test_head_losses_and_metrics(ops):
         close(got, ref.reshape(1), 2e-5, "circle loss n=%d" % n)
 
 
-def test_nested_fork_join_under_graph_capture(ops):
+def test_nested_fork_join(ops):
     """utils/streams.py: a fork issued inside a branch of another fork gets side streams of its own nesting depth (round 1
-    handed it the stream it was running on, which is what failed under capture).  Capture a nested fork, replay it
-    twice, compare with the sequential result."""
+    handed it the stream it was running on).  Eager: the nested pattern runs on distinct streams and is correct.  Under
+    hipGraph capture ROCm 7.2 segfaults in hipStreamEndCapture on a nested fork even so (recorded in streams.py), hence the
+    inner fork is sequential there: capture + two replays of the same function must still be correct, with the OUTER
+    (flat, 3-way) fork captured as graph branches."""
     from cmr_agent_amd.utils import streams
     x = rnd(4096, 64, seed=5).to(DEV)
     w = [rnd(64, 64, seed=10 + i).to(DEV) for i in range(4)]
+    seen = []
 
     def work():
         def inner():
-            a, b = streams.fork_join(lambda: ops.linear(x, w[0]), lambda: ops.linear(x, w[1]), tag="t_inner")
+            seen.append(torch.cuda.current_stream())
+            a, b = streams.fork_join(lambda: (seen.append(torch.cuda.current_stream()), ops.linear(x, w[0]))[1],
+                                     lambda: ops.linear(x, w[1]), tag="t_inner")
             return a + b
         c, d, e = streams.fork_join(inner, lambda: ops.linear(x, w[2]), lambda: ops.linear(x, w[3]), tag="t_outer")
         return c + d + e
@@ -559,21 +564,24 @@ def test_nested_fork_join_under_graph_capture(ops):
     eager = work()
     torch.cuda.synchronize()
     assert torch.equal(eager, ref)
+    main = torch.cuda.current_stream()
+    assert seen[0] != main and seen[1] != main and seen[0] != seen[1]          # eager: outer side stream, inner side stream
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         work()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    del seen[:]
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         out = work()
+    assert seen[0] == seen[1]                                                  # captured: the inner fork stayed on its stream
     for _ in range(2):
         out.zero_()
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
-    assert len({streams._side_stream(x.device, 0, 0), streams._side_stream(x.device, 1, 0), torch.cuda.current_stream()}) == 3
 
 
 def test_argument_guards(ops):

@@ -1,0 +1,355 @@
+"""GPU tier, agent update path: every training-side entry point of libcmr_hip.so against plain torch-CPU
+autograd of the same op, then the whole minibatch update (train-mode forward, BC + PPO loss, backward into the flat
+gradient bucket, fused Adam) against oracle/train_oracle.py and the fixture generated from the reference's CMRAgent
+module + torch.optim.Adam (tests/golden/make_golden_train.py).
+
+Tolerances (fp32 GPU vs fp32 CPU): per op 2e-5 of the output scale; whole update: logits 1e-4 * max|ref|, every
+parameter gradient within 2e-4 of the largest gradient entry of the model (gradients of conv biases in front of a
+BatchNorm are mathematically zero: ~1e-7 noise on both sides); parameters after two Adam steps: see the comment in
+test_agent_update_matches_oracle_and_reference_fixture; losses of both steps 3e-4 relative."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases as C
+import golden_util as G
+from cmr_agent_amd.utils import hashfill
+from oracle import train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cmr_agent_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def close(got, ref, rtol=2e-5, name=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= rtol * scale, "%s: max|d| %.3e vs scale %.3e" % (name, err, scale)
+
+
+@pytest.mark.parametrize("rows,Cc", [(5000, 128), (777, 64), (3001, 8)])
+def test_batchnorm_train_forward_backward(ops, rows, Cc):
+    x = (rnd(rows, Cc, seed=1) * 2 + rnd(1, Cc, seed=2) * 3).requires_grad_(True)       # channel means well away from 0
+    gamma, beta = rnd(Cc, seed=3) + 1.5, rnd(Cc, seed=4)
+    rm, rv = rnd(Cc, seed=5), rnd(Cc, seed=6) + 1.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    gamma_r, beta_r = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.leaky_relu(F.batch_norm(x, rm_ref, rv_ref, gamma_r, beta_r, True, 0.1, 1e-5), 0.2)
+    dz = rnd(rows, Cc, seed=7)
+    y.backward(dz)
+    xd, rmd, rvd = x.detach().to(DEV), rm.to(DEV), rv.to(DEV)
+    stat = ops.bn_stats(xd, gamma.to(DEV), beta.to(DEV), rmd, rvd)
+    z = ops.affine_act(xd, stat[2], stat[3], slope=0.2)
+    close(z, y, name="bn+lrelu forward")
+    close(rmd, rm_ref, 1e-6, "running_mean")
+    close(rvd, rv_ref, 1e-5, "running_var")
+    dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    dx = ops.bn_bwd(dz.to(DEV), z, 0.2, xd, stat, dg, db)
+    close(dx, x.grad, 5e-5, "bn backward dx")
+    close(dg, gamma_r.grad, 5e-5, "dgamma")
+    close(db, beta_r.grad, 5e-5, "dbeta")
+    # no activation + accumulate input
+    x2 = x.detach().clone().requires_grad_(True)
+    F.batch_norm(x2, None, None, gamma, beta, True, 0.1, 1e-5).backward(dz)
+    add = rnd(rows, Cc, seed=8)
+    dx2 = ops.bn_bwd(dz.to(DEV), None, 1.0, xd, stat, None, None, add=add.to(DEV))
+    close(dx2, x2.grad + add, 5e-5, "bn backward (no act, add)")
+    close(ops.act_bwd(dz.to(DEV), z, 0.2, add=add.to(DEV)), dz * torch.where(y > 0, 1.0, 0.2) + add, name="act_bwd")
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 12, 20, 128, 128), (1, 9, 13, 64, 64), (3, 2, 3, 128, 128), (4, 32, 48, 128, 128), (2, 8, 16, 64, 128)])
+def test_conv3x3_weight_and_data_gradients(ops, B, H, W, cin, cout):
+    """wgrad on the matrix cores and dgrad = forward kernels with cmr_pack_conv3x3_f32(transpose=1) vs torch autograd."""
+    x = rnd(B, cin, H, W, seed=11).requires_grad_(True)
+    w = (rnd(cout, cin, 3, 3, seed=12) / 10).requires_grad_(True)
+    y = F.conv2d(x, w, None, 1, 1)
+    dy = rnd(B, cout, H, W, seed=13)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.detach().contiguous().to(DEV)
+    dw = torch.empty(cout * cin * 9, device=DEV)
+    ops.conv3x3_wgrad(xd, dyd, dw)
+    close(dw.view(cout, cin, 3, 3), w.grad, 3e-5, "conv wgrad")
+    w9, u = ops.pack_conv3x3(wd.view(-1), cout, cin)
+    close(ops.conv3x3(xd, w9, None, cout, 1, 1.0, u=u).permute(0, 3, 1, 2), y, 5e-5, "forward through packed weights")
+    w9t, ut = ops.pack_conv3x3(wd.view(-1), cout, cin, transpose=True)
+    dx = ops.conv3x3(dyd, w9t, None, cin, 1, 1.0, u=ut)
+    close(dx.permute(0, 3, 1, 2), x.grad, 5e-5, "conv dgrad")
+    ops.WINOGRAD = False
+    try:
+        dx2 = ops.conv3x3(dyd, w9t, None, cin, 1, 1.0)
+    finally:
+        ops.WINOGRAD = True
+    close(dx2.permute(0, 3, 1, 2), x.grad, 5e-5, "conv dgrad (direct kernel)")
+
+
+@pytest.mark.parametrize("rows,n,k", [(4001, 8, 8), (3000, 64, 8), (5555, 128, 64), (2048, 64, 128), (1000, 64, 64), (9000, 128, 128), (7, 128, 128)])
+def test_linear_weight_gradient(ops, rows, n, k):
+    dy, x = rnd(rows, n, seed=21), rnd(rows, k, seed=22)
+    ref = dy.double().t() @ x.double()
+    dw = torch.full((n, k + 4), 7.0, device=DEV)                      # row stride != k: a sub-block of a larger gradient matrix
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, dw.shape[1], n, k)
+    close(dw[:, :k], ref.float(), 2e-5, "linear wgrad")
+    assert float(dw[:, k:].min()) == 7.0
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, dw.shape[1], n, k, accumulate=True)
+    close(dw[:, :k], 2 * ref.float(), 2e-5, "linear wgrad accumulate")
+    # left part of a wider output, narrower k than the operand (the streamed half of a concatenated input)
+    if k >= 64:
+        dw2 = torch.zeros((n, k), device=DEV)
+        ops.linear_wgrad(dy.to(DEV), x.to(DEV)[:, :32], dw2, k, n, 32)
+        close(dw2[:, :32], (dy.double().t() @ x[:, :32].double()).float(), 2e-5, "linear wgrad, strided x")
+
+
+def test_column_reductions_pool_backward(ops):
+    B, N, Cc = 3, 1777, 64
+    x = rnd(B * N, Cc, seed=31)
+    x[5] = x[900]                                                       # exact ties: the first index must win
+    x[5, :8] = 5.0
+    x[900, :8] = 5.0
+    xd = x.to(DEV)
+    mx, arg = ops.colmax_arg(xd, B, N)
+    ref = x.view(B, N, Cc).max(dim=1)
+    assert torch.equal(mx.cpu(), ref[0]) and torch.equal(arg.cpu().long(), ref[1])
+    close(ops.colsum(xd, B, N), x.view(B, N, Cc).double().sum(1).float(), 1e-6, "colsum")
+    close(ops.colsum(xd[:, 32:], B, N), x[:, 32:].reshape(B, N, 32).double().sum(1).float(), 1e-6, "colsum of a column block")
+    g = rnd(B, Cc, seed=32)
+    dx = torch.zeros(B * N, Cc, device=DEV)
+    ops.add_at_arg(dx, arg, g.to(DEV), B, N)
+    xr = x.view(B, N, Cc).clone().requires_grad_(True)
+    xr.max(dim=1)[0].backward(g)
+    close(dx, xr.grad.view(B * N, Cc), 0, "max backward")
+    # [LeakyReLU -> AvgPool] backward, 2x2 and global
+    for ph, pw in ((2, 2), (6, 10)):
+        c = rnd(2, 128, 6, 10, seed=33).requires_grad_(True)
+        d = F.leaky_relu(c, 0.01)
+        y = F.avg_pool2d(d, (ph, pw))
+        gy = rnd(*y.shape, seed=34)
+        y.backward(gy)
+        got = ops.pool_act_bwd(gy.permute(0, 2, 3, 1).contiguous().to(DEV), d.detach().permute(0, 2, 3, 1).contiguous().to(DEV), ph, pw, 0.01)
+        close(got.permute(0, 3, 1, 2), c.grad, 1e-6, "pool+act backward %dx%d" % (ph, pw))
+
+
+def test_small_linear_backward(ops):
+    R, k1, k2, n = 10, 128, 128, 24
+    x1, x2 = rnd(R, k1, seed=41).requires_grad_(True), rnd(R, k2, seed=42).requires_grad_(True)
+    w, b = (rnd(n, k1 + k2, seed=43) / 8).requires_grad_(True), rnd(n, seed=44).requires_grad_(True)
+    y = F.leaky_relu(F.linear(torch.cat([x1, x2], 1), w, b), 0.01)
+    dy = rnd(R, n, seed=45)
+    y.backward(dy)
+    dw, db = torch.empty(n, k1 + k2, device=DEV), torch.empty(n, device=DEV)
+    dx1, dx2 = torch.ones(R, k1, device=DEV), torch.ones(R, k2, device=DEV)
+    wd = w.detach().to(DEV)
+    ops.linear_bwd_small(x1.detach().to(DEV), dy.to(DEV), wd, k1 + k2, n, y=y.detach().to(DEV), slope=0.01, x2=x2.detach().to(DEV), dw=dw,
+                         lddw=k1 + k2, db=db, dx1=dx1, dx2=dx2, acc_dx=True)
+    close(dw, w.grad, name="small dW"), close(db, b.grad, name="small db")
+    close(dx1, x1.grad + 1, name="small dX1 (accumulate)"), close(dx2, x2.grad + 1, name="small dX2 (accumulate)")
+
+
+def _loss_batch(B, seed, S=11):
+    g = torch.Generator().manual_seed(seed)
+    ri = lambda *s: torch.randint(0, S, s, generator=g)
+    return dict(expert_actions_r=ri(B, 1), expert_actions_t=ri(B, 2), action_r=ri(B, 1), action_t=ri(B, 2),
+                action_logprob=torch.rand(B, 3, generator=g) * 2.4 - 3.6, state_value_ref=torch.rand(B, 1, generator=g) * 2 - 1,
+                advantages=torch.rand(B, 1, generator=g) * 2 - 1)
+
+
+@pytest.mark.parametrize("B,alpha", [(10, 1.0), (4, 1.0), (37, 1.0), (10, 0.0)])
+def test_agent_loss_and_logit_gradients(ops, B, alpha):
+    from cmr_agent_amd.config import KittiConfiguration
+    cfg = KittiConfiguration(device="cpu")
+    cfg.alpha = alpha
+    S = cfg.num_steps
+    b = _loss_batch(B, 50 + B)
+    r = (rnd(B, 1, S, seed=51) * 3).requires_grad_(True)
+    t = (rnd(B, 2, S, seed=52) * 3).requires_grad_(True)
+    v = rnd(B, 1, 1, seed=53).requires_grad_(True)
+    ref = TO.agent_losses(r, t, v, b, cfg)
+    ref["loss"].backward()
+    pad = lambda x, n: F.pad(x.detach().reshape(B, -1), (0, n - x[0].numel())).contiguous().to(DEV)
+    dev = lambda x: x.contiguous().to(DEV)
+    out, d_r, d_t, d_v = ops.agent_loss(pad(r, 12), pad(t, 24), pad(v, 4), dev(b["expert_actions_r"]), dev(b["expert_actions_t"]),
+                                        dev(b["action_r"]), dev(b["action_t"]), dev(b["action_logprob"]), dev(b["state_value_ref"]),
+                                        dev(b["advantages"]), 1, 2, S, alpha, cfg.CLIP_EPS, cfg.W_VALUE, cfg.W_ENTROPY)
+    out = out.cpu()
+    names = ("loss", "clone_loss") + (("policy_loss", "value_loss", "entropy_loss", "ppo_loss") if alpha > 0 else ())
+    for i, k in enumerate(names):
+        assert abs(float(out[i]) - float(ref[k])) <= 2e-5 * max(1.0, abs(float(ref[k]))), (k, float(out[i]), float(ref[k]))
+    close(d_r[:, :S], r.grad.view(B, S), 3e-5, "d r_logits")
+    close(d_t[:, :2 * S], t.grad.view(B, 2 * S), 3e-5, "d t_logits")
+    close(d_v[:, :1], v.grad.view(B, 1) if v.grad is not None else torch.zeros(B, 1), 3e-5, "d value")
+    assert float(d_r[:, S:].abs().max()) == 0 and float(d_t[:, 2 * S:].abs().max()) == 0
+
+
+def test_fused_adam_matches_torch(ops):
+    n = 4096 + 8
+    p0, grads = rnd(n, seed=61), [rnd(n, seed=62 + i) * (10.0 ** (i - 1)) for i in range(3)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.99), weight_decay=1e-6)
+    p, m, v = p0.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for i, g in enumerate(grads):
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam(p, (g * 4).to(DEV), m, v, 1e-3, 0.9, 0.99, 1e-8, 1e-6, i + 1, grad_scale=0.25)    # 4 ranks summed, scaled back
+    assert float((p.cpu() - ref.data).abs().max()) < 2e-7
+
+
+def test_flat_bucket_keeps_module_api():
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train import FlatBucket
+    cfg = C.train_config("agent_train_small", device=DEV)
+    agent = CMRAgent(cfg)
+    sd0 = hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG)
+    agent.load_state_dict(sd0, strict=False)
+    agent = agent.to(DEV)
+    bucket = FlatBucket(agent)
+    sd = agent.state_dict()
+    for k, v in sd0.items():
+        if not k.endswith("num_batches_tracked"):
+            assert torch.equal(sd[k].cpu(), v), k
+    total = sum(p.numel() for p in agent.parameters())
+    assert total == 1608714 and bucket.numel >= total and bucket.numel % 4 == 0
+    bucket.check_attached()
+    agent.load_state_dict({k: v * 2 for k, v in sd0.items()}, strict=False)            # in place: still in the bucket
+    bucket.check_attached()
+    assert abs(float(bucket.params.double().sum()) - 2 * sum(float(v.double().sum()) for k, v in sd0.items() if TO.is_parameter(k))) < 1e-2
+    w = bucket.w("state_3d_embed.0.net.0.weight")
+    assert tuple(w.shape) == (8, 8) and float(w[5:].abs().max()) == 0 and float(w[:, 5:].abs().max()) == 0
+
+
+def _product_agent(cfg):
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.utils.checkpoint import load_checked
+    agent = CMRAgent(cfg)
+    load_checked(agent, hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG))
+    return agent.to(DEV)
+
+
+def _to_dev(batch):
+    return {k: v.to(DEV) for k, v in batch.items()}
+
+
+def _compare_grads(got, ref, tol_frac):
+    gmax = max(float(g.abs().max()) for g in ref.values())
+    bad = []
+    for k, r in ref.items():
+        err = float((got[k].cpu().double() - r.double()).abs().max())
+        if err > tol_frac * gmax:
+            bad.append("%s: max|d| %.3e (|g|max %.3e, model max %.3e)" % (k, err, float(r.abs().max()), gmax))
+    return bad
+
+
+def test_agent_update_matches_oracle_and_reference_fixture():
+    """The whole minibatch update on agent_train_small vs the oracle (full tensors) and the reference-generated fixture."""
+    from cmr_agent_amd.train import AgentUpdate
+    case = "agent_train_small"
+    cfg_d, cfg_c = C.train_config(case, device=DEV), C.train_config(case)
+    batches = C.train_inputs(case)
+    sd0 = {k: v for k, v in hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG).items() if not k.endswith("num_batches_tracked")}
+    # ---- one forward / backward
+    agent = _product_agent(cfg_d)
+    up = AgentUpdate(agent, cfg_d)
+    losses, (r, t, v) = up.forward_backward(_to_dev(batches[0]))
+    torch.cuda.synchronize()
+    ol, og, (orr, ot, ov) = TO.agent_forward_backward({k: x.clone() for k, x in sd0.items()}, batches[0], cfg_c, True)
+    for got, ref, name in ((r, orr, "r_logits"), (t, ot, "t_logits"), (v, ov, "value")):
+        close(got, ref, 1e-4, name)
+    lv = losses.cpu()
+    for i, k in enumerate(("loss", "clone_loss", "policy_loss", "value_loss", "entropy_loss", "ppo_loss")):
+        assert abs(float(lv[i]) - float(ol[k])) <= 1e-4 * max(1.0, abs(float(ol[k]))), (k, float(lv[i]), float(ol[k]))
+    bad = _compare_grads(up.bucket.logical_grads(), og, 2e-4)
+    assert not bad, "gradients vs oracle autograd:\n  " + "\n  ".join(bad)
+    # running statistics moved like the reference's BatchNorm layers
+    osd_one, _ = TO.adam_train(sd0, batches[:1], cfg_c, True)
+    sd1 = agent.state_dict()
+    for k in osd_one:
+        if k.endswith(("running_mean", "running_var")):
+            close(sd1[k], osd_one[k], 1e-5, k)
+    # ---- two optimizer steps from scratch
+    agent2 = _product_agent(cfg_d)
+    up2 = AgentUpdate(agent2, cfg_d)
+    hist = [up2.step(_to_dev(b)).cpu() for b in batches]
+    torch.cuda.synchronize()
+    osd, ohist = TO.adam_train(sd0, batches, cfg_c, True)
+    sd2 = {k: x.detach().cpu() for k, x in agent2.state_dict().items() if not k.endswith("num_batches_tracked")}
+    # Parameters after two Adam steps.  Adam's first steps move a weight by ~lr * sign(g): where the true gradient is
+    # ZERO -- the bias of a conv that feeds a BatchNorm (the batch mean removes it) -- both sides step along fp32 rounding
+    # noise, so those biases (and the running means that carry them) random-walk by up to lr per step on either side and
+    # are compared against that bound only; everything else must agree tightly, bar the rare weight whose gradient is
+    # itself at noise level (bounded as a fraction).
+    lr, nst = cfg_c.lr, len(batches)
+    zero_grad_bias = {"state_2d_embed.%d.bias" % i for i in (0, 6, 12, 18)}
+    for i in range(4):
+        zero_grad_bias |= {"state_3d_embed.%d.net.0.bias" % i, "state_3d_embed.%d.net.3.bias" % i, "state_3d_embed.%d.shortcut.0.bias" % i}
+    n_all = n_bad = 0
+    for k in osd:
+        d = (sd2[k].double() - osd[k].double()).abs()
+        if k in zero_grad_bias or k.endswith("running_mean"):
+            assert float(d.max()) <= 2.2 * lr * nst, (k, float(d.max()))
+        elif k.endswith("running_var"):
+            assert float(d.max()) <= 2e-4 * max(1.0, float(osd[k].abs().max())), (k, float(d.max()))
+        else:
+            assert float(d.max()) <= 2.2 * lr * nst, (k, float(d.max()))
+            n_all += d.numel()
+            n_bad += int((d > 2e-5).sum())
+    assert n_bad <= 1e-3 * n_all, "parameters after two Adam steps: %d of %d differ by more than 2e-5" % (n_bad, n_all)
+    for i, h in enumerate(ohist):
+        assert abs(float(hist[i][0]) - float(h["loss"])) <= 2e-4 * max(1.0, abs(float(h["loss"]))), (i, float(hist[i][0]), float(h["loss"]))
+    # ---- the fixture generated from the reference's own module + torch.optim.Adam: logits of the first forward, losses of
+    # both steps (the second one is computed with the updated weights)
+    fx = G.load_case(case + "_trainbn")
+    e = G.compare("r_logits", r.cpu(), fx["r_logits"], 1e-4 * float(abs(fx["r_logits"]["sample"]).max()), 0)
+    assert e is None, e
+    for i in range(nst):
+        for j, name in enumerate(("loss", "clone_loss", "policy_loss", "value_loss", "entropy_loss", "ppo_loss")):
+            want = float(fx["step%d/%s" % (i, name)]["sample"][0])
+            assert abs(float(hist[i][j]) - want) <= 3e-4 * max(1.0, abs(want)), (i, name, float(hist[i][j]), want)
+    # after the update the inference path (eval mode: BN folded into packed weight plans) must see the NEW weights: the
+    # updated agent in eval mode == a fresh module loaded with its state dict (same kernels -> tight)
+    agent2.eval()
+    fresh = _product_agent(cfg_d)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in agent2.state_dict().items()})
+    fresh.eval()
+    s2d, s3d = batches[0]["states_2d"].to(DEV), batches[0]["states_3d"].to(DEV)
+    with torch.no_grad():
+        r_a, t_a, v_a = agent2(s2d, s3d)
+        r_f, t_f, v_f = fresh(s2d, s3d)
+        r_0, _, _ = _product_agent(cfg_d).eval()(s2d, s3d)
+    close(r_a, r_f, 1e-6, "eval-mode forward after the update vs a fresh module with the same weights")
+    close(t_a, t_f, 1e-6, "t"), close(v_a, v_f, 1e-6, "v")
+    assert float((r_a - r_0).abs().max()) > 1e-3 * float(r_0.abs().max())      # and the update did change the policy
+    rr, _, _ = TO.O.cmr_agent(osd, batches[0]["states_2d"], batches[0]["states_3d"], cfg_c)
+    close(r_a, rr, 5e-3, "eval-mode forward after the update vs the oracle's updated weights (running means carry the bias walk)")
+
+
+def test_buffer_ordering_quirk_on_device():
+    """Buffer.get_samples() of the product (device tensors) vs the fixture made with the reference's Buffer."""
+    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.environment.buffer import Buffer
+    cfg = KittiConfiguration(device=DEV)
+    buf = Buffer(cfg)
+    for traj in C.buffer_inputs():
+        buf.start_trajectory()
+        for s in traj:
+            d = {k: v.to(DEV) for k, v in s.items()}
+            buf.log_step(d["state_2d"], d["state_3d"], d["state_value"], d["reward"], d["expert_action_r"], d["expert_action_t"],
+                         d["action_r"], d["action_t"], d["action_logprob"])
+    names = ("states_2d", "states_3d", "state_values", "expert_actions_r", "expert_actions_t", "actions_r", "actions_t",
+             "actions_logprob", "returns", "advantages")
+    G.assert_case("buffer_order", dict(zip(names, buf.get_samples())), atol=1e-5, rtol=1e-5)
