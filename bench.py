@@ -139,14 +139,78 @@ def cpu_baseline(spec, budget_s=20.0):
                        "torch CPU fp32" % (n, w["steps"], w["H"], w["W"], w["N"]))
 
 
+def train_main(args):
+    """--mode train: the agent update of Train_Agent.py:263-305 at the headline map size.  One STEP =
+    one minibatch of 10 buffered observations per GPU (the reference's PPO minibatch, Train_Agent.py:260) through
+    cmr_agent_amd.train.AgentUpdate: train-mode forward, BC + PPO loss, HIP backward into the flat gradient bucket, ONE
+    RCCL all-reduce of the bucket (N > 1), fused Adam.  Prints one JSON line with the whole-job samples/s and the
+    all-reduce time per step (HIP events around the collective)."""
+    from cmr_agent_amd.train import AgentUpdate
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ranks = Ranks(backend="nccl", device=dev)
+    w = WORKLOAD
+    cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
+    agent = CMRAgent(cfg)
+    load_checked(agent, hashfill.make_state_dict(spec["agent"], AGENT_TAG))
+    agent = agent.to(dev)
+    up = AgentUpdate(agent, cfg, dist=ranks.dist)
+    MB, h, wd, S = 10, cfg.image_H, cfg.image_W, cfg.num_steps
+    g = torch.Generator().manual_seed(ranks.shard_seed(cfg.seed))
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    s3 = torch.cat([rnd(MB, 3, w["N"]) * 80 - 40, (rnd(MB, 2, w["N"]) > 0.5).float()], 1)
+    batch = dict(states_2d=(rnd(MB, h, wd, 128) * 0.4 - 0.2).to(dev).permute(0, 3, 1, 2), states_3d=s3.to(dev),
+                 expert_actions_r=torch.randint(0, S, (MB, 1), generator=g).to(dev), expert_actions_t=torch.randint(0, S, (MB, 2), generator=g).to(dev),
+                 action_r=torch.randint(0, S, (MB, 1), generator=g).to(dev), action_t=torch.randint(0, S, (MB, 2), generator=g).to(dev),
+                 action_logprob=(rnd(MB, 3) * 2.4 - 3.6).to(dev), state_value_ref=(rnd(MB, 1) * 2 - 1).to(dev),
+                 advantages=(rnd(MB, 1) * 2 - 1).to(dev))
+    for _ in range(args.warmup):
+        up.step(batch)
+    ranks.barrier()
+    ar_ms, t0 = 0.0, time.perf_counter()
+    for _ in range(args.steps):
+        losses = up.step(batch)
+        if world > 1:
+            ar_ms += up.allreduce_ms()
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    assert torch.isfinite(losses).all()
+    if ranks.rank == 0:
+        # dense work of one update: forward convs + data gradients + weight gradients of the eight 128->128 3x3 convolutions
+        # (no data gradient for the first one) and of the 1x1 stacks of the 3-D branch
+        conv_f = sum(2.0 * 9 * 128 * 128 * MB * (h >> s) * (wd >> s) * 2 for s in range(4))
+        flops = conv_f * 3 - 2.0 * 9 * 128 * 128 * MB * h * wd
+        print(json.dumps({
+            "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
+            "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "agent update: minibatch of 10 observations [128,88,304] + [5,16384] per GPU, BC + PPO loss, "
+                                   "Adam (lr 1e-3, betas .9/.99, wd 1e-6)", "minibatch_per_gpu": MB,
+                       "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
+            "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
+            "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
+            "loss": float(losses[0])}))
+    ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=("register", "train"), default="register",
+                    help="register (default): the headline registration iteration; train: the agent's minibatch update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     args = ap.parse_args()
+    if args.mode == "train":
+        return train_main(args)
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -43,3 +43,82 @@ def test_two_rank_protocol():
     assert res[0][0] != res[1][0]                 # different shards per rank
     assert res[0][1] == res[1][1] == 2.0          # MAX over ranks
     assert res[0][2] == res[1][2] == 2 * 40 / 2.0  # whole-job units / max time
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# data-parallel agent update: ONE all-reduce of the flat gradient bucket per optimizer step
+# ----------------------------------------------------------------------------------------------------------------------
+def _dp_worker(rank, world, port, out):
+    """Each rank owns half of every minibatch.  The gradients come from the CPU oracle (the HIP backward cannot run
+    here), everything else is the product's data-parallel machinery: FlatBucket layout, its all-reduce over gloo, the
+    1 / world scaling that the fused Adam kernel applies (here: torch.optim.Adam on the flat tensor, the same formula)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import json
+    import cases as C
+    import golden_util as G
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train.flatbucket import FlatBucket
+    from cmr_agent_amd.utils import hashfill
+    from cmr_agent_amd.utils.checkpoint import load_checked
+    from cmr_agent_amd.utils.dist import Ranks
+    from oracle import train_oracle as TO
+    torch.set_num_threads(2)
+    r = Ranks(backend="gloo", device=torch.device("cpu"))
+    specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+    cfg = C.train_config("agent_train_small")
+    agent = CMRAgent(cfg)
+    load_checked(agent, hashfill.make_state_dict(specs["agent"], C.AGENT_TAG))
+    bucket = FlatBucket(agent)
+    flat = torch.nn.Parameter(bucket.params)                     # shares the bucket's storage
+    opt = torch.optim.Adam([flat], lr=cfg.lr, betas=(0.9, 0.99), weight_decay=cfg.weight_decay)
+    for batch in C.train_inputs("agent_train_small"):
+        B = batch["states_2d"].shape[0]
+        lo, hi = rank * B // world, (rank + 1) * B // world
+        shard = {k: v[lo:hi] for k, v in batch.items()}
+        sd = {k: v.detach().clone() for k, v in agent.state_dict().items() if not k.endswith("num_batches_tracked")}
+        _, grads, _ = TO.agent_forward_backward(sd, shard, cfg, bn_training=False)
+        bucket.grads.zero_()
+        for k, g in bucket.logical_grads().items():
+            g.copy_(grads[k])
+        n = bucket.all_reduce(r.dist)                            # the ONE collective of the step
+        flat.grad = bucket.grads / n
+        opt.step()
+    out[rank] = (bucket.numel, bucket.params.clone().numpy(), {k: v.detach().clone().numpy() for k, v in agent.state_dict().items()})
+    r.close()
+
+
+def test_data_parallel_update_equals_single_rank_on_the_concatenated_batch():
+    """World 2 over gloo, two optimizer steps, BatchNorm in eval mode (with batch statistics the two halves normalise
+    differently, as torch DDP without SyncBN does): both ranks end with bit-identical parameters, equal to a single
+    process that sees the whole minibatch (up to fp32 summation order, which Adam turns into +-lr on the rare weight whose
+    gradient is at rounding-noise level)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases as C
+    import golden_util as G
+    from cmr_agent_amd.utils import hashfill
+    from oracle import train_oracle as TO
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    n0, flat0, sd_a = res[0]
+    n1, flat1, sd_b = res[1]
+    assert n0 == n1 and n0 % 4 == 0
+    assert (flat0 == flat1).all()                                 # bit-identical buckets on both ranks
+    specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+    cfg = C.train_config("agent_train_small")
+    sd0 = {k: v for k, v in hashfill.make_state_dict(specs["agent"], C.AGENT_TAG).items() if not k.endswith("num_batches_tracked")}
+    single, _ = TO.adam_train(sd0, C.train_inputs("agent_train_small"), cfg, bn_training=False)
+    n_all = n_bad = 0
+    for k, v in single.items():
+        d = (torch.from_numpy(sd_a[k]).double() - v.double()).abs()
+        assert float(d.max()) <= 2.2 * cfg.lr * 2, (k, float(d.max()))
+        n_all += d.numel()
+        n_bad += int((d > 2e-6).sum())
+    assert n_bad <= 2e-3 * n_all, (n_bad, n_all)
+    moved = max(float((torch.from_numpy(sd_a[k]).double() - sd0[k].double()).abs().max()) for k in single)
+    assert moved > 1e-3                                           # and the update did move the weights
