@@ -57,16 +57,27 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_partial_kernel(const flo
   }
 }
 
-__global__ void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ part, int nblk, int64_t rows, int C,
-                                      float eps, float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ stat) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// sum over a wave of doubles, same value in every lane afterwards (fixed butterfly order: deterministic)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per channel: lane l adds partials l, l + 64, ... in double, then a butterfly over the wave
+__global__ __launch_bounds__(64) void bn_stats_final_kernel(const float* __restrict__ x, const float* __restrict__ part, int nblk, int64_t rows,
+                                                            int C, float eps, float momentum, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float* __restrict__ stat) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     s += (double)part[(int64_t)b * 2 * C + c];
     ss += (double)part[(int64_t)b * 2 * C + C + c];
   }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane != 0) return;
   const double n = (double)rows;
   const double pm = s / n;
   double var = ss / n - pm * pm;
@@ -146,15 +157,17 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float
 }
 
 // coef[0][c] = sum dy / n, coef[1][c] = sum dy xhat / n;  dgamma / dbeta written (or accumulated) into the gradient bucket
-__global__ void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int64_t rows, int C, float* __restrict__ coef,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restrict__ part, int nblk, int64_t rows, int C, float* __restrict__ coef,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, sx = 0.0;
-  for (int b = 0; b < nblk; ++b) {
+  for (int b = lane; b < nblk; b += 64) {
     s += (double)part[(int64_t)b * 2 * C + c];
     sx += (double)part[(int64_t)b * 2 * C + C + c];
   }
+  s = wave_sum(s);
+  sx = wave_sum(sx);
+  if (lane != 0) return;
   coef[c] = (float)(s / (double)rows);
   coef[C + c] = (float)(sx / (double)rows);
   if (dbeta) dbeta[c] = (float)s;
@@ -277,25 +290,34 @@ __global__ __launch_bounds__(RED_THREADS) void col_partial_kernel(const float* _
   }
 }
 
+// one wave per (batch, channel): lane l folds partials l, l + 64, ..., then a butterfly over the wave
 template <bool MAXARG>
-__global__ void col_final_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int nblk, int C, float* __restrict__ out,
-                                 int32_t* __restrict__ arg) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void col_final_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi, int nblk, int C,
+                                                       float* __restrict__ out, int32_t* __restrict__ arg) {
+  const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   if (MAXARG) {
     float a = -INFINITY;
     int ia = 0x7fffffff;
-    for (int k = 0; k < nblk; ++k) {
+    for (int k = lane; k < nblk; k += 64) {
       const float v = pv[((int64_t)b * nblk + k) * C + c];
       const int iv = pi[((int64_t)b * nblk + k) * C + c];
       if (v > a || (v == a && iv < ia)) { a = v; ia = iv; }
     }
-    out[(int64_t)b * C + c] = a;
-    arg[(int64_t)b * C + c] = ia;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v = __shfl_xor(a, o, 64);
+      const int iv = __shfl_xor(ia, o, 64);
+      if (v > a || (v == a && iv < ia)) { a = v; ia = iv; }
+    }
+    if (lane == 0) {
+      out[(int64_t)b * C + c] = a;
+      arg[(int64_t)b * C + c] = ia;
+    }
   } else {
     double a = 0.0;
-    for (int k = 0; k < nblk; ++k) a += (double)pv[((int64_t)b * nblk + k) * C + c];
-    out[(int64_t)b * C + c] = (float)a;
+    for (int k = lane; k < nblk; k += 64) a += (double)pv[((int64_t)b * nblk + k) * C + c];
+    a = wave_sum(a);
+    if (lane == 0) out[(int64_t)b * C + c] = (float)a;
   }
 }
 
@@ -493,7 +515,7 @@ extern "C" int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C
   const int nb = red_blocks(rows, C);
   CMR_REQUIRE(ws_bytes >= (int64_t)nb * 2 * C * (int64_t)sizeof(float));
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, stream, x, ldx, rows, C, (float*)ws);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, x, (const float*)ws, nb, rows, C, eps, momentum,
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(64), 0, stream, x, (const float*)ws, nb, rows, C, eps, momentum,
                      gamma, beta, running_mean, running_var, stat);
   return cmr_launch_status();
 }
@@ -522,7 +544,7 @@ extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int
   float* part = (float*)ws;
   float* coef = part + (int64_t)nb * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat, rows, C, part);
-  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, (const float*)part, nb, rows, C, coef, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, stream, (const float*)part, nb, rows, C, coef, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat,
                      (const float*)coef, add, ldadd, dx, lddx, rows, C);
   return cmr_launch_status();
@@ -565,7 +587,7 @@ extern "C" int cmr_colsum_f32(const float* x, int64_t ldx, float* out, void* ws,
   const int nb = col_blocks(N, C);
   CMR_REQUIRE(ws_bytes >= (int64_t)B * nb * C * 4);
   hipLaunchKernelGGL(col_partial_kernel<false>, dim3(nb, B), dim3(RED_THREADS), 0, stream, x, ldx, N, C, (float*)ws, (int32_t*)nullptr);
-  hipLaunchKernelGGL(col_final_kernel<false>, dim3((C + 63) / 64, B), dim3(64), 0, stream, (const float*)ws, (const int32_t*)nullptr, nb, C,
+  hipLaunchKernelGGL(col_final_kernel<false>, dim3(C, B), dim3(64), 0, stream, (const float*)ws, (const int32_t*)nullptr, nb, C,
                      out, (int32_t*)nullptr);
   return cmr_launch_status();
 }
@@ -578,7 +600,7 @@ extern "C" int cmr_colmax_arg_f32(const float* x, int64_t ldx, float* out, int32
   float* pv = (float*)ws;
   int32_t* pi = (int32_t*)(pv + (int64_t)B * nb * C);
   hipLaunchKernelGGL(col_partial_kernel<true>, dim3(nb, B), dim3(RED_THREADS), 0, stream, x, ldx, N, C, pv, pi);
-  hipLaunchKernelGGL(col_final_kernel<true>, dim3((C + 63) / 64, B), dim3(64), 0, stream, (const float*)pv, (const int32_t*)pi, nb, C, out,
+  hipLaunchKernelGGL(col_final_kernel<true>, dim3(C, B), dim3(64), 0, stream, (const float*)pv, (const int32_t*)pi, nb, C, out,
                      arg);
   return cmr_launch_status();
 }

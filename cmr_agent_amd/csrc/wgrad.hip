@@ -49,6 +49,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
   int xx = p % W, t_ = p / W, yy = t_ % H, bb = t_ / H;
 
   float a_cur, v_cur[9], a_nxt = 0.f, v_nxt[9];
+  // Addresses: any linear pixel index clamped to [0, last_pix] is readable; whether a tap lies inside the image is decided
+  // by the masks (3 row tests x 3 column tests), so the loads need one add and one clamp each and no 2-D arithmetic.
   auto load = [&](float& a, float (&v)[9], int bq, int yq, int xq) {
     const int base = (bq * H + yq) * W + xq;
     a = db[(int64_t)min(base, last_pix) * Cout];
@@ -57,20 +59,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int y2 = yq + ky - 1, x2 = xq + kx - 1;
-        const int yc = min(max(y2, 0), H - 1), xc = min(max(x2, 0), W - 1);
-        const int pix = min((bq * H + yc) * W + xc, last_pix);
+        const int pix = min(max(base + (ky - 1) * W + (kx - 1), 0), last_pix);
         v[ky * 3 + kx] = xb[(int64_t)pix * Cin];
       }
   };
   auto mask = [&](float (&v)[9], int yq, int xq) {
+    const bool oy[3] = {yq > 0, true, yq < H - 1};
+    const bool ox[3] = {xq > 0, true, xq < W - 1};
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const bool ok = (unsigned)(yq + ky - 1) < (unsigned)H && (unsigned)(xq + kx - 1) < (unsigned)W;
-        v[ky * 3 + kx] = ok ? v[ky * 3 + kx] : 0.f;
-      }
+      for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = (oy[ky] && ox[kx]) ? v[ky * 3 + kx] : 0.f;
   };
 
   if (w0 < w1) {
@@ -101,15 +100,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     }
 }
 
+// Sum of the per-wave partial outputs.  Workgroup = 32 consecutive outputs x 8 slice groups: thread (o, g) adds slices
+// g, g + 8, ... in double (coalesced over o), the 8 group sums are combined through LDS in a fixed order.
+constexpr int RED_OUT = 32, RED_GRP = 8;
+
 __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* __restrict__ part, int nslices, int Cout, int Cin,
                                                                    float* __restrict__ dw) {
+  __shared__ double sm[RED_GRP][RED_OUT];
   const int total = 9 * Cout * Cin;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
+  const int o = threadIdx.x % RED_OUT, g = threadIdx.x / RED_OUT;
+  const int i = blockIdx.x * RED_OUT + o;
   double s = 0.0;
-  for (int k = 0; k < nslices; ++k) s += (double)part[(int64_t)k * total + i];
-  dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)s;
+  if (i < total)
+    for (int k = g; k < nslices; k += RED_GRP) s += (double)part[(int64_t)k * total + i];
+  sm[g][o] = s;
+  __syncthreads();
+  if (g == 0 && i < total) {
+#pragma unroll
+    for (int k = 1; k < RED_GRP; ++k) s += sm[k][o];
+    const int ci = i % Cin, co = (i / Cin) % Cout, tap = i / (Cin * Cout);
+    dw[((int64_t)co * Cin + ci) * 9 + tap] = (float)s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -198,13 +209,21 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, int nslices, int npad, int kpad, int n, int k,
                                                                   float* __restrict__ dw, int64_t lddw, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n * k) return;
+  __shared__ double sm[RED_GRP][RED_OUT];
+  const int o = threadIdx.x % RED_OUT, g = threadIdx.x / RED_OUT;
+  const int i = blockIdx.x * RED_OUT + o;
   const int row = i / k, col = i - row * k;
   double s = 0.0;
-  for (int j = 0; j < nslices; ++j) s += (double)part[((int64_t)j * npad + row) * kpad + col];
-  float* d = dw + (int64_t)row * lddw + col;
-  *d = accumulate ? *d + (float)s : (float)s;
+  if (i < n * k)
+    for (int j = g; j < nslices; j += RED_GRP) s += (double)part[((int64_t)j * npad + row) * kpad + col];
+  sm[g][o] = s;
+  __syncthreads();
+  if (g == 0 && i < n * k) {
+#pragma unroll
+    for (int j = 1; j < RED_GRP; ++j) s += sm[j][o];
+    float* d = dw + (int64_t)row * lddw + col;
+    *d = accumulate ? *d + (float)s : (float)s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -285,7 +304,7 @@ extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
   else
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
-  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + 255) / 256), dim3(256), 0, stream, (const float*)part,
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
                      slices * nsplit, Cout, Cin, dw);
   return cmr_launch_status();
 }
@@ -316,7 +335,7 @@ extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const 
   else if (ntp == 4 && ktp == 2) CMR_LW(4, 2);
   else CMR_LW(4, 4);
 #undef CMR_LW
-  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n * k + 255) / 256), dim3(256), 0, stream, (const float*)part, slices * (4 / ntp),
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n * k + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part, slices * (4 / ntp),
                      ntp * 32, ktp * 32, n, k, dw, lddw, accumulate);
   return cmr_launch_status();
 }
