@@ -33,6 +33,7 @@ from cmr_agent_amd.runtime import RegistrationGraph  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
 from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
 from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
+from cmr_agent_amd.utils.workmodel import CallTimer  # noqa: E402
 
 WORKLOAD = dict(B=8, N=16384, H=352, W=1216, M=1280, steps=10)
 GEO_TAG, AGENT_TAG = "geo4/", "agent/"
@@ -78,42 +79,6 @@ def registration_step(geo, agent, cfg, batch):
         ar, at = agent.action_from_logits(r, t, deterministic=True)
         pose = env.step(ar, at, pose, cfg)
     return pose.cpu()                                   # final pose D2H (Test_Agent.py:185)
-
-
-class ConvTimer:
-    """HIP-event timing of every stride-1 conv3x3 launch on the launch stream (torch's current stream)."""
-
-    def __init__(self):
-        self.records = []
-        self._orig = ops.conv3x3
-
-    def __enter__(self):
-        def timed(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None):
-            B, H, W, cin = x.shape
-            wino = (ops.WINOGRAD and u is not None and stride == 1 and out is None
-                    and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= ops.WINO_MIN_TILES)      # ops.conv3x3 dispatch
-            if not wino:       # stride-2 and small-map launches run the other conv kernels
-                return self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool, u)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            y = self._orig(x, w9, bias, cout, stride, slope, res, post, out, pool, u)
-            e1.record()
-            flops = 2.0 * 9 * cin * cout * B * H * W
-            # algorithmic bytes: input once, output once, residual/table once, weights once
-            nbytes = 4.0 * (B * H * W * (cin + cout * (2 if res is not None else 1) / (pool * pool)) + 9 * cin * cout)
-            self.records.append((e0, e1, flops, nbytes))
-            return y
-        ops.conv3x3 = timed
-        return self
-
-    def __exit__(self, *a):
-        ops.conv3x3 = self._orig
-
-    def summary(self):
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
-        fl = sum(r[2] for r in self.records)
-        by = sum(r[3] for r in self.records)
-        return dict(launches=len(self.records), ms=ms, flops=fl, bytes=by)
 
 
 def cpu_baseline(spec, budget_s=20.0):
@@ -248,7 +213,7 @@ def main():
             pose = run_step()
         barrier()
         elapsed = time.perf_counter() - t0
-        with ConvTimer() as ct:                          # HIP events around every tiled conv3x3 launch
+        with CallTimer() as ct:                          # HIP events around EVERY C-ABI call, with its algorithmic work
             for _ in range(args.steps):
                 registration_step(geo, agent, cfg, batch)
             torch.cuda.synchronize()
@@ -256,7 +221,16 @@ def main():
     elapsed = ranks.max_over_ranks(elapsed)
 
     if rank == 0:
-        conv = ct.summary()
+        table = ct.table()
+        dom = [d for d in table if d["name"] == "cmr_conv3x3_wino_nhwc_f32"][0]
+        conv = dict(launches=dom["calls"], ms=dom["ms"], flops=dom["flops"], bytes=dom["bytes"])
+        sum_ideal = sum(d["ideal_ms"] for d in table if d["modelled"])
+        sum_meas = sum(d["ms"] for d in table if d["modelled"])
+        unmodelled = [d["name"] for d in table if not d["modelled"]]
+        kernels = [dict(entry=d["name"], bound=d["bound"], calls_per_step=d["calls"] / args.steps, ms_per_step=round(d["ms"] / args.steps, 4),
+                        ideal_ms_per_step=round(d["ideal_ms"] / args.steps, 4), frac=round(d["frac"], 3),
+                        gflop_per_step=round(d["flops"] / args.steps / 1e9, 2), mb_per_step=round(d["bytes"] / args.steps / 1e6, 1))
+                   for d in table if d["modelled"]]
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes)
         traffic = None
@@ -290,6 +264,11 @@ def main():
                          "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                          "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9,
                          "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
+                         # sum over every entry point of its ideal time (algorithmic FLOPs / fp32 MFMA peak for
+                         # MFMA-class calls, algorithmic bytes / 8 TB/s for HBM-class ones) / sum of the measured times
+                         "path": sum_ideal / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
+                         "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled,
+                         "kernels": kernels[:14],
                          "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the "
                                      "side-stream branches of the forward run concurrently, as in the replayed graph)" % args.steps},
             "launch_mode": "eager" if args.eager else "hipGraph replay",

@@ -78,9 +78,10 @@ _ERR = {-1: "invalid argument (shape / alignment / null pointer)", -2: "kernel l
 UNSUPPORTED = -3
 
 
-def call(name, *args, allow_unsupported=False):
+def call(name, *args, allow_unsupported=False, work_extra=None):
     """Invoke an int-returning entry point; raises CmrError on a non-zero status
-    (returns UNSUPPORTED instead of raising when the caller has a fallback entry point)."""
+    (returns UNSUPPORTED instead of raising when the caller has a fallback entry point).
+    work_extra: sizes the arguments do not carry (rows behind a CSR), for utils/workmodel.CallTimer only."""
     rc = getattr(load(), name)(*args)
     if rc == UNSUPPORTED and allow_unsupported:
         return rc

@@ -243,21 +243,36 @@ __global__ __launch_bounds__(512) void cbr_block_kernel(const CbrArgs a) {
   }
 }
 
-// out[b][c] = max over the tiles of batch b of part[tile][c]  (tiles_per_batch consecutive tiles per batch)
-__global__ __launch_bounds__(1024) void colmax_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                               int tiles_per_batch, int C) {
-  __shared__ float sm[1024];
+// out[b][c] = max over the tiles of batch b of part[tile][c]  (tiles_per_batch consecutive tiles per batch).
+// Two launches: out <- -inf, then gridDim.z tile chunks per (batch, 64-channel block) fold their maxima into out with
+// an atomic max on the ordered-integer image of the float (order independent, hence deterministic).  Round 1 ran one
+// workgroup per (batch, channel block): 8-16 workgroups on the whole chip, 31 us for <= 1 MB.
+__global__ void colmax_init_kernel(float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = -INFINITY;
+}
+
+__device__ __forceinline__ void cbr_atomic_max(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void colmax_partials_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int tiles_per_batch, int C) {
+  __shared__ float sm[256];
   const int b = blockIdx.x, cblk = blockIdx.y * 64;
-  const int c = cblk + (threadIdx.x & 63), grp = threadIdx.x >> 6;        // 16 tile groups x 64 channels
+  const int c = cblk + (threadIdx.x & 63), grp = threadIdx.x >> 6;        // 4 tile groups x 64 channels
+  const int per = (tiles_per_batch + gridDim.z - 1) / gridDim.z;
+  const int t0 = blockIdx.z * per, t1 = min(t0 + per, tiles_per_batch);
   float m = -INFINITY;
   if (c < C)
-    for (int t = grp; t < tiles_per_batch; t += 16) m = fmaxf(m, part[((int64_t)b * tiles_per_batch + t) * C + c]);
+    for (int t = t0 + grp; t < t1; t += 4) m = fmaxf(m, part[((int64_t)b * tiles_per_batch + t) * C + c]);
   sm[threadIdx.x] = m;
   __syncthreads();
   if (grp == 0 && c < C) {
 #pragma unroll
-    for (int g = 1; g < 16; ++g) m = fmaxf(m, sm[threadIdx.x + 64 * g]);
-    out[(int64_t)b * C + c] = m;
+    for (int g = 1; g < 4; ++g) m = fmaxf(m, sm[threadIdx.x + 64 * g]);
+    if (m > -INFINITY) cbr_atomic_max(out + (int64_t)b * C + c, m);
   }
 }
 
@@ -308,6 +323,9 @@ extern "C" int cmr_cbr_block_f32(const float* x1, int64_t ld1, int k1, const flo
 extern "C" int cmr_colmax_partials_f32(const float* part, float* out, int B, int tiles_per_batch, int C,
                                        hipStream_t stream) {
   CMR_REQUIRE(part && out && B > 0 && B <= 65535 && tiles_per_batch > 0 && C > 0);
-  hipLaunchKernelGGL(colmax_partials_kernel, dim3(B, (C + 63) / 64), dim3(1024), 0, stream, part, out, tiles_per_batch, C);
+  hipLaunchKernelGGL(colmax_init_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, out, B * C);
+  int z = (tiles_per_batch + 31) / 32;             // >= 32 tiles per chunk: 8 loads per thread
+  z = z < 1 ? 1 : (z > 64 ? 64 : z);
+  hipLaunchKernelGGL(colmax_partials_kernel, dim3(B, (C + 63) / 64, z), dim3(256), 0, stream, part, out, tiles_per_batch, C);
   return cmr_launch_status();
 }

@@ -70,11 +70,18 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(cons
   const int nchunk = a.Cin / WT_KC;
 
   struct Tile { int b, co0, oy0, ox0; };
-  auto decode = [&](int t) {
+  // Workgroup -> tile.  Workgroups are dealt to the 8 XCDs round-robin (id % 8) and every XCD has its own L2, so XCD x
+  // takes a CONTIGUOUS band of the tile order (ids x, x + 8, x + 16, ... -> consecutive tiles): horizontally adjacent
+  // tiles (shared halo columns), the next tile row (shared halo rows) and the cout groups of one input tile (fastest
+  // index: they read the same halo) are then resident in the same L2 at about the same time.
+  auto decode = [&](int id) {
+    const int nblk = gridDim.x, per = nblk >> 3, rem = nblk & 7, xcd = id & 7;
+    int t = xcd * per + (xcd < rem ? xcd : rem) + (id >> 3);
     Tile r;
+    r.co0 = (t % nco) * 32 * NT; t /= nco;
     r.ox0 = (t % tiles_x) * WT_TW; t /= tiles_x;
-    r.oy0 = (t % tiles_y) * WT_TH; t /= tiles_y;
-    r.b = t / nco; r.co0 = (t % nco) * 32 * NT;
+    r.oy0 = (t % tiles_y) * WT_TH;
+    r.b = t / tiles_y;
     return r;
   };
 

@@ -356,7 +356,7 @@ def vecattn_front(q, pa4, pb4, ib, d0, d2, g0, g2, rows, iq=None, divq=1, ia=Non
 def segment_softmax(attn, vp, nseg, scale, order=None, offsets=None, fixed_len=0):
     out = torch.empty((nseg, 64), dtype=f32, device=attn.device)
     _lib.call("cmr_segment_softmax_f32", _p(attn), _p(vp), _p(_i32(order)), _p(_i32(offsets)), fixed_len, float(scale),
-              _p(out), nseg, _stream())
+              _p(out), nseg, _stream(), work_extra={"_rows": attn.shape[0]})
     return out
 
 
@@ -366,7 +366,7 @@ def segment_reduce(src, order, offsets, nseg, mode):
     C = src.shape[1]
     out = torch.empty((nseg, C), dtype=f32, device=src.device)
     _lib.call("cmr_segment_reduce_f32", _p(src), _ld(src), _p(_i32(order)), _p(_i32(offsets)), _p(out), C, nseg, C,
-              {"sum": 0, "max": 1, "mean": 2}[mode], _stream())
+              {"sum": 0, "max": 1, "mean": 2}[mode], _stream(), work_extra={"_rows": src.shape[0]})
     return out
 
 

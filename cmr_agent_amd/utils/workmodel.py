@@ -1,0 +1,173 @@
+"""Algorithmic work of every C-ABI entry point on the registration path: FLOPs = 2 x MACs of the math the
+call implements, bytes = each distinct input and output once, weights once (fp32).  A call is MFMA-class when
+FLOPs / bytes exceeds the fp32 ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) and its ideal time is FLOPs / peak, else
+HBM-class with ideal time bytes / bandwidth.  bench.py times every call with HIP events (CallTimer) and reports
+roofline.path = sum(ideal) / sum(measured) over the whole path, plus the per-entry-point table.
+
+The numbers are ALGORITHMIC, not what the kernels issue: Winograd issues 16/36 of a convolution's multiplies, the fused
+layer kernels recompute small GEMMs, the transposed-GEMM chains pad K; none of that is credited."""
+import torch
+
+from .. import _lib
+
+FP32_MFMA_PEAK = 157.3e12      # FLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32, 256 CUs at 2.4 GHz)
+HBM_PEAK = 8.0e12              # B/s
+RIDGE = FP32_MFMA_PEAK / HBM_PEAK
+F = 4                          # bytes per float
+
+
+def _linear(a):
+    rows, k1, n = a["rows"], a["k1"], a["n_out"]
+    k2 = a["k2"] if a["x2"] else 0
+    src2 = 0
+    if a["x2"]:
+        src2 = rows * k2 if a["idx2"] else max(rows // max(a["div2"], 1), 1) * k2
+    by = F * (rows * k1 + src2 + rows * n + n * (k1 + k2) + (rows * n if a["res"] and not a["res_mod"] else 0))
+    return 2.0 * rows * (k1 + k2) * n, by
+
+
+def _cbr(a):
+    rows, kx, ch, co, k1 = a["rows"], a["kx"], a["ch"], a["co"], a["k1"]
+    w = kx * ch + ch * co + (kx * co if a["wsc"] else 0)
+    src2 = 0
+    if a["x2"]:
+        src2 = rows * (kx - k1) if a["idx2"] else max(rows // max(a["div2"], 1), 1) * (kx - k1)
+    return 2.0 * rows * w, F * (rows * k1 + src2 + (rows * co if a["y"] else 0) + w)
+
+
+def _conv(a, stride=None):
+    s = a.get("stride", 1) if stride is None else stride
+    B, H, W, ci, co, pool = a["B"], a["H"], a["W"], a["Cin"], a["Cout"], a.get("pool", 1)
+    opix = B * ((H - 1) // s + 1) * ((W - 1) // s + 1)
+    by = F * (B * H * W * ci + opix * co / (pool * pool) + (opix * co if a["res"] else 0) + 9 * ci * co)
+    return 2.0 * 9 * ci * co * opix, by
+
+
+def _heads(a):
+    w = 2 * 128 * 128 + sum(256 * a[p + "_n0"] + a[p + "_n0"] * a[p + "_n1"] + a[p + "_n1"] * a[p + "_n2"] for p in "rtv")
+    return 2.0 * a["B"] * w, F * (a["B"] * a["npix"] * 128 + w)
+
+
+def _vecattn(a):
+    rows = a["rows"]
+    if a["feat"]:
+        return rows * 2.0 * (3 * 4096 + 192 + 4096 + 2 * 4096), rows * (256 + 256 + 32 + 512)
+    return rows * 2.0 * (192 + 4096 + 2 * 4096), rows * (512 + 256 + 32 + 512)
+
+
+WORK = {
+    "cmr_linear_f32": _linear,
+    "cmr_cbr_block_f32": _cbr,
+    "cmr_colmax_partials_f32": lambda a: (0, F * a["B"] * a["tiles_per_batch"] * a["C"]),
+    "cmr_layernorm64_f32": lambda a: (0, F * a["rows"] * 64 * (3 if a["res"] else 2)),
+    "cmr_conv3x3_nhwc_f32": _conv,
+    "cmr_conv3x3_wino_nhwc_f32": lambda a: _conv(a, 1),
+    # ResidualBlock(3 -> 64): conv3x3 3->3, conv3x3 3->64, 1x1 shortcut 3->64
+    "cmr_stem_block_f32": lambda a: (2.0 * (81 + 1728 + 192) * a["B"] * a["H"] * a["W"], F * a["B"] * a["H"] * a["W"] * (3 + 64)),
+    "cmr_avgpool_nhwc_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (1 + 1.0 / (a["kh"] * a["kw"]))),
+    "cmr_upsample_concat_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * (2 * a["C1"] + a["C2"] * (1 + 1.0 / a["scale"] ** 2))),
+    "cmr_patchify_nhwc_f32": lambda a: (0, 2 * F * a["B"] * a["H"] * a["W"] * a["C"]),
+    "cmr_transpose_f32": lambda a: (0, 2 * F * a["batch"] * a["R"] * a["Cn"]),
+    "cmr_mha_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),
+    "cmr_la_reduce_f32": lambda a: (2.0 * a["B"] * a["S"] * 576, F * a["B"] * a["S"] * 128),
+    "cmr_la_apply_f32": lambda a: (2.0 * a["B"] * a["L"] * 576, F * a["B"] * a["L"] * 128),
+    "cmr_agent_heads_f32": _heads,
+    "cmr_ln64_linear_f32": lambda a: (2.0 * 64 * (a["rows_x"] * a["n_out_x"] + (a["rows_y"] * a["n_out_y"] if a["y"] else 0)),
+                                      F * (a["rows_x"] * (64 + a["n_out_x"]) + (a["rows_y"] * (64 + a["n_out_y"]) if a["y"] else 0)
+                                           + 64 * (a["n_out_x"] + (a["n_out_y"] if a["y"] else 0)))),
+    "cmr_vit_out_ffn_f32": lambda a: (2.0 * a["rows"] * (4096 + 2 * 65536), F * (a["rows"] * 192 + 4096 + 2 * 65536)),
+    # LinearAttention.py:46-60: k / v projections + per-head 8x8 state (source side); q projection, application, merge,
+    # MLP 128 -> 128 -> 64 (query side): 17.5 + 66.7 = 84 kFLOP per token pair, as SURVEY.md 8a row a10 counts
+    "cmr_la_kv_state_f32": lambda a: (2.0 * a["B"] * a["S"] * (2 * 4096 + 576), F * (a["B"] * a["S"] * 64 + 2 * 4096)),
+    "cmr_la_query_layer_f32": lambda a: (2.0 * a["B"] * a["L"] * (4096 + 576 + 4096 + 16384 + 8192),
+                                         F * (a["B"] * a["L"] * 128 + 2 * 4096 + 16384 + 8192)),
+    "cmr_vecattn_front_f32": _vecattn,
+    "cmr_focal_metrics_f32": lambda a: (0, a["rows"] * 16),
+    "cmr_circle_loss_f32": lambda a: (2.0 * a["B"] * a["n"] * a["n"] * 64, F * a["B"] * a["n"] * 128),
+    "cmr_planar_to_rows_f32": lambda a: (0, F * a["B"] * a["N"] * (a["C"] + a["Cpad"])),
+    "cmr_concat_rows_f32": lambda a: (0, F * a["rows"] * (2 * a["C1"] + a["C2"])),
+    "cmr_index_to_global_i32": lambda a: (0, 12 * a["B"] * a["N"]),
+    "cmr_csr_build_i32": lambda a: (0, 8 * a["B"] * a["n_per_batch"] + 8 * a["B"] * a["seg_per_batch"]),
+    "cmr_knn16_f32": lambda a: (8.0 * a["B"] * a["M"] * a["M"], a["B"] * a["M"] * (16 + 64)),
+    "cmr_nearest_f32": lambda a: (8.0 * a["B"] * a["Nq"] * a["Nc"], a["B"] * (a["Nq"] * 28 + a["Nc"] * 16)),
+    "cmr_rel_pos_f32": lambda a: (0, a["rows"] * 48),
+    "cmr_vecattn_prep_f32": lambda a: (0, F * a["rows"] * 64 * 6),
+    "cmr_segment_softmax_f32": lambda a: (0, F * a["_rows"] * 128 + F * a["nseg"] * 64),
+    "cmr_segment_reduce_f32": lambda a: (0, F * a["_rows"] * a["C"] + F * a["nseg"] * a["C"]),
+    "cmr_gather_rows_f32": lambda a: (0, a["rows"] * (2 * F * a["C"] + 4)),
+    "cmr_colmax_f32": lambda a: (0, F * a["B"] * a["N"] * a["C"]),
+    "cmr_colmean_f32": lambda a: (0, F * a["B"] * a["N"] * a["C"]),
+    # environment.py:24-126: per point xyz0 + mask + 64-d feature in, 8-float state row out; per cell image feature +
+    # accumulator + count in, [img | mean] + projected half out
+    "cmr_project_scatter_f32": lambda a: (0, a["B"] * a["N"] * (16 + 1 + 256 + 32)),
+    "cmr_observation_finalize_f32": lambda a: (0, a["B"] * a["h"] * a["w"] * (256 + 256 + 4 + 512 + 256)),
+    "cmr_pose_step_f32": lambda a: (0, a["B"] * 128),
+    "cmr_to_disentangled_f32": lambda a: (0, a["B"] * 128),
+    "cmr_argmax_rows_f32": lambda a: (0, a["outer"] * a["inner"] * (F * a["n"] + 8)),
+    "cmr_softmax2_f32": lambda a: (0, a["rows"] * 14),
+    "cmr_l2norm64_f32": lambda a: (0, a["rows"] * 512),
+}
+
+
+def work(name, args, extra=None):
+    """-> (flops, bytes) of one call, or None when the entry point is not modelled."""
+    fn = WORK.get(name)
+    if fn is None:
+        return None
+    names = _lib.prototypes()[name][2]
+    a = dict(zip(names, args))
+    if extra:
+        a.update(extra)
+    if "_rows" not in a:
+        a["_rows"] = a.get("nseg", 0) * max(a.get("fixed_len", 0), 1)
+    fl, by = fn(a)
+    return float(fl), float(by)
+
+
+def ideal_seconds(flops, nbytes):
+    return max(flops / FP32_MFMA_PEAK, nbytes / HBM_PEAK)
+
+
+class CallTimer:
+    """HIP-event timing of every C-ABI call on the stream it is issued on (torch's current stream at the call), with the
+    algorithmic work of the call.  Use around an EAGER pass (events cannot sit inside a replayed graph)."""
+
+    def __init__(self):
+        self.records = []          # (name, e0, e1, flops, bytes)
+        self._orig = None
+
+    def __enter__(self):
+        self._orig = _lib.call
+
+        def timed(name, *args, allow_unsupported=False, work_extra=None):
+            wk = work(name, args, work_extra)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = self._orig(name, *args, allow_unsupported=allow_unsupported)
+            e1.record()
+            if rc != _lib.UNSUPPORTED:
+                self.records.append((name, e0, e1) + (wk if wk is not None else (None, None)))
+            return rc
+        _lib.call = timed
+        return self
+
+    def __exit__(self, *a):
+        _lib.call = self._orig
+
+    def table(self):
+        """-> list of dicts per entry point, sorted by measured time."""
+        agg = {}
+        for name, e0, e1, fl, by in self.records:
+            ms = e0.elapsed_time(e1)
+            d = agg.setdefault(name, dict(name=name, calls=0, ms=0.0, flops=0.0, bytes=0.0, ideal_ms=0.0, modelled=fl is not None))
+            d["calls"] += 1
+            d["ms"] += ms
+            if fl is not None:
+                d["flops"] += fl
+                d["bytes"] += by
+                d["ideal_ms"] += 1e3 * ideal_seconds(fl, by)
+        rows = sorted(agg.values(), key=lambda d: -d["ms"])
+        for d in rows:
+            d["bound"] = "mfma" if d["bytes"] and d["flops"] / d["bytes"] > RIDGE else "hbm"
+            d["frac"] = d["ideal_ms"] / d["ms"] if d["ms"] > 0 else 0.0
+        return rows

@@ -24,6 +24,14 @@ DEV = "cuda"
 SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
 
 
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    """other test modules switch autograd off process-wide at import (torch.set_grad_enabled(False)); the torch-CPU
+    references of this file need it"""
+    with torch.enable_grad():
+        yield
+
+
 @pytest.fixture(scope="module")
 def ops():
     from cmr_agent_amd import ops as _ops

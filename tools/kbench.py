@@ -134,6 +134,44 @@ def main():
     if "vit" in a.what:
         bench_vit(8 * 418, 8 * 256, 8, a.reps)
         bench_vit(8 * 256, 8 * 418, 8, a.reps)
+    if "points" in a.what:
+        # BASELINE configs[4] sizes: the point-side ops of the geometric model at 65 536 points (PointNN FPS / ball query /
+        # kNN stress), per batch of B clouds.  Bytes = what the op must read / write once.
+        for Bp in (1, 8):
+            N, S = 65536, 1280
+            xyz = (torch.rand(Bp, 3, N, device=DEV) * 80 - 40)
+            x4 = ops.planar_to_rows(xyz, 4)
+            start = torch.zeros(Bp, dtype=torch.int64, device=DEV)
+            t = timeit(lambda: ops.fps(x4, start, Bp, N, S), max(a.reps // 4, 2))
+            print("fps            B=%d %6d -> %4d : %9.1f us  = %6.2f us per round (2-barrier floor ~ 2 x 0.5 us); %5.2f GB/s of xyz0 reads if re-streamed "
+                  "(the cloud stays in registers / LDS: algorithmic bytes %.2f MB)" % (Bp, N, S, t, t / S, Bp * N * 16.0 * S / t / 1e3, Bp * N * 16 / 1e6))
+            idx = ops.fps(x4, start, Bp, N, S)
+            nodes4 = ops.gather_rows(x4, (idx + torch.arange(Bp, device=DEV).view(Bp, 1) * N).view(-1).int())
+            t = timeit(lambda: ops.ball_query(x4, nodes4, Bp, N, S, 32, 2.0), a.reps)
+            by = Bp * (N * 16 + S * 16 + S * 32 * 8)
+            print("ball_query     B=%d %4d x %6d k=32 : %9.1f us  %6.3f TB/s algorithmic (%0.2f MB); %5.1f Gpair/s" % (Bp, S, N, t, by / t / 1e6, by / 1e6, Bp * S * N / t / 1e3))
+            t = timeit(lambda: ops.knn16(nodes4, Bp, S), a.reps)
+            print("knn16          B=%d %4d x %4d        : %9.1f us  %5.1f Gpair/s" % (Bp, S, S, t, Bp * S * S / t / 1e3))
+            t = timeit(lambda: ops.nearest(x4, nodes4, Bp, N, S), a.reps)
+            by = Bp * (N * (16 + 4 + 8) + S * 16)
+            print("nearest        B=%d %6d x %4d      : %9.1f us  %6.3f TB/s algorithmic; %5.1f Gpair/s" % (Bp, N, S, t, by / t / 1e6, Bp * S * N / t / 1e3))
+            _, local = ops.nearest(x4, nodes4, Bp, N, S)
+            gidx = ops.index_to_global(local, S)
+            t = timeit(lambda: ops.csr_build(gidx, Bp, N, S), a.reps)
+            by = Bp * (N * 8 + S * 8)
+            print("csr_build      B=%d %6d -> %4d seg  : %9.1f us  %6.3f TB/s algorithmic" % (Bp, N, S, t, by / t / 1e6))
+            offsets, order = ops.csr_build(gidx, Bp, N, S)
+            feat = torch.randn(Bp * N, 64, device=DEV)
+            t = timeit(lambda: ops.segment_reduce(feat, order, offsets, Bp * S, "max"), a.reps)
+            by = Bp * (N * 260 + S * 256)
+            print("segment_reduce B=%d %6d x 64 (max)  : %9.1f us  %6.3f TB/s algorithmic" % (Bp, N, t, by / t / 1e6))
+            a_, v_ = torch.randn(Bp * N, 64, device=DEV), torch.randn(Bp * N, 64, device=DEV)
+            t = timeit(lambda: ops.segment_softmax(a_, v_, Bp * S, 0.125, order=order, offsets=offsets), a.reps)
+            by = Bp * (N * 516 + S * 256)
+            print("segment_softmax B=%d %6d x 64       : %9.1f us  %6.3f TB/s algorithmic" % (Bp, N, t, by / t / 1e6))
+            sq = timeit(lambda: ops.square_distance(nodes4, x4, Bp, S, N), max(a.reps // 4, 2))
+            by = Bp * S * N * 4
+            print("square_distance B=%d %4d x %6d      : %9.1f us  %6.3f TB/s (output write)" % (Bp, S, N, sq, by / sq / 1e6))
     if "linear" in a.what:
         N, P4, M, T = 8 * 16384, 8 * 26752, 8 * 1280, 8 * 418
         for args in [(N, 64, 64), (N, 64, 64, 64, True), (N, 64, 128), (N, 64, 128, 64, True), (N, 128, 64), (N, 4, 64), (N, 8, 8),
