@@ -365,6 +365,23 @@ int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, i
  * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]. */
 int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, hipStream_t stream);
 
+/* ---- dataset-side geometry of one frame ------------------------------------------ */
+/* dataset/KittiDataset.py:273-276, :284, :312-336 (same code in NuScenesDataset.py): velodyne -> camera transform of the
+ * down-sampled cloud (choice = the np.random.choice indices, null = all points in order), projection with the 1/4-scale
+ * intrinsics, round-half-even pixel, in-picture test, pc_mask, img_mask (coo_matrix(...).toarray() > 0), the random pose.
+ * raw: planar float32 rows [>=3][ld_raw] as stored in the .npy; tr12 / k9 / prand12 are HOST arrays (float64, row-major
+ * 3x4 / 3x3 / 3x4) copied by value; everything else is device memory.  Arithmetic in float64 like numpy.
+ * Outputs: pc_cam / pc_out planar float32 [3][N], pc_mask int64 [N], xy float64 [2][N] (pc_[0:2]), img_mask int64 [h*w]. */
+int cmr_dataset_project_f64(const float* raw, int64_t ld_raw, const int64_t* choice, const double* tr12, const double* k9,
+                            const double* prand12, int w, int h, float* pc_cam, float* pc_out, int64_t* pc_mask, double* xy,
+                            int64_t* img_mask, int64_t N, hipStream_t stream);
+/* KittiDataset.py:338-345: pc_idx_for_circle_loss = np.where(is_in_picture)[0][perm[:nsel]] (ordered compaction by a
+ * scan, compact_ws int32 [N]), the float32 pixel coordinates of those points and their np.round as int64.  count receives
+ * the number of in-picture points; samples whose perm entry is >= count are marked with index -1. */
+int cmr_dataset_circle_select_f64(const int64_t* pc_mask, const double* xy, const int64_t* perm, int nsel, int64_t N,
+                                  int32_t* compact_ws, int64_t* count, int64_t* idx_out, float* xy_float, int64_t* xy_int,
+                                  hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -876,3 +876,33 @@ def feature_propagation(w, xyz1, xyz2, points1, points2):
         x = F.relu(_bn(_conv1d(x, w.sub("mlp_convs.%d" % i)), w.sub("mlp_bns.%d" % i)))
         i += 1
     return x
+
+
+# ----------------------------------------------------------------------------------------------
+# dataset-side geometry of one frame (dataset/KittiDataset.py:273-367)
+# ----------------------------------------------------------------------------------------------
+def kitti_frame(raw, P_Tr, K, P_random, img_hw4, choice, perm, node_candidates, fps_start, num_node, n_circle=512):
+    """numpy restatement of the geometric part of KittiDataset.__getitem__ with the random draws as arguments.
+    raw float32 [>=3, n]; P_Tr float64 4x4; K float32 3x3 (1/4 scale); P_random float32 4x4."""
+    h, w = img_hw4
+    pc = raw[0:3, :]
+    pc = np.dot(P_Tr[0:3, 0:3], pc) + P_Tr[0:3, 3:]                       # :273-276
+    pc = pc[:, choice]                                                   # :284 (downsample_pc)
+    pc_in_cam = pc
+    pc_ = np.dot(K, pc)                                                   # :313
+    pc_[0:2, :] = pc_[0:2, :] / pc_[2:, :]
+    xy = np.round(pc_[0:2, :])
+    inpic = (xy[0, :] >= 0) & (xy[0, :] <= (w - 1)) & (xy[1, :] >= 0) & (xy[1, :] <= (h - 1)) & (pc_[2, :] > 0)   # :317-318
+    img_mask = np.zeros((h, w), dtype=np.int64)
+    xy2 = xy[:, inpic].astype(np.int64)
+    img_mask[xy2[1], xy2[0]] = 1                                          # :333-337 coo_matrix(...).toarray() > 0
+    idx = np.where(inpic)[0][perm[0:n_circle]]                            # :339-342
+    xyf = pc_[0:2, idx]
+    out = dict(pc_in_cam_space=pc_in_cam.astype(np.float32), pc_mask=inpic.astype(np.int64), img_mask=img_mask,
+               pc_idx_for_circle_loss=idx.astype(np.int64), pc_xy_float_for_circle_loss=xyf.astype(np.float32),
+               pc_xy_int_for_circle_loss=np.round(xyf).astype(np.int64), K=K.astype(np.float32),
+               P=np.linalg.inv(P_random).astype(np.float32))
+    pc = np.dot(P_random[0:3, 0:3], pc) + P_random[0:3, 3:]               # :352
+    node, _ = dataset_fps(pc[:, node_candidates], num_node, fps_start)    # :356-357
+    out.update(pc=pc.astype(np.float32), node=np.asarray(node, dtype=np.float32), pt2node=np.asarray(nearest_node(pc, node), dtype=np.int64))
+    return out

@@ -282,3 +282,48 @@ def buffer_inputs():
                 action_logprob=-base.view(B, 1).repeat(1, 3) * 0.001))
         trajs.append(steps)
     return trajs
+
+
+# ----------------------------------------------------------------------------------------------
+# dataset-side geometry of one frame (KittiDataset.py:258-423)
+# ----------------------------------------------------------------------------------------------
+FRAME = dict(n_raw=6000, num_pt=4096, num_node=128, H=160, W=512, img_h=376, img_w=1241)
+TRAIN_FIXTURES = TRAIN_FIXTURES + ("kitti_frame",)
+# calib.txt rows of a KITTI odometry sequence (P2 and Tr; public calibration numbers, data not code)
+FRAME_P2 = [7.188560000000e+02, 0.0, 6.071928000000e+02, 4.538225000000e+01, 0.0, 7.188560000000e+02, 1.852157000000e+02,
+            -1.130887000000e-01, 0.0, 0.0, 1.0, 3.779761000000e-03]
+FRAME_TR = [4.276802385584e-04, -9.999672484946e-01, -8.084491683471e-03, -1.198459927713e-02, -7.210626507497e-03,
+            8.081198471645e-03, -9.999413164504e-01, -5.403984729748e-02, 9.999738645903e-01, 4.859485810390e-04,
+            -7.206933692422e-03, -2.921968648686e-01]
+
+
+def frame_raw_cloud():
+    """velodyne-frame cloud [4, n] float32 (x forward, y left, z up, reflectance), as the reference's .npy files store it."""
+    n = FRAME["n_raw"]
+    xyz = np.stack([hashfill.uniform("case/frame/x", (n,), 0.5, 60.0), hashfill.uniform("case/frame/y", (n,), -30.0, 30.0),
+                    hashfill.uniform("case/frame/z", (n,), -2.0, 1.0), hashfill.uniform("case/frame/r", (n,), 0.0, 1.0)])
+    return xyz.astype(np.float32)
+
+
+def frame_calib():
+    """KittiCalibHelper.read_calib_files (KittiDataset.py:63-99) for the P2 / Tr rows above -> (P_Tr float64 4x4, K float32 3x3),
+    then the intrinsics chain of __getitem__ (:290-310) for the 'val' centre crop -> K at 1/4 scale (float32)."""
+    f = FRAME
+    mat = np.asarray(FRAME_P2, dtype=np.float64).reshape(3, 4).astype(np.float32)
+    K = mat[0:3, 0:3]
+    tz = mat[2, 3]
+    P = np.identity(4)
+    P[0:3, 3] = np.asarray([(mat[0, 3] - K[0, 2] * tz) / K[0, 0], (mat[1, 3] - K[1, 2] * tz) / K[1, 1], tz])
+    Tr = np.identity(4)
+    Tr[0:3, :] = np.asarray(FRAME_TR, dtype=np.float64).reshape(3, 4).astype(np.float32)
+    P_Tr = np.dot(P, Tr)
+    rw, rh = int(round(f["img_w"] * 0.5)), int(round(f["img_h"] * 0.5))
+    dx, dy = int((rw - f["W"]) / 2), int((rh - f["H"]) / 2)
+    Kq = 0.5 * K
+    Kq[2, 2] = 1
+    Kq = np.copy(Kq)
+    Kq[0, 2] -= dx
+    Kq[1, 2] -= dy
+    Kq = 0.25 * Kq
+    Kq[2, 2] = 1
+    return P_Tr, Kq

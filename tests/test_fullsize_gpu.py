@@ -216,3 +216,33 @@ def test_geo_forward_at_65536_points():
         geo(one)
     assert float((one["pc_geo_feat"] - data["pc_geo_feat"][1:2]).abs().max()) < 1e-5
     assert torch.equal(one["pc_overlap_pred"], data["pc_overlap_pred"][1:2])
+
+
+def test_kitti_frame_preprocessing_on_device():
+    """cmr_agent_amd.dataset.preprocess_frame (csrc/dataset.hip + FPS / nearest-node kernels) on the
+    synthetic KITTI frame vs the oracle's numpy restatement and the fixture made by the reference's
+    KittiDataset.__getitem__ (random draws replayed).  float32 outputs within 1 ulp-level tolerance (float64 arithmetic on
+    both sides, fused multiply-adds on the device), masks and index-valued outputs exact."""
+    import numpy as np
+    from cmr_agent_amd.dataset import preprocess_frame
+    from test_oracle_golden import FRAME_KEYS, frame_inputs
+    i = frame_inputs()
+    f = C.FRAME
+    hw4 = (f["H"] // 4, f["W"] // 4)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    got = preprocess_frame(dev(i["raw"]), i["P_Tr"], i["K"], i["P_random"], hw4, choice=dev(i["choice"]), perm=dev(i["perm"]),
+                           node_candidates=dev(i["cand"]), fps_start=i["fps_start"], num_node=f["num_node"])
+    torch.cuda.synchronize()
+    ref = O.kitti_frame(i["raw"], i["P_Tr"], i["K"], i["P_random"], hw4, i["choice"], i["perm"], i["cand"], i["fps_start"], f["num_node"])
+    assert int(got["in_picture_count"]) == int(ref["pc_mask"].sum())
+    for k in FRAME_KEYS:
+        g, r = got[k].cpu().numpy(), np.asarray(ref[k])
+        assert g.shape == r.shape, (k, g.shape, r.shape)
+        if r.dtype.kind in "iu":
+            assert (g == r).all(), (k, int((g != r).sum()))
+        else:
+            assert np.abs(g.astype(np.float64) - r).max() <= 1e-6 * max(1.0, np.abs(r).max()), (k, np.abs(g - r).max())
+    G.assert_case("kitti_frame", {k: got[k] for k in FRAME_KEYS}, atol=1e-5, rtol=1e-6)
+    # identity down-sampling / no samples / no nodes: the optional parts are really optional
+    lite = preprocess_frame(dev(i["raw"]), i["P_Tr"], i["K"], i["P_random"], hw4)
+    assert lite["pc"].shape == (3, f["n_raw"]) and "node" not in lite and "pc_idx_for_circle_loss" not in lite

@@ -111,3 +111,31 @@ def test_buffer_ordering_quirk():
     G.assert_case("buffer_order", dict(zip(names, out)), atol=1e-6, rtol=1e-6)
     # the quirk itself: sample i of the states is (step i // B, batch i % B) but return i is (batch i // T, step i % T)
     assert float(out[0][1, 0, 0, 0]) == 1.0 and float(out[0][2, 0, 0, 0]) == 10.0
+
+
+def frame_inputs():
+    """raw cloud, calib, and the reference's recorded random draws (from the fixture) of the kitti_frame case."""
+    import numpy as np
+    from cmr_agent_amd.dataset.frame import random_transform
+    fx = G.load_case("kitti_frame")
+    P_Tr, Kq = C.frame_calib()
+    u = fx["draw_uniform"]["sample"]
+    P_random = random_transform(list(u[0:3]), list(u[3:6]))
+    return dict(raw=C.frame_raw_cloud(), P_Tr=P_Tr, K=Kq, P_random=P_random, choice=fx["draw_choice"]["sample"].astype(np.int64),
+                perm=fx["draw_perm"]["sample"].astype(np.int64), cand=fx["draw_node_candidates"]["sample"].astype(np.int64),
+                fps_start=int(fx["draw_fps_start"]["sample"][0]))
+
+
+FRAME_KEYS = ("pc", "pc_in_cam_space", "K", "P", "img_mask", "pc_mask", "pc_idx_for_circle_loss", "pc_xy_float_for_circle_loss",
+              "pc_xy_int_for_circle_loss", "pt2node", "node")
+
+
+def test_kitti_frame_geometry():
+    """oracle.kitti_frame (numpy restatement of KittiDataset.py:273-367, random draws replayed) vs the fixture produced by
+    the reference's KittiDataset.__getitem__ on the synthetic frame (tests/golden/make_golden_dataset.py)."""
+    from oracle import cmr_oracle as O
+    i = frame_inputs()
+    f = C.FRAME
+    out = O.kitti_frame(i["raw"], i["P_Tr"], i["K"], i["P_random"], (f["H"] // 4, f["W"] // 4), i["choice"], i["perm"], i["cand"],
+                        i["fps_start"], f["num_node"])
+    G.assert_case("kitti_frame", {k: out[k] for k in FRAME_KEYS}, atol=0, rtol=0)
