@@ -112,7 +112,8 @@ def test_data_parallel_update_equals_single_rank_on_the_concatenated_batch():
     specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
     cfg = C.train_config("agent_train_small")
     sd0 = {k: v for k, v in hashfill.make_state_dict(specs["agent"], C.AGENT_TAG).items() if not k.endswith("num_batches_tracked")}
-    single, _ = TO.adam_train(sd0, C.train_inputs("agent_train_small"), cfg, bn_training=False)
+    with torch.enable_grad():        # another test module switches autograd off process-wide at import
+        single, _ = TO.adam_train(sd0, C.train_inputs("agent_train_small"), cfg, bn_training=False)
     n_all = n_bad = 0
     for k, v in single.items():
         d = (torch.from_numpy(sd_a[k]).double() - v.double()).abs()
