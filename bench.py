@@ -26,7 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from cmr_agent_amd import ops  # noqa: E402
-from cmr_agent_amd.config import KittiConfiguration  # noqa: E402
+from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
 from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
 from cmr_agent_amd.runtime import RegistrationGraph  # noqa: E402
@@ -35,7 +35,17 @@ from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
 from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
 from cmr_agent_amd.utils.workmodel import CallTimer  # noqa: E402
 
-WORKLOAD = dict(B=8, N=16384, H=352, W=1216, M=1280, steps=10)
+WORKLOADS = {
+    # BASELINE.json configs[1]: the headline
+    "c1": dict(B=8, N=16384, H=352, W=1216, M=1280, steps=10, cfg="kitti", dtype="f32",
+               name="BASELINE.json configs[1]: KittiConfig, batch 8 per GPU, 16384 pts, 352x1216 image, 10 agent steps"),
+    # BASELINE.json configs[3]: NuScenesConfig, batch 32 over 8 GPUs = 4 per GPU, 32768 pts, 900x1600 -> 896x1600 (sizes must be
+    # multiples of 32), bf16 convolutions
+    "c3": dict(B=4, N=32768, H=896, W=1600, M=1280, steps=10, cfg="nuscenes", dtype="bf16",
+               name="BASELINE.json configs[3]: NuScenesConfig, batch 4 per GPU, 32768 pts, 896x1600 image (900x1600 is not a valid size), "
+                    "10 agent steps"),
+}
+WORKLOAD = WORKLOADS["c1"]
 GEO_TAG, AGENT_TAG = "geo4/", "agent/"
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 
@@ -172,6 +182,9 @@ def main():
     ap.add_argument("--mode", choices=("register", "train"), default="register",
                     help="register (default): the headline registration iteration; train: the agent's minibatch update")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
+                    help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     args = ap.parse_args()
     if args.mode == "train":
@@ -186,8 +199,11 @@ def main():
     ranks = Ranks(backend="nccl", device=dev)          # RCCL: timing barrier / MAX only, no data-path collective
     rank = ranks.rank
 
-    w = WORKLOAD
-    cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
+    w = WORKLOADS[args.workload]
+    dtype = args.dtype or w["dtype"]
+    ops.CONV_BF16 = dtype == "bf16"
+    Cfg = NuScenesConfiguration if w["cfg"] == "nuscenes" else KittiConfiguration
+    cfg = Cfg(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
     geo, agent, spec = load_models(cfg, dev)
     # the path shards by batch: every rank registers its own B pairs, no data-path collective
     batch = synthetic.make_batch(w["B"], w["N"], w["H"], w["W"], w["M"], hip_fps(dev), hip_nearest(dev),
@@ -222,7 +238,7 @@ def main():
 
     if rank == 0:
         table = ct.table()
-        dom = [d for d in table if d["name"] == "cmr_conv3x3_wino_nhwc_f32"][0]
+        dom = [d for d in table if d["name"] == ("cmr_conv3x3_bf16_nhwc_f32" if dtype == "bf16" else "cmr_conv3x3_wino_nhwc_f32")][0]
         conv = dict(launches=dom["calls"], ms=dom["ms"], flops=dom["flops"], bytes=dom["bytes"])
         sum_ideal = sum(d["ideal_ms"] for d in table if d["modelled"])
         sum_meas = sum(d["ms"] for d in table if d["modelled"])
@@ -233,47 +249,52 @@ def main():
                    for d in table if d["modelled"]]
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes)
-        traffic = None
+        traffic, traffic_src = None, "profiles/r02_pmc_path.json"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, traffic_src)))
             wino = [v for k, v in pmc.items() if "conv3x3_wino_kernel" in k]       # both template instances, launch-weighted
-            traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in wino) / sum(v["launches"] for v in wino)
+            traffic = (sum((v["hbm_fetch_bytes"] + v["hbm_write_bytes"]) * v["launches_per_iteration"] for v in wino)
+                       / sum(v["launches_per_iteration"] for v in wino))
         except Exception:
             pass
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
         iters = world * w["B"] * args.steps
+        common = {"algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
+                  "launches_per_step": conv["launches"] / args.steps, "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
+                  "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9, "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
+                  # sum over every entry point of its ideal time (algorithmic FLOPs / fp32 MFMA peak for MFMA-class
+                  # calls, algorithmic bytes / 8 TB/s for HBM-class ones) / sum of the measured times
+                  "path": sum_ideal / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
+                  "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled, "kernels": kernels[:14],
+                  "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the side-stream "
+                              "branches of the forward run concurrently, as in the replayed graph)" % args.steps}
+        if dtype == "bf16":
+            # the bf16 convolution is HBM-class: 73.7 kFLOP per 512 B (64 -> 64) against a bf16 ridge of ~310 FLOP/B
+            gbs = conv["bytes"] / (conv["ms"] * 1e-3) / 1e9
+            roofline = dict(kernel="conv3x3_bf16_kernel (NHWC 3x3 stride-1 direct, v_mfma_f32_32x32x16_bf16, fp32 accumulate)", bound="hbm",
+                            achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=None,
+                            mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2500.0,
+                            path_note="ideal times of `path` are priced at the fp32 peaks (utils/workmodel.py)", **common)
+        else:
+            roofline = dict(kernel="conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)", bound="mfma",
+                            achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP32_MFMA_PEAK_TFLOPS,
+                            # `achieved` counts the ALGORITHMIC work of the convolution (2*9*Cin*Cout flop per output pixel); Winograd
+                            # issues 16/36 of those multiplies on the matrix cores, which is how frac can pass 1
+                            mfma_executed=achieved * 16.0 / 36.0, mfma_executed_frac=achieved * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS,
+                            traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src, **common)
         line = {
-            "metric": "registration iters/sec (KITTI 352x1216 img + 16384 pts, 1 geo forward + 10 agent steps)",
+            "metric": "registration iters/sec (%s %dx%d img + %d pts, 1 geo forward + %d agent steps)" % (
+                "KITTI" if w["cfg"] == "kitti" else "nuScenes", w["H"], w["W"], w["N"], w["steps"]),
             "value": ranks.aggregate_rate(w["B"] * args.steps, elapsed), "unit": "registration iters/s", "per_gpu": iters / elapsed / world,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: KittiConfig, batch 8 per GPU, 16384 pts, 352x1216 image, "
-                                   "10 agent steps, fp32, hash-filled weights", "batch_per_gpu": w["B"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": w["name"] + (", fp32" if dtype == "f32" else ", bf16 3x3 convolutions (fp32 accumulate and storage, "
+                                                "everything else fp32)") + ", hash-filled weights", "batch_per_gpu": w["B"],
                        "parallelism": "batch sharding, no data-path collective"},
-            "agent_steps_per_s": iters * w["steps"] / elapsed,
-            "roofline": {"kernel": "conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)",
-                         "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         # `achieved` counts the ALGORITHMIC work of the convolution (2*9*Cin*Cout flop per output pixel);
-                         # Winograd issues 16/36 of those multiplies on the matrix cores, which is how frac can pass 1
-                         "mfma_executed": achieved * 16.0 / 36.0, "mfma_executed_frac": achieved * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json)",
-                         "algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
-                         "launches_per_step": conv["launches"] / args.steps,
-                         "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
-                         "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9,
-                         "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
-                         # sum over every entry point of its ideal time (algorithmic FLOPs / fp32 MFMA peak for
-                         # MFMA-class calls, algorithmic bytes / 8 TB/s for HBM-class ones) / sum of the measured times
-                         "path": sum_ideal / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
-                         "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled,
-                         "kernels": kernels[:14],
-                         "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the "
-                                     "side-stream branches of the forward run concurrently, as in the replayed graph)" % args.steps},
+            "agent_steps_per_s": iters * w["steps"] / elapsed, "roofline": roofline,
             "launch_mode": "eager" if args.eager else "hipGraph replay",
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c1":
             line["cpu_baseline"] = cpu_baseline(spec)
         print(json.dumps(line))
     ranks.close()

@@ -1,0 +1,245 @@
+// Stride-1 3x3 convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the bf16 variant of
+// the convolution kernels (SURVEY.md 7 step 9 / BASELINE configs[2], configs[3]).  Activations stay fp32 NHWC in HBM (same
+// buffers, same epilogue as the fp32 kernels: folded-BN bias, residual, LeakyReLU, positional table, fused 2x2 average
+// pool); operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) when the halo tile is staged in LDS,
+// weights are packed to bf16 MFMA fragments when the module's plan is built.
+//
+// The bf16 MFMA rate is 16 x the fp32 one, so the direct form is already HBM-bound (a 64 -> 64 layer moves 512 B per pixel
+// for 73.7 kFLOP: 3.5 GB / 8 TB/s = 0.44 ms at 352x1216x8 against 0.10 ms of matrix time) and Winograd's transforms
+// would only cost accuracy.  What has to be organised is operand reuse, not multiplies:
+//   * persistent workgroups (one per CU): the 9 x Cin x (32 NT) weight slice of the workgroup's cout group is loaded
+//     into LDS ONCE (72 KB as ready-made A fragments, 1 KB per wave read) and reused for every spatial tile it processes;
+//   * per tile the (8+2) x (TW+2) pixel halo is converted to bf16 into LDS (pixel stride Cin*2 + 16 bytes: conflict-free
+//     ds_read_b128 of 8 channels for 16 consecutive pixels), the next tile's global loads are already in flight in
+//     registers while the current tile is multiplied (one wave per SIMD: up to 512 VGPRs, the prefetch costs nothing);
+//   * B operand = 32 pixels x 16 channels of one tap straight from the halo image (lane = pixel), A = weight fragment;
+//     every MFMA is fed by at most two ds_read_b128, which the LDS array sustains (MI355X_MICROARCH.md, LDS issue rates).
+#include "cmr_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct B16Args {
+  const float* x; int B, H, W;
+  const void* wfrag;     // [Cout/(32 NT)][9 taps][Cin/16][NT][64 lanes][8] bf16
+  const float* bias; const float* res; const float* post;
+  float* y; int Cout; float slope; int pool;
+  int tiles_x, tiles_y;
+};
+
+__device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// TW = 32: wave w owns rows 2w, 2w+1 as two 32-pixel blocks (lane = column).
+// TW = 16: wave w owns rows 2w, 2w+1 as ONE block (lane = 16 (row & 1) + column).
+template <int CIN, int NT, int TW>
+__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
+  constexpr int KS = CIN / 16, NB = TW / 16;
+  constexpr int TH = 8, HR = TH + 2, HC = TW + 2;
+  constexpr int PS = CIN * 2 + 16;                      // bytes per halo pixel
+  constexpr int WBYTES = 9 * KS * NT * 1024;
+  constexpr int C4 = CIN / 4;
+  constexpr int NPIECE = HR * HC * C4;
+  constexpr int NLOAD = (NPIECE + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Ws = smem;
+  unsigned char* Xs = smem + WBYTES;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ngroups = a.Cout / (32 * NT);
+  const int group = blockIdx.x % ngroups;
+  const int co0 = group * 32 * NT;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(a.wfrag) + (size_t)group * WBYTES);
+    for (int i = tid; i < WBYTES / 16; i += 256) reinterpret_cast<uint4*>(Ws)[i] = src[i];
+  }
+  const int nsp = a.B * a.tiles_y * a.tiles_x;
+  const int step = gridDim.x / ngroups;
+
+  struct Tile { int b, oy0, ox0; };
+  auto decode = [&](int s) {
+    Tile t;
+    t.ox0 = (s % a.tiles_x) * TW; s /= a.tiles_x;
+    t.oy0 = (s % a.tiles_y) * TH;
+    t.b = s / a.tiles_y;
+    return t;
+  };
+  f32x4 pv[NLOAD];
+  auto issue_loads = [&](int s) {                      // branch-free: clamped addresses, padding applied at the LDS store
+    const Tile t = decode(s);
+    const float* xb = a.x + (int64_t)t.b * a.H * a.W * CIN;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      int e = tid + 256 * i;
+      e = e < NPIECE ? e : NPIECE - 1;
+      const int p = e / C4, c = e - p * C4;
+      int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      pv[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN + 4 * c));
+    }
+  };
+  auto store_lds = [&](int s) {
+    const Tile t = decode(s);
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int e = tid + 256 * i;
+      if (e < NPIECE) {
+        const int p = e / C4, c = e - p * C4;
+        const int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+        const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        bf16x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (__bf16)(inb ? pv[i][k] : 0.f);
+        *reinterpret_cast<bf16x4*>(Xs + p * PS + c * 8) = v;
+      }
+    }
+  };
+
+  int s = blockIdx.x / ngroups;
+  if (s < nsp) issue_loads(s);
+  // this lane's pixel inside the tile, per block
+  int prow[NB], pcol[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    prow[nb] = TW == 32 ? 2 * wave + nb : 2 * wave + (l31 >> 4);
+    pcol[nb] = TW == 32 ? l31 : (l31 & 15);
+  }
+  for (; s < nsp; s += step) {
+    __syncthreads();                                    // weights resident (first pass) / everybody done with the previous halo image
+    store_lds(s);
+    __syncthreads();
+    {
+      const int sn = s + step < nsp ? s + step : s;     // last tile: a harmless re-read instead of a branch around the loads
+      issue_loads(sn);
+    }
+    f32x16 acc[NT][NB];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][nb][r] = 0.f;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        bf16x8 av[NT], bv[NB];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          av[nt] = *reinterpret_cast<const bf16x8*>(Ws + ((tap * KS + ks) * NT + nt) * 1024 + lane * 16);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          bv[nb] = *reinterpret_cast<const bf16x8*>(Xs + ((prow[nb] + ky) * HC + pcol[nb] + kx) * PS + ks * 32 + h * 16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv[nb], acc[nt][nb], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: register 4q+e of tile nt = channel co0 + 32 nt + 8q + 4h + e of this lane's pixel
+    const Tile t = decode(s);
+    const int Ho = a.H, Wo = a.W;
+    if (a.pool == 2) {
+      // LeakyReLU(conv + bias), then the 2x2 mean: rows 2w / 2w+1 are the two blocks (TW = 32) or lane halves 16 apart
+      // (TW = 16); the column partner is lane ^ 1
+      const int py = (t.oy0 >> 1) + wave, px = (t.ox0 >> 1) + (pcol[0] >> 1);
+      const bool writer = (l31 & 1) == 0 && (TW == 32 || (l31 & 16) == 0) && py < (Ho >> 1) && px < (Wo >> 1);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cq = co0 + nt * 32 + q * 8 + 4 * h;
+          const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq : b16_zero16);
+          f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = acc[nt][nb][4 * q + e] + bs[e];
+              sum[e] += v > 0.f ? v : v * a.slope;
+            }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = sum[e];
+            v += __shfl_xor(v, 1, 64);
+            if (TW == 16) v += __shfl_xor(v, 16, 64);
+            sum[e] = 0.25f * v;
+          }
+          if (writer) *reinterpret_cast<f32x4*>(a.y + (((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + cq) = sum;
+        }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int oy = t.oy0 + prow[nb], ox = t.ox0 + pcol[nb];
+        const bool ok = oy < Ho && ox < Wo;
+        const int64_t pix = ((int64_t)t.b * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0);
+        f32x4 ov[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cq = co0 + nt * 32 + q * 8 + 4 * h;
+            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq : b16_zero16);
+            const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res ? a.res + pix * a.Cout + cq : b16_zero16);
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float u = acc[nt][nb][4 * q + e] + bs[e] + rs[e];
+              v[e] = u > 0.f ? u : u * a.slope;
+            }
+            if (a.post) v += *reinterpret_cast<const f32x4*>(a.post + ((int64_t)(ok ? oy : 0) * Wo + (ok ? ox : 0)) * a.Cout + cq);
+            ov[nt][q] = v;
+          }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
+        if (ok) {
+          float* yp = a.y + pix * a.Cout + co0 + 4 * h;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nt][q];
+        }
+      }
+    }
+  }
+}
+
+template <int CIN, int NT, int TW>
+int launch_b16(B16Args a, hipStream_t stream) {
+  constexpr int smem = 9 * (CIN / 16) * NT * 1024 + 10 * (TW + 2) * (CIN * 2 + 16);
+  static_assert(smem <= 160 * 1024, "weight slice + halo image must fit in LDS");
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  a.tiles_x = (a.W + TW - 1) / TW;
+  a.tiles_y = (a.H + 7) / 8;
+  const int ngroups = a.Cout / (32 * NT);
+  const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
+  int per_group = 256 / ngroups;                       // one persistent workgroup per CU
+  if (per_group < 1) per_group = 1;
+  if (per_group > nsp) per_group = (int)nsp;
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
+  return cmr_launch_status();
+}
+
+}  // namespace
+
+extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
+                                         const float* res, const float* post, float* y, int Cout, float slope, int pool,
+                                         hipStream_t stream) {
+  CMR_REQUIRE(x && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(wfrag) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
+              (!post || cmr_aligned16(post)));
+  CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
+  CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
+  B16Args a{x, B, H, W, wfrag, bias, res, post, y, Cout, slope, pool, 0, 0};
+  if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 32>(a, stream);
+  if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 32>(a, stream);
+  if (Cin == 128 && nt == 1 && Cout % 32 == 0) return launch_b16<128, 1, 16>(a, stream);
+  return CMR_EUNSUPPORTED;
+}

@@ -78,6 +78,19 @@ def winograd_u(w):
     return u.permute(0, 1, 3, 4, 2, 5).contiguous().reshape(16, co, ci)
 
 
+def conv_bf16_frags(w):
+    """[Cout, Cin, 3, 3] fp32 -> (bf16 MFMA A fragments [Cout/(32 nt)][9][Cin/16][nt][64 lanes][8], nt) for
+    cmr_conv3x3_bf16_nhwc_f32, or None when the shape is not served.  lane = 32 h + l holds
+    W[cout = 32 (g nt + t) + l][cin = 16 ks + 8 h + j][ky][kx], j = 0..7 (round to nearest even)."""
+    co, ci = w.shape[0], w.shape[1]
+    if ci not in (64, 128) or co % 32:
+        return None
+    nt = 2 if (ci == 64 and co % 64 == 0) else 1
+    g = co // (32 * nt)
+    f = w.reshape(g, nt, 32, ci // 16, 2, 8, 3, 3).permute(0, 6, 7, 3, 1, 4, 2, 5)       # [g][ky][kx][ks][t][h][l][j]
+    return f.contiguous().to(torch.bfloat16).reshape(-1), nt
+
+
 def conv9(conv, bn=None, cin_slice=None):
     """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout], U fragments (16*Cout*Cin floats) for the Winograd kernel).
     cin_slice restricts the input channels (the agent's image / projection halves)."""
@@ -85,7 +98,9 @@ def conv9(conv, bn=None, cin_slice=None):
     if cin_slice is not None:
         w = w[:, cin_slice]
     co, ci = w.shape[0], w.shape[1]
-    return w.permute(2, 3, 0, 1).reshape(9, co, ci).contiguous(), b.contiguous(), winograd_u(w)
+    u = winograd_u(w)
+    u.bf16 = conv_bf16_frags(w)          # operands of the bf16 variant travel with the fp32 ones (ops.conv3x3 picks by ops.CONV_BF16)
+    return w.permute(2, 3, 0, 1).reshape(9, co, ci).contiguous(), b.contiguous(), u
 
 
 class Planned(nn.Module):

@@ -95,6 +95,7 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
     return out
 
 
+CONV_BF16 = False        # True: stride-1 3x3 convolutions run on the bf16 matrix cores (cmr_conv3x3_bf16_nhwc_f32) where served
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
 
@@ -113,6 +114,24 @@ def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     return y
 
 
+def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1):
+    """Stride-1 3x3 convolution on the bf16 matrix cores; frags = (bf16 fragment tensor, nt) from _pack.conv_bf16_frags.
+    Returns None when the library does not serve the shape (the caller falls back to the fp32 kernels)."""
+    B, H, W, cin = x.shape
+    wf, nt = frags
+    if not x.is_contiguous() or wf.dtype != torch.bfloat16 or wf.numel() != 9 * cin * cout:
+        raise ValueError("conv3x3_bf16: bad operand layout")
+    if pool == 2 and (res is not None or post is not None):
+        raise ValueError("conv3x3: pool=2 cannot be combined with res / post")
+    if pool == 2 and (H % 2 or W % 2):
+        return None
+    hp, wp = (H // 2, W // 2) if pool == 2 else (H, W)
+    y = torch.empty((B, hp, wp, cout), dtype=f32, device=x.device)
+    rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, float(slope), pool,
+                   _stream(), allow_unsupported=True)
+    return None if rc == _lib.UNSUPPORTED else y
+
+
 def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None):
     """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout] (or the 2x2 average-pooled
     map when pool=2: fused into the conv epilogue where the tiled kernel runs, a second kernel otherwise).
@@ -121,6 +140,10 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
         raise ValueError("conv3x3: bad operand layout")
+    if CONV_BF16 and stride == 1 and out is None and getattr(u, "bf16", None) is not None:
+        y = conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool)
+        if y is not None:
+            return y
     if (WINOGRAD and u is not None and stride == 1 and out is None
             and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= WINO_MIN_TILES):
         return conv3x3_wino(x, u, bias, cout, slope, res, post, pool)

@@ -50,6 +50,11 @@ def bench_conv(B, H, W, cin, cout, stride, reps):
         u = torch.randn(16, cout, cin, device=DEV) / math.sqrt(9 * cin)
         us2 = timeit(lambda: ops.conv3x3(x, w, b, cout, 1, 0.2, res=res, u=u), reps)
         line += "   | winograd %8.1f us  %6.1f algorithmic TFLOP/s" % (us2, fl / us2 / 1e6)
+        from cmr_agent_amd.models._pack import conv_bf16_frags
+        fr = conv_bf16_frags(torch.randn(cout, cin, 3, 3, device=DEV) / math.sqrt(9 * cin))
+        if fr is not None and ops.conv3x3_bf16(x, fr, b, cout, 0.2, res=res) is not None:
+            us3 = timeit(lambda: ops.conv3x3_bf16(x, fr, b, cout, 0.2, res=res), reps)
+            line += "   | bf16 %8.1f us  %6.1f TFLOP/s  %5.2f TB/s" % (us3, fl / us3 / 1e6, by / us3 / 1e6)
     print(line)
 
 
