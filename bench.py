@@ -91,8 +91,20 @@ def registration_step(geo, agent, cfg, batch):
     return pose.cpu()                                   # final pose D2H (Test_Agent.py:185)
 
 
-def cpu_baseline(spec, budget_s=20.0):
-    """The oracle on ONE sample of the workload shape (B=1), repeated while the budget lasts."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(spec, budget_s=25.0):
+    """The oracle on the SAME batch shape as the GPU step (B = 8 pairs of the workload), like for like: one warm-up pass on
+    a single pair, then the batch of 8 timed up to 3 times while the budget lasts (at least once); the median is reported
+    (SURVEY.md 8d asks for 1 warm-up + median of 5: 5 x ~8 s does not fit the bounded 10-30 s sample)."""
     from oracle import cmr_oracle as O
     w = WORKLOAD
     torch.set_num_threads(min(os.cpu_count() or 1, 32))     # past ~32 threads torch's small CPU ops only get slower
@@ -100,18 +112,20 @@ def cpu_baseline(spec, budget_s=20.0):
                              action_num=w["steps"])
     geo_sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
     agent_sd = hashfill.make_state_dict(spec["agent"], AGENT_TAG)
-    batch = synthetic.make_batch(1, w["N"], w["H"], w["W"], w["M"], O.dataset_fps, O.nearest_node, seed=2023, n_circle=16)
-    n, t0 = 0, time.perf_counter()
+    batch = synthetic.make_batch(w["B"], w["N"], w["H"], w["W"], w["M"], O.dataset_fps, O.nearest_node, seed=2023, n_circle=16)
+    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == w["B"] else v) for k, v in batch.items()}
+    times, t_start = [], time.perf_counter()
     with torch.no_grad():
-        while True:
+        O.registration_iteration(geo_sd, agent_sd, one, cfg)                    # warm-up (allocator, thread pool)
+        while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
+            t0 = time.perf_counter()
             O.registration_iteration(geo_sd, agent_sd, batch, cfg)
-            n += 1
-            if time.perf_counter() - t0 > budget_s or n >= 16:
-                break
-    dt = time.perf_counter() - t0
-    return dict(value=n / dt, unit="registration iters/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d x (1 sample: 1 geo forward + %d agent steps, %dx%d image, %d points) through oracle/cmr_oracle.py, "
-                       "torch CPU fp32" % (n, w["steps"], w["H"], w["W"], w["N"]))
+            times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return dict(value=w["B"] / med, unit="registration iters/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
+                sample="median of %d timed passes (after 1 warm-up on one pair) over the batch of %d pairs (1 geo forward + %d agent "
+                       "steps, %dx%d image, %d points) through oracle/cmr_oracle.py, torch CPU fp32; seconds per pass: %s"
+                       % (len(times), w["B"], w["steps"], w["H"], w["W"], w["N"], ", ".join("%.2f" % t for t in times)))
 
 
 def train_main(args):

@@ -86,3 +86,32 @@ def test_agent_image_half_cache_is_per_registration():
     # leave l2 at l1's image contribution
     assert float((l1 - l2).abs().max()) > 5 * tol
     assert float((l2 - want).abs().max()) < tol, float((l2 - want).abs().max())
+
+
+def test_entry_point_scripts_run_end_to_end(tmp_path):
+    """Test_Agent.py and Train_Agent.py (the reference's entry points) on small synthetic pairs: the
+    evaluation prints a recall, the training loop reaches an agent update (num_trajectory = 4 batches) with finite
+    losses and writes a checkpoint with the reference's state_dict keys."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "Test_Agent.py"), "--pairs", "2", "--num-pt", "4096"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "Registration Recall:" in r.stdout
+    out = tmp_path / "ckpt"
+    r = subprocess.run([sys.executable, os.path.join(root, "Train_Agent.py"), "--batches", "4", "--img", "96x160", "--num-pt", "2048",
+                        "--batch-size", "2", "--out", str(out)], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    logs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    upd = [l for l in logs if "train_loss/BC_Loss" in l]
+    assert len(upd) == 1 and upd[0]["minibatches"] == 8                 # 4 trajectories x 10 steps x 2 pairs / 10
+    assert all(abs(upd[0][k]) < 1e4 for k in ("train_loss/BC_Loss", "train_loss/PPO_Loss"))
+    ck = [f for f in os.listdir(out) if f.endswith(".pth")]
+    assert ck
+    sd = torch.load(os.path.join(out, ck[0]), map_location="cpu")
+    spec = json.load(open(os.path.join(root, "tests", "golden", "specs.json")))["agent"]
+    assert set(sd) == set(spec) and all(list(sd[k].shape) == spec[k] for k in spec)
