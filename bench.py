@@ -143,6 +143,8 @@ def train_main(args):
     dev = torch.device("cuda", local_rank)
     ranks = Ranks(backend="nccl", device=dev)
     w = WORKLOAD
+    dtype = args.dtype or "f32"
+    ops.CONV_BF16 = dtype == "bf16"      # forward and data-gradient convolutions on the bf16 cores; weight gradients stay fp32
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
     agent = CMRAgent(cfg)
@@ -178,9 +180,10 @@ def train_main(args):
             "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
             "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "agent update: minibatch of 10 observations [128,88,304] + [5,16384] per GPU, BC + PPO loss, "
-                                   "Adam (lr 1e-3, betas .9/.99, wd 1e-6)", "minibatch_per_gpu": MB,
+                                   "Adam (lr 1e-3, betas .9/.99, wd 1e-6)" + ("; forward / data-gradient 3x3 convolutions in bf16 (fp32 "
+                                   "accumulate), weight gradients and everything else fp32" if dtype == "bf16" else ""), "minibatch_per_gpu": MB,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
             "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,

@@ -3,9 +3,8 @@
 //   cat([embed_2d, embed_3d])                                                                (state, 256)
 //   policy_r / policy_t / value: three 3-layer MLPs with LeakyReLU                           (logits, value)
 // All of it is 8-row (one row per sample) matrix-vector work: as thirteen separate launches it is pure launch
-// latency (~90 us per agent step).  One workgroup per sample; a wave produces one output channel at a time
-// (lanes split the input vector in float4 pieces, one coalesced row read, xor-shuffle reduction); the three heads
-// advance layer by layer together so that every layer is a single pass over 16 waves.
+// latency (~90 us per agent step).  One workgroup per (sample, head); a wave produces one output channel at a time
+// (lanes split the input vector in float4 pieces, one coalesced row read, xor-shuffle reduction).
 #include "cmr_common.h"
 
 namespace {
@@ -60,7 +59,7 @@ __device__ __forceinline__ void ah_gemv(const float* __restrict__ W, const float
 __global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a) {
   __shared__ __attribute__((aligned(16))) float red[8][AH_C];
   __shared__ __attribute__((aligned(16))) float va[AH_C], vb[AH_C], state[AH_STATE];
-  __shared__ __attribute__((aligned(16))) float h0[3][AH_MAXW], h1[3][AH_MAXW];
+  __shared__ __attribute__((aligned(16))) float h0[1][AH_MAXW], h1[1][AH_MAXW];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // ---- AvgPool2d((H, W)): per-sample channel mean, 8 pixel groups x 128 channels, fixed summation order
@@ -69,6 +68,13 @@ __global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a)
     const float* xp = a.x + (int64_t)b * a.npix * AH_C + c;
     float s = 0.f;
     int p = g;
+    for (; p + 120 < a.npix; p += 128) {                      // 16 loads in flight per thread
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = xp[(int64_t)(p + 8 * i) * AH_C];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += v[i];
+    }
     for (; p + 56 < a.npix; p += 64) {                        // 8 loads in flight per thread
       float v[8];
 #pragma unroll
@@ -92,16 +98,14 @@ __global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a)
   __syncthreads();
   ah_gemv(a.w26, a.b26, vb, AH_C, AH_C, state, false, a.slope, wave, lane);
   __syncthreads();
-  // ---- the three heads, layer by layer
-#pragma unroll
-  for (int i = 0; i < 3; ++i) ah_gemv(a.h[i].w0, a.h[i].b0, state, AH_STATE, a.h[i].n0, h0[i], true, a.slope, wave, lane);
+  // ---- ONE head per workgroup (blockIdx.y): the pool and the two 1x1 convs above are recomputed by the three workgroups
+  // of a sample (345 KB of reads), which is cheaper than streaming the three heads' 1.2 MB through one CU layer by layer
+  const AhHead& hd = a.h[blockIdx.y];
+  ah_gemv(hd.w0, hd.b0, state, AH_STATE, hd.n0, h0[0], true, a.slope, wave, lane);
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 3; ++i) ah_gemv(a.h[i].w1, a.h[i].b1, h0[i], a.h[i].n0, a.h[i].n1, h1[i], true, a.slope, wave, lane);
+  ah_gemv(hd.w1, hd.b1, h0[0], hd.n0, hd.n1, h1[0], true, a.slope, wave, lane);
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 3; ++i)
-    ah_gemv(a.h[i].w2, a.h[i].b2, h1[i], a.h[i].n1, a.h[i].n2, a.h[i].out + (int64_t)b * a.h[i].ldo, false, a.slope, wave, lane);
+  ah_gemv(hd.w2, hd.b2, h1[0], hd.n1, hd.n2, hd.out + (int64_t)b * hd.ldo, false, a.slope, wave, lane);
 }
 
 }  // namespace
@@ -128,6 +132,6 @@ extern "C" int cmr_agent_heads_f32(const float* x, int B, int npix, const float*
     CMR_REQUIRE(h.n0 > 0 && h.n0 <= AH_MAXW && h.n0 % 4 == 0 && h.n1 > 0 && h.n1 <= AH_MAXW && h.n1 % 4 == 0);
     CMR_REQUIRE(cmr_aligned16(h.w0) && cmr_aligned16(h.w1) && cmr_aligned16(h.w2));
   }
-  hipLaunchKernelGGL(agent_heads_kernel, dim3(B), dim3(AH_THREADS), 0, stream, a);
+  hipLaunchKernelGGL(agent_heads_kernel, dim3(B, 3), dim3(AH_THREADS), 0, stream, a);
   return cmr_launch_status();
 }

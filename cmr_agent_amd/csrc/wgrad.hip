@@ -231,8 +231,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* _
 // of the forward kernels: w9 [9][Co'][Ci'] and Winograd U = G g G^T as MFMA A fragments [16][Co'/32][Ci'/8][64][4].
 // transpose != 0 gives the data-gradient convolution: W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx].
 // ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 wg_bf16;
+
 __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int transpose, float* __restrict__ w9,
-                                                           float* __restrict__ ufrag) {
+                                                           float* __restrict__ ufrag, wg_bf16* __restrict__ bfrag, int nt) {
   const int Cop = transpose ? Ci : Co, Cip = transpose ? Co : Ci;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cop * Cip) return;
@@ -245,6 +247,14 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
       g[ky][kx] = transpose ? w[((int64_t)c * Ci + o) * 9 + (2 - ky) * 3 + (2 - kx)] : w[((int64_t)o * Ci + c) * 9 + ky * 3 + kx];
 #pragma unroll
   for (int t = 0; t < 9; ++t) w9[((int64_t)t * Cop + o) * Cip + c] = g[t / 3][t % 3];
+  if (bfrag) {
+    // bf16 A fragments of cmr_conv3x3_bf16_nhwc_f32: [Co'/(32 nt)][9][Ci'/16][nt][64 lanes][8], lane = 32 h + (o & 31) holding
+    // W'[o][c = 16 ks + 8 h + j]
+    const int grp = o / (32 * nt), tt = (o / 32) % nt, ks = c >> 4, hh = (c >> 3) & 1, j = c & 7;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      bfrag[(((((int64_t)grp * 9 + t) * (Cip / 16) + ks) * nt + tt) * 64 + hh * 32 + (o & 31)) * 8 + j] = (wg_bf16)g[t / 3][t % 3];
+  }
   if (!ufrag) return;
   // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
   float gg[4][3];
@@ -340,9 +350,12 @@ extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const 
   return cmr_launch_status();
 }
 
-extern "C" int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, hipStream_t stream) {
+extern "C" int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, void* bf16_frag, int bf16_nt,
+                                    hipStream_t stream) {
   CMR_REQUIRE(w && w9 && Cout > 0 && Cin > 0);
   if (ufrag) CMR_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0);
-  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, stream, w, Cout, Cin, transpose, w9, ufrag);
+  if (bf16_frag) CMR_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0 && (bf16_nt == 1 || bf16_nt == 2) && (transpose ? Cin : Cout) % (32 * bf16_nt) == 0);
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, stream, w, Cout, Cin, transpose, w9, ufrag,
+                     (wg_bf16*)bf16_frag, bf16_nt);
   return cmr_launch_status();
 }

@@ -706,5 +706,11 @@ def pack_conv3x3(w, cout, cin, transpose=False, want_u=True):
     co, ci = (cin, cout) if transpose else (cout, cin)
     w9 = torch.empty((9, co, ci), dtype=f32, device=w.device)
     u = torch.empty((16, co, ci), dtype=f32, device=w.device) if want_u and co % 32 == 0 and ci % 32 == 0 else None
-    _lib.call("cmr_pack_conv3x3_f32", _p(w), cout, cin, int(transpose), _p(w9), _p(u), _stream())
+    bf, nt = None, 1
+    if CONV_BF16 and u is not None and ci in (64, 128):          # operands of the bf16 variant, same attribute as _pack.conv9 sets
+        nt = 2 if (ci == 64 and co % 64 == 0) else 1
+        bf = torch.empty((9 * co * ci,), dtype=torch.bfloat16, device=w.device)
+    _lib.call("cmr_pack_conv3x3_f32", _p(w), cout, cin, int(transpose), _p(w9), _p(u), _p(bf), nt, _stream())
+    if bf is not None:
+        u.bf16 = (bf, nt)
     return w9, u

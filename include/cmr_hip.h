@@ -362,8 +362,10 @@ int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k);
 int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
                          int64_t lddw, int accumulate, void* ws, int64_t ws_bytes, hipStream_t stream);
 /* nn.Conv2d weight [Cout][Cin][3][3] -> operand layouts of the forward kernels (w9 [9][Co'][Ci'] and the Winograd
- * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]. */
-int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, hipStream_t stream);
+ * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx].  bf16_frag
+ * (optional) receives the bf16 A fragments of cmr_conv3x3_bf16_nhwc_f32 for cout groups of 32 * bf16_nt. */
+int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int transpose, float* w9, float* ufrag, void* bf16_frag, int bf16_nt,
+                         hipStream_t stream);
 
 /* ---- dataset-side geometry of one frame ------------------------------------------ */
 /* dataset/KittiDataset.py:273-276, :284, :312-336 (same code in NuScenesDataset.py): velodyne -> camera transform of the

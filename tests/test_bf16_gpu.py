@@ -79,3 +79,68 @@ def test_registration_iteration_bf16_convolutions_meet_the_bf16_bars():
     assert same >= 0.95 * total
     ov = (got["pc_overlap_pred"] == ref["pc_overlap_pred"]).double().mean()
     assert float(ov) >= 0.98, float(ov)
+
+
+@pytest.mark.parametrize("cout,cin", [(128, 128), (64, 64), (64, 128), (128, 64)])
+def test_pack_kernel_bf16_fragments(cout, cin):
+    """cmr_pack_conv3x3_f32's bf16 output (the per-step repacking of the agent update) == the plan-time packing, bit for
+    bit, for the forward weights and for the transposed + flipped data-gradient weights."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import conv_bf16_frags
+    w = (rnd(cout, cin, 3, 3, seed=7) / 10).to(DEV)
+    ops.CONV_BF16 = True
+    try:
+        _, u = ops.pack_conv3x3(w.reshape(-1), cout, cin)
+        _, ut = ops.pack_conv3x3(w.reshape(-1), cout, cin, transpose=True)
+    finally:
+        ops.CONV_BF16 = False
+    ref, nt = conv_bf16_frags(w)
+    assert u.bf16[1] == nt and torch.equal(u.bf16[0].view(torch.int16), ref.view(torch.int16))
+    reft, ntt = conv_bf16_frags(w.transpose(0, 1).flip(2, 3).contiguous())
+    assert ut.bf16[1] == ntt and torch.equal(ut.bf16[0].view(torch.int16), reft.view(torch.int16))
+
+
+def test_agent_update_with_bf16_convolutions():
+    """BASELINE configs[2] names a bf16 training update: forward and data-gradient convolutions on the bf16 cores (weight
+    gradients, BatchNorm, loss, Adam fp32) against the fp32 oracle: logits within 2e-2 of their scale, every sizeable
+    parameter gradient with cosine >= 0.98 to the oracle's (observed: 0.988 on the first conv, whose gradient has crossed
+    seven bf16 data-gradient convolutions; > 0.999 on the heads)."""
+    import json
+    import os
+    import cases as C
+    import golden_util as G
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train import AgentUpdate
+    from cmr_agent_amd.utils import hashfill
+    from cmr_agent_amd.utils.checkpoint import load_checked
+    from oracle import train_oracle as TO
+    specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+    case = "agent_train_small"
+    cfg_d, cfg_c = C.train_config(case, device=DEV), C.train_config(case)
+    batch = C.train_inputs(case)[0]
+    sd0 = {k: v for k, v in hashfill.make_state_dict(specs["agent"], C.AGENT_TAG).items() if not k.endswith("num_batches_tracked")}
+    agent = CMRAgent(cfg_d)
+    load_checked(agent, hashfill.make_state_dict(specs["agent"], C.AGENT_TAG))
+    up = AgentUpdate(agent.to(DEV), cfg_d)
+    ops.CONV_BF16 = True
+    try:
+        losses, (r, t, v) = up.forward_backward({k: x.to(DEV) for k, x in batch.items()})
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_BF16 = False
+    with torch.enable_grad():
+        ol, og, (orr, ot, ov) = TO.agent_forward_backward({k: x.clone() for k, x in sd0.items()}, batch, cfg_c, True)
+    for got, ref in ((r, orr), (t, ot), (v, ov)):
+        assert float((got.cpu() - ref).abs().max()) <= 2e-2 * max(1.0, float(ref.abs().max()))
+    assert abs(float(losses[0]) - float(ol["loss"])) <= 2e-2 * abs(float(ol["loss"]))
+    grads = up.bucket.logical_grads()
+    gmax = max(float(g.norm()) for g in og.values())
+    worst = 1.0
+    for k, ref in og.items():
+        if float(ref.norm()) < 1e-3 * gmax:
+            continue
+        cos = float(F.cosine_similarity(grads[k].cpu().double().reshape(1, -1), ref.double().reshape(1, -1)))
+        worst = min(worst, cos)
+        assert cos >= 0.98, (k, cos)
+    print("  worst gradient cosine %.5f" % worst)
