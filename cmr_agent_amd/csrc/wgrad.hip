@@ -43,27 +43,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
   const float* xb = x + ci_t * 32 + l31;
   const float* db = dy + co_t * 32 + l31;
   const int last_pix = B * H * W - 1;
+  const int cin_sh = 31 - __builtin_clz(Cin), cout_sh = 31 - __builtin_clz(Cout);   // channel counts are powers of two (host check)
 
-  // coordinates of this lane's pixel of pair q
+  // coordinates of this lane's pixel of pair q: linear index 2q + h, (x, y) only for the padding masks
   int p = 2 * w0 + h;
-  int xx = p % W, t_ = p / W, yy = t_ % H, bb = t_ / H;
+  int xx = p % W, yy = (p / W) % H;
 
-  float a_cur, v_cur[9], a_nxt = 0.f, v_nxt[9];
+  // Integer work per step is kept to adds, clamps and shifts: the first version recomputed (b H + y) W + x and multiplied by
+  // the channel count for every tap -- 20 v_mul_lo_u32 + 12 v_mad_u64_u32 (quarter rate) per step, ~900 issue cycles
+  // against 576 cycles of MFMA, i.e. the kernel was VALU-bound at 48 % of its matrix bound whatever the prefetch depth.
   // Addresses: any linear pixel index clamped to [0, last_pix] is readable; whether a tap lies inside the image is decided
-  // by the masks (3 row tests x 3 column tests), so the loads need one add and one clamp each and no 2-D arithmetic.
-  auto load = [&](float& a, float (&v)[9], int bq, int yq, int xq) {
-    const int base = (bq * H + yq) * W + xq;
-    a = db[(int64_t)min(base, last_pix) * Cout];
-    a = base <= last_pix ? a : 0.f;               // odd pixel count: the second lane half of the last pair
+  // by the masks (3 row tests x 3 column tests).
+  int toff[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+  for (int t = 0; t < 9; ++t) toff[t] = (t / 3 - 1) * W + (t % 3 - 1);
+  auto load = [&](float& a, float (&v)[9], int base) {
+    a = db[(int64_t)(min(base, last_pix) << cout_sh)];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int pix = min(max(base + (ky - 1) * W + (kx - 1), 0), last_pix);
-        v[ky * 3 + kx] = xb[(int64_t)pix * Cin];
-      }
+    for (int t = 0; t < 9; ++t) v[t] = xb[(int64_t)(min(max(base + toff[t], 0), last_pix) << cin_sh)];
   };
-  auto mask = [&](float (&v)[9], int yq, int xq) {
+  auto mask = [&](float& a, float (&v)[9], int base, int yq, int xq) {
+    a = base <= last_pix ? a : 0.f;               // odd pixel count: the second lane half of the last pair
     const bool oy[3] = {yq > 0, true, yq < H - 1};
     const bool ox[3] = {xq > 0, true, xq < W - 1};
 #pragma unroll
@@ -72,23 +72,46 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
       for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = (oy[ky] && ox[kx]) ? v[ky * 3 + kx] : 0.f;
   };
 
+  constexpr int NSET = 3;                         // two steps (20 loads) in flight
+  float sa[NSET], sv[NSET][9];
+  int sp[NSET], sx[NSET], sy[NSET];
+  auto advance = [&](int& xq, int& yq) {
+    xq += 2;
+    if (xq >= W) { xq -= W; ++yq; }              // W >= 2: one wrap per step
+    if (yq >= H) yq -= H;
+  };
+  sp[0] = p; sx[0] = xx; sy[0] = yy;
+#pragma unroll
+  for (int i = 1; i < NSET - 1; ++i) {
+    sp[i] = sp[i - 1] + 2; sx[i] = sx[i - 1]; sy[i] = sy[i - 1];
+    advance(sx[i], sy[i]);
+  }
   if (w0 < w1) {
-    load(a_cur, v_cur, bb, yy, xx);
-    mask(v_cur, yy, xx);
-  }
-  for (int q = w0; q < w1; ++q) {
-    int xn = xx + 2, yn = yy, bn = bb;
-    if (xn >= W) { xn -= W; ++yn; }              // W >= 2: one wrap per step
-    if (yn >= H) { yn -= H; ++bn; }
-    load(a_nxt, v_nxt, bn, yn, xn);          // past the end of the slice this reads a valid, unused address
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[t] = cmr_mfma32(a_cur, v_cur[t], acc[t]);
-    mask(v_nxt, yn, xn);
-    a_cur = a_nxt;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) v_cur[t] = v_nxt[t];
-    xx = xn; yy = yn; bb = bn;
+    for (int i = 0; i < NSET - 1; ++i) load(sa[i], sv[i], sp[i]);   // past the end of the slice: valid, unused addresses
   }
+  // Register sets rotate through the roles (consumed now | loaded earlier | being loaded) and nothing ever COPIES a loaded
+  // value: a rotation by assignment (cur = nxt) reads the load's destination and drags an s_waitcnt vmcnt(0) to the top of
+  // every iteration.  The padding mask is applied when a set is consumed, for the same reason.
+#define CMR_WG_STEP(C, VALID)                                                              \
+  {                                                                                        \
+    constexpr int L = (C + NSET - 1) % NSET, P = (C + NSET - 2) % NSET;                    \
+    sp[L] = sp[P] + 2; sx[L] = sx[P]; sy[L] = sy[P];                                       \
+    advance(sx[L], sy[L]);                                                                 \
+    load(sa[L], sv[L], sp[L]);                                                             \
+    __builtin_amdgcn_sched_barrier(0); /* the loads are issued BEFORE this step's MFMAs */ \
+    mask(sa[C], sv[C], sp[C], sy[C], sx[C]);                                               \
+    const float av = (VALID) ? sa[C] : 0.f;                                                \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) acc[t] = cmr_mfma32(av, sv[C][t], acc[t]); \
+  }
+  // straight-line groups of NSET steps (one exit: extra exits made hipcc spill the accumulators); the last group's steps
+  // past the end of the slice multiply by a zero dY
+  for (int q = w0; q < w1; q += NSET) {
+    CMR_WG_STEP(0, true)
+    CMR_WG_STEP(1, q + 1 < w1)
+    CMR_WG_STEP(2, q + 2 < w1)
+  }
+#undef CMR_WG_STEP
 
   float* out = part + ((int64_t)(blockIdx.x * NSPLIT + split) * 9) * Cout * Cin;
 #pragma unroll
@@ -158,7 +181,9 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     xcol[t] = x + (k_ok[t] ? t * 32 + l31 : 0);
   }
 
-  float a_cur[UNR], v_cur[UNR][KT], a_nxt[UNR], v_nxt[UNR][KT];
+  // two register sets alternate between "consumed now" and "being loaded" (no copies of loaded values, masks applied at
+  // consumption: see conv3x3_wgrad_kernel); steps past the end of the slice are masked to zero by their row test
+  float sa[2][UNR], sv[2][UNR][KT];
   auto load = [&](float (&a)[UNR], float (&v)[UNR][KT], int64_t step) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
@@ -169,34 +194,30 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
       for (int t = 0; t < KT; ++t) v[u][t] = xcol[t][rc * ldx];
     }
   };
-  auto mask = [&](float (&a)[UNR], float (&v)[UNR][KT], int64_t step) {
+  auto mask = [&](float (&a)[UNR], float (&v)[UNR][KT], int64_t step, bool live) {
 #pragma unroll
     for (int u = 0; u < UNR; ++u) {
-      const bool ok = (step * UNR + u) * 2 + h < rows;
+      const bool ok = live && (step * UNR + u) * 2 + h < rows;
       a[u] = ok && n_ok ? a[u] : 0.f;
 #pragma unroll
       for (int t = 0; t < KT; ++t) v[u][t] = k_ok[t] ? v[u][t] : 0.f;
     }
   };
-  if (w0 < w1) {
-    load(a_cur, v_cur, w0);
-    mask(a_cur, v_cur, w0);
+  const int64_t last = nsteps - 1;
+  if (w0 < w1) load(sa[0], sv[0], w0);
+#define CMR_LW_STEP(C, L, S)                                                                 \
+  {                                                                                          \
+    load(sa[L], sv[L], (S) + 1 < nsteps ? (S) + 1 : last);                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    mask(sa[C], sv[C], (S), (S) < w1);                                                       \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                          \
+      _Pragma("unroll") for (int t = 0; t < KT; ++t) acc[t] = cmr_mfma32(sa[C][u], sv[C][u][t], acc[t]); \
   }
-  for (int64_t s = w0; s < w1; ++s) {
-    const int64_t sn = s + 1 < nsteps ? s + 1 : s;
-    load(a_nxt, v_nxt, sn);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u)
-#pragma unroll
-      for (int t = 0; t < KT; ++t) acc[t] = cmr_mfma32(a_cur[u], v_cur[u][t], acc[t]);
-    mask(a_nxt, v_nxt, sn);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      a_cur[u] = a_nxt[u];
-#pragma unroll
-      for (int t = 0; t < KT; ++t) v_cur[u][t] = v_nxt[u][t];
-    }
+  for (int64_t s = w0; s < w1; s += 2) {
+    CMR_LW_STEP(0, 1, s)
+    CMR_LW_STEP(1, 0, s + 1)
   }
+#undef CMR_LW_STEP
   float* out = part + (int64_t)(blockIdx.x * NSPLIT + split) * (NT * 32) * (KT * 32);
 #pragma unroll
   for (int t = 0; t < KT; ++t)
@@ -300,7 +321,7 @@ extern "C" int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci
 extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                                      int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W >= 2);
-  CMR_REQUIRE(Cout % 32 == 0 && (Cin == 32 || Cin == 64 || Cin == 128));
+  CMR_REQUIRE((Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (Cin == 32 || Cin == 64 || Cin == 128));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff * 16);
   CMR_REQUIRE((int64_t)B * H * W < 0x7fffffff);
   const int nci = Cin / 32, nsplit = 4 / nci;
