@@ -406,6 +406,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
                                                      const float* __restrict__ bias /*[64] (both BN shifts)*/,
                                                      float* __restrict__ y, int B, int H, int W, float slope) {
   __shared__ __attribute__((aligned(16))) float ws[64 * 36];
+  __shared__ __attribute__((aligned(16))) float tpatch[4 * 32 * 68];      // output transpose, one 32 x 64 patch per wave
   for (int e = threadIdx.x; e < 64 * 32; e += 256) {
     const int c = e >> 5, k = e & 31;
     ws[c * 36 + k] = k < 27 ? w3[k * 64 + c] : (k < 30 ? w1[(k - 27) * 64 + c] : 0.f);
@@ -505,10 +506,24 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
       }
 #pragma unroll
     for (int i = 0; i < 8; ++i) cmr_pin(ov[i]);
-    if (p < total) {
-      float* yp = y + p * 64 + 4 * h;
+    // The 876 MB output map is the kernel's traffic.  With lane = pixel a store instruction scattered 32-byte pieces over 32
+    // different 256-byte rows; the tile goes through the wave's private LDS patch instead (row pitch 68 floats: conflict
+    // free both ways; LDS instructions of one wave execute in order, so no barrier) and leaves as 8 stores of 1 KB each:
+    // 16 lanes x 16 B = one whole pixel row, 4 consecutive rows per instruction.
+    float* tp = tpatch + wave * (32 * 68);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(yp + 8 * i) = ov[i];
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(&tp[l31 * 68 + 8 * i + 4 * h]) = ov[i];
+    f32x4 rv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rv[i] = *reinterpret_cast<const f32x4*>(&tp[(4 * i + (lane >> 4)) * 68 + 4 * (lane & 15)]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cmr_pin(rv[i]);
+    {
+      const int64_t p0 = tile * 32 + (lane >> 4);
+      float* yp = y + p0 * 64 + 4 * (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (p0 + 4 * i < total) *reinterpret_cast<f32x4*>(yp + (int64_t)(4 * i) * 64) = rv[i];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) xc[i] = xn[i];

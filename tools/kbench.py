@@ -139,6 +139,12 @@ def main():
     if "vit" in a.what:
         bench_vit(8 * 418, 8 * 256, 8, a.reps)
         bench_vit(8 * 256, 8 * 418, 8, a.reps)
+    if "stem" in a.what:
+        r = lambda *shape: torch.randn(*shape, device=DEV) * 0.1
+        img = torch.rand(8, 3, 352, 1216, device=DEV)
+        t = timeit(lambda: ops.stem_block(img, r(3, 3, 3, 3), r(3), r(27, 64), r(3, 64), r(64), 0.2), a.reps)
+        by = 8 * 352 * 1216 * (3 + 64) * 4.0
+        print("stem_block 8x352x1216 3->64 (stem_a + stem_b): %.1f us  %.2f TB/s algorithmic (%.0f MB)" % (t, by / t / 1e6, by / 1e6))
     if "points" in a.what:
         # BASELINE configs[4] sizes: the point-side ops of the geometric model at 65 536 points (PointNN FPS / ball query /
         # kNN stress), per batch of B clouds.  Bytes = what the op must read / write once.
