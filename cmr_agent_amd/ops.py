@@ -714,3 +714,142 @@ def pack_conv3x3(w, cout, cin, transpose=False, want_u=True):
     if bf is not None:
         u.bf16 = (bf, nt)
     return w9, u
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# geometric-model update (Train_Geo.py:166-174): backward pieces -- see include/cmr_hip.h
+# ----------------------------------------------------------------------------------------------------------------------
+def axpy(y, x, alpha=1.0):
+    """y += alpha * x on row maps."""
+    _rows(y), _rows(x)
+    _lib.call("cmr_axpy_f32", _p(y), _ld(y), _p(x), _ld(x), float(alpha), y.shape[0], y.shape[1], _stream())
+    return y
+
+
+def act(x, kind, param=0.0, out=None):
+    _rows(x)
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=f32, device=x.device)
+    _lib.call("cmr_act_f32", _p(x), _ld(x), _p(out), _ld(out), x.shape[0], x.shape[1], int(kind), float(param), _stream())
+    return out
+
+
+def act_bwd_x(dy, x, kind, param=0.0, out=None, accumulate=False):
+    _rows(dy), _rows(x)
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=f32, device=x.device)
+        accumulate = False
+    _lib.call("cmr_act_bwd_x_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(out), _ld(out), x.shape[0], x.shape[1], int(kind), float(param),
+              int(accumulate), _stream())
+    return out
+
+
+def layernorm64_bwd(dy, x, gamma, eps, dgamma, dbeta, acc_params, out=None, accumulate=False):
+    _rows(dy), _rows(x)
+    rows = x.shape[0]
+    if out is None:
+        out = torch.empty((rows, 64), dtype=f32, device=x.device)
+        accumulate = False
+    nb = _lib.load().cmr_layernorm64_bwd_workspace_bytes(rows)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_layernorm64_bwd_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(gamma), float(eps), _p(out), _ld(out), int(accumulate),
+              _p(dgamma), _p(dbeta), int(acc_params), rows, _p(ws), nb, _stream())
+    return out
+
+
+def l2norm64_bwd(dy, x, out=None, accumulate=False):
+    _rows(dy), _rows(x)
+    if out is None:
+        out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
+        accumulate = False
+    _lib.call("cmr_l2norm64_bwd_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(out), _ld(out), int(accumulate), x.shape[0], _stream())
+    return out
+
+
+def zero_insert2(g, H, W):
+    B, Ho, Wo, C = g.shape
+    out = torch.empty((B, H, W, C), dtype=f32, device=g.device)
+    _lib.call("cmr_zero_insert2_f32", _p(g), _p(out), B, Ho, Wo, H, W, C, _stream())
+    return out
+
+
+def patchify_bwd(dpatches, B, H, W, C, P, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=f32, device=dpatches.device)
+        accumulate = False
+    _lib.call("cmr_patchify_bwd_f32", _p(dpatches), _p(out), B, H, W, C, P, int(accumulate), _stream())
+    return out
+
+
+def upsample_bwd(dcat, coff, B, H, W, C2, scale, out=None, accumulate=False):
+    """dcat: NHWC [B,H,W,Ctot] contiguous; -> d proxy rows [B * (H/s) * (W/s), C2]."""
+    ldc = dcat.shape[3]
+    if out is None:
+        out = torch.empty((B * (H // scale) * (W // scale), C2), dtype=f32, device=dcat.device)
+        accumulate = False
+    _lib.call("cmr_upsample_bwd_f32", _p(dcat), ldc, coff, _p(out), B, H, W, C2, scale, int(accumulate), _stream())
+    return out
+
+
+def im2col3(x4):
+    B, H, W, c = x4.shape
+    if c != 4 or not x4.is_contiguous():
+        raise ValueError("im2col3 expects a contiguous NHWC tensor with 4 channels (xyz0-style padding)")
+    cols = torch.empty((B * H * W, 36), dtype=f32, device=x4.device)
+    _lib.call("cmr_im2col3_f32", _p(x4), _p(cols), B, H, W, _stream())
+    return cols
+
+
+def col2im3(dcols, B, H, W, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty((B, H, W, 4), dtype=f32, device=dcols.device)
+        accumulate = False
+    _lib.call("cmr_col2im3_f32", _p(dcols), _p(out), B, H, W, int(accumulate), _stream())
+    return out
+
+
+def mha_bwd(q, k, v, o, dout, B, Tq, Tk, dq=None, dk=None, dv=None, acc=(False, False, False)):
+    mk = lambda t, r: (torch.empty((r, 64), dtype=f32, device=q.device), False) if t is None else (t, True)
+    (dq, aq), (dk, ak), (dv, av) = mk(dq, B * Tq), mk(dk, B * Tk), mk(dv, B * Tk)
+    ws = torch.empty((B * Tq * 16,), dtype=f32, device=q.device)
+    _lib.call("cmr_mha_bwd_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(_rows(o)), _ld(o), _p(_rows(dout)),
+              _ld(dout), _p(dq), _ld(dq), int(aq and acc[0]), _p(dk), _ld(dk), int(ak and acc[1]), _p(dv), _ld(dv), int(av and acc[2]),
+              _p(ws), ws.numel() * 4, B, Tq, Tk, _stream())
+    return dq, dk, dv
+
+
+def la_bwd(qf, kf, v, kvsum, dmsg, B, L, S, eps, dqf=None, dkf=None, dv=None, acc=(False, False, False)):
+    mk = lambda t, r: (torch.empty((r, 64), dtype=f32, device=qf.device), False) if t is None else (t, True)
+    (dqf, aq), (dkf, ak), (dv, av) = mk(dqf, B * L), mk(dkf, B * S), mk(dv, B * S)
+    nb = _lib.load().cmr_la_bwd_workspace_bytes(B, L)
+    ws = _ws(nb, qf.device)
+    _lib.call("cmr_la_bwd_f32", _p(_rows(qf)), _ld(qf), _p(_rows(kf)), _ld(kf), _p(_rows(v)), _ld(v), _p(kvsum), _p(_rows(dmsg)), _ld(dmsg),
+              _p(dqf), _ld(dqf), int(aq and acc[0]), _p(dkf), _ld(dkf), int(ak and acc[1]), _p(dv), _ld(dv), int(av and acc[2]), _p(ws), nb, B,
+              L, S, float(eps), _stream())
+    return dqf, dkf, dv
+
+
+def segment_softmax_bwd(attn, vp, dout, nseg, scale, order=None, offsets=None, fixed_len=0):
+    dattn, dvp = torch.empty_like(attn), torch.empty_like(vp)
+    _lib.call("cmr_segment_softmax_bwd_f32", _p(attn), _p(vp), _p(_i32(order)), _p(_i32(offsets)), fixed_len, float(scale), _p(dout), _p(dattn),
+              _p(dvp), nseg, _stream())
+    return dattn, dvp
+
+
+def focal_bwd(logits_rows, label_i64, alpha, grad_scale=1.0):
+    R = logits_rows.shape[0]
+    out = torch.zeros((R, 4), dtype=f32, device=logits_rows.device)
+    _lib.call("cmr_focal_bwd_f32", _p(logits_rows), logits_rows.stride(0), _p(label_i64), float(alpha), R, float(grad_scale), _p(out), 4,
+              _stream())
+    return out
+
+
+def circle_loss_bwd(pc_feat_rows, img_feat_nhwc, pc_idx, xy_int, xy_float, B, N, d_pc, d_img, dist_thres, pos_margin, neg_margin, log_scale,
+                    grad_scale=1.0):
+    _, h, w, _ = img_feat_nhwc.shape
+    n = pc_idx.shape[1]
+    nb = _lib.load().cmr_circle_bwd_workspace_bytes(B, n)
+    ws = _ws(nb, pc_feat_rows.device)
+    _lib.call("cmr_circle_loss_bwd_f32", _p(_rows(pc_feat_rows)), _p(img_feat_nhwc), _p(pc_idx), _p(xy_int), _p(xy_float), B, N, h, w, n,
+              float(dist_thres), float(pos_margin), float(neg_margin), float(log_scale), float(grad_scale), _p(d_pc), _p(d_img), _p(ws), nb,
+              _stream())

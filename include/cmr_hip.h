@@ -393,6 +393,54 @@ int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, cons
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,
                               hipStream_t stream);
 
+/* ---- geometric-model update: backward pieces (reference Train_Geo.py:166-174) ---------------------- */
+/* The training forward of MultiHeadModel is the op-level composition of the inference entry points above with BatchNorm
+ * in batch-statistics mode (cmr_agent_amd/train/geo_update.py); these are the backward kernels of its ops.  `accumulate`
+ * flags add into the destination (a value that feeds several consumers, a parameter used twice). */
+int cmr_axpy_f32(float* y, int64_t ldy, const float* x, int64_t ldx, float alpha, int64_t rows, int C, hipStream_t stream);
+/* y = act(x) (ReLU / LeakyReLU / erf-GELU / elu+1) and dx (+)= dy act'(x) with x the PRE-activation. */
+int cmr_act_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, int act, float act_param, hipStream_t stream);
+int cmr_act_bwd_x_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx, int64_t rows, int C, int act,
+                      float act_param, int accumulate, hipStream_t stream);
+/* nn.LayerNorm(64) backward (ImageViT.py:140-141, IMGPCEncoder.py:86-87, LinearAttention.py:33-34). */
+int64_t cmr_layernorm64_bwd_workspace_bytes(int64_t rows);
+int cmr_layernorm64_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, const float* gamma, float eps, float* dx,
+                            int64_t lddx, int accumulate_dx, float* dgamma, float* dbeta, int accumulate_params, int64_t rows, void* ws,
+                            int64_t ws_bytes, hipStream_t stream);
+/* F.normalize(dim=1) backward over 64 channels (MultiHeadModel.py:233,241). */
+int cmr_l2norm64_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx, int accumulate, int64_t rows,
+                         hipStream_t stream);
+/* out[b,2y,2x,:] = g[b,y,x,:], zero elsewhere: a stride-2 convolution's data / weight gradients are the stride-1 ones of its
+ * zero-inserted output gradient (ImageResNet.py:13,24-36). */
+int cmr_zero_insert2_f32(const float* g, float* out, int B, int Ho, int Wo, int H, int W, int C, hipStream_t stream);
+/* adjoints of cmr_patchify_nhwc_f32, of the nearest up-sampling half of cmr_upsample_concat_f32, and the 3-channel im2col pair
+ * that turns the stem's convolutions (ImageResNet.py:5-40 with 3 input channels) into row GEMMs in the training path. */
+int cmr_patchify_bwd_f32(const float* dpatches, float* dx, int B, int H, int W, int C, int P, int accumulate, hipStream_t stream);
+int cmr_upsample_bwd_f32(const float* dcat, int64_t ldc, int coff, float* dproxy, int B, int H, int W, int C2, int scale, int accumulate,
+                         hipStream_t stream);
+int cmr_im2col3_f32(const float* x4, float* cols, int B, int H, int W, hipStream_t stream);
+int cmr_col2im3_f32(const float* dcols, float* dx4, int B, int H, int W, int accumulate, hipStream_t stream);
+/* softmax attention backward (forward cmr_mha_f32; ImageViT.py:81-108, IMGPCEncoder.py:36-58): ws = 16 floats per query row. */
+int cmr_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                    const float* dout, int64_t lddo, float* dq, int64_t lddq, int acc_dq, float* dk, int64_t lddk, int acc_dk, float* dv,
+                    int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq, int Tk, hipStream_t stream);
+/* linear attention core backward (forward cmr_la_reduce_f32 + cmr_la_apply_f32; LinearAttention.py:53-60). */
+int64_t cmr_la_bwd_workspace_bytes(int B, int L);
+int cmr_la_bwd_f32(const float* qf, int64_t ldq, const float* kf, int64_t ldk, const float* v, int64_t ldv, const float* kvsum,
+                   const float* dmsg, int64_t lddm, float* dqf, int64_t lddq, int acc_dq, float* dkf, int64_t lddk, int acc_dk, float* dv,
+                   int64_t lddv, int acc_dv, void* ws, int64_t ws_bytes, int B, int L, int S, float eps, hipStream_t stream);
+/* group / neighbourhood softmax backward (forward cmr_segment_softmax_f32; PointNN.py:171-182, :227-229). */
+int cmr_segment_softmax_bwd_f32(const float* attn, const float* vp, const int32_t* order, const int32_t* offsets, int fixed_len, float scale,
+                                const float* dout, float* dattn, float* dvp, int64_t nseg, hipStream_t stream);
+/* focal / circle loss backward (forward cmr_focal_metrics_f32 / cmr_circle_loss_f32): gradients w.r.t. the 2-class logits rows; the
+ * circle loss ADDS its gradient into the dense maps d_pc_feat [B*N,64] / d_img_feat [B,h,w,64] at the sampled positions. */
+int cmr_focal_bwd_f32(const float* logits, int64_t ld, const int64_t* label, float alpha, int64_t rows, float grad_scale, float* dlogits,
+                      int64_t ldd, hipStream_t stream);
+int64_t cmr_circle_bwd_workspace_bytes(int B, int n);
+int cmr_circle_loss_bwd_f32(const float* pc_feat, const float* img_feat, const int64_t* pc_idx, const int64_t* xy_int, const float* xy_float,
+                            int B, int N, int h, int w, int n, float dist_thres, float pos_margin, float neg_margin, float log_scale,
+                            float grad_scale, float* d_pc_feat, float* d_img_feat, void* ws, int64_t ws_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,217 @@
+"""GPU tier, geometric-model update (Train_Geo.py:166-174): every backward entry point of csrc/train_geo.hip
+against torch-CPU autograd of the same op (tolerance 3e-5 of the output scale unless stated), then -- further down -- the
+tape-driven modules and the whole MultiHeadModel step against oracle autograd."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cmr_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    with torch.enable_grad():
+        yield
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cmr_agent_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * (hi - lo) + lo
+
+
+def close(got, ref, rtol=3e-5, name=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-6)
+    err = float((got - ref).abs().max())
+    assert err <= rtol * scale, "%s: max|d| %.3e vs scale %.3e" % (name, err, scale)
+
+
+ACTS = {1: lambda v, p: F.relu(v), 2: lambda v, p: F.leaky_relu(v, p), 3: lambda v, p: F.gelu(v), 4: lambda v, p: F.elu(v) + 1}
+
+
+@pytest.mark.parametrize("kind", [1, 2, 3, 4])
+def test_activation_forward_backward(ops, kind):
+    x = (rnd(777, 64, seed=kind) * 3).requires_grad_(True)
+    y = ACTS[kind](x, 0.2)
+    dy = rnd(777, 64, seed=10 + kind)
+    y.backward(dy)
+    xd = x.detach().to(DEV)
+    close(ops.act(xd, kind, 0.2), y, name="act fwd")
+    close(ops.act_bwd_x(dy.to(DEV), xd, kind, 0.2), x.grad, name="act bwd")
+    acc = torch.ones(777, 64, device=DEV)
+    close(ops.act_bwd_x(dy.to(DEV), xd, kind, 0.2, out=acc, accumulate=True), x.grad + 1, name="act bwd accumulate")
+    a = rnd(100, 64, seed=20).to(DEV)
+    close(ops.axpy(a.clone(), xd[:100], 0.5), a.cpu() + 0.5 * x.detach()[:100], name="axpy")
+
+
+@pytest.mark.parametrize("rows,eps", [(1000, 1e-6), (37, 1e-5), (20000, 1e-5)])
+def test_layernorm_backward(ops, rows, eps):
+    x = (rnd(rows, 64, seed=1) * 2 + 0.5).requires_grad_(True)
+    g, b = (rnd(64, seed=2) + 1.5).requires_grad_(True), rnd(64, seed=3).requires_grad_(True)
+    dy = rnd(rows, 64, seed=4)
+    F.layer_norm(x, (64,), g, b, eps).backward(dy)
+    dg, db = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    dx = ops.layernorm64_bwd(dy.to(DEV), x.detach().to(DEV), g.detach().to(DEV), eps, dg, db, False)
+    close(dx, x.grad, 5e-5, "ln dx"), close(dg, g.grad, 5e-5, "ln dgamma"), close(db, b.grad, 5e-5, "ln dbeta")
+    ops.layernorm64_bwd(dy.to(DEV), x.detach().to(DEV), g.detach().to(DEV), eps, dg, db, True, out=dx, accumulate=True)
+    close(dx, 2 * x.grad, 5e-5, "ln dx accumulate"), close(dg, 2 * g.grad, 5e-5, "ln dgamma accumulate")
+
+
+def test_l2norm_backward(ops):
+    x = rnd(999, 64, seed=5).requires_grad_(True)
+    dy = rnd(999, 64, seed=6)
+    F.normalize(x, dim=1).backward(dy)
+    close(ops.l2norm64_bwd(dy.to(DEV), x.detach().to(DEV)), x.grad, name="l2norm bwd")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 12, 20), (1, 9, 13)])
+def test_stride2_conv_gradients_through_zero_insertion(ops, B, H, W):
+    """stride-2 3x3 conv: dgrad = stride-1 transposed-weight conv of the zero-inserted dy; wgrad = stride-1 wgrad of it."""
+    x = rnd(B, 64, H, W, seed=7).requires_grad_(True)
+    w = (rnd(64, 64, 3, 3, seed=8) / 10).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = rnd(*y.shape, seed=9)
+    y.backward(dy)
+    dyz = ops.zero_insert2(dy.permute(0, 2, 3, 1).contiguous().to(DEV), H, W)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = w.detach().contiguous().to(DEV)
+    w9t, ut = ops.pack_conv3x3(wd.view(-1), 64, 64, transpose=True)
+    close(ops.conv3x3(dyz, w9t, None, 64, 1, 1.0, u=ut).permute(0, 3, 1, 2), x.grad, 5e-5, "stride-2 dgrad")
+    dw = torch.empty(64 * 64 * 9, device=DEV)
+    ops.conv3x3_wgrad(xd, dyz, dw)
+    close(dw.view(64, 64, 3, 3), w.grad, 5e-5, "stride-2 wgrad")
+
+
+def test_layout_adjoints(ops):
+    B, H, W, C, P = 2, 16, 24, 64, 8
+    x = rnd(B, H, W, C, seed=11).to(DEV)
+    p = ops.patchify(x, P)
+    close(ops.patchify_bwd(p, B, H, W, C, P), x, 0, "patchify adjoint = inverse permutation")
+    close(ops.patchify_bwd(p, B, H, W, C, P, out=x.clone(), accumulate=True), 2 * x, 1e-7, "patchify adjoint accumulate")
+    proxy = rnd(B * (H // 8) * (W // 8), 64, seed=12).requires_grad_(True)
+    f = rnd(B, H, W, 64, seed=13)
+    up = proxy.view(B, H // 8, W // 8, 64).repeat_interleave(8, 1).repeat_interleave(8, 2)
+    cat = torch.cat([f, up], 3)
+    g = rnd(B, H, W, 128, seed=14)
+    cat.backward(g)
+    close(ops.upsample_bwd(g.to(DEV), 64, B, H, W, 64, 8), proxy.grad, name="upsample bwd")
+    # 3-channel stem convolutions as row GEMMs
+    img = rnd(B, 3, H, W, seed=15).requires_grad_(True)
+    w = (rnd(64, 3, 3, 3, seed=16) / 3).requires_grad_(True)
+    y = F.conv2d(img, w, None, 1, 1)
+    gy = rnd(*y.shape, seed=17)
+    y.backward(gy)
+    x4 = torch.zeros(B, H, W, 4)
+    x4[..., :3] = img.detach().permute(0, 2, 3, 1)
+    cols = ops.im2col3(x4.to(DEV))
+    wm = torch.zeros(64, 36)
+    wm.view(64, 9, 4)[:, :, :3] = w.detach().permute(0, 2, 3, 1).reshape(64, 9, 3)          # [co][tap][c]
+    close(ops.linear(cols, wm.to(DEV)).view(B, H, W, 64).permute(0, 3, 1, 2), y, name="stem conv as row GEMM")
+    dcols = ops.linear(gy.permute(0, 2, 3, 1).reshape(-1, 64).contiguous().to(DEV), wm.t().contiguous().to(DEV))
+    close(ops.col2im3(dcols, B, H, W)[..., :3].permute(0, 3, 1, 2), img.grad, name="col2im3")
+
+
+@pytest.mark.parametrize("B,Tq,Tk", [(2, 50, 30), (3, 418, 256), (1, 257, 300)])
+def test_softmax_attention_backward(ops, B, Tq, Tk):
+    q, k, v = (rnd(B, Tq, 64, seed=21).requires_grad_(True), rnd(B, Tk, 64, seed=22).requires_grad_(True),
+               rnd(B, Tk, 64, seed=23).requires_grad_(True))
+    hs = lambda t, T: t.view(B, T, 8, 8).permute(0, 2, 1, 3)
+    p = torch.softmax(hs(q, Tq) @ hs(k, Tk).transpose(-1, -2) / math.sqrt(8), -1)
+    o = (p @ hs(v, Tk)).permute(0, 2, 1, 3).reshape(B, Tq, 64)
+    do = rnd(B, Tq, 64, seed=24)
+    o.backward(do)
+    dev = lambda t, T: t.detach().reshape(B * T, 64).contiguous().to(DEV)
+    od = ops.mha(dev(q, Tq), dev(k, Tk), dev(v, Tk), B, Tq, Tk)
+    close(od, o.reshape(B * Tq, 64), name="mha fwd")
+    dq, dk, dv = ops.mha_bwd(dev(q, Tq), dev(k, Tk), dev(v, Tk), od, dev(do, Tq), B, Tq, Tk)
+    close(dq, q.grad.reshape(-1, 64), 5e-5, "mha dq"), close(dk, k.grad.reshape(-1, 64), 5e-5, "mha dk")
+    close(dv, v.grad.reshape(-1, 64), 5e-5, "mha dv")
+
+
+@pytest.mark.parametrize("B,L,S", [(2, 70, 45), (2, 1280, 5120), (1, 9000, 333)])
+def test_linear_attention_core_backward(ops, B, L, S):
+    qf, kf, v = (rnd(B, L, 64, seed=31, lo=0.1, hi=2).requires_grad_(True), rnd(B, S, 64, seed=32, lo=0.1, hi=2).requires_grad_(True),
+                 rnd(B, S, 64, seed=33).requires_grad_(True))
+    h8 = lambda t: t.view(B, -1, 8, 8)
+    kv = torch.einsum("nshd,nshv->nhdv", h8(kf), h8(v) / S)
+    z = 1 / (torch.einsum("nlhd,nhd->nlh", h8(qf), h8(kf).sum(1)) + 1e-6)
+    msg = (torch.einsum("nlhd,nhdv,nlh->nlhv", h8(qf), kv, z) * S).reshape(B, L, 64)
+    dm = rnd(B, L, 64, seed=34)
+    msg.backward(dm)
+    dev = lambda t: t.detach().reshape(-1, 64).contiguous().to(DEV)
+    kvsum = ops.la_reduce(dev(kf), dev(v), B, S)
+    close(ops.la_apply(dev(qf), kvsum, B, L, S, 1e-6), msg.reshape(-1, 64), 5e-5, "la fwd")
+    dq, dk, dv = ops.la_bwd(dev(qf), dev(kf), dev(v), kvsum, dev(dm), B, L, S, 1e-6)
+    close(dq, qf.grad.reshape(-1, 64), 1e-4, "la dq"), close(dk, kf.grad.reshape(-1, 64), 1e-4, "la dk")
+    close(dv, v.grad.reshape(-1, 64), 1e-4, "la dv")
+
+
+def test_segment_softmax_backward(ops):
+    R, nseg = 3000, 200
+    a, vp = rnd(R, 64, seed=41, lo=-3, hi=3).requires_grad_(True), rnd(R, 64, seed=42).requires_grad_(True)
+    key = torch.randint(0, nseg - 5, (R,), generator=torch.Generator().manual_seed(43))
+    key[:nseg - 5] = torch.arange(nseg - 5)                                     # every used segment non-empty
+    onehot = F.one_hot(key, nseg).bool()                                         # [R, nseg]
+    logits = (a * 0.125).unsqueeze(1).masked_fill(~onehot.unsqueeze(2), float("-inf"))     # [R, nseg, 64]
+    p = torch.softmax(logits, 0)
+    p = torch.nan_to_num(p)
+    out = (p * vp.unsqueeze(1)).sum(0)
+    dout = rnd(nseg, 64, seed=44)
+    out.backward(dout)
+    g = key.int().to(DEV)
+    offsets, order = ops.csr_build(g, 1, R, nseg)
+    ad, vd = a.detach().to(DEV), vp.detach().to(DEV)
+    close(ops.segment_softmax(ad, vd, nseg, 0.125, order=order, offsets=offsets), out, name="segment softmax fwd")
+    da, dv = ops.segment_softmax_bwd(ad, vd, dout.to(DEV), nseg, 0.125, order=order, offsets=offsets)
+    close(da, a.grad, 5e-5, "segment softmax d attn"), close(dv, vp.grad, 5e-5, "segment softmax d vp")
+    # fixed-length neighbourhoods (kNN transformer): 16 consecutive rows per segment
+    a2, v2 = rnd(160, 64, seed=45, lo=-3, hi=3).requires_grad_(True), rnd(160, 64, seed=46).requires_grad_(True)
+    o2 = (torch.softmax(a2.view(10, 16, 64) * 0.125, 1) * v2.view(10, 16, 64)).sum(1)
+    d2 = rnd(10, 64, seed=47)
+    o2.backward(d2)
+    da2, dv2 = ops.segment_softmax_bwd(a2.detach().to(DEV), v2.detach().to(DEV), d2.to(DEV), 10, 0.125, fixed_len=16)
+    close(da2, a2.grad, 5e-5, "knn softmax d attn"), close(dv2, v2.grad, 5e-5, "knn softmax d vp")
+
+
+def test_focal_and_circle_loss_backward(ops):
+    B, n_pts = 2, 3000
+    logits = (rnd(B, 2, n_pts, seed=51, lo=-3, hi=3)).requires_grad_(True)
+    label = (rnd(B, n_pts, seed=52) > 0.3).long()
+    O.focal_loss(logits, label, 0.75).backward()
+    rows = torch.zeros(B * n_pts, 4)
+    rows[:, :2] = logits.detach().permute(0, 2, 1).reshape(-1, 2)
+    got = ops.focal_bwd(rows.to(DEV), label.view(-1).to(DEV), 0.75)
+    close(got[:, :2], logits.grad.permute(0, 2, 1).reshape(-1, 2), 5e-5, "focal bwd")
+    for n in (64, 37):
+        N, h, w = 500, 12, 20
+        pc = F.normalize(rnd(B, 64, N, seed=53), dim=1).requires_grad_(True)
+        img = F.normalize(rnd(B, 64, h, w, seed=54), dim=1).requires_grad_(True)
+        g = torch.Generator().manual_seed(55 + n)
+        pc_idx = torch.randint(0, N, (B, n), generator=g)
+        pc_idx[:, 1] = pc_idx[:, 0]                                                # a repeated sample index
+        xy_f = torch.stack([torch.rand(B, n, generator=g) * (w - 1), torch.rand(B, n, generator=g) * (h - 1)], 1)
+        xy_i = xy_f.round().long()
+        pix = torch.stack([img[i][:, xy_i[i][1], xy_i[i][0]] for i in range(B)], 0)
+        pts = torch.stack([pc[i][:, pc_idx[i]] for i in range(B)], 0)
+        dmap = torch.sqrt(torch.sum(torch.square(xy_f.unsqueeze(-1) - xy_i.unsqueeze(-2)), dim=1))
+        O.circle_loss(pix, pts, dmap).backward()
+        pc_rows = pc.detach().permute(0, 2, 1).reshape(B * N, 64).contiguous().to(DEV)
+        img_nhwc = img.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+        d_pc, d_img = torch.zeros(B * N, 64, device=DEV), torch.zeros(B, h, w, 64, device=DEV)
+        ops.circle_loss_bwd(pc_rows, img_nhwc, pc_idx.to(DEV), xy_i.to(DEV), xy_f.to(DEV), B, N, d_pc, d_img, 1.0, 0.1, 1.4, 10.0)
+        close(d_pc, pc.grad.permute(0, 2, 1).reshape(B * N, 64), 2e-4, "circle d pc (n=%d)" % n)
+        close(d_img, img.grad.permute(0, 2, 3, 1), 2e-4, "circle d img (n=%d)" % n)
+        pc.grad = None
+        img.grad = None
