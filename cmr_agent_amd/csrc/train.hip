@@ -476,13 +476,15 @@ __global__ __launch_bounds__(256) void agent_loss_kernel(const LossArgs a) {
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n4, float lr, float b1, float b2, float eps, float wd, float bc1, float sqrt_bc2,
-                                                   float gscale) {
+                                                   float gscale, float clip) {
   const float step = lr / bc1;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     f32x4 pv = ld4(p + 4 * i), gv = ld4(g + 4 * i) * gscale, mv = ld4(m + 4 * i), vv = ld4(v + 4 * i);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float gg = gv[e] + wd * pv[e];
+      float gr = gv[e];
+      if (clip > 0.f) gr = fminf(fmaxf(gr, -clip), clip);      // nn.utils.clip_grad_value_ (Train_Geo.py:172), before weight decay
+      const float gg = gr + wd * pv[e];
       mv[e] = mv[e] + (gg - mv[e]) * (1.f - b1);               // exp_avg.lerp_(grad, 1 - beta1)
       vv[e] = vv[e] * b2 + (1.f - b2) * gg * gg;               // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
       const float denom = sqrtf(vv[e]) / sqrt_bc2 + eps;        // (exp_avg_sq.sqrt() / sqrt(bias_correction2)).add_(eps)
@@ -501,7 +503,7 @@ inline unsigned ew_grid(int64_t items) {
   return (unsigned)g;
 }
 
-inline bool chan_ok(int C) { return C == 8 || C == 16 || C == 32 || C == 64 || C == 128 || C == 256; }
+inline bool chan_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 64 || C == 128 || C == 256 || C == 512 || C == 1024; }
 
 }  // namespace
 
@@ -638,11 +640,12 @@ extern "C" int cmr_agent_loss_f32(const float* r_logits, int64_t ldr, const floa
 }
 
 extern "C" int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, hipStream_t stream) {
+                            float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, float grad_clip,
+                            hipStream_t stream) {
   CMR_REQUIRE(p && g && m && v && n >= 0 && n % 4 == 0 && cmr_aligned16(p) && cmr_aligned16(g) && cmr_aligned16(m) && cmr_aligned16(v));
   CMR_REQUIRE(bias_correction1 > 0.f && bias_correction2 > 0.f);
   if (n == 0) return CMR_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, lr, beta1, beta2, eps, weight_decay,
-                     bias_correction1, sqrtf(bias_correction2), grad_scale);
+                     bias_correction1, sqrtf(bias_correction2), grad_scale, grad_clip);
   return cmr_launch_status();
 }

@@ -674,9 +674,9 @@ def agent_loss(r_logits, t_logits, value, expert_r, expert_t, act_r, act_t, old_
     return out, d_r, d_t, d_v
 
 
-def adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_clip=0.0):
     _lib.call("cmr_adam_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
-              float(weight_decay), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), _stream())
+              float(weight_decay), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), float(grad_clip), _stream())
 
 
 def conv3x3_wgrad(x, dy, dw):
@@ -853,3 +853,16 @@ def circle_loss_bwd(pc_feat_rows, img_feat_nhwc, pc_idx, xy_int, xy_float, B, N,
     _lib.call("cmr_circle_loss_bwd_f32", _p(_rows(pc_feat_rows)), _p(img_feat_nhwc), _p(pc_idx), _p(xy_int), _p(xy_float), B, N, h, w, n,
               float(dist_thres), float(pos_margin), float(neg_margin), float(log_scale), float(grad_scale), _p(d_pc), _p(d_img), _p(ws), nb,
               _stream())
+
+
+def linear_wgrad_any(dy, x, dw, accumulate=False):
+    """dw [n, k] (+)= dy^T x for any n, k: 128 x 128 blocks of the output through the row-streaming MFMA kernel
+    (cmr_linear_wgrad_f32 serves n, k <= 128; the MLP of the transformer blocks has n or k = 1024, the patch embedding k = 4096)."""
+    n, k = dw.shape
+    if dy.shape[1] < n or x.shape[1] < k:
+        raise ValueError("linear_wgrad_any: operand widths %d / %d vs gradient %s" % (dy.shape[1], x.shape[1], tuple(dw.shape)))
+    ld = dw.stride(0)
+    for n0 in range(0, n, 128):
+        for k0 in range(0, k, 128):
+            linear_wgrad(dy[:, n0:min(n0 + 128, n)], x[:, k0:min(k0 + 128, k)], dw[n0:, k0:], ld, n=min(128, n - n0), k=min(128, k - k0),
+                         accumulate=accumulate)

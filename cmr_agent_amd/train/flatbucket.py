@@ -21,8 +21,11 @@ class Slot:
 
     def __init__(self, name, shape, offset):
         self.name, self.shape, self.offset = name, tuple(shape), offset
-        if len(shape) == 4 and tuple(shape[2:]) == (3, 3):
-            self.store = (shape[0] * shape[1] * 9,)
+        if len(shape) == 4 and shape[2] * shape[3] > 1:          # spatial conv kernels (3x3, the 8x8 patch conv): flat, own layout
+            n = 1
+            for s in shape:
+                n *= s
+            self.store = (_ceil4(n),)
         elif len(shape) >= 2:
             k = 1
             for s in shape[1:]:
@@ -40,8 +43,11 @@ class Slot:
     def view(self, flat):
         """logical view (the Parameter's own shape) of this slot inside `flat`."""
         st = flat[self.offset:self.offset + self.size].view(self.store)
-        if len(self.shape) == 4 and tuple(self.shape[2:]) == (3, 3):
-            return st.view(self.shape)
+        if len(self.shape) == 4 and self.shape[2] * self.shape[3] > 1:
+            n = 1
+            for s in self.shape:
+                n *= s
+            return st[:n].view(self.shape)
         if len(self.shape) >= 2:
             v = st[:self.shape[0], :self.shape[1]]
             for _ in range(len(self.shape) - 2):
@@ -56,7 +62,7 @@ class Slot:
 
 class FlatBucket:
     def __init__(self, module):
-        params = list(module.named_parameters())
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]     # frozen tables (ImageViT position_embeddings) stay out
         if not params:
             raise ValueError("FlatBucket: module has no parameters")
         dev = params[0][1].device
@@ -68,6 +74,7 @@ class FlatBucket:
             self.slots[name] = s
             off += s.size
         self.numel = off
+        self.by_id = {id(p): self.slots[name] for name, p in params}
         self.params = torch.zeros(off, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
         with torch.no_grad():
@@ -82,9 +89,16 @@ class FlatBucket:
         """Parameters must still live in the bucket (module.to() / .cuda() after construction would detach them)."""
         lo, hi = self.params.data_ptr(), self.params.data_ptr() + 4 * self.numel
         for name, p in self._module.named_parameters():
-            if not (lo <= p.data_ptr() < hi):
+            if p.requires_grad and not (lo <= p.data_ptr() < hi):
                 raise RuntimeError("FlatBucket: parameter %s no longer lives in the flat bucket (module moved / re-created "
                                    "after the bucket was built)" % name)
+
+    def wp(self, param):
+        """stored (padded) weight of a Parameter object."""
+        return self.by_id[id(param)].stored(self.params)
+
+    def gp(self, param):
+        return self.by_id[id(param)].stored(self.grads)
 
     def w(self, name):
         return self.slots[name].stored(self.params)

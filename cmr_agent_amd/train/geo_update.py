@@ -1,0 +1,295 @@
+"""One optimizer step of MultiHeadModel on the HIP path: the `model.train(); model(data); data['loss'].backward();
+clip_grad_value_(1); optimizer.step()` of the reference's Train_Geo.py:166-174.
+
+The training forward below is the reference's forward (ImageResNet / ImageViT / PointNN / PointViT / IMGPCEncoder /
+LinearAttention / IMGPCEnDecoder / MultiHeadModel) written over the tape ops of train/tape.py: every BatchNorm uses batch
+statistics (and moves its running statistics), nothing is folded or fused across layers, and each op leaves its backward on
+the tape.  Losses = focal (points, alpha .75) + focal (pixels, alpha .5) + circle loss (MultiHeadModel.py:49-50, 98-99,
+240-270); their gradients seed the tape; gradients land in ONE flat bucket, which is all-reduced once per step over the
+data-parallel ranks and consumed by the fused Adam launch (gradient value clipping at 1 folded in).
+
+Dropout (p = 0.1 in 40 places of the reference, incl. on the attention probabilities) is NOT applied: parity with the
+reference is defined with dropout off, and a training run here is therefore un-regularised in that one
+respect.  Documented in DESIGN.md."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..models.PointViT import PointGeometry
+from .flatbucket import FlatBucket
+from .tape import Tape, Var
+
+f32 = torch.float32
+RELU, LRELU, GELU, ELU1 = ops.ACT_RELU, ops.ACT_LRELU, ops.ACT_GELU, ops.ACT_ELU1
+LOSS_KEYS = ("loss", "pc_overlap_loss", "img_overlap_loss", "geometric_loss", "pc_overlap_precision", "pc_overlap_recall",
+             "pc_overlap_accuracy", "img_overlap_precision", "img_overlap_recall", "img_overlap_accuracy")
+
+
+class GeoUpdate:
+    def __init__(self, model, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, grad_clip=1.0):
+        self.model, self.cfg, self.dist = model, config, dist
+        self.bucket = FlatBucket(model)
+        n = self.bucket.numel
+        dev = self.bucket.params.device
+        self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
+        self.lr = config.lr if lr is None else lr
+        self.betas, self.eps = betas, eps
+        self.weight_decay = config.weight_decay if weight_decay is None else weight_decay
+        self.grad_clip = grad_clip
+        self.t = 0
+        self._pos2d = {}
+
+    # ------------------------------------------------------------------------------------------------------ building blocks
+    def _resblock(self, t, x, dims, blk, post=None):
+        """ImageResNet.py:5-40 in train mode -> (Var rows, dims)."""
+        cl, s = blk.conv_layers, blk.SLOPE
+        if blk.inchannel == 3:                                   # stem: 3-channel convolutions as row GEMMs
+            a = t.act(t.bn(t.conv3x3_c3(x, dims, cl[0], need_dx=False), cl[1]), LRELU, s)
+            b = t.bn(t.conv3x3_c3(a, dims, cl[3], need_dx=True), cl[4])
+            sc = t.bn(t.linear(x, blk.shortcut[0].weight, blk.shortcut[0].bias), blk.shortcut[1])
+            return t.act(t.add(b, sc), LRELU, s), dims
+        a, d1 = t.conv3x3(x, dims, cl[0], blk.stride)
+        a = t.act(t.bn(a, cl[1]), LRELU, s)
+        b, d2 = t.conv3x3(a, d1, cl[3], 1)
+        b = t.bn(b, cl[4])
+        if isinstance(blk.shortcut, nn.Identity):
+            sc = x
+        elif blk.shortcut[0].kernel_size == (1, 1):
+            sc = t.bn(t.linear(x, blk.shortcut[0].weight, blk.shortcut[0].bias), blk.shortcut[1])
+        else:
+            sc, _ = t.conv3x3(x, dims, blk.shortcut[0], 2)
+            sc = t.bn(sc, blk.shortcut[1])
+        y = t.act(t.add(b, sc), LRELU, s)
+        if post is not None:
+            y = t.add_const(y, post, post.shape[0])
+        return y, d2
+
+    def _vit_block(self, t, x, y, blk, B, tx, ty):
+        """ImageViT.py:144-158 (y None) / IMGPCEncoder.py:90-102 (cross: both inputs through the SAME attention_norm)."""
+        at = blk.attn
+        xn = t.layernorm(x, blk.attention_norm, blk.LN_EPS)
+        yn = xn if y is None else t.layernorm(y, blk.attention_norm, blk.LN_EPS)
+        q = t.linear(xn, at.query.weight, at.query.bias)
+        k = t.linear(yn, at.key.weight, at.key.bias)
+        v = t.linear(yn, at.value.weight, at.value.bias)
+        ctx = t.mha(q, k, v, B, tx, tx if y is None else ty)
+        x1 = t.add(t.linear(ctx, at.out.weight, at.out.bias), x)
+        h = t.layernorm(x1, blk.ffn_norm, blk.LN_EPS)
+        m = t.linear(t.act(t.linear(h, blk.ffn.fc1.weight, blk.ffn.fc1.bias), GELU), blk.ffn.fc2.weight, blk.ffn.fc2.bias)
+        return t.add(m, x1)
+
+    def _mini_pointnet(self, t, x, mp):
+        for layer in (mp.layer_1, mp.layer_2, mp.layer_3):
+            x = t.act(t.bn(t.linear(x, layer[0].weight, layer[0].bias), layer[1]), LRELU, mp.SLOPE)
+        return x
+
+    def _cbr1d(self, t, x, m):
+        """PointNN.py:260-282."""
+        h = t.act(t.bn(t.linear(x, m.net[0].weight, m.net[0].bias), m.net[1]), LRELU, m.SLOPE)
+        y = t.bn(t.linear(h, m.net[3].weight, m.net[3].bias), m.net[4])
+        sc = x if isinstance(m.shortcut, nn.Identity) else t.bn(t.linear(x, m.shortcut[0].weight, m.shortcut[0].bias), m.shortcut[1])
+        return t.act(t.add(y, sc), LRELU, m.SLOPE)
+
+    def _vector_attention(self, t, m, q_rows, k, v, rel, nseg, order, offsets, fixed_len):
+        d, g = m.fc_delta, m.fc_gamma
+        pos = t.linear(t.act(t.linear(rel, d[0].weight, d[0].bias), RELU), d[2].weight, d[2].bias)
+        a_in = t.add(t.add(q_rows, k, -1.0), pos)
+        a = t.linear(t.act(t.linear(a_in, g[0].weight, g[0].bias), RELU), g[2].weight, g[2].bias)
+        return t.segment_softmax(a, t.add(v, pos), nseg, 0.125, order=order, offsets=offsets, fixed_len=fixed_len)
+
+    def _group_pt(self, t, m, xyz4, feat, node4, node_feat, gidx, offsets, order):
+        """PointNN.py:149-185."""
+        x = t.linear(feat, m.fc1_0.weight, m.fc1_0.bias)
+        xx = t.linear(node_feat, m.fc1_1.weight, m.fc1_1.bias)
+        q = t.gather(t.linear(xx, m.w_qs.weight), gidx, (offsets, order))
+        k, v = t.linear(x, m.w_ks.weight), t.linear(x, m.w_vs.weight)
+        R, S = feat.v.shape[0], node_feat.v.shape[0]
+        rel = Var(ops.rel_pos(xyz4, node4, R, ib=gidx))
+        res = self._vector_attention(t, m, q, k, v, rel, S, order, offsets, 0)
+        return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), node_feat)
+
+    def _knn_pt(self, t, m, node4, feat, knn, knn_csr, rep, rep_csr):
+        """PointNN.py:209-232: neighbourhoods of 16, rows ordered [node][neighbour]."""
+        x = t.linear(feat, m.fc1.weight, m.fc1.bias)
+        q = t.gather(t.linear(x, m.w_qs.weight), rep, rep_csr)
+        k = t.gather(t.linear(x, m.w_ks.weight), knn, knn_csr)
+        v = t.gather(t.linear(x, m.w_vs.weight), knn, knn_csr)
+        S = feat.v.shape[0]
+        rel = Var(ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn))
+        res = self._vector_attention(t, m, q, k, v, rel, S, None, None, 16)
+        return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), feat)
+
+    def _la(self, t, la, x, y, B, L, S):
+        """LinearAttention.py:38-73."""
+        q = t.act(t.linear(x, la.q_proj.weight), ELU1)
+        k = t.act(t.linear(y, la.k_proj.weight), ELU1)
+        v = t.linear(y, la.v_proj.weight)
+        msg = t.la_core(q, k, v, B, L, S, la.eps)
+        msg = t.layernorm(t.linear(msg, la.merge.weight), la.norm1, la.LN_EPS)
+        hid = t.act(t.linear(t.cat(x, msg), la.mlp[0].weight), RELU)
+        return t.add(x, t.layernorm(t.linear(hid, la.mlp[3].weight), la.norm2, la.LN_EPS))
+
+    def _patch_embed(self, t, emb, f2, dims):
+        """ImageViT.py:19-22, 52-56: 8x8 stride-8 convolution as a GEMM over patch rows, + the (frozen) 1-D sinusoid table."""
+        P = self.cfg.patch_size
+        B, h, w = dims
+        T = (h // P) * (w // P)
+        patches = t.patchify(f2, dims, P)
+        conv = emb.patch_embeddings
+        co, ci = conv.weight.shape[0], conv.weight.shape[1]
+        wm = conv.weight.detach().permute(0, 2, 3, 1).reshape(co, P * P * ci).contiguous()     # [(ky, kx, cin)] like patchify
+        pos = emb._pos_rows(T, f2.v.device)
+        y = Var(ops.linear(patches.v, wm, t.W(conv.bias), res=pos, res_mod=T))
+
+        def bwd():
+            if y.g is None:
+                return
+            dw = torch.empty((co, P * P * ci), dtype=f32, device=wm.device)
+            ops.linear_wgrad_any(y.g, patches.v, dw, False)
+            gw, acc = t.G(conv.weight)
+            if acc:
+                raise RuntimeError("patch embedding is used once per step")
+            gw[:dw.numel()].view(co, ci, P, P).copy_(dw.view(co, P, P, ci).permute(0, 3, 1, 2))        # back to [co][cin][ky][kx]
+            t._param_vec_grad(conv.bias, ops.colsum(y.g, 1, y.g.shape[0]).view(-1))
+            t.give(patches, ops.linear(y.g, wm.t().contiguous()), owned=True)
+        t.nodes.append(bwd)
+        return y, T
+
+    # ------------------------------------------------------------------------------------------------------------- forward
+    def _forward(self, t, data):
+        cfg, model = self.cfg, self.model
+        ed = model.encoder_decoder
+        enc = ed.encoder
+        dev = self.bucket.params.device
+        img = data["img"].to(dev).contiguous()
+        pc, node, idx = data["pc"].to(dev), data["node"].to(dev), data["pt2node"].to(dev)
+        B, _, H, W = img.shape
+        # ---- image tower
+        x4 = Var(ops.planar_to_rows(img.view(B, 3, H * W), 4))                               # [B*H*W, 4] rgb0
+        rl = enc.img_transformer.embeddings.mini_resnet.residual_learning
+        x, d = self._resblock(t, x4, (B, H, W), rl[0])
+        f0, d0 = self._resblock(t, x, d, rl[1])
+        x, d = self._resblock(t, f0, d0, rl[2])
+        f1, d1 = self._resblock(t, x, d, rl[3])
+        x, d = self._resblock(t, f1, d1, rl[4])
+        f2, d2 = self._resblock(t, x, d, rl[5])
+        h, w = d2[1], d2[2]
+        img_proxy, T = self._patch_embed(t, enc.img_transformer.embeddings, f2, d2)
+        for blk in enc.img_transformer.sa_encoder_layers:
+            img_proxy = self._vit_block(t, img_proxy, None, blk, B, T, T)
+        # ---- point tower
+        geo = PointGeometry(pc, node, idx)
+        N, M, Q = geo.N, geo.M, cfg.num_proxy
+        pe = enc.pt_transformer.embeddings
+        pc4, node4 = Var(geo.pc4), Var(geo.node4)
+        csr = (geo.offsets, geo.order)
+        x_feat = self._mini_pointnet(t, pc4, pe.raw_point_mlp)
+        node_feat = self._mini_pointnet(t, node4, pe.raw_point_mlp)
+        node_feat = self._group_pt(t, pe.group_transformer_0, geo.pc4, x_feat, geo.node4, node_feat, geo.gidx, *csr)
+        x_feat = self._mini_pointnet(t, t.cat(x_feat, t.gather(node_feat, geo.gidx, csr)), pe.point_mlp_0)
+        node_feat = self._group_pt(t, pe.group_transformer_1, geo.pc4, x_feat, geo.node4, node_feat, geo.gidx, *csr)
+        x_feat = self._mini_pointnet(t, t.cat(x_feat, t.gather(node_feat, geo.gidx, csr)), pe.point_mlp_1)
+        node_feat = self._group_pt(t, pe.group_transformer_node, geo.pc4, x_feat, geo.node4, node_feat, geo.gidx, *csr)
+        knn = geo.knn()
+        knn_csr = ops.csr_build(knn, B, M * 16, M)                                  # neighbours never leave their sample
+        rep = (torch.arange(B * M, device=dev, dtype=torch.int32).view(-1, 1).expand(B * M, 16)).reshape(-1).contiguous()
+        rep_csr = ops.csr_build(rep, B, M * 16, M)
+        for layer in pe.knn_transformers:
+            node_feat = self._knn_pt(t, layer, geo.node4, node_feat, knn, knn_csr, rep, rep_csr)
+        prow = pe._proxy_rows(B, M, Q, dev)
+        prow_csr = ops.csr_build(prow, B, Q, M)
+        proxy4 = ops.gather_rows(geo.node4, prow)
+        proxy_feat = t.gather(node_feat, prow, prow_csr)
+        n2p_global, n2p_local = ops.nearest(geo.node4, proxy4, B, M, Q)
+        n2p_csr = ops.csr_build(n2p_global, B, M, Q)
+        pt_proxy = self._group_pt(t, pe.group_transformer_proxy, geo.node4, node_feat, proxy4, proxy_feat, n2p_global, *n2p_csr)
+        for blk in enc.pt_transformer.sa_encoder_layers:
+            pt_proxy = self._vit_block(t, pt_proxy, None, blk, B, Q, Q)
+        # ---- coarse matcher
+        for i in range(cfg.num_ca_layer_coarse):
+            img_proxy = self._vit_block(t, img_proxy, pt_proxy, enc.p2i_ca_layers[i], B, T, Q)
+            pt_proxy = self._vit_block(t, pt_proxy, img_proxy, enc.i2p_ca_layers[i], B, Q, T)
+            img_proxy = self._vit_block(t, img_proxy, None, enc.img_sa_layers[i], B, T, T)
+            pt_proxy = self._vit_block(t, pt_proxy, None, enc.pt_sa_layers[i], B, Q, Q)
+        # ---- decoder: proxies -> nodes / pixels, fuse convs, linear attention
+        nod = t.cat(node_feat, t.gather(pt_proxy, n2p_global, n2p_csr))
+        for layer in list(ed.node_fuse_convs)[:-1]:
+            nod = self._cbr1d(t, nod, layer)
+        pix = t.upsample_concat(f2, img_proxy, d2, cfg.patch_size)
+        key = (h, w)
+        if key not in self._pos2d:
+            self._pos2d[key] = ed._pos_table(h, w, dev).view(h * w, -1).contiguous()
+        for i, layer in enumerate(list(ed.img_fuse_convs)[:-1]):
+            pix, _ = self._resblock(t, pix, d2, layer, post=self._pos2d[key] if i == 0 else None)
+        L = h * w
+        for i in range(cfg.linear_attention_num):
+            nod = self._la(t, ed.pixel_to_node_LA[i], nod, pix, B, M, L)
+            pix = self._la(t, ed.node_to_pixel_LA[i], pix, nod, B, L, M)
+            nod = self._la(t, ed.node_self_LA[i], nod, nod, B, M, M)
+            pix = self._la(t, ed.pixel_self_LA[i], pix, pix, B, L, L)
+        # ---- heads
+        outs = {}
+        for name, head in (("overlap", model.overlap_head), ("geo", model.geo_head)):
+            xh = t.cat(x_feat, t.gather(nod, geo.gidx, csr))
+            for layer in head.point_fuse_convs:
+                xh = self._cbr1d(t, xh, layer)
+            pcs = getattr(head, head._pc_name)
+            pts = t.linear(t.act(t.linear(xh, pcs[0].weight, pcs[0].bias), LRELU, 0.2), pcs[2].weight, pcs[2].bias)
+            yh = pix
+            for layer in head.img_res_convs:
+                yh, _ = self._resblock(t, yh, d2, layer)
+            ims = getattr(head, head._img_name)
+            pxs = t.linear(t.act(t.linear(yh, ims[0].weight, ims[0].bias), LRELU, 0.2), ims[2].weight, ims[2].bias)
+            outs[name] = (pts, pxs)
+        pc_geo, img_geo = t.l2norm(outs["geo"][0]), t.l2norm(outs["geo"][1])
+        return dict(B=B, N=N, h=h, w=w, pc_logits=outs["overlap"][0], img_logits=outs["overlap"][1], pc_geo=pc_geo, img_geo=img_geo)
+
+    # ----------------------------------------------------------------------------------------------------------------- API
+    def forward_backward(self, data, grad_scale=1.0):
+        """data: the reference's batch dict incl. the label keys (KittiDataset.py:400-423).  Fills the gradient bucket; returns
+        a dict of device scalars: the four losses and six overlap metrics of MultiHeadModel.forward."""
+        self.bucket.check_attached()
+        self.bucket.grads.zero_()                           # every used slice is overwritten; frozen / unused ones must read 0
+        t = Tape(self.bucket)
+        o = self._forward(t, data)
+        B, N, h, w = o["B"], o["N"], o["h"], o["w"]
+        dev = self.bucket.params.device
+        lab = lambda k: data[k].to(dev).contiguous()
+        gh = self.model.geo_head
+        pc_l, im_l = o["pc_logits"], o["img_logits"]
+        pcm, imm = lab("pc_mask").view(-1), lab("img_mask").view(-1)
+        pc = ops.focal_metrics(pc_l.v, pcm, 0.75, B)
+        im = ops.focal_metrics(im_l.v, imm, 0.5, B)
+        pci, xyi, xyf = lab("pc_idx_for_circle_loss"), lab("pc_xy_int_for_circle_loss"), lab("pc_xy_float_for_circle_loss").float()
+        img_geo_map = o["img_geo"].v.view(B, h, w, 64)
+        geo = ops.circle_loss(o["pc_geo"].v, img_geo_map, pci, xyi, xyf, B, N, gh.dist_thres, gh.pos_margin, gh.neg_margin, 10, gh.lambda_geo)
+        losses = {"pc_overlap_loss": pc[0], "img_overlap_loss": im[0], "geometric_loss": geo[0], "loss": (pc[0] + im[0]) + geo[0]}
+        for tag, v in (("pc", pc), ("img", im)):
+            losses[tag + "_overlap_precision"], losses[tag + "_overlap_recall"], losses[tag + "_overlap_accuracy"] = v[1], v[2], v[3]
+        # seeds: d loss / d logits, d loss / d normalised features
+        pc_l.g = ops.focal_bwd(pc_l.v, pcm, 0.75, grad_scale)
+        im_l.g = ops.focal_bwd(im_l.v, imm, 0.5, grad_scale)
+        o["pc_geo"].g = torch.zeros((B * N, 64), dtype=f32, device=dev)
+        o["img_geo"].g = torch.zeros((B * h * w, 64), dtype=f32, device=dev)
+        ops.circle_loss_bwd(o["pc_geo"].v, img_geo_map, pci, xyi, xyf, B, N, o["pc_geo"].g, o["img_geo"].g, gh.dist_thres, gh.pos_margin,
+                            gh.neg_margin, 10, grad_scale * gh.lambda_geo)
+        t.backward()
+        return losses
+
+    def optimizer_step(self):
+        world = 1
+        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+            world = self.bucket.all_reduce(self.dist)
+        self.t += 1
+        ops.adam(self.bucket.params, self.bucket.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
+                 self.weight_decay, self.t, grad_scale=1.0 / world, grad_clip=self.grad_clip)
+        self.model.invalidate()
+
+    def step(self, data):
+        losses = self.forward_backward(data)
+        self.optimizer_step()
+        return losses
+
+    def set_lr(self, lr):
+        self.lr = lr

@@ -1,0 +1,366 @@
+"""A minimal reverse-mode tape over the HIP ops, for the geometric model's training step (reference
+Train_Geo.py:166-174 relies on torch autograd).
+
+The training forward is written as calls of the op functions below; each op launches its forward kernel(s) through
+`cmr_agent_amd.ops`, returns a `Var` and appends a closure that, given the gradient of its output, launches the backward
+kernel(s) and hands gradients to its inputs.  `Tape.backward()` runs the closures in reverse.  There is no torch autograd,
+no CPU path and no torch arithmetic: torch supplies device memory (`empty` / `zeros` / views / copies), as everywhere else
+in the package.
+
+Values are row maps `[rows, C]` (unit inner stride, arbitrary row stride), images are the same storage viewed as
+`[B, H, W, C]`.  Parameters live in a `FlatBucket`; their gradients are written (first use in a step) or accumulated
+(parameter shared by several calls, e.g. the shared raw-point MLP, or the LayerNorm a cross-attention block applies to both
+its inputs) straight into the flat gradient buffer."""
+import torch
+
+from .. import ops
+
+f32 = torch.float32
+
+
+class Var:
+    __slots__ = ("v", "g")
+
+    def __init__(self, v):
+        self.v = v          # value, 2-D rows
+        self.g = None       # gradient (same shape), set by consumers' backward closures
+
+
+class Tape:
+    WINOGRAD = True         # 3x3 convolutions (forward and data gradient) on the Winograd kernel; False = direct kernel (debug aid)
+
+    def __init__(self, bucket):
+        self.bucket = bucket
+        self.nodes = []
+        self.touched = set()            # parameter ids whose gradient slice has been written in this step
+
+    # ------------------------------------------------------------------------------------------------------------ engine
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+
+    def give(self, var, g, alpha=1.0, owned=False):
+        """hand gradient contribution alpha * g to `var` (owned: the buffer g may be kept and mutated)."""
+        if var is None:
+            return
+        if var.g is None:
+            if owned and alpha == 1.0:
+                var.g = g
+            else:
+                var.g = torch.zeros((g.shape[0], g.shape[1]), dtype=f32, device=g.device)
+                ops.axpy(var.g, g, alpha)
+        else:
+            ops.axpy(var.g, g, alpha)
+
+    def target(self, var, rows, C):
+        """-> (buffer, accumulate): where a backward kernel with an `accumulate` flag should write var's gradient."""
+        if var.g is None:
+            var.g = torch.empty((rows, C), dtype=f32, device=var.v.device)
+            return var.g, False
+        return var.g, True
+
+    # parameters ---------------------------------------------------------------------------------------------------------
+    def W(self, param):
+        return self.bucket.wp(param)
+
+    def G(self, param):
+        """-> (gradient storage view, accumulate flag) of a parameter; first touch in a step overwrites."""
+        acc = id(param) in self.touched
+        self.touched.add(id(param))
+        return self.bucket.gp(param), acc
+
+    def _param_vec_grad(self, param, vec):
+        """accumulate / write a [C] gradient vector (bias, BatchNorm / LayerNorm affine) into the bucket."""
+        g, acc = self.G(param)
+        if acc:
+            ops.axpy(g.view(1, -1), vec.view(1, -1))
+        else:
+            g.copy_(vec)
+
+    # ------------------------------------------------------------------------------------------------------------ ops
+    def linear(self, x, weight, bias=None, const_res=None, res_mod=0):
+        """y = x W^T + b (+ constant residual rows, e.g. a position table).  weight: nn.Parameter [n, k(, 1(, 1))]."""
+        W = self.W(weight)                                     # [n4, k4]
+        b = self.W(bias) if bias is not None else None
+        if x.v.shape[1] != W.shape[1]:
+            raise ValueError("linear: input width %d vs stored weight %s" % (x.v.shape[1], tuple(W.shape)))
+        y = Var(ops.linear(x.v, W, b, res=const_res, res_mod=res_mod))
+
+        def bwd():
+            if y.g is None:
+                return
+            dy = y.g
+            gw, acc = self.G(weight)
+            ops.linear_wgrad_any(dy, x.v, gw, acc)
+            if bias is not None:
+                self._param_vec_grad(bias, ops.colsum(dy, 1, dy.shape[0]).view(-1))
+            wt = ops.transpose(W.view(1, *W.shape))[0]         # [k4, n4]
+            self.give(x, ops.linear(dy, wt), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def bn(self, x, bn):
+        """BatchNorm in batch-statistics mode over the rows of x (nn.BatchNorm1d / 2d in train())."""
+        C = x.v.shape[1]
+        gamma, beta = self.W(bn.weight), self.W(bn.bias)
+        c = bn.running_mean.numel()
+        if c == C:
+            rm, rv = bn.running_mean, bn.running_var
+        else:                                                   # widths that are not a multiple of 4 (the stem's 3 channels)
+            rm = torch.zeros(C, dtype=f32, device=x.v.device)
+            rv = torch.ones(C, dtype=f32, device=x.v.device)
+            rm[:c] = bn.running_mean
+            rv[:c] = bn.running_var
+        stat = ops.bn_stats(x.v, gamma, beta, rm, rv, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
+        if c != C:
+            bn.running_mean.copy_(rm[:c])
+            bn.running_var.copy_(rv[:c])
+        y = Var(ops.affine_act(x.v, stat[2], stat[3]))
+
+        def bwd():
+            if y.g is None:
+                return
+            dg = torch.empty(C, dtype=f32, device=x.v.device)
+            db = torch.empty(C, dtype=f32, device=x.v.device)
+            dx = ops.bn_bwd(y.g, None, 1.0, x.v, stat, dg, db)
+            self._param_vec_grad(bn.weight, dg)
+            self._param_vec_grad(bn.bias, db)
+            self.give(x, dx, owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def act(self, x, kind, param=0.0):
+        y = Var(ops.act(x.v, kind, param))
+
+        def bwd():
+            if y.g is None:
+                return
+            buf, acc = self.target(x, *x.v.shape)
+            ops.act_bwd_x(y.g, x.v, kind, param, out=buf, accumulate=acc)
+        self.nodes.append(bwd)
+        return y
+
+    def add(self, a, b, alpha_b=1.0):
+        """y = a + alpha_b * b (alpha_b in {1, -1})."""
+        if alpha_b == 1.0:
+            y = Var(ops.affine_act(a.v, res=b.v))
+        else:
+            C = a.v.shape[1]
+            one = torch.ones(C, dtype=f32, device=a.v.device)
+            zero = torch.zeros(C, dtype=f32, device=a.v.device)
+            y = Var(ops.affine_act(a.v, one, zero, res=b.v, rscale=torch.full((C,), float(alpha_b), dtype=f32, device=a.v.device), rshift=zero))
+
+        def bwd():
+            if y.g is None:
+                return
+            self.give(a, y.g)
+            self.give(b, y.g, alpha=alpha_b)
+        self.nodes.append(bwd)
+        return y
+
+    def add_const(self, x, table, period):
+        """y[r] = x[r] + table[r % period] (position tables): constant, gradient passes through."""
+        rows, C = x.v.shape
+        out = torch.empty((rows, C), dtype=f32, device=x.v.device)
+        for s in range(0, rows, period):
+            ops.affine_act(x.v[s:s + period], res=table, out=out[s:s + period])
+        y = Var(out)
+
+        def bwd():
+            if y.g is not None:
+                self.give(x, y.g)
+        self.nodes.append(bwd)
+        return y
+
+    def layernorm(self, x, ln, eps):
+        gamma, beta = self.W(ln.weight), self.W(ln.bias)
+        y = Var(ops.layernorm64(x.v, gamma, beta, eps))
+
+        def bwd():
+            if y.g is None:
+                return
+            dg = torch.empty(64, dtype=f32, device=x.v.device)
+            db = torch.empty(64, dtype=f32, device=x.v.device)
+            buf, acc = self.target(x, *x.v.shape)
+            ops.layernorm64_bwd(y.g, x.v, gamma, eps, dg, db, False, out=buf, accumulate=acc)
+            self._param_vec_grad(ln.weight, dg)
+            self._param_vec_grad(ln.bias, db)
+        self.nodes.append(bwd)
+        return y
+
+    def gather(self, x, idx, csr):
+        """y[r] = x[idx[r]] (idx int32 global rows); csr = (offsets, order) of idx over x's rows for the scatter-add backward."""
+        y = Var(ops.gather_rows(x.v, idx))
+
+        def bwd():
+            if y.g is None:
+                return
+            offsets, order = csr
+            self.give(x, ops.segment_reduce(y.g, order, offsets, x.v.shape[0], "sum"), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def cat(self, a, b):
+        ca, cb = a.v.shape[1], b.v.shape[1]
+        y = Var(ops.concat_rows(a.v, b.v))
+
+        def bwd():
+            if y.g is None:
+                return
+            self.give(a, y.g[:, :ca])
+            self.give(b, y.g[:, ca:])
+        self.nodes.append(bwd)
+        return y
+
+    def cols(self, x, lo, hi):
+        """column slice as a separate value (k / v halves of a fused projection)."""
+        y = Var(x.v[:, lo:hi])
+
+        def bwd():
+            if y.g is None:
+                return
+            if x.g is None:
+                x.g = torch.zeros(x.v.shape, dtype=f32, device=x.v.device)
+            ops.axpy(x.g[:, lo:hi], y.g)
+        self.nodes.append(bwd)
+        return y
+
+    def segment_softmax(self, attn, vp, nseg, scale, order=None, offsets=None, fixed_len=0):
+        y = Var(ops.segment_softmax(attn.v, vp.v, nseg, scale, order=order, offsets=offsets, fixed_len=fixed_len))
+
+        def bwd():
+            if y.g is None:
+                return
+            da, dv = ops.segment_softmax_bwd(attn.v, vp.v, y.g, nseg, scale, order=order, offsets=offsets, fixed_len=fixed_len)
+            self.give(attn, da, owned=True)
+            self.give(vp, dv, owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def mha(self, q, k, v, B, Tq, Tk):
+        y = Var(ops.mha(q.v, k.v, v.v, B, Tq, Tk))
+
+        def bwd():
+            if y.g is None:
+                return
+            dq, dk, dv = ops.mha_bwd(q.v, k.v, v.v, y.v, y.g, B, Tq, Tk)
+            self.give(q, dq, owned=True)
+            self.give(k, dk, owned=True)
+            self.give(v, dv, owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def la_core(self, qf, kf, v, B, L, S, eps):
+        kvsum = ops.la_reduce(kf.v, v.v, B, S)
+        y = Var(ops.la_apply(qf.v, kvsum, B, L, S, eps))
+
+        def bwd():
+            if y.g is None:
+                return
+            dq, dk, dv = ops.la_bwd(qf.v, kf.v, v.v, kvsum, y.g, B, L, S, eps)
+            self.give(qf, dq, owned=True)
+            self.give(kf, dk, owned=True)
+            self.give(v, dv, owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def l2norm(self, x):
+        y = Var(ops.l2norm64(x.v))
+
+        def bwd():
+            if y.g is None:
+                return
+            buf, acc = self.target(x, *x.v.shape)
+            ops.l2norm64_bwd(y.g, x.v, out=buf, accumulate=acc)
+        self.nodes.append(bwd)
+        return y
+
+    # ---- convolutions: x is the row view of a contiguous NHWC map (B, H, W given) -----------------------------------------
+    def conv3x3(self, x, dims, conv, stride=1):
+        """nn.Conv2d(3x3, padding 1, stride 1|2) with bias, no activation, Cin in {64, 128} -> (Var, (B, Ho, Wo))."""
+        B, H, W = dims
+        cout, cin = conv.weight.shape[0], conv.weight.shape[1]
+        wflat = self.W(conv.weight)
+        w9, u = ops.pack_conv3x3(wflat, cout, cin, want_u=self.WINOGRAD)
+        xi = x.v.view(B, H, W, cin)
+        yv = ops.conv3x3(xi, w9, self.W(conv.bias), cout, stride, 1.0, u=u)
+        Ho, Wo = yv.shape[1], yv.shape[2]
+        y = Var(yv.view(-1, cout))
+
+        def bwd():
+            if y.g is None:
+                return
+            dy = y.g.view(B, Ho, Wo, cout)
+            if not dy.is_contiguous():
+                dy = dy.contiguous()
+            if stride == 2:
+                dy = ops.zero_insert2(dy, H, W)                # stride-2 gradients = stride-1 ones of the zero-inserted dy
+            gw, acc = self.G(conv.weight)
+            if acc:
+                tmp = torch.empty(cout * cin * 9, dtype=f32, device=dy.device)
+                ops.conv3x3_wgrad(xi, dy, tmp)
+                ops.axpy(gw[:cout * cin * 9].view(1, -1), tmp.view(1, -1))
+            else:
+                ops.conv3x3_wgrad(xi, dy, gw[:cout * cin * 9])
+            self._param_vec_grad(conv.bias, ops.colsum(y.g, 1, y.g.shape[0]).view(-1))
+            w9t, ut = ops.pack_conv3x3(wflat, cout, cin, transpose=True, want_u=self.WINOGRAD)
+            self.give(x, ops.conv3x3(dy, w9t, None, cin, 1, 1.0, u=ut).view(-1, cin), owned=True)
+        self.nodes.append(bwd)
+        return y, (B, Ho, Wo)
+
+    def conv3x3_c3(self, x4, dims, conv, need_dx):
+        """3x3 convolution with 3 input channels (the stem) as a row GEMM over im2col rows: x4 = Var of [B*H*W, 4] (xyz0-style)."""
+        B, H, W = dims
+        cout = conv.weight.shape[0]
+        cols = ops.im2col3(x4.v.view(B, H, W, 4))
+        n4 = (cout + 3) // 4 * 4
+        wm = torch.zeros((n4, 36), dtype=f32, device=cols.device)                  # [co][tap][c] <- parameter [co][c][ky][kx]
+        wm.view(n4, 9, 4)[:cout, :, :3] = conv.weight.detach().permute(0, 2, 3, 1).reshape(cout, 9, 3)
+        bias = self.W(conv.bias)
+        y = Var(ops.linear(cols, wm, bias))
+
+        def bwd():
+            if y.g is None:
+                return
+            dw = torch.zeros((n4, 36), dtype=f32, device=cols.device)
+            ops.linear_wgrad_any(y.g, cols, dw, False)
+            gw, acc = self.G(conv.weight)
+            gl = dw.view(n4, 9, 4)[:cout, :, :3].reshape(cout, 3, 3, 3).permute(0, 3, 1, 2).reshape(-1)     # back to [co][c][ky][kx]
+            if acc:
+                raise RuntimeError("conv3x3_c3: the stem's convolutions are used once per step")
+            gw[:gl.numel()].copy_(gl)                                                                # layout copy into the bucket
+            self._param_vec_grad(conv.bias, ops.colsum(y.g, 1, y.g.shape[0]).view(-1))
+            if need_dx:
+                dcols = ops.linear(y.g, wm.t().contiguous())
+                self.give(x4, ops.col2im3(dcols, B, H, W).view(-1, 4), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def upsample_concat(self, f, proxy, dims, scale):
+        """[f | nearest-upsampled proxy tokens] per pixel (IMGPCEnDecoder.py:85-89)."""
+        B, H, W = dims
+        c1, c2 = f.v.shape[1], proxy.v.shape[1]
+        y = Var(ops.upsample_concat(f.v.view(B, H, W, c1), proxy.v, scale).view(-1, c1 + c2))
+
+        def bwd():
+            if y.g is None:
+                return
+            g = y.g if y.g.is_contiguous() else y.g.contiguous()
+            self.give(f, g[:, :c1])
+            self.give(proxy, ops.upsample_bwd(g.view(B, H, W, c1 + c2), c1, B, H, W, c2, scale), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def patchify(self, x, dims, P):
+        B, H, W = dims
+        C = x.v.shape[1]
+        y = Var(ops.patchify(x.v.view(B, H, W, C), P))
+
+        def bwd():
+            if y.g is None:
+                return
+            g = y.g if y.g.is_contiguous() else y.g.contiguous()
+            self.give(x, ops.patchify_bwd(g, B, H, W, C, P).view(-1, C), owned=True)
+        self.nodes.append(bwd)
+        return y

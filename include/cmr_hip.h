@@ -349,9 +349,11 @@ int cmr_agent_loss_f32(const float* r_logits, int64_t ldr, const float* t_logits
                        int64_t lddt, float* d_v, int64_t lddv, float* out, int B, int dr, int dt, int S, float alpha,
                        float clip_eps, float w_value, float w_entropy, float grad_scale, hipStream_t stream);
 /* torch.optim.Adam step (Train_Agent.py:121-127, :305) over the flat parameter bucket: g <- grad_scale * g + wd * p;
- * m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).  n % 4 == 0 (the bucket pads every tensor). */
+ * m, v moments; p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps).  n % 4 == 0 (the bucket pads every tensor).  grad_clip > 0
+ * clamps the scaled gradient to [-clip, clip] first (nn.utils.clip_grad_value_, Train_Geo.py:172). */
 int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, hipStream_t stream);
+                 float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, float grad_clip,
+                 hipStream_t stream);
 /* nn.Conv2d(3x3, stride 1, pad 1) weight gradient on the matrix cores: dw [Cout][Cin][3][3] = sum over the minibatch
  * pixels of dy (x) shifted x (NHWC maps, W >= 2, Cin in {32,64,128}, Cout % 32 == 0). */
 int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);

@@ -113,3 +113,76 @@ def buffer_samples(trajectories, gamma, gae_lambda):
         rets.append(ret.reshape(-1, 1))                                # iterating [B,T,1] over B and concatenating = reshape
         advs.append(adv.reshape(-1, 1))
     return out + [torch.cat(rets, 0), torch.cat(advs, 0)]
+
+
+# ----------------------------------------------------------------------------------------------
+# geometric model update (Train_Geo.py:166-174)
+# ----------------------------------------------------------------------------------------------
+GEO_FROZEN = ("position_embeddings",)          # nn.Parameter(requires_grad=False), ImageViT.py:23-24
+# ImageViT.py:17-23 registers the pyramid and the patch convolution twice (embedding_layers.{0,1} and by name): ONE Parameter
+# under two state_dict keys.  The functional forward reads the named ones; the aliases follow them.
+GEO_ALIASES = (("embeddings.embedding_layers.0.", "embeddings.mini_resnet."), ("embeddings.embedding_layers.1.", "embeddings.patch_embeddings."))
+
+
+def canonical_key(key):
+    for alias, name in GEO_ALIASES:
+        if alias in key:
+            return key.replace(alias, name)
+    return key
+
+
+def is_geo_parameter(key):
+    return key.endswith(PARAM_SUFFIXES)
+
+
+def _tie_aliases(sd):
+    """alias keys refer to the canonical key's tensor (same storage: running statistics move together)"""
+    return {k: sd[canonical_key(k)] if canonical_key(k) in sd else v for k, v in sd.items()}
+
+
+def geo_forward_backward(sd, data, cfg, bn_training=True):
+    """`model.train(); model(data); data['loss'].backward()` of Train_Geo.py:166-171 with every nn.Dropout at p = 0 (the
+    reference's dropout draws are not reproducible across implementations; parity is defined without them):
+    forward of cmr_oracle.multi_head_model with batch statistics, loss = focal + focal + circle (MultiHeadModel.py:98-102,
+    269), autograd.  Running statistics in `sd` move in place.  Returns (outputs incl. the losses / metrics,
+    grads {param key: tensor}); alias keys carry their parameter's gradient."""
+    sd = _tie_aliases(sd)
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if is_geo_parameter(k) and canonical_key(k) == k}
+    work = dict(sd)
+    work.update({k: leaves[canonical_key(k)] for k in sd if is_geo_parameter(k)})
+    prev = O.BN_TRAINING
+    O.BN_TRAINING = bn_training
+    try:
+        with torch.enable_grad():
+            out = O.multi_head_model(work, data, cfg, with_loss=True)
+            out["loss"].backward()
+    finally:
+        O.BN_TRAINING = prev
+    g = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)
+    grads = {k: g(leaves[canonical_key(k)]) for k in sd if is_geo_parameter(k)}
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}, grads
+
+
+def geo_adam_train(sd, batches, cfg, bn_training=True, clip=1.0, grad_hook=None):
+    """Train_Geo.py:118-124, 166-174: Adam(lr, betas=(0.9, 0.99), weight_decay) over model.parameters() (each Parameter
+    once), clip_grad_value_(parameters, 1) before every step.  Returns (new state dict, [outputs per step])."""
+    sd = _tie_aliases({k: v.detach().clone() for k, v in sd.items()})
+    params = {k: torch.nn.Parameter(sd[k]) for k in sd if is_geo_parameter(k) and canonical_key(k) == k}
+    opt = torch.optim.Adam(list(params.values()), lr=cfg.lr, betas=(0.9, 0.99), weight_decay=cfg.weight_decay)
+    history = []
+    for data in batches:
+        cur = dict(sd)
+        cur.update({k: params[canonical_key(k)].data for k in sd if is_geo_parameter(k)})
+        out, grads = geo_forward_backward(cur, data, cfg, bn_training)      # running statistics: shared storage with sd
+        if grad_hook is not None:
+            grads = grad_hook(grads)
+        opt.zero_grad()
+        for k, p in params.items():
+            p.grad = grads[k].clone()
+        if clip:
+            torch.nn.utils.clip_grad_value_(list(params.values()), clip)
+        opt.step()
+        history.append(out)
+    res = dict(sd)
+    res.update({k: params[canonical_key(k)].data.clone() for k in sd if is_geo_parameter(k)})
+    return res, history

@@ -237,6 +237,18 @@ TRAIN_CASES = {
 TRAIN_FIXTURES = ("agent_train_small_trainbn", "agent_train_small_evalbn", "buffer_order")
 
 
+# geometric-model update (Train_Geo.py:166-174): the e2e_small shape, two batches (seeds 2023 / 2024), dropout off
+GEO_TRAIN_CASE = "e2e_small"
+GEO_TRAIN_SEEDS = (2023, 2024)
+GEO_TRAIN_FIXTURE = "geo_train_small"
+
+
+def geo_train_batches(case=GEO_TRAIN_CASE, seeds=GEO_TRAIN_SEEDS):
+    c = _case(case)
+    return [synthetic.make_batch(c["B"], c["N"], c["H"], c["W"], c["M"], O.dataset_fps, O.nearest_node, seed=s, n_circle=c["n_circle"])
+            for s in seeds]
+
+
 def train_config(case, device="cpu"):
     from cmr_agent_amd.config import KittiConfiguration
     c = TRAIN_CASES[case]
@@ -288,7 +300,7 @@ def buffer_inputs():
 # dataset-side geometry of one frame (KittiDataset.py:258-423)
 # ----------------------------------------------------------------------------------------------
 FRAME = dict(n_raw=6000, num_pt=4096, num_node=128, H=160, W=512, img_h=376, img_w=1241)
-TRAIN_FIXTURES = TRAIN_FIXTURES + ("kitti_frame",)
+TRAIN_FIXTURES = TRAIN_FIXTURES + ("kitti_frame", GEO_TRAIN_FIXTURE)
 # calib.txt rows of a KITTI odometry sequence (P2 and Tr; public calibration numbers, data not code)
 FRAME_P2 = [7.188560000000e+02, 0.0, 6.071928000000e+02, 4.538225000000e+01, 0.0, 7.188560000000e+02, 1.852157000000e+02,
             -1.130887000000e-01, 0.0, 0.0, 1.0, 3.779761000000e-03]

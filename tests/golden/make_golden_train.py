@@ -11,7 +11,13 @@
   buffer_order.npz    Buffer.get_samples() of the reference's replay buffer on tests/cases.py:buffer_inputs (the
       step-major / batch-major ordering quirk).
 
-Cross-checks oracle/train_oracle.py against both while doing so.  Run in the authoring container only."""
+  geo_train_small.npz   the reference's MultiHeadModel in train() mode on tests/cases.py:geo_train_batches (two batches of the
+      e2e_small shape) with p = 0 written into every nn.Dropout (the draws are not reproducible across implementations; the
+      forward is otherwise the unmodified module code, with the sine table resized as for the e2e fixtures): the four losses
+      and six metrics of both steps, every parameter's gradient (norm + strided sample) after the first loss.backward(), and
+      the parameters + running statistics after two steps of clip_grad_value_(1) + Adam as Train_Geo.py:73-78, 166-174.
+
+Cross-checks oracle/train_oracle.py against all of them while doing so.  Run in the authoring container only."""
 import json
 import os
 import sys
@@ -32,8 +38,9 @@ from oracle import train_oracle as TO  # noqa: E402
 GRAD_SAMPLES = 256
 
 
-def pack_state(prefix, sd, named):
+def pack_state(prefix, sd, named, samples=None):
     """per-tensor norm + strided sample of at most GRAD_SAMPLES values, concatenated in key order."""
+    GRAD_SAMPLES = samples or globals()["GRAD_SAMPLES"]
     keys = sorted(sd)
     named[prefix + "norms"] = torch.stack([sd[k].double().norm() for k in keys]).float()
     parts = []
@@ -83,6 +90,66 @@ def run_agent(ns, case, bn_training, report):
     print(tag, report[tag])
 
 
+GEO_SAMPLES = 48
+
+
+def run_geo(ns, report):
+    case = C.GEO_TRAIN_CASE
+    c = C.E2E_CASES[case]
+    cfg = ns.config.KittiConfiguration()
+    cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_pt = c["H"], c["W"], c["N"]
+    cfg.image_H, cfg.image_W = c["H"] // 4, c["W"] // 4
+    cfg.num_node, cfg.num_proxy = c["M"], c["Q"]
+    geo = ns.models.MultiHeadModel(cfg)
+    hashfill.fill_state_dict(geo.state_dict(), C.GEO_TAG)
+    h, w = cfg.image_H, cfg.image_W
+    geo.encoder_decoder.pixel_pos_encoding = ns.utils.PositionEncodingSine2D(cfg.embed_dim, (h, w))      # as make_golden.run_e2e
+    ndrop = 0
+    for m in geo.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+            ndrop += 1
+    geo.train()
+    keep = lambda sd: {k: v.detach().clone() for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    sd0 = keep(geo.state_dict())
+    opt = torch.optim.Adam(geo.parameters(), lr=cfg.lr, betas=(0.9, 0.99), weight_decay=cfg.weight_decay)   # Train_Geo.py:73-78
+    batches = C.geo_train_batches()
+    named, names = {}, dict(geo.named_parameters(remove_duplicate=False))
+    scal = C.LOSS_KEYS + C.METRIC_KEYS
+    for i, b in enumerate(batches):
+        data = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in b.items()}
+        opt.zero_grad()
+        geo.encoder_decoder(data)                       # MultiHeadModel.forward :317-326 without the (40, 128) view of :340
+        data["loss"] = 0.
+        geo.overlap_head(data)
+        geo.geo_head(data)
+        data["loss"].backward()
+        if i == 0:
+            grads0 = {k: p.grad.detach().clone() for k, p in names.items() if p.requires_grad}
+            pack_state("grad_", grads0, named, GEO_SAMPLES)
+        for k in scal:
+            named["step%d/%s" % (i, k)] = torch.as_tensor(data[k]).detach().reshape(1).float()
+        torch.nn.utils.clip_grad_value_(geo.parameters(), 1)                                            # Train_Geo.py:173
+        opt.step()
+    final = keep(geo.state_dict())
+    final = {k: v for k, v in final.items() if not k.endswith("position_embeddings")}                # frozen, image-size specific
+    pack_state("final_", final, named, GEO_SAMPLES)
+    named["n_dropout_modules"] = torch.tensor([ndrop])
+    # oracle cross-check on the full tensors
+    ocfg = C.e2e_config(case)
+    sd_in = {k: v for k, v in sd0.items() if not k.endswith("position_embeddings")}
+    _, og = TO.geo_forward_backward({k: v.clone() for k, v in sd_in.items()}, batches[0], ocfg, True)
+    osd, hist = TO.geo_adam_train(sd_in, batches, ocfg, True)
+    gscale = max(float(g.abs().max()) for g in grads0.values())
+    report[C.GEO_TRAIN_FIXTURE] = dict(
+        loss=float(max(abs(float(hist[i][k]) - float(named["step%d/%s" % (i, k)])) for i in range(len(batches)) for k in scal)),
+        grad_max_abs_diff_over_max_grad=float(max((og[k] - grads0[k]).abs().max() for k in grads0)) / gscale,
+        final_param_max_abs_diff=float(max((osd[k] - final[k]).abs().max() for k in final)),
+        final_param_frac_above_2e_5=float(sum(((osd[k] - final[k]).abs() > 2e-5).sum() for k in final)) / sum(v.numel() for v in final.values()))
+    G.save_case(C.GEO_TRAIN_FIXTURE, named)
+    print(C.GEO_TRAIN_FIXTURE, report[C.GEO_TRAIN_FIXTURE])
+
+
 def run_buffer(ns, report):
     cfg = ns.config.KittiConfiguration()
     ns.buffer.DEVICE = torch.device("cpu")
@@ -109,6 +176,7 @@ def main():
         run_agent(ns, case, True, report)
         run_agent(ns, case, False, report)
     run_buffer(ns, report)
+    run_geo(ns, report)
     rp = os.path.join(G.OUT_DIR, "oracle_vs_reference.json")
     rep = json.load(open(rp))
     rep.update(report)

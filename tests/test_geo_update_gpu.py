@@ -1,0 +1,175 @@
+"""GPU tier, geometric-model update (Train_Geo.py:166-174): cmr_agent_amd.train.GeoUpdate -- train-mode forward of
+MultiHeadModel on the HIP tape, focal + focal + circle loss, backward into the flat gradient bucket, value clipping + fused
+Adam -- against oracle/train_oracle.py (torch-CPU autograd of the functional restatement; equal to the reference's own module
+to the last bit, tests/golden/oracle_vs_reference.json) and against the fixture generated from the reference's MultiHeadModel +
+torch.optim.Adam (tests/golden/make_golden_train.py:run_geo).
+
+How the bars are set.  The first forward/backward is compared tensor by tensor.  This network is deep (60+ normalised layers,
+ReLU / LeakyReLU kinks, near-saturated softmaxes): feeding the ORACLE an input perturbed by 1e-6 relative already moves the
+small gradient tensors by several per cent of their own scale (tools/geo_train_debug.py), so per-tensor errors
+are bounded against the model's largest gradient entry (3e-3; measured 4e-4 / 1.7e-3 on the two steps) and, for tensors that are not themselves at noise level, against
+their own scale (0.15); the whole gradient vector must have cosine >= 0.99999 with the oracle's.  A free-running second Adam
+step is chaotic in the same sense (Adam's first steps move every weight by lr * sign(g), so an entry whose gradient is at noise
+level lands 2 lr away on either side: 31 % of the entries of the oracle itself differ by more than 2e-5 after two steps under
+that 1e-6 perturbation).  So the second step is checked TEACHER-FORCED -- a fresh HIP model loaded with the oracle's state after
+step one must reproduce the oracle's step-two losses and gradients to the same bars as step one -- and the free-running
+trajectory is only required to stay inside the envelope (every weight within 4.4 lr, losses within 3e-4 relative)."""
+import json
+import os
+
+import pytest
+import torch
+
+import cases as C
+import golden_util as G
+from oracle import train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+SCALARS = C.LOSS_KEYS + C.METRIC_KEYS
+
+
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    with torch.enable_grad():
+        yield
+
+
+def _to_dev(b):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def _model(cfg, sd):
+    from cmr_agent_amd.models import MultiHeadModel
+    from cmr_agent_amd.utils.checkpoint import load_checked
+    m = MultiHeadModel(cfg)
+    load_checked(m, sd)
+    return m.to(DEV)
+
+
+def _logical_grads(up, model):
+    named = dict(model.named_parameters(remove_duplicate=False))
+    return {k: up.bucket.by_id[id(p)].view(up.bucket.grads) for k, p in named.items() if p.requires_grad}
+
+
+def _check_scalars(got, ref, rtol, what):
+    for k in SCALARS:
+        g, r = float(got[k]), float(ref[k])
+        assert abs(g - r) <= rtol * max(1.0, abs(r)), "%s %s: hip %.7f oracle %.7f" % (what, k, g, r)
+
+
+def _check_grads(lg, og, what):
+    gmax = max(float(g.abs().max()) for g in og.values())
+    bad, dot, nh, no = [], 0.0, 0.0, 0.0
+    for k, g in og.items():
+        h = lg[k].detach().cpu().double().reshape(g.shape)
+        g = g.double()
+        d, m = float((h - g).abs().max()), float(g.abs().max())
+        if d > 3e-3 * gmax or (m > 1e-4 * gmax and d > 0.15 * m):
+            bad.append("%s: max|d| %.3e, own max %.3e, model max %.3e" % (k, d, m, gmax))
+        if TO.canonical_key(k) == k:
+            dot, nh, no = dot + float((h * g).sum()), nh + float((h * h).sum()), no + float((g * g).sum())
+    assert not bad, what + " gradients vs oracle autograd:\n  " + "\n  ".join(bad[:20])
+    cos = dot / (nh * no) ** 0.5
+    assert cos >= 0.99999, "%s: cosine of the whole gradient vector %.7f" % (what, cos)
+    return gmax
+
+
+def test_geo_update_matches_oracle_and_reference_fixture():
+    from cmr_agent_amd.train import GeoUpdate
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    sd0 = {k: v for k, v in geo_sd.items() if not k.endswith("num_batches_tracked")}
+    batches = C.geo_train_batches()
+    fx = G.load_case(C.GEO_TRAIN_FIXTURE)
+    # ---- step one: forward / backward
+    model = _model(cfg, geo_sd)
+    up = GeoUpdate(model, cfg)
+    losses = up.forward_backward(_to_dev(batches[0]))
+    torch.cuda.synchronize()
+    sd_ref = {k: x.clone() for k, x in sd0.items()}
+    out, og = TO.geo_forward_backward(sd_ref, batches[0], cfg, True)                 # moves sd_ref's running statistics
+    _check_scalars(losses, out, 1e-5, "step 0")
+    lg = _logical_grads(up, model)
+    gmax = _check_grads(lg, og, "step 0")
+    msd = model.state_dict()
+    for k in sd_ref:
+        if k.endswith(("running_mean", "running_var")):
+            ref = sd_ref[TO.canonical_key(k)]
+            assert float((msd[k].cpu() - ref).abs().max()) <= 1e-4 * max(1.0, float(ref.abs().max())), k
+    # the reference's own numbers for the same step
+    for k in SCALARS:
+        want = float(fx["step0/" + k]["sample"][0])
+        assert abs(float(losses[k]) - want) <= 1e-5 * max(1.0, abs(want)), (k, float(losses[k]), want)
+    packed = {}
+    keys = sorted(lg)
+    packed["grad_norms"] = torch.stack([lg[k].double().norm() for k in keys]).float()
+    packed["grad_samples"] = torch.cat([lg[k].reshape(-1)[::max(1, -(-lg[k].numel() // 48))] for k in keys]).float()
+    e = G.compare("grad_samples", packed["grad_samples"].cpu(), fx["grad_samples"], 3e-3 * gmax, 0)
+    assert e is None, e
+    e = G.compare("grad_norms", packed["grad_norms"].cpu(), fx["grad_norms"], 3e-3 * gmax, 0.15)
+    assert e is None, e
+    # ---- step two, teacher-forced: the oracle's state after one clipped Adam step
+    osd1, _ = TO.geo_adam_train(sd0, batches[:1], cfg, True)
+    model_b = _model(cfg, osd1)
+    up_b = GeoUpdate(model_b, cfg)
+    losses_b = up_b.forward_backward(_to_dev(batches[1]))
+    torch.cuda.synchronize()
+    out_b, og_b = TO.geo_forward_backward({k: x.clone() for k, x in osd1.items()}, batches[1], cfg, True)
+    _check_scalars(losses_b, out_b, 1e-5, "step 1 (teacher-forced)")
+    _check_grads(_logical_grads(up_b, model_b), og_b, "step 1 (teacher-forced)")
+    # ---- two free-running optimizer steps
+    model2 = _model(cfg, geo_sd)
+    up2 = GeoUpdate(model2, cfg)
+    hist = [{k: float(v) for k, v in up2.step(_to_dev(b)).items()} for b in batches]
+    torch.cuda.synchronize()
+    osd, ohist = TO.geo_adam_train(sd0, batches, cfg, True)
+    for i in range(len(batches)):
+        for k in C.LOSS_KEYS:
+            want, ref = float(fx["step%d/%s" % (i, k)]["sample"][0]), float(ohist[i][k])
+            assert abs(hist[i][k] - ref) <= 3e-4 * max(1.0, abs(ref)), (i, k, hist[i][k], ref)
+            assert abs(hist[i][k] - want) <= 3e-4 * max(1.0, abs(want)), (i, k, hist[i][k], want)
+    sd2 = {k: x.detach().cpu() for k, x in model2.state_dict().items()}
+    lr = cfg.lr
+    moved = 0.0
+    for k in osd:
+        d = float((sd2[k].double() - osd[k].double()).abs().max())
+        if k.endswith("running_var"):
+            assert d <= 2e-3 * max(1.0, float(osd[k].abs().max())), (k, d)
+        elif k.endswith("running_mean"):
+            assert d <= 4.4 * lr + 2e-3 * float(osd[k].abs().max()), (k, d)
+        else:
+            assert d <= 4.4 * lr, (k, d)
+            moved = max(moved, float((sd2[k].double() - sd0[k].double()).abs().max()))
+    assert moved >= 1.5 * lr                                   # and the optimizer did move the weights
+    # ---- the inference path sees the new weights: updated model in eval mode == a fresh module with its state dict
+    model2.eval()
+    fresh = _model(cfg, {k: v.detach().clone() for k, v in model2.state_dict().items()}).eval()
+    with torch.no_grad():
+        da, db = _to_dev(batches[0]), _to_dev(batches[0])
+        model2(da)
+        fresh(db)
+    for k in ("pc_overlap_logits", "img_geo_feat"):
+        assert float((da[k] - db[k]).abs().max()) <= 1e-6 * max(1.0, float(db[k].abs().max())), k
+
+
+def test_fused_adam_with_value_clipping():
+    """cmr_adam_f32 with grad_clip = 1 == nn.utils.clip_grad_value_(params, 1) followed by torch.optim.Adam.step (the clip
+    acts on the raw gradient, the L2 weight decay is added after it), two steps, incl. zero and far-out-of-range gradients."""
+    from cmr_agent_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n = 4096
+    p0 = torch.rand(n, generator=g) * 2 - 1
+    grads = [torch.randn(n, generator=g) * 2, torch.randn(n, generator=g) * 0.5]
+    grads[0][:64] = 0.0
+    grads[0][64:128] = 37.0
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.99), weight_decay=1e-2)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for t, gr in enumerate(grads, 1):
+        ref.grad = gr.clone()
+        torch.nn.utils.clip_grad_value_([ref], 1.0)
+        opt.step()
+        ops.adam(p, gr.to(DEV), m, v, 1e-3, 0.9, 0.99, 1e-8, 1e-2, t, grad_clip=1.0)
+        assert float((p.cpu() - ref.data).abs().max()) <= 2e-7, t

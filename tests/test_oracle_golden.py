@@ -100,6 +100,38 @@ def test_agent_training_step(bn_training):
     G.assert_case(case + ("_trainbn" if bn_training else "_evalbn"), named, atol=1e-6, rtol=1e-5)
 
 
+def test_geo_training_steps():
+    """oracle/train_oracle.py:geo_adam_train (train-mode MultiHeadModel forward with dropout off, focal + focal + circle loss,
+    autograd, clip_grad_value_(1), Adam) vs the fixture produced by the reference's MultiHeadModel module + torch.optim.Adam
+    (tests/golden/make_golden_train.py:run_geo): losses and metrics of two steps, every parameter gradient of the first,
+    parameters and running statistics after the second.
+
+    In the authoring container the two agree to the last bit (oracle_vs_reference.json).  The tolerances below allow for a
+    different host CPU: two Adam steps from scratch move every weight by +-lr per step along the SIGN of its gradient, so an
+    entry whose gradient is at rounding-noise level may land 2 lr away (and the second step inherits it); gradients of the
+    first step themselves are compared against 1e-3 of the model's largest entry."""
+    from oracle import train_oracle as TO
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    sd0 = {k: v for k, v in geo_sd.items() if not k.endswith("num_batches_tracked")}
+    batches = C.geo_train_batches()
+    _, grads = TO.geo_forward_backward({k: x.clone() for k, x in sd0.items()}, batches[0], cfg, True)
+    final, hist = TO.geo_adam_train(sd0, batches, cfg, True)
+    named = {}
+    for i, h in enumerate(hist):
+        for k in C.LOSS_KEYS + C.METRIC_KEYS:
+            named["step%d/%s" % (i, k)] = torch.as_tensor(h[k]).reshape(1).float()
+    G.assert_case(C.GEO_TRAIN_FIXTURE, {k: v for k, v in named.items() if k.startswith("step0/")}, atol=1e-5, rtol=1e-5)
+    G.assert_case(C.GEO_TRAIN_FIXTURE, {k: v for k, v in named.items() if k.startswith("step1/")}, atol=2e-3, rtol=2e-3)
+    gmax = max(float(g.abs().max()) for g in grads.values())
+    packed = {}
+    _packed("grad_", grads, packed, 48)
+    G.assert_case(C.GEO_TRAIN_FIXTURE, packed, atol=1e-3 * gmax, rtol=1e-3)
+    packed = {}
+    _packed("final_", final, packed, 48)
+    G.assert_case(C.GEO_TRAIN_FIXTURE, packed, atol=4.4 * cfg.lr, rtol=1e-3)
+
+
 def test_buffer_ordering_quirk():
     """Buffer.get_samples(): logged fields step-major, returns / advantages batch-major (buffer.py:127-143)."""
     from cmr_agent_amd.config import KittiConfiguration
