@@ -191,13 +191,62 @@ def train_main(args):
     ranks.close()
 
 
+def geo_train_main(args):
+    """--mode train-geo: the geometric-model update of Train_Geo.py:166-174 at the reference's training
+    configuration (KittiConfig: 160x512 crop, 40 960 points, batch 8 per GPU).  One STEP = one batch through
+    cmr_agent_amd.train.GeoUpdate: train-mode forward on the HIP tape, focal + focal + circle loss, backward into the flat
+    gradient bucket, ONE RCCL all-reduce of it (N > 1), value clipping + fused Adam."""
+    from cmr_agent_amd.train import GeoUpdate
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ranks = Ranks(backend="nccl", device=dev)
+    dtype = args.dtype or "f32"
+    ops.CONV_BF16 = dtype == "bf16"
+    cfg = KittiConfiguration(device=dev)
+    B = cfg.train_batch_size
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
+    model = MultiHeadModel(cfg)
+    load_checked(model, hashfill.make_state_dict(spec["geo"], GEO_TAG))
+    model = model.to(dev)
+    up = GeoUpdate(model, cfg, dist=ranks.dist)
+    batch = synthetic.make_batch(B, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, hip_fps(dev), hip_nearest(dev),
+                                 seed=ranks.shard_seed(cfg.seed), n_circle=512, device=dev)
+    for _ in range(args.warmup):
+        up.step(batch)
+    ranks.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = up.step(batch)
+    ranks.barrier()
+    elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    loss = float(losses["loss"])
+    assert loss == loss
+    if ranks.rank == 0:
+        print(json.dumps({
+            "metric": "geometric-model update pairs/sec (Train_Geo.py step at the KittiConfig training shape)",
+            "value": world * B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": "MultiHeadModel update: batch of %d pairs (160x512 image, %d points, %d nodes) per GPU, focal + focal + "
+                                   "circle loss, clip_grad_value_ 1, Adam (lr 1e-3, betas .9/.99, wd 1e-6), dropout off" % (B, cfg.num_pt, cfg.num_node),
+                       "batch_per_gpu": B,
+                       "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
+            "loss": loss}))
+    ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=("register", "train"), default="register",
-                    help="register (default): the headline registration iteration; train: the agent's minibatch update")
+    ap.add_argument("--mode", choices=("register", "train", "train-geo"), default="register",
+                    help="register (default): the headline registration iteration; train: the agent's minibatch update; "
+                         "train-geo: the geometric model's training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
@@ -206,6 +255,8 @@ def main():
     args = ap.parse_args()
     if args.mode == "train":
         return train_main(args)
+    if args.mode == "train-geo":
+        return geo_train_main(args)
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

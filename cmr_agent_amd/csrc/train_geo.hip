@@ -134,6 +134,19 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __rest
   }
 }
 
+// the same for two interleaved outputs: part[b][0..n) -> out0, part[b][n..2n) -> out1 (LayerNorm's dgamma / dbeta in one launch)
+__global__ __launch_bounds__(64) void reduce_partials2_kernel(const float* __restrict__ part, int nblk, int n, float* __restrict__ out0,
+                                                              float* __restrict__ out1, int accumulate) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  for (int b = lane; b < nblk; b += 64) s += (double)part[(int64_t)b * 2 * n + i];
+  s = wave_sum_d(s);
+  if (lane == 0) {
+    float* d = i < n ? out0 + i : out1 + (i - n);
+    *d = accumulate ? *d + (float)s : (float)s;
+  }
+}
+
 // ---- F.normalize over 64 channels: y = x / max(|x|, 1e-12);  dx = (dy - y (y . dy)) / max(|x|, 1e-12) -------------------------
 __global__ __launch_bounds__(256) void l2norm64_bwd_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                            float* __restrict__ dx, int64_t lddx, int accumulate, int64_t rows) {
@@ -695,11 +708,8 @@ extern "C" int cmr_layernorm64_bwd_f32(const float* dy, int64_t lddy, const floa
   const int nb = ln_blocks(rows);
   CMR_REQUIRE(ws_bytes >= (int64_t)nb * 128 * (int64_t)sizeof(float));
   hipLaunchKernelGGL(ln64_bwd_kernel, dim3(nb), dim3(256), 0, stream, dy, lddy, x, ldx, gamma, eps, dx, lddx, accumulate_dx, rows, (float*)ws);
-  // part[blk][0][64] -> dgamma, part[blk][1][64] -> dbeta: two strided reductions over the same partials
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(64), dim3(64), 0, stream, (const float*)ws, nb, 128, dgamma, (const int32_t*)nullptr,
-                     accumulate_params);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(64), dim3(64), 0, stream, (const float*)ws + 64, nb, 128, dbeta, (const int32_t*)nullptr,
-                     accumulate_params);
+  // part[blk][0][64] -> dgamma, part[blk][1][64] -> dbeta
+  hipLaunchKernelGGL(reduce_partials2_kernel, dim3(128), dim3(64), 0, stream, (const float*)ws, nb, 64, dgamma, dbeta, accumulate_params);
   return cmr_launch_status();
 }
 

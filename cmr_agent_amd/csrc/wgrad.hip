@@ -147,17 +147,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// linear / conv1d(k=1) weight gradient over a row map:  dW[n][k] = sum_r dY[r][n] X[r][k]      (n, k <= 128)
-// grid (slices); workgroup = 4 waves; wave = (n tile, row sub-slice); KT accumulator tiles (all of k).
+// linear / conv1d(k=1) weight gradient over a row map:  dW[n][k] = sum_r dY[r][n] X[r][k],  db[n] = sum_r dY[r][n]
+// grid (row slices, n blocks of NT*32, k blocks of KT*32); workgroup = 4 waves; wave = (n tile, row sub-slice) holding KT
+// accumulator tiles.  The slices of one (n block, k block) are summed by linear_wgrad_reduce_kernel (double accumulation,
+// fixed order: deterministic).  Small row counts (tokens: 640 .. 2048 rows) still get one slice per 128 rows, so that a
+// 1024 x 64 MLP gradient runs on ~100 CUs instead of one.
 // ------------------------------------------------------------------------------------------------------------------
 template <int NT, int KT>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, int64_t lddy, int n, const float* __restrict__ x,
-                                                           int64_t ldx, int k, int64_t rows, float* __restrict__ part) {
+                                                           int64_t ldx, int k, int64_t rows, float* __restrict__ part,
+                                                           float* __restrict__ part_b) {
   constexpr int NSPLIT = 4 / NT;
   constexpr int UNR = 4;                       // row pairs per step: (1 + KT) * UNR loads in flight
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, l31 = lane & 31;
   const int n_t = wave % NT, split = wave / NT;
+  const int n0 = blockIdx.y * (NT * 32), k0 = blockIdx.z * (KT * 32);
   const int64_t nsteps = (rows + 2 * UNR - 1) / (2 * UNR);
   const int64_t per_blk = (nsteps + gridDim.x - 1) / gridDim.x;
   const int64_t s0 = min((int64_t)blockIdx.x * per_blk, nsteps), s1 = min(s0 + per_blk, nsteps);
@@ -169,16 +174,17 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   for (int t = 0; t < KT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
 
-  const int ncol = n_t * 32 + l31;
+  const int ncol = n0 + n_t * 32 + l31;
   const bool n_ok = ncol < n;
   const float* dcol = dy + (n_ok ? ncol : 0);
   bool k_ok[KT];
   const float* xcol[KT];
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
-    k_ok[t] = t * 32 + l31 < k;
-    xcol[t] = x + (k_ok[t] ? t * 32 + l31 : 0);
+    k_ok[t] = k0 + t * 32 + l31 < k;
+    xcol[t] = x + (k_ok[t] ? k0 + t * 32 + l31 : 0);
   }
 
   // two register sets alternate between "consumed now" and "being loaded" (no copies of loaded values, masks applied at
@@ -210,15 +216,18 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
     load(sa[L], sv[L], (S) + 1 < nsteps ? (S) + 1 : last);                                   \
     __builtin_amdgcn_sched_barrier(0);                                                       \
     mask(sa[C], sv[C], (S), (S) < w1);                                                       \
-    _Pragma("unroll") for (int u = 0; u < UNR; ++u)                                          \
+    _Pragma("unroll") for (int u = 0; u < UNR; ++u) {                                        \
+      bsum += sa[C][u];                                                                      \
       _Pragma("unroll") for (int t = 0; t < KT; ++t) acc[t] = cmr_mfma32(sa[C][u], sv[C][u][t], acc[t]); \
+    }                                                                                        \
   }
   for (int64_t s = w0; s < w1; s += 2) {
     CMR_LW_STEP(0, 1, s)
     CMR_LW_STEP(1, 0, s + 1)
   }
 #undef CMR_LW_STEP
-  float* out = part + (int64_t)(blockIdx.x * NSPLIT + split) * (NT * 32) * (KT * 32);
+  const int64_t nsl = (int64_t)gridDim.x * NSPLIT, sl = (int64_t)blockIdx.x * NSPLIT + split;
+  float* out = part + (((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * nsl + sl) * (NT * 32) * (KT * 32);
 #pragma unroll
   for (int t = 0; t < KT; ++t)
 #pragma unroll
@@ -226,24 +235,44 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
       const int row = cmr_mfma_row(r, lane);
       out[(int64_t)(n_t * 32 + row) * (KT * 32) + t * 32 + l31] = acc[t][r];
     }
+  if (part_b && blockIdx.z == 0) {
+    bsum += __shfl_xor(bsum, 32);                                       // the two row parities
+    if (h == 0) part_b[((int64_t)blockIdx.y * nsl + sl) * (NT * 32) + n_t * 32 + l31] = bsum;
+  }
 }
 
-__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, int nslices, int npad, int kpad, int n, int k,
-                                                                  float* __restrict__ dw, int64_t lddw, int accumulate) {
+// outputs [0, n k): dW entries; [n k, n k + n): db entries (when part_b)
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int nslices,
+                                                                  int npad, int kpad, int nblk, int n, int k, float* __restrict__ dw,
+                                                                  int64_t lddw, int accumulate, float* __restrict__ db, int acc_db) {
   __shared__ double sm[RED_GRP][RED_OUT];
   const int o = threadIdx.x % RED_OUT, g = threadIdx.x / RED_OUT;
-  const int i = blockIdx.x * RED_OUT + o;
-  const int row = i / k, col = i - row * k;
+  const int64_t i = (int64_t)blockIdx.x * RED_OUT + o;
+  const int64_t nk = (int64_t)n * k, total = nk + (part_b ? n : 0);
   double s = 0.0;
-  if (i < n * k)
-    for (int j = g; j < nslices; j += RED_GRP) s += (double)part[((int64_t)j * npad + row) * kpad + col];
+  int row = 0, col = 0;
+  if (i < nk) {
+    row = (int)(i / k), col = (int)(i - (int64_t)row * k);
+    const int nb = row / npad, kb = col / kpad;
+    const float* p = part + ((int64_t)kb * nblk + nb) * nslices * npad * kpad + (int64_t)(row - nb * npad) * kpad + (col - kb * kpad);
+    for (int j = g; j < nslices; j += RED_GRP) s += (double)p[(int64_t)j * npad * kpad];
+  } else if (i < total) {
+    row = (int)(i - nk);
+    const int nb = row / npad;
+    const float* p = part_b + (int64_t)nb * nslices * npad + (row - nb * npad);
+    for (int j = g; j < nslices; j += RED_GRP) s += (double)p[(int64_t)j * npad];
+  }
   sm[g][o] = s;
   __syncthreads();
-  if (g == 0 && i < n * k) {
+  if (g == 0 && i < total) {
 #pragma unroll
     for (int j = 1; j < RED_GRP; ++j) s += sm[j][o];
-    float* d = dw + (int64_t)row * lddw + col;
-    *d = accumulate ? *d + (float)s : (float)s;
+    if (i < nk) {
+      float* d = dw + (int64_t)row * lddw + col;
+      *d = accumulate ? *d + (float)s : (float)s;
+    } else {
+      db[row] = acc_db ? db[row] + (float)s : (float)s;
+    }
   }
 }
 
@@ -340,34 +369,57 @@ extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int
   return cmr_launch_status();
 }
 
-extern "C" int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k) {
+namespace {
+struct LwPlan { int ntp, ktp, nblk, kblk, slices; int64_t part_floats, partb_floats; };
+inline LwPlan lw_plan(int64_t rows, int n, int k) {
+  LwPlan p;
   const int nt = (n + 31) / 32, kt = (k + 31) / 32;
-  const int ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4), ktp = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
-  return (int64_t)wgrad_slices(rows / 8) * (4 / ntp) * (ntp * 32) * (ktp * 32) * (int64_t)sizeof(float);
+  p.ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
+  p.ktp = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
+  p.nblk = (n + p.ntp * 32 - 1) / (p.ntp * 32);
+  p.kblk = (k + p.ktp * 32 - 1) / (p.ktp * 32);
+  int64_t s = rows / 128;                       // >= 128 rows (16 steps) per slice
+  const int64_t cap = 1024 / ((int64_t)p.nblk * p.kblk) > 8 ? 1024 / ((int64_t)p.nblk * p.kblk) : 8;   // ~4 workgroups per CU in total
+  if (s > cap) s = cap;
+  if (s > 256) s = 256;
+  if (s < 1) s = 1;
+  p.slices = (int)s;
+  const int64_t nsl = (int64_t)p.slices * (4 / p.ntp);
+  p.part_floats = (int64_t)p.nblk * p.kblk * nsl * (p.ntp * 32) * (p.ktp * 32);
+  p.partb_floats = (int64_t)p.nblk * nsl * (p.ntp * 32);
+  return p;
+}
+}  // namespace
+
+extern "C" int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k) {
+  const LwPlan p = lw_plan(rows, n, k);
+  return (p.part_floats + p.partb_floats) * (int64_t)sizeof(float);
 }
 
 extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
-                                    int64_t lddw, int accumulate, void* ws, int64_t ws_bytes, hipStream_t stream) {
-  CMR_REQUIRE(dy && x && dw && ws && rows > 0 && n > 0 && n <= 128 && k > 0 && k <= 128);
-  const int nt = (n + 31) / 32, kt = (k + 31) / 32;
-  const int ntp = nt <= 1 ? 1 : (nt == 2 ? 2 : 4), ktp = kt <= 1 ? 1 : (kt == 2 ? 2 : 4);
-  const int slices = wgrad_slices(rows / 8);
-  CMR_REQUIRE(ws_bytes >= (int64_t)slices * (4 / ntp) * (ntp * 32) * (ktp * 32) * (int64_t)sizeof(float));
+                                    int64_t lddw, int accumulate, float* db, int accumulate_db, void* ws, int64_t ws_bytes,
+                                    hipStream_t stream) {
+  CMR_REQUIRE(dy && x && dw && ws && rows > 0 && n > 0 && k > 0 && (int64_t)n * k < 0x7fffffff);
+  const LwPlan p = lw_plan(rows, n, k);
+  CMR_REQUIRE(p.nblk <= 65535 && p.kblk <= 65535);
+  CMR_REQUIRE(ws_bytes >= (p.part_floats + p.partb_floats) * (int64_t)sizeof(float));
   float* part = (float*)ws;
-#define CMR_LW(NT, KT)                                                                                                      \
-  hipLaunchKernelGGL((linear_wgrad_kernel<NT, KT>), dim3(slices), dim3(256), 0, stream, dy, lddy, n, x, ldx, k, rows, part)
-  if (ntp == 1 && ktp == 1) CMR_LW(1, 1);
-  else if (ntp == 1 && ktp == 2) CMR_LW(1, 2);
-  else if (ntp == 1 && ktp == 4) CMR_LW(1, 4);
-  else if (ntp == 2 && ktp == 1) CMR_LW(2, 1);
-  else if (ntp == 2 && ktp == 2) CMR_LW(2, 2);
-  else if (ntp == 2 && ktp == 4) CMR_LW(2, 4);
-  else if (ntp == 4 && ktp == 1) CMR_LW(4, 1);
-  else if (ntp == 4 && ktp == 2) CMR_LW(4, 2);
+  float* part_b = db ? part + p.part_floats : nullptr;
+  const dim3 grid(p.slices, p.nblk, p.kblk);
+#define CMR_LW(NT, KT) hipLaunchKernelGGL((linear_wgrad_kernel<NT, KT>), grid, dim3(256), 0, stream, dy, lddy, n, x, ldx, k, rows, part, part_b)
+  if (p.ntp == 1 && p.ktp == 1) CMR_LW(1, 1);
+  else if (p.ntp == 1 && p.ktp == 2) CMR_LW(1, 2);
+  else if (p.ntp == 1 && p.ktp == 4) CMR_LW(1, 4);
+  else if (p.ntp == 2 && p.ktp == 1) CMR_LW(2, 1);
+  else if (p.ntp == 2 && p.ktp == 2) CMR_LW(2, 2);
+  else if (p.ntp == 2 && p.ktp == 4) CMR_LW(2, 4);
+  else if (p.ntp == 4 && p.ktp == 1) CMR_LW(4, 1);
+  else if (p.ntp == 4 && p.ktp == 2) CMR_LW(4, 2);
   else CMR_LW(4, 4);
 #undef CMR_LW
-  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((n * k + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part, slices * (4 / ntp),
-                     ntp * 32, ktp * 32, n, k, dw, lddw, accumulate);
+  const int64_t outs = (int64_t)n * k + (db ? n : 0);
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((outs + RED_OUT - 1) / RED_OUT)), dim3(256), 0, stream, (const float*)part,
+                     (const float*)part_b, p.slices * (4 / p.ntp), p.ntp * 32, p.ktp * 32, p.nblk, n, k, dw, lddw, accumulate, db, accumulate_db);
   return cmr_launch_status();
 }
 

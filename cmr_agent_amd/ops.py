@@ -690,15 +690,16 @@ def conv3x3_wgrad(x, dy, dw):
     _lib.call("cmr_conv3x3_wgrad_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
 
 
-def linear_wgrad(dy, x, dw, lddw, n=None, k=None, accumulate=False):
-    """dw[n][k] (+)= dy^T x over the rows; dw is a raw view (pointer + row stride)."""
+def linear_wgrad(dy, x, dw, lddw, n=None, k=None, accumulate=False, db=None, accumulate_db=False):
+    """dw[n][k] (+)= dy^T x over the rows, db[n] (+)= column sums of dy (optional); dw is a raw view (pointer + row stride)."""
     _rows(dy), _rows(x)
     rows = dy.shape[0]
     n = dy.shape[1] if n is None else n
     k = x.shape[1] if k is None else k
     nb = _lib.load().cmr_linear_wgrad_workspace_bytes(rows, n, k)
     ws = _ws(nb, x.device)
-    _lib.call("cmr_linear_wgrad_f32", _p(dy), _ld(dy), n, _p(x), _ld(x), k, rows, _p(dw), int(lddw), int(accumulate), _p(ws), nb, _stream())
+    _lib.call("cmr_linear_wgrad_f32", _p(dy), _ld(dy), n, _p(x), _ld(x), k, rows, _p(dw), int(lddw), int(accumulate), _p(db),
+              int(accumulate_db), _p(ws), nb, _stream())
 
 
 def pack_conv3x3(w, cout, cin, transpose=False, want_u=True):
@@ -855,14 +856,10 @@ def circle_loss_bwd(pc_feat_rows, img_feat_nhwc, pc_idx, xy_int, xy_float, B, N,
               _stream())
 
 
-def linear_wgrad_any(dy, x, dw, accumulate=False):
-    """dw [n, k] (+)= dy^T x for any n, k: 128 x 128 blocks of the output through the row-streaming MFMA kernel
-    (cmr_linear_wgrad_f32 serves n, k <= 128; the MLP of the transformer blocks has n or k = 1024, the patch embedding k = 4096)."""
+def linear_wgrad_any(dy, x, dw, accumulate=False, db=None, accumulate_db=False):
+    """dw [n, k] (+)= dy^T x (and db) for any n, k (the MLP of the transformer blocks has n or k = 1024, the patch embedding
+    k = 4096): one launch."""
     n, k = dw.shape
     if dy.shape[1] < n or x.shape[1] < k:
         raise ValueError("linear_wgrad_any: operand widths %d / %d vs gradient %s" % (dy.shape[1], x.shape[1], tuple(dw.shape)))
-    ld = dw.stride(0)
-    for n0 in range(0, n, 128):
-        for k0 in range(0, k, 128):
-            linear_wgrad(dy[:, n0:min(n0 + 128, n)], x[:, k0:min(k0 + 128, k)], dw[n0:, k0:], ld, n=min(128, n - n0), k=min(128, k - k0),
-                         accumulate=accumulate)
+    linear_wgrad(dy, x, dw, dw.stride(0), n=n, k=k, accumulate=accumulate, db=db, accumulate_db=accumulate_db)

@@ -45,14 +45,12 @@ class GeoUpdate:
         """ImageResNet.py:5-40 in train mode -> (Var rows, dims)."""
         cl, s = blk.conv_layers, blk.SLOPE
         if blk.inchannel == 3:                                   # stem: 3-channel convolutions as row GEMMs
-            a = t.act(t.bn(t.conv3x3_c3(x, dims, cl[0], need_dx=False), cl[1]), LRELU, s)
-            b = t.bn(t.conv3x3_c3(a, dims, cl[3], need_dx=True), cl[4])
+            a = t.bn(t.conv3x3_c3(x, dims, cl[0], need_dx=False), cl[1], slope=s)
             sc = t.bn(t.linear(x, blk.shortcut[0].weight, blk.shortcut[0].bias), blk.shortcut[1])
-            return t.act(t.add(b, sc), LRELU, s), dims
+            return t.bn(t.conv3x3_c3(a, dims, cl[3], need_dx=True), cl[4], slope=s, res=sc), dims
         a, d1 = t.conv3x3(x, dims, cl[0], blk.stride)
-        a = t.act(t.bn(a, cl[1]), LRELU, s)
+        a = t.bn(a, cl[1], slope=s)
         b, d2 = t.conv3x3(a, d1, cl[3], 1)
-        b = t.bn(b, cl[4])
         if isinstance(blk.shortcut, nn.Identity):
             sc = x
         elif blk.shortcut[0].kernel_size == (1, 1):
@@ -60,7 +58,7 @@ class GeoUpdate:
         else:
             sc, _ = t.conv3x3(x, dims, blk.shortcut[0], 2)
             sc = t.bn(sc, blk.shortcut[1])
-        y = t.act(t.add(b, sc), LRELU, s)
+        y = t.bn(b, cl[4], slope=s, res=sc)
         if post is not None:
             y = t.add_const(y, post, post.shape[0])
         return y, d2
@@ -81,21 +79,20 @@ class GeoUpdate:
 
     def _mini_pointnet(self, t, x, mp):
         for layer in (mp.layer_1, mp.layer_2, mp.layer_3):
-            x = t.act(t.bn(t.linear(x, layer[0].weight, layer[0].bias), layer[1]), LRELU, mp.SLOPE)
+            x = t.bn(t.linear(x, layer[0].weight, layer[0].bias), layer[1], slope=mp.SLOPE)
         return x
 
     def _cbr1d(self, t, x, m):
         """PointNN.py:260-282."""
-        h = t.act(t.bn(t.linear(x, m.net[0].weight, m.net[0].bias), m.net[1]), LRELU, m.SLOPE)
-        y = t.bn(t.linear(h, m.net[3].weight, m.net[3].bias), m.net[4])
+        h = t.bn(t.linear(x, m.net[0].weight, m.net[0].bias), m.net[1], slope=m.SLOPE)
         sc = x if isinstance(m.shortcut, nn.Identity) else t.bn(t.linear(x, m.shortcut[0].weight, m.shortcut[0].bias), m.shortcut[1])
-        return t.act(t.add(y, sc), LRELU, m.SLOPE)
+        return t.bn(t.linear(h, m.net[3].weight, m.net[3].bias), m.net[4], slope=m.SLOPE, res=sc)
 
     def _vector_attention(self, t, m, q_rows, k, v, rel, nseg, order, offsets, fixed_len):
         d, g = m.fc_delta, m.fc_gamma
-        pos = t.linear(t.act(t.linear(rel, d[0].weight, d[0].bias), RELU), d[2].weight, d[2].bias)
+        pos = t.linear(t.linear(rel, d[0].weight, d[0].bias, act=RELU), d[2].weight, d[2].bias)
         a_in = t.add(t.add(q_rows, k, -1.0), pos)
-        a = t.linear(t.act(t.linear(a_in, g[0].weight, g[0].bias), RELU), g[2].weight, g[2].bias)
+        a = t.linear(t.linear(a_in, g[0].weight, g[0].bias, act=RELU), g[2].weight, g[2].bias)
         return t.segment_softmax(a, t.add(v, pos), nseg, 0.125, order=order, offsets=offsets, fixed_len=fixed_len)
 
     def _group_pt(self, t, m, xyz4, feat, node4, node_feat, gidx, offsets, order):
@@ -127,7 +124,7 @@ class GeoUpdate:
         v = t.linear(y, la.v_proj.weight)
         msg = t.la_core(q, k, v, B, L, S, la.eps)
         msg = t.layernorm(t.linear(msg, la.merge.weight), la.norm1, la.LN_EPS)
-        hid = t.act(t.linear(t.cat(x, msg), la.mlp[0].weight), RELU)
+        hid = t.linear(t.cat(x, msg), la.mlp[0].weight, act=RELU)
         return t.add(x, t.layernorm(t.linear(hid, la.mlp[3].weight), la.norm2, la.LN_EPS))
 
     def _patch_embed(self, t, emb, f2, dims):
@@ -146,12 +143,12 @@ class GeoUpdate:
             if y.g is None:
                 return
             dw = torch.empty((co, P * P * ci), dtype=f32, device=wm.device)
-            ops.linear_wgrad_any(y.g, patches.v, dw, False)
             gw, acc = t.G(conv.weight)
-            if acc:
+            gb, accb = t.G(conv.bias)
+            if acc or accb:
                 raise RuntimeError("patch embedding is used once per step")
+            ops.linear_wgrad_any(y.g, patches.v, dw, False, db=gb)
             gw[:dw.numel()].view(co, ci, P, P).copy_(dw.view(co, P, P, ci).permute(0, 3, 1, 2))        # back to [co][cin][ky][kx]
-            t._param_vec_grad(conv.bias, ops.colsum(y.g, 1, y.g.shape[0]).view(-1))
             t.give(patches, ops.linear(y.g, wm.t().contiguous()), owned=True)
         t.nodes.append(bwd)
         return y, T
@@ -235,12 +232,12 @@ class GeoUpdate:
             for layer in head.point_fuse_convs:
                 xh = self._cbr1d(t, xh, layer)
             pcs = getattr(head, head._pc_name)
-            pts = t.linear(t.act(t.linear(xh, pcs[0].weight, pcs[0].bias), LRELU, 0.2), pcs[2].weight, pcs[2].bias)
+            pts = t.linear(t.linear(xh, pcs[0].weight, pcs[0].bias, act=LRELU, slope=0.2), pcs[2].weight, pcs[2].bias)
             yh = pix
             for layer in head.img_res_convs:
                 yh, _ = self._resblock(t, yh, d2, layer)
             ims = getattr(head, head._img_name)
-            pxs = t.linear(t.act(t.linear(yh, ims[0].weight, ims[0].bias), LRELU, 0.2), ims[2].weight, ims[2].bias)
+            pxs = t.linear(t.linear(yh, ims[0].weight, ims[0].bias, act=LRELU, slope=0.2), ims[2].weight, ims[2].bias)
             outs[name] = (pts, pxs)
         pc_geo, img_geo = t.l2norm(outs["geo"][0]), t.l2norm(outs["geo"][1])
         return dict(B=B, N=N, h=h, w=w, pc_logits=outs["overlap"][0], img_logits=outs["overlap"][1], pc_geo=pc_geo, img_geo=img_geo)

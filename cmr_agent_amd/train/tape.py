@@ -19,11 +19,12 @@ f32 = torch.float32
 
 
 class Var:
-    __slots__ = ("v", "g")
+    __slots__ = ("v", "g", "own")
 
     def __init__(self, v):
         self.v = v          # value, 2-D rows
         self.g = None       # gradient (same shape), set by consumers' backward closures
+        self.own = False    # g is a buffer of this Var alone (may be accumulated into in place); False: shared with another Var
 
 
 class Tape:
@@ -33,6 +34,8 @@ class Tape:
         self.bucket = bucket
         self.nodes = []
         self.touched = set()            # parameter ids whose gradient slice has been written in this step
+        self._consts = {}
+        self._wt = {}
 
     # ------------------------------------------------------------------------------------------------------------ engine
     def backward(self):
@@ -41,24 +44,40 @@ class Tape:
         self.nodes = []
 
     def give(self, var, g, alpha=1.0, owned=False):
-        """hand gradient contribution alpha * g to `var` (owned: the buffer g may be kept and mutated)."""
+        """hand gradient contribution alpha * g to `var`.  owned: g is a fresh buffer nobody else refers to.  A first contribution
+        is kept by reference (no copy, no zero fill); a Var whose gradient is shared copies on the first accumulation."""
         if var is None:
             return
         if var.g is None:
-            if owned and alpha == 1.0:
-                var.g = g
+            if alpha == 1.0:
+                var.g, var.own = g, owned
             else:
-                var.g = torch.zeros((g.shape[0], g.shape[1]), dtype=f32, device=g.device)
-                ops.axpy(var.g, g, alpha)
-        else:
+                var.g, var.own = ops.affine_act(g, self._const(g.shape[1], alpha, g.device), self._const(g.shape[1], 0.0, g.device)), True
+        elif var.own:
             ops.axpy(var.g, g, alpha)
+        else:
+            C = g.shape[1]
+            if alpha == 1.0:
+                var.g = ops.affine_act(var.g, res=g)
+            else:
+                var.g = ops.affine_act(var.g, self._const(C, 1.0, g.device), self._const(C, 0.0, g.device), res=g,
+                                       rscale=self._const(C, alpha, g.device), rshift=self._const(C, 0.0, g.device))
+            var.own = True
 
     def target(self, var, rows, C):
         """-> (buffer, accumulate): where a backward kernel with an `accumulate` flag should write var's gradient."""
         if var.g is None:
-            var.g = torch.empty((rows, C), dtype=f32, device=var.v.device)
+            var.g, var.own = torch.empty((rows, C), dtype=f32, device=var.v.device), True
             return var.g, False
+        if not var.own:
+            var.g, var.own = var.g.clone() if var.g.is_contiguous() else ops.affine_act(var.g), True
         return var.g, True
+
+    def _const(self, C, value, device):
+        key = (C, float(value))
+        if key not in self._consts:
+            self._consts[key] = torch.full((C,), float(value), dtype=f32, device=device)
+        return self._consts[key]
 
     # parameters ---------------------------------------------------------------------------------------------------------
     def W(self, param):
@@ -78,30 +97,52 @@ class Tape:
         else:
             g.copy_(vec)
 
+    def vec_out(self, param):
+        """-> (buffer a kernel should OVERWRITE with the [C] gradient of `param`, finish()): the bucket slice itself on the first
+        use of the parameter in a step, a scratch vector that finish() adds to the slice afterwards."""
+        g, acc = self.G(param)
+        if not acc:
+            return g, lambda: None
+        tmp = torch.empty_like(g)
+        return tmp, lambda: ops.axpy(g.view(1, -1), tmp.view(1, -1))
+
     # ------------------------------------------------------------------------------------------------------------ ops
-    def linear(self, x, weight, bias=None, const_res=None, res_mod=0):
-        """y = x W^T + b (+ constant residual rows, e.g. a position table).  weight: nn.Parameter [n, k(, 1(, 1))]."""
+    def linear(self, x, weight, bias=None, const_res=None, res_mod=0, act=ops.ACT_NONE, slope=0.0):
+        """y = act(x W^T + b (+ constant residual rows, e.g. a position table)).  weight: nn.Parameter [n, k(, 1(, 1))]; act in
+        {none, ReLU, LeakyReLU} (their backward needs only the output)."""
+        if act not in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU):
+            raise ValueError("linear: fused activation must be ReLU / LeakyReLU")
         W = self.W(weight)                                     # [n4, k4]
         b = self.W(bias) if bias is not None else None
         if x.v.shape[1] != W.shape[1]:
             raise ValueError("linear: input width %d vs stored weight %s" % (x.v.shape[1], tuple(W.shape)))
-        y = Var(ops.linear(x.v, W, b, res=const_res, res_mod=res_mod))
+        y = Var(ops.linear(x.v, W, b, res=const_res, res_mod=res_mod, act=act, act_param=slope))
 
         def bwd():
             if y.g is None:
                 return
-            dy = y.g
+            dy = y.g if act == ops.ACT_NONE else ops.act_bwd(y.g, y.v, 0.0 if act == ops.ACT_RELU else slope)
             gw, acc = self.G(weight)
-            ops.linear_wgrad_any(dy, x.v, gw, acc)
             if bias is not None:
-                self._param_vec_grad(bias, ops.colsum(dy, 1, dy.shape[0]).view(-1))
-            wt = ops.transpose(W.view(1, *W.shape))[0]         # [k4, n4]
-            self.give(x, ops.linear(dy, wt), owned=True)
+                gb, accb = self.G(bias)
+                ops.linear_wgrad_any(dy, x.v, gw, acc, db=gb, accumulate_db=accb)
+            else:
+                ops.linear_wgrad_any(dy, x.v, gw, acc)
+            self.give(x, ops.linear(dy, self.WT(weight)), owned=True)
         self.nodes.append(bwd)
         return y
 
-    def bn(self, x, bn):
-        """BatchNorm in batch-statistics mode over the rows of x (nn.BatchNorm1d / 2d in train())."""
+    def WT(self, weight):
+        """transposed copy [k4, n4] of a stored weight matrix (operand of the data-gradient GEMM), made once per step."""
+        key = id(weight)
+        if key not in self._wt:
+            W = self.W(weight)
+            self._wt[key] = ops.transpose(W.view(1, *W.shape))[0]
+        return self._wt[key]
+
+    def bn(self, x, bn, slope=1.0, res=None):
+        """LeakyReLU_slope(BatchNorm(x) (+ res)) in batch-statistics mode over the rows of x (nn.BatchNorm1d / 2d in train());
+        slope 1 = no activation.  res: a Var added before the activation (residual branches)."""
         C = x.v.shape[1]
         gamma, beta = self.W(bn.weight), self.W(bn.bias)
         c = bn.running_mean.numel()
@@ -116,16 +157,22 @@ class Tape:
         if c != C:
             bn.running_mean.copy_(rm[:c])
             bn.running_var.copy_(rv[:c])
-        y = Var(ops.affine_act(x.v, stat[2], stat[3]))
+        y = Var(ops.affine_act(x.v, stat[2], stat[3], res=None if res is None else res.v, slope=slope))
 
         def bwd():
             if y.g is None:
                 return
-            dg = torch.empty(C, dtype=f32, device=x.v.device)
-            db = torch.empty(C, dtype=f32, device=x.v.device)
-            dx = ops.bn_bwd(y.g, None, 1.0, x.v, stat, dg, db)
-            self._param_vec_grad(bn.weight, dg)
-            self._param_vec_grad(bn.bias, db)
+            dg, fin_g = self.vec_out(bn.weight)
+            db, fin_b = self.vec_out(bn.bias)
+            if res is not None and slope != 1.0:
+                dz = ops.act_bwd(y.g, y.v, slope)                # gradient at the sum: goes to the residual branch and into the BN
+                self.give(res, dz, owned=False)
+                dx = ops.bn_bwd(dz, None, 1.0, x.v, stat, dg, db)
+            else:
+                if res is not None:
+                    self.give(res, y.g)
+                dx = ops.bn_bwd(y.g, None if slope == 1.0 else y.v, slope, x.v, stat, dg, db)
+            fin_g(), fin_b()
             self.give(x, dx, owned=True)
         self.nodes.append(bwd)
         return y
@@ -180,12 +227,12 @@ class Tape:
         def bwd():
             if y.g is None:
                 return
-            dg = torch.empty(64, dtype=f32, device=x.v.device)
-            db = torch.empty(64, dtype=f32, device=x.v.device)
+            dg, accg = self.G(ln.weight)
+            db, accb = self.G(ln.bias)
+            if accg != accb:
+                raise RuntimeError("layernorm: weight and bias of one LayerNorm must be used together")
             buf, acc = self.target(x, *x.v.shape)
-            ops.layernorm64_bwd(y.g, x.v, gamma, eps, dg, db, False, out=buf, accumulate=acc)
-            self._param_vec_grad(ln.weight, dg)
-            self._param_vec_grad(ln.bias, db)
+            ops.layernorm64_bwd(y.g, x.v, gamma, eps, dg, db, accg, out=buf, accumulate=acc)
         self.nodes.append(bwd)
         return y
 
@@ -303,7 +350,9 @@ class Tape:
                 ops.axpy(gw[:cout * cin * 9].view(1, -1), tmp.view(1, -1))
             else:
                 ops.conv3x3_wgrad(xi, dy, gw[:cout * cin * 9])
-            self._param_vec_grad(conv.bias, ops.colsum(y.g, 1, y.g.shape[0]).view(-1))
+            gb, fin = self.vec_out(conv.bias)
+            ops.colsum(y.g, 1, y.g.shape[0], out=gb.view(1, -1))
+            fin()
             w9t, ut = ops.pack_conv3x3(wflat, cout, cin, transpose=True, want_u=self.WINOGRAD)
             self.give(x, ops.conv3x3(dy, w9t, None, cin, 1, 1.0, u=ut).view(-1, cin), owned=True)
         self.nodes.append(bwd)
@@ -324,13 +373,13 @@ class Tape:
             if y.g is None:
                 return
             dw = torch.zeros((n4, 36), dtype=f32, device=cols.device)
-            ops.linear_wgrad_any(y.g, cols, dw, False)
+            gb, accb = self.G(conv.bias)
+            ops.linear_wgrad_any(y.g, cols, dw, False, db=gb, accumulate_db=accb)
             gw, acc = self.G(conv.weight)
             gl = dw.view(n4, 9, 4)[:cout, :, :3].reshape(cout, 3, 3, 3).permute(0, 3, 1, 2).reshape(-1)     # back to [co][c][ky][kx]
             if acc:
                 raise RuntimeError("conv3x3_c3: the stem's convolutions are used once per step")
             gw[:gl.numel()].copy_(gl)                                                                # layout copy into the bucket
-            self._param_vec_grad(conv.bias, ops.colsum(y.g, 1, y.g.shape[0]).view(-1))
             if need_dx:
                 dcols = ops.linear(y.g, wm.t().contiguous())
                 self.give(x4, ops.col2im3(dcols, B, H, W).view(-1, 4), owned=True)

@@ -359,10 +359,13 @@ int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float 
 int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                           int64_t ws_bytes, hipStream_t stream);
-/* nn.Conv1d(k=1) / nn.Linear weight gradient over a row map: dw [n][k] (+)= dy^T x  (n, k <= 128). */
+/* nn.Conv1d(k=1) / nn.Linear weight and bias gradient over a row map: dw [n][k] (+)= dy^T x, db [n] (+)= column sums of dy
+ * (db optional), any n, k: one launch over (row slices) x (n blocks of 128) x (k blocks of 128) + one deterministic
+ * reduction of the slices. */
 int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k);
 int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
-                         int64_t lddw, int accumulate, void* ws, int64_t ws_bytes, hipStream_t stream);
+                         int64_t lddw, int accumulate, float* db, int accumulate_db, void* ws, int64_t ws_bytes,
+                         hipStream_t stream);
 /* nn.Conv2d weight [Cout][Cin][3][3] -> operand layouts of the forward kernels (w9 [9][Co'][Ci'] and the Winograd
  * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx].  bf16_frag
  * (optional) receives the bf16 A fragments of cmr_conv3x3_bf16_nhwc_f32 for cout groups of 32 * bf16_nt. */

@@ -108,7 +108,8 @@ def test_conv3x3_weight_and_data_gradients(ops, B, H, W, cin, cout):
     close(dx2.permute(0, 3, 1, 2), x.grad, 5e-5, "conv dgrad (direct kernel)")
 
 
-@pytest.mark.parametrize("rows,n,k", [(4001, 8, 8), (3000, 64, 8), (5555, 128, 64), (2048, 64, 128), (1000, 64, 64), (9000, 128, 128), (7, 128, 128)])
+@pytest.mark.parametrize("rows,n,k", [(4001, 8, 8), (3000, 64, 8), (5555, 128, 64), (2048, 64, 128), (1000, 64, 64), (9000, 128, 128), (7, 128, 128),
+                                      (640, 1024, 64), (2048, 64, 1024), (640, 64, 4096), (777, 200, 136), (40000, 36, 68)])
 def test_linear_weight_gradient(ops, rows, n, k):
     dy, x = rnd(rows, n, seed=21), rnd(rows, k, seed=22)
     ref = dy.double().t() @ x.double()
@@ -116,8 +117,13 @@ def test_linear_weight_gradient(ops, rows, n, k):
     ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, dw.shape[1], n, k)
     close(dw[:, :k], ref.float(), 2e-5, "linear wgrad")
     assert float(dw[:, k:].min()) == 7.0
-    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, dw.shape[1], n, k, accumulate=True)
+    db = torch.full((n + 4,), 3.0, device=DEV)                        # bias gradient from the same launch
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, dw.shape[1], n, k, accumulate=True, db=db)
     close(dw[:, :k], 2 * ref.float(), 2e-5, "linear wgrad accumulate")
+    close(db[:n], dy.double().sum(0).float(), 2e-5, "bias gradient")
+    assert float(db[n:].min()) == 3.0
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), dw, dw.shape[1], n, k, db=db, accumulate_db=True)
+    close(db[:n], 2 * dy.double().sum(0).float(), 2e-5, "bias gradient accumulate")
     # left part of a wider output, narrower k than the operand (the streamed half of a concatenated input)
     if k >= 64:
         dw2 = torch.zeros((n, k), device=DEV)
