@@ -206,7 +206,7 @@ def geo_train_main(args):
     ranks = Ranks(backend="nccl", device=dev)
     dtype = args.dtype or "f32"
     ops.CONV_BF16 = dtype == "bf16"
-    cfg = KittiConfiguration(device=dev)
+    cfg = KittiConfiguration(device=dev, num_pt=args.num_pt)        # --num-pt 65536 = BASELINE.json configs[4]
     B = cfg.train_batch_size
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
     model = MultiHeadModel(cfg)
@@ -251,6 +251,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
                     help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
+    ap.add_argument("--num-pt", type=int, default=None, help="train-geo: points per cloud (default KittiConfig's 40960; configs[4] = 65536)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
     args = ap.parse_args()
     if args.mode == "train":

@@ -496,6 +496,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Transposed shadow of the matrix parameters of a flat bucket: table row = (src offset, n, k, dst offset, first tile); one
+// workgroup per 32 x 32 tile of one matrix: dst[k][n] = src[n][k].  One launch per optimizer step instead of one per layer.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_slots_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              const int64_t* __restrict__ table, int nslots) {
+  __shared__ float tile[32][33];
+  const int64_t t = blockIdx.x;
+  int lo = 0, hi = nslots - 1;                               // last slot whose first tile <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 5 + 4] <= t) lo = mid; else hi = mid - 1;
+  }
+  const int64_t* e = table + lo * 5;
+  const int n = (int)e[1], k = (int)e[2];
+  const int tk = (k + 31) / 32;
+  const int local = (int)(t - e[4]);
+  const int r0 = (local / tk) * 32, c0 = (local % tk) * 32;
+  const float* a = src + e[0];
+  float* b = dst + e[3];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + 8 * i, c = c0 + tx;
+    tile[ty + 8 * i][tx] = (r < n && c < k) ? a[(int64_t)r * k + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i, r = r0 + tx;
+    if (c < k && r < n) b[(int64_t)c * n + r] = tile[tx][ty + 8 * i];
+  }
+}
+
 inline unsigned ew_grid(int64_t items) {
   int64_t g = (items + 255) / 256;
   if (g > 4096) g = 4096;
@@ -647,5 +681,12 @@ extern "C" int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_
   if (n == 0) return CMR_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, lr, beta1, beta2, eps, weight_decay,
                      bias_correction1, sqrtf(bias_correction2), grad_scale, grad_clip);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_transpose_slots_f32(const float* src, float* dst, const int64_t* table, int nslots, int64_t total_tiles,
+                                       hipStream_t stream) {
+  CMR_REQUIRE(src && dst && table && nslots > 0 && total_tiles > 0 && total_tiles < 0x7fffffff);
+  hipLaunchKernelGGL(transpose_slots_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, src, dst, table, nslots);
   return cmr_launch_status();
 }

@@ -694,8 +694,8 @@ extern "C" int cmr_act_bwd_x_f32(const float* dy, int64_t lddy, const float* x, 
 }
 
 static inline int ln_blocks(int64_t rows) {
-  int64_t nb = (rows + 255) / 256;
-  return (int)(nb > 512 ? 512 : (nb < 1 ? 1 : nb));
+  int64_t nb = (rows + 31) / 32;                 // 16 rows per pass of a workgroup: two passes, so that 640 token rows still fill 20 CUs
+  return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }
 
 extern "C" int64_t cmr_layernorm64_bwd_workspace_bytes(int64_t rows) { return (int64_t)ln_blocks(rows) * 128 * sizeof(float); }

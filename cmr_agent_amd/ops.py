@@ -679,6 +679,12 @@ def adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, 
               float(weight_decay), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), float(grad_clip), _stream())
 
 
+def transpose_slots(src, dst, table, nslots, total_tiles):
+    """dst <- per-slot transposes of the matrix parameters in the flat buffer src (table: FlatBucket.transpose_table)."""
+    _lib.call("cmr_transpose_slots_f32", _p(src), _p(dst), _p(table), int(nslots), int(total_tiles), _stream())
+    return dst
+
+
 def conv3x3_wgrad(x, dy, dw):
     """x [B,H,W,Cin], dy [B,H,W,Cout] (contiguous NHWC) -> dw (flat view of [Cout,Cin,3,3] in the gradient bucket)."""
     B, H, W, cin = x.shape

@@ -85,6 +85,27 @@ class FlatBucket:
                 p.grad = self.slots[name].view(self.grads)
         self._module = module
 
+    def transposed(self):
+        """-> flat buffer holding W^T ([k4][n4], same offsets) of every matrix slot, refreshed from the current parameters by ONE
+        launch (the data-gradient GEMMs read weights transposed)."""
+        from .. import ops
+        if getattr(self, "_tt", None) is None:
+            rows, tiles = [], 0
+            for s in self.slots.values():
+                if len(s.store) == 2:
+                    n, k = s.store
+                    rows.append([s.offset, n, k, s.offset, tiles])
+                    tiles += ((n + 31) // 32) * ((k + 31) // 32)
+            self._tt = (torch.tensor(rows, dtype=torch.int64, device=self.params.device), len(rows), tiles)
+            self._paramsT = torch.zeros_like(self.params)
+        table, n, tiles = self._tt
+        ops.transpose_slots(self.params, self._paramsT, table, n, tiles)
+        return self._paramsT
+
+    def wT(self, param, flatT):
+        s = self.by_id[id(param)]
+        return flatT[s.offset:s.offset + s.size].view(s.store[1], s.store[0])
+
     def check_attached(self):
         """Parameters must still live in the bucket (module.to() / .cuda() after construction would detach them)."""
         lo, hi = self.params.data_ptr(), self.params.data_ptr() + 4 * self.numel

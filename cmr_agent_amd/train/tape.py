@@ -35,7 +35,7 @@ class Tape:
         self.nodes = []
         self.touched = set()            # parameter ids whose gradient slice has been written in this step
         self._consts = {}
-        self._wt = {}
+        self._flatT = None
 
     # ------------------------------------------------------------------------------------------------------------ engine
     def backward(self):
@@ -134,11 +134,9 @@ class Tape:
 
     def WT(self, weight):
         """transposed copy [k4, n4] of a stored weight matrix (operand of the data-gradient GEMM), made once per step."""
-        key = id(weight)
-        if key not in self._wt:
-            W = self.W(weight)
-            self._wt[key] = ops.transpose(W.view(1, *W.shape))[0]
-        return self._wt[key]
+        if self._flatT is None:
+            self._flatT = self.bucket.transposed()
+        return self.bucket.wT(weight, self._flatT)
 
     def bn(self, x, bn, slope=1.0, res=None):
         """LeakyReLU_slope(BatchNorm(x) (+ res)) in batch-statistics mode over the rows of x (nn.BatchNorm1d / 2d in train());

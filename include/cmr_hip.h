@@ -354,6 +354,10 @@ int cmr_agent_loss_f32(const float* r_logits, int64_t ldr, const float* t_logits
 int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, float grad_clip,
                  hipStream_t stream);
+/* Transposed shadow of the matrix parameters of a flat bucket (operands of the data-gradient GEMMs): table [nslots][5] int64 =
+ * (src offset, n, k, dst offset, first tile index), tiles of 32 x 32; dst[k][n] = src[n][k] for every slot, one launch. */
+int cmr_transpose_slots_f32(const float* src, float* dst, const int64_t* table, int nslots, int64_t total_tiles,
+                            hipStream_t stream);
 /* nn.Conv2d(3x3, stride 1, pad 1) weight gradient on the matrix cores: dw [Cout][Cin][3][3] = sum over the minibatch
  * pixels of dy (x) shifted x (NHWC maps, W >= 2, Cin in {32,64,128}, Cout % 32 == 0). */
 int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
