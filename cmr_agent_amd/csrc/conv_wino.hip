@@ -354,6 +354,340 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(cons
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised persistent variant (64 couts per tile, Cin >= 64, maps with many tiles per CU).
+//
+// In the kernel above a workgroup is serial -- halo + U prologue, K loop, output transform + stores -- and the matrix pipe
+// is only busy in the middle part; two co-resident workgroups overlap by chance (measured duty 52 %).  Here ONE workgroup
+// of 8 waves owns a CU and walks over its tiles: waves 0-3 do nothing but [ds_read + input transform + MFMA] and hand their
+// accumulators over through LDS (stage 1 of the output transform); waves 4-7 feed them (LDS-DMA of the next halo chunk,
+// issued one chunk ahead) and finish the PREVIOUS tile (stage 2, bias / residual / activation / table, global stores)
+// while the MFMA waves are already multiplying the next one.  One s_barrier per 32-channel chunk, executed by all 8 waves,
+// is the only synchronisation:
+//   interval (tile k, chunk c):  MFMA waves: GEMM(k, c) from halo[g & 1]; after the last chunk: T(k) -> LDS
+//                                helpers:    DMA of the next chunk in sequence -> halo[(g + 1) & 1];
+//                                            c == 0: T(k - 1) -> registers (stage 2);  c == 1: epilogue math + stores of tile k - 1
+// T(k) is written after the LAST chunk's GEMM and T(k - 1) is read in the FIRST chunk's interval, so with >= 2 chunks the
+// two never meet.  Inside a chunk the MFMA waves prefetch the next k-group's patch rows and U fragments under the current
+// k-group's MFMAs (U straight into the registers the just-issued MFMAs have consumed).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int WS_T_OFF = 2 * WT_HALO_FLOATS;
+constexpr int WS_SMEM_FLOATS = WS_T_OFF + 2 * 8192;
+
+__device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs a, const int tiles_x, const int tiles_y, const int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nco = a.Cout / 64;
+  const int nchunk = a.Cin / WT_KC;
+  const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+
+  struct Tile { int b, co0, oy0, ox0; };
+  auto decode = [&](int id) {                                      // same XCD-banded order as above, over ntiles virtual workgroups
+    id = id < ntiles ? id : ntiles - 1;
+    const int per = ntiles >> 3, rem = ntiles & 7, xcd = id & 7;
+    int t = xcd * per + (xcd < rem ? xcd : rem) + (id >> 3);
+    Tile r;
+    r.co0 = (t % nco) * 64; t /= nco;
+    r.ox0 = (t % tiles_x) * WT_TW; t /= tiles_x;
+    r.oy0 = (t % tiles_y) * WT_TH;
+    r.b = t / tiles_y;
+    return r;
+  };
+
+  if (wave < 4) {
+    // =========================================== MFMA waves ===========================================
+    const int h = lane >> 5, l31 = lane & 31;
+    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    const int ty = l31 >> 3, tx = l31 & 7;
+    int pa[4], pb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      pa[c] = wt_lds((2 * ty + ra) * WT_PITCH + (c & 1) * (WT_PITCH / 2) + tx + (c >> 1), h);
+      pb[c] = wt_lds((2 * ty + rb) * WT_PITCH + (c & 1) * (WT_PITCH / 2) + tx + (c >> 1), h);
+    }
+    // U fragments through a buffer resource: ONE per-lane VGPR offset (lane * 16 bytes), everything else is a scalar offset --
+    // eight 64-bit per-lane pointers (16 VGPRs) would not fit next to 128 accumulators + the software pipeline
+    const __amdgpu_buffer_rsrc_t ursrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.u, 0, 16 * a.Cout * a.Cin * 4, 0x00020000);
+    const int lane_off = lane * 16;
+    const int utile = (a.Cin / 8) * 1024;             // bytes between cout tiles
+    const int upos = a.Cout * a.Cin * 4;              // bytes between positions
+    const int uwave = 4 * wave * upos;                // position (wave, 0)
+    auto load_u = [&](int soff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, lane_off, soff, 0)); };
+    int ub = uwave + (decode(blockIdx.x).co0 / 32) * utile;
+    f32x4 wc[4][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wc[j][n] = load_u(ub + j * upos + n * utile);
+    int g = 0;
+    for (int k = 0; k <= nk; ++k) {
+      const bool live = k < nk;
+      const int ubn = uwave + (decode((int)blockIdx.x + (k + 1 < nk ? k + 1 : k) * (int)gridDim.x).co0 / 32) * utile;   // next tile's U (or this one's again)
+      f32x16 acc[4][NT];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+      for (int chunk = 0; chunk < nchunk; ++chunk, ++g) {
+        ws_barrier_lds();                               // halo[g & 1] landed (helpers waited for their DMA before arriving)
+        if (!live) continue;
+        const float* halo = smem + (g & 1) * WT_HALO_FLOATS;
+        const int uc = ub + chunk * (WT_KC / 8) * 1024;
+        const int un = chunk + 1 < nchunk ? ub + (chunk + 1) * (WT_KC / 8) * 1024 : ubn;
+        f32x4 vf[4];
+        {                                               // k-group 0 of the chunk: nothing to hide behind
+          f32x4 tc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x4 da = *reinterpret_cast<const f32x4*>(&halo[pa[c]]);
+            const f32x4 db = *reinterpret_cast<const f32x4*>(&halo[pb[c]]);
+            tc[c] = da + sgn * db;
+          }
+          vf[0] = tc[0] - tc[2];
+          vf[1] = tc[1] + tc[2];
+          vf[2] = tc[2] - tc[1];
+          vf[3] = tc[1] - tc[3];
+        }
+#pragma unroll
+        for (int kg = 0; kg < WT_KC / 8; ++kg) {
+          const int up = kg + 1 < WT_KC / 8 ? uc + (kg + 1) * 1024 : un;
+          const bool more = kg + 1 < WT_KC / 8;         // compile-time after unrolling
+          const int kx = (kg + 1) * 8;
+          // next k-group's fragments, built up in place: vn[0] = t0 - t2, vn[1] = t1 + t2, vn[2] = t2 - t1, vn[3] = t1 - t3
+          f32x4 da[2], db[2], vn[4], t1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int n = 0; n < NT; ++n) acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], acc[j][n]);
+            // the 8 MFMAs above have read wc[j][*]: refill them with the next k-group's fragments (24 MFMAs = 1 536 cycles of lead)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) wc[j][n] = load_u(up + j * upos + n * utile);
+            if (more) {
+              if (j == 0) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                  da[c] = *reinterpret_cast<const f32x4*>(&halo[pa[c] ^ kx]);
+                  db[c] = *reinterpret_cast<const f32x4*>(&halo[pb[c] ^ kx]);
+                }
+              } else if (j == 1) {
+                vn[0] = da[0] + sgn * db[0];
+                t1 = da[1] + sgn * db[1];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                  da[c] = *reinterpret_cast<const f32x4*>(&halo[pa[c + 2] ^ kx]);
+                  db[c] = *reinterpret_cast<const f32x4*>(&halo[pb[c + 2] ^ kx]);
+                }
+              } else if (j == 2) {
+                const f32x4 t2 = da[0] + sgn * db[0];
+                vn[0] -= t2;
+                vn[1] = t1 + t2;
+                vn[2] = t2 - t1;
+                vn[3] = t1 - (da[1] + sgn * db[1]);
+              }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vf[j] = vn[j];
+          }
+        }
+      }
+      if (live) {
+        // stage 1 of the output transform: T[w][b] = sum_j M[w][j] A[j][b] -> LDS (read by the helpers after the next barrier)
+        float* Ts = smem + WS_T_OFF;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            f32x4 t0, t1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int r = 4 * rq + e;
+              t0[e] = (acc[0][n][r] + acc[1][n][r]) + acc[2][n][r];
+              t1[e] = (acc[1][n][r] - acc[2][n][r]) - acc[3][n][r];
+            }
+            *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 0) * NT + n) * 4 + rq) * 64 + lane) * 4]) = t0;
+            *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 1) * NT + n) * 4 + rq) * 64 + lane) * 4]) = t1;
+          }
+      }
+      ub = ubn;
+    }
+  } else {
+    // ============================================ helpers ============================================
+    const int hw = wave - 4;
+    const int Ho = a.H, Wo = a.W;
+    auto dma_halo = [&](const Tile& t, int chunk, float* halo) {
+      const float* xc = a.x + (int64_t)t.b * a.H * a.W * a.Cin + chunk * WT_KC;
+#pragma unroll
+      for (int i = 0; i < WT_DMA_PER_WAVE; ++i) {
+        int kb = hw + 4 * i;
+        kb = kb < WT_DMA ? kb : WT_DMA - 1;
+        const int slot = 8 * kb + (lane >> 3);
+        const int py = slot / WT_PITCH, r = slot % WT_PITCH;
+        const int px = r < WT_PITCH / 2 ? 2 * r : 2 * r - (WT_PITCH - 1);
+        const int iy = t.oy0 - 1 + py, ix = t.ox0 - 1 + px;
+        const bool inb = px < WT_HC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+        const float* src = inb ? xc + (unsigned)((iy * a.W + ix) * a.Cin + ((lane & 7) ^ wt_key(slot)) * 4) : wt_zero16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(halo + kb * 256), 16, 0, 0);
+      }
+    };
+    const int q = hw;
+    const int tyf = (lane & 31) >> 3, txf = lane & 7;
+    Tile prev = decode(blockIdx.x), cur = prev;
+    dma_halo(cur, 0, smem);                              // chunk (0, 0); completed by the wait in front of the first barrier
+    f32x4 yv[NT][2][2], bs[NT], rs[NT][2][2];
+    int g = 0;
+    for (int k = 0; k <= nk; ++k) {
+      const Tile nxt = decode((int)blockIdx.x + (k + 1) * (int)gridDim.x);
+      for (int chunk = 0; chunk < nchunk; ++chunk, ++g) {
+        __syncthreads();                                 // s_waitcnt vmcnt(0): this wave's DMA (and stores) are done
+        // feed: the next chunk in sequence goes into the buffer the MFMA waves have just left
+        if (chunk + 1 < nchunk) {
+          if (k < nk) dma_halo(cur, chunk + 1, smem + ((g + 1) & 1) * WT_HALO_FLOATS);
+        } else if (k + 1 < nk) {
+          dma_halo(nxt, 0, smem + ((g + 1) & 1) * WT_HALO_FLOATS);
+        }
+        if (k == 0) continue;
+        const int cq = prev.co0 + 8 * q + 4 * (lane >> 5);
+        if (chunk == 0) {
+          // stage 2: wave q finishes the 4 outputs (a, b) of register quad q of both cout tiles
+          const float* Ts = smem + WS_T_OFF;
+          const float* bp = a.bias ? a.bias + cq : wt_zero16;
+          const int bst = a.bias ? 32 : 0;
+#pragma unroll
+          for (int n = 0; n < NT; ++n) bs[n] = *reinterpret_cast<const f32x4*>(bp + bst * n);
+          const float* rp = a.res ? a.res + (int64_t)prev.b * Ho * Wo * a.Cout + cq : wt_zero16;
+          const int rst = a.res ? a.Cout : 0, rn = a.res ? 32 : 0;
+          if (a.pool == 1) {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) {
+                int oy = prev.oy0 + 2 * tyf + aa, ox = prev.ox0 + 2 * txf + bb;
+                oy = oy < Ho ? oy : Ho - 1;
+                ox = ox < Wo ? ox : Wo - 1;
+                const int pix = oy * Wo + ox;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) rs[n][aa][bb] = *reinterpret_cast<const f32x4*>(rp + (int64_t)pix * rst + rn * n);
+              }
+          }
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+              f32x4 tw[4];
+#pragma unroll
+              for (int w = 0; w < 4; ++w) tw[w] = *reinterpret_cast<const f32x4*>(&Ts[((((w * 2 + bb) * NT + n) * 4 + q) * 64 + lane) * 4]);
+              yv[n][0][bb] = (tw[0] + tw[1]) + tw[2];
+              yv[n][1][bb] = (tw[1] - tw[2]) - tw[3];
+            }
+        } else if (chunk == 1) {
+          if (a.pool == 2) {
+            const int py = (prev.oy0 >> 1) + tyf, px = (prev.ox0 >> 1) + txf;
+            const int hp2 = Ho >> 1, wp2 = Wo >> 1;
+            f32x4 sv[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+              f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const float v = yv[n][aa][bb][e] + bs[n][e];
+                    s[e] += v > 0.f ? v : v * a.slope;
+                  }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s[e] *= 0.25f;
+              sv[n] = s;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) cmr_pin(sv[n]);
+            if (py < hp2 && px < wp2) {
+              float* yp = a.y + (((int64_t)prev.b * hp2 + py) * wp2 + px) * a.Cout + cq;
+#pragma unroll
+              for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(yp + 32 * n) = sv[n];
+            }
+          } else {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                  f32x4 v = yv[n][aa][bb] + bs[n];
+                  v += rs[n][aa][bb];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+                  yv[n][aa][bb] = v;
+                }
+            if (a.post) {
+#pragma unroll
+              for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                  int oy = prev.oy0 + 2 * tyf + aa, ox = prev.ox0 + 2 * txf + bb;
+                  oy = oy < Ho ? oy : Ho - 1;
+                  ox = ox < Wo ? ox : Wo - 1;
+                  const float* pp = a.post + (int64_t)(oy * Wo + ox) * a.Cout + cq;
+#pragma unroll
+                  for (int n = 0; n < NT; ++n) yv[n][aa][bb] += *reinterpret_cast<const f32x4*>(pp + 32 * n);
+                }
+            }
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) cmr_pin(yv[n][aa][bb]);
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+              for (int bb = 0; bb < 2; ++bb) {
+                const int oy = prev.oy0 + 2 * tyf + aa, ox = prev.ox0 + 2 * txf + bb;
+                if (oy < Ho && ox < Wo) {
+                  float* yp = a.y + (((int64_t)prev.b * Ho + oy) * Wo + ox) * a.Cout + cq;
+#pragma unroll
+                  for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(yp + 32 * n) = yv[n][aa][bb];
+                }
+              }
+          }
+        }
+      }
+      prev = cur;
+      cur = nxt;
+    }
+  }
+}
+
+int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
+  constexpr int smem = WS_SMEM_FLOATS * (int)sizeof(float);
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  cus -= cus % 8;                                          // a multiple of the XCD count keeps a workgroup's tiles on one XCD's band
+  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  hipLaunchKernelGGL(conv3x3_wino_ws_kernel, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
+  return cmr_launch_status();
+}
+
 template <int NT>
 int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
   constexpr int smem = wt_smem_floats<NT>() * (int)sizeof(float);
@@ -364,6 +698,13 @@ int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hip
 }
 
 }  // namespace
+
+static int CMR_WINO_WS = 1;      // wave-specialised persistent kernel for large maps (cmr_set_wino_variant: A/B measurements)
+extern "C" int cmr_set_wino_variant(int wave_specialised) {
+  const int old = CMR_WINO_WS;
+  CMR_WINO_WS = wave_specialised;
+  return old;
+}
 
 extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                                          const float* res, const float* post, float* y, int Cout, float slope, int pool,
@@ -378,6 +719,7 @@ extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, in
   // take 32-cout workgroups, twice as many and three per CU
   const int64_t ntiles64 = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
   CMR_REQUIRE(2 * ntiles64 < 0x7fffffff);
+  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 2048) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, stream);
   if (ntiles64 >= 512) return launch_wino<2>(a, tiles_x, tiles_y, ntiles64, stream);
   return launch_wino<1>(a, tiles_x, tiles_y, 2 * ntiles64, stream);
 }

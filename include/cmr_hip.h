@@ -79,6 +79,9 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
 int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,
                               hipStream_t stream);
+/* Process-wide switch between the two Winograd kernels for maps of >= 2048 tiles (1 = wave-specialised persistent kernel,
+ * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
+int cmr_set_wino_variant(int wave_specialised);
 
 /* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.
  * ImageResNet.py:50 with :9-23. */

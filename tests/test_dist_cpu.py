@@ -123,3 +123,59 @@ def test_data_parallel_update_equals_single_rank_on_the_concatenated_batch():
     assert n_bad <= 2e-3 * n_all, (n_bad, n_all)
     moved = max(float((torch.from_numpy(sd_a[k]).double() - sd0[k].double()).abs().max()) for k in single)
     assert moved > 1e-3                                           # and the update did move the weights
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# geometric-model bucket (Train_Geo.py under data parallelism): aliased / frozen parameters, same ONE all-reduce
+# ----------------------------------------------------------------------------------------------------------------------
+def _geo_bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import cases as C
+    from cmr_agent_amd.models import MultiHeadModel
+    from cmr_agent_amd.train.flatbucket import FlatBucket
+    from cmr_agent_amd.utils.dist import Ranks
+    torch.set_num_threads(2)
+    r = Ranks(backend="gloo", device=torch.device("cpu"))
+    torch.manual_seed(11)                                         # same initial model on both ranks
+    model = MultiHeadModel(C.e2e_config("e2e_small"))
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    bucket = FlatBucket(model)
+    after = model.state_dict()
+    same = all(torch.equal(before[k], after[k]) for k in before)              # re-pointing the parameters changed no value
+    g = torch.Generator().manual_seed(100 + rank)
+    for name, view in bucket.logical_grads().items():
+        view.copy_(torch.rand(view.shape, generator=g) - 0.5)                  # rank-specific "gradients" in the logical views
+    mine = bucket.grads.clone()
+    n = bucket.all_reduce(r.dist)
+    named = dict(model.named_parameters(remove_duplicate=False))
+    alias = "encoder_decoder.encoder.img_transformer.embeddings."
+    tied = named[alias + "embedding_layers.1.weight"] is named[alias + "patch_embeddings.weight"]
+    frozen_out = id(named[alias + "position_embeddings"]) not in bucket.by_id
+    pad_zero = True
+    for s in bucket.slots.values():                                # padding of the stored matrices never carries a gradient
+        st = s.stored(bucket.grads)
+        if len(s.store) == 2 and (s.store[0] != s.shape[0] or s.store[1] != s.shape[1]):
+            pad_zero = pad_zero and float(st[s.shape[0]:].abs().sum()) == 0.0 and float(st[:, s.shape[1]:].abs().sum()) == 0.0
+    out[rank] = (n, bucket.numel, mine.numpy(), bucket.grads.clone().numpy(), same, tied, frozen_out, pad_zero,
+                 len(bucket.slots), sum(1 for p in model.parameters() if p.requires_grad))
+    r.close()
+
+
+def test_geo_model_bucket_all_reduce():
+    """FlatBucket over MultiHeadModel: the parameters registered under two names are held once, the frozen position table stays
+    out, values survive the re-pointing, and one all-reduce leaves both ranks with the identical SUM of the two gradient
+    buckets (the 1 / world factor is applied by the Adam launch)."""
+    world, port = 2, _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_geo_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    a, b = res[0], res[1]
+    assert a[0] == b[0] == 2 and a[1] == b[1]
+    assert (a[3] == b[3]).all()
+    assert (a[3] == a[2] + b[2]).all()
+    for r in (a, b):
+        assert r[4] and r[5] and r[6] and r[7]
+        assert r[8] == r[9]                                        # one slot per distinct trainable Parameter
