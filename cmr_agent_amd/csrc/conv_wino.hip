@@ -372,10 +372,12 @@ __global__ __launch_bounds__(256, NT == 1 ? 3 : 2) void conv3x3_wino_kernel(cons
 // k-group's MFMAs (U straight into the registers the just-issued MFMAs have consumed).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int WS_T_OFF = 2 * WT_HALO_FLOATS;
-constexpr int WS_SMEM_FLOATS = WS_T_OFF + 2 * 8192;
+constexpr int WS_T_ROW = 68;                          // floats per (position pair, Winograd tile) row of T: 64 couts + 4 of padding (bank spread)
+constexpr int WS_SMEM_FLOATS = WS_T_OFF + 8 * 32 * WS_T_ROW;
 
 __device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+template <int dbg>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs a, const int tiles_x, const int tiles_y, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = 2;
@@ -468,11 +470,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int n = 0; n < NT; ++n) acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], acc[j][n]);
+              for (int n = 0; n < NT; ++n) if (!(dbg & 32)) acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], acc[j][n]);
             // the 8 MFMAs above have read wc[j][*]: refill them with the next k-group's fragments (24 MFMAs = 1 536 cycles of lead)
+            if (!(dbg & 8)) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n) wc[j][n] = load_u(up + j * upos + n * utile);
-            if (more) {
+              for (int n = 0; n < NT; ++n) wc[j][n] = load_u(up + j * upos + n * utile);
+            }
+            if (more && !(dbg & 16)) {
               if (j == 0) {
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -503,9 +507,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
           }
         }
       }
-      if (live) {
-        // stage 1 of the output transform: T[w][b] = sum_j M[w][j] A[j][b] -> LDS (read by the helpers after the next barrier)
+      if (live && !(dbg & 4)) {
+        // stage 1 of the output transform: T[w][b] = sum_j M[w][j] A[j][b] -> LDS, pixel-major: row (w, b, tile) holds the 64 couts, so
+        // that the helpers can finish WHOLE pixels (16 lanes x 16 bytes = the 256 contiguous bytes of a pixel's cout group)
         float* Ts = smem + WS_T_OFF;
+        const int h = lane >> 5, l31 = lane & 31;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -517,8 +523,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
               t0[e] = (acc[0][n][r] + acc[1][n][r]) + acc[2][n][r];
               t1[e] = (acc[1][n][r] - acc[2][n][r]) - acc[3][n][r];
             }
-            *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 0) * NT + n) * 4 + rq) * 64 + lane) * 4]) = t0;
-            *reinterpret_cast<f32x4*>(&Ts[((((wave * 2 + 1) * NT + n) * 4 + rq) * 64 + lane) * 4]) = t1;
+            *reinterpret_cast<f32x4*>(&Ts[((wave * 2 + 0) * 32 + l31) * WS_T_ROW + n * 32 + 8 * rq + 4 * h]) = t0;
+            *reinterpret_cast<f32x4*>(&Ts[((wave * 2 + 1) * 32 + l31) * WS_T_ROW + n * 32 + 8 * rq + 4 * h]) = t1;
           }
       }
       ub = ubn;
@@ -543,127 +549,140 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
                                          (__attribute__((address_space(3))) void*)(halo + kb * 256), 16, 0, 0);
       }
     };
-    const int q = hw;
-    const int tyf = (lane & 31) >> 3, txf = lane & 7;
+    // epilogue items of this lane: channel quad cq4 (couts 4 cq4 .. 4 cq4 + 3 of the tile's 64) of Winograd tiles t0 and t0 + 16;
+    // 16 consecutive lanes = one whole pixel's cout group (256 contiguous bytes in y / res / post)
+    const int hidx = hw * 64 + lane;
+    const int cq4 = hidx & 15, t0 = hidx >> 4;
     Tile prev = decode(blockIdx.x), cur = prev;
     dma_halo(cur, 0, smem);                              // chunk (0, 0); completed by the wait in front of the first barrier
-    f32x4 yv[NT][2][2], bs[NT], rs[NT][2][2];
-    int g = 0;
+    f32x4 yv[2][2][2];                                   // [item][a][b]
+    int g = 0, pend = 0;
     for (int k = 0; k <= nk; ++k) {
       const Tile nxt = decode((int)blockIdx.x + (k + 1) * (int)gridDim.x);
       for (int chunk = 0; chunk < nchunk; ++chunk, ++g) {
-        __syncthreads();                                 // s_waitcnt vmcnt(0): this wave's DMA (and stores) are done
-        // feed: the next chunk in sequence goes into the buffer the MFMA waves have just left
+        // This wave's DMA of the previous interval must have landed before the barrier.  vmcnt counts loads, LDS-DMA and stores
+        // together in issue order, and the stores of interval 1 are issued BEHIND that interval's DMA: on a tile that lies fully
+        // inside the map their number is known (8, or 2 pooled), so the wait leaves exactly them in flight instead of tying
+        // the barrier to the completion of 32 KB of stores; any other interval drains everything.
+        if (pend == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pend = 0;
+        ws_barrier_lds();
+        // feed: the next chunk in sequence goes into the buffer the MFMA waves have just left (first thing in the interval:
+        // it has to land before the next barrier)
         if (chunk + 1 < nchunk) {
           if (k < nk) dma_halo(cur, chunk + 1, smem + ((g + 1) & 1) * WT_HALO_FLOATS);
         } else if (k + 1 < nk) {
           dma_halo(nxt, 0, smem + ((g + 1) & 1) * WT_HALO_FLOATS);
         }
-        if (k == 0) continue;
-        const int cq = prev.co0 + 8 * q + 4 * (lane >> 5);
+        if (k == 0 || (dbg & 2)) continue;
+        const int cq = prev.co0 + 4 * cq4;
         if (chunk == 0) {
-          // stage 2: wave q finishes the 4 outputs (a, b) of register quad q of both cout tiles
+          // interval 0 of the next tile: everything that computes.  Residual / bias loads first (in flight during the LDS
+          // work), stage 2 from T, then bias + residual + LeakyReLU (+ table); the finished pixels stay in registers.
           const float* Ts = smem + WS_T_OFF;
-          const float* bp = a.bias ? a.bias + cq : wt_zero16;
-          const int bst = a.bias ? 32 : 0;
-#pragma unroll
-          for (int n = 0; n < NT; ++n) bs[n] = *reinterpret_cast<const f32x4*>(bp + bst * n);
+          const f32x4 bsv = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq : wt_zero16);
+          f32x4 rs[2][2][2];
           const float* rp = a.res ? a.res + (int64_t)prev.b * Ho * Wo * a.Cout + cq : wt_zero16;
-          const int rst = a.res ? a.Cout : 0, rn = a.res ? 32 : 0;
+          const int rst = a.res ? a.Cout : 0;
           if (a.pool == 1) {
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-              for (int bb = 0; bb < 2; ++bb) {
-                int oy = prev.oy0 + 2 * tyf + aa, ox = prev.ox0 + 2 * txf + bb;
-                oy = oy < Ho ? oy : Ho - 1;
-                ox = ox < Wo ? ox : Wo - 1;
-                const int pix = oy * Wo + ox;
+              for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) rs[n][aa][bb] = *reinterpret_cast<const f32x4*>(rp + (int64_t)pix * rst + rn * n);
-              }
+                for (int bb = 0; bb < 2; ++bb) {
+                  const int t = t0 + 16 * ii;
+                  int oy = prev.oy0 + 2 * (t >> 3) + aa, ox = prev.ox0 + 2 * (t & 7) + bb;
+                  oy = oy < Ho ? oy : Ho - 1;
+                  ox = ox < Wo ? ox : Wo - 1;
+                  rs[ii][aa][bb] = *reinterpret_cast<const f32x4*>(rp + (int64_t)(oy * Wo + ox) * rst);
+                }
           }
 #pragma unroll
-          for (int n = 0; n < NT; ++n)
+          for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
             for (int bb = 0; bb < 2; ++bb) {
               f32x4 tw[4];
 #pragma unroll
-              for (int w = 0; w < 4; ++w) tw[w] = *reinterpret_cast<const f32x4*>(&Ts[((((w * 2 + bb) * NT + n) * 4 + q) * 64 + lane) * 4]);
-              yv[n][0][bb] = (tw[0] + tw[1]) + tw[2];
-              yv[n][1][bb] = (tw[1] - tw[2]) - tw[3];
+              for (int w = 0; w < 4; ++w)
+                tw[w] = *reinterpret_cast<const f32x4*>(&Ts[((w * 2 + bb) * 32 + t0 + 16 * ii) * WS_T_ROW + 4 * cq4]);
+              yv[ii][0][bb] = (tw[0] + tw[1]) + tw[2];
+              yv[ii][1][bb] = (tw[1] - tw[2]) - tw[3];
             }
-        } else if (chunk == 1) {
           if (a.pool == 2) {
-            const int py = (prev.oy0 >> 1) + tyf, px = (prev.ox0 >> 1) + txf;
-            const int hp2 = Ho >> 1, wp2 = Wo >> 1;
-            f32x4 sv[NT];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-              f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int ii = 0; ii < 2; ++ii) {
+              f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
               for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
-                    const float v = yv[n][aa][bb][e] + bs[n][e];
-                    s[e] += v > 0.f ? v : v * a.slope;
+                    const float v = yv[ii][aa][bb][e] + bsv[e];
+                    sacc[e] += v > 0.f ? v : v * a.slope;
                   }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) s[e] *= 0.25f;
-              sv[n] = s;
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) cmr_pin(sv[n]);
-            if (py < hp2 && px < wp2) {
-              float* yp = a.y + (((int64_t)prev.b * hp2 + py) * wp2 + px) * a.Cout + cq;
-#pragma unroll
-              for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(yp + 32 * n) = sv[n];
+              for (int e = 0; e < 4; ++e) sacc[e] *= 0.25f;
+              yv[ii][0][0] = sacc;
             }
           } else {
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-              for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                  f32x4 v = yv[n][aa][bb] + bs[n];
-                  v += rs[n][aa][bb];
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
-                  yv[n][aa][bb] = v;
-                }
-            if (a.post) {
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
               for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
-                  int oy = prev.oy0 + 2 * tyf + aa, ox = prev.ox0 + 2 * txf + bb;
-                  oy = oy < Ho ? oy : Ho - 1;
-                  ox = ox < Wo ? ox : Wo - 1;
-                  const float* pp = a.post + (int64_t)(oy * Wo + ox) * a.Cout + cq;
+                  f32x4 v = yv[ii][aa][bb] + bsv;
+                  v += rs[ii][aa][bb];
 #pragma unroll
-                  for (int n = 0; n < NT; ++n) yv[n][aa][bb] += *reinterpret_cast<const f32x4*>(pp + 32 * n);
+                  for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+                  yv[ii][aa][bb] = v;
                 }
+            if (a.post) {
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                  for (int bb = 0; bb < 2; ++bb) {
+                    const int t = t0 + 16 * ii;
+                    int oy = prev.oy0 + 2 * (t >> 3) + aa, ox = prev.ox0 + 2 * (t & 7) + bb;
+                    oy = oy < Ho ? oy : Ho - 1;
+                    ox = ox < Wo ? ox : Wo - 1;
+                    yv[ii][aa][bb] += *reinterpret_cast<const f32x4*>(a.post + (int64_t)(oy * Wo + ox) * a.Cout + cq);
+                  }
             }
+          }
+        } else if (chunk == 1) {
+          // interval 1: nothing but the stores, issued right behind the DMA
+          if (dbg & 1) continue;
+          __builtin_amdgcn_sched_barrier(0);
+          const bool full = prev.oy0 + WT_TH <= Ho && prev.ox0 + WT_TW <= Wo;
+          pend = full ? (a.pool == 2 ? 2 : 8) : 0;
+          if (a.pool == 2) {
+            const int hp2 = Ho >> 1, wp2 = Wo >> 1;
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
+            for (int ii = 0; ii < 2; ++ii) {
+              const int t = t0 + 16 * ii;
+              const int py = (prev.oy0 >> 1) + (t >> 3), px = (prev.ox0 >> 1) + (t & 7);
+              if (py < hp2 && px < wp2)
+                __builtin_nontemporal_store(yv[ii][0][0], reinterpret_cast<f32x4*>(a.y + (((int64_t)prev.b * hp2 + py) * wp2 + px) * a.Cout + cq));
+            }
+          } else {
 #pragma unroll
-              for (int bb = 0; bb < 2; ++bb)
+            for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                for (int n = 0; n < NT; ++n) cmr_pin(yv[n][aa][bb]);
+              for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-              for (int bb = 0; bb < 2; ++bb) {
-                const int oy = prev.oy0 + 2 * tyf + aa, ox = prev.ox0 + 2 * txf + bb;
-                if (oy < Ho && ox < Wo) {
-                  float* yp = a.y + (((int64_t)prev.b * Ho + oy) * Wo + ox) * a.Cout + cq;
-#pragma unroll
-                  for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(yp + 32 * n) = yv[n][aa][bb];
+                for (int bb = 0; bb < 2; ++bb) {
+                  const int t = t0 + 16 * ii;
+                  const int oy = prev.oy0 + 2 * (t >> 3) + aa, ox = prev.ox0 + 2 * (t & 7) + bb;
+                  if (oy < Ho && ox < Wo)
+                    __builtin_nontemporal_store(yv[ii][aa][bb], reinterpret_cast<f32x4*>(a.y + (((int64_t)prev.b * Ho + oy) * Wo + ox) * a.Cout + cq));
                 }
-              }
           }
         }
       }
@@ -673,10 +692,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
   }
 }
 
-int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
+template <int DBG>
+int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
   constexpr int smem = WS_SMEM_FLOATS * (int)sizeof(float);
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel<DBG>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -684,8 +704,13 @@ int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, 
   }
   cus -= cus % 8;                                          // a multiple of the XCD count keeps a workgroup's tiles on one XCD's band
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
-  hipLaunchKernelGGL(conv3x3_wino_ws_kernel, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
+  hipLaunchKernelGGL(conv3x3_wino_ws_kernel<DBG>, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
   return cmr_launch_status();
+}
+int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
+  // DBG bits (compile-time ablations used while tuning: 1 no stores, 2 no epilogue, 4 no T hand-over, 8 no U loads, 16 no LDS
+  // prefetch, 32 no MFMAs) are not instantiated in the shipped library
+  return launch_wino_ws_t<0>(a, tiles_x, tiles_y, ntiles, stream);
 }
 
 template <int NT>
@@ -702,7 +727,7 @@ int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hip
 static int CMR_WINO_WS = 1;      // wave-specialised persistent kernel for large maps (cmr_set_wino_variant: A/B measurements)
 extern "C" int cmr_set_wino_variant(int wave_specialised) {
   const int old = CMR_WINO_WS;
-  CMR_WINO_WS = wave_specialised;
+  CMR_WINO_WS = wave_specialised & 1;
   return old;
 }
 

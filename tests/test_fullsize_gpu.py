@@ -126,6 +126,46 @@ def test_direct_and_winograd_convolutions_agree_at_full_size():
     assert float((lhs - rhs).abs().max()) < 5e-5 * float(rhs.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,res,post,pool", [
+    (8, 176, 608, 64, 64, True, False, 1),      # the second-level shape of configs[1]: 6 688 tiles, 26 per workgroup
+    (8, 88, 304, 128, 128, True, False, 1),     # the agent's first-level convolution: four 32-channel chunks, two cout groups
+    (3, 301, 407, 64, 128, False, True, 1),     # ragged right / bottom tiles (301 = 37 * 8 + 5, 407 = 25 * 16 + 7) + position table
+    (4, 352, 608, 64, 64, False, False, 2),     # fused 2x2 average pool
+    (6, 150, 330, 256, 64, True, False, 1),     # eight chunks, one cout group, ragged tiles
+])
+def test_wave_specialised_winograd_kernel_equals_the_four_wave_kernel(B, H, W, cin, cout, res, post, pool):
+    """Maps of >= 2 048 tiles are served by the persistent wave-specialised kernel (4 MFMA waves + 4 feeder / epilogue waves per
+    CU).  Same arithmetic in the same order as the 4-wave workgroups: the results must be BIT-IDENTICAL, and both agree with
+    the direct kernel within the Winograd rounding."""
+    import math
+    from cmr_agent_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H + cin)
+    x = (torch.rand(B, H, W, cin, generator=g) - 0.5).to(DEV)
+    w9 = ((torch.rand(9, cout, cin, generator=g) - 0.5) / math.sqrt(cin)).to(DEV)
+    wt = w9.view(3, 3, cout, cin).permute(2, 3, 0, 1).contiguous()
+    _, u = ops.pack_conv3x3(wt.view(-1), cout, cin)
+    b = torch.rand(cout, generator=g).to(DEV)
+    r = (torch.rand(B, H, W, cout, generator=g) - 0.5).to(DEV) if res else None
+    p = (torch.rand(H, W, cout, generator=g) - 0.5).to(DEV) if post else None
+    assert ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= 2048
+    old = lib.cmr_set_wino_variant(0)
+    try:
+        y4 = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
+        lib.cmr_set_wino_variant(1)
+        y8 = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
+        y8b = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
+    finally:
+        lib.cmr_set_wino_variant(old)
+    assert torch.equal(y4, y8) and torch.equal(y8, y8b)
+    ops.WINOGRAD = False
+    try:
+        yd = ops.conv3x3(x, w9, b, cout, 1, 0.2, res=r, post=p, pool=pool)
+    finally:
+        ops.WINOGRAD = True
+    assert float((yd - y8).abs().max()) < 5e-5 * float(yd.abs().max())
+
+
 def test_fps_and_knn_properties_at_65536_points():
     from cmr_agent_amd import ops
     B, N, S = 2, 65536, 1280                                   # BASELINE configs[4]: FPS / grouping stress
