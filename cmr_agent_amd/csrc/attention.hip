@@ -1,9 +1,11 @@
 // Attention kernels of the coarse (softmax) and fine (linear) matchers.
 //
 // cmr_mha_f32        softmax(Q K^T / sqrt(dh)) V for 8 heads x 8 dims on <= ~2k tokens
-//                    (ImageViT.py:81-108, PointViT.py:117-140, IMGPCEncoder.py:36-58).  Head dim 8 and
-//                    T <= 1400 make this a latency problem, not an MFMA one: K/V of one head live in
-//                    LDS (broadcast b128 reads), one query per lane, two passes (max, then exp/sum).
+//                    (ImageViT.py:81-108, PointViT.py:117-140, IMGPCEncoder.py:36-58).  K/V of one head live in
+//                    LDS.  Default: mha_mfma_kernel -- both contractions on v_mfma_f32_16x16x4_f32, the score tile
+//                    stays in the accumulator registers and IS the operand of the second contraction, online softmax
+//                    (13 us at 8 x 418 x 256 tokens).  mha_kernel (one query per 4 lanes on the vector ALUs, two passes:
+//                    max, then exp / sum; 19 us) stays selectable through cmr_set_mha_variant for A/B runs.
 // cmr_la_reduce_f32  KV[h,d,v] = sum_s K~[s,h,d] * V[s,h,v] / S  and  Ksum[h,d] = sum_s K~[s,h,d]
 // cmr_la_apply_f32   msg[l,h,v] = (Q~[l,h,:] . KV[h,:,v]) * S / (Q~[l,h,:] . Ksum[h,:] + eps)
 //                    (LinearAttention.py:53-60; K~,Q~ = elu+1 are produced by the projection epilogue).
@@ -73,6 +75,94 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ q, i
   f32x4 o1 = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
   *reinterpret_cast<f32x4*>(op) = o0;
   *reinterpret_cast<f32x4*>(op + 4) = o1;
+}
+
+
+// ---- the same attention on the matrix cores (v_mfma_f32_16x16x4_f32) ---------------------------------------------------
+// One wave = 16 queries of one (batch, head); a step = 16 keys.  S^T = K Q^T (keys on the rows, queries on the columns) is
+// two MFMAs (8 head dims = 2 x 4): lane (i, g) = (l & 15, l >> 4) supplies K[key i][2g + s] and Q[query i][2g + s] in step s.  In
+// the 16x16 accumulator layout lane (q, g) then holds the scores of query q for the keys 4g .. 4g + 3 -- which is exactly the B
+// operand of the next contraction, O^T += V^T P^T (4 MFMAs, one per register: contraction index = lane group g <-> key 4g + r),
+// with A = V^T[d][key] read as ONE b128 per lane from a transposed V image in LDS (rows 8.. are a zero row: 8 of the 16 output
+// rows are head dims).  Online softmax: running max / sum per query; the max is combined over the four lane groups with two
+// xor-shuffles per step, the sums once at the end.  The output tile has the head dims on the rows: lane (q, g < 2) ends up with
+// O[q][4g .. 4g + 3] -- one b128 store.  No P tile ever leaves the registers.
+typedef float mha_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mha_mfma_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
+                                                       const float* __restrict__ v, int64_t ldv, float* __restrict__ o, int64_t ldo, int Tq,
+                                                       int Tk, int Tkp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tkp][8], then V_h^T [9][Tkp] (row 8 = zeros)
+  float* ks = kv;
+  float* vt = kv + (size_t)Tkp * DH;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const float* kb = k + (int64_t)b * Tk * ldk + head * DH;
+  const float* vb = v + (int64_t)b * Tk * ldv + head * DH;
+  for (int e = threadIdx.x; e < Tkp * 2; e += 256) {
+    const int t = e >> 1, half = (e & 1) * 4;
+    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+    if (t < Tk) {
+      kk = *reinterpret_cast<const f32x4*>(kb + (int64_t)t * ldk + half);
+      vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)t * ldv + half);
+    }
+    *reinterpret_cast<f32x4*>(&ks[t * DH + half]) = kk;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vt[(half + i) * Tkp + t] = vv[i];
+  }
+  for (int t = threadIdx.x; t < Tkp; t += 256) vt[8 * Tkp + t] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  if (q0 >= Tq) return;
+  const int tq = q0 + i < Tq ? q0 + i : Tq - 1;
+  const float* qp = q + ((int64_t)b * Tq + tq) * ldq + head * DH + 2 * g;
+  const float qa = qp[0], qb = qp[1];
+  const float* krow = ks + i * DH + 2 * g;                       // + k0 * DH
+  const float* vrow = vt + (i < 8 ? i : 8) * Tkp + 4 * g;        // + k0
+  float m = -INFINITY, l = 0.f;
+  mha_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < Tkp; k0 += 32) {                        // two 16-key steps per running-max update
+    const float2 ka0 = *reinterpret_cast<const float2*>(krow + k0 * DH);
+    const float2 ka1 = *reinterpret_cast<const float2*>(krow + (k0 + 16) * DH);
+    const mha_f32x4 vf0 = *reinterpret_cast<const mha_f32x4*>(vrow + k0);
+    const mha_f32x4 vf1 = *reinterpret_cast<const mha_f32x4*>(vrow + k0 + 16);
+    mha_f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.x, qa, s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.x, qa, s1, 0, 0, 0);
+    s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.y, qb, s0, 0, 0, 0);
+    s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.y, qb, s1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s0[r] = k0 + 4 * g + r < Tk ? s0[r] * scale : -INFINITY;
+      s1[r] = k0 + 16 + 4 * g + r < Tk ? s1[r] * scale : -INFINITY;
+    }
+    float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+    bm = fmaxf(bm, __shfl_xor(bm, 16));
+    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    const float mn = fmaxf(m, bm);                               // finite from the first step on (key 0 is always valid)
+    const float alpha = expf(m - mn);
+    m = mn;
+    mha_f32x4 p0, p1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p0[r] = expf(s0[r] - mn);
+      p1[r] = expf(s1[r] - mn);
+    }
+    l = l * alpha + (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[r], p0[r], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[r], p1[r], acc, 0, 0, 0);
+  }
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  if (g < 2 && q0 + i < Tq) {
+    const float inv = 1.f / l;
+    f32x4 out = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+    *reinterpret_cast<f32x4*>(o + ((int64_t)b * Tq + q0 + i) * ldo + head * DH + 4 * g) = out;
+  }
 }
 
 // partial sums over a slab of TS tokens: thread (h,d,v) accumulates K[s,h,d]*V[s,h,v]/S; threads with
@@ -155,11 +245,28 @@ __global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__
 
 }  // namespace
 
+static int CMR_MHA_MFMA = 1;     // 1 = matrix-core kernel (default), 0 = the one-query-per-lane-group VALU kernel
+extern "C" int cmr_set_mha_variant(int mfma) {
+  const int old = CMR_MHA_MFMA;
+  CMR_MHA_MFMA = mfma;
+  return old;
+}
+
 extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                            float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
   CMR_REQUIRE(q && k && v && o && B > 0 && B <= 65535 && Tq > 0 && Tk > 0);
   CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
   CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(o));
+  if (CMR_MHA_MFMA) {
+    const int Tkp = (Tk + 31) / 32 * 32;
+    const size_t smem = (size_t)Tkp * (DH + 9) * sizeof(float);
+    CMR_REQUIRE(smem <= 160 * 1024);
+    static CmrSmemCache granted{};
+    if (cmr_grant_smem(reinterpret_cast<const void*>(mha_mfma_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+    dim3 grid((Tq + 63) / 64, NH, B);
+    hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk, Tkp, 0.35355339059327373f);
+    return cmr_launch_status();
+  }
   const size_t smem = (size_t)Tk * DH * 2 * sizeof(float);
   CMR_REQUIRE(smem <= 160 * 1024);
   static CmrSmemCache granted{};

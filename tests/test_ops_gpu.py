@@ -142,8 +142,20 @@ def test_pool_upsample_patchify_transpose(ops):
     close(ops.transpose(t.to(DEV)), t.transpose(1, 2), 0, "transpose")
 
 
-@pytest.mark.parametrize("B,Tq,Tk", [(2, 50, 30), (1, 418, 256), (2, 256, 418), (1, 70, 1400)])
-def test_mha(ops, B, Tq, Tk):
+@pytest.mark.parametrize("variant", [1, 0], ids=["mfma", "valu"])
+@pytest.mark.parametrize("B,Tq,Tk", [(2, 50, 30), (1, 418, 256), (2, 256, 418), (1, 70, 1400), (3, 17, 16), (2, 15, 100), (1, 64, 2047)])
+def test_mha(ops, B, Tq, Tk, variant):
+    """Both kernels of cmr_mha_f32: Q K^T and P V on v_mfma_f32_16x16x4_f32 with an online softmax (the default), and the
+    two-pass vector-ALU kernel."""
+    from cmr_agent_amd import _lib
+    old = _lib.load().cmr_set_mha_variant(variant)
+    try:
+        _mha_case(ops, B, Tq, Tk)
+    finally:
+        _lib.load().cmr_set_mha_variant(old)
+
+
+def _mha_case(ops, B, Tq, Tk):
     q, k, v = rnd(B * Tq, 64, seed=33, lo=-3, hi=3), rnd(B * Tk, 64, seed=34, lo=-3, hi=3), rnd(B * Tk, 64, seed=35)
     qh = q.view(B, Tq, 8, 8).permute(0, 2, 1, 3).double()
     kh = k.view(B, Tk, 8, 8).permute(0, 2, 1, 3).double()
