@@ -321,7 +321,7 @@ def main():
         traffic, traffic_src = None, "profiles/r02_pmc_path.json"
         try:
             pmc = json.load(open(os.path.join(ROOT, traffic_src)))
-            wino = [v for k, v in pmc.items() if "conv3x3_wino_kernel" in k]       # both template instances, launch-weighted
+            wino = [v for k, v in pmc.items() if "conv3x3_wino" in k]       # the wave-specialised kernel and both 4-wave instances, launch-weighted
             traffic = (sum((v["hbm_fetch_bytes"] + v["hbm_write_bytes"]) * v["launches_per_iteration"] for v in wino)
                        / sum(v["launches_per_iteration"] for v in wino))
         except Exception:
@@ -345,7 +345,7 @@ def main():
                             mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2500.0,
                             path_note="ideal times of `path` are priced at the fp32 peaks (utils/workmodel.py)", **common)
         else:
-            roofline = dict(kernel="conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)", bound="mfma",
+            roofline = dict(kernel="conv3x3_wino_ws_kernel / conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)", bound="mfma",
                             achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP32_MFMA_PEAK_TFLOPS,
                             # `achieved` counts the ALGORITHMIC work of the convolution (2*9*Cin*Cout flop per output pixel); Winograd
                             # issues 16/36 of those multiplies on the matrix cores, which is how frac can pass 1
