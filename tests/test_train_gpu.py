@@ -352,6 +352,25 @@ def test_agent_update_matches_oracle_and_reference_fixture():
     close(r_a, rr, 5e-3, "eval-mode forward after the update vs the oracle's updated weights (running means carry the bias walk)")
 
 
+def test_forty_updates_on_one_minibatch_fit_it():
+    """Beyond per-step parity: from torch's default initialisation, 40 updates on ONE fixed minibatch must fit it -- behaviour-
+    cloning cross-entropy from ~5.1 (2 x ln 11 plus noise) to below 0.3, total loss below a tenth of its starting value."""
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train import AgentUpdate
+    case = "agent_train_small"
+    cfg = C.train_config(case, device=DEV)
+    torch.manual_seed(0)
+    agent = CMRAgent(cfg).to(DEV)
+    up = AgentUpdate(agent, cfg)
+    batch = _to_dev(C.train_inputs(case)[0])
+    first = up.step(batch).cpu()
+    for _ in range(39):
+        last = up.step(batch)
+    last = last.cpu()
+    assert torch.isfinite(last).all()
+    assert float(last[1]) < 0.3 and float(last[0]) < 0.1 * float(first[0]), (first.tolist(), last.tolist())
+
+
 def test_buffer_ordering_quirk_on_device():
     """Buffer.get_samples() of the product (device tensors) vs the fixture made with the reference's Buffer."""
     from cmr_agent_amd.config import KittiConfiguration
