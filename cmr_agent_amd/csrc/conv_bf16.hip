@@ -1,4 +1,4 @@
-// Stride-1 3x3 convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the bf16 variant of
+// Stride-1 / stride-2 3x3 convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) -- the bf16 variant of
 // the convolution kernels (SURVEY.md 7 step 9 / BASELINE configs[2], configs[3]).  Activations stay fp32 NHWC in HBM (same
 // buffers, same epilogue as the fp32 kernels: folded-BN bias, residual, LeakyReLU, positional table, fused 2x2 average
 // pool); operands are rounded to bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32) when the halo tile is staged in LDS,
@@ -33,10 +33,13 @@ __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.
 
 // TW = 32: wave w owns rows 2w, 2w+1 as two 32-pixel blocks (lane = column).
 // TW = 16: wave w owns rows 2w, 2w+1 as ONE block (lane = 16 (row & 1) + column).
-template <int CIN, int NT, int TW>
+// S = stride (1 | 2): the output tile stays TH x TW, the halo image grows to ((TH - 1) S + 3) x ((TW - 1) S + 3) input pixels and a
+// lane's pixel sits at (S row + ky, S column + kx) in it (S = 2: 288 bytes between neighbouring lanes = 8 banks apart, still
+// conflict free).  a.H / a.W are the INPUT sizes; the output is ((H - 1) / S + 1) x ((W - 1) / S + 1).
+template <int CIN, int NT, int TW, int S = 1>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   constexpr int KS = CIN / 16, NB = TW / 16;
-  constexpr int TH = 8, HR = TH + 2, HC = TW + 2;
+  constexpr int TH = 8, HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
   constexpr int PS = CIN * 2 + 16;                      // bytes per halo pixel
   constexpr int WBYTES = 9 * KS * NT * 1024;
   constexpr int C4 = CIN / 4;
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       int e = tid + 256 * i;
       e = e < NPIECE ? e : NPIECE - 1;
       const int p = e / C4, c = e - p * C4;
-      int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+      int iy = t.oy0 * S - 1 + p / HC, ix = t.ox0 * S - 1 + p % HC;
       iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
       ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
       pv[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN + 4 * c));
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       const int e = tid + 256 * i;
       if (e < NPIECE) {
         const int p = e / C4, c = e - p * C4;
-        const int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+        const int iy = t.oy0 * S - 1 + p / HC, ix = t.ox0 * S - 1 + p % HC;
         const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         bf16x4 v;
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
           av[nt] = *reinterpret_cast<const bf16x8*>(Ws + ((tap * KS + ks) * NT + nt) * 1024 + lane * 16);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
-          bv[nb] = *reinterpret_cast<const bf16x8*>(Xs + ((prow[nb] + ky) * HC + pcol[nb] + kx) * PS + ks * 32 + h * 16);
+          bv[nb] = *reinterpret_cast<const bf16x8*>(Xs + ((prow[nb] * S + ky) * HC + pcol[nb] * S + kx) * PS + ks * 32 + h * 16);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
     }
     // ---- epilogue: register 4q+e of tile nt = channel co0 + 32 nt + 8q + 4h + e of this lane's pixel
     const Tile t = decode(s);
-    const int Ho = a.H, Wo = a.W;
-    if (a.pool == 2) {
+    const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+    if (S == 1 && a.pool == 2) {
       // LeakyReLU(conv + bias), then the 2x2 mean: rows 2w / 2w+1 are the two blocks (TW = 32) or lane halves 16 apart
       // (TW = 16); the column partner is lane ^ 1
       const int py = (t.oy0 >> 1) + wave, px = (t.ox0 >> 1) + (pcol[0] >> 1);
@@ -210,34 +213,40 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   }
 }
 
-template <int CIN, int NT, int TW>
+template <int CIN, int NT, int TW, int S = 1>
 int launch_b16(B16Args a, hipStream_t stream) {
-  constexpr int smem = 9 * (CIN / 16) * NT * 1024 + 10 * (TW + 2) * (CIN * 2 + 16);
+  constexpr int smem = 9 * (CIN / 16) * NT * 1024 + (7 * S + 3) * ((TW - 1) * S + 3) * (CIN * 2 + 16);
   static_assert(smem <= 160 * 1024, "weight slice + halo image must fit in LDS");
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
-  a.tiles_x = (a.W + TW - 1) / TW;
-  a.tiles_y = (a.H + 7) / 8;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW, S>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  a.tiles_x = ((a.W - 1) / S + 1 + TW - 1) / TW;
+  a.tiles_y = ((a.H - 1) / S + 1 + 7) / 8;
   const int ngroups = a.Cout / (32 * NT);
   const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
   int per_group = 256 / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > nsp) per_group = (int)nsp;
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW, S>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
   return cmr_launch_status();
 }
 
 }  // namespace
 
 extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
-                                         const float* res, const float* post, float* y, int Cout, float slope, int pool,
+                                         const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                                          hipStream_t stream) {
-  CMR_REQUIRE(x && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0);
+  CMR_REQUIRE(x && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0 && (stride == 1 || stride == 2));
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(wfrag) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
               (!post || cmr_aligned16(post)));
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
   B16Args a{x, B, H, W, wfrag, bias, res, post, y, Cout, slope, pool, 0, 0};
+  if (stride == 2) {
+    if (pool != 1) return CMR_EINVAL;
+    if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 16, 2>(a, stream);
+    if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 16, 2>(a, stream);
+    return CMR_EUNSUPPORTED;
+  }
   if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 32>(a, stream);
   if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 32>(a, stream);
   if (Cin == 128 && nt == 1 && Cout % 32 == 0) return launch_b16<128, 1, 16>(a, stream);

@@ -76,7 +76,7 @@ class ResidualBlock(Planned):
             B, H, W, c = x.shape
             res = ops.linear(x.view(B * H * W, c), sc[1], sc[2]).view(B, H, W, self.outchannel)
         else:
-            res = ops.conv3x3(x, sc[1], sc[2], self.outchannel, 2, 1.0)
+            res = ops.conv3x3(x, sc[1], sc[2], self.outchannel, 2, 1.0, u=sc[3])        # u only carries the bf16 operands here
         return ops.conv3x3(t, p["b"][0], p["b"][1], self.outchannel, 1, self.SLOPE, res=res, post=post, u=p["b"][2])
 
     def forward(self, x):

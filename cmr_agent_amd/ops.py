@@ -114,8 +114,8 @@ def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     return y
 
 
-def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1):
-    """Stride-1 3x3 convolution on the bf16 matrix cores; frags = (bf16 fragment tensor, nt) from _pack.conv_bf16_frags.
+def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, stride=1):
+    """3x3 convolution (stride 1 | 2) on the bf16 matrix cores; frags = (bf16 fragment tensor, nt) from _pack.conv_bf16_frags.
     Returns None when the library does not serve the shape (the caller falls back to the fp32 kernels)."""
     B, H, W, cin = x.shape
     wf, nt = frags
@@ -125,10 +125,12 @@ def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1):
         raise ValueError("conv3x3: pool=2 cannot be combined with res / post")
     if pool == 2 and (H % 2 or W % 2):
         return None
-    hp, wp = (H // 2, W // 2) if pool == 2 else (H, W)
+    if stride == 2 and (pool != 1 or cin != 64):
+        return None
+    hp, wp = (H // 2, W // 2) if pool == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
     y = torch.empty((B, hp, wp, cout), dtype=f32, device=x.device)
-    rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, float(slope), pool,
-                   _stream(), allow_unsupported=True)
+    rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, int(stride),
+                   float(slope), pool, _stream(), allow_unsupported=True)
     return None if rc == _lib.UNSUPPORTED else y
 
 
@@ -140,8 +142,8 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
         raise ValueError("conv3x3: bad operand layout")
-    if CONV_BF16 and stride == 1 and out is None and getattr(u, "bf16", None) is not None:
-        y = conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool)
+    if CONV_BF16 and out is None and getattr(u, "bf16", None) is not None:
+        y = conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool, stride)
         if y is not None:
             return y
     if (WINOGRAD and u is not None and stride == 1 and out is None

@@ -399,13 +399,14 @@ int cmr_dataset_circle_select_f64(const int64_t* pc_mask, const double* xy, cons
                                   int32_t* compact_ws, int64_t* count, int64_t* idx_out, float* xy_float, int64_t* xy_int,
                                   hipStream_t stream);
 
-/* ---- bf16 matrix-core variant of the stride-1 3x3 convolution (BASELINE configs[2] / [3]) ---- */
-/* Same contract as cmr_conv3x3_wino_nhwc_f32 (fp32 NHWC in / out, folded-BN bias, residual, LeakyReLU, positional table,
- * optional fused 2x2 average pool) with the products on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32
- * accumulate).  wfrag: bf16 A fragments [Cout/(32 nt)][9][Cin/16][nt][64][8] (cmr_agent_amd/models/_pack.py:conv_bf16_frags).
- * Served shapes: (Cin 64, nt 1|2), (Cin 128, nt 1); anything else returns CMR_EUNSUPPORTED. */
+/* ---- bf16 matrix-core variant of the 3x3 convolution (BASELINE configs[2] / [3]) ---- */
+/* Same contract as cmr_conv3x3_nhwc_f32 (fp32 NHWC in / out, stride 1|2, folded-BN bias, residual, LeakyReLU, positional
+ * table, optional fused 2x2 average pool at stride 1) with the products on v_mfma_f32_32x32x16_bf16 (operands rounded to
+ * bf16, fp32 accumulate).  wfrag: bf16 A fragments [Cout/(32 nt)][9][Cin/16][nt][64][8]
+ * (cmr_agent_amd/models/_pack.py:conv_bf16_frags).  Served shapes: stride 1: (Cin 64, nt 1|2), (Cin 128, nt 1); stride 2:
+ * (Cin 64, nt 1|2); anything else returns CMR_EUNSUPPORTED. */
 int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
-                              const float* res, const float* post, float* y, int Cout, float slope, int pool,
+                              const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                               hipStream_t stream);
 
 /* ---- geometric-model update: backward pieces (reference Train_Geo.py:166-174) ---------------------- */

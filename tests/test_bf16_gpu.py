@@ -1,4 +1,4 @@
-"""GPU tier, bf16 variants (BASELINE configs[2], configs[3]): the stride-1 3x3 convolution on the
+"""GPU tier, bf16 variants (BASELINE configs[2], configs[3]): the 3x3 convolution (stride 1 and 2) on the
 bf16 matrix cores.  Op level: against torch's convolution of the SAME bf16-rounded operands (products of bf16 numbers are
 exact in fp32, so only the summation order differs: rtol 2e-5 of the output scale) and against the fp32 convolution at
 the bf16 bar (relative error <= 1e-2 of the output scale).  End to end: the whole registration iteration with every served
@@ -17,22 +17,25 @@ def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
     return torch.rand(*shape, generator=g) * (hi - lo) + lo
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout,pool,res,post", [
-    (2, 16, 64, 64, 64, 1, True, False), (1, 13, 37, 64, 64, 1, False, True), (2, 8, 32, 64, 32, 1, False, False),
-    (2, 12, 20, 128, 128, 1, True, False), (1, 9, 23, 128, 64, 1, False, False), (3, 16, 48, 128, 128, 2, False, False),
-    (2, 24, 64, 64, 64, 2, False, False), (1, 40, 128, 64, 128, 1, True, True)])
-def test_conv3x3_bf16(B, H, W, cin, cout, pool, res, post):
+@pytest.mark.parametrize("B,H,W,cin,cout,pool,res,post,stride", [
+    (2, 16, 64, 64, 64, 1, True, False, 1), (1, 13, 37, 64, 64, 1, False, True, 1), (2, 8, 32, 64, 32, 1, False, False, 1),
+    (2, 12, 20, 128, 128, 1, True, False, 1), (1, 9, 23, 128, 64, 1, False, False, 1), (3, 16, 48, 128, 128, 2, False, False, 1),
+    (2, 24, 64, 64, 64, 2, False, False, 1), (1, 40, 128, 64, 128, 1, True, True, 1),
+    (2, 16, 64, 64, 64, 1, False, False, 2), (1, 33, 71, 64, 64, 1, True, True, 2), (2, 50, 130, 64, 32, 1, False, False, 2),
+    (1, 96, 160, 64, 128, 1, False, False, 2)])
+def test_conv3x3_bf16(B, H, W, cin, cout, pool, res, post, stride):
     from cmr_agent_amd import ops
     from cmr_agent_amd.models._pack import conv_bf16_frags
     x = rnd(B, cin, H, W, seed=1)
     w = rnd(cout, cin, 3, 3, seed=2) / 12
     b = rnd(cout, seed=3)
-    r = rnd(B, cout, H, W, seed=4) if res else None
-    p = rnd(1, cout, H, W, seed=5) if post else None
+    ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = rnd(B, cout, ho, wo, seed=4) if res else None
+    p = rnd(1, cout, ho, wo, seed=5) if post else None
     bf = lambda t: t.to(torch.bfloat16).double()
 
     def ref(xx, ww):
-        y = F.conv2d(xx, ww, b.double(), 1, 1)
+        y = F.conv2d(xx, ww, b.double(), stride, 1)
         if r is not None:
             y = y + r.double()
         y = F.leaky_relu(y, 0.2)
@@ -42,7 +45,8 @@ def test_conv3x3_bf16(B, H, W, cin, cout, pool, res, post):
     want_bf, want_fp = ref(bf(x), bf(w)), ref(x.double(), w.double())
     nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(DEV)
     frags = conv_bf16_frags(w.to(DEV))
-    got = ops.conv3x3_bf16(nhwc(x), frags, b.to(DEV), cout, 0.2, res=nhwc(r), post=None if p is None else nhwc(p)[0].contiguous(), pool=pool)
+    got = ops.conv3x3_bf16(nhwc(x), frags, b.to(DEV), cout, 0.2, res=nhwc(r), post=None if p is None else nhwc(p)[0].contiguous(), pool=pool,
+                           stride=stride)
     assert got is not None
     got = got.permute(0, 3, 1, 2).cpu().double()
     scale = float(want_fp.abs().max())

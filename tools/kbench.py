@@ -46,6 +46,12 @@ def bench_conv(B, H, W, cin, cout, stride, reps):
     by = 4.0 * (x.numel() + 2 * out.numel())
     line = "conv3x3 %4dx%-4d %3d->%-3d s%d : %8.1f us  %6.1f TFLOP/s  (%5.2f TB/s algorithmic)" % (
         H, W, cin, cout, stride, us, fl / us / 1e6, by / us / 1e6)
+    if stride == 2 and cin == 64:
+        from cmr_agent_amd.models._pack import conv_bf16_frags
+        fr = conv_bf16_frags(torch.randn(cout, cin, 3, 3, device=DEV) / math.sqrt(9 * cin))
+        if ops.conv3x3_bf16(x, fr, b, cout, 0.2, res=res, stride=2) is not None:
+            us3 = timeit(lambda: ops.conv3x3_bf16(x, fr, b, cout, 0.2, res=res, stride=2), reps)
+            line += "   | bf16 %8.1f us  %6.1f TFLOP/s  %5.2f TB/s" % (us3, fl / us3 / 1e6, by / us3 / 1e6)
     if stride == 1:
         u = torch.randn(16, cout, cin, device=DEV) / math.sqrt(9 * cin)
         us2 = timeit(lambda: ops.conv3x3(x, w, b, cout, 1, 0.2, res=res, u=u), reps)
