@@ -437,6 +437,104 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
   }
 }
 
+
+// Farthest point sampling for clouds that do not fit one workgroup's registers (> 16 384 points; BASELINE configs[4] = 65 536):
+// G workgroups of 256 threads per cloud, each keeping its slice (coordinates + running min-distance, PER points per thread)
+// in registers.  A round = local arg-max (wave shuffles + LDS), then ONE 64-bit atomic max per workgroup on the round's word
+// (key = distance bits << 32 | ~index: distances are >= 0, so the unsigned order of the bits is the float order, and among
+// equal distances the lowest index wins, like torch.max), an arrival counter, and a bounded spin until all G workgroups of
+// the cloud have arrived.  Every round has its own word (zeroed by the entry point), so nothing is ever reset; the words are
+// turned into plain indices by fps_unpack_kernel afterwards.  The G workgroups of a cloud must be co-resident (the entry point
+// sizes G so that B * G <= 256); a workgroup that waits longer than FPS_SPIN polls raises the error word and leaves, and
+// everybody who sees the error word leaves too: the grid always drains.
+constexpr int FPS_CT = 256;
+constexpr unsigned FPS_SPIN = 1u << 22;
+template <int PER>
+__global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restrict__ xyz4, const int64_t* __restrict__ start,
+                                                          unsigned long long* __restrict__ win /*[B][npoint]*/,
+                                                          unsigned* __restrict__ cnt /*[B] arrivals, then [B] error flags*/, int B, int G,
+                                                          int N, int npoint) {
+  __shared__ float red_d[4];
+  __shared__ int red_i[4];
+  __shared__ int far_s;
+  const int b = blockIdx.x % B, w = blockIdx.x / B;             // the workgroups of cloud b are blockIdx = b (mod B): one XCD when B = 8
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* xb = xyz4 + (int64_t)b * N * 4;
+  const int slice = (N + G - 1) / G;
+  const int lo = w * slice, hi = min(N, lo + slice);
+  float px[PER], py[PER], pz[PER], dist[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = lo + tid + j * FPS_CT;
+    f32x4 p = {0.f, 0.f, 0.f, 0.f};
+    if (i < hi) p = *reinterpret_cast<const f32x4*>(xb + (int64_t)i * 4);
+    px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+    dist[j] = i < hi ? 1e10f : -1.f;
+  }
+  unsigned long long* wb = win + (int64_t)b * npoint;
+  unsigned* err = cnt + B + b;
+  int far = (int)start[b];
+  if (w == 0 && tid == 0) wb[0] = (unsigned long long)far;        // round 0's word holds the start index as it is
+  for (int it = 0; it + 1 < npoint; ++it) {
+    const f32x4 c = *reinterpret_cast<const f32x4*>(xb + (int64_t)far * 4);
+    float bd = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = lo + tid + j * FPS_CT;
+      const float d = sqdist3(px[j], py[j], pz[j], c[0], c[1], c[2]);
+      dist[j] = i < hi ? fminf(dist[j], d) : -1.f;
+      if (dist[j] > bd) { bd = dist[j]; bi = i; }             // ascending i within a thread: first max kept
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float od = __shfl_xor(bd, m);
+      const int oi = __shfl_xor(bi, m);
+      if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (lane == 0) { red_d[wave] = bd; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (red_d[k] > bd || (red_d[k] == bd && red_i[k] < bi)) { bd = red_d[k]; bi = red_i[k]; }
+      if (bd >= 0.f) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi);
+        __hip_atomic_fetch_max(&wb[it + 1], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __hip_atomic_fetch_add(&cnt[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned want = (unsigned)G * (unsigned)(it + 1);
+      unsigned spins = 0;
+      bool bad = false;
+      while (__hip_atomic_load(&cnt[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spins > FPS_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (bad) {
+        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        far_s = -1;
+      } else {
+        const unsigned long long k = __hip_atomic_load(&wb[it + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        far_s = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+      }
+    }
+    __syncthreads();
+    far = far_s;
+    if (far < 0) return;                                        // uniform: the whole workgroup leaves
+  }
+}
+
+__global__ __launch_bounds__(256) void fps_unpack_kernel(const unsigned long long* __restrict__ win, const unsigned* __restrict__ cnt,
+                                                         int64_t* __restrict__ out, int B, int npoint) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * npoint) return;
+  const int b = (int)(i / npoint), it = (int)(i % npoint);
+  const unsigned long long k = win[i];
+  int64_t v = it == 0 ? (int64_t)k : (int64_t)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+  if (cnt[B + b] != 0u) v = -1;                                 // a cloud whose workgroups could not meet: every index invalid
+  out[i] = v;
+}
+
 // ball query: one wave per query; ascending scan, first `nsample` hits with d2 <= r2, padded
 // with the first hit (pointnet_util.py:86-92).  A query with no hit yields N (as the reference).
 __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ xyz4, const float* __restrict__ new4,
@@ -646,6 +744,46 @@ extern "C" int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out
   else if (per <= 40) FPS_CASE(40, false);
   else FPS_CASE(64, false);
 #undef FPS_CASE
+  return cmr_launch_status();
+}
+
+
+// Cooperative variant for N > 16 384 (and any N the caller prefers): G workgroups per cloud.  ws: [B][npoint] 64-bit round words,
+// then [2 B] 32-bit counters / error flags.  out[b][:] = -1 for a cloud whose workgroups did not all become resident.
+static int fps_groups(int B, int N) {
+  int g = 256 / B;                                              // all B * G workgroups resident at once, one per CU
+  const int cap = B <= 4 ? 16 : 8;                              // measured at 65 536 points: 16 groups 2.9 us / round at B = 1, 8 groups 3.8 at B = 8
+  if (g > cap) g = cap;
+  const int need = (N + 64 * FPS_CT - 1) / (64 * FPS_CT);       // <= 64 points per thread
+  if (g < need) g = need;
+  return g < 1 ? 1 : g;
+}
+
+extern "C" int64_t cmr_fps_workspace_bytes(int B, int N, int npoint) {
+  (void)N;
+  return (int64_t)B * npoint * 8 + (int64_t)2 * B * 4;
+}
+
+extern "C" int cmr_fps_ws_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
+                              hipStream_t stream) {
+  CMR_REQUIRE(xyz4 && start && out && ws && B > 0 && N > 0 && npoint > 0 && cmr_aligned16(xyz4) && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0);
+  CMR_REQUIRE(ws_bytes >= cmr_fps_workspace_bytes(B, N, npoint));
+  const int G = fps_groups(B, N);
+  CMR_REQUIRE((int64_t)B * G <= 256);                            // co-residency of every cloud's workgroups
+  const int per = ((N + G - 1) / G + FPS_CT - 1) / FPS_CT;
+  CMR_REQUIRE(per <= 64);
+  if (hipMemsetAsync(ws, 0, (size_t)cmr_fps_workspace_bytes(B, N, npoint), stream) != hipSuccess) return CMR_ELAUNCH;
+  unsigned long long* win = (unsigned long long*)ws;
+  unsigned* cnt = (unsigned*)(win + (int64_t)B * npoint);
+#define FPS_COOP(P) hipLaunchKernelGGL((fps_coop_kernel<P>), dim3(B * G), dim3(FPS_CT), 0, stream, xyz4, start, win, cnt, B, G, N, npoint)
+  if (per <= 4) FPS_COOP(4);
+  else if (per <= 8) FPS_COOP(8);
+  else if (per <= 16) FPS_COOP(16);
+  else if (per <= 32) FPS_COOP(32);
+  else FPS_COOP(64);
+#undef FPS_COOP
+  hipLaunchKernelGGL(fps_unpack_kernel, dim3((unsigned)(((int64_t)B * npoint + 255) / 256)), dim3(256), 0, stream, (const unsigned long long*)win,
+                     (const unsigned*)cnt, out, B, npoint);
   return cmr_launch_status();
 }
 

@@ -420,9 +420,20 @@ def weighted_gather3(src, idx, wgt):
     return out
 
 
-def fps(xyz4, start, B, N, npoint):
+FPS_COOP_MIN_N = 16385      # clouds above this take the multi-workgroup kernel (one workgroup keeps <= 16 384 points in registers)
+
+
+def fps(xyz4, start, B, N, npoint, coop=None):
+    """Farthest point sampling -> int64 [B, npoint] local indices.  coop: None = by size, True / False = force the multi- /
+    single-workgroup kernel (identical results)."""
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz4.device)
-    _lib.call("cmr_fps_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _stream())
+    use = (N >= FPS_COOP_MIN_N and B <= 64) if coop is None else coop
+    if use:
+        nb = _lib.load().cmr_fps_workspace_bytes(B, N, npoint)
+        ws = torch.empty((nb // 8 + 1,), dtype=torch.int64, device=xyz4.device)
+        _lib.call("cmr_fps_ws_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _p(ws), nb, _stream())
+    else:
+        _lib.call("cmr_fps_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _stream())
     return out
 
 

@@ -256,6 +256,12 @@ int cmr_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, float
 
 /* pointnet_util.py:50-70 (start index explicit), :73-93, :19-33. */
 int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, hipStream_t stream);
+/* The same sampling with several workgroups per cloud (slices in registers, one 64-bit atomic max + an arrival counter per
+ * round; bit-identical indices): for clouds above 16 384 points (BASELINE configs[4]: 65 536), B * groups <= 256.  ws = scratch of
+ * cmr_fps_workspace_bytes.  A cloud whose workgroups could not all become resident gets -1 in every slot (bounded waits). */
+int64_t cmr_fps_workspace_bytes(int B, int N, int npoint);
+int cmr_fps_ws_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
+                   hipStream_t stream);
 int cmr_ball_query_f32(const float* xyz4, const float* new4, int64_t* out, int B, int N, int S, int nsample,
                        float radius2, hipStream_t stream);
 int cmr_square_distance_f32(const float* a4, const float* b4, float* out, int B, int N, int M, hipStream_t stream);

@@ -368,14 +368,29 @@ def test_vector_attention_pieces(ops):
     close(got, val[idx.long()], 0, "gather_rows")
 
 
+@pytest.mark.parametrize("coop", [False, True], ids=["one-workgroup", "multi-workgroup"])
 @pytest.mark.parametrize("B,N,npoint", [(2, 500, 64), (2, 4096, 256), (1, 10240, 1280), (1, 20000, 128)])
-def test_fps_matches_pointnet_util(ops, B, N, npoint):
+def test_fps_matches_pointnet_util(ops, B, N, npoint, coop):
+    """Both FPS kernels (one workgroup per cloud; several per cloud with an atomic-max round word) against the oracle's
+    restatement of pointnet_util.farthest_point_sample: identical indices."""
     xyz = _cloud(B, N, 50).permute(0, 2, 1).contiguous()
     start = torch.tensor([3, 77][:B])
     ref = O.farthest_point_sample(xyz, npoint, start)
     x4 = ops.planar_to_rows4(xyz.permute(0, 2, 1).contiguous().to(DEV))
-    got = ops.fps(x4, start.to(DEV), B, N, npoint)
+    got = ops.fps(x4, start.to(DEV), B, N, npoint, coop=coop)
     assert torch.equal(got.cpu(), ref)
+
+
+def test_fps_kernels_agree_at_65536_points_with_duplicates(ops):
+    """BASELINE configs[4] size, with exact duplicates in the cloud (ties: the lowest index must win in both kernels)."""
+    B, N, npoint = 3, 65536, 300
+    xyz = _cloud(B, N, 52)                                   # [B, 3, N]
+    xyz[:, :, 1000:1200] = xyz[:, :, 5000:5200]
+    x4 = ops.planar_to_rows4(xyz.contiguous().to(DEV))
+    start = torch.tensor([0, 7, 65535]).to(DEV)
+    a = ops.fps(x4, start, B, N, npoint, coop=False)
+    b = ops.fps(x4, start, B, N, npoint, coop=True)
+    assert int(b.min()) >= 0 and torch.equal(a, b)
 
 
 def test_ball_query_matches_pointnet_util(ops):
