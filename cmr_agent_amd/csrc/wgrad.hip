@@ -72,7 +72,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
       for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = (oy[ky] && ox[kx]) ? v[ky * 3 + kx] : 0.f;
   };
 
-  constexpr int NSET = 3;                         // two steps (20 loads) in flight
+  constexpr int NSET = 5;                         // four steps (40 loads, 2 300 MFMA cycles) in flight: every step touches new lines of
+                                                  // dY and of the lowest tap row, i.e. waits for an HBM miss (~2 000 cycles), not an L2 hit
   float sa[NSET], sv[NSET][9];
   int sp[NSET], sx[NSET], sy[NSET];
   auto advance = [&](int& xq, int& yq) {
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     CMR_WG_STEP(0, true)
     CMR_WG_STEP(1, q + 1 < w1)
     CMR_WG_STEP(2, q + 2 < w1)
+    CMR_WG_STEP(3, q + 3 < w1)
+    CMR_WG_STEP(4, q + 4 < w1)
   }
 #undef CMR_WG_STEP
 
