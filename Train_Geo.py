@@ -65,6 +65,7 @@ def main():
     ap.add_argument('--img', type=str, default=None, help="HxW network input size (multiples of 32), default from the config")
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--out', default=None, help="directory for checkpoints (default: config.ckpt_dir)")
+    ap.add_argument('--no-graph', action='store_true', help="launch every kernel of the step from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,6 +118,8 @@ def main():
                     os.makedirs(out_dir, exist_ok=True)
                     torch.save({k: v.detach().clone() for k, v in model.state_dict().items()},
                                os.path.join(out_dir, "epoch-%d-loss-%f.pth" % (epoch, x)))
+            if not args.no_graph and update._graph is None:
+                update.enable_graph(data)                                                        # forward + backward of this batch shape, captured once
             t0 = time.perf_counter()
             losses = update.step(data)
             if ranks.rank == 0:

@@ -215,6 +215,8 @@ def geo_train_main(args):
     up = GeoUpdate(model, cfg, dist=ranks.dist)
     batch = synthetic.make_batch(B, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, hip_fps(dev), hip_nearest(dev),
                                  seed=ranks.shard_seed(cfg.seed), n_circle=512, device=dev)
+    if not args.eager:
+        up.enable_graph(batch)          # forward + backward replayed from a hipGraph; all-reduce and Adam launched per step
     for _ in range(args.warmup):
         up.step(batch)
     ranks.barrier()

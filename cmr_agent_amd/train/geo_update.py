@@ -39,6 +39,8 @@ class GeoUpdate:
         self.grad_clip = grad_clip
         self.t = 0
         self._pos2d = {}
+        self._pos1d = {}
+        self._graph = None
 
     # ------------------------------------------------------------------------------------------------------ building blocks
     def _resblock(self, t, x, dims, blk, post=None):
@@ -136,7 +138,9 @@ class GeoUpdate:
         conv = emb.patch_embeddings
         co, ci = conv.weight.shape[0], conv.weight.shape[1]
         wm = conv.weight.detach().permute(0, 2, 3, 1).reshape(co, P * P * ci).contiguous()     # [(ky, kx, cin)] like patchify
-        pos = emb._pos_rows(T, f2.v.device)
+        if T not in self._pos1d:                               # own cache: the module's plan is dropped after every optimizer step
+            self._pos1d[T] = emb._pos_rows(T, f2.v.device).clone()
+        pos = self._pos1d[T]
         y = Var(ops.linear(patches.v, wm, t.W(conv.bias), res=pos, res_mod=T))
 
         def bwd():
@@ -283,8 +287,44 @@ class GeoUpdate:
                  self.weight_decay, self.t, grad_scale=1.0 / world, grad_clip=self.grad_clip)
         self.model.invalidate()
 
+    GRAPH_KEYS = ("img", "pc", "node", "pt2node", "pc_mask", "img_mask", "pc_idx_for_circle_loss", "pc_xy_int_for_circle_loss",
+                  "pc_xy_float_for_circle_loss")
+
+    def enable_graph(self, data):
+        """Capture forward + backward of one batch shape into a hipGraph (the optimizer launch and the all-reduce stay outside:
+        the bias corrections are launch arguments).  The step is ~3 300 launches, which the host issues about as fast as the GPU
+        executes them; replaying them removes the host from the loop.  `data`: a batch of the shape to train on (its tensors are
+        copied into static buffers; later batches are copied into the same buffers by step()).  BatchNorm running statistics
+        moved by the warm-up passes are restored."""
+        dev = self.bucket.params.device
+        self._static = {k: data[k].to(dev).clone() for k in self.GRAPH_KEYS}
+        saved = {n: b.detach().clone() for n, b in self.model.named_buffers()}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward_backward(self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_losses = self.forward_backward(self._static)
+        with torch.no_grad():
+            for n, b in self.model.named_buffers():
+                b.copy_(saved[n])
+        self._graph = graph
+
     def step(self, data):
-        losses = self.forward_backward(data)
+        if self._graph is not None:
+            for k, v in self._static.items():
+                src = data[k]
+                if tuple(src.shape) != tuple(v.shape):
+                    raise ValueError("GeoUpdate.step: batch tensor %s has shape %s, the captured graph was built for %s" % (k, tuple(src.shape), tuple(v.shape)))
+                v.copy_(src, non_blocking=True)
+            self._graph.replay()
+            losses = self._static_losses
+        else:
+            losses = self.forward_backward(data)
         self.optimizer_step()
         return losses
 

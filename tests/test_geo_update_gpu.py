@@ -194,3 +194,26 @@ def test_forty_steps_on_one_batch_reduce_every_loss():
     assert last["loss"] < 0.5 * first["loss"], (first, last)
     assert last["pc_overlap_loss"] < 0.25 * first["pc_overlap_loss"] and last["img_overlap_loss"] < 0.25 * first["img_overlap_loss"], (first, last)
     assert last["geometric_loss"] < first["geometric_loss"]
+
+
+def test_graph_replay_equals_eager_steps():
+    """GeoUpdate.enable_graph: forward + backward replayed from a hipGraph (Adam launched per step) must walk the same
+    trajectory as the eager path -- every kernel of the step is deterministic, so three steps on changing batches end with
+    bit-identical parameters, running statistics and losses; the warm-up passes of the capture leave no trace."""
+    from cmr_agent_amd.train import GeoUpdate
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batches = [_to_dev(b) for b in C.geo_train_batches(seeds=(2023, 2024, 2025))]
+    runs = []
+    for use_graph in (False, True):
+        model = _model(cfg, geo_sd)
+        up = GeoUpdate(model, cfg)
+        if use_graph:
+            up.enable_graph(batches[0])
+        losses = [{k: float(v) for k, v in up.step(b).items()} for b in batches]
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    (l0, s0), (l1, s1) = runs
+    assert l0 == l1
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
