@@ -377,6 +377,8 @@ constexpr int WS_SMEM_FLOATS = WS_T_OFF + 8 * 32 * WS_T_ROW;
 
 __device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// dbg: compile-time ablation mask used while tuning (see launch_wino_ws); the library instantiates 0 only, where every
+// `dbg & ...` test folds away.
 template <int dbg>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs a, const int tiles_x, const int tiles_y, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
