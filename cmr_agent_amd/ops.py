@@ -74,7 +74,7 @@ def cbr_block(x1, w1, b1, w2, b2, wsc, slope, x2=None, idx2=None, div2=1, rows_p
     part = torch.empty((ntiles, co), dtype=f32, device=x1.device) if want_colmax else None
     s1 = b1.stride(0) if b1.dim() == 2 else 0
     s2 = b2.stride(0) if b2.dim() == 2 else 0
-    rc = _lib.call("cmr_cbr_block_f32", _p(x1), _ld(x1), k1, _p(x2), _ld(x2) if x2 is not None else 0, _p(_i32(idx2)),
+    rc = _lib.call("cmr_cbr_block_bf16_f32" if CONV_BF16 else "cmr_cbr_block_f32", _p(x1), _ld(x1), k1, _p(x2), _ld(x2) if x2 is not None else 0, _p(_i32(idx2)),
                    int(div2), kx, ch, co, _p(w1), _p(b1), s1, _p(w2), _p(b2), s2, _p(wsc), _p(y), co, _p(part), rows, rpb,
                    float(slope), _stream(), allow_unsupported=True)
     if rc == _lib.UNSUPPORTED:

@@ -58,6 +58,7 @@ def _vecattn(a):
 WORK = {
     "cmr_linear_f32": _linear,
     "cmr_cbr_block_f32": _cbr,
+    "cmr_cbr_block_bf16_f32": _cbr,
     "cmr_colmax_partials_f32": lambda a: (0, F * a["B"] * a["tiles_per_batch"] * a["C"]),
     "cmr_layernorm64_f32": lambda a: (0, F * a["rows"] * 64 * (3 if a["res"] else 2)),
     "cmr_conv3x3_nhwc_f32": _conv,

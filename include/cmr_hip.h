@@ -56,6 +56,13 @@ int cmr_cbr_block_f32(const float* x1, int64_t ld1, int k1, const float* x2, int
                       int64_t div2, int kx, int ch, int co, const float* w1, const float* b1, int64_t b1_stride,
                       const float* w2, const float* b2, int64_t b2_stride, const float* wsc, float* y, int64_t ldy,
                       float* colmax_part, int64_t rows, int64_t rows_per_batch, float slope, hipStream_t stream);
+/* bf16 matrix-core variant of the same block (same arguments, fp32 rows / weights / biases; operands rounded to bf16 on their
+ * way into v_mfma_f32_32x32x16_bf16, fp32 accumulation; the hidden activations go from the accumulator registers of the first
+ * GEMM straight into the second as its bf16 operand).  Enabled by cmr_agent_amd.ops.CONV_BF16 (BASELINE configs[2] / [3]). */
+int cmr_cbr_block_bf16_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_t ld2, const int32_t* idx2,
+                           int64_t div2, int kx, int ch, int co, const float* w1, const float* b1, int64_t b1_stride,
+                           const float* w2, const float* b2, int64_t b2_stride, const float* wsc, float* y, int64_t ldy,
+                           float* colmax_part, int64_t rows, int64_t rows_per_batch, float slope, hipStream_t stream);
 int cmr_colmax_partials_f32(const float* part, float* out, int B, int tiles_per_batch, int C, hipStream_t stream);
 
 /* y = LayerNorm_64(x) * gamma + beta (+ res).  ImageViT.py:139-140, IMGPCEncoder.py:86-87 (eps 1e-6),

@@ -148,3 +148,58 @@ def test_agent_update_with_bf16_convolutions():
         worst = min(worst, cos)
         assert cos >= 0.98, (k, cos)
     print("  worst gradient cosine %.5f" % worst)
+
+
+@pytest.mark.parametrize("kx,ch,co,conv,k1,per_batch,colmax", [
+    (64, 64, 64, False, 64, False, False),      # identity shortcut, one source
+    (64, 64, 64, False, 32, False, False),      # identity shortcut over a concatenated [x1 | gathered x2] input
+    (128, 128, 64, True, 64, False, False),     # the first fuse block: cat of two 64-channel sources, conv shortcut
+    (64, 128, 64, True, 64, True, True),        # the agent's 3-D blocks: per-batch bias rows + column maxima
+    (64, 128, 128, False, 64, True, True),
+    (8, 8, 64, True, 8, False, True),           # the agent's first block (5 + 3 padding channels)
+])
+def test_cbr_block_bf16(kx, ch, co, conv, k1, per_batch, colmax):
+    """cmr_cbr_block_bf16_f32 against (a) a torch emulation that rounds the same operands to bf16 -- x, the weights and the
+    hidden activations on their way into the second GEMM -- with fp32 accumulation: agreement to 2e-3 of the output scale (a
+    hidden activation that sits on a bf16 rounding boundary may round the other way: one bf16 ulp of one product), and (b) the
+    fp32 block: 2e-2 of the output scale."""
+    from cmr_agent_amd import ops
+    B, rpb = 3, 352
+    rows = B * rpb
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    x1 = rnd(rows, k1, seed=61)
+    x2 = rnd(40, kx - k1, seed=62) if k1 < kx else None
+    idx = (torch.arange(rows) * 7 % 40).int() if x2 is not None else None
+    x = x1 if x2 is None else torch.cat([x1, x2[idx.long()]], 1)
+    w1, w2 = rnd(ch, kx, seed=63) / kx ** 0.5, rnd(co, ch, seed=64) / ch ** 0.5
+    wsc = rnd(co, kx, seed=65) / kx ** 0.5 if conv else None
+    b1 = rnd(B, ch, seed=66) if per_batch else rnd(ch, seed=66)
+    b2 = rnd(B, co, seed=67) if per_batch else rnd(co, seed=67)
+    rowb = torch.arange(rows) // rpb
+
+    def ref(rounded):
+        r = bf if rounded else (lambda t: t)
+        bb1 = b1[rowb] if per_batch else b1
+        bb2 = b2[rowb] if per_batch else b2
+        hid = F.leaky_relu(r(x).double() @ r(w1).double().t() + bb1.double(), 0.2)
+        hid = r(hid.float()).double()
+        y = hid @ r(w2).double().t() + bb2.double()
+        if conv:
+            y = y + r(x).double() @ r(wsc).double().t()
+        else:
+            y[:, :kx] += x.double()[:, :min(kx, co)] if kx <= co else 0
+        return F.leaky_relu(y, 0.2)
+    want_bf, want_fp = ref(True), ref(False)
+    d = lambda t: None if t is None else t.to(DEV)
+    ops.CONV_BF16 = True
+    try:
+        out = ops.cbr_block(d(x1), d(w1), d(b1), d(w2), d(b2), d(wsc), 0.2, x2=d(x2), idx2=d(idx), rows_per_batch=rpb, want_colmax=colmax)
+    finally:
+        ops.CONV_BF16 = False
+    assert out is not None
+    y, cm = out
+    scale = float(want_fp.abs().max())
+    assert float((y.cpu().double() - want_bf).abs().max()) <= 2e-3 * scale, float((y.cpu().double() - want_bf).abs().max()) / scale
+    assert float((y.cpu().double() - want_fp).abs().max()) <= 2e-2 * scale
+    if colmax:
+        assert torch.equal(cm.cpu(), y.cpu().view(B, rpb, co).max(1)[0])

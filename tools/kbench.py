@@ -138,8 +138,13 @@ def main():
             b2 = r(B, co) if perb else r(co)
             wsc = r(co, kx) if conv else None
             t = timeit(lambda: ops.cbr_block(x, w1, b1, w2, b2, wsc, 0.2, rows_per_batch=rows // B, want_colmax=True), a.reps)
+            ops.CONV_BF16 = True
+            tb = timeit(lambda: ops.cbr_block(x, w1, b1, w2, b2, wsc, 0.2, rows_per_batch=rows // B, want_colmax=True), a.reps)
+            ops.CONV_BF16 = False
             fl = 2.0 * rows * (kx * ch + ch * co + (kx * co if conv else 0))
-            print("cbr_block %3d->%3d->%3d sc=%d: %7.1f us (incl. colmax pass)  %5.1f TFLOP/s" % (kx, ch, co, conv, t, fl / t / 1e6))
+            by = 4.0 * rows * (kx + co)
+            print("cbr_block %3d->%3d->%3d sc=%d: %7.1f us (incl. colmax pass)  %5.1f TFLOP/s   | bf16 %7.1f us  %5.1f TFLOP/s  %5.2f TB/s" % (
+                kx, ch, co, conv, t, fl / t / 1e6, tb, fl / tb / 1e6, by / tb / 1e6))
     if "heads" in a.what:
         r = lambda *shape: torch.randn(*shape, device=DEV) * 0.1
         x, e3d = r(8 * 418, 128), r(8, 128)
