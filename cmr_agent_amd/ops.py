@@ -95,7 +95,8 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
     return out
 
 
-CONV_BF16 = False        # True: stride-1 3x3 convolutions run on the bf16 matrix cores (cmr_conv3x3_bf16_nhwc_f32) where served
+CONV_BF16 = False        # True: bf16 mode -- 3x3 convolutions (cmr_conv3x3_bf16_nhwc_f32) and ConvBNReLURes1D blocks
+                         # (cmr_cbr_block_bf16_f32) run on the bf16 matrix cores where served; storage and everything else stay fp32
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
 
