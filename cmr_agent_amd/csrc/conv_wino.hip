@@ -746,7 +746,7 @@ extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, in
   // take 32-cout workgroups, twice as many and three per CU
   const int64_t ntiles64 = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
   CMR_REQUIRE(2 * ntiles64 < 0x7fffffff);
-  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 512) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, stream);
+  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 200) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, stream);
   if (ntiles64 >= 512) return launch_wino<2>(a, tiles_x, tiles_y, ntiles64, stream);
   return launch_wino<1>(a, tiles_x, tiles_y, 2 * ntiles64, stream);
 }

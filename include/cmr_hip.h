@@ -86,7 +86,7 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
 int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,
                               hipStream_t stream);
-/* Process-wide switch between the two Winograd kernels for maps of >= 512 tiles (1 = wave-specialised persistent kernel,
+/* Process-wide switch between the two Winograd kernels for maps of >= 200 tiles (1 = wave-specialised persistent kernel,
  * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
 int cmr_set_wino_variant(int wave_specialised);
 

@@ -11,7 +11,7 @@ lib = _lib.load()
 torch.manual_seed(0)
 for (B, H, W, ci, co, res, post, pool) in [(8, 352, 1216, 64, 64, True, False, 1), (8, 176, 608, 64, 64, True, False, 1), (8, 88, 304, 128, 128, True, False, 1),
                                            (8, 88, 304, 128, 64, False, True, 1), (8, 88, 304, 64, 64, True, False, 1), (3, 301, 407, 64, 128, False, False, 1),
-                                           (8, 352, 1216, 64, 64, False, False, 2), (8, 88, 304, 256, 128, True, False, 1), (8, 44, 152, 128, 128, True, False, 1), (8, 88, 304, 64, 128, True, False, 1), (10, 88, 304, 128, 128, True, False, 1)]:
+                                           (8, 352, 1216, 64, 64, False, False, 2), (8, 88, 304, 256, 128, True, False, 1), (8, 44, 152, 128, 128, True, False, 1), (8, 88, 304, 64, 128, True, False, 1), (10, 88, 304, 128, 128, True, False, 1), (8, 22, 76, 128, 128, True, False, 1), (8, 22, 76, 128, 128, False, False, 2), (8, 44, 152, 128, 128, False, False, 2)]:
     x = torch.randn(B, H, W, ci, device=DEV)
     w9 = torch.randn(9, co, ci, device=DEV) / math.sqrt(9 * ci)
     wt = w9.view(3, 3, co, ci).permute(2, 3, 0, 1).contiguous()
