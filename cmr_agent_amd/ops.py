@@ -95,8 +95,9 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
     return out
 
 
-CONV_BF16 = False        # True: bf16 mode -- 3x3 convolutions (cmr_conv3x3_bf16_nhwc_f32) and ConvBNReLURes1D blocks
-                         # (cmr_cbr_block_bf16_f32) run on the bf16 matrix cores where served; storage and everything else stay fp32
+CONV_BF16 = False        # True: bf16 mode -- 3x3 convolutions (cmr_conv3x3_bf16_nhwc_f32), ConvBNReLURes1D blocks (cmr_cbr_block_bf16_f32)
+                         # and the query side of the linear-attention layers (cmr_la_query_layer_bf16_f32) run on the bf16 matrix cores
+                         # where served; storage and everything else stay fp32
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
 
@@ -287,7 +288,7 @@ def la_query_layer(x, kvsum, wq, wmerge, ln1, w0, w3, ln2, B, L, S, eps, ln_eps,
     does not serve the shape (too many batch states for LDS) so that the caller can take the unfused path."""
     if out is None:
         out = torch.empty((B * L, 64), dtype=f32, device=x.device)
-    rc = _lib.call("cmr_la_query_layer_f32", _p(_rows(x)), _ld(x), _p(kvsum), _p(wq), _p(wmerge), _p(ln1[0]), _p(ln1[1]),
+    rc = _lib.call("cmr_la_query_layer_bf16_f32" if CONV_BF16 else "cmr_la_query_layer_f32", _p(_rows(x)), _ld(x), _p(kvsum), _p(wq), _p(wmerge), _p(ln1[0]), _p(ln1[1]),
                    _p(w0), _p(w3), _p(ln2[0]), _p(ln2[1]), _p(out), _ld(out), B, L, S, float(eps), float(ln_eps),
                    _stream(), allow_unsupported=True)
     return None if rc == _lib.UNSUPPORTED else out

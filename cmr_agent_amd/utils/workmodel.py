@@ -83,6 +83,8 @@ WORK = {
     "cmr_la_kv_state_f32": lambda a: (2.0 * a["B"] * a["S"] * (2 * 4096 + 576), F * (a["B"] * a["S"] * 64 + 2 * 4096)),
     "cmr_la_query_layer_f32": lambda a: (2.0 * a["B"] * a["L"] * (4096 + 576 + 4096 + 16384 + 8192),
                                          F * (a["B"] * a["L"] * 128 + 2 * 4096 + 16384 + 8192)),
+    "cmr_la_query_layer_bf16_f32": lambda a: (2.0 * a["B"] * a["L"] * (4096 + 576 + 4096 + 16384 + 8192),
+                                         F * (a["B"] * a["L"] * 128 + 2 * 4096 + 16384 + 8192)),
     "cmr_vecattn_front_f32": _vecattn,
     "cmr_focal_metrics_f32": lambda a: (0, a["rows"] * 16),
     "cmr_circle_loss_f32": lambda a: (2.0 * a["B"] * a["n"] * a["n"] * 64, F * a["B"] * a["n"] * 128),

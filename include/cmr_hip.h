@@ -171,6 +171,13 @@ int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* kvsum, cons
                            const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
                            const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, int B, int L, int S, float eps,
                            float ln_eps, hipStream_t stream);
+/* bf16 matrix-core variant of the same layer (same arguments; the four GEMMs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation,
+ * operands rounded to bf16; the per-head state product, both LayerNorms and the residual stay fp32).  Enabled by
+ * cmr_agent_amd.ops.CONV_BF16. */
+int cmr_la_query_layer_bf16_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,
+                                const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
+                                const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, int B, int L, int S,
+                                float eps, float ln_eps, hipStream_t stream);
 
 /* Front half of the vector attention of GroupPointTransformer / KnnPointTransformer (PointNN.py:151-170, 219-226) in one
  * launch, per row r (a (point, owning node) or (node, neighbour) pair):

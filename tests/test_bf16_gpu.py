@@ -203,3 +203,46 @@ def test_cbr_block_bf16(kx, ch, co, conv, k1, per_batch, colmax):
     assert float((y.cpu().double() - want_fp).abs().max()) <= 2e-2 * scale
     if colmax:
         assert torch.equal(cm.cpu(), y.cpu().view(B, rpb, co).max(1)[0])
+
+
+@pytest.mark.parametrize("B,L,S", [(2, 70, 45), (1, 1280, 3000), (3, 2000, 1280)])
+def test_la_query_layer_bf16(B, L, S):
+    """cmr_la_query_layer_bf16_f32 against a torch emulation that rounds the operands of the four GEMMs to bf16 (fp32
+    accumulation; state product, LayerNorms, residual in fp32): 3e-3 of the output scale (a value on a bf16 rounding boundary
+    may round the other way), and against the fp32 layer: 3e-2."""
+    from cmr_agent_amd import ops
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    x = rnd(B * L, 64, seed=71)
+    y = rnd(B * S, 64, seed=72)
+    wq, wk, wv, wm = (rnd(64, 64, seed=73 + i) / 8 for i in range(4))
+    w0, w3 = rnd(128, 128, seed=77) / 11, rnd(64, 128, seed=78) / 11
+    g1, b1, g2, b2 = rnd(64, seed=79) + 1.5, rnd(64, seed=80), rnd(64, seed=81) + 1.5, rnd(64, seed=82)
+    d = lambda t: t.to(DEV)
+    kv = ops.la_kv_state(d(y), d(wk), d(wv), B, S)                  # fp32 state (the source side stays fp32)
+    kvc = kv.cpu().double().view(B, 576)
+
+    def ref(r):
+        q = F.elu(r(x).double() @ r(wq).double().t()) + 1                                   # [B*L, 64]
+        qh = q.view(B, L, 8, 8)
+        KV = kvc[:, :512].view(B, 8, 8, 8)                                                    # [b, head, d, v]
+        Ks = kvc[:, 512:].view(B, 8, 8)
+        num = torch.einsum("blhd,bhdv->blhv", qh, KV)
+        den = torch.einsum("blhd,bhd->blh", qh, Ks) + 1e-6
+        msg = (num / den.unsqueeze(-1) * S).reshape(B * L, 64)
+        m = F.layer_norm(r(msg.float()).double() @ r(wm).double().t(), (64,), g1.double(), b1.double(), 1e-5)
+        hid = F.relu(torch.cat([r(x).double(), r(m.float()).double()], 1) @ r(w0).double().t())
+        o = F.layer_norm(r(hid.float()).double() @ r(w3).double().t(), (64,), g2.double(), b2.double(), 1e-5)
+        return x.double() + o
+    want_bf, want_fp = ref(bf), ref(lambda t: t)
+    args = (d(x), kv, d(wq), d(wm), (d(g1), d(b1)), d(w0), d(w3), (d(g2), d(b2)), B, L, S, 1e-6, 1e-5)
+    ops.CONV_BF16 = True
+    try:
+        got = ops.la_query_layer(*args)
+    finally:
+        ops.CONV_BF16 = False
+    fp = ops.la_query_layer(*args)
+    assert got is not None and fp is not None
+    scale = float(want_fp.abs().max())
+    assert float((fp.cpu().double() - want_fp).abs().max()) <= 1e-4 * scale          # the emulation itself is the layer
+    assert float((got.cpu().double() - want_bf).abs().max()) <= 3e-3 * scale, float((got.cpu().double() - want_bf).abs().max()) / scale
+    assert float((got.cpu().double() - want_fp).abs().max()) <= 3e-2 * scale
