@@ -64,6 +64,18 @@ def frag_pack(w):
     return w.reshape(n // 32, 32, k // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
+def frag_pack_bf16(w, acc_order=False):
+    """W [n_out, k] (n_out % 32 == 0, k % 16 == 0) -> bf16 MFMA A fragments [n_out/32][k/16][64 lanes][8] for
+    v_mfma_f32_32x32x16_bf16: lane = 32 h + l holds W[32 tile + l][c(s, h, j)], j = 0..7.  Natural order: c = 16 s + 8 h + j (the
+    operand rows are read from memory).  acc_order: c = 32 (s // 2) + 8 (2 (s % 2) + j // 4) + 4 h + j % 4 -- the order in which
+    the accumulator tile of the previous GEMM holds its channels, so that those registers are the operand as they stand."""
+    n, k = w.shape
+    s, hh, j = torch.meshgrid(torch.arange(k // 16), torch.arange(2), torch.arange(8), indexing="ij")
+    c = 32 * (s // 2) + 8 * (2 * (s % 2) + j // 4) + 4 * hh + j % 4 if acc_order else 16 * s + 8 * hh + j       # [S, 2, 8]
+    f = w.reshape(n // 32, 32, k)[:, :, c.to(w.device)]                                                          # [T, 32, S, 2, 8]
+    return f.permute(0, 2, 3, 1, 4).contiguous().to(torch.bfloat16).reshape(-1)
+
+
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 

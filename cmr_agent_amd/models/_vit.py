@@ -31,9 +31,10 @@ class Attention(Planned):
         kv = (torch.cat([wk, wv], 0).contiguous(), torch.cat([bk, bv], 0).contiguous())
         qkv = (torch.cat([wq, wk, wv], 0).contiguous(), torch.cat([bq, bk, bv], 0).contiguous())
         wo, bo = _pack.lin(self.out)
-        f = _pack.frag_pack
+        f, fb = _pack.frag_pack, _pack.frag_pack_bf16
         return dict(q=(wq, bq), kv=kv, qkv=qkv, out=(wo, bo),
-                    q_f=(f(wq), bq), kv_f=(f(kv[0]), kv[1]), qkv_f=(f(qkv[0]), qkv[1]), out_f=(f(wo), bo))
+                    q_f=(f(wq), bq), kv_f=(f(kv[0]), kv[1]), qkv_f=(f(qkv[0]), qkv[1]), out_f=(f(wo), bo),
+                    q_b=(fb(wq), bq), kv_b=(fb(kv[0]), kv[1]), qkv_b=(fb(qkv[0]), qkv[1]), out_b=(fb(wo), bo))     # bf16 mode
 
     def rows(self, xn, yn, B, tx, ty, residual):
         """out-projection(softmax-attention(xn, yn)) + residual; yn is None for self-attention."""
@@ -61,7 +62,8 @@ class Mlp(Planned):
 
     def _build_plan(self):
         fc1, fc2 = _pack.lin(self.fc1), _pack.lin(self.fc2)
-        return dict(fc1=fc1, fc2=fc2, fc1_f=(_pack.frag_pack(fc1[0]), fc1[1]), fc2_f=(_pack.frag_pack(fc2[0]), fc2[1]))
+        return dict(fc1=fc1, fc2=fc2, fc1_f=(_pack.frag_pack(fc1[0]), fc1[1]), fc2_f=(_pack.frag_pack(fc2[0]), fc2[1]),
+                    fc1_b=(_pack.frag_pack_bf16(fc1[0], acc_order=True), fc1[1]), fc2_b=(_pack.frag_pack_bf16(fc2[0], acc_order=True), fc2[1]))
 
     def rows(self, xn, residual):
         p = self.plan()
@@ -91,13 +93,14 @@ class Block(Planned):
         p = self.plan()
         if self.FUSED and self.ffn.fc1.out_features == 1024:
             a, m = self.attn.plan(), self.ffn.plan()
+            sfx = "_b" if ops.CONV_BF16 else "_f"            # bf16 mode: bf16 weight fragments, bf16 matrix cores
             if y is None or y is x:
-                qkv = ops.ln64_linear(x, *a["qkv_f"], *p["n1"], self.LN_EPS)
+                qkv = ops.ln64_linear(x, *a["qkv" + sfx], *p["n1"], self.LN_EPS)
                 ctx = ops.mha(qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192], B, tx, tx)
             else:
-                q, kv = ops.ln64_linear(x, *a["q_f"], *p["n1"], self.LN_EPS, y, *a["kv_f"])
+                q, kv = ops.ln64_linear(x, *a["q" + sfx], *p["n1"], self.LN_EPS, y, *a["kv" + sfx])
                 ctx = ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, tx, ty)
-            return ops.vit_out_ffn(ctx, x, *a["out_f"], p["n2"], self.LN_EPS, *m["fc1_f"], *m["fc2_f"])
+            return ops.vit_out_ffn(ctx, x, *a["out" + sfx], p["n2"], self.LN_EPS, *m["fc1" + sfx], *m["fc2" + sfx])
         xn = ops.layernorm64(x, *p["n1"], self.LN_EPS)
         yn = None if (y is None or y is x) else ops.layernorm64(y, *p["n1"], self.LN_EPS)
         x = self.attn.rows(xn, yn, B, tx, ty, residual=x)

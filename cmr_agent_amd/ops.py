@@ -253,13 +253,14 @@ def ln64_linear(x, wf_x, bias_x, gamma, beta, eps, y=None, wf_y=None, bias_y=Non
     fragment-packed (_pack.frag_pack).  Returns out_x [rows_x, n_x] (and out_y [rows_y, n_y])."""
     nx = bias_x.numel()
     ox = torch.empty((x.shape[0], nx), dtype=f32, device=x.device)
+    name = "cmr_ln64_linear_bf16_f32" if wf_x.dtype == torch.bfloat16 else "cmr_ln64_linear_f32"       # by the fragments' dtype
     if y is None:
-        _lib.call("cmr_ln64_linear_f32", _p(_rows(x)), _ld(x), x.shape[0], _p(wf_x), _p(bias_x), nx, _p(ox), _ld(ox), None, 0, 0,
+        _lib.call(name, _p(_rows(x)), _ld(x), x.shape[0], _p(wf_x), _p(bias_x), nx, _p(ox), _ld(ox), None, 0, 0,
                   None, None, 0, None, 0, _p(gamma), _p(beta), float(eps), _stream())
         return ox
     ny = bias_y.numel()
     oy = torch.empty((y.shape[0], ny), dtype=f32, device=y.device)
-    _lib.call("cmr_ln64_linear_f32", _p(_rows(x)), _ld(x), x.shape[0], _p(wf_x), _p(bias_x), nx, _p(ox), _ld(ox), _p(_rows(y)),
+    _lib.call(name, _p(_rows(x)), _ld(x), x.shape[0], _p(wf_x), _p(bias_x), nx, _p(ox), _ld(ox), _p(_rows(y)),
               _ld(y), y.shape[0], _p(wf_y), _p(bias_y), ny, _p(oy), _ld(oy), _p(gamma), _p(beta), float(eps), _stream())
     return ox, oy
 
@@ -269,7 +270,7 @@ def vit_out_ffn(ctx, x, wo_f, bo, ln, eps, w1_f, b1, w2_f, b2):
     if b1.numel() != 1024 or bo.numel() != 64:
         raise ValueError("vit_out_ffn is instantiated for embed_dim 64 / mlp_dim 1024")
     out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
-    _lib.call("cmr_vit_out_ffn_f32", _p(_rows(ctx)), _ld(ctx), _p(_rows(x)), _ld(x), _p(wo_f), _p(bo), _p(ln[0]), _p(ln[1]),
+    _lib.call("cmr_vit_out_ffn_bf16_f32" if w1_f.dtype == torch.bfloat16 else "cmr_vit_out_ffn_f32", _p(_rows(ctx)), _ld(ctx), _p(_rows(x)), _ld(x), _p(wo_f), _p(bo), _p(ln[0]), _p(ln[1]),
               float(eps), _p(w1_f), _p(b1), _p(w2_f), _p(b2), _p(out), _ld(out), x.shape[0], _stream())
     return out
 

@@ -154,6 +154,16 @@ int cmr_ln64_linear_f32(const float* x, int64_t ldx, int64_t rows_x, const float
 int cmr_vit_out_ffn_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f, const float* bo,
                         const float* ln_g, const float* ln_b, float eps, const float* w1_f, const float* b1, const float* w2_f,
                         const float* b2, float* out, int64_t ldo, int64_t rows, hipStream_t stream);
+/* bf16 matrix-core variants of the two kernels above (same arguments; the _f weights are bf16 A fragments
+ * [n_out/32][k/16][64 lanes][8], cmr_agent_amd/models/_pack.py:frag_pack_bf16 -- natural k order for wf_x / wf_y / wo_f, accumulator
+ * order for w1_f / w2_f; products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; LayerNorm, GELU, biases, residuals fp32). */
+int cmr_ln64_linear_bf16_f32(const float* x, int64_t ldx, int64_t rows_x, const void* wf_x, const float* bias_x, int n_out_x,
+                             float* out_x, int64_t ldo_x, const float* y, int64_t ldy, int64_t rows_y, const void* wf_y,
+                             const float* bias_y, int n_out_y, float* out_y, int64_t ldo_y, const float* gamma, const float* beta,
+                             float eps, hipStream_t stream);
+int cmr_vit_out_ffn_bf16_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const void* wo_f, const float* bo,
+                             const float* ln_g, const float* ln_b, float eps, const void* w1_f, const float* b1, const void* w2_f,
+                             const float* b2, float* out, int64_t ldo, int64_t rows, hipStream_t stream);
 
 /* Fused linear-attention layer (LinearAttention.py:38-73) in two kernels; the unfused entry points above stay for
  * callers that need the intermediates.

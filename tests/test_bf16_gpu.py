@@ -246,3 +246,56 @@ def test_la_query_layer_bf16(B, L, S):
     assert float((fp.cpu().double() - want_fp).abs().max()) <= 1e-4 * scale          # the emulation itself is the layer
     assert float((got.cpu().double() - want_bf).abs().max()) <= 3e-3 * scale, float((got.cpu().double() - want_bf).abs().max()) / scale
     assert float((got.cpu().double() - want_fp).abs().max()) <= 3e-2 * scale
+
+
+@pytest.mark.parametrize("rows_x,rows_y", [(3344, 2048), (70, 33), (1, 0), (418, 0)])
+def test_vit_block_fused_pieces_bf16(rows_x, rows_y):
+    """cmr_ln64_linear_bf16_f32 (one or two row sets) and cmr_vit_out_ffn_bf16_f32 against a torch emulation that rounds the GEMM
+    operands to bf16 (normalised rows, ctx, LN(x1), the hidden activations, every weight; fp32 accumulation, LayerNorm / GELU /
+    biases / residuals in fp32): 3e-3 of the output scale (a value on a rounding boundary may round the other way), and against
+    the unrounded block at the bf16 bar (3e-2)."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import frag_pack_bf16
+    bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    idn = lambda t: t
+    g, b = rnd(64, seed=1, lo=0.5, hi=1.5), rnd(64, seed=2)
+    wq, bq = rnd(64, 64, seed=3, lo=-0.3, hi=0.3), rnd(64, seed=4)
+    wkv, bkv = rnd(128, 64, seed=5, lo=-0.3, hi=0.3), rnd(128, seed=6)
+    x = rnd(rows_x, 64, seed=7, lo=-2, hi=2)
+    ln = lambda t: F.layer_norm(t.double(), (64,), g.double(), b.double(), 1e-6)
+    d = lambda t: t.to(DEV).contiguous()
+
+    def proj(r, t, w, bias):
+        return r(ln(t).float()).double() @ r(w).double().T + bias.double()
+
+    def check(got, t, w, bias, tag):
+        want_bf, want_fp = proj(bf, t, w, bias), proj(idn, t, w, bias)
+        scale = float(want_fp.abs().max())
+        e_bf = float((got.cpu().double() - want_bf).abs().max()) / scale
+        e_fp = float((got.cpu().double() - want_fp).abs().max()) / scale
+        assert e_bf <= 3e-3 and e_fp <= 3e-2, (tag, e_bf, e_fp)
+    if rows_y:
+        y = rnd(rows_y, 64, seed=8, lo=-2, hi=2)
+        oq, okv = ops.ln64_linear(d(x), d(frag_pack_bf16(wq)), d(bq), d(g), d(b), 1e-6, d(y), d(frag_pack_bf16(wkv)), d(bkv))
+        check(oq, x, wq, bq, "ln-q")
+        check(okv, y, wkv, bkv, "ln-kv")
+    else:
+        wqkv, bqkv = torch.cat([wq, wkv], 0), torch.cat([bq, bkv], 0)
+        o = ops.ln64_linear(d(x), d(frag_pack_bf16(wqkv)), d(bqkv), d(g), d(b), 1e-6)
+        check(o, x, wqkv, bqkv, "ln-qkv")
+    ctx = rnd(rows_x, 64, seed=9)
+    wo, bo = rnd(64, 64, seed=10, lo=-0.3, hi=0.3), rnd(64, seed=11)
+    w1, b1 = rnd(1024, 64, seed=12, lo=-0.2, hi=0.2), rnd(1024, seed=13)
+    w2, b2 = rnd(64, 1024, seed=14, lo=-0.1, hi=0.1), rnd(64, seed=15)
+
+    def ref(r):
+        x1 = r(ctx).double() @ r(wo).double().T + bo.double() + x.double()
+        hid = F.gelu(r(ln(x1).float()).double() @ r(w1).double().T + b1.double())
+        return x1 + r(hid.float()).double() @ r(w2).double().T + b2.double()
+    want_bf, want_fp = ref(bf), ref(idn)
+    got = ops.vit_out_ffn(d(ctx), d(x), d(frag_pack_bf16(wo)), d(bo), (d(g), d(b)), 1e-6, d(frag_pack_bf16(w1, acc_order=True)), d(b1),
+                          d(frag_pack_bf16(w2, acc_order=True)), d(b2))
+    scale = float(want_fp.abs().max())
+    e_bf = float((got.cpu().double() - want_bf).abs().max()) / scale
+    e_fp = float((got.cpu().double() - want_fp).abs().max()) / scale
+    assert e_bf <= 3e-3 and e_fp <= 3e-2, (e_bf, e_fp)

@@ -101,6 +101,13 @@ def bench_vit(rows_x, rows_y, B, reps):
     _lib.load().cmr_set_mha_variant(old)
     t4 = timeit(lambda: ops.vit_out_ffn(q, x, wo, bo, (g, b), 1e-6, w1, b1, w2, b2), reps)
     print("vit block rows %d / %d: ln+qkv %.1f us  ln+q,kv %.1f us  mha %.1f us (vector-ALU kernel %.1f us)  out+ffn %.1f us" % (rows_x, rows_y, t1, t2, t3, t3v, t4))
+    from cmr_agent_amd.models._pack import frag_pack_bf16 as fb
+    wqb, wkvb, wqkvb = fb(r(64, 64)), fb(r(128, 64)), fb(r(192, 64))
+    wob, w1b, w2b = fb(r(64, 64)), fb(r(1024, 64), acc_order=True), fb(r(64, 1024), acc_order=True)
+    t1 = timeit(lambda: ops.ln64_linear(x, wqkvb, bqkv, g, b, 1e-6), reps)
+    t2 = timeit(lambda: ops.ln64_linear(x, wqb, bq, g, b, 1e-6, y, wkvb, bkv), reps)
+    t4 = timeit(lambda: ops.vit_out_ffn(q, x, wob, bo, (g, b), 1e-6, w1b, b1, w2b, b2), reps)
+    print("   bf16 fragments           : ln+qkv %.1f us  ln+q,kv %.1f us  out+ffn %.1f us" % (t1, t2, t4))
 
 
 def main():
