@@ -885,3 +885,65 @@ def linear_wgrad_any(dy, x, dw, accumulate=False, db=None, accumulate_db=False):
     if dy.shape[1] < n or x.shape[1] < k:
         raise ValueError("linear_wgrad_any: operand widths %d / %d vs gradient %s" % (dy.shape[1], x.shape[1], tuple(dw.shape)))
     linear_wgrad(dy, x, dw, dw.stride(0), n=n, k=k, accumulate=accumulate, db=db, accumulate_db=accumulate_db)
+
+
+# ---- IterModel (models/IterModel.py): the stages around the cost volume's convolutions ----------------------------------------
+
+def iter_sample_poses(r_amp, t_amp, nlabel):
+    """-> (delta_r [nlabel], delta_t [nlabel], rt [nlabel^3, 3, 4]: rows 0..2 of the inverse sampled poses)."""
+    dev = r_amp.device
+    dr, dt = torch.empty(nlabel, dtype=f32, device=dev), torch.empty(nlabel, dtype=f32, device=dev)
+    rt = torch.empty((nlabel ** 3, 3, 4), dtype=f32, device=dev)
+    _lib.call("cmr_iter_sample_poses_f32", _p(r_amp), _p(t_amp), int(nlabel), _p(dr), _p(dt), _p(rt), _stream())
+    return dr, dt, rt
+
+
+def iter_warp_scatter(pc_3n, feat_rows, score, mask_u8, standby_u8, rt, K, h, w):
+    """-> (acc [P, h, w, 64] feature sums, cnt [P, h, w], occ [P, h, w], sel [N] the point mask in use)."""
+    N, P = pc_3n.shape[1], rt.shape[0]
+    if tuple(pc_3n.shape) != (3, N) or tuple(feat_rows.shape) != (N, 64) or not (pc_3n.is_contiguous() and feat_rows.is_contiguous()):
+        raise ValueError("iter_warp_scatter: pc [3, N] planar and feat [N, 64] rows, contiguous")
+    if score.numel() != N or mask_u8.numel() != N or standby_u8.numel() != N or mask_u8.dtype != torch.uint8 or standby_u8.dtype != torch.uint8:
+        raise ValueError("iter_warp_scatter: score [N] float32, masks [N] uint8")
+    dev = pc_3n.device
+    acc = torch.empty((P, h, w, 64), dtype=f32, device=dev)
+    cnt, occ = torch.empty((P, h, w), dtype=f32, device=dev), torch.empty((P, h, w), dtype=f32, device=dev)
+    sel = torch.empty(N, dtype=torch.uint8, device=dev)
+    _lib.call("cmr_iter_warp_scatter_f32", _p(pc_3n), _p(feat_rows), _p(score), _p(mask_u8), _p(standby_u8), _p(sel), _p(rt), _p(K),
+              _p(acc), _p(cnt), _p(occ), N, P, h, w, _stream())
+    return acc, cnt, occ, sel
+
+
+def iter_finalize(acc, cnt, plane, w1, base):
+    """res [P, h, w, 64] = base [h, w, 64] + conv3x3(plane [P, h, w], w1 [9, 64]); acc (if given) becomes the scatter mean in place."""
+    P, h, w = plane.shape
+    res = torch.empty((P, h, w, 64), dtype=f32, device=plane.device)
+    _lib.call("cmr_iter_finalize_f32", _p(acc), _p(cnt), _p(plane), _p(w1), _p(base), _p(res), P, h, w, _stream())
+    return res
+
+
+def iter_head(x, w24, b24, w26, b26, slope):
+    """x [P, hh, ww, C >= 8] -> logits [P]: global average of channels 0..7, 8 -> 4, LeakyReLU, 4 -> 1."""
+    P, hh, ww, C = x.shape
+    logits = torch.empty(P, dtype=f32, device=x.device)
+    _lib.call("cmr_iter_head_f32", _p(x), C, hh * ww, _p(w24), _p(b24), _p(w26), _p(b26), float(slope), _p(logits), P, _stream())
+    return logits
+
+
+def iter_decide(logits, nlabel, label_r, label_tx, label_tz, delta_r, delta_t):
+    """-> (label [P], out_f [4] = (loss, ry, tx, tz), out_i [5] = (label, i_ry, i_tx, i_tz, i_joint), matrix_i [4, 4])."""
+    dev = logits.device
+    label = torch.empty(nlabel ** 3, dtype=f32, device=dev)
+    out_f, out_i = torch.empty(4, dtype=f32, device=dev), torch.empty(5, dtype=torch.int64, device=dev)
+    m = torch.empty((4, 4), dtype=f32, device=dev)
+    _lib.call("cmr_iter_decide_f32", _p(logits), int(nlabel), _p(label_r), _p(label_tx), _p(label_tz), _p(delta_r), _p(delta_t), _p(label),
+              _p(out_f), _p(out_i), _p(m), _stream())
+    return label, out_f, out_i, m
+
+
+def iter_apply(matrix_i, pc_3n, matrix_acc):
+    """-> (matrix_i[0:3, 0:3] pc + matrix_i[0:3, 3] as [3, N], matrix_i @ matrix_acc)."""
+    N = pc_3n.shape[1]
+    pc_out, acc_out = torch.empty_like(pc_3n), torch.empty((4, 4), dtype=f32, device=pc_3n.device)
+    _lib.call("cmr_iter_apply_f32", _p(matrix_i), _p(pc_3n), _p(pc_out), N, _p(matrix_acc), _p(acc_out), _stream())
+    return pc_out, acc_out

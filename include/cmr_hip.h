@@ -487,6 +487,37 @@ int cmr_circle_loss_bwd_f32(const float* pc_feat, const float* img_feat, const i
                             int B, int N, int h, int w, int n, float dist_thres, float pos_margin, float neg_margin, float log_scale,
                             float grad_scale, float* d_pc_feat, float* d_img_feat, void* ws, int64_t ws_bytes, hipStream_t stream);
 
+/* ---- IterModel: pose cost volume (models/IterModel.py:24-475) ------------------------------------------------
+ * The reference warps the predicted-overlap points of ONE pair under nlabel^3 sampled poses, scatter-means their features onto the
+ * 1/4-scale image grid, stacks [image features | warped features | occupancy | image overlap] per pose and runs a Conv3d chain with
+ * (1, 3, 3) kernels.  Here the volume is a batch of P = nlabel^3 NHWC maps on cmr_conv3x3_*_nhwc_f32; these entry points are the
+ * stages around the convolutions.
+ * cmr_iter_sample_poses_f32 (IterModel.py:132-173): delta_r / delta_t [nlabel] = 2 amp / (nlabel - 1) * (-(nlabel-1)/2 .. (nlabel-1)/2),
+ *   rt [P][3][4] = rows 0..2 of the inverse of [R_y(delta_r[i]) | (delta_t[j], 0, delta_t[k])], p = (i nlabel + j) nlabel + k.
+ * cmr_iter_warp_scatter_f32 (IterModel.py:273-345): sel = mask if any(mask) else standby; for selected points in view of pose p,
+ *   acc[p][y w + x][0:64] += feat[n], cnt += 1, occ += score[n] (pc planar [3][N], feat rows [N][64]; the accumulators are cleared here).
+ * cmr_iter_finalize_f32 (IterModel.py:347-377 and the one-channel input halves of cost_volume_convs[0]): acc <- acc / max(cnt, 1) when
+ *   acc is given; res[p][cell][0:64] = base[cell] + sum_taps w1[tap][c] plane[p][cell + tap] (zero padding), plane [P][h][w].
+ * cmr_iter_head_f32 (IterModel.py:62-66): global average of channels 0..7 of x [P][cells][ldc], 1x1 conv 8 -> 4, LeakyReLU, 4 -> 1.
+ * cmr_iter_decide_f32 (IterModel.py:175-193, 391-473): label_out [P] = label_r (x) (label_tx (x) label_tz); out_f = [cross entropy of
+ *   logits vs arg-max(label_out), chosen ry, tx, tz]; out_i = [label, arg-max of the three softmax marginals, arg-max of the joint];
+ *   matrix_i [4][4] = inverse of the chosen step.
+ * cmr_iter_apply_f32 (IterModel.py:466-472): pc_out = matrix_i[0:3, 0:3] pc + matrix_i[0:3, 3]; acc_out = matrix_i acc_in. */
+int cmr_iter_sample_poses_f32(const float* r_amp, const float* t_amp, int nlabel, float* delta_r, float* delta_t, float* rt,
+                              hipStream_t stream);
+int cmr_iter_warp_scatter_f32(const float* pc, const float* feat, const float* score, const uint8_t* mask, const uint8_t* standby,
+                              uint8_t* sel, const float* rt, const float* Kmat, float* acc, float* cnt, float* occ, int N, int P,
+                              int h, int w, hipStream_t stream);
+int cmr_iter_finalize_f32(float* acc, const float* cnt, const float* plane, const float* w1, const float* base, float* res, int P,
+                          int h, int w, hipStream_t stream);
+int cmr_iter_head_f32(const float* x, int ldc, int cells, const float* w24, const float* b24, const float* w26, const float* b26,
+                      float slope, float* logits, int P, hipStream_t stream);
+int cmr_iter_decide_f32(const float* logits, int nlabel, const float* label_r, const float* label_tx, const float* label_tz,
+                        const float* delta_r, const float* delta_t, float* label_out, float* out_f, int64_t* out_i,
+                        float* matrix_i, hipStream_t stream);
+int cmr_iter_apply_f32(const float* matrix_i, const float* pc, float* pc_out, int N, const float* acc_in, float* acc_out,
+                       hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

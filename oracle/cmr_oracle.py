@@ -906,3 +906,123 @@ def kitti_frame(raw, P_Tr, K, P_random, img_hw4, choice, perm, node_candidates, 
     node, _ = dataset_fps(pc[:, node_candidates], num_node, fps_start)    # :356-357
     out.update(pc=pc.astype(np.float32), node=np.asarray(node, dtype=np.float32), pt2node=np.asarray(nearest_node(pc, node), dtype=np.int64))
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# IterModel: 9^3 pose cost volume (models/IterModel.py:24-475)
+# ----------------------------------------------------------------------------------------------
+
+def iter_angle2matrix(angle):
+    """extrinsic-xyz Euler angles [..., 3] -> rotation matrices [..., 3, 3] (IterModel.py:98-130)."""
+    dims = list(angle.shape)
+    a = angle.reshape(-1, 3)
+    si, sj, sk = torch.sin(a[:, 0]), torch.sin(a[:, 1]), torch.sin(a[:, 2])
+    ci, cj, ck = torch.cos(a[:, 0]), torch.cos(a[:, 1]), torch.cos(a[:, 2])
+    cc, cs, sc, ss = ci * ck, ci * sk, si * ck, si * sk
+    M = torch.stack([cj * ck, sj * sc - cs, sj * cc + ss,
+                     cj * sk, sj * ss + cc, sj * cs - sc,
+                     -sj, cj * si, cj * ci], 1).to(torch.float32)
+    return M.view(dims + [3])
+
+
+def iter_sample_poses(r_amp, t_amp, nlabel=9):
+    """-> (delta_R [B, n], delta_T [B, n], inverse sampled poses [B, n, n, n, 3, 4]); pose (i, j, k) = rotation delta_R[i] about y,
+    translation (delta_T[j], 0, delta_T[k]) (IterModel.py:132-173)."""
+    base = torch.arange(-(nlabel - 1) // 2, (nlabel - 1) // 2 + 1).unsqueeze(0)
+    delta_R = (2 * r_amp / (nlabel - 1)) * base
+    delta_T = (2 * t_amp / (nlabel - 1)) * base
+    B = delta_R.shape[0]
+    ang = torch.stack([torch.zeros_like(delta_R), delta_R, torch.zeros_like(delta_R)], -1)       # [B, n, 3]
+    Rm = iter_angle2matrix(ang)                                                                    # [B, n, 3, 3]
+    RT = torch.eye(4).repeat(B, nlabel, nlabel, nlabel, 1, 1)
+    tx = delta_T.view(B, 1, nlabel, 1).expand(B, nlabel, nlabel, nlabel)
+    tz = delta_T.view(B, 1, 1, nlabel).expand(B, nlabel, nlabel, nlabel)
+    RT[..., 0, 3] = tx
+    RT[..., 2, 3] = tz
+    RT[..., 0:3, 0:3] = Rm.view(B, nlabel, 1, 1, 3, 3)
+    return delta_R, delta_T, torch.linalg.inv(RT)[..., 0:3, :]
+
+
+def iter_cost_volume_convs(w, x):
+    """cost_volume_convs (IterModel.py:39-67): Conv3d kernels (1, 3, 3) = one 3x3 convolution per pose slice, so the volume
+    [B, C, P, h, w] is run as a batch of B P maps.  x [P, C, h, w] -> logits [P]."""
+    lr = lambda t: F.leaky_relu(t, 0.01)
+
+    def conv(i, t, pad=1):
+        return F.conv2d(t, w["%d.weight" % i].squeeze(2), w["%d.bias" % i], padding=pad)
+
+    def bn(i, t):
+        s = w["%d.weight" % i] / torch.sqrt(w["%d.running_var" % i] + BN_EPS)
+        return t * s.view(1, -1, 1, 1) + (w["%d.bias" % i] - w["%d.running_mean" % i] * s).view(1, -1, 1, 1)
+    x = lr(bn(1, conv(0, x)))
+    x = F.avg_pool2d(lr(conv(3, x)), 2)
+    x = lr(bn(7, conv(6, x)))
+    x = F.avg_pool2d(lr(conv(9, x)), 2)
+    x = lr(bn(13, conv(12, x)))
+    x = F.avg_pool2d(lr(conv(15, x)), 2)
+    x = lr(bn(19, conv(18, x)))
+    x = lr(conv(21, x))
+    x = F.avg_pool2d(x, (x.shape[2], x.shape[3]))            # AvgPool3d((1, 5, 16)) on the 5 x 16 map the 160 x 512 image leaves
+    x = lr(conv(24, x, 0))
+    return conv(26, x, 0).view(-1)
+
+
+def iter_model(sd, data, nlabel=9, chunk=27):
+    """IterModel.forward (IterModel.py:250-475) for the batch of ONE pair it is written for (IterModel.py:273, :372).  `data`
+    holds what MultiHeadModel leaves in the batch dict plus R_amplitude / T_amplitude / label_* / matrix_accumulated.
+    Generalisation: the scatter's dump bin is h*w where the reference writes the literal 5120 (= 40 * 128, IterModel.py:317)."""
+    w = Weights(sd, "cost_volume_convs.")
+    pc_mask = data["pc_overlap_pred"][0].bool()
+    if pc_mask.sum() == 0:
+        pc_mask = data["pc_overlap_pred_standby"][0].bool()
+    delta_R, delta_T, rt = iter_sample_poses(data["R_amplitude"], data["T_amplitude"], nlabel)
+    P = nlabel ** 3
+    rt = rt.reshape(rt.shape[0], P, 3, 4)
+    pc = data["pc_i"].unsqueeze(1)                                                  # [1, 1, 3, N]
+    pc_rt = rt[:, :, :, 0:3] @ pc + rt[:, :, :, 3:4]
+    prj = data["K"].unsqueeze(1) @ pc_rt
+    prj[:, :, 0:2, :] = prj[:, :, 0:2, :] / prj[:, :, 2:3, :]
+    H, W = data["img"].shape[2] // 4, data["img"].shape[3] // 4
+    in_cam = (prj[:, :, 0] >= 0) & (prj[:, :, 0] <= W - 1) & (prj[:, :, 1] >= 0) & (prj[:, :, 1] <= H - 1) & (prj[:, :, 2] > 0)
+    in_cam = in_cam[:, :, pc_mask][0]                                              # [P, M]
+    xy = prj[:, :, 0:2, :].round().int()[:, :, :, pc_mask][0]                      # [P, 2, M]
+    idx = (xy[:, 1] * W + xy[:, 0]).long()
+    idx[~in_cam] = H * W
+    feat = data["pc_geo_feat"][0][:, pc_mask]                                       # [64, M]
+    score = data["pc_is_in_cam_scores"][0, pc_mask].unsqueeze(0).repeat(P, 1)
+    score[~in_cam] = 0.0
+    img_feat = data["img_geo_feat"][0]                                              # [64, h, w]
+    ov = data["img_overlap_pred"].reshape(1, 1, H, W).float()
+    logits, occ_all = [], []
+    for s in range(0, P, chunk):                                                    # the reference chunks by 200 poses (:330)
+        ii = idx[s:s + chunk]
+        n = ii.shape[0]
+        warped = scatter_mean(feat.unsqueeze(0).expand(n, -1, -1), ii.unsqueeze(1).expand(-1, feat.shape[0], -1), 2, H * W + 1)
+        occ = scatter_sum(score[s:s + chunk], ii, 1, H * W + 1)
+        warped, occ = warped[:, :, :H * W].reshape(n, -1, H, W), occ[:, :H * W].reshape(n, 1, H, W)
+        occ_all.append(occ)
+        x = torch.cat([img_feat.unsqueeze(0).expand(n, -1, -1, -1), warped, occ, ov.expand(n, -1, -1, -1)], 1)
+        logits.append(iter_cost_volume_convs(w, x))
+    logits = torch.cat(logits).unsqueeze(0)                                          # [1, P]
+    out = {"delta_R": delta_R, "delta_T": delta_T, "cost_colume_logits": logits, "3d_weight": torch.cat(occ_all).view(1, P, H, W),
+           "pc_idx": idx}
+    # cost_volume_ce_loss (IterModel.py:175-193)
+    lab = data["label_T_x"].float().unsqueeze(-1) @ data["label_T_z"].float().unsqueeze(-2)
+    lab = data["label_R"].float().unsqueeze(-1) @ lab.view(lab.shape[0], -1).unsqueeze(-2)
+    lab = lab.view(lab.shape[0], -1)
+    out["cost_volume_label"] = lab
+    out["cost_volume_loss"] = F.cross_entropy(logits, lab.argmax(1))
+    # marginal arg-maxes -> the step taken (IterModel.py:441-473)
+    pred = torch.softmax(logits, 1)[0].view(nlabel, nlabel, nlabel)
+    ry = delta_R[0][pred.sum(-1).sum(-1).argmax()].view(1)
+    tx = delta_T[0][pred.sum(0).sum(-1).argmax()].view(1)
+    tz = delta_T[0][pred.sum(0).sum(0).argmax()].view(1)
+    out["3d_weight_id"] = pred.view(-1).argmax()
+    m = torch.eye(4).unsqueeze(0)
+    m[:, 0:3, 0:3] = iter_angle2matrix(torch.stack([torch.zeros_like(ry), ry, torch.zeros_like(ry)], 1))
+    m[:, 0, 3], m[:, 2, 3] = tx, tz
+    m_inv = torch.linalg.inv(m)
+    out["matrix_i"] = m_inv
+    out["matrix_accumulated"] = m_inv @ data["matrix_accumulated"]
+    out["pc_i"] = m_inv[:, 0:3, 0:3] @ data["pc_i"] + m_inv[:, 0:3, 3:4]
+    return out

@@ -339,3 +339,48 @@ def frame_calib():
     Kq = 0.25 * Kq
     Kq[2, 2] = 1
     return P_Tr, Kq
+
+
+# ----------------------------------------------------------------------------------------------
+# IterModel: pose cost volume (models/IterModel.py:250-475).  The reference writes it for ONE pair on the
+# 160 x 512 image (40 x 128 feature map, literals at :317 / :372); nlabel is an attribute (:28), so the small case samples 3^3 poses
+# ----------------------------------------------------------------------------------------------
+ITER_CASES = {
+    "iter_model_n3": dict(nlabel=3, N=1200, r_amp=0.10, t_amp=1.5),
+    "iter_model_n9": dict(nlabel=9, N=3000, r_amp=0.20, t_amp=2.0),
+}
+ITER_TAG = "iter/"
+ITER_KEYS = ("delta_R", "delta_T", "cost_colume_logits", "3d_weight", "cost_volume_label", "cost_volume_loss", "3d_weight_id",
+             "matrix_i", "matrix_accumulated", "pc_i")
+TRAIN_FIXTURES = TRAIN_FIXTURES + tuple(sorted(ITER_CASES))
+
+
+def iter_inputs(case):
+    """The batch dict IterModel.forward reads: what MultiHeadModel leaves behind for one pair (features, overlap predictions,
+    scores) plus the sampling amplitudes, the one-hot-like labels and the accumulated pose."""
+    c = ITER_CASES[case]
+    n, N, H, W = c["nlabel"], c["N"], 160, 512
+    t = lambda name, shape, lo=-1.0, hi=1.0: u("%s/%s" % (case, name), shape, lo, hi)
+    pc = torch.stack([t("x", (N,), -22.0, 22.0), t("y", (N,), -2.5, 2.5), t("z", (N,), 3.0, 45.0)]).unsqueeze(0)      # camera frame
+    feat = F_normalize(t("pc_feat", (1, 64, N)))
+    img_feat = F_normalize(t("img_feat", (1, 64, H // 4, W // 4)))
+    labels = {}
+    for k in ("label_R", "label_T_x", "label_T_z"):
+        v = t(k, (1, n), 0.0, 1.0)
+        labels[k] = v / v.sum()
+    mat = torch.eye(4).unsqueeze(0)
+    mat[0, 0:3, 3] = torch.tensor([0.3, -0.1, 0.7])
+    return dict(pc_i=pc, pc_geo_feat=feat, img_geo_feat=img_feat, img=torch.zeros(1, 3, H, W),
+                K=torch.tensor([[[58.0, 0.0, 63.5], [0.0, 58.0, 19.5], [0.0, 0.0, 1.0]]]),
+                pc_overlap_pred=t("ov", (1, N), 0.0, 1.0) < 0.6, pc_overlap_pred_standby=t("ov2", (1, N), 0.0, 1.0) < 0.9,
+                pc_is_in_cam_scores=t("score", (1, N), 0.0, 1.0), img_overlap_pred=(t("img_ov", (1, H // 4, W // 4), 0.0, 1.0) < 0.7).float(),
+                R_amplitude=torch.tensor([c["r_amp"]]), T_amplitude=torch.tensor([c["t_amp"]]), matrix_accumulated=mat, **labels)
+
+
+def F_normalize(x):
+    return x / x.norm(dim=1, keepdim=True).clamp(min=1e-12)
+
+
+def iter_oracle(case, sd):
+    out = O.iter_model(sd, iter_inputs(case), ITER_CASES[case]["nlabel"])
+    return {k: torch.as_tensor(out[k]).float() if k in ("cost_volume_loss", "3d_weight_id") else out[k] for k in ITER_KEYS}

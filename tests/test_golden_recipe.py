@@ -18,7 +18,7 @@ import golden_util as G
 HERE = os.path.dirname(os.path.abspath(__file__))
 pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="reference tree not present")
 
-GENERATORS = ("make_golden.py", "make_golden_metrics.py", "make_golden_rollout.py", "make_golden_train.py", "make_golden_dataset.py")
+GENERATORS = ("make_golden.py", "make_golden_metrics.py", "make_golden_rollout.py", "make_golden_train.py", "make_golden_dataset.py", "make_golden_iter.py")
 
 
 @pytest.fixture(scope="module")

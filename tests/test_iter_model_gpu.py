@@ -1,0 +1,133 @@
+"""GPU tier, IterModel (models/IterModel.py:24-475): the pose cost volume on the HIP path against the fixtures made by
+running the reference's IterModel on CPU (tests/golden/make_golden_iter.py) and against the oracle's intermediates.
+
+What differs from the reference by construction, and how the tolerances account for it:
+  * the sampled poses are inverted in closed form ([R | t]^-1 = [R^T | -R^T t]) where the reference calls torch.linalg.inv, and sinf / cosf
+    are the device's: the 3 x 4 matrices agree to 1e-6; a projected point that sits within ~1e-5 px of a rounding boundary may land in
+    the neighbouring cell, so occupancy / warped features are compared cell-wise with a bound on the FRACTION of cells that differ;
+  * scatter sums are float atomics (summation order varies) and the first convolution is split into image half / planes / warped
+    half: logits agree to 4e-6 absolute on values of order 2e-2.
+With hash-filled weights the global pooling leaves the logits nearly pose-independent (spread ~1e-5), so the arg-max decisions are
+checked for consistency with the device's own logits AND against the fixture wherever the fixture's margin is above the tolerance."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases as C
+import golden_util as G
+from cmr_agent_amd.utils import hashfill
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+LOGIT_ATOL = 4e-6            # measured (profiles/r02_iter_model.txt): 1.1e-8 at 27 poses / 1 200 points, 1.7e-6 at 729 poses / 3 000 points
+
+
+def _model(nlabel):
+    from cmr_agent_amd.models import IterModel
+    from cmr_agent_amd.config import KittiConfiguration
+    m = IterModel(KittiConfiguration(device=DEV))
+    m.nlabel = nlabel
+    sd = hashfill.make_state_dict(SPECS["iter"], C.ITER_TAG)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all(k.endswith("num_batches_tracked") for k in missing), (missing, unexpected)
+    return m.to(DEV).eval(), sd
+
+
+def test_pose_sampling_and_warp_scatter_vs_oracle():
+    """cmr_iter_sample_poses_f32 / cmr_iter_warp_scatter_f32 / cmr_iter_finalize_f32 against the oracle's poses, cell indices,
+    scatter-mean and occupancy (nlabel = 3)."""
+    from cmr_agent_amd import ops
+    from oracle import cmr_oracle as O
+    case = "iter_model_n3"
+    n = C.ITER_CASES[case]["nlabel"]
+    data = C.iter_inputs(case)
+    dR, dT, rt = O.iter_sample_poses(data["R_amplitude"], data["T_amplitude"], n)
+    d = lambda t: t.to(DEV).contiguous()
+    gr, gt, grt = ops.iter_sample_poses(d(data["R_amplitude"]), d(data["T_amplitude"]), n)
+    assert torch.equal(gr.cpu(), dR[0]) and torch.equal(gt.cpu(), dT[0])
+    assert float((grt.cpu() - rt.reshape(-1, 3, 4)).abs().max()) <= 2e-6
+    H, W = 40, 128
+    feat_rows = d(data["pc_geo_feat"][0].t())
+    u8 = lambda t: d(t.reshape(-1).to(torch.uint8))
+    acc, cnt, occ, sel = ops.iter_warp_scatter(d(data["pc_i"][0]), feat_rows, d(data["pc_is_in_cam_scores"][0]), u8(data["pc_overlap_pred"]),
+                                               u8(data["pc_overlap_pred_standby"]), grt, d(data["K"]).view(-1), H, W)
+    assert torch.equal(sel.cpu().bool(), data["pc_overlap_pred"][0])
+    ora = O.iter_model(hashfill.make_state_dict(SPECS["iter"], C.ITER_TAG), C.iter_inputs(case), n)
+    idx = ora["pc_idx"]                                                         # [P, M] cell of every selected point, H*W = out of view
+    want_cnt = torch.zeros(n ** 3, H * W + 1).scatter_add_(1, idx, torch.ones(idx.shape))[:, :H * W]
+    diff_cells = float((cnt.cpu().view(n ** 3, -1) != want_cnt).float().mean())
+    assert diff_cells <= 2e-4, diff_cells                                        # rounding-boundary points only
+    same = (cnt.cpu().view(n ** 3, -1) == want_cnt)
+    want_occ = ora["3d_weight"].view(n ** 3, -1)
+    assert float(((occ.cpu().view(n ** 3, -1) - want_occ).abs() * same).max()) <= 1e-5
+    # scatter mean + the occupancy stencil of the first convolution
+    w1 = torch.from_numpy(hashfill.uniform("case/iter/w1", (9, 64)).astype(np.float32))
+    base = torch.from_numpy(hashfill.uniform("case/iter/base", (H * W, 64)).astype(np.float32))
+    res = ops.iter_finalize(acc, cnt, occ, d(w1), d(base))
+    feat = data["pc_geo_feat"][0][:, data["pc_overlap_pred"][0]]                  # [64, M]
+    P = n ** 3
+    want_mean = O.scatter_mean(feat.unsqueeze(0).expand(P, -1, -1), idx.unsqueeze(1).expand(-1, 64, -1), 2, H * W + 1)[:, :, :H * W]
+    got_mean = acc.cpu().view(P, H * W, 64).permute(0, 2, 1)
+    assert float(((got_mean - want_mean).abs() * same.unsqueeze(1)).max()) <= 1e-5
+    occ_c = occ.cpu().view(P, 1, H, W)
+    want_res = torch.nn.functional.conv2d(occ_c, w1.t().reshape(64, 1, 3, 3), padding=1).permute(0, 2, 3, 1) + base.view(1, H, W, 64)
+    assert float((res.cpu() - want_res).abs().max()) <= 1e-4
+    # no selected point at all -> the standby mask is used (IterModel.py:274-275)
+    none = torch.zeros_like(u8(data["pc_overlap_pred"]))
+    _, _, _, sel2 = ops.iter_warp_scatter(d(data["pc_i"][0]), feat_rows, d(data["pc_is_in_cam_scores"][0]), none, u8(data["pc_overlap_pred_standby"]),
+                                          grt, d(data["K"]).view(-1), H, W)
+    assert torch.equal(sel2.cpu().bool(), data["pc_overlap_pred_standby"][0])
+
+
+@pytest.mark.parametrize("case", sorted(C.ITER_CASES))
+def test_iter_model_forward_vs_reference_fixture(case):
+    n = C.ITER_CASES[case]["nlabel"]
+    model, sd = _model(n)
+    data = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in C.iter_inputs(case).items()}
+    pc_before = data["pc_i"].clone()
+    assert model(data) == 0
+    fx = G.load_case(case)
+    named = {k: data[k] for k in C.ITER_KEYS}
+    # exact or near-exact pieces
+    G.assert_case(case, named, atol=0, rtol=0, only=("delta_R", "delta_T", "cost_volume_label"))
+    G.assert_case(case, named, atol=LOGIT_ATOL, rtol=0, only=("cost_colume_logits",))
+    G.assert_case(case, {"cost_volume_loss": named["cost_volume_loss"].reshape(())}, atol=1e-5, rtol=0)
+    e = G.compare("3d_weight", named["3d_weight"], fx["3d_weight"], atol=1e-5, rtol=1e-5)
+    if e is not None:                                                            # cells next to a rounding boundary
+        s = named["3d_weight"].cpu().numpy().reshape(-1)[::fx["3d_weight"]["stride"]]
+        bad = float((np.abs(s - fx["3d_weight"]["sample"]) > 1e-5).mean())
+        assert bad <= 5e-4, (bad, e)
+    # decisions: consistent with the device's own logits ...
+    logits = named["cost_colume_logits"].cpu()[0]
+    pred = torch.softmax(logits.double(), 0).view(n, n, n)
+    m = named["matrix_i"].cpu()[0]
+    i_ry, i_tx, i_tz = int(pred.sum((1, 2)).argmax()), int(pred.sum((0, 2)).argmax()), int(pred.sum((0, 1)).argmax())
+    ry, tx, tz = float(named["delta_R"][0, i_ry]), float(named["delta_T"][0, i_tx]), float(named["delta_T"][0, i_tz])
+    want = torch.eye(4, dtype=torch.float64)
+    want[0, 0], want[0, 2], want[2, 0], want[2, 2] = np.cos(ry), np.sin(ry), -np.sin(ry), np.cos(ry)
+    want[0, 3], want[2, 3] = tx, tz
+    assert float((m.double() - torch.linalg.inv(want)).abs().max()) <= 1e-6
+    assert int(named["3d_weight_id"]) == int(logits.argmax())
+    assert float((named["pc_i"].cpu()[0].double() - (m[:3, :3].double() @ pc_before.cpu()[0].double() + m[:3, 3:4].double())).abs().max()) <= 1e-4
+    acc0 = C.iter_inputs(case)["matrix_accumulated"][0]
+    assert float((named["matrix_accumulated"].cpu()[0] - m @ acc0).abs().max()) <= 1e-5
+    # ... and equal to the reference's wherever the reference's own margin exceeds what the logits' tolerance can move
+    gold_logits = torch.from_numpy(fx["cost_colume_logits"]["sample"]).double()
+    if gold_logits.numel() == n ** 3:
+        gp = torch.softmax(gold_logits, 0).view(n, n, n)
+        margins = [gp.sum(ax).sort(descending=True)[0] for ax in ((1, 2), (0, 2), (0, 1))]
+        if all(float(s[0] - s[1]) > 4 * n * n * LOGIT_ATOL * float(gp.max()) for s in margins):
+            G.assert_case(case, named, atol=1e-5, rtol=1e-5, only=("matrix_i", "matrix_accumulated", "pc_i"))
+        if float(gold_logits.sort(descending=True)[0][0] - gold_logits.sort(descending=True)[0][1]) > 2 * LOGIT_ATOL:
+            G.assert_case(case, {"3d_weight_id": named["3d_weight_id"].float()}, atol=0, rtol=0)
+
+
+def test_iter_model_state_dict_is_the_references():
+    from cmr_agent_amd.models import IterModel
+    from cmr_agent_amd.config import KittiConfiguration
+    sd = IterModel(KittiConfiguration(device="cpu")).state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == SPECS["iter"]

@@ -171,3 +171,10 @@ def test_kitti_frame_geometry():
     out = O.kitti_frame(i["raw"], i["P_Tr"], i["K"], i["P_random"], (f["H"] // 4, f["W"] // 4), i["choice"], i["perm"], i["cand"],
                         i["fps_start"], f["num_node"])
     G.assert_case("kitti_frame", {k: out[k] for k in FRAME_KEYS}, atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("case", sorted(C.ITER_CASES))
+def test_iter_model(case):
+    """oracle.iter_model vs the fixture made by running the reference's models/IterModel.py (tests/golden/make_golden_iter.py)."""
+    sd = hashfill.make_state_dict(SPECS["iter"], C.ITER_TAG)
+    G.assert_case(case, C.iter_oracle(case, sd), atol=1e-6, rtol=1e-6)

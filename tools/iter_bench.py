@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""IterModel on the device: errors against the reference fixture and the time of one forward (729 poses, 40 x 128 maps)
+with its stages.  python tools/iter_bench.py [--points N] [--bf16]"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases as C  # noqa: E402
+import golden_util as G  # noqa: E402
+from cmr_agent_amd import ops  # noqa: E402
+from cmr_agent_amd.config import KittiConfiguration  # noqa: E402
+from cmr_agent_amd.models import IterModel  # noqa: E402
+from cmr_agent_amd.utils import hashfill  # noqa: E402
+from cmr_agent_amd.utils.workmodel import CallTimer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    torch.set_grad_enabled(False)
+    specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+    m = IterModel(KittiConfiguration(device="cuda"))
+    m.load_state_dict(hashfill.make_state_dict(specs["iter"], C.ITER_TAG), strict=False)
+    m = m.cuda().eval()
+    for case in sorted(C.ITER_CASES):
+        m.nlabel = C.ITER_CASES[case]["nlabel"]
+        data = {k: v.cuda() for k, v in C.iter_inputs(case).items()}
+        m(data)
+        fx = G.load_case(case)
+        lg = data["cost_colume_logits"].cpu().numpy().reshape(-1)
+        ref = fx["cost_colume_logits"]["sample"]
+        occ = data["3d_weight"].cpu().numpy().reshape(-1)[::fx["3d_weight"]["stride"]]
+        print("%s: logits max|d| %.2e (values %.3e .. %.3e, spread %.2e); occupancy cells off %.2e; loss d %.1e; joint arg-max %d vs %d" % (
+            case, np.abs(lg - ref).max(), ref.min(), ref.max(), ref.max() - ref.min(), float((np.abs(occ - fx["3d_weight"]["sample"]) > 1e-5).mean()),
+            abs(float(data["cost_volume_loss"]) - float(fx["cost_volume_loss"]["sample"][0])), int(data["3d_weight_id"]),
+            int(fx["3d_weight_id"]["sample"][0])))
+    # timing at the BASELINE point count
+    ops.CONV_BF16 = a.bf16
+    m.nlabel = 9
+    c = dict(C.ITER_CASES["iter_model_n9"], N=a.points)
+    C.ITER_CASES["bench"] = c
+    base = {k: v.cuda() for k, v in C.iter_inputs("bench").items()}
+    run = lambda: m(dict(base))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.reps):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / a.reps
+    print("IterModel forward, 729 poses, %d points (%.0f %% selected), 40x128 maps, %s: %.2f ms" % (
+        a.points, 100 * float(base["pc_overlap_pred"].float().mean()), "bf16 convolutions" if a.bf16 else "fp32", ms))
+    timer = CallTimer()
+    with timer:
+        run()
+    torch.cuda.synchronize()
+    for d in timer.table():
+        print("   %-34s %3d calls %8.3f ms" % (d["name"], d["calls"], d["ms"]))
+
+
+if __name__ == "__main__":
+    main()
