@@ -15,6 +15,7 @@
 //   * B operand = 32 pixels x 16 channels of one tap straight from the halo image (lane = pixel), A = weight fragment;
 //     every MFMA is fed by at most two ds_read_b128, which the LDS array sustains (MI355X_MICROARCH.md, LDS issue rates).
 #include "cmr_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -27,6 +28,10 @@ struct B16Args {
   const float* bias; const float* res; const float* post;
   float* y; int Cout; float slope; int pool;
   int tiles_x, tiles_y;
+  // 0 / 1 multipliers of the optional operands' offsets, set by the HOST: a null operand is read at offset 0 of a zero page.  Written
+  // as `ptr ? offset : 0` in the kernel, hipcc turns every such select into a branch around the address arithmetic, and one branch
+  // in the tile loop degrades each later s_waitcnt to vmcnt(0) (81 of them in the first version of this kernel)
+  int res_mul, bias_mul;
 };
 
 __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -36,7 +41,7 @@ __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.
 // S = stride (1 | 2): the output tile stays TH x TW, the halo image grows to ((TH - 1) S + 3) x ((TW - 1) S + 3) input pixels and a
 // lane's pixel sits at (S row + ky, S column + kx) in it (S = 2: 288 bytes between neighbouring lanes = 8 banks apart, still
 // conflict free).  a.H / a.W are the INPUT sizes; the output is ((H - 1) / S + 1) x ((W - 1) / S + 1).
-template <int CIN, int NT, int TW, int S = 1>
+template <int CIN, int NT, int TW, int S = 1, bool POOL = false, bool POST = false>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   constexpr int KS = CIN / 16, NB = TW / 16;
   constexpr int TH = 8, HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
@@ -45,6 +50,12 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   constexpr int C4 = CIN / 4;
   constexpr int NPIECE = HR * HC * C4;
   constexpr int NLOAD = (NPIECE + 255) / 256;
+  // halo images kept in flight in registers: two where the register budget (512 per lane at one wave per SIMD) allows it
+#ifdef B16_DEPTH
+  constexpr int NBUF = B16_DEPTH;
+#else
+  constexpr int NBUF = (NLOAD * 8 + NT * NB * (POST ? 48 : 32)) <= 280 ? 2 : 1;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ws = smem;
   unsigned char* Xs = smem + WBYTES;
@@ -52,26 +63,75 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
   const int ngroups = a.Cout / (32 * NT);
-  const int group = blockIdx.x % ngroups;
+  // Workgroup -> (cout group, first tile, tile stride).  Workgroups land on the 8 XCDs round-robin by blockIdx and every XCD has
+  // its own L2: when the grid divides evenly and there are several cout groups, the `ngroups` workgroups that walk over the SAME
+  // tiles (one per cout group) and the families that take NEIGHBOURING tiles are put on one XCD, and every XCD gets one contiguous
+  // band of tiles -- the input is then fetched from HBM once per XCD instead of once per cout group (88x304 128->128: 188 -> 177 us).
+  // With ONE cout group the banded order measured 2-7 % slower at 352x1216, so it keeps the plain round-robin order.
+  int group, s, step, s_end;
+  {
+    const int nsp_all = a.B * a.tiles_y * a.tiles_x;
+    const int nfam = gridDim.x / ngroups;                     // families = workgroups per cout group
+#ifndef B16_NO_XCD
+    if (nfam % 8 == 0 && ngroups > 1) {
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      const int fam_x = nfam >> 3;                            // families per XCD
+      group = slot % ngroups;
+      const int fam = slot / ngroups;                         // 0 .. fam_x - 1
+      const int band0 = (int)((int64_t)nsp_all * xcd / 8), band1 = (int)((int64_t)nsp_all * (xcd + 1) / 8);
+      s = band0 + fam; step = fam_x; s_end = band1;
+    } else
+#endif
+    {
+      group = blockIdx.x % ngroups;
+      s = blockIdx.x / ngroups; step = nfam; s_end = nsp_all;
+    }
+  }
   const int co0 = group * 32 * NT;
   {
     const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(a.wfrag) + (size_t)group * WBYTES);
     for (int i = tid; i < WBYTES / 16; i += 256) reinterpret_cast<uint4*>(Ws)[i] = src[i];
   }
-  const int nsp = a.B * a.tiles_y * a.tiles_x;
-  const int step = gridDim.x / ngroups;
+  const int nsp = s_end;
+  if (s >= nsp) return;                                  // (uniform) nothing to do for this workgroup
 
   struct Tile { int b, oy0, ox0; };
-  auto decode = [&](int s) {
+  auto decode = [&](int st) __attribute__((always_inline)) {
     Tile t;
-    t.ox0 = (s % a.tiles_x) * TW; s /= a.tiles_x;
-    t.oy0 = (s % a.tiles_y) * TH;
-    t.b = s / a.tiles_y;
+    t.ox0 = (st % a.tiles_x) * TW; st /= a.tiles_x;
+    t.oy0 = (st % a.tiles_y) * TH;
+    t.b = st / a.tiles_y;
     return t;
   };
-  f32x4 pv[NLOAD];
-  auto issue_loads = [&](int s) {                      // branch-free: clamped addresses, padding applied at the LDS store
-    const Tile t = decode(s);
+  // The tile loop is straight-line code with no load in its epilogue.  What that took (each item was a measured stall):
+  //  * optional operands are read through host-made 0 / 1 offset multipliers (B16Args) from a zero page instead of `ptr ? .. : ..`
+  //    (hipcc turns the selects into branches, and a branch degrades every later s_waitcnt to vmcnt(0));
+  //  * the folded-BN bias is loaded ONCE per workgroup; residual (and table) rows of the tile are requested before its multiplies,
+  //    AHEAD of the next halo image in issue order (loads retire in order: the epilogue then waits with a counted vmcnt that leaves
+  //    the halo prefetch in flight).  The first version loaded bias / residual / table inside the epilogue, where the second pixel
+  //    block's loads were sunk into the first block's predicated store region: 16 dependent loads, each behind s_waitcnt vmcnt(0),
+  //    ~10 of the 12.7 us a tile took;
+  //  * every output of the tile is computed in place in the accumulators and pinned before the first predicated store.
+  f32x4 pv[NBUF][NLOAD];
+  f32x4 rv[NB][NT][4];
+  f32x4 tv[POST ? NB : 1][POST ? NT : 1][4];
+  f32x4 bsr[NT][4];
+  const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const float* rbase = a.res ? a.res : b16_zero16;       // pointer selects once, outside the tile loop
+  const float* bbase = a.bias ? a.bias : b16_zero16;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bsr[nt][q] = *reinterpret_cast<const f32x4*>(bbase + (co0 + nt * 32 + q * 8 + 4 * h) * a.bias_mul);
+  // this lane's pixel inside the tile, per block
+  int prow[NB], pcol[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    prow[nb] = TW == 32 ? 2 * wave + nb : 2 * wave + (l31 >> 4);
+    pcol[nb] = TW == 32 ? l31 : (l31 & 15);
+  }
+  auto issue_loads = [&](int st, f32x4 (&dst)[NLOAD]) __attribute__((always_inline)) {   // branch-free: clamped addresses, padding applied at the LDS store
+    const Tile t = decode(st);
     const float* xb = a.x + (int64_t)t.b * a.H * a.W * CIN;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
@@ -81,11 +141,11 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       int iy = t.oy0 * S - 1 + p / HC, ix = t.ox0 * S - 1 + p % HC;
       iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
       ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
-      pv[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN + 4 * c));
+      dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN + 4 * c));
     }
   };
-  auto store_lds = [&](int s) {
-    const Tile t = decode(s);
+  auto store_lds = [&](int st, const f32x4 (&src)[NLOAD]) __attribute__((always_inline)) {
+    const Tile t = decode(st);
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       const int e = tid + 256 * i;
@@ -95,29 +155,40 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
         const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
         bf16x4 v;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (__bf16)(inb ? pv[i][k] : 0.f);
+        for (int k = 0; k < 4; ++k) v[k] = (__bf16)(inb ? src[i][k] : 0.f);
         *reinterpret_cast<bf16x4*>(Xs + p * PS + c * 8) = v;
       }
     }
   };
-
-  int s = blockIdx.x / ngroups;
-  if (s < nsp) issue_loads(s);
-  // this lane's pixel inside the tile, per block
-  int prow[NB], pcol[NB];
+  auto issue_rows = [&](const Tile& t) __attribute__((always_inline)) {   // residual (+ table) rows of this tile; null operands: the zero page
+    if constexpr (!POOL) {
 #pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    prow[nb] = TW == 32 ? 2 * wave + nb : 2 * wave + (l31 >> 4);
-    pcol[nb] = TW == 32 ? l31 : (l31 & 15);
-  }
-  for (; s < nsp; s += step) {
-    __syncthreads();                                    // weights resident (first pass) / everybody done with the previous halo image
-    store_lds(s);
-    __syncthreads();
-    {
-      const int sn = s + step < nsp ? s + step : s;     // last tile: a harmless re-read instead of a branch around the loads
-      issue_loads(sn);
+      for (int nb = 0; nb < NB; ++nb) {
+        const int oy = t.oy0 + prow[nb], ox = t.ox0 + pcol[nb];
+        const bool ok = oy < Ho && ox < Wo;
+        const int oyc = ok ? oy : 0, oxc = ok ? ox : 0;
+        const int64_t pix = ((int64_t)t.b * Ho + oyc) * Wo + oxc;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int cq = co0 + nt * 32 + q * 8 + 4 * h;
+            rv[nb][nt][q] = *reinterpret_cast<const f32x4*>(rbase + (pix * a.Cout + cq) * a.res_mul);
+            if constexpr (POST) tv[nb][nt][q] = *reinterpret_cast<const f32x4*>(a.post + ((int64_t)oyc * Wo + oxc) * a.Cout + cq);
+          }
+      }
     }
+  };
+  issue_loads(s, pv[0]);
+  if (NBUF == 2) issue_loads(s + step < nsp ? s + step : s, pv[NBUF - 1]);
+  auto tile_pass = [&](auto PTAG) __attribute__((always_inline)) {
+    constexpr int P = decltype(PTAG)::value % NBUF;
+    __syncthreads();                                    // weights resident (first pass) / everybody done with the previous halo image
+    store_lds(s, pv[P]);
+    __syncthreads();
+    const Tile t = decode(s);
+    issue_rows(t);
+    issue_loads(s + NBUF * step < nsp ? s + NBUF * step : s, pv[P]);   // past the end: a harmless re-read instead of a branch around the loads
     f32x16 acc[NT][NB];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -125,8 +196,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][nb][r] = 0.f;
+#ifdef B16_ABL_NOMFMA
+#pragma unroll
+    for (int tap = 0; tap < 1; ++tap) {
+#else
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+#endif
       const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -144,25 +220,22 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       }
     }
     // ---- epilogue: register 4q+e of tile nt = channel co0 + 32 nt + 8q + 4h + e of this lane's pixel
-    const Tile t = decode(s);
-    const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
-    if (S == 1 && a.pool == 2) {
+    if constexpr (POOL) {
       // LeakyReLU(conv + bias), then the 2x2 mean: rows 2w / 2w+1 are the two blocks (TW = 32) or lane halves 16 apart
       // (TW = 16); the column partner is lane ^ 1
       const int py = (t.oy0 >> 1) + wave, px = (t.ox0 >> 1) + (pcol[0] >> 1);
       const bool writer = (l31 & 1) == 0 && (TW == 32 || (l31 & 16) == 0) && py < (Ho >> 1) && px < (Wo >> 1);
+      f32x4 pooled[NT][4];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int cq = co0 + nt * 32 + q * 8 + 4 * h;
-          const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq : b16_zero16);
           f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float v = acc[nt][nb][4 * q + e] + bs[e];
+              const float v = acc[nt][nb][4 * q + e] + bsr[nt][q][e];
               sum[e] += v > 0.f ? v : v * a.slope;
             }
 #pragma unroll
@@ -172,53 +245,75 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
             if (TW == 16) v += __shfl_xor(v, 16, 64);
             sum[e] = 0.25f * v;
           }
-          if (writer) *reinterpret_cast<f32x4*>(a.y + (((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + cq) = sum;
+          pooled[nt][q] = sum;
         }
-    } else {
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {
-        const int oy = t.oy0 + prow[nb], ox = t.ox0 + pcol[nb];
-        const bool ok = oy < Ho && ox < Wo;
-        const int64_t pix = ((int64_t)t.b * Ho + (ok ? oy : 0)) * Wo + (ok ? ox : 0);
-        f32x4 ov[NT][4];
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cmr_pin(pooled[nt][q]);
+      if (writer) {
+        float* yp = a.y + (((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + co0 + 4 * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = pooled[nt][q];
+      }
+    } else {
+      f32x4 ov[NB][NT][4];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const int cq = co0 + nt * 32 + q * 8 + 4 * h;
-            const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq : b16_zero16);
-            const f32x4 rs = *reinterpret_cast<const f32x4*>(a.res ? a.res + pix * a.Cout + cq : b16_zero16);
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float u = acc[nt][nb][4 * q + e] + bs[e] + rs[e];
+              const float u = acc[nt][nb][4 * q + e] + bsr[nt][q][e] + rv[nb][nt][q][e];
               v[e] = u > 0.f ? u : u * a.slope;
             }
-            if (a.post) v += *reinterpret_cast<const f32x4*>(a.post + ((int64_t)(ok ? oy : 0) * Wo + (ok ? ox : 0)) * a.Cout + cq);
-            ov[nt][q] = v;
+            if constexpr (POST) v += tv[nb][nt][q];
+            ov[nb][nt][q] = v;
           }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
-        if (ok) {
-          float* yp = a.y + pix * a.Cout + co0 + 4 * h;
+          for (int q = 0; q < 4; ++q) cmr_pin(ov[nb][nt][q]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int oy = t.oy0 + prow[nb], ox = t.ox0 + pcol[nb];
+#ifdef B16_ABL_NOSTORE
+        if (oy < Ho && ox < Wo && ov[nb][0][0][0] == 12345.678f) {
+#else
+        if (oy < Ho && ox < Wo) {
+#endif
+          float* yp = a.y + (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nt][q];
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nb][nt][q];
         }
       }
     }
+  };
+  for (;;) {                                            // two passes per trip: the register sets alternate under static names
+    tile_pass(std::integral_constant<int, 0>{});
+    s += step;
+    if (s >= nsp) break;
+    tile_pass(std::integral_constant<int, 1>{});
+    s += step;
+    if (s >= nsp) break;
   }
 }
 
-template <int CIN, int NT, int TW, int S = 1>
-int launch_b16(B16Args a, hipStream_t stream) {
+template <int CIN, int NT, int TW, int S, bool POOL, bool POST>
+int launch_b16p(B16Args a, hipStream_t stream) {
   constexpr int smem = 9 * (CIN / 16) * NT * 1024 + (7 * S + 3) * ((TW - 1) * S + 3) * (CIN * 2 + 16);
   static_assert(smem <= 160 * 1024, "weight slice + halo image must fit in LDS");
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW, S>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW, S, POOL, POST>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   a.tiles_x = ((a.W - 1) / S + 1 + TW - 1) / TW;
   a.tiles_y = ((a.H - 1) / S + 1 + 7) / 8;
   const int ngroups = a.Cout / (32 * NT);
@@ -226,8 +321,20 @@ int launch_b16(B16Args a, hipStream_t stream) {
   int per_group = 256 / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > nsp) per_group = (int)nsp;
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW, S>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW, S, POOL, POST>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
   return cmr_launch_status();
+}
+
+template <int CIN, int NT, int TW, int S = 1>
+int launch_b16(B16Args a, hipStream_t stream) {
+  a.res_mul = a.res ? 1 : 0; a.bias_mul = a.bias ? 1 : 0;
+  if constexpr (S == 1) {
+    if (a.pool == 2) return launch_b16p<CIN, NT, TW, S, true, false>(a, stream);
+    if (a.post) return launch_b16p<CIN, NT, TW, S, false, true>(a, stream);
+  } else {
+    if (a.post) return CMR_EUNSUPPORTED;               // no caller adds the table to a strided convolution; the fp32 kernel serves it
+  }
+  return launch_b16p<CIN, NT, TW, S, false, false>(a, stream);
 }
 
 }  // namespace
@@ -240,7 +347,7 @@ extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, in
               (!post || cmr_aligned16(post)));
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
-  B16Args a{x, B, H, W, wfrag, bias, res, post, y, Cout, slope, pool, 0, 0};
+  B16Args a{x, B, H, W, wfrag, bias, res, post, y, Cout, slope, pool, 0, 0, 0, 0};
   if (stride == 2) {
     if (pool != 1) return CMR_EINVAL;
     if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 16, 2>(a, stream);
