@@ -51,11 +51,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   constexpr int NPIECE = HR * HC * C4;
   constexpr int NLOAD = (NPIECE + 255) / 256;
   // halo images kept in flight in registers: two where the register budget (512 per lane at one wave per SIMD) allows it
-#ifdef B16_DEPTH
-  constexpr int NBUF = B16_DEPTH;
-#else
   constexpr int NBUF = (NLOAD * 8 + NT * NB * (POST ? 48 : 32)) <= 280 ? 2 : 1;
-#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ws = smem;
   unsigned char* Xs = smem + WBYTES;
@@ -72,7 +68,6 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   {
     const int nsp_all = a.B * a.tiles_y * a.tiles_x;
     const int nfam = gridDim.x / ngroups;                     // families = workgroups per cout group
-#ifndef B16_NO_XCD
     if (nfam % 8 == 0 && ngroups > 1) {
       const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
       const int fam_x = nfam >> 3;                            // families per XCD
@@ -80,9 +75,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       const int fam = slot / ngroups;                         // 0 .. fam_x - 1
       const int band0 = (int)((int64_t)nsp_all * xcd / 8), band1 = (int)((int64_t)nsp_all * (xcd + 1) / 8);
       s = band0 + fam; step = fam_x; s_end = band1;
-    } else
-#endif
-    {
+    } else {
       group = blockIdx.x % ngroups;
       s = blockIdx.x / ngroups; step = nfam; s_end = nsp_all;
     }
@@ -196,13 +189,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][nb][r] = 0.f;
-#ifdef B16_ABL_NOMFMA
-#pragma unroll
-    for (int tap = 0; tap < 1; ++tap) {
-#else
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-#endif
       const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -284,11 +272,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         const int oy = t.oy0 + prow[nb], ox = t.ox0 + pcol[nb];
-#ifdef B16_ABL_NOSTORE
-        if (oy < Ho && ox < Wo && ov[nb][0][0][0] == 12345.678f) {
-#else
         if (oy < Ho && ox < Wo) {
-#endif
           float* yp = a.y + (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
@@ -332,9 +316,276 @@ int launch_b16(B16Args a, hipStream_t stream) {
     if (a.pool == 2) return launch_b16p<CIN, NT, TW, S, true, false>(a, stream);
     if (a.post) return launch_b16p<CIN, NT, TW, S, false, true>(a, stream);
   } else {
-    if (a.post) return CMR_EUNSUPPORTED;               // no caller adds the table to a strided convolution; the fp32 kernel serves it
+    if (a.post) return launch_b16p<CIN, NT, TW, S, false, true>(a, stream);
   }
   return launch_b16p<CIN, NT, TW, S, false, false>(a, stream);
+}
+
+// ---- two-team kernel (stride 1) ------------------------------------------------------------------------------------------------
+// The kernel above runs ONE wave per SIMD, so nothing overlaps: a tile is [convert + stage the halo] [issue the next loads] [multiply]
+// [epilogue + stores], back to back (7.5 us per 256 pixels at 64 -> 64, of which 2.2 us multiply).  Here a workgroup is TWO teams of
+// four waves (two waves per SIMD) that share the weight slice in LDS and own one 8x16-pixel halo buffer each; while one team
+// multiplies, the other finishes its previous tile, stages its next one and requests the one after -- the hardware interleaves the two
+// waves of a SIMD, no instruction scheduling is asked of the compiler.  Both teams run the SAME straight-line loop
+//     M(u) ; barrier ; X(u) ; barrier          M = multiply unit u from the team's buffer, X = [epilogue] + stage u+1 + request u+2
+// with team 1 delayed by one barrier, so M of one team always faces X of the other.  A unit is a (tile, 64-channel K chunk): Cin = 128
+// takes two units per tile through the same 26 KB buffer, which is what lets two buffers sit next to the 72 KB of weights.
+template <int CIN, int NT, bool POOL, bool POST>
+__global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
+  constexpr int KC = CIN / 64, KS = CIN / 16;
+  constexpr int TH = 8, TW = 16, HR = TH + 2, HC = TW + 2;
+  constexpr int PS = 64 * 2 + 16;                       // bytes per halo pixel of one K chunk
+  constexpr int WBYTES = 9 * KS * NT * 1024;
+  constexpr int XBYTES = HR * HC * PS;
+  constexpr int NPIECE = HR * HC * 16;                  // float4 pieces of one unit
+  constexpr int NLOAD = (NPIECE + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int team = wave >> 2, tw = wave & 3, ttid = tid & 255;
+  unsigned char* Ws = smem;
+  unsigned char* Xs = smem + WBYTES + team * XBYTES;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ngroups = a.Cout / (32 * NT);
+  int group, s0, step, s_end;
+  {
+    const int nsp_all = a.B * a.tiles_y * a.tiles_x;
+    const int nfam = gridDim.x / ngroups;
+    if (nfam % 8 == 0 && ngroups > 1) {                 // cout groups of one tile and neighbouring tiles on one XCD (see above)
+      const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+      const int fam_x = nfam >> 3;
+      group = slot % ngroups;
+      const int band0 = (int)((int64_t)nsp_all * xcd / 8), band1 = (int)((int64_t)nsp_all * (xcd + 1) / 8);
+      s0 = band0 + slot / ngroups; step = fam_x; s_end = band1;
+    } else {
+      group = blockIdx.x % ngroups;
+      s0 = blockIdx.x / ngroups; step = nfam; s_end = nsp_all;
+    }
+  }
+  const int co0 = group * 32 * NT;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(static_cast<const unsigned char*>(a.wfrag) + (size_t)group * WBYTES);
+    for (int i = tid; i < WBYTES / 16; i += 512) reinterpret_cast<uint4*>(Ws)[i] = src[i];
+  }
+  if (s0 >= s_end) return;                              // (uniform over the workgroup)
+  // tiles of this workgroup: s0 + j step; team 0 takes the even j, team 1 the odd ones; both make the same number of passes (a team
+  // that runs out re-reads its last tile and keeps its stores to itself), because every wave has to meet every barrier
+  const int ntile_wg = (s_end - s0 + step - 1) / step;
+  const int npass = (ntile_wg + 1) / 2;
+  const int s_last = s0 + (ntile_wg - 1) * step;
+  auto tile_of = [&](int i) __attribute__((always_inline)) { const int sj = s0 + (2 * i + team) * step; return sj < s_end ? sj : s_last; };
+
+  struct Tile { int b, oy0, ox0; };
+  auto decode = [&](int st) __attribute__((always_inline)) {
+    Tile t;
+    t.ox0 = (st % a.tiles_x) * TW; st /= a.tiles_x;
+    t.oy0 = (st % a.tiles_y) * TH;
+    t.b = st / a.tiles_y;
+    return t;
+  };
+  // ONE halo image in flight per team, requested a whole period (two phases) before it is staged.  Two register sets for Cin = 128
+  // (each chunk requested a tile ahead) measured 5 % slower.
+  f32x4 pv[1][NLOAD];
+  f32x4 rv[NT][4];
+  f32x4 tv[POST ? NT : 1][4];
+  const int Ho = a.H, Wo = a.W;
+  const float* rbase = a.res ? a.res : b16_zero16;
+  // the folded-BN bias of this cout group sits in LDS (the epilogue runs in the X phase, where an LDS read costs nothing and a
+  // register array would cost 8 NT registers of a 256-register budget)
+  float* Bs = reinterpret_cast<float*>(smem + WBYTES + 2 * XBYTES);
+  if (tid < 32 * NT) Bs[tid] = (a.bias ? a.bias : b16_zero16)[(co0 + tid) * a.bias_mul];
+  const int prow = 2 * tw + (l31 >> 4), pcol = l31 & 15;       // this lane's pixel inside the tile
+  auto issue_loads = [&](const Tile& t, int kc, f32x4 (&dst)[NLOAD]) __attribute__((always_inline)) {
+    const float* xb = a.x + (int64_t)t.b * a.H * a.W * CIN + kc * 64;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      int e = ttid + 256 * i;
+      e = e < NPIECE ? e : NPIECE - 1;
+      const int p = e >> 4, c = e & 15;
+      int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+      iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+      ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+      dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN + 4 * c));
+    }
+  };
+  auto store_lds = [&](const Tile& t, const f32x4 (&src)[NLOAD]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      const int e = ttid + 256 * i;
+      if (e < NPIECE) {
+        const int p = e >> 4, c = e & 15;
+        const int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+        const bool inb = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+        bf16x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (__bf16)(inb ? src[i][k] : 0.f);
+        *reinterpret_cast<bf16x4*>(Xs + p * PS + c * 8) = v;
+      }
+    }
+  };
+  auto issue_rows = [&](const Tile& t) __attribute__((always_inline)) {
+    if constexpr (!POOL) {
+      const int oy = t.oy0 + prow, ox = t.ox0 + pcol;
+      const bool ok = oy < Ho && ox < Wo;
+      const int oyc = ok ? oy : 0, oxc = ok ? ox : 0;
+      const int64_t pix = ((int64_t)t.b * Ho + oyc) * Wo + oxc;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cq = co0 + nt * 32 + q * 8 + 4 * h;
+          rv[nt][q] = *reinterpret_cast<const f32x4*>(rbase + (pix * a.Cout + cq) * a.res_mul);
+          if constexpr (POST) tv[nt][q] = *reinterpret_cast<const f32x4*>(a.post + ((int64_t)oyc * Wo + oxc) * a.Cout + cq);
+        }
+    }
+  };
+  f32x16 acc[NT];
+  // 36 steps (9 taps x 4 k-steps of the chunk), each NT weight fragments + 1 pixel fragment from LDS feeding NT matrix instructions.
+  // hipcc emits read / s_waitcnt lgkmcnt(0) / multiply per step, i.e. the LDS latency in front of every instruction -- and that is
+  // the faster form HERE: issuing the reads one or two steps ahead into rotating register sets (measured, 2 and 3 sets, with scheduling
+  // barriers) made every shape 3-6 % slower, because the other team's X phase lives in exactly those gaps.
+  auto multiply = [&](int kc) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 av[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          av[nt] = *reinterpret_cast<const bf16x8*>(Ws + ((tap * KS + kc * 4 + ks) * NT + nt) * 1024 + lane * 16);
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(Xs + ((prow + ky) * HC + pcol + kx) * PS + ks * 32 + h * 16);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt], 0, 0, 0);
+      }
+    }
+  };
+  auto epilogue = [&](const Tile& t, bool live) __attribute__((always_inline)) {
+    // register 4q+e of tile nt = channel co0 + 32 nt + 8q + 4h + e of this lane's pixel
+    f32x4 ov[NT][4];
+    if constexpr (POOL) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float v = acc[nt][4 * q + e] + Bs[nt * 32 + q * 8 + 4 * h + e];
+            v = v > 0.f ? v : v * a.slope;
+            v += __shfl_xor(v, 1, 64);                  // column partner
+            v += __shfl_xor(v, 16, 64);                 // row partner (rows 2 tw / 2 tw + 1 sit 16 lanes apart)
+            ov[nt][q][e] = 0.25f * v;
+          }
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = acc[nt][4 * q + e] + Bs[nt * 32 + q * 8 + 4 * h + e] + rv[nt][q][e];
+            ov[nt][q][e] = u > 0.f ? u : u * a.slope;
+          }
+          if constexpr (POST) ov[nt][q] += tv[nt][q];
+        }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
+    if constexpr (POOL) {
+      const int py = (t.oy0 >> 1) + tw, px = (t.ox0 >> 1) + (pcol >> 1);
+      if (live && (l31 & 17) == 0 && py < (Ho >> 1) && px < (Wo >> 1)) {
+        float* yp = a.y + (((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + co0 + 4 * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nt][q];
+      }
+    } else {
+      const int oy = t.oy0 + prow, ox = t.ox0 + pcol;
+      if (live && oy < Ho && ox < Wo) {
+        float* yp = a.y + (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nt][q];
+      }
+    }
+  };
+
+  // prologue: unit 0 staged, the next ones (and the first tile's rows, if its last chunk comes next) requested
+  Tile tcur = decode(tile_of(0));
+  Tile tnext = decode(tile_of(npass > 1 ? 1 : 0));
+  issue_loads(tcur, 0, pv[0]);
+  store_lds(tcur, pv[0]);
+  if constexpr (KC == 2) {
+    issue_loads(tcur, 1, pv[0]);
+  } else {
+    issue_rows(tcur);
+    issue_loads(tnext, 0, pv[0]);
+  }
+  __syncthreads();                                      // weights and both teams' first units are in LDS
+  if (team == 1) __syncthreads();                       // team 1 runs one phase behind
+  for (int i = 0; i < npass; ++i) {
+    // past the end: a harmless re-read instead of a branch around the loads
+    const Tile tnn = decode(tile_of(i + 2 < npass ? i + 2 : (i + 1 < npass ? i + 1 : i)));
+    const bool live = s0 + (2 * i + team) * step < s_end;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    if constexpr (KC == 2) {
+      multiply(0);
+      __syncthreads();
+      store_lds(tcur, pv[0]);                           // (tile, chunk 1)
+      issue_rows(tcur);                                 // ahead of the halo request in issue order: the epilogue's wait leaves that in flight
+      issue_loads(tnext, 0, pv[0]);
+      __syncthreads();
+      multiply(1);
+      __syncthreads();
+      epilogue(tcur, live);
+      store_lds(tnext, pv[0]);                          // (next tile, chunk 0)
+      issue_loads(tnext, 1, pv[0]);
+      __syncthreads();
+    } else {
+      multiply(0);
+      __syncthreads();
+      epilogue(tcur, live);
+      store_lds(tnext, pv[0]);
+      issue_rows(tnext);
+      issue_loads(tnn, 0, pv[0]);
+      __syncthreads();
+    }
+    tcur = tnext;
+    tnext = tnn;
+  }
+  if (team == 0) __syncthreads();                       // team 0 waits out team 1's last phase
+}
+
+template <int CIN, int NT, bool POOL, bool POST>
+int launch_tt_p(B16Args a, hipStream_t stream) {
+  constexpr int smem = 9 * (CIN / 16) * NT * 1024 + 2 * 10 * 18 * 144 + 256;
+  static_assert(smem <= 160 * 1024, "weight slice + two halo buffers must fit in LDS");
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  a.tiles_x = (a.W + 15) / 16;
+  a.tiles_y = (a.H + 7) / 8;
+  const int ngroups = a.Cout / (32 * NT);
+  const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
+  int per_group = 256 / ngroups;                       // one persistent workgroup per CU
+  if (per_group < 1) per_group = 1;
+  if (per_group > (nsp + 1) / 2) per_group = (int)((nsp + 1) / 2);      // a workgroup has two teams
+  hipLaunchKernelGGL((conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
+  return cmr_launch_status();
+}
+
+template <int CIN, int NT>
+int launch_tt(B16Args a, hipStream_t stream) {
+  a.res_mul = a.res ? 1 : 0; a.bias_mul = a.bias ? 1 : 0;
+  if (a.pool == 2) return launch_tt_p<CIN, NT, true, false>(a, stream);
+  if (a.post) return launch_tt_p<CIN, NT, false, true>(a, stream);
+  return launch_tt_p<CIN, NT, false, false>(a, stream);
 }
 
 }  // namespace
@@ -354,8 +605,14 @@ extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, in
     if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 16, 2>(a, stream);
     return CMR_EUNSUPPORTED;
   }
+#ifndef B16_ONE_TEAM
+  if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_tt<64, 2>(a, stream);
+  if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_tt<64, 1>(a, stream);
+  if (Cin == 128 && nt == 1 && Cout % 32 == 0) return launch_tt<128, 1>(a, stream);
+#else
   if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 32>(a, stream);
   if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 32>(a, stream);
   if (Cin == 128 && nt == 1 && Cout % 32 == 0) return launch_b16<128, 1, 16>(a, stream);
+#endif
   return CMR_EUNSUPPORTED;
 }
