@@ -234,7 +234,7 @@ def geo_train_main(args):
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
             "config": {"workload": "MultiHeadModel update: batch of %d pairs (160x512 image, %d points, %d nodes) per GPU, focal + focal + "
-                                   "circle loss, clip_grad_value_ 1, Adam (lr 1e-3, betas .9/.99, wd 1e-6), dropout off" % (B, cfg.num_pt, cfg.num_node),
+                                   "circle loss, dropout 0.1 at the reference's sites, clip_grad_value_ 1, Adam (lr 1e-3, betas .9/.99, wd 1e-6)" % (B, cfg.num_pt, cfg.num_node),
                        "batch_per_gpu": B,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
             "loss": loss}))

@@ -17,10 +17,14 @@ constexpr int DH = 8, NH = 8, CH = 64;
 
 // 256 threads = 64 queries of one (batch, head) x 4 lanes; lane `sub` of a query takes keys sub, sub+4, ...
 // and the four partial (max, sum, weighted value) states are merged with two xor-shuffles each.
+// DROP: dropout on the attention probabilities (ImageViT.py:100, PointViT.py:129, IMGPCEncoder.py:47, train mode): the softmax
+// normaliser runs over all keys, the value sum over the kept ones scaled by 1 / (1 - p); mask element = ((b 8 + head) Tq + query) Tk + key.
 constexpr int MHA_Q = 64, MHA_SPLIT = 4;
+template <bool DROP>
 __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k,
                                                   int64_t ldk, const float* __restrict__ v, int64_t ldv,
-                                                  float* __restrict__ o, int64_t ldo, int Tq, int Tk, float scale) {
+                                                  float* __restrict__ o, int64_t ldo, int Tq, int Tk, float scale, uint32_t thr = 0,
+                                                  float keep_scale = 1.f, const int64_t* __restrict__ seed_ptr = nullptr, uint64_t site = 0) {
   extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tk][8] then V_h [Tk][8]
   float* ks = kv;
   float* vs = kv + (size_t)Tk * DH;
@@ -53,13 +57,16 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ q, i
   m = fmaxf(m, __shfl_xor(m, 2));
   float l = 0.f;
   float acc[DH] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint64_t seed = DROP ? (uint64_t)seed_ptr[0] : 0;
+  const uint64_t mrow = (((uint64_t)b * NH + head) * Tq + tq) * Tk;
   for (int t = sub; t < Tk; t += MHA_SPLIT) {
     const float p = expf(score(t) - m);
     l += p;
+    const float pd = DROP ? (cmr_keep(seed, site, mrow + t, thr) ? p * keep_scale : 0.f) : p;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(&vs[t * DH]);
     const f32x4 v1 = *reinterpret_cast<const f32x4*>(&vs[t * DH + 4]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i] += p * v0[i]; acc[4 + i] += p * v1[i]; }
+    for (int i = 0; i < 4; ++i) { acc[i] += pd * v0[i]; acc[4 + i] += pd * v1[i]; }
   }
   l += __shfl_xor(l, 1);
   l += __shfl_xor(l, 2);
@@ -270,10 +277,25 @@ extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t 
   const size_t smem = (size_t)Tk * DH * 2 * sizeof(float);
   CMR_REQUIRE(smem <= 160 * 1024);
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_kernel<false>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   dim3 grid((Tq + 63) / 64, NH, B);
-  hipLaunchKernelGGL(mha_kernel, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
-                     0.35355339059327373f);
+  hipLaunchKernelGGL(mha_kernel<false>, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
+                     0.35355339059327373f, 0u, 1.f, (const int64_t*)nullptr, (uint64_t)0);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_mha_dropout_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,
+                                   int64_t ldo, int B, int Tq, int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream) {
+  CMR_REQUIRE(q && k && v && o && seed && B > 0 && B <= 65535 && Tq > 0 && Tk > 0 && p >= 0.f && p < 1.f);
+  CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
+  CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(o));
+  const size_t smem = (size_t)Tk * DH * 2 * sizeof(float);
+  CMR_REQUIRE(smem <= 160 * 1024);
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_kernel<true>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  dim3 grid((Tq + 63) / 64, NH, B);
+  hipLaunchKernelGGL(mha_kernel<true>, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk, 0.35355339059327373f,
+                     cmr_drop_threshold(p), 1.f / (1.f - p), seed, (uint64_t)site);
   return cmr_launch_status();
 }
 

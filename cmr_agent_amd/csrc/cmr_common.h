@@ -60,3 +60,19 @@ __device__ __forceinline__ f32x16 cmr_mfma32(float a, float b, f32x16 c) {
 }
 
 __device__ __forceinline__ int cmr_mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// Dropout mask, counter based (no state, no stored mask): element `idx` of dropout site `site` in the step whose seed is `seed` is KEPT
+// iff the low 32 bits of a 64-bit mix (murmur3 finaliser) of the three reach thr = p * 2^32.  Forward and backward call it with the same
+// arguments, so the backward pass regenerates the forward mask.
+__device__ __forceinline__ bool cmr_keep(uint64_t seed, uint64_t site, uint64_t idx, uint32_t thr) {
+  uint64_t x = (idx + site * 0x9E3779B97F4A7C15ull) ^ seed;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+  x ^= x >> 33;
+  return (uint32_t)x >= thr;
+}
+static inline uint32_t cmr_drop_threshold(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t <= 0.0 ? 0u : (t >= 4294967295.0 ? 4294967295u : (uint32_t)t);
+}
+

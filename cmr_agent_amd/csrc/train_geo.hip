@@ -266,17 +266,38 @@ __global__ __launch_bounds__(256) void col2im3_kernel(const float* __restrict__ 
 }
 
 
+// ---- dropout (nn.Dropout in train mode): y = x * keep / (1 - p), element index = row * C + column; in place allowed.  The backward
+// pass is the same launch on the gradient (same seed and site -> same mask).
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy, int64_t rows,
+                                                      int C, uint32_t thr, float keep_scale, const int64_t* __restrict__ seed_ptr,
+                                                      uint64_t site) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = C / 4;
+  const int64_t r = e / c4;
+  if (r >= rows) return;
+  const int c = (int)(e - r * c4) * 4;
+  const uint64_t seed = (uint64_t)seed_ptr[0];
+  f32x4 v = ld4(x + r * ldx + c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = cmr_keep(seed, site, (uint64_t)r * C + c + i, thr) ? v[i] * keep_scale : 0.f;
+  st4(y + r * ldy + c, v);
+}
+
 // ---- softmax attention backward (8 heads x 8 dims; forward = cmr_mha_f32) ------------------------------------------------------
 // P = softmax(Q K^T / sqrt 8); O = P V.  dV = P^T dO; dS = P o (dO V^T - D), D_i = dO_i . O_i; dQ = dS K / sqrt 8; dK = dS^T Q / sqrt 8.
 // Kernel 1: one thread per (query, head), K / V of the head in LDS: log-sum-exp of the row, D, dQ (written) -- lse / D are kept
 // for kernel 2: one thread per (key, head), Q / dO / lse / D of the head in LDS: dK, dV.  No atomics.
 constexpr int AH_DH = 8, AH_NH = 8;
 
+// With dropout on the probabilities (forward cmr_mha_dropout_f32): O = (P o M) V with M = mask / (1 - p), so dV = (P o M)^T dO and
+// dP = M o (dO V^T); D_i = dO_i . O_i still equals sum_k P_ik dP_ik, and dS = P o (dP - D) as before.  The mask is regenerated.
+template <bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
                                                          const float* __restrict__ v, int64_t ldv, const float* __restrict__ o, int64_t ldo,
                                                          const float* __restrict__ dout, int64_t lddo, float* __restrict__ dq, int64_t lddq,
                                                          int acc_dq, float* __restrict__ lse, float* __restrict__ dsum, int Tq, int Tk,
-                                                         float scale) {
+                                                         float scale, uint32_t thr, float keep_scale, const int64_t* __restrict__ seed_ptr,
+                                                         uint64_t site) {
   extern __shared__ __attribute__((aligned(16))) float kv[];
   float* ks = kv;
   float* vs = kv + (size_t)Tk * AH_DH;
@@ -315,6 +336,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
     l += expf(sc * scale - m);
   }
   const float L = m + logf(l);
+  const uint64_t seed = DROP ? (uint64_t)seed_ptr[0] : 0;
+  const uint64_t mrow = (((uint64_t)b * AH_NH + head) * Tq + tq) * Tk;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < Tk; ++t) {
     float sc = 0.f, dp = 0.f;
@@ -323,6 +346,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
       sc += qv[d] * ks[t * 8 + d];
       dp += gv[d] * vs[t * 8 + d];
     }
+    if (DROP) dp = cmr_keep(seed, site, mrow + t, thr) ? dp * keep_scale : 0.f;
     const float ds = expf(sc * scale - L) * (dp - D) * scale;
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] += ds * ks[t * 8 + d];
@@ -336,11 +360,13 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
   dsum[row * 8 + head] = D;
 }
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
                                                           const float* __restrict__ v, int64_t ldv, const float* __restrict__ dout, int64_t lddo,
                                                           const float* __restrict__ lse, const float* __restrict__ dsum, float* __restrict__ dk,
                                                           int64_t lddk, int acc_dk, float* __restrict__ dv, int64_t lddv, int acc_dv, int Tq,
-                                                          int Tk, float scale) {
+                                                          int Tk, float scale, uint32_t thr, float keep_scale,
+                                                          const int64_t* __restrict__ seed_ptr, uint64_t site) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* qs = sm;                              // [Tq][8]
   float* gs = qs + (size_t)Tq * 8;             // [Tq][8]
@@ -367,6 +393,8 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
     vv[d] = v[row * ldv + head * 8 + d];
   }
   float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const uint64_t seed = DROP ? (uint64_t)seed_ptr[0] : 0;
+  const uint64_t mhead = ((uint64_t)b * AH_NH + head) * Tq;
   for (int t = 0; t < Tq; ++t) {
     float sc = 0.f, dp = 0.f;
 #pragma unroll
@@ -375,10 +403,16 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
       dp += gs[t * 8 + d] * vv[d];
     }
     const float p = expf(sc * scale - ls[t]);
+    float pm = p;
+    if (DROP) {
+      const float mf = cmr_keep(seed, site, (mhead + t) * Tk + tk, thr) ? keep_scale : 0.f;
+      pm = p * mf;
+      dp *= mf;
+    }
     const float dsv = p * (dp - ds_[t]) * scale;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      av[d] += p * gs[t * 8 + d];
+      av[d] += pm * gs[t * 8 + d];
       ak[d] += dsv * qs[t * 8 + d];
     }
   }
@@ -753,9 +787,11 @@ extern "C" int cmr_col2im3_f32(const float* dcols, float* dx4, int B, int H, int
   return cmr_launch_status();
 }
 
-extern "C" int cmr_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
-                               const float* dout, int64_t lddo, float* dq, int64_t lddq, int acc_dq, float* dk, int64_t lddk, int acc_dk,
-                               float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq, int Tk, hipStream_t stream) {
+template <bool DROP>
+static int mha_bwd_launch(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                          const float* dout, int64_t lddo, float* dq, int64_t lddq, int acc_dq, float* dk, int64_t lddk, int acc_dk, float* dv,
+                          int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq, int Tk, float p, const int64_t* seed,
+                          int64_t site, hipStream_t stream) {
   CMR_REQUIRE(q && k && v && o && dout && dq && dk && dv && ws && B > 0 && B <= 65535 && Tq > 0 && Tk > 0);
   CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && lddo % 4 == 0 && cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) &&
               cmr_aligned16(dout));
@@ -765,13 +801,42 @@ extern "C" int cmr_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int6
   const size_t sm1 = (size_t)Tk * 16 * sizeof(float), sm2 = (size_t)Tq * 18 * sizeof(float);
   CMR_REQUIRE(sm1 <= 160 * 1024 && sm2 <= 160 * 1024);
   static CmrSmemCache g1{}, g2{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_bwd_dq_kernel), sm1, g1) != CMR_OK) return CMR_ELAUNCH;
-  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_bwd_dkv_kernel), sm2, g2) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_bwd_dq_kernel<DROP>), sm1, g1) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_bwd_dkv_kernel<DROP>), sm2, g2) != CMR_OK) return CMR_ELAUNCH;
   const float scale = 0.35355339059327373f;
-  hipLaunchKernelGGL(mha_bwd_dq_kernel, dim3((Tq + 255) / 256, AH_NH, B), dim3(256), sm1, stream, q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, dq,
-                     lddq, acc_dq, lse, dsum, Tq, Tk, scale);
-  hipLaunchKernelGGL(mha_bwd_dkv_kernel, dim3((Tk + 255) / 256, AH_NH, B), dim3(256), sm2, stream, q, ldq, k, ldk, v, ldv, dout, lddo,
-                     (const float*)lse, (const float*)dsum, dk, lddk, acc_dk, dv, lddv, acc_dv, Tq, Tk, scale);
+  const uint32_t thr = cmr_drop_threshold(p);
+  const float ks = 1.f / (1.f - p);
+  hipLaunchKernelGGL(mha_bwd_dq_kernel<DROP>, dim3((Tq + 255) / 256, AH_NH, B), dim3(256), sm1, stream, q, ldq, k, ldk, v, ldv, o, ldo, dout,
+                     lddo, dq, lddq, acc_dq, lse, dsum, Tq, Tk, scale, thr, ks, seed, (uint64_t)site);
+  hipLaunchKernelGGL(mha_bwd_dkv_kernel<DROP>, dim3((Tk + 255) / 256, AH_NH, B), dim3(256), sm2, stream, q, ldq, k, ldk, v, ldv, dout, lddo,
+                     (const float*)lse, (const float*)dsum, dk, lddk, acc_dk, dv, lddv, acc_dv, Tq, Tk, scale, thr, ks, seed, (uint64_t)site);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_mha_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o, int64_t ldo,
+                               const float* dout, int64_t lddo, float* dq, int64_t lddq, int acc_dq, float* dk, int64_t lddk, int acc_dk,
+                               float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq, int Tk, hipStream_t stream) {
+  return mha_bwd_launch<false>(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, dq, lddq, acc_dq, dk, lddk, acc_dk, dv, lddv, acc_dv, ws, ws_bytes, B,
+                               Tq, Tk, 0.f, nullptr, 0, stream);
+}
+
+extern "C" int cmr_mha_dropout_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o,
+                                       int64_t ldo, const float* dout, int64_t lddo, float* dq, int64_t lddq, int acc_dq, float* dk,
+                                       int64_t lddk, int acc_dk, float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq,
+                                       int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream) {
+  CMR_REQUIRE(seed && p >= 0.f && p < 1.f);
+  return mha_bwd_launch<true>(q, ldq, k, ldk, v, ldv, o, ldo, dout, lddo, dq, lddq, acc_dq, dk, lddk, acc_dk, dv, lddv, acc_dv, ws, ws_bytes, B,
+                              Tq, Tk, p, seed, site, stream);
+}
+
+extern "C" int cmr_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, float p, const int64_t* seed,
+                               int64_t site, hipStream_t stream) {
+  CMR_REQUIRE(x && y && seed && rows > 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && p >= 0.f && p < 1.f);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(y));
+  const int64_t pieces = rows * (C / 4);
+  CMR_REQUIRE((pieces + 255) / 256 < 0x7fffffff);
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, x, ldx, y, ldy, rows, C, cmr_drop_threshold(p),
+                     1.f / (1.f - p), seed, (uint64_t)site);
   return cmr_launch_status();
 }
 

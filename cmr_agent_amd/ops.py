@@ -947,3 +947,35 @@ def iter_apply(matrix_i, pc_3n, matrix_acc):
     pc_out, acc_out = torch.empty_like(pc_3n), torch.empty((4, 4), dtype=f32, device=pc_3n.device)
     _lib.call("cmr_iter_apply_f32", _p(matrix_i), _p(pc_3n), _p(pc_out), N, _p(matrix_acc), _p(acc_out), _stream())
     return pc_out, acc_out
+
+
+# ---- dropout (train mode; include/cmr_hip.h) ---------------------------------------------------------------------------------------
+
+def dropout(x, p, seed, site, out=None):
+    """y = x * keep / (1 - p) with the counter-based mask of (seed[0], site); seed: int64 device tensor [1].  The backward pass is the same
+    call on the gradient.  out may be x (in place)."""
+    _rows(x)
+    if seed.dtype != torch.int64 or not seed.is_cuda:
+        raise ValueError("dropout: seed must be an int64 device tensor")
+    if out is None:
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=f32, device=x.device)
+    _lib.call("cmr_dropout_f32", _p(x), _ld(x), _p(_rows(out)), _ld(out), x.shape[0], x.shape[1], float(p), _p(seed), int(site), _stream())
+    return out
+
+
+def mha_dropout(q, k, v, B, Tq, Tk, p, seed, site):
+    """softmax attention with dropout on the probabilities (train mode)."""
+    out = torch.empty((B * Tq, 64), dtype=f32, device=q.device)
+    _lib.call("cmr_mha_dropout_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(out), _ld(out), B, Tq, Tk, float(p),
+              _p(seed), int(site), _stream())
+    return out
+
+
+def mha_dropout_bwd(q, k, v, o, dout, B, Tq, Tk, p, seed, site):
+    dq, dk, dv = (torch.empty((B * Tq, 64), dtype=f32, device=q.device), torch.empty((B * Tk, 64), dtype=f32, device=q.device),
+                  torch.empty((B * Tk, 64), dtype=f32, device=q.device))
+    ws = torch.empty((B * Tq * 16,), dtype=f32, device=q.device)
+    _lib.call("cmr_mha_dropout_bwd_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(_rows(o)), _ld(o), _p(_rows(dout)),
+              _ld(dout), _p(dq), _ld(dq), 0, _p(dk), _ld(dk), 0, _p(dv), _ld(dv), 0, _p(ws), ws.numel() * 4, B, Tq, Tk, float(p), _p(seed),
+              int(site), _stream())
+    return dq, dk, dv

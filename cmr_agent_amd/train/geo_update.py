@@ -8,9 +8,12 @@ the tape.  Losses = focal (points, alpha .75) + focal (pixels, alpha .5) + circl
 240-270); their gradients seed the tape; gradients land in ONE flat bucket, which is all-reduced once per step over the
 data-parallel ranks and consumed by the fused Adam launch (gradient value clipping at 1 folded in).
 
-Dropout (p = 0.1 in 40 places of the reference, incl. on the attention probabilities) is NOT applied: parity with the
-reference is defined with dropout off, and a training run here is therefore un-regularised in that one
-respect.  Documented in DESIGN.md."""
+Dropout: the reference trains with p = 0.1 in 141 nn.Dropout modules (embeddings, attention probabilities, projections, MLPs,
+the linear-attention layers, the two fuse stacks).  `dropout=True` (the default, as `model.train()` in the reference) applies
+them at the same places with counter-based masks (csrc/cmr_common.h:cmr_keep; one device seed advanced per step, one site number
+per call, masks regenerated in the backward pass).  The draws are not torch's, so parity with the reference / the oracle is
+defined -- and tested -- with `dropout=False`; what is tested with dropout on is the mask statistics, the
+forward / backward of each dropout site against torch autograd under the same mask, and step-level reproducibility."""
 import torch
 import torch.nn as nn
 
@@ -26,7 +29,8 @@ LOSS_KEYS = ("loss", "pc_overlap_loss", "img_overlap_loss", "geometric_loss", "p
 
 
 class GeoUpdate:
-    def __init__(self, model, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, grad_clip=1.0):
+    def __init__(self, model, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, grad_clip=1.0, dropout=True,
+                 dropout_seed=None):
         self.model, self.cfg, self.dist = model, config, dist
         self.bucket = FlatBucket(model)
         n = self.bucket.numel
@@ -41,6 +45,11 @@ class GeoUpdate:
         self._pos2d = {}
         self._pos1d = {}
         self._graph = None
+        # dropout: one int64 seed on the device, advanced once per step OUTSIDE the captured graph (the kernels read it through a pointer,
+        # so replays draw fresh masks); ranks start from different seeds
+        rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
+        base = (config.seed if dropout_seed is None else dropout_seed) * 1000003 + rank * 7919
+        self.drop_seed = torch.full((1,), base, dtype=torch.int64, device=dev) if dropout else None
 
     # ------------------------------------------------------------------------------------------------------ building blocks
     def _resblock(self, t, x, dims, blk, post=None):
@@ -73,10 +82,12 @@ class GeoUpdate:
         q = t.linear(xn, at.query.weight, at.query.bias)
         k = t.linear(yn, at.key.weight, at.key.bias)
         v = t.linear(yn, at.value.weight, at.value.bias)
-        ctx = t.mha(q, k, v, B, tx, tx if y is None else ty)
-        x1 = t.add(t.linear(ctx, at.out.weight, at.out.bias), x)
+        ctx = t.mha(q, k, v, B, tx, tx if y is None else ty, p=at.attn_dropout.p)
+        x1 = t.add(t.dropout(t.linear(ctx, at.out.weight, at.out.bias), at.proj_dropout.p), x)
         h = t.layernorm(x1, blk.ffn_norm, blk.LN_EPS)
-        m = t.linear(t.act(t.linear(h, blk.ffn.fc1.weight, blk.ffn.fc1.bias), GELU), blk.ffn.fc2.weight, blk.ffn.fc2.bias)
+        pm = blk.ffn.dropout.p                                   # ImageViT.py:128-133: fc1, GELU, dropout, fc2, dropout
+        m = t.dropout(t.act(t.linear(h, blk.ffn.fc1.weight, blk.ffn.fc1.bias), GELU), pm)
+        m = t.dropout(t.linear(m, blk.ffn.fc2.weight, blk.ffn.fc2.bias), pm)
         return t.add(m, x1)
 
     def _mini_pointnet(self, t, x, mp):
@@ -125,9 +136,9 @@ class GeoUpdate:
         k = t.act(t.linear(y, la.k_proj.weight), ELU1)
         v = t.linear(y, la.v_proj.weight)
         msg = t.la_core(q, k, v, B, L, S, la.eps)
-        msg = t.layernorm(t.linear(msg, la.merge.weight), la.norm1, la.LN_EPS)
-        hid = t.linear(t.cat(x, msg), la.mlp[0].weight, act=RELU)
-        return t.add(x, t.layernorm(t.linear(hid, la.mlp[3].weight), la.norm2, la.LN_EPS))
+        msg = t.dropout(t.layernorm(t.linear(msg, la.merge.weight), la.norm1, la.LN_EPS), la.att_dropout.p)
+        hid = t.dropout(t.linear(t.cat(x, msg), la.mlp[0].weight, act=RELU), la.mlp[2].p)
+        return t.add(x, t.layernorm(t.dropout(t.linear(hid, la.mlp[3].weight), la.mlp[4].p), la.norm2, la.LN_EPS))
 
     def _patch_embed(self, t, emb, f2, dims):
         """ImageViT.py:19-22, 52-56: 8x8 stride-8 convolution as a GEMM over patch rows, + the (frozen) 1-D sinusoid table."""
@@ -155,7 +166,7 @@ class GeoUpdate:
             gw[:dw.numel()].view(co, ci, P, P).copy_(dw.view(co, P, P, ci).permute(0, 3, 1, 2))        # back to [co][cin][ky][kx]
             t.give(patches, ops.linear(y.g, wm.t().contiguous()), owned=True)
         t.nodes.append(bwd)
-        return y, T
+        return t.dropout(y, emb.dropout.p), T                    # ImageViT.py:56
 
     # ------------------------------------------------------------------------------------------------------------- forward
     def _forward(self, t, data):
@@ -217,12 +228,14 @@ class GeoUpdate:
         nod = t.cat(node_feat, t.gather(pt_proxy, n2p_global, n2p_csr))
         for layer in list(ed.node_fuse_convs)[:-1]:
             nod = self._cbr1d(t, nod, layer)
+        nod = t.dropout(nod, ed.node_fuse_convs[-1].p)           # IMGPCEnDecoder.py:38
         pix = t.upsample_concat(f2, img_proxy, d2, cfg.patch_size)
         key = (h, w)
         if key not in self._pos2d:
             self._pos2d[key] = ed._pos_table(h, w, dev).view(h * w, -1).contiguous()
         for i, layer in enumerate(list(ed.img_fuse_convs)[:-1]):
             pix, _ = self._resblock(t, pix, d2, layer, post=self._pos2d[key] if i == 0 else None)
+        pix = t.dropout(pix, ed.img_fuse_convs[-1].p)            # IMGPCEnDecoder.py:54
         L = h * w
         for i in range(cfg.linear_attention_num):
             nod = self._la(t, ed.pixel_to_node_LA[i], nod, pix, B, M, L)
@@ -252,7 +265,7 @@ class GeoUpdate:
         a dict of device scalars: the four losses and six overlap metrics of MultiHeadModel.forward."""
         self.bucket.check_attached()
         self.bucket.grads.zero_()                           # every used slice is overwritten; frozen / unused ones must read 0
-        t = Tape(self.bucket)
+        t = Tape(self.bucket, self.drop_seed)
         o = self._forward(t, data)
         B, N, h, w = o["B"], o["N"], o["h"], o["w"]
         dev = self.bucket.params.device
@@ -315,6 +328,8 @@ class GeoUpdate:
         self._graph = graph
 
     def step(self, data):
+        if self.drop_seed is not None:
+            self.drop_seed += 1                                  # fresh masks for this step (read through the pointer, also by the replayed graph)
         if self._graph is not None:
             for k, v in self._static.items():
                 src = data[k]

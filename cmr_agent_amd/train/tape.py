@@ -30,8 +30,10 @@ class Var:
 class Tape:
     WINOGRAD = True         # 3x3 convolutions (forward and data gradient) on the Winograd kernel; False = direct kernel (debug aid)
 
-    def __init__(self, bucket):
+    def __init__(self, bucket, drop_seed=None):
         self.bucket = bucket
+        self.drop_seed = drop_seed      # int64 device tensor [1]: dropout is applied iff given; advanced by the owner once per step
+        self._site = 0                  # dropout sites are numbered in call order: the same masks whenever the seed is the same
         self.nodes = []
         self.touched = set()            # parameter ids whose gradient slice has been written in this step
         self._consts = {}
@@ -283,13 +285,36 @@ class Tape:
         self.nodes.append(bwd)
         return y
 
-    def mha(self, q, k, v, B, Tq, Tk):
-        y = Var(ops.mha(q.v, k.v, v.v, B, Tq, Tk))
+    def dropout(self, x, p):
+        """nn.Dropout(p) in train mode (identity when the tape has no seed or p == 0): the mask is regenerated in the backward pass."""
+        if self.drop_seed is None or p <= 0.0:
+            return x
+        seed, site = self.drop_seed, self._site
+        self._site += 1
+        y = Var(ops.dropout(x.v, p, seed, site))
 
         def bwd():
             if y.g is None:
                 return
-            dq, dk, dv = ops.mha_bwd(q.v, k.v, v.v, y.v, y.g, B, Tq, Tk)
+            self.give(x, ops.dropout(y.g, p, seed, site), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def mha(self, q, k, v, B, Tq, Tk, p=0.0):
+        """p: dropout rate on the attention probabilities (train mode)."""
+        drop = self.drop_seed is not None and p > 0.0
+        seed, site = self.drop_seed, self._site
+        if drop:
+            self._site += 1
+        y = Var(ops.mha_dropout(q.v, k.v, v.v, B, Tq, Tk, p, seed, site) if drop else ops.mha(q.v, k.v, v.v, B, Tq, Tk))
+
+        def bwd():
+            if y.g is None:
+                return
+            if drop:
+                dq, dk, dv = ops.mha_dropout_bwd(q.v, k.v, v.v, y.v, y.g, B, Tq, Tk, p, seed, site)
+            else:
+                dq, dk, dv = ops.mha_bwd(q.v, k.v, v.v, y.v, y.g, B, Tq, Tk)
             self.give(q, dq, owned=True)
             self.give(k, dk, owned=True)
             self.give(v, dv, owned=True)

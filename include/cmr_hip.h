@@ -518,6 +518,22 @@ int cmr_iter_decide_f32(const float* logits, int nlabel, const float* label_r, c
 int cmr_iter_apply_f32(const float* matrix_i, const float* pc, float* pc_out, int N, const float* acc_in, float* acc_out,
                        hipStream_t stream);
 
+/* ---- dropout (train mode; the reference trains MultiHeadModel with p = 0.1 in 141 nn.Dropout modules) --------------------------
+ * Counter-based masks: element idx of site `site` is kept iff mix64(seed[0], site, idx) >= p 2^32 (csrc/cmr_common.h:cmr_keep); seed is
+ * a DEVICE int64 (advanced once per optimizer step by the host, so that a captured hipGraph draws fresh masks on every replay).
+ * cmr_dropout_f32: y = x * keep / (1 - p), idx = row * C + column (ImageViT.py:56, :107, :130-132, LinearAttention.py:27-29, :66,
+ *   IMGPCEnDecoder.py:38, :54 ...); the backward pass is the same call on the gradient.
+ * cmr_mha_dropout_f32 / cmr_mha_dropout_bwd_f32: cmr_mha_f32 / cmr_mha_bwd_f32 with dropout on the attention probabilities
+ *   (ImageViT.py:100, PointViT.py:129, IMGPCEncoder.py:47), idx = ((b 8 + head) Tq + query) Tk + key. */
+int cmr_dropout_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t rows, int C, float p, const int64_t* seed,
+                    int64_t site, hipStream_t stream);
+int cmr_mha_dropout_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,
+                        int64_t ldo, int B, int Tq, int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream);
+int cmr_mha_dropout_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* o,
+                            int64_t ldo, const float* dout, int64_t lddo, float* dq, int64_t lddq, int acc_dq, float* dk,
+                            int64_t lddk, int acc_dk, float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq,
+                            int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,7 +85,7 @@ def test_geo_update_matches_oracle_and_reference_fixture():
     fx = G.load_case(C.GEO_TRAIN_FIXTURE)
     # ---- step one: forward / backward
     model = _model(cfg, geo_sd)
-    up = GeoUpdate(model, cfg)
+    up = GeoUpdate(model, cfg, dropout=False)
     losses = up.forward_backward(_to_dev(batches[0]))
     torch.cuda.synchronize()
     sd_ref = {k: x.clone() for k, x in sd0.items()}
@@ -113,7 +113,7 @@ def test_geo_update_matches_oracle_and_reference_fixture():
     # ---- step two, teacher-forced: the oracle's state after one clipped Adam step
     osd1, _ = TO.geo_adam_train(sd0, batches[:1], cfg, True)
     model_b = _model(cfg, osd1)
-    up_b = GeoUpdate(model_b, cfg)
+    up_b = GeoUpdate(model_b, cfg, dropout=False)
     losses_b = up_b.forward_backward(_to_dev(batches[1]))
     torch.cuda.synchronize()
     out_b, og_b = TO.geo_forward_backward({k: x.clone() for k, x in osd1.items()}, batches[1], cfg, True)
@@ -121,7 +121,7 @@ def test_geo_update_matches_oracle_and_reference_fixture():
     _check_grads(_logical_grads(up_b, model_b), og_b, "step 1 (teacher-forced)")
     # ---- two free-running optimizer steps
     model2 = _model(cfg, geo_sd)
-    up2 = GeoUpdate(model2, cfg)
+    up2 = GeoUpdate(model2, cfg, dropout=False)
     hist = [{k: float(v) for k, v in up2.step(_to_dev(b)).items()} for b in batches]
     torch.cuda.synchronize()
     osd, ohist = TO.geo_adam_train(sd0, batches, cfg, True)
@@ -184,7 +184,7 @@ def test_forty_steps_on_one_batch_reduce_every_loss():
     cfg = C.e2e_config(C.GEO_TRAIN_CASE)
     torch.manual_seed(0)
     model = MultiHeadModel(cfg).to(DEV)
-    up = GeoUpdate(model, cfg)
+    up = GeoUpdate(model, cfg, dropout=False)
     data = _to_dev(C.e2e_batch(C.GEO_TRAIN_CASE))
     first = {k: float(v) for k, v in up.step(data).items()}
     for _ in range(39):
@@ -207,7 +207,7 @@ def test_graph_replay_equals_eager_steps():
     runs = []
     for use_graph in (False, True):
         model = _model(cfg, geo_sd)
-        up = GeoUpdate(model, cfg)
+        up = GeoUpdate(model, cfg, dropout=False)
         if use_graph:
             up.enable_graph(batches[0])
         losses = [{k: float(v) for k, v in up.step(b).items()} for b in batches]

@@ -11,7 +11,7 @@ SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
 cfg = C.e2e_config("e2e_small"); batch = C.e2e_batch("e2e_small")
 geo_sd, _ = C.e2e_state_dicts(SPECS)
 model = MultiHeadModel(cfg); load_checked(model, geo_sd); model = model.to("cuda")
-up = GeoUpdate(model, cfg)
+up = GeoUpdate(model, cfg, dropout=False)
 data = {k: (v.to("cuda") if torch.is_tensor(v) else v) for k, v in batch.items()}
 up.step(data)
 sites = collections.Counter()

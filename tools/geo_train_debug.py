@@ -17,7 +17,7 @@ geo_sd, _ = C.e2e_state_dicts(SPECS)
 model = MultiHeadModel(cfg)
 load_checked(model, geo_sd)
 model = model.to("cuda")
-up = GeoUpdate(model, cfg)
+up = GeoUpdate(model, cfg, dropout=False)
 if "--direct" in sys.argv:
     from cmr_agent_amd.train.tape import Tape
     Tape.WINOGRAD = False
@@ -76,7 +76,7 @@ print("running statistics differing:", bad)
 if "--steps" in sys.argv:
     batches = C.geo_train_batches()
     model2 = MultiHeadModel(cfg); load_checked(model2, geo_sd); model2 = model2.to("cuda")
-    up2 = GeoUpdate(model2, cfg)
+    up2 = GeoUpdate(model2, cfg, dropout=False)
     hist = []
     for b in batches:
         l = up2.step({k: (v.to("cuda") if torch.is_tensor(v) else v) for k, v in b.items()})
