@@ -342,7 +342,7 @@ def main():
         if dtype == "bf16":
             # the bf16 convolution is HBM-class: 73.7 kFLOP per 512 B (64 -> 64) against a bf16 ridge of ~310 FLOP/B
             gbs = conv["bytes"] / (conv["ms"] * 1e-3) / 1e9
-            roofline = dict(kernel="conv3x3_bf16_kernel (NHWC 3x3 stride-1 direct, v_mfma_f32_32x32x16_bf16, fp32 accumulate)", bound="hbm",
+            roofline = dict(kernel="conv3x3_bf16_tt_kernel / conv3x3_bf16_kernel (NHWC 3x3 direct: two-team stride-1 kernel, one-team stride-2 kernel; v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM)", bound="hbm",
                             achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=None,
                             mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2500.0,
                             path_note="ideal times of `path` are priced at the fp32 peaks (utils/workmodel.py)", **common)
