@@ -22,7 +22,11 @@ def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
     (2, 12, 20, 128, 128, 1, True, False, 1), (1, 9, 23, 128, 64, 1, False, False, 1), (3, 16, 48, 128, 128, 2, False, False, 1),
     (2, 24, 64, 64, 64, 2, False, False, 1), (1, 40, 128, 64, 128, 1, True, True, 1),
     (2, 16, 64, 64, 64, 1, False, False, 2), (1, 33, 71, 64, 64, 1, True, True, 2), (2, 50, 130, 64, 32, 1, False, False, 2),
-    (1, 96, 160, 64, 128, 1, False, False, 2)])
+    (1, 96, 160, 64, 128, 1, False, False, 2),
+    # two-team kernel: one tile (the second team idles), a 1-pixel-high map, XCD-banded cout groups (256 workgroups, 16-tile bands,
+    # even and uneven), an odd number of tiles per workgroup
+    (1, 8, 16, 64, 64, 1, True, False, 1), (1, 1, 5, 128, 128, 1, False, False, 1), (2, 64, 128, 128, 128, 1, True, False, 1),
+    (3, 40, 72, 128, 128, 2, False, False, 1), (5, 24, 48, 64, 64, 1, True, True, 1)])
 def test_conv3x3_bf16(B, H, W, cin, cout, pool, res, post, stride):
     from cmr_agent_amd import ops
     from cmr_agent_amd.models._pack import conv_bf16_frags
