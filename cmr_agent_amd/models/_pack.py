@@ -103,6 +103,15 @@ def conv_bf16_frags(w):
     return f.contiguous().to(torch.bfloat16).reshape(-1), nt
 
 
+def conv_s2_frags(w):
+    """[Cout, Cin, 3, 3] -> MFMA A fragments of the stride-2 kernel (cmr_conv3x3_s2_nhwc_f32): [9 taps][Cout/32][Cin/8][64 lanes][4], lane =
+    32 h + l holding W[32 tile + l][8 kgroup + 4 h .. + 3][ky][kx] -- frag_pack of every tap.  None when the shape is not served."""
+    co, ci = w.shape[0], w.shape[1]
+    if ci != 64 or co % 64:
+        return None
+    return torch.stack([frag_pack(w[:, :, t // 3, t % 3].contiguous()) for t in range(9)]).contiguous()
+
+
 def conv9(conv, bn=None, cin_slice=None):
     """Conv2d 3x3 -> (W [9, Cout, Cin], bias [Cout], U fragments (16*Cout*Cin floats) for the Winograd kernel).
     cin_slice restricts the input channels (the agent's image / projection halves)."""
@@ -112,6 +121,7 @@ def conv9(conv, bn=None, cin_slice=None):
     co, ci = w.shape[0], w.shape[1]
     u = winograd_u(w)
     u.bf16 = conv_bf16_frags(w)          # operands of the bf16 variant travel with the fp32 ones (ops.conv3x3 picks by ops.CONV_BF16)
+    u.s2 = conv_s2_frags(w) if tuple(getattr(conv, "stride", (1, 1))) == (2, 2) else None      # fragment weights of the stride-2 fp32 kernel
     return w.permute(2, 3, 0, 1).reshape(9, co, ci).contiguous(), b.contiguous(), u
 
 

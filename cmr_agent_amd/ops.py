@@ -98,6 +98,7 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
 CONV_BF16 = False        # True: bf16 mode -- 3x3 convolutions (cmr_conv3x3_bf16_nhwc_f32), ConvBNReLURes1D blocks (cmr_cbr_block_bf16_f32)
                          # and the query side of the linear-attention layers (cmr_la_query_layer_bf16_f32) run on the bf16 matrix cores
                          # where served; storage and everything else stay fp32
+STRIDE2_FRAGS = True     # stride-2 convolutions (Cin = 64) on the fragment-weight kernel cmr_conv3x3_s2_nhwc_f32; False = the tiled kernel (A/B, tests)
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
 
@@ -147,6 +148,12 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
     if CONV_BF16 and out is None and getattr(u, "bf16", None) is not None:
         y = conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool, stride)
         if y is not None:
+            return y
+    if (STRIDE2_FRAGS and stride == 2 and out is None and pool == 1 and post is None and getattr(u, "s2", None) is not None):
+        y = torch.empty((B, ho, wo, cout), dtype=f32, device=x.device)
+        rc = _lib.call("cmr_conv3x3_s2_nhwc_f32", _p(x), B, H, W, cin, _p(u.s2), _p(bias), _p(res), None, _p(y), cout, float(slope), _stream(),
+                       allow_unsupported=True)
+        if rc != _lib.UNSUPPORTED:
             return y
     if (WINOGRAD and u is not None and stride == 1 and out is None
             and ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= WINO_MIN_TILES):

@@ -63,6 +63,7 @@ WORK = {
     "cmr_layernorm64_f32": lambda a: (0, F * a["rows"] * 64 * (3 if a["res"] else 2)),
     "cmr_conv3x3_nhwc_f32": _conv,
     "cmr_conv3x3_wino_nhwc_f32": lambda a: _conv(a, 1),
+    "cmr_conv3x3_s2_nhwc_f32": lambda a: _conv(a, 2),
     "cmr_conv3x3_bf16_nhwc_f32": _conv,
     # ResidualBlock(3 -> 64): conv3x3 3->3, conv3x3 3->64, 1x1 shortcut 3->64
     "cmr_stem_block_f32": lambda a: (2.0 * (81 + 1728 + 192) * a["B"] * a["H"] * a["W"], F * a["B"] * a["H"] * a["W"] * (3 + 64)),

@@ -86,6 +86,13 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
 int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,
                               hipStream_t stream);
+/* Stride-2 3x3 convolution (the two strided convolutions of a down-sampling ResidualBlock, ImageResNet.py:9-14, :24-27) with the weights
+ * as MFMA A fragments [9 taps][Cout/32][Cin/8][64 lanes][4] read straight from L2 (cmr_agent_amd/models/_pack.py:conv_s2_frags): same
+ * arithmetic and epilogue as cmr_conv3x3_nhwc_f32 at stride 2 (bias, residual, LeakyReLU), two barriers per 16-channel halo chunk instead
+ * of one per tap.  Served: Cin = 64, Cout % 64 == 0, no table operand; otherwise CMR_EUNSUPPORTED (-3) and the caller uses
+ * cmr_conv3x3_nhwc_f32. */
+int cmr_conv3x3_s2_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* wfrag, const float* bias, const float* res,
+                            const float* post, float* y, int Cout, float slope, hipStream_t stream);
 /* Process-wide switch between the two Winograd kernels for maps of >= 200 tiles (1 = wave-specialised persistent kernel,
  * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
 int cmr_set_wino_variant(int wave_specialised);

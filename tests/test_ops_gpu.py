@@ -627,3 +627,37 @@ def test_argument_guards(ops):
         scatter.scatter_sum(src, idx.unsqueeze(1).expand(2, 64, 100), dim=2, dim_size=5)
     with pytest.raises(IndexError):
         scatter.scatter_sum(src, (idx - 1).unsqueeze(1).expand(2, 64, 100), dim=2, dim_size=10)
+
+
+@pytest.mark.parametrize("B,H,W,cout,res", [(2, 16, 64, 64, True), (1, 33, 71, 64, False), (3, 9, 130, 128, True), (1, 2, 3, 64, True),
+                                            (2, 50, 200, 64, False)])
+def test_conv3x3_stride2_fragment_weight_kernel(ops, B, H, W, cout, res):
+    """cmr_conv3x3_s2_nhwc_f32 (fragment weights from L2, two barriers per halo chunk) against torch's stride-2 convolution and against the
+    tiled kernel it replaces (cmr_conv3x3_nhwc_f32)."""
+    from cmr_agent_amd.models._pack import conv_s2_frags
+    x = rnd(B, 64, H, W, seed=1)
+    w = rnd(cout, 64, 3, 3, seed=2) / 12
+    b = rnd(cout, seed=3)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    r = rnd(B, cout, ho, wo, seed=4) if res else None
+    want = F.conv2d(x.double(), w.double(), b.double(), 2, 1)
+    if r is not None:
+        want = want + r.double()
+    want = F.leaky_relu(want, 0.2)
+    nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(DEV)
+    w9 = w.permute(2, 3, 0, 1).reshape(9, cout, 64).contiguous().to(DEV)
+
+    class U:
+        pass
+    u = U()
+    u.s2, u.bf16 = conv_s2_frags(w.to(DEV)), None
+    assert u.s2 is not None and ops.STRIDE2_FRAGS
+    got = ops.conv3x3(nhwc(x), w9, b.to(DEV), cout, 2, 0.2, res=nhwc(r), u=u)
+    ops.STRIDE2_FRAGS = False
+    try:
+        old = ops.conv3x3(nhwc(x), w9, b.to(DEV), cout, 2, 0.2, res=nhwc(r), u=u)
+    finally:
+        ops.STRIDE2_FRAGS = True
+    scale = float(want.abs().max())
+    assert float((got.permute(0, 3, 1, 2).cpu().double() - want).abs().max()) <= 5e-5 * scale
+    assert float((got - old).abs().max()) <= 2e-5 * scale
