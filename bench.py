@@ -304,6 +304,17 @@ def main():
             for _ in range(args.steps):
                 registration_step(geo, agent, cfg, batch)
             torch.cuda.synchronize()
+        # the same pass with every branch on ONE stream: each kernel's duration alone on the device (the pass above times a side-stream
+        # kernel from its launch to its end, including the time it waits for CUs the concurrent convolution holds)
+        from cmr_agent_amd.utils import streams
+        streams.ENABLED = False
+        try:
+            with CallTimer() as ct1:
+                for _ in range(min(args.steps, 5)):
+                    registration_step(geo, agent, cfg, batch)
+                torch.cuda.synchronize()
+        finally:
+            streams.ENABLED = True
     assert torch.isfinite(pose).all()
     elapsed = ranks.max_over_ranks(elapsed)
 
@@ -314,6 +325,10 @@ def main():
         sum_ideal = sum(d["ideal_ms"] for d in table if d["modelled"])
         sum_meas = sum(d["ms"] for d in table if d["modelled"])
         unmodelled = [d["name"] for d in table if not d["modelled"]]
+        t1 = ct1.table()
+        n1 = min(args.steps, 5)
+        alone_ideal = sum(d["ideal_ms"] for d in t1 if d["modelled"])
+        alone_meas = sum(d["ms"] for d in t1 if d["modelled"])
         kernels = [dict(entry=d["name"], bound=d["bound"], calls_per_step=d["calls"] / args.steps, ms_per_step=round(d["ms"] / args.steps, 4),
                         ideal_ms_per_step=round(d["ideal_ms"] / args.steps, 4), frac=round(d["frac"], 3),
                         gflop_per_step=round(d["flops"] / args.steps / 1e9, 2), mb_per_step=round(d["bytes"] / args.steps / 1e6, 1))
@@ -337,6 +352,8 @@ def main():
                   # calls, algorithmic bytes / 8 TB/s for HBM-class ones) / sum of the measured times
                   "path": sum_ideal / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
                   "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled, "kernels": kernels[:14],
+                  # the same ratio with every kernel timed ALONE on the device (single stream): what the kernels themselves achieve
+                  "path_alone": alone_ideal / alone_meas, "path_alone_kernel_ms_per_step": alone_meas / n1,
                   "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the side-stream "
                               "branches of the forward run concurrently, as in the replayed graph)" % args.steps}
         if dtype == "bf16":
