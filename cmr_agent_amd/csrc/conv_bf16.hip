@@ -32,16 +32,28 @@ struct B16Args {
   // as `ptr ? offset : 0` in the kernel, hipcc turns every such select into a branch around the address arithmetic, and one branch
   // in the tile loop degrades each later s_waitcnt to vmcnt(0) (81 of them in the first version of this kernel)
   int res_mul, bias_mul;
+  int x_bf16, y_bf16;    // activations stored as bf16 NHWC (input / output): a convolution whose output only feeds another bf16 convolution
+                         // writes the bf16 values that one would round its fp32 input to anyway -- same results, half the bytes
 };
 
 __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+// four floats -> four bf16 (round to nearest even, v_cvt_pk_bf16_f32) as 8 bytes
+__device__ __forceinline__ uint2 b16_pack4(const f32x4& v) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  uint2 w;
+  w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[0], v[1]}, bf16x2_t));
+  w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_t){v[2], v[3]}, bf16x2_t));
+  return w;
+}
 
 // TW = 32: wave w owns rows 2w, 2w+1 as two 32-pixel blocks (lane = column).
 // TW = 16: wave w owns rows 2w, 2w+1 as ONE block (lane = 16 (row & 1) + column).
 // S = stride (1 | 2): the output tile stays TH x TW, the halo image grows to ((TH - 1) S + 3) x ((TW - 1) S + 3) input pixels and a
 // lane's pixel sits at (S row + ky, S column + kx) in it (S = 2: 288 bytes between neighbouring lanes = 8 banks apart, still
 // conflict free).  a.H / a.W are the INPUT sizes; the output is ((H - 1) / S + 1) x ((W - 1) / S + 1).
-template <int CIN, int NT, int TW, int S = 1, bool POOL = false, bool POST = false>
+template <int CIN, int NT, int TW, int S = 1, bool POOL = false, bool POST = false, bool OUT16 = false>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   constexpr int KS = CIN / 16, NB = TW / 16;
   constexpr int TH = 8, HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
@@ -273,11 +285,14 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
       for (int nb = 0; nb < NB; ++nb) {
         const int oy = t.oy0 + prow[nb], ox = t.ox0 + pcol[nb];
         if (oy < Ho && ox < Wo) {
-          float* yp = a.y + (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h;
+          const int64_t o = (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nb][nt][q];
+            for (int q = 0; q < 4; ++q) {
+              if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.y) + o + nt * 32 + q * 8) = b16_pack4(ov[nb][nt][q]);
+              else *reinterpret_cast<f32x4*>(a.y + o + nt * 32 + q * 8) = ov[nb][nt][q];
+            }
         }
       }
     }
@@ -292,12 +307,12 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
   }
 }
 
-template <int CIN, int NT, int TW, int S, bool POOL, bool POST>
+template <int CIN, int NT, int TW, int S, bool POOL, bool POST, bool OUT16 = false>
 int launch_b16p(B16Args a, hipStream_t stream) {
   constexpr int smem = 9 * (CIN / 16) * NT * 1024 + (7 * S + 3) * ((TW - 1) * S + 3) * (CIN * 2 + 16);
   static_assert(smem <= 160 * 1024, "weight slice + halo image must fit in LDS");
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW, S, POOL, POST>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_kernel<CIN, NT, TW, S, POOL, POST, OUT16>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   a.tiles_x = ((a.W - 1) / S + 1 + TW - 1) / TW;
   a.tiles_y = ((a.H - 1) / S + 1 + 7) / 8;
   const int ngroups = a.Cout / (32 * NT);
@@ -305,7 +320,7 @@ int launch_b16p(B16Args a, hipStream_t stream) {
   int per_group = 256 / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > nsp) per_group = (int)nsp;
-  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW, S, POOL, POST>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_kernel<CIN, NT, TW, S, POOL, POST, OUT16>), dim3(ngroups * per_group), dim3(256), smem, stream, a);
   return cmr_launch_status();
 }
 
@@ -316,8 +331,10 @@ int launch_b16(B16Args a, hipStream_t stream) {
     if (a.pool == 2) return launch_b16p<CIN, NT, TW, S, true, false>(a, stream);
     if (a.post) return launch_b16p<CIN, NT, TW, S, false, true>(a, stream);
   } else {
-    if (a.post) return launch_b16p<CIN, NT, TW, S, false, true>(a, stream);
+    if (a.post) return a.y_bf16 ? CMR_EUNSUPPORTED : launch_b16p<CIN, NT, TW, S, false, true>(a, stream);
+    if (a.y_bf16) return launch_b16p<CIN, NT, TW, S, false, false, true>(a, stream);
   }
+  if (a.y_bf16) return CMR_EUNSUPPORTED;               // bf16 output of the one-team kernel: the strided instance only
   return launch_b16p<CIN, NT, TW, S, false, false>(a, stream);
 }
 
@@ -330,14 +347,16 @@ int launch_b16(B16Args a, hipStream_t stream) {
 //     M(u) ; barrier ; X(u) ; barrier          M = multiply unit u from the team's buffer, X = [epilogue] + stage u+1 + request u+2
 // with team 1 delayed by one barrier, so M of one team always faces X of the other.  A unit is a (tile, 64-channel K chunk): Cin = 128
 // takes two units per tile through the same 26 KB buffer, which is what lets two buffers sit next to the 72 KB of weights.
-template <int CIN, int NT, bool POOL, bool POST>
+template <int CIN, int NT, bool POOL, bool POST, int IO = 0>      // IO: bit 0 = bf16 input, bit 1 = bf16 output
 __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
   constexpr int KC = CIN / 64, KS = CIN / 16;
   constexpr int TH = 8, TW = 16, HR = TH + 2, HC = TW + 2;
   constexpr int PS = 64 * 2 + 16;                       // bytes per halo pixel of one K chunk
   constexpr int WBYTES = 9 * KS * NT * 1024;
   constexpr int XBYTES = HR * HC * PS;
-  constexpr int NPIECE = HR * HC * 16;                  // float4 pieces of one unit
+  constexpr int PPP = IN16 ? 8 : 16;                    // 16-byte pieces per halo pixel of one unit (8 bf16 | 4 floats each)
+  constexpr int NPIECE = HR * HC * PPP;
   constexpr int NLOAD = (NPIECE + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -396,16 +415,17 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
   if (tid < 32 * NT) Bs[tid] = (a.bias ? a.bias : b16_zero16)[(co0 + tid) * a.bias_mul];
   const int prow = 2 * tw + (l31 >> 4), pcol = l31 & 15;       // this lane's pixel inside the tile
   auto issue_loads = [&](const Tile& t, int kc, f32x4 (&dst)[NLOAD]) __attribute__((always_inline)) {
-    const float* xb = a.x + (int64_t)t.b * a.H * a.W * CIN + kc * 64;
+    constexpr int ES = IN16 ? 2 : 4;                    // bytes per stored activation
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)t.b * a.H * a.W * CIN + kc * 64) * ES;
 #pragma unroll
     for (int i = 0; i < NLOAD; ++i) {
       int e = ttid + 256 * i;
       e = e < NPIECE ? e : NPIECE - 1;
-      const int p = e >> 4, c = e & 15;
+      const int p = e / PPP, c = e % PPP;
       int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
       iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
       ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
-      dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN + 4 * c));
+      dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN * ES + 16 * c));
     }
   };
   auto store_lds = [&](const Tile& t, const f32x4 (&src)[NLOAD]) __attribute__((always_inline)) {
@@ -413,19 +433,20 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
     for (int i = 0; i < NLOAD; ++i) {
       const int e = ttid + 256 * i;
       if (e < NPIECE) {
-        const int p = e >> 4, c = e & 15;
+        const int p = e / PPP, c = e % PPP;
         const int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
         const bool inb = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
-        // two packed conversions (v_cvt_pk_bf16_f32) and the padding as a mask on the packed words: 5 instead of 10 instructions per piece
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t lo = __builtin_convertvector((f32x2_t){src[i][0], src[i][1]}, bf16x2_t);
-        const bf16x2_t hi = __builtin_convertvector((f32x2_t){src[i][2], src[i][3]}, bf16x2_t);
         const unsigned keep = inb ? 0xffffffffu : 0u;
-        uint2 w;
-        w.x = __builtin_bit_cast(unsigned, lo) & keep;
-        w.y = __builtin_bit_cast(unsigned, hi) & keep;
-        *reinterpret_cast<uint2*>(Xs + p * PS + c * 8) = w;
+        if constexpr (IN16) {                           // already bf16: 16 bytes = 8 channels, the padding as a mask
+          uint4 w = __builtin_bit_cast(uint4, src[i]);
+          w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
+          *reinterpret_cast<uint4*>(Xs + p * PS + c * 16) = w;
+        } else {
+          // two packed conversions (v_cvt_pk_bf16_f32) and the padding as a mask on the packed words: 5 instead of 10 instructions per piece
+          uint2 w = b16_pack4(src[i]);
+          w.x &= keep; w.y &= keep;
+          *reinterpret_cast<uint2*>(Xs + p * PS + c * 8) = w;
+        }
       }
     }
   };
@@ -499,24 +520,23 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
+    auto put = [&](int64_t o) __attribute__((always_inline)) {   // the lane's 4 x NT quads at element offset o (+ 32 nt + 8 q), fp32 or bf16
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.y) + o + nt * 32 + q * 8) = b16_pack4(ov[nt][q]);
+          else *reinterpret_cast<f32x4*>(a.y + o + nt * 32 + q * 8) = ov[nt][q];
+        }
+    };
     if constexpr (POOL) {
       const int py = (t.oy0 >> 1) + tw, px = (t.ox0 >> 1) + (pcol >> 1);
       if (live && (l31 & 17) == 0 && py < (Ho >> 1) && px < (Wo >> 1)) {
-        float* yp = a.y + (((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + co0 + 4 * h;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nt][q];
+        put((((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + co0 + 4 * h);
       }
     } else {
       const int oy = t.oy0 + prow, ox = t.ox0 + pcol;
-      if (live && oy < Ho && ox < Wo) {
-        float* yp = a.y + (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yp + nt * 32 + q * 8) = ov[nt][q];
-      }
+      if (live && oy < Ho && ox < Wo) put((((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + co0 + 4 * h);
     }
   };
 
@@ -569,12 +589,12 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
   if (team == 0) __syncthreads();                       // team 0 waits out team 1's last phase
 }
 
-template <int CIN, int NT, bool POOL, bool POST>
+template <int CIN, int NT, bool POOL, bool POST, int IO>
 int launch_tt_p(B16Args a, hipStream_t stream) {
   constexpr int smem = 9 * (CIN / 16) * NT * 1024 + 2 * 10 * 18 * 144 + 256;
   static_assert(smem <= 160 * 1024, "weight slice + two halo buffers must fit in LDS");
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   a.tiles_x = (a.W + 15) / 16;
   a.tiles_y = (a.H + 7) / 8;
   const int ngroups = a.Cout / (32 * NT);
@@ -582,43 +602,63 @@ int launch_tt_p(B16Args a, hipStream_t stream) {
   int per_group = 256 / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > (nsp + 1) / 2) per_group = (int)((nsp + 1) / 2);      // a workgroup has two teams
-  hipLaunchKernelGGL((conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
   return cmr_launch_status();
+}
+
+template <int CIN, int NT, int IO>
+int launch_tt_io(B16Args a, hipStream_t stream) {
+  if (a.pool == 2) return launch_tt_p<CIN, NT, true, false, IO>(a, stream);
+  if (a.post) {
+    if constexpr (IO == 0) return launch_tt_p<CIN, NT, false, true, 0>(a, stream);
+    else return CMR_EUNSUPPORTED;                      // the table operand only occurs with fp32 activations
+  }
+  return launch_tt_p<CIN, NT, false, false, IO>(a, stream);
 }
 
 template <int CIN, int NT>
 int launch_tt(B16Args a, hipStream_t stream) {
   a.res_mul = a.res ? 1 : 0; a.bias_mul = a.bias ? 1 : 0;
-  if (a.pool == 2) return launch_tt_p<CIN, NT, true, false>(a, stream);
-  if (a.post) return launch_tt_p<CIN, NT, false, true>(a, stream);
-  return launch_tt_p<CIN, NT, false, false>(a, stream);
+  switch ((a.x_bf16 ? 1 : 0) | (a.y_bf16 ? 2 : 0)) {
+    case 1: return launch_tt_io<CIN, NT, 1>(a, stream);
+    case 2: return launch_tt_io<CIN, NT, 2>(a, stream);
+    case 3: return launch_tt_io<CIN, NT, 3>(a, stream);
+    default: return launch_tt_io<CIN, NT, 0>(a, stream);
+  }
 }
 
 }  // namespace
 
-extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
-                                         const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
-                                         hipStream_t stream) {
+static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
+                                 const float* res, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
+                                 hipStream_t stream) {
   CMR_REQUIRE(x && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0 && (stride == 1 || stride == 2));
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(wfrag) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
               (!post || cmr_aligned16(post)));
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
-  B16Args a{x, B, H, W, wfrag, bias, res, post, y, Cout, slope, pool, 0, 0, 0, 0};
+  B16Args a{static_cast<const float*>(x), B, H, W, wfrag, bias, res, post, static_cast<float*>(y), Cout, slope, pool, 0, 0, 0, 0, x_bf16, y_bf16};
   if (stride == 2) {
     if (pool != 1) return CMR_EINVAL;
+    if (x_bf16) return CMR_EUNSUPPORTED;               // the strided instance reads fp32 activations (it opens a ResidualBlock)
     if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 16, 2>(a, stream);
     if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 16, 2>(a, stream);
     return CMR_EUNSUPPORTED;
   }
-#ifndef B16_ONE_TEAM
   if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_tt<64, 2>(a, stream);
   if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_tt<64, 1>(a, stream);
   if (Cin == 128 && nt == 1 && Cout % 32 == 0) return launch_tt<128, 1>(a, stream);
-#else
-  if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 32>(a, stream);
-  if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 32>(a, stream);
-  if (Cin == 128 && nt == 1 && Cout % 32 == 0) return launch_b16<128, 1, 16>(a, stream);
-#endif
   return CMR_EUNSUPPORTED;
+}
+
+extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
+                                         const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
+                                         hipStream_t stream) {
+  return conv3x3_bf16_dispatch(x, 0, B, H, W, Cin, wfrag, nt, bias, res, post, y, 0, Cout, stride, slope, pool, stream);
+}
+
+extern "C" int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
+                                       const float* res, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
+                                       hipStream_t stream) {
+  return conv3x3_bf16_dispatch(x, x_bf16, B, H, W, Cin, wfrag, nt, bias, res, post, y, y_bf16, Cout, stride, slope, pool, stream);
 }

@@ -120,10 +120,11 @@ class CMRAgent(Planned):
                     cache["val"] = ops.conv3x3(img_src, wi, bi, c, 1, 1.0, u=ui)
                     cache["tag"] = tag
                 wp, _, up = p["conv0_proj"]
-                x = ops.conv3x3(proj, wp, None, c, 1, SLOPE, res=cache["val"], u=up)
+                x = ops.conv3x3(proj, wp, None, c, 1, SLOPE, res=cache["val"], u=up, out_bf16=True)
             else:
-                x = ops.conv3x3(x, wa, ba, c, 1, SLOPE, u=ua)
-            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE, pool=2 if stage < 3 else 1, u=ub)     # AvgPool2d(2,2) in the epilogue
+                x = ops.conv3x3(x, wa, ba, c, 1, SLOPE, u=ua, out_bf16=True)
+            # every map of the chain only feeds the next convolution (bf16 mode: stored as bf16); the last one goes to the heads in fp32
+            x = ops.conv3x3(x, wb, bb, c, 1, SLOPE, pool=2 if stage < 3 else 1, u=ub, out_bf16=stage < 3)     # AvgPool2d(2,2) in the epilogue
             if stage == 3:
                 kh, kw = self.config.image_H // 8, self.config.image_W // 8
                 if (x.shape[1], x.shape[2]) != (kh, kw):

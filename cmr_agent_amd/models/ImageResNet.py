@@ -68,7 +68,9 @@ class ResidualBlock(Planned):
         if p["stem"]:
             assert post is None
             return ops.stem_block(x, p["wa"], p["ba"], p["w3"], p["w1"], p["bb"], self.SLOPE)
-        t = ops.conv3x3(x, p["a"][0], p["a"][1], self.inchannel, self.stride, self.SLOPE, u=p["a"][2])
+        # t only feeds conv b: in bf16 mode it is stored as bf16 (what conv b would round it to anyway)
+        t = ops.conv3x3(x, p["a"][0], p["a"][1], self.inchannel, self.stride, self.SLOPE, u=p["a"][2],
+                        out_bf16=post is None and getattr(p["b"][2], "bf16", None) is not None)      # (the table operand goes with fp32 maps)
         sc = p["sc"]
         if sc is None:
             res = x

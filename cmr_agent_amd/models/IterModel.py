@@ -95,12 +95,12 @@ class IterModel(Planned):
         base = ops.iter_finalize(None, None, ov, p["w_ov"], base[0])                          # + overlap plane -> [1, h, w, 64]
         res = ops.iter_finalize(acc, cnt, occ, p["w_occ"], base[0])                           # acc <- mean; + occupancy plane per pose
         ww, _, uw = p["warped"]
-        x = ops.conv3x3(acc, ww, None, 64, 1, SLOPE, res=res, u=uw)
+        x = ops.conv3x3(acc, ww, None, 64, 1, SLOPE, res=res, u=uw, out_bf16=True)        # bf16 mode: the chain's maps are stored as bf16
         del res, acc
         # ---- the rest of cost_volume_convs: (conv, pool) (conv+BN, conv, pool) x 2, conv+BN, conv
         pools = (2, 1, 2, 1, 2, 1, 1)
-        for (w9, b, u), pool in zip(p["chain"], pools):
-            x = ops.conv3x3(x, w9, b, 64, 1, SLOPE, pool=pool, u=u)
+        for i, ((w9, b, u), pool) in enumerate(zip(p["chain"], pools)):
+            x = ops.conv3x3(x, w9, b, 64, 1, SLOPE, pool=pool, u=u, out_bf16=i < len(pools) - 1)
         logits = ops.iter_head(x, p["w24"], p["b24"], p["w26"], p["b26"], SLOPE)
         data_batch["cost_colume_logits"] = logits.view(1, -1)
         data_batch["weight"] = data_batch["img_overlap_pred"].unsqueeze(1).unsqueeze(1)

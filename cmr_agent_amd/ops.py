@@ -98,6 +98,7 @@ def layernorm64(x, gamma, beta, eps, res=None, out=None):
 CONV_BF16 = False        # True: bf16 mode -- 3x3 convolutions (cmr_conv3x3_bf16_nhwc_f32), ConvBNReLURes1D blocks (cmr_cbr_block_bf16_f32)
                          # and the query side of the linear-attention layers (cmr_la_query_layer_bf16_f32) run on the bf16 matrix cores
                          # where served; storage and everything else stay fp32
+BF16_CHAINS = True       # bf16 mode: a convolution whose output only feeds another bf16 convolution stores it as bf16 (bit-identical, half the bytes)
 STRIDE2_FRAGS = True     # stride-2 convolutions (Cin = 64) on the fragment-weight kernel cmr_conv3x3_s2_nhwc_f32; False = the tiled kernel (A/B, tests)
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
@@ -117,27 +118,36 @@ def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     return y
 
 
-def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, stride=1):
-    """3x3 convolution (stride 1 | 2) on the bf16 matrix cores; frags = (bf16 fragment tensor, nt) from _pack.conv_bf16_frags.
-    Returns None when the library does not serve the shape (the caller falls back to the fp32 kernels)."""
+def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, stride=1, out_bf16=False):
+    """3x3 convolution (stride 1 | 2) on the bf16 matrix cores; frags = (bf16 fragment tensor, nt) from _pack.conv_bf16_frags.  x is fp32 or
+    bf16 NHWC (a bf16 x is the output of another bf16 convolution); out_bf16: store the result as bf16 (for a following bf16 convolution:
+    that one would round fp32 to the same values).  Returns None when the library does not serve the shape (the caller falls back to the
+    fp32 kernels -- impossible once x is bf16, which raises instead)."""
     B, H, W, cin = x.shape
     wf, nt = frags
-    if not x.is_contiguous() or wf.dtype != torch.bfloat16 or wf.numel() != 9 * cin * cout:
+    xb = x.dtype == torch.bfloat16
+    if not x.is_contiguous() or wf.dtype != torch.bfloat16 or wf.numel() != 9 * cin * cout or x.dtype not in (f32, torch.bfloat16):
         raise ValueError("conv3x3_bf16: bad operand layout")
     if pool == 2 and (res is not None or post is not None):
         raise ValueError("conv3x3: pool=2 cannot be combined with res / post")
-    if pool == 2 and (H % 2 or W % 2):
-        return None
-    if stride == 2 and (pool != 1 or cin != 64):
-        return None
-    hp, wp = (H // 2, W // 2) if pool == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
-    y = torch.empty((B, hp, wp, cout), dtype=f32, device=x.device)
-    rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, int(stride),
-                   float(slope), pool, _stream(), allow_unsupported=True)
-    return None if rc == _lib.UNSUPPORTED else y
+    unserved = (pool == 2 and (H % 2 or W % 2)) or (stride == 2 and (pool != 1 or cin != 64 or xb)) or ((xb or out_bf16) and post is not None)
+    if not unserved:
+        hp, wp = (H // 2, W // 2) if pool == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
+        y = torch.empty((B, hp, wp, cout), dtype=torch.bfloat16 if out_bf16 else f32, device=x.device)
+        if xb or out_bf16:
+            rc = _lib.call("cmr_conv3x3_bf16io_nhwc", _p(x), int(xb), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), int(out_bf16),
+                           cout, int(stride), float(slope), pool, _stream(), allow_unsupported=True)
+        else:
+            rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, int(stride),
+                           float(slope), pool, _stream(), allow_unsupported=True)
+        if rc != _lib.UNSUPPORTED:
+            return y
+    if xb:
+        raise ValueError("conv3x3_bf16: a bf16 input of shape %s (stride %d, pool %d) is not served" % (tuple(x.shape), stride, pool))
+    return None
 
 
-def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None):
+def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None, out_bf16=False):
     """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout] (or the 2x2 average-pooled
     map when pool=2: fused into the conv epilogue where the tiled kernel runs, a second kernel otherwise).
     u [16,Cout,Cin] (= G g G^T) enables the Winograd kernel for stride 1."""
@@ -145,8 +155,13 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
     ho, wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if not x.is_contiguous() or tuple(w9.shape) != (9, cout, cin):
         raise ValueError("conv3x3: bad operand layout")
+    if x.dtype == torch.bfloat16:                           # the output of a bf16 convolution: only a bf16 convolution reads it
+        if getattr(u, "bf16", None) is None or out is not None:
+            raise ValueError("conv3x3: bf16 activations need the bf16 operands of the layer (u.bf16)")
+        return conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool, stride, out_bf16)
     if CONV_BF16 and out is None and getattr(u, "bf16", None) is not None:
-        y = conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool, stride)
+        # out_bf16 is a REQUEST: honoured when the bf16 kernel serves the layer (the result's dtype tells), ignored on the fp32 kernels
+        y = conv3x3_bf16(x, u.bf16, bias, cout, slope, res, post, pool, stride, out_bf16 and BF16_CHAINS)
         if y is not None:
             return y
     if (STRIDE2_FRAGS and stride == 2 and out is None and pool == 1 and post is None and getattr(u, "s2", None) is not None):

@@ -525,6 +525,15 @@ int cmr_iter_decide_f32(const float* logits, int nlabel, const float* label_r, c
 int cmr_iter_apply_f32(const float* matrix_i, const float* pc, float* pc_out, int N, const float* acc_in, float* acc_out,
                        hipStream_t stream);
 
+/* cmr_conv3x3_bf16_nhwc_f32 with the activations optionally STORED as bf16 NHWC (x_bf16 / y_bf16 != 0): for chains of bf16 convolutions
+ * (conv a -> conv b of a ResidualBlock, ImageResNet.py:9-14; the eight convolutions of the agent's 2-D embedding, CMRAgent.py:34-56).  The
+ * consumer rounds its fp32 input to bf16 (RNE) anyway, so a producer that writes those bf16 values gives bit-identical results with
+ * half the bytes.  Served: stride 1 with any combination, stride 2 with fp32 input; residual / bias fp32; no table operand with bf16
+ * activations.  Otherwise CMR_EUNSUPPORTED (-3). */
+int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
+                            const float* res, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
+                            hipStream_t stream);
+
 /* ---- dropout (train mode; the reference trains MultiHeadModel with p = 0.1 in 141 nn.Dropout modules) --------------------------
  * Counter-based masks: element idx of site `site` is kept iff mix64(seed[0], site, idx) >= p 2^32 (csrc/cmr_common.h:cmr_keep); seed is
  * a DEVICE int64 (advanced once per optimizer step by the host, so that a captured hipGraph draws fresh masks on every replay).

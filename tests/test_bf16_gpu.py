@@ -303,3 +303,41 @@ def test_vit_block_fused_pieces_bf16(rows_x, rows_y):
     e_bf = float((got.cpu().double() - want_bf).abs().max()) / scale
     e_fp = float((got.cpu().double() - want_fp).abs().max()) / scale
     assert e_bf <= 3e-3 and e_fp <= 3e-2, (e_bf, e_fp)
+
+
+def test_bf16_activation_chains_are_bit_identical_to_fp32_storage():
+    """A bf16 convolution whose output only feeds another bf16 convolution stores it as bf16 (cmr_conv3x3_bf16io_nhwc): the consumer would
+    round the fp32 values to exactly those (RNE), so results must not change by one bit -- op level (stride 1 -> pool, stride 2 -> stride 1,
+    Cin 64 and 128), a whole ResidualBlock, the agent's 2-D embedding."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import conv_bf16_frags
+    from cmr_agent_amd.models.ImageResNet import ResidualBlock
+    d = lambda t: t.to(DEV)
+    for cin, B, H, W, stride, pool in ((64, 2, 24, 40, 1, 1), (128, 3, 16, 48, 1, 2), (64, 2, 33, 70, 2, 1), (128, 1, 9, 21, 1, 1)):
+        x = d(rnd(B, H, W, cin, seed=1))
+        w1, w2 = d(rnd(cin, cin, 3, 3, seed=2) / 12), d(rnd(64, cin, 3, 3, seed=3) / 12)
+        b1, b2 = d(rnd(cin, seed=4)), d(rnd(64, seed=5))
+        f1, f2 = conv_bf16_frags(w1), conv_bf16_frags(w2)
+        ho, wo = ((H - 1) // stride + 1) // pool, ((W - 1) // stride + 1) // pool
+        r = d(rnd(B, ho, wo, 64, seed=6))
+        t32 = ops.conv3x3_bf16(x, f1, b1, cin, 0.2, stride=stride, pool=pool)
+        t16 = ops.conv3x3_bf16(x, f1, b1, cin, 0.2, stride=stride, pool=pool, out_bf16=True)
+        assert t16.dtype == torch.bfloat16 and torch.equal(t16, t32.to(torch.bfloat16))
+        y32 = ops.conv3x3_bf16(t32, f2, b2, 64, 0.2, res=r)
+        y16 = ops.conv3x3_bf16(t16, f2, b2, 64, 0.2, res=r)
+        assert y16.dtype == torch.float32 and torch.equal(y16, y32), (cin, stride, pool)
+        z16 = ops.conv3x3_bf16(t16, f2, b2, 64, 0.2, out_bf16=True)              # bf16 in AND out
+        assert torch.equal(z16, ops.conv3x3_bf16(t32, f2, b2, 64, 0.2).to(torch.bfloat16))
+    torch.manual_seed(0)
+    ops.CONV_BF16 = True
+    try:
+        for cin, cout, stride in ((64, 64, 1), (64, 64, 2), (128, 64, 1)):
+            blk = ResidualBlock(cin, cout, stride).to(DEV).eval()
+            x = d(rnd(2, 24, 56, cin, seed=7))
+            outs = []
+            for chains in (True, False):
+                ops.BF16_CHAINS = chains
+                outs.append(blk.forward_cl(x))
+            assert torch.equal(outs[0], outs[1]), (cin, cout, stride)
+    finally:
+        ops.CONV_BF16, ops.BF16_CHAINS = False, True
