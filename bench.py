@@ -255,6 +255,9 @@ def main():
                     help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
     ap.add_argument("--num-pt", type=int, default=None, help="train-geo: points per cloud (default KittiConfig's 40960; configs[4] = 65536)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
+    ap.add_argument("--alone-pass", action="store_true", help="one more (untimed) eager pass with every branch on ONE stream: adds "
+                    "roofline.path_alone, each kernel's duration alone on the device (off by default so that the kernel statistics of a "
+                    "profiled default run contain the same launches the JSON line averages over)")
     args = ap.parse_args()
     if args.mode == "train":
         return train_main(args)
@@ -306,29 +309,35 @@ def main():
             torch.cuda.synchronize()
         # the same pass with every branch on ONE stream: each kernel's duration alone on the device (the pass above times a side-stream
         # kernel from its launch to its end, including the time it waits for CUs the concurrent convolution holds)
-        from cmr_agent_amd.utils import streams
-        streams.ENABLED = False
-        try:
-            with CallTimer() as ct1:
-                for _ in range(min(args.steps, 5)):
-                    registration_step(geo, agent, cfg, batch)
-                torch.cuda.synchronize()
-        finally:
-            streams.ENABLED = True
+        ct1 = None
+        if args.alone_pass:
+            from cmr_agent_amd.utils import streams
+            streams.ENABLED = False
+            try:
+                with CallTimer() as ct1:
+                    for _ in range(min(args.steps, 5)):
+                        registration_step(geo, agent, cfg, batch)
+                    torch.cuda.synchronize()
+            finally:
+                streams.ENABLED = True
     assert torch.isfinite(pose).all()
     elapsed = ranks.max_over_ranks(elapsed)
 
     if rank == 0:
         table = ct.table()
-        dom = [d for d in table if d["name"] == ("cmr_conv3x3_bf16_nhwc_f32" if dtype == "bf16" else "cmr_conv3x3_wino_nhwc_f32")][0]
-        conv = dict(launches=dom["calls"], ms=dom["ms"], flops=dom["flops"], bytes=dom["bytes"])
+        dom_names = ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc") if dtype == "bf16" else ("cmr_conv3x3_wino_nhwc_f32",)
+        doms = [d for d in table if d["name"] in dom_names]
+        conv = dict(launches=sum(d["calls"] for d in doms), ms=sum(d["ms"] for d in doms), flops=sum(d["flops"] for d in doms),
+                    bytes=sum(d["bytes"] for d in doms))
         sum_ideal = sum(d["ideal_ms"] for d in table if d["modelled"])
         sum_meas = sum(d["ms"] for d in table if d["modelled"])
         unmodelled = [d["name"] for d in table if not d["modelled"]]
-        t1 = ct1.table()
-        n1 = min(args.steps, 5)
-        alone_ideal = sum(d["ideal_ms"] for d in t1 if d["modelled"])
-        alone_meas = sum(d["ms"] for d in t1 if d["modelled"])
+        alone = {}
+        if ct1 is not None:
+            t1 = ct1.table()
+            # the same ratio with every kernel timed ALONE on the device (single stream): what the kernels themselves achieve
+            alone = {"path_alone": sum(d["ideal_ms"] for d in t1 if d["modelled"]) / sum(d["ms"] for d in t1 if d["modelled"]),
+                     "path_alone_kernel_ms_per_step": sum(d["ms"] for d in t1 if d["modelled"]) / min(args.steps, 5)}
         kernels = [dict(entry=d["name"], bound=d["bound"], calls_per_step=d["calls"] / args.steps, ms_per_step=round(d["ms"] / args.steps, 4),
                         ideal_ms_per_step=round(d["ideal_ms"] / args.steps, 4), frac=round(d["frac"], 3),
                         gflop_per_step=round(d["flops"] / args.steps / 1e9, 2), mb_per_step=round(d["bytes"] / args.steps / 1e6, 1))
@@ -352,8 +361,7 @@ def main():
                   # calls, algorithmic bytes / 8 TB/s for HBM-class ones) / sum of the measured times
                   "path": sum_ideal / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
                   "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled, "kernels": kernels[:14],
-                  # the same ratio with every kernel timed ALONE on the device (single stream): what the kernels themselves achieve
-                  "path_alone": alone_ideal / alone_meas, "path_alone_kernel_ms_per_step": alone_meas / n1,
+                  **alone,
                   "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the side-stream "
                               "branches of the forward run concurrently, as in the replayed graph)" % args.steps}
         if dtype == "bf16":

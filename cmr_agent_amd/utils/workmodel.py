@@ -43,6 +43,14 @@ def _conv(a, stride=None):
     return 2.0 * 9 * ci * co * opix, by
 
 
+def _conv_io(a):
+    s = a.get("stride", 1)
+    B, H, W, ci, co, pool = a["B"], a["H"], a["W"], a["Cin"], a["Cout"], a.get("pool", 1)
+    opix = B * ((H - 1) // s + 1) * ((W - 1) // s + 1)
+    by = (2 if a["x_bf16"] else F) * B * H * W * ci + (2 if a["y_bf16"] else F) * opix * co / (pool * pool) + F * ((opix * co if a["res"] else 0) + 9 * ci * co)
+    return 2.0 * 9 * ci * co * opix, by
+
+
 def _heads(a):
     w = 2 * 128 * 128 + sum(256 * a[p + "_n0"] + a[p + "_n0"] * a[p + "_n1"] + a[p + "_n1"] * a[p + "_n2"] for p in "rtv")
     return 2.0 * a["B"] * w, F * (a["B"] * a["npix"] * 128 + w)
@@ -65,6 +73,7 @@ WORK = {
     "cmr_conv3x3_wino_nhwc_f32": lambda a: _conv(a, 1),
     "cmr_conv3x3_s2_nhwc_f32": lambda a: _conv(a, 2),
     "cmr_conv3x3_bf16_nhwc_f32": _conv,
+    "cmr_conv3x3_bf16io_nhwc": _conv_io,
     # ResidualBlock(3 -> 64): conv3x3 3->3, conv3x3 3->64, 1x1 shortcut 3->64
     "cmr_stem_block_f32": lambda a: (2.0 * (81 + 1728 + 192) * a["B"] * a["H"] * a["W"], F * a["B"] * a["H"] * a["W"] * (3 + 64)),
     "cmr_avgpool_nhwc_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (1 + 1.0 / (a["kh"] * a["kw"]))),
