@@ -347,11 +347,15 @@ int launch_b16(B16Args a, hipStream_t stream) {
 //     M(u) ; barrier ; X(u) ; barrier          M = multiply unit u from the team's buffer, X = [epilogue] + stage u+1 + request u+2
 // with team 1 delayed by one barrier, so M of one team always faces X of the other.  A unit is a (tile, 64-channel K chunk): Cin = 128
 // takes two units per tile through the same 26 KB buffer, which is what lets two buffers sit next to the 72 KB of weights.
-template <int CIN, int NT, bool POOL, bool POST, int IO = 0>      // IO: bit 0 = bf16 input, bit 1 = bf16 output
+// S = 2 (the strided convolutions of the down-sampling blocks, Cin = 64, NT = 2): a team's tile is 4 x 16 OUTPUT pixels (9 x 33 input
+// pixels: two 42 KB buffers still fit next to the weights), and its four waves are 2 pixel blocks x 2 cout tiles -- one accumulator each.
+template <int CIN, int NT, bool POOL, bool POST, int IO = 0, int S = 1>      // IO: bit 0 = bf16 input, bit 1 = bf16 output
 __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
   constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  static_assert(S == 1 || (S == 2 && NT == 2 && CIN == 64 && !POOL && !IN16), "strided instance: 64 -> 64 k, fp32 input");
+  constexpr int NTW = S == 1 ? NT : 1;                  // cout tiles per wave
   constexpr int KC = CIN / 64, KS = CIN / 16;
-  constexpr int TH = 8, TW = 16, HR = TH + 2, HC = TW + 2;
+  constexpr int TH = S == 1 ? 8 : 4, TW = 16, HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
   constexpr int PS = 64 * 2 + 16;                       // bytes per halo pixel of one K chunk
   constexpr int WBYTES = 9 * KS * NT * 1024;
   constexpr int XBYTES = HR * HC * PS;
@@ -405,15 +409,16 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
   // ONE halo image in flight per team, requested a whole period (two phases) before it is staged.  Two register sets for Cin = 128
   // (each chunk requested a tile ahead) measured 5 % slower.
   f32x4 pv[1][NLOAD];
-  f32x4 rv[NT][4];
-  f32x4 tv[POST ? NT : 1][4];
-  const int Ho = a.H, Wo = a.W;
+  f32x4 rv[NTW][4];
+  f32x4 tv[POST ? NTW : 1][4];
+  const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
+  const int nt0 = S == 1 ? 0 : (tw >> 1);               // first cout tile of this wave
   const float* rbase = a.res ? a.res : b16_zero16;
   // the folded-BN bias of this cout group sits in LDS (the epilogue runs in the X phase, where an LDS read costs nothing and a
   // register array would cost 8 NT registers of a 256-register budget)
   float* Bs = reinterpret_cast<float*>(smem + WBYTES + 2 * XBYTES);
   if (tid < 32 * NT) Bs[tid] = (a.bias ? a.bias : b16_zero16)[(co0 + tid) * a.bias_mul];
-  const int prow = 2 * tw + (l31 >> 4), pcol = l31 & 15;       // this lane's pixel inside the tile
+  const int prow = 2 * (S == 1 ? tw : (tw & 1)) + (l31 >> 4), pcol = l31 & 15;       // this lane's pixel inside the tile
   auto issue_loads = [&](const Tile& t, int kc, f32x4 (&dst)[NLOAD]) __attribute__((always_inline)) {
     constexpr int ES = IN16 ? 2 : 4;                    // bytes per stored activation
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)t.b * a.H * a.W * CIN + kc * 64) * ES;
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
       int e = ttid + 256 * i;
       e = e < NPIECE ? e : NPIECE - 1;
       const int p = e / PPP, c = e % PPP;
-      int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+      int iy = t.oy0 * S - 1 + p / HC, ix = t.ox0 * S - 1 + p % HC;
       iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
       ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
       dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN * ES + 16 * c));
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
       const int e = ttid + 256 * i;
       if (e < NPIECE) {
         const int p = e / PPP, c = e % PPP;
-        const int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+        const int iy = t.oy0 * S - 1 + p / HC, ix = t.ox0 * S - 1 + p % HC;
         const bool inb = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
         const unsigned keep = inb ? 0xffffffffu : 0u;
         if constexpr (IN16) {                           // already bf16: 16 bytes = 8 channels, the padding as a mask
@@ -457,16 +462,16 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
       const int oyc = ok ? oy : 0, oxc = ok ? ox : 0;
       const int64_t pix = ((int64_t)t.b * Ho + oyc) * Wo + oxc;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int cq = co0 + nt * 32 + q * 8 + 4 * h;
+          const int cq = co0 + (nt0 + nt) * 32 + q * 8 + 4 * h;
           rv[nt][q] = *reinterpret_cast<const f32x4*>(rbase + (pix * a.Cout + cq) * a.res_mul);
           if constexpr (POST) tv[nt][q] = *reinterpret_cast<const f32x4*>(a.post + ((int64_t)oyc * Wo + oxc) * a.Cout + cq);
         }
     }
   };
-  f32x16 acc[NT];
+  f32x16 acc[NTW];
   // 36 steps (9 taps x 4 k-steps of the chunk), each NT weight fragments + 1 pixel fragment from LDS feeding NT matrix instructions.
   // hipcc emits read / s_waitcnt lgkmcnt(0) / multiply per step, i.e. the LDS latency in front of every instruction -- and that is
   // the faster form HERE: issuing the reads one or two steps ahead into rotating register sets (measured, 2 and 3 sets, with scheduling
@@ -477,27 +482,27 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
       const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 av[NT];
+        bf16x8 av[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          av[nt] = *reinterpret_cast<const bf16x8*>(Ws + ((tap * KS + kc * 4 + ks) * NT + nt) * 1024 + lane * 16);
-        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(Xs + ((prow + ky) * HC + pcol + kx) * PS + ks * 32 + h * 16);
+        for (int nt = 0; nt < NTW; ++nt)
+          av[nt] = *reinterpret_cast<const bf16x8*>(Ws + ((tap * KS + kc * 4 + ks) * NT + nt0 + nt) * 1024 + lane * 16);
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(Xs + ((prow * S + ky) * HC + pcol * S + kx) * PS + ks * 32 + h * 16);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[nt], bv, acc[nt], 0, 0, 0);
       }
     }
   };
   auto epilogue = [&](const Tile& t, bool live) __attribute__((always_inline)) {
     // register 4q+e of tile nt = channel co0 + 32 nt + 8q + 4h + e of this lane's pixel
-    f32x4 ov[NT][4];
+    f32x4 ov[NTW][4];
     if constexpr (POOL) {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float v = acc[nt][4 * q + e] + Bs[nt * 32 + q * 8 + 4 * h + e];
+            float v = acc[nt][4 * q + e] + Bs[(nt0 + nt) * 32 + q * 8 + 4 * h + e];
             v = v > 0.f ? v : v * a.slope;
             v += __shfl_xor(v, 1, 64);                  // column partner
             v += __shfl_xor(v, 16, 64);                 // row partner (rows 2 tw / 2 tw + 1 sit 16 lanes apart)
@@ -505,28 +510,28 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
           }
     } else {
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float u = acc[nt][4 * q + e] + Bs[nt * 32 + q * 8 + 4 * h + e] + rv[nt][q][e];
+            const float u = acc[nt][4 * q + e] + Bs[(nt0 + nt) * 32 + q * 8 + 4 * h + e] + rv[nt][q][e];
             ov[nt][q][e] = u > 0.f ? u : u * a.slope;
           }
           if constexpr (POST) ov[nt][q] += tv[nt][q];
         }
     }
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
-    auto put = [&](int64_t o) __attribute__((always_inline)) {   // the lane's 4 x NT quads at element offset o (+ 32 nt + 8 q), fp32 or bf16
+    auto put = [&](int64_t o) __attribute__((always_inline)) {   // the lane's 4 x NTW quads at element offset o (+ 32 nt + 8 q), fp32 or bf16
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.y) + o + nt * 32 + q * 8) = b16_pack4(ov[nt][q]);
-          else *reinterpret_cast<f32x4*>(a.y + o + nt * 32 + q * 8) = ov[nt][q];
+          if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.y) + o + (nt0 + nt) * 32 + q * 8) = b16_pack4(ov[nt][q]);
+          else *reinterpret_cast<f32x4*>(a.y + o + (nt0 + nt) * 32 + q * 8) = ov[nt][q];
         }
     };
     if constexpr (POOL) {
@@ -558,7 +563,7 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
     const Tile tnn = decode(tile_of(i + 2 < npass ? i + 2 : (i + 1 < npass ? i + 1 : i)));
     const bool live = s0 + (2 * i + team) * step < s_end;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     if constexpr (KC == 2) {
@@ -589,20 +594,21 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
   if (team == 0) __syncthreads();                       // team 0 waits out team 1's last phase
 }
 
-template <int CIN, int NT, bool POOL, bool POST, int IO>
+template <int CIN, int NT, bool POOL, bool POST, int IO, int S = 1>
 int launch_tt_p(B16Args a, hipStream_t stream) {
-  constexpr int smem = 9 * (CIN / 16) * NT * 1024 + 2 * 10 * 18 * 144 + 256;
+  constexpr int TH = S == 1 ? 8 : 4;
+  constexpr int smem = 9 * (CIN / 16) * NT * 1024 + 2 * ((TH - 1) * S + 3) * (15 * S + 3) * 144 + 256;
   static_assert(smem <= 160 * 1024, "weight slice + two halo buffers must fit in LDS");
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
-  a.tiles_x = (a.W + 15) / 16;
-  a.tiles_y = (a.H + 7) / 8;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO, S>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  a.tiles_x = ((a.W - 1) / S + 1 + 15) / 16;
+  a.tiles_y = ((a.H - 1) / S + 1 + TH - 1) / TH;
   const int ngroups = a.Cout / (32 * NT);
   const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
   int per_group = 256 / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > (nsp + 1) / 2) per_group = (int)((nsp + 1) / 2);      // a workgroup has two teams
-  hipLaunchKernelGGL((conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO, S>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
   return cmr_launch_status();
 }
 
@@ -641,6 +647,12 @@ static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W,
   if (stride == 2) {
     if (pool != 1) return CMR_EINVAL;
     if (x_bf16) return CMR_EUNSUPPORTED;               // the strided instance reads fp32 activations (it opens a ResidualBlock)
+#ifndef B16_S2_ONE_TEAM
+    if (Cin == 64 && nt == 2 && Cout % 64 == 0 && !post) {
+      a.res_mul = a.res ? 1 : 0; a.bias_mul = a.bias ? 1 : 0;
+      return y_bf16 ? launch_tt_p<64, 2, false, false, 2, 2>(a, stream) : launch_tt_p<64, 2, false, false, 0, 2>(a, stream);
+    }
+#endif
     if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 16, 2>(a, stream);
     if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 16, 2>(a, stream);
     return CMR_EUNSUPPORTED;
