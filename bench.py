@@ -241,12 +241,62 @@ def geo_train_main(args):
     ranks.close()
 
 
+def iter_main(args):
+    """--mode iter: one IterModel forward (models/IterModel.py:250-475) on the pair it is written for: 160x512 image (40x128
+    maps), 729 sampled poses, BASELINE configs[1]'s 16 384 points.  One STEP = one forward on a batch dict as MultiHeadModel leaves it
+    (synthetic features, hash-filled weights).  Replicas only across GPUs (the model handles one pair)."""
+    from cmr_agent_amd.models import IterModel
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ranks = Ranks(backend="nccl", device=dev)
+    dtype = args.dtype or "f32"
+    ops.CONV_BF16 = dtype == "bf16"
+    spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
+    model = IterModel(KittiConfiguration(device=dev))
+    load_checked(model, hashfill.make_state_dict(spec["iter"], "iter/"))
+    model = model.to(dev).eval()
+    N = args.num_pt or 16384
+    base = {k: v.to(dev) for k, v in synthetic.make_iter_batch("bench", N, 9, 0.2, 2.0).items()}
+    run = lambda: model(dict(base))
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            run()
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        ranks.barrier()
+        elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+        with CallTimer() as ct:
+            run()
+            torch.cuda.synchronize()
+    if ranks.rank == 0:
+        table = ct.table()
+        conv = [d for d in table if d["name"].startswith("cmr_conv3x3")]
+        cms, cfl = sum(d["ms"] for d in conv), sum(d["flops"] for d in conv)
+        stages = {d["name"]: round(d["ms"], 3) for d in table}
+        print(json.dumps({
+            "metric": "IterModel forwards/sec (729 sampled poses, 40x128 maps, %d points)" % N, "value": world * args.steps / elapsed,
+            "unit": "cost-volume forwards/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": "IterModel.forward on one pair: 160x512 image, %d points (60 %% selected), nlabel 9; hash-filled weights" % N,
+                       "parallelism": "replicas only (the model is written for one pair)"},
+            "roofline": {"kernel": "the nine 3x3 convolutions of cost_volume_convs as a batch of 729 maps (Winograd fp32 / bf16 two-team kernel)",
+                         "bound": "mfma", "achieved": cfl / (cms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": cfl / (cms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "note": "algorithmic FLOPs of the convolutions as launched (channel counts padded to 64) / their summed HIP-event time; "
+                                 "priced at the fp32 peak in both modes", "stage_ms": stages}}))
+    ranks.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=("register", "train", "train-geo"), default="register",
+    ap.add_argument("--mode", choices=("register", "train", "train-geo", "iter"), default="register",
                     help="register (default): the headline registration iteration; train: the agent's minibatch update; "
                          "train-geo: the geometric model's training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -263,6 +313,8 @@ def main():
         return train_main(args)
     if args.mode == "train-geo":
         return geo_train_main(args)
+    if args.mode == "iter":
+        return iter_main(args)
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -109,3 +109,25 @@ def make_batch(B, N, H, W, M, fps_fn, nearest_fn, seed=2023, n_circle=512, devic
         "pt2node": i64(np.stack(p2n)), "node": f32(np.stack(nodes)),
         "angles": torch.from_numpy(raw["angles"]), "translation": torch.from_numpy(raw["translation"]),
     }
+
+
+def make_iter_batch(name, N, nlabel, r_amp, t_amp):
+    """The batch dict IterModel.forward reads (models/IterModel.py:250-475): what MultiHeadModel leaves behind for ONE pair on the 160 x 512
+    image (unit-norm features, overlap predictions, scores) plus the sampling amplitudes, the one-hot-like labels and the accumulated pose.
+    Hash-filled from `name` (tests/cases.py:iter_inputs and bench.py --mode iter draw from here), CPU tensors."""
+    import torch
+    H, W = 160, 512
+    t = lambda key, shape, lo=-1.0, hi=1.0: torch.from_numpy(hashfill.uniform("case/%s/%s" % (name, key), shape, lo, hi).astype(np.float32))
+    unit = lambda x: x / x.norm(dim=1, keepdim=True).clamp(min=1e-12)
+    pc = torch.stack([t("x", (N,), -22.0, 22.0), t("y", (N,), -2.5, 2.5), t("z", (N,), 3.0, 45.0)]).unsqueeze(0)      # camera frame
+    labels = {}
+    for k in ("label_R", "label_T_x", "label_T_z"):
+        v = t(k, (1, nlabel), 0.0, 1.0)
+        labels[k] = v / v.sum()
+    mat = torch.eye(4).unsqueeze(0)
+    mat[0, 0:3, 3] = torch.tensor([0.3, -0.1, 0.7])
+    return dict(pc_i=pc, pc_geo_feat=unit(t("pc_feat", (1, 64, N))), img_geo_feat=unit(t("img_feat", (1, 64, H // 4, W // 4))),
+                img=torch.zeros(1, 3, H, W), K=torch.tensor([[[58.0, 0.0, 63.5], [0.0, 58.0, 19.5], [0.0, 0.0, 1.0]]]),
+                pc_overlap_pred=t("ov", (1, N), 0.0, 1.0) < 0.6, pc_overlap_pred_standby=t("ov2", (1, N), 0.0, 1.0) < 0.9,
+                pc_is_in_cam_scores=t("score", (1, N), 0.0, 1.0), img_overlap_pred=(t("img_ov", (1, H // 4, W // 4), 0.0, 1.0) < 0.7).float(),
+                R_amplitude=torch.tensor([r_amp]), T_amplitude=torch.tensor([t_amp]), matrix_accumulated=mat, **labels)

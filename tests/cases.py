@@ -357,28 +357,9 @@ TRAIN_FIXTURES = TRAIN_FIXTURES + tuple(sorted(ITER_CASES))
 
 def iter_inputs(case):
     """The batch dict IterModel.forward reads: what MultiHeadModel leaves behind for one pair (features, overlap predictions,
-    scores) plus the sampling amplitudes, the one-hot-like labels and the accumulated pose."""
+    scores) plus the sampling amplitudes, the one-hot-like labels and the accumulated pose (cmr_agent_amd/utils/synthetic.py)."""
     c = ITER_CASES[case]
-    n, N, H, W = c["nlabel"], c["N"], 160, 512
-    t = lambda name, shape, lo=-1.0, hi=1.0: u("%s/%s" % (case, name), shape, lo, hi)
-    pc = torch.stack([t("x", (N,), -22.0, 22.0), t("y", (N,), -2.5, 2.5), t("z", (N,), 3.0, 45.0)]).unsqueeze(0)      # camera frame
-    feat = F_normalize(t("pc_feat", (1, 64, N)))
-    img_feat = F_normalize(t("img_feat", (1, 64, H // 4, W // 4)))
-    labels = {}
-    for k in ("label_R", "label_T_x", "label_T_z"):
-        v = t(k, (1, n), 0.0, 1.0)
-        labels[k] = v / v.sum()
-    mat = torch.eye(4).unsqueeze(0)
-    mat[0, 0:3, 3] = torch.tensor([0.3, -0.1, 0.7])
-    return dict(pc_i=pc, pc_geo_feat=feat, img_geo_feat=img_feat, img=torch.zeros(1, 3, H, W),
-                K=torch.tensor([[[58.0, 0.0, 63.5], [0.0, 58.0, 19.5], [0.0, 0.0, 1.0]]]),
-                pc_overlap_pred=t("ov", (1, N), 0.0, 1.0) < 0.6, pc_overlap_pred_standby=t("ov2", (1, N), 0.0, 1.0) < 0.9,
-                pc_is_in_cam_scores=t("score", (1, N), 0.0, 1.0), img_overlap_pred=(t("img_ov", (1, H // 4, W // 4), 0.0, 1.0) < 0.7).float(),
-                R_amplitude=torch.tensor([c["r_amp"]]), T_amplitude=torch.tensor([c["t_amp"]]), matrix_accumulated=mat, **labels)
-
-
-def F_normalize(x):
-    return x / x.norm(dim=1, keepdim=True).clamp(min=1e-12)
+    return synthetic.make_iter_batch(case, c["N"], c["nlabel"], c["r_amp"], c["t_amp"])
 
 
 def iter_oracle(case, sd):

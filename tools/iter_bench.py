@@ -47,9 +47,8 @@ def main():
     # timing at the BASELINE point count
     ops.CONV_BF16 = a.bf16
     m.nlabel = 9
-    c = dict(C.ITER_CASES["iter_model_n9"], N=a.points)
-    C.ITER_CASES["bench"] = c
-    base = {k: v.cuda() for k, v in C.iter_inputs("bench").items()}
+    from cmr_agent_amd.utils import synthetic
+    base = {k: v.cuda() for k, v in synthetic.make_iter_batch("bench", a.points, 9, 0.2, 2.0).items()}
     run = lambda: m(dict(base))
     for _ in range(3):
         run()
