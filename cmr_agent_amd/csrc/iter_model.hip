@@ -82,6 +82,155 @@ __global__ __launch_bounds__(256) void iter_warp_scatter_kernel(const float* __r
   }
 }
 
+// The same warp + scatter-mean WITHOUT global atomics (they execute at the memory side at ~1.3 TB/s of added bytes, MI355X_MICROARCH.md:
+// 459 M of them were 2.6 of the model's 7.4 ms) and without 64-lane LDS float atomics either (measured: ~240 cycles per ds_add_f32
+// wave-instruction, 2.1 ms of a first version of this kernel).  A workgroup owns one pose and one BAND of whole map rows (384 cells x 64
+// channels = 96 KB of LDS).  Per chunk of 4 096 points: (1) every thread projects 4 points (all workgroups of a pose project all points:
+// 14 x redundant and still cheap), bins the scores of band + halo rows and the per-cell counts with single-lane LDS atomics and lists the
+// points of the band; (2) a counting sort of the list by cell (prefix sum over the 384 counts, one integer LDS atomic per listed point);
+// (3) wave k sums the feature rows of cells k, k + 16, ... in registers (lane = channel, four rows in flight) and adds the sum to its
+// slab row with a plain read-modify-write -- the wave owns the cell.  The band is written ONCE, coalesced: the scatter mean (the
+// convolution's NHWC input), the occupancy plane and -- since the band also holds the scores of its two halo rows -- the residual
+// operand of the first convolution (image-half convolution + 3x3 stencil of the occupancy plane).  No memset, no accumulators in HBM, no
+// separate finalisation pass.
+constexpr int IB_THREADS = 1024, IB_WAVES = IB_THREADS / 64, IB_CELLS = 384, IB_CHUNK = 4096;
+__global__ __launch_bounds__(IB_THREADS) void iter_warp_band_kernel(const float* __restrict__ pc /*[3][N]*/, const float* __restrict__ feat /*[N][64]*/,
+                                                                    const float* __restrict__ score, const uint8_t* __restrict__ sel,
+                                                                    const float* __restrict__ rt, const float* __restrict__ Kmat,
+                                                                    const float* __restrict__ w1 /*[9][64]*/, const float* __restrict__ base /*[h*w][64]*/,
+                                                                    float* __restrict__ warped, float* __restrict__ res, float* __restrict__ occ,
+                                                                    int N, int h, int w, int band_rows) {
+  extern __shared__ __attribute__((aligned(16))) float ib_smem[];
+  float* slab = ib_smem;                               // [band_rows * w][64]
+  float* cnt_s = slab + IB_CELLS * 64;                 // [band_rows * w] points per cell (all chunks)
+  float* occ_s = cnt_s + IB_CELLS;                     // [(band_rows + 2) * w]: halo row above, the band, halo row below
+  uint32_t* list = reinterpret_cast<uint32_t*>(occ_s + IB_CELLS + 2 * 384);   // [IB_CHUNK] (cell << 16) | point offset in the chunk
+  uint16_t* sorted = reinterpret_cast<uint16_t*>(list + IB_CHUNK);            // [IB_CHUNK] point offsets grouped by cell
+  int* ccnt = reinterpret_cast<int*>(sorted + IB_CHUNK);                      // [IB_CELLS] points per cell in this chunk
+  int* coff = ccnt + IB_CELLS;                                                // [IB_CELLS + 1] exclusive prefix sum
+  int* cfill = coff + IB_CELLS + 1;                                           // [IB_CELLS]
+  __shared__ int nlist;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = blockIdx.y, r0 = blockIdx.x * band_rows;
+  const int rows = r0 + band_rows <= h ? band_rows : h - r0;
+  const int ncell = rows * w;
+  for (int e = tid; e < IB_CELLS * 16; e += IB_THREADS) reinterpret_cast<f32x4*>(slab)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int e = tid; e < IB_CELLS + IB_CELLS + 2 * 384; e += IB_THREADS) cnt_s[e] = 0.f;       // cnt_s and occ_s are adjacent
+  const float* R = rt + (int64_t)p * 12;
+  const float r0_ = R[0], r1 = R[1], r2 = R[2], r3 = R[3], r4 = R[4], r5 = R[5], r6 = R[6], r7 = R[7], r8 = R[8], r9 = R[9], r10 = R[10],
+              r11 = R[11];
+  const float k0 = Kmat[0], k1 = Kmat[1], k2 = Kmat[2], k3 = Kmat[3], k4 = Kmat[4], k5 = Kmat[5], k6 = Kmat[6], k7 = Kmat[7], k8 = Kmat[8];
+  for (int c0 = 0; c0 < N; c0 += IB_CHUNK) {
+    if (tid == 0) nlist = 0;
+    for (int e = tid; e < IB_CELLS; e += IB_THREADS) { ccnt[e] = 0; cfill[e] = 0; }
+    __syncthreads();
+    // ---- (1) project this chunk's points (4 per thread, all their loads issued first), bin scores and counts, list the band's points
+    {
+      constexpr int PT = IB_CHUNK / IB_THREADS;
+      float px[PT], py[PT], pz[PT], ps[PT];
+      bool on[PT];
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        const int n = c0 + tid + i * IB_THREADS;
+        const int nc = n < N ? n : N - 1;
+        on[i] = n < N && sel[nc] != 0;
+        px[i] = pc[nc]; py[i] = pc[N + nc]; pz[i] = pc[2 * (int64_t)N + nc]; ps[i] = score[nc];
+      }
+#pragma unroll
+      for (int i = 0; i < PT; ++i) {
+        const float x = px[i], y = py[i], z = pz[i];
+        const float tx = (r0_ * x + r1 * y + r2 * z) + r3;
+        const float ty = (r4 * x + r5 * y + r6 * z) + r7;
+        const float tz = (r8 * x + r9 * y + r10 * z) + r11;
+        float u = k0 * tx + k1 * ty + k2 * tz;
+        float v = k3 * tx + k4 * ty + k5 * tz;
+        const float zc = k6 * tx + k7 * ty + k8 * tz;
+        u = u / zc;
+        v = v / zc;
+        const bool in_view = on[i] && (u >= 0.f) && (u <= (float)(w - 1)) && (v >= 0.f) && (v <= (float)(h - 1)) && (zc > 0.f);
+        const int yi = in_view ? (int)rintf(v) : -4, xi = in_view ? (int)rintf(u) : 0;
+        const int ry = yi - (r0 - 1);                  // row inside band + halo
+        if (in_view && ry >= 0 && ry <= rows + 1) {
+          atomicAdd(&occ_s[ry * w + xi], ps[i]);
+          if (ry >= 1 && ry <= rows) {
+            const int cell = (ry - 1) * w + xi;
+            atomicAdd(&cnt_s[cell], 1.f);
+            atomicAdd(&ccnt[cell], 1);
+            const int slot = atomicAdd(&nlist, 1);
+            list[slot] = ((uint32_t)cell << 16) | (uint32_t)(tid + i * IB_THREADS);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- (2) counting sort by cell: prefix sum of the 384 counts (one wave), then one integer atomic per listed point
+    if (wave == 0) {
+      int run = 0;
+      for (int b0 = 0; b0 < IB_CELLS; b0 += 64) {
+        const int c = ccnt[b0 + lane];
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o);
+          if (lane >= o) incl += t;
+        }
+        coff[b0 + lane] = run + incl - c;
+        run += __shfl(incl, 63);
+      }
+      if (lane == 0) coff[IB_CELLS] = run;
+    }
+    __syncthreads();
+    const int nl = nlist;
+    for (int e = tid; e < nl; e += IB_THREADS) {
+      const uint32_t it = list[e];
+      const int cell = (int)(it >> 16);
+      sorted[coff[cell] + atomicAdd(&cfill[cell], 1)] = (uint16_t)(it & 0xffffu);
+    }
+    __syncthreads();
+    // ---- (3) wave k owns cells k, k + 16, ...: sum of their feature rows in registers, plain read-modify-write of the slab row
+    for (int cell = wave; cell < ncell; cell += IB_WAVES) {
+      const int b0 = coff[cell], b1 = coff[cell + 1];
+      if (b0 == b1) continue;
+      float acc = 0.f;
+      for (int j = b0; j < b1; j += 4) {
+        float fv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int jj = j + q < b1 ? j + q : b0;
+          fv[q] = feat[(int64_t)(c0 + sorted[jj]) * 64 + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (j + q < b1) acc += fv[q];
+      }
+      slab[cell * 64 + lane] += acc;
+    }
+    __syncthreads();
+  }
+  // ---- write the band: mean features, occupancy, residual operand (16 threads per cell, float4 each)
+  const int64_t cell0 = (int64_t)p * h * w + (int64_t)r0 * w;
+  for (int e = tid; e < ncell * 16; e += IB_THREADS) {
+    const int cell = e >> 4, c = (e & 15) * 4;
+    const float n = fmaxf(cnt_s[cell], 1.f);
+    f32x4 a = *reinterpret_cast<const f32x4*>(&slab[cell * 64 + c]);
+    a[0] /= n; a[1] /= n; a[2] /= n; a[3] /= n;
+    *reinterpret_cast<f32x4*>(warped + (cell0 + cell) * 64 + c) = a;
+    const int yy = cell / w, xx = cell - yy * w;       // row inside the band; occ_s row index = yy + 1
+    f32x4 r = *reinterpret_cast<const f32x4*>(base + ((int64_t)(r0 * w) + cell) * 64 + c);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int xs = xx + t % 3 - 1;
+      if (xs < 0 || xs >= w) continue;
+      const float sv = occ_s[(yy + t / 3) * w + xs];   // rows outside the image never received a point: zero padding
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w1 + t * 64 + c);
+      r[0] += wv[0] * sv; r[1] += wv[1] * sv; r[2] += wv[2] * sv; r[3] += wv[3] * sv;
+    }
+    *reinterpret_cast<f32x4*>(res + (cell0 + cell) * 64 + c) = r;
+    if ((e & 15) == 0) occ[cell0 + cell] = occ_s[(yy + 1) * w + xx];
+  }
+}
+
 // 16 threads per cell: acc <- acc / max(cnt, 1) (scatter_mean) and res = base[cell] + sum_taps w1[tap][c] plane[p, cell + tap]: the
 // one-channel input halves of the first convolution (occupancy per pose, the image overlap prediction once) added to its
 // pose-independent image half, so that the matrix cores only see the 64 warped channels (IterModel.py:373-377 cat order)
@@ -264,6 +413,24 @@ extern "C" int cmr_iter_warp_scatter_f32(const float* pc, const float* feat, con
   hipLaunchKernelGGL(iter_mask_select_kernel, dim3(1), dim3(1024), 0, stream, mask, standby, sel, N);
   hipLaunchKernelGGL(iter_warp_scatter_kernel, dim3((N + 63) / 64, P), dim3(256), 0, stream, pc, feat, score, sel, rt, Kmat, acc, cnt, occ,
                      N, h, w);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_iter_warp_bin_f32(const float* pc, const float* feat, const float* score, const uint8_t* mask, const uint8_t* standby,
+                                     uint8_t* sel, const float* rt, const float* Kmat, const float* w1, const float* base, float* warped,
+                                     float* res, float* occ, int N, int P, int h, int w, hipStream_t stream) {
+  CMR_REQUIRE(pc && feat && score && mask && standby && sel && rt && Kmat && w1 && base && warped && res && occ);
+  CMR_REQUIRE(N > 0 && N < (1 << 24) && P > 0 && P <= 65535 && h > 0 && w > 0 && w <= IB_CELLS && (int64_t)P * h * w < ((int64_t)1 << 31));
+  CMR_REQUIRE(cmr_aligned16(w1) && cmr_aligned16(base) && cmr_aligned16(warped) && cmr_aligned16(res) && cmr_aligned16(feat));
+  const int band_rows = IB_CELLS / w;
+  CMR_REQUIRE(band_rows * w < 65536);
+  const size_t smem = (size_t)(IB_CELLS * 64 + IB_CELLS + IB_CELLS + 2 * 384) * sizeof(float) + IB_CHUNK * (sizeof(uint32_t) + sizeof(uint16_t)) +
+                      (3 * IB_CELLS + 1) * sizeof(int);
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(iter_warp_band_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  hipLaunchKernelGGL(iter_mask_select_kernel, dim3(1), dim3(1024), 0, stream, mask, standby, sel, N);
+  hipLaunchKernelGGL(iter_warp_band_kernel, dim3((h + band_rows - 1) / band_rows, P), dim3(IB_THREADS), smem, stream, pc, feat, score, sel, rt,
+                     Kmat, w1, base, warped, res, occ, N, h, w, band_rows);
   return cmr_launch_status();
 }
 

@@ -84,16 +84,16 @@ class IterModel(Planned):
         delta_r, delta_t, rt = ops.iter_sample_poses(f(data_batch["R_amplitude"]), f(data_batch["T_amplitude"]), n)
         data_batch["delta_R"], data_batch["delta_T"] = delta_r.view(1, n), delta_t.view(1, n)
         feat_rows = ops.transpose(f(data_batch["pc_geo_feat"]))[0]                            # [N, 64]
-        acc, cnt, occ, _ = ops.iter_warp_scatter(pc[0], feat_rows, f(data_batch["pc_is_in_cam_scores"]).view(-1),
-                                                 u8(data_batch["pc_overlap_pred"][0]), u8(data_batch["pc_overlap_pred_standby"][0]),
-                                                 rt, f(data_batch["K"]).view(-1), h, w)
         # ---- first convolution: image half once, one-channel planes as a stencil, warped half on the matrix cores
         img_feat = to_nhwc(f(data_batch["img_geo_feat"]))
         ov = f(data_batch["img_overlap_pred"]).view(1, h, w)
         wi, bi, ui = p["img"]
         base = ops.conv3x3(img_feat, wi, bi, 64, 1, 1.0, u=ui)                                # [1, h, w, 64], no activation
         base = ops.iter_finalize(None, None, ov, p["w_ov"], base[0])                          # + overlap plane -> [1, h, w, 64]
-        res = ops.iter_finalize(acc, cnt, occ, p["w_occ"], base[0])                           # acc <- mean; + occupancy plane per pose
+        # warp + scatter-mean binned per band of map rows in LDS; the same launch writes the residual operand (base + occupancy stencil)
+        acc, res, occ, _ = ops.iter_warp_bin(pc[0], feat_rows, f(data_batch["pc_is_in_cam_scores"]).view(-1),
+                                             u8(data_batch["pc_overlap_pred"][0]), u8(data_batch["pc_overlap_pred_standby"][0]),
+                                             rt, f(data_batch["K"]).view(-1), p["w_occ"], base[0], h, w)
         ww, _, uw = p["warped"]
         x = ops.conv3x3(acc, ww, None, 64, 1, SLOPE, res=res, u=uw, out_bf16=True)        # bf16 mode: the chain's maps are stored as bf16
         del res, acc

@@ -936,6 +936,25 @@ def iter_warp_scatter(pc_3n, feat_rows, score, mask_u8, standby_u8, rt, K, h, w)
     return acc, cnt, occ, sel
 
 
+def iter_warp_bin(pc_3n, feat_rows, score, mask_u8, standby_u8, rt, K, w_occ, base, h, w):
+    """-> (warped [P, h, w, 64] scatter mean, res [P, h, w, 64] = base + 3x3 stencil of the occupancy plane, occ [P, h, w], sel [N])."""
+    N, P = pc_3n.shape[1], rt.shape[0]
+    if tuple(pc_3n.shape) != (3, N) or tuple(feat_rows.shape) != (N, 64) or not (pc_3n.is_contiguous() and feat_rows.is_contiguous()):
+        raise ValueError("iter_warp_bin: pc [3, N] planar and feat [N, 64] rows, contiguous")
+    if score.numel() != N or mask_u8.numel() != N or standby_u8.numel() != N or mask_u8.dtype != torch.uint8 or standby_u8.dtype != torch.uint8:
+        raise ValueError("iter_warp_bin: score [N] float32, masks [N] uint8")
+    if tuple(base.shape) != (h, w, 64) or tuple(w_occ.shape) != (9, 64) or w > 384:
+        raise ValueError("iter_warp_bin: base [h, w, 64], w_occ [9, 64], w <= 384")
+    dev = pc_3n.device
+    warped = torch.empty((P, h, w, 64), dtype=f32, device=dev)
+    res = torch.empty((P, h, w, 64), dtype=f32, device=dev)
+    occ = torch.empty((P, h, w), dtype=f32, device=dev)
+    sel = torch.empty(N, dtype=torch.uint8, device=dev)
+    _lib.call("cmr_iter_warp_bin_f32", _p(pc_3n), _p(feat_rows), _p(score), _p(mask_u8), _p(standby_u8), _p(sel), _p(rt), _p(K), _p(w_occ),
+              _p(base), _p(warped), _p(res), _p(occ), N, P, h, w, _stream())
+    return warped, res, occ, sel
+
+
 def iter_finalize(acc, cnt, plane, w1, base):
     """res [P, h, w, 64] = base [h, w, 64] + conv3x3(plane [P, h, w], w1 [9, 64]); acc (if given) becomes the scatter mean in place."""
     P, h, w = plane.shape

@@ -515,6 +515,12 @@ int cmr_iter_sample_poses_f32(const float* r_amp, const float* t_amp, int nlabel
 int cmr_iter_warp_scatter_f32(const float* pc, const float* feat, const float* score, const uint8_t* mask, const uint8_t* standby,
                               uint8_t* sel, const float* rt, const float* Kmat, float* acc, float* cnt, float* occ, int N, int P,
                               int h, int w, hipStream_t stream);
+/* cmr_iter_warp_bin_f32: cmr_iter_warp_scatter_f32 + the per-pose cmr_iter_finalize_f32 in one launch and without global atomics: a workgroup
+ * bins the points of one pose that land in its band of map rows in LDS and writes warped [P][h*w][64] = scatter mean, occ [P][h*w] and
+ * res [P][h*w][64] = base + 3x3 stencil of the occupancy plane with w1 [9][64], each once (w <= 384). */
+int cmr_iter_warp_bin_f32(const float* pc, const float* feat, const float* score, const uint8_t* mask, const uint8_t* standby,
+                          uint8_t* sel, const float* rt, const float* Kmat, const float* w1, const float* base, float* warped,
+                          float* res, float* occ, int N, int P, int h, int w, hipStream_t stream);
 int cmr_iter_finalize_f32(float* acc, const float* cnt, const float* plane, const float* w1, const float* base, float* res, int P,
                           int h, int w, hipStream_t stream);
 int cmr_iter_head_f32(const float* x, int ldc, int cells, const float* w24, const float* b24, const float* w26, const float* b26,
