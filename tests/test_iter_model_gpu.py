@@ -175,3 +175,28 @@ def test_iter_model_on_the_geometric_models_own_outputs():
     m = data["matrix_i"].cpu()[0]
     assert float((data["matrix_accumulated"].cpu()[0] - m).abs().max()) <= 1e-6            # geo leaves the identity there
     assert torch.isfinite(data["pc_i"]).all() and data["pc_i"].shape == (1, 3, batch["pc"].shape[2])
+
+
+@pytest.mark.parametrize("N,n", [(1200, 3), (5000, 3), (4096, 5)])
+def test_band_binned_scatter_equals_the_atomic_scatter(N, n):
+    """cmr_iter_warp_bin_f32 (LDS band binning, counting sort, per-cell register sums) against cmr_iter_warp_scatter_f32 +
+    cmr_iter_finalize_f32 (global atomics, second pass): same cells, same occupancy and counts, means / residual operand to fp32 summation
+    order; chunk boundaries (N = 4096, 5000 > one chunk) and the standby mask included."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.utils import synthetic
+    d = {k: v.to(DEV) for k, v in synthetic.make_iter_batch("band%d" % N, N, n, 0.15, 1.8).items()}
+    _, _, rt = ops.iter_sample_poses(d["R_amplitude"], d["T_amplitude"], n)
+    feat = ops.transpose(d["pc_geo_feat"].contiguous())[0]
+    u8 = lambda t: t.reshape(-1).to(torch.uint8).contiguous()
+    H, W = 40, 128
+    base = torch.from_numpy(hashfill.uniform("case/band/base", (H, W, 64)).astype(np.float32)).to(DEV)
+    w1 = torch.from_numpy(hashfill.uniform("case/band/w1", (9, 64)).astype(np.float32)).to(DEV)
+    for mask in (u8(d["pc_overlap_pred"]), torch.zeros(N, dtype=torch.uint8, device=DEV)):
+        common = (d["pc_i"][0].contiguous(), feat, d["pc_is_in_cam_scores"].view(-1).contiguous(), mask, u8(d["pc_overlap_pred_standby"]))
+        acc, cnt, occ0, sel0 = ops.iter_warp_scatter(*common, rt, d["K"].view(-1).contiguous(), H, W)
+        res0 = ops.iter_finalize(acc, cnt, occ0, w1, base)
+        warped, res, occ, sel = ops.iter_warp_bin(*common, rt, d["K"].view(-1).contiguous(), w1, base, H, W)
+        assert torch.equal(sel, sel0)
+        assert torch.equal(occ != 0, occ0 != 0) and float((occ - occ0).abs().max()) <= 1e-5
+        assert float((warped - acc).abs().max()) <= 2e-6
+        assert float((res - res0).abs().max()) <= 2e-5
