@@ -126,6 +126,47 @@ def test_direct_and_winograd_convolutions_agree_at_full_size():
     assert float((lhs - rhs).abs().max()) < 5e-5 * float(rhs.abs().max())
 
 
+def test_stride2_fragment_kernel_and_bf16_kernels_at_full_size():
+    """At BASELINE configs[1]'s map sizes (B = 8): the fragment-weight stride-2 kernel is bit-identical to the tiled kernel; the two-team
+    bf16 kernels (stride 1 and 2) agree with the one-team form of the same arithmetic through linearity and with the fp32 convolution at the
+    bf16 bar; bf16-stored chains change nothing."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import conv_bf16_frags, conv_s2_frags
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(8, 352, 1216, 64, generator=g) - 0.5).to(DEV)
+    w = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) / 12).to(DEV)
+    b = torch.rand(64, generator=g).to(DEV)
+    w9 = w.permute(2, 3, 0, 1).reshape(9, 64, 64).contiguous()
+
+    class U:
+        pass
+    u = U()
+    u.s2, u.bf16 = conv_s2_frags(w), None
+    y_new = ops.conv3x3(x, w9, b, 64, 2, 0.2, u=u)
+    ops.STRIDE2_FRAGS = False
+    try:
+        y_old = ops.conv3x3(x, w9, b, 64, 2, 0.2, u=u)
+    finally:
+        ops.STRIDE2_FRAGS = True
+    assert torch.equal(y_new, y_old)
+    fr = conv_bf16_frags(w)
+    for stride in (1, 2):
+        y32 = ops.conv3x3(x, w9, b, 64, stride, 0.2, u=u) if stride == 2 else None
+        y16 = ops.conv3x3_bf16(x, fr, b, 64, 0.2, stride=stride)
+        if y32 is not None:
+            assert float((y16 - y32).abs().max()) <= 1e-2 * float(y32.abs().max())
+        # bf16-stored output = the rounded fp32 output, and a consumer gives the same result from either
+        yb = ops.conv3x3_bf16(x, fr, b, 64, 0.2, stride=stride, out_bf16=True)
+        assert torch.equal(yb, y16.to(torch.bfloat16))
+        z32, z16 = ops.conv3x3_bf16(y16, fr, b, 64, 0.2, res=y16), ops.conv3x3_bf16(yb, fr, b, 64, 0.2, res=y16)
+        assert torch.equal(z32, z16)
+        # linearity of the bf16 kernel in its (bf16-exact) input: conv(2 x) - bias = 2 (conv(x) - bias) exactly (powers of two)
+        xb = x.to(torch.bfloat16).float()
+        lhs = ops.conv3x3_bf16(2.0 * xb, fr, None, 64, 1.0, stride=stride)
+        rhs = 2.0 * ops.conv3x3_bf16(xb, fr, None, 64, 1.0, stride=stride)
+        assert torch.equal(lhs, rhs)
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout,res,post,pool", [
     (8, 176, 608, 64, 64, True, False, 1),      # the second-level shape of configs[1]: 6 688 tiles, 26 per workgroup
     (8, 88, 304, 128, 128, True, False, 1),     # the agent's first-level convolution: four 32-channel chunks, two cout groups
