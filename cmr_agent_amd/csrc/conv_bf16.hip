@@ -17,6 +17,8 @@
 #include "cmr_common.h"
 #include <type_traits>
 
+extern int cmr_conv_cu_budget;      // conv_wino.hip: CUs the persistent convolution kernels may occupy (0 = all)
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -605,7 +607,8 @@ int launch_tt_p(B16Args a, hipStream_t stream) {
   a.tiles_y = ((a.H - 1) / S + 1 + TH - 1) / TH;
   const int ngroups = a.Cout / (32 * NT);
   const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
-  int per_group = 256 / ngroups;                       // one persistent workgroup per CU
+  const int cus = cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < 256 ? cmr_conv_cu_budget - cmr_conv_cu_budget % 8 : 256;
+  int per_group = cus / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > (nsp + 1) / 2) per_group = (int)((nsp + 1) / 2);      // a workgroup has two teams
   hipLaunchKernelGGL((conv3x3_bf16_tt_kernel<CIN, NT, POOL, POST, IO, S>), dim3(ngroups * per_group), dim3(512), smem, stream, a);

@@ -20,6 +20,8 @@
 // Y[a][b] = sum_i A^T[a][i] T[i][b] for register quad q (4 consecutive channels -> float4 stores).
 #include "cmr_common.h"
 
+extern int cmr_conv_cu_budget;
+
 namespace {
 
 struct WinoArgs {
@@ -704,6 +706,7 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
+  if (cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < cus) cus = cmr_conv_cu_budget;
   cus -= cus % 8;                                          // a multiple of the XCD count keeps a workgroup's tiles on one XCD's band
   const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
   hipLaunchKernelGGL(conv3x3_wino_ws_kernel<DBG>, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
@@ -725,6 +728,16 @@ int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hip
 }
 
 }  // namespace
+
+// CUs the PERSISTENT convolution kernels (wave-specialised Winograd here, the two-team bf16 kernel in conv_bf16.hip) may occupy; 0 = all.
+// Those kernels fill a CU completely (registers), so a concurrent branch on another stream only runs between their launches; a caller
+// that forks such a branch (the point tower beside the image tower) leaves it a few CUs for the duration.
+__attribute__((visibility("hidden"))) int cmr_conv_cu_budget = 0;
+extern "C" int cmr_set_conv_cu_budget(int cus) {
+  const int old = cmr_conv_cu_budget;
+  cmr_conv_cu_budget = cus < 0 ? 0 : cus;
+  return old;
+}
 
 static int CMR_WINO_WS = 1;      // wave-specialised persistent kernel for large maps (cmr_set_wino_variant: A/B measurements)
 extern "C" int cmr_set_wino_variant(int wave_specialised) {

@@ -4,6 +4,7 @@ models/IMGPCEncoder.py (:105-164).  Inputs stay on the device of the module's pa
 (the reference hard-codes .cuda(), :130-134)."""
 import torch.nn as nn
 
+from .. import ops
 from ..utils.streams import fork_join
 from ._pack import Planned, device_of
 from ._vit import Attention, Block, Mlp  # noqa: F401
@@ -42,8 +43,22 @@ class IMGPCEncoder(Planned):
 
         # the two towers are independent: the point tower (kNN, grouping, small GEMMs) runs on a side stream
         # underneath the image tower's convolutions; so do the two self-attention blocks of every coarse layer
-        (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat), (img_proxy, T, f2, f1, f0) = fork_join(
-            point_tower, lambda: self.img_transformer.forward_cl(img), tag="towers")
+        def image_tower():
+            # the persistent convolution kernels fill every CU they get (registers): beside them the point tower only runs between their
+            # launches.  Leaving it part of the chip shortens the towers phase: bf16 mode 160 of 256 CUs (673 -> 692 it/s at configs[1];
+            # 192: 682, 144: 681, 128: 674), fp32 Winograd 224 (351 -> 353.4; 240: 350, 208: 352) -- tools/tower_budget_ab.py
+            # (tuned at configs[1]: 26 image pixels per point; an image tower that is larger relative to the cloud gives up fewer CUs -- quadratically:
+            # at the nuScenes shape, 44 pixels per point, the linear rule still cost 1 %)
+            budget = ops.TOWER_CU_BUDGET if ops.CONV_BF16 else ops.TOWER_CU_BUDGET_F32
+            if budget:
+                give = (256 - budget) * (26.1 * pc.shape[2] / float(img.shape[2] * img.shape[3])) ** 2
+                budget = 256 - 8 * int(min(256 - budget, give) / 8 + 0.5)
+            if budget and budget < 256:
+                with ops.conv_cu_budget(budget):
+                    return self.img_transformer.forward_cl(img)
+            return self.img_transformer.forward_cl(img)
+
+        (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat), (img_proxy, T, f2, f1, f0) = fork_join(point_tower, image_tower, tag="towers")
         for i in range(self.config.num_ca_layer_coarse):
             img_proxy = self.p2i_ca_layers[i].rows(img_proxy, pt_proxy, B, T, Q)
             pt_proxy = self.i2p_ca_layers[i].rows(pt_proxy, img_proxy, B, Q, T)

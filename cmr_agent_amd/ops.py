@@ -104,6 +104,23 @@ WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles 
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
 
 
+TOWER_CU_BUDGET = 160    # bf16 mode: CUs of the image tower's persistent convolution kernels while the point tower runs beside it (0 = all)
+TOWER_CU_BUDGET_F32 = 224  # the same for the fp32 Winograd kernels (matrix-bound: a smaller gain from a smaller concession)
+
+
+class conv_cu_budget:
+    """with conv_cu_budget(n): the persistent convolution kernels launched inside occupy at most n CUs (cmr_set_conv_cu_budget)."""
+
+    def __init__(self, cus):
+        self.cus = int(cus)
+
+    def __enter__(self):
+        self.old = _lib.load().cmr_set_conv_cu_budget(self.cus)
+
+    def __exit__(self, *a):
+        _lib.load().cmr_set_conv_cu_budget(self.old)
+
+
 def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     """Stride-1 3x3 convolution through the fused Winograd F(2x2,3x3) kernel; u [16,Cout,Cin] = G g G^T."""
     B, H, W, cin = x.shape

@@ -96,6 +96,10 @@ int cmr_conv3x3_s2_nhwc_f32(const float* x, int B, int H, int W, int Cin, const 
 /* Process-wide switch between the two Winograd kernels for maps of >= 200 tiles (1 = wave-specialised persistent kernel,
  * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
 int cmr_set_wino_variant(int wave_specialised);
+/* CUs the persistent convolution kernels (wave-specialised Winograd, two-team bf16) may occupy from now on (0 = all; rounded down to a
+ * multiple of 8).  They fill a CU completely, so a branch forked onto another stream only progresses between their launches unless it is
+ * left some CUs: the image tower runs with a reduced budget while the point tower runs beside it.  Returns the previous setting. */
+int cmr_set_conv_cu_budget(int cus);
 
 /* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.
  * ImageResNet.py:50 with :9-23. */

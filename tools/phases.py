@@ -23,6 +23,12 @@ def graph_time(fn, reps=5):
     return 1e3 * (time.perf_counter() - t0) / reps, out
 
 def main():
+    from cmr_agent_amd import ops
+    ops.CONV_BF16 = "bf16" in sys.argv            # python tools/phases.py sub bf16
+    from cmr_agent_amd import _lib
+    for a in sys.argv:
+        if a.startswith("cus="):
+            _lib.load().cmr_set_conv_cu_budget(int(a[4:]))
     dev = torch.device("cuda", 0); w = BM.WORKLOAD
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
     geo, agent, _ = BM.load_models(cfg, dev)
