@@ -46,7 +46,7 @@ class IMGPCEncoder(Planned):
         def image_tower():
             # the persistent convolution kernels fill every CU they get (registers): beside them the point tower only runs between their
             # launches.  Leaving it part of the chip shortens the towers phase: bf16 mode 160 of 256 CUs (673 -> 692 it/s at configs[1];
-            # 192: 682, 144: 681, 128: 674), fp32 Winograd 224 (351 -> 353.4; 240: 350, 208: 352) -- tools/tower_budget_ab.py
+            # 192: 682, 144: 681, 128: 674); the fp32 Winograd kernels are matrix-bound and stay within noise at 240 / 224 / 208 -- tools/tower_budget_ab.py
             # (tuned at configs[1]: 26 image pixels per point; an image tower that is larger relative to the cloud gives up fewer CUs -- quadratically:
             # at the nuScenes shape, 44 pixels per point, the linear rule still cost 1 %)
             budget = ops.TOWER_CU_BUDGET if ops.CONV_BF16 else ops.TOWER_CU_BUDGET_F32

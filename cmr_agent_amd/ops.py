@@ -105,7 +105,7 @@ WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct k
 
 
 TOWER_CU_BUDGET = 160    # bf16 mode: CUs of the image tower's persistent convolution kernels while the point tower runs beside it (0 = all)
-TOWER_CU_BUDGET_F32 = 224  # the same for the fp32 Winograd kernels (matrix-bound: a smaller gain from a smaller concession)
+TOWER_CU_BUDGET_F32 = 0  # the same for the fp32 Winograd kernels: matrix-bound, within noise at 240 / 224 / 208 (two boxes) -- left alone
 
 
 class conv_cu_budget:
