@@ -341,3 +341,24 @@ def test_bf16_activation_chains_are_bit_identical_to_fp32_storage():
             assert torch.equal(outs[0], outs[1]), (cin, cout, stride)
     finally:
         ops.CONV_BF16, ops.BF16_CHAINS = False, True
+
+
+def test_conv_cu_budget_changes_nothing_but_the_grid():
+    """cmr_set_conv_cu_budget: the persistent convolution kernels (wave-specialised Winograd, two-team bf16) on 64 / 160 CUs give the
+    bit-identical result of the full-chip launch (the tile -> workgroup assignment changes, the arithmetic per tile does not)."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import conv_bf16_frags, winograd_u
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(4, 88, 304, 64, generator=g) - 0.5).to(DEV)
+    w = ((torch.rand(64, 64, 3, 3, generator=g) - 0.5) / 12).to(DEV)
+    b = torch.rand(64, generator=g).to(DEV)
+    u, fr = winograd_u(w), conv_bf16_frags(w)
+    ref_w = ops.conv3x3_wino(x, u, b, 64, 0.2, res=x)
+    ref_b = ops.conv3x3_bf16(x, fr, b, 64, 0.2, res=x)
+    ref_s = ops.conv3x3_bf16(x, fr, b, 64, 0.2, stride=2)
+    for cus in (64, 160, 250):
+        with ops.conv_cu_budget(cus):
+            assert torch.equal(ops.conv3x3_wino(x, u, b, 64, 0.2, res=x), ref_w), cus
+            assert torch.equal(ops.conv3x3_bf16(x, fr, b, 64, 0.2, res=x), ref_b), cus
+            assert torch.equal(ops.conv3x3_bf16(x, fr, b, 64, 0.2, stride=2), ref_s), cus
+    assert torch.equal(ops.conv3x3_wino(x, u, b, 64, 0.2, res=x), ref_w)        # the budget is restored on exit
