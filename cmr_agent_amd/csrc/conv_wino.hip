@@ -432,6 +432,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #pragma unroll
       for (int n = 0; n < NT; ++n) wc[j][n] = load_u(ub + j * upos + n * utile);
     int g = 0;
+    [[maybe_unused]] uint64_t tm_busy = 0, tm_wait = 0, tm_mark = (dbg & 64) ? __builtin_amdgcn_s_memtime() : 0;
     for (int k = 0; k <= nk; ++k) {
       const bool live = k < nk;
       const int ubn = uwave + (decode((int)blockIdx.x + (k + 1 < nk ? k + 1 : k) * (int)gridDim.x).co0 / 32) * utile;   // next tile's U (or this one's again)
@@ -443,7 +444,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
       for (int chunk = 0; chunk < nchunk; ++chunk, ++g) {
+        if (dbg & 64) { const uint64_t t = __builtin_amdgcn_s_memtime(); tm_busy += t - tm_mark; tm_mark = t; }
         ws_barrier_lds();                               // halo[g & 1] landed (helpers waited for their DMA before arriving)
+        if (dbg & 64) { const uint64_t t = __builtin_amdgcn_s_memtime(); tm_wait += t - tm_mark; tm_mark = t; }
         if (!live) continue;
         const float* halo = smem + (g & 1) * WT_HALO_FLOATS;
         const int uc = ub + chunk * (WT_KC / 8) * 1024;
@@ -533,34 +536,69 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
       }
       ub = ubn;
     }
+    if ((dbg & 64) && lane == 0) {                       // timing build only: a.post is the stamp buffer [workgroup][wave][2]
+      float* o = const_cast<float*>(a.post) + ((int)blockIdx.x * 8 + wave) * 2;
+      o[0] = (float)tm_busy; o[1] = (float)tm_wait;
+    }
   } else {
     // ============================================ helpers ============================================
     const int hw = wave - 4;
     const int Ho = a.H, Wo = a.W;
-    auto dma_halo = [&](const Tile& t, int chunk, float* halo) {
-      const float* xc = a.x + (int64_t)t.b * a.H * a.W * a.Cin + chunk * WT_KC;
+    // The helpers are the younger wave of every SIMD's pair and would get the VALU issue slots the MFMA wave leaves over (their
+    // epilogue then takes longer than a chunk of MFMAs and the MFMA waves wait at the barrier: 12-20 % of the launch by s_memtime
+    // stamps, tools/wino_timing.py); the MFMA wave needs one issue slot per 64 cycles and does not notice.
+    __builtin_amdgcn_s_setprio(1);
+    // Everything per-lane is tile-invariant and computed once: byte offsets relative to a per-tile SCALAR base (the address
+    // arithmetic of a tile is a handful of SALU instructions instead of ~600 VALU / readlane instructions per helper wave).
+    // Halo DMA: block kb = hw + 4 i covers LDS slots 8 kb .. 8 kb + 7; lane >> 3 = slot in the block, lane & 7 = 16-byte piece.
+    unsigned doff[WT_DMA_PER_WAVE];
+    int dpy[WT_DMA_PER_WAVE], dpx[WT_DMA_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < WT_DMA_PER_WAVE; ++i) {
+      int kb = hw + 4 * i;
+      kb = kb < WT_DMA ? kb : WT_DMA - 1;
+      const int slot = 8 * kb + (lane >> 3);
+      const int py = slot / WT_PITCH, r = slot % WT_PITCH;
+      const int px = r < WT_PITCH / 2 ? 2 * r : 2 * r - (WT_PITCH - 1);
+      doff[i] = (unsigned)(((py * a.W + px) * a.Cin + ((lane & 7) ^ wt_key(slot)) * 4) * 4);
+      dpy[i] = px < WT_HC ? py : 0x40000000;              // the unused slots of a row never pass the bounds test: zero page
+      dpx[i] = px;
+    }
+    auto dma_halo = [&](const Tile& t, int chunk, float* halo) __attribute__((always_inline)) {
+      const int y0 = t.oy0 - 1, x0 = t.ox0 - 1;
+      const char* base = reinterpret_cast<const char*>(a.x + ((int64_t)t.b * a.H * a.W + (int64_t)y0 * a.W + x0) * a.Cin + chunk * WT_KC);
 #pragma unroll
       for (int i = 0; i < WT_DMA_PER_WAVE; ++i) {
-        int kb = hw + 4 * i;
-        kb = kb < WT_DMA ? kb : WT_DMA - 1;
-        const int slot = 8 * kb + (lane >> 3);
-        const int py = slot / WT_PITCH, r = slot % WT_PITCH;
-        const int px = r < WT_PITCH / 2 ? 2 * r : 2 * r - (WT_PITCH - 1);
-        const int iy = t.oy0 - 1 + py, ix = t.ox0 - 1 + px;
-        const bool inb = px < WT_HC && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        const float* src = inb ? xc + (unsigned)((iy * a.W + ix) * a.Cin + ((lane & 7) ^ wt_key(slot)) * 4) : wt_zero16;
+        if (hw + 4 * i >= WT_DMA) continue;                 // (wave-uniform) blocks 25..27 do not exist
+        const bool inb = (unsigned)(dpy[i] + y0) < (unsigned)a.H && (unsigned)(dpx[i] + x0) < (unsigned)a.W;
+        const char* src = inb ? base + doff[i] : reinterpret_cast<const char*>(wt_zero16);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(halo + kb * 256), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void*)(halo + (hw + 4 * i) * 256), 16, 0, 0);
       }
     };
     // epilogue items of this lane: channel quad cq4 (couts 4 cq4 .. 4 cq4 + 3 of the tile's 64) of Winograd tiles t0 and t0 + 16;
     // 16 consecutive lanes = one whole pixel's cout group (256 contiguous bytes in y / res / post)
     const int hidx = hw * 64 + lane;
     const int cq4 = hidx & 15, t0 = hidx >> 4;
+    unsigned poff[2][2][2], qoff[2];                      // byte offsets of the lane's 8 pixels (pooled: 2) from the tile's first pixel
+    int pdy[2], pdx[2];
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int t = t0 + 16 * ii;
+      pdy[ii] = 2 * (t >> 3);
+      pdx[ii] = 2 * (t & 7);
+      qoff[ii] = (unsigned)((((t >> 3) * (Wo >> 1) + (t & 7)) * a.Cout + 4 * cq4) * 4);
+#pragma unroll
+      for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) poff[ii][aa][bb] = (unsigned)((((pdy[ii] + aa) * Wo + pdx[ii] + bb) * a.Cout + 4 * cq4) * 4);
+    }
+    const unsigned coff = (unsigned)(16 * cq4);            // the tile's first pixel: where loads of pixels outside the map go
     Tile prev = decode(blockIdx.x), cur = prev;
     dma_halo(cur, 0, smem);                              // chunk (0, 0); completed by the wait in front of the first barrier
     f32x4 yv[2][2][2];                                   // [item][a][b]
     int g = 0, pend = 0;
+    [[maybe_unused]] uint64_t tm_busy = 0, tm_wait = 0, tm_vm = 0, tm_dma = 0, tm_epi = 0, tm_st = 0, tm_mark = (dbg & 64) ? __builtin_amdgcn_s_memtime() : 0;
     for (int k = 0; k <= nk; ++k) {
       const Tile nxt = decode((int)blockIdx.x + (k + 1) * (int)gridDim.x);
       for (int chunk = 0; chunk < nchunk; ++chunk, ++g) {
@@ -568,11 +606,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
         // together in issue order, and the stores of interval 1 are issued BEHIND that interval's DMA: on a tile that lies fully
         // inside the map their number is known (8, or 2 pooled), so the wait leaves exactly them in flight instead of tying
         // the barrier to the completion of 32 KB of stores; any other interval drains everything.
+        if (dbg & 64) { const uint64_t t = __builtin_amdgcn_s_memtime(); tm_busy += t - tm_mark; tm_mark = t; }
         if (pend == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else if (pend == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pend = 0;
+        if (dbg & 64) { const uint64_t t = __builtin_amdgcn_s_memtime(); tm_vm += t - tm_mark; tm_mark = t; }
         ws_barrier_lds();
+        if (dbg & 64) { const uint64_t t = __builtin_amdgcn_s_memtime(); tm_wait += t - tm_mark; tm_mark = t; }
         // feed: the next chunk in sequence goes into the buffer the MFMA waves have just left (first thing in the interval:
         // it has to land before the next barrier)
         if (chunk + 1 < nchunk) {
@@ -580,29 +621,38 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
         } else if (k + 1 < nk) {
           dma_halo(nxt, 0, smem + ((g + 1) & 1) * WT_HALO_FLOATS);
         }
+        [[maybe_unused]] uint64_t tm_p = 0;
+        if (dbg & 64) { __builtin_amdgcn_sched_barrier(0); tm_p = __builtin_amdgcn_s_memtime(); tm_dma += tm_p - tm_mark; }
         if (k == 0 || (dbg & 2)) continue;
-        const int cq = prev.co0 + 4 * cq4;
         if (chunk == 0) {
           // interval 0 of the next tile: everything that computes.  Residual / bias loads first (in flight during the LDS
           // work), stage 2 from T, then bias + residual + LeakyReLU (+ table); the finished pixels stay in registers.
           const float* Ts = smem + WS_T_OFF;
-          const f32x4 bsv = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + cq : wt_zero16);
+          const f32x4 bsv = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + prev.co0 + 4 * cq4 : wt_zero16);
           f32x4 rs[2][2][2];
-          const float* rp = a.res ? a.res + (int64_t)prev.b * Ho * Wo * a.Cout + cq : wt_zero16;
-          const int rst = a.res ? a.Cout : 0;
+          const int64_t pix0 = ((int64_t)prev.b * Ho + prev.oy0) * Wo + prev.ox0;          // the tile's first pixel (scalar)
+          const int ly = Ho - prev.oy0, lx = Wo - prev.ox0;
+          const bool full = ly >= WT_TH && lx >= WT_TW;
           if (a.pool == 1) {
+            if (a.res) {
+              const char* rb = reinterpret_cast<const char*>(a.res + pix0 * a.Cout + prev.co0);
 #pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
+              for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-              for (int aa = 0; aa < 2; ++aa)
+                for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                  const int t = t0 + 16 * ii;
-                  int oy = prev.oy0 + 2 * (t >> 3) + aa, ox = prev.ox0 + 2 * (t & 7) + bb;
-                  oy = oy < Ho ? oy : Ho - 1;
-                  ox = ox < Wo ? ox : Wo - 1;
-                  rs[ii][aa][bb] = *reinterpret_cast<const f32x4*>(rp + (int64_t)(oy * Wo + ox) * rst);
-                }
+                  for (int bb = 0; bb < 2; ++bb) {
+                    const unsigned o = full || (pdy[ii] + aa < ly && pdx[ii] + bb < lx) ? poff[ii][aa][bb] : coff;
+                    rs[ii][aa][bb] = *reinterpret_cast<const f32x4*>(rb + o);
+                  }
+            } else {
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                  for (int bb = 0; bb < 2; ++bb) rs[ii][aa][bb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
           }
 #pragma unroll
           for (int ii = 0; ii < 2; ++ii)
@@ -645,57 +695,81 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
                   for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
                   yv[ii][aa][bb] = v;
                 }
-            if (a.post) {
+            if (a.post && !(dbg & 64)) {
+              const char* pb = reinterpret_cast<const char*>(a.post + ((int64_t)prev.oy0 * Wo + prev.ox0) * a.Cout + prev.co0);
 #pragma unroll
               for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
                   for (int bb = 0; bb < 2; ++bb) {
-                    const int t = t0 + 16 * ii;
-                    int oy = prev.oy0 + 2 * (t >> 3) + aa, ox = prev.ox0 + 2 * (t & 7) + bb;
-                    oy = oy < Ho ? oy : Ho - 1;
-                    ox = ox < Wo ? ox : Wo - 1;
-                    yv[ii][aa][bb] += *reinterpret_cast<const f32x4*>(a.post + (int64_t)(oy * Wo + ox) * a.Cout + cq);
+                    const unsigned o = full || (pdy[ii] + aa < ly && pdx[ii] + bb < lx) ? poff[ii][aa][bb] : coff;
+                    yv[ii][aa][bb] += *reinterpret_cast<const f32x4*>(pb + o);
                   }
             }
           }
-        } else if (chunk == 1) {
-          // interval 1: nothing but the stores, issued right behind the DMA
-          if (dbg & 1) continue;
-          __builtin_amdgcn_sched_barrier(0);
-          const bool full = prev.oy0 + WT_TH <= Ho && prev.ox0 + WT_TW <= Wo;
-          pend = full ? (a.pool == 2 ? 2 : 8) : 0;
-          if (a.pool == 2) {
-            const int hp2 = Ho >> 1, wp2 = Wo >> 1;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-              const int t = t0 + 16 * ii;
-              const int py = (prev.oy0 >> 1) + (t >> 3), px = (prev.ox0 >> 1) + (t & 7);
-              if (py < hp2 && px < wp2)
-                __builtin_nontemporal_store(yv[ii][0][0], reinterpret_cast<f32x4*>(a.y + (((int64_t)prev.b * hp2 + py) * wp2 + px) * a.Cout + cq));
-            }
-          } else {
+          if (dbg & 64) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
               for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                  const int t = t0 + 16 * ii;
-                  const int oy = prev.oy0 + 2 * (t >> 3) + aa, ox = prev.ox0 + 2 * (t & 7) + bb;
-                  if (oy < Ho && ox < Wo)
-                    __builtin_nontemporal_store(yv[ii][aa][bb], reinterpret_cast<f32x4*>(a.y + (((int64_t)prev.b * Ho + oy) * Wo + ox) * a.Cout + cq));
-                }
+                for (int bb = 0; bb < 2; ++bb) cmr_pin(yv[ii][aa][bb]);
+            __builtin_amdgcn_sched_barrier(0);
+            tm_epi += __builtin_amdgcn_s_memtime() - tm_p;
           }
+        } else if (chunk == 1) {
+          // interval 1: nothing but the stores, issued right behind the DMA
+          if (dbg & 1) continue;
+          __builtin_amdgcn_sched_barrier(0);
+          const int ly = Ho - prev.oy0, lx = Wo - prev.ox0;
+          const bool full = ly >= WT_TH && lx >= WT_TW;
+          pend = full ? (a.pool == 2 ? 2 : 8) : 0;
+          if (a.pool == 2) {
+            const int hp2 = Ho >> 1, wp2 = Wo >> 1;
+            char* yb = reinterpret_cast<char*>(a.y + (((int64_t)prev.b * hp2 + (prev.oy0 >> 1)) * wp2 + (prev.ox0 >> 1)) * a.Cout + prev.co0);
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+              if (full || ((prev.oy0 + pdy[ii]) >> 1 < hp2 && (prev.ox0 + pdx[ii]) >> 1 < wp2))
+                __builtin_nontemporal_store(yv[ii][0][0], reinterpret_cast<f32x4*>(yb + qoff[ii]));
+          } else {
+            char* yb = reinterpret_cast<char*>(a.y + (((int64_t)prev.b * Ho + prev.oy0) * Wo + prev.ox0) * a.Cout + prev.co0);
+            if (full) {
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                  for (int bb = 0; bb < 2; ++bb) __builtin_nontemporal_store(yv[ii][aa][bb], reinterpret_cast<f32x4*>(yb + poff[ii][aa][bb]));
+            } else {
+#pragma unroll
+              for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                  for (int bb = 0; bb < 2; ++bb)
+                    if (pdy[ii] + aa < ly && pdx[ii] + bb < lx)
+                      __builtin_nontemporal_store(yv[ii][aa][bb], reinterpret_cast<f32x4*>(yb + poff[ii][aa][bb]));
+            }
+          }
+          if (dbg & 64) { __builtin_amdgcn_sched_barrier(0); tm_st += __builtin_amdgcn_s_memtime() - tm_p; }
         }
       }
       prev = cur;
       cur = nxt;
     }
+    if ((dbg & 64) && lane == 0) {
+      float* o = const_cast<float*>(a.post) + ((int)blockIdx.x * 8 + wave) * 2;
+      o[0] = (float)tm_busy; o[1] = (float)tm_wait;
+      float* q = const_cast<float*>(a.post) + 2 * 8 * gridDim.x + ((int)blockIdx.x * 4 + hw) * 4;
+      q[0] = (float)tm_vm; q[1] = (float)tm_dma; q[2] = (float)tm_epi; q[3] = (float)tm_st;
+    }
   }
 }
 
+#ifndef CMR_WS_DBG
+#define CMR_WS_DBG 0
+#endif
 template <int DBG>
 int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
   constexpr int smem = WS_SMEM_FLOATS * (int)sizeof(float);
@@ -714,8 +788,9 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
 }
 int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
   // DBG bits (compile-time ablations used while tuning: 1 no stores, 2 no epilogue, 4 no T hand-over, 8 no U loads, 16 no LDS
-  // prefetch, 32 no MFMAs) are not instantiated in the shipped library
-  return launch_wino_ws_t<0>(a, tiles_x, tiles_y, ntiles, stream);
+  // prefetch, 32 no MFMAs, 64 s_memtime stamps of busy / barrier-wait cycles per wave into the buffer passed as `post`) are not
+  // instantiated in the shipped library: tools/ab_build.sh cmr_agent_amd/csrc/conv_wino.hip <tag> -DCMR_WS_DBG=<mask>
+  return launch_wino_ws_t<CMR_WS_DBG>(a, tiles_x, tiles_y, ntiles, stream);
 }
 
 template <int NT>
