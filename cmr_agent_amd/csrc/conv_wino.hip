@@ -436,13 +436,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
     for (int k = 0; k <= nk; ++k) {
       const bool live = k < nk;
       const int ubn = uwave + (decode((int)blockIdx.x + (k + 1 < nk ? k + 1 : k) * (int)gridDim.x).co0 / 32) * utile;   // next tile's U (or this one's again)
-      f32x16 acc[4][NT];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[j][n][r] = 0.f;
+      f32x16 acc[4][NT];                                // not zeroed: the first k-step of a tile multiplies onto the constant 0
       for (int chunk = 0; chunk < nchunk; ++chunk, ++g) {
         if (dbg & 64) { const uint64_t t = __builtin_amdgcn_s_memtime(); tm_busy += t - tm_mark; tm_mark = t; }
         ws_barrier_lds();                               // halo[g & 1] landed (helpers waited for their DMA before arriving)
@@ -477,7 +471,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int n = 0; n < NT; ++n) if (!(dbg & 32)) acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], acc[j][n]);
+              for (int n = 0; n < NT; ++n) {
+                if (dbg & 32) continue;
+                if (kg == 0 && e == 0 && chunk == 0) {      // (wave-uniform branch around one MFMA; 128 v_mov per tile otherwise)
+                  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                  acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], zero);
+                } else {
+                  acc[j][n] = cmr_mfma32(wc[j][n][e], vf[j][e], acc[j][n]);
+                }
+              }
             // the 8 MFMAs above have read wc[j][*]: refill them with the next k-group's fragments (24 MFMAs = 1 536 cycles of lead)
             if (!(dbg & 8)) {
 #pragma unroll
