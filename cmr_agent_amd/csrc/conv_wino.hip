@@ -678,7 +678,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
                     const float v = yv[ii][aa][bb][e] + bsv[e];
-                    sacc[e] += v > 0.f ? v : v * a.slope;
+                    sacc[e] += fmaxf(v, v * a.slope);                 // LeakyReLU for 0 <= slope <= 1 (the entry point routes other slopes elsewhere)
                   }
 #pragma unroll
               for (int e = 0; e < 4; ++e) sacc[e] *= 0.25f;
@@ -694,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
                   f32x4 v = yv[ii][aa][bb] + bsv;
                   v += rs[ii][aa][bb];
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.slope;
+                  for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
                   yv[ii][aa][bb] = v;
                 }
             if (a.post && !(dbg & 64)) {
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
               if (full || ((prev.oy0 + pdy[ii]) >> 1 < hp2 && (prev.ox0 + pdx[ii]) >> 1 < wp2))
                 __builtin_nontemporal_store(yv[ii][0][0], reinterpret_cast<f32x4*>(yb + qoff[ii]));
           } else {
-            char* yb = reinterpret_cast<char*>(a.y + (((int64_t)prev.b * Ho + prev.oy0) * Wo + prev.ox0) * a.Cout + prev.co0);
+            char* yb = reinterpret_cast<char*>(a.y + ((dbg & 128) ? (int64_t)(blockIdx.x & 7) * 16 * Wo : (((int64_t)prev.b * Ho + prev.oy0) * Wo + prev.ox0)) * a.Cout + prev.co0);
             if (full) {
 #pragma unroll
               for (int ii = 0; ii < 2; ++ii)
@@ -790,7 +790,7 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
 }
 int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
   // DBG bits (compile-time ablations used while tuning: 1 no stores, 2 no epilogue, 4 no T hand-over, 8 no U loads, 16 no LDS
-  // prefetch, 32 no MFMAs, 64 s_memtime stamps of busy / barrier-wait cycles per wave into the buffer passed as `post`) are not
+  // prefetch, 32 no MFMAs, 128 every tile stored over the same few tiles (stores without HBM write traffic), 64 s_memtime stamps of busy / barrier-wait cycles per wave into the buffer passed as `post`) are not
   // instantiated in the shipped library: tools/ab_build.sh cmr_agent_amd/csrc/conv_wino.hip <tag> -DCMR_WS_DBG=<mask>
   return launch_wino_ws_t<CMR_WS_DBG>(a, tiles_x, tiles_y, ntiles, stream);
 }
@@ -836,7 +836,7 @@ extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, in
   // take 32-cout workgroups, twice as many and three per CU
   const int64_t ntiles64 = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
   CMR_REQUIRE(2 * ntiles64 < 0x7fffffff);
-  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 200) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, stream);
+  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 200 && slope >= 0.f && slope <= 1.f) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, stream);
   if (ntiles64 >= 512) return launch_wino<2>(a, tiles_x, tiles_y, ntiles64, stream);
   return launch_wino<1>(a, tiles_x, tiles_y, 2 * ntiles64, stream);
 }

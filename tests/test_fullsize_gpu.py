@@ -207,6 +207,16 @@ def test_wave_specialised_winograd_kernel_equals_the_four_wave_kernel(B, H, W, c
     finally:
         ops.WINOGRAD = True
     assert float((yd - y8).abs().max()) < 5e-5 * float(yd.abs().max())
+    # the persistent kernel's epilogue computes LeakyReLU as max(v, slope v), valid for 0 <= slope <= 1 (slope 0 = ReLU, 1 = none): it
+    # must agree there; any other slope is served by the 4-wave kernel's select and must agree with the direct kernel too
+    for slope in (0.0, 1.0, 1.5, -0.25):
+        ys = ops.conv3x3_wino(x, u, b, cout, slope, res=r, post=p, pool=pool)
+        ops.WINOGRAD = False
+        try:
+            yd = ops.conv3x3(x, w9, b, cout, 1, slope, res=r, post=p, pool=pool)
+        finally:
+            ops.WINOGRAD = True
+        assert float((yd - ys).abs().max()) < 5e-5 * max(float(yd.abs().max()), 1.0), slope
 
 
 def test_fps_and_knn_properties_at_65536_points():
