@@ -559,6 +559,10 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
     issue_loads(tnext, 0, pv[0]);
   }
   __syncthreads();                                      // weights and both teams' first units are in LDS
+  // Team 1's waves are the younger of every SIMD's pair and lose the issue arbitration in every phase (by age); one static priority
+  // for that half, no per-phase flips: mid-size maps -8...10 % (176x608 64->64 159 -> 144 us, 88x304 128->128 125 -> 115 us), the
+  // HBM-bound full-resolution maps unchanged
+  if (team == 1) __builtin_amdgcn_s_setprio(1);
   if (team == 1) __syncthreads();                       // team 1 runs one phase behind
   for (int i = 0; i < npass; ++i) {
     // past the end: a harmless re-read instead of a branch around the loads
