@@ -407,6 +407,8 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
                                                      float* __restrict__ y, int B, int H, int W, float slope) {
   __shared__ __attribute__((aligned(16))) float ws[64 * 36];
   __shared__ __attribute__((aligned(16))) float tpatch[4 * 32 * 68];      // output transpose, one 32 x 64 patch per wave
+  __shared__ __attribute__((aligned(16))) float bs[64];
+  if (threadIdx.x < 64) bs[threadIdx.x] = bias[threadIdx.x];
   for (int e = threadIdx.x; e < 64 * 32; e += 256) {
     const int c = e >> 5, k = e & 31;
     ws[c * 36 + k] = k < 27 ? w3[k * 64 + c] : (k < 30 ? w1[(k - 27) * 64 + c] : 0.f);
@@ -422,20 +424,19 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
 
   const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw;
   // per-lane description of its 16 K entries: k = 8g + 4h + e
-  int off[16], offc[16], code[16];  // code: 0..8 = (dy+1)*3+(dx+1) tap of t, 9 = centre of x, 10 = zero pad; offc = centre of the channel
+  int off[16], code[16];            // code: 0..8 = (dy+1)*3+(dx+1) tap of t, 9 = centre of x, 10 = zero pad
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int k = 8 * (i >> 2) + 4 * h + (i & 3);
     if (k < 27) {
       const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
       off[i] = (int)(ci * hw) + (ky - 1) * W + (kx - 1);
-      offc[i] = (int)(ci * hw);
       code[i] = ky * 3 + kx;
     } else if (k < 30) {
-      off[i] = offc[i] = (int)((k - 27) * hw);
+      off[i] = (int)((k - 27) * hw);
       code[i] = 9;
     } else {
-      off[i] = offc[i] = 0;
+      off[i] = 0;
       code[i] = 10;
     }
   }
@@ -459,27 +460,30 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
     if (!valid) m = 0;
     const float* tp = t + (int64_t)b * 3 * hw + rem;
     const float* xp = x + (int64_t)b * 3 * hw + rem;
-    // branch-free: an out-of-image tap re-reads the (always valid) centre pixel of its channel and is masked after
-    // the load -- a conditional load or a pointer select is compiled to a branch + s_waitcnt vmcnt(0) per tap
+    // branch-free: an out-of-image tap reads whatever lies at its offset, clamped into the sample's three planes, and is masked
+    // after the load -- a conditional load or a pointer select is compiled to a branch + s_waitcnt vmcnt(0) per tap
+    const int lim = (int)(3 * hw) - 1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const bool ok = (m >> code[i]) & 1u;
-      const float v = (code[i] == 9 ? xp : tp)[ok ? off[i] : offc[i]];
+      int idx = rem + off[i];
+      idx = idx < 0 ? 0 : (idx > lim ? lim : idx);
+      const float v = (code[i] == 9 ? xp : tp)[idx - rem];
       dst[i] = ok ? v : 0.f;
     }
   };
 
-  f32x4 bv[8];                      // bias of this lane's 8 channel quads, loaded once
-#pragma unroll
-  for (int i = 0; i < 8; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + 8 * i + 4 * h);
   const int64_t ntiles = (total + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * 4;
-  float xc[16], xn[16];
+  // the operands of the next TWO tiles are in flight (one tile of work, ~2 500 cycles, does not cover a load's latency while the
+  // kernel's own 876 MB of stores queue in front of it); three register sets change roles, no copies (a copy would wait for the load)
+  float xa[16], xb[16], xc[16];
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  gather(tile < ntiles ? tile : 0, xc);
-  for (; tile < ntiles; tile += tstride) {
-    gather(tile + tstride < ntiles ? tile + tstride : tile, xn);
-    __builtin_amdgcn_sched_barrier(0);           // the next tile's 16 loads are issued BEFORE this tile's MFMAs, not after
+  gather(tile < ntiles ? tile : 0, xa);
+  gather(tile + tstride < ntiles ? tile + tstride : 0, xb);
+  auto step = [&](const float (&cur)[16], float (&fill)[16]) __attribute__((always_inline)) {
+    gather(tile + 2 * tstride < ntiles ? tile + 2 * tstride : tile, fill);
+    __builtin_amdgcn_sched_barrier(0);           // those 16 loads are issued BEFORE this tile's MFMAs, not after
     f32x16 acc[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -489,8 +493,8 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[0] = cmr_mfma32(wf[0][g][j], xc[g * 4 + j], acc[0]);
-        acc[1] = cmr_mfma32(wf[1][g][j], xc[g * 4 + j], acc[1]);
+        acc[0] = cmr_mfma32(wf[0][g][j], cur[g * 4 + j], acc[0]);
+        acc[1] = cmr_mfma32(wf[1][g][j], cur[g * 4 + j], acc[1]);
       }
     const int64_t p = tile * 32 + l31;
     f32x4 ov[8];
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
-        v += bv[4 * n + q];
+        v += *reinterpret_cast<const f32x4*>(&bs[8 * (4 * n + q) + 4 * h]);      // (LDS: 32 registers for three operand sets)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
         ov[4 * n + q] = v;
@@ -525,8 +529,14 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
       for (int i = 0; i < 8; ++i)
         if (p0 + 4 * i < total) *reinterpret_cast<f32x4*>(yp + (int64_t)(4 * i) * 64) = rv[i];
     }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) xc[i] = xn[i];
+    tile += tstride;
+  };
+  while (tile < ntiles) {
+    step(xa, xc);
+    if (tile >= ntiles) break;
+    step(xb, xa);
+    if (tile >= ntiles) break;
+    step(xc, xb);
   }
 }
 
