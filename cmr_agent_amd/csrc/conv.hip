@@ -254,32 +254,50 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
 }
 
 // ---- MiniResNet block 0 (3 input channels), direct VALU convolutions -------------------------
-// stem_a: t = LReLU(conv3x3(3->3)(x) + b)      NCHW [B,3,H,W] -> NCHW [B,3,H,W]
+// stem_a: t = LReLU(conv3x3(3->3)(x) + b)      NCHW [B,3,H,W] -> planes 0..2 of the scratch [B,6,H,W]; planes 3..5 = x
+// (stem_b gathers its 30 operand entries -- 27 taps of t, 3 centres of x -- from ONE base pointer)
 __global__ __launch_bounds__(256) void stem_a_kernel(const float* __restrict__ x, const float* __restrict__ w /*[3][3][3][3]*/,
                                                      const float* __restrict__ bias, float* __restrict__ t, int B, int H,
                                                      int W, float slope) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  // grid (columns / 256, rows, samples): no divisions; a tap outside the image re-reads a clamped (valid) pixel and is
+  // multiplied by 0 -- branch-free, 27 coalesced loads in flight per thread
+  const int xx = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y, b = blockIdx.z;
+  if (xx >= W) return;
   const int64_t hw = (int64_t)H * W;
-  if (p >= B * hw) return;
-  const int b = (int)(p / hw);
-  const int yy = (int)((p % hw) / W), xx = (int)(p % W);
-  float o[3] = {bias[0], bias[1], bias[2]};
-  for (int ci = 0; ci < 3; ++ci)
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = yy + ky - 1;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = xx + kx - 1;
-        if (ix < 0 || ix >= W) continue;
-        const float v = x[((int64_t)b * 3 + ci) * hw + (int64_t)iy * W + ix];
+  const float* xb = x + (int64_t)b * 3 * hw;
+  float v[3][3][3];
 #pragma unroll
-        for (int co = 0; co < 3; ++co) o[co] += v * w[((co * 3 + ci) * 3 + ky) * 3 + kx];
-      }
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = yy + ky - 1;
+    const int cy = iy < 0 ? 0 : (iy >= H ? H - 1 : iy);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = xx + kx - 1;
+      const int cx = ix < 0 ? 0 : (ix >= W ? W - 1 : ix);
+      const float keep = (iy == cy && ix == cx) ? 1.f : 0.f;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) v[ci][ky][kx] = xb[ci * hw + (int64_t)cy * W + cx] * keep;
     }
+  }
+  // same summation order as before: ci outermost, then ky, kx
+  float o[3] = {bias[0], bias[1], bias[2]};
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int iy = yy + ky - 1, ix = xx + kx - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;       // (skipped, not added as 0: -0.0 + 0 would change nothing, but keep the exact sequence)
+#pragma unroll
+        for (int co = 0; co < 3; ++co) o[co] += v[ci][ky][kx] * w[((co * 3 + ci) * 3 + ky) * 3 + kx];
+      }
+  float* tb = t + (int64_t)b * 6 * hw + (int64_t)yy * W + xx;
 #pragma unroll
   for (int co = 0; co < 3; ++co) {
-    const float v = o[co];
-    t[((int64_t)b * 3 + co) * hw + (int64_t)yy * W + xx] = v > 0.f ? v : v * slope;
+    const float r = o[co];
+    tb[co * hw] = r > 0.f ? r : r * slope;
+    tb[(3 + co) * hw] = v[co][1][1];
   }
 }
 
@@ -395,12 +413,15 @@ int launch_conv_direct(const ConvArgs& a, hipStream_t stream) {
 
 __device__ __attribute__((aligned(16))) const float cmr_conv_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-// stem_b: y = LReLU(conv3x3(3->64)(t) + conv1x1(3->64)(x) + b)   NCHW t, x -> NHWC [B,H,W,64]
+// stem_b: y = LReLU(conv3x3(3->64)(t) + conv1x1(3->64)(x) + b)   scratch planes [B,6,H,W] (t | x) -> NHWC [B,H,W,64]
 // as a K = 32 GEMM on fp32 MFMA (27 taps of t, 3 channels of x, 2 zero pads).  Each wave owns tiles of
 // 32 consecutive (flattened) pixels: the pixel operand is gathered with scalar loads that are coalesced
 // across lanes (planar input), the [64][32] weight block lives in registers for the whole kernel, and
-// the next tile's 16 loads are in flight while the current tile is multiplied.  Output-bound (256 B/pixel).
-__global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t, const float* __restrict__ x,
+// the next two tiles' 16 loads each are in flight while the current tile is multiplied.  Output-bound (256 B/pixel) on paper; in
+// practice bound by the VALU issue slots of the two waves of a SIMD, so the per-tile instruction stream is kept short:
+// the pixel coordinates advance incrementally (no division), the nine neighbour-inside bits come from two row / column
+// patterns, one base pointer serves all entries, LeakyReLU is max(v, slope v) (0 <= slope <= 1, checked by the entry point).
+__global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ tx /*[B][6][H][W]*/,
                                                      const float* __restrict__ w3 /*[27][64] (ci,ky,kx major)*/,
                                                      const float* __restrict__ w1 /*[3][64]*/,
                                                      const float* __restrict__ bias /*[64] (both BN shifts)*/,
@@ -422,7 +443,8 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
 #pragma unroll
     for (int g = 0; g < 4; ++g) wf[n][g] = *reinterpret_cast<const f32x4*>(&ws[(n * 32 + l31) * 36 + g * 8 + 4 * h]);
 
-  const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw;
+  const int hw = H * W;                       // (the entry point requires 6 H W < 2^31)
+  const int64_t total = (int64_t)B * hw;
   // per-lane description of its 16 K entries: k = 8g + 4h + e
   int off[16], code[16];            // code: 0..8 = (dy+1)*3+(dx+1) tap of t, 9 = centre of x, 10 = zero pad
 #pragma unroll
@@ -430,73 +452,78 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
     const int k = 8 * (i >> 2) + 4 * h + (i & 3);
     if (k < 27) {
       const int ci = k / 9, ky = (k % 9) / 3, kx = k % 3;
-      off[i] = (int)(ci * hw) + (ky - 1) * W + (kx - 1);
+      off[i] = ci * hw + (ky - 1) * W + (kx - 1);
       code[i] = ky * 3 + kx;
     } else if (k < 30) {
-      off[i] = (int)((k - 27) * hw);
+      off[i] = (k - 24) * hw;       // planes 3..5
       code[i] = 9;
     } else {
       off[i] = 0;
       code[i] = 10;
     }
   }
-  auto gather = [&](int64_t tile, float (&dst)[16]) {
-    int64_t p = tile * 32 + l31;
-    const bool valid = p < total;
-    if (!valid) p = 0;
-    const int b = (int)(p / hw);
-    const int rem = (int)(p - (int64_t)b * hw);
-    const int yy = rem / W, xx = rem - yy * W;
-    // bit (dy+1)*3+(dx+1) set when that neighbour is inside the image; bit 9 always; bit 10 never
-    unsigned m = 0;
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy)
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const bool in = yy + dy >= 0 && yy + dy < H && xx + dx >= 0 && xx + dx < W;
-        m |= (in ? 1u : 0u) << ((dy + 1) * 3 + dx + 1);
-      }
-    m |= 1u << 9;
-    if (!valid) m = 0;
-    const float* tp = t + (int64_t)b * 3 * hw + rem;
-    const float* xp = x + (int64_t)b * 3 * hw + rem;
-    // branch-free: an out-of-image tap reads whatever lies at its offset, clamped into the sample's three planes, and is masked
-    // after the load -- a conditional load or a pointer select is compiled to a branch + s_waitcnt vmcnt(0) per tap
-    const int lim = (int)(3 * hw) - 1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const bool ok = (m >> code[i]) & 1u;
-      int idx = rem + off[i];
-      idx = idx < 0 ? 0 : (idx > lim ? lim : idx);
-      const float v = (code[i] == 9 ? xp : tp)[idx - rem];
-      dst[i] = ok ? v : 0.f;
-    }
-  };
-
   const int64_t ntiles = (total + 31) / 32;
   const int64_t tstride = (int64_t)gridDim.x * 4;
+  // position of this lane's pixel in the tile being GATHERED: sample gb, offset grem in the sample, row gy, column gx; advanced by
+  // the tile stride after every gather (one division here, none in the loop: the stride is split into samples / rows / columns once)
+  const int64_t step_px = tstride * 32;
+  const int st_b = (int)(step_px / hw), st_r = (int)(step_px % hw);
+  const int st_y = st_r / W, st_x = st_r % W;
+  int gb, grem, gy, gx;
+  {
+    int64_t p = ((int64_t)blockIdx.x * 4 + wave) * 32 + l31;
+    p = p < total ? p : 0;
+    gb = (int)(p / hw);
+    grem = (int)(p % hw);
+    gy = grem / W;
+    gx = grem % W;
+  }
+  const int lim = 6 * hw - 1;
+  auto gather = [&](bool valid, float (&dst)[16]) __attribute__((always_inline)) {
+    // bit (dy+1)*3+(dx+1) set when that neighbour is inside the image; bit 9 always; bit 10 never
+    const unsigned rows = (gy > 0 ? 0x007u : 0u) | 0x038u | (gy < H - 1 ? 0x1c0u : 0u);
+    const unsigned cols = (gx > 0 ? 0x049u : 0u) | 0x092u | (gx < W - 1 ? 0x124u : 0u);
+    const bool ok = valid && gb < B;                       // (the last tile may end inside sample B: nothing is read from there)
+    const unsigned m = ok ? ((rows & cols) | 0x200u) : 0u;
+    const float* tp = tx + (int64_t)(ok ? gb : 0) * 6 * hw;
+    // branch-free: an out-of-image tap reads whatever lies at its offset, clamped into the sample's six planes, and is masked
+    // after the load -- a conditional load or a pointer select is compiled to a branch + s_waitcnt vmcnt(0) per tap
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      int idx = grem + off[i];
+      idx = idx < 0 ? 0 : (idx > lim ? lim : idx);
+      const float v = tp[idx];
+      dst[i] = (m >> code[i]) & 1u ? v : 0.f;
+    }
+    // advance to the tile this wave gathers next
+    gx += st_x; gy += st_y; grem += st_r; gb += st_b;
+    if (gx >= W) { gx -= W; gy += 1; }
+    if (grem >= hw) { grem -= hw; gy -= H; gb += 1; }
+  };
+
   // the operands of the next TWO tiles are in flight (one tile of work, ~2 500 cycles, does not cover a load's latency while the
   // kernel's own 876 MB of stores queue in front of it); three register sets change roles, no copies (a copy would wait for the load)
   float xa[16], xb[16], xc[16];
   int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  gather(tile < ntiles ? tile : 0, xa);
-  gather(tile + tstride < ntiles ? tile + tstride : 0, xb);
+  gather(tile < ntiles, xa);
+  gather(tile + tstride < ntiles, xb);
   auto step = [&](const float (&cur)[16], float (&fill)[16]) __attribute__((always_inline)) {
-    gather(tile + 2 * tstride < ntiles ? tile + 2 * tstride : tile, fill);
+    gather(tile + 2 * tstride < ntiles, fill);
     __builtin_amdgcn_sched_barrier(0);           // those 16 loads are issued BEFORE this tile's MFMAs, not after
     f32x16 acc[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[0] = cmr_mfma32(wf[0][g][j], cur[g * 4 + j], acc[0]);
-        acc[1] = cmr_mfma32(wf[1][g][j], cur[g * 4 + j], acc[1]);
+        if (g == 0 && j == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[0] = cmr_mfma32(wf[0][g][j], cur[0], zero);
+          acc[1] = cmr_mfma32(wf[1][g][j], cur[0], zero);
+        } else {
+          acc[0] = cmr_mfma32(wf[0][g][j], cur[g * 4 + j], acc[0]);
+          acc[1] = cmr_mfma32(wf[1][g][j], cur[g * 4 + j], acc[1]);
+        }
       }
-    const int64_t p = tile * 32 + l31;
     f32x4 ov[8];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -505,7 +532,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
         f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
         v += *reinterpret_cast<const f32x4*>(&bs[8 * (4 * n + q) + 4 * h]);      // (LDS: 32 registers for three operand sets)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
         ov[4 * n + q] = v;
       }
 #pragma unroll
@@ -523,11 +550,16 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
 #pragma unroll
     for (int i = 0; i < 8; ++i) cmr_pin(rv[i]);
     {
-      const int64_t p0 = tile * 32 + (lane >> 4);
-      float* yp = y + p0 * 64 + 4 * (lane & 15);
+      const int64_t p0 = tile * 32;                                     // (scalar)
+      float* yp = y + p0 * 64 + (lane >> 4) * 64 + 4 * (lane & 15);
+      if (p0 + 32 <= total) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (p0 + 4 * i < total) *reinterpret_cast<f32x4*>(yp + (int64_t)(4 * i) * 64) = rv[i];
+        for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(rv[i], reinterpret_cast<f32x4*>(yp + 4 * i * 64));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (p0 + (lane >> 4) + 4 * i < total) *reinterpret_cast<f32x4*>(yp + 4 * i * 64) = rv[i];
+      }
     }
     tile += tstride;
   };
@@ -640,14 +672,15 @@ extern "C" int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin
 extern "C" int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,
                                   const float* b_b, float* tmp_nchw, float* y_nhwc, int B, int H, int W, float slope,
                                   hipStream_t stream) {
-  CMR_REQUIRE(x_nchw && w_a && b_a && w3 && w1 && b_b && tmp_nchw && y_nhwc && B > 0 && H > 0 && W > 0);
+  CMR_REQUIRE(x_nchw && w_a && b_a && w3 && w1 && b_b && tmp_nchw && y_nhwc && B > 0 && H > 0 && W > 0 && slope >= 0.f && slope <= 1.f);
   const int64_t total = (int64_t)B * H * W;
-  hipLaunchKernelGGL(stem_a_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x_nchw, w_a, b_a,
+  CMR_REQUIRE(H <= 65535 && B <= 65535);
+  hipLaunchKernelGGL(stem_a_kernel, dim3((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0, stream, x_nchw, w_a, b_a,
                      tmp_nchw, B, H, W, slope);
-  CMR_REQUIRE((int64_t)3 * H * W < 0x7fffffff && cmr_aligned16(b_b) && cmr_aligned16(y_nhwc));
+  CMR_REQUIRE((int64_t)6 * H * W < 0x7fffffff && cmr_aligned16(b_b) && cmr_aligned16(y_nhwc));
   const int64_t stiles = (total + 31) / 32;
   const unsigned sgrid = (unsigned)(stiles + 3) / 4 < 1024u ? (unsigned)((stiles + 3) / 4) : 1024u;
-  hipLaunchKernelGGL(stem_b_kernel, dim3(sgrid), dim3(256), 0, stream, tmp_nchw, x_nchw, w3, w1, b_b, y_nhwc, B, H, W, slope);
+  hipLaunchKernelGGL(stem_b_kernel, dim3(sgrid), dim3(256), 0, stream, tmp_nchw, w3, w1, b_b, y_nhwc, B, H, W, slope);
   return cmr_launch_status();
 }
 

@@ -211,7 +211,7 @@ def stem_block(img_nchw, w_a, b_a, w3, w1, b_b, slope):
     B, c, H, W = img_nchw.shape
     if c != 3 or not img_nchw.is_contiguous():
         raise ValueError("stem expects a contiguous [B,3,H,W] image")
-    tmp = torch.empty_like(img_nchw)
+    tmp = torch.empty((B, 6, H, W), dtype=f32, device=img_nchw.device)      # conv-a output | a copy of the image (stem_b's single operand base)
     out = torch.empty((B, H, W, 64), dtype=f32, device=img_nchw.device)
     _lib.call("cmr_stem_block_f32", _p(img_nchw), _p(w_a), _p(b_a), _p(w3), _p(w1), _p(b_b), _p(tmp), _p(out), B, H, W,
               float(slope), _stream())

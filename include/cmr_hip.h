@@ -101,8 +101,8 @@ int cmr_set_wino_variant(int wave_specialised);
  * left some CUs: the image tower runs with a reduced budget while the point tower runs beside it.  Returns the previous setting. */
 int cmr_set_conv_cu_budget(int cus);
 
-/* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.
- * ImageResNet.py:50 with :9-23. */
+/* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.  tmp_nchw is scratch of
+ * [B][6][H][W] floats (conv-a output | a copy of the image); 0 <= slope <= 1.  ImageResNet.py:50 with :9-23. */
 int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,
                        const float* b_b, float* tmp_nchw, float* y_nhwc, int B, int H, int W, float slope,
                        hipStream_t stream);
