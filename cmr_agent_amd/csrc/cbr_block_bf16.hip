@@ -223,19 +223,15 @@ __global__ __launch_bounds__(512) void cbr_block_bf16_kernel(const CbbArgs a) {
         for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(yrow + n * 32 + q * 8) = ov[n][q];
     }
     if (a.colmax_part) {
+      const bool whole = tile * 32 + 32 <= rows;          // (wave-uniform) only the last tile has rows to mask
 #pragma unroll
       for (int n = 0; n < T2; ++n)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           f32x4 v = ov[n][q];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float m = valid ? v[e] : -INFINITY;
-#pragma unroll
-            for (int s = 1; s < 32; s <<= 1) m = fmaxf(m, __shfl_xor(m, s));
-            v[e] = m;
-          }
-          if (l31 == 0) *reinterpret_cast<f32x4*>(a.colmax_part + (int64_t)tile * CO + n * 32 + q * 8 + 4 * h) = v;
+          for (int e = 0; e < 4; ++e) v[e] = cmr_rowmax32(whole || valid ? v[e] : -INFINITY);
+          if (l31 == 16) *reinterpret_cast<f32x4*>(a.colmax_part + (int64_t)tile * CO + n * 32 + q * 8 + 4 * h) = v;
         }
     }
     rc = rn;

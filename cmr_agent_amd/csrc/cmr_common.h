@@ -59,6 +59,38 @@ __device__ __forceinline__ f32x16 cmr_mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// The value the partner lane (lane ^ 32) holds: v_permlane32_swap (gfx950) + a select, on the VALU -- __shfl_xor(v, 32) is a
+// ds_bpermute_b32 round trip through LDS with an address and a wait (36 of them per tile in the linear-attention query layer).
+// For 1-D workgroups whose size is a multiple of 64.
+__device__ __forceinline__ float cmr_xhalf(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // r[0] = [lo | lo], r[1] = [hi | hi]
+  return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+
+// Maximum over the 32 lanes that share lane >> 5 (the 32 rows of a tile in the MFMA result layout), on the DPP data path: quad
+// permutes, the two row mirrors and row_bcast:15 into rows 1 / 3 -- five VALU instructions per value and nothing through LDS
+// (__shfl_xor compiles to ds_bpermute_b32: 160 LDS round trips + their waits per tile).  The result is valid in lanes 16..31 of
+// each half.  max is exact and order independent: the same bits as before.
+// (Done on the order-preserving integer image of the float -- k = bits ^ ((bits >> 31) & 0x7fffffff), an involution -- because a
+// float max behind a DPP move is canonicalised first (two extra v_max per step) and is not folded into v_max_f32_dpp.)
+template <int CTRL>
+__device__ __forceinline__ int cmr_dpp(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }      // every lane has a source
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int cmr_dpp_rows(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ int cmr_imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ float cmr_rowmax32(float x) {
+  int m = __builtin_bit_cast(int, x);
+  m ^= (m >> 31) & 0x7fffffff;
+  m = cmr_imax(m, cmr_dpp<0xB1>(m));          // quad_perm:[1,0,3,2]
+  m = cmr_imax(m, cmr_dpp<0x4E>(m));          // quad_perm:[2,3,0,1]
+  m = cmr_imax(m, cmr_dpp<0x141>(m));         // row_half_mirror
+  m = cmr_imax(m, cmr_dpp<0x140>(m));         // row_mirror
+  m = cmr_imax(m, cmr_dpp_rows<0x142, 0xa>(m));    // row_bcast:15 -> rows 1 and 3 (rows 0 and 2 keep their own value)
+  m ^= (m >> 31) & 0x7fffffff;
+  return __builtin_bit_cast(float, m);
+}
+
 __device__ __forceinline__ int cmr_mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // Dropout mask, counter based (no state, no stored mask): element `idx` of dropout site `site` in the step whose seed is `seed` is KEPT

@@ -20,7 +20,7 @@ constexpr int LA_D = 64, LA_HID = 128, LA_STATE = 576;    // 8 heads x (8x8 KV +
 constexpr int LA_LD64 = LA_D + 4, LA_LD128 = LA_HID + 4;  // padded LDS weight rows (conflict-free b128 reads)
 
 __device__ __forceinline__ float la_elu1(float v) { return v > 0.f ? v + 1.f : expf(v); }   // F.elu(v) + 1
-__device__ __forceinline__ float la_xhalf(float v) { return __shfl_xor(v, 32); }            // partner lane (other 4 dims of the head)
+__device__ __forceinline__ float la_xhalf(float v) { return cmr_xhalf(v); }            // partner lane (other 4 dims of the head)
 
 // LayerNorm over the 64 channels of this lane's row (32 here, 32 in the partner lane), in place
 __device__ __forceinline__ void la_layernorm(f32x16 (&v)[2], const float* __restrict__ gs, const float* __restrict__ bs,

@@ -18,7 +18,7 @@
 
 namespace {
 
-__device__ __forceinline__ float vf_xhalf(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ float vf_xhalf(float v) { return cmr_xhalf(v); }
 __device__ __forceinline__ float vf_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 // LayerNorm over the 64 channels of a row held as 8 fragments (32 channels here, 32 in lane ^ 32), in place

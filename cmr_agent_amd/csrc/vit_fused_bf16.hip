@@ -18,7 +18,7 @@ namespace {
 
 typedef __bf16 vb_bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float vb_xhalf(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ float vb_xhalf(float v) { return cmr_xhalf(v); }
 __device__ __forceinline__ float vb_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 // LayerNorm over the 64 channels of a row held as 8 float4 pieces (4 in this lane, 4 in lane ^ 32); chan(i) = first channel of piece i
