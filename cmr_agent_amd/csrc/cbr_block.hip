@@ -272,6 +272,53 @@ __global__ __launch_bounds__(256) void colmax_partials_kernel(const float* __res
   }
 }
 
+// The same reduction in ONE launch, without the -inf fill and without atomics, when C is a multiple of 64: a 1024-thread
+// workgroup per (batch, 64-channel block) = 64 tile groups x 16 channel quads, 8 x 16-byte loads in flight per thread
+// (512 tiles x 64 channels = 128 KB per workgroup, L2 resident: the block kernel has just written it), then the 64 groups
+// fold through LDS in two steps.  max is order independent: the same bits as the atomic form.
+__global__ __launch_bounds__(1024) void colmax_direct_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             int tiles_per_batch, int C) {
+  __shared__ f32x4 red[64][16];
+  const int b = blockIdx.x, c = blockIdx.y * 64 + 4 * (threadIdx.x & 15);
+  const int q = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const float* p = part + (int64_t)b * tiles_per_batch * C + c;
+  const f32x4 ninf = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  f32x4 m = ninf;
+  for (int t0 = g; t0 < tiles_per_batch; t0 += 64 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + 64 * i;
+      v[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)(t < tiles_per_batch ? t : t0) * C);      // (t0 again: harmless under max)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[i][e]);
+  }
+  red[g][q] = m;
+  __syncthreads();
+  if (g < 8) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      const f32x4 o = red[g + 8 * i][q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], o[e]);
+    }
+    red[g][q] = m;
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      const f32x4 o = red[i][q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], o[e]);
+    }
+    *reinterpret_cast<f32x4*>(out + (int64_t)b * C + c) = m;
+  }
+}
+
 template <int KX, int CH, int CO, bool CONV_SC>
 int launch_cbr(const CbrArgs& a, hipStream_t stream) {
   constexpr int T1 = (CH + 31) / 32;
@@ -319,6 +366,10 @@ extern "C" int cmr_cbr_block_f32(const float* x1, int64_t ld1, int k1, const flo
 extern "C" int cmr_colmax_partials_f32(const float* part, float* out, int B, int tiles_per_batch, int C,
                                        hipStream_t stream) {
   CMR_REQUIRE(part && out && B > 0 && B <= 65535 && tiles_per_batch > 0 && C > 0);
+  if (C % 64 == 0 && cmr_aligned16(part) && cmr_aligned16(out)) {
+    hipLaunchKernelGGL(colmax_direct_kernel, dim3(B, C / 64), dim3(1024), 0, stream, part, out, tiles_per_batch, C);
+    return cmr_launch_status();
+  }
   hipLaunchKernelGGL(colmax_init_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, out, B * C);
   int z = (tiles_per_batch + 31) / 32;             // >= 32 tiles per chunk: 8 loads per thread
   z = z < 1 ? 1 : (z > 64 ? 64 : z);
