@@ -415,6 +415,23 @@ def test_col_reductions(ops):
     close(ops.colmax(x128.to(DEV), B, 700), x128.view(B, 700, 128).max(1)[0], 0, "colmax128")
 
 
+@pytest.mark.parametrize("B,tiles,C", [(3, 37, 64), (2, 700, 128), (2, 5, 192), (8, 512, 64), (2, 41, 96), (1, 1, 64)])
+def test_colmax_of_block_partials(ops, B, tiles, C):
+    """cmr_colmax_partials_f32 (the per-tile column maxima a ConvBNReLURes1D block leaves behind -> the per-sample maximum): the
+    single-launch form for C a multiple of 64 and the fill + atomic form for the rest, incl. all-negative columns, -inf partials of
+    empty tiles and tile counts that are not a multiple of the reduction's group width."""
+    from cmr_agent_amd import _lib
+    from cmr_agent_amd.ops import _p, _stream
+    part = rnd(B * tiles, C, seed=60 + tiles, lo=-9, hi=3)
+    part[:, 1] = -part[:, 1].abs() - 1.0                     # an all-negative column
+    if tiles > 2:
+        part[1] = float("-inf")                              # a tile without valid rows
+    pd = part.to(DEV)
+    out = torch.full((B, C), 7.0, device=DEV)                # no assumption about the previous content
+    _lib.call("cmr_colmax_partials_f32", _p(pd), _p(out), B, tiles, C, _stream())
+    assert torch.equal(out.cpu(), part.view(B, tiles, C).max(1)[0])
+
+
 def test_observation_and_pose(ops):
     B, N, h, w = 2, 4000, 24, 40
     pc = torch.stack([rnd(B, N, seed=55, lo=-30, hi=30), rnd(B, N, seed=56, lo=-2, hi=2), rnd(B, N, seed=57, lo=1, hi=60)], 1)
