@@ -432,6 +432,25 @@ def test_colmax_of_block_partials(ops, B, tiles, C):
     assert torch.equal(out.cpu(), part.view(B, tiles, C).max(1)[0])
 
 
+@pytest.mark.parametrize("kx,ch,co,conv", [(64, 128, 64, True), (64, 128, 128, False), (8, 8, 64, True), (64, 64, 64, False)])
+def test_cbr_block_column_maxima_are_the_maxima_of_its_rows(ops, kx, ch, co, conv):
+    """The fp32 block's per-tile maxima (DPP reduction over the 32 rows of a tile in the matrix-core result layout) folded per
+    sample are exactly the column maxima of the rows it wrote -- all-negative columns included (bias -50 on one channel)."""
+    B, rpb = 3, 352
+    rows = B * rpb
+    x = rnd(rows, kx, seed=71, lo=-2, hi=2)
+    w1, w2 = rnd(ch, kx, seed=72) / kx ** 0.5, rnd(co, ch, seed=73) / ch ** 0.5
+    wsc = rnd(co, kx, seed=74) / kx ** 0.5 if conv else None
+    b1, b2 = rnd(B, ch, seed=75), rnd(B, co, seed=76)
+    b2[:, 3] = -50.0
+    d = lambda t: None if t is None else t.to(DEV)
+    out = ops.cbr_block(d(x), d(w1), d(b1), d(w2), d(b2), d(wsc), 0.2, rows_per_batch=rpb, want_colmax=True)
+    assert out is not None
+    y, cm = out
+    assert float(y[:, 3].max()) < 0
+    assert torch.equal(cm.cpu(), y.cpu().view(B, rpb, co).max(1)[0])
+
+
 def test_observation_and_pose(ops):
     B, N, h, w = 2, 4000, 24, 40
     pc = torch.stack([rnd(B, N, seed=55, lo=-30, hi=30), rnd(B, N, seed=56, lo=-2, hi=2), rnd(B, N, seed=57, lo=1, hi=60)], 1)
