@@ -91,6 +91,17 @@ __device__ __forceinline__ float cmr_rowmax32(float x) {
   return __builtin_bit_cast(float, m);
 }
 
+// Partner values for lane ^ 1 (DPP quad permute: folds into the consuming VALU instruction) and lane ^ 16 (v_permlane16_swap + select),
+// instead of ds_bpermute_b32 round trips.  1-D workgroups, size a multiple of 64.
+__device__ __forceinline__ float cmr_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float cmr_xor16(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);      // r[0] = rows [0 0 2 2], r[1] = rows [1 1 3 3]
+  return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+
 __device__ __forceinline__ int cmr_mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // Dropout mask, counter based (no state, no stored mask): element `idx` of dropout site `site` in the step whose seed is `seed` is KEPT

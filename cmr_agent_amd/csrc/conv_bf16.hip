@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const B16Args a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float v = sum[e];
-            v += __shfl_xor(v, 1, 64);
-            if (TW == 16) v += __shfl_xor(v, 16, 64);
+            v += cmr_xor1(v);
+            if (TW == 16) v += cmr_xor16(v);
             sum[e] = 0.25f * v;
           }
           pooled[nt][q] = sum;
@@ -506,8 +506,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
           for (int e = 0; e < 4; ++e) {
             float v = acc[nt][4 * q + e] + Bs[(nt0 + nt) * 32 + q * 8 + 4 * h + e];
             v = v > 0.f ? v : v * a.slope;
-            v += __shfl_xor(v, 1, 64);                  // column partner
-            v += __shfl_xor(v, 16, 64);                 // row partner (rows 2 tw / 2 tw + 1 sit 16 lanes apart)
+            v += cmr_xor1(v);                  // column partner
+            v += cmr_xor16(v);                 // row partner (rows 2 tw / 2 tw + 1 sit 16 lanes apart)
             ov[nt][q][e] = 0.25f * v;
           }
     } else {
