@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* __restrict__
       s1[r] = k0 + 16 + 4 * g + r < Tk ? s1[r] * scale : -INFINITY;
     }
     float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-    bm = fmaxf(bm, __shfl_xor(bm, 16));
-    bm = fmaxf(bm, __shfl_xor(bm, 32));
+    bm = fmaxf(bm, cmr_xor16(bm));                                // (VALU lane exchanges: two LDS round trips sat on the
+    bm = fmaxf(bm, cmr_xhalf(bm));                                //  serial max -> exp -> multiply chain of every key block)
     const float mn = fmaxf(m, bm);                               // finite from the first step on (key 0 is always valid)
     const float alpha = expf(m - mn);
     m = mn;
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[r], p1[r], acc, 0, 0, 0);
   }
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
+  l += cmr_xor16(l);
+  l += cmr_xhalf(l);
   if (g < 2 && q0 + i < Tq) {
     const float inv = 1.f / l;
     f32x4 out = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
