@@ -21,11 +21,16 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # `--gpus N` without a launcher: start the N ranks as a child (python -m torch.distributed.run ...) before anything touches the GPU
+    from cmr_agent_amd.utils.launch import spawn_ranks_if_needed
+    spawn_ranks_if_needed(__file__)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from bench import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
@@ -35,6 +40,7 @@ from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
 from cmr_agent_amd.train import AgentUpdate  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
 from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
+from cmr_agent_amd.train.optim import LRSchedule  # noqa: E402
 from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
 
 SAMPLE_KEYS = ("states_2d", "states_3d", "state_values", "expert_actions_r", "expert_actions_t", "action_r", "action_t",
@@ -115,20 +121,31 @@ def main():
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--geo-ckpt', default=None)
     ap.add_argument('--out', default=None, help="directory for agent checkpoints (default: config.ckpt_dir)")
+    ap.add_argument('--optimizer', choices=("ADAM", "SGD"), default=None, help="overrides config.optimizer")
+    ap.add_argument('--lr-scheduler', choices=("StepLR", "ExponentialLR", "CosineAnnealingLR"), default=None, help="overrides config.lr_scheduler")
+    ap.add_argument('--gpus', type=int, default=1, help="data-parallel ranks, one per GPU (started here when no launcher did)")
+    ap.add_argument('--dist-backend', choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI")
+    ap.add_argument('--share-gpu', action='store_true', help="every rank on device 0 (rehearsal on a one-GPU box; needs gloo)")
     args = ap.parse_args()
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.share_gpu and world > 1 and args.dist_backend == "nccl":
+        raise SystemExit("--share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    dev = Ranks.local_device(args.share_gpu)
+    ranks = Ranks(backend=args.dist_backend, device=dev)
     Cfg = {"kitti": KittiConfiguration, "nuscenes": NuScenesConfiguration}[args.dataset]
     kw = {}
     if args.img:
         kw["cropped_img_H"], kw["cropped_img_W"] = (int(v) for v in args.img.lower().split("x"))
     config = Cfg(num_pt=args.num_pt, device=dev, **kw)
     B = args.batch_size or config.train_batch_size
-    if config.optimizer != "ADAM":
-        raise NotImplementedError("the HIP update implements the reference's default optimizer (ADAM, Train_Agent.py:121-127)")
+    if args.optimizer:
+        config.optimizer = args.optimizer
+    if args.lr_scheduler:
+        config.lr_scheduler = args.lr_scheduler
+    schedule = LRSchedule.from_config(config)                        # raises for a scheduler / optimizer the reference does not offer
 
     torch.manual_seed(config.seed)                                   # identical initial agent on every rank
     np.random.seed(config.seed + ranks.rank)
@@ -146,6 +163,9 @@ def main():
     update = AgentUpdate(agent, config, dist=ranks.dist)            # lr / betas (0.9, 0.99) / weight decay as Train_Agent.py:121-127
     if ranks.dist is not None:
         ranks.dist.broadcast(update.bucket.params, src=0)
+        n = ranks.collective_ranks()                                 # a real all-reduce on device memory over every rank
+        if ranks.rank == 0:
+            print(json.dumps({"ranks": n, "dist_backend": args.dist_backend, "gradient_bucket_floats": update.bucket.numel}))
     agent.eval()
     sample_gen = torch.Generator().manual_seed(config.seed + 17 * ranks.rank)
     torch.manual_seed(config.seed + 1000 * (ranks.rank + 1))         # action sampling differs per rank from here on
@@ -197,10 +217,7 @@ def main():
             global_step += 1
         if ranks.rank == 0:
             print("%d-th epoch end." % epoch)
-        if config.lr_scheduler == "StepLR" and (epoch + 1) % config.step_size == 0:       # Train_Agent.py:136-141, :318
-            update.set_lr(update.lr * config.scheduler_gamma)
-        elif config.lr_scheduler == "ExponentialLR":
-            update.set_lr(update.lr * config.scheduler_gamma)
+        update.set_lr(schedule.lr(epoch + 1))                            # lr_scheduler.step() once per epoch (Train_Agent.py:126-141, :317)
     ranks.close()
 
 

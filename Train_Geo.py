@@ -19,11 +19,16 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # `--gpus N` without a launcher: start the N ranks as a child (python -m torch.distributed.run ...) before anything touches the GPU
+    from cmr_agent_amd.utils.launch import spawn_ranks_if_needed
+    spawn_ranks_if_needed(__file__)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from bench import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
@@ -31,6 +36,7 @@ from cmr_agent_amd.models import MultiHeadModel  # noqa: E402
 from cmr_agent_amd.train import GeoUpdate  # noqa: E402
 from cmr_agent_amd.utils import synthetic  # noqa: E402
 from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
+from cmr_agent_amd.train.optim import LRSchedule  # noqa: E402
 from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
 
 VAL_SCALARS = (("val_loss/loss", "loss"), ("val_loss/geometric_loss", "geometric_loss"), ("val_loss/pc_overlap_loss", "pc_overlap_loss"),
@@ -66,20 +72,31 @@ def main():
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--out', default=None, help="directory for checkpoints (default: config.ckpt_dir)")
     ap.add_argument('--no-graph', action='store_true', help="launch every kernel of the step from Python instead of replaying a hipGraph")
+    ap.add_argument('--optimizer', choices=("ADAM", "SGD"), default=None, help="overrides config.optimizer")
+    ap.add_argument('--lr-scheduler', choices=("StepLR", "ExponentialLR", "CosineAnnealingLR"), default=None, help="overrides config.lr_scheduler")
+    ap.add_argument('--gpus', type=int, default=1, help="data-parallel ranks, one per GPU (started here when no launcher did)")
+    ap.add_argument('--dist-backend', choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI")
+    ap.add_argument('--share-gpu', action='store_true', help="every rank on device 0 (rehearsal on a one-GPU box; needs gloo)")
     args = ap.parse_args()
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.share_gpu and world > 1 and args.dist_backend == "nccl":
+        raise SystemExit("--share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    dev = Ranks.local_device(args.share_gpu)
+    ranks = Ranks(backend=args.dist_backend, device=dev)
     Cfg = {"kitti": KittiConfiguration, "nuscenes": NuScenesConfiguration}[args.dataset]
     kw = {}
     if args.img:
         kw["cropped_img_H"], kw["cropped_img_W"] = (int(v) for v in args.img.lower().split("x"))
     config = Cfg(num_pt=args.num_pt, device=dev, **kw)
     B = args.batch_size or config.train_batch_size
-    if config.optimizer != "ADAM":
-        raise NotImplementedError("the HIP update implements the reference's default optimizer (ADAM, Train_Geo.py:72-78)")
+    if args.optimizer:
+        config.optimizer = args.optimizer
+    if args.lr_scheduler:
+        config.lr_scheduler = args.lr_scheduler
+    schedule = LRSchedule.from_config(config)                        # raises for a scheduler / optimizer the reference does not offer
     val_interval = args.val_interval or config.val_interval
 
     torch.manual_seed(config.seed)                                   # identical initial model on every rank
@@ -93,6 +110,9 @@ def main():
     update = GeoUpdate(model, config, dist=ranks.dist)              # lr / betas (0.9, 0.99) / weight decay as Train_Geo.py:72-78
     if ranks.dist is not None:
         ranks.dist.broadcast(update.bucket.params, src=0)
+        n = ranks.collective_ranks()                                 # a real all-reduce on device memory over every rank
+        if ranks.rank == 0:
+            print(json.dumps({"ranks": n, "dist_backend": args.dist_backend, "gradient_bucket_floats": update.bucket.numel}))
 
     def loader(n, base_seed, bs):
         for i in range(n):
@@ -134,10 +154,7 @@ def main():
             global_step += 1
         if ranks.rank == 0:
             print("%d-th epoch end." % epoch)
-        if config.lr_scheduler == "StepLR" and (epoch + 1) % config.step_size == 0:              # Train_Geo.py:84-89, :191
-            update.set_lr(update.lr * config.scheduler_gamma)
-        elif config.lr_scheduler == "ExponentialLR":
-            update.set_lr(update.lr * config.scheduler_gamma)
+        update.set_lr(schedule.lr(epoch + 1))                            # lr_scheduler.step() once per epoch (Train_Geo.py:80-95, :190)
     ranks.close()
 
 

@@ -6,7 +6,10 @@ once + action_num x [observation_from_a_pose -> CMRAgent -> argmax action -> env
 copied to the host.  Workload = BASELINE.json configs[1]: KittiConfig, batch 8 per GPU, 16384
 points, 352x1216 image, 10 agent steps, fp32.  Inputs are resident in HBM before the timed region.
 
-  python bench.py [--gpus N --steps K --warmup W]            (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W]
+      N>1: one rank per GPU.  Under torch.distributed.run the ranks are already there; a bare `python bench.py --gpus N` starts
+      them itself (cmr_agent_amd/utils/launch.py).  `--dist-backend gloo --share-gpu` puts every rank on device 0: a rehearsal
+      of the launcher, the barrier / MAX protocol and the bucket all-reduce on a one-GPU box (not a scaling number).
 
 Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (stride-1 3x3 NHWC convolution on
 fp32 MFMA): algorithmic FLOPs of its launches / their HIP-event time inside the timed region, against
@@ -19,11 +22,17 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # --gpus N without a launcher: this process only starts `python -m torch.distributed.run ... bench.py <same flags>` as a
+    # child, relays rank 0's JSON line and exits with the child's code.  Nothing has touched the GPU at this point.
+    from cmr_agent_amd.utils.launch import spawn_ranks_if_needed
+    spawn_ranks_if_needed(__file__)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from cmr_agent_amd import ops  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
@@ -101,10 +110,11 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(spec, budget_s=25.0):
-    """The oracle on the SAME batch shape as the GPU step (B = 8 pairs of the workload), like for like: one warm-up pass on
-    a single pair, then the batch of 8 timed up to 3 times while the budget lasts (at least once); the median is reported
-    (SURVEY.md 8d asks for 1 warm-up + median of 5: 5 x ~8 s does not fit the bounded 10-30 s sample)."""
+def cpu_baseline(spec, budget_s=24.0, pairs=2, passes=3):
+    """The oracle on a BOUNDED sample of the same workload (1 warm-up + median): one warm-up pass on a single pair,
+    then `passes` timed passes over a batch of `pairs` pairs of the workload's shape (the full batch of 8 takes ~21 s per pass on
+    the box's host cores, so 3 passes of it do not fit the 10-30 s bound; the per-pair cost at batch 2 and batch 8 agrees within
+    noise); the median is reported, scaled to pairs / s."""
     from oracle import cmr_oracle as O
     w = WORKLOAD
     torch.set_num_threads(min(os.cpu_count() or 1, 32))     # past ~32 threads torch's small CPU ops only get slower
@@ -112,36 +122,115 @@ def cpu_baseline(spec, budget_s=25.0):
                              action_num=w["steps"])
     geo_sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
     agent_sd = hashfill.make_state_dict(spec["agent"], AGENT_TAG)
-    batch = synthetic.make_batch(w["B"], w["N"], w["H"], w["W"], w["M"], O.dataset_fps, O.nearest_node, seed=2023, n_circle=16)
-    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == w["B"] else v) for k, v in batch.items()}
-    times, t_start = [], time.perf_counter()
+    batch = synthetic.make_batch(pairs, w["N"], w["H"], w["W"], w["M"], O.dataset_fps, O.nearest_node, seed=2023, n_circle=16)
+    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == pairs else v) for k, v in batch.items()}
     with torch.no_grad():
         O.registration_iteration(geo_sd, agent_sd, one, cfg)                    # warm-up (allocator, thread pool)
-        while len(times) < 3 and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
-            t0 = time.perf_counter()
-            O.registration_iteration(geo_sd, agent_sd, batch, cfg)
-            times.append(time.perf_counter() - t0)
-    med = sorted(times)[len(times) // 2]
-    return dict(value=w["B"] / med, unit="registration iters/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
-                sample="median of %d timed passes (after 1 warm-up on one pair) over the batch of %d pairs (1 geo forward + %d agent "
-                       "steps, %dx%d image, %d points) through oracle/cmr_oracle.py, torch CPU fp32; seconds per pass: %s"
-                       % (len(times), w["B"], w["steps"], w["H"], w["W"], w["N"], ", ".join("%.2f" % t for t in times)))
+        med, times = _median_timed(lambda: O.registration_iteration(geo_sd, agent_sd, batch, cfg), passes, budget_s)
+    return dict(value=pairs / med, unit="registration iters/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
+                sample="median of %d timed passes (after 1 warm-up on one pair) over a batch of %d pairs of the workload's shape (1 geo "
+                       "forward + %d agent steps, %dx%d image, %d points; the GPU step has %d pairs) through oracle/cmr_oracle.py, torch "
+                       "CPU fp32; seconds per pass: %s"
+                       % (len(times), pairs, w["steps"], w["H"], w["W"], w["N"], w["B"], ", ".join("%.2f" % t for t in times)))
 
 
-def train_main(args):
+def setup_ranks(args):
+    """One rank per GPU (LOCAL_RANK), RCCL (backend "nccl") for the timing protocol and the gradient bucket."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.share_gpu and world > 1 and args.dist_backend == "nccl":
+        raise SystemExit("--share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    dev = Ranks.local_device(args.share_gpu)
+    ranks = Ranks(backend=args.dist_backend, device=dev)
+    return dev, ranks, world
+
+
+def dist_info(ranks, args):
+    """Evidence of the collective layer for the JSON line: world size as summed by a real all-reduce on device memory."""
+    n = ranks.collective_ranks()
+    d = {"dist_backend": args.dist_backend if ranks.world > 1 else None, "collective_ranks": n}
+    if ranks.world > 1 and args.dist_backend == "nccl":
+        d["rccl_ranks"] = n
+    if args.share_gpu and ranks.world > 1:
+        d["share_gpu"] = "all %d ranks on device 0 (protocol rehearsal, not a scaling measurement)" % ranks.world
+    return d
+
+
+def _median_timed(fn, passes, budget_s):
+    """fn() timed up to `passes` times while the budget lasts (at least once) -> (median seconds, [seconds])."""
+    times, t_start = [], time.perf_counter()
+    while len(times) < passes and (not times or time.perf_counter() - t_start + times[-1] < budget_s):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return sorted(times)[len(times) // 2], times
+
+
+def train_roofline(table, steps, dom_names, dom_label, peak_mfma=FP32_MFMA_PEAK_TFLOPS):
+    """roofline object of a training step from a CallTimer table: the dominant kernel family (by measured time among `dom_names`)
+    on ISSUED work (Winograd launches priced at 16/36 of their algorithmic multiplies), and the whole path = sum of ideal times /
+    sum of measured times over every modelled C-ABI call of the step."""
+    doms = [d for d in table if d["name"] in dom_names]
+    ms, calls = sum(d["ms"] for d in doms), sum(d["calls"] for d in doms)
+    fl, fli, by = sum(d["flops"] for d in doms), sum(d["issued_flops"] for d in doms), sum(d["bytes"] for d in doms)
+    mod = [d for d in table if d["modelled"]]
+    allms = sum(d["ms"] for d in table)
+    out = dict(kernel=dom_label, launches_per_step=calls / steps, avg_launch_us=1e3 * ms / max(calls, 1),
+               dominant_ms_per_step=ms / steps, kernel_ms_per_step=allms / steps,
+               path=sum(d["ideal_issued_ms"] for d in mod) / max(sum(d["ms"] for d in mod), 1e-9),
+               path_modelled_share_of_kernel_time=sum(d["ms"] for d in mod) / max(allms, 1e-9),
+               kernels=[dict(entry=d["name"], bound=d["bound"] if d["modelled"] else None, calls_per_step=d["calls"] / steps,
+                             ms_per_step=round(d["ms"] / steps, 4), frac=round(d["frac"], 3) if d["modelled"] else None)
+                        for d in table[:10]], traffic=None,
+               timed_in="separate eager pass of %d step(s), HIP events around every C-ABI call on its own stream" % steps)
+    if by and fl / by > 19.7:
+        ach = fli / (ms * 1e-3) / 1e12
+        out.update(bound="mfma", achieved=ach, peak=peak_mfma, unit="TFLOP/s", frac=ach / peak_mfma,
+                   frac_algorithmic=fl / (ms * 1e-3) / 1e12 / peak_mfma, algorithmic_gflop_per_launch=fl / max(calls, 1) / 1e9)
+    else:
+        ach = by / (ms * 1e-3) / 1e9
+        out.update(bound="hbm", achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
+                   algorithmic_bytes_per_launch=by / max(calls, 1))
+    return out
+
+
+def agent_update_batch(MB, h, wd, N, S, g, dev):
+    rnd = lambda *s: torch.rand(*s, generator=g)
+    s3 = torch.cat([rnd(MB, 3, N) * 80 - 40, (rnd(MB, 2, N) > 0.5).float()], 1)
+    return dict(states_2d=(rnd(MB, h, wd, 128) * 0.4 - 0.2).to(dev).permute(0, 3, 1, 2), states_3d=s3.to(dev),
+                expert_actions_r=torch.randint(0, S, (MB, 1), generator=g).to(dev), expert_actions_t=torch.randint(0, S, (MB, 2), generator=g).to(dev),
+                action_r=torch.randint(0, S, (MB, 1), generator=g).to(dev), action_t=torch.randint(0, S, (MB, 2), generator=g).to(dev),
+                action_logprob=(rnd(MB, 3) * 2.4 - 3.6).to(dev), state_value_ref=(rnd(MB, 1) * 2 - 1).to(dev),
+                advantages=(rnd(MB, 1) * 2 - 1).to(dev))
+
+
+def agent_update_cpu_baseline(spec, w, MB, budget_s=14.0):
+    """oracle/train_oracle.py (torch-CPU autograd + torch.optim.Adam, pinned to the reference's module) on the same minibatch shape:
+    1 warm-up on 2 observations, then the minibatch of 10 timed up to 3 times; median."""
+    from oracle import train_oracle as TO
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device="cpu", action_num=w["steps"])
+    sd = hashfill.make_state_dict(spec["agent"], AGENT_TAG)
+    g = torch.Generator().manual_seed(7)
+    small = agent_update_batch(2, cfg.image_H, cfg.image_W, w["N"], cfg.num_steps, g, "cpu")
+    full = agent_update_batch(MB, cfg.image_H, cfg.image_W, w["N"], cfg.num_steps, g, "cpu")
+    TO.adam_train(sd, [small], cfg)
+    med, times = _median_timed(lambda: TO.adam_train(sd, [full], cfg), 3, budget_s)
+    return dict(value=MB / med, unit="buffered observations/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
+                sample="median of %d timed updates (after 1 warm-up on 2 observations) of one minibatch of %d observations through "
+                       "oracle/train_oracle.py (autograd + Adam, torch CPU fp32); seconds per update: %s"
+                       % (len(times), MB, ", ".join("%.2f" % t for t in times)))
+
+
+def train_main(args, ctx=None, with_cpu=False):
     """--mode train: the agent update of Train_Agent.py:263-305 at the headline map size.  One STEP =
     one minibatch of 10 buffered observations per GPU (the reference's PPO minibatch, Train_Agent.py:260) through
     cmr_agent_amd.train.AgentUpdate: train-mode forward, BC + PPO loss, HIP backward into the flat gradient bucket, ONE
-    RCCL all-reduce of the bucket (N > 1), fused Adam.  Prints one JSON line with the whole-job samples/s and the
-    all-reduce time per step (HIP events around the collective)."""
+    RCCL all-reduce of the bucket (N > 1), fused Adam.  Returns the JSON line (rank 0; None elsewhere) with the whole-job
+    samples/s, the all-reduce time per step (HIP events around the collective), a `roofline` and (N = 1) a `cpu_baseline`."""
     from cmr_agent_amd.train import AgentUpdate
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    dev, ranks, world = ctx or setup_ranks(args)
     w = WORKLOAD
     dtype = args.dtype or "f32"
     ops.CONV_BF16 = dtype == "bf16"      # forward and data-gradient convolutions on the bf16 cores; weight gradients stay fp32
@@ -151,15 +240,10 @@ def train_main(args):
     load_checked(agent, hashfill.make_state_dict(spec["agent"], AGENT_TAG))
     agent = agent.to(dev)
     up = AgentUpdate(agent, cfg, dist=ranks.dist)
-    MB, h, wd, S = 10, cfg.image_H, cfg.image_W, cfg.num_steps
+    MB, h, wd = 10, cfg.image_H, cfg.image_W
     g = torch.Generator().manual_seed(ranks.shard_seed(cfg.seed))
-    rnd = lambda *s: torch.rand(*s, generator=g)
-    s3 = torch.cat([rnd(MB, 3, w["N"]) * 80 - 40, (rnd(MB, 2, w["N"]) > 0.5).float()], 1)
-    batch = dict(states_2d=(rnd(MB, h, wd, 128) * 0.4 - 0.2).to(dev).permute(0, 3, 1, 2), states_3d=s3.to(dev),
-                 expert_actions_r=torch.randint(0, S, (MB, 1), generator=g).to(dev), expert_actions_t=torch.randint(0, S, (MB, 2), generator=g).to(dev),
-                 action_r=torch.randint(0, S, (MB, 1), generator=g).to(dev), action_t=torch.randint(0, S, (MB, 2), generator=g).to(dev),
-                 action_logprob=(rnd(MB, 3) * 2.4 - 3.6).to(dev), state_value_ref=(rnd(MB, 1) * 2 - 1).to(dev),
-                 advantages=(rnd(MB, 1) * 2 - 1).to(dev))
+    batch = agent_update_batch(MB, h, wd, w["N"], cfg.num_steps, g, dev)
+    info = dist_info(ranks, args)
     for _ in range(args.warmup):
         up.step(batch)
     ranks.barrier()
@@ -171,12 +255,27 @@ def train_main(args):
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     assert torch.isfinite(losses).all()
+    bucket_sum = float(up.bucket.grads.double().sum())     # identical on every rank after the all-reduce
+    sums = [bucket_sum]
+    if world > 1:
+        t = torch.tensor([bucket_sum], dtype=torch.float64, device=dev)
+        lo, hi = t.clone(), t.clone()
+        ranks.dist.all_reduce(lo, op=ranks.dist.ReduceOp.MIN)
+        ranks.dist.all_reduce(hi, op=ranks.dist.ReduceOp.MAX)
+        sums = [float(lo), float(hi)]
+    with CallTimer() as ct:
+        up.step(batch)
+        torch.cuda.synchronize()
+    ranks.barrier()
+    line = None
     if ranks.rank == 0:
         # dense work of one update: forward convs + data gradients + weight gradients of the eight 128->128 3x3 convolutions
         # (no data gradient for the first one) and of the 1x1 stacks of the 3-D branch
         conv_f = sum(2.0 * 9 * 128 * 128 * MB * (h >> s) * (wd >> s) * 2 for s in range(4))
         flops = conv_f * 3 - 2.0 * 9 * 128 * 128 * MB * h * wd
-        print(json.dumps({
+        conv_names = ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wgrad_f32", "cmr_conv3x3_nhwc_f32", "cmr_conv3x3_bf16_nhwc_f32",
+                      "cmr_conv3x3_bf16io_nhwc")
+        line = {
             "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
             "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -186,24 +285,43 @@ def train_main(args):
                                    "accumulate), weight gradients and everything else fp32" if dtype == "bf16" else ""), "minibatch_per_gpu": MB,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
             "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
+            "gradient_bucket_sum_min_max_over_ranks": sums, "gradient_buckets_identical": sums[0] == sums[-1],
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
-            "loss": float(losses[0])}))
-    ranks.close()
+            "roofline": train_roofline(ct.table(), 1, conv_names, "3x3 convolutions of the update: forward + data gradient (Winograd "
+                                       "conv3x3_wino_ws_kernel) and weight gradient (conv3x3_wgrad_kernel), fp32 MFMA"),
+            "loss": float(losses[0]), **info}
+        if with_cpu and world == 1:
+            line["cpu_baseline"] = agent_update_cpu_baseline(spec, w, MB)
+    return line
 
 
-def geo_train_main(args):
+def geo_update_cpu_baseline(spec, num_pt, B, budget_s=16.0):
+    """oracle/train_oracle.py:geo_adam_train (autograd + clip + Adam) on a BOUNDED sample: 1 warm-up + up to 3 timed steps on a batch
+    of 2 pairs of the same shape (per-pair cost; BatchNorm statistics over 2 instead of 8 pairs do not change the work)."""
+    from oracle import cmr_oracle as O
+    from oracle import train_oracle as TO
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    cfg = KittiConfiguration(device="cpu", num_pt=num_pt)
+    sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
+    nb = 2
+    batch = synthetic.make_batch(nb, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, O.dataset_fps, O.nearest_node,
+                                 seed=5, n_circle=512)
+    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == nb else v) for k, v in batch.items()}
+    TO.geo_adam_train(sd, [one], cfg)
+    med, times = _median_timed(lambda: TO.geo_adam_train(sd, [batch], cfg), 3, budget_s)
+    return dict(value=nb / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
+                sample="median of %d timed steps (after 1 warm-up on one pair) on a batch of %d pairs (160x512 image, %d points; the GPU "
+                       "step has %d) through oracle/train_oracle.py (autograd + clip + Adam, torch CPU fp32); seconds per step: %s"
+                       % (len(times), nb, cfg.num_pt, B, ", ".join("%.2f" % t for t in times)))
+
+
+def geo_train_main(args, ctx=None, with_cpu=False):
     """--mode train-geo: the geometric-model update of Train_Geo.py:166-174 at the reference's training
     configuration (KittiConfig: 160x512 crop, 40 960 points, batch 8 per GPU).  One STEP = one batch through
     cmr_agent_amd.train.GeoUpdate: train-mode forward on the HIP tape, focal + focal + circle loss, backward into the flat
     gradient bucket, ONE RCCL all-reduce of it (N > 1), value clipping + fused Adam."""
     from cmr_agent_amd.train import GeoUpdate
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    dev, ranks, world = ctx or setup_ranks(args)
     dtype = args.dtype or "f32"
     ops.CONV_BF16 = dtype == "bf16"
     cfg = KittiConfiguration(device=dev, num_pt=args.num_pt)        # --num-pt 65536 = BASELINE.json configs[4]
@@ -215,20 +333,29 @@ def geo_train_main(args):
     up = GeoUpdate(model, cfg, dist=ranks.dist)
     batch = synthetic.make_batch(B, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, hip_fps(dev), hip_nearest(dev),
                                  seed=ranks.shard_seed(cfg.seed), n_circle=512, device=dev)
+    info = dist_info(ranks, args)
+    with CallTimer() as ct:                 # eager, before the graph is captured: every C-ABI call of one step with its work
+        up.step(batch)
+        torch.cuda.synchronize()
     if not args.eager:
         up.enable_graph(batch)          # forward + backward replayed from a hipGraph; all-reduce and Adam launched per step
     for _ in range(args.warmup):
         up.step(batch)
     ranks.barrier()
-    t0 = time.perf_counter()
+    ar_ms, t0 = 0.0, time.perf_counter()
     for _ in range(args.steps):
         losses = up.step(batch)
+        if world > 1:
+            ar_ms += up.allreduce_ms()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     loss = float(losses["loss"])
     assert loss == loss
+    line = None
     if ranks.rank == 0:
-        print(json.dumps({
+        table = ct.table()
+        dom = max((d for d in table if d["modelled"]), key=lambda d: d["ms"])
+        line = {
             "metric": "geometric-model update pairs/sec (Train_Geo.py step at the KittiConfig training shape)",
             "value": world * B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
@@ -237,20 +364,22 @@ def geo_train_main(args):
                                    "circle loss, dropout 0.1 at the reference's sites, clip_grad_value_ 1, Adam (lr 1e-3, betas .9/.99, wd 1e-6)" % (B, cfg.num_pt, cfg.num_node),
                        "batch_per_gpu": B,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
-            "loss": loss}))
-    ranks.close()
+            "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
+            "launches_per_step": sum(d["calls"] for d in table),
+            "roofline": train_roofline(table, 1, (dom["name"],), "%s (the entry point with the largest summed time of the step)" % dom["name"]),
+            "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
+            "loss": loss, **info}
+        if with_cpu and world == 1:
+            line["cpu_baseline"] = geo_update_cpu_baseline(spec, cfg.num_pt, B)
+    return line
 
 
-def iter_main(args):
+def iter_main(args, ctx=None):
     """--mode iter: one IterModel forward (models/IterModel.py:250-475) on the pair it is written for: 160x512 image (40x128
     maps), 729 sampled poses, BASELINE configs[1]'s 16 384 points.  One STEP = one forward on a batch dict as MultiHeadModel leaves it
     (synthetic features, hash-filled weights).  Replicas only across GPUs (the model handles one pair)."""
     from cmr_agent_amd.models import IterModel
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)
+    dev, ranks, world = ctx or setup_ranks(args)
     dtype = args.dtype or "f32"
     ops.CONV_BF16 = dtype == "bf16"
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
@@ -272,12 +401,13 @@ def iter_main(args):
         with CallTimer() as ct:
             run()
             torch.cuda.synchronize()
+    line = None
     if ranks.rank == 0:
         table = ct.table()
         conv = [d for d in table if d["name"].startswith("cmr_conv3x3")]
-        cms, cfl = sum(d["ms"] for d in conv), sum(d["flops"] for d in conv)
+        cms, cfl = sum(d["ms"] for d in conv), sum(d["issued_flops"] for d in conv)
         stages = {d["name"]: round(d["ms"], 3) for d in table}
-        print(json.dumps({
+        line = ({
             "metric": "IterModel forwards/sec (729 sampled poses, 40x128 maps, %d points)" % N, "value": world * args.steps / elapsed,
             "unit": "cost-volume forwards/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
@@ -286,9 +416,23 @@ def iter_main(args):
             "roofline": {"kernel": "the nine 3x3 convolutions of cost_volume_convs as a batch of 729 maps (Winograd fp32 / bf16 two-team kernel)",
                          "bound": "mfma", "achieved": cfl / (cms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": cfl / (cms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "note": "algorithmic FLOPs of the convolutions as launched (channel counts padded to 64) / their summed HIP-event time; "
-                                 "priced at the fp32 peak in both modes", "stage_ms": stages}}))
-    ranks.close()
+                         "note": "ISSUED FLOPs of the convolutions as launched (channel counts padded to 64; Winograd launches at 16/36 of "
+                                 "their algorithmic multiplies) / their summed HIP-event time; priced at the fp32 peak in both modes",
+                         "stage_ms": stages}})
+    return line
+
+
+def compact(line):
+    """sub-object of the default line for a secondary configuration (BASELINE.json configs[2] / configs[4] at 1 GPU)."""
+    r = line["roofline"]
+    out = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in line}
+    out["workload"] = line["config"]["workload"]
+    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "path", "traffic",
+                                         "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step") if k in r}
+    for k in ("cpu_baseline", "launches_per_step", "launch_mode"):
+        if k in line:
+            out[k] = line[k]
+    return out
 
 
 def main():
@@ -300,6 +444,8 @@ def main():
                     help="register (default): the headline registration iteration; train: the agent's minibatch update; "
                          "train-geo: the geometric model's training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-lines", action="store_true", help="register mode at 1 GPU: skip the `train` / `train_geo` sub-objects "
+                    "(BASELINE.json configs[2] / configs[4] at 1 GPU) of the default line")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
                     help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
@@ -308,21 +454,21 @@ def main():
     ap.add_argument("--alone-pass", action="store_true", help="one more (untimed) eager pass with every branch on ONE stream: adds "
                     "roofline.path_alone, each kernel's duration alone on the device (off by default so that the kernel statistics of a "
                     "profiled default run contain the same launches the JSON line averages over)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI (default); gloo: host "
+                    "collectives on device tensors, for --share-gpu rehearsals")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0 (one-GPU box): exercises launcher, barrier / MAX "
+                    "protocol and the bucket all-reduce on real HIP gradients; needs --dist-backend gloo")
     args = ap.parse_args()
-    if args.mode == "train":
-        return train_main(args)
-    if args.mode == "train-geo":
-        return geo_train_main(args)
-    if args.mode == "iter":
-        return iter_main(args)
+    if args.mode != "register":
+        fn = {"train": train_main, "train-geo": geo_train_main, "iter": iter_main}[args.mode]
+        ctx = setup_ranks(args)
+        line = fn(args, ctx, with_cpu=not args.no_cpu_baseline) if args.mode != "iter" else iter_main(args, ctx)
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        ctx[1].close()
+        return
 
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    ranks = Ranks(backend="nccl", device=dev)          # RCCL: timing barrier / MAX only, no data-path collective
+    dev, ranks, world = setup_ranks(args)          # RCCL: timing barrier / MAX only, no data-path collective
     rank = ranks.rank
 
     w = WORKLOADS[args.workload]
@@ -374,6 +520,8 @@ def main():
                 streams.ENABLED = True
     assert torch.isfinite(pose).all()
     elapsed = ranks.max_over_ranks(elapsed)
+    info = dist_info(ranks, args)
+    line = None
 
     if rank == 0:
         table = ct.table()
@@ -381,17 +529,18 @@ def main():
         doms = [d for d in table if d["name"] in dom_names]
         conv = dict(launches=sum(d["calls"] for d in doms), ms=sum(d["ms"] for d in doms), flops=sum(d["flops"] for d in doms),
                     bytes=sum(d["bytes"] for d in doms))
-        sum_ideal = sum(d["ideal_ms"] for d in table if d["modelled"])
+        sum_ideal = sum(d["ideal_issued_ms"] for d in table if d["modelled"])      # Winograd priced at the 16/36 it issues
+        sum_ideal_alg = sum(d["ideal_ms"] for d in table if d["modelled"])
         sum_meas = sum(d["ms"] for d in table if d["modelled"])
         unmodelled = [d["name"] for d in table if not d["modelled"]]
         alone = {}
         if ct1 is not None:
             t1 = ct1.table()
             # the same ratio with every kernel timed ALONE on the device (single stream): what the kernels themselves achieve
-            alone = {"path_alone": sum(d["ideal_ms"] for d in t1 if d["modelled"]) / sum(d["ms"] for d in t1 if d["modelled"]),
+            alone = {"path_alone": sum(d["ideal_issued_ms"] for d in t1 if d["modelled"]) / sum(d["ms"] for d in t1 if d["modelled"]),
                      "path_alone_kernel_ms_per_step": sum(d["ms"] for d in t1 if d["modelled"]) / min(args.steps, 5)}
         kernels = [dict(entry=d["name"], bound=d["bound"], calls_per_step=d["calls"] / args.steps, ms_per_step=round(d["ms"] / args.steps, 4),
-                        ideal_ms_per_step=round(d["ideal_ms"] / args.steps, 4), frac=round(d["frac"], 3),
+                        ideal_ms_per_step=round(d["ideal_issued_ms"] / args.steps, 4), frac=round(d["frac"], 3),
                         gflop_per_step=round(d["flops"] / args.steps / 1e9, 2), mb_per_step=round(d["bytes"] / args.steps / 1e6, 1))
                    for d in table if d["modelled"]]
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
@@ -409,9 +558,11 @@ def main():
         common = {"algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                   "launches_per_step": conv["launches"] / args.steps, "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                   "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9, "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
-                  # sum over every entry point of its ideal time (algorithmic FLOPs / fp32 MFMA peak for MFMA-class
-                  # calls, algorithmic bytes / 8 TB/s for HBM-class ones) / sum of the measured times
-                  "path": sum_ideal / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
+                  # sum over every entry point of its ideal time (FLOPs / fp32 MFMA peak for MFMA-class calls, algorithmic
+                  # bytes / 8 TB/s for HBM-class ones) / sum of the measured times.  `path` counts the FLOPs a kernel ISSUES (Winograd
+                  # launches: 16/36 of the convolution's multiplies), so it is a hardware fraction <= 1; path_algorithmic credits the
+                  # convolution's full 2*9*Cin*Cout per pixel
+                  "path": sum_ideal / sum_meas, "path_algorithmic": sum_ideal_alg / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
                   "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled, "kernels": kernels[:14],
                   **alone,
                   "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the side-stream "
@@ -422,13 +573,17 @@ def main():
             roofline = dict(kernel="conv3x3_bf16_tt_kernel / conv3x3_bf16_kernel (NHWC 3x3 direct: two-team stride-1 kernel, one-team stride-2 kernel; v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM)", bound="hbm",
                             achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=None,
                             mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2500.0,
-                            path_note="ideal times of `path` are priced at the fp32 peaks (utils/workmodel.py)", **common)
+                            path_note="ideal times of `path` are priced at the fp32 peaks (utils/workmodel.py); the bf16 direct "
+                                      "convolution issues all 36/36 multiplies", **common)
         else:
+            # `achieved` / `frac`: the multiplies the kernel ISSUES on the matrix cores (F(2x2,3x3): 16/36 of the convolution's
+            # 2*9*Cin*Cout flop per output pixel) over its HIP-event time -- a position under the fp32 MFMA roof, <= 1 by construction;
+            # the algorithmic figure (what a direct convolution would have to sustain) stays beside it
+            issued = achieved * 16.0 / 36.0
             roofline = dict(kernel="conv3x3_wino_ws_kernel / conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)", bound="mfma",
-                            achieved=achieved, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / FP32_MFMA_PEAK_TFLOPS,
-                            # `achieved` counts the ALGORITHMIC work of the convolution (2*9*Cin*Cout flop per output pixel); Winograd
-                            # issues 16/36 of those multiplies on the matrix cores, which is how frac can pass 1
-                            mfma_executed=achieved * 16.0 / 36.0, mfma_executed_frac=achieved * 16.0 / 36.0 / FP32_MFMA_PEAK_TFLOPS,
+                            achieved=issued, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=issued / FP32_MFMA_PEAK_TFLOPS,
+                            basis="issued MFMA work (16/36 of the algorithmic multiplies)",
+                            achieved_algorithmic=achieved, frac_algorithmic=achieved / FP32_MFMA_PEAK_TFLOPS,
                             traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src, **common)
         line = {
             "metric": "registration iters/sec (%s %dx%d img + %d pts, 1 geo forward + %d agent steps)" % (
@@ -440,11 +595,26 @@ def main():
                                                 "everything else fp32)") + ", hash-filled weights", "batch_per_gpu": w["B"],
                        "parallelism": "batch sharding, no data-path collective"},
             "agent_steps_per_s": iters * w["steps"] / elapsed, "roofline": roofline,
-            "launch_mode": "eager" if args.eager else "hipGraph replay",
+            "launch_mode": "eager" if args.eager else "hipGraph replay", **info,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c1":
             line["cpu_baseline"] = cpu_baseline(spec)
-        print(json.dumps(line))
+    if world == 1 and args.workload == "c1" and not args.no_train_lines and args.dtype is None:
+        # BASELINE.json configs[2] (per-GPU bf16 agent update) and configs[4] (Train_Geo step at 65 536 points) at 1 GPU, each with
+        # its own roofline and CPU baseline, folded into the default line so that the driver's record carries them
+        del geo, agent, batch
+        if not args.eager:
+            del rg, run_step
+        torch.cuda.empty_cache()
+        sub = argparse.Namespace(**vars(args))
+        sub.steps, sub.warmup, sub.dtype, sub.eager = 10, 3, "bf16", False
+        line["train"] = compact(train_main(sub, (dev, ranks, world), with_cpu=not args.no_cpu_baseline))
+        ops.CONV_BF16 = False
+        torch.cuda.empty_cache()
+        sub.steps, sub.warmup, sub.dtype, sub.num_pt = 5, 2, "f32", 65536
+        line["train_geo"] = compact(geo_train_main(sub, (dev, ranks, world), with_cpu=not args.no_cpu_baseline))
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     ranks.close()
 
 

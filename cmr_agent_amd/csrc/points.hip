@@ -374,6 +374,9 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 // registers, argmax by wave shuffle + LDS across the 16 waves (lowest index wins ties, like
 // torch.max).  xyz4 [B,N,4]; start [B]; out [B,npoint] int64 (local indices).
 constexpr int FPS_T = 1024;
+// start index of a cloud, forced into [0, N): the reference indexes xyz[start] and raises for an index outside the cloud
+// (pointnet_util.py:62-66); a kernel cannot raise, and must not read outside the cloud either.
+__device__ __forceinline__ int fps_start(int64_t s, int N) { return s < 0 ? 0 : (s >= N ? N - 1 : (int)s); }
 template <int PER, bool CACHE>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz4, const int64_t* __restrict__ start,
                                                     int64_t* __restrict__ out, int N, int npoint) {
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
       px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
     }
   }
-  int far = (int)start[b];
+  int far = fps_start(start[b], N);
   for (int it = 0; it < npoint; ++it) {
     if (tid == 0) out[(int64_t)b * npoint + it] = far;
     const f32x4 c = *reinterpret_cast<const f32x4*>(xb + (int64_t)far * 4);
@@ -453,7 +456,7 @@ template <int PER>
 __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restrict__ xyz4, const int64_t* __restrict__ start,
                                                           unsigned long long* __restrict__ win /*[B][npoint]*/,
                                                           unsigned* __restrict__ cnt /*[B] arrivals, then [B] error flags*/, int B, int G,
-                                                          int N, int npoint) {
+                                                          int N, int npoint, unsigned spin_limit) {
   __shared__ float red_d[4];
   __shared__ int red_i[4];
   __shared__ int far_s;
@@ -473,7 +476,7 @@ __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restric
   }
   unsigned long long* wb = win + (int64_t)b * npoint;
   unsigned* err = cnt + B + b;
-  int far = (int)start[b];
+  int far = fps_start(start[b], N);
   if (w == 0 && tid == 0) wb[0] = (unsigned long long)far;        // round 0's word holds the start index as it is
   for (int it = 0; it + 1 < npoint; ++it) {
     const f32x4 c = *reinterpret_cast<const f32x4*>(xb + (int64_t)far * 4);
@@ -505,16 +508,20 @@ __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restric
       __hip_atomic_fetch_add(&cnt[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned want = (unsigned)G * (unsigned)(it + 1);
       unsigned spins = 0;
-      bool bad = false;
-      while (__hip_atomic_load(&cnt[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (++spins > FPS_SPIN || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = true; break; }
+      bool bad = spin_limit == 0u;                              // 0 = "fail at once" (tests of the repair path)
+      while (!bad && __hip_atomic_load(&cnt[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (++spins > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = true; break; }
         __builtin_amdgcn_s_sleep(1);
+      }
+      unsigned long long k = 0ull;
+      if (!bad) {
+        k = __hip_atomic_load(&wb[it + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = k == 0ull;                                        // no workgroup had a candidate this round: not a valid index either
       }
       if (bad) {
         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         far_s = -1;
       } else {
-        const unsigned long long k = __hip_atomic_load(&wb[it + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         far_s = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
       }
     }
@@ -531,8 +538,60 @@ __global__ __launch_bounds__(256) void fps_unpack_kernel(const unsigned long lon
   const int b = (int)(i / npoint), it = (int)(i % npoint);
   const unsigned long long k = win[i];
   int64_t v = it == 0 ? (int64_t)k : (int64_t)(0xffffffffu - (unsigned)(k & 0xffffffffull));
-  if (cnt[B + b] != 0u) v = -1;                                 // a cloud whose workgroups could not meet: every index invalid
+  if (cnt[B + b] != 0u) v = -1;                                 // a cloud whose workgroups could not meet: fps_repair_kernel rewrites it
   out[i] = v;
+}
+
+// Repair pass behind fps_coop_kernel: one workgroup per cloud, which leaves at once unless the cloud's error word is set (its
+// workgroups did not all become resident within the spin bound -- e.g. persistent kernels of another stream held the CUs).  Then
+// it redoes the whole cloud alone: same distances, same tie rule, running min-distances in the workspace (any N).  The caller
+// therefore never sees the -1 of a failed cloud, with no host round trip and nothing a hipGraph capture could not record.
+__global__ __launch_bounds__(FPS_T) void fps_repair_kernel(const float* __restrict__ xyz4, const int64_t* __restrict__ start,
+                                                           unsigned* __restrict__ cnt, float* __restrict__ distws,
+                                                           int64_t* __restrict__ out, int B, int N, int npoint) {
+  __shared__ float red_d[16];
+  __shared__ int red_i[16];
+  __shared__ int far_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (cnt[B + b] == 0u) return;                                 // uniform per workgroup
+  const float* xb = xyz4 + (int64_t)b * N * 4;
+  float* db = distws + (int64_t)b * N;
+  for (int i = tid; i < N; i += FPS_T) db[i] = 1e10f;           // each thread only ever touches its own entries
+  int far = fps_start(start[b], N);
+  for (int it = 0; it < npoint; ++it) {
+    if (tid == 0) out[(int64_t)b * npoint + it] = far;
+    const f32x4 c = *reinterpret_cast<const f32x4*>(xb + (int64_t)far * 4);
+    float bd = -1.f;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < N; i += FPS_T) {
+      const f32x4 p = *reinterpret_cast<const f32x4*>(xb + (int64_t)i * 4);
+      const float d = fminf(db[i], sqdist3(p[0], p[1], p[2], c[0], c[1], c[2]));
+      db[i] = d;
+      if (d > bd) { bd = d; bi = i; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float od = __shfl_xor(bd, m);
+      const int oi = __shfl_xor(bi, m);
+      if (od > bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if (lane == 0) { red_d[wave] = bd; red_i[wave] = bi; }
+    __syncthreads();
+    if (wave == 0) {
+      float d2 = lane < 16 ? red_d[lane] : -2.f;
+      int i2 = lane < 16 ? red_i[lane] : 0x7fffffff;
+#pragma unroll
+      for (int m = 8; m >= 1; m >>= 1) {
+        const float od = __shfl_xor(d2, m);
+        const int oi = __shfl_xor(i2, m);
+        if (od > d2 || (od == d2 && oi < i2)) { d2 = od; i2 = oi; }
+      }
+      if (lane == 0) far_s = i2 < N ? i2 : 0;
+    }
+    __syncthreads();
+    far = far_s;
+  }
+  if (tid == 0) cnt[B + b] = 2u;                                // 2 = "was repaired" (visible to the caller in the workspace)
 }
 
 // ball query: one wave per query; ascending scan, first `nsample` hits with d2 <= r2, padded
@@ -749,7 +808,8 @@ extern "C" int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out
 
 
 // Cooperative variant for N > 16 384 (and any N the caller prefers): G workgroups per cloud.  ws: [B][npoint] 64-bit round words,
-// then [2 B] 32-bit counters / error flags.  out[b][:] = -1 for a cloud whose workgroups did not all become resident.
+// then [2 B] 32-bit counters / status words, then [B][N] floats for the repair pass.  A cloud whose workgroups did not all become
+// resident within the spin bound is recomputed by fps_repair_kernel in the same call: out never holds the -1 of a failed cloud.
 static int fps_groups(int B, int N) {
   int g = 256 / B;                                              // all B * G workgroups resident at once, one per CU
   const int cap = B <= 4 ? 16 : 8;                              // measured at 65 536 points: 16 groups 2.9 us / round at B = 1, 8 groups 3.8 at B = 8
@@ -759,23 +819,27 @@ static int fps_groups(int B, int N) {
   return g < 1 ? 1 : g;
 }
 
+// workspace: [B][npoint] 64-bit round words | [B] arrival counters | [B] status words (0 ok, 2 repaired) | pad | [B][N] floats (repair)
+static int64_t fps_words_bytes(int B, int npoint) { return ((int64_t)B * npoint * 8 + (int64_t)2 * B * 4 + 15) / 16 * 16; }
+
 extern "C" int64_t cmr_fps_workspace_bytes(int B, int N, int npoint) {
-  (void)N;
-  return (int64_t)B * npoint * 8 + (int64_t)2 * B * 4;
+  return fps_words_bytes(B, npoint) + (int64_t)B * N * 4;
 }
 
-extern "C" int cmr_fps_ws_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
-                              hipStream_t stream) {
+static int fps_ws_launch(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
+                         unsigned spin_limit, hipStream_t stream) {
   CMR_REQUIRE(xyz4 && start && out && ws && B > 0 && N > 0 && npoint > 0 && cmr_aligned16(xyz4) && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0);
   CMR_REQUIRE(ws_bytes >= cmr_fps_workspace_bytes(B, N, npoint));
   const int G = fps_groups(B, N);
   CMR_REQUIRE((int64_t)B * G <= 256);                            // co-residency of every cloud's workgroups
   const int per = ((N + G - 1) / G + FPS_CT - 1) / FPS_CT;
   CMR_REQUIRE(per <= 64);
-  if (hipMemsetAsync(ws, 0, (size_t)cmr_fps_workspace_bytes(B, N, npoint), stream) != hipSuccess) return CMR_ELAUNCH;
+  if (hipMemsetAsync(ws, 0, (size_t)fps_words_bytes(B, npoint), stream) != hipSuccess) return CMR_ELAUNCH;
   unsigned long long* win = (unsigned long long*)ws;
   unsigned* cnt = (unsigned*)(win + (int64_t)B * npoint);
-#define FPS_COOP(P) hipLaunchKernelGGL((fps_coop_kernel<P>), dim3(B * G), dim3(FPS_CT), 0, stream, xyz4, start, win, cnt, B, G, N, npoint)
+  float* distws = (float*)((char*)ws + fps_words_bytes(B, npoint));
+#define FPS_COOP(P) \
+  hipLaunchKernelGGL((fps_coop_kernel<P>), dim3(B * G), dim3(FPS_CT), 0, stream, xyz4, start, win, cnt, B, G, N, npoint, spin_limit)
   if (per <= 4) FPS_COOP(4);
   else if (per <= 8) FPS_COOP(8);
   else if (per <= 16) FPS_COOP(16);
@@ -784,7 +848,20 @@ extern "C" int cmr_fps_ws_f32(const float* xyz4, const int64_t* start, int64_t* 
 #undef FPS_COOP
   hipLaunchKernelGGL(fps_unpack_kernel, dim3((unsigned)(((int64_t)B * npoint + 255) / 256)), dim3(256), 0, stream, (const unsigned long long*)win,
                      (const unsigned*)cnt, out, B, npoint);
+  // clouds whose workgroups did not meet are redone by ONE workgroup each (a no-op launch of B workgroups otherwise)
+  hipLaunchKernelGGL(fps_repair_kernel, dim3(B), dim3(FPS_T), 0, stream, xyz4, start, cnt, distws, out, B, N, npoint);
   return cmr_launch_status();
+}
+
+extern "C" int cmr_fps_ws_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
+                              hipStream_t stream) {
+  return fps_ws_launch(xyz4, start, out, B, N, npoint, ws, ws_bytes, FPS_SPIN, stream);
+}
+
+extern "C" int cmr_fps_ws_spin_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws,
+                                   int64_t ws_bytes, int spin_limit, hipStream_t stream) {
+  CMR_REQUIRE(spin_limit >= 0);
+  return fps_ws_launch(xyz4, start, out, B, N, npoint, ws, ws_bytes, (unsigned)spin_limit, stream);
 }
 
 extern "C" int cmr_ball_query_f32(const float* xyz4, const float* new4, int64_t* out, int B, int N, int S, int nsample,

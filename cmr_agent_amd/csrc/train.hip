@@ -496,6 +496,25 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// fused SGD with momentum over the flat bucket (torch.optim.SGD semantics, the 'SGD' branch of Train_Agent.py:111-117 /
+// Train_Geo.py:65-71: dampening 0, no Nesterov): g += wd * p; buf = g on the first step, else momentum * buf + g; p -= lr * buf.
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, int64_t n4,
+                                                  float lr, float momentum, float wd, float gscale, float clip, int first) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    f32x4 pv = ld4(p + 4 * i), gv = ld4(g + 4 * i) * gscale, bv = ld4(buf + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gr = gv[e];
+      if (clip > 0.f) gr = fminf(fmaxf(gr, -clip), clip);
+      const float gg = gr + wd * pv[e];
+      bv[e] = first ? gg : bv[e] * momentum + gg;               // buf.mul_(momentum).add_(grad)
+      pv[e] = pv[e] - lr * bv[e];
+    }
+    st4(p + 4 * i, pv);
+    st4(buf + 4 * i, bv);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Transposed shadow of the matrix parameters of a flat bucket: table row = (src offset, n, k, dst offset, first tile); one
 // workgroup per 32 x 32 tile of one matrix: dst[k][n] = src[n][k].  One launch per optimizer step instead of one per layer.
@@ -681,6 +700,15 @@ extern "C" int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_
   if (n == 0) return CMR_OK;
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, p, g, m, v, n / 4, lr, beta1, beta2, eps, weight_decay,
                      bias_correction1, sqrtf(bias_correction2), grad_scale, grad_clip);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_sgd_f32(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay,
+                           float grad_scale, float grad_clip, int first_step, hipStream_t stream) {
+  CMR_REQUIRE(p && g && buf && n >= 0 && n % 4 == 0 && cmr_aligned16(p) && cmr_aligned16(g) && cmr_aligned16(buf));
+  if (n == 0) return CMR_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n / 4)), dim3(256), 0, stream, p, g, buf, n / 4, lr, momentum, weight_decay, grad_scale,
+                     grad_clip, first_step);
   return cmr_launch_status();
 }
 

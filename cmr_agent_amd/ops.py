@@ -465,15 +465,23 @@ def weighted_gather3(src, idx, wgt):
 FPS_COOP_MIN_N = 16385      # clouds above this take the multi-workgroup kernel (one workgroup keeps <= 16 384 points in registers)
 
 
-def fps(xyz4, start, B, N, npoint, coop=None):
+def fps(xyz4, start, B, N, npoint, coop=None, spin_limit=None, status=None):
     """Farthest point sampling -> int64 [B, npoint] local indices.  coop: None = by size, True / False = force the multi- /
-    single-workgroup kernel (identical results)."""
+    single-workgroup kernel (identical results).  The multi-workgroup kernel needs the workgroups of a cloud co-resident; a cloud
+    that could not get them within the spin bound is recomputed by one workgroup inside the same call (never -1 in the result).
+    spin_limit: polls per round before giving a cloud up (None = the library's bound, 0 = give up at once: tests).  status: a list
+    that receives the int32 [B] device view of the per-cloud status words (0 cooperative, 2 repaired)."""
     out = torch.empty((B, npoint), dtype=torch.int64, device=xyz4.device)
     use = (N >= FPS_COOP_MIN_N and B <= 64) if coop is None else coop
     if use:
         nb = _lib.load().cmr_fps_workspace_bytes(B, N, npoint)
         ws = torch.empty((nb // 8 + 1,), dtype=torch.int64, device=xyz4.device)
-        _lib.call("cmr_fps_ws_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _p(ws), nb, _stream())
+        if spin_limit is None:
+            _lib.call("cmr_fps_ws_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _p(ws), nb, _stream())
+        else:
+            _lib.call("cmr_fps_ws_spin_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _p(ws), nb, int(spin_limit), _stream())
+        if status is not None:
+            status.append(ws.view(torch.int32)[2 * B * npoint + B:2 * B * npoint + 2 * B])
     else:
         _lib.call("cmr_fps_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _stream())
     return out
@@ -732,6 +740,12 @@ def agent_loss(r_logits, t_logits, value, expert_r, expert_t, act_r, act_t, old_
 def adam(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_clip=0.0):
     _lib.call("cmr_adam_f32", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
               float(weight_decay), 1.0 - beta1 ** step, 1.0 - beta2 ** step, float(grad_scale), float(grad_clip), _stream())
+
+
+def sgd(p, g, buf, lr, momentum, weight_decay, step, grad_scale=1.0, grad_clip=0.0):
+    """torch.optim.SGD(momentum, weight_decay) over the flat bucket; step counts from 1."""
+    _lib.call("cmr_sgd_f32", _p(p), _p(g), _p(buf), p.numel(), float(lr), float(momentum), float(weight_decay), float(grad_scale),
+              float(grad_clip), int(step == 1), _stream())
 
 
 def transpose_slots(src, dst, table, nslots, total_tiles):

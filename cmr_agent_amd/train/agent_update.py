@@ -16,6 +16,7 @@ import torch
 from .. import ops
 from ..models.ImageResNet import to_nhwc
 from .flatbucket import FlatBucket
+from .optim import FlatOptimizer
 
 SLOPE2D = 0.01     # nn.LeakyReLU() default in state_2d_embed and the heads (CMRAgent.py:36)
 SLOPE3D = 0.2      # ConvBNReLURes1D (PointNN.py:267)
@@ -37,17 +38,15 @@ def _pad_running(bn, cpad):
 class AgentUpdate:
     """agent: cmr_agent_amd.models.CMRAgent already on its device.  dist: torch.distributed (or None) for data parallelism."""
 
-    def __init__(self, agent, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None):
+    def __init__(self, agent, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, optimizer=None):
         self.agent, self.cfg, self.dist = agent, config, dist
         self.bucket = FlatBucket(agent)
-        n = self.bucket.numel
-        dev = self.bucket.params.device
-        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.lr = config.lr if lr is None else lr
-        self.betas, self.eps = betas, eps
-        self.weight_decay = config.weight_decay if weight_decay is None else weight_decay
-        self.t = 0
+        # Train_Agent.py:111-124: 'ADAM' (lr, betas (0.9, 0.99), weight decay) or 'SGD' (lr, config.momentum, weight decay)
+        # BatchNorm's forward in train() mode advances num_batches_tracked (a state_dict buffer): once per module and step here
+        self._nbt = list({id(m): m.num_batches_tracked for m in agent.modules()
+                          if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None}.values())
+        self.opt = FlatOptimizer(self.bucket, optimizer or getattr(config, "optimizer", "ADAM"), config.lr if lr is None else lr, betas, eps,
+                                 config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0))
         self.last_allreduce_ms = None
         f = config.embed_dim
         self.f = f
@@ -275,9 +274,7 @@ class AgentUpdate:
                 self._ar_events = (e0, e1)
             else:
                 world = self.bucket.all_reduce(self.dist)
-        self.t += 1
-        ops.adam(self.bucket.params, self.bucket.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                 self.weight_decay, self.t, grad_scale=1.0 / world)
+        self.opt.step(world)
         self.agent.invalidate()                                     # inference plans (folded BN, packed weights) are stale now
 
     def allreduce_ms(self):
@@ -290,8 +287,16 @@ class AgentUpdate:
     def step(self, batch):
         """One optimizer step on one minibatch (Train_Agent.py:263-305).  Returns the loss vector (device tensor [8])."""
         losses, _ = self.forward_backward(batch)
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
         self.optimizer_step()
         return losses
 
+    # optimizer state under the names torch.optim.Adam uses (tests, checkpoints)
+    lr = property(lambda self: self.opt.lr)
+    t = property(lambda self: self.opt.t)
+    exp_avg = property(lambda self: self.opt.exp_avg)
+    exp_avg_sq = property(lambda self: self.opt.exp_avg_sq)
+
     def set_lr(self, lr):
-        self.lr = lr
+        self.opt.lr = lr

@@ -20,6 +20,7 @@ import torch.nn as nn
 from .. import ops
 from ..models.PointViT import PointGeometry
 from .flatbucket import FlatBucket
+from .optim import FlatOptimizer
 from .tape import Tape, Var
 
 f32 = torch.float32
@@ -30,18 +31,17 @@ LOSS_KEYS = ("loss", "pc_overlap_loss", "img_overlap_loss", "geometric_loss", "p
 
 class GeoUpdate:
     def __init__(self, model, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, grad_clip=1.0, dropout=True,
-                 dropout_seed=None):
+                 dropout_seed=None, optimizer=None):
         self.model, self.cfg, self.dist = model, config, dist
         self.bucket = FlatBucket(model)
-        n = self.bucket.numel
         dev = self.bucket.params.device
-        self.exp_avg = torch.zeros(n, dtype=f32, device=dev)
-        self.exp_avg_sq = torch.zeros(n, dtype=f32, device=dev)
-        self.lr = config.lr if lr is None else lr
-        self.betas, self.eps = betas, eps
-        self.weight_decay = config.weight_decay if weight_decay is None else weight_decay
+        # Train_Geo.py:65-78: 'ADAM' (lr, betas (0.9, 0.99), weight decay) or 'SGD' (lr, config.momentum, weight decay)
+        # BatchNorm's forward in train() mode advances num_batches_tracked (a state_dict buffer): once per module and step here
+        self._nbt = list({id(m): m.num_batches_tracked for m in model.modules()
+                          if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None}.values())
+        self.opt = FlatOptimizer(self.bucket, optimizer or getattr(config, "optimizer", "ADAM"), config.lr if lr is None else lr, betas, eps,
+                                 config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0))
         self.grad_clip = grad_clip
-        self.t = 0
         self._pos2d = {}
         self._pos1d = {}
         self._graph = None
@@ -294,11 +294,24 @@ class GeoUpdate:
     def optimizer_step(self):
         world = 1
         if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
-            world = self.bucket.all_reduce(self.dist)
-        self.t += 1
-        ops.adam(self.bucket.params, self.bucket.grads, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps,
-                 self.weight_decay, self.t, grad_scale=1.0 / world, grad_clip=self.grad_clip)
+            if self.bucket.grads.device.type == "cuda":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                world = self.bucket.all_reduce(self.dist)
+                e1.record()
+                self._ar_events = (e0, e1)
+            else:
+                world = self.bucket.all_reduce(self.dist)
+        self.opt.step(world, grad_clip=self.grad_clip)
         self.model.invalidate()
+
+    def allreduce_ms(self):
+        """HIP-event time of the last step's gradient all-reduce (0 on one rank)."""
+        ev = getattr(self, "_ar_events", None)
+        if ev is None:
+            return 0.0
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1])
 
     GRAPH_KEYS = ("img", "pc", "node", "pt2node", "pc_mask", "img_mask", "pc_idx_for_circle_loss", "pc_xy_int_for_circle_loss",
                   "pc_xy_float_for_circle_loss")
@@ -340,8 +353,15 @@ class GeoUpdate:
             losses = self._static_losses
         else:
             losses = self.forward_backward(data)
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)
         self.optimizer_step()
         return losses
 
+    lr = property(lambda self: self.opt.lr)
+    t = property(lambda self: self.opt.t)
+    exp_avg = property(lambda self: self.opt.exp_avg)
+    exp_avg_sq = property(lambda self: self.opt.exp_avg_sq)
+
     def set_lr(self, lr):
-        self.lr = lr
+        self.opt.lr = lr

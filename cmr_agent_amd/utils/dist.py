@@ -14,6 +14,7 @@ class Ranks:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = device
+        self.backend = backend or "nccl"
         if self.world > 1:
             import torch.distributed as dist
             if not dist.is_initialized():
@@ -22,6 +23,26 @@ class Ranks:
                     kw["device_id"] = device
                 dist.init_process_group(backend or "nccl", **kw)
             self.dist = dist
+
+    @staticmethod
+    def local_device(share_gpu=False):
+        """The HIP device of this rank: its LOCAL_RANK, or device 0 for every rank under --share-gpu (rehearsal of the N > 1
+        protocol on a one-GPU box; needs the gloo backend, RCCL refuses two ranks on one device)."""
+        idx = 0 if share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(idx)
+        return torch.device("cuda", idx)
+
+    def collective_ranks(self):
+        """World size as seen by a REAL collective on device memory: all-reduce (sum) of one float 1.0 per rank.  bench.py
+        reports it as `rccl_ranks` under the nccl backend -- evidence that RCCL executed, not an environment variable."""
+        if self.dist is None:
+            return 1
+        t = torch.ones(1, dtype=torch.float32, device=self.device if self.device is not None else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        n = int(round(float(t.item())))
+        if n != self.world:
+            raise RuntimeError("collective over %d ranks summed to %d" % (self.world, n))
+        return n
 
     def shard_seed(self, base):
         """Every rank draws different pairs: the reference seed (KittiConfig.py:30) + rank."""

@@ -124,7 +124,17 @@ WORK = {
     "cmr_argmax_rows_f32": lambda a: (0, a["outer"] * a["inner"] * (F * a["n"] + 8)),
     "cmr_softmax2_f32": lambda a: (0, a["rows"] * 14),
     "cmr_l2norm64_f32": lambda a: (0, a["rows"] * 512),
+    # training direction (Train_Agent.py:296-305, Train_Geo.py:166-174): weight gradients as GEMMs over the minibatch's pixels / rows
+    "cmr_conv3x3_wgrad_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
+                                        F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
+    "cmr_linear_wgrad_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (a["n"] + a["k"]) + a["n"] * a["k"])),
+    "cmr_adam_f32": lambda a: (0, 28 * a["n"]),
 }
+
+# Multiplies the kernel ISSUES on the matrix cores per algorithmic multiply: F(2x2,3x3) Winograd computes 2x2 outputs with 16
+# products instead of 36.  `roofline.frac` prices the dominant kernel on issued work (<= 1 by construction); the algorithmic
+# figure stays beside it as frac_algorithmic.
+ISSUED = {"cmr_conv3x3_wino_nhwc_f32": 16.0 / 36.0}
 
 
 def work(name, args, extra=None):
@@ -177,15 +187,19 @@ class CallTimer:
         agg = {}
         for name, e0, e1, fl, by in self.records:
             ms = e0.elapsed_time(e1)
-            d = agg.setdefault(name, dict(name=name, calls=0, ms=0.0, flops=0.0, bytes=0.0, ideal_ms=0.0, modelled=fl is not None))
+            d = agg.setdefault(name, dict(name=name, calls=0, ms=0.0, flops=0.0, bytes=0.0, ideal_ms=0.0, issued_flops=0.0,
+                                          ideal_issued_ms=0.0, modelled=fl is not None))
             d["calls"] += 1
             d["ms"] += ms
             if fl is not None:
                 d["flops"] += fl
                 d["bytes"] += by
                 d["ideal_ms"] += 1e3 * ideal_seconds(fl, by)
+                d["issued_flops"] += fl * ISSUED.get(name, 1.0)
+                d["ideal_issued_ms"] += 1e3 * ideal_seconds(fl * ISSUED.get(name, 1.0), by)
         rows = sorted(agg.values(), key=lambda d: -d["ms"])
         for d in rows:
             d["bound"] = "mfma" if d["bytes"] and d["flops"] / d["bytes"] > RIDGE else "hbm"
-            d["frac"] = d["ideal_ms"] / d["ms"] if d["ms"] > 0 else 0.0
+            d["frac"] = d["ideal_issued_ms"] / d["ms"] if d["ms"] > 0 else 0.0
+            d["frac_algorithmic"] = d["ideal_ms"] / d["ms"] if d["ms"] > 0 else 0.0
         return rows

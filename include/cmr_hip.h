@@ -289,14 +289,22 @@ int cmr_segment_reduce_f32(const float* src, int64_t lds, const int32_t* order, 
 int cmr_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo, int64_t rows, int C,
                         hipStream_t stream);
 
-/* pointnet_util.py:50-70 (start index explicit), :73-93, :19-33. */
+/* pointnet_util.py:50-70 (start index explicit), :73-93, :19-33.  start[b] outside [0, N) is forced into the cloud (the
+ * reference raises IndexError at xyz[batch_indices, farthest]; a kernel cannot, and must not read outside the cloud). */
 int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, hipStream_t stream);
 /* The same sampling with several workgroups per cloud (slices in registers, one 64-bit atomic max + an arrival counter per
  * round; bit-identical indices): for clouds above 16 384 points (BASELINE configs[4]: 65 536), B * groups <= 256.  ws = scratch of
- * cmr_fps_workspace_bytes.  A cloud whose workgroups could not all become resident gets -1 in every slot (bounded waits). */
+ * cmr_fps_workspace_bytes.  The waits between the workgroups of a cloud are bounded; a cloud whose workgroups could not all
+ * become resident in time (CU-filling kernels of another stream) is recomputed by ONE workgroup in the same call (repair
+ * launch behind the cooperative one; no host round trip, capturable), so `out` always holds the reference's indices.  After
+ * the call the int32 word at ws + B*npoint*8 + 4*(B + b) is 0 (cloud b sampled cooperatively) or 2 (repaired). */
 int64_t cmr_fps_workspace_bytes(int B, int N, int npoint);
 int cmr_fps_ws_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
                    hipStream_t stream);
+/* The same call with the spin bound as an argument (polls per round before a workgroup gives its cloud up; 0 = give up at once):
+ * lets a caller trade waiting for the repair pass, and lets the tests drive the repair path on purpose. */
+int cmr_fps_ws_spin_f32(const float* xyz4, const int64_t* start, int64_t* out, int B, int N, int npoint, void* ws, int64_t ws_bytes,
+                        int spin_limit, hipStream_t stream);
 int cmr_ball_query_f32(const float* xyz4, const float* new4, int64_t* out, int B, int N, int S, int nsample,
                        float radius2, hipStream_t stream);
 int cmr_square_distance_f32(const float* a4, const float* b4, float* out, int B, int N, int M, hipStream_t stream);
@@ -401,6 +409,11 @@ int cmr_agent_loss_f32(const float* r_logits, int64_t ldr, const float* t_logits
 int cmr_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, float bias_correction1, float bias_correction2, float grad_scale, float grad_clip,
                  hipStream_t stream);
+/* torch.optim.SGD step (the 'SGD' branch of Train_Agent.py:111-117 / Train_Geo.py:65-71: momentum, L2 weight decay, dampening 0,
+ * no Nesterov) over the flat parameter bucket: g <- grad_scale * g (clamped when grad_clip > 0) + wd * p; buf = g on the first
+ * step, momentum * buf + g afterwards; p -= lr * buf.  n % 4 == 0. */
+int cmr_sgd_f32(float* p, const float* g, float* buf, int64_t n, float lr, float momentum, float weight_decay, float grad_scale,
+                float grad_clip, int first_step, hipStream_t stream);
 /* Transposed shadow of the matrix parameters of a flat bucket (operands of the data-gradient GEMMs): table [nslots][5] int64 =
  * (src offset, n, k, dst offset, first tile index), tiles of 32 x 32; dst[k][n] = src[n][k] for every slot, one launch. */
 int cmr_transpose_slots_f32(const float* src, float* dst, const int64_t* table, int nslots, int64_t total_tiles,

@@ -393,6 +393,53 @@ def test_fps_kernels_agree_at_65536_points_with_duplicates(ops):
     assert int(b.min()) >= 0 and torch.equal(a, b)
 
 
+def test_fps_repairs_clouds_whose_workgroups_could_not_meet(ops):
+    """The multi-workgroup kernel gives a cloud up when its workgroups do not all arrive within the spin bound; the repair launch of
+    the same call must then produce the reference's indices (never -1).  spin_limit = 0 forces every cloud down that path."""
+    B, N, npoint = 2, 20000, 128
+    xyz = _cloud(B, N, 50).permute(0, 2, 1).contiguous()
+    start = torch.tensor([3, 77])
+    ref = O.farthest_point_sample(xyz, npoint, start)
+    x4 = ops.planar_to_rows4(xyz.permute(0, 2, 1).contiguous().to(DEV))
+    st = []
+    got = ops.fps(x4, start.to(DEV), B, N, npoint, coop=True, spin_limit=0, status=st)
+    assert st[0].cpu().tolist() == [2, 2]                       # both clouds were repaired
+    assert torch.equal(got.cpu(), ref)
+    st = []
+    got = ops.fps(x4, start.to(DEV), B, N, npoint, coop=True, status=st)
+    assert st[0].cpu().tolist() == [0, 0] and torch.equal(got.cpu(), ref)
+    # a start index outside the cloud is forced into it (the reference raises IndexError; a kernel must not read out of range)
+    bad = torch.tensor([-5, N + 9]).to(DEV)
+    for coop in (False, True):
+        got = ops.fps(x4, bad, B, N, npoint, coop=coop)
+        want = O.farthest_point_sample(xyz, npoint, torch.tensor([0, N - 1]))
+        assert torch.equal(got.cpu(), want)
+
+
+def test_fps_multi_workgroup_under_a_cu_filling_kernel_on_another_stream(ops):
+    """The product keeps persistent, CU-filling convolutions on other streams (fork_join towers) while the point tower samples: the
+    cooperative FPS must return the reference's indices with such a kernel in flight."""
+    from cmr_agent_amd.models._pack import winograd_u
+    B, N, npoint = 8, 65536, 200
+    xyz = _cloud(B, N, 53)
+    x4 = ops.planar_to_rows4(xyz.contiguous().to(DEV))
+    start = torch.arange(B).to(DEV)
+    want = ops.fps(x4, start, B, N, npoint, coop=False)
+    xg = (torch.rand(8, 352, 1216, 64, generator=torch.Generator().manual_seed(5)) - 0.5).to(DEV)
+    u = winograd_u((torch.rand(64, 64, 3, 3, generator=torch.Generator().manual_seed(6)) - 0.5).to(DEV))
+    bias = torch.zeros(64, device=DEV)
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(6):                                      # ~7 ms of persistent workgroups holding every CU
+            ops.conv3x3_wino(xg, u, bias, 64, 0.2)
+    st = []
+    got = ops.fps(x4, start, B, N, npoint, coop=True, status=st)
+    torch.cuda.synchronize()
+    assert int(got.min()) >= 0 and torch.equal(got, want)
+    assert all(v in (0, 2) for v in st[0].cpu().tolist())
+
+
 def test_ball_query_matches_pointnet_util(ops):
     B, N, S = 2, 3000, 128
     xyz = _cloud(B, N, 51).permute(0, 2, 1).contiguous()

@@ -224,6 +224,57 @@ def test_fused_adam_matches_torch(ops):
     assert float((p.cpu() - ref.data).abs().max()) < 2e-7
 
 
+def test_fused_sgd_matches_torch(ops):
+    """the 'SGD' branch of Train_Agent.py:111-117: momentum config.momentum (0.98), L2 weight decay; 4 summed ranks scaled back."""
+    n = 4096 + 8
+    p0, grads = rnd(n, seed=71), [rnd(n, seed=72 + i) * (10.0 ** (i - 1)) for i in range(4)]
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.SGD([ref], lr=1e-3, momentum=0.98, weight_decay=1e-6)
+    p, buf = p0.to(DEV), torch.full((n,), 7.0, device=DEV)             # garbage in the buffer: the first step must overwrite it
+    for i, g in enumerate(grads):
+        ref.grad = g.clone()
+        opt.step()
+        ops.sgd(p, (g * 4).to(DEV), buf, 1e-3, 0.98, 1e-6, i + 1, grad_scale=0.25)
+    assert float((p.cpu() - ref.data).abs().max()) < 2e-7
+    assert float((buf.cpu() - opt.state[ref]["momentum_buffer"]).abs().max()) < 1e-5 * float(opt.state[ref]["momentum_buffer"].abs().max())
+
+
+def test_agent_update_sgd_branch_and_batch_counters():
+    """AgentUpdate(optimizer='SGD') == torch.optim.SGD on the oracle's gradients; num_batches_tracked advances once per step."""
+    from cmr_agent_amd.train import AgentUpdate
+    case = "agent_train_small"
+    cfg_d, cfg_c = C.train_config(case, device=DEV), C.train_config(case)
+    batches = C.train_inputs(case)
+    sd0 = {k: v for k, v in hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG).items() if not k.endswith("num_batches_tracked")}
+    agent = _product_agent(cfg_d)
+    up = AgentUpdate(agent, cfg_d, optimizer="SGD")
+    assert up.opt.kind == "SGD" and up.opt.momentum == cfg_d.momentum
+    for b in batches:
+        up.step(_to_dev(b))
+    torch.cuda.synchronize()
+    sd = {k: v.detach().clone() for k, v in sd0.items()}
+    params = {k: torch.nn.Parameter(sd[k]) for k in sd if TO.is_parameter(k)}
+    opt = torch.optim.SGD(list(params.values()), lr=cfg_c.lr, momentum=cfg_c.momentum, weight_decay=cfg_c.weight_decay)
+    for b in batches:
+        cur = dict(sd)
+        cur.update({k: p.data for k, p in params.items()})
+        _, grads, _ = TO.agent_forward_backward(cur, b, cfg_c, True)
+        for k in sd:
+            if not TO.is_parameter(k):
+                sd[k] = cur[k]
+        for k, p in params.items():
+            p.grad = grads[k].clone()
+        opt.step()
+    got = agent.state_dict()
+    upd = max(float((p.data - sd0[k]).abs().max()) for k, p in params.items())      # largest parameter movement of the run
+    assert upd > 0
+    for k, p in params.items():
+        d = float((got[k].cpu() - p.data).abs().max())
+        assert d <= 1e-7 + 2e-3 * upd, (k, d, upd)                      # gradient-level agreement (2e-4 of the model's max), accumulated
+    nbt = [v for k, v in got.items() if k.endswith("num_batches_tracked")]
+    assert nbt and all(int(v) == len(batches) for v in nbt)
+
+
 def test_flat_bucket_keeps_module_api():
     from cmr_agent_amd.models import CMRAgent
     from cmr_agent_amd.train import FlatBucket
