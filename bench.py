@@ -167,31 +167,42 @@ def _median_timed(fn, passes, budget_s):
     return sorted(times)[len(times) // 2], times
 
 
-def train_roofline(table, steps, dom_names, dom_label, peak_mfma=FP32_MFMA_PEAK_TFLOPS):
-    """roofline object of a training step from a CallTimer table: the dominant kernel family (by measured time among `dom_names`)
-    on ISSUED work (Winograd launches priced at 16/36 of their algorithmic multiplies), and the whole path = sum of ideal times /
-    sum of measured times over every modelled C-ABI call of the step."""
-    doms = [d for d in table if d["name"] in dom_names]
-    ms, calls = sum(d["ms"] for d in doms), sum(d["calls"] for d in doms)
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md); ridge 2500 / 8 = 312 FLOP/B
+
+
+def train_roofline(table, steps, families):
+    """roofline object of a training step from a CallTimer table.  families: [(label, entry-point names, matrix peak in TFLOP/s)];
+    the DOMINANT one is the family with the largest summed HIP-event time, priced on ISSUED work (Winograd launches at 16/36 of
+    their algorithmic multiplies) against its own roof: matrix peak when its FLOP/B exceeds the ridge of that peak, else 8 TB/s on
+    its algorithmic bytes.  `path` = sum of ideal times / sum of measured times over every modelled C-ABI call of the step."""
+    fams = []
+    for label, names, peak in families:
+        doms = [d for d in table if d["name"] in names]
+        if doms:
+            fams.append((sum(d["ms"] for d in doms), label, doms, peak))
+    ms, label, doms, peak = max(fams)
+    calls = sum(d["calls"] for d in doms)
     fl, fli, by = sum(d["flops"] for d in doms), sum(d["issued_flops"] for d in doms), sum(d["bytes"] for d in doms)
     mod = [d for d in table if d["modelled"]]
     allms = sum(d["ms"] for d in table)
-    out = dict(kernel=dom_label, launches_per_step=calls / steps, avg_launch_us=1e3 * ms / max(calls, 1),
+    out = dict(kernel=label, launches_per_step=calls / steps, avg_launch_us=1e3 * ms / max(calls, 1),
                dominant_ms_per_step=ms / steps, kernel_ms_per_step=allms / steps,
                path=sum(d["ideal_issued_ms"] for d in mod) / max(sum(d["ms"] for d in mod), 1e-9),
+               path_note="ideal times priced at the fp32 MFMA peak / 8 TB/s (utils/workmodel.py), Winograd at the 16/36 it issues",
                path_modelled_share_of_kernel_time=sum(d["ms"] for d in mod) / max(allms, 1e-9),
+               families_ms_per_step={lab: round(m / steps, 4) for m, lab, _, _ in fams},
                kernels=[dict(entry=d["name"], bound=d["bound"] if d["modelled"] else None, calls_per_step=d["calls"] / steps,
                              ms_per_step=round(d["ms"] / steps, 4), frac=round(d["frac"], 3) if d["modelled"] else None)
                         for d in table[:10]], traffic=None,
                timed_in="separate eager pass of %d step(s), HIP events around every C-ABI call on its own stream" % steps)
-    if by and fl / by > 19.7:
+    if by and fl / by > peak * 1e12 / 8e12:
         ach = fli / (ms * 1e-3) / 1e12
-        out.update(bound="mfma", achieved=ach, peak=peak_mfma, unit="TFLOP/s", frac=ach / peak_mfma,
-                   frac_algorithmic=fl / (ms * 1e-3) / 1e12 / peak_mfma, algorithmic_gflop_per_launch=fl / max(calls, 1) / 1e9)
+        out.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak,
+                   frac_algorithmic=fl / (ms * 1e-3) / 1e12 / peak, algorithmic_gflop_per_launch=fl / max(calls, 1) / 1e9)
     else:
         ach = by / (ms * 1e-3) / 1e9
         out.update(bound="hbm", achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
-                   algorithmic_bytes_per_launch=by / max(calls, 1))
+                   algorithmic_bytes_per_launch=by / max(calls, 1), flop_per_byte=fl / by if by else 0.0)
     return out
 
 
@@ -273,8 +284,12 @@ def train_main(args, ctx=None, with_cpu=False):
         # (no data gradient for the first one) and of the 1x1 stacks of the 3-D branch
         conv_f = sum(2.0 * 9 * 128 * 128 * MB * (h >> s) * (wd >> s) * 2 for s in range(4))
         flops = conv_f * 3 - 2.0 * 9 * 128 * 128 * MB * h * wd
-        conv_names = ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wgrad_f32", "cmr_conv3x3_nhwc_f32", "cmr_conv3x3_bf16_nhwc_f32",
-                      "cmr_conv3x3_bf16io_nhwc")
+        families = [("conv3x3_wino_ws_kernel: forward + data-gradient 3x3 convolutions (Winograd F(2x2,3x3), fp32 MFMA)",
+                     ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_nhwc_f32"), FP32_MFMA_PEAK_TFLOPS),
+                    ("conv3x3_wgrad_kernel: 3x3 weight gradients as a GEMM over the minibatch's pixels (fp32 MFMA)",
+                     ("cmr_conv3x3_wgrad_f32",), FP32_MFMA_PEAK_TFLOPS),
+                    ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
+                     ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc"), BF16_MFMA_PEAK_TFLOPS)]
         line = {
             "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
             "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
@@ -287,8 +302,7 @@ def train_main(args, ctx=None, with_cpu=False):
             "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
             "gradient_bucket_sum_min_max_over_ranks": sums, "gradient_buckets_identical": sums[0] == sums[-1],
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
-            "roofline": train_roofline(ct.table(), 1, conv_names, "3x3 convolutions of the update: forward + data gradient (Winograd "
-                                       "conv3x3_wino_ws_kernel) and weight gradient (conv3x3_wgrad_kernel), fp32 MFMA"),
+            "roofline": train_roofline(ct.table(), 1, families),
             "loss": float(losses[0]), **info}
         if with_cpu and world == 1:
             line["cpu_baseline"] = agent_update_cpu_baseline(spec, w, MB)
@@ -366,7 +380,8 @@ def geo_train_main(args, ctx=None, with_cpu=False):
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
             "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
             "launches_per_step": sum(d["calls"] for d in table),
-            "roofline": train_roofline(table, 1, (dom["name"],), "%s (the entry point with the largest summed time of the step)" % dom["name"]),
+            "roofline": train_roofline(table, 1, [("%s (the entry point with the largest summed time of the step)" % dom["name"],
+                                                   (dom["name"],), FP32_MFMA_PEAK_TFLOPS)]),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
             "loss": loss, **info}
         if with_cpu and world == 1:
@@ -428,7 +443,8 @@ def compact(line):
     out = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in line}
     out["workload"] = line["config"]["workload"]
     out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "path", "traffic",
-                                         "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step") if k in r}
+                                         "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
+                                         "families_ms_per_step", "flop_per_byte") if k in r}
     for k in ("cpu_baseline", "launches_per_step", "launch_mode"):
         if k in line:
             out[k] = line[k]

@@ -106,13 +106,19 @@ __device__ __forceinline__ int cmr_mfma_row(int r, int lane) { return (r & 3) + 
 
 // Dropout mask, counter based (no state, no stored mask): element `idx` of dropout site `site` in the step whose seed is `seed` is KEPT
 // iff the low 32 bits of a 64-bit mix (murmur3 finaliser) of the three reach thr = p * 2^32.  Forward and backward call it with the same
-// arguments, so the backward pass regenerates the forward mask.
-__device__ __forceinline__ bool cmr_keep(uint64_t seed, uint64_t site, uint64_t idx, uint32_t thr) {
-  uint64_t x = (idx + site * 0x9E3779B97F4A7C15ull) ^ seed;
+// arguments, so the backward pass regenerates the forward mask.  (seed, site) go through the finaliser FIRST and the element index is
+// mixed into that key: with `(idx + site * G) ^ seed` in one mix, the mask of seed s + 1 was the mask of seed s with neighbouring
+// elements swapped ((A ^ (s + 1)) == ((A ^ 1) ^ s) for even s), i.e. consecutive steps -- and ranks, whose seeds differ by a constant --
+// dropped almost the same pattern.  The key is wave-uniform, so the second mix is the only per-element cost.
+__device__ __forceinline__ uint64_t cmr_mix64(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
   x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
   x ^= x >> 33;
-  return (uint32_t)x >= thr;
+  return x;
+}
+__device__ __forceinline__ bool cmr_keep(uint64_t seed, uint64_t site, uint64_t idx, uint32_t thr) {
+  const uint64_t key = cmr_mix64(seed + site * 0x9E3779B97F4A7C15ull);
+  return (uint32_t)cmr_mix64(key ^ idx) >= thr;
 }
 static inline uint32_t cmr_drop_threshold(float p) {
   const double t = (double)p * 4294967296.0;

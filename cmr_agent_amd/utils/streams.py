@@ -20,24 +20,19 @@ _pool = {}
 _depth = 0
 
 
-def _side_stream(device, depth, i):
-    """One stream per (nesting depth, branch index).  Round 1 keyed the pool by the branch index alone, so a fork issued
-    from inside branch 0 of another fork was handed the very stream it was already running on as its "side" stream:
-    `side.wait_stream(main)` then recorded an event on that stream and made the same stream wait for it, and both
-    branches ran on one stream.  Under hipGraph capture that self-dependency is what failed (it had been blamed on
-    ROCm 7.2 and papered over by refusing nested forks).  With the depth in the key a nested fork can never receive the
-    stream it runs on, and nested forks run concurrently in eager mode.
+def _side_stream(parent, i):
+    """One stream per (stream the fork is issued on, branch index).  Round 1 keyed the pool by the branch index alone, so a fork
+    issued from inside branch 0 of another fork was handed the very stream it was running on (a self-dependency that failed under
+    capture); round 2 keyed it by (depth, index), which still gave the inner forks of two DIFFERENT outer branches the same side
+    stream (false serialisation between siblings, and under capture two unrelated branches joined through one stream).  Keyed by
+    the parent stream, a side stream is only ever shared by successive forks issued from the same stream, which are ordered anyway.
 
-    Under hipGraph capture a nested fork still fails on ROCm 7.2 -- with distinct streams at every depth and every side
-    stream joined back before the capture ends, hipStreamEndCapture itself dies with SIGSEGV (python frame:
-    torch/cuda/graphs.py capture_end <- CUDAGraph.__exit__; reproduced in round 2 by
-    tests/test_ops_gpu.py::test_nested_fork_join before the guard below went back in; the eager run of the same nested
-    pattern was correct).  That is a runtime defect, not an ordering bug of fork_join, so while a capture is in progress
-    an inner fork runs its branches sequentially on the stream it is on (flat n-way forks capture fine and are what the
-    models use)."""
-    key = (device, depth, i)
+    Under hipGraph capture a nested fork still runs its branches sequentially (guard in fork_join): with round 2's pool,
+    hipStreamEndCapture died with SIGSEGV on a nested fork (gpurun_out/r02_t2.log).  tools/nested_capture_min.py is the torch-only
+    reproduction of that pattern; DESIGN.md section 6b records what it does on this ROCm / torch build."""
+    key = (parent.device, parent.cuda_stream, i)
     if key not in _pool:
-        _pool[key] = torch.cuda.Stream(device=device)
+        _pool[key] = torch.cuda.Stream(device=parent.device)
     return _pool[key]
 
 
@@ -55,7 +50,7 @@ def fork_join(*fns, tag=""):
     if _depth > 0 and torch.cuda.is_current_stream_capturing():
         return tuple(f() for f in fns)
     main = torch.cuda.current_stream()
-    sides = [_side_stream(main.device, _depth, i) for i in range(len(fns) - 1)]
+    sides = [_side_stream(main, i) for i in range(len(fns) - 1)]
     if any(s == main for s in sides):
         raise RuntimeError("fork_join: a side stream equals the current stream (called from a foreign stream pool?)")
     for s in sides:

@@ -40,6 +40,15 @@ def test_dropout_mask_statistics_scaling_and_determinism():
         assert not torch.equal(y, ops.dropout(x, p, _seed(8), 3))                     # other step
         both = (ops.dropout(x, p, _seed(8), 3) != 0) & kept
         assert abs(float(both.float().mean()) - (1 - p) ** 2) < 6e-3                   # independent across seeds
+    # consecutive steps (GeoUpdate advances the seed by 1 per step) and ranks (seed + 7919 * rank) are not shifted / permuted copies of
+    # one another: under any shift of -2 .. +2 elements the masks agree on about (1 - p)^2 + p^2 of the elements, like independent draws
+    p = 0.3
+    flat = lambda s_: (ops.dropout(x, p, _seed(s_), 3) != 0).reshape(-1)
+    for s0, s1 in ((100, 101), (101, 102), (7, 7 + 7919), (2 ** 20, 2 ** 20 + 1)):
+        a, b = flat(s0), flat(s1)
+        for sh in (-2, -1, 0, 1, 2):
+            agree = float((a[2:-2] == b[2 + sh:b.numel() - 2 + sh]).float().mean())
+            assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 6e-3, (s0, s1, sh, agree)
     assert torch.equal(ops.dropout(x, 0.0, _seed(1), 0), x)
     # strided rows, in place, and the backward pass = the same call on the gradient
     big = torch.randn(300, 128, device=DEV)
