@@ -12,13 +12,14 @@ namespace {
 constexpr int AH_THREADS = 1024, AH_WAVES = AH_THREADS / 64;
 constexpr int AH_C = 128, AH_STATE = 256, AH_MAXW = 256;      // 2-D channels, state width, widest hidden layer
 
-struct AhHead { const float *w0, *b0, *w1, *b1, *w2, *b2; int n0, n1, n2; float* out; int ldo; };
+struct AhHead { const float *w0, *b0, *w1, *b1, *w2, *b2; int n0, n1, n2; float* out; int ldo; int64_t* act; int degree; };
 struct AhArgs {
   const float* x; int npix;              // [B][npix][128] last feature map (already activated)
   const float *w24, *b24, *w26, *b26;    // conv1x1 128 -> 128 (LeakyReLU), conv1x1 128 -> 128
   const float* e3d;                      // [B][128]
   AhHead h[3];
   float slope;
+  int num_steps;                         // > 0: heads 0 / 1 also emit argmax over each group of num_steps logits (CMRAgent.py:118-123)
 };
 
 // y[n] = act(b[n] + sum_k W[n][k] x[k]) for the outputs n = wave, wave + 16, ...; x in LDS, k % 4 == 0, k <= 256.
@@ -106,6 +107,22 @@ __global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a)
   ah_gemv(hd.w1, hd.b1, h0[0], hd.n0, hd.n1, h1[0], true, a.slope, wave, lane);
   __syncthreads();
   ah_gemv(hd.w2, hd.b2, h1[0], hd.n1, hd.n2, hd.out + (int64_t)b * hd.ldo, false, a.slope, wave, lane);
+  // deterministic action of this head: argmax of Categorical(logits).probs = argmax of the logits, first maximum on ties (what
+  // cmr_argmax_rows_f32 returns for the same rows) -- saves the two argmax launches of every agent step
+  if (hd.act != nullptr && a.num_steps > 0) {
+    __syncthreads();                                          // the logits above were written by lane 0 of several waves
+    const int d = hd.degree;
+    if (tid < d) {
+      const float* p = hd.out + (int64_t)b * hd.ldo + tid * a.num_steps;
+      float best = p[0];
+      int bi = 0;
+      for (int i = 1; i < a.num_steps; ++i) {
+        const float v = p[i];
+        if (v > best) { best = v; bi = i; }
+      }
+      hd.act[(int64_t)b * d + tid] = bi;
+    }
+  }
 }
 
 }  // namespace
@@ -118,14 +135,18 @@ extern "C" int cmr_agent_heads_f32(const float* x, int B, int npix, const float*
                                    int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
                                    const float* v_w0, const float* v_b0, const float* v_w1, const float* v_b1, const float* v_w2, const float* v_b2,
                                    int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                                   int num_steps, int degree_r, int degree_t, int64_t* r_act, int64_t* t_act,
                                    float slope, hipStream_t stream) {
   CMR_REQUIRE(x && w24 && b24 && w26 && b26 && e3d && B > 0 && npix > 0);
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w24) && cmr_aligned16(w26));
   AhArgs a{};
   a.x = x; a.npix = npix; a.w24 = w24; a.b24 = b24; a.w26 = w26; a.b26 = b26; a.e3d = e3d; a.slope = slope;
-  a.h[0] = AhHead{r_w0, r_b0, r_w1, r_b1, r_w2, r_b2, r_n0, r_n1, r_n2, r_out, r_ldo};
-  a.h[1] = AhHead{t_w0, t_b0, t_w1, t_b1, t_w2, t_b2, t_n0, t_n1, t_n2, t_out, t_ldo};
-  a.h[2] = AhHead{v_w0, v_b0, v_w1, v_b1, v_w2, v_b2, v_n0, v_n1, v_n2, v_out, v_ldo};
+  // actions (optional): the logical widths degree * num_steps must fit the (padded) head widths
+  CMR_REQUIRE((!r_act && !t_act) || (num_steps > 0 && degree_r > 0 && degree_t > 0 && degree_r * num_steps <= r_n2 && degree_t * num_steps <= t_n2));
+  a.num_steps = (r_act || t_act) ? num_steps : 0;
+  a.h[0] = AhHead{r_w0, r_b0, r_w1, r_b1, r_w2, r_b2, r_n0, r_n1, r_n2, r_out, r_ldo, r_act, degree_r};
+  a.h[1] = AhHead{t_w0, t_b0, t_w1, t_b1, t_w2, t_b2, t_n0, t_n1, t_n2, t_out, t_ldo, t_act, degree_t};
+  a.h[2] = AhHead{v_w0, v_b0, v_w1, v_b1, v_w2, v_b2, v_n0, v_n1, v_n2, v_out, v_ldo, nullptr, 0};
   for (int i = 0; i < 3; ++i) {
     const AhHead& h = a.h[i];
     CMR_REQUIRE(h.w0 && h.w1 && h.w2 && h.b0 && h.b1 && h.b2 && h.out && h.n2 > 0 && h.ldo >= h.n2);

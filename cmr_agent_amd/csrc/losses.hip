@@ -42,12 +42,18 @@ __global__ __launch_bounds__(256) void focal_partial_kernel(const float* __restr
   if (threadIdx.x < 5) part[blockIdx.x * 5 + threadIdx.x] = red[threadIdx.x][0];
 }
 
-// out = {loss, precision, recall, accuracy}
-__global__ void focal_final_kernel(const float* __restrict__ part, int nwg, int64_t rows, int B, float* __restrict__ out) {
-  if (threadIdx.x != 0) return;
+// out = {loss, precision, recall, accuracy}.  One wave: lane l sums partials l, l + 64, ... in ascending order, then a fixed xor-shuffle
+// tree over the 64 lanes (deterministic; a single thread walking all partials took 50 us at 512 workgroups).
+__global__ __launch_bounds__(64) void focal_final_kernel(const float* __restrict__ part, int nwg, int64_t rows, int B, float* __restrict__ out) {
   float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int i = 0; i < nwg; ++i)
+  for (int i = threadIdx.x; i < nwg; i += 64)
+#pragma unroll
     for (int k = 0; k < 5; ++k) s[k] += part[i * 5 + k];
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) s[k] += __shfl_xor(s[k], m);
+  if (threadIdx.x != 0) return;
   out[0] = s[0] / (float)rows;
   out[1] = s[1] / s[2];                                // (label[pred == 1]).sum() / pred.sum()   (NaN when nothing is predicted)
   out[2] = s[1] / s[3];                                // (pred[label == 1]).sum() / label.sum()

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void ln64_linear_kernel(const LnLinArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  const uint32_t gt = blockIdx.x * 4 + wave;
+  const uint32_t gt = blockIdx.x * (blockDim.x >> 6) + wave;       // one tile per wave; 1 or 4 waves per workgroup
   if (gt >= a.tiles) return;
   const LnLinProblem& P = gt < a.tiles0 ? a.p[0] : a.p[1];
   const uint32_t tile = gt < a.tiles0 ? gt : gt - a.tiles0;
@@ -213,6 +213,142 @@ __global__ __launch_bounds__(512) void vit_out_ffn_kernel(const OutFfnArgs a) {
   }
 }
 
+
+// ---- the same out-projection + MLP on 16-ROW tiles (v_mfma_f32_16x16x4_f32) -------------------------------------------------------
+// vit_out_ffn_kernel gives a 32-row tile to one workgroup: B*T = 3 344 image proxies are 105 workgroups (2 048 point proxies: 64) and
+// each SIMD holds two waves of 320 MFMAs x 64 cycles = 21 us of matrix work on 40 % of the chip.  With 16x16x4 MFMAs (same FLOP
+// rate, half the rows per tile) the same block is 209 / 128 workgroups of 10 us each.  Operand layout of 16x16x4 with the weights as
+// A: lane = 16 g + m supplies W[m][4 ks + g]; activations as B: lane = 16 g + n supplies x[row n][4 ks + g]; D: lane holds channels
+// 4 g + r (r = 0..3) of row n.  A lane therefore owns ONE row and, of every 16-channel tile T, the channels 16 T + 4 g + r -- which is
+// again the B operand of k-steps (T, r) of the next GEMM when its weights are stored in that order ([n_out/16][k/16][64 lanes][4],
+// lane = 16 g + m holding W[16 To + m][16 T + 4 g + r], r = 0..3: cmr_agent_amd/models/_pack.py:frag_pack16).  Rows read from memory
+// are read in the same order (float4 at channel 16 T + 4 g).
+__device__ __forceinline__ f32x4 vf_mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// acc[To] = sum over k-tiles T (KT of them, from kt0) and r of Wf[tile0 + To][kt0 + T][lane][r] * bfrag(T, r); fragments requested D
+// k-tiles ahead through a register ring (they come straight from L2)
+template <int TO, int KT, int D, typename BF>
+__device__ __forceinline__ void vf16_gemm(const float* __restrict__ wf, int kt_total, int tile0, int kt0, int lane, f32x4 (&acc)[TO], BF bfrag) {
+  static_assert(D >= 1 && D <= KT, "prefetch depth");
+#pragma unroll
+  for (int t = 0; t < TO; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* wp = wf + ((int64_t)tile0 * kt_total + kt0) * 256 + lane * 4;
+  const int64_t tstride = (int64_t)kt_total * 256;
+  f32x4 ring[D][TO];
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+#pragma unroll
+    for (int t = 0; t < TO; ++t) ring[d][t] = *reinterpret_cast<const f32x4*>(wp + t * tstride + d * 256);
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = bfrag(kt, r);
+#pragma unroll
+      for (int t = 0; t < TO; ++t) acc[t] = vf_mfma16(ring[kt % D][t][r], b, acc[t]);
+    }
+    if (kt + D < KT) {
+#pragma unroll
+      for (int t = 0; t < TO; ++t) ring[kt % D][t] = *reinterpret_cast<const f32x4*>(wp + t * tstride + (kt + D) * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// sum over the four lane groups g (lanes l, l ^ 16, l ^ 32, l ^ 48)
+__device__ __forceinline__ float vf16_allg(float v) {
+  v += cmr_xor16(v);
+  return v + cmr_xhalf(v);
+}
+
+__global__ __launch_bounds__(512) void vit_out_ffn16_kernel(const OutFfnArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[7 * 4 * 64 * 4];     // partial outputs of waves 1..7: [w][tile][lane][4]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const uint32_t row = blockIdx.x * 16 + n;
+  const bool valid = row < a.rows;
+  const uint32_t rowc = valid ? row : 0;
+  const float* cp = a.ctx + (int64_t)rowc * a.ldc + 4 * g;
+  const float* xp = a.x + (int64_t)rowc * a.ldx + 4 * g;
+  f32x4 cf[4], x1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    cf[t] = *reinterpret_cast<const f32x4*>(cp + 16 * t);
+    x1[t] = *reinterpret_cast<const f32x4*>(xp + 16 * t);
+  }
+  // ---- x1 = ctx Wo + bo + x     (every wave: 64 MFMAs)
+  {
+    f32x4 acc[4];
+    vf16_gemm<4, 4, 4>(a.wo_f, 4, 0, 0, lane, acc, [&](int t, int r) { return cf[t][r]; });
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bo + 16 * t + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x1[t][e] = (acc[t][e] + bv[e]) + x1[t][e];
+    }
+  }
+  // ---- LayerNorm(64) of the row: 16 channels here, the others in the three partner lanes
+  f32x4 xn[4];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s += (x1[t][0] + x1[t][1]) + (x1[t][2] + x1[t][3]);
+    const float mean = vf16_allg(s) * (1.f / 64.f);
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = x1[t][e] - mean;
+        xn[t][e] = d;
+        q += d * d;
+      }
+    const float rstd = 1.f / sqrtf(vf16_allg(q) * (1.f / 64.f) + a.eps);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(a.g2 + 16 * t + 4 * g);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2n + 16 * t + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) xn[t][e] = xn[t][e] * rstd * gv[e] + bv[e];
+    }
+  }
+  // ---- this wave's 128 hidden units: fc1 + GELU (8 tiles of 16), then its K-slice of fc2
+  f32x4 hid[8];
+  vf16_gemm<8, 4, 4>(a.w1_f, 4, 8 * wave, 0, lane, hid, [&](int t, int r) { return xn[t][r]; });
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + 128 * wave + 16 * t + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) hid[t][e] = vf_gelu(hid[t][e] + bv[e]);
+  }
+  f32x4 part[4];
+  vf16_gemm<4, 8, 8>(a.w2_f, 64, 0, 8 * wave, lane, part, [&](int t, int r) { return hid[t][r]; });
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&red[(((wave - 1) * 4 + t) * 64 + lane) * 4]) = part[t];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  f32x4 ov[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x4 s = part[t];
+#pragma unroll
+    for (int w = 0; w < 7; ++w) s += *reinterpret_cast<const f32x4*>(&red[((w * 4 + t) * 64 + lane) * 4]);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b2 + 16 * t + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ov[t][e] = (s[e] + bv[e]) + x1[t][e];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) cmr_pin(ov[t]);
+  if (valid) {
+    float* yp = a.out + (int64_t)row * a.ldo + 4 * g;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(yp + 16 * t) = ov[t];
+  }
+}
+
 }  // namespace
 
 extern "C" int cmr_ln64_linear_f32(const float* x, int64_t ldx, int64_t rows_x, const float* wf_x, const float* bias_x,
@@ -236,7 +372,10 @@ extern "C" int cmr_ln64_linear_f32(const float* x, int64_t ldx, int64_t rows_x, 
     a.p[1] = a.p[0];
   }
   a.g = gamma; a.b = beta; a.eps = eps;
-  hipLaunchKernelGGL(ln64_linear_kernel, dim3((a.tiles + 3) / 4), dim3(256), 0, stream, a);
+  // the proxy sets of this path are <= 169 tiles: one wave per workgroup spreads them over as many CUs (each wave's chain of L2
+  // fragment loads then runs on its own CU) instead of packing four onto each of 43
+  if (a.tiles <= 2048) hipLaunchKernelGGL(ln64_linear_kernel, dim3(a.tiles), dim3(64), 0, stream, a);
+  else hipLaunchKernelGGL(ln64_linear_kernel, dim3((a.tiles + 3) / 4), dim3(256), 0, stream, a);
   return cmr_launch_status();
 }
 
@@ -250,5 +389,18 @@ extern "C" int cmr_vit_out_ffn_f32(const float* ctx, int64_t ldc, const float* x
               cmr_aligned16(b2) && cmr_aligned16(ln_g) && cmr_aligned16(ln_b));
   const OutFfnArgs a{ctx, ldc, x, ldx, wo_f, bo, ln_g, ln_b, eps, w1_f, b1, w2_f, b2, out, ldo, (uint32_t)rows};
   hipLaunchKernelGGL(vit_out_ffn_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(512), 0, stream, a);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_vit_out_ffn16_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f16,
+                                     const float* bo, const float* ln_g, const float* ln_b, float eps, const float* w1_f16,
+                                     const float* b1, const float* w2_f16, const float* b2, float* out, int64_t ldo, int64_t rows,
+                                     hipStream_t stream) {
+  CMR_REQUIRE(ctx && x && wo_f16 && bo && ln_g && ln_b && w1_f16 && b1 && w2_f16 && b2 && out && rows > 0 && rows < (int64_t)0x7fffffe0);
+  CMR_REQUIRE(ldc % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && cmr_aligned16(ctx) && cmr_aligned16(x) && cmr_aligned16(out) &&
+              cmr_aligned16(wo_f16) && cmr_aligned16(w1_f16) && cmr_aligned16(w2_f16) && cmr_aligned16(bo) && cmr_aligned16(b1) &&
+              cmr_aligned16(b2) && cmr_aligned16(ln_g) && cmr_aligned16(ln_b));
+  const OutFfnArgs a{ctx, ldc, x, ldx, wo_f16, bo, ln_g, ln_b, eps, w1_f16, b1, w2_f16, b2, out, ldo, (uint32_t)rows};
+  hipLaunchKernelGGL(vit_out_ffn16_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(512), 0, stream, a);
   return cmr_launch_status();
 }

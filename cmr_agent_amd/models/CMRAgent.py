@@ -156,8 +156,12 @@ class CMRAgent(Planned):
         heads = [p[name] for name in ("policy_r", "policy_t", "value")]
         if self.FUSED_TAIL and e3d.is_contiguous():
             # AvgPool2d((H, W)) + the two 1x1 convs + the three heads: one launch (13 otherwise)
-            out = ops.agent_heads(xr, B, kh * kw, p["c24"], p["c26"], e3d, heads, SLOPE)
+            # ... and the deterministic actions (argmax per group of num_steps logits): attached to the logits, picked up by
+            # action_from_logits(deterministic=True) instead of two more launches per step
+            out, acts = ops.agent_heads(xr, B, kh * kw, p["c24"], p["c26"], e3d, heads, SLOPE,
+                                        actions=(self.config.num_steps, self.degree_r, self.degree_t))
         else:
+            acts = None
             x = ops.colmean(xr, B, kh * kw)                  # AvgPool2d((H, W)) = per-sample channel mean
             e2 = ops.linear(ops.linear(x.view(B, c), *p["c24"], act=ops.ACT_LRELU, act_param=SLOPE), *p["c26"])
             out = []
@@ -166,8 +170,11 @@ class CMRAgent(Planned):
                 hcur = ops.linear(hcur, *l1, act=ops.ACT_LRELU, act_param=SLOPE)
                 out.append(ops.linear(hcur, *l2))
         S = self.config.num_steps          # head widths are padded to a multiple of 4: slice, then split
-        return (out[0][:, :self.degree_r * S].view(B, self.degree_r, S), out[1][:, :self.degree_t * S].view(B, self.degree_t, S),
-                out[2][:, :1].view(B, 1, 1))
+        r = out[0][:, :self.degree_r * S].view(B, self.degree_r, S)
+        t = out[1][:, :self.degree_t * S].view(B, self.degree_t, S)
+        if acts is not None:
+            r._cmr_argmax, t._cmr_argmax = (acts[0], r._version), (acts[1], t._version)
+        return r, t, out[2][:, :1].view(B, 1, 1)
 
     def forward(self, state_2d, state_3d):
         """state_2d [B,128,h,w], state_3d [B,5,N] (reference layout; the views produced by
@@ -184,7 +191,12 @@ class CMRAgent(Planned):
     def action_from_logits(r_logits, t_logits, deterministic=False):
         """CMRAgent.py:118-127.  deterministic: argmax (of the Categorical probs = of the logits)."""
         if deterministic:
-            return ops.argmax_rows(r_logits), ops.argmax_rows(t_logits)
+            # logits that come straight from forward() carry their argmax (same launch); anything else (modified in place,
+            # sliced, user-made) goes through the argmax kernel
+            def pick(x):
+                a = getattr(x, "_cmr_argmax", None)
+                return a[0] if a is not None and a[1] == x._version else ops.argmax_rows(x)
+            return pick(r_logits), pick(t_logits)
         from torch.distributions import Categorical
         return Categorical(logits=r_logits).sample(), Categorical(logits=t_logits).sample()
 

@@ -64,6 +64,14 @@ def frag_pack(w):
     return w.reshape(n // 32, 32, k // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
+def frag_pack16(w):
+    """W [n_out, k] (both % 16 == 0) -> v_mfma_f32_16x16x4_f32 A fragments [n_out/16][k/16][64 lanes][4] (flat), lane = 16 g + m
+    holding W[16 To + m][16 T + 4 g + r], r = 0..3: the order in which a lane of the transposed GEMM owns the channels of a row
+    (accumulator register r of tile T in lane group g is channel 16 T + 4 g + r), so GEMMs chain through the accumulators."""
+    n, k = w.shape
+    return w.reshape(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+
+
 def frag_pack_bf16(w, acc_order=False):
     """W [n_out, k] (n_out % 32 == 0, k % 16 == 0) -> bf16 MFMA A fragments [n_out/32][k/16][64 lanes][8] for
     v_mfma_f32_32x32x16_bf16: lane = 32 h + l holds W[32 tile + l][c(s, h, j)], j = 0..7.  Natural order: c = 16 s + 8 h + j (the

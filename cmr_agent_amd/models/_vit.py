@@ -34,6 +34,7 @@ class Attention(Planned):
         f, fb = _pack.frag_pack, _pack.frag_pack_bf16
         return dict(q=(wq, bq), kv=kv, qkv=qkv, out=(wo, bo),
                     q_f=(f(wq), bq), kv_f=(f(kv[0]), kv[1]), qkv_f=(f(qkv[0]), qkv[1]), out_f=(f(wo), bo),
+                    out_f16=(_pack.frag_pack16(wo), bo),
                     q_b=(fb(wq), bq), kv_b=(fb(kv[0]), kv[1]), qkv_b=(fb(qkv[0]), qkv[1]), out_b=(fb(wo), bo))     # bf16 mode
 
     def rows(self, xn, yn, B, tx, ty, residual):
@@ -63,6 +64,7 @@ class Mlp(Planned):
     def _build_plan(self):
         fc1, fc2 = _pack.lin(self.fc1), _pack.lin(self.fc2)
         return dict(fc1=fc1, fc2=fc2, fc1_f=(_pack.frag_pack(fc1[0]), fc1[1]), fc2_f=(_pack.frag_pack(fc2[0]), fc2[1]),
+                    fc1_f16=(_pack.frag_pack16(fc1[0]), fc1[1]), fc2_f16=(_pack.frag_pack16(fc2[0]), fc2[1]),
                     fc1_b=(_pack.frag_pack_bf16(fc1[0], acc_order=True), fc1[1]), fc2_b=(_pack.frag_pack_bf16(fc2[0], acc_order=True), fc2[1]))
 
     def rows(self, xn, residual):
@@ -86,6 +88,7 @@ class Block(Planned):
         g = lambda ln: (ln.weight.detach().contiguous(), ln.bias.detach().contiguous())
         return dict(n1=g(self.attention_norm), n2=g(self.ffn_norm))
 
+    ROWS16 = True     # fp32: the block tail on 16-row tiles (twice the workgroups for the 3 344 / 2 048-row proxy sets)
     FUSED = True      # three launches per block (ops.ln64_linear, ops.mha, ops.vit_out_ffn); False = one per reference op
 
     def rows(self, x, y, B, tx, ty):
@@ -100,6 +103,8 @@ class Block(Planned):
             else:
                 q, kv = ops.ln64_linear(x, *a["q" + sfx], *p["n1"], self.LN_EPS, y, *a["kv" + sfx])
                 ctx = ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, tx, ty)
+            if sfx == "_f" and self.ROWS16:
+                return ops.vit_out_ffn(ctx, x, *a["out_f16"], p["n2"], self.LN_EPS, *m["fc1_f16"], *m["fc2_f16"], rows16=True)
             return ops.vit_out_ffn(ctx, x, *a["out" + sfx], p["n2"], self.LN_EPS, *m["fc1" + sfx], *m["fc2" + sfx])
         xn = ops.layernorm64(x, *p["n1"], self.LN_EPS)
         yn = None if (y is None or y is x) else ops.layernorm64(y, *p["n1"], self.LN_EPS)

@@ -274,17 +274,26 @@ def la_apply(qf, kvsum, B, L, S, eps, out=None):
     return out
 
 
-def agent_heads(x, B, npix, c24, c26, e3d, heads, slope):
+def agent_heads(x, B, npix, c24, c26, e3d, heads, slope, actions=None):
     """x [B*npix,128] (last 2-D feature map) -> global mean -> two 1x1 convs -> cat with e3d [B,128] -> the three
-    MLP heads.  c24 / c26 / heads[i][j] are (W [out,in], bias) pairs; returns the three logit tensors [B, n2_i]."""
+    MLP heads.  c24 / c26 / heads[i][j] are (W [out,in], bias) pairs; returns the three logit tensors [B, n2_i].
+    actions = (num_steps, degree_r, degree_t): the same launch also emits the deterministic actions (argmax per group of
+    num_steps logits) -> returns (outs, (action_r [B,degree_r], action_t [B,degree_t]))."""
     outs, args = [], []
     for (w0, b0), (w1, b1), (w2, b2) in heads:
         o = torch.empty((B, w2.shape[0]), dtype=f32, device=x.device)
         outs.append(o)
         args += [_p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), w0.shape[0], w1.shape[0], w2.shape[0], _p(o), o.stride(0)]
+    if actions is None:
+        _lib.call("cmr_agent_heads_f32", _p(_rows(x)), B, npix, _p(c24[0]), _p(c24[1]), _p(c26[0]), _p(c26[1]), _p(e3d), *args,
+                  0, 0, 0, None, None, float(slope), _stream())
+        return outs
+    S, dr, dt = actions
+    ar = torch.empty((B, dr), dtype=torch.int64, device=x.device)
+    at = torch.empty((B, dt), dtype=torch.int64, device=x.device)
     _lib.call("cmr_agent_heads_f32", _p(_rows(x)), B, npix, _p(c24[0]), _p(c24[1]), _p(c26[0]), _p(c26[1]), _p(e3d), *args,
-              float(slope), _stream())
-    return outs
+              int(S), int(dr), int(dt), _p(ar), _p(at), float(slope), _stream())
+    return outs, (ar, at)
 
 
 def ln64_linear(x, wf_x, bias_x, gamma, beta, eps, y=None, wf_y=None, bias_y=None):
@@ -304,12 +313,13 @@ def ln64_linear(x, wf_x, bias_x, gamma, beta, eps, y=None, wf_y=None, bias_y=Non
     return ox, oy
 
 
-def vit_out_ffn(ctx, x, wo_f, bo, ln, eps, w1_f, b1, w2_f, b2):
-    """attention out-projection + residual, then the pre-LN MLP (64 -> 1024 -> 64, erf GELU) + residual."""
+def vit_out_ffn(ctx, x, wo_f, bo, ln, eps, w1_f, b1, w2_f, b2, rows16=False):
+    """attention out-projection + residual, then the pre-LN MLP (64 -> 1024 -> 64, erf GELU) + residual.  rows16: the fp32 kernel on
+    16-row tiles; the weights are then _pack.frag_pack16 fragments."""
     if b1.numel() != 1024 or bo.numel() != 64:
         raise ValueError("vit_out_ffn is instantiated for embed_dim 64 / mlp_dim 1024")
     out = torch.empty((x.shape[0], 64), dtype=f32, device=x.device)
-    _lib.call("cmr_vit_out_ffn_bf16_f32" if w1_f.dtype == torch.bfloat16 else "cmr_vit_out_ffn_f32", _p(_rows(ctx)), _ld(ctx), _p(_rows(x)), _ld(x), _p(wo_f), _p(bo), _p(ln[0]), _p(ln[1]),
+    _lib.call("cmr_vit_out_ffn_bf16_f32" if w1_f.dtype == torch.bfloat16 else ("cmr_vit_out_ffn16_f32" if rows16 else "cmr_vit_out_ffn_f32"), _p(_rows(ctx)), _ld(ctx), _p(_rows(x)), _ld(x), _p(wo_f), _p(bo), _p(ln[0]), _p(ln[1]),
               float(eps), _p(w1_f), _p(b1), _p(w2_f), _p(b2), _p(out), _ld(out), x.shape[0], _stream())
     return out
 

@@ -91,6 +91,7 @@ WORK = {
                                       F * (a["rows_x"] * (64 + a["n_out_x"]) + (a["rows_y"] * (64 + a["n_out_y"]) if a["y"] else 0)
                                            + 64 * (a["n_out_x"] + (a["n_out_y"] if a["y"] else 0)))),
     "cmr_vit_out_ffn_f32": lambda a: (2.0 * a["rows"] * (4096 + 2 * 65536), F * (a["rows"] * 192 + 4096 + 2 * 65536)),
+    "cmr_vit_out_ffn16_f32": lambda a: (2.0 * a["rows"] * (4096 + 2 * 65536), F * (a["rows"] * 192 + 4096 + 2 * 65536)),
     "cmr_vit_out_ffn_bf16_f32": lambda a: (2.0 * a["rows"] * (4096 + 2 * 65536), F * (a["rows"] * 192 + 4096 + 2 * 65536)),
     # LinearAttention.py:46-60: k / v projections + per-head 8x8 state (source side); q projection, application, merge,
     # MLP 128 -> 128 -> 64 (query side): 17.5 + 66.7 = 84 kFLOP per token pair, as SURVEY.md 8a row a10 counts

@@ -140,7 +140,9 @@ int cmr_la_apply_f32(const float* qf, int64_t ldq, const float* kvsum, float* ms
 /* Tail of CMRAgent.forward (CMRAgent.py:52-56 global pool + two 1x1 convs, :101-116 the three MLP heads on
  * cat([embed_2d, embed_3d])) in one launch, one workgroup per sample.  x [B][npix][128] is the activated output of the
  * last 3x3 conv; weights are the PyTorch [out][in] matrices; head i: 256 -> n0 -> n1 -> n2 with LeakyReLU(slope)
- * between, logits written to out[b * ldo + 0..n2). */
+ * between, logits written to out[b * ldo + 0..n2).  r_act / t_act (optional, int64 [B][degree]): the deterministic actions of
+ * CMRAgent.action_from_logits (CMRAgent.py:118-123), argmax over each group of num_steps logits with the first maximum on ties
+ * (= cmr_argmax_rows_f32 on the same rows), emitted by the same launch. */
 int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const float* b24, const float* w26,
                         const float* b26, const float* e3d,
                         const float* r_w0, const float* r_b0, const float* r_w1, const float* r_b1, const float* r_w2, const float* r_b2,
@@ -149,6 +151,7 @@ int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const
                         int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
                         const float* v_w0, const float* v_b0, const float* v_w1, const float* v_b1, const float* v_w2, const float* v_b2,
                         int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                        int num_steps, int degree_r, int degree_t, int64_t* r_act, int64_t* t_act,
                         float slope, hipStream_t stream);
 
 /* Pre-LN transformer block (ImageViT.py:61-158 = PointViT.py:96-183 = IMGPCEncoder.py:14-102) in three launches.
@@ -165,6 +168,12 @@ int cmr_ln64_linear_f32(const float* x, int64_t ldx, int64_t rows_x, const float
 int cmr_vit_out_ffn_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f, const float* bo,
                         const float* ln_g, const float* ln_b, float eps, const float* w1_f, const float* b1, const float* w2_f,
                         const float* b2, float* out, int64_t ldo, int64_t rows, hipStream_t stream);
+/* The same block tail on 16-row tiles (v_mfma_f32_16x16x4_f32): twice the workgroups for the small proxy sets of this path
+ * (3 344 / 2 048 rows -> 209 / 128 workgroups).  Weights as 16x16x4 A fragments [n_out/16][k/16][64 lanes][4], lane = 16 g + m
+ * holding W[16 To + m][16 T + 4 g + r], r = 0..3 (cmr_agent_amd/models/_pack.py:frag_pack16); same arguments otherwise. */
+int cmr_vit_out_ffn16_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f16, const float* bo,
+                          const float* ln_g, const float* ln_b, float eps, const float* w1_f16, const float* b1,
+                          const float* w2_f16, const float* b2, float* out, int64_t ldo, int64_t rows, hipStream_t stream);
 /* bf16 matrix-core variants of the two kernels above (same arguments; the _f weights are bf16 A fragments
  * [n_out/32][k/16][64 lanes][8], cmr_agent_amd/models/_pack.py:frag_pack_bf16 -- natural k order for wf_x / wf_y / wo_f, accumulator
  * order for w1_f / w2_f; products on v_mfma_f32_32x32x16_bf16, fp32 accumulation; LayerNorm, GELU, biases, residuals fp32). */

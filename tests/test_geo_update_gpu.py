@@ -8,7 +8,7 @@ How the bars are set.  The first forward/backward is compared tensor by tensor. 
 ReLU / LeakyReLU kinks, near-saturated softmaxes): feeding the ORACLE an input perturbed by 1e-6 relative already moves the
 small gradient tensors by several per cent of their own scale (tools/geo_train_debug.py), so per-tensor errors
 are bounded against the model's largest gradient entry (3e-3; measured 4e-4 / 1.7e-3 on the two steps) and, for tensors that are not themselves at noise level, against
-their own scale (0.15); the whole gradient vector must have cosine >= 0.99999 with the oracle's.  A free-running second Adam
+their own scale (0.08, see _check_grads); the whole gradient vector must have cosine >= 0.99999 with the oracle's.  A free-running second Adam
 step is chaotic in the same sense (Adam's first steps move every weight by lr * sign(g), so an entry whose gradient is at noise
 level lands 2 lr away on either side: 31 % of the entries of the oracle itself differ by more than 2e-5 after two steps under
 that 1e-6 perturbation).  So the second step is checked TEACHER-FORCED -- a fresh HIP model loaded with the oracle's state after
@@ -66,7 +66,11 @@ def _check_grads(lg, og, what):
         h = lg[k].detach().cpu().double().reshape(g.shape)
         g = g.double()
         d, m = float((h - g).abs().max()), float(g.abs().max())
-        if d > 3e-3 * gmax or (m > 1e-4 * gmax and d > 0.15 * m):
+        # own-scale bar: 8 % for tensors above noise level.  Measured worst (profiles/r02_train_geo_gradient_parity.txt): 5.7 % on
+        # group_transformer_node.fc_gamma.0.bias, whose LARGEST entry is 9.3e-5 = 6.7e-5 of the model's largest gradient entry -- a
+        # tensor that is itself the difference of near-cancelling segment-softmax terms; the next ones are 4.0 % at |g| 6e-4 and
+        # 1.9 % at 3.6e-4, everything with |g| > 1e-2 agrees to < 1.6 % of its own scale and < 4.2e-4 of the model's
+        if d > 3e-3 * gmax or (m > 1e-4 * gmax and d > 0.08 * m):
             bad.append("%s: max|d| %.3e, own max %.3e, model max %.3e" % (k, d, m, gmax))
         if TO.canonical_key(k) == k:
             dot, nh, no = dot + float((h * g).sum()), nh + float((h * h).sum()), no + float((g * g).sum())

@@ -233,6 +233,9 @@ def test_vit_block_fused_pieces(ops, rows_x, rows_y):
     ref = x1 + F.gelu(ln(x1) @ w1.double().T + b1.double()) @ w2.double().T + b2.double()
     got = ops.vit_out_ffn(d(ctx), d(x), d(frag_pack(wo)), d(bo), (d(g), d(b)), 1e-6, d(frag_pack(w1)), d(b1), d(frag_pack(w2)), d(b2))
     close(got, ref, 2e-5, "out-ffn")
+    from cmr_agent_amd.models._pack import frag_pack16
+    got = ops.vit_out_ffn(d(ctx), d(x), d(frag_pack16(wo)), d(bo), (d(g), d(b)), 1e-6, d(frag_pack16(w1)), d(b1), d(frag_pack16(w2)), d(b2), rows16=True)
+    close(got, ref, 2e-5, "out-ffn on 16-row tiles")
 
 
 @pytest.mark.parametrize("B,npix", [(8, 418), (2, 60), (1, 7)])
@@ -252,6 +255,14 @@ def test_agent_heads_fused_tail(ops, B, npix):
     for g, h in zip(got, heads):
         ref = f(F.leaky_relu(f(F.leaky_relu(f(st, h[0]), 0.01), h[1]), 0.01), h[2])
         close(g, ref, 2e-5, "head")
+    # the same launch with the deterministic actions: identical logits, actions = argmax per group of num_steps logits (first maximum),
+    # i.e. what cmr_argmax_rows_f32 returns on those rows; heads 36 = 3 x 11 + 3 pad, 24 = 2 x 11 + 2 pad
+    got2, (ar, at) = ops.agent_heads(d(x).view(B * npix, 128), B, npix, dd(c24), dd(c26), d(e3d), [[dd(l) for l in h] for h in heads], 0.01,
+                                     actions=(11, 3, 2))
+    for g, g2 in zip(got, got2):
+        assert torch.equal(g, g2)
+    assert torch.equal(ar, ops.argmax_rows(got2[0][:, :33].view(B, 3, 11))) and torch.equal(at, ops.argmax_rows(got2[1][:, :22].view(B, 2, 11)))
+    assert torch.equal(ar.cpu(), got2[0][:, :33].view(B, 3, 11).cpu().argmax(-1))
 
 
 @pytest.mark.parametrize("mode", ["group", "knn"])
