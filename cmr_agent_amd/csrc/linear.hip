@@ -376,6 +376,144 @@ __global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a) {
   }
 }
 
+// Row-streaming fast path of the weight-stationary kernel for the shapes that carry most of this entry point's bytes:
+// X [rows][64] contiguous (K = 64, no second source), Y [rows][32 NT] contiguous, residual (optional) laid out like Y.
+// linear_ws_kernel reads X in MFMA operand layout -- lane (row, h) takes 16 bytes of ITS row, so one wave instruction touches 32 cache
+// lines for 32 useful bytes each, and the stores do the same: the texture path, not HBM, sets its rate (2.2-3.4 TB/s measured).  Here
+// a tile of 32 rows is what it is in memory, 8 KB of contiguous bytes: lane (r4, c) = (lane / 16, lane % 16) reads chunk c of row
+// 4 i + r4 with instruction i (1 KB contiguous per wave instruction, whole 256-B rows), TWO tiles ahead; the tile is turned into operand
+// layout through a wave-private 8 KB LDS buffer (chunk c of row r stored at position c ^ (r & 15): conflict-free for the row-wise writes
+// and for the operand reads, where 16 lanes read 16 different rows at one chunk), the accumulators go back through the same buffer and
+// bias / residual / activation / store happen in the coalesced layout (float4 of 4 consecutive couts per lane, whole rows per
+// instruction).  No workgroup barrier after the weights are staged; every wave walks its own tiles.
+template <int NT, int AC>
+__global__ __launch_bounds__(256) void linear_row64_kernel(const LinearArgs a) {
+  constexpr int LDWS = 64 + 4;
+  constexpr int OC = 8 * NT;                 // 16-byte chunks per output row
+  constexpr int RPI = 64 / OC;               // output rows per store instruction
+  constexpr int NI = 32 / RPI;               // store instructions per tile
+  extern __shared__ __attribute__((aligned(16))) float Ws[];    // [32 NT][68] weights | [32 NT] bias | [4 waves][32][64] tile buffers
+  float* Bs = Ws + 32 * NT * LDWS;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* T = Bs + 32 * NT + wave * 2048;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int c = lane & 15, r4 = lane >> 4;
+  const uint32_t rows = (uint32_t)a.rows;
+  const uint32_t ntiles = (rows + 31) / 32;
+  const uint32_t tstride = gridDim.x * 4;
+  const uint32_t last16 = rows * 16 - 1;     // index of the last 16-byte chunk of X (clamp: rows past the end re-read it, never stored)
+
+  auto load_tile = [&](uint32_t tile, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      uint32_t q = (tile * 32 + 4 * i + r4) * 16 + c;            // chunk index in X
+      q = q < last16 ? q : last16;
+      dst[i] = *reinterpret_cast<const f32x4*>(a.x1 + (size_t)q * 4);
+    }
+  };
+  f32x4 xa[8], xb[8];
+  uint32_t tile = blockIdx.x * 4 + wave;
+  load_tile(tile, xa);
+  load_tile(tile + tstride, xb);
+  for (int e = tid; e < 32 * NT * 16; e += 256) {
+    const int n = e >> 4, cc = (e & 15) * 4;
+    *reinterpret_cast<f32x4*>(&Ws[n * LDWS + cc]) = *reinterpret_cast<const f32x4*>(a.w + (int64_t)n * a.ldw + cc);
+  }
+  if (tid < 32 * NT) Bs[tid] = a.bias ? a.bias[tid] : 0.f;
+  __syncthreads();
+  const float* resb = a.res ? a.res : cmr_zero16;
+  const uint32_t res_on = a.res ? 1u : 0u;
+  const uint32_t lasto = rows * OC - 1;
+
+  for (; tile < ntiles; tile += tstride) {
+    // ---- rows -> operand layout through the wave's buffer
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = 4 * i + r4;
+      *reinterpret_cast<f32x4*>(&T[r * 64 + ((c ^ (r & 15)) << 2)]) = xa[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xa[i] = xb[i];
+    load_tile(tile + 2 * tstride, xb);                          // two tiles ahead
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+    const float* wrow = Ws + l31 * LDWS + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(&T[l31 * 64 + (((2 * g + h) ^ (l31 & 15)) << 2)]);
+      f32x4 wv[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wv[n] = *reinterpret_cast<const f32x4*>(wrow + n * 32 * LDWS + g * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = cmr_mfma32(wv[n][j], xv[j], acc[n]);
+    }
+    // ---- accumulators (lane = row l31, couts 32 n + 8 q + 4 h ..) -> coalesced layout through the same buffer (row stride 4 OC floats)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+        const int ch = 8 * n + 2 * q + h;
+        *reinterpret_cast<f32x4*>(&T[l31 * (4 * OC) + ((ch ^ (l31 & (OC - 1))) << 2)]) = v;
+      }
+    const int oc = lane & (OC - 1), orr = lane / OC;            // this lane's output chunk and row within a store instruction
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(&Bs[4 * oc]);
+    f32x4 ov[NI], rv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      uint32_t q = (tile * 32 + RPI * i + orr) * OC + oc;
+      q = q < lasto ? q : lasto;
+      rv[i] = *reinterpret_cast<const f32x4*>(resb + (size_t)(q * res_on) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int r = RPI * i + orr;
+      ov[i] = *reinterpret_cast<const f32x4*>(&T[r * (4 * OC) + ((oc ^ (r & (OC - 1))) << 2)]);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      f32x4 v = ov[i] + bv;
+      if (a.res) v += rv[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = ws_act<AC>(v[e], a.act_param);
+      ov[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) cmr_pin(ov[i]);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const uint32_t row = tile * 32 + RPI * i + orr;
+      if (row < rows) *reinterpret_cast<f32x4*>(a.y + ((size_t)row * OC + oc) * 4) = ov[i];
+    }
+  }
+}
+
+template <int NT, int AC>
+int launch_linear_row64_a(LinearArgs a, hipStream_t stream) {
+  const size_t smem = ((size_t)32 * NT * (64 + 4 + 1) + 4 * 2048) * sizeof(float);
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(linear_row64_kernel<NT, AC>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
+  const int64_t ntiles = (a.rows + 31) / 32;
+  int64_t gx = (ntiles + 3) / 4;
+  if (gx > 768) gx = 768;                   // up to 3 resident workgroups per CU
+  hipLaunchKernelGGL((linear_row64_kernel<NT, AC>), dim3((unsigned)gx), dim3(256), smem, stream, a);
+  return cmr_launch_status();
+}
+
+template <int NT>
+int launch_linear_row64(const LinearArgs& a, hipStream_t stream) {
+  if (a.act == CMR_ACT_GELU) return launch_linear_row64_a<NT, 1>(a, stream);
+  if (a.act == CMR_ACT_ELU1) return launch_linear_row64_a<NT, 2>(a, stream);
+  return launch_linear_row64_a<NT, 0>(a, stream);
+}
+
 // Split-K variant: one workgroup = one 32-row tile x 64 output channels, its 8 waves each take 1/8 of K
 // (operands straight from global / L2 in fragment layout, 4 k-groups prefetched ahead), partial
 // accumulators are summed through LDS and wave 0 runs the float4 epilogue.
@@ -533,6 +671,14 @@ __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restric
 
 }  // namespace
 
+static int g_linear_row64 = 1;
+// A/B switch for benchmarks and tests (1 = use the row-streaming fast path where it applies; default): returns the previous value.
+extern "C" int cmr_set_linear_row64(int on) {
+  const int old = g_linear_row64;
+  g_linear_row64 = on ? 1 : 0;
+  return old;
+}
+
 extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_t ld2, int k2,
                               const int32_t* idx2, int64_t div2, const float* w, int64_t ldw, const float* bias,
                               const float* res, int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int64_t rows,
@@ -556,6 +702,15 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   // float4 epilogue needs 4-aligned output channels (the host layer pads the few odd heads)
   const bool vec_ok = (n_out % 4 == 0) && (ldy % 4 == 0) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) &&
                       (!res || (ldres % 4 == 0 && cmr_aligned16(res)));
+  // contiguous [rows][64] -> [rows][64 | 32] (+ residual laid out like the output): the row-streaming fast path.  Measured
+  // (tools/linear_bench.py, profiles/r03_linear_bench.txt): 10 240 rows 7.7 -> 6.2 us, 53 504 rows 12.6 -> 10.4 us, but 131 072 /
+  // 214 016 rows 24.8 -> 28.8 / 33.8 -> 38.5 us: at 2 waves per SIMD the longer per-tile chain (two LDS round trips) costs more than
+  // the whole-row accesses save, and the generic kernel takes the same 34 us with and without a residual (4.8 vs 3.2 TB/s), i.e. it
+  // is not the texture path that bounds it at those sizes.  So: node / proxy-sized row sets only.
+  if (vec_ok && !a.x2 && a.k1 == 64 && a.ld1 == 64 && (n_out == 64 || n_out == 32) && ldy == n_out && a.ldw % 4 == 0 &&
+      (!res || (ldres == n_out && res_mod <= 0)) && rows >= 2048 && rows <= 65536 && g_linear_row64) {
+    return n_out == 64 ? launch_linear_row64<2>(a, stream) : launch_linear_row64<1>(a, stream);
+  }
   if (a.k1 + a.k2 <= 128 && vec_ok && rows < (int64_t)0x7fffffc0) {       // weights fit in LDS: weight-stationary streaming kernel
     if (n_out <= 32 || (n_out > 64 && n_out <= 96)) return launch_linear_ws<1>(a, stream);
     if (n_out % 128 == 0) return launch_linear_ws<4>(a, stream);

@@ -44,6 +44,9 @@ int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_
                    int64_t div2, const float* w, int64_t ldw, const float* bias, const float* res, int64_t ldres,
                    int64_t res_mod, float* y, int64_t ldy, int64_t rows, int n_out, int act, float act_param,
                    hipStream_t stream);
+/* Debug / benchmark switch: 0 routes the contiguous [rows][64] -> [rows][64 | 32] calls of cmr_linear_f32 through the generic
+ * weight-stationary kernel instead of the row-streaming fast path (bit-identical results); returns the previous setting. */
+int cmr_set_linear_row64(int on);
 
 /* Whole ConvBNReLURes1D block in one kernel (PointNN.py:260-282 with BN folded):
  *   hid = lrelu(W1 x + b1);  y = lrelu(W2 hid + b2 + (Wsc x | x)),  x = [x1[:, :k1] | x2[map][:, :kx-k1]].

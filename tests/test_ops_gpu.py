@@ -49,6 +49,27 @@ def test_linear_basic(ops, rows, k1, n_out, act):
     close(got, ref, 2e-5 if k1 <= 1024 else 5e-5, "linear")
 
 
+@pytest.mark.parametrize("rows,n_out,act,res", [(2048 + 17, 64, 0, False), (2048 + 17, 32, 4, True), (65536, 64, 4, False), (40960, 64, 2, True),
+                                              (53504, 32, 3, False), (10240, 64, 1, True)])
+def test_linear_row_streaming_fast_path(ops, rows, n_out, act, res):
+    """Contiguous [rows][64] -> [rows][64 | 32] calls take linear_row64_kernel (whole-row loads / stores, operand layout through LDS):
+    bit-identical to the generic weight-stationary kernel (same products in the same order), and right against torch fp64."""
+    from cmr_agent_amd import _lib
+    x, w, b = rnd(rows, 64, seed=5), rnd(n_out, 64, seed=6, lo=-0.2, hi=0.2), rnd(n_out, seed=7)
+    r = rnd(rows, n_out, seed=8) if res else None
+    d = lambda t: None if t is None else t.to(DEV)
+    got = ops.linear(d(x), d(w), d(b), res=d(r), act=act, act_param=0.2)
+    old = _lib.load().cmr_set_linear_row64(0)
+    try:
+        want = ops.linear(d(x), d(w), d(b), res=d(r), act=act, act_param=0.2)
+    finally:
+        _lib.load().cmr_set_linear_row64(old)
+    assert old == 1 and torch.equal(got, want)
+    ref = x.double() @ w.double().T + b.double() + (r.double() if res else 0)
+    ref = {0: lambda v: v, 1: torch.relu, 2: lambda v: F.leaky_relu(v, 0.2), 3: F.gelu, 4: lambda v: F.elu(v) + 1}[act](ref)
+    close(got, ref, 2e-5, "row-streaming linear")
+
+
 def test_linear_two_sources_gather_residual(ops):
     rows, m = 5000, 37
     x1, x2 = rnd(rows, 64, seed=4), rnd(m, 64, seed=5)
