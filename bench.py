@@ -38,7 +38,7 @@ from cmr_agent_amd import ops  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
 from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
-from cmr_agent_amd.runtime import RegistrationGraph  # noqa: E402
+from cmr_agent_amd.runtime import PipelinedRegistrationGraph, RegistrationGraph  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
 from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
 from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
@@ -470,6 +470,9 @@ def main():
     ap.add_argument("--alone-pass", action="store_true", help="one more (untimed) eager pass with every branch on ONE stream: adds "
                     "roofline.path_alone, each kernel's duration alone on the device (off by default so that the kernel statistics of a "
                     "profiled default run contain the same launches the JSON line averages over)")
+    ap.add_argument("--pipeline", action="store_true", help="register mode: two-stage software pipeline over consecutive batches in one "
+                    "hipGraph (geo forward of batch i concurrently with the agent loop of batch i - 1; cmr_agent_amd/runtime.py)")
+    ap.add_argument("--no-pipeline-line", action="store_true", help="skip the `pipelined` sub-object (second measurement of the same steps)")
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI (default); gloo: host "
                     "collectives on device tensors, for --share-gpu rehearsals")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0 (one-GPU box): exercises launcher, barrier / MAX "
@@ -506,7 +509,7 @@ def main():
     if args.eager:
         run_step = lambda: registration_step(geo, agent, cfg, batch)
     else:
-        rg = RegistrationGraph(geo, agent, cfg, batch)
+        rg = (PipelinedRegistrationGraph if args.pipeline else RegistrationGraph)(geo, agent, cfg, batch)
         run_step = lambda: rg.run().cpu()
     with torch.no_grad():
         for _ in range(args.warmup):
@@ -517,6 +520,21 @@ def main():
             pose = run_step()
         barrier()
         elapsed = time.perf_counter() - t0
+        # the same K steps through the two-stage software pipeline over consecutive batches (geo forward of batch i concurrently with
+        # the agent loop of batch i - 1, one hipGraph): a throughput mode, reported BESIDE the headline (whose step is one batch's
+        # geo forward + agent loop back to back)
+        pipe = None
+        if not args.eager and not args.pipeline and not args.no_pipeline_line:
+            rgp = PipelinedRegistrationGraph(geo, agent, cfg, batch)
+            for _ in range(args.warmup):
+                rgp.run().cpu()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pose_p = rgp.run().cpu()
+            barrier()
+            pipe = (ranks.max_over_ranks(time.perf_counter() - t1), bool(torch.equal(pose_p, pose)))
+            del rgp
         with CallTimer() as ct:                          # HIP events around EVERY C-ABI call, with its algorithmic work
             for _ in range(args.steps):
                 registration_step(geo, agent, cfg, batch)
@@ -611,8 +629,16 @@ def main():
                                                 "everything else fp32)") + ", hash-filled weights", "batch_per_gpu": w["B"],
                        "parallelism": "batch sharding, no data-path collective"},
             "agent_steps_per_s": iters * w["steps"] / elapsed, "roofline": roofline,
-            "launch_mode": "eager" if args.eager else "hipGraph replay", **info,
+            "launch_mode": "eager" if args.eager else ("hipGraph replay, 2-stage software pipeline over consecutive batches (geo forward of "
+                           "batch i || agent loop of batch i - 1)" if args.pipeline else "hipGraph replay"), **info,
         }
+        if pipe is not None:
+            line["pipelined"] = {"value": ranks.aggregate_rate(w["B"] * args.steps, pipe[0]), "unit": "registration iters/s",
+                                 "ms_per_step": 1e3 * pipe[0] / args.steps, "poses_identical_to_unpipelined": pipe[1],
+                                 "what": "same K steps, same batches, through cmr_agent_amd.runtime.PipelinedRegistrationGraph: one hipGraph per "
+                                         "step = geo forward of batch i on one stream || the 10 agent steps of batch i - 1 on another; per "
+                                         "replay the device does one geo forward + one agent loop.  Throughput mode (a batch's latency is "
+                                         "not shorter); NOT the headline value"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "c1":
             line["cpu_baseline"] = cpu_baseline(spec)
     if world == 1 and args.workload == "c1" and not args.no_train_lines and args.dtype is None:

@@ -16,8 +16,8 @@ namespace {
 // conv3x3 (stride 1, pad 1, NHWC) weight gradient:  dW[co][ci][ky][kx] = sum_{b,y,x} dY[b,y,x,co] X[b,y+ky-1,x+kx-1,ci]
 // grid (slices, Cout/32); workgroup = 4 waves; wave = (ci tile, pixel sub-slice); 9 accumulator tiles (one per tap).
 // One MFMA step consumes the pixels (2q, 2q+1) of the flattened [B*H*W] map (each lane tracks the coordinates of its own
-// pixel, so a pair may straddle a row or an image).  Loads of step q+1 are issued before the MFMAs
-// of step q (straight-line, clamped addresses, masks applied afterwards: see DESIGN.md "hipcc rules").
+// pixel, so a pair may straddle a row or an image).  Loads run four steps ahead of the MFMAs (straight-line, clamped addresses,
+// masks applied at consumption: see DESIGN.md "hipcc rules").
 // ------------------------------------------------------------------------------------------------------------------
 template <int NCI>
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
@@ -54,56 +54,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
   // against 576 cycles of MFMA, i.e. the kernel was VALU-bound at 48 % of its matrix bound whatever the prefetch depth.
   // Addresses: any linear pixel index clamped to [0, last_pix] is readable; whether a tap lies inside the image is decided
   // by the masks (3 row tests x 3 column tests).
-  int toff[9];
+  // Column reuse: tap (ky, kx = -1) of the pixel p is the linear pixel p + (ky - 1) W - 1 = (p - 2) + (ky - 1) W + 1, i.e. tap
+  // (ky, kx = +1) of the SAME lane one step earlier (a step advances every lane by two pixels).  So a step loads only the columns
+  // kx = 0 and kx = +1 of the three rows (6 loads + dY instead of 9 + 1) and multiplies the previous step's kx = +1 registers
+  // again, under THIS step's padding mask.  With ten dword loads per nine MFMAs the texture path was the ceiling: a wave load of
+  // 64 dwords costs ~16 address cycles whatever it carries, four steps per 576 MFMA cycles and CU = 640 cycles of it.
+  int toff[6];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) toff[t] = (t / 3 - 1) * W + (t % 3 - 1);
-  auto load = [&](float& a, float (&v)[9], int base) {
-    a = db[(int64_t)(min(base, last_pix) << cout_sh)];
+  for (int t = 0; t < 6; ++t) toff[t] = (t / 2 - 1) * W + (t % 2);        // (ky, kx = 0 | +1)
+  auto load = [&](float& a, float (&v)[6], int base) {
+    a = db[(int64_t)(min(max(base, 0), last_pix) << cout_sh)];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = xb[(int64_t)(min(max(base + toff[t], 0), last_pix) << cin_sh)];
-  };
-  auto mask = [&](float& a, float (&v)[9], int base, int yq, int xq) {
-    a = base <= last_pix ? a : 0.f;               // odd pixel count: the second lane half of the last pair
-    const bool oy[3] = {yq > 0, true, yq < H - 1};
-    const bool ox[3] = {xq > 0, true, xq < W - 1};
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) v[ky * 3 + kx] = (oy[ky] && ox[kx]) ? v[ky * 3 + kx] : 0.f;
+    for (int t = 0; t < 6; ++t) v[t] = xb[(int64_t)(min(max(base + toff[t], 0), last_pix) << cin_sh)];
   };
 
-  constexpr int NSET = 5;                         // four steps (40 loads, 2 300 MFMA cycles) in flight: every step touches new lines of
-                                                  // dY and of the lowest tap row, i.e. waits for an HBM miss (~2 000 cycles), not an L2 hit
-  float sa[NSET], sv[NSET][9];
+  constexpr int NSET = 6;                         // consumed now | the previous step's (its kx = +1 columns are this step's kx = -1) |
+                                                  // three loaded earlier | being loaded: four steps (28 loads, 2 300 MFMA cycles) in flight
+  float sa[NSET], sv[NSET][6];
   int sp[NSET], sx[NSET], sy[NSET];
   auto advance = [&](int& xq, int& yq) {
     xq += 2;
     if (xq >= W) { xq -= W; ++yq; }              // W >= 2: one wrap per step
     if (yq >= H) yq -= H;
   };
+  // set NSET - 1 plays "the step before the first": pixel p - 2 (clamped address, only its kx = +1 columns are read)
+  sp[NSET - 1] = p - 2; sx[NSET - 1] = 0; sy[NSET - 1] = 0;
   sp[0] = p; sx[0] = xx; sy[0] = yy;
 #pragma unroll
-  for (int i = 1; i < NSET - 1; ++i) {
+  for (int i = 1; i < NSET - 2; ++i) {
     sp[i] = sp[i - 1] + 2; sx[i] = sx[i - 1]; sy[i] = sy[i - 1];
     advance(sx[i], sy[i]);
   }
   if (w0 < w1) {
+    load(sa[NSET - 1], sv[NSET - 1], sp[NSET - 1]);
 #pragma unroll
-    for (int i = 0; i < NSET - 1; ++i) load(sa[i], sv[i], sp[i]);   // past the end of the slice: valid, unused addresses
+    for (int i = 0; i < NSET - 2; ++i) load(sa[i], sv[i], sp[i]);   // past the end of the slice: valid, unused addresses
   }
-  // Register sets rotate through the roles (consumed now | loaded earlier | being loaded) and nothing ever COPIES a loaded
-  // value: a rotation by assignment (cur = nxt) reads the load's destination and drags an s_waitcnt vmcnt(0) to the top of
-  // every iteration.  The padding mask is applied when a set is consumed, for the same reason.
+  // Register sets rotate through the roles and nothing ever COPIES a loaded value: a rotation by assignment (cur = nxt) reads the
+  // load's destination and drags an s_waitcnt vmcnt(0) to the top of every iteration.  The padding mask is applied when a set is
+  // consumed (into fresh registers), for the same reason.
 #define CMR_WG_STEP(C, VALID)                                                              \
   {                                                                                        \
-    constexpr int L = (C + NSET - 1) % NSET, P = (C + NSET - 2) % NSET;                    \
+    constexpr int L = (C + NSET - 2) % NSET, P = (C + NSET - 3) % NSET, M1 = (C + NSET - 1) % NSET; \
     sp[L] = sp[P] + 2; sx[L] = sx[P]; sy[L] = sy[P];                                       \
     advance(sx[L], sy[L]);                                                                 \
     load(sa[L], sv[L], sp[L]);                                                             \
     __builtin_amdgcn_sched_barrier(0); /* the loads are issued BEFORE this step's MFMAs */ \
-    mask(sa[C], sv[C], sp[C], sy[C], sx[C]);                                               \
-    const float av = (VALID) ? sa[C] : 0.f;                                                \
-    _Pragma("unroll") for (int t = 0; t < 9; ++t) acc[t] = cmr_mfma32(av, sv[C][t], acc[t]); \
+    const bool live = (VALID) && sp[C] <= last_pix; /* odd pixel count: second lane half of the last pair */ \
+    const float av = live ? sa[C] : 0.f;                                                   \
+    const bool oy[3] = {sy[C] > 0, true, sy[C] < H - 1};                                   \
+    const bool oxl = sx[C] > 0, oxr = sx[C] < W - 1;                                       \
+    _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                     \
+      const float vl = (oy[ky] && oxl) ? sv[M1][2 * ky + 1] : 0.f;                         \
+      const float vc = oy[ky] ? sv[C][2 * ky] : 0.f;                                       \
+      const float vr = (oy[ky] && oxr) ? sv[C][2 * ky + 1] : 0.f;                          \
+      acc[3 * ky] = cmr_mfma32(av, vl, acc[3 * ky]);                                       \
+      acc[3 * ky + 1] = cmr_mfma32(av, vc, acc[3 * ky + 1]);                               \
+      acc[3 * ky + 2] = cmr_mfma32(av, vr, acc[3 * ky + 2]);                               \
+    }                                                                                      \
   }
   // straight-line groups of NSET steps (one exit: extra exits made hipcc spill the accumulators); the last group's steps
   // past the end of the slice multiply by a zero dY
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     CMR_WG_STEP(2, q + 2 < w1)
     CMR_WG_STEP(3, q + 3 < w1)
     CMR_WG_STEP(4, q + 4 < w1)
+    CMR_WG_STEP(5, q + 5 < w1)
   }
 #undef CMR_WG_STEP
 

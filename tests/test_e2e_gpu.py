@@ -32,6 +32,48 @@ def test_registration_iteration_nuscenes_config3_shape():
     parity_e2e.run_case("e2e_config3", check_golden=False, verbose=True)
 
 
+def test_pipelined_graph_gives_every_batch_the_unpipelined_result():
+    """cmr_agent_amd.runtime.PipelinedRegistrationGraph runs geo(batch i) beside the agent loop of batch i - 1 in one hipGraph: run(batch)
+    must return, one call later, what RegistrationGraph returns for that batch (same kernels in the same order per batch), for
+    alternating different batches, and flush() must deliver the last one."""
+    import cases as C
+    import parity_e2e
+    from cmr_agent_amd.runtime import PipelinedRegistrationGraph, RegistrationGraph
+    from cmr_agent_amd.utils import synthetic
+    from oracle import cmr_oracle as O
+    case = "e2e_small"
+    c = C.E2E_CASES[case]
+    cfg = C.e2e_config(case)
+    cfg.r_steps, cfg.t_steps = cfg.r_steps.cuda(), cfg.t_steps.cuda()      # step tables on the device: no host copy inside the capture
+    geo, agent, _, _ = parity_e2e.build_models(cfg)
+    batches = [{k: (v.cuda() if torch.is_tensor(v) else v) for k, v in
+                synthetic.make_batch(c["B"], c["N"], c["H"], c["W"], c["M"], O.dataset_fps, O.nearest_node, seed=sd, n_circle=c["n_circle"]).items()}
+               for sd in (2023, 7, 99)]
+    snap = lambda g: [g.static_pose.clone()] + [x.clone() for x in g.static_last]
+    with torch.no_grad():
+        plain = RegistrationGraph(geo, agent, cfg, batches[0])
+        want = []
+        for b in batches:
+            plain.run(b)
+            want.append(snap(plain))
+        # the hash-filled agent's actions hardly depend on the pair, its logits / value do: that is what tells the batches apart
+        assert not torch.equal(want[0][1], want[1][1]) and not torch.equal(want[1][3], want[2][3])
+        pipe = PipelinedRegistrationGraph(geo, agent, cfg, batches[0])
+        pipe.run(batches[0])                                   # submits batch 0 (returns the priming batch's pose)
+        pipe.run(batches[1]); got0 = snap(pipe)                # agent loop of batch 0 || geo of batch 1
+        pipe.run(batches[2]); got1 = snap(pipe)
+        pipe.flush(); got2 = snap(pipe)
+    torch.cuda.synchronize()
+    # poses (products of the discrete action tables) are equal to the bit; logits / value agree to rounding only -- the observation's
+    # scatter-mean uses float atomics, whose order differs from launch to launch even within one graph -- and each must match ITS batch
+    scale = max(float(w_[1].abs().max()) for w_ in want)
+    for i, g in enumerate((got0, got1, got2)):
+        assert torch.equal(g[0], want[i][0])
+        for j in range(3):
+            err = max(float((x - y).abs().max()) for x, y in zip(g[1:], want[j][1:]))
+            assert (err <= 1e-4 * scale) == (i == j), (i, j, err, scale)
+
+
 def test_registration_iteration_op_level_paths(monkeypatch):
     """Same iteration with every layer-level fusion and the side streams switched off: the op-level composition
     must meet the same oracle / golden bars."""

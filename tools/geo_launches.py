@@ -1,0 +1,34 @@
+"""Launch census of ONE GeoUpdate step (Train_Geo.py:166-174) at --num-pt points: C-ABI calls by entry point (count, summed HIP-event ms), eager,
+side streams off.  python tools/geo_launches.py [num_pt]"""
+import os, sys, json, collections
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CMR_STREAMS", "0")
+import bench as BM
+from cmr_agent_amd import _lib
+from cmr_agent_amd.config import KittiConfiguration
+from cmr_agent_amd.models import MultiHeadModel
+from cmr_agent_amd.train import GeoUpdate
+from cmr_agent_amd.utils import hashfill, synthetic
+from cmr_agent_amd.utils.checkpoint import load_checked
+from cmr_agent_amd.utils.workmodel import CallTimer
+
+def main():
+    dev = torch.device("cuda", 0)
+    npt = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    cfg = KittiConfiguration(device=dev, num_pt=npt)
+    spec = json.load(open(os.path.join(BM.ROOT, "tests", "golden", "specs.json")))
+    model = MultiHeadModel(cfg); load_checked(model, hashfill.make_state_dict(spec["geo"], BM.GEO_TAG)); model = model.to(dev)
+    up = GeoUpdate(model, cfg)
+    batch = synthetic.make_batch(cfg.train_batch_size, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, BM.hip_fps(dev), BM.hip_nearest(dev),
+                                 seed=cfg.seed, n_circle=512, device=dev)
+    up.step(batch); torch.cuda.synchronize()
+    with CallTimer() as ct:
+        up.step(batch); torch.cuda.synchronize()
+    tab = ct.table()
+    print("entry point                         calls      ms   us/call")
+    for d in tab:
+        print("%-34s %6d %7.2f %8.1f" % (d["name"], d["calls"], d["ms"], 1e3 * d["ms"] / d["calls"]))
+    print("TOTAL calls %d, summed ms %.1f" % (sum(d["calls"] for d in tab), sum(d["ms"] for d in tab)))
+
+main()
