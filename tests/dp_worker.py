@@ -1,0 +1,48 @@
+"""Rank body of tests/test_dist_gpu.py: AgentUpdate steps of the data-parallel agent update (Train_Agent.py:296-305) on real HIP
+gradients, one rank per process (launched through cmr_agent_amd.utils.launch.rank_command).  Rank r takes minibatch r of
+cases.train_inputs as its shard of every step; every rank writes its final parameter bucket, gradient bucket and losses to
+<out>/rank<r>.pt.    python dp_worker.py <out dir> <backend> <share_gpu 0|1> <steps>"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import cases as C  # noqa: E402
+import golden_util as G  # noqa: E402
+from cmr_agent_amd.models import CMRAgent  # noqa: E402
+from cmr_agent_amd.train import AgentUpdate  # noqa: E402
+from cmr_agent_amd.utils import hashfill  # noqa: E402
+from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
+from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
+
+
+def main():
+    out, backend, share, steps = sys.argv[1], sys.argv[2], sys.argv[3] == "1", int(sys.argv[4])
+    dev = Ranks.local_device(share)
+    ranks = Ranks(backend=backend, device=dev)
+    specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+    case = "agent_train_small"
+    cfg = C.train_config(case, device=dev)
+    agent = CMRAgent(cfg)
+    load_checked(agent, hashfill.make_state_dict(specs["agent"], C.AGENT_TAG))
+    agent = agent.to(dev)
+    up = AgentUpdate(agent, cfg, dist=ranks.dist)
+    n = ranks.collective_ranks()
+    batches = C.train_inputs(case)
+    shard = {k: v.to(dev) for k, v in batches[ranks.rank % len(batches)].items()}
+    losses = []
+    for _ in range(steps):
+        losses.append(up.step(shard).cpu())
+    torch.cuda.synchronize()
+    torch.save({"params": up.bucket.params.cpu(), "grads": up.bucket.grads.cpu(), "losses": torch.stack(losses), "ranks": n,
+                "allreduce_ms": up.allreduce_ms()}, os.path.join(out, "rank%d.pt" % ranks.rank))
+    ranks.close()
+
+
+if __name__ == "__main__":
+    main()
