@@ -135,6 +135,154 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same contraction with the operands staged in LDS (round 3).  conv3x3_wgrad_kernel fetches every operand of every MFMA with a
+// dword load (7 per 9 MFMAs after the column reuse) and every tap of a pixel comes back from L2 once per tap row: 0.44-0.46 of the
+// fp32 matrix peak whatever the prefetch depth.  Here a workgroup walks DOWN a 32-pixel-wide column strip of one image with a ring of
+// four input rows in LDS (rows y-1, y, y+1 in use, row y+2 arriving): every input pixel is read from memory once per strip (plus the
+// two halo columns), as float4, and the nine taps are nine LDS addresses.  wave = ci tile (x pair split when Cin = 64), nine
+// accumulator tiles per wave for the workgroup's cout tile, as before; workgroups are persistent over strips (static stride) and
+// write ONE partial per wave at the end, summed by conv3x3_wgrad_reduce_kernel in the same fixed order.
+//   LDS: X ring [4][34][Cin + 32] floats (pixel stride Cin + 32: the two lane halves of an operand read -- pixels 2q and 2q + 1 --
+//   fall 32 banks apart), dY [2][32][32] floats.  One __syncthreads per image row.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCI>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                                                int Cout, int rps, float* __restrict__ part) {
+  constexpr int CIN = 32 * NCI, XS = CIN + 32, TW = 32, HC = TW + 2, NSPLIT = 4 / NCI;
+  constexpr int C4 = CIN / 4, NPIECE = HC * C4, NL = (NPIECE + 255) / 256;
+  constexpr int NPAIR = 16 / NSPLIT;                   // pixel pairs of a row tile per wave
+  extern __shared__ __attribute__((aligned(16))) float wg_smem[];
+  float* Xr = wg_smem;                                  // [4][HC][XS]
+  float* Dr = wg_smem + 4 * HC * XS;                    // [2][TW][32]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ci_t = wave % NCI, split = wave / NCI;
+  const int co_t = blockIdx.y;
+  const int ntx = (W + TW - 1) / TW, nys = (H + rps - 1) / rps;
+  const int nstrips = B * ntx * nys;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging roles of this thread (fixed): NL float4 pieces of an input row (halo pixel px, channels 4 c4 ..), one float4 of a dY row
+  int spx[NL], sc4[NL];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    int e = tid + 256 * i;
+    e = e < NPIECE ? e : NPIECE - 1;                    // duplicates of the last piece: identical value to the identical address
+    spx[i] = e / C4; sc4[i] = e - spx[i] * C4;
+  }
+  const int dpx = tid >> 3, dc4 = tid & 7;
+  const int64_t img_px = (int64_t)H * W;
+
+  for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    const int ys = strip % nys, xt = (strip / nys) % ntx, b = strip / (nys * ntx);
+    const int y0 = ys * rps, y1 = min(H, y0 + rps), x0 = xt * TW;
+    const float* xb = x + (int64_t)b * img_px * CIN;
+    const float* db = dy + (int64_t)b * img_px * Cout + co_t * 32;
+    // loads are branch-free (clamped addresses) and NOTHING touches a loaded value before it is stored to LDS, where the padding mask
+    // is applied: a select right after the load would put an s_waitcnt vmcnt(0) in front of the row's MFMAs (hipcc rules)
+    auto load_xrow = [&](int r, f32x4 (&dst)[NL]) {
+      const int rc = min(max(r, 0), H - 1);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int xc = min(max(x0 - 1 + spx[i], 0), W - 1);
+        dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((rc * W + xc) * CIN + 4 * sc4[i]));
+      }
+    };
+    auto store_xrow = [&](int r, const f32x4 (&src)[NL]) {
+      float* slot = Xr + ((r + 1) & 3) * (HC * XS);
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const int xx = x0 - 1 + spx[i];
+        const bool ok = r >= 0 && r < H && xx >= 0 && xx < W;
+        *reinterpret_cast<f32x4*>(slot + spx[i] * XS + 4 * sc4[i]) = ok ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto load_drow = [&](int r) -> f32x4 {
+      const int rc = min(r, H - 1), xc = min(x0 + dpx, W - 1);
+      return *reinterpret_cast<const f32x4*>(db + (unsigned)((rc * W + xc) * Cout + 4 * dc4));
+    };
+    auto store_drow = [&](int r, bool live, const f32x4& v) {
+      const bool ok = live && r < H && x0 + dpx < W;
+      *reinterpret_cast<f32x4*>(Dr + (r & 1) * (TW * 32) + dpx * 32 + 4 * dc4) = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- prime the ring: rows y0 - 1, y0, y0 + 1 and dY row y0 (the previous strip's last row ended with a barrier)
+    {
+      f32x4 r0[NL], r1[NL], r2[NL];
+      load_xrow(y0 - 1, r0); load_xrow(y0, r1); load_xrow(y0 + 1, r2);
+      const f32x4 d0 = load_drow(y0);
+      store_xrow(y0 - 1, r0); store_xrow(y0, r1); store_xrow(y0 + 1, r2);
+      store_drow(y0, true, d0);
+    }
+    __syncthreads();
+    for (int y = y0; y < y1; ++y) {
+      f32x4 nx[NL];
+      load_xrow(y + 2, nx);                             // in flight under this row's MFMAs
+      const f32x4 nd = load_drow(y + 1);
+      const float* dr = Dr + (y & 1) * (TW * 32) + l31;
+      const float* xr0 = Xr + ((y) & 3) * (HC * XS) + ci_t * 32 + l31;        // row y - 1
+      const float* xr1 = Xr + ((y + 1) & 3) * (HC * XS) + ci_t * 32 + l31;    // row y
+      const float* xr2 = Xr + ((y + 2) & 3) * (HC * XS) + ci_t * 32 + l31;    // row y + 1
+      // operands of pair q: pixel px = 2 q + h of the tile; tap column kx = halo pixel px + kx.  Pair q + 1 shares its kx = 0 column
+      // with pair q's kx = 2: per pair 2 new X values per row + 1 dY value are read from LDS, ONE PAIR AHEAD of the MFMAs that use
+      // them (scheduling barrier: hipcc otherwise sinks every read to just before its use and waits lgkmcnt(0) twice per pair)
+      const int q0 = split * NPAIR;
+      float av, bv[9], an, n1[3], n2[3];
+      {
+        const int px = 2 * q0 + h;
+        av = dr[px * 32];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          bv[kx] = xr0[(px + kx) * XS];
+          bv[3 + kx] = xr1[(px + kx) * XS];
+          bv[6 + kx] = xr2[(px + kx) * XS];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) {
+        if (i + 1 < NPAIR) {
+          const int px = 2 * (q0 + i + 1) + h;
+          an = dr[px * 32];
+          n1[0] = xr0[(px + 1) * XS]; n2[0] = xr0[(px + 2) * XS];
+          n1[1] = xr1[(px + 1) * XS]; n2[1] = xr1[(px + 2) * XS];
+          n1[2] = xr2[(px + 1) * XS]; n2[2] = xr2[(px + 2) * XS];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] = cmr_mfma32(av, bv[t], acc[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < NPAIR) {
+          av = an;
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            bv[3 * ky] = bv[3 * ky + 2];
+            bv[3 * ky + 1] = n1[ky];
+            bv[3 * ky + 2] = n2[ky];
+          }
+        }
+      }
+      store_xrow(y + 2, nx);                            // slot of row y - 2: nobody reads it any more
+      store_drow(y + 1, y + 1 < y1, nd);                // past the strip: zeros (never read)
+      __syncthreads();
+    }
+  }
+  float* out = part + ((int64_t)(blockIdx.x * NSPLIT + split) * 9) * Cout * CIN;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = cmr_mfma_row(r, lane);
+      out[((int64_t)t * Cout + co_t * 32 + row) * CIN + ci_t * 32 + l31] = acc[t][r];
+    }
+}
+
 // Sum of the per-wave partial outputs.  Workgroup = 32 consecutive outputs x 8 slice groups: thread (o, g) adds slices
 // g, g + 8, ... in double (coalesced over o), the 8 group sums are combined through LDS in a fixed order.
 constexpr int RED_OUT = 32, RED_GRP = 8;
@@ -352,10 +500,41 @@ inline int wgrad_slices(int64_t work_items) {
 
 }  // namespace
 
+// persistent workgroups of the LDS-staged kernel per cout tile, and rows per column strip
+struct WgLdsPlan { int use, groups, rps; };
+static int g_wgrad_lds = 1;
+inline WgLdsPlan wgrad_lds_plan(int B, int H, int W, int Cin, int Cout) {
+  WgLdsPlan p{0, 0, 0};
+  // Measured (tools/wgrad_bench.py, profiles/r03_wgrad_bench.txt; minibatch 10, 128 -> 128): 44x152 263 -> 227 us, 22x76 111 -> 87 us,
+  // 11x38 48 -> 45 us, but 88x304 902 -> 979 us and 8 x 160x512 64 -> 64 558 -> 599 us: both kernels sit at 0.51-0.56 of the nominal
+  // fp32 matrix peak on large maps (one wave per SIMD and a barrier per image row here, two waves per SIMD and L2 operand traffic
+  // there), so the staged kernel takes the maps whose row tiles the direct kernel's long slices balance badly, and nothing else
+  const int64_t npx = (int64_t)B * H * W;
+  if (!g_wgrad_lds || (Cin != 128 && Cin != 64) || npx < 4096 || npx > 150000) return p;
+  const int per_cu = Cin == 128 ? 1 : 2;                // LDS: 95 KB / 60 KB per workgroup
+  int groups = 256 * per_cu / (Cout / 32);
+  const int ntx = (W + 31) / 32;
+  int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)8 * groups));       // ~8 strips per workgroup (balance); >= 4 rows (halo rows amortised)
+  if (rps < 4) rps = 4;
+  if (rps > H) rps = H;
+  const int64_t nstrips = (int64_t)B * ntx * ((H + rps - 1) / rps);
+  if (groups > nstrips) groups = (int)nstrips;
+  p.use = 1; p.groups = groups; p.rps = rps;
+  return p;
+}
+
+extern "C" int cmr_set_wgrad_variant(int lds_staged) {
+  const int old = g_wgrad_lds;
+  g_wgrad_lds = lds_staged ? 1 : 0;
+  return old;
+}
+
 extern "C" int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const int nci = Cin / 32;
   const int nsplit = nci > 0 && nci <= 4 ? 4 / nci : 1;
-  const int slices = wgrad_slices(((int64_t)B * H * W + 1) / 2);
+  int slices = wgrad_slices(((int64_t)B * H * W + 1) / 2);
+  const int groups = 512;                               // upper bound of wgrad_lds_plan().groups, whichever variant is switched on
+  if (slices < groups) slices = groups;
   return (int64_t)slices * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float);
 }
 
@@ -366,10 +545,28 @@ extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff * 16);
   CMR_REQUIRE((int64_t)B * H * W < 0x7fffffff);
   const int nci = Cin / 32, nsplit = 4 / nci;
+  float* part = (float*)ws;
+  const WgLdsPlan lp = wgrad_lds_plan(B, H, W, Cin, Cout);
+  if (lp.use) {
+    CMR_REQUIRE(ws_bytes >= (int64_t)lp.groups * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float));
+    const size_t smem = ((size_t)4 * 34 * (Cin + 32) + 2 * 32 * 32) * sizeof(float);
+    dim3 grid(lp.groups, Cout / 32);
+    if (nci == 4) {
+      static CmrSmemCache granted{};
+      if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<4>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+      hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<4>, grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, lp.rps, part);
+    } else {
+      static CmrSmemCache granted{};
+      if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<2>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+      hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<2>, grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, lp.rps, part);
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
+                       lp.groups * nsplit, Cout, Cin, dw);
+    return cmr_launch_status();
+  }
   const int slices = wgrad_slices(((int64_t)B * H * W + 1) / 2);
   CMR_REQUIRE(ws_bytes >= (int64_t)slices * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float));
   dim3 grid(slices, Cout / 32);
-  float* part = (float*)ws;
   if (nci == 4)
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<4>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
   else if (nci == 2)

@@ -81,6 +81,31 @@ def test_batchnorm_train_forward_backward(ops, rows, Cc):
     close(ops.act_bwd(dz.to(DEV), z, 0.2, add=add.to(DEV)), dz * torch.where(y > 0, 1.0, 0.2) + add, name="act_bwd")
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 32, 48, 128, 128), (3, 37, 51, 128, 128), (2, 44, 152, 64, 128), (5, 22, 38, 128, 64), (1, 64, 65, 64, 64)])
+def test_conv3x3_weight_gradient_lds_staged_kernel(ops, B, H, W, cin, cout):
+    """Maps of >= 4096 pixels with Cin 64 / 128 take conv3x3_wgrad_lds_kernel (column strips, a ring of input rows in LDS): against torch
+    autograd and against the direct kernel (cmr_set_wgrad_variant(0)); ragged widths (not multiples of 32, odd), strips that end mid-image."""
+    from cmr_agent_amd import _lib
+    x = rnd(B, cin, H, W, seed=21)
+    w = (rnd(cout, cin, 3, 3, seed=22) / 10).requires_grad_(True)
+    dy = rnd(B, cout, H, W, seed=23)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = torch.empty(cout * cin * 9, device=DEV)
+    ops.conv3x3_wgrad(xd, dyd, dw)
+    close(dw.view(cout, cin, 3, 3), w.grad, 3e-5, "conv wgrad (LDS-staged)")
+    old = _lib.load().cmr_set_wgrad_variant(0)
+    try:
+        dw0 = torch.empty_like(dw)
+        ops.conv3x3_wgrad(xd, dyd, dw0)
+    finally:
+        _lib.load().cmr_set_wgrad_variant(old)
+    assert old == 1
+    close(dw, dw0, 2e-5, "LDS-staged vs direct kernel")
+    assert not torch.equal(dw, dw0) or B * H * W < 4096          # a different kernel did run (other summation order)
+
+
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 12, 20, 128, 128), (1, 9, 13, 64, 64), (3, 2, 3, 128, 128), (4, 32, 48, 128, 128), (2, 8, 16, 64, 128)])
 def test_conv3x3_weight_and_data_gradients(ops, B, H, W, cin, cout):
     """wgrad on the matrix cores and dgrad = forward kernels with cmr_pack_conv3x3_f32(transpose=1) vs torch autograd."""

@@ -1,0 +1,24 @@
+"""conv3x3 weight gradient alone at the agent update's shapes (minibatch 10): LDS-staged kernel vs direct kernel (hipGraph of REPS calls)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cmr_agent_amd import ops, _lib
+from kbench import timeit
+
+def main():
+    dev = "cuda"
+    for B, H, W, ci, co in ((10, 88, 304, 128, 128), (10, 44, 152, 128, 128), (10, 22, 76, 128, 128), (10, 11, 38, 128, 128), (8, 160, 512, 64, 64), (8, 40, 128, 64, 64)):
+        x, dy = torch.randn(B, H, W, ci, device=dev), torch.randn(B, H, W, co, device=dev)
+        dw = torch.empty(co * ci * 9, device=dev)
+        fl = 2.0 * 9 * ci * co * B * H * W
+        t = {}
+        for v in (1, 0):
+            _lib.load().cmr_set_wgrad_variant(v)
+            t[v] = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw), 10)
+        _lib.load().cmr_set_wgrad_variant(1)
+        print("wgrad %2d x %3dx%-3d %3d->%-3d : LDS-staged %7.1f us = %5.1f TFLOP/s (%.2f of peak) | direct %7.1f us = %5.1f TFLOP/s" % (
+            B, H, W, ci, co, t[1], fl / t[1] / 1e6, fl / t[1] / 1e6 / 157.3, t[0], fl / t[0] / 1e6))
+
+if __name__ == "__main__":
+    main()
