@@ -579,7 +579,7 @@ def main():
                    for d in table if d["modelled"]]
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes)
-        traffic, traffic_src = None, "profiles/r02_pmc_path.json"
+        traffic, traffic_src = None, "profiles/r03_pmc_path.json"
         try:
             pmc = json.load(open(os.path.join(ROOT, traffic_src)))
             wino = [v for k, v in pmc.items() if "conv3x3_wino" in k]       # the wave-specialised kernel and both 4-wave instances, launch-weighted
