@@ -58,7 +58,7 @@ def main():
             pose_source, pose_target = env.init(data)
             pose_target = env.to_disentangled(pose_target, data['pc'])
             for _ in range(config.action_num):
-                s2, s3 = env.observation_from_a_pose(data, pose_source)
+                s2, s3 = env.observation_from_a_pose(data, pose_source, materialize_state_2d=False)
                 r_logits, t_logits, _ = agent(s2, s3)
                 action_r, action_t = agent.action_from_logits(r_logits, t_logits, deterministic=True)
                 pose_source = env.step(action_r, action_t, pose_source, config)

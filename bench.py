@@ -93,7 +93,7 @@ def registration_step(geo, agent, cfg, batch):
     pose, target = env.init(data)
     target = env.to_disentangled(target, data['pc'])
     for _ in range(cfg.action_num):
-        s2, s3 = env.observation_from_a_pose(data, pose)
+        s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
         r, t, _ = agent(s2, s3)
         ar, at = agent.action_from_logits(r, t, deterministic=True)
         pose = env.step(ar, at, pose, cfg)

@@ -63,21 +63,25 @@ def to_disentangled(poses, pcd):
 
 
 @torch.no_grad()
-def observation_from_a_pose(data, RT):
+def observation_from_a_pose(data, RT, materialize_state_2d=True):
     """-> (state_2d [B,128,h,w], state_3d [B,5,N]) as views of channels-last / row storage.
-    New storage is returned on every call (the reference's replay buffer keeps them)."""
+    New storage is returned on every call (the reference's replay buffer keeps them).
+    materialize_state_2d=False (inference loops whose only consumer is CMRAgent): state_2d is returned as a shape-only `meta`
+    tensor carrying the two halves it stands for (image features | projected point features) in `_cmr_split`, which is what
+    CMRAgent.forward convolves; the concatenated 128-channel map (110 of the 275 MB this function moves per step at the headline
+    shape) is then never written.  Anything that needs the values must ask for the materialised observation (the default)."""
     ctx = _context(data)
     B, N, h, w = ctx.B, ctx.N, ctx.h, ctx.w
     dev = ctx.pc4.device
     state3d = torch.empty((B * N, 8), dtype=torch.float32, device=dev)
-    state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev)
+    state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev) if materialize_state_2d else None
     proj = torch.empty((B, h, w, 64), dtype=torch.float32, device=dev)
     zero_first, ctx.dirty = ctx.dirty, True
     ops.project_scatter(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.acc, ctx.cnt,
                         state3d, zero_first=zero_first)
     ops.observation_finalize(ctx.img, ctx.acc, ctx.cnt, state2d, proj, B, h, w, True, clear=True)
     ctx.dirty = False
-    obs2d = state2d.permute(0, 3, 1, 2)
+    obs2d = state2d.permute(0, 3, 1, 2) if state2d is not None else torch.empty((B, 128, h, w), dtype=torch.float32, device="meta")
     # the agent's first conv is linear in its input: hand it the two halves separately so that the image half
     # (constant over the steps of one registration) is convolved once (CMRAgent.forward_cl)
     obs2d._cmr_split = (ctx.img, proj, ctx.agent_cache)

@@ -180,12 +180,18 @@ class CMRAgent(Planned):
         """state_2d [B,128,h,w], state_3d [B,5,N] (reference layout; the views produced by
         cmr_agent_amd.environment are consumed without a copy)."""
         B, _, N = state_3d.shape
-        s2 = to_nhwc(state_2d)
+        split = getattr(state_2d, "_cmr_split", None)
+        if state_2d.device.type == "meta":                  # environment.observation_from_a_pose(materialize_state_2d=False)
+            if split is None:
+                raise ValueError("CMRAgent.forward: a shape-only state_2d must carry its two halves (_cmr_split)")
+            s2 = None
+        else:
+            s2 = to_nhwc(state_2d)
         if state_3d.stride(1) == 1 and state_3d.stride(2) == 8 and state_3d.stride(0) == 8 * N:
             s3 = torch.as_strided(state_3d, (B * N, 8), (8, 1))            # view of the env's [B*N,8] rows
         else:
             s3 = ops.planar_to_rows(state_3d.contiguous(), 8)
-        return self.forward_cl(s2, s3, B, N, getattr(state_2d, "_cmr_split", None))
+        return self.forward_cl(s2, s3, B, N, split)
 
     @staticmethod
     def action_from_logits(r_logits, t_logits, deterministic=False):

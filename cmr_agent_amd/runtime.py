@@ -34,7 +34,7 @@ class RegistrationGraph:
         pose, target = env.init(data)
         env.to_disentangled(target, data['pc'])
         for _ in range(self.cfg.action_num):
-            s2, s3 = env.observation_from_a_pose(data, pose)
+            s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
             r, t, v = self.agent(s2, s3)
             ar, at = self.agent.action_from_logits(r, t, deterministic=True)
             pose = env.step(ar, at, pose, self.cfg)
@@ -109,7 +109,7 @@ class PipelinedRegistrationGraph:
         pose, target = env.init(data)
         env.to_disentangled(target, data['pc'])
         for _ in range(self.cfg.action_num):
-            s2, s3 = env.observation_from_a_pose(data, pose)
+            s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
             r, t, v = self.agent(s2, s3)
             ar, at = self.agent.action_from_logits(r, t, deterministic=True)
             pose = env.step(ar, at, pose, self.cfg)

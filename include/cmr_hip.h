@@ -343,8 +343,9 @@ int cmr_colmean_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t w
 int cmr_project_scatter_f32(const float* pc4, const float* feat, const uint8_t* overlap, const float* pose,
                             const float* Kmat, const float* mean4, float* acc, float* cnt, float* state3d, int B, int N,
                             int h, int w, int zero_first, hipStream_t stream);
-/* state2d = [img_feat | acc / max(cnt,1)]; proj (optional) receives the second half alone as [B,h,w,64].
- * clear = 1: cells with cnt > 0 are reset to zero after they have been read. */
+/* state2d = [img_feat | acc / max(cnt,1)]; proj (optional) receives the second half alone as [B,h,w,64].  state2d may be null
+ * when proj is given (a caller that consumes the two halves separately, as CMRAgent's first convolution does: the 128-channel
+ * map is then neither written nor is img_feat read).  clear = 1: cells with cnt > 0 are reset to zero after they have been read. */
 int cmr_observation_finalize_f32(const float* img_feat, float* acc, float* cnt, float* state2d, float* proj,
                                  int B, int h, int w, int write_img, int clear, hipStream_t stream);
 /* environment.py:179-260 (step + euler_angles_to_matrix 'XYZ'), :14-21 (to_disentangled). */

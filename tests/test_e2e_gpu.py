@@ -74,6 +74,36 @@ def test_pipelined_graph_gives_every_batch_the_unpipelined_result():
             assert (err <= 1e-4 * scale) == (i == j), (i, j, err, scale)
 
 
+def test_shape_only_observation_gives_the_materialised_result():
+    """environment.observation_from_a_pose(materialize_state_2d=False) -- what the inference loops use -- never writes the concatenated
+    128-channel map: the agent must produce the same logits / value / actions from the two halves as from the materialised observation
+    (to rounding: the scatter-mean uses float atomics), the shape-only tensor must keep the reference's shape, and using it without
+    its halves must fail loudly instead of reading null."""
+    import cases as C
+    import parity_e2e
+    from cmr_agent_amd.environment import environment as env
+    case = "e2e_small"
+    cfg = C.e2e_config(case)
+    geo, agent, _, _ = parity_e2e.build_models(cfg)
+    data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in C.e2e_batch(case).items()}
+    with torch.no_grad():
+        geo(data)
+        pose, _ = env.init(data)
+        pose[:, 0, 3] += 0.3
+        s2, s3 = env.observation_from_a_pose(data, pose)
+        r0, t0, v0 = agent(s2, s3)
+        m2, m3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
+        assert m2.device.type == "meta" and tuple(m2.shape) == tuple(s2.shape)
+        r1, t1, v1 = agent(m2, m3)
+        for a, b in ((r0, r1), (t0, t1), (v0, v1)):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max()))
+        assert torch.equal(agent.action_from_logits(r0, t0, True)[0], agent.action_from_logits(r1, t1, True)[0])
+        assert torch.equal(s3, m3)
+        bare = torch.empty(tuple(s2.shape), device="meta")
+        with pytest.raises(ValueError):
+            agent(bare, m3)
+
+
 def test_registration_iteration_op_level_paths(monkeypatch):
     """Same iteration with every layer-level fusion and the side streams switched off: the op-level composition
     must meet the same oracle / golden bars."""
