@@ -607,8 +607,9 @@ def main():
             roofline = dict(kernel="conv3x3_bf16_tt_kernel / conv3x3_bf16_kernel (NHWC 3x3 direct: two-team stride-1 kernel, one-team stride-2 kernel; v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM)", bound="hbm",
                             achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=None,
                             mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2500.0,
-                            path_note="ideal times of `path` are priced at the fp32 peaks (utils/workmodel.py); the bf16 direct "
-                                      "convolution issues all 36/36 multiplies", **common)
+                            path_note="ideal times of `path`: entry points whose products run on the bf16 cores are priced at the bf16 "
+                                      "matrix peak (2.5 PFLOP/s dense, ridge 312 FLOP/B -- most of them are HBM-class there), the rest at "
+                                      "the fp32 peak (utils/workmodel.py); the bf16 direct convolution issues all 36/36 multiplies", **common)
         else:
             # `achieved` / `frac`: the multiplies the kernel ISSUES on the matrix cores (F(2x2,3x3): 16/36 of the convolution's
             # 2*9*Cin*Cout flop per output pixel) over its HIP-event time -- a position under the fp32 MFMA roof, <= 1 by construction;

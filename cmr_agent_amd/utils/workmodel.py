@@ -153,8 +153,16 @@ def work(name, args, extra=None):
     return float(fl), float(by)
 
 
-def ideal_seconds(flops, nbytes):
-    return max(flops / FP32_MFMA_PEAK, nbytes / HBM_PEAK)
+BF16_MFMA_PEAK = 2500e12      # FLOP/s dense, v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md); ridge 312 FLOP/B
+
+
+def matrix_peak(name):
+    """Matrix peak an entry point is priced against: the bf16 peak for the entry points whose products run on the bf16 cores."""
+    return BF16_MFMA_PEAK if "bf16" in name else FP32_MFMA_PEAK
+
+
+def ideal_seconds(flops, nbytes, name=""):
+    return max(flops / matrix_peak(name), nbytes / HBM_PEAK)
 
 
 class CallTimer:
@@ -195,12 +203,12 @@ class CallTimer:
             if fl is not None:
                 d["flops"] += fl
                 d["bytes"] += by
-                d["ideal_ms"] += 1e3 * ideal_seconds(fl, by)
+                d["ideal_ms"] += 1e3 * ideal_seconds(fl, by, name)
                 d["issued_flops"] += fl * ISSUED.get(name, 1.0)
-                d["ideal_issued_ms"] += 1e3 * ideal_seconds(fl * ISSUED.get(name, 1.0), by)
+                d["ideal_issued_ms"] += 1e3 * ideal_seconds(fl * ISSUED.get(name, 1.0), by, name)
         rows = sorted(agg.values(), key=lambda d: -d["ms"])
         for d in rows:
-            d["bound"] = "mfma" if d["bytes"] and d["flops"] / d["bytes"] > RIDGE else "hbm"
+            d["bound"] = "mfma" if d["bytes"] and d["flops"] / d["bytes"] > matrix_peak(d["name"]) / HBM_PEAK else "hbm"
             d["frac"] = d["ideal_issued_ms"] / d["ms"] if d["ms"] > 0 else 0.0
             d["frac_algorithmic"] = d["ideal_ms"] / d["ms"] if d["ms"] > 0 else 0.0
         return rows
