@@ -289,15 +289,20 @@ def train_main(args, ctx=None, with_cpu=False):
                     ("conv3x3_wgrad_kernel: 3x3 weight gradients as a GEMM over the minibatch's pixels (fp32 MFMA)",
                      ("cmr_conv3x3_wgrad_f32",), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
-                     ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc"), BF16_MFMA_PEAK_TFLOPS)]
+                     ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc"), BF16_MFMA_PEAK_TFLOPS),
+                    ("conv3x3_wgrad_bf16_kernel: 3x3 weight gradients on v_mfma_f32_32x32x16_bf16 (rows transposed into LDS, fp32 accumulate)",
+                     ("cmr_conv3x3_wgrad_bf16_f32",), BF16_MFMA_PEAK_TFLOPS),
+                    ("linear_ws_kernel / linear_wgrad_kernel: the 1x1 stacks of the 3-D branch, forward + data gradient + weight gradient "
+                     "(fp32 MFMA, row-streaming)", ("cmr_linear_f32", "cmr_linear_wgrad_f32"), FP32_MFMA_PEAK_TFLOPS)]
         line = {
             "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
             "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "agent update: minibatch of 10 observations [128,88,304] + [5,16384] per GPU, BC + PPO loss, "
-                                   "Adam (lr 1e-3, betas .9/.99, wd 1e-6)" + ("; forward / data-gradient 3x3 convolutions in bf16 (fp32 "
-                                   "accumulate), weight gradients and everything else fp32" if dtype == "bf16" else ""), "minibatch_per_gpu": MB,
+                                   "Adam (lr 1e-3, betas .9/.99, wd 1e-6)" + ("; forward / data-gradient / weight-gradient 3x3 convolutions on "
+                                   "the bf16 matrix cores (operands rounded to bf16, fp32 accumulate, fp32 maps and parameters), everything "
+                                   "else fp32" if dtype == "bf16" else ""), "minibatch_per_gpu": MB,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
             "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
             "gradient_bucket_sum_min_max_over_ranks": sums, "gradient_buckets_identical": sums[0] == sums[-1],

@@ -283,6 +283,190 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __r
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 variant of the weight gradient (round 3; bf16 training mode, BASELINE configs[2]): the same contraction on
+// v_mfma_f32_32x32x16_bf16 -- 16 pixels per instruction instead of 2, fp32 accumulate, operands rounded to bf16 (RNE).  At 16 x the
+// fp32 matrix rate the multiplies are free (18 instructions of 16 cycles per 32-pixel row tile and wave); what has to be organised is
+// the operand layout: the contraction index (pixels) must run INSIDE a lane's 16-byte operand, while NHWC memory runs channels.  So
+// the rows are transposed on their way into LDS: a lane loads 4 channels of ONE pixel (lanes 0..31 an even pixel, 32..63 its odd
+// neighbour), exchanges two of them with the partner lane (v_permlane32_swap), packs (even, odd) pixel pairs per channel and writes
+// two dwords into X^T[channel][pixel pair].  Operand of tap column kx for the 16-pixel block pb: the 8 pixels e0 + kx .. + 7 with
+// e0 = 16 pb + 8 h of channel row ci: five dwords from LDS, kx = 1 through four v_alignbit.  Column strips, ring of four input rows,
+// persistent workgroups and partial layout exactly as conv3x3_wgrad_lds_kernel (same reduction kernel).
+//   LDS: X^T ring [4][Cin][21 dwords] (21: odd row stride -> the 32 channel rows of an operand read fall on 32 banks; 42 >= 34 halo
+//   pixels), dY^T [2][32][21 dwords].  45 KB at Cin = 128: three workgroups per CU.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned wg_pack2(float lo, float hi) {            // (bf16(lo) | bf16(hi) << 16), round to nearest even
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, b2));
+}
+
+template <int NCI, int NCO, int TW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                                                 int Cout, int rps, float* __restrict__ part) {
+  // TW = 32 | 64 pixels per row tile (64: twice the bytes in flight per barrier interval -- the kernel waits on memory, not on its 18 / 36
+  // matrix instructions per row)
+  constexpr int CIN = 32 * NCI, RS = TW / 2 + 5, NSPLIT = 4 / NCI;   // RS odd: 21 | 37 dwords >= TW / 2 + 1 pairs (+ the dword past an operand)
+  constexpr int NPAIRX = TW / 2 + 1, NPAIRD = TW / 2, NBLK = TW / 16;
+  constexpr int C4 = CIN / 4;                          // channel quads per pixel: 32 (Cin 128) | 16 (Cin 64)
+  constexpr int PPI = 32 / C4;                         // pixel pairs per wave instruction of the X staging: 1 | 2
+  constexpr int NXI = (NPAIRX + 4 * PPI - 1) / (4 * PPI);   // staging iterations per wave for the pixel pairs of a halo row
+  extern __shared__ __attribute__((aligned(16))) unsigned wgb_smem[];
+  unsigned* XT = wgb_smem;                              // [4][CIN][RS]
+  unsigned* DT = wgb_smem + 4 * CIN * RS;               // [2][32 NCO][RS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ci_t = wave % NCI, split = wave / NCI;
+  const int co_t = blockIdx.y;
+  const int ntx = (W + TW - 1) / TW, nys = (H + rps - 1) / rps;
+  const int nstrips = B * ntx * nys;
+
+  // NCO cout tiles per workgroup share one staging of the input rows (the input is then read Cout / (32 NCO) times per launch)
+  f32x16 acc[NCO][9];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
+
+  // staging roles: X: lane -> (channel quad xc4, pair slot within the instruction xps, parity h); dY: (quad dc4 of 8 NCO, pair slot dps)
+  constexpr int DQ = 8 * NCO, DPI = 32 / DQ;            // dY channel quads; pixel pairs per wave instruction: 4 | 2
+  constexpr int NDI = NPAIRD / (4 * DPI);               // dY staging iterations per wave
+  const int xc4 = l31 % C4, xps = l31 / C4;
+  const int dc4 = l31 % DQ, dps = l31 / DQ;
+  const int64_t img_px = (int64_t)H * W;
+
+  for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+    const int ys = strip % nys, xt = (strip / nys) % ntx, b = strip / (nys * ntx);
+    const int y0 = ys * rps, y1 = min(H, y0 + rps), x0 = xt * TW;
+    const float* xb = x + (int64_t)b * img_px * CIN;
+    const float* db = dy + (int64_t)b * img_px * Cout + co_t * (32 * NCO);
+    // pixel pair pp of a halo row = halo elements 2 pp, 2 pp + 1 = image columns x0 - 1 + 2 pp (+ 1); this lane's element: 2 pp + h
+    auto xpair = [&](int i) { return min((wave + 4 * i) * PPI + xps, NPAIRX - 1); };   // duplicates of the last pair: identical writes
+    auto load_xrow = [&](int r, f32x4 (&dst)[NXI]) {
+      const int rc = min(max(r, 0), H - 1);
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) {
+        const int xc = min(max(x0 - 1 + 2 * xpair(i) + h, 0), W - 1);
+        dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((rc * W + xc) * CIN + 4 * xc4));
+      }
+    };
+    // (even, odd) pixel pairs per channel: lanes 0..31 hold the even pixel, 32..63 the odd one, of the same 4 channels.  The low half
+    // finishes channels 0, 1 of the quad, the high half channels 2, 3: each sends the partner the two values it needs.
+    auto store_pairs = [&](unsigned* row0, int quad, int pp, f32x4 v, bool ok) {
+      v = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      const float s0 = h ? v[0] : v[2], s1 = h ? v[1] : v[3];
+      const float r0 = cmr_xhalf(s0), r1 = cmr_xhalf(s1);
+      const unsigned w0 = h ? wg_pack2(r0, v[2]) : wg_pack2(v[0], r0);
+      const unsigned w1 = h ? wg_pack2(r1, v[3]) : wg_pack2(v[1], r1);
+      unsigned* p = row0 + (4 * quad + 2 * h) * RS + pp;
+      p[0] = w0;
+      p[RS] = w1;
+    };
+    auto store_xrow = [&](int r, const f32x4 (&src)[NXI]) {
+      unsigned* slot = XT + ((r + 1) & 3) * (CIN * RS);
+#pragma unroll
+      for (int i = 0; i < NXI; ++i) {
+        const int xx = x0 - 1 + 2 * xpair(i) + h;
+        store_pairs(slot, xc4, xpair(i), src[i], r >= 0 && r < H && xx >= 0 && xx < W);
+      }
+    };
+    // dY row: 16 pixel pairs x 8 NCO channel quads; element 2 pp + h = image column x0 + 2 pp + h
+    auto dpair = [&](int i) { return (wave * NDI + i) * DPI + dps; };
+    auto load_drow = [&](int r, f32x4 (&dst)[NDI]) {
+      const int rc = min(r, H - 1);
+#pragma unroll
+      for (int i = 0; i < NDI; ++i) {
+        const int xc = min(x0 + 2 * dpair(i) + h, W - 1);
+        dst[i] = *reinterpret_cast<const f32x4*>(db + (unsigned)((rc * W + xc) * Cout + 4 * dc4));
+      }
+    };
+    auto store_drow = [&](int r, bool live, const f32x4 (&src)[NDI]) {
+#pragma unroll
+      for (int i = 0; i < NDI; ++i)
+        store_pairs(DT + (r & 1) * (32 * NCO * RS), dc4, dpair(i), src[i], live && r < H && x0 + 2 * dpair(i) + h < W);
+    };
+
+    // Rows are requested TWO iterations before they are staged: a row tile is 18 matrix instructions (~0.15 us), so with the loads
+    // of row y + 2 issued at the top of iteration y and stored at its bottom every iteration waited a full memory round trip (2 us
+    // per row: 254 us at 10 x 88 x 304).  Two register sets alternate (rows y + 2 / y + 3) under static names, two rows per trip.
+    f32x4 xa[NXI], xb2[NXI], da[NDI], dbv[NDI];
+    {
+      f32x4 r0[NXI], r1[NXI], r2[NXI], d0[NDI];
+      load_xrow(y0 - 1, r0); load_xrow(y0, r1); load_xrow(y0 + 1, r2);
+      load_drow(y0, d0);
+      load_xrow(y0 + 2, xa);                             // stays in registers until the bottom of iteration y0
+      load_drow(y0 + 1, da);
+      store_xrow(y0 - 1, r0); store_xrow(y0, r1); store_xrow(y0 + 1, r2);
+      store_drow(y0, true, d0);
+    }
+    __syncthreads();
+    auto multiply_row = [&](int y) __attribute__((always_inline)) {
+      const unsigned* dr = DT + (y & 1) * (32 * NCO * RS) + l31 * RS;
+      const unsigned* xr[3] = {XT + ((y) & 3) * (CIN * RS) + (ci_t * 32 + l31) * RS, XT + ((y + 1) & 3) * (CIN * RS) + (ci_t * 32 + l31) * RS,
+                               XT + ((y + 2) & 3) * (CIN * RS) + (ci_t * 32 + l31) * RS};
+#pragma unroll
+      for (int pbi = 0; pbi < NBLK / NSPLIT; ++pbi) {
+        const int pb = split * (NBLK / NSPLIT) + pbi;   // Cin = 64: the pixel blocks of a row tile are split over two waves
+        const int d0 = 8 * pb + 4 * h;                  // first dword of this lane's 8 pixels (dY: element = pixel; X: element = pixel + kx)
+        wg_bf16x8 av[NCO];
+#pragma unroll
+        for (int c = 0; c < NCO; ++c) {
+          uint4 aw;
+          aw.x = dr[c * 32 * RS + d0]; aw.y = dr[c * 32 * RS + d0 + 1]; aw.z = dr[c * 32 * RS + d0 + 2]; aw.w = dr[c * 32 * RS + d0 + 3];
+          av[c] = __builtin_bit_cast(wg_bf16x8, aw);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          unsigned q[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) q[i] = xr[ky][d0 + i];
+          const uint4 b0 = {q[0], q[1], q[2], q[3]};
+          const uint4 b1 = {__builtin_amdgcn_alignbit(q[1], q[0], 16), __builtin_amdgcn_alignbit(q[2], q[1], 16),
+                            __builtin_amdgcn_alignbit(q[3], q[2], 16), __builtin_amdgcn_alignbit(q[4], q[3], 16)};
+          const uint4 b2 = {q[1], q[2], q[3], q[4]};
+#pragma unroll
+          for (int c = 0; c < NCO; ++c) {
+            acc[c][3 * ky] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], __builtin_bit_cast(wg_bf16x8, b0), acc[c][3 * ky], 0, 0, 0);
+            acc[c][3 * ky + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], __builtin_bit_cast(wg_bf16x8, b1), acc[c][3 * ky + 1], 0, 0, 0);
+            acc[c][3 * ky + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], __builtin_bit_cast(wg_bf16x8, b2), acc[c][3 * ky + 2], 0, 0, 0);
+          }
+        }
+      }
+    };
+    for (int y = y0; y < y1; y += 2) {
+      load_xrow(y + 3, xb2);                            // set B: row y + 3, staged at the bottom of iteration y + 1
+      load_drow(y + 2, dbv);
+      multiply_row(y);
+      store_xrow(y + 2, xa);                            // set A was requested one iteration ago; slot of row y - 2
+      store_drow(y + 1, y + 1 < y1, da);
+      __syncthreads();
+      if (y + 1 >= y1) break;                           // (uniform)
+      load_xrow(y + 4, xa);
+      load_drow(y + 3, da);
+      multiply_row(y + 1);
+      store_xrow(y + 3, xb2);
+      store_drow(y + 2, y + 2 < y1, dbv);
+      __syncthreads();
+    }
+  }
+  float* out = part + ((int64_t)(blockIdx.x * NSPLIT + split) * 9) * Cout * CIN;
+#pragma unroll
+  for (int c = 0; c < NCO; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = cmr_mfma_row(r, lane);
+        out[((int64_t)t * Cout + (co_t * NCO + c) * 32 + row) * CIN + ci_t * 32 + l31] = acc[c][t][r];
+      }
+}
+
 // Sum of the per-wave partial outputs.  Workgroup = 32 consecutive outputs x 8 slice groups: thread (o, g) adds slices
 // g, g + 8, ... in double (coalesced over o), the 8 group sums are combined through LDS in a fixed order.
 constexpr int RED_OUT = 32, RED_GRP = 8;
@@ -575,6 +759,47 @@ extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
                      slices * nsplit, Cout, Cin, dw);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
+                                          int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W >= 2);
+  CMR_REQUIRE((Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (Cin == 64 || Cin == 128));
+  CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff);       // 32-bit element offsets within an image batch
+  const int nci = Cin / 32, nsplit = 4 / nci;
+  // persistent workgroups, one per CU (288 accumulator registers per wave at two cout tiles), over all cout groups; ~8 column strips
+  // of >= 4 rows per workgroup
+  const int tw = ((W + 63) / 64 * 64 <= (W + 31) / 32 * 32) ? 64 : 32;     // 64-pixel row tiles unless they pad the width more than 32-pixel ones (152 -> 192 vs 160)
+  // two cout tiles per workgroup (288 accumulator registers) spill at Cin = 128 and with 64-pixel tiles (measured slower): narrow Cin = 64 maps only
+  const int nco = (nci == 2 && tw == 32 && Cout % 64 == 0) ? 2 : 1;
+  int groups = 256 / (Cout / (32 * nco));
+  const int ntx = (W + tw - 1) / tw;
+  int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)8 * groups));
+  if (rps < 4) rps = 4;
+  if (rps > H) rps = H;
+  const int64_t nstrips = (int64_t)B * ntx * ((H + rps - 1) / rps);
+  if (groups > nstrips) groups = (int)nstrips;
+  if (groups > 512) groups = 512;                        // workspace bound of cmr_conv3x3_wgrad_workspace_bytes
+  CMR_REQUIRE(ws_bytes >= (int64_t)groups * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float));
+  const int rs = tw / 2 + 5;
+  const size_t smem = ((size_t)4 * Cin * rs + 2 * 32 * nco * rs) * sizeof(unsigned);
+  float* part = (float*)ws;
+  dim3 grid(groups, Cout / (32 * nco));
+#define CMR_WGB_LAUNCH(NCI_, NCO_, TW_)                                                                                               \
+  {                                                                                                                                   \
+    static CmrSmemCache granted{};                                                                                                    \
+    if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_>), smem, granted) != CMR_OK) return CMR_ELAUNCH; \
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_>), grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, rps, part);   \
+  }
+  if (nci == 4 && tw == 64) CMR_WGB_LAUNCH(4, 1, 64)
+  else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32)
+  else if (nco == 2) CMR_WGB_LAUNCH(2, 2, 32)
+  else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64)
+  else CMR_WGB_LAUNCH(2, 1, 32)
+#undef CMR_WGB_LAUNCH
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
+                     groups * nsplit, Cout, Cin, dw);
   return cmr_launch_status();
 }
 

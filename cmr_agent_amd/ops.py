@@ -764,6 +764,9 @@ def transpose_slots(src, dst, table, nslots, total_tiles):
     return dst
 
 
+WGRAD_BF16 = True        # with CONV_BF16: 3x3 weight gradients on the bf16 cores as well (False: fp32 weight gradients, round 2's behaviour)
+
+
 def conv3x3_wgrad(x, dy, dw):
     """x [B,H,W,Cin], dy [B,H,W,Cout] (contiguous NHWC) -> dw (flat view of [Cout,Cin,3,3] in the gradient bucket)."""
     B, H, W, cin = x.shape
@@ -772,7 +775,10 @@ def conv3x3_wgrad(x, dy, dw):
         raise ValueError("conv3x3_wgrad: bad operand layout")
     nb = _lib.load().cmr_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
     ws = _ws(nb, x.device)
-    _lib.call("cmr_conv3x3_wgrad_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
+    # bf16 training mode: the weight gradient on the bf16 matrix cores too (operands rounded to bf16, fp32 accumulate), like the forward
+    # and data-gradient convolutions
+    name = "cmr_conv3x3_wgrad_bf16_f32" if (CONV_BF16 and WGRAD_BF16 and cin in (64, 128)) else "cmr_conv3x3_wgrad_f32"
+    _lib.call(name, _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
 
 
 def linear_wgrad(dy, x, dw, lddw, n=None, k=None, accumulate=False, db=None, accumulate_db=False):

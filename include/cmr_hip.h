@@ -434,6 +434,11 @@ int cmr_transpose_slots_f32(const float* src, float* dst, const int64_t* table, 
 /* nn.Conv2d(3x3, stride 1, pad 1) weight gradient on the matrix cores: dw [Cout][Cin][3][3] = sum over the minibatch
  * pixels of dy (x) shifted x (NHWC maps, W >= 2, Cin in {32,64,128}, Cout % 32 == 0). */
 int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+/* The same gradient with the products on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: operands rounded to bf16, fp32 accumulate;
+ * the bf16 training mode of BASELINE configs[2]).  x / dy stay fp32 NHWC; Cin in {64, 128}; workspace of
+ * cmr_conv3x3_wgrad_workspace_bytes. */
+int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
+                               int64_t ws_bytes, hipStream_t stream);
 /* A/B switch: 1 (default) = the LDS-staged kernel for Cin 64 / 128 on maps of >= 4096 pixels (a ring of input rows in LDS, every
  * tap an LDS address), 0 = the direct kernel everywhere (operands by dword loads).  Same sums in a different order (results agree
  * to fp32 rounding); returns the previous setting. */

@@ -92,6 +92,33 @@ def test_registration_iteration_bf16_convolutions_meet_the_bf16_bars(case):
     assert float(ov) >= 0.98, float(ov)
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 12, 20, 128, 128), (4, 32, 48, 128, 128), (3, 37, 51, 128, 64), (2, 44, 152, 64, 128), (1, 9, 13, 64, 64),
+                                            (2, 5, 2, 128, 32), (10, 22, 76, 128, 128)])
+def test_conv3x3_weight_gradient_bf16(B, H, W, cin, cout):
+    """cmr_conv3x3_wgrad_bf16_f32 (v_mfma_f32_32x32x16_bf16, rows transposed into LDS as (even, odd) pixel pairs): exact against torch on
+    bf16-ROUNDED operands in float64 up to fp32 accumulation order, and within bf16 rounding of the fp32 gradient; ragged widths, odd
+    sizes, strips that end mid-image, widths below one tile."""
+    from cmr_agent_amd import ops
+    x, dy = rnd(B, cin, H, W, seed=31), rnd(B, cout, H, W, seed=32)
+    bf = lambda t: t.to(torch.bfloat16).double()
+    def wgrad(xx, dd):
+        w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xx, w, None, 1, 1).backward(dd)
+        return w.grad
+    want_bf, want_fp = wgrad(bf(x), bf(dy)), wgrad(x.double(), dy.double())
+    xd, dyd = x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = torch.empty(cout * cin * 9, device=DEV)
+    ops.CONV_BF16 = True
+    try:
+        ops.conv3x3_wgrad(xd, dyd, dw)
+    finally:
+        ops.CONV_BF16 = False
+    got = dw.view(cout, cin, 3, 3).cpu().double()
+    scale = float(want_fp.abs().max())
+    assert float((got - want_bf).abs().max()) <= 3e-5 * scale, float((got - want_bf).abs().max()) / scale
+    assert float((got - want_fp).abs().max()) <= 1.5e-2 * scale
+
+
 def test_configs3_batch_of_four_in_bf16_is_sample_independent_and_rigid():
     """BASELINE configs[3] runs 4 pairs per GPU in bf16.  No oracle at that size in seconds, so size-independent properties: every pair of
     the batch of 4 gets the result it gets alone (no cross-sample coupling anywhere on the inference path: eval-mode BatchNorm, per-sample

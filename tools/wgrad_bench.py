@@ -17,8 +17,12 @@ def main():
             _lib.load().cmr_set_wgrad_variant(v)
             t[v] = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw), 10)
         _lib.load().cmr_set_wgrad_variant(1)
-        print("wgrad %2d x %3dx%-3d %3d->%-3d : LDS-staged %7.1f us = %5.1f TFLOP/s (%.2f of peak) | direct %7.1f us = %5.1f TFLOP/s" % (
-            B, H, W, ci, co, t[1], fl / t[1] / 1e6, fl / t[1] / 1e6 / 157.3, t[0], fl / t[0] / 1e6))
+        ops.CONV_BF16 = True
+        tb = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw), 10)
+        ops.CONV_BF16 = False
+        by = 4.0 * B * H * W * (ci + co)
+        print("wgrad %2d x %3dx%-3d %3d->%-3d : LDS-staged %7.1f us = %5.1f TFLOP/s (%.2f of peak) | direct %7.1f us = %5.1f TFLOP/s | bf16 %7.1f us = %6.1f TFLOP/s, %4.2f TB/s" % (
+            B, H, W, ci, co, t[1], fl / t[1] / 1e6, fl / t[1] / 1e6 / 157.3, t[0], fl / t[0] / 1e6, tb, fl / tb / 1e6, by / tb / 1e6))
 
 if __name__ == "__main__":
     main()
