@@ -102,8 +102,9 @@ def test_conv3x3_weight_gradient_bf16(B, H, W, cin, cout):
     x, dy = rnd(B, cin, H, W, seed=31), rnd(B, cout, H, W, seed=32)
     bf = lambda t: t.to(torch.bfloat16).double()
     def wgrad(xx, dd):
-        w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
-        F.conv2d(xx, w, None, 1, 1).backward(dd)
+        with torch.enable_grad():                        # an earlier test of the session may have left autograd switched off
+            w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, requires_grad=True)
+            F.conv2d(xx, w, None, 1, 1).backward(dd)
         return w.grad
     want_bf, want_fp = wgrad(bf(x), bf(dy)), wgrad(x.double(), dy.double())
     xd, dyd = x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV)

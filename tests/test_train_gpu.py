@@ -87,9 +87,10 @@ def test_conv3x3_weight_gradient_lds_staged_kernel(ops, B, H, W, cin, cout):
     autograd and against the direct kernel (cmr_set_wgrad_variant(0)); ragged widths (not multiples of 32, odd), strips that end mid-image."""
     from cmr_agent_amd import _lib
     x = rnd(B, cin, H, W, seed=21)
-    w = (rnd(cout, cin, 3, 3, seed=22) / 10).requires_grad_(True)
     dy = rnd(B, cout, H, W, seed=23)
-    F.conv2d(x, w, None, 1, 1).backward(dy)
+    with torch.enable_grad():
+        w = (rnd(cout, cin, 3, 3, seed=22) / 10).requires_grad_(True)
+        F.conv2d(x, w, None, 1, 1).backward(dy)
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
     dw = torch.empty(cout * cin * 9, device=DEV)
