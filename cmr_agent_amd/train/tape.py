@@ -130,7 +130,13 @@ class Tape:
                 ops.linear_wgrad_any(dy, x.v, gw, acc, db=gb, accumulate_db=accb)
             else:
                 ops.linear_wgrad_any(dy, x.v, gw, acc)
-            self.give(x, ops.linear(dy, self.WT(weight)), owned=True)
+            if x.g is None:
+                self.give(x, ops.linear(dy, self.WT(weight)), owned=True)
+            else:
+                # a second consumer of x: the accumulation rides in the data-gradient GEMM's epilogue (residual operand; in place
+                # when the buffer is ours) instead of a separate pass over the row map
+                x.g = ops.linear(dy, self.WT(weight), res=x.g, out=x.g if x.own and x.g.is_contiguous() else None)
+                x.own = True
         self.nodes.append(bwd)
         return y
 
@@ -377,7 +383,12 @@ class Tape:
             ops.colsum(y.g, 1, y.g.shape[0], out=gb.view(1, -1))
             fin()
             w9t, ut = ops.pack_conv3x3(wflat, cout, cin, transpose=True, want_u=self.WINOGRAD)
-            self.give(x, ops.conv3x3(dy, w9t, None, cin, 1, 1.0, u=ut).view(-1, cin), owned=True)
+            if x.g is not None and x.g.is_contiguous():
+                # second consumer of x (a ResidualBlock's input feeds conv a and the shortcut): accumulate in the convolution's epilogue
+                x.g = ops.conv3x3(dy, w9t, None, cin, 1, 1.0, res=x.g.view(B, H, W, cin), u=ut).view(-1, cin)
+                x.own = True
+            else:
+                self.give(x, ops.conv3x3(dy, w9t, None, cin, 1, 1.0, u=ut).view(-1, cin), owned=True)
         self.nodes.append(bwd)
         return y, (B, Ho, Wo)
 

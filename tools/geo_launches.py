@@ -23,6 +23,25 @@ def main():
     batch = synthetic.make_batch(cfg.train_batch_size, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, BM.hip_fps(dev), BM.hip_nearest(dev),
                                  seed=cfg.seed, n_circle=512, device=dev)
     up.step(batch); torch.cuda.synchronize()
+    # second hook: (entry point, rows, C) of every call with its HIP-event time -> which passes run over the big row maps
+    protos, recs, orig = _lib.prototypes(), [], _lib.call
+    def hook(name, *args, **kw):
+        names = protos[name][2]
+        a = dict(zip(names, args))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); rc = orig(name, *args, **kw); e1.record()
+        recs.append((name, int(a.get("rows", a.get("nseg", 0)) or 0), int(a.get("C", a.get("n_out", a.get("n", 0))) or 0), e0, e1))
+        return rc
+    _lib.call = hook
+    up.step(batch); torch.cuda.synchronize()
+    _lib.call = orig
+    import collections
+    agg = collections.OrderedDict()
+    for name, rows, C, e0, e1 in recs:
+        d = agg.setdefault((name, rows, C), [0, 0.0]); d[0] += 1; d[1] += e0.elapsed_time(e1)
+    print("entry point (rows, C)                                   calls      ms")
+    for (name, rows, C), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+        print("%-40s %8d %5d %5d %7.2f" % (name, rows, C, n, ms))
     with CallTimer() as ct:
         up.step(batch); torch.cuda.synchronize()
     tab = ct.table()
