@@ -67,6 +67,9 @@ class PipelinedRegistrationGraph:
     back to back each phase leaves the other's resource idle; batches are independent, so the pipeline changes no
     result -- every batch still goes through exactly Test_Agent.py:150-170 -- only WHEN its two phases run.
 
+    Inside the two stages the models' own fork_join branches run sequentially (a fork issued from a forked stream cannot be captured
+    on this ROCm build): the pipeline trades the intra-stage concurrency for the inter-stage one.
+
     Per replay the device does one geo forward and one agent loop = the work of one registration step; `run()` returns the final
     pose of the PREVIOUS batch (pipeline depth 2: call `flush()` for the last one).  Throughput, not latency: the latency of one
     batch is that of RegistrationGraph (geo + loop back to back) or a little more."""
