@@ -76,10 +76,14 @@ class PipelinedRegistrationGraph:
 
     STABLE_KEYS = ("pc", "K", "P")
 
+    # Measured alternative, off: one hipGraph PER STAGE replayed on two streams, so that each stage keeps its own fork_join branches.
+    # 382.7 it/s fp32 / 703.9 bf16 = the unpipelined rate, against 408.4 / 804.9 for the single graph: two graph launches on two
+    # streams do not overlap on this runtime (CMR_PIPE_TWO_GRAPHS=1 to repeat the measurement).
+    TWO_GRAPHS = __import__("os").environ.get("CMR_PIPE_TWO_GRAPHS", "0") == "1"
+
     def __init__(self, geo_model, agent, config, example_batch, warmup=2):
         self.geo, self.agent, self.cfg = geo_model, agent, config
         self.static_in = {k: example_batch[k].clone() for k in INPUT_KEYS if k in example_batch}
-        self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
@@ -87,11 +91,26 @@ class PipelinedRegistrationGraph:
             self.geo(data)                                  # prime: batch "-1" = the example batch
             self.stable = self._snapshot(data)
             for _ in range(warmup):
-                self._iteration()
+                if self.TWO_GRAPHS:
+                    self._geo_stage(); self._agent_loop()
+                else:
+                    self._iteration()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.static_pose = self._iteration()
+        if self.TWO_GRAPHS:
+            # A fork issued from a forked stream cannot be captured on this ROCm build, and both stages fork inside
+            # (image / point tower, heads; the agent's 2-D / 3-D branches).  So each stage is its OWN graph, captured at nesting depth
+            # 0, and the two graphs are replayed on two streams per step; the hand-over copies follow on the caller's stream.
+            self.s_geo, self.s_agent = torch.cuda.Stream(), torch.cuda.Stream()
+            self.graph_geo, self.graph_agent = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph_geo):
+                self._fresh = self._agent_inputs(self._geo_stage())
+            with torch.no_grad(), torch.cuda.graph(self.graph_agent):
+                self.static_pose = self._agent_loop()
+        else:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.static_pose = self._iteration()
 
     @staticmethod
     def _agent_inputs(data):
@@ -153,10 +172,27 @@ class PipelinedRegistrationGraph:
             for k, buf in self.static_in.items():
                 if batch[k].data_ptr() != buf.data_ptr():
                     buf.copy_(batch[k], non_blocking=True)
-        self.graph.replay()
+        self._replay()
         return self.static_pose
+
+    def _replay(self):
+        if not self.TWO_GRAPHS:
+            self.graph.replay()
+            return
+        main = torch.cuda.current_stream()
+        self.s_geo.wait_stream(main)
+        self.s_agent.wait_stream(main)
+        with torch.cuda.stream(self.s_geo):
+            self.graph_geo.replay()
+        with torch.cuda.stream(self.s_agent):
+            self.graph_agent.replay()
+        main.wait_stream(self.s_geo)
+        main.wait_stream(self.s_agent)
+        with torch.no_grad():
+            for k, v in self._fresh.items():                # hand batch i over to the next replay's agent stage
+                self.stable[k].copy_(v)
 
     def flush(self):
         """One more replay so that the last submitted batch's agent loop runs; returns its pose (the geo stage re-runs the last inputs)."""
-        self.graph.replay()
+        self._replay()
         return self.static_pose
