@@ -56,7 +56,7 @@ def main():
                                         hip_fps(dev), hip_nearest(dev), seed=config.seed + i, n_circle=16, device=dev)
             geo_model(data)
             pose_source, pose_target = env.init(data)
-            pose_target = env.to_disentangled(pose_target, data['pc'])
+            pose_target = env.to_disentangled(pose_target, data['pc'], data=data)
             for _ in range(config.action_num):
                 s2, s3 = env.observation_from_a_pose(data, pose_source, materialize_state_2d=False)
                 r_logits, t_logits, _ = agent(s2, s3)

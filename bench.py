@@ -91,7 +91,7 @@ def registration_step(geo, agent, cfg, batch):
     data = dict(batch)
     geo(data)
     pose, target = env.init(data)
-    target = env.to_disentangled(target, data['pc'])
+    target = env.to_disentangled(target, data['pc'], data=data)
     for _ in range(cfg.action_num):
         s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
         r, t, _ = agent(s2, s3)

@@ -35,7 +35,8 @@ class _ObsContext:
         if c != 64:
             raise ValueError("observation kernels are instantiated for 64-d geometric features")
         self.K = data['K'].to(dev).contiguous()
-        self.mean4 = ops.colmean(self.pc4, self.B, self.N)
+        cen = data.get('_cmr_centroid')
+        self.mean4 = cen[1] if (cen is not None and cen[0] is pc) else _centroid(pc, self.pc4)
         cells = self.B * self.h * self.w
         # scatter-mean accumulators: zeroed once here, re-zeroed sparsely by every observation_finalize(clear=True)
         self.acc = torch.zeros((cells, 64), dtype=torch.float32, device=dev)
@@ -53,12 +54,28 @@ def _context(data):
     return ctx
 
 
-@torch.no_grad()
-def to_disentangled(poses, pcd):
-    """t <- t - mu + R mu with mu the centroid of the cloud; mutates and returns `poses`."""
+def _centroid(pcd, pc4=None):
+    """Per-sample centroid rows [B,4] of a cloud [B,3(+),N]."""
     B, _, N = pcd.shape
-    pc4 = ops.planar_to_rows(pcd[:, 0:3, :].contiguous(), 4)
-    ops.to_disentangled(poses, ops.colmean(pc4, B, N))
+    if pc4 is None:
+        pc4 = ops.planar_to_rows(pcd[:, 0:3, :].contiguous(), 4)
+    return ops.colmean(pc4, B, N)
+
+
+@torch.no_grad()
+def to_disentangled(poses, pcd, data=None):
+    """t <- t - mu + R mu with mu the centroid of the cloud; mutates and returns `poses`.  data (optional, the batch dict `pcd` belongs
+    to): the centroid is left there for the observations of the same registration, which need it too (and the row layout of the
+    cloud the geo model left there is used instead of converting it again)."""
+    pc4 = None
+    if data is not None and data.get('pc') is pcd:
+        cl = data.get('_cmr')
+        if cl is not None and 'geo' in cl and cl['geo'].pc4.device == pcd.device:
+            pc4 = cl['geo'].pc4
+    mean4 = _centroid(pcd, pc4)
+    if data is not None and data.get('pc') is pcd:
+        data['_cmr_centroid'] = (pcd, mean4)
+    ops.to_disentangled(poses, mean4)
     return poses
 
 
@@ -89,12 +106,24 @@ def observation_from_a_pose(data, RT, materialize_state_2d=True):
     return obs2d, obs3d
 
 
+_EYES = {}
+
+
+def _identity(B, dev):
+    key = (B, str(dev))
+    if key not in _EYES:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return torch.eye(4, device=dev).repeat(B, 1, 1)      # never cache a tensor that lives in a graph's private pool
+        _EYES[key] = torch.eye(4, device=dev).repeat(B, 1, 1)
+    return _EYES[key]
+
+
 def init(data):
     """Identity start pose and the ground-truth pose (for the expert)."""
     dev = data['pc'].device
     B = data['pc'].shape[0]
     pose_target = data['P'].to(dev)
-    pose_source = torch.eye(4, device=dev).repeat(B, 1, 1)
+    pose_source = _identity(B, dev).clone()                  # one copy launch instead of eye + repeat (3)
     return pose_source, pose_target
 
 

@@ -32,7 +32,7 @@ class RegistrationGraph:
         data = dict(self.static_in)
         self.geo(data)
         pose, target = env.init(data)
-        env.to_disentangled(target, data['pc'])
+        env.to_disentangled(target, data['pc'], data=data)
         for _ in range(self.cfg.action_num):
             s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
             r, t, v = self.agent(s2, s3)
@@ -129,7 +129,7 @@ class PipelinedRegistrationGraph:
     def _agent_loop(self):
         data = self._stable_view()
         pose, target = env.init(data)
-        env.to_disentangled(target, data['pc'])
+        env.to_disentangled(target, data['pc'], data=data)
         for _ in range(self.cfg.action_num):
             s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
             r, t, v = self.agent(s2, s3)
