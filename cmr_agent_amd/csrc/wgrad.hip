@@ -585,6 +585,113 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same row-map weight gradient with the operands staged in LDS (round 3), for n, k in {32, 64, 96, 128}: linear_wgrad_kernel
+// fetches every MFMA operand with a dword load (lane = channel), reads dY once per k block and X once per n block of the workgroup,
+// and sits at ~2 TB/s algorithmic on the 524 288-row point maps (130 us for 268 MB).  Here a workgroup stages blocks of 32 rows of
+// dY and X with float4 loads (whole rows, each byte read ONCE per workgroup) into a double-buffered LDS tile, holds the WHOLE
+// [n x k] gradient in its four waves' accumulators ((n / 32) (k / 32) / 4 tiles per wave) and walks the row blocks with a static
+// stride; operands are ds_read_b32 (lane = channel, the two lane halves = the two rows of a 32x32x2 step; row stride = width + 32
+// floats, so the halves fall 32 banks apart).  One __syncthreads per block; 3 workgroups per CU at 64 x 64.  Partials go to the
+// workspace in linear_wgrad_reduce_kernel's layout (one n block, one k block, gridDim.x slices).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NT, int KT>
+__global__ __launch_bounds__(256) void linear_wgrad_lds_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
+                                                               int64_t rows, float* __restrict__ part, float* __restrict__ part_b) {
+  constexpr int N = 32 * NT, K = 32 * KT, DS = N + 32, XS = K + 32, R = 32;
+  constexpr int TPW = NT * KT / 4 > 0 ? NT * KT / 4 : 1;          // tiles per wave (NT KT in {1, 2, 4, ...}: waves beyond the tile count idle)
+  constexpr int NLD = (R * N / 4 + 255) / 256, NLX = (R * K / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float lw_smem[];
+  float* Dl = lw_smem;                                   // [2][R][DS]
+  float* Xl = lw_smem + 2 * R * DS;                      // [2][R][XS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int64_t nblocks = (rows + R - 1) / R;
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  const bool active = wave * TPW < NT * KT;
+
+  auto load_block = [&](int64_t blk, f32x4 (&dv)[NLD], f32x4 (&xv)[NLX]) {     // branch-free: clamped row, masked at the LDS store
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i, r = e / (N / 4), c = e % (N / 4);
+      int64_t row = blk * R + (r < R ? r : R - 1);
+      row = row < rows ? row : rows - 1;
+      dv[i] = *reinterpret_cast<const f32x4*>(dy + row * lddy + 4 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int e = tid + 256 * i, r = e / (K / 4), c = e % (K / 4);
+      int64_t row = blk * R + (r < R ? r : R - 1);
+      row = row < rows ? row : rows - 1;
+      xv[i] = *reinterpret_cast<const f32x4*>(x + row * ldx + 4 * c);
+    }
+  };
+  auto store_block = [&](int64_t blk, int buf, const f32x4 (&dv)[NLD], const f32x4 (&xv)[NLX]) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = tid + 256 * i, r = e / (N / 4), c = e % (N / 4);
+      if (r < R) *reinterpret_cast<f32x4*>(Dl + (buf * R + r) * DS + 4 * c) = (blk < nblocks && blk * R + r < rows) ? dv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int e = tid + 256 * i, r = e / (K / 4), c = e % (K / 4);
+      if (r < R) *reinterpret_cast<f32x4*>(Xl + (buf * R + r) * XS + 4 * c) = (blk < nblocks && blk * R + r < rows) ? xv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  f32x4 dv[NLD], xv[NLX];
+  int64_t blk = blockIdx.x;
+  load_block(blk < nblocks ? blk : nblocks - 1, dv, xv);
+  store_block(blk, 0, dv, xv);
+  __syncthreads();
+  int buf = 0;
+  for (; blk < nblocks; blk += gridDim.x) {
+    const int64_t nb = blk + gridDim.x;
+    load_block(nb < nblocks ? nb : nblocks - 1, dv, xv);          // next block of this workgroup: in flight under the MFMAs
+    if (active) {
+      const float* dl = Dl + buf * R * DS + l31;
+      const float* xl = Xl + buf * R * XS + l31;
+#pragma unroll
+      for (int j = 0; j < R / 2; ++j) {
+        const int rr = 2 * j + h;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
+          const float a = dl[rr * DS + 32 * nt];
+          const float b = xl[rr * XS + 32 * kt];
+          if (kt == 0) bsum += a;
+          acc[t] = cmr_mfma32(a, b, acc[t]);
+        }
+      }
+    }
+    store_block(nb, buf ^ 1, dv, xv);                             // the other buffer: last read one iteration ago, behind a barrier
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (!active) return;
+  float* out = part + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(int64_t)(nt * 32 + cmr_mfma_row(r, lane)) * K + kt * 32 + l31] = acc[t][r];
+  }
+  if (part_b) {
+    // bsum holds this lane's rows of channel(s) 32 nt + l31 for the tiles with kt == 0: with TPW > 1 and KT < TPW several nt share the
+    // register -- handled by the host (part_b only with KT >= TPW, i.e. one nt per wave among its kt == 0 tiles)
+    bsum += __shfl_xor(bsum, 32);
+    const int tile0 = wave * TPW, nt0 = tile0 / KT;
+    if (h == 0 && tile0 % KT == 0) part_b[(int64_t)blockIdx.x * N + nt0 * 32 + l31] = bsum;
+  }
+}
+
 // outputs [0, n k): dW entries; [n k, n k + n): db entries (when part_b)
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int nslices,
                                                                   int npad, int kpad, int nblk, int n, int k, float* __restrict__ dw,
@@ -707,6 +814,17 @@ inline WgLdsPlan wgrad_lds_plan(int B, int H, int W, int Cin, int Cout) {
   return p;
 }
 
+static int g_lwgrad_lds = 1;
+// Measured (tools/lwgrad_bench.py, profiles/r03_lwgrad_bench.txt): 524 288 rows 64x64 122 -> 84 us, 128x64 218 -> 129 us; 163 840 rows 5-20 %
+// faster; at 40 960 rows and below the direct kernel's finer slices win (31 vs 38 us): the staged kernel takes maps of >= 65 536 rows.
+static int64_t g_lwgrad_min_rows = 65536;
+extern "C" int cmr_set_linear_wgrad_variant(int lds_staged) {
+  const int old = g_lwgrad_lds;
+  g_lwgrad_lds = lds_staged ? 1 : 0;
+  g_lwgrad_min_rows = lds_staged == 2 ? 8192 : 65536;      // 2: also mid-size maps (tests of the ragged cases)
+  return old;
+}
+
 extern "C" int cmr_set_wgrad_variant(int lds_staged) {
   const int old = g_wgrad_lds;
   g_wgrad_lds = lds_staged ? 1 : 0;
@@ -827,7 +945,12 @@ inline LwPlan lw_plan(int64_t rows, int n, int k) {
 
 extern "C" int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k) {
   const LwPlan p = lw_plan(rows, n, k);
-  return (p.part_floats + p.partb_floats) * (int64_t)sizeof(float);
+  int64_t bytes = (p.part_floats + p.partb_floats) * (int64_t)sizeof(float);
+  if (n % 32 == 0 && k % 32 == 0 && n <= 128 && k <= 128) {          // the LDS-staged variant: up to 768 whole-gradient partials
+    const int64_t lds = (int64_t)768 * ((int64_t)n * k + n) * (int64_t)sizeof(float);
+    if (lds > bytes) bytes = lds;
+  }
+  return bytes;
 }
 
 extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
@@ -838,6 +961,44 @@ extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const 
   CMR_REQUIRE(p.nblk <= 65535 && p.kblk <= 65535);
   CMR_REQUIRE(ws_bytes >= (p.part_floats + p.partb_floats) * (int64_t)sizeof(float));
   float* part = (float*)ws;
+  {
+    // LDS-staged variant: whole-row float4 staging, the full [n x k] gradient per workgroup (see linear_wgrad_lds_kernel)
+    const int nt = n / 32, kt = k / 32;
+    const bool shape_ok = n % 32 == 0 && k % 32 == 0 && ((nt == 2 && kt == 2) || (nt == 4 && kt == 2) || (nt == 2 && kt == 4) || (nt == 4 && kt == 4) ||
+                                                         (nt == 1 && kt == 2) || (nt == 2 && kt == 1) || (nt == 1 && kt == 4) || (nt == 4 && kt == 1));
+    if (g_lwgrad_lds && shape_ok && rows >= g_lwgrad_min_rows && lddy % 4 == 0 && ldx % 4 == 0 && cmr_aligned16(dy) && cmr_aligned16(x)) {
+      const int64_t nblocks = (rows + 31) / 32;
+      const size_t smem_wg = (size_t)2 * 32 * (n + k + 64) * sizeof(float);
+      int per_cu = (int)((size_t)160 * 1024 / smem_wg);  // 3 workgroups per CU at 64 x 64, 2 at 128 x 64, 1 at 128 x 128
+      if (per_cu > 3) per_cu = 3;
+      int groups = 256 * per_cu;
+      if (groups > nblocks / 8) groups = (int)(nblocks / 8 > 0 ? nblocks / 8 : 1);    // >= 8 row blocks per workgroup: every partial is 4 n k bytes the reduction reads back
+      const int64_t need = ((int64_t)groups * n * k + (int64_t)groups * n) * (int64_t)sizeof(float);
+      if (ws_bytes >= need) {
+        float* pb = db ? part + (int64_t)groups * n * k : nullptr;
+        const size_t smem = (size_t)2 * 32 * (n + k + 64) * sizeof(float);
+#define CMR_LWL(NT_, KT_)                                                                                                             \
+  {                                                                                                                                   \
+    static CmrSmemCache granted{};                                                                                                    \
+    if (cmr_grant_smem(reinterpret_cast<const void*>(linear_wgrad_lds_kernel<NT_, KT_>), smem, granted) != CMR_OK) return CMR_ELAUNCH;   \
+    hipLaunchKernelGGL((linear_wgrad_lds_kernel<NT_, KT_>), dim3(groups), dim3(256), smem, stream, dy, lddy, x, ldx, rows, part, pb);   \
+  }
+        if (nt == 2 && kt == 2) CMR_LWL(2, 2)
+        else if (nt == 4 && kt == 2) CMR_LWL(4, 2)
+        else if (nt == 2 && kt == 4) CMR_LWL(2, 4)
+        else if (nt == 4 && kt == 4) CMR_LWL(4, 4)
+        else if (nt == 1 && kt == 2) CMR_LWL(1, 2)
+        else if (nt == 2 && kt == 1) CMR_LWL(2, 1)
+        else if (nt == 1 && kt == 4) CMR_LWL(1, 4)
+        else CMR_LWL(4, 1)
+#undef CMR_LWL
+        const int64_t outs = (int64_t)n * k + (db ? n : 0);
+        hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((outs + RED_OUT - 1) / RED_OUT)), dim3(256), 0, stream, (const float*)part,
+                           (const float*)pb, groups, n, k, 1, n, k, dw, lddw, accumulate, db, accumulate_db);
+        return cmr_launch_status();
+      }
+    }
+  }
   float* part_b = db ? part + p.part_floats : nullptr;
   const dim3 grid(p.slices, p.nblk, p.kblk);
 #define CMR_LW(NT, KT) hipLaunchKernelGGL((linear_wgrad_kernel<NT, KT>), grid, dim3(256), 0, stream, dy, lddy, n, x, ldx, k, rows, part, part_b)

@@ -452,6 +452,10 @@ int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k);
 int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
                          int64_t lddw, int accumulate, float* db, int accumulate_db, void* ws, int64_t ws_bytes,
                          hipStream_t stream);
+/* A/B switch: 1 (default) = row maps of >= 65 536 rows with n, k multiples of 32 up to 128 take the LDS-staged kernel (whole-row
+ * float4 staging, the full gradient per workgroup), 2 = from 8192 rows on (tests), 0 = the direct kernel everywhere.  Same sums in
+ * another order; returns the previous on / off setting. */
+int cmr_set_linear_wgrad_variant(int lds_staged);
 /* nn.Conv2d weight [Cout][Cin][3][3] -> operand layouts of the forward kernels (w9 [9][Co'][Ci'] and the Winograd
  * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx].  bf16_frag
  * (optional) receives the bf16 A fragments of cmr_conv3x3_bf16_nhwc_f32 for cout groups of 32 * bf16_nt. */

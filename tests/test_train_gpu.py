@@ -134,6 +134,37 @@ def test_conv3x3_weight_and_data_gradients(ops, B, H, W, cin, cout):
     close(dx2.permute(0, 3, 1, 2), x.grad, 5e-5, "conv dgrad (direct kernel)")
 
 
+@pytest.mark.parametrize("rows,n,k,bias", [(8192, 64, 64, True), (40961, 64, 64, False), (20000, 128, 64, True), (9000, 64, 128, True), (8200, 128, 128, True),
+                                           (163840, 64, 64, True), (10007, 32, 64, True), (12000, 64, 32, False), (8193, 128, 32, True)])
+def test_linear_weight_gradient_lds_staged_kernel(ops, rows, n, k, bias):
+    """Row maps of >= 8192 rows with n, k in {32, 64, 128} take linear_wgrad_lds_kernel (whole-row staging, the full gradient per
+    workgroup): against float64 and against the direct kernel (cmr_set_linear_wgrad_variant(0)); ragged row counts, strided operands,
+    accumulation into an existing gradient."""
+    from cmr_agent_amd import _lib
+    dyf, xf = rnd(rows, n + 8, seed=41), rnd(rows, k + 4, seed=42)
+    dy, x = dyf[:, :n], xf[:, :k]                                   # strided views (ld = n + 8 / k + 4)
+    want = dy.double().t() @ x.double()
+    wantb = dy.double().sum(0)
+    d = lambda t: t.to(DEV)
+    dyd, xd = d(dyf)[:, :n], d(xf)[:, :k]
+    dw0 = rnd(n, k, seed=43)
+    outs = []
+    for variant in (2, 0):                                       # 2 = staged kernel from 8192 rows on (default: from 65 536)
+        old = _lib.load().cmr_set_linear_wgrad_variant(variant)
+        try:
+            dw, db = d(dw0).clone(), torch.zeros(n, device=DEV)
+            ops.linear_wgrad(dyd, xd, dw, dw.stride(0), accumulate=True, db=db if bias else None)
+        finally:
+            _lib.load().cmr_set_linear_wgrad_variant(1)
+        outs.append((dw.cpu(), db.cpu()))
+    scale = float(want.abs().max())
+    for dw, db in outs:
+        assert float((dw.double() - (want + dw0.double())).abs().max()) <= 3e-5 * scale
+        if bias:
+            assert float((db.double() - wantb).abs().max()) <= 3e-5 * float(wantb.abs().max())
+    assert not torch.equal(outs[0][0], outs[1][0])                 # two different kernels ran
+
+
 @pytest.mark.parametrize("rows,n,k", [(4001, 8, 8), (3000, 64, 8), (5555, 128, 64), (2048, 64, 128), (1000, 64, 64), (9000, 128, 128), (7, 128, 128),
                                       (640, 1024, 64), (2048, 64, 1024), (640, 64, 4096), (777, 200, 136), (40000, 36, 68)])
 def test_linear_weight_gradient(ops, rows, n, k):
