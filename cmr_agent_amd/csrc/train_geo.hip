@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 
 // ---- softmax attention backward (8 heads x 8 dims; forward = cmr_mha_f32) ------------------------------------------------------
 // P = softmax(Q K^T / sqrt 8); O = P V.  dV = P^T dO; dS = P o (dO V^T - D), D_i = dO_i . O_i; dQ = dS K / sqrt 8; dK = dS^T Q / sqrt 8.
-// Kernel 1: one thread per (query, head), K / V of the head in LDS: log-sum-exp of the row, D, dQ (written) -- lse / D are kept
-// for kernel 2: one thread per (key, head), Q / dO / lse / D of the head in LDS: dK, dV.  No atomics.
+// Kernel 1: four lanes per (query, head), K / V of the head in LDS: log-sum-exp of the row (online, one pass), D, dQ (written) -- lse / D
+// are kept for kernel 2: four lanes per (key, head), Q / dO / lse / D of the head in LDS: dK, dV.  No atomics.
 constexpr int AH_DH = 8, AH_NH = 8;
 
 // With dropout on the probabilities (forward cmr_mha_dropout_f32): O = (P o M) V with M = mask / (1 - p), so dV = (P o M)^T dO and
@@ -308,8 +308,12 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
     st4(&vs[t * AH_DH + half], ld4(v + ((int64_t)b * Tk + t) * ldv + head * AH_DH + half));
   }
   __syncthreads();
-  const int tq = blockIdx.x * 256 + threadIdx.x;
-  if (tq >= Tq) return;
+  // four lanes per query (keys t = sub, sub + 4, ...): the one-thread-per-query form walked the keys three times in a serial loop of
+  // up to 418 iterations, 64 workgroups on the chip -- 96 us for an 80 x 256-token problem
+  const int sub = threadIdx.x & 3;
+  const int tqr = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool live = tqr < Tq;
+  const int tq = live ? tqr : Tq - 1;                   // clamped: every lane takes part in the shuffles
   const int64_t row = (int64_t)b * Tq + tq;
   float qv[8], gv[8], ov[8];
 #pragma unroll
@@ -321,25 +325,29 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
   float D = 0.f;
 #pragma unroll
   for (int d = 0; d < 8; ++d) D += gv[d] * ov[d];
-  float m = -INFINITY;
-  for (int t = 0; t < Tk; ++t) {
+  // log-sum-exp of the row: online (max, sum) over this lane's keys, combined over the four lanes
+  float m = -INFINITY, l = 0.f;
+  for (int t = sub; t < Tk; t += 4) {
     float sc = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) sc += qv[d] * ks[t * 8 + d];
-    m = fmaxf(m, sc * scale);
+    sc *= scale;
+    const float mn = fmaxf(m, sc);
+    l = l * expf(m - mn) + expf(sc - mn);
+    m = mn;
   }
-  float l = 0.f;
-  for (int t = 0; t < Tk; ++t) {
-    float sc = 0.f;
 #pragma unroll
-    for (int d = 0; d < 8; ++d) sc += qv[d] * ks[t * 8 + d];
-    l += expf(sc * scale - m);
+  for (int x = 1; x <= 2; x <<= 1) {
+    const float mo = __shfl_xor(m, x), lo = __shfl_xor(l, x);
+    const float mn = fmaxf(m, mo);
+    l = (m == -INFINITY ? 0.f : l * expf(m - mn)) + (mo == -INFINITY ? 0.f : lo * expf(mo - mn));
+    m = mn;
   }
   const float L = m + logf(l);
   const uint64_t seed = DROP ? (uint64_t)seed_ptr[0] : 0;
   const uint64_t mrow = (((uint64_t)b * AH_NH + head) * Tq + tq) * Tk;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int t = 0; t < Tk; ++t) {
+  for (int t = sub; t < Tk; t += 4) {
     float sc = 0.f, dp = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
@@ -351,6 +359,12 @@ __global__ __launch_bounds__(256) void mha_bwd_dq_kernel(const float* __restrict
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] += ds * ks[t * 8 + d];
   }
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    acc[d] += __shfl_xor(acc[d], 1);
+    acc[d] += __shfl_xor(acc[d], 2);
+  }
+  if (!live || sub != 0) return;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
     float* dst = dq + row * lddq + head * 8 + d;
@@ -383,8 +397,10 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
     ds_[t] = dsum[((int64_t)b * Tq + t) * 8 + head];
   }
   __syncthreads();
-  const int tk = blockIdx.x * 256 + threadIdx.x;
-  if (tk >= Tk) return;
+  const int sub = threadIdx.x & 3;                      // four lanes per key (queries t = sub, sub + 4, ...)
+  const int tkr = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool live = tkr < Tk;
+  const int tk = live ? tkr : Tk - 1;
   const int64_t row = (int64_t)b * Tk + tk;
   float kvv[8], vv[8];
 #pragma unroll
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
   float ak[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const uint64_t seed = DROP ? (uint64_t)seed_ptr[0] : 0;
   const uint64_t mhead = ((uint64_t)b * AH_NH + head) * Tq;
-  for (int t = 0; t < Tq; ++t) {
+  for (int t = sub; t < Tq; t += 4) {
     float sc = 0.f, dp = 0.f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
@@ -416,6 +432,12 @@ __global__ __launch_bounds__(256) void mha_bwd_dkv_kernel(const float* __restric
       ak[d] += dsv * qs[t * 8 + d];
     }
   }
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    ak[d] += __shfl_xor(ak[d], 1); ak[d] += __shfl_xor(ak[d], 2);
+    av[d] += __shfl_xor(av[d], 1); av[d] += __shfl_xor(av[d], 2);
+  }
+  if (!live || sub != 0) return;
 #pragma unroll
   for (int d = 0; d < 8; ++d) {
     float* a = dk + row * lddk + head * 8 + d;
@@ -806,9 +828,9 @@ static int mha_bwd_launch(const float* q, int64_t ldq, const float* k, int64_t l
   const float scale = 0.35355339059327373f;
   const uint32_t thr = cmr_drop_threshold(p);
   const float ks = 1.f / (1.f - p);
-  hipLaunchKernelGGL(mha_bwd_dq_kernel<DROP>, dim3((Tq + 255) / 256, AH_NH, B), dim3(256), sm1, stream, q, ldq, k, ldk, v, ldv, o, ldo, dout,
+  hipLaunchKernelGGL(mha_bwd_dq_kernel<DROP>, dim3((Tq + 63) / 64, AH_NH, B), dim3(256), sm1, stream, q, ldq, k, ldk, v, ldv, o, ldo, dout,
                      lddo, dq, lddq, acc_dq, lse, dsum, Tq, Tk, scale, thr, ks, seed, (uint64_t)site);
-  hipLaunchKernelGGL(mha_bwd_dkv_kernel<DROP>, dim3((Tk + 255) / 256, AH_NH, B), dim3(256), sm2, stream, q, ldq, k, ldk, v, ldv, dout, lddo,
+  hipLaunchKernelGGL(mha_bwd_dkv_kernel<DROP>, dim3((Tk + 63) / 64, AH_NH, B), dim3(256), sm2, stream, q, ldq, k, ldk, v, ldv, dout, lddo,
                      (const float*)lse, (const float*)dsum, dk, lddk, acc_dk, dv, lddv, acc_dv, Tq, Tk, scale, thr, ks, seed, (uint64_t)site);
   return cmr_launch_status();
 }
