@@ -101,28 +101,60 @@ __global__ __launch_bounds__(256) void circle_pairs_kernel(const float* __restri
 
 __device__ __forceinline__ float softplus20(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // F.softplus defaults
 
-// one workgroup per sample, thread t: row t and column t log-sum-exps; partial[b] = sum_t (row term + column term)
-__global__ __launch_bounds__(512) void circle_reduce_kernel(const float* __restrict__ EP, const float* __restrict__ EN, int n,
-                                                            float log_scale, float* __restrict__ part) {
+// Row and column log-sum-exps of EP / EN and their softplus terms: terms[b][0 .. n) = rows, [n .. 2 n) = columns.
+// Blocks [0, ceil(n / 4)): four waves = four rows, lanes along the row (coalesced), online (max, sum) per lane then a wave reduction.
+// Blocks beyond: 256 threads = 256 columns, each walks the rows of its column (consecutive threads read consecutive addresses).
+// (The first version gave one workgroup a whole sample and one THREAD a row and a column: 2 x 512 strided serial steps, 8 workgroups on
+// the chip -- 630 us at n = 512 against ~10 us of memory time.)
+__device__ __forceinline__ void lse_push(float& m, float& s, float v) {
+  const float mn = fmaxf(m, v);
+  s = s * expf(m - mn) + expf(v - mn);
+  m = mn;
+}
+__device__ __forceinline__ void lse_merge(float& m, float& s, float mo, float so) {
+  const float mn = fmaxf(m, mo);
+  s = (m == -INFINITY ? 0.f : s * expf(m - mn)) + (mo == -INFINITY ? 0.f : so * expf(mo - mn));
+  m = mn;
+}
+
+__global__ __launch_bounds__(256) void circle_terms_kernel(const float* __restrict__ EP, const float* __restrict__ EN, int n, float log_scale,
+                                                           float* __restrict__ terms) {
+  const int b = blockIdx.y;
+  const float* ep = EP + (int64_t)b * n * n;
+  const float* en = EN + (int64_t)b * n * n;
+  const int row_blocks = (n + 3) / 4;
+  if ((int)blockIdx.x < row_blocks) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    float mp = -INFINITY, sp = 0.f, mn = -INFINITY, sn = 0.f;
+    for (int k = lane; k < n; k += 64) {
+      lse_push(mp, sp, ep[(int64_t)r * n + k]);
+      lse_push(mn, sn, en[(int64_t)r * n + k]);
+    }
+#pragma unroll
+    for (int x = 32; x >= 1; x >>= 1) {
+      lse_merge(mp, sp, __shfl_xor(mp, x), __shfl_xor(sp, x));
+      lse_merge(mn, sn, __shfl_xor(mn, x), __shfl_xor(sn, x));
+    }
+    if (lane == 0) terms[(int64_t)b * 2 * n + r] = softplus20((mp + logf(sp)) + (mn + logf(sn))) / log_scale;
+  } else {
+    const int c = (blockIdx.x - row_blocks) * 256 + threadIdx.x;
+    if (c >= n) return;
+    float mp = -INFINITY, sp = 0.f, mn = -INFINITY, sn = 0.f;
+    for (int k = 0; k < n; ++k) {
+      lse_push(mp, sp, ep[(int64_t)k * n + c]);
+      lse_push(mn, sn, en[(int64_t)k * n + c]);
+    }
+    terms[(int64_t)b * 2 * n + n + c] = softplus20((mp + logf(sp)) + (mn + logf(sn))) / log_scale;
+  }
+}
+
+// partial[b] = sum of the 2 n terms of sample b: thread t adds terms t, t + 512, ... in order, then a fixed tree
+__global__ __launch_bounds__(512) void circle_reduce_kernel(const float* __restrict__ terms, int n, float* __restrict__ part) {
   __shared__ float red[512];
   const int b = blockIdx.x, t = threadIdx.x;
   float term = 0.f;
-  for (int r = t; r < n; r += 512) {
-    const float* ep = EP + (int64_t)b * n * n;
-    const float* en = EN + (int64_t)b * n * n;
-    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    for (int k = 0; k < n; ++k) {
-      m[0] = fmaxf(m[0], ep[(int64_t)r * n + k]); m[1] = fmaxf(m[1], en[(int64_t)r * n + k]);
-      m[2] = fmaxf(m[2], ep[(int64_t)k * n + r]); m[3] = fmaxf(m[3], en[(int64_t)k * n + r]);
-    }
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < n; ++k) {
-      s[0] += expf(ep[(int64_t)r * n + k] - m[0]); s[1] += expf(en[(int64_t)r * n + k] - m[1]);
-      s[2] += expf(ep[(int64_t)k * n + r] - m[2]); s[3] += expf(en[(int64_t)k * n + r] - m[3]);
-    }
-    const float lpr = m[0] + logf(s[0]), lnr = m[1] + logf(s[1]), lpc = m[2] + logf(s[2]), lnc = m[3] + logf(s[3]);
-    term += softplus20(lpr + lnr) / log_scale + softplus20(lpc + lnc) / log_scale;
-  }
+  for (int r = t; r < 2 * n; r += 512) term += terms[(int64_t)b * 2 * n + r];
   red[t] = term;
   __syncthreads();
   for (int st = 256; st >= 1; st >>= 1) {
@@ -157,7 +189,7 @@ extern "C" int cmr_focal_metrics_f32(const float* logits, int64_t ld, const int6
 }
 
 extern "C" int64_t cmr_circle_loss_workspace_bytes(int B, int n) {
-  return B <= 0 || n <= 0 ? 0 : ((int64_t)2 * B * n * n + B) * (int64_t)sizeof(float);
+  return B <= 0 || n <= 0 ? 0 : ((int64_t)2 * B * n * n + B + (int64_t)2 * B * n) * (int64_t)sizeof(float);
 }
 
 extern "C" int cmr_circle_loss_f32(const float* pc_feat, const float* img_feat, const int64_t* pc_idx, const int64_t* xy_int,
@@ -170,9 +202,12 @@ extern "C" int cmr_circle_loss_f32(const float* pc_feat, const float* img_feat, 
   float* EP = (float*)workspace;
   float* EN = EP + (int64_t)B * n * n;
   float* part = EN + (int64_t)B * n * n;
+  float* terms = part + B;
   hipLaunchKernelGGL(circle_pairs_kernel, dim3((n + 15) / 16, (n + 15) / 16, B), dim3(256), 0, stream, pc_feat, img_feat, pc_idx,
                      xy_int, xy_float, N, h, w, n, dist_thres, pos_margin, neg_margin, log_scale, EP, EN);
-  hipLaunchKernelGGL(circle_reduce_kernel, dim3(B), dim3(512), 0, stream, (const float*)EP, (const float*)EN, n, log_scale, part);
+  hipLaunchKernelGGL(circle_terms_kernel, dim3((n + 3) / 4 + (n + 255) / 256, B), dim3(256), 0, stream, (const float*)EP, (const float*)EN, n,
+                     log_scale, terms);
+  hipLaunchKernelGGL(circle_reduce_kernel, dim3(B), dim3(512), 0, stream, (const float*)terms, n, part);
   hipLaunchKernelGGL(circle_final_kernel, dim3(1), dim3(64), 0, stream, (const float*)part, B, n, lambda, out);
   return cmr_launch_status();
 }
