@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
                                                      const float* __restrict__ w3 /*[27][64] (ci,ky,kx major)*/,
                                                      const float* __restrict__ w1 /*[3][64]*/,
                                                      const float* __restrict__ bias /*[64] (both BN shifts)*/,
-                                                     float* __restrict__ y, int B, int H, int W, float slope) {
+                                                     float* __restrict__ y, int B, int H, int W, float slope, int out_bf16) {
   __shared__ __attribute__((aligned(16))) float ws[64 * 36];
   __shared__ __attribute__((aligned(16))) float tpatch[4 * 32 * 68];      // output transpose, one 32 x 64 patch per wave
   __shared__ __attribute__((aligned(16))) float bs[64];
@@ -549,7 +549,19 @@ __global__ __launch_bounds__(256) void stem_b_kernel(const float* __restrict__ t
     for (int i = 0; i < 8; ++i) rv[i] = *reinterpret_cast<const f32x4*>(&tp[(4 * i + (lane >> 4)) * 68 + 4 * (lane & 15)]);
 #pragma unroll
     for (int i = 0; i < 8; ++i) cmr_pin(rv[i]);
-    {
+    if (out_bf16) {                                                     // (uniform) the map stored as bf16: 16 lanes x 8 B = one pixel row
+      typedef float f2_t __attribute__((ext_vector_type(2)));
+      typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+      const int64_t p0 = tile * 32;
+      __bf16* yp = reinterpret_cast<__bf16*>(y) + p0 * 64 + (lane >> 4) * 64 + 4 * (lane & 15);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        uint2 w;
+        w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){rv[i][0], rv[i][1]}, b2_t));
+        w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f2_t){rv[i][2], rv[i][3]}, b2_t));
+        if (p0 + (lane >> 4) + 4 * i < total) *reinterpret_cast<uint2*>(yp + 4 * i * 64) = w;
+      }
+    } else {
       const int64_t p0 = tile * 32;                                     // (scalar)
       float* yp = y + p0 * 64 + (lane >> 4) * 64 + 4 * (lane & 15);
       if (p0 + 32 <= total) {
@@ -670,7 +682,7 @@ extern "C" int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin
 }
 
 extern "C" int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,
-                                  const float* b_b, float* tmp_nchw, float* y_nhwc, int B, int H, int W, float slope,
+                                  const float* b_b, float* tmp_nchw, void* y_nhwc, int out_bf16, int B, int H, int W, float slope,
                                   hipStream_t stream) {
   CMR_REQUIRE(x_nchw && w_a && b_a && w3 && w1 && b_b && tmp_nchw && y_nhwc && B > 0 && H > 0 && W > 0 && slope >= 0.f && slope <= 1.f);
   const int64_t total = (int64_t)B * H * W;
@@ -680,7 +692,8 @@ extern "C" int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const f
   CMR_REQUIRE((int64_t)6 * H * W < 0x7fffffff && cmr_aligned16(b_b) && cmr_aligned16(y_nhwc));
   const int64_t stiles = (total + 31) / 32;
   const unsigned sgrid = (unsigned)(stiles + 3) / 4 < 1024u ? (unsigned)((stiles + 3) / 4) : 1024u;
-  hipLaunchKernelGGL(stem_b_kernel, dim3(sgrid), dim3(256), 0, stream, tmp_nchw, w3, w1, b_b, y_nhwc, B, H, W, slope);
+  hipLaunchKernelGGL(stem_b_kernel, dim3(sgrid), dim3(256), 0, stream, tmp_nchw, w3, w1, b_b, static_cast<float*>(y_nhwc), B, H, W, slope,
+                     out_bf16);
   return cmr_launch_status();
 }
 

@@ -36,6 +36,7 @@ struct B16Args {
   int res_mul, bias_mul;
   int x_bf16, y_bf16;    // activations stored as bf16 NHWC (input / output): a convolution whose output only feeds another bf16 convolution
                          // writes the bf16 values that one would round its fp32 input to anyway -- same results, half the bytes
+  int res_bf16;          // the residual operand is a bf16 NHWC map (bf16-STORED towers: the block input of a ResidualBlock, round 3)
 };
 
 __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -351,10 +352,11 @@ int launch_b16(B16Args a, hipStream_t stream) {
 // takes two units per tile through the same 26 KB buffer, which is what lets two buffers sit next to the 72 KB of weights.
 // S = 2 (the strided convolutions of the down-sampling blocks, Cin = 64, NT = 2): a team's tile is 4 x 16 OUTPUT pixels (9 x 33 input
 // pixels: two 42 KB buffers still fit next to the weights), and its four waves are 2 pixel blocks x 2 cout tiles -- one accumulator each.
-template <int CIN, int NT, bool POOL, bool POST, int IO = 0, int S = 1>      // IO: bit 0 = bf16 input, bit 1 = bf16 output
+template <int CIN, int NT, bool POOL, bool POST, int IO = 0, int S = 1>      // IO: bit 0 = bf16 input, bit 1 = bf16 output, bit 2 = bf16 residual
 __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
-  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
-  static_assert(S == 1 || (S == 2 && NT == 2 && CIN == 64 && !POOL && !IN16), "strided instance: 64 -> 64 k, fp32 input");
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0, RES16 = (IO & 4) != 0;
+  static_assert(S == 1 || (S == 2 && NT == 2 && CIN == 64 && !POOL), "strided instance: 64 -> 64 k");
+  static_assert(!RES16 || (!POOL && !POST), "a bf16 residual goes with plain epilogues");
   constexpr int NTW = S == 1 ? NT : 1;                  // cout tiles per wave
   constexpr int KC = CIN / 64, KS = CIN / 16;
   constexpr int TH = S == 1 ? 8 : 4, TW = 16, HR = (TH - 1) * S + 3, HC = (TW - 1) * S + 3;
@@ -411,7 +413,9 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
   // ONE halo image in flight per team, requested a whole period (two phases) before it is staged.  Two register sets for Cin = 128
   // (each chunk requested a tile ahead) measured 5 % slower.
   f32x4 pv[1][NLOAD];
-  f32x4 rv[NTW][4];
+  f32x4 rv[RES16 ? 1 : NTW][4];
+  uint2 rw[RES16 ? NTW : 1][4];                         // bf16 residual: the raw words, widened in the epilogue (nothing touches a loaded
+                                                        // value before its use: a conversion here would drag s_waitcnt vmcnt(0) in front of the multiplies)
   f32x4 tv[POST ? NTW : 1][4];
   const int Ho = (a.H - 1) / S + 1, Wo = (a.W - 1) / S + 1;
   const int nt0 = S == 1 ? 0 : (tw >> 1);               // first cout tile of this wave
@@ -468,7 +472,8 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int cq = co0 + (nt0 + nt) * 32 + q * 8 + 4 * h;
-          rv[nt][q] = *reinterpret_cast<const f32x4*>(rbase + (pix * a.Cout + cq) * a.res_mul);
+          if constexpr (RES16) rw[nt][q] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(rbase) + (pix * a.Cout + cq) * a.res_mul);
+          else rv[nt][q] = *reinterpret_cast<const f32x4*>(rbase + (pix * a.Cout + cq) * a.res_mul);
           if constexpr (POST) tv[nt][q] = *reinterpret_cast<const f32x4*>(a.post + ((int64_t)oyc * Wo + oxc) * a.Cout + cq);
         }
     }
@@ -515,9 +520,17 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_tt_kernel(const B16Args a) {
       for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+          f32x4 rr;
+          if constexpr (RES16) {
+            const uint2 w = rw[nt][q];                  // bf16 -> fp32: the 16 bits are the top half of the float
+            rr = f32x4{__builtin_bit_cast(float, w.x << 16), __builtin_bit_cast(float, w.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w.y << 16), __builtin_bit_cast(float, w.y & 0xffff0000u)};
+          } else {
+            rr = rv[nt][q];
+          }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            const float u = acc[nt][4 * q + e] + Bs[(nt0 + nt) * 32 + q * 8 + 4 * h + e] + rv[nt][q][e];
+            const float u = acc[nt][4 * q + e] + Bs[(nt0 + nt) * 32 + q * 8 + 4 * h + e] + rr[e];
             ov[nt][q][e] = u > 0.f ? u : u * a.slope;
           }
           if constexpr (POST) ov[nt][q] += tv[nt][q];
@@ -632,6 +645,15 @@ int launch_tt_io(B16Args a, hipStream_t stream) {
 template <int CIN, int NT>
 int launch_tt(B16Args a, hipStream_t stream) {
   a.res_mul = a.res ? 1 : 0; a.bias_mul = a.bias ? 1 : 0;
+  if (a.res && a.res_bf16) {
+    // bf16 residual (the input of a ResidualBlock in a bf16-stored tower): 64 -> 64 layers with a bf16 input, plain epilogue
+    if constexpr (CIN == 64 && NT == 2) {
+      if (a.pool == 2 || a.post || !a.x_bf16) return CMR_EUNSUPPORTED;
+      return a.y_bf16 ? launch_tt_p<CIN, NT, false, false, 7>(a, stream) : launch_tt_p<CIN, NT, false, false, 5>(a, stream);
+    } else {
+      return CMR_EUNSUPPORTED;
+    }
+  }
   switch ((a.x_bf16 ? 1 : 0) | (a.y_bf16 ? 2 : 0)) {
     case 1: return launch_tt_io<CIN, NT, 1>(a, stream);
     case 2: return launch_tt_io<CIN, NT, 2>(a, stream);
@@ -643,23 +665,26 @@ int launch_tt(B16Args a, hipStream_t stream) {
 }  // namespace
 
 static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
-                                 const float* res, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
+                                 const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
                                  hipStream_t stream) {
   CMR_REQUIRE(x && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0 && (stride == 1 || stride == 2));
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(wfrag) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
               (!post || cmr_aligned16(post)));
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
-  B16Args a{static_cast<const float*>(x), B, H, W, wfrag, bias, res, post, static_cast<float*>(y), Cout, slope, pool, 0, 0, 0, 0, x_bf16, y_bf16};
+  B16Args a{static_cast<const float*>(x), B, H, W, wfrag, bias, static_cast<const float*>(res), post, static_cast<float*>(y), Cout, slope, pool,
+            0, 0, 0, 0, x_bf16, y_bf16, res && res_bf16 ? 1 : 0};
   if (stride == 2) {
     if (pool != 1) return CMR_EINVAL;
-    if (x_bf16) return CMR_EUNSUPPORTED;               // the strided instance reads fp32 activations (it opens a ResidualBlock)
+    if (a.res_bf16) return CMR_EUNSUPPORTED;
 #ifndef B16_S2_ONE_TEAM
     if (Cin == 64 && nt == 2 && Cout % 64 == 0 && !post) {
       a.res_mul = a.res ? 1 : 0; a.bias_mul = a.bias ? 1 : 0;
+      if (x_bf16) return y_bf16 ? launch_tt_p<64, 2, false, false, 3, 2>(a, stream) : launch_tt_p<64, 2, false, false, 1, 2>(a, stream);
       return y_bf16 ? launch_tt_p<64, 2, false, false, 2, 2>(a, stream) : launch_tt_p<64, 2, false, false, 0, 2>(a, stream);
     }
 #endif
+    if (x_bf16) return CMR_EUNSUPPORTED;               // the one-team strided instances read fp32 activations
     if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 16, 2>(a, stream);
     if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 16, 2>(a, stream);
     return CMR_EUNSUPPORTED;
@@ -673,11 +698,11 @@ static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W,
 extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                                          const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                                          hipStream_t stream) {
-  return conv3x3_bf16_dispatch(x, 0, B, H, W, Cin, wfrag, nt, bias, res, post, y, 0, Cout, stride, slope, pool, stream);
+  return conv3x3_bf16_dispatch(x, 0, B, H, W, Cin, wfrag, nt, bias, res, 0, post, y, 0, Cout, stride, slope, pool, stream);
 }
 
 extern "C" int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
-                                       const float* res, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
-                                       hipStream_t stream) {
-  return conv3x3_bf16_dispatch(x, x_bf16, B, H, W, Cin, wfrag, nt, bias, res, post, y, y_bf16, Cout, stride, slope, pool, stream);
+                                       const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope,
+                                       int pool, hipStream_t stream) {
+  return conv3x3_bf16_dispatch(x, x_bf16, B, H, W, Cin, wfrag, nt, bias, res, res_bf16, post, y, y_bf16, Cout, stride, slope, pool, stream);
 }

@@ -60,26 +60,29 @@ class ResidualBlock(Planned):
         return p
 
     # -- forward --------------------------------------------------------------------------------
-    def forward_cl(self, x, post=None):
+    def forward_cl(self, x, post=None, out_bf16=False):
         """x: NHWC [B,H,W,Cin] (or the NCHW image for the 3-channel stem) -> NHWC [B,Ho,Wo,Cout].
-        `post` [Ho,Wo,Cout] is added after the final activation (2-D sine table)."""
+        `post` [Ho,Wo,Cout] is added after the final activation (2-D sine table).
+        out_bf16 (bf16 mode with ops.BF16_STORE): the block's OUTPUT map is stored as bf16 -- for maps that only feed further bf16
+        convolutions (the two finer levels of MiniResNet); x may then be a bf16 map itself, and so is the residual."""
         self._require_eval()
         p = self.plan()
         if p["stem"]:
             assert post is None
-            return ops.stem_block(x, p["wa"], p["ba"], p["w3"], p["w1"], p["bb"], self.SLOPE)
+            return ops.stem_block(x, p["wa"], p["ba"], p["w3"], p["w1"], p["bb"], self.SLOPE, out_bf16=out_bf16)
         # t only feeds conv b: in bf16 mode it is stored as bf16 (what conv b would round it to anyway)
         t = ops.conv3x3(x, p["a"][0], p["a"][1], self.inchannel, self.stride, self.SLOPE, u=p["a"][2],
                         out_bf16=post is None and getattr(p["b"][2], "bf16", None) is not None)      # (the table operand goes with fp32 maps)
         sc = p["sc"]
+        xb = x.dtype == torch.bfloat16
         if sc is None:
             res = x
         elif sc[0] == "1x1":
             B, H, W, c = x.shape
             res = ops.linear(x.view(B * H * W, c), sc[1], sc[2]).view(B, H, W, self.outchannel)
         else:
-            res = ops.conv3x3(x, sc[1], sc[2], self.outchannel, 2, 1.0, u=sc[3])        # u only carries the bf16 operands here
-        return ops.conv3x3(t, p["b"][0], p["b"][1], self.outchannel, 1, self.SLOPE, res=res, post=post, u=p["b"][2])
+            res = ops.conv3x3(x, sc[1], sc[2], self.outchannel, 2, 1.0, u=sc[3], out_bf16=xb)   # u only carries the bf16 operands here
+        return ops.conv3x3(t, p["b"][0], p["b"][1], self.outchannel, 1, self.SLOPE, res=res, post=post, u=p["b"][2], out_bf16=out_bf16)
 
     def forward(self, x):
         if self.inchannel == 3:
@@ -110,11 +113,26 @@ class MiniResNet(Planned):
 
     def forward_cl(self, img_nchw):
         rl = self.residual_learning
-        x = rl[0].forward_cl(img_nchw)
-        f0 = rl[1].forward_cl(x)
-        f1 = rl[3].forward_cl(rl[2].forward_cl(f0))
+        # bf16 mode: the full- and half-resolution maps (84 % of the tower's activation bytes) are only ever read by bf16 convolutions
+        # -- as input, where they are rounded to bf16 anyway, and as the residual of their own block -- so they are STORED as bf16
+        # (stem output, both block outputs of each level, the stride-2 shortcuts); the quarter-resolution level that everything else
+        # reads stays fp32.  img_feat_0 / img_feat_1 are then bf16 tensors in the batch dict.
+        st = bool(ops.CONV_BF16 and ops.BF16_STORE and ops.BF16_CHAINS and self._bf16_served())
+        x = rl[0].forward_cl(img_nchw, out_bf16=st)
+        f0 = rl[1].forward_cl(x, out_bf16=st)
+        f1 = rl[3].forward_cl(rl[2].forward_cl(f0, out_bf16=st), out_bf16=st)
         f2 = rl[5].forward_cl(rl[4].forward_cl(f1))
         return f2, f1, f0
+
+    def _bf16_served(self):
+        """bf16 storage needs every block of the two finer levels on the bf16 kernels (64 -> 64 layers with bf16 operands packed)."""
+        for blk in self.residual_learning[1:5]:
+            p = blk.plan()
+            if blk.inchannel != 64 or blk.outchannel != 64 or getattr(p["a"][2], "bf16", None) is None or getattr(p["b"][2], "bf16", None) is None:
+                return False
+            if p["sc"] is not None and (p["sc"][0] != "3x3" or getattr(p["sc"][3], "bf16", None) is None):
+                return False
+        return True
 
     def forward(self, x):
         return tuple(f.permute(0, 3, 1, 2) for f in self.forward_cl(x.contiguous()))

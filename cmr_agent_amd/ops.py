@@ -99,6 +99,8 @@ CONV_BF16 = False        # True: bf16 mode -- 3x3 convolutions (cmr_conv3x3_bf16
                          # and the query side of the linear-attention layers (cmr_la_query_layer_bf16_f32) run on the bf16 matrix cores
                          # where served; storage and everything else stay fp32
 BF16_CHAINS = True       # bf16 mode: a convolution whose output only feeds another bf16 convolution stores it as bf16 (bit-identical, half the bytes)
+BF16_STORE = True        # bf16 mode: the full- and half-resolution maps of the image tower (read only by bf16 convolutions, as input and as the
+                         # residual of their own block) are STORED as bf16; not bit-neutral (the residual enters the epilogue rounded to bf16)
 STRIDE2_FRAGS = True     # stride-2 convolutions (Cin = 64) on the fragment-weight kernel cmr_conv3x3_s2_nhwc_f32; False = the tiled kernel (A/B, tests)
 WINOGRAD = True          # stride-1 convolutions on maps with enough 8x16 tiles go through Winograd F(2x2,3x3)
 WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct kernel has more parallelism
@@ -147,20 +149,21 @@ def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, s
         raise ValueError("conv3x3_bf16: bad operand layout")
     if pool == 2 and (res is not None or post is not None):
         raise ValueError("conv3x3: pool=2 cannot be combined with res / post")
-    unserved = (pool == 2 and (H % 2 or W % 2)) or (stride == 2 and (pool != 1 or cin != 64 or xb)) or ((xb or out_bf16) and post is not None)
+    rb = res is not None and res.dtype == torch.bfloat16          # bf16-stored towers: the block input is the residual, as bf16
+    unserved = (pool == 2 and (H % 2 or W % 2)) or (stride == 2 and (pool != 1 or cin != 64)) or ((xb or out_bf16) and post is not None)
     if not unserved:
         hp, wp = (H // 2, W // 2) if pool == 2 else ((H - 1) // stride + 1, (W - 1) // stride + 1)
         y = torch.empty((B, hp, wp, cout), dtype=torch.bfloat16 if out_bf16 else f32, device=x.device)
-        if xb or out_bf16:
-            rc = _lib.call("cmr_conv3x3_bf16io_nhwc", _p(x), int(xb), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), int(out_bf16),
-                           cout, int(stride), float(slope), pool, _stream(), allow_unsupported=True)
+        if xb or out_bf16 or rb:
+            rc = _lib.call("cmr_conv3x3_bf16io_nhwc", _p(x), int(xb), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), int(rb), _p(post), _p(y),
+                           int(out_bf16), cout, int(stride), float(slope), pool, _stream(), allow_unsupported=True)
         else:
             rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, int(stride),
                            float(slope), pool, _stream(), allow_unsupported=True)
         if rc != _lib.UNSUPPORTED:
             return y
-    if xb:
-        raise ValueError("conv3x3_bf16: a bf16 input of shape %s (stride %d, pool %d) is not served" % (tuple(x.shape), stride, pool))
+    if xb or rb:
+        raise ValueError("conv3x3_bf16: bf16 operands of shape %s (stride %d, pool %d, bf16 residual %s) are not served" % (tuple(x.shape), stride, pool, rb))
     return None
 
 
@@ -207,13 +210,13 @@ def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=Non
     return out
 
 
-def stem_block(img_nchw, w_a, b_a, w3, w1, b_b, slope):
+def stem_block(img_nchw, w_a, b_a, w3, w1, b_b, slope, out_bf16=False):
     B, c, H, W = img_nchw.shape
     if c != 3 or not img_nchw.is_contiguous():
         raise ValueError("stem expects a contiguous [B,3,H,W] image")
     tmp = torch.empty((B, 6, H, W), dtype=f32, device=img_nchw.device)      # conv-a output | a copy of the image (stem_b's single operand base)
-    out = torch.empty((B, H, W, 64), dtype=f32, device=img_nchw.device)
-    _lib.call("cmr_stem_block_f32", _p(img_nchw), _p(w_a), _p(b_a), _p(w3), _p(w1), _p(b_b), _p(tmp), _p(out), B, H, W,
+    out = torch.empty((B, H, W, 64), dtype=torch.bfloat16 if out_bf16 else f32, device=img_nchw.device)
+    _lib.call("cmr_stem_block_f32", _p(img_nchw), _p(w_a), _p(b_a), _p(w3), _p(w1), _p(b_b), _p(tmp), _p(out), int(out_bf16), B, H, W,
               float(slope), _stream())
     return out
 

@@ -47,7 +47,8 @@ def _conv_io(a):
     s = a.get("stride", 1)
     B, H, W, ci, co, pool = a["B"], a["H"], a["W"], a["Cin"], a["Cout"], a.get("pool", 1)
     opix = B * ((H - 1) // s + 1) * ((W - 1) // s + 1)
-    by = (2 if a["x_bf16"] else F) * B * H * W * ci + (2 if a["y_bf16"] else F) * opix * co / (pool * pool) + F * ((opix * co if a["res"] else 0) + 9 * ci * co)
+    by = ((2 if a["x_bf16"] else F) * B * H * W * ci + (2 if a["y_bf16"] else F) * opix * co / (pool * pool)
+          + (2 if a.get("res_bf16") else F) * (opix * co if a["res"] else 0) + F * 9 * ci * co)
     return 2.0 * 9 * ci * co * opix, by
 
 
@@ -75,7 +76,7 @@ WORK = {
     "cmr_conv3x3_bf16_nhwc_f32": _conv,
     "cmr_conv3x3_bf16io_nhwc": _conv_io,
     # ResidualBlock(3 -> 64): conv3x3 3->3, conv3x3 3->64, 1x1 shortcut 3->64
-    "cmr_stem_block_f32": lambda a: (2.0 * (81 + 1728 + 192) * a["B"] * a["H"] * a["W"], F * a["B"] * a["H"] * a["W"] * (3 + 64)),
+    "cmr_stem_block_f32": lambda a: (2.0 * (81 + 1728 + 192) * a["B"] * a["H"] * a["W"], a["B"] * a["H"] * a["W"] * (F * 3 + (2 if a.get("out_bf16") else F) * 64)),
     "cmr_avgpool_nhwc_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (1 + 1.0 / (a["kh"] * a["kw"]))),
     "cmr_upsample_concat_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * (2 * a["C1"] + a["C2"] * (1 + 1.0 / a["scale"] ** 2))),
     "cmr_patchify_nhwc_f32": lambda a: (0, 2 * F * a["B"] * a["H"] * a["W"] * a["C"]),

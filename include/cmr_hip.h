@@ -104,10 +104,11 @@ int cmr_set_wino_variant(int wave_specialised);
  * left some CUs: the image tower runs with a reduced budget while the point tower runs beside it.  Returns the previous setting. */
 int cmr_set_conv_cu_budget(int cus);
 
-/* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out.  tmp_nchw is scratch of
- * [B][6][H][W] floats (conv-a output | a copy of the image); 0 <= slope <= 1.  ImageResNet.py:50 with :9-23. */
+/* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out (fp32, or bf16 when out_bf16 != 0: the
+ * bf16-stored image tower of the bf16 mode).  tmp_nchw is scratch of [B][6][H][W] floats (conv-a output | a copy of the image);
+ * 0 <= slope <= 1.  ImageResNet.py:50 with :9-23. */
 int cmr_stem_block_f32(const float* x_nchw, const float* w_a, const float* b_a, const float* w3, const float* w1,
-                       const float* b_b, float* tmp_nchw, float* y_nhwc, int B, int H, int W, float slope,
+                       const float* b_b, float* tmp_nchw, void* y_nhwc, int out_bf16, int B, int H, int W, float slope,
                        hipStream_t stream);
 
 /* AvgPool2d((kh,kw), stride=(kh,kw)) on NHWC; (kh,kw)=(H,W) is the global pool.  CMRAgent.py:39,45,51,56. */
@@ -577,11 +578,13 @@ int cmr_iter_apply_f32(const float* matrix_i, const float* pc, float* pc_out, in
 /* cmr_conv3x3_bf16_nhwc_f32 with the activations optionally STORED as bf16 NHWC (x_bf16 / y_bf16 != 0): for chains of bf16 convolutions
  * (conv a -> conv b of a ResidualBlock, ImageResNet.py:9-14; the eight convolutions of the agent's 2-D embedding, CMRAgent.py:34-56).  The
  * consumer rounds its fp32 input to bf16 (RNE) anyway, so a producer that writes those bf16 values gives bit-identical results with
- * half the bytes.  Served: stride 1 with any combination, stride 2 with fp32 input; residual / bias fp32; no table operand with bf16
- * activations.  Otherwise CMR_EUNSUPPORTED (-3). */
+ * half the bytes.  Served: stride 1 with any combination, stride 2 (64 -> 64 k) with fp32 or bf16 input; bias fp32; no table operand
+ * with bf16 activations.  res_bf16 != 0: the residual is a bf16 NHWC map too (bf16-STORED towers, round 3: the input of a
+ * ResidualBlock is then only ever read as bf16; 64 -> 64 k layers with a bf16 input, stride 1, plain epilogue) -- this one is NOT
+ * bit-neutral: the residual enters the fp32 epilogue rounded to bf16.  Otherwise CMR_EUNSUPPORTED (-3). */
 int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
-                            const float* res, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
-                            hipStream_t stream);
+                            const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope,
+                            int pool, hipStream_t stream);
 
 /* ---- dropout (train mode; the reference trains MultiHeadModel with p = 0.1 in 141 nn.Dropout modules) --------------------------
  * Counter-based masks: element idx of site `site` is kept iff mix64(seed[0], site, idx) >= p 2^32 (csrc/cmr_common.h:cmr_keep); seed is

@@ -411,6 +411,50 @@ def test_bf16_activation_chains_are_bit_identical_to_fp32_storage():
         ops.CONV_BF16, ops.BF16_CHAINS = False, True
 
 
+def test_bf16_stored_tower_instances_and_mini_resnet():
+    """bf16 STORAGE of the image tower's two finer levels (ops.BF16_STORE): the new kernel instances -- bf16 residual (bf16 or fp32 output),
+    stride 2 with a bf16 input -- against the same convolution fed the widened operands, and MiniResNet with bf16-stored levels against
+    fp32-stored levels: identical up to the bf16 rounding of the residuals (img_feat_2 within 1e-2 of its scale, cosine > 0.9999)."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import conv_bf16_frags
+    from cmr_agent_amd.models.ImageResNet import MiniResNet
+    d = lambda t: t.to(DEV)
+    B, H, W = 2, 24, 40
+    x16 = d(rnd(B, H, W, 64, seed=1)).to(torch.bfloat16)
+    r16 = d(rnd(B, H, W, 64, seed=2)).to(torch.bfloat16)
+    w, b = d(rnd(64, 64, 3, 3, seed=3) / 12), d(rnd(64, seed=4))
+    fr = conv_bf16_frags(w)
+    ref = ops.conv3x3_bf16(x16.float(), fr, b, 64, 0.2, res=r16.float())                       # fp32-stored copies of the same bf16 values
+    got32 = ops.conv3x3_bf16(x16, fr, b, 64, 0.2, res=r16)                                      # bf16 in, bf16 residual, fp32 out
+    got16 = ops.conv3x3_bf16(x16, fr, b, 64, 0.2, res=r16, out_bf16=True)
+    assert got32.dtype == torch.float32 and torch.equal(got32, ref)
+    assert got16.dtype == torch.bfloat16 and torch.equal(got16, ref.to(torch.bfloat16))
+    for Hs, Ws in ((24, 40), (33, 70)):                                                         # stride 2, bf16 input
+        xs = d(rnd(B, Hs, Ws, 64, seed=5)).to(torch.bfloat16)
+        ref2 = ops.conv3x3_bf16(xs.float(), fr, b, 64, 1.0, stride=2)
+        assert torch.equal(ops.conv3x3_bf16(xs, fr, b, 64, 1.0, stride=2), ref2)
+        assert torch.equal(ops.conv3x3_bf16(xs, fr, b, 64, 1.0, stride=2, out_bf16=True), ref2.to(torch.bfloat16))
+    torch.manual_seed(0)
+    net = MiniResNet(3, 64).to(DEV).eval()
+    img = d(rnd(2, 3, 64, 96, seed=6))
+    ops.CONV_BF16 = True
+    try:
+        outs = {}
+        for store in (True, False):
+            ops.BF16_STORE = store
+            outs[store] = net.forward_cl(img)
+    finally:
+        ops.CONV_BF16, ops.BF16_STORE = False, True
+    assert outs[True][2].dtype == torch.bfloat16 and outs[True][1].dtype == torch.bfloat16 and outs[True][0].dtype == torch.float32
+    assert outs[False][2].dtype == torch.float32
+    for lvl in range(3):
+        a, bb = outs[True][lvl].float(), outs[False][lvl]
+        scale = float(bb.abs().max())
+        assert float((a - bb).abs().max()) <= 1.5e-2 * scale, lvl
+        cos = F.cosine_similarity(a.reshape(-1, 64).double(), bb.reshape(-1, 64).double(), dim=1)
+        assert float(cos.mean()) > 0.9999, (lvl, float(cos.mean()))
+
+
 def test_conv_cu_budget_changes_nothing_but_the_grid():
     """cmr_set_conv_cu_budget: the persistent convolution kernels (wave-specialised Winograd, two-team bf16) on 64 / 160 CUs give the
     bit-identical result of the full-chip launch (the tile -> workgroup assignment changes, the arithmetic per tile does not)."""
