@@ -63,6 +63,8 @@ def load():
         fn.restype = ret
         fn.argtypes = argtypes
     _lib = lib
+    if os.environ.get("CMR_B16_MM") == "0":             # A/B measurements: the two-team bf16 convolution for every layer
+        lib.cmr_set_conv_bf16_variant(0, 0)
     return lib
 
 

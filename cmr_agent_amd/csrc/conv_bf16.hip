@@ -37,6 +37,7 @@ struct B16Args {
   int x_bf16, y_bf16;    // activations stored as bf16 NHWC (input / output): a convolution whose output only feeds another bf16 convolution
                          // writes the bf16 values that one would round its fp32 input to anyway -- same results, half the bytes
   int res_bf16;          // the residual operand is a bf16 NHWC map (bf16-STORED towers: the block input of a ResidualBlock, round 3)
+  int wnt;               // cout tiles per group in the fragment layout of wfrag (the matrix-class kernel walks it by 32-cout tile)
 };
 
 __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -662,7 +663,301 @@ int launch_tt(B16Args a, hipStream_t stream) {
   }
 }
 
+// ---- matrix-class kernel (stride 1, 128-cout groups, no residual / table) -----------------------------------------------------------
+// The kernels above are built for the HBM-class layers (64 -> 64: 74 kFLOP per 512 B).  A 128 -> 128 layer does 295 kFLOP per pixel,
+// sits AT the bf16 ridge, and there the two-team kernel is bound by LDS, not HBM: with one accumulator per wave every MFMA is fed by
+// two ds_read_b128 (1 KB each; four waves x 2 KB per 32-cycle instruction = twice what the LDS array delivers), and the input is read
+// once per 32-cout group.  Here the REGISTER tile is what is organised:
+//   * workgroup = 8 x 32 pixels x 128 couts, 8 waves.  Waves 0-3 multiply: wave (c, p) owns cout tiles 2c, 2c+1 and pixel rows
+//     4p..4p+3 -> 2 x 4 accumulators; per k-step 4 pixel fragments from LDS + 2 weight fragments feed 8 MFMAs (0.5 LDS reads per
+//     instruction instead of 2);
+//   * the weight fragments never touch LDS (295 KB per layer would not fit): a wave streams ITS two cout tiles from L2 into a ring
+//     of D k-steps of registers, refilled into the slot the just-issued MFMAs consumed -- the stream is cyclic over the tile's
+//     9 x Cin/16 k-steps and tile independent, so it never drains between tiles;
+//   * waves 4-7 only stage: halo of the next (tile, 64-channel chunk) from HBM/L2 through registers (conversion + zero padding) into
+//     the other LDS buffer.  Their long-latency loads live in their own vmcnt queues -- in ONE wave they would sit between the ring
+//     loads and every ring wait would also wait for HBM.
+// One barrier per (tile, chunk) unit, met by all eight waves.  Results: same products as the kernels above, accumulated chunk-major.
+template <int CIN, bool POOL, int IO>      // IO: bit 0 = bf16 input, bit 1 = bf16 output
+__global__ __launch_bounds__(512) void conv3x3_bf16_mm_kernel(const B16Args a) {
+  constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  constexpr int KC = CIN / 64, KSG = CIN / 16, KT = 36 * KC;
+  constexpr int TH = 8, TW = 32, HR = TH + 2, HC = TW + 2, NPIX = HR * HC;
+  constexpr int PS = 64 * 2 + 16;
+  constexpr int XBYTES = NPIX * PS;
+  constexpr int D = 6;                                  // ring depth in k-steps (36 % D == 0: static slots under the unrolled loop)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* Bs = reinterpret_cast<float*>(smem + 2 * XBYTES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ngroups = a.Cout / 128;
+  const int group = blockIdx.x % ngroups;
+  const int s0 = blockIdx.x / ngroups, step = gridDim.x / ngroups;
+  const int nsp = a.B * a.tiles_y * a.tiles_x;
+  if (s0 >= nsp) return;                                // (uniform over the workgroup)
+  const int ntile = (nsp - s0 + step - 1) / step;
+  const int nunits = ntile * KC;
+  struct Tile { int b, oy0, ox0; };
+  auto decode = [&](int st) __attribute__((always_inline)) {
+    Tile t;
+    t.ox0 = (st % a.tiles_x) * TW; st /= a.tiles_x;
+    t.oy0 = (st % a.tiles_y) * TH;
+    t.b = st / a.tiles_y;
+    return t;
+  };
+  if (tid < 128) Bs[tid] = (a.bias ? a.bias : b16_zero16)[(group * 128 + tid) * a.bias_mul];
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ staging waves
+    const int ht = tid - 256;
+    constexpr int PPP = IN16 ? 8 : 16;                  // 16-byte pieces per halo pixel of one unit
+    constexpr int NPIECE = NPIX * PPP;
+    constexpr int NLOAD = (NPIECE + 255) / 256;
+    constexpr int ES = IN16 ? 2 : 4;
+    f32x4 pv[NLOAD];
+    auto issue_loads = [&](int u) __attribute__((always_inline)) {
+      const Tile t = decode(s0 + (u / KC) * step);
+      const int kc = u % KC;
+      const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)t.b * a.H * a.W * CIN + kc * 64) * ES;
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        int e = ht + 256 * i;
+        e = e < NPIECE ? e : NPIECE - 1;
+        const int p = e / PPP, c = e % PPP;
+        int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+        iy = iy < 0 ? 0 : (iy >= a.H ? a.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= a.W ? a.W - 1 : ix);
+        pv[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((iy * a.W + ix) * CIN * ES + 16 * c));
+      }
+    };
+    auto store_lds = [&](int u) __attribute__((always_inline)) {
+      const Tile t = decode(s0 + (u / KC) * step);
+      unsigned char* Xs = smem + (u & 1) * XBYTES;
+#pragma unroll
+      for (int i = 0; i < NLOAD; ++i) {
+        const int e = ht + 256 * i;
+        if (e < NPIECE) {
+          const int p = e / PPP, c = e % PPP;
+          const int iy = t.oy0 - 1 + p / HC, ix = t.ox0 - 1 + p % HC;
+          const bool inb = ((unsigned)iy < (unsigned)a.H) & ((unsigned)ix < (unsigned)a.W);
+          const unsigned keep = inb ? 0xffffffffu : 0u;
+          if constexpr (IN16) {
+            uint4 w = __builtin_bit_cast(uint4, pv[i]);
+            w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
+            *reinterpret_cast<uint4*>(Xs + p * PS + c * 16) = w;
+          } else {
+            uint2 w = b16_pack4(pv[i]);
+            w.x &= keep; w.y &= keep;
+            *reinterpret_cast<uint2*>(Xs + p * PS + c * 8) = w;
+          }
+        }
+      }
+    };
+    issue_loads(0);
+    store_lds(0);
+    issue_loads(nunits > 1 ? 1 : 0);
+    __syncthreads();                                    // unit 0 staged
+    for (int u = 0; u < nunits; ++u) {
+      // the multiplying waves read buffer u & 1 now; the other one was read during unit u - 1 and is free.  Past the end: a harmless
+      // re-stage / re-read of the last unit instead of branches around the loads
+      const int un = u + 1 < nunits ? u + 1 : u;
+      if (u + 1 < nunits) store_lds(un);
+      issue_loads(u + 2 < nunits ? u + 2 : un);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- multiplying waves
+  const int h = lane >> 5, l31 = lane & 31;
+  const int cw = wave & 1, pw = wave >> 1;
+  // wave-uniform fragment bases (scalar registers) + ONE per-lane byte offset that is re-materialised per unit (b16_fresh): every ring
+  // load is `v_add_u32 voff, lane16, literal ; global_load_dwordx4 v, voff, s[base]`.  Written as per-lane 64-bit addresses the 144
+  // loop-invariant address pairs are hoisted out of the tile loop and spilled (250 spilled registers in the first version).
+  constexpr int WNT = CIN == 64 ? 2 : 1;                // cout tiles per group in the fragment layout (_pack.conv_bf16_frags)
+  const unsigned char* wp[2];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int T = group * 4 + 2 * cw + nt;              // 32-cout tile of the layer; fragments are stored [T / WNT][tap][ks][T % WNT][lane][8]
+    wp[nt] = static_cast<const unsigned char*>(a.wfrag) + ((size_t)(T / WNT) * 9 * KSG * WNT + (T % WNT)) * 1024;
+  }
+  unsigned lane16 = lane * 16;
+  bf16x8 ring[D][2];
+  auto load_a = [&](int j, bf16x8 (&dst)[2]) __attribute__((always_inline)) {     // stream position j of the tile: (chunk, tap, ks)
+    const int r = j % 36;
+    const unsigned off = (unsigned)(((r / 4) * KSG + (j / 36) * 4 + (r % 4)) * WNT * 1024);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) dst[nt] = *reinterpret_cast<const bf16x8*>(wp[nt] + (size_t)(lane16 + off));
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_a(d, ring[d]);
+  const int lanebase = ((4 * pw) * HC + l31) * PS + h * 16;
+  const int Ho = a.H, Wo = a.W;
+  f32x16 acc[2][4];
+  auto multiply = [&](auto CH, int buf) __attribute__((always_inline)) {
+    constexpr int ch = decltype(CH)::value;
+    asm volatile("" : "+v"(lane16));                    // see load_a
+    const unsigned char* xs = smem + buf * XBYTES + lanebase;
+    bf16x8 bv[2][4];
+    auto read_b = [&](int jj, bf16x8 (&dst)[4]) __attribute__((always_inline)) {
+      const int tap = jj / 4, ks = jj % 4, ky = tap / 3, kx = tap % 3;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) dst[nb] = *reinterpret_cast<const bf16x8*>(xs + ((nb + ky) * HC + kx) * PS + ks * 32);
+    };
+    read_b(0, bv[0]);
+#pragma unroll
+    for (int jj = 0; jj < 36; ++jj) {
+      if (jj + 1 < 36) read_b(jj + 1, bv[(jj + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);                // the next k-step's pixel fragments are requested BEFORE this k-step's 8 MFMAs, not under the last one
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          acc[nt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ring[jj % D][nt], bv[jj & 1][nb], acc[nt][nb], 0, 0, 0);
+      load_a((ch * 36 + jj + D) % KT, ring[jj % D]);
+      __builtin_amdgcn_sched_barrier(0);                // keeps the 36 k-steps in program order (the scheduler would pull the ring loads up and spill)
+    }
+  };
+  auto epilogue = [&](const Tile& t) __attribute__((always_inline)) {
+    // register 4q+e of accumulator (nt, nb) = channel 128 group + 32 (2 cw + nt) + 8q + 4h + e of pixel (row 4 pw + nb, column l31)
+    const int cbase = (2 * cw) * 32 + 4 * h;
+    if constexpr (POOL) {
+      const int px = (t.ox0 >> 1) + (l31 >> 1);
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int py = (t.oy0 >> 1) + 2 * pw + pr;
+        f32x4 ov[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(&Bs[cbase + nt * 32 + q * 8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v0 = acc[nt][2 * pr][4 * q + e] + bq[e], v1 = acc[nt][2 * pr + 1][4 * q + e] + bq[e];
+              v0 = v0 > 0.f ? v0 : v0 * a.slope;
+              v1 = v1 > 0.f ? v1 : v1 * a.slope;
+              float v = v0 + v1;
+              v += cmr_xor1(v);
+              ov[nt][q][e] = 0.25f * v;
+            }
+          }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
+        if ((l31 & 1) == 0 && py < (Ho >> 1) && px < (Wo >> 1)) {
+          const int64_t o = (((int64_t)t.b * (Ho >> 1) + py) * (Wo >> 1) + px) * a.Cout + group * 128 + cbase;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.y) + o + nt * 32 + q * 8) = b16_pack4(ov[nt][q]);
+              else *reinterpret_cast<f32x4*>(a.y + o + nt * 32 + q * 8) = ov[nt][q];
+            }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int oy = t.oy0 + 4 * pw + nb, ox = t.ox0 + l31;
+        f32x4 ov[2][4];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(&Bs[cbase + nt * 32 + q * 8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float u = acc[nt][nb][4 * q + e] + bq[e];
+              ov[nt][q][e] = u > 0.f ? u : u * a.slope;
+            }
+          }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) cmr_pin(ov[nt][q]);
+        if (oy < Ho && ox < Wo) {
+          const int64_t o = (((int64_t)t.b * Ho + oy) * Wo + ox) * a.Cout + group * 128 + cbase;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if constexpr (OUT16) *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.y) + o + nt * 32 + q * 8) = b16_pack4(ov[nt][q]);
+              else *reinterpret_cast<f32x4*>(a.y + o + nt * 32 + q * 8) = ov[nt][q];
+            }
+        }
+      }
+    }
+  };
+  __syncthreads();                                      // unit 0 staged (and the bias)
+  for (int i = 0; i < ntile; ++i) {
+    const Tile t = decode(s0 + i * step);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][nb][r] = 0.f;
+    if constexpr (KC == 2) {
+      multiply(std::integral_constant<int, 0>{}, 0);
+      __syncthreads();
+      multiply(std::integral_constant<int, 1>{}, 1);
+    } else {
+      multiply(std::integral_constant<int, 0>{}, i & 1);
+    }
+    epilogue(t);
+    __syncthreads();
+  }
+}
+
+template <int CIN, bool POOL, int IO>
+int launch_mm_p(B16Args a, hipStream_t stream) {
+  constexpr int smem = 2 * 10 * 34 * 144 + 512;
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_mm_kernel<CIN, POOL, IO>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  a.tiles_x = (a.W + 31) / 32;
+  a.tiles_y = (a.H + 7) / 8;
+  a.bias_mul = a.bias ? 1 : 0;
+  const int ngroups = a.Cout / 128;
+  const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
+  const int cus = cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < 256 ? cmr_conv_cu_budget - cmr_conv_cu_budget % 8 : 256;
+  int per_group = cus / ngroups;                        // one persistent workgroup per CU
+  if (per_group < 1) per_group = 1;
+  if (per_group > nsp) per_group = (int)nsp;
+  hipLaunchKernelGGL((conv3x3_bf16_mm_kernel<CIN, POOL, IO>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
+  return cmr_launch_status();
+}
+
+template <int CIN>
+int launch_mm(const B16Args& a, hipStream_t stream) {
+  const int io = (a.x_bf16 ? 1 : 0) | (a.y_bf16 ? 2 : 0);
+  if (a.pool == 2) {
+    switch (io) {
+      case 0: return launch_mm_p<CIN, true, 0>(a, stream);
+      case 1: return launch_mm_p<CIN, true, 1>(a, stream);
+      case 2: return launch_mm_p<CIN, true, 2>(a, stream);
+      default: return launch_mm_p<CIN, true, 3>(a, stream);
+    }
+  }
+  switch (io) {
+    case 0: return launch_mm_p<CIN, false, 0>(a, stream);
+    case 1: return launch_mm_p<CIN, false, 1>(a, stream);
+    case 2: return launch_mm_p<CIN, false, 2>(a, stream);
+    default: return launch_mm_p<CIN, false, 3>(a, stream);
+  }
+}
+
 }  // namespace
+
+static int CMR_B16_MM = 1;             // matrix-class kernel for the 128-cout layers (cmr_set_conv_bf16_variant: A/B measurements)
+static int CMR_B16_MM_MIN_TILES = 128;
+extern "C" int cmr_set_conv_bf16_variant(int matrix_class, int min_tiles) {
+  CMR_REQUIRE(matrix_class == 0 || matrix_class == 1);
+  CMR_B16_MM = matrix_class;
+  if (min_tiles > 0) CMR_B16_MM_MIN_TILES = min_tiles;
+  return CMR_OK;
+}
 
 static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                                  const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
@@ -673,7 +968,7 @@ static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W,
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
   B16Args a{static_cast<const float*>(x), B, H, W, wfrag, bias, static_cast<const float*>(res), post, static_cast<float*>(y), Cout, slope, pool,
-            0, 0, 0, 0, x_bf16, y_bf16, res && res_bf16 ? 1 : 0};
+            0, 0, 0, 0, x_bf16, y_bf16, res && res_bf16 ? 1 : 0, nt};
   if (stride == 2) {
     if (pool != 1) return CMR_EINVAL;
     if (a.res_bf16) return CMR_EUNSUPPORTED;
@@ -688,6 +983,11 @@ static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W,
     if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_b16<64, 2, 16, 2>(a, stream);
     if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_b16<64, 1, 16, 2>(a, stream);
     return CMR_EUNSUPPORTED;
+  }
+  // 128-cout layers without residual / table on maps with enough 8x32 tiles: the matrix-class kernel (register-tiled, weights streamed)
+  if (CMR_B16_MM && Cout % 128 == 0 && !res && !post && (Cin == 64 || Cin == 128) && nt == (Cin == 64 ? 2 : 1) &&
+      (int64_t)B * ((H + 7) / 8) * ((W + 31) / 32) * (Cout / 128) >= CMR_B16_MM_MIN_TILES) {
+    return Cin == 64 ? launch_mm<64>(a, stream) : launch_mm<128>(a, stream);
   }
   if (Cin == 64 && nt == 2 && Cout % 64 == 0) return launch_tt<64, 2>(a, stream);
   if (Cin == 64 && nt == 1 && Cout % 32 == 0) return launch_tt<64, 1>(a, stream);

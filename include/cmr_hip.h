@@ -103,6 +103,12 @@ int cmr_set_wino_variant(int wave_specialised);
  * multiple of 8).  They fill a CU completely, so a branch forked onto another stream only progresses between their launches unless it is
  * left some CUs: the image tower runs with a reduced budget while the point tower runs beside it.  Returns the previous setting. */
 int cmr_set_conv_cu_budget(int cus);
+/* Process-wide switch of the bf16 convolution's kernel choice for 128-cout layers without residual / table operand (stride 1,
+ * Cin = 64 | 128): matrix_class = 1 (default) routes maps of at least min_tiles 8x32-pixel tiles (x Cout / 128; min_tiles <= 0 keeps the
+ * current threshold) to the register-tiled kernel that streams the weight fragments from L2 (conv3x3_bf16_mm_kernel), 0 keeps the
+ * two-team kernel everywhere.  Same products, accumulated per 64-channel chunk: results agree to fp32 rounding of the sums.  A/B
+ * measurements and tests only.  Returns CMR_OK. */
+int cmr_set_conv_bf16_variant(int matrix_class, int min_tiles);
 
 /* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out (fp32, or bf16 when out_bf16 != 0: the
  * bf16-stored image tower of the bf16 mode).  tmp_nchw is scratch of [B][6][H][W] floats (conv-a output | a copy of the image);

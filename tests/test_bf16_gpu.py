@@ -58,6 +58,47 @@ def test_conv3x3_bf16(B, H, W, cin, cout, pool, res, post, stride):
     assert float((got - want_fp).abs().max()) <= 1e-2 * scale
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout,pool,in16,out16", [
+    (2, 64, 256, 128, 128, 1, False, False), (2, 64, 256, 128, 128, 2, True, True), (1, 44, 152, 128, 128, 1, True, False),
+    (3, 22, 76, 128, 128, 2, False, True), (2, 40, 100, 64, 128, 1, False, False), (1, 30, 66, 64, 128, 2, True, True),
+    (1, 9, 33, 128, 256, 1, True, True), (1, 8, 32, 128, 128, 1, False, False), (5, 17, 31, 64, 128, 1, True, False)])
+def test_conv3x3_bf16_matrix_class_kernel(B, H, W, cin, cout, pool, in16, out16):
+    """conv3x3_bf16_mm_kernel (128-cout layers without residual: register-tiled, weight fragments streamed from L2, staging waves):
+    forced for every map size through cmr_set_conv_bf16_variant; against torch on the same bf16-rounded operands (2e-5 of the output scale,
+    + half a bf16 ulp when the output is stored as bf16) and against the two-team kernel (same products, other summation order)."""
+    from cmr_agent_amd import ops, _lib
+    from cmr_agent_amd.models._pack import conv_bf16_frags
+    lib = _lib.load()
+    x = rnd(B, cin, H, W, seed=11)
+    if in16:
+        x = x.to(torch.bfloat16).float()
+    w = rnd(cout, cin, 3, 3, seed=12) / 12
+    b = rnd(cout, seed=13)
+    bf = lambda t: t.to(torch.bfloat16).double()
+    y = F.leaky_relu(F.conv2d(bf(x), bf(w), b.double(), 1, 1), 0.2)
+    want = F.avg_pool2d(y, 2) if pool == 2 else y
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if in16:
+        xd = xd.to(torch.bfloat16)
+    frags = conv_bf16_frags(w.to(DEV))
+    run = lambda: ops.conv3x3_bf16(xd, frags, b.to(DEV), cout, 0.2, pool=pool, out_bf16=out16)
+    try:
+        assert lib.cmr_set_conv_bf16_variant(1, 1) == 0
+        got = run()
+        assert lib.cmr_set_conv_bf16_variant(0, 0) == 0
+        old = run()
+    finally:
+        lib.cmr_set_conv_bf16_variant(1, 128)
+    assert got is not None and got.dtype == (torch.bfloat16 if out16 else torch.float32)
+    g = got.float().permute(0, 3, 1, 2).cpu().double()
+    scale = float(want.abs().max())
+    tol = 2e-5 * scale + (2.0 ** -8 * scale if out16 else 0.0)
+    assert float((g - want).abs().max()) <= tol, float((g - want).abs().max()) / scale
+    if old is not None:
+        o = old.float().permute(0, 3, 1, 2).cpu().double()
+        assert float((g - o).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("case", ["e2e_native", "e2e_config3"], ids=["reference-native-160x512", "configs3-896x1600-32768pts"])
 def test_registration_iteration_bf16_convolutions_meet_the_bf16_bars(case):
     """SURVEY.md 8c's bf16 bars (cosine >= 0.999 on the unit-norm features, >= 95 % of the actions, overlap mask >= 98 %) against the fp32
