@@ -206,16 +206,45 @@ struct LaStateArgs {
   uint32_t S; int tiles_per_wave; float s;
 };
 
+// BF16 (the bf16 mode of BASELINE configs[2] / [3]): the two projections run on v_mfma_f32_32x32x16_bf16 (16 instructions per 32-row tile
+// instead of 128 fp32 ones; rows and weights rounded to bf16 on the way, fp32 accumulate), whose 32x32 result has the SAME register
+// layout -- so elu+1, 1/S and the row contraction K^T V (fp32 MFMA, the state is a sum over up to 10^5 rows) are unchanged.
+typedef __bf16 la_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LA_WPS = LA_D * 2 + 16;            // bytes per weight row in LDS (bf16): conflict-free ds_read_b128 over 32 consecutive rows
+
+__device__ __forceinline__ la_bf16x8 la_pack8(const f32x4& lo, const f32x4& hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  uint4 w;
+  w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[0], lo[1]}, b2));
+  w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[2], lo[3]}, b2));
+  w.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){hi[0], hi[1]}, b2));
+  w.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){hi[2], hi[3]}, b2));
+  return __builtin_bit_cast(la_bf16x8, w);
+}
+
+template <bool BF16>
 __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs a) {
-  __shared__ __attribute__((aligned(16))) float Wk[LA_D * LA_LD64];
-  __shared__ __attribute__((aligned(16))) float Wv[LA_D * LA_LD64];
+  // fp32: [64][LA_LD64] floats per matrix; bf16: [64] rows of LA_WPS bytes
+  __shared__ __attribute__((aligned(16))) float Wk[BF16 ? LA_D * LA_WPS / 4 : LA_D * LA_LD64];
+  __shared__ __attribute__((aligned(16))) float Wv[BF16 ? LA_D * LA_WPS / 4 : LA_D * LA_LD64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
-  for (int e = tid; e < LA_D * (LA_D / 4); e += 512) {
-    const int n = e / (LA_D / 4), c = (e % (LA_D / 4)) * 4;
-    *reinterpret_cast<f32x4*>(&Wk[n * LA_LD64 + c]) = *reinterpret_cast<const f32x4*>(a.wk + n * LA_D + c);
-    *reinterpret_cast<f32x4*>(&Wv[n * LA_LD64 + c]) = *reinterpret_cast<const f32x4*>(a.wv + n * LA_D + c);
+  if constexpr (BF16) {
+    for (int e = tid; e < LA_D * (LA_D / 8); e += 512) {
+      const int n = e / (LA_D / 8), c = (e % (LA_D / 8)) * 8;
+      *reinterpret_cast<la_bf16x8*>(reinterpret_cast<unsigned char*>(Wk) + n * LA_WPS + c * 2) =
+          la_pack8(*reinterpret_cast<const f32x4*>(a.wk + n * LA_D + c), *reinterpret_cast<const f32x4*>(a.wk + n * LA_D + c + 4));
+      *reinterpret_cast<la_bf16x8*>(reinterpret_cast<unsigned char*>(Wv) + n * LA_WPS + c * 2) =
+          la_pack8(*reinterpret_cast<const f32x4*>(a.wv + n * LA_D + c), *reinterpret_cast<const f32x4*>(a.wv + n * LA_D + c + 4));
+    }
+  } else {
+    for (int e = tid; e < LA_D * (LA_D / 4); e += 512) {
+      const int n = e / (LA_D / 4), c = (e % (LA_D / 4)) * 4;
+      *reinterpret_cast<f32x4*>(&Wk[n * LA_LD64 + c]) = *reinterpret_cast<const f32x4*>(a.wk + n * LA_D + c);
+      *reinterpret_cast<f32x4*>(&Wv[n * LA_LD64 + c]) = *reinterpret_cast<const f32x4*>(a.wv + n * LA_D + c);
+    }
   }
   __syncthreads();
   const int b = blockIdx.y;
@@ -235,33 +264,57 @@ __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs
     if (tile >= tiles_b) break;
     const uint32_t row = tile * 32 + l31;
     const uint32_t rowc = row < a.S ? row : 0;
-    const float* yp = yb + (int64_t)rowc * a.ldy + 4 * h;
-    f32x4 yf[8];
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) yf[kg] = *reinterpret_cast<const f32x4*>(yp + kg * 8);
     f32x16 kk[2], vv[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { kk[t][r] = 0.f; vv[t][r] = 0.f; }
-    const float* wkr = Wk + l31 * LA_LD64 + 4 * h;
-    const float* wvr = Wv + l31 * LA_LD64 + 4 * h;
+    if constexpr (BF16) {
+      // A = rows: lane (row l31, half h) holds y[row][16 ks + 8 h .. + 7]; B = weights: lane (channel l31, half h) holds W[32 t + l31][same k]
+      const float* yp = yb + (int64_t)rowc * a.ldy + 8 * h;
+      f32x4 yf[8];
 #pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-      f32x4 wk4[2], wv4[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        wk4[t] = *reinterpret_cast<const f32x4*>(wkr + t * 32 * LA_LD64 + kg * 8);
-        wv4[t] = *reinterpret_cast<const f32x4*>(wvr + t * 32 * LA_LD64 + kg * 8);
+      for (int ks = 0; ks < 4; ++ks) {
+        yf[2 * ks] = *reinterpret_cast<const f32x4*>(yp + ks * 16);
+        yf[2 * ks + 1] = *reinterpret_cast<const f32x4*>(yp + ks * 16 + 4);
       }
+      const unsigned char* wkr = reinterpret_cast<const unsigned char*>(Wk) + l31 * LA_WPS + h * 16;
+      const unsigned char* wvr = reinterpret_cast<const unsigned char*>(Wv) + l31 * LA_WPS + h * 16;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int ks = 0; ks < 4; ++ks) {
+        const la_bf16x8 ya = la_pack8(yf[2 * ks], yf[2 * ks + 1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          kk[t] = cmr_mfma32(yf[kg][j], wk4[t][j], kk[t]);      // D[row][channel 32t + l31]
-          vv[t] = cmr_mfma32(yf[kg][j], wv4[t][j], vv[t]);
+          const la_bf16x8 wkb = *reinterpret_cast<const la_bf16x8*>(wkr + t * 32 * LA_WPS + ks * 32);
+          const la_bf16x8 wvb = *reinterpret_cast<const la_bf16x8*>(wvr + t * 32 * LA_WPS + ks * 32);
+          kk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, wkb, kk[t], 0, 0, 0);      // D[row][channel 32t + l31]
+          vv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ya, wvb, vv[t], 0, 0, 0);
         }
-      __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const float* yp = yb + (int64_t)rowc * a.ldy + 4 * h;
+      f32x4 yf[8];
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) yf[kg] = *reinterpret_cast<const f32x4*>(yp + kg * 8);
+      const float* wkr = Wk + l31 * LA_LD64 + 4 * h;
+      const float* wvr = Wv + l31 * LA_LD64 + 4 * h;
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        f32x4 wk4[2], wv4[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          wk4[t] = *reinterpret_cast<const f32x4*>(wkr + t * 32 * LA_LD64 + kg * 8);
+          wv4[t] = *reinterpret_cast<const f32x4*>(wvr + t * 32 * LA_LD64 + kg * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            kk[t] = cmr_mfma32(yf[kg][j], wk4[t][j], kk[t]);      // D[row][channel 32t + l31]
+            vv[t] = cmr_mfma32(yf[kg][j], wv4[t][j], vv[t]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     // K = elu + 1 (rows past the end contribute nothing), V = v / S
     const bool partial = tile * 32 + 32 > a.S;
@@ -333,17 +386,28 @@ extern "C" int64_t cmr_la_kv_state_workspace_bytes(int B, int S) {
   return (int64_t)B * la_state_nslab(S) * 8 * LA_STATE * sizeof(float);
 }
 
-extern "C" int cmr_la_kv_state_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum,
-                                   void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
+static int la_kv_state_launch(bool bf16, const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, void* workspace,
+                              int64_t workspace_bytes, int B, int S, hipStream_t stream) {
   CMR_REQUIRE(y && wk && wv && kvsum && workspace && B > 0 && B <= 65535 && S > 0);
   CMR_REQUIRE(ldy % 4 == 0 && cmr_aligned16(y) && cmr_aligned16(wk) && cmr_aligned16(wv));
   CMR_REQUIRE(workspace_bytes >= cmr_la_kv_state_workspace_bytes(B, S));
   const int nslab = la_state_nslab(S);
   const LaStateArgs a{y, ldy, wk, wv, (float*)workspace, (uint32_t)S, la_state_tiles_per_wave(S), (float)S};
-  hipLaunchKernelGGL(la_state_partial_kernel, dim3(nslab, B), dim3(512), 0, stream, a);
+  if (bf16) hipLaunchKernelGGL(la_state_partial_kernel<true>, dim3(nslab, B), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL(la_state_partial_kernel<false>, dim3(nslab, B), dim3(512), 0, stream, a);
   hipLaunchKernelGGL(la_state_final_kernel, dim3(LA_STATE / 64, B), dim3(1024), 0, stream, (const float*)workspace, kvsum,
                      nslab * 8);
   return cmr_launch_status();
+}
+
+extern "C" int cmr_la_kv_state_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum,
+                                   void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
+  return la_kv_state_launch(false, y, ldy, wk, wv, kvsum, workspace, workspace_bytes, B, S, stream);
+}
+
+extern "C" int cmr_la_kv_state_bf16_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum,
+                                        void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
+  return la_kv_state_launch(true, y, ldy, wk, wv, kvsum, workspace, workspace_bytes, B, S, stream);
 }
 
 extern "C" int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,

@@ -327,12 +327,16 @@ def vit_out_ffn(ctx, x, wo_f, bo, ln, eps, w1_f, b1, w2_f, b2, rows16=False):
     return out
 
 
+LA_STATE_BF16 = True      # with CONV_BF16: the K / V projections of the state kernel on the bf16 cores as well (False: round 2's fp32 state kernel)
+
+
 def la_kv_state(y, wk, wv, B, S):
     """Fused k/v projections + per-(batch, head) state of one linear-attention layer: y [B*S,64] -> [B,576]."""
     ws_bytes = _lib.load().cmr_la_kv_state_workspace_bytes(B, S)
     ws = torch.empty((ws_bytes // 4,), dtype=f32, device=y.device)
     kvsum = torch.empty((B, 576), dtype=f32, device=y.device)
-    _lib.call("cmr_la_kv_state_f32", _p(_rows(y)), _ld(y), _p(wk), _p(wv), _p(kvsum), _p(ws), ws_bytes, B, S, _stream())
+    _lib.call("cmr_la_kv_state_bf16_f32" if (CONV_BF16 and LA_STATE_BF16) else "cmr_la_kv_state_f32", _p(_rows(y)), _ld(y), _p(wk), _p(wv), _p(kvsum), _p(ws), ws_bytes, B, S,
+              _stream())
     return kvsum
 
 

@@ -97,6 +97,7 @@ WORK = {
     # LinearAttention.py:46-60: k / v projections + per-head 8x8 state (source side); q projection, application, merge,
     # MLP 128 -> 128 -> 64 (query side): 17.5 + 66.7 = 84 kFLOP per token pair, as SURVEY.md 8a row a10 counts
     "cmr_la_kv_state_f32": lambda a: (2.0 * a["B"] * a["S"] * (2 * 4096 + 576), F * (a["B"] * a["S"] * 64 + 2 * 4096)),
+    "cmr_la_kv_state_bf16_f32": lambda a: (2.0 * a["B"] * a["S"] * (2 * 4096 + 576), F * (a["B"] * a["S"] * 64 + 2 * 4096)),
     "cmr_la_query_layer_f32": lambda a: (2.0 * a["B"] * a["L"] * (4096 + 576 + 4096 + 16384 + 8192),
                                          F * (a["B"] * a["L"] * 128 + 2 * 4096 + 16384 + 8192)),
     "cmr_la_query_layer_bf16_f32": lambda a: (2.0 * a["B"] * a["L"] * (4096 + 576 + 4096 + 16384 + 8192),

@@ -207,6 +207,11 @@ int cmr_vit_out_ffn_bf16_f32(const float* ctx, int64_t ldc, const float* x, int6
 int64_t cmr_la_kv_state_workspace_bytes(int B, int S);
 int cmr_la_kv_state_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, void* workspace,
                         int64_t workspace_bytes, int B, int S, hipStream_t stream);
+/* The same state with the two projections on the bf16 matrix cores (rows and weights rounded to bf16, fp32 accumulate; elu + 1, 1 / S and
+ * the row contraction K^T V stay fp32): the bf16 mode's source side of the layer, next to cmr_la_query_layer_bf16_f32.  Same arguments and
+ * workspace. */
+int cmr_la_kv_state_bf16_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, void* workspace,
+                             int64_t workspace_bytes, int B, int S, hipStream_t stream);
 int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,
                            const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
                            const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, int B, int L, int S, float eps,

@@ -361,6 +361,35 @@ def test_la_query_layer_bf16(B, L, S):
     assert float((got.cpu().double() - want_fp).abs().max()) <= 3e-2 * scale
 
 
+@pytest.mark.parametrize("B,S", [(2, 45), (1, 3000), (3, 26752), (2, 33)])
+def test_la_kv_state_bf16(B, S):
+    """cmr_la_kv_state_bf16_f32 (K / V projections on the bf16 cores, the rest of the state kernel in fp32) against a float64 emulation with
+    the projection operands rounded to bf16: 1e-4 of the state's scale (sums of up to 26 752 rows); against the fp32 state: 1e-2."""
+    from cmr_agent_amd import ops
+    bf = lambda t: t.to(torch.bfloat16).double()
+    y = rnd(B * S, 64, seed=91)
+    wk, wv = rnd(64, 64, seed=92) / 8, rnd(64, 64, seed=93) / 8
+
+    def ref(r):
+        k = (F.elu(r(y) @ r(wk).t()) + 1).view(B, S, 8, 8)
+        v = ((r(y) @ r(wv).t()) / S).view(B, S, 8, 8)
+        kv = torch.einsum("bshd,bshv->bhdv", k, v).reshape(B, 512)
+        return torch.cat([kv, k.sum(1).reshape(B, 64)], 1)
+    want_bf, want_fp = ref(bf), ref(lambda t: t.double())
+    d = lambda t: t.to(DEV)
+    fp = ops.la_kv_state(d(y), d(wk), d(wv), B, S).cpu().double()
+    ops.CONV_BF16 = True
+    try:
+        got = ops.la_kv_state(d(y), d(wk), d(wv), B, S).cpu().double()
+    finally:
+        ops.CONV_BF16 = False
+    for lo, hi in ((0, 512), (512, 576)):                   # KV and Ksum have different scales
+        scale = float(want_fp[:, lo:hi].abs().max())
+        assert float((fp[:, lo:hi] - want_fp[:, lo:hi]).abs().max()) <= 1e-4 * scale
+        assert float((got[:, lo:hi] - want_bf[:, lo:hi]).abs().max()) <= 1e-4 * scale, float((got[:, lo:hi] - want_bf[:, lo:hi]).abs().max()) / scale
+        assert float((got[:, lo:hi] - want_fp[:, lo:hi]).abs().max()) <= 1e-2 * scale
+
+
 @pytest.mark.parametrize("rows_x,rows_y", [(3344, 2048), (70, 33), (1, 0), (418, 0)])
 def test_vit_block_fused_pieces_bf16(rows_x, rows_y):
     """cmr_ln64_linear_bf16_f32 (one or two row sets) and cmr_vit_out_ffn_bf16_f32 against a torch emulation that rounds the GEMM
