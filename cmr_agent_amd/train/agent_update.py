@@ -196,18 +196,15 @@ class AgentUpdate:
             dsum = ops.act_bwd(dfeat, r["out"], SLOPE3D)                                      # final LeakyReLU
             dh2raw = self._bn_bwd(dsum, None, 1.0, r["h2raw"], r["st2"], p + "net.4")
             gw2 = bk.g(p + "net.3.weight")
-            ops.linear_wgrad(dh2raw, r["h1"], gw2, gw2.shape[1])
-            ops.colsum(dh2raw, 1, R, out=bk.g(p + "net.3.bias").view(1, -1))
+            ops.linear_wgrad(dh2raw, r["h1"], gw2, gw2.shape[1], db=bk.g(p + "net.3.bias"))       # bias gradient = column sums of dh2raw, same launch
             dh1 = ops.linear(dh2raw, self._wT(p + "net.3.weight"))
             dh1raw = self._bn_bwd(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], p + "net.1")
             w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
             if i == 0:
-                ops.linear_wgrad(dh1raw, r["x"], gw1, gw1.shape[1])
-                ops.colsum(dh1raw, 1, R, out=bk.g(p + "net.0.bias").view(1, -1))
+                ops.linear_wgrad(dh1raw, r["x"], gw1, gw1.shape[1], db=bk.g(p + "net.0.bias"))
                 dsc = self._bn_bwd(dsum, None, 1.0, r["scraw"], r["stsc"], p + "shortcut.1")
                 gws = bk.g(p + "shortcut.0.weight")
-                ops.linear_wgrad(dsc, r["x"], gws, gws.shape[1])
-                ops.colsum(dsc, 1, R, out=bk.g(p + "shortcut.0.bias").view(1, -1))
+                ops.linear_wgrad(dsc, r["x"], gws, gws.shape[1], db=bk.g(p + "shortcut.0.bias"))
                 break
             # input of this block = cat([feat_prev (f), broadcast max_prev (f)]): streamed half -> row GEMMs, broadcast half ->
             # per-sample column sums through the small-rows kernel
