@@ -21,6 +21,7 @@
 #include "cmr_common.h"
 
 extern int cmr_conv_cu_budget;
+extern int cmr_conv_slices;
 
 namespace {
 
@@ -784,7 +785,15 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
   }
   if (cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < cus) cus = cmr_conv_cu_budget;
   cus -= cus % 8;                                          // a multiple of the XCD count keeps a workgroup's tiles on one XCD's band
-  const unsigned grid = (unsigned)(ntiles < cus ? ntiles : cus);
+  // time slicing (cmr_set_conv_slices): n x as many workgroups, each walking 1 / n of the tiles -- a CU is handed back to the dispatcher
+  // n times per launch, so a branch on another stream is served in between instead of after the launch; never below 8 tiles per workgroup
+  int64_t want = cus;
+  if (cmr_conv_slices > 1) {
+    int sl = cmr_conv_slices;
+    while (sl > 1 && ntiles / ((int64_t)cus * sl) < 8) --sl;
+    want = (int64_t)cus * sl;
+  }
+  const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
   hipLaunchKernelGGL(conv3x3_wino_ws_kernel<DBG>, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
   return cmr_launch_status();
 }
@@ -813,6 +822,14 @@ __attribute__((visibility("hidden"))) int cmr_conv_cu_budget = 0;
 extern "C" int cmr_set_conv_cu_budget(int cus) {
   const int old = cmr_conv_cu_budget;
   cmr_conv_cu_budget = cus < 0 ? 0 : cus;
+  return old;
+}
+
+// Workgroups per CU the persistent Winograd kernel is split into (1 = one workgroup per CU walks all of the CU's tiles).
+__attribute__((visibility("hidden"))) int cmr_conv_slices = 1;
+extern "C" int cmr_set_conv_slices(int slices) {
+  const int old = cmr_conv_slices;
+  cmr_conv_slices = slices < 1 ? 1 : (slices > 64 ? 64 : slices);
   return old;
 }
 

@@ -56,6 +56,9 @@ class IMGPCEncoder(Planned):
             if budget and budget < 256:
                 with ops.conv_cu_budget(budget):
                     return self.img_transformer.forward_cl(img)
+            if not ops.CONV_BF16 and ops.TOWER_SLICES_F32 > 1:
+                with ops.conv_slices(ops.TOWER_SLICES_F32):
+                    return self.img_transformer.forward_cl(img)
             return self.img_transformer.forward_cl(img)
 
         (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat), (img_proxy, T, f2, f1, f0) = fork_join(point_tower, image_tower, tag="towers")

@@ -1,6 +1,8 @@
 """Tensor-level wrappers over the C ABI (include/cmr_hip.h).  PyTorch is used for device
 memory and the current HIP stream only; every computation is a HIP kernel.  Arguments are
 2-D row views ([rows, C], unit inner stride, arbitrary row stride) unless stated otherwise."""
+import os
+
 import torch
 
 from . import _lib
@@ -108,6 +110,22 @@ WINO_MIN_TILES = 64      # below that (11x38 at B < 6 ...) the per-wave direct k
 
 TOWER_CU_BUDGET = 160    # bf16 mode: CUs of the image tower's persistent convolution kernels while the point tower runs beside it (0 = all)
 TOWER_CU_BUDGET_F32 = 0  # the same for the fp32 Winograd kernels: matrix-bound, within noise at 240 / 224 / 208 (two boxes) -- left alone
+
+
+TOWER_SLICES_F32 = int(os.environ.get("CMR_TOWER_SLICES", "1"))     # fp32: workgroups per CU of the image tower's Winograd launches while the point tower runs beside it
+
+
+class conv_slices:
+    """with conv_slices(n): the persistent Winograd launches inside are split into n workgroups per CU (cmr_set_conv_slices)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.old = _lib.load().cmr_set_conv_slices(self.n)
+
+    def __exit__(self, *a):
+        _lib.load().cmr_set_conv_slices(self.old)
 
 
 class conv_cu_budget:

@@ -16,6 +16,7 @@ import os
 import torch
 
 ENABLED = os.environ.get("CMR_STREAMS", "1") != "0"
+SIDE_PRIORITY = os.environ.get("CMR_SIDE_PRIORITY", "0") == "1"     # side branches on high-priority streams (A/B measurements)
 _pool = {}
 _depth = 0
 
@@ -32,7 +33,7 @@ def _side_stream(parent, i):
     reproduction of that pattern; DESIGN.md section 6b records what it does on this ROCm / torch build."""
     key = (parent.device, parent.cuda_stream, i)
     if key not in _pool:
-        _pool[key] = torch.cuda.Stream(device=parent.device)
+        _pool[key] = torch.cuda.Stream(device=parent.device, priority=-1 if SIDE_PRIORITY else 0)
     return _pool[key]
 
 

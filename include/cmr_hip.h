@@ -103,6 +103,11 @@ int cmr_set_wino_variant(int wave_specialised);
  * multiple of 8).  They fill a CU completely, so a branch forked onto another stream only progresses between their launches unless it is
  * left some CUs: the image tower runs with a reduced budget while the point tower runs beside it.  Returns the previous setting. */
 int cmr_set_conv_cu_budget(int cus);
+/* Time slicing of the persistent Winograd kernel: from now on a launch uses `slices` workgroups per CU of its budget, each walking
+ * 1 / slices of the tiles (never fewer than 8 tiles per workgroup), so CUs return to the dispatcher during the launch and a branch
+ * forked onto another stream is served in between.  1 (default) = one workgroup per CU.  Results do not depend on it.  Returns the
+ * previous setting. */
+int cmr_set_conv_slices(int slices);
 /* Process-wide switch of the bf16 convolution's kernel choice for 128-cout layers without residual / table operand (stride 1,
  * Cin = 64 | 128): matrix_class = 1 (default) routes maps of at least min_tiles 8x32-pixel tiles (x Cout / 128; min_tiles <= 0 keeps the
  * current threshold) to the register-tiled kernel that streams the weight fragments from L2 (conv3x3_bf16_mm_kernel), 0 keeps the
