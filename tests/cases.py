@@ -233,6 +233,8 @@ def rollout_inputs(seed=7):
 TRAIN_CASES = {
     # two minibatches of 4 samples, 16x24 observation maps (global pool 2x3), 320 points
     "agent_train_small": dict(B=4, h=16, w=24, N=320, nbatch=2),
+    # BASELINE configs[2] per GPU / the shape bench.py --mode train measures: one minibatch of 10 observations of 88x304, 16 384 points
+    "agent_train_full": dict(B=10, h=88, w=304, N=16384, nbatch=1),
 }
 TRAIN_FIXTURES = ("agent_train_small_trainbn", "agent_train_small_evalbn", "buffer_order")
 

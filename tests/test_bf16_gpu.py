@@ -544,3 +544,23 @@ def test_conv_cu_budget_changes_nothing_but_the_grid():
             assert torch.equal(ops.conv3x3_bf16(x, fr, b, 64, 0.2, res=x), ref_b), cus
             assert torch.equal(ops.conv3x3_bf16(x, fr, b, 64, 0.2, stride=2), ref_s), cus
     assert torch.equal(ops.conv3x3_wino(x, u, b, 64, 0.2, res=x), ref_w)        # the budget is restored on exit
+
+
+def test_conv_slices_change_nothing_but_the_grid():
+    """cmr_set_conv_slices: the wave-specialised Winograd kernel launched as 2 / 5 / 64 workgroups per CU (never fewer than 8 tiles per
+    workgroup) gives the bit-identical result of the one-workgroup-per-CU launch, with and without a CU budget."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models._pack import winograd_u
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(8, 88, 304, 64, generator=g) - 0.5).to(DEV)
+    w = ((torch.rand(128, 64, 3, 3, generator=g) - 0.5) / 12).to(DEV)
+    b = torch.rand(128, generator=g).to(DEV)
+    u = winograd_u(w)
+    ref = ops.conv3x3_wino(x, u, b, 128, 0.2)
+    for n in (2, 5, 64):
+        with ops.conv_slices(n):
+            assert torch.equal(ops.conv3x3_wino(x, u, b, 128, 0.2), ref), n
+            with ops.conv_cu_budget(96):
+                assert torch.equal(ops.conv3x3_wino(x, u, b, 128, 0.2), ref), n
+    assert torch.equal(ops.conv3x3_wino(x, u, b, 128, 0.2), ref)
+
