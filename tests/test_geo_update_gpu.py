@@ -221,3 +221,32 @@ def test_graph_replay_equals_eager_steps():
     assert l0 == l1
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
+
+
+def test_geo_update_at_the_configs4_shape_vs_oracle():
+    """One forward / backward of the geometric model at BASELINE configs[4]'s shape (KittiConfig training crop 160x512, 65 536 points
+    per cloud, 512 circle-loss pairs; 2 pairs instead of the 8 of a step so that the host autograd stays within seconds) against
+    oracle/train_oracle.py, dropout off: the sizes at which the 131 072-row per-point stacks, their LDS-staged weight gradients and the
+    20 480-pixel linear-attention layers actually run.  Same bars as the fixture-size test (losses 1e-5; every gradient tensor within 3e-3
+    of the model's largest entry and, above noise level, 8 % of its own scale; whole-vector cosine >= 0.99999)."""
+    import sys
+    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.train import GeoUpdate
+    from cmr_agent_amd.utils import hashfill, synthetic
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench as BM
+    dev = torch.device("cuda", 0)
+    cfg_d, cfg_c = KittiConfiguration(device=dev, num_pt=65536), KittiConfiguration(device="cpu", num_pt=65536)
+    geo_sd = hashfill.make_state_dict(SPECS["geo"], BM.GEO_TAG)
+    sd0 = {k: v for k, v in geo_sd.items() if not k.endswith("num_batches_tracked")}
+    batch = synthetic.make_batch(2, cfg_d.num_pt, cfg_d.cropped_img_H, cfg_d.cropped_img_W, cfg_d.num_node, BM.hip_fps(dev), BM.hip_nearest(dev),
+                                 seed=11, n_circle=512, device=dev)
+    model = _model(cfg_d, geo_sd)
+    up = GeoUpdate(model, cfg_d, dropout=False)
+    losses = up.forward_backward(batch)
+    torch.cuda.synchronize()
+    cpu_batch = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    out, og = TO.geo_forward_backward({k: x.clone() for k, x in sd0.items()}, cpu_batch, cfg_c, True)
+    _check_scalars(losses, out, 1e-5, "configs[4] shape")
+    _check_grads(_logical_grads(up, model), og, "configs[4] shape")
+
