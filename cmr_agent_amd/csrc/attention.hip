@@ -10,6 +10,7 @@
 // cmr_la_apply_f32   msg[l,h,v] = (Q~[l,h,:] . KV[h,:,v]) * S / (Q~[l,h,:] . Ksum[h,:] + eps)
 //                    (LinearAttention.py:53-60; K~,Q~ = elu+1 are produced by the projection epilogue).
 #include "cmr_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -95,74 +96,95 @@ __global__ __launch_bounds__(256) void mha_kernel(const float* __restrict__ q, i
 // xor-shuffles per step, the sums once at the end.  The output tile has the head dims on the rows: lane (q, g < 2) ends up with
 // O[q][4g .. 4g + 3] -- one b128 store.  No P tile ever leaves the registers.
 typedef float mha_f32x4 __attribute__((ext_vector_type(4)));
+// Keys are staged in chunks of at most MHA_KCH (the online softmax simply runs on across chunks): the K / V image of a head with 1 400
+// keys (nuScenes: 28 x 50 proxies) is 95 KB -- ONE workgroup per CU, one wave per SIMD, and nothing to cover the dependent
+// LDS -> MFMA -> exp -> MFMA chain of a step; 512-key chunks are 35 KB, four workgroups share a CU.  Up to 512 keys (KITTI: 418 / 256
+// proxies) there is one chunk and the kernel is the round-2 one.
+constexpr int MHA_KCH = 512;
+// LIBM_EXP: exp through libm's expf instead of v_exp_f32(x log2 e) (cmr_mha_expf_f32: the training tape's no-dropout forward, whose
+// backward kernels recompute the probabilities with expf)
+template <bool LIBM_EXP>
+__device__ __forceinline__ float mha_exp(float x) {
+  if constexpr (LIBM_EXP) return expf(x);
+  else return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+}
+template <bool LIBM_EXP>
 __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
                                                        const float* __restrict__ v, int64_t ldv, float* __restrict__ o, int64_t ldo, int Tq,
-                                                       int Tk, int Tkp, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tkp][8], then V_h^T [9][Tkp] (row 8 = zeros)
+                                                       int Tk, int Tcp, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tcp][8], then V_h^T [9][Tcp] (row 8 = zeros); Tcp = padded chunk length
   float* ks = kv;
-  float* vt = kv + (size_t)Tkp * DH;
+  float* vt = kv + (size_t)Tcp * DH;
   const int head = blockIdx.y, b = blockIdx.z;
   const float* kb = k + (int64_t)b * Tk * ldk + head * DH;
   const float* vb = v + (int64_t)b * Tk * ldv + head * DH;
-  for (int e = threadIdx.x; e < Tkp * 2; e += 256) {
-    const int t = e >> 1, half = (e & 1) * 4;
-    f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
-    if (t < Tk) {
-      kk = *reinterpret_cast<const f32x4*>(kb + (int64_t)t * ldk + half);
-      vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)t * ldv + half);
-    }
-    *reinterpret_cast<f32x4*>(&ks[t * DH + half]) = kk;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) vt[(half + i) * Tkp + t] = vv[i];
-  }
-  for (int t = threadIdx.x; t < Tkp; t += 256) vt[8 * Tkp + t] = 0.f;
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, g = lane >> 4;
   const int q0 = (blockIdx.x * 4 + wave) * 16;
-  if (q0 >= Tq) return;
+  const bool active = q0 < Tq;                                   // (wave-uniform) idle waves still stage and meet the barriers
   const int tq = q0 + i < Tq ? q0 + i : Tq - 1;
   const float* qp = q + ((int64_t)b * Tq + tq) * ldq + head * DH + 2 * g;
   const float qa = qp[0], qb = qp[1];
   const float* krow = ks + i * DH + 2 * g;                       // + k0 * DH
-  const float* vrow = vt + (i < 8 ? i : 8) * Tkp + 4 * g;        // + k0
+  const float* vrow = vt + (i < 8 ? i : 8) * Tcp + 4 * g;        // + k0
   float m = -INFINITY, l = 0.f;
   mha_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k0 = 0; k0 < Tkp; k0 += 32) {                        // two 16-key steps per running-max update
-    const float2 ka0 = *reinterpret_cast<const float2*>(krow + k0 * DH);
-    const float2 ka1 = *reinterpret_cast<const float2*>(krow + (k0 + 16) * DH);
-    const mha_f32x4 vf0 = *reinterpret_cast<const mha_f32x4*>(vrow + k0);
-    const mha_f32x4 vf1 = *reinterpret_cast<const mha_f32x4*>(vrow + k0 + 16);
-    mha_f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.x, qa, s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.x, qa, s1, 0, 0, 0);
-    s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.y, qb, s0, 0, 0, 0);
-    s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.y, qb, s1, 0, 0, 0);
+  for (int t = threadIdx.x; t < Tcp; t += 256) vt[8 * Tcp + t] = 0.f;
+  for (int c0 = 0; c0 < Tk; c0 += Tcp) {
+    if (c0 > 0) __syncthreads();                                 // everybody done with the previous chunk
+    for (int e = threadIdx.x; e < Tcp * 2; e += 256) {
+      const int t = e >> 1, half = (e & 1) * 4;
+      f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+      if (c0 + t < Tk) {
+        kk = *reinterpret_cast<const f32x4*>(kb + (int64_t)(c0 + t) * ldk + half);
+        vv = *reinterpret_cast<const f32x4*>(vb + (int64_t)(c0 + t) * ldv + half);
+      }
+      *reinterpret_cast<f32x4*>(&ks[t * DH + half]) = kk;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s0[r] = k0 + 4 * g + r < Tk ? s0[r] * scale : -INFINITY;
-      s1[r] = k0 + 16 + 4 * g + r < Tk ? s1[r] * scale : -INFINITY;
+      for (int j = 0; j < 4; ++j) vt[(half + j) * Tcp + t] = vv[j];
     }
-    float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
-    bm = fmaxf(bm, cmr_xor16(bm));                                // (VALU lane exchanges: two LDS round trips sat on the
-    bm = fmaxf(bm, cmr_xhalf(bm));                                //  serial max -> exp -> multiply chain of every key block)
-    const float mn = fmaxf(m, bm);                               // finite from the first step on (key 0 is always valid)
-    const float alpha = expf(m - mn);
-    m = mn;
-    mha_f32x4 p0, p1;
+    __syncthreads();
+    if (!active) continue;
+    const int nk = Tk - c0 < Tcp ? Tk - c0 : Tcp;                // keys of this chunk
+    for (int k0 = 0; k0 < nk; k0 += 32) {                        // two 16-key steps per running-max update
+      const float2 ka0 = *reinterpret_cast<const float2*>(krow + k0 * DH);
+      const float2 ka1 = *reinterpret_cast<const float2*>(krow + (k0 + 16) * DH);
+      const mha_f32x4 vf0 = *reinterpret_cast<const mha_f32x4*>(vrow + k0);
+      const mha_f32x4 vf1 = *reinterpret_cast<const mha_f32x4*>(vrow + k0 + 16);
+      mha_f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.x, qa, s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.x, qa, s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.y, qb, s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.y, qb, s1, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      p0[r] = expf(s0[r] - mn);
-      p1[r] = expf(s1[r] - mn);
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = k0 + 4 * g + r < nk ? s0[r] * scale : -INFINITY;
+        s1[r] = k0 + 16 + 4 * g + r < nk ? s1[r] * scale : -INFINITY;
+      }
+      float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      bm = fmaxf(bm, cmr_xor16(bm));                              // (VALU lane exchanges: two LDS round trips sat on the
+      bm = fmaxf(bm, cmr_xhalf(bm));                              //  serial max -> exp -> multiply chain of every key block)
+      const float mn = fmaxf(m, bm);                             // finite from the first step on (key 0 of a chunk is always valid)
+      // exp(x) as v_exp_f32(x log2 e): libm's expf spends five more instructions per value on a range reduction that a softmax does not
+      // need (x <= 0; terms below 2^-126 vanish either way) -- 20 -> 16 us at 418 keys, 80 -> 61 us at 1 400
+      const float alpha = mha_exp<LIBM_EXP>(m - mn);
+      m = mn;
+      mha_f32x4 p0, p1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p0[r] = mha_exp<LIBM_EXP>(s0[r] - mn);
+        p1[r] = mha_exp<LIBM_EXP>(s1[r] - mn);
+      }
+      l = l * alpha + (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[r], p0[r], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[r], p1[r], acc, 0, 0, 0);
     }
-    l = l * alpha + (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] *= alpha;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[r], p0[r], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[r], p1[r], acc, 0, 0, 0);
   }
+  if (!active) return;
   l += cmr_xor16(l);
   l += cmr_xhalf(l);
   if (g < 2 && q0 + i < Tq) {
@@ -252,6 +274,7 @@ __global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__
 
 }  // namespace
 
+static int CMR_MHA_KEY_CHUNK = MHA_KCH;   // keys staged per chunk (env CMR_MHA_KEY_CHUNK at first use: A/B measurements)
 static int CMR_MHA_MFMA = 1;     // 1 = matrix-core kernel (default), 0 = the one-query-per-lane-group VALU kernel
 extern "C" int cmr_set_mha_variant(int mfma) {
   const int old = CMR_MHA_MFMA;
@@ -259,19 +282,28 @@ extern "C" int cmr_set_mha_variant(int mfma) {
   return old;
 }
 
-extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+static int mha_launch(bool libm_exp, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                            float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
   CMR_REQUIRE(q && k && v && o && B > 0 && B <= 65535 && Tq > 0 && Tk > 0);
   CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
   CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(o));
   if (CMR_MHA_MFMA) {
+    static const bool kch_env = [] { const char* e = getenv("CMR_MHA_KEY_CHUNK"); if (e && atoi(e) >= 32) CMR_MHA_KEY_CHUNK = atoi(e) / 32 * 32; return true; }();
+    (void)kch_env;
     const int Tkp = (Tk + 31) / 32 * 32;
-    const size_t smem = (size_t)Tkp * (DH + 9) * sizeof(float);
+    const int Tcp = Tkp < CMR_MHA_KEY_CHUNK ? Tkp : CMR_MHA_KEY_CHUNK;      // chunk length (the last chunk may be shorter)
+    const size_t smem = (size_t)Tcp * (DH + 9) * sizeof(float);
     CMR_REQUIRE(smem <= 160 * 1024);
-    static CmrSmemCache granted{};
-    if (cmr_grant_smem(reinterpret_cast<const void*>(mha_mfma_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
     dim3 grid((Tq + 63) / 64, NH, B);
-    hipLaunchKernelGGL(mha_mfma_kernel, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk, Tkp, 0.35355339059327373f);
+    if (libm_exp) {
+      static CmrSmemCache granted_l{};
+      if (cmr_grant_smem(reinterpret_cast<const void*>(mha_mfma_kernel<true>), smem, granted_l) != CMR_OK) return CMR_ELAUNCH;
+      hipLaunchKernelGGL(mha_mfma_kernel<true>, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk, Tcp, 0.35355339059327373f);
+    } else {
+      static CmrSmemCache granted{};
+      if (cmr_grant_smem(reinterpret_cast<const void*>(mha_mfma_kernel<false>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+      hipLaunchKernelGGL(mha_mfma_kernel<false>, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk, Tcp, 0.35355339059327373f);
+    }
     return cmr_launch_status();
   }
   const size_t smem = (size_t)Tk * DH * 2 * sizeof(float);
@@ -282,6 +314,16 @@ extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t 
   hipLaunchKernelGGL(mha_kernel<false>, grid, dim3(256), smem, stream, q, ldq, k, ldk, v, ldv, o, ldo, Tq, Tk,
                      0.35355339059327373f, 0u, 1.f, (const int64_t*)nullptr, (uint64_t)0);
   return cmr_launch_status();
+}
+
+extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                           float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
+  return mha_launch(false, q, ldq, k, ldk, v, ldv, o, ldo, B, Tq, Tk, stream);
+}
+
+extern "C" int cmr_mha_expf_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
+  return mha_launch(true, q, ldq, k, ldk, v, ldv, o, ldo, B, Tq, Tk, stream);
 }
 
 extern "C" int cmr_mha_dropout_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,

@@ -19,7 +19,9 @@ namespace {
 constexpr int LA_D = 64, LA_HID = 128, LA_STATE = 576;    // 8 heads x (8x8 KV + 8 Ksum)
 constexpr int LA_LD64 = LA_D + 4, LA_LD128 = LA_HID + 4;  // padded LDS weight rows (conflict-free b128 reads)
 
-__device__ __forceinline__ float la_elu1(float v) { return v > 0.f ? v + 1.f : expf(v); }   // F.elu(v) + 1
+// F.elu(v) + 1; the negative branch as v_exp_f32(v log2 e) -- libm's expf costs five more instructions per value for a range reduction
+// that buys nothing at |v| of a projected feature (state kernel 67 -> 62 us fp32, 39 -> 34 us bf16 at 8 x 26 752 rows)
+__device__ __forceinline__ float la_elu1(float v) { return v > 0.f ? v + 1.f : __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }
 __device__ __forceinline__ float la_xhalf(float v) { return cmr_xhalf(v); }            // partner lane (other 4 dims of the head)
 
 // LayerNorm over the 64 channels of this lane's row (32 here, 32 in the partner lane), in place

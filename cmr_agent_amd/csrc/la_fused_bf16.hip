@@ -19,7 +19,7 @@ typedef __bf16 lb_bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int LB_D = 64, LB_HID = 128, LB_STATE = 576;
 
-__device__ __forceinline__ float lb_elu1(float v) { return v > 0.f ? v + 1.f : expf(v); }
+__device__ __forceinline__ float lb_elu1(float v) { return v > 0.f ? v + 1.f : __builtin_amdgcn_exp2f(v * 1.4426950408889634f); }   // see la_fused.hip
 __device__ __forceinline__ float lb_xhalf(float v) { return cmr_xhalf(v); }
 
 __device__ __forceinline__ void lb_layernorm(f32x16 (&v)[2], const float* __restrict__ gs, const float* __restrict__ bs, int h, float eps) {

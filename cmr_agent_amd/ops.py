@@ -271,10 +271,11 @@ def transpose(x):
     return out
 
 
-def mha(q, k, v, B, Tq, Tk, out=None):
+def mha(q, k, v, B, Tq, Tk, out=None, libm_exp=False):
+    """softmax(Q K^T / sqrt(8)) V per head; libm_exp: exponentials through expf (the training tape's forward, see cmr_mha_expf_f32)."""
     if out is None:
         out = torch.empty((B * Tq, 64), dtype=f32, device=q.device)
-    _lib.call("cmr_mha_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(out), _ld(out), B, Tq,
+    _lib.call("cmr_mha_expf_f32" if libm_exp else "cmr_mha_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(out), _ld(out), B, Tq,
               Tk, _stream())
     return out
 

@@ -312,7 +312,7 @@ class Tape:
         seed, site = self.drop_seed, self._site
         if drop:
             self._site += 1
-        y = Var(ops.mha_dropout(q.v, k.v, v.v, B, Tq, Tk, p, seed, site) if drop else ops.mha(q.v, k.v, v.v, B, Tq, Tk))
+        y = Var(ops.mha_dropout(q.v, k.v, v.v, B, Tq, Tk, p, seed, site) if drop else ops.mha(q.v, k.v, v.v, B, Tq, Tk, libm_exp=True))
 
         def bwd():
             if y.g is None:

@@ -82,6 +82,7 @@ WORK = {
     "cmr_patchify_nhwc_f32": lambda a: (0, 2 * F * a["B"] * a["H"] * a["W"] * a["C"]),
     "cmr_transpose_f32": lambda a: (0, 2 * F * a["batch"] * a["R"] * a["Cn"]),
     "cmr_mha_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),
+    "cmr_mha_expf_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),
     "cmr_la_reduce_f32": lambda a: (2.0 * a["B"] * a["S"] * 576, F * a["B"] * a["S"] * 128),
     "cmr_la_apply_f32": lambda a: (2.0 * a["B"] * a["L"] * 576, F * a["B"] * a["L"] * 128),
     "cmr_agent_heads_f32": _heads,

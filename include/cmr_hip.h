@@ -140,6 +140,10 @@ int cmr_transpose_f32(const float* x, float* y, int batch, int R, int Cn, hipStr
 /* softmax(Q K^T / sqrt(8)) V, 8 heads x 8 dims.  ImageViT.py:93-104, IMGPCEncoder.py:45-53. */
 int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,
                 int64_t ldo, int B, int Tq, int Tk, hipStream_t stream);
+/* The same attention with the exponentials through libm's expf instead of v_exp_f32(x log2 e) (about 25 % slower): the no-dropout forward
+ * of the training tape, whose backward kernels (cmr_mha_bwd_f32) recompute the probabilities with expf. */
+int cmr_mha_expf_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o, int64_t ldo, int B,
+                     int Tq, int Tk, hipStream_t stream);
 /* Process-wide switch between the two softmax-attention kernels (1 = v_mfma_f32_16x16x4_f32 for Q K^T and P V, the default;
  * 0 = one query per 4 lanes on the vector ALUs): A/B measurements and tests only.  Returns the previous setting. */
 int cmr_set_mha_variant(int mfma);

@@ -176,14 +176,26 @@ def test_mha(ops, B, Tq, Tk, variant):
         _lib.load().cmr_set_mha_variant(old)
 
 
-def _mha_case(ops, B, Tq, Tk):
+@pytest.mark.parametrize("B,Tq,Tk", [(1, 1400, 1400), (2, 100, 513), (1, 33, 1024), (2, 418, 418)])
+def test_mha_key_chunks_and_libm_variant(ops, B, Tq, Tk):
+    """Keys beyond 512 are staged chunk by chunk with the online softmax running on (1 400 x 1 400: the nuScenes proxy count; chunk
+    boundaries on and off a multiple of the key count); cmr_mha_expf_f32 (libm exponentials, the training tape's forward) against the
+    same reference and within 2e-6 of the default kernel."""
+    _mha_case(ops, B, Tq, Tk)
+    _mha_case(ops, B, Tq, Tk, libm_exp=True)
+    q, k, v = rnd(B * Tq, 64, seed=33, lo=-3, hi=3).to(DEV), rnd(B * Tk, 64, seed=34, lo=-3, hi=3).to(DEV), rnd(B * Tk, 64, seed=35).to(DEV)
+    a, b = ops.mha(q, k, v, B, Tq, Tk), ops.mha(q, k, v, B, Tq, Tk, libm_exp=True)
+    assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+def _mha_case(ops, B, Tq, Tk, libm_exp=False):
     q, k, v = rnd(B * Tq, 64, seed=33, lo=-3, hi=3), rnd(B * Tk, 64, seed=34, lo=-3, hi=3), rnd(B * Tk, 64, seed=35)
     qh = q.view(B, Tq, 8, 8).permute(0, 2, 1, 3).double()
     kh = k.view(B, Tk, 8, 8).permute(0, 2, 1, 3).double()
     vh = v.view(B, Tk, 8, 8).permute(0, 2, 1, 3).double()
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(8), -1) @ vh).permute(0, 2, 1, 3).reshape(B * Tq, 64)
     kv = torch.cat([k, v], 1).to(DEV)                      # fused [K|V] buffer, ld = 128
-    got = ops.mha(q.to(DEV), kv[:, :64], kv[:, 64:], B, Tq, Tk)
+    got = ops.mha(q.to(DEV), kv[:, :64], kv[:, 64:], B, Tq, Tk, libm_exp=libm_exp)
     close(got, ref, 2e-5, "mha")
 
 

@@ -3,6 +3,9 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+if "--lib" in sys.argv:
+    from cmr_agent_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from cmr_agent_amd import ops
 from kbench import timeit
 

@@ -3,6 +3,9 @@ matcher -- at the proxy counts of BASELINE configs[1] (B = 8, T = 418, Q = 256).
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--lib" in sys.argv:
+    from cmr_agent_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from cmr_agent_amd import ops
 from cmr_agent_amd.models._pack import frag_pack, frag_pack16
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
