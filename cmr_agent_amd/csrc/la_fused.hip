@@ -318,7 +318,8 @@ __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // K = elu + 1 (rows past the end contribute nothing), V = v / S
+    // K = elu + 1 (rows past the end contribute nothing); V's 1 / S is applied to the summed state in la_state_final_kernel (one division
+    // per state entry instead of 32 ten-instruction fp32 divisions per lane and tile)
     const bool partial = tile * 32 + 32 > a.S;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -328,7 +329,6 @@ __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs
         if (partial && tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.S) k = 0.f;
         kk[t][r] = k;
         ksum[t] += k;
-        vv[t][r] = vv[t][r] / a.s;
       }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs
 // kvsum[b][c] = sum over the partial states, fixed order: 16 interleaved groups of partials per column, then
 // the 16 group sums in sequence.  grid (9 column blocks of 64, B), 1024 threads = 16 groups x 64 columns.
 __global__ __launch_bounds__(1024) void la_state_final_kernel(const float* __restrict__ part, float* __restrict__ kvsum,
-                                                              int npart) {
+                                                              int npart, float s_len) {
   __shared__ float red[16][64];
   const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   const float* p = part + (int64_t)b * npart * LA_STATE + col;
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(1024) void la_state_final_kernel(const float* __res
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
-    kvsum[(int64_t)b * LA_STATE + col] = t;
+    kvsum[(int64_t)b * LA_STATE + col] = col < 512 ? t / s_len : t;        // KV = K^T (V / S); Ksum is not scaled
   }
 }
 
@@ -398,7 +398,7 @@ static int la_kv_state_launch(bool bf16, const float* y, int64_t ldy, const floa
   if (bf16) hipLaunchKernelGGL(la_state_partial_kernel<true>, dim3(nslab, B), dim3(512), 0, stream, a);
   else hipLaunchKernelGGL(la_state_partial_kernel<false>, dim3(nslab, B), dim3(512), 0, stream, a);
   hipLaunchKernelGGL(la_state_final_kernel, dim3(LA_STATE / 64, B), dim3(1024), 0, stream, (const float*)workspace, kvsum,
-                     nslab * 8);
+                     nslab * 8, (float)S);
   return cmr_launch_status();
 }
 
