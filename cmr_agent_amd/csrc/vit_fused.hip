@@ -261,8 +261,17 @@ __device__ __forceinline__ float vf16_allg(float v) {
   return v + cmr_xhalf(v);
 }
 
+#ifdef CMR_FFN_STAMPS
+#define FFN_STAMP(i) do { uint64_t t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_[i] = t_; } while (0)
+#else
+#define FFN_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(512) void vit_out_ffn16_kernel(const OutFfnArgs a) {
   __shared__ __attribute__((aligned(16))) float red[7 * 4 * 64 * 4];     // partial outputs of waves 1..7: [w][tile][lane][4]
+#ifdef CMR_FFN_STAMPS
+  uint64_t st_[9];
+#endif
+  FFN_STAMP(0);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, n = lane & 15;
@@ -277,6 +286,7 @@ __global__ __launch_bounds__(512) void vit_out_ffn16_kernel(const OutFfnArgs a) 
     cf[t] = *reinterpret_cast<const f32x4*>(cp + 16 * t);
     x1[t] = *reinterpret_cast<const f32x4*>(xp + 16 * t);
   }
+  FFN_STAMP(1);
   // ---- x1 = ctx Wo + bo + x     (every wave: 64 MFMAs)
   {
     f32x4 acc[4];
@@ -288,6 +298,7 @@ __global__ __launch_bounds__(512) void vit_out_ffn16_kernel(const OutFfnArgs a) 
       for (int e = 0; e < 4; ++e) x1[t][e] = (acc[t][e] + bv[e]) + x1[t][e];
     }
   }
+  FFN_STAMP(2);
   // ---- LayerNorm(64) of the row: 16 channels here, the others in the three partner lanes
   f32x4 xn[4];
   {
@@ -313,22 +324,27 @@ __global__ __launch_bounds__(512) void vit_out_ffn16_kernel(const OutFfnArgs a) 
       for (int e = 0; e < 4; ++e) xn[t][e] = xn[t][e] * rstd * gv[e] + bv[e];
     }
   }
+  FFN_STAMP(3);
   // ---- this wave's 128 hidden units: fc1 + GELU (8 tiles of 16), then its K-slice of fc2
   f32x4 hid[8];
   vf16_gemm<8, 4, 4>(a.w1_f, 4, 8 * wave, 0, lane, hid, [&](int t, int r) { return xn[t][r]; });
+  FFN_STAMP(4);
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b1 + 128 * wave + 16 * t + 4 * g);
 #pragma unroll
     for (int e = 0; e < 4; ++e) hid[t][e] = vf_gelu(hid[t][e] + bv[e]);
   }
+  FFN_STAMP(5);
   f32x4 part[4];
   vf16_gemm<4, 8, 8>(a.w2_f, 64, 0, 8 * wave, lane, part, [&](int t, int r) { return hid[t][r]; });
+  FFN_STAMP(6);
   if (wave > 0) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&red[(((wave - 1) * 4 + t) * 64 + lane) * 4]) = part[t];
   }
   __syncthreads();
+  FFN_STAMP(7);
   if (wave != 0) return;
   f32x4 ov[4];
 #pragma unroll
@@ -347,6 +363,14 @@ __global__ __launch_bounds__(512) void vit_out_ffn16_kernel(const OutFfnArgs a) 
 #pragma unroll
     for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(yp + 16 * t) = ov[t];
   }
+#ifdef CMR_FFN_STAMPS
+  FFN_STAMP(8);
+  if (lane == 0 && valid) {                            // debug build: the stage durations (100 MHz ticks of s_memtime) over the row's first floats
+    float* yp = a.out + (int64_t)row * a.ldo;
+    for (int i = 0; i < 8; ++i) yp[i] = (float)(st_[i + 1] - st_[i]);
+    yp[8] = (float)(st_[0] & 0xffffff);
+  }
+#endif
 }
 
 }  // namespace
