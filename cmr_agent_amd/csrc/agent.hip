@@ -79,6 +79,76 @@ __global__ __launch_bounds__(256) void observation_finalize_kernel(const float* 
   if (write_img) *reinterpret_cast<f32x4*>(state2d + cell * 128 + c) = *reinterpret_cast<const f32x4*>(img_feat + cell * 64 + c);
 }
 
+// ---- the projected half of the observation written directly (inference loops that consume the two halves separately) -----------
+// project_scatter + observation_finalize make two passes over the whole [B,h,w,64] map per agent step (accumulate, then normalise /
+// copy / re-zero: 165 MB at 8 x 88 x 304) although only the cells that received points change.  Here the map `proj` is kept across
+// steps and touched per POINT only:
+//   obs_project_kernel  (thread per point)  zeroes the cell its point occupied in the previous step (proj row + count), projects the
+//                                           point with the new pose, writes the state_3d row and the new cell index (-1: not in view)
+//   obs_count_kernel    (thread per point)  cnt[cell] += 1
+//   obs_scatter_kernel  (wave per 4 points) proj[cell][c] += feat[p][c] / cnt[cell]      (scatter_mean as a sum of pre-divided terms)
+// The clears of a step never meet the increments of the same step (different launches), so no buffer parity has to survive between
+// hipGraph replays; cells hit by nobody stay zero from the initial fill.
+__global__ __launch_bounds__(256) void obs_project_kernel(const float* __restrict__ pc4, const uint8_t* __restrict__ overlap,
+                                                          const float* __restrict__ pose, const float* __restrict__ Kmat,
+                                                          const float* __restrict__ mean4, float* __restrict__ proj, float* __restrict__ cnt,
+                                                          int32_t* __restrict__ cell, float* __restrict__ state3d, int B, int N, int h, int w) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (int64_t)B * N) return;
+  const int32_t prev = cell[p];
+  if (prev >= 0) {
+    f32x4* row = reinterpret_cast<f32x4*>(proj + (int64_t)prev * 64);
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) row[i] = z;
+    cnt[prev] = 0.f;
+  }
+  const int b = (int)(p / N);
+  const f32x4 pt = *reinterpret_cast<const f32x4*>(pc4 + p * 4);
+  const float* R = pose + b * 16;
+  const float* Kb = Kmat + b * 9;
+  const float mx = mean4[b * 4 + 0], my = mean4[b * 4 + 1], mz = mean4[b * 4 + 2];
+  const float cx = pt[0] - mx, cy = pt[1] - my, cz = pt[2] - mz;
+  const float tx = (R[0] * cx + R[1] * cy + R[2] * cz) + mx + R[3];
+  const float ty = (R[4] * cx + R[5] * cy + R[6] * cz) + my + R[7];
+  const float tz = (R[8] * cx + R[9] * cy + R[10] * cz) + mz + R[11];
+  float u = Kb[0] * tx + Kb[1] * ty + Kb[2] * tz;
+  float v = Kb[3] * tx + Kb[4] * ty + Kb[5] * tz;
+  const float zc = Kb[6] * tx + Kb[7] * ty + Kb[8] * tz;
+  u = u / zc;
+  v = v / zc;
+  const bool inside = (u >= 0.f) && (u <= (float)(w - 1)) && (v >= 0.f) && (v <= (float)(h - 1)) && (zc > 0.f);
+  const bool ov = overlap[p] != 0;
+  *reinterpret_cast<f32x4*>(state3d + p * 8) = f32x4{pt[0], pt[1], pt[2], ov ? 1.f : 0.f};
+  *reinterpret_cast<f32x4*>(state3d + p * 8 + 4) = f32x4{inside ? 1.f : 0.f, 0.f, 0.f, 0.f};
+  int32_t c = -1;
+  if (ov && inside) {
+    const int xi = (int)rintf(u), yi = (int)rintf(v);            // torch.round = half to even
+    c = (int32_t)((int64_t)b * h * w + (int64_t)yi * w + xi);
+  }
+  cell[p] = c;
+}
+
+__global__ __launch_bounds__(256) void obs_count_kernel(const int32_t* __restrict__ cell, float* __restrict__ cnt, int64_t total) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= total) return;
+  const int32_t c = cell[p];
+  if (c >= 0) atomicAdd(cnt + c, 1.f);
+}
+
+__global__ __launch_bounds__(256) void obs_scatter_kernel(const float* __restrict__ feat, const int32_t* __restrict__ cell,
+                                                          const float* __restrict__ cnt, float* __restrict__ proj, int64_t total) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int64_t p = p0 + q;
+    if (p >= total) return;
+    const int32_t c = cell[p];
+    if (c >= 0) atomicAdd(proj + (int64_t)c * 64 + lane, feat[p * 64 + lane] / cnt[c]);
+  }
+}
+
 // pose[b] <- [E_xyz(move_r) @ R | t + move_t]   with move_* looked up in the float64 step tables and
 // rounded to float32 on assignment (environment.py:186-205).  One thread per sample.
 __global__ void pose_step_kernel(float* __restrict__ pose, const int64_t* __restrict__ act_r, const int64_t* __restrict__ act_t,
@@ -195,6 +265,21 @@ extern "C" int cmr_project_scatter_f32(const float* pc4, const float* feat, cons
   const int64_t total = (int64_t)B * N;
   hipLaunchKernelGGL(project_scatter_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, pc4, feat, overlap,
                      pose, Kmat, mean4, acc, cnt, state3d, B, N, h, w);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_observation_proj_f32(const float* pc4, const float* feat, const uint8_t* overlap, const float* pose, const float* Kmat,
+                                        const float* mean4, float* proj, float* cnt, int32_t* cell, float* state3d, int B, int N, int h,
+                                        int w, hipStream_t stream) {
+  CMR_REQUIRE(pc4 && feat && overlap && pose && Kmat && mean4 && proj && cnt && cell && state3d && B > 0 && N > 0 && h > 0 && w > 0);
+  CMR_REQUIRE((int64_t)B * h * w < 0x7fffffff && cmr_aligned16(proj) && cmr_aligned16(state3d) && cmr_aligned16(pc4));
+  const int64_t total = (int64_t)B * N;
+  const unsigned per_point = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(obs_project_kernel, dim3(per_point), dim3(256), 0, stream, pc4, overlap, pose, Kmat, mean4, proj, cnt, cell, state3d, B, N,
+                     h, w);
+  hipLaunchKernelGGL(obs_count_kernel, dim3(per_point), dim3(256), 0, stream, (const int32_t*)cell, cnt, total);
+  hipLaunchKernelGGL(obs_scatter_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, feat, (const int32_t*)cell,
+                     (const float*)cnt, proj, total);
   return cmr_launch_status();
 }
 

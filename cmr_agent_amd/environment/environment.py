@@ -14,6 +14,9 @@ from ..models.ImageResNet import to_nhwc
 from ..models.PointNN import rows_from_bcl
 
 
+DIRECT_PROJ = True      # shape-only observations keep the projected half in place (cmr_observation_proj_f32); False: scatter + finalize sweeps
+
+
 class _ObsContext:
     """Per-batch constants of the agent loop + the reusable scatter / state buffers."""
 
@@ -42,6 +45,9 @@ class _ObsContext:
         self.acc = torch.zeros((cells, 64), dtype=torch.float32, device=dev)
         self.cnt = torch.zeros((cells,), dtype=torch.float32, device=dev)
         self.first = True
+        # state of the direct projected-half path (materialize_state_2d=False): the map itself, its counts and every point's cell of the
+        # previous observation; created on first use
+        self.proj = self.proj_cnt = self.proj_cell = None
         self.agent_cache = {}     # CMRAgent keeps the image half of its first conv here (constant over the steps of THIS registration)
         self.dirty = False        # True between a scatter and its finalize: an interrupted call must not leak accumulators
 
@@ -91,6 +97,19 @@ def observation_from_a_pose(data, RT, materialize_state_2d=True):
     B, N, h, w = ctx.B, ctx.N, ctx.h, ctx.w
     dev = ctx.pc4.device
     state3d = torch.empty((B * N, 8), dtype=torch.float32, device=dev)
+    if not materialize_state_2d and DIRECT_PROJ:
+        # only the projected half is wanted: it lives in the context and is updated per point (the cells of the previous observation are
+        # zeroed, the new ones receive feat / count) instead of being rebuilt by two sweeps over the whole map.  The returned halves alias
+        # the context's storage: valid until the next observation of this batch -- which is all CMRAgent.forward needs.
+        if ctx.proj is None:
+            ctx.proj = torch.zeros((B, h, w, 64), dtype=torch.float32, device=dev)
+            ctx.proj_cnt = torch.zeros((B * h * w,), dtype=torch.float32, device=dev)
+            ctx.proj_cell = torch.full((B * N,), -1, dtype=torch.int32, device=dev)
+        ops.observation_proj(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.proj, ctx.proj_cnt,
+                             ctx.proj_cell, state3d)
+        obs2d = torch.empty((B, 128, h, w), dtype=torch.float32, device="meta")
+        obs2d._cmr_split = (ctx.img, ctx.proj, ctx.agent_cache)
+        return obs2d, state3d.view(B, N, 8)[:, :, :5].permute(0, 2, 1)
     state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev) if materialize_state_2d else None
     proj = torch.empty((B, h, w, 64), dtype=torch.float32, device=dev)
     zero_first, ctx.dirty = ctx.dirty, True

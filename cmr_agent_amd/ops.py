@@ -565,6 +565,14 @@ def observation_finalize(img_feat, acc, cnt, state2d, proj, B, h, w, write_img, 
               int(write_img), int(clear), _stream())
 
 
+def observation_proj(pc4, feat, overlap_u8, pose, K, mean4, B, N, h, w, proj, cnt, cell, state3d):
+    """The projected half of the observation maintained in place (see cmr_observation_proj_f32): proj / cnt / cell are the caller's state."""
+    if cell.dtype != torch.int32 or cell.numel() != B * N or proj.numel() != B * h * w * 64 or cnt.numel() != B * h * w:
+        raise ValueError("observation_proj: state buffers of the wrong shape / dtype")
+    _lib.call("cmr_observation_proj_f32", _p(pc4), _p(feat), _p(overlap_u8), _p(pose), _p(K), _p(mean4), _p(proj), _p(cnt), _p(cell), _p(state3d),
+              B, N, h, w, _stream())
+
+
 def pose_step(pose, act_r, act_t, r_steps, t_steps, six_dof):
     _lib.call("cmr_pose_step_f32", _p(pose), _p(act_r), _p(act_t), _p(r_steps), _p(t_steps), pose.shape[0], int(six_dof),
               _stream())

@@ -369,6 +369,15 @@ int cmr_project_scatter_f32(const float* pc4, const float* feat, const uint8_t* 
  * map is then neither written nor is img_feat read).  clear = 1: cells with cnt > 0 are reset to zero after they have been read. */
 int cmr_observation_finalize_f32(const float* img_feat, float* acc, float* cnt, float* state2d, float* proj,
                                  int B, int h, int w, int write_img, int clear, hipStream_t stream);
+/* The projected half of the observation alone, maintained in place across the steps of a registration (inference loops that hand the two
+ * halves of state_2d to CMRAgent separately; environment.observation_from_a_pose(materialize_state_2d = False)): proj [B,h,w,64], cnt
+ * [B*h*w] and cell [B*N] (int32, the cell of every point in the previous call, -1 = none) are STATE owned by the caller -- zero / zero / -1
+ * before the first call, untouched between calls.  Each call zeroes the cells of the previous call per point, projects with `pose`, writes
+ * state3d [B*N,8] like cmr_project_scatter_f32 and adds feat / count into the cells hit now: proj = scatter_mean (environment.py:39-80) with
+ * the mean formed as a sum of pre-divided terms, cells without points 0.  Three launches over the points; the full map is never swept. */
+int cmr_observation_proj_f32(const float* pc4, const float* feat, const uint8_t* overlap, const float* pose, const float* Kmat,
+                             const float* mean4, float* proj, float* cnt, int32_t* cell, float* state3d, int B, int N, int h, int w,
+                             hipStream_t stream);
 /* environment.py:179-260 (step + euler_angles_to_matrix 'XYZ'), :14-21 (to_disentangled). */
 int cmr_pose_step_f32(float* pose, const int64_t* act_r, const int64_t* act_t, const double* r_steps,
                       const double* t_steps, int B, int six_dof, hipStream_t stream);

@@ -104,6 +104,36 @@ def test_shape_only_observation_gives_the_materialised_result():
             agent(bare, m3)
 
 
+def test_in_place_projected_observation_over_a_pose_sequence():
+    """cmr_observation_proj_f32 keeps the projected half of the observation in place and only touches the cells of the previous and of
+    the current pose: over a sequence of poses (cells get vacated, re-entered, shared by several points; one pose throws every point out
+    of view) the map must equal the scatter + finalize result of each pose -- to rounding of the mean (sum of pre-divided terms, float
+    atomics) -- vacated cells exactly zero, and state_3d bit-identical."""
+    import cases as C
+    import parity_e2e
+    from cmr_agent_amd.environment import environment as env
+    case = "e2e_small"
+    cfg = C.e2e_config(case)
+    geo, agent, _, _ = parity_e2e.build_models(cfg)
+    data = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in C.e2e_batch(case).items()}
+    with torch.no_grad():
+        geo(data)
+        pose0, _ = env.init(data)
+        shifts = [(0.0, 0.0, 0.0), (0.4, 0.0, 0.0), (0.4, -0.3, 0.2), (0.0, 0.0, -1.0e4), (0.0, 0.0, 0.0), (-0.5, 0.2, 0.0), (-0.5, 0.2, 0.0)]
+        for k, (dx, dy, dz) in enumerate(shifts):
+            pose = pose0.clone()
+            pose[:, 0, 3] += dx; pose[:, 1, 3] += dy; pose[:, 2, 3] += dz
+            s2, s3 = env.observation_from_a_pose(data, pose)                                  # scatter + finalize, materialised
+            m2, m3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)      # in place
+            want = s2[:, 64:].permute(0, 2, 3, 1)
+            got = m2._cmr_split[1]
+            assert torch.equal(s3, m3), k
+            assert torch.equal(got == 0, want == 0), k                                        # the same cells are occupied, the others exactly zero
+            assert float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max())), k
+            if k == 3:
+                assert float(got.abs().max()) == 0.0                                          # everything behind the camera: the map is empty again
+
+
 def test_registration_iteration_op_level_paths(monkeypatch):
     """Same iteration with every layer-level fusion and the side streams switched off: the op-level composition
     must meet the same oracle / golden bars."""
