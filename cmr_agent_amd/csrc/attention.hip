@@ -194,6 +194,180 @@ __global__ __launch_bounds__(256) void mha_mfma_kernel(const float* __restrict__
   }
 }
 
+// ---- LayerNorm + Q / K / V projections + attention in one launch (inference: ops.mha_ln, one launch less per transformer block) ---------
+// The projections of a block are 64 -> 192 on a few thousand rows: as their own launch (ln64_linear) they are a 12 us round trip through
+// HBM in front of a 13 us attention launch.  Here every workgroup (64 queries of one (batch, head)) normalises the source rows itself
+// and projects them onto ITS head's 8 + 8 key / value dims while it stages them -- 16 MFMAs per 16 source rows, recomputed by the
+// ~7 workgroups that share a (batch, head): a few microseconds, no launch, no q / k / v arrays.  Layouts (v_mfma_f32_16x16x4_f32):
+//   source tile of 16 rows: lane (i, g) holds the normalised channels 16g .. 16g+15 of row i; MFMA step s contracts channel 16g + s of
+//     lane group g (A = rows); B = wkv[head][s][lane (n, g)] = W_k|v[8 head + n][16g + s] (n < 8: key dim n, else value dim n - 8).
+//     The accumulator of lane (n, g) then holds rows 4g .. 4g+3 of output column n -> K image / transposed V image in LDS.
+//   queries: Q^T = W_q x^T with the rows of W_q arranged so that lane (query, g) ends up with dims 2g, 2g+1 in its first two
+//     accumulator registers -- exactly the (qa, qb) operands of the score MFMAs above.
+struct MhaLnArgs {
+  const float* x; int64_t ldx; const float* y; int64_t ldy;      // query rows [B*Tq], source rows [B*Tk] (y == x: self-attention)
+  const float *gamma, *beta; float eps;
+  const float *wq, *wkv;                                          // [8 heads][16 steps][64 lanes]
+  const float *bq, *bk, *bv;                                      // [64] each
+  float* o; int64_t ldo; int Tq, Tk, Tcp; float scale;
+};
+
+// normalised channels 16g .. 16g+15 of one row (LayerNorm over all 64: the other 48 sit in the three partner lanes); the row's 16 raw
+// channels are loaded by the caller (mha_ln_load), a tile ahead of their use
+__device__ __forceinline__ void mha_ln_load(const float* __restrict__ rp, int g, f32x4 (&v)[4]) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = *reinterpret_cast<const f32x4*>(rp + 16 * g + 4 * t);
+}
+__device__ __forceinline__ void mha_ln_norm(const f32x4 (&v)[4], const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int g,
+                                            float (&xn)[16]) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) s += (v[t][0] + v[t][1]) + (v[t][2] + v[t][3]);
+  s += cmr_xor16(s);
+  s += cmr_xhalf(s);
+  const float mean = s * (1.f / 64.f);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[t][e] - mean;
+      xn[4 * t + e] = d;
+      q += d * d;
+    }
+  q += cmr_xor16(q);
+  q += cmr_xhalf(q);
+  const float rstd = 1.f / sqrtf(q * (1.f / 64.f) + eps);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x4 gv = *reinterpret_cast<const f32x4*>(gamma + 16 * g + 4 * t);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(beta + 16 * g + 4 * t);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xn[4 * t + e] = xn[4 * t + e] * rstd * gv[e] + bv[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void mha_ln_kernel(const MhaLnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float kv[];  // K_h [Tcp][8], then V_h^T [9][Tcp] (row 8 = zeros)
+  const int Tcp = a.Tcp, Tq = a.Tq, Tk = a.Tk;
+  float* ks = kv;
+  float* vt = kv + (size_t)Tcp * DH;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  const int q0 = (blockIdx.x * 4 + wave) * 16;
+  const bool active = q0 < Tq;
+  // this head's projection fragments: one float per lane and step
+  float wkv[16], wq[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    wkv[s] = a.wkv[(head * 16 + s) * 64 + lane];
+    wq[s] = a.wq[(head * 16 + s) * 64 + lane];
+  }
+  const float bkv = i < 8 ? a.bk[head * DH + i] : a.bv[head * DH + i - 8];
+  // ---- queries of this wave: qa, qb = Q[query i][2g], Q[query i][2g + 1]
+  float qa, qb;
+  {
+    const int tq = q0 + i < Tq ? q0 + i : Tq - 1;
+    float xn[16];
+    f32x4 raw[4];
+    mha_ln_load(a.x + ((int64_t)b * Tq + tq) * a.ldx, g, raw);
+    mha_ln_norm(raw, a.gamma, a.beta, a.eps, g, xn);
+    mha_f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s], xn[s], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wq[s + 1], xn[s + 1], c1, 0, 0, 0);
+    }
+    qa = (c0[0] + c1[0]) + a.bq[head * DH + 2 * g];
+    qb = (c0[1] + c1[1]) + a.bq[head * DH + 2 * g + 1];
+  }
+  const float* krow = ks + i * DH + 2 * g;                       // + k0 * DH
+  const float* vrow = vt + (i < 8 ? i : 8) * Tcp + 4 * g;        // + k0
+  float m = -INFINITY, l = 0.f;
+  mha_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int t = threadIdx.x; t < Tcp; t += 256) vt[8 * Tcp + t] = 0.f;
+  const float* yb = a.y + (int64_t)b * Tk * a.ldy;
+  for (int c0k = 0; c0k < Tk; c0k += Tcp) {
+    if (c0k > 0) __syncthreads();                                // everybody done with the previous chunk
+    // ---- stage the chunk: wave w projects the 16-row source tiles w, w + 4, ... (rows past the end: zeros)
+    // (the next tile's rows are requested before this tile is normalised and multiplied: one memory round trip per chunk, not per tile)
+    auto src_row = [&](int t0) __attribute__((always_inline)) {
+      const int src = c0k + t0 + i;
+      return yb + (int64_t)(src < Tk ? src : Tk - 1) * a.ldy;
+    };
+    f32x4 nxt[4];
+    mha_ln_load(src_row(wave * 16), g, nxt);
+    for (int t0 = wave * 16; t0 < Tcp; t0 += 64) {
+      f32x4 cur[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+      mha_ln_load(src_row(t0 + 64 < Tcp ? t0 + 64 : t0), g, nxt);
+      float xn[16];
+      mha_ln_norm(cur, a.gamma, a.beta, a.eps, g, xn);
+      mha_f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 16; s += 2) {
+        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s], wkv[s], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xn[s + 1], wkv[s + 1], d1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 4 * g + r;                            // row of the chunk; column i of the projection
+        const float val = c0k + t < Tk ? (d0[r] + d1[r]) + bkv : 0.f;
+        if (i < 8) ks[t * DH + i] = val;
+        else vt[(i - 8) * Tcp + t] = val;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int nk = Tk - c0k < Tcp ? Tk - c0k : Tcp;
+    for (int k0 = 0; k0 < nk; k0 += 32) {
+      const float2 ka0 = *reinterpret_cast<const float2*>(krow + k0 * DH);
+      const float2 ka1 = *reinterpret_cast<const float2*>(krow + (k0 + 16) * DH);
+      const mha_f32x4 vf0 = *reinterpret_cast<const mha_f32x4*>(vrow + k0);
+      const mha_f32x4 vf1 = *reinterpret_cast<const mha_f32x4*>(vrow + k0 + 16);
+      mha_f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.x, qa, s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.x, qa, s1, 0, 0, 0);
+      s0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka0.y, qb, s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ka1.y, qb, s1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s0[r] = k0 + 4 * g + r < nk ? s0[r] * a.scale : -INFINITY;
+        s1[r] = k0 + 16 + 4 * g + r < nk ? s1[r] * a.scale : -INFINITY;
+      }
+      float bm = fmaxf(fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3])), fmaxf(fmaxf(s1[0], s1[1]), fmaxf(s1[2], s1[3])));
+      bm = fmaxf(bm, cmr_xor16(bm));
+      bm = fmaxf(bm, cmr_xhalf(bm));
+      const float mn = fmaxf(m, bm);
+      const float alpha = mha_exp<false>(m - mn);
+      m = mn;
+      mha_f32x4 p0, p1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p0[r] = mha_exp<false>(s0[r] - mn);
+        p1[r] = mha_exp<false>(s1[r] - mn);
+      }
+      l = l * alpha + (((p0[0] + p0[1]) + (p0[2] + p0[3])) + ((p1[0] + p1[1]) + (p1[2] + p1[3])));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] *= alpha;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf0[r], p0[r], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(vf1[r], p1[r], acc, 0, 0, 0);
+    }
+  }
+  if (!active) return;
+  l += cmr_xor16(l);
+  l += cmr_xhalf(l);
+  if (g < 2 && q0 + i < Tq) {
+    const float inv = 1.f / l;
+    f32x4 out = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+    *reinterpret_cast<f32x4*>(a.o + ((int64_t)b * Tq + q0 + i) * a.ldo + head * DH + 4 * g) = out;
+  }
+}
+
 // partial sums over a slab of TS tokens: thread (h,d,v) accumulates K[s,h,d]*V[s,h,v]/S; threads with
 // v == 0 also accumulate Ksum.  part layout: [B][nslab][576]  (512 KV entries then 64 Ksum entries)
 constexpr int LA_TS = 32;
@@ -324,6 +498,24 @@ extern "C" int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t 
 extern "C" int cmr_mha_expf_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                 float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
   return mha_launch(true, q, ldq, k, ldk, v, ldv, o, ldo, B, Tq, Tk, stream);
+}
+
+extern "C" int cmr_mha_ln_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gamma, const float* beta, float eps,
+                              const float* wq_frag, const float* wkv_frag, const float* bq, const float* bk, const float* bv, float* o,
+                              int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
+  CMR_REQUIRE(x && y && gamma && beta && wq_frag && wkv_frag && bq && bk && bv && o && B > 0 && B <= 65535 && Tq > 0 && Tk > 0);
+  CMR_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldo % 4 == 0 && cmr_aligned16(x) && cmr_aligned16(y) && cmr_aligned16(o) &&
+              cmr_aligned16(gamma) && cmr_aligned16(beta));
+  const int Tkp = (Tk + 31) / 32 * 32;
+  int Tcp = Tkp < CMR_MHA_KEY_CHUNK ? Tkp : CMR_MHA_KEY_CHUNK;
+  Tcp = (Tcp + 63) / 64 * 64;                          // whole 16-row tiles for each of the four staging waves
+  const size_t smem = (size_t)Tcp * (DH + 9) * sizeof(float);
+  CMR_REQUIRE(smem <= 160 * 1024);
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(mha_ln_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  const MhaLnArgs a{x, ldx, y, ldy, gamma, beta, eps, wq_frag, wkv_frag, bq, bk, bv, o, ldo, Tq, Tk, Tcp, 0.35355339059327373f};
+  hipLaunchKernelGGL(mha_ln_kernel, dim3((Tq + 63) / 64, NH, B), dim3(256), smem, stream, a);
+  return cmr_launch_status();
 }
 
 extern "C" int cmr_mha_dropout_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o,

@@ -356,8 +356,18 @@ __global__ __launch_bounds__(1024) void la_state_final_kernel(const float* __res
   __shared__ float red[16][64];
   const int b = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;
   const float* p = part + (int64_t)b * npart * LA_STATE + col;
+  // npart <= 256 (32 slabs x 8 waves): the <= 16 partials of this thread are requested together and summed in index order -- the same
+  // sum as the one-load-per-iteration loop, without 16 memory round trips behind each other
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int i = grp + 16 * j;
+    v[j] = p[(int64_t)(i < npart ? i : 0) * LA_STATE];
+  }
   float s = 0.f;
-  for (int i = grp; i < npart; i += 16) s += p[(int64_t)i * LA_STATE];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s += grp + 16 * j < npart ? v[j] : 0.f;
+  for (int i = grp + 256; i < npart; i += 16) s += p[(int64_t)i * LA_STATE];       // (not reached with the launch geometry above)
   red[grp][threadIdx.x & 63] = s;
   __syncthreads();
   if (grp == 0) {

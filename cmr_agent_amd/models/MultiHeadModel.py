@@ -98,6 +98,17 @@ class GeometricDistanceHead(_Head):
         return self.finish_cl(cl, *self.trunk_cl(cl))
 
 
+_EYE4 = {}
+
+
+def _eye4(dev):
+    """Cached [1,4,4] identity per device (callers clone it: data['matrix_accumulated'] is theirs to modify)."""
+    key = str(dev)
+    if key not in _EYE4:
+        _EYE4[key] = torch.eye(4, device=dev).unsqueeze(0)
+    return _EYE4[key]
+
+
 class MultiHeadModel(Planned):
     def __init__(self, config):
         super().__init__()
@@ -160,6 +171,6 @@ class MultiHeadModel(Planned):
         data_batch['pc_is_in_cam_scores'] = cl["pc_prob"].view(B, N)
         data_batch['img_overlap_pred'] = cl["img_prob"].view(B, h, w)            # reference: view(B, 40, 128), :340
         data_batch['inlier_mask_in_cam_i'] = data_batch['pc_overlap_pred_standby']
-        data_batch['matrix_accumulated'] = torch.eye(4, device=cl["pc"].device).unsqueeze(0)
+        data_batch['matrix_accumulated'] = _eye4(cl["pc"].device).clone()          # one copy launch instead of eye's three
         data_batch['_cmr'] = cl
         return 0

@@ -72,6 +72,21 @@ def frag_pack16(w):
     return w.reshape(n // 16, 16, k // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
 
 
+def mha_ln_frags(wq, bq, wk, bk, wv, bv):
+    """nn.Linear weights [64 out, 64 in] / biases of an 8 x 8-head attention -> operands of cmr_mha_ln_f32:
+    wq_frag [8][16][64]: lane 16 g + m of step s holds Wq[8 h + 2 (m // 4) + m % 4][16 g + s] for m % 4 < 2, else 0 (the query's dims
+    2g', 2g'+1 land in the first two accumulator registers of lane group g' = m // 4);
+    wkv_frag [8][16][64]: lane 16 g + n holds Wk[8 h + n][16 g + s] (n < 8) or Wv[8 h + n - 8][16 g + s]."""
+    dev = wq.device
+    h, s, g, m = torch.meshgrid(torch.arange(8), torch.arange(16), torch.arange(4), torch.arange(16), indexing="ij")
+    h, s, g, m = h.to(dev), s.to(dev), g.to(dev), m.to(dev)
+    cin = 16 * g + s
+    qrow = 8 * h + 2 * (m // 4) + m % 4
+    wq_f = torch.where(m % 4 < 2, wq[qrow.clamp(max=63), cin], torch.zeros((), device=dev, dtype=wq.dtype))
+    wkv_f = torch.where(m < 8, wk[(8 * h + m).clamp(max=63), cin], wv[(8 * h + m - 8).clamp(min=0), cin])
+    return (wq_f.reshape(-1).contiguous(), wkv_f.reshape(-1).contiguous(), bq.contiguous(), bk.contiguous(), bv.contiguous())
+
+
 def frag_pack_bf16(w, acc_order=False):
     """W [n_out, k] (n_out % 32 == 0, k % 16 == 0) -> bf16 MFMA A fragments [n_out/32][k/16][64 lanes][8] for
     v_mfma_f32_32x32x16_bf16: lane = 32 h + l holds W[32 tile + l][c(s, h, j)], j = 0..7.  Natural order: c = 16 s + 8 h + j (the

@@ -35,7 +35,8 @@ class Attention(Planned):
         return dict(q=(wq, bq), kv=kv, qkv=qkv, out=(wo, bo),
                     q_f=(f(wq), bq), kv_f=(f(kv[0]), kv[1]), qkv_f=(f(qkv[0]), qkv[1]), out_f=(f(wo), bo),
                     out_f16=(_pack.frag_pack16(wo), bo),
-                    q_b=(fb(wq), bq), kv_b=(fb(kv[0]), kv[1]), qkv_b=(fb(qkv[0]), qkv[1]), out_b=(fb(wo), bo))     # bf16 mode
+                    q_b=(fb(wq), bq), kv_b=(fb(kv[0]), kv[1]), qkv_b=(fb(qkv[0]), qkv[1]), out_b=(fb(wo), bo),     # bf16 mode
+                    ln_mha=_pack.mha_ln_frags(wq, bq, wk, bk, wv, bv))
 
     def rows(self, xn, yn, B, tx, ty, residual):
         """out-projection(softmax-attention(xn, yn)) + residual; yn is None for self-attention."""
@@ -89,7 +90,10 @@ class Block(Planned):
         return dict(n1=g(self.attention_norm), n2=g(self.ffn_norm))
 
     ROWS16 = True     # fp32: the block tail on 16-row tiles (twice the workgroups for the 3 344 / 2 048-row proxy sets)
-    FUSED = True      # three launches per block (ops.ln64_linear, ops.mha, ops.vit_out_ffn); False = one per reference op
+    FUSED = True      # fused launches per block (ops.ln64_linear, ops.mha, ops.vit_out_ffn); False = one per reference op
+    FUSED_QKV = True  # two launches per block: LayerNorm + Q / K / V projections inside the attention launch (ops.mha_ln) ...
+    FUSED_QKV_MAX = 8192   # ... while (query blocks per head) x (source rows) stays below this: every query block re-projects the source rows
+                           # (KITTI: 7 x 418; the 1 400-proxy self-attention of the nuScenes shape, 22 x 1 400, keeps the separate projection launch)
 
     def rows(self, x, y, B, tx, ty):
         self._require_eval()
@@ -97,7 +101,10 @@ class Block(Planned):
         if self.FUSED and self.ffn.fc1.out_features == 1024:
             a, m = self.attn.plan(), self.ffn.plan()
             sfx = "_b" if ops.CONV_BF16 else "_f"            # bf16 mode: bf16 weight fragments, bf16 matrix cores
-            if y is None or y is x:
+            if self.FUSED_QKV and ((tx + 63) // 64) * ty <= self.FUSED_QKV_MAX:
+                # LayerNorm + projections inside the attention launch (both modes: the projections are 16 fp32 MFMAs per 16 rows there)
+                ctx = ops.mha_ln(x, None if (y is None or y is x) else y, p["n1"], self.LN_EPS, a["ln_mha"], B, tx, ty)
+            elif y is None or y is x:
                 qkv = ops.ln64_linear(x, *a["qkv" + sfx], *p["n1"], self.LN_EPS)
                 ctx = ops.mha(qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192], B, tx, tx)
             else:

@@ -280,6 +280,17 @@ def mha(q, k, v, B, Tq, Tk, out=None, libm_exp=False):
     return out
 
 
+def mha_ln(x, y, ln, eps, frags, B, Tq, Tk, out=None):
+    """LayerNorm + Q / K / V projections + softmax attention in one launch (cmr_mha_ln_f32); frags = _pack.mha_ln_frags(...)."""
+    wq_f, wkv_f, bq, bk, bv = frags
+    if out is None:
+        out = torch.empty((B * Tq, 64), dtype=f32, device=x.device)
+    y = x if y is None else y
+    _lib.call("cmr_mha_ln_f32", _p(_rows(x)), _ld(x), _p(_rows(y)), _ld(y), _p(ln[0]), _p(ln[1]), float(eps), _p(wq_f), _p(wkv_f), _p(bq), _p(bk),
+              _p(bv), _p(out), _ld(out), B, Tq, Tk, _stream())
+    return out
+
+
 def la_reduce(kf, v, B, S):
     ws_bytes = _lib.load().cmr_la_reduce_workspace_bytes(B, S)
     ws = torch.empty((ws_bytes // 4,), dtype=f32, device=kf.device)

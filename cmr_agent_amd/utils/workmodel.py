@@ -83,6 +83,9 @@ WORK = {
     "cmr_transpose_f32": lambda a: (0, 2 * F * a["batch"] * a["R"] * a["Cn"]),
     "cmr_mha_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),
     "cmr_mha_expf_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),
+    # attention + the projections (64 -> 64 for the queries, 64 -> 128 for the source rows; algorithmic: once per row, not per workgroup)
+    "cmr_mha_ln_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64 + 2.0 * 64 * a["B"] * (64 * a["Tq"] + 128 * a["Tk"]),
+                                F * 64 * a["B"] * (2 * a["Tq"] + a["Tk"])),
     "cmr_la_reduce_f32": lambda a: (2.0 * a["B"] * a["S"] * 576, F * a["B"] * a["S"] * 128),
     "cmr_la_apply_f32": lambda a: (2.0 * a["B"] * a["L"] * 576, F * a["B"] * a["L"] * 128),
     "cmr_agent_heads_f32": _heads,

@@ -144,6 +144,14 @@ int cmr_mha_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const 
  * of the training tape, whose backward kernels (cmr_mha_bwd_f32) recompute the probabilities with expf. */
 int cmr_mha_expf_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, float* o, int64_t ldo, int B,
                      int Tq, int Tk, hipStream_t stream);
+/* LayerNorm(64) + the block's query / key / value projections + the attention above in ONE launch (inference; ImageViT.py:81-108,
+ * IMGPCEncoder.py:36-58, :93-94 -- x and y pass through the SAME norm): o = softmax(Q K^T / sqrt 8) V with Q = LN(x) Wq^T + bq,
+ * K | V = LN(y) Wk|v^T + bk|v (y == x: self-attention).  Every workgroup (64 queries of one (batch, head)) normalises and projects the
+ * source rows onto its head's dims while staging them, so q / k / v never exist in memory.  wq_frag / wkv_frag: [8 heads][16][64] floats
+ * (cmr_agent_amd/models/_pack.py:mha_ln_frags).  Same value as cmr_ln64_linear_f32 + cmr_mha_f32 up to fp32 summation order. */
+int cmr_mha_ln_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gamma, const float* beta, float eps,
+                   const float* wq_frag, const float* wkv_frag, const float* bq, const float* bk, const float* bv, float* o, int64_t ldo,
+                   int B, int Tq, int Tk, hipStream_t stream);
 /* Process-wide switch between the two softmax-attention kernels (1 = v_mfma_f32_16x16x4_f32 for Q K^T and P V, the default;
  * 0 = one query per 4 lanes on the vector ALUs): A/B measurements and tests only.  Returns the previous setting. */
 int cmr_set_mha_variant(int mfma);

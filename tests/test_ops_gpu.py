@@ -188,6 +188,33 @@ def test_mha_key_chunks_and_libm_variant(ops, B, Tq, Tk):
     assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
+@pytest.mark.parametrize("B,Tq,Tk,cross", [(2, 50, 30, True), (1, 418, 418, False), (2, 256, 418, True), (1, 100, 1400, True), (3, 17, 16, True),
+                                           (1, 1400, 1400, False), (2, 15, 513, True)])
+def test_mha_with_layernorm_and_projections_in_the_launch(ops, B, Tq, Tk, cross):
+    """cmr_mha_ln_f32: LayerNorm + Q / K / V projections + attention in one launch against a float64 restatement of
+    LN -> Linear x 3 -> softmax attention, and against the two-launch path (ln64_linear + mha)."""
+    from cmr_agent_amd.models._pack import mha_ln_frags, frag_pack
+    x = rnd(B * Tq, 64, seed=41, lo=-2, hi=2)
+    y = rnd(B * Tk, 64, seed=42, lo=-2, hi=2) if cross else x
+    wq, wk, wv = (rnd(64, 64, seed=43 + i) / 4 for i in range(3))
+    bq, bk, bv = (rnd(64, seed=46 + i) for i in range(3))
+    ga, be = rnd(64, seed=49) + 1.5, rnd(64, seed=50)
+    ln = lambda t: torch.nn.functional.layer_norm(t.double(), (64,), ga.double(), be.double(), 1e-6)
+    q = (ln(x) @ wq.double().t() + bq.double()).view(B, Tq, 8, 8).permute(0, 2, 1, 3)
+    k = (ln(y) @ wk.double().t() + bk.double()).view(B, Tk, 8, 8).permute(0, 2, 1, 3)
+    v = (ln(y) @ wv.double().t() + bv.double()).view(B, Tk, 8, 8).permute(0, 2, 1, 3)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(8), -1) @ v).permute(0, 2, 1, 3).reshape(B * Tq, 64)
+    d = lambda t: t.to(DEV)
+    frags = mha_ln_frags(d(wq), d(bq), d(wk), d(bk), d(wv), d(bv))
+    xd, yd = d(x), (d(y) if cross else None)
+    got = ops.mha_ln(xd, yd, (d(ga), d(be)), 1e-6, frags, B, Tq, Tk)
+    close(got, ref, 3e-5, "mha_ln")
+    if cross:
+        qd, kvd = ops.ln64_linear(xd, frag_pack(d(wq)), d(bq), d(ga), d(be), 1e-6, yd, frag_pack(torch.cat([d(wk), d(wv)], 0)), torch.cat([d(bk), d(bv)]))
+        two = ops.mha(qd, kvd[:, :64], kvd[:, 64:], B, Tq, Tk)
+        close(got, two.cpu(), 3e-5, "mha_ln vs ln64_linear + mha")
+
+
 def _mha_case(ops, B, Tq, Tk, libm_exp=False):
     q, k, v = rnd(B * Tq, 64, seed=33, lo=-3, hi=3), rnd(B * Tk, 64, seed=34, lo=-3, hi=3), rnd(B * Tk, 64, seed=35)
     qh = q.view(B, Tq, 8, 8).permute(0, 2, 1, 3).double()
