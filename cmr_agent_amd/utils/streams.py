@@ -40,6 +40,11 @@ def _side_stream(parent, i):
 _ONLY = set(t for t in os.environ.get("CMR_STREAMS_ONLY", "").split(",") if t)      # debugging: fork only these tags
 
 
+# forks whose MAIN branch is issued before the side branches ("*": every tagged fork; "none": the round-2 order, sides first).  Measured at
+# configs[1] (profiles/r03_mainfirst.txt): fp32 unchanged (401 vs 401 it/s), bf16 mode 808-820 -> 837-844 it/s with every fork main-first
+MAIN_FIRST = set(t for t in os.environ.get("CMR_STREAMS_MAIN_FIRST", "*").split(",") if t)
+
+
 def fork_join(*fns, tag=""):
     """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn on the current stream and
     returns all results (in argument order) after joining.  Sequential on CPU / when disabled.  Forks may nest in eager
@@ -49,7 +54,7 @@ def fork_join(*fns, tag=""):
     if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY):
         return tuple(f() for f in fns)
     if _depth > 0 and torch.cuda.is_current_stream_capturing():
-        return tuple(f() for f in fns)
+        return tuple(f() for f in fns)                           # (argument order: the order the pipelined runtime was tuned with)
     main = torch.cuda.current_stream()
     sides = [_side_stream(main, i) for i in range(len(fns) - 1)]
     if any(s == main for s in sides):
@@ -59,10 +64,19 @@ def fork_join(*fns, tag=""):
     _depth += 1
     try:
         out = []
-        for s, f in zip(sides, fns[:-1]):
-            with torch.cuda.stream(s):
-                out.append(f())
-        out.append(fns[-1]())
+        if tag and (tag in MAIN_FIRST or ("*" in MAIN_FIRST and tag != "pipeline")):    # the two-stage pipeline keeps geo stage (side) first: 942 vs 849-875 it/s in bf16 mode
+            # issue order = the order in which a replayed hipGraph hands the nodes to the device: a main branch of few, long kernels
+            # (the image tower) goes first, the many short launches of the side branch are fed while it already runs
+            last = fns[-1]()
+            for s, f in zip(sides, fns[:-1]):
+                with torch.cuda.stream(s):
+                    out.append(f())
+            out.append(last)
+        else:
+            for s, f in zip(sides, fns[:-1]):
+                with torch.cuda.stream(s):
+                    out.append(f())
+            out.append(fns[-1]())
     finally:
         _depth -= 1
     for s in sides:
