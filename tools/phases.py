@@ -42,7 +42,7 @@ def main():
         pose, target = env.init(data)
         env.to_disentangled(target, data['pc'])
         for _ in range(cfg.action_num):
-            s2, s3 = env.observation_from_a_pose(data, pose)
+            s2, s3 = env.observation_from_a_pose(data, pose, materialize_state_2d=False)
             r, t, _ = agent(s2, s3)
             ar, at = agent.action_from_logits(r, t, deterministic=True)
             pose = env.step(ar, at, pose, cfg)
@@ -57,7 +57,7 @@ def main():
         from cmr_agent_amd.models.ImageResNet import to_nhwc
         s3r = torch.as_strided(s3, (B * N, 8), (8, 1)) if s3.stride(1) == 1 else None
         split = getattr(s2, "_cmr_split", None)
-        to, _ = graph_time(lambda: env.observation_from_a_pose(data, pose), 20)
+        to, _ = graph_time(lambda: env.observation_from_a_pose(data, pose, materialize_state_2d=False), 20)
         t2, _ = graph_time(lambda: agent._embed_2d(to_nhwc(s2), B, split), 20)
         t3, _ = graph_time(lambda: agent._embed_3d_any(s3r, B, N), 20)
         tf, _ = graph_time(lambda: agent(s2, s3), 20)
