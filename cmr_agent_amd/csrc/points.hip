@@ -69,18 +69,26 @@ __global__ __launch_bounds__(256) void index_to_global_kernel(const int64_t* __r
 }
 
 // ---- CSR (segments = destination rows, members listed in ascending source order) ------------
-// One wave per segment scans the `n_per_batch` keys of its batch.  Deterministic and stable.
+// Counting sort: count the keys with atomics, scan, drop every source row into its segment through a per-segment cursor (any order),
+// then ONE wave per segment puts its members into ascending order (rank by counting in LDS; segments are a handful to a few hundred
+// rows).  Deterministic and stable like the round-1 build (one wave per segment scanning ALL keys of its batch, twice: 10 240 segments x
+// 16 384 keys = 153 us at BASELINE configs[1]; 212 us per call at 65 536 points), at the cost of the keys themselves.  Keys outside
+// their batch's segment range are ignored, as before.
+__device__ __forceinline__ bool csr_key_ok(int32_t k, int b, int seg_per_batch) {
+  return k >= b * seg_per_batch && k < (b + 1) * seg_per_batch;
+}
+
+__global__ __launch_bounds__(256) void csr_zero_kernel(int32_t* __restrict__ count, int total_seg) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < total_seg) count[i] = 0;
+}
+
 __global__ __launch_bounds__(256) void csr_count_kernel(const int32_t* __restrict__ key, int32_t* __restrict__ count,
-                                                        int n_per_batch, int seg_per_batch, int total_seg) {
-  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (seg >= total_seg) return;
-  const int b = seg / seg_per_batch;
-  const int32_t* kb = key + (int64_t)b * n_per_batch;
-  int c = 0;
-  for (int i = lane; i < n_per_batch; i += 64) c += (kb[i] == seg);
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m);
-  if (lane == 0) count[seg] = c;
+                                                        int n_per_batch, int seg_per_batch, int64_t total_keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_keys) return;
+  const int32_t k = key[i];
+  if (csr_key_ok(k, (int)(i / n_per_batch), seg_per_batch)) atomicAdd(count + k, 1);
 }
 
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t* __restrict__ count,
@@ -105,14 +113,47 @@ __global__ __launch_bounds__(1024) void exclusive_scan_kernel(const int32_t* __r
   if (tid == 1023) offsets[n] = sums[1023];
 }
 
-__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ key, const int32_t* __restrict__ offsets,
-                                                       int32_t* __restrict__ order, int n_per_batch, int seg_per_batch,
-                                                       int total_seg) {
-  const int seg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+// every source row takes the next free slot of its segment (count[] runs down to zero: it is the cursor)
+__global__ __launch_bounds__(256) void csr_scatter_kernel(const int32_t* __restrict__ key, const int32_t* __restrict__ offsets,
+                                                          int32_t* __restrict__ count, int32_t* __restrict__ order, int n_per_batch,
+                                                          int seg_per_batch, int64_t total_keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total_keys) return;
+  const int32_t k = key[i];
+  if (!csr_key_ok(k, (int)(i / n_per_batch), seg_per_batch)) return;
+  const int slot = atomicSub(count + k, 1) - 1;
+  order[offsets[k] + slot] = (int32_t)i;
+}
+
+// one wave per segment: members into ascending order (they are distinct row numbers: rank = how many are smaller), count[] restored
+constexpr int CSR_SORT_CAP = 1024;
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int32_t* __restrict__ key, const int32_t* __restrict__ offsets,
+                                                       int32_t* __restrict__ count, int32_t* __restrict__ order, int n_per_batch,
+                                                       int seg_per_batch, int total_seg) {
+  __shared__ int32_t buf[4][CSR_SORT_CAP];
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int seg = blockIdx.x * 4 + w;
   if (seg >= total_seg) return;
+  const int lo = offsets[seg], n = offsets[seg + 1] - lo;
+  if (lane == 0) count[seg] = n;
+  if (n <= 1) return;
+  if (n <= CSR_SORT_CAP) {
+    volatile int32_t* mine = buf[w];
+    for (int j = lane; j < n; j += 64) mine[j] = order[lo + j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < n; j += 64) {
+      const int32_t x = mine[j];
+      int rank = 0;
+      for (int q = 0; q < n; ++q) rank += mine[q] < x;
+      order[lo + rank] = x;
+    }
+    return;
+  }
+  // a segment longer than the LDS buffer: the round-1 way for this segment (scan the batch's keys in order)
   const int b = seg / seg_per_batch;
   const int32_t* kb = key + (int64_t)b * n_per_batch;
-  int pos = offsets[seg];
+  int pos = lo;
   for (int i0 = 0; i0 < n_per_batch; i0 += 64) {
     const int i = i0 + lane;
     const bool hit = i < n_per_batch && kb[i] == seg;
@@ -709,11 +750,15 @@ extern "C" int cmr_index_to_global_i32(const int64_t* idx, int32_t* out, int B, 
 extern "C" int cmr_csr_build_i32(const int32_t* key, int32_t* count, int32_t* offsets, int32_t* order, int B,
                                  int n_per_batch, int seg_per_batch, hipStream_t stream) {
   CMR_REQUIRE(key && count && offsets && order && B > 0 && n_per_batch > 0 && seg_per_batch > 0);
+  CMR_REQUIRE((int64_t)B * seg_per_batch < 2147483647LL && (int64_t)B * n_per_batch < 2147483647LL);
   const int total = B * seg_per_batch;
-  hipLaunchKernelGGL(csr_count_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, key, count, n_per_batch,
-                     seg_per_batch, total);
-  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, count, offsets, total);
-  hipLaunchKernelGGL(csr_fill_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, key, offsets, order, n_per_batch,
+  const int64_t nkeys = (int64_t)B * n_per_batch;
+  hipLaunchKernelGGL(csr_zero_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, count, total);
+  hipLaunchKernelGGL(csr_count_kernel, GRID1D(nkeys), dim3(256), 0, stream, key, count, n_per_batch, seg_per_batch, nkeys);
+  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, stream, (const int32_t*)count, offsets, total);
+  hipLaunchKernelGGL(csr_scatter_kernel, GRID1D(nkeys), dim3(256), 0, stream, key, (const int32_t*)offsets, count, order, n_per_batch,
+                     seg_per_batch, nkeys);
+  hipLaunchKernelGGL(csr_sort_kernel, dim3((total + 3) / 4), dim3(256), 0, stream, key, (const int32_t*)offsets, count, order, n_per_batch,
                      seg_per_batch, total);
   return cmr_launch_status();
 }

@@ -383,6 +383,28 @@ def test_layout_and_csr(ops):
     assert torch.equal(order.cpu().long(), torch.sort(gref, stable=True)[1])
 
 
+@pytest.mark.parametrize("B,N,M,skew", [(2, 5000, 7, 0), (1, 40000, 3, 0), (3, 3000, 1280, 0), (2, 20000, 50, 3), (8, 16384, 1280, 0), (1, 1, 1, 0)])
+def test_csr_build_counting_sort(ops, B, N, M, skew):
+    """cmr_csr_build_i32 as a counting sort with per-segment ordering: empty segments, segments beyond the 64 lanes of a wave, beyond the
+    1 024-entry LDS buffer (the scanning fallback), skewed distributions, keys that point outside their batch's segments (ignored: the
+    rows they would have occupied stay at the end of `order`, unreferenced)."""
+    g = torch.Generator().manual_seed(7 + N + M)
+    idx = torch.randint(0, M, (B, N), generator=g)
+    if skew:
+        idx = (idx.float() ** skew / float(M) ** (skew - 1)).long().clamp(max=M - 1)        # most rows in the first segments
+    key = (idx + torch.arange(B).view(B, 1) * M).reshape(-1).int()
+    bad = torch.rand(B * N, generator=g) < 0.01
+    if B * N > 100:
+        key[bad] = torch.where(torch.rand(int(bad.sum()), generator=g) < 0.5, torch.tensor(-3), torch.tensor(B * M + 5)).int()
+    offsets, order = ops.csr_build(key.to(DEV), B, N, M)
+    rows = torch.arange(B * N)
+    ok = (key >= (rows // N) * M) & (key < (rows // N + 1) * M)
+    cnt = torch.bincount(key[ok].long(), minlength=B * M)
+    assert torch.equal(offsets.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
+    want = rows[ok][torch.sort(key[ok].long(), stable=True)[1]]
+    assert torch.equal(order.cpu().long()[:int(ok.sum())], want)
+
+
 def test_knn_and_nearest(ops):
     B, M = 2, 1280
     nodes = _cloud(B, M, 40)
