@@ -517,7 +517,12 @@ int launch_linear_row64(const LinearArgs& a, hipStream_t stream) {
 // Split-K variant: one workgroup = one 32-row tile x 64 output channels, its 8 waves each take 1/8 of K
 // (operands straight from global / L2 in fragment layout, 4 k-groups prefetched ahead), partial
 // accumulators are summed through LDS and wave 0 runs the float4 epilogue.
-__global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) {
+// PATCH: the rows are the P x P patches of an NHWC map [B][H][W][C] (a stride-P convolution as a GEMM: ImageViT.py:37-56), read in place:
+// row (b, Y, X) = the P row segments of P C contiguous floats at ((b H + P Y + py) W + P X) C -- no patchified copy of the map
+// (cmr_patchify_nhwc_f32 wrote and this kernel re-read 55 MB at BASELINE configs[1]: 22 + 71 us).
+struct PatchGeom { int H, W, C, P; };
+template <bool PATCH>
+__global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a, const PatchGeom pg) {
   __shared__ __attribute__((aligned(16))) float red[7 * 32 * 64];      // partial tiles of waves 1..7
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, l31 = lane & 31;
@@ -527,7 +532,24 @@ __global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) 
   const bool valid = row < a.rows;
   if (!valid) row = 0;
   const int kper = a.k1 / 8;                          // multiple of 8 (k1 % 64 == 0)
-  const float* xp = a.x1 + row * a.ld1 + wave * kper + 4 * h;
+  const float* xp;
+  int pc = 0, seg_skip = 0;                           // PATCH: floats per patch row segment, distance from a segment's end to the next one's start
+  if constexpr (PATCH) {
+    const int tw = pg.W / pg.P, th = pg.H / pg.P;
+    const int X = (int)(row % tw), Y = (int)((row / tw) % th), b = (int)(row / ((int64_t)tw * th));
+    pc = pg.P * pg.C;
+    seg_skip = pg.W * pg.C - pc;
+    const int k0 = wave * kper + 4 * h, py0 = k0 / pc;
+    xp = a.x1 + (((int64_t)b * pg.H + pg.P * Y + py0) * pg.W + pg.P * X) * pg.C + (k0 - py0 * pc);
+  } else {
+    xp = a.x1 + row * a.ld1 + wave * kper + 4 * h;
+  }
+  // offset of k-group g of this lane from xp: g * 8 floats, plus the gaps between the patch row segments crossed on the way
+  const int koff0 = PATCH ? (wave * kper + 4 * h) % (pc > 0 ? pc : 1) : 0;
+  auto xoff = [&](int g) __attribute__((always_inline)) {
+    if constexpr (PATCH) return g * 8 + ((koff0 + g * 8) / pc) * seg_skip;
+    else return g * 8;
+  };
   const int c0n = col_base + l31, c1n = col_base + 32 + l31;
   const float* w0 = a.w + (int64_t)(c0n < a.n_out ? c0n : 0) * a.ldw + wave * kper + 4 * h;
   const float* w1 = a.w + (int64_t)(c1n < a.n_out ? c1n : 0) * a.ldw + wave * kper + 4 * h;
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int g = i < ng ? i : 0;
-    xc[i] = *reinterpret_cast<const f32x4*>(xp + g * 8);
+    xc[i] = *reinterpret_cast<const f32x4*>(xp + xoff(g));
     wc0[i] = *reinterpret_cast<const f32x4*>(w0 + g * 8);
     wc1[i] = *reinterpret_cast<const f32x4*>(w1 + g * 8);
   }
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(512) void linear_splitk_kernel(const LinearArgs a) 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int g = g0 + 4 + i < ng ? g0 + 4 + i : 0;
-      xn[i] = *reinterpret_cast<const f32x4*>(xp + g * 8);
+      xn[i] = *reinterpret_cast<const f32x4*>(xp + xoff(g));
       wn0[i] = *reinterpret_cast<const f32x4*>(w0 + g * 8);
       wn1[i] = *reinterpret_cast<const f32x4*>(w1 + g * 8);
     }
@@ -720,7 +742,7 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   // the 8 waves of a workgroup so that a 32-row tile is not one wave's serial chain of K/2 MFMAs
   if (vec_ok && !a.x2 && a.k1 % 64 == 0 && a.k1 >= 512 && rows <= 65536) {
     dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((n_out + 63) / 64));
-    hipLaunchKernelGGL(linear_splitk_kernel, grid, dim3(512), 0, stream, a);
+    hipLaunchKernelGGL(linear_splitk_kernel<false>, grid, dim3(512), 0, stream, a, PatchGeom{0, 0, 0, 0});
     return cmr_launch_status();
   }
   const unsigned gy = (unsigned)((n_out + 63) / 64);
@@ -731,6 +753,21 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
     dim3 grid((unsigned)((rows + 127) / 128), gy);
     hipLaunchKernelGGL(linear_kernel<1>, grid, dim3(256), 0, stream, a);
   }
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_patch_embed_f32(const float* x_nhwc, int B, int H, int W, int C, int P, const float* w, int64_t ldw, const float* bias,
+                                   const float* res, int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int n_out, hipStream_t stream) {
+  CMR_REQUIRE(x_nhwc && w && y && B > 0 && H > 0 && W > 0 && C > 0 && P > 0 && n_out > 0 && H % P == 0 && W % P == 0);
+  const int K = P * P * C;
+  const int64_t rows = (int64_t)B * (H / P) * (W / P);
+  // each of the 8 waves takes K / 8 of the contraction in float4 pieces that must not straddle a patch row segment
+  CMR_REQUIRE(K % 64 == 0 && K >= 512 && (P * C) % 8 == 0 && rows <= 65536 && (int64_t)B * H * W * C < 0x7fffffff);
+  CMR_REQUIRE(n_out % 4 == 0 && ldy % 4 == 0 && ldw % 4 == 0 && cmr_aligned16(x_nhwc) && cmr_aligned16(w) && cmr_aligned16(y) &&
+              (!bias || cmr_aligned16(bias)) && (!res || (ldres % 4 == 0 && cmr_aligned16(res))));
+  const LinearArgs a{x_nhwc, (int64_t)K, K, nullptr, 0, 0, nullptr, 1, w, ldw, bias, res, ldres, res_mod, y, ldy, rows, n_out, CMR_ACT_NONE, 0.f};
+  dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((n_out + 63) / 64));
+  hipLaunchKernelGGL(linear_splitk_kernel<true>, grid, dim3(512), 0, stream, a, PatchGeom{H, W, C, P});
   return cmr_launch_status();
 }
 

@@ -40,10 +40,9 @@ class _ObsContext:
         self.K = data['K'].to(dev).contiguous()
         cen = data.get('_cmr_centroid')
         self.mean4 = cen[1] if (cen is not None and cen[0] is pc) else _centroid(pc, self.pc4)
-        cells = self.B * self.h * self.w
-        # scatter-mean accumulators: zeroed once here, re-zeroed sparsely by every observation_finalize(clear=True)
-        self.acc = torch.zeros((cells, 64), dtype=torch.float32, device=dev)
-        self.cnt = torch.zeros((cells,), dtype=torch.float32, device=dev)
+        # scatter-mean accumulators of the materialised path: created (zeroed once) on first use, re-zeroed sparsely by every
+        # observation_finalize(clear=True); the inference loops never touch them
+        self.acc = self.cnt = None
         self.first = True
         # state of the direct projected-half path (materialize_state_2d=False): the map itself, its counts and every point's cell of the
         # previous observation; created on first use
@@ -112,6 +111,9 @@ def observation_from_a_pose(data, RT, materialize_state_2d=True):
         return obs2d, state3d.view(B, N, 8)[:, :, :5].permute(0, 2, 1)
     state2d = torch.empty((B, h, w, 128), dtype=torch.float32, device=dev) if materialize_state_2d else None
     proj = torch.empty((B, h, w, 64), dtype=torch.float32, device=dev)
+    if ctx.acc is None:
+        ctx.acc = torch.zeros((B * h * w, 64), dtype=torch.float32, device=dev)
+        ctx.cnt = torch.zeros((B * h * w,), dtype=torch.float32, device=dev)
     zero_first, ctx.dirty = ctx.dirty, True
     ops.project_scatter(ctx.pc4, ctx.feat, ctx.overlap, RT.contiguous(), ctx.K, ctx.mean4, B, N, h, w, ctx.acc, ctx.cnt,
                         state3d, zero_first=zero_first)

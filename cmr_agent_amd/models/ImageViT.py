@@ -62,7 +62,7 @@ class Embeddings(Planned):
             raise ValueError("1/4-scale map %dx%d is not a multiple of the patch size %d" % (h, w, P))
         T = (h // P) * (w // P)
         p = self.plan()
-        tokens = ops.linear(ops.patchify(f2, P), p["w"], p["b"], res=self._pos_rows(T, f2.device), res_mod=T)
+        tokens = ops.patch_embed(f2, P, p["w"], p["b"], res=self._pos_rows(T, f2.device), res_mod=T)       # patches read in place
         return tokens, T, f2, f1, f0
 
     def forward(self, x):

@@ -261,6 +261,20 @@ def patchify(x, P):
     return out
 
 
+def patch_embed(x, P, w, bias, res=None, res_mod=0):
+    """Conv2d(kernel = stride = P) on an NHWC map as one GEMM over the patches read in place: [B,H,W,C] -> [B*(H/P)*(W/P), n_out];
+    w [n_out, P*P*C] in (ky, kx, c) order.  Falls back to patchify + linear where the kernel does not serve the shape."""
+    B, H, W, C = x.shape
+    n_out, K = w.shape
+    rows = B * (H // P) * (W // P)
+    if K % 64 == 0 and K >= 512 and (P * C) % 8 == 0 and rows <= 65536 and n_out % 4 == 0 and x.is_contiguous() and x.dtype == f32:
+        out = torch.empty((rows, n_out), dtype=f32, device=x.device)
+        _lib.call("cmr_patch_embed_f32", _p(x), B, H, W, C, P, _p(w), w.stride(0), _p(bias), _p(res), _ld(res) if res is not None else 0,
+                  int(res_mod), _p(out), n_out, n_out, _stream())
+        return out
+    return linear(patchify(x, P), w, bias, res=res, res_mod=res_mod)
+
+
 def transpose(x):
     """[batch, R, C] contiguous -> [batch, C, R] contiguous."""
     b, r, c = x.shape

@@ -131,6 +131,12 @@ int cmr_upsample_concat_f32(const float* f, const float* proxy, float* out, int 
 
 /* non-overlapping PxP patches as rows [(ky,kx,c)] for the stride-P patch conv.  ImageViT.py:19-22,51. */
 int cmr_patchify_nhwc_f32(const float* x, float* out, int B, int H, int W, int C, int P, hipStream_t stream);
+/* The patch embedding itself (ImageViT.py:37-56: Conv2d(C, n_out, kernel = stride = P) + position rows) as ONE GEMM that reads the P x P
+ * patches of x [B][H][W][C] in place: y[(b, Y, X)][:] = sum_{py,px,c} w[:][(py P + px) C + c] x[b][P Y + py][P X + px][c] + bias (+ res
+ * rows, row % res_mod when res_mod > 0).  = cmr_patchify_nhwc_f32 + cmr_linear_f32 without the patchified copy.  P P C % 64 == 0,
+ * (P C) % 8 == 0, at most 65 536 patches. */
+int cmr_patch_embed_f32(const float* x_nhwc, int B, int H, int W, int C, int P, const float* w, int64_t ldw, const float* bias,
+                        const float* res, int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int n_out, hipStream_t stream);
 
 /* [batch][R][C] -> [batch][C][R]: layout changes at the nn.Module boundary (NCHW <-> NHWC). */
 int cmr_transpose_f32(const float* x, float* y, int batch, int R, int Cn, hipStream_t stream);

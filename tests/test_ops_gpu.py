@@ -163,6 +163,21 @@ def test_pool_upsample_patchify_transpose(ops):
     close(ops.transpose(t.to(DEV)), t.transpose(1, 2), 0, "transpose")
 
 
+@pytest.mark.parametrize("B,H,W,C,P,n", [(2, 16, 24, 64, 8, 64), (1, 88, 304, 64, 8, 64), (3, 8, 12, 32, 4, 64), (2, 12, 20, 64, 4, 128), (1, 6, 6, 8, 2, 64)])
+def test_patch_embedding_reads_patches_in_place(ops, B, H, W, C, P, n):
+    """cmr_patch_embed_f32 (split-K GEMM whose rows are the patches of the NHWC map, no patchified copy) against torch's stride-P
+    convolution + position rows; shapes the kernel does not serve take patchify + linear."""
+    x = rnd(B, H, W, C, seed=151)
+    w = rnd(n, C, P, P, seed=152) / math.sqrt(C * P * P)
+    b = rnd(n, seed=153)
+    T = (H // P) * (W // P)
+    pos = rnd(T, n, seed=154)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=P).permute(0, 2, 3, 1).reshape(B, T, n) + pos.double()
+    wk = w.permute(0, 2, 3, 1).reshape(n, -1).contiguous()
+    got = ops.patch_embed(x.to(DEV), P, wk.to(DEV), b.to(DEV), res=pos.to(DEV), res_mod=T)
+    close(got, ref.reshape(B * T, n), 5e-5, "patch embedding")
+
+
 @pytest.mark.parametrize("variant", [1, 0], ids=["mfma", "valu"])
 @pytest.mark.parametrize("B,Tq,Tk", [(2, 50, 30), (1, 418, 256), (2, 256, 418), (1, 70, 1400), (3, 17, 16), (2, 15, 100), (1, 64, 2047)])
 def test_mha(ops, B, Tq, Tk, variant):
