@@ -242,8 +242,11 @@ __device__ __forceinline__ float ws_act(float v, float slope) {
   return v > 0.f ? v : v * slope;
 }
 
+#ifndef CMR_WS_MINB
+#define CMR_WS_MINB 1
+#endif
 template <int NT, int G, int NSEG, int AC>
-__global__ __launch_bounds__(256) void linear_ws_kernel(const LinearArgs a) {
+__global__ __launch_bounds__(256, CMR_WS_MINB) void linear_ws_kernel(const LinearArgs a) {
   constexpr int KPAD = NSEG * 8 * G, LDWS = KPAD + 4;
   constexpr bool RES_EARLY = NT < 4;       // residual rows requested before the tile's MFMAs (registers permitting)
   extern __shared__ __attribute__((aligned(16))) float Ws[];   // [32*NT][KPAD + 4] weights, then [32*NT] bias
@@ -627,7 +630,7 @@ int launch_linear_ws_ga(LinearArgs a, hipStream_t stream) {
   if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
   const int64_t ntiles = (a.rows + 31) / 32;
   int64_t gx = (ntiles + 3) / 4;
-  if (gx > 512) gx = 512;                   // 2 resident workgroups per CU; each wave walks its tiles with stride
+  if (gx > 256 * (CMR_WS_MINB > 2 ? CMR_WS_MINB : 2)) gx = 256 * (CMR_WS_MINB > 2 ? CMR_WS_MINB : 2);   // resident workgroups per CU x 256; each wave walks its tiles with stride
   dim3 grid((unsigned)gx, (unsigned)((a.n_out + 32 * NT - 1) / (32 * NT)));
   hipLaunchKernelGGL((linear_ws_kernel<NT, G, NSEG, AC>), grid, dim3(256), smem, stream, a);
   return cmr_launch_status();

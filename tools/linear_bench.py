@@ -3,12 +3,15 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cmr_agent_amd import ops, _lib
+from cmr_agent_amd import _lib
+if "--lib" in sys.argv:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+from cmr_agent_amd import ops
 from kbench import timeit
 
 def main():
     dev = "cuda"
-    for rows, n_out, act, res in ((214016, 64, 0, False), (214016, 64, 4, False), (214016, 64, 0, True), (131072, 64, 4, False), (214016, 32, 4, False), (53504, 64, 0, False), (10240, 64, 0, False)):
+    for rows, n_out, act, res in ((214016, 64, 0, False), (214016, 64, 4, False), (214016, 64, 0, True), (131072, 64, 4, False), (214016, 32, 4, False), (53504, 64, 0, False), (10240, 64, 0, False), (524288, 64, 4, False)):
         x, w, b = torch.randn(rows, 64, device=dev), torch.randn(n_out, 64, device=dev) * 0.1, torch.randn(n_out, device=dev)
         r = torch.randn(rows, n_out, device=dev) if res else None
         out = torch.empty(rows, n_out, device=dev)
