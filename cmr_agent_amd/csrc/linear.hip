@@ -759,6 +759,154 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   return cmr_launch_status();
 }
 
+// ---- bf16 mode: the big contiguous row maps (K <= 128, n_out <= 128) on v_mfma_f32_32x32x16_bf16 -----------------------------------------
+// In fp32 a 64 -> 64 layer sits at the fp32 ridge (16 FLOP/B) and linear_ws_kernel is bound by its MFMA chain (34 us for 110 MB at 214 016
+// rows); on the bf16 cores the products take 1/16 of the time and the layer is a pure stream.  Transposed product (D[channel][row]: weights
+// = A operand, rows = B operand): a lane owns one row, its accumulator registers are 4 x 4 consecutive output channels -> float4 epilogue.
+// The whole weight matrix lives in registers as bf16 fragments (NT x KS x 4 VGPRs, converted once per wave); rows are converted on the fly.
+typedef __bf16 lin_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ lin_bf16x8 lin_pack8(const f32x4& lo, const f32x4& hi) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  uint4 w;
+  w.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[0], lo[1]}, b2));
+  w.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[2], lo[3]}, b2));
+  w.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){hi[0], hi[1]}, b2));
+  w.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){hi[2], hi[3]}, b2));
+  return __builtin_bit_cast(lin_bf16x8, w);
+}
+
+// AC as in linear_ws_kernel (0: none / ReLU / LeakyReLU through the slope, 1: GELU, 2: elu + 1); RES: a residual operand is given.
+// Register budget <= 128 (four waves per SIMD: a stream, not a GEMM): weight fragments 8 NT KS / 4 ... 32, the raw rows of the NEXT tile 8 KS,
+// this tile's rows as bf16 4 KS, accumulators 16 NT (initialised with the bias from LDS).
+template <int NT, int KS, int AC, bool RES>      // n_out <= 32 NT, K = 16 KS
+#ifndef CMR_LRB_MINB
+#define CMR_LRB_MINB 2
+#endif
+__global__ __launch_bounds__(256, CMR_LRB_MINB) void linear_rows_bf16_kernel(const LinearArgs a) {
+  __shared__ __attribute__((aligned(16))) float Bs[32 * NT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  if (tid < 32 * NT) Bs[tid] = (a.bias && tid < a.n_out) ? a.bias[tid] : 0.f;
+  // weight fragments: lane (cout l31, half h) of tile t, step ks holds W[32 t + l31][16 ks + 8 h .. + 7] (rows past n_out: zeros)
+  lin_bf16x8 wf[NT][KS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int n = 32 * t + l31;
+    const float* wr = a.w + (int64_t)(n < a.n_out ? n : 0) * a.ldw + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f32x4 lo = *reinterpret_cast<const f32x4*>(wr + 16 * ks), hi = *reinterpret_cast<const f32x4*>(wr + 16 * ks + 4);
+      if (n >= a.n_out) { lo = f32x4{0.f, 0.f, 0.f, 0.f}; hi = lo; }
+      wf[t][ks] = lin_pack8(lo, hi);
+    }
+  }
+  __syncthreads();
+  const uint32_t rows = (uint32_t)a.rows;
+  const uint32_t ntiles = (rows + 31) / 32, tstride = gridDim.x * 4;
+  auto load_tile = [&](uint32_t tile, f32x4 (&dst)[2 * KS]) __attribute__((always_inline)) {
+    uint32_t row = tile * 32 + l31;
+    row = (tile < ntiles && row < rows) ? row : 0;
+    const float* xp = a.x1 + (int64_t)row * a.ld1 + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      dst[2 * ks] = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
+      dst[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+    }
+  };
+  f32x4 raw[2 * KS];
+  uint32_t tile = blockIdx.x * 4 + wave;
+  load_tile(tile, raw);
+  for (; tile < ntiles; tile += tstride) {
+    lin_bf16x8 xb[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xb[ks] = lin_pack8(raw[2 * ks], raw[2 * ks + 1]);
+    load_tile(tile + tstride, raw);                            // next tile of this wave in flight under this one's products / stores
+    const uint32_t row = tile * 32 + l31;
+    f32x4 rv[RES ? NT : 1][4];
+    if constexpr (RES) {
+      const uint32_t rowc = row < rows ? row : 0;
+      const uint32_t rr = a.res_mod > 0 ? rowc % (uint32_t)a.res_mod : rowc;
+      const float* rp = a.res + (int64_t)rr * a.ldres + 4 * h;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 32 * t + 8 * q;
+          rv[t][q] = *reinterpret_cast<const f32x4*>(rp + (c + 4 * h < a.n_out ? c : 0));
+        }
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(&Bs[32 * t + 8 * q + 4 * h]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = bq[e];
+      }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], xb[ks], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[t][4 * q + e];
+          if constexpr (RES) v += rv[t][q][e];
+          acc[t][4 * q + e] = ws_act<AC>(v, a.act_param);
+        }
+    if (row < rows) {
+      float* yp = a.y + (int64_t)row * a.ldy + 4 * h;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (32 * t + 8 * q + 4 * h < a.n_out)
+            *reinterpret_cast<f32x4*>(yp + 32 * t + 8 * q) = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+    }
+  }
+}
+
+template <int NT, int KS, int AC>
+int launch_linear_rows_bf16_a(LinearArgs a, hipStream_t stream) {
+  if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
+  const int64_t ntiles = (a.rows + 31) / 32;
+  int64_t gx = (ntiles + 3) / 4;
+  if (gx > 256 * CMR_LRB_MINB) gx = 256 * CMR_LRB_MINB;     // resident workgroups per CU x 256
+  if (a.res) hipLaunchKernelGGL((linear_rows_bf16_kernel<NT, KS, AC, true>), dim3((unsigned)gx), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((linear_rows_bf16_kernel<NT, KS, AC, false>), dim3((unsigned)gx), dim3(256), 0, stream, a);
+  return cmr_launch_status();
+}
+
+template <int NT, int KS>
+int launch_linear_rows_bf16(const LinearArgs& a, hipStream_t stream) {
+  if (a.act == CMR_ACT_GELU) return launch_linear_rows_bf16_a<NT, KS, 1>(a, stream);
+  if (a.act == CMR_ACT_ELU1) return launch_linear_rows_bf16_a<NT, KS, 2>(a, stream);
+  return launch_linear_rows_bf16_a<NT, KS, 0>(a, stream);
+}
+
+extern "C" int cmr_linear_rows_bf16_f32(const float* x, int64_t ldx, int k, const float* w, int64_t ldw, const float* bias, const float* res,
+                                        int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int64_t rows, int n_out, int act,
+                                        float act_param, hipStream_t stream) {
+  CMR_REQUIRE(x && w && y && rows > 0 && rows < (int64_t)0x7fffffc0 && n_out > 0 && act >= CMR_ACT_NONE && act <= CMR_ACT_ELU1);
+  CMR_REQUIRE(ldx % 4 == 0 && ldw % 4 == 0 && ldy % 4 == 0 && n_out % 4 == 0 && cmr_aligned16(x) && cmr_aligned16(w) && cmr_aligned16(y) &&
+              (!bias || cmr_aligned16(bias)) && (!res || (ldres % 4 == 0 && cmr_aligned16(res) && (ldres >= n_out || res_mod > 0))));
+  const LinearArgs a{x, ldx, k, nullptr, 0, 0, nullptr, 1, w, ldw, bias, res, ldres, res_mod, y, ldy, rows, n_out, act, act_param};
+  if (k == 64 && n_out <= 32) return launch_linear_rows_bf16<1, 4>(a, stream);
+  if (k == 64 && n_out <= 64) return launch_linear_rows_bf16<2, 4>(a, stream);
+  if (k == 64 && n_out <= 128) return launch_linear_rows_bf16<4, 4>(a, stream);
+  if (k == 128 && n_out <= 32) return launch_linear_rows_bf16<1, 8>(a, stream);
+  if (k == 128 && n_out <= 64) return launch_linear_rows_bf16<2, 8>(a, stream);
+  if (k == 32 && n_out <= 32) return launch_linear_rows_bf16<1, 2>(a, stream);
+  if (k == 32 && n_out <= 64) return launch_linear_rows_bf16<2, 2>(a, stream);
+  return CMR_EUNSUPPORTED;
+}
+
 extern "C" int cmr_patch_embed_f32(const float* x_nhwc, int B, int H, int W, int C, int P, const float* w, int64_t ldw, const float* bias,
                                    const float* res, int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int n_out, hipStream_t stream) {
   CMR_REQUIRE(x_nhwc && w && y && B > 0 && H > 0 && W > 0 && C > 0 && P > 0 && n_out > 0 && H % P == 0 && W % P == 0);

@@ -36,6 +36,23 @@ def _i32(t):
     return t
 
 
+LINEAR_BF16 = os.environ.get("CMR_LINEAR_BF16", "1") != "0"            # with CONV_BF16: contiguous row maps of at least LINEAR_BF16_MIN_ROWS rows through cmr_linear_rows_bf16_f32
+LINEAR_BF16_MIN_ROWS = 16384
+
+
+class fp32_linears:
+    """with fp32_linears(): row GEMMs stay on cmr_linear_f32 whatever the mode -- the training updates (bf16 mode there means the
+    convolutions: forward, data and weight gradients; the 1x1 stacks and their gradients are fp32)."""
+
+    def __enter__(self):
+        global LINEAR_BF16
+        self.old, LINEAR_BF16 = LINEAR_BF16, False
+
+    def __exit__(self, *a):
+        global LINEAR_BF16
+        LINEAR_BF16 = self.old
+
+
 def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, act=ACT_NONE, act_param=0.0, out=None):
     _rows(x1, "x1")
     rows, k1 = x1.shape
@@ -51,6 +68,12 @@ def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, ac
     _rows(out, "out")
     if res is not None:
         _rows(res, "res")
+    if CONV_BF16 and LINEAR_BF16 and x2 is None and rows >= LINEAR_BF16_MIN_ROWS and k1 in (32, 64, 128) and n_out <= 128 and n_out % 4 == 0:
+        # bf16 mode: the big row maps stream through the bf16 cores (the fp32 kernel is bound by its MFMA chain at these shapes)
+        rc = _lib.call("cmr_linear_rows_bf16_f32", _p(x1), _ld(x1), k1, _p(w), kw, _p(bias), _p(res), _ld(res) if res is not None else 0,
+                       int(res_mod), _p(out), _ld(out), rows, n_out, act, float(act_param), _stream(), allow_unsupported=True)
+        if rc != _lib.UNSUPPORTED:
+            return out
     _lib.call("cmr_linear_f32", _p(x1), _ld(x1), k1, _p(x2), _ld(x2) if x2 is not None else 0, k2, _p(_i32(idx2)),
               int(div2), _p(w), kw, _p(bias), _p(res), _ld(res) if res is not None else 0, int(res_mod), _p(out),
               _ld(out), rows, n_out, act, float(act_param), _stream())

@@ -233,7 +233,11 @@ class AgentUpdate:
             dfeat, dg = dprev, dgprev
 
     # ------------------------------------------------------------------------------------------------------------- API
-    def forward_backward(self, batch, grad_scale=1.0):
+    def forward_backward(self, *args, **kw):
+        with ops.fp32_linears():
+            return self._forward_backward(*args, **kw)
+
+    def _forward_backward(self, batch, grad_scale=1.0):
         """batch: dict with the ten tensors of the reference's TensorDataset (Train_Agent.py:264-266; names as in
         oracle/train_oracle.py / tests/cases.py:train_inputs).  Fills the gradient bucket; returns (losses [8] device
         tensor, (r_logits, t_logits, value))."""

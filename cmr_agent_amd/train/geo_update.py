@@ -260,7 +260,11 @@ class GeoUpdate:
         return dict(B=B, N=N, h=h, w=w, pc_logits=outs["overlap"][0], img_logits=outs["overlap"][1], pc_geo=pc_geo, img_geo=img_geo)
 
     # ----------------------------------------------------------------------------------------------------------------- API
-    def forward_backward(self, data, grad_scale=1.0):
+    def forward_backward(self, *args, **kw):
+        with ops.fp32_linears():
+            return self._forward_backward(*args, **kw)
+
+    def _forward_backward(self, data, grad_scale=1.0):
         """data: the reference's batch dict incl. the label keys (KittiDataset.py:400-423).  Fills the gradient bucket; returns
         a dict of device scalars: the four losses and six overlap metrics of MultiHeadModel.forward."""
         self.bucket.check_attached()

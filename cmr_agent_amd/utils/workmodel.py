@@ -81,6 +81,7 @@ WORK = {
     "cmr_upsample_concat_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * (2 * a["C1"] + a["C2"] * (1 + 1.0 / a["scale"] ** 2))),
     "cmr_patchify_nhwc_f32": lambda a: (0, 2 * F * a["B"] * a["H"] * a["W"] * a["C"]),
     "cmr_transpose_f32": lambda a: (0, 2 * F * a["batch"] * a["R"] * a["Cn"]),
+    "cmr_linear_rows_bf16_f32": lambda a: (2.0 * a["rows"] * a["k"] * a["n_out"], F * (a["rows"] * (a["k"] + a["n_out"] * (2 if a["res"] else 1)) + a["k"] * a["n_out"])),
     "cmr_patch_embed_f32": lambda a: (2.0 * a["B"] * (a["H"] // a["P"]) * (a["W"] // a["P"]) * a["P"] * a["P"] * a["C"] * a["n_out"],
                                      F * (a["B"] * a["H"] * a["W"] * a["C"] + a["B"] * (a["H"] // a["P"]) * (a["W"] // a["P"]) * a["n_out"] + a["P"] * a["P"] * a["C"] * a["n_out"])),
     "cmr_mha_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),

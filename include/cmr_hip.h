@@ -137,6 +137,12 @@ int cmr_patchify_nhwc_f32(const float* x, float* out, int B, int H, int W, int C
  * (P C) % 8 == 0, at most 65 536 patches. */
 int cmr_patch_embed_f32(const float* x_nhwc, int B, int H, int W, int C, int P, const float* w, int64_t ldw, const float* bias,
                         const float* res, int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int n_out, hipStream_t stream);
+/* bf16 mode: y = act(x W^T + bias (+ res)) for the big contiguous row maps on the bf16 matrix cores (rows and weights rounded to bf16,
+ * fp32 accumulate, fp32 tensors): K in {32, 64, 128}, n_out <= 128 (K = 128: <= 64); other shapes return CMR_EUNSUPPORTED (-3) and the
+ * caller uses cmr_linear_f32.  Same argument meaning as cmr_linear_f32 without the second source. */
+int cmr_linear_rows_bf16_f32(const float* x, int64_t ldx, int k, const float* w, int64_t ldw, const float* bias, const float* res,
+                             int64_t ldres, int64_t res_mod, float* y, int64_t ldy, int64_t rows, int n_out, int act, float act_param,
+                             hipStream_t stream);
 
 /* [batch][R][C] -> [batch][C][R]: layout changes at the nn.Module boundary (NCHW <-> NHWC). */
 int cmr_transpose_f32(const float* x, float* y, int batch, int R, int Cn, hipStream_t stream);

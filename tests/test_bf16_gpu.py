@@ -361,6 +361,44 @@ def test_la_query_layer_bf16(B, L, S):
     assert float((got.cpu().double() - want_fp).abs().max()) <= 3e-2 * scale
 
 
+@pytest.mark.parametrize("rows,k,n,act,res,res_mod", [(20000, 64, 64, 0, False, 0), (40001, 64, 32, 2, True, 0), (16384, 128, 64, 3, False, 0),
+                                                       (33000, 64, 128, 1, True, 1000), (17000, 32, 64, 4, False, 0), (16390, 64, 4, 0, False, 0)])
+def test_linear_rows_bf16(rows, k, n, act, res, res_mod):
+    """cmr_linear_rows_bf16_f32 (bf16 mode: contiguous row maps of >= 16 384 rows through the bf16 cores) against torch on the same
+    bf16-rounded operands (2e-5 of the output scale) and against the fp32 product (1e-2); below the row threshold and in the training
+    updates (ops.fp32_linears) the fp32 kernel keeps the call."""
+    from cmr_agent_amd import ops
+    x, w, b = rnd(rows, k, seed=201), rnd(n, k, seed=202) / 6, rnd(n, seed=203)
+    r = rnd(res_mod if res_mod else rows, n, seed=204) if res else None
+    bf = lambda t: t.to(torch.bfloat16).double()
+
+    def ref(xx, ww):
+        y = xx @ ww.t() + b.double()
+        if r is not None:
+            y = y + (r.double()[torch.arange(rows) % res_mod] if res_mod else r.double())
+        if act == 1: y = torch.relu(y)
+        if act == 2: y = F.leaky_relu(y, 0.2)
+        if act == 3: y = F.gelu(y)
+        if act == 4: y = F.elu(y) + 1
+        return y
+    want_bf, want_fp = ref(bf(x), bf(w)), ref(x.double(), w.double())
+    d = lambda t: None if t is None else t.to(DEV)
+    args = (d(x), d(w), d(b))
+    kw = dict(res=d(r), res_mod=res_mod, act=act, act_param=0.2)
+    fp = ops.linear(*args, **kw).cpu().double()
+    ops.CONV_BF16 = True
+    try:
+        got = ops.linear(*args, **kw).cpu().double()
+        with ops.fp32_linears():
+            kept = ops.linear(*args, **kw).cpu().double()
+    finally:
+        ops.CONV_BF16 = False
+    scale = float(want_fp.abs().max())
+    assert float((fp - want_fp).abs().max()) <= 1e-4 * scale and torch.equal(kept, fp)
+    assert float((got - want_bf).abs().max()) <= 2e-5 * scale, float((got - want_bf).abs().max()) / scale
+    assert float((got - want_fp).abs().max()) <= 1e-2 * scale
+
+
 @pytest.mark.parametrize("B,S", [(2, 45), (1, 3000), (3, 26752), (2, 33)])
 def test_la_kv_state_bf16(B, S):
     """cmr_la_kv_state_bf16_f32 (K / V projections on the bf16 cores, the rest of the state kernel in fp32) against a float64 emulation with
