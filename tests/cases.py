@@ -236,6 +236,7 @@ TRAIN_CASES = {
     # BASELINE configs[2] per GPU / the shape bench.py --mode train measures: one minibatch of 10 observations of 88x304, 16 384 points
     "agent_train_full": dict(B=10, h=88, w=304, N=16384, nbatch=1),
 }
+TRAIN_CASES_ORACLE_ONLY = ("agent_train_full",)
 TRAIN_FIXTURES = ("agent_train_small_trainbn", "agent_train_small_evalbn", "buffer_order")
 
 

@@ -173,6 +173,8 @@ def main():
     ns = ref_harness.load_reference()
     report = {}
     for case in C.TRAIN_CASES:
+        if case in C.TRAIN_CASES_ORACLE_ONLY:          # shapes checked against the oracle on the GPU box only (no committed fixture)
+            continue
         run_agent(ns, case, True, report)
         run_agent(ns, case, False, report)
     run_buffer(ns, report)
