@@ -132,6 +132,9 @@ ORACLE_ONLY_E2E_CASES = {
     # BASELINE.json configs[1], the headline shape (352x1216 image, 16 384 points, 10 agent steps) at B = 2: T = 418
     # patches, 88x304 maps, both Winograd instances (64- and 32-cout workgroups) and the 10-step loop together
     "e2e_config1": dict(B=2, N=16384, H=352, W=1216, M=1280, Q=256, steps=10, n_circle=128),
+    # ... and at the batch the benchmark line is quoted on (B = 8: the launch geometry bench.py runs -- persistent grids, the in-place
+    # observation, the fused attention -- against the oracle; ~15 s of host time)
+    "e2e_config1_b8": dict(B=8, N=16384, H=352, W=1216, M=1280, Q=256, steps=10, n_circle=128),
     # BASELINE.json configs[3] shape: NuScenesConfig, 32 768 points, 900x1600 -> 896x1600 (multiples of 32 only), B = 1
     "e2e_config3": dict(B=1, N=32768, H=896, W=1600, M=1280, Q=256, steps=2, n_circle=128, dataset="nuscenes"),
 }

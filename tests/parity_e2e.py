@@ -60,9 +60,12 @@ UNIT = ("pc_geo_feat", "img_geo_feat", "pc_is_in_cam_scores", "img_overlap_pred"
 DISCRETE = ("node2proxy", "pc_overlap_pred")
 
 
-def compare(named, ref, verbose=False, atol=1e-4):
-    """named / ref: dict name -> cpu tensor.  Returns list of error strings."""
+def compare(named, ref, verbose=False, atol=1e-4, sparse_outliers=None):
+    """named / ref: dict name -> cpu tensor.  Returns list of error strings.
+    sparse_outliers: {key: (max fraction of entries above atol * scale, hard bound in units of scale)} for tensors known to contain a
+    few ill-conditioned rows (where the fp32 ORACLE itself is that far from its float64 evaluation: tests/test_conditioning_cpu.py)."""
     errs = []
+    sparse_outliers = sparse_outliers or {}
     for k, r in ref.items():
         if k not in named:
             continue
@@ -91,11 +94,18 @@ def compare(named, ref, verbose=False, atol=1e-4):
         if verbose:
             print("  %-28s max|d| %.3e (tol %.3e)" % (k, err, atol * scale))
         if err > atol * scale:
+            if k in sparse_outliers:
+                frac_max, hard = sparse_outliers[k]
+                frac = float((d > atol * scale).float().mean())
+                if verbose:
+                    print("  %-28s   (sparse outliers allowed: %.2e of the entries above tolerance, bound %.1e)" % (k, frac, frac_max))
+                if frac <= frac_max and err <= hard * scale:
+                    continue
             errs.append("%s: max|d| %.3e > %.3e" % (k, err, atol * scale))
     return errs
 
 
-def run_case(case, check_golden=True, verbose=False):
+def run_case(case, check_golden=True, verbose=False, sparse_outliers=None):
     cfg = C.e2e_config(case)
     geo, agent, geo_sd, agent_sd = build_models(cfg)
     batch = C.e2e_batch(case)
@@ -103,7 +113,7 @@ def run_case(case, check_golden=True, verbose=False):
     ref = C.e2e_oracle(case, geo_sd, agent_sd, batch)
     if verbose:
         print("product vs oracle (%s)" % case)
-    errs = compare(got, ref, verbose)
+    errs = compare(got, ref, verbose, sparse_outliers=sparse_outliers)
     assert not errs, "HIP path vs oracle:\n  " + "\n  ".join(errs)
     if check_golden:
         fx = G.load_case(case)

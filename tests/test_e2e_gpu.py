@@ -25,6 +25,19 @@ def test_registration_iteration_headline_config1():
     parity_e2e.run_case("e2e_config1", check_golden=False, verbose=True)
 
 
+def test_registration_iteration_headline_shape_at_the_benchmark_batch():
+    """BASELINE.json configs[1] exactly as bench.py runs it: 8 pairs of 352x1216 / 16 384 points, 10 agent steps, against the oracle
+    (features, losses, per-step logits / values, actions and poses), at the tolerances of the small cases -- with one allowance: pair 5 of
+    this batch has 8 of its 1 280 nodes on which the third pixel-to-node linear-attention layer is ill-conditioned (a LayerNorm over a
+    nearly constant message row): the fp32 ORACLE is 2.1e-4 of the feature scale away from its own float64 evaluation on exactly those
+    rows (tests/test_conditioning_cpu.py pins that), and so is any fp32 path.  The node-side tensors downstream of that layer may hold
+    <= 0.1 % of their entries above the 1e-4 tolerance, none above 1e-3 of the scale; everything else -- image side, the other 7 pairs,
+    every agent step's logits, actions and poses -- meets the usual bars (tools/e2e_per_sample.py, tools/decoder_trace.py)."""
+    import parity_e2e
+    allow = {k: (1e-3, 1e-3) for k in ("fused_node_feat", "pc_overlap_logits", "pc_geo_feat", "pc_is_in_cam_scores")}
+    parity_e2e.run_case("e2e_config1_b8", check_golden=False, verbose=True, sparse_outliers=allow)
+
+
 def test_registration_iteration_nuscenes_config3_shape():
     """BASELINE.json configs[3] shape (896x1600 next to 900x1600, 32 768 points; NuScenesConfig), B = 1, 2 agent steps,
     against the oracle."""
