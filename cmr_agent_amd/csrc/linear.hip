@@ -696,6 +696,123 @@ __global__ __launch_bounds__(256) void layernorm64_kernel(const float* __restric
 
 }  // namespace
 
+// ---- fp32 row maps with the weights in REGISTERS (K = 64, n_out <= 64, no second source) --------------------------------------------------
+// linear_ws_kernel reads its weight fragments from LDS in front of every k-group (32 ds_read_b128 per tile) and keeps the generality of two
+// sources / gathers in its loop; for the shape that carries most of this entry point's bytes the whole matrix is 64 VGPRs per lane (NT = 2:
+// 16 KB over 64 lanes), so the tile loop here is: rows of the next tile requested, 64 MFMAs fed from registers only, float4 epilogue.
+// SAME arithmetic in the SAME order as linear_ws_kernel (k-groups ascending, bias / residual / activation after the products): bit-identical.
+template <int NT, int AC, bool RES>
+__global__ __launch_bounds__(256) void linear_wreg_kernel(const LinearArgs a) {
+  __shared__ __attribute__((aligned(16))) float Bs[32 * NT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  if (tid < 32 * NT) Bs[tid] = (a.bias && tid < a.n_out) ? a.bias[tid] : 0.f;
+  f32x4 wf[NT][8];                                  // lane (cout l31, half h): W[32 n + l31][8 i + 4 h .. + 3]
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int c = 32 * n + l31;
+    const float* wr = a.w + (int64_t)(c < a.n_out ? c : 0) * a.ldw + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      wf[n][i] = *reinterpret_cast<const f32x4*>(wr + 8 * i);
+      if (c >= a.n_out) wf[n][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
+  const uint32_t rows = (uint32_t)a.rows;
+  const uint32_t ntiles = (rows + 31) / 32, tstride = gridDim.x * 4;
+  auto load_tile = [&](uint32_t tile, f32x4 (&dst)[8]) __attribute__((always_inline)) {
+    uint32_t row = tile * 32 + l31;
+    const bool valid = tile < ntiles && row < rows;
+    const float* xp = valid ? a.x1 + (int64_t)row * a.ld1 + 4 * h : cmr_zero16;
+    const int st = valid ? 8 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(xp + st * i);
+  };
+  // (rows of the next TWO tiles in flight measured slower: 42 vs 33 us at 214 016 rows -- the tile loop is not waiting for memory)
+  f32x4 xc[8], xn[8];
+  uint32_t tile = blockIdx.x * 4 + wave;
+  load_tile(tile, xc);
+  for (; tile < ntiles; tile += tstride) {
+    const uint32_t row = tile * 32 + l31;
+    f32x4 rv[RES ? NT : 1][4];
+    if constexpr (RES) {
+      const uint32_t rowc = row < rows ? row : 0;
+      const uint32_t rr = a.res_mod > 0 ? rowc % (uint32_t)a.res_mod : rowc;
+      const float* rp = a.res + (int64_t)rr * a.ldres + 4 * h;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 32 * n + 8 * q;
+          rv[n][q] = *reinterpret_cast<const f32x4*>(rp + (c + 4 * h < a.n_out ? c : 0));
+        }
+    }
+    load_tile(tile + tstride, xn);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[n] = cmr_mfma32(wf[n][i][j], xc[i][j], acc[n]);
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+        v += *reinterpret_cast<const f32x4*>(&Bs[32 * n + 8 * q + 4 * h]);
+        if constexpr (RES) v += rv[n][q];
+        else v += f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = ws_act<AC>(v[e], a.act_param);
+      }
+    if (row < rows) {
+      float* yp = a.y + (int64_t)row * a.ldy + 4 * h;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (32 * n + 8 * q + 4 * h < a.n_out)
+            *reinterpret_cast<f32x4*>(yp + 32 * n + 8 * q) = f32x4{acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xc[i] = xn[i];
+  }
+}
+
+template <int NT, int AC>
+int launch_linear_wreg_a(LinearArgs a, hipStream_t stream) {
+  if (AC == 0) a.act_param = a.act == CMR_ACT_NONE ? 1.f : (a.act == CMR_ACT_RELU ? 0.f : a.act_param);
+  const int64_t ntiles = (a.rows + 31) / 32;
+  int64_t gx = (ntiles + 3) / 4;
+  if (gx > 512) gx = 512;
+  if (a.res) hipLaunchKernelGGL((linear_wreg_kernel<NT, AC, true>), dim3((unsigned)gx), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((linear_wreg_kernel<NT, AC, false>), dim3((unsigned)gx), dim3(256), 0, stream, a);
+  return cmr_launch_status();
+}
+
+template <int NT>
+int launch_linear_wreg(const LinearArgs& a, hipStream_t stream) {
+  if (a.act == CMR_ACT_GELU) return launch_linear_wreg_a<NT, 1>(a, stream);
+  if (a.act == CMR_ACT_ELU1) return launch_linear_wreg_a<NT, 2>(a, stream);
+  return launch_linear_wreg_a<NT, 0>(a, stream);
+}
+
+static int g_linear_wreg = 1;            // register-weights kernel for K = 64 row maps (cmr_set_linear_wreg: A/B measurements, tests)
+static int64_t g_linear_wreg_min_rows = 65537;
+extern "C" int cmr_set_linear_wreg(int on, int64_t min_rows) {
+  const int old = g_linear_wreg;
+  g_linear_wreg = on ? 1 : 0;
+  if (min_rows > 0) g_linear_wreg_min_rows = min_rows;
+  return old;
+}
+
 static int g_linear_row64 = 1;
 // A/B switch for benchmarks and tests (1 = use the row-streaming fast path where it applies; default): returns the previous value.
 extern "C" int cmr_set_linear_row64(int on) {
@@ -735,6 +852,9 @@ extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float*
   if (vec_ok && !a.x2 && a.k1 == 64 && a.ld1 == 64 && (n_out == 64 || n_out == 32) && ldy == n_out && a.ldw % 4 == 0 &&
       (!res || (ldres == n_out && res_mod <= 0)) && rows >= 2048 && rows <= 65536 && g_linear_row64) {
     return n_out == 64 ? launch_linear_row64<2>(a, stream) : launch_linear_row64<1>(a, stream);
+  }
+  if (g_linear_wreg && vec_ok && !a.x2 && a.k1 == 64 && n_out <= 64 && rows >= g_linear_wreg_min_rows && rows < (int64_t)0x7fffffc0) {
+    return n_out <= 32 ? launch_linear_wreg<1>(a, stream) : launch_linear_wreg<2>(a, stream);
   }
   if (a.k1 + a.k2 <= 128 && vec_ok && rows < (int64_t)0x7fffffc0) {       // weights fit in LDS: weight-stationary streaming kernel
     if (n_out <= 32 || (n_out > 64 && n_out <= 96)) return launch_linear_ws<1>(a, stream);

@@ -47,6 +47,9 @@ int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_
 /* Debug / benchmark switch: 0 routes the contiguous [rows][64] -> [rows][64 | 32] calls of cmr_linear_f32 through the generic
  * weight-stationary kernel instead of the row-streaming fast path (bit-identical results); returns the previous setting. */
 int cmr_set_linear_row64(int on);
+/* The same kind of switch for the register-weights kernel (K = 64, n_out <= 64, one source, at least min_rows rows; min_rows <= 0 keeps the
+ * threshold): bit-identical to the weight-stationary kernel.  Returns the previous on / off setting. */
+int cmr_set_linear_wreg(int on, int64_t min_rows);
 
 /* Whole ConvBNReLURes1D block in one kernel (PointNN.py:260-282 with BN folded):
  *   hid = lrelu(W1 x + b1);  y = lrelu(W2 hid + b2 + (Wsc x | x)),  x = [x1[:, :k1] | x2[map][:, :kx-k1]].

@@ -163,6 +163,32 @@ def test_pool_upsample_patchify_transpose(ops):
     close(ops.transpose(t.to(DEV)), t.transpose(1, 2), 0, "transpose")
 
 
+@pytest.mark.parametrize("rows,n,act,res,res_mod", [(70001, 64, 0, False, 0), (131072, 64, 2, True, 0), (66000, 32, 3, False, 0), (80000, 64, 4, True, 1000),
+                                                     (65600, 12, 1, False, 0)])
+def test_linear_register_weights_kernel_is_bit_identical(ops, rows, n, act, res, res_mod):
+    """linear_wreg_kernel (K = 64 row maps above 65 536 rows: the weight matrix in registers, no LDS reads in the tile loop) must give the
+    bits of the weight-stationary kernel it replaces (same products, same order), and those of the oracle formula to 1e-5."""
+    from cmr_agent_amd import _lib
+    lib = _lib.load()
+    x, w, b = rnd(rows, 64, seed=211), rnd(n, 64, seed=212) / 6, rnd(n, seed=213)
+    r = rnd(res_mod if res_mod else rows, n, seed=214) if res else None
+    d = lambda t: None if t is None else t.to(DEV)
+    kw = dict(res=d(r), res_mod=res_mod, act=act, act_param=0.2)
+    old = lib.cmr_set_linear_wreg(1, 0)
+    try:
+        new = ops.linear(d(x), d(w), d(b), **kw)
+        lib.cmr_set_linear_wreg(0, 0)
+        ws = ops.linear(d(x), d(w), d(b), **kw)
+    finally:
+        lib.cmr_set_linear_wreg(old, 0)
+    assert torch.equal(new, ws)
+    y = x.double() @ w.double().t() + b.double()
+    if r is not None:
+        y = y + (r.double()[torch.arange(rows) % res_mod] if res_mod else r.double())
+    y = {0: y, 1: torch.relu(y), 2: torch.nn.functional.leaky_relu(y, 0.2), 3: torch.nn.functional.gelu(y), 4: torch.nn.functional.elu(y) + 1}[act]
+    close(new, y, 1e-5, "linear (register weights)")
+
+
 @pytest.mark.parametrize("B,H,W,C,P,n", [(2, 16, 24, 64, 8, 64), (1, 88, 304, 64, 8, 64), (3, 8, 12, 32, 4, 64), (2, 12, 20, 64, 4, 128), (1, 6, 6, 8, 2, 64)])
 def test_patch_embedding_reads_patches_in_place(ops, B, H, W, C, P, n):
     """cmr_patch_embed_f32 (split-K GEMM whose rows are the patches of the NHWC map, no patchified copy) against torch's stride-P
