@@ -730,8 +730,15 @@ __global__ __launch_bounds__(256) void linear_wreg_kernel(const LinearArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[i] = *reinterpret_cast<const f32x4*>(xp + st * i);
   };
-  // (rows of the next TWO tiles in flight measured slower: 42 vs 33 us at 214 016 rows -- the tile loop is not waiting for memory)
+  // The launch used to cost its vector-memory issue time PLUS its matrix time (profiles/r03_pmc_linear.txt: waves issue-stalled 74 % of
+  // their life at 42 % MFMA busy): a wave issued its 8 row loads and 8 stores in bursts, in order, in front of and behind its 64 MFMAs.
+  // Here ONE load of the next tile and ONE store of the PREVIOUS tile's result follow each k-group's 8 MFMAs, so a memory instruction
+  // waits for the address path while matrix instructions of the same wave are executing.  (Two tiles of rows in flight, or more resident
+  // waves, were slower: every load instruction re-touches the lines of its 32 rows in a 32 KB L1.)
   f32x4 xc[8], xn[8];
+  f32x4 prev[NT][4];                                // outputs of the previous tile of this wave, stored under this tile's products
+  float* pyp = a.y;                                 // where they go (valid only when phave)
+  bool phave = false;
   uint32_t tile = blockIdx.x * 4 + wave;
   load_tile(tile, xc);
   for (; tile < ntiles; tile += tstride) {
@@ -749,18 +756,28 @@ __global__ __launch_bounds__(256) void linear_wreg_kernel(const LinearArgs a) {
           rv[n][q] = *reinterpret_cast<const f32x4*>(rp + (c + 4 * h < a.n_out ? c : 0));
         }
     }
-    load_tile(tile + tstride, xn);
+    const uint32_t nrow = (tile + tstride) * 32 + l31;
+    const bool nvalid = tile + tstride < ntiles && nrow < rows;
+    const float* nxp = nvalid ? a.x1 + (int64_t)nrow * a.ld1 + 4 * h : cmr_zero16;
+    const int nst = nvalid ? 8 : 0;
     f32x16 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = cmr_mfma32(wf[n][i][j], xc[i][j], acc[n]);
+      xn[i] = *reinterpret_cast<const f32x4*>(nxp + nst * i);
+      if (i < 4 * NT) {                                          // store i of the previous tile: (n, q) = (i / 4, i % 4)
+        const int n = i / 4, q = i % 4;
+        if (phave && 32 * n + 8 * q + 4 * h < a.n_out) *reinterpret_cast<f32x4*>(pyp + 32 * n + 8 * q) = prev[n][q];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -770,19 +787,20 @@ __global__ __launch_bounds__(256) void linear_wreg_kernel(const LinearArgs a) {
         if constexpr (RES) v += rv[n][q];
         else v += f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[n][4 * q + e] = ws_act<AC>(v[e], a.act_param);
+        for (int e = 0; e < 4; ++e) v[e] = ws_act<AC>(v[e], a.act_param);
+        prev[n][q] = v;
       }
-    if (row < rows) {
-      float* yp = a.y + (int64_t)row * a.ldy + 4 * h;
-#pragma unroll
-      for (int n = 0; n < NT; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (32 * n + 8 * q + 4 * h < a.n_out)
-            *reinterpret_cast<f32x4*>(yp + 32 * n + 8 * q) = f32x4{acc[n][4 * q], acc[n][4 * q + 1], acc[n][4 * q + 2], acc[n][4 * q + 3]};
-    }
+    phave = row < rows;
+    pyp = a.y + (int64_t)(phave ? row : 0) * a.ldy + 4 * h;
 #pragma unroll
     for (int i = 0; i < 8; ++i) xc[i] = xn[i];
+  }
+  if (phave) {                                                   // the last tile's result
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (32 * n + 8 * q + 4 * h < a.n_out) *reinterpret_cast<f32x4*>(pyp + 32 * n + 8 * q) = prev[n][q];
   }
 }
 

@@ -30,7 +30,10 @@ def main():
         a = dict(zip(names, args))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); rc = orig(name, *args, **kw); e1.record()
-        recs.append((name, int(a.get("rows", a.get("nseg", 0)) or 0), int(a.get("C", a.get("n_out", a.get("n", 0))) or 0), e0, e1))
+        tag = name
+        if name == "cmr_linear_f32":       # which row GEMMs are one-source K = 64 (the register-weights kernel's shape)
+            tag = "%s[k1=%d%s]" % (name, int(a.get("k1", 0)), "+x2" if a.get("x2") else "")
+        recs.append((tag, int(a.get("rows", a.get("nseg", 0)) or 0), int(a.get("C", a.get("n_out", a.get("n", 0))) or 0), e0, e1))
         return rc
     _lib.call = hook
     up.step(batch); torch.cuda.synchronize()
