@@ -602,7 +602,11 @@ def main():
                   # launches: 16/36 of the convolution's multiplies), so it is a hardware fraction <= 1; path_algorithmic credits the
                   # convolution's full 2*9*Cin*Cout per pixel
                   "path": sum_ideal / sum_meas, "path_algorithmic": sum_ideal_alg / sum_meas, "path_ideal_ms_per_step": sum_ideal / args.steps,
-                  "path_kernel_ms_per_step": sum_meas / args.steps, "path_unmodelled": unmodelled, "kernels": kernels[:14],
+                  "path_kernel_ms_per_step": sum_meas / args.steps,
+                  # the same ideal time over the MEASURED step (the timed region's graph replays): the branches of a step run concurrently, so
+                  # the event times above add up to more than the step; this is the fraction of the step its roofline-ideal work explains
+                  "path_step": (sum_ideal / args.steps) / (1e3 * elapsed / args.steps),
+                  "path_unmodelled": unmodelled, "kernels": kernels[:14],
                   **alone,
                   "timed_in": "separate eager pass of the same %d steps (HIP events on the stream of each launch; the side-stream "
                               "branches of the forward run concurrently, as in the replayed graph)" % args.steps}
