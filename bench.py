@@ -472,9 +472,9 @@ def main():
                     help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
     ap.add_argument("--num-pt", type=int, default=None, help="train-geo: points per cloud (default KittiConfig's 40960; configs[4] = 65536)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
-    ap.add_argument("--alone-pass", action="store_true", help="one more (untimed) eager pass with every branch on ONE stream: adds "
-                    "roofline.path_alone, each kernel's duration alone on the device (off by default so that the kernel statistics of a "
-                    "profiled default run contain the same launches the JSON line averages over)")
+    ap.add_argument("--no-alone-pass", action="store_true", help="skip the second (untimed) eager pass with every branch on ONE stream, which "
+                    "adds roofline.frac_alone / path_alone / kernels_alone: each kernel's duration alone on the device (the first pass times a "
+                    "side-stream call from its launch, including its wait for the CUs the concurrent convolutions hold)")
     ap.add_argument("--pipeline", action="store_true", help="register mode: two-stage software pipeline over consecutive batches in one "
                     "hipGraph (geo forward of batch i concurrently with the agent loop of batch i - 1; cmr_agent_amd/runtime.py)")
     ap.add_argument("--no-pipeline-line", action="store_true", help="skip the `pipelined` sub-object (second measurement of the same steps)")
@@ -547,7 +547,7 @@ def main():
         # the same pass with every branch on ONE stream: each kernel's duration alone on the device (the pass above times a side-stream
         # kernel from its launch to its end, including the time it waits for CUs the concurrent convolution holds)
         ct1 = None
-        if args.alone_pass:
+        if not args.no_alone_pass and not args.eager:
             from cmr_agent_amd.utils import streams
             streams.ENABLED = False
             try:
@@ -576,8 +576,17 @@ def main():
         if ct1 is not None:
             t1 = ct1.table()
             # the same ratio with every kernel timed ALONE on the device (single stream): what the kernels themselves achieve
-            alone = {"path_alone": sum(d["ideal_issued_ms"] for d in t1 if d["modelled"]) / sum(d["ms"] for d in t1 if d["modelled"]),
-                     "path_alone_kernel_ms_per_step": sum(d["ms"] for d in t1 if d["modelled"]) / min(args.steps, 5)}
+            dom1 = [d for d in t1 if d["name"] in dom_names]
+            ms1, fl1, n1 = sum(d["ms"] for d in dom1), sum(d["flops"] for d in dom1), sum(d["calls"] for d in dom1)
+            tf1 = fl1 / (ms1 * 1e-3) / 1e12 * (1.0 if dtype == "bf16" else 16.0 / 36.0)
+            alone = {"frac_alone": (sum(d["bytes"] for d in dom1) / (ms1 * 1e-3) / 1e9 / 8000.0) if dtype == "bf16" else tf1 / FP32_MFMA_PEAK_TFLOPS,
+                     "avg_launch_us_alone": 1e3 * ms1 / max(n1, 1),
+                     "path_alone": sum(d["ideal_issued_ms"] for d in t1 if d["modelled"]) / sum(d["ms"] for d in t1 if d["modelled"]),
+                     "path_alone_kernel_ms_per_step": sum(d["ms"] for d in t1 if d["modelled"]) / min(args.steps, 5),
+                     "kernels_alone": [dict(entry=d["name"], bound=d["bound"], calls_per_step=d["calls"] / min(args.steps, 5),
+                                            ms_per_step=round(d["ms"] / min(args.steps, 5), 4),
+                                            ideal_ms_per_step=round(d["ideal_issued_ms"] / min(args.steps, 5), 4), frac=round(d["frac"], 3))
+                                       for d in t1 if d["modelled"]][:8]}
         kernels = [dict(entry=d["name"], bound=d["bound"], calls_per_step=d["calls"] / args.steps, ms_per_step=round(d["ms"] / args.steps, 4),
                         ideal_ms_per_step=round(d["ideal_issued_ms"] / args.steps, 4), frac=round(d["frac"], 3),
                         gflop_per_step=round(d["flops"] / args.steps / 1e9, 2), mb_per_step=round(d["bytes"] / args.steps / 1e6, 1))
