@@ -595,6 +595,10 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 // floats, so the halves fall 32 banks apart).  One __syncthreads per block; 3 workgroups per CU at 64 x 64.  Partials go to the
 // workspace in linear_wgrad_reduce_kernel's layout (one n block, one k block, gridDim.x slices).
 // ------------------------------------------------------------------------------------------------------------------
+#ifndef CMR_LW_DEEP
+#define CMR_LW_DEEP 1
+#endif
+constexpr bool LW_DEEP = CMR_LW_DEEP != 0;
 template <int NT, int KT>
 __global__ __launch_bounds__(256) void linear_wgrad_lds_kernel(const float* __restrict__ dy, int64_t lddy, const float* __restrict__ x, int64_t ldx,
                                                                int64_t rows, float* __restrict__ part, float* __restrict__ part_b) {
@@ -646,34 +650,61 @@ __global__ __launch_bounds__(256) void linear_wgrad_lds_kernel(const float* __re
     }
   };
 
-  f32x4 dv[NLD], xv[NLX];
-  int64_t blk = blockIdx.x;
-  load_block(blk < nblocks ? blk : nblocks - 1, dv, xv);
-  store_block(blk, 0, dv, xv);
-  __syncthreads();
-  int buf = 0;
-  for (; blk < nblocks; blk += gridDim.x) {
-    const int64_t nb = blk + gridDim.x;
-    load_block(nb < nblocks ? nb : nblocks - 1, dv, xv);          // next block of this workgroup: in flight under the MFMAs
-    if (active) {
-      const float* dl = Dl + buf * R * DS + l31;
-      const float* xl = Xl + buf * R * XS + l31;
+  auto multiply = [&](int buf) {
+    if (!active) return;
+    const float* dl = Dl + buf * R * DS + l31;
+    const float* xl = Xl + buf * R * XS + l31;
 #pragma unroll
-      for (int j = 0; j < R / 2; ++j) {
-        const int rr = 2 * j + h;
+    for (int j = 0; j < R / 2; ++j) {
+      const int rr = 2 * j + h;
 #pragma unroll
-        for (int t = 0; t < TPW; ++t) {
-          const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
-          const float a = dl[rr * DS + 32 * nt];
-          const float b = xl[rr * XS + 32 * kt];
-          if (kt == 0) bsum += a;
-          acc[t] = cmr_mfma32(a, b, acc[t]);
-        }
+      for (int t = 0; t < TPW; ++t) {
+        const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
+        const float a = dl[rr * DS + 32 * nt];
+        const float b = xl[rr * XS + 32 * kt];
+        if (kt == 0) bsum += a;
+        acc[t] = cmr_mfma32(a, b, acc[t]);
       }
     }
-    store_block(nb, buf ^ 1, dv, xv);                             // the other buffer: last read one iteration ago, behind a barrier
+  };
+  const int64_t g = gridDim.x;
+  auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
+  int64_t blk = blockIdx.x;
+  if (LW_DEEP && NLD + NLX <= 8) {
+    // Two blocks ahead in registers (blocks blk + g in d1 / x1, blk + 2 g in d2 / x2; blk itself in LDS): one block of MFMAs per wave
+    // (1 024 cycles at 64 x 64) is shorter than a loaded HBM round trip, so with ONE block in flight every wave met its own loads again at
+    // the LDS store.  The body is unrolled twice so that the two register sets swap roles without moves; blocks are still multiplied
+    // in the same order: bit-identical partials.
+    f32x4 d1[NLD], x1[NLX], d2[NLD], x2[NLX];
+    load_block(clampb(blk), d1, x1);
+    store_block(blk, 0, d1, x1);
+    load_block(clampb(blk + g), d1, x1);
     __syncthreads();
-    buf ^= 1;
+    for (; blk < nblocks; blk += 2 * g) {
+      load_block(clampb(blk + 2 * g), d2, x2);
+      multiply(0);
+      store_block(blk + g, 1, d1, x1);
+      __syncthreads();
+      if (blk + g >= nblocks) break;                                // (uniform over the workgroup)
+      load_block(clampb(blk + 3 * g), d1, x1);
+      multiply(1);
+      store_block(blk + 2 * g, 0, d2, x2);
+      __syncthreads();
+    }
+  } else {
+    f32x4 dv[NLD], xv[NLX];
+    load_block(clampb(blk), dv, xv);
+    store_block(blk, 0, dv, xv);
+    __syncthreads();
+    int buf = 0;
+    for (; blk < nblocks; blk += g) {
+      const int64_t nb = blk + g;
+      load_block(clampb(nb), dv, xv);                               // next block of this workgroup: in flight under the MFMAs
+      multiply(buf);
+      store_block(nb, buf ^ 1, dv, xv);                             // the other buffer: last read one iteration ago, behind a barrier
+      __syncthreads();
+      buf ^= 1;
+    }
   }
   if (!active) return;
   float* out = part + (int64_t)blockIdx.x * N * K;
@@ -693,31 +724,48 @@ __global__ __launch_bounds__(256) void linear_wgrad_lds_kernel(const float* __re
 }
 
 // outputs [0, n k): dW entries; [n k, n k + n): db entries (when part_b)
-__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int nslices,
+// (round 3) A thread used to walk its 96 slices of a 768-slice sum one dependent load at a time: 130 workgroups of 256 threads took 30-35 us
+// for 12.8 MB (profiles/r03_pmc_lwgrad.txt: 92 % of the wave cycles waiting on memory) -- more than a third of the weight gradient of a
+// 524 288-row map.  Now 32 slice groups (1 024 threads) and LRED_U independent loads in flight per thread; sums still in double, fixed order.
+constexpr int LRED_GRP = 32, LRED_U = 8;
+__global__ __launch_bounds__(RED_OUT * LRED_GRP) void linear_wgrad_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int nslices,
                                                                   int npad, int kpad, int nblk, int n, int k, float* __restrict__ dw,
                                                                   int64_t lddw, int accumulate, float* __restrict__ db, int acc_db) {
-  __shared__ double sm[RED_GRP][RED_OUT];
+  __shared__ double sm[LRED_GRP][RED_OUT];
   const int o = threadIdx.x % RED_OUT, g = threadIdx.x / RED_OUT;
   const int64_t i = (int64_t)blockIdx.x * RED_OUT + o;
   const int64_t nk = (int64_t)n * k, total = nk + (part_b ? n : 0);
   double s = 0.0;
   int row = 0, col = 0;
+  const float* p = part;
+  int64_t stride = 0;
   if (i < nk) {
     row = (int)(i / k), col = (int)(i - (int64_t)row * k);
     const int nb = row / npad, kb = col / kpad;
-    const float* p = part + ((int64_t)kb * nblk + nb) * nslices * npad * kpad + (int64_t)(row - nb * npad) * kpad + (col - kb * kpad);
-    for (int j = g; j < nslices; j += RED_GRP) s += (double)p[(int64_t)j * npad * kpad];
+    p = part + ((int64_t)kb * nblk + nb) * nslices * npad * kpad + (int64_t)(row - nb * npad) * kpad + (col - kb * kpad);
+    stride = (int64_t)npad * kpad;
   } else if (i < total) {
     row = (int)(i - nk);
     const int nb = row / npad;
-    const float* p = part_b + (int64_t)nb * nslices * npad + (row - nb * npad);
-    for (int j = g; j < nslices; j += RED_GRP) s += (double)p[(int64_t)j * npad];
+    p = part_b + (int64_t)nb * nslices * npad + (row - nb * npad);
+    stride = npad;
   }
+  if (i < total)
+    for (int j0 = g; j0 < nslices; j0 += LRED_GRP * LRED_U) {
+      float v[LRED_U];
+#pragma unroll
+      for (int u = 0; u < LRED_U; ++u) {
+        const int j = j0 + u * LRED_GRP;
+        v[u] = p[(int64_t)(j < nslices ? j : j0) * stride];          // (branch-free: a slice past the end re-reads j0 and is dropped below)
+      }
+#pragma unroll
+      for (int u = 0; u < LRED_U; ++u) s += j0 + u * LRED_GRP < nslices ? (double)v[u] : 0.0;
+    }
   sm[g][o] = s;
   __syncthreads();
   if (g == 0 && i < total) {
 #pragma unroll
-    for (int j = 1; j < RED_GRP; ++j) s += sm[j][o];
+    for (int j = 1; j < LRED_GRP; ++j) s += sm[j][o];
     if (i < nk) {
       float* d = dw + (int64_t)row * lddw + col;
       *d = accumulate ? *d + (float)s : (float)s;
@@ -993,7 +1041,7 @@ extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const 
         else CMR_LWL(4, 1)
 #undef CMR_LWL
         const int64_t outs = (int64_t)n * k + (db ? n : 0);
-        hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((outs + RED_OUT - 1) / RED_OUT)), dim3(256), 0, stream, (const float*)part,
+        hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((outs + RED_OUT - 1) / RED_OUT)), dim3(RED_OUT * LRED_GRP), 0, stream, (const float*)part,
                            (const float*)pb, groups, n, k, 1, n, k, dw, lddw, accumulate, db, accumulate_db);
         return cmr_launch_status();
       }
@@ -1013,7 +1061,7 @@ extern "C" int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const 
   else CMR_LW(4, 4);
 #undef CMR_LW
   const int64_t outs = (int64_t)n * k + (db ? n : 0);
-  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((outs + RED_OUT - 1) / RED_OUT)), dim3(256), 0, stream, (const float*)part,
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((outs + RED_OUT - 1) / RED_OUT)), dim3(RED_OUT * LRED_GRP), 0, stream, (const float*)part,
                      (const float*)part_b, p.slices * (4 / p.ntp), p.ntp * 32, p.ktp * 32, p.nblk, n, k, dw, lddw, accumulate, db, accumulate_db);
   return cmr_launch_status();
 }

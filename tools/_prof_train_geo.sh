@@ -4,6 +4,6 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_train_geo
 rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats -d $O --output-format csv -- python3 $R/bench.py --mode train-geo --steps 3 --warmup 1 > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O --output-format csv -- python3 $R/bench.py --mode train-geo --num-pt 65536 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench.json 2> $O/bench.err
 find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 head -45 $O/kernel_stats.csv | cut -c1-220

@@ -4,6 +4,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from cmr_agent_amd import ops, _lib
+if "--lib" in sys.argv:                                   # A/B: another build of the library (tools/ab_build.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from kbench import timeit
 
 def main():
