@@ -304,9 +304,9 @@ __device__ __forceinline__ unsigned wg_pack2(float lo, float hi) {            //
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, b2));
 }
 
-template <int NCI, int NCO, int TW>
+template <int NCI, int NCO, int TW, bool BIAS>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
-                                                                 int Cout, int rps, float* __restrict__ part) {
+                                                                 int Cout, int rps, float* __restrict__ part, float* __restrict__ part_b) {
   // TW = 32 | 64 pixels per row tile (64: twice the bytes in flight per barrier interval -- the kernel waits on memory, not on its 18 / 36
   // matrix instructions per row)
   constexpr int CIN = 32 * NCI, RS = TW / 2 + 5, NSPLIT = 4 / NCI;   // RS odd: 21 | 37 dwords >= TW / 2 + 1 pairs (+ the dword past an operand)
@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
 
+  // bias gradient (BIAS): every dY element of the launch is staged by exactly ONE lane of ONE workgroup (strips partition the
+  // pixels, blockIdx.y the couts), in fp32 before it is rounded -- the lane keeps the running sums of its channel quad, the workgroup
+  // writes one partial row at the end (cmr_colsum_f32 used to re-read the whole map for it: 25 us per 88x304 layer of the agent update)
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   // staging roles: X: lane -> (channel quad xc4, pair slot within the instruction xps, parity h); dY: (quad dc4 of 8 NCO, pair slot dps)
   constexpr int DQ = 8 * NCO, DPI = 32 / DQ;            // dY channel quads; pixel pairs per wave instruction: 4 | 2
   constexpr int NDI = NPAIRD / (4 * DPI);               // dY staging iterations per wave
@@ -388,8 +392,11 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
     };
     auto store_drow = [&](int r, bool live, const f32x4 (&src)[NDI]) {
 #pragma unroll
-      for (int i = 0; i < NDI; ++i)
-        store_pairs(DT + (r & 1) * (32 * NCO * RS), dc4, dpair(i), src[i], live && r < H && x0 + 2 * dpair(i) + h < W);
+      for (int i = 0; i < NDI; ++i) {
+        const bool ok = live && r < H && x0 + 2 * dpair(i) + h < W;
+        if (BIAS) bsum += ok ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        store_pairs(DT + (r & 1) * (32 * NCO * RS), dc4, dpair(i), src[i], ok);
+      }
     };
 
     // Rows are requested TWO iterations before they are staged: a row tile is 18 matrix instructions (~0.15 us), so with the loads
@@ -465,6 +472,40 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
         const int row = cmr_mfma_row(r, lane);
         out[((int64_t)t * Cout + (co_t * NCO + c) * 32 + row) * CIN + ci_t * 32 + l31] = acc[c][t][r];
       }
+  if (BIAS) {                                           // lanes (wave, h, dps) of one channel quad -> one sum, in a fixed order
+    float* red = reinterpret_cast<float*>(wgb_smem);
+    __syncthreads();                                    // the last row tile's operands have been read
+    *reinterpret_cast<f32x4*>(red + 4 * tid) = bsum;
+    __syncthreads();
+    if (tid < 32 * NCO) {
+      const int quad = tid >> 2, e = tid & 3;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int d = 0; d < DPI; ++d) t += red[4 * (w * 64 + hh * 32 + d * DQ + quad) + e];
+      part_b[(int64_t)blockIdx.x * Cout + co_t * (32 * NCO) + tid] = t;
+    }
+  }
+}
+
+// db[c] = sum over the workgroup partials of the kernel above: 32 channels x 32 slice groups per workgroup, double accumulation, fixed order
+__global__ __launch_bounds__(1024) void conv_bias_reduce_kernel(const float* __restrict__ part_b, int nslices, int Cout, float* __restrict__ db) {
+  __shared__ double sm[32][32];
+  const int o = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + o;
+  double s = 0.0;
+  if (c < Cout)
+    for (int j = g; j < nslices; j += 32) s += (double)part_b[(int64_t)j * Cout + c];
+  sm[g][o] = s;
+  __syncthreads();
+  if (g == 0 && c < Cout) {
+#pragma unroll
+    for (int j = 1; j < 32; ++j) s += sm[j][o];
+    db[c] = (float)s;
+  }
 }
 
 // Sum of the per-wave partial outputs.  Workgroup = 32 consecutive outputs x 8 slice groups: thread (o, g) adds slices
@@ -928,8 +969,15 @@ extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int
   return cmr_launch_status();
 }
 
+extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, float* db,
+                                               void* ws, int64_t ws_bytes, hipStream_t stream);
 extern "C" int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                                           int64_t ws_bytes, hipStream_t stream) {
+  return cmr_conv3x3_wgrad_bias_bf16_f32(x, dy, B, H, W, Cin, Cout, dw, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, float* db,
+                                               void* ws, int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W >= 2);
   CMR_REQUIRE((Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (Cin == 64 || Cin == 128));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff);       // 32-bit element offsets within an image batch
@@ -938,7 +986,8 @@ extern "C" int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B
   // of >= 4 rows per workgroup
   const int tw = ((W + 63) / 64 * 64 <= (W + 31) / 32 * 32) ? 64 : 32;     // 64-pixel row tiles unless they pad the width more than 32-pixel ones (152 -> 192 vs 160)
   // two cout tiles per workgroup (288 accumulator registers) spill at Cin = 128 and with 64-pixel tiles (measured slower): narrow Cin = 64 maps only
-  const int nco = (nci == 2 && tw == 32 && Cout % 64 == 0) ? 2 : 1;
+  // (with the bias sums the two-tile instance spills 176 registers: one tile then)
+  const int nco = (nci == 2 && tw == 32 && Cout % 64 == 0 && !db) ? 2 : 1;
   int groups = 256 / (Cout / (32 * nco));
   const int ntx = (W + tw - 1) / tw;
   int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)8 * groups));
@@ -947,25 +996,33 @@ extern "C" int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B
   const int64_t nstrips = (int64_t)B * ntx * ((H + rps - 1) / rps);
   if (groups > nstrips) groups = (int)nstrips;
   if (groups > 512) groups = 512;                        // workspace bound of cmr_conv3x3_wgrad_workspace_bytes
-  CMR_REQUIRE(ws_bytes >= (int64_t)groups * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float));
+  const int64_t part_floats = (int64_t)groups * nsplit * 9 * Cout * Cin;
+  CMR_REQUIRE(ws_bytes >= (part_floats + (db ? (int64_t)groups * Cout : 0)) * (int64_t)sizeof(float));
   const int rs = tw / 2 + 5;
   const size_t smem = ((size_t)4 * Cin * rs + 2 * 32 * nco * rs) * sizeof(unsigned);
   float* part = (float*)ws;
+  float* part_b = db ? part + part_floats : nullptr;
   dim3 grid(groups, Cout / (32 * nco));
-#define CMR_WGB_LAUNCH(NCI_, NCO_, TW_)                                                                                               \
+#define CMR_WGB_LAUNCH(NCI_, NCO_, TW_, BIAS_)                                                                                        \
   {                                                                                                                                   \
     static CmrSmemCache granted{};                                                                                                    \
-    if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_>), smem, granted) != CMR_OK) return CMR_ELAUNCH; \
-    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_>), grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, rps, part);   \
+    if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_, BIAS_>), smem, granted) != CMR_OK) return CMR_ELAUNCH; \
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_, BIAS_>), grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, rps, part, part_b);   \
   }
-  if (nci == 4 && tw == 64) CMR_WGB_LAUNCH(4, 1, 64)
-  else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32)
-  else if (nco == 2) CMR_WGB_LAUNCH(2, 2, 32)
-  else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64)
-  else CMR_WGB_LAUNCH(2, 1, 32)
+  if (db) {
+    if (nci == 4 && tw == 64) CMR_WGB_LAUNCH(4, 1, 64, true)
+    else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32, true)
+    else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64, true)
+    else CMR_WGB_LAUNCH(2, 1, 32, true)
+  } else if (nci == 4 && tw == 64) CMR_WGB_LAUNCH(4, 1, 64, false)
+  else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32, false)
+  else if (nco == 2) CMR_WGB_LAUNCH(2, 2, 32, false)
+  else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64, false)
+  else CMR_WGB_LAUNCH(2, 1, 32, false)
 #undef CMR_WGB_LAUNCH
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
                      groups * nsplit, Cout, Cin, dw);
+  if (db) hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, stream, (const float*)part_b, groups, Cout, db);
   return cmr_launch_status();
 }
 

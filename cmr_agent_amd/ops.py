@@ -849,8 +849,9 @@ def transpose_slots(src, dst, table, nslots, total_tiles):
 WGRAD_BF16 = True        # with CONV_BF16: 3x3 weight gradients on the bf16 cores as well (False: fp32 weight gradients, round 2's behaviour)
 
 
-def conv3x3_wgrad(x, dy, dw):
-    """x [B,H,W,Cin], dy [B,H,W,Cout] (contiguous NHWC) -> dw (flat view of [Cout,Cin,3,3] in the gradient bucket)."""
+def conv3x3_wgrad(x, dy, dw, db=None):
+    """x [B,H,W,Cin], dy [B,H,W,Cout] (contiguous NHWC) -> dw (flat view of [Cout,Cin,3,3] in the gradient bucket); db [Cout] (optional):
+    the bias gradient, from the same launch on the bf16 path, by a column sum over dy otherwise."""
     B, H, W, cin = x.shape
     cout = dy.shape[3]
     if not (x.is_contiguous() and dy.is_contiguous()) or dw.numel() != cout * cin * 9:
@@ -859,8 +860,14 @@ def conv3x3_wgrad(x, dy, dw):
     ws = _ws(nb, x.device)
     # bf16 training mode: the weight gradient on the bf16 matrix cores too (operands rounded to bf16, fp32 accumulate), like the forward
     # and data-gradient convolutions
-    name = "cmr_conv3x3_wgrad_bf16_f32" if (CONV_BF16 and WGRAD_BF16 and cin in (64, 128)) else "cmr_conv3x3_wgrad_f32"
-    _lib.call(name, _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
+    if CONV_BF16 and WGRAD_BF16 and cin in (64, 128):
+        if db is not None and (db.numel() != cout or not db.is_contiguous()):
+            raise ValueError("conv3x3_wgrad: db must be a contiguous [Cout] view")
+        _lib.call("cmr_conv3x3_wgrad_bias_bf16_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(db), _p(ws), nb, _stream())
+        return
+    _lib.call("cmr_conv3x3_wgrad_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
+    if db is not None:
+        colsum(dy.view(-1, cout), 1, B * H * W, out=db.view(1, cout))
 
 
 def linear_wgrad(dy, x, dw, lddw, n=None, k=None, accumulate=False, db=None, accumulate_db=False):

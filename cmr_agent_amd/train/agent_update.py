@@ -173,13 +173,11 @@ class AgentUpdate:
             H, W = st["H"], st["W"]
             ph, pw = (2, 2) if s < 3 else (H, W)
             dc = ops.pool_act_bwd(g.contiguous(), st["d"], ph, pw, SLOPE2D)                 # through the pool and conv b's LeakyReLU
-            ops.conv3x3_wgrad(st["z"], dc, bk.g(st["nb"] + ".weight"))
-            ops.colsum(dc.view(-1, c), 1, B * H * W, out=bk.g(st["nb"] + ".bias").view(1, c))
+            ops.conv3x3_wgrad(st["z"], dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"))
             w9t, ut = ops.pack_conv3x3(bk.w(st["nb"] + ".weight"), c, c, transpose=True)
             dz = ops.conv3x3(dc, w9t, None, c, 1, 1.0, u=ut)
             da = self._bn_bwd(dz.view(-1, c), st["z"].view(-1, c), SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
-            ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"))
-            ops.colsum(da.view(-1, c), 1, B * H * W, out=bk.g(st["na"] + ".bias").view(1, c))
+            ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"), db=bk.g(st["na"] + ".bias"))
             if s > 0:
                 w9t, ut = ops.pack_conv3x3(bk.w(st["na"] + ".weight"), c, c, transpose=True)
                 g = ops.conv3x3(da, w9t, None, c, 1, 1.0, u=ut)

@@ -492,6 +492,11 @@ int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout
  * cmr_conv3x3_wgrad_workspace_bytes. */
 int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                                int64_t ws_bytes, hipStream_t stream);
+/* The same launch + the bias gradient db [Cout] = sum of dy over all pixels (torch.nn.Conv2d's bias.grad; autograd of
+ * Train_Agent.py:296-305): every dy element is staged by exactly one lane of the weight-gradient kernel, which keeps fp32 running
+ * sums per channel -- replaces a cmr_colsum_f32 pass over dy.  db null: identical to the entry point above. */
+int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, float* db, void* ws,
+                                    int64_t ws_bytes, hipStream_t stream);
 /* A/B switch: 1 (default) = the LDS-staged kernel for Cin 64 / 128 on maps of >= 4096 pixels (a ring of input rows in LDS, every
  * tap an LDS address), 0 = the direct kernel everywhere (operands by dword loads).  Same sums in a different order (results agree
  * to fp32 rounding); returns the previous setting. */

@@ -149,16 +149,24 @@ def test_conv3x3_weight_gradient_bf16(B, H, W, cin, cout):
         return w.grad
     want_bf, want_fp = wgrad(bf(x), bf(dy)), wgrad(x.double(), dy.double())
     xd, dyd = x.permute(0, 2, 3, 1).contiguous().to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV)
-    dw = torch.empty(cout * cin * 9, device=DEV)
+    dw, db = torch.empty(cout * cin * 9, device=DEV), torch.full((cout,), float("nan"), device=DEV)
+    dw0 = torch.empty_like(dw)
     ops.CONV_BF16 = True
     try:
-        ops.conv3x3_wgrad(xd, dyd, dw)
+        ops.conv3x3_wgrad(xd, dyd, dw, db=db)                # cmr_conv3x3_wgrad_bias_bf16_f32: the bias gradient from the same launch
+        ops.conv3x3_wgrad(xd, dyd, dw0)
     finally:
         ops.CONV_BF16 = False
     got = dw.view(cout, cin, 3, 3).cpu().double()
     scale = float(want_fp.abs().max())
     assert float((got - want_bf).abs().max()) <= 3e-5 * scale, float((got - want_bf).abs().max()) / scale
     assert float((got - want_fp).abs().max()) <= 1.5e-2 * scale
+    # asking for the bias gradient does not change the weight gradient (beyond the summation order: one cout tile per workgroup then)
+    assert float((dw - dw0).abs().max()) <= 2e-6 * scale
+    # bias.grad = sum of dy over batch and pixels, from the UNROUNDED fp32 values (fp32 running sums per lane, double across workgroups)
+    want_db = dy.double().sum(dim=(0, 2, 3))
+    err = float((db.cpu().double() - want_db).abs().max())
+    assert err <= 2e-5 * float(dy.double().abs().sum(dim=(0, 2, 3)).max()), err
 
 
 def test_configs3_batch_of_four_in_bf16_is_sample_independent_and_rigid():
