@@ -1132,3 +1132,170 @@ extern "C" int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int trans
                      (wg_bf16*)bf16_frag, bf16_nt);
   return cmr_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward of y = act(x W^T + b) on a SMALL row map (the transformer / proxy layers of Train_Geo.py: 640 - 4 096 rows, widths <= 128) in
+// ONE launch:   dYe = dY * act'(Y);   dW (+)= dYe^T X;   db (+)= column sums of dYe;   dX = dYe W (+ res)
+// These layers used to cost four launch-sized kernels each (activation backward, weight-gradient partials, their reduction, the
+// data-gradient GEMM: ~30 us for ~10 MFLOP); there are ~150 of them per geometric update.  Workgroups of 16 waves take one of two roles:
+//   blocks [0, n k / 256): one 16 x 16 tile of dW (v_mfma_f32_16x16x4_f32: 16 - 64 workgroups instead of the 4 - 16 of 32 x 32 tiles -- the
+//                        role is a latency chain, not arithmetic).  Wave w multiplies the row quads w, w + 16, ... (48 operand loads in
+//                        flight per lane), the 16 partial tiles are summed through LDS in a fixed order (double), db rides with k block 0.
+//   the other blocks:    4 row tiles of dX each (one per SIMD); W (<= 64 KB) is staged in LDS by all 16 waves, a lane owns one row (the transposed
+//                        form of linear_ws_kernel: operands W[n][.] from LDS, dYe[row][n .. n + 3] from registers).
+// Deterministic: no atomics, fixed summation orders.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct LbrArgs {
+  const float *dy, *y, *x, *w, *res;
+  float *dw, *db, *dx;
+  int64_t lddy, ldy, ldx, ldw, lddw, lddx, ldres;
+  int rows, n, k, acc_dw, acc_db;
+  float slope;
+};
+constexpr int LBR_U = 16, LBR_MAX_ROWS = 4096;
+
+template <int KT>
+__global__ __launch_bounds__(1024) void linear_bwd_rows_kernel(const LbrArgs a) {
+  __shared__ __attribute__((aligned(16))) float lbr_smem[16 * 32 * 33 + 16 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  constexpr int K16 = 2 * KT;                            // 16-column blocks of k
+  const int ntw = (a.n / 16) * (K16);                    // 16 x 16 tiles of dW
+  if ((int)blockIdx.x < ntw) {
+    // ---------------- one 16 x 16 tile of dW (+ db): v_mfma_f32_16x16x4_f32, four rows per instruction (lane >> 4 = row of the quad)
+    float* red = lbr_smem;                               // [16 waves][16][17]
+    float* redb = lbr_smem + 16 * 16 * 17;               // [16][64]
+    const int tn = blockIdx.x / K16, tk = blockIdx.x % K16;
+    const int l15 = lane & 15, rq = lane >> 4;
+    const int nquads = (a.rows + 3) / 4;
+    const float* dyp = a.dy + tn * 16 + l15;
+    const float* yp = a.y ? a.y + tn * 16 + l15 : nullptr;
+    const float* xp = a.x + tk * 16 + l15;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int q0 = wave; q0 < nquads; q0 += 16 * LBR_U) {
+      float av[LBR_U], bv[LBR_U], yv[LBR_U];
+#pragma unroll
+      for (int u = 0; u < LBR_U; ++u) {
+        const int r = 4 * (q0 + 16 * u) + rq;
+        const int64_t rc = r < a.rows ? r : 0;           // (branch-free: rows past the end re-read row 0 and are zeroed below)
+        av[u] = dyp[rc * a.lddy];
+        bv[u] = xp[rc * a.ldx];
+        yv[u] = yp ? yp[rc * a.ldy] : 1.f;
+      }
+#pragma unroll
+      for (int u = 0; u < LBR_U; ++u) {
+        const int r = 4 * (q0 + 16 * u) + rq;
+        float d = yv[u] > 0.f ? av[u] : av[u] * a.slope;
+        d = r < a.rows ? d : 0.f;
+        bsum += d;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(d, bv[u], acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 16 + 4 * rq + r) * 17 + l15] = acc[r];      // D[4 (lane >> 4) + r][lane & 15]
+    redb[wave * 64 + lane] = bsum;
+    __syncthreads();
+    if (tid < 256) {
+      const int row = tid >> 4, col = tid & 15;
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) s += (double)red[(w * 16 + row) * 17 + col];
+      float* d = a.dw + (int64_t)(tn * 16 + row) * a.lddw + tk * 16 + col;
+      *d = a.acc_dw ? *d + (float)s : (float)s;
+    }
+    if (a.db && tk == 0 && tid < 16) {
+      double s = 0.0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) s += (double)redb[w * 64 + 16 * g + tid];
+      float* d = a.db + tn * 16 + tid;
+      *d = a.acc_db ? *d + (float)s : (float)s;
+    }
+    return;
+  }
+  // ---------------- 4 row tiles of dX
+  if (a.dx == nullptr) return;
+  constexpr int K = 32 * KT;
+  // FOUR row tiles per workgroup (waves 0-3, one per SIMD; waves 4-15 only help staging W): with 16 tiles the workgroup's CU multiplied all of
+  // them through its four matrix pipes -- 7.5 us for 640 rows on 2 of 256 CUs
+  const int tile = ((int)blockIdx.x - ntw) * 4 + (wave < 4 ? wave : 0);
+  const int row = tile * 32 + l31;
+  const bool valid = row < a.rows;
+  const int64_t rc = valid ? row : 0;
+  const float* dyr = a.dy + rc * a.lddy + 4 * h;
+  const float* yr = a.y ? a.y + rc * a.ldy + 4 * h : nullptr;
+  const int ng = a.n / 8;                                // k-groups of the contraction over n (a multiple of 4)
+  // the first k-groups of this lane's row are requested BEFORE W is staged: one memory round trip for both
+  constexpr int TRIP = KT == 4 ? 4 : 8;                  // (64 accumulator registers at k = 128: four groups per trip)
+  f32x4 dv[TRIP], yv[TRIP];
+  auto load_trip = [&](int g0) {
+#pragma unroll
+    for (int i = 0; i < TRIP; ++i) {
+      const int g = g0 + i < ng ? g0 + i : 0;            // (uniform) groups past the end re-read group 0 and are skipped below
+      dv[i] = *reinterpret_cast<const f32x4*>(dyr + g * 8);
+      yv[i] = yr ? *reinterpret_cast<const f32x4*>(yr + g * 8) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+  };
+  load_trip(0);
+  float* Ws = lbr_smem;                                  // [n][K]  (n <= 128: <= 64 KB)
+  for (int e = tid; e < a.n * (K / 4); e += 1024) {
+    const int nn = e / (K / 4), c = (e % (K / 4)) * 4;
+    *reinterpret_cast<f32x4*>(&Ws[nn * K + c]) = *reinterpret_cast<const f32x4*>(a.w + (int64_t)nn * a.ldw + c);
+  }
+  __syncthreads();
+  if (wave >= 4 || tile * 32 >= a.rows) return;          // (wave-uniform; no barrier below)
+  f32x16 acc[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  for (int g0 = 0; g0 < ng; g0 += TRIP) {
+    if (g0 > 0) load_trip(g0);
+#pragma unroll
+    for (int i = 0; i < TRIP; ++i) {
+      if (g0 + i >= ng) break;                           // (uniform)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dv[i][e] = yv[i][e] > 0.f ? dv[i][e] : dv[i][e] * a.slope;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* wr = Ws + ((g0 + i) * 8 + 4 * h + j) * K + l31;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) acc[t] = cmr_mfma32(wr[32 * t], dv[i][j], acc[t]);
+      }
+    }
+  }
+  if (valid) {
+    float* dxr = a.dx + (int64_t)row * a.lddx + 4 * h;
+    const float* rr = a.res ? a.res + (int64_t)row * a.ldres + 4 * h : nullptr;
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        if (rr) v += *reinterpret_cast<const f32x4*>(rr + 32 * t + 8 * q);
+        *reinterpret_cast<f32x4*>(dxr + 32 * t + 8 * q) = v;
+      }
+  }
+}
+}  // namespace
+
+extern "C" int cmr_linear_bwd_rows_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float slope, const float* x, int64_t ldx,
+                                       const float* w, int64_t ldw, int64_t rows, int n, int k, float* dw, int64_t lddw, int accumulate_dw,
+                                       float* db, int accumulate_db, const float* res, int64_t ldres, float* dx, int64_t lddx,
+                                       hipStream_t stream) {
+  CMR_REQUIRE(dy && x && w && dw && rows > 0 && n > 0 && k > 0);
+  if (rows > LBR_MAX_ROWS || n % 32 != 0 || n > 128 || !(k == 32 || k == 64 || k == 128)) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(lddy % 4 == 0 && cmr_aligned16(dy) && (!y || (ldy % 4 == 0 && cmr_aligned16(y))) && ldw % 4 == 0 && cmr_aligned16(w));
+  CMR_REQUIRE(!dx || (lddx % 4 == 0 && cmr_aligned16(dx) && (!res || (ldres % 4 == 0 && cmr_aligned16(res)))));
+  const LbrArgs a{dy, y, x, w, res, dw, db, dx, lddy, ldy, ldx, ldw, lddw, lddx, ldres, (int)rows, n, k, accumulate_dw, accumulate_db, slope};
+  const int kt = k / 32, tiles = (int)((rows + 31) / 32);
+  const dim3 grid((unsigned)((n / 16) * (k / 16) + (dx ? (tiles + 3) / 4 : 0)));
+  if (kt == 1) hipLaunchKernelGGL(linear_bwd_rows_kernel<1>, grid, dim3(1024), 0, stream, a);
+  else if (kt == 2) hipLaunchKernelGGL(linear_bwd_rows_kernel<2>, grid, dim3(1024), 0, stream, a);
+  else hipLaunchKernelGGL(linear_bwd_rows_kernel<4>, grid, dim3(1024), 0, stream, a);
+  return cmr_launch_status();
+}

@@ -1036,6 +1036,32 @@ def circle_loss_bwd(pc_feat_rows, img_feat_nhwc, pc_idx, xy_int, xy_float, B, N,
               _stream())
 
 
+LINEAR_BWD_ROWS = os.environ.get("CMR_LINEAR_BWD_ROWS", "1") != "0"     # A/B: the one-launch backward of small row-map linears
+
+
+def linear_bwd_rows(dy, y, slope, x, w, dw, accumulate_dw=False, db=None, accumulate_db=False, res=None, out=None, want_dx=True):
+    """One-launch backward of y = act(x W^T + b) on a small row map: dw (+)= dYe^T x, db (+)= colsum(dYe), returns dx = dYe W (+ res)
+    (None with want_dx False) -- or False when the shape is not served (caller composes act_bwd / linear_wgrad / linear)."""
+    if not LINEAR_BWD_ROWS:
+        return False
+    _rows(dy), _rows(x)
+    rows, n = dy.shape
+    k = x.shape[1]
+    if tuple(dw.shape) != (n, k) or tuple(w.shape) != (n, k) or x.shape[0] != rows or rows > 4096 or n % 32 or n > 128 or k not in (32, 64, 128):
+        return False
+    if (y is not None and tuple(y.shape) != (rows, n)) or (res is not None and tuple(res.shape) != (rows, k)) or w.stride(1) != 1 or dw.stride(1) != 1:
+        return False
+    if want_dx and out is None:
+        out = torch.empty((rows, k), dtype=f32, device=x.device)
+    rc = _lib.call("cmr_linear_bwd_rows_f32", _p(dy), _ld(dy), _p(y), _ld(y) if y is not None else 0, float(slope), _p(x), _ld(x), _p(w),
+                   w.stride(0), rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(db), int(accumulate_db), _p(res),
+                   _ld(res) if res is not None else 0, _p(out) if want_dx else None, _ld(out) if want_dx else 0, _stream(),
+                   allow_unsupported=True)
+    if rc == _lib.UNSUPPORTED:
+        return False
+    return out if want_dx else None
+
+
 def linear_wgrad_any(dy, x, dw, accumulate=False, db=None, accumulate_db=False):
     """dw [n, k] (+)= dy^T x (and db) for any n, k (the MLP of the transformer blocks has n or k = 1024, the patch embedding
     k = 4096): one launch."""

@@ -123,11 +123,21 @@ class Tape:
         def bwd():
             if y.g is None:
                 return
-            dy = y.g if act == ops.ACT_NONE else ops.act_bwd(y.g, y.v, 0.0 if act == ops.ACT_RELU else slope)
             gw, acc = self.G(weight)
+            # small row maps (transformer / proxy layers): activation backward, both gradients and the data gradient in ONE launch
+            gbv, accb = self.G(bias) if bias is not None else (None, False)
+            inplace = x.g is not None and x.own and x.g.is_contiguous()
+            dx = ops.linear_bwd_rows(y.g, None if act == ops.ACT_NONE else y.v, 0.0 if act == ops.ACT_RELU else slope, x.v, W, gw, acc,
+                                     db=gbv, accumulate_db=accb, res=x.g, out=x.g if inplace else None)
+            if dx is not False:
+                if x.g is None:
+                    self.give(x, dx, owned=True)
+                else:
+                    x.g, x.own = dx, True
+                return
+            dy = y.g if act == ops.ACT_NONE else ops.act_bwd(y.g, y.v, 0.0 if act == ops.ACT_RELU else slope)
             if bias is not None:
-                gb, accb = self.G(bias)
-                ops.linear_wgrad_any(dy, x.v, gw, acc, db=gb, accumulate_db=accb)
+                ops.linear_wgrad_any(dy, x.v, gw, acc, db=gbv, accumulate_db=accb)
             else:
                 ops.linear_wgrad_any(dy, x.v, gw, acc)
             if x.g is None:

@@ -141,6 +141,7 @@ WORK = {
                                              F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     "cmr_conv3x3_wgrad_bias_bf16_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
                                                   F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
+    "cmr_linear_bwd_rows_f32": lambda a: (4.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (3 * a["n"] + 3 * a["k"]) + 2 * a["n"] * a["k"])),
     "cmr_linear_wgrad_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (a["n"] + a["k"]) + a["n"] * a["k"])),
     "cmr_adam_f32": lambda a: (0, 28 * a["n"]),
 }

@@ -454,6 +454,15 @@ int cmr_colmax_arg_f32(const float* x, int64_t ldx, float* out, int32_t* arg, vo
                        hipStream_t stream);
 int cmr_add_at_arg_f32(float* dx, int64_t lddx, const int32_t* arg, const float* g, int64_t ldg, int B, int N, int C,
                        hipStream_t stream);
+/* Backward of y = act(x W^T + b) on a small row map (rows <= 4096; n % 32 == 0, n <= 128; k in {32, 64, 128}) in ONE launch -- the
+ * autograd of nn.Linear / Conv1d(k=1) (+ ReLU / LeakyReLU) in Train_Geo.py:166-174's backward for the transformer / proxy layers:
+ *   dYe = dy * (y > 0 ? 1 : slope) (y null: dYe = dy);  dw [n][k] (+)= dYe^T x;  db [n] (+)= column sums of dYe (optional);
+ *   dx [rows][k] = dYe w (+ res) (optional; res may alias dx).  w [n][k] is the forward weight (no transposed copy needed).
+ * Deterministic (fixed summation orders).  Returns -3 (unsupported) outside the shapes above: the caller composes cmr_act_bwd_f32,
+ * cmr_linear_wgrad_f32 and cmr_linear_f32. */
+int cmr_linear_bwd_rows_f32(const float* dy, int64_t lddy, const float* y, int64_t ldy, float slope, const float* x, int64_t ldx,
+                            const float* w, int64_t ldw, int64_t rows, int n, int k, float* dw, int64_t lddw, int accumulate_dw,
+                            float* db, int accumulate_db, const float* res, int64_t ldres, float* dx, int64_t lddx, hipStream_t stream);
 /* nn.Linear / 1x1 conv backward on a handful of rows (<= 1024; the layers after the global pools, CMRAgent.py:57-59,70-86):
  * dYe = dY * LeakyReLU'(Y) (Y null: none); dW = dYe^T [X1|X2]; db = sum dYe; dX1 / dX2 (+)= dYe W. */
 int cmr_linear_bwd_small_f32(const float* x1, int64_t ldx1, int k1, const float* x2, int64_t ldx2, int k2, const float* y,

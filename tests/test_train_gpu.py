@@ -188,6 +188,47 @@ def test_linear_weight_gradient(ops, rows, n, k):
         close(dw2[:, :32], (dy.double().t() @ x[:, :32].double()).float(), 2e-5, "linear wgrad, strided x")
 
 
+@pytest.mark.parametrize("rows,n,k,act,bias,second", [(640, 64, 64, "none", True, False), (2048, 64, 64, "relu", True, True), (2047, 128, 64, "lrelu", True, False),
+                                                       (33, 64, 128, "lrelu", False, True), (4096, 128, 128, "none", True, True), (1, 32, 32, "relu", True, False),
+                                                       (1281, 96, 64, "none", True, False)])
+def test_linear_backward_of_a_small_row_map_in_one_launch(ops, rows, n, k, act, bias, second):
+    """cmr_linear_bwd_rows_f32: activation backward + dW + db + dX (+ accumulation into an existing dX) of y = act(x W^T + b) against float64
+    and against the composed path (act_bwd, linear_wgrad, linear) it replaces; odd row counts, one row, strided operands, accumulating
+    into existing dW / db; shapes outside its range are declined."""
+    x, w, dyv = rnd(rows, k + 4, seed=51)[:, :k], rnd(n, k, seed=52) * 0.2, rnd(rows, n, seed=53)
+    yv = (x.double() @ w.double().t()).float()
+    slope = {"none": 1.0, "relu": 0.0, "lrelu": 0.2}[act]
+    yact = torch.where(yv > 0, yv, yv * slope) if act != "none" else yv
+    dye = dyv.double() * (torch.where(yact > 0, 1.0, slope).double() if act != "none" else 1.0)
+    res = rnd(rows, k, seed=54) if second else None
+    want_dw, want_db = dye.t() @ x.double(), dye.sum(0)
+    want_dx = dye @ w.double() + (res.double() if second else 0.0)
+    d = lambda t: t.to(DEV)
+    xd = d(rnd(rows, k + 4, seed=51))[:, :k]
+    dw0, db0 = rnd(n, k, seed=55), rnd(n, seed=56)
+    dw, db = d(dw0).clone(), d(db0).clone()
+    resd = d(res).clone() if second else None
+    dx = ops.linear_bwd_rows(d(dyv), d(yact) if act != "none" else None, slope, xd, d(w), dw, True, db=db if bias else None, accumulate_db=True,
+                             res=resd, out=resd)
+    assert dx is not False
+    if second:
+        assert dx.data_ptr() == resd.data_ptr()                       # accumulated in place
+    sw, sx = float(want_dw.abs().max()), float(want_dx.abs().max())
+    assert float((dw.cpu().double() - (want_dw + dw0.double())).abs().max()) <= 3e-5 * max(sw, 1.0)
+    assert float((dx.cpu().double() - want_dx).abs().max()) <= 3e-5 * max(sx, 1.0)
+    if bias:
+        assert float((db.cpu().double() - (want_db + db0.double())).abs().max()) <= 3e-5 * max(float(want_db.abs().max()), 1.0)
+    # overwrite mode + no dX
+    dw2 = torch.full((n, k), 9.0, device=DEV)
+    assert ops.linear_bwd_rows(d(dyv), d(yact) if act != "none" else None, slope, xd, d(w), dw2, False, want_dx=False) is None
+    assert float((dw2.cpu().double() - want_dw).abs().max()) <= 3e-5 * max(sw, 1.0)
+    # declined shapes: too many rows, widths outside the instantiated set
+    big = torch.zeros(4097, n, device=DEV)
+    assert ops.linear_bwd_rows(big, None, 1.0, torch.zeros(4097, k, device=DEV), d(w), dw2) is False
+    assert ops.linear_bwd_rows(torch.zeros(8, 48, device=DEV), None, 1.0, torch.zeros(8, 64, device=DEV), torch.zeros(48, 64, device=DEV),
+                               torch.zeros(48, 64, device=DEV)) is False
+
+
 def test_column_reductions_pool_backward(ops):
     B, N, Cc = 3, 1777, 64
     x = rnd(B * N, Cc, seed=31)
