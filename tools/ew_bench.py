@@ -2,10 +2,13 @@
 """Streaming (element-wise / row-wise) kernels of the training path at the point-level map size: time and HBM rate.  Development tool."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from cmr_agent_amd import ops
+from cmr_agent_amd import ops, _lib
+if "--lib" in sys.argv:                                   # A/B: another build of the library (tools/ab_build.sh)
+    _lib.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from kbench import timeit
 DEV = "cuda"
-for rows in (327680, 40960):
+for rows in (524288, 40960):
     x = torch.randn(rows, 64, device=DEV); y = torch.randn(rows, 64, device=DEV); o = torch.empty_like(x)
     g = torch.rand(64, device=DEV) + 0.5; b = torch.randn(64, device=DEV)
     mb = rows * 64 * 4 / 1e6
