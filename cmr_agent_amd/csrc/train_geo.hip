@@ -550,13 +550,43 @@ __global__ __launch_bounds__(256) void segment_softmax_bwd_kernel(const float* _
   if (seg >= nseg) return;
   const int64_t lo = offsets ? offsets[seg] : seg * fixed_len;
   const int64_t hi = offsets ? offsets[seg + 1] : lo + fixed_len;
+  // eight members in flight per pass, as in segment_softmax_kernel (same order of operations: bit-identical)
+  constexpr int U = 8;
   float m = -INFINITY;
-  for (int64_t i = lo; i < hi; ++i) {
+  int64_t i = lo;
+  for (; i + U <= hi; i += U) {
+    int64_t r[U];
+    float a[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = order ? (int64_t)order[i + u] : i + u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) a[u] = attn[r[u] * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < U; ++u) m = fmaxf(m, a[u] * scale);
+  }
+  for (; i < hi; ++i) {
     const int64_t r = order ? order[i] : i;
     m = fmaxf(m, attn[r * 64 + lane] * scale);
   }
   float l = 0.f, acc = 0.f;
-  for (int64_t i = lo; i < hi; ++i) {
+  for (i = lo; i + U <= hi; i += U) {
+    int64_t r[U];
+    float a[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = order ? (int64_t)order[i + u] : i + u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = attn[r[u] * 64 + lane];
+      w[u] = vp[r[u] * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = expf(a[u] * scale - m);
+      l += p;
+      acc += p * w[u];
+    }
+  }
+  for (; i < hi; ++i) {
     const int64_t r = order ? order[i] : i;
     const float p = expf(attn[r * 64 + lane] * scale - m);
     l += p;
@@ -564,7 +594,24 @@ __global__ __launch_bounds__(256) void segment_softmax_bwd_kernel(const float* _
   }
   const float o = hi > lo ? acc / l : 0.f;
   const float g = dout[seg * 64 + lane];
-  for (int64_t i = lo; i < hi; ++i) {
+  for (i = lo; i + U <= hi; i += U) {
+    int64_t r[U];
+    float a[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) r[u] = order ? (int64_t)order[i + u] : i + u;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = attn[r[u] * 64 + lane];
+      w[u] = vp[r[u] * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float p = expf(a[u] * scale - m) / l;
+      dvp[r[u] * 64 + lane] = p * g;
+      dattn[r[u] * 64 + lane] = scale * p * g * (w[u] - o);
+    }
+  }
+  for (; i < hi; ++i) {
     const int64_t r = order ? order[i] : i;
     const float p = expf(attn[r * 64 + lane] * scale - m) / l;
     const float w = vp[r * 64 + lane];
