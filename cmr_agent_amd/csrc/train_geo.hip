@@ -670,11 +670,35 @@ __device__ __forceinline__ void circle_terms(const CircleArgs& a, int b, int i, 
 }
 
 __global__ __launch_bounds__(64) void circle_dist_kernel(const CircleArgs a) {
-  // one wave per (i, b): lane = channel; d_ij for all j
+  // one wave per (i, b): lane = channel; d_ij for all j.  Eight gathered pixel rows in flight per trip (the one-row-per-iteration loop was a
+  // chain of 512 dependent memory round trips per wave: ~300 us of the 800 us this loss's backward took); same sums in the same order.
   const int i = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const float pv = a.pc_feat[((int64_t)b * a.N + a.pc_idx[(int64_t)b * a.n + i]) * 64 + lane];
-  for (int j = 0; j < a.n; ++j) {
-    const int64_t px = a.xy_int[((int64_t)b * 2 + 0) * a.n + j], py = a.xy_int[((int64_t)b * 2 + 1) * a.n + j];
+  const int64_t* xi = a.xy_int + (int64_t)b * 2 * a.n;
+  constexpr int U = 8;
+  int j = 0;
+  for (; j + U <= a.n; j += U) {
+    float iv[U], sq[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t px = xi[j + u], py = xi[a.n + j + u];
+      iv[u] = a.img_feat[(((int64_t)b * a.h + py) * a.w + px) * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) sq[u] = (pv - iv[u]) * (pv - iv[u]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+#pragma unroll
+      for (int u = 0; u < U; ++u) sq[u] += __shfl_xor(sq[u], m);
+    if (lane < U) {
+      float v = sq[0];
+#pragma unroll
+      for (int u = 1; u < U; ++u) v = lane == u ? sq[u] : v;      // (every lane holds every total after the butterfly)
+      a.dmat[((int64_t)b * a.n + i) * a.n + j + lane] = sqrtf(v);
+    }
+  }
+  for (; j < a.n; ++j) {
+    const int64_t px = xi[j], py = xi[a.n + j];
     const float iv = a.img_feat[(((int64_t)b * a.h + py) * a.w + px) * 64 + lane];
     float s = (pv - iv) * (pv - iv);
 #pragma unroll
@@ -736,36 +760,71 @@ __global__ __launch_bounds__(256) void circle_weight_kernel(const CircleArgs a) 
 }
 
 __global__ __launch_bounds__(64) void circle_feat_kernel(const CircleArgs a) {
-  // blockIdx.z = 0: d pts_i = sum_j G_ij (pts_i - pix_j);  1: d pix_j = - sum_i G_ij (pts_i - pix_j)
+  // blockIdx.z = 0: d pts_i = sum_j G_ij (pts_i - pix_j);  1: d pix_j = - sum_i G_ij (pts_i - pix_j).  Eight gathered rows (and their
+  // G entries) in flight per trip, accumulated in index order as before.
   const int idx = blockIdx.x, b = blockIdx.y, side = blockIdx.z, lane = threadIdx.x;
-  auto pts = [&](int i) { return a.pc_feat[((int64_t)b * a.N + a.pc_idx[(int64_t)b * a.n + i]) * 64 + lane]; };
-  auto pix = [&](int j) {
-    const int64_t px = a.xy_int[((int64_t)b * 2 + 0) * a.n + j], py = a.xy_int[((int64_t)b * 2 + 1) * a.n + j];
-    return a.img_feat[(((int64_t)b * a.h + py) * a.w + px) * 64 + lane];
-  };
+  const int64_t* xi = a.xy_int + (int64_t)b * 2 * a.n;
+  const int64_t* pi = a.pc_idx + (int64_t)b * a.n;
+  auto pts = [&](int i) { return a.pc_feat[((int64_t)b * a.N + pi[i]) * 64 + lane]; };
+  auto pix = [&](int j) { return a.img_feat[(((int64_t)b * a.h + xi[a.n + j]) * a.w + xi[j]) * 64 + lane]; };
+  constexpr int U = 8;
   float acc = 0.f;
   if (side == 0) {
     const float me = pts(idx);
-    for (int j = 0; j < a.n; ++j) acc += a.dmat[((int64_t)b * a.n + idx) * a.n + j] * (me - pix(j));
+    const float* grow = a.dmat + ((int64_t)b * a.n + idx) * a.n;
+    int j = 0;
+    for (; j + U <= a.n; j += U) {
+      float g[U], v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { g[u] = grow[j + u]; v[u] = pix(j + u); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc += g[u] * (me - v[u]);
+    }
+    for (; j < a.n; ++j) acc += grow[j] * (me - pix(j));
     a.dpts[((int64_t)b * a.n + idx) * 64 + lane] = acc;
   } else {
     const float me = pix(idx);
-    for (int i = 0; i < a.n; ++i) acc -= a.dmat[((int64_t)b * a.n + i) * a.n + idx] * (pts(i) - me);
+    const float* gcol = a.dmat + (int64_t)b * a.n * a.n + idx;
+    int i = 0;
+    for (; i + U <= a.n; i += U) {
+      float g[U], v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { g[u] = gcol[(int64_t)(i + u) * a.n]; v[u] = pts(i + u); }
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc -= g[u] * (v[u] - me);
+    }
+    for (; i < a.n; ++i) acc -= gcol[(int64_t)i * a.n] * (pts(i) - me);
     a.dpix[((int64_t)b * a.n + idx) * 64 + lane] = acc;
   }
 }
 
 __global__ __launch_bounds__(64) void circle_scatter_kernel(const CircleArgs a, float* __restrict__ d_pc, float* __restrict__ d_img) {
-  // one wave per (batch, side): samples in order, so repeated indices accumulate deterministically
-  const int b = blockIdx.x, side = blockIdx.y, lane = threadIdx.x;
-  for (int k = 0; k < a.n; ++k) {
-    if (side == 0) {
-      d_pc[((int64_t)b * a.N + a.pc_idx[(int64_t)b * a.n + k]) * 64 + lane] += a.dpts[((int64_t)b * a.n + k) * 64 + lane];
-    } else {
-      const int64_t px = a.xy_int[((int64_t)b * 2 + 0) * a.n + k], py = a.xy_int[((int64_t)b * 2 + 1) * a.n + k];
-      d_img[(((int64_t)b * a.h + py) * a.w + px) * 64 + lane] += a.dpix[((int64_t)b * a.n + k) * 64 + lane];
+  // Samples may repeat an index, and the additions into one row have to happen in sample order (deterministic, = the sequential loop this
+  // replaces: one wave per (batch, side) walking 512 read-modify-writes).  One wave per (sample k, batch, side): the wave of the FIRST
+  // occurrence of a row adds every sample of that row, in sample order; the others have nothing to do.
+  const int k = blockIdx.x, b = blockIdx.y, side = blockIdx.z, lane = threadIdx.x;
+  const int64_t* xi = a.xy_int + (int64_t)b * 2 * a.n;
+  const int64_t* pi = a.pc_idx + (int64_t)b * a.n;
+  auto key = [&](int q) -> int64_t { return side == 0 ? pi[q] : xi[a.n + q] * a.w + xi[q]; };
+  const int64_t mine = key(k);
+  // any earlier sample with the same row?  (lanes split the earlier samples)
+  int earlier = 0;
+  for (int q = lane; q < k; q += 64) earlier |= key(q) == mine ? 1 : 0;
+  if (__any(earlier)) return;
+  float* dst = side == 0 ? d_pc + ((int64_t)b * a.N + mine) * 64 + lane : d_img + ((int64_t)b * a.h * a.w + mine) * 64 + lane;
+  const float* src = (side == 0 ? a.dpts : a.dpix) + (int64_t)b * a.n * 64 + lane;
+  float v = *dst + src[(int64_t)k * 64];
+  for (int q0 = k + 1; q0 < a.n; q0 += 64) {            // later samples of the same row, in order
+    const int q = q0 + lane;
+    const bool same = q < a.n && key(q) == mine;
+    uint64_t mask = __ballot(same);
+    while (mask) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      v += src[(int64_t)(q0 + l) * 64];
     }
   }
+  *dst = v;
 }
 
 }  // namespace
@@ -966,6 +1025,6 @@ extern "C" int cmr_circle_loss_bwd_f32(const float* pc_feat, const float* img_fe
   hipLaunchKernelGGL(circle_lse_kernel, dim3(n, B, 2), dim3(64), 0, stream, a);
   hipLaunchKernelGGL(circle_weight_kernel, dim3((unsigned)(((int64_t)B * n * n + 255) / 256)), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(circle_feat_kernel, dim3(n, B, 2), dim3(64), 0, stream, a);
-  hipLaunchKernelGGL(circle_scatter_kernel, dim3(B, 2), dim3(64), 0, stream, a, d_pc_feat, d_img_feat);
+  hipLaunchKernelGGL(circle_scatter_kernel, dim3(n, B, 2), dim3(64), 0, stream, a, d_pc_feat, d_img_feat);
   return cmr_launch_status();
 }
