@@ -453,6 +453,15 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   out[r * ldo + c] = src[(int64_t)idx[r] * lds + c];
 }
 
+__global__ __launch_bounds__(256) void gather_rows4_kernel(const float* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ out, int64_t ldo, int64_t rows, int Q) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r = e / Q;
+  if (r >= rows) return;
+  const int c = (int)(e % Q) * 4;
+  *reinterpret_cast<f32x4*>(out + r * ldo + c) = *reinterpret_cast<const f32x4*>(src + (int64_t)idx[r] * lds + c);
+}
+
 // ---- pointnet_util --------------------------------------------------------------------------
 // Farthest point sampling: one workgroup (1024 threads) per cloud, running min-distance in
 // registers, argmax by wave shuffle + LDS across the 16 waves (lowest index wins ties, like
@@ -874,6 +883,10 @@ extern "C" int cmr_segment_reduce_f32(const float* src, int64_t lds, const int32
 extern "C" int cmr_gather_rows_f32(const float* src, int64_t lds, const int32_t* idx, float* out, int64_t ldo,
                                    int64_t rows, int C, hipStream_t stream) {
   CMR_REQUIRE(src && idx && out && rows > 0 && C > 0);
+  if (C % 4 == 0 && lds % 4 == 0 && ldo % 4 == 0 && cmr_aligned16(src) && cmr_aligned16(out)) {      // 16 bytes per thread
+    hipLaunchKernelGGL(gather_rows4_kernel, GRID1D(rows * (C / 4)), dim3(256), 0, stream, src, lds, idx, out, ldo, rows, C / 4);
+    return cmr_launch_status();
+  }
   hipLaunchKernelGGL(gather_rows_kernel, GRID1D(rows * C), dim3(256), 0, stream, src, lds, idx, out, ldo, rows, C);
   return cmr_launch_status();
 }

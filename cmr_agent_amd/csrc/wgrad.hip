@@ -519,8 +519,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_reduce_kernel(const float* 
   const int o = threadIdx.x % RED_OUT, g = threadIdx.x / RED_OUT;
   const int i = blockIdx.x * RED_OUT + o;
   double s = 0.0;
-  if (i < total)
-    for (int k = g; k < nslices; k += RED_GRP) s += (double)part[(int64_t)k * total + i];
+  if (i < total) {
+    int k = g;
+    for (; k + 7 * RED_GRP < nslices; k += 8 * RED_GRP) {         // eight slices in flight per thread, added in slice order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(k + u * RED_GRP) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; k < nslices; k += RED_GRP) s += (double)part[(int64_t)k * total + i];
+  }
   sm[g][o] = s;
   __syncthreads();
   if (g == 0 && i < total) {
