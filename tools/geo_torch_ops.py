@@ -1,0 +1,30 @@
+"""Which torch (aten) ops run on the device inside ONE geometric-model update, and from which line of the package (the non-C-ABI launches of the
+replayed step).  python tools/geo_torch_ops.py [num_pt]"""
+import collections, json, os, sys, traceback
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as BM
+from cmr_agent_amd.config import KittiConfiguration
+from cmr_agent_amd.models import MultiHeadModel
+from cmr_agent_amd.train import GeoUpdate
+from cmr_agent_amd.utils import hashfill, synthetic
+from cmr_agent_amd.utils.checkpoint import load_checked
+from reg_torch_ops_lib import Log, sites
+
+dev = torch.device("cuda", 0)
+npt = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+cfg = KittiConfiguration(device=dev, num_pt=npt)
+spec = json.load(open(os.path.join(BM.ROOT, "tests", "golden", "specs.json")))
+model = MultiHeadModel(cfg); load_checked(model, hashfill.make_state_dict(spec["geo"], BM.GEO_TAG)); model = model.to(dev)
+up = GeoUpdate(model, cfg)
+batch = synthetic.make_batch(cfg.train_batch_size, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, BM.hip_fps(dev), BM.hip_nearest(dev),
+                             seed=cfg.seed, n_circle=512, device=dev)
+up.step(batch); torch.cuda.synchronize()
+with Log():
+    up.step(batch)
+torch.cuda.synchronize()
+print("%d device-side torch ops per step" % sum(sites.values()))
+for (op, site), n in sites.most_common(50):
+    print("%4d  %-28s %s" % (n, op, site))
