@@ -11,7 +11,7 @@ from cmr_agent_amd.models import MultiHeadModel
 from cmr_agent_amd.train import GeoUpdate
 from cmr_agent_amd.utils import hashfill, synthetic
 from cmr_agent_amd.utils.checkpoint import load_checked
-from reg_torch_ops_lib import Log, sites
+from reg_torch_ops_lib import Log, sites, clone_bytes
 
 dev = torch.device("cuda", 0)
 npt = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
@@ -28,3 +28,5 @@ torch.cuda.synchronize()
 print("%d device-side torch ops per step" % sum(sites.values()))
 for (op, site), n in sites.most_common(50):
     print("%4d  %-28s %s" % (n, op, site))
+for site, nb in clone_bytes.most_common(5):
+    print("clone: %8.1f MB  %s" % (nb / 1e6, site))

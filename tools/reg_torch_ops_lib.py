@@ -4,6 +4,7 @@ import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
 sites = collections.Counter()
+clone_bytes = collections.Counter()          # bytes produced by clone() per site
 VIEW = ("view", "reshape", "expand", "permute", "transpose", "t.default", "unsqueeze", "squeeze", "slice", "select", "as_strided", "alias", "detach",
         "_unsafe_view", "unbind", "split", "narrow", "empty", "sym_", "size", "stride", "is_", "_local_scalar", "lift_fresh", "unfold")
 
@@ -19,6 +20,8 @@ class Log(TorchDispatchMode):
             fr = [x for x in traceback.extract_stack()[:-1] if "/cmr_agent_amd/" in x.filename or x.filename.endswith("bench.py")]
             site = "%s:%d  %s" % (os.path.basename(fr[-1].filename), fr[-1].lineno, (fr[-1].line or "")[:80]) if fr else "?"
             sites[(name.replace("aten.", ""), site)] += 1
+            if "clone" in name and torch.is_tensor(out):
+                clone_bytes[site] += out.numel() * out.element_size()
         return out
 
 
