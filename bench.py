@@ -142,16 +142,20 @@ def setup_ranks(args):
     if args.share_gpu and world > 1 and args.dist_backend == "nccl":
         raise SystemExit("--share-gpu needs --dist-backend gloo (RCCL refuses two ranks on one device)")
     dev = Ranks.local_device(args.share_gpu)
-    ranks = Ranks(backend=args.dist_backend, device=dev)
+    ranks = Ranks(backend=args.dist_backend, device=dev, force=getattr(args, "force_dist", False))
     return dev, ranks, world
 
 
 def dist_info(ranks, args):
     """Evidence of the collective layer for the JSON line: world size as summed by a real all-reduce on device memory."""
     n = ranks.collective_ranks()
-    d = {"dist_backend": args.dist_backend if ranks.world > 1 else None, "collective_ranks": n}
-    if ranks.world > 1 and args.dist_backend == "nccl":
-        d["rccl_ranks"] = n
+    d = {"dist_backend": args.dist_backend if ranks.dist is not None else None, "collective_ranks": n}
+    if ranks.dist is not None and args.dist_backend == "nccl":
+        d["rccl_ranks"] = n                      # world size as summed by a real RCCL all-reduce on device memory
+        d["rccl_version"] = ranks.rccl_version()
+        if ranks.forced:
+            d["rccl_note"] = ("world size 1 with a real process group (Ranks.force_init): librccl loaded, communicator created with "
+                              "device_id on this GPU, every collective of the path executed as a sum over one rank")
     if args.share_gpu and ranks.world > 1:
         d["share_gpu"] = "all %d ranks on device 0 (protocol rehearsal, not a scaling measurement)" % ranks.world
     return d
@@ -261,7 +265,7 @@ def train_main(args, ctx=None, with_cpu=False):
     ar_ms, t0 = 0.0, time.perf_counter()
     for _ in range(args.steps):
         losses = up.step(batch)
-        if world > 1:
+        if ranks.dist is not None:
             ar_ms += up.allreduce_ms()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
@@ -304,7 +308,7 @@ def train_main(args, ctx=None, with_cpu=False):
                                    "the bf16 matrix cores (operands rounded to bf16, fp32 accumulate, fp32 maps and parameters), everything "
                                    "else fp32" if dtype == "bf16" else ""), "minibatch_per_gpu": MB,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
-            "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
+            "allreduce_ms_per_step": ar_ms / args.steps if ranks.dist is not None else 0.0,
             "gradient_bucket_sum_min_max_over_ranks": sums, "gradient_buckets_identical": sums[0] == sums[-1],
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
             "roofline": train_roofline(ct.table(), 1, families),
@@ -314,58 +318,102 @@ def train_main(args, ctx=None, with_cpu=False):
     return line
 
 
-def geo_update_cpu_baseline(spec, num_pt, B, budget_s=16.0):
-    """oracle/train_oracle.py:geo_adam_train (autograd + clip + Adam) on a BOUNDED sample: 1 warm-up + up to 3 timed steps on a batch
-    of 2 pairs of the same shape (per-pair cost; BatchNorm statistics over 2 instead of 8 pairs do not change the work)."""
+def geo_update_cpu_baseline(spec, num_pt, B, H, W, budget_s=16.0):
+    """oracle/train_oracle.py:geo_adam_train (autograd + clip + Adam) on a BOUNDED sample: 1 warm-up on one small pair, then up to 3 timed
+    steps on a batch of `nb` pairs of the GPU step's shape (2 at 160x512, 1 at 352x1216: per-pair cost; BatchNorm statistics over fewer
+    pairs do not change the work)."""
     from oracle import cmr_oracle as O
     from oracle import train_oracle as TO
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    cfg = KittiConfiguration(device="cpu", num_pt=num_pt)
+    cfg = KittiConfiguration(device="cpu", num_pt=num_pt, cropped_img_H=H, cropped_img_W=W)
     sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
-    nb = 2
-    batch = synthetic.make_batch(nb, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, O.dataset_fps, O.nearest_node,
-                                 seed=5, n_circle=512)
-    one = {k: (v[:1] if torch.is_tensor(v) and v.shape[0] == nb else v) for k, v in batch.items()}
-    TO.geo_adam_train(sd, [one], cfg)
+    nb = 2 if H * W <= 160 * 512 else 1
+    batch = synthetic.make_batch(nb, cfg.num_pt, H, W, cfg.num_node, O.dataset_fps, O.nearest_node, seed=5, n_circle=512)
+    wcfg = KittiConfiguration(device="cpu", num_pt=8192)
+    warm = synthetic.make_batch(1, 8192, wcfg.cropped_img_H, wcfg.cropped_img_W, wcfg.num_node, O.dataset_fps, O.nearest_node, seed=5, n_circle=512)
+    TO.geo_adam_train(sd, [warm], wcfg)
     med, times = _median_timed(lambda: TO.geo_adam_train(sd, [batch], cfg), 3, budget_s)
     return dict(value=nb / med, unit="pairs/s", cores=torch.get_num_threads(), kind="port", cpu=_cpu_model(),
-                sample="median of %d timed steps (after 1 warm-up on one pair) on a batch of %d pairs (160x512 image, %d points; the GPU "
-                       "step has %d) through oracle/train_oracle.py (autograd + clip + Adam, torch CPU fp32); seconds per step: %s"
-                       % (len(times), nb, cfg.num_pt, B, ", ".join("%.2f" % t for t in times)))
+                sample="median of %d timed step(s) (after 1 warm-up on one 160x512 / 8 192-point pair) on a batch of %d pair(s) (%dx%d image, %d "
+                       "points; the GPU step has %d) through oracle/train_oracle.py (autograd + clip + Adam, torch CPU fp32); node sampling / "
+                       "nearest node / ball query of the GPU step's prologue are NOT in the CPU figure; seconds per step: %s"
+                       % (len(times), nb, H, W, cfg.num_pt, B, ", ".join("%.2f" % t for t in times)))
+
+
+class GeoPrologue:
+    """The dataset-side point work of a Train_Geo step on the device, per batch, INSIDE the timed step (reference
+    dataset/KittiDataset.py:107-126 farthest-point sampling of the 1 280 nodes, :359-367 nearest node of every point,
+    models/pointnet_util.py:73-93 query_ball_point).  Stress reading of BASELINE configs[4]: FPS runs over ALL points of each cloud (the
+    loader samples among 8 x 1 280 candidates), the ball query (radius 2, 32 samples) groups the cloud around the nodes.  The nodes
+    and the point -> node assignment it produces are what the step trains on."""
+
+    def __init__(self, B, N, M, dev, radius=2.0, nsample=32):
+        self.B, self.N, self.M, self.radius, self.nsample = B, N, M, radius, nsample
+        self.start = torch.zeros(B, dtype=torch.int64, device=dev)
+        self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __call__(self, batch):
+        B, N, M = self.B, self.N, self.M
+        self.ev[0].record()
+        rows = ops.planar_to_rows(batch["pc"], 4)                                    # [B*N, 4] xyz0
+        fidx = ops.fps(rows, self.start, B, N, M)                                    # int64 [B, M] local
+        gidx = ops.index_to_global(fidx, N)
+        nodes4 = ops.gather_rows(rows, gidx)                                         # [B*M, 4]
+        _, local = ops.nearest(rows, nodes4, B, N, M, want_global=False)             # int64 [B, N]
+        self.group = ops.ball_query(rows, nodes4, B, N, M, self.nsample, self.radius)    # int64 [B, M, 32]
+        batch["node"] = ops.transpose(nodes4.view(B, M, 4))[:, :3].contiguous()      # [B, 3, M] as the loader emits it
+        batch["pt2node"] = local
+        self.ev[1].record()
+        return batch
+
+    def ms(self):
+        self.ev[1].synchronize()
+        return self.ev[0].elapsed_time(self.ev[1])
 
 
 def geo_train_main(args, ctx=None, with_cpu=False):
-    """--mode train-geo: the geometric-model update of Train_Geo.py:166-174 at the reference's training
-    configuration (KittiConfig: 160x512 crop, 40 960 points, batch 8 per GPU).  One STEP = one batch through
-    cmr_agent_amd.train.GeoUpdate: train-mode forward on the HIP tape, focal + focal + circle loss, backward into the flat
-    gradient bucket, ONE RCCL all-reduce of it (N > 1), value clipping + fused Adam."""
+    """--mode train-geo: the geometric-model update of Train_Geo.py:166-174.  Default shape = the reference's training
+    configuration (KittiConfig: 160x512 crop, 40 960 points, batch 8 per GPU); `--img 352x1216 --num-pt 65536 --prologue` = SURVEY.md
+    8d's C5 / BASELINE configs[4] with the on-device node sampling, nearest-node assignment and a ball query inside the timed step.
+    One STEP = one batch through cmr_agent_amd.train.GeoUpdate: (prologue,) train-mode forward on the HIP tape, focal + focal + circle
+    loss, backward into the flat gradient bucket, ONE RCCL all-reduce of it (N > 1), value clipping + fused Adam."""
     from cmr_agent_amd.train import GeoUpdate
     dev, ranks, world = ctx or setup_ranks(args)
     dtype = args.dtype or "f32"
     ops.CONV_BF16 = dtype == "bf16"
-    cfg = KittiConfiguration(device=dev, num_pt=args.num_pt)        # --num-pt 65536 = BASELINE.json configs[4]
-    B = cfg.train_batch_size
+    kw = {}
+    if getattr(args, "img", None):
+        kw["cropped_img_H"], kw["cropped_img_W"] = (int(v) for v in args.img.lower().split("x"))
+    cfg = KittiConfiguration(device=dev, num_pt=args.num_pt, **kw)        # --num-pt 65536 = BASELINE.json configs[4]
+    B, H, W = cfg.train_batch_size, cfg.cropped_img_H, cfg.cropped_img_W
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
     model = MultiHeadModel(cfg)
     load_checked(model, hashfill.make_state_dict(spec["geo"], GEO_TAG))
     model = model.to(dev)
     up = GeoUpdate(model, cfg, dist=ranks.dist)
-    batch = synthetic.make_batch(B, cfg.num_pt, cfg.cropped_img_H, cfg.cropped_img_W, cfg.num_node, hip_fps(dev), hip_nearest(dev),
+    batch = synthetic.make_batch(B, cfg.num_pt, H, W, cfg.num_node, hip_fps(dev), hip_nearest(dev),
                                  seed=ranks.shard_seed(cfg.seed), n_circle=512, device=dev)
+    prologue = GeoPrologue(B, cfg.num_pt, cfg.num_node, dev) if getattr(args, "prologue", False) else None
+    if prologue is not None:
+        prologue(batch)
     info = dist_info(ranks, args)
     with CallTimer() as ct:                 # eager, before the graph is captured: every C-ABI call of one step with its work
+        if prologue is not None:
+            prologue(batch)
         up.step(batch)
         torch.cuda.synchronize()
     if not args.eager:
         up.enable_graph(batch)          # forward + backward replayed from a hipGraph; all-reduce and Adam launched per step
     for _ in range(args.warmup):
-        up.step(batch)
+        up.step(batch if prologue is None else prologue(batch))
     ranks.barrier()
-    ar_ms, t0 = 0.0, time.perf_counter()
+    ar_ms, pro_ms, t0 = 0.0, 0.0, time.perf_counter()
     for _ in range(args.steps):
-        losses = up.step(batch)
-        if world > 1:
+        losses = up.step(batch if prologue is None else prologue(batch))
+        if ranks.dist is not None:
             ar_ms += up.allreduce_ms()
+        if prologue is not None:
+            pro_ms += prologue.ms()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     loss = float(losses["loss"])
@@ -375,22 +423,32 @@ def geo_train_main(args, ctx=None, with_cpu=False):
         table = ct.table()
         dom = max((d for d in table if d["modelled"]), key=lambda d: d["ms"])
         line = {
-            "metric": "geometric-model update pairs/sec (Train_Geo.py step at the KittiConfig training shape)",
+            "metric": "geometric-model update pairs/sec (Train_Geo.py step, %dx%d image, %d points%s)" % (
+                H, W, cfg.num_pt, ", node sampling + nearest node + ball query on the device inside the step" if prologue is not None else ""),
             "value": world * B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": "MultiHeadModel update: batch of %d pairs (160x512 image, %d points, %d nodes) per GPU, focal + focal + "
-                                   "circle loss, dropout 0.1 at the reference's sites, clip_grad_value_ 1, Adam (lr 1e-3, betas .9/.99, wd 1e-6)" % (B, cfg.num_pt, cfg.num_node),
+            "config": {"workload": "MultiHeadModel update: batch of %d pairs (%dx%d image, %d points, %d nodes) per GPU, focal + focal + "
+                                   "circle loss, dropout 0.1 at the reference's sites, clip_grad_value_ 1, Adam (lr 1e-3, betas .9/.99, wd 1e-6)%s"
+                                   % (B, H, W, cfg.num_pt, cfg.num_node,
+                                      "; per step, timed: farthest-point sampling of the %d nodes over all %d points of each cloud, nearest node of "
+                                      "every point, query_ball_point(radius 2, 32 samples) around the nodes (SURVEY.md 8d C5)" % (cfg.num_node, cfg.num_pt)
+                                      if prologue is not None else ""),
                        "batch_per_gpu": B,
                        "parallelism": "data parallel: one flat-bucket RCCL all-reduce (%d floats) per optimizer step" % up.bucket.numel},
-            "allreduce_ms_per_step": ar_ms / args.steps if world > 1 else 0.0,
+            "allreduce_ms_per_step": ar_ms / args.steps if ranks.dist is not None else 0.0,
             "launches_per_step": sum(d["calls"] for d in table),
             "roofline": train_roofline(table, 1, [("%s (the entry point with the largest summed time of the step)" % dom["name"],
                                                    (dom["name"],), FP32_MFMA_PEAK_TFLOPS)]),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
             "loss": loss, **info}
+        if prologue is not None:
+            line["prologue_ms"] = pro_ms / args.steps
+            line["prologue"] = "HIP events around planar_to_rows + fps + gather + nearest + ball_query + transpose of every timed step (inside ms_per_step)"
         if with_cpu and world == 1:
-            line["cpu_baseline"] = geo_update_cpu_baseline(spec, cfg.num_pt, B)
+            line["cpu_baseline"] = geo_update_cpu_baseline(spec, cfg.num_pt, B, H, W)
+    del up, model, batch
+    torch.cuda.empty_cache()
     return line
 
 
@@ -442,61 +500,13 @@ def iter_main(args, ctx=None):
     return line
 
 
-def compact(line):
-    """sub-object of the default line for a secondary configuration (BASELINE.json configs[2] / configs[4] at 1 GPU)."""
-    r = line["roofline"]
-    out = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in line}
-    out["workload"] = line["config"]["workload"]
-    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "path", "traffic",
-                                         "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
-                                         "families_ms_per_step", "flop_per_byte") if k in r}
-    for k in ("cpu_baseline", "launches_per_step", "launch_mode"):
-        if k in line:
-            out[k] = line[k]
-    return out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--mode", choices=("register", "train", "train-geo", "iter"), default="register",
-                    help="register (default): the headline registration iteration; train: the agent's minibatch update; "
-                         "train-geo: the geometric model's training step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-lines", action="store_true", help="register mode at 1 GPU: skip the `train` / `train_geo` sub-objects "
-                    "(BASELINE.json configs[2] / configs[4] at 1 GPU) of the default line")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
-    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
-                    help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
-    ap.add_argument("--num-pt", type=int, default=None, help="train-geo: points per cloud (default KittiConfig's 40960; configs[4] = 65536)")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
-    ap.add_argument("--no-alone-pass", action="store_true", help="skip the second (untimed) eager pass with every branch on ONE stream, which "
-                    "adds roofline.frac_alone / path_alone / kernels_alone: each kernel's duration alone on the device (the first pass times a "
-                    "side-stream call from its launch, including its wait for the CUs the concurrent convolutions hold)")
-    ap.add_argument("--pipeline", action="store_true", help="register mode: two-stage software pipeline over consecutive batches in one "
-                    "hipGraph (geo forward of batch i concurrently with the agent loop of batch i - 1; cmr_agent_amd/runtime.py)")
-    ap.add_argument("--no-pipeline-line", action="store_true", help="skip the `pipelined` sub-object (second measurement of the same steps)")
-    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI (default); gloo: host "
-                    "collectives on device tensors, for --share-gpu rehearsals")
-    ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0 (one-GPU box): exercises launcher, barrier / MAX "
-                    "protocol and the bucket all-reduce on real HIP gradients; needs --dist-backend gloo")
-    args = ap.parse_args()
-    if args.mode != "register":
-        fn = {"train": train_main, "train-geo": geo_train_main, "iter": iter_main}[args.mode]
-        ctx = setup_ranks(args)
-        line = fn(args, ctx, with_cpu=not args.no_cpu_baseline) if args.mode != "iter" else iter_main(args, ctx)
-        if line is not None:
-            print(json.dumps(line), flush=True)
-        ctx[1].close()
-        return
-
-    dev, ranks, world = setup_ranks(args)          # RCCL: timing barrier / MAX only, no data-path collective
+def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipeline=True, with_alone=True):
+    """The registration iteration of one workload (WORKLOADS) -> the JSON line (rank 0; None elsewhere)."""
+    dev, ranks, world = ctx
     rank = ranks.rank
 
-    w = WORKLOADS[args.workload]
-    dtype = args.dtype or w["dtype"]
+    w = WORKLOADS[workload]
+    dtype = dtype or w["dtype"]
     ops.CONV_BF16 = dtype == "bf16"
     Cfg = NuScenesConfiguration if w["cfg"] == "nuscenes" else KittiConfiguration
     cfg = Cfg(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
@@ -529,7 +539,7 @@ def main():
         # the agent loop of batch i - 1, one hipGraph): a throughput mode, reported BESIDE the headline (whose step is one batch's
         # geo forward + agent loop back to back)
         pipe = None
-        if not args.eager and not args.pipeline and not args.no_pipeline_line:
+        if not args.eager and not args.pipeline and with_pipeline:
             rgp = PipelinedRegistrationGraph(geo, agent, cfg, batch)
             for _ in range(args.warmup):
                 rgp.run().cpu()
@@ -547,7 +557,7 @@ def main():
         # the same pass with every branch on ONE stream: each kernel's duration alone on the device (the pass above times a side-stream
         # kernel from its launch to its end, including the time it waits for CUs the concurrent convolution holds)
         ct1 = None
-        if not args.no_alone_pass and not args.eager:
+        if with_alone and not args.eager:
             from cmr_agent_amd.utils import streams
             streams.ENABLED = False
             try:
@@ -637,7 +647,9 @@ def main():
                             achieved=issued, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=issued / FP32_MFMA_PEAK_TFLOPS,
                             basis="issued MFMA work (16/36 of the algorithmic multiplies)",
                             achieved_algorithmic=achieved, frac_algorithmic=achieved / FP32_MFMA_PEAK_TFLOPS,
-                            traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src, **common)
+                            traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src,
+                            traffic_source="committed profile (the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command kept under "
+                                           "profiles/), not a counter read in this run", **common)
         line = {
             "metric": "registration iters/sec (%s %dx%d img + %d pts, 1 geo forward + %d agent steps)" % (
                 "KITTI" if w["cfg"] == "kitti" else "nuScenes", w["H"], w["W"], w["N"], w["steps"]),
@@ -658,25 +670,111 @@ def main():
                                          "step = geo forward of batch i on one stream || the 10 agent steps of batch i - 1 on another; per "
                                          "replay the device does one geo forward + one agent loop.  Throughput mode (a batch's latency is "
                                          "not shorter); NOT the headline value"}
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c1":
+        if world == 1 and with_cpu and workload == "c1":
             line["cpu_baseline"] = cpu_baseline(spec)
+    del geo, agent, batch, run_step
+    if not args.eager:
+        del rg
+    torch.cuda.empty_cache()
+    return line
+
+
+def compact(line):
+    """sub-object of the default line for a secondary configuration (BASELINE.json configs[2] / configs[4] at 1 GPU)."""
+    r = line["roofline"]
+    out = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in line}
+    out["workload"] = line["config"]["workload"]
+    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "path", "path_step", "path_modelled_share_of_kernel_time", "traffic",
+                                         "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
+                                         "families_ms_per_step", "flop_per_byte") if k in r}
+    for k in ("cpu_baseline", "launches_per_step", "launch_mode", "prologue_ms", "prologue", "allreduce_ms_per_step", "rccl_ranks", "rccl_version",
+              "rccl_note", "collective_ranks", "per_gpu", "agent_steps_per_s"):
+        if k in line:
+            out[k] = line[k]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--mode", choices=("register", "train", "train-geo", "iter"), default="register",
+                    help="register (default): the headline registration iteration; train: the agent's minibatch update; "
+                         "train-geo: the geometric model's training step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-lines", action="store_true", help="register mode at 1 GPU: skip the `train` / `train_geo` sub-objects "
+                    "(BASELINE.json configs[2] / configs[4] at 1 GPU) of the default line")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default=None,
+                    help="bf16: stride-1 3x3 convolutions on the bf16 matrix cores (fp32 accumulate, fp32 storage); default per workload")
+    ap.add_argument("--num-pt", type=int, default=None, help="train-geo: points per cloud (default KittiConfig's 40960; configs[4] = 65536)")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying the hipGraph")
+    ap.add_argument("--no-alone-pass", action="store_true", help="skip the second (untimed) eager pass with every branch on ONE stream, which "
+                    "adds roofline.frac_alone / path_alone / kernels_alone: each kernel's duration alone on the device (the first pass times a "
+                    "side-stream call from its launch, including its wait for the CUs the concurrent convolutions hold)")
+    ap.add_argument("--pipeline", action="store_true", help="register mode: two-stage software pipeline over consecutive batches in one "
+                    "hipGraph (geo forward of batch i concurrently with the agent loop of batch i - 1; cmr_agent_amd/runtime.py)")
+    ap.add_argument("--no-pipeline-line", action="store_true", help="skip the `pipelined` sub-object (second measurement of the same steps)")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl", help="nccl = RCCL over xGMI (default); gloo: host "
+                    "collectives on device tensors, for --share-gpu rehearsals")
+    ap.add_argument("--force-dist", action="store_true", help="world size 1: initialise the process group anyway (RCCL with one rank), so that "
+                    "the training modes execute their all-reduce; the default line does this for its train / train_geo sub-objects")
+    ap.add_argument("--no-force-dist", action="store_true", help="default line: do not bring RCCL up at world size 1 for the training sub-objects")
+    ap.add_argument("--img", default=None, help="train-geo: image crop HxW (default KittiConfig's 160x512; SURVEY.md 8d C5 = 352x1216)")
+    ap.add_argument("--prologue", action="store_true", help="train-geo: node sampling (FPS over all points), nearest node and a ball query on the "
+                    "device inside every timed step (SURVEY.md 8d C5), reported as prologue_ms")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0 (one-GPU box): exercises launcher, barrier / MAX "
+                    "protocol and the bucket all-reduce on real HIP gradients; needs --dist-backend gloo")
+    args = ap.parse_args()
+    if args.mode != "register":
+        fn = {"train": train_main, "train-geo": geo_train_main, "iter": iter_main}[args.mode]
+        ctx = setup_ranks(args)
+        line = fn(args, ctx, with_cpu=not args.no_cpu_baseline) if args.mode != "iter" else iter_main(args, ctx)
+        if line is not None:
+            print(json.dumps(line), flush=True)
+        ctx[1].close()
+        return
+
+    ctx = setup_ranks(args)          # RCCL: timing barrier / MAX only, no data-path collective
+    dev, ranks, world = ctx
+    rank = ranks.rank
+    line = register_main(args, ctx, args.workload, args.dtype, with_cpu=not args.no_cpu_baseline, with_pipeline=not args.no_pipeline_line,
+                         with_alone=not args.no_alone_pass)
     if world == 1 and args.workload == "c1" and not args.no_train_lines and args.dtype is None:
-        # BASELINE.json configs[2] (per-GPU bf16 agent update) and configs[4] (Train_Geo step at 65 536 points) at 1 GPU, each with
-        # its own roofline and CPU baseline, folded into the default line so that the driver's record carries them
-        del geo, agent, batch
-        if not args.eager:
-            del rg, run_step
-        torch.cuda.empty_cache()
+        # The other BASELINE.json configurations at 1 GPU, each with its own roofline, folded into the default line so that the driver's
+        # record carries them: configs[3] (`c3`: nuScenes shape, bf16), configs[2] (`train`: per-GPU bf16 agent update), configs[4] as
+        # SURVEY.md 8d's C5 (`train_geo`: Train_Geo step at 352x1216 / 65 536 points with the point prologue inside the step) and the same
+        # step at the reference's own training crop (`train_geo_160x512`, round 3's figure).
         sub = argparse.Namespace(**vars(args))
-        sub.steps, sub.warmup, sub.dtype, sub.eager = 10, 3, "bf16", False
-        line["train"] = compact(train_main(sub, (dev, ranks, world), with_cpu=not args.no_cpu_baseline))
+        sub.eager, sub.pipeline = False, False
+        sub.steps, sub.warmup = 5, 2
+        c3 = register_main(sub, ctx, "c3", None, with_cpu=False, with_pipeline=False, with_alone=False)
+        ops.CONV_BF16 = False
+        # the training lines run with a REAL process group at world size 1 (RCCL loads, the communicator comes up on this device, the one
+        # collective of the update executes as a sum over one rank); if that cannot be set up the lines are still measured, without it
+        if ranks.dist is None and args.dist_backend == "nccl" and not args.no_force_dist:
+            try:
+                ranks.force_init()
+            except Exception as e:              # noqa: BLE001 -- reported in the line, never fatal for the measurement
+                line["rccl_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
+        sub.steps, sub.warmup, sub.dtype = 10, 3, "bf16"
+        train = train_main(sub, ctx, with_cpu=not args.no_cpu_baseline)
         ops.CONV_BF16 = False
         torch.cuda.empty_cache()
-        sub.steps, sub.warmup, sub.dtype, sub.num_pt = 5, 2, "f32", 65536
-        line["train_geo"] = compact(geo_train_main(sub, (dev, ranks, world), with_cpu=not args.no_cpu_baseline))
+        sub.steps, sub.warmup, sub.dtype, sub.num_pt, sub.img, sub.prologue = 5, 2, "f32", 65536, "352x1216", True
+        geo5 = geo_train_main(sub, ctx, with_cpu=not args.no_cpu_baseline)
+        sub.img, sub.prologue = None, False
+        geo160 = geo_train_main(sub, ctx, with_cpu=False)
+        if rank == 0:
+            line["c3"] = compact(c3)
+            line["train"] = compact(train)
+            line["train_geo"] = compact(geo5)
+            line["train_geo_160x512"] = compact(geo160)
     if rank == 0:
         print(json.dumps(line), flush=True)
     ranks.close()
+
 
 
 if __name__ == "__main__":

@@ -13,6 +13,10 @@ import torch  # noqa: F401  -- MUST be imported before libcmr_hip.so is loaded: 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "lib", "libcmr_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "cmr_hip.h")
+# the A/B build (-DCMR_AB_SWITCHES): the same entry points + the kernel-variant switches of include/cmr_hip_ab.h.  Tests that compare two
+# kernels bit for bit and tools/*_bench.py load it through ab(); the product never does.
+AB_LIB_PATH = os.path.join(_PKG, "lib", "libcmr_hip_ab.so")
+AB_HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "cmr_hip_ab.h")
 
 _SCALARS = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "hipStream_t": ctypes.c_void_p}
 _RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64}
@@ -22,6 +26,7 @@ def parse_header(path=HEADER_PATH):
     """-> {name: (restype, [argtypes], [argnames])} for every `cmr_*` prototype."""
     text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r'#include\s+"cmr_hip.h"', "", text)
     protos = {}
     for m in re.finditer(r"\b(int|int64_t)\s+(cmr_\w+)\s*\(([^)]*)\)\s*;", text):
         ret, name, args = m.group(1), m.group(2), m.group(3)
@@ -44,28 +49,64 @@ class CmrError(RuntimeError):
 
 _lib = None
 _protos = None
+_ab_lib = None
+
+
+def _bind(path, protos):
+    if not os.path.exists(path):
+        raise CmrError("HIP library %s is missing -- build it with `make` (or __graft_entry__.build()); "
+                       "cmr_agent_amd has no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    for name, (ret, argtypes, _) in protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise CmrError("%s does not export %s (declared in its header)" % (os.path.basename(path), name))
+        fn.restype = ret
+        fn.argtypes = argtypes
+    return lib
 
 
 def load():
     global _lib, _protos
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise CmrError("HIP library %s is missing -- build it with `make` (or __graft_entry__.build()); "
-                       "cmr_agent_amd has no CPU fallback" % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
     _protos = parse_header()
-    for name, (ret, argtypes, _) in _protos.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError:
-            raise CmrError("libcmr_hip.so does not export %s (declared in include/cmr_hip.h)" % name)
-        fn.restype = ret
-        fn.argtypes = argtypes
-    _lib = lib
-    if os.environ.get("CMR_B16_MM") == "0":             # A/B measurements: the two-team bf16 convolution for every layer
-        lib.cmr_set_conv_bf16_variant(0, 0)
-    return lib
+    _lib = _bind(LIB_PATH, _protos)
+    return _lib
+
+
+def load_ab():
+    """The A/B library (every entry point of the product + the cmr_set_* switches)."""
+    global _ab_lib
+    if _ab_lib is None:
+        load()
+        protos = dict(_protos)
+        protos.update(parse_header(AB_HEADER_PATH))
+        _ab_lib = _bind(AB_LIB_PATH, protos)
+    return _ab_lib
+
+
+def use_ab():
+    """tools/*_bench.py: switch this process to the A/B library for good (every later ops.* call and load() return it)."""
+    global _lib
+    _lib = load_ab()
+    return _lib
+
+
+class ab:
+    """with _lib.ab() as lib: every ops.* call inside goes to libcmr_hip_ab.so, whose switches `lib.cmr_set_*` select kernel variants
+    (tests / tools only).  Same kernels, same results as the product library under the default settings."""
+
+    def __enter__(self):
+        global _lib
+        self.old = load()
+        _lib = load_ab()
+        return _lib
+
+    def __exit__(self, *a):
+        global _lib
+        _lib = self.old
 
 
 def prototypes():

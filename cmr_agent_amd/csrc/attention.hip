@@ -448,13 +448,17 @@ __global__ __launch_bounds__(256) void la_apply_kernel(const float* __restrict__
 
 }  // namespace
 
-static int CMR_MHA_KEY_CHUNK = MHA_KCH;   // keys staged per chunk (env CMR_MHA_KEY_CHUNK at first use: A/B measurements)
+#ifdef CMR_AB_SWITCHES          // A/B build only (libcmr_hip_ab.so): the product library dispatches by constants
+static int CMR_MHA_KEY_CHUNK = MHA_KCH;   // keys staged per chunk (env CMR_MHA_KEY_CHUNK at first use)
 static int CMR_MHA_MFMA = 1;     // 1 = matrix-core kernel (default), 0 = the one-query-per-lane-group VALU kernel
 extern "C" int cmr_set_mha_variant(int mfma) {
   const int old = CMR_MHA_MFMA;
   CMR_MHA_MFMA = mfma;
   return old;
 }
+#else
+static constexpr int CMR_MHA_KEY_CHUNK = MHA_KCH, CMR_MHA_MFMA = 1;
+#endif
 
 static int mha_launch(bool libm_exp, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                            float* o, int64_t ldo, int B, int Tq, int Tk, hipStream_t stream) {
@@ -462,8 +466,10 @@ static int mha_launch(bool libm_exp, const float* q, int64_t ldq, const float* k
   CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0);
   CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(o));
   if (CMR_MHA_MFMA) {
+#ifdef CMR_AB_SWITCHES
     static const bool kch_env = [] { const char* e = getenv("CMR_MHA_KEY_CHUNK"); if (e && atoi(e) >= 32) CMR_MHA_KEY_CHUNK = atoi(e) / 32 * 32; return true; }();
     (void)kch_env;
+#endif
     const int Tkp = (Tk + 31) / 32 * 32;
     const int Tcp = Tkp < CMR_MHA_KEY_CHUNK ? Tkp : CMR_MHA_KEY_CHUNK;      // chunk length (the last chunk may be shorter)
     const size_t smem = (size_t)Tcp * (DH + 9) * sizeof(float);

@@ -17,7 +17,6 @@
 #include "cmr_common.h"
 #include <type_traits>
 
-extern int cmr_conv_cu_budget;      // conv_wino.hip: CUs the persistent convolution kernels may occupy (0 = all)
 
 namespace {
 
@@ -38,6 +37,7 @@ struct B16Args {
                          // writes the bf16 values that one would round its fp32 input to anyway -- same results, half the bytes
   int res_bf16;          // the residual operand is a bf16 NHWC map (bf16-STORED towers: the block input of a ResidualBlock, round 3)
   int wnt;               // cout tiles per group in the fragment layout of wfrag (the matrix-class kernel walks it by 32-cout tile)
+  int cu_budget;         // host only: CUs the persistent kernels may occupy (0 = all); an argument of the entry points
 };
 
 __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -625,7 +625,7 @@ int launch_tt_p(B16Args a, hipStream_t stream) {
   a.tiles_y = ((a.H - 1) / S + 1 + TH - 1) / TH;
   const int ngroups = a.Cout / (32 * NT);
   const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
-  const int cus = cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < 256 ? cmr_conv_cu_budget - cmr_conv_cu_budget % 8 : 256;
+  const int cus = a.cu_budget >= 8 && a.cu_budget < 256 ? a.cu_budget - a.cu_budget % 8 : 256;
   int per_group = cus / ngroups;                       // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > (nsp + 1) / 2) per_group = (int)((nsp + 1) / 2);      // a workgroup has two teams
@@ -921,7 +921,7 @@ int launch_mm_p(B16Args a, hipStream_t stream) {
   a.bias_mul = a.bias ? 1 : 0;
   const int ngroups = a.Cout / 128;
   const int64_t nsp = (int64_t)a.B * a.tiles_x * a.tiles_y;
-  const int cus = cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < 256 ? cmr_conv_cu_budget - cmr_conv_cu_budget % 8 : 256;
+  const int cus = a.cu_budget >= 8 && a.cu_budget < 256 ? a.cu_budget - a.cu_budget % 8 : 256;
   int per_group = cus / ngroups;                        // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > nsp) per_group = (int)nsp;
@@ -950,7 +950,8 @@ int launch_mm(const B16Args& a, hipStream_t stream) {
 
 }  // namespace
 
-static int CMR_B16_MM = 1;             // matrix-class kernel for the 128-cout layers (cmr_set_conv_bf16_variant: A/B measurements)
+#ifdef CMR_AB_SWITCHES
+static int CMR_B16_MM = 1;             // matrix-class kernel for the 128-cout layers (cmr_set_conv_bf16_variant: A/B measurements, libcmr_hip_ab.so only)
 static int CMR_B16_MM_MIN_TILES = 128;
 extern "C" int cmr_set_conv_bf16_variant(int matrix_class, int min_tiles) {
   CMR_REQUIRE(matrix_class == 0 || matrix_class == 1);
@@ -958,17 +959,20 @@ extern "C" int cmr_set_conv_bf16_variant(int matrix_class, int min_tiles) {
   if (min_tiles > 0) CMR_B16_MM_MIN_TILES = min_tiles;
   return CMR_OK;
 }
+#else
+static constexpr int CMR_B16_MM = 1, CMR_B16_MM_MIN_TILES = 128;
+#endif
 
 static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                                  const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope, int pool,
-                                 hipStream_t stream) {
+                                 int cu_budget, hipStream_t stream) {
   CMR_REQUIRE(x && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0 && (stride == 1 || stride == 2));
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(wfrag) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) && (!res || cmr_aligned16(res)) &&
               (!post || cmr_aligned16(post)));
   CMR_REQUIRE(pool == 1 || (pool == 2 && !res && !post && H % 2 == 0 && W % 2 == 0));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
   B16Args a{static_cast<const float*>(x), B, H, W, wfrag, bias, static_cast<const float*>(res), post, static_cast<float*>(y), Cout, slope, pool,
-            0, 0, 0, 0, x_bf16, y_bf16, res && res_bf16 ? 1 : 0, nt};
+            0, 0, 0, 0, x_bf16, y_bf16, res && res_bf16 ? 1 : 0, nt, cu_budget};
   if (stride == 2) {
     if (pool != 1) return CMR_EINVAL;
     if (a.res_bf16) return CMR_EUNSUPPORTED;
@@ -997,12 +1001,12 @@ static int conv3x3_bf16_dispatch(const void* x, int x_bf16, int B, int H, int W,
 
 extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                                          const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
-                                         hipStream_t stream) {
-  return conv3x3_bf16_dispatch(x, 0, B, H, W, Cin, wfrag, nt, bias, res, 0, post, y, 0, Cout, stride, slope, pool, stream);
+                                         int cu_budget, hipStream_t stream) {
+  return conv3x3_bf16_dispatch(x, 0, B, H, W, Cin, wfrag, nt, bias, res, 0, post, y, 0, Cout, stride, slope, pool, cu_budget, stream);
 }
 
 extern "C" int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                                        const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope,
-                                       int pool, hipStream_t stream) {
-  return conv3x3_bf16_dispatch(x, x_bf16, B, H, W, Cin, wfrag, nt, bias, res, res_bf16, post, y, y_bf16, Cout, stride, slope, pool, stream);
+                                       int pool, int cu_budget, hipStream_t stream) {
+  return conv3x3_bf16_dispatch(x, x_bf16, B, H, W, Cin, wfrag, nt, bias, res, res_bf16, post, y, y_bf16, Cout, stride, slope, pool, cu_budget, stream);
 }

@@ -20,8 +20,6 @@
 // Y[a][b] = sum_i A^T[a][i] T[i][b] for register quad q (4 consecutive channels -> float4 stores).
 #include "cmr_common.h"
 
-extern int cmr_conv_cu_budget;
-extern int cmr_conv_slices;
 
 namespace {
 
@@ -774,7 +772,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #define CMR_WS_DBG 0
 #endif
 template <int DBG>
-int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
+int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, int cu_budget, int slices, hipStream_t stream) {
   constexpr int smem = WS_SMEM_FLOATS * (int)sizeof(float);
   static CmrSmemCache granted{};
   if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel<DBG>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
@@ -783,13 +781,14 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
   }
-  if (cmr_conv_cu_budget > 0 && cmr_conv_cu_budget < cus) cus = cmr_conv_cu_budget;
+  if (cu_budget > 0 && cu_budget < cus) cus = cu_budget;
+  if (cus < 8) cus = 8;
   cus -= cus % 8;                                          // a multiple of the XCD count keeps a workgroup's tiles on one XCD's band
-  // time slicing (cmr_set_conv_slices): n x as many workgroups, each walking 1 / n of the tiles -- a CU is handed back to the dispatcher
+  // time slicing (`slices` argument): n x as many workgroups, each walking 1 / n of the tiles -- a CU is handed back to the dispatcher
   // n times per launch, so a branch on another stream is served in between instead of after the launch; never below 8 tiles per workgroup
   int64_t want = cus;
-  if (cmr_conv_slices > 1) {
-    int sl = cmr_conv_slices;
+  if (slices > 1) {
+    int sl = slices > 64 ? 64 : slices;
     while (sl > 1 && ntiles / ((int64_t)cus * sl) < 8) --sl;
     want = (int64_t)cus * sl;
   }
@@ -797,11 +796,11 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
   hipLaunchKernelGGL(conv3x3_wino_ws_kernel<DBG>, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
   return cmr_launch_status();
 }
-int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hipStream_t stream) {
+int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, int cu_budget, int slices, hipStream_t stream) {
   // DBG bits (compile-time ablations used while tuning: 1 no stores, 2 no epilogue, 4 no T hand-over, 8 no U loads, 16 no LDS
   // prefetch, 32 no MFMAs, 128 every tile stored over the same few tiles (stores without HBM write traffic), 64 s_memtime stamps of busy / barrier-wait cycles per wave into the buffer passed as `post`) are not
   // instantiated in the shipped library: tools/ab_build.sh cmr_agent_amd/csrc/conv_wino.hip <tag> -DCMR_WS_DBG=<mask>
-  return launch_wino_ws_t<CMR_WS_DBG>(a, tiles_x, tiles_y, ntiles, stream);
+  return launch_wino_ws_t<CMR_WS_DBG>(a, tiles_x, tiles_y, ntiles, cu_budget, slices, stream);
 }
 
 template <int NT>
@@ -815,34 +814,25 @@ int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hip
 
 }  // namespace
 
-// CUs the PERSISTENT convolution kernels (wave-specialised Winograd here, the two-team bf16 kernel in conv_bf16.hip) may occupy; 0 = all.
-// Those kernels fill a CU completely (registers), so a concurrent branch on another stream only runs between their launches; a caller
-// that forks such a branch (the point tower beside the image tower) leaves it a few CUs for the duration.
-__attribute__((visibility("hidden"))) int cmr_conv_cu_budget = 0;
-extern "C" int cmr_set_conv_cu_budget(int cus) {
-  const int old = cmr_conv_cu_budget;
-  cmr_conv_cu_budget = cus < 0 ? 0 : cus;
-  return old;
-}
-
-// Workgroups per CU the persistent Winograd kernel is split into (1 = one workgroup per CU walks all of the CU's tiles).
-__attribute__((visibility("hidden"))) int cmr_conv_slices = 1;
-extern "C" int cmr_set_conv_slices(int slices) {
-  const int old = cmr_conv_slices;
-  cmr_conv_slices = slices < 1 ? 1 : (slices > 64 ? 64 : slices);
-  return old;
-}
-
-static int CMR_WINO_WS = 1;      // wave-specialised persistent kernel for large maps (cmr_set_wino_variant: A/B measurements)
+// cu_budget: CUs the PERSISTENT kernel (wave-specialised Winograd here, the two-team / matrix-class bf16 kernels in conv_bf16.hip) may
+// occupy; 0 = all.  Those kernels fill a CU completely (registers), so a concurrent branch on another stream only runs between their
+// launches; a caller that forks such a branch (the point tower beside the image tower) leaves it a few CUs for the duration.
+// slices: workgroups per CU the persistent Winograd kernel is split into (<= 1: one workgroup per CU walks all of the CU's tiles).
+// Both are ARGUMENTS of the call: the library keeps no launch policy of its own (round 3 had process-global setters here).
+#ifdef CMR_AB_SWITCHES
+static int CMR_WINO_WS = 1;      // wave-specialised persistent kernel for large maps (cmr_set_wino_variant: A/B measurements, libcmr_hip_ab.so only)
 extern "C" int cmr_set_wino_variant(int wave_specialised) {
   const int old = CMR_WINO_WS;
   CMR_WINO_WS = wave_specialised & 1;
   return old;
 }
+#else
+static constexpr int CMR_WINO_WS = 1;
+#endif
 
 extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                                          const float* res, const float* post, float* y, int Cout, float slope, int pool,
-                                         hipStream_t stream) {
+                                         int cu_budget, int slices, hipStream_t stream) {
   CMR_REQUIRE(x && u && y && B > 0 && H > 0 && W > 0 && Cin % 32 == 0 && Cin >= 32 && Cout % 64 == 0 && Cout >= 64);
   CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(u) && cmr_aligned16(y) && (!bias || cmr_aligned16(bias)) &&
               (!res || cmr_aligned16(res)) && (!post || cmr_aligned16(post)));
@@ -853,7 +843,7 @@ extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, in
   // take 32-cout workgroups, twice as many and three per CU
   const int64_t ntiles64 = (int64_t)tiles_x * tiles_y * B * (Cout / 64);
   CMR_REQUIRE(2 * ntiles64 < 0x7fffffff);
-  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 200 && slope >= 0.f && slope <= 1.f) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, stream);
+  if (CMR_WINO_WS && Cin >= 64 && ntiles64 >= 200 && slope >= 0.f && slope <= 1.f) return launch_wino_ws(a, tiles_x, tiles_y, ntiles64, cu_budget, slices, stream);
   if (ntiles64 >= 512) return launch_wino<2>(a, tiles_x, tiles_y, ntiles64, stream);
   return launch_wino<1>(a, tiles_x, tiles_y, 2 * ntiles64, stream);
 }

@@ -822,7 +822,10 @@ int launch_linear_wreg(const LinearArgs& a, hipStream_t stream) {
   return launch_linear_wreg_a<NT, 0>(a, stream);
 }
 
-static int g_linear_wreg = 1;            // register-weights kernel for K = 64 row maps (cmr_set_linear_wreg: A/B measurements, tests)
+// Kernel-variant switches exist only in the A/B build (-DCMR_AB_SWITCHES -> cmr_agent_amd/lib/libcmr_hip_ab.so, include/cmr_hip_ab.h: tests
+// that compare variants bit for bit, tools/*_bench.py); the product library has no mutable state: the dispatch below is a constant.
+#ifdef CMR_AB_SWITCHES
+static int g_linear_wreg = 1;            // register-weights kernel for K = 64 row maps
 static int64_t g_linear_wreg_min_rows = 65537;
 extern "C" int cmr_set_linear_wreg(int on, int64_t min_rows) {
   const int old = g_linear_wreg;
@@ -832,12 +835,16 @@ extern "C" int cmr_set_linear_wreg(int on, int64_t min_rows) {
 }
 
 static int g_linear_row64 = 1;
-// A/B switch for benchmarks and tests (1 = use the row-streaming fast path where it applies; default): returns the previous value.
+// 1 = use the row-streaming fast path where it applies (default): returns the previous value.
 extern "C" int cmr_set_linear_row64(int on) {
   const int old = g_linear_row64;
   g_linear_row64 = on ? 1 : 0;
   return old;
 }
+#else
+static constexpr int g_linear_wreg = 1, g_linear_row64 = 1;
+static constexpr int64_t g_linear_wreg_min_rows = 65537;
+#endif
 
 extern "C" int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_t ld2, int k2,
                               const int32_t* idx2, int64_t div2, const float* w, int64_t ldw, const float* bias,

@@ -891,7 +891,11 @@ inline int wgrad_slices(int64_t work_items) {
 
 // persistent workgroups of the LDS-staged kernel per cout tile, and rows per column strip
 struct WgLdsPlan { int use, groups, rps; };
+#ifdef CMR_AB_SWITCHES          // variant switches: A/B build only (libcmr_hip_ab.so)
 static int g_wgrad_lds = 1;
+#else
+static constexpr int g_wgrad_lds = 1;
+#endif
 inline WgLdsPlan wgrad_lds_plan(int B, int H, int W, int Cin, int Cout) {
   WgLdsPlan p{0, 0, 0};
   // Measured (tools/wgrad_bench.py, profiles/r03_wgrad_bench.txt; minibatch 10, 128 -> 128): 44x152 263 -> 227 us, 22x76 111 -> 87 us,
@@ -912,9 +916,14 @@ inline WgLdsPlan wgrad_lds_plan(int B, int H, int W, int Cin, int Cout) {
   return p;
 }
 
+#ifdef CMR_AB_SWITCHES
 static int g_lwgrad_lds = 1;
+#else
+static constexpr int g_lwgrad_lds = 1;
+#endif
 // Measured (tools/lwgrad_bench.py, profiles/r03_lwgrad_bench.txt): 524 288 rows 64x64 122 -> 84 us, 128x64 218 -> 129 us; 163 840 rows 5-20 %
 // faster; at 40 960 rows and below the direct kernel's finer slices win (31 vs 38 us): the staged kernel takes maps of >= 65 536 rows.
+#ifdef CMR_AB_SWITCHES
 static int64_t g_lwgrad_min_rows = 65536;
 extern "C" int cmr_set_linear_wgrad_variant(int lds_staged) {
   const int old = g_lwgrad_lds;
@@ -928,6 +937,9 @@ extern "C" int cmr_set_wgrad_variant(int lds_staged) {
   g_wgrad_lds = lds_staged ? 1 : 0;
   return old;
 }
+#else
+static constexpr int64_t g_lwgrad_min_rows = 65536;
+#endif
 
 extern "C" int64_t cmr_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
   const int nci = Cin / 32;

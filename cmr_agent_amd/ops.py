@@ -138,30 +138,47 @@ TOWER_CU_BUDGET_F32 = 0  # the same for the fp32 Winograd kernels: matrix-bound,
 TOWER_SLICES_F32 = int(os.environ.get("CMR_TOWER_SLICES", "1"))     # fp32: workgroups per CU of the image tower's Winograd launches while the point tower runs beside it
 
 
+# Launch policy of the persistent convolution kernels: ARGUMENTS of every call (the library keeps no state); the host side keeps the current
+# values per thread, set for the extent of a `with` block by the code that forks a concurrent branch.
+import threading
+
+_policy = threading.local()
+
+
+def _cu_budget():
+    return getattr(_policy, "cu_budget", 0)
+
+
+def _slices():
+    return getattr(_policy, "slices", 1)
+
+
 class conv_slices:
-    """with conv_slices(n): the persistent Winograd launches inside are split into n workgroups per CU (cmr_set_conv_slices)."""
+    """with conv_slices(n): the persistent Winograd launches inside are split into n workgroups per CU (`slices` argument of
+    cmr_conv3x3_wino_nhwc_f32)."""
 
     def __init__(self, n):
-        self.n = int(n)
+        self.n = max(1, int(n))
 
     def __enter__(self):
-        self.old = _lib.load().cmr_set_conv_slices(self.n)
+        self.old, _policy.slices = _slices(), self.n
 
     def __exit__(self, *a):
-        _lib.load().cmr_set_conv_slices(self.old)
+        _policy.slices = self.old
 
 
 class conv_cu_budget:
-    """with conv_cu_budget(n): the persistent convolution kernels launched inside occupy at most n CUs (cmr_set_conv_cu_budget)."""
+    """with conv_cu_budget(n): the persistent convolution kernels launched inside occupy at most n CUs (`cu_budget` argument of the
+    convolution entry points; 0 = all)."""
 
     def __init__(self, cus):
-        self.cus = int(cus)
+        self.cus = max(0, int(cus))
 
     def __enter__(self):
-        self.old = _lib.load().cmr_set_conv_cu_budget(self.cus)
+        self.old, _policy.cu_budget = _cu_budget(), self.cus
 
     def __exit__(self, *a):
-        _lib.load().cmr_set_conv_cu_budget(self.old)
+        _policy.cu_budget = self.old
 
 
 def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
@@ -174,7 +191,7 @@ def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     hp, wp = (H // 2, W // 2) if pool == 2 else (H, W)
     y = torch.empty((B, hp, wp, cout), dtype=f32, device=x.device)
     _lib.call("cmr_conv3x3_wino_nhwc_f32", _p(x), B, H, W, cin, _p(u), _p(bias), _p(res), _p(post), _p(y), cout,
-              float(slope), pool, _stream())
+              float(slope), pool, _cu_budget(), _slices(), _stream())
     return y
 
 
@@ -197,10 +214,10 @@ def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, s
         y = torch.empty((B, hp, wp, cout), dtype=torch.bfloat16 if out_bf16 else f32, device=x.device)
         if xb or out_bf16 or rb:
             rc = _lib.call("cmr_conv3x3_bf16io_nhwc", _p(x), int(xb), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), int(rb), _p(post), _p(y),
-                           int(out_bf16), cout, int(stride), float(slope), pool, _stream(), allow_unsupported=True)
+                           int(out_bf16), cout, int(stride), float(slope), pool, _cu_budget(), _stream(), allow_unsupported=True)
         else:
             rc = _lib.call("cmr_conv3x3_bf16_nhwc_f32", _p(x), B, H, W, cin, _p(wf), nt, _p(bias), _p(res), _p(post), _p(y), cout, int(stride),
-                           float(slope), pool, _stream(), allow_unsupported=True)
+                           float(slope), pool, _cu_budget(), _stream(), allow_unsupported=True)
         if rc != _lib.UNSUPPORTED:
             return y
     if xb or rb:

@@ -148,13 +148,10 @@ class PipelinedRegistrationGraph:
     BUDGET = tuple(int(v) for v in __import__("os").environ.get("CMR_PIPE_BUDGET", "0,0").split(","))
 
     def _with_budget(self, cus, fn):
-        from . import _lib
+        from . import ops
         def run():
-            old = _lib.load().cmr_set_conv_cu_budget(cus)
-            try:
+            with ops.conv_cu_budget(cus):
                 return fn()
-            finally:
-                _lib.load().cmr_set_conv_cu_budget(old)
         return run
 
     def _iteration(self):

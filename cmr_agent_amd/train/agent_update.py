@@ -48,6 +48,11 @@ class AgentUpdate:
         self.opt = FlatOptimizer(self.bucket, optimizer or getattr(config, "optimizer", "ADAM"), config.lr if lr is None else lr, betas, eps,
                                  config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0))
         self.last_allreduce_ms = None
+        # bf16 mode (ops.CONV_BF16) only: the data-gradient convolutions of the `fp32_early_dgrads` EARLIEST layers of the 2-D tower (the
+        # last ones of the backward chain: conv b of stage 0, conv a of stage 1, ...) stay on the fp32 kernels; and, for diagnosis
+        # (tools/bf16_grad_cosines.py), the forward / backward halves of an update can be pinned to fp32 separately
+        self.fp32_early_dgrads = 0
+        self.bf16_forward = self.bf16_backward = True
         f = config.embed_dim
         self.f = f
         self.dims3d = [(5, f), (2 * f, f), (2 * f, f), (2 * f, 2 * f)]
@@ -149,6 +154,18 @@ class AgentUpdate:
         ops.linear_bwd_small(x1, dy, w, w.shape[1], w.shape[0], y=y, slope=SLOPE2D, x2=x2, dw=gw, lddw=gw.shape[1], db=bk.g(name + ".bias"),
                              dx1=dx1, dx2=dx2, acc_dx=acc)
 
+    def _dgrad(self, dy, name, c, depth):
+        """data gradient of a 2-D tower convolution = the forward kernel on the transposed / flipped weights; `depth` counts the
+        data-gradient convolutions from the input side (0 = conv b of stage 0)."""
+        mode = ops.CONV_BF16
+        if depth < self.fp32_early_dgrads:
+            ops.CONV_BF16 = False
+        try:
+            w9t, ut = ops.pack_conv3x3(self.bucket.w(name + ".weight"), c, c, transpose=True)
+            return ops.conv3x3(dy, w9t, None, c, 1, 1.0, u=ut)
+        finally:
+            ops.CONV_BF16 = mode
+
     def _backward(self, T, d_outs, B, N):
         bk = self.bucket
         dev = bk.params.device
@@ -174,13 +191,11 @@ class AgentUpdate:
             ph, pw = (2, 2) if s < 3 else (H, W)
             dc = ops.pool_act_bwd(g.contiguous(), st["d"], ph, pw, SLOPE2D)                 # through the pool and conv b's LeakyReLU
             ops.conv3x3_wgrad(st["z"], dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"))
-            w9t, ut = ops.pack_conv3x3(bk.w(st["nb"] + ".weight"), c, c, transpose=True)
-            dz = ops.conv3x3(dc, w9t, None, c, 1, 1.0, u=ut)
+            dz = self._dgrad(dc, st["nb"], c, 2 * s)
             da = self._bn_bwd(dz.view(-1, c), st["z"].view(-1, c), SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
             ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"), db=bk.g(st["na"] + ".bias"))
             if s > 0:
-                w9t, ut = ops.pack_conv3x3(bk.w(st["na"] + ".weight"), c, c, transpose=True)
-                g = ops.conv3x3(da, w9t, None, c, 1, 1.0, u=ut)
+                g = self._dgrad(da, st["na"], c, 2 * s - 1)
         # ---- 3-D branch
         R = B * N
         dg = de3d                                                   # gradient w.r.t. the per-sample max of the current block
@@ -248,7 +263,12 @@ class AgentUpdate:
             s3 = torch.as_strided(st3, (B * N, 8), (8, 1))
         else:
             s3 = ops.planar_to_rows(st3.contiguous(), 8)
-        T, (o_r, o_t, o_v) = self._forward(s2.contiguous(), s3, B, N)
+        mode = ops.CONV_BF16
+        ops.CONV_BF16 = mode and self.bf16_forward
+        try:
+            T, (o_r, o_t, o_v) = self._forward(s2.contiguous(), s3, B, N)
+        finally:
+            ops.CONV_BF16 = mode
         S, dr, dt = cfg.num_steps, ag.degree_r, ag.degree_t
         i64 = lambda t: t.to(torch.int64).contiguous()
         alpha = float(cfg.alpha)
@@ -257,13 +277,17 @@ class AgentUpdate:
             o_r, o_t, o_v, i64(batch["expert_actions_r"]), i64(batch["expert_actions_t"]), i64(batch["action_r"]), i64(batch["action_t"]),
             f32c(batch["action_logprob"], dr + dt) if alpha > 0 else None, f32c(batch["state_value_ref"], 1) if alpha > 0 else None,
             f32c(batch["advantages"], 1) if alpha > 0 else None, dr, dt, S, alpha, cfg.CLIP_EPS, cfg.W_VALUE, cfg.W_ENTROPY, grad_scale)
-        self._backward(T, (d_r, d_t, d_v), B, N)
+        ops.CONV_BF16 = mode and self.bf16_backward
+        try:
+            self._backward(T, (d_r, d_t, d_v), B, N)
+        finally:
+            ops.CONV_BF16 = mode
         return losses, (o_r[:, :dr * S].view(B, dr, S), o_t[:, :dt * S].view(B, dt, S), o_v[:, :1].view(B, 1, 1))
 
     def optimizer_step(self):
         """all-reduce (sum) of the gradient bucket over the ranks, then the fused Adam launch (mean folded into grad_scale)."""
         world = 1
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+        if self.dist is not None and self.dist.is_initialized():         # world 1 only when forced (Ranks.force_init)
             dev = self.bucket.grads.device
             if dev.type == "cuda":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

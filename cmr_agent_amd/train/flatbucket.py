@@ -132,8 +132,10 @@ class FlatBucket:
 
     def all_reduce(self, dist, group=None):
         """Sum the gradient bucket over the ranks: the ONE collective of the training path (RCCL over xGMI on the GPU box,
-        gloo in the CPU tests).  The division by the world size is folded into the Adam kernel (grad_scale)."""
-        if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+        gloo in the CPU tests).  The division by the world size is folded into the Adam kernel (grad_scale).  A process group of ONE
+        rank only exists when the caller forced it (utils/dist.py:Ranks.force_init): the collective then runs as well -- a sum over one
+        rank, the bucket unchanged -- so that the RCCL path executes on a one-GPU box."""
+        if dist is not None and dist.is_initialized():
             dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
             return dist.get_world_size(group)
         return 1

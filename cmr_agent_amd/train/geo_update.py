@@ -297,7 +297,7 @@ class GeoUpdate:
 
     def optimizer_step(self):
         world = 1
-        if self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1:
+        if self.dist is not None and self.dist.is_initialized():         # world 1 only when forced (Ranks.force_init)
             if self.bucket.grads.device.type == "cuda":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

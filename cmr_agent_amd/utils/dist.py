@@ -8,21 +8,54 @@ import torch
 
 
 class Ranks:
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, force=False):
+        """force: initialise the process group even at world size 1 (see force_init)."""
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
         self.device = device
         self.backend = backend or "nccl"
+        self.forced = False
         if self.world > 1:
-            import torch.distributed as dist
-            if not dist.is_initialized():
-                kw = {}
-                if backend == "nccl" and device is not None:
-                    kw["device_id"] = device
-                dist.init_process_group(backend or "nccl", **kw)
-            self.dist = dist
+            self._init()
+        elif force:
+            self.force_init()
+
+    def _init(self, **extra):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            kw = dict(extra)
+            if self.backend == "nccl" and self.device is not None and self.device.type == "cuda":
+                kw["device_id"] = self.device
+            dist.init_process_group(self.backend, **kw)
+        self.dist = dist
+
+    def force_init(self):
+        """World size 1 with a REAL process group: `init_process_group("nccl", world_size=1)` loads librccl, creates the communicator on
+        this rank's device (the `device_id=` path) and makes every collective of the training path execute -- a sum over one rank --
+        instead of being skipped.  Everything about the RCCL leg that a one-GPU box can prove.  Under a launcher the
+        rendezvous comes from its environment; otherwise a private TCP store on 127.0.0.1."""
+        if self.dist is not None:
+            return True
+        if self.world != 1:
+            raise RuntimeError("force_init is for world size 1")
+        extra = {}
+        if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
+            from .launch import free_port
+            extra = dict(init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        self._init(**extra)
+        self.forced = True
+        return True
+
+    def rccl_version(self):
+        """version tuple of the RCCL build behind backend "nccl" (None on a CPU-only torch)."""
+        try:
+            v = torch.cuda.nccl.version()
+            return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+        except Exception:
+            return None
 
     @staticmethod
     def local_device(share_gpu=False):

@@ -44,13 +44,6 @@ int cmr_linear_f32(const float* x1, int64_t ld1, int k1, const float* x2, int64_
                    int64_t div2, const float* w, int64_t ldw, const float* bias, const float* res, int64_t ldres,
                    int64_t res_mod, float* y, int64_t ldy, int64_t rows, int n_out, int act, float act_param,
                    hipStream_t stream);
-/* Debug / benchmark switch: 0 routes the contiguous [rows][64] -> [rows][64 | 32] calls of cmr_linear_f32 through the generic
- * weight-stationary kernel instead of the row-streaming fast path (bit-identical results); returns the previous setting. */
-int cmr_set_linear_row64(int on);
-/* The same kind of switch for the register-weights kernel (K = 64, n_out <= 64, one source, at least min_rows rows; min_rows <= 0 keeps the
- * threshold): bit-identical to the weight-stationary kernel.  Returns the previous on / off setting. */
-int cmr_set_linear_wreg(int on, int64_t min_rows);
-
 /* Whole ConvBNReLURes1D block in one kernel (PointNN.py:260-282 with BN folded):
  *   hid = lrelu(W1 x + b1);  y = lrelu(W2 hid + b2 + (Wsc x | x)),  x = [x1[:, :k1] | x2[map][:, :kx-k1]].
  * The hidden activations stay in MFMA accumulator registers (transposed GEMM: accumulators of layer 1 are the
@@ -88,10 +81,15 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
 /* Same convolution (stride 1) by Winograd F(2x2,3x3): u = G g G^T of the folded weights, transformed host-side and
  * stored as MFMA A fragments [16 positions][Cout/32][Cin/8][64 lanes][4] with lane 32h+l holding
  * U[pos][32 tile + l][8 kgroup + 4h .. +3] (16*Cout*Cin floats; cmr_agent_amd/models/_pack.py:winograd_u); input / output transforms, the 16 position GEMMs and the epilogue of cmr_conv3x3_nhwc_f32
- * (bias, residual, LeakyReLU, table, optional 2x2 average pool) are fused in one kernel. */
+ * (bias, residual, LeakyReLU, table, optional 2x2 average pool) are fused in one kernel.
+ * Launch policy of the PERSISTENT kernel (maps of >= 200 tiles), per call -- the library keeps no state:
+ *   cu_budget  CUs it may occupy (0 = all; rounded down to a multiple of 8).  It fills a CU completely, so a branch forked onto another
+ *              stream only progresses between its launches unless it is left some CUs (the image tower beside the point tower);
+ *   slices     workgroups per CU of that budget, each walking 1 / slices of the tiles (never fewer than 8 tiles per workgroup), so CUs
+ *              return to the dispatcher during the launch; <= 1 = one workgroup per CU.  Results do not depend on either. */
 int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,
-                              hipStream_t stream);
+                              int cu_budget, int slices, hipStream_t stream);
 /* Stride-2 3x3 convolution (the two strided convolutions of a down-sampling ResidualBlock, ImageResNet.py:9-14, :24-27) with the weights
  * as MFMA A fragments [9 taps][Cout/32][Cin/8][64 lanes][4] read straight from L2 (cmr_agent_amd/models/_pack.py:conv_s2_frags): same
  * arithmetic and epilogue as cmr_conv3x3_nhwc_f32 at stride 2 (bias, residual, LeakyReLU), two barriers per 16-channel halo chunk instead
@@ -99,25 +97,6 @@ int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, cons
  * cmr_conv3x3_nhwc_f32. */
 int cmr_conv3x3_s2_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* wfrag, const float* bias, const float* res,
                             const float* post, float* y, int Cout, float slope, hipStream_t stream);
-/* Process-wide switch between the two Winograd kernels for maps of >= 200 tiles (1 = wave-specialised persistent kernel,
- * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
-int cmr_set_wino_variant(int wave_specialised);
-/* CUs the persistent convolution kernels (wave-specialised Winograd, two-team bf16) may occupy from now on (0 = all; rounded down to a
- * multiple of 8).  They fill a CU completely, so a branch forked onto another stream only progresses between their launches unless it is
- * left some CUs: the image tower runs with a reduced budget while the point tower runs beside it.  Returns the previous setting. */
-int cmr_set_conv_cu_budget(int cus);
-/* Time slicing of the persistent Winograd kernel: from now on a launch uses `slices` workgroups per CU of its budget, each walking
- * 1 / slices of the tiles (never fewer than 8 tiles per workgroup), so CUs return to the dispatcher during the launch and a branch
- * forked onto another stream is served in between.  1 (default) = one workgroup per CU.  Results do not depend on it.  Returns the
- * previous setting. */
-int cmr_set_conv_slices(int slices);
-/* Process-wide switch of the bf16 convolution's kernel choice for 128-cout layers without residual / table operand (stride 1,
- * Cin = 64 | 128): matrix_class = 1 (default) routes maps of at least min_tiles 8x32-pixel tiles (x Cout / 128; min_tiles <= 0 keeps the
- * current threshold) to the register-tiled kernel that streams the weight fragments from L2 (conv3x3_bf16_mm_kernel), 0 keeps the
- * two-team kernel everywhere.  Same products, accumulated per 64-channel chunk: results agree to fp32 rounding of the sums.  A/B
- * measurements and tests only.  Returns CMR_OK. */
-int cmr_set_conv_bf16_variant(int matrix_class, int min_tiles);
-
 /* MiniResNet block 0 (3 -> 64 channels, 1x1 shortcut), NCHW image in, NHWC features out (fp32, or bf16 when out_bf16 != 0: the
  * bf16-stored image tower of the bf16 mode).  tmp_nchw is scratch of [B][6][H][W] floats (conv-a output | a copy of the image);
  * 0 <= slope <= 1.  ImageResNet.py:50 with :9-23. */
@@ -167,10 +146,6 @@ int cmr_mha_expf_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, c
 int cmr_mha_ln_f32(const float* x, int64_t ldx, const float* y, int64_t ldy, const float* gamma, const float* beta, float eps,
                    const float* wq_frag, const float* wkv_frag, const float* bq, const float* bk, const float* bv, float* o, int64_t ldo,
                    int B, int Tq, int Tk, hipStream_t stream);
-/* Process-wide switch between the two softmax-attention kernels (1 = v_mfma_f32_16x16x4_f32 for Q K^T and P V, the default;
- * 0 = one query per 4 lanes on the vector ALUs): A/B measurements and tests only.  Returns the previous setting. */
-int cmr_set_mha_variant(int mfma);
-
 /* kvsum[b] = { KV[h][d][v] = sum_s K~ V / S (512), Ksum[h][d] (64) }.  LinearAttention.py:55-58. */
 int64_t cmr_la_reduce_workspace_bytes(int B, int S);
 int cmr_la_reduce_f32(const float* kf, int64_t ldk, const float* v, int64_t ldv, float* kvsum, void* workspace,
@@ -506,10 +481,6 @@ int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B, int H, in
  * sums per channel -- replaces a cmr_colsum_f32 pass over dy.  db null: identical to the entry point above. */
 int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, float* db, void* ws,
                                     int64_t ws_bytes, hipStream_t stream);
-/* A/B switch: 1 (default) = the LDS-staged kernel for Cin 64 / 128 on maps of >= 4096 pixels (a ring of input rows in LDS, every
- * tap an LDS address), 0 = the direct kernel everywhere (operands by dword loads).  Same sums in a different order (results agree
- * to fp32 rounding); returns the previous setting. */
-int cmr_set_wgrad_variant(int lds_staged);
 int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                           int64_t ws_bytes, hipStream_t stream);
 /* nn.Conv1d(k=1) / nn.Linear weight and bias gradient over a row map: dw [n][k] (+)= dy^T x, db [n] (+)= column sums of dy
@@ -519,10 +490,6 @@ int64_t cmr_linear_wgrad_workspace_bytes(int64_t rows, int n, int k);
 int cmr_linear_wgrad_f32(const float* dy, int64_t lddy, int n, const float* x, int64_t ldx, int k, int64_t rows, float* dw,
                          int64_t lddw, int accumulate, float* db, int accumulate_db, void* ws, int64_t ws_bytes,
                          hipStream_t stream);
-/* A/B switch: 1 (default) = row maps of >= 65 536 rows with n, k multiples of 32 up to 128 take the LDS-staged kernel (whole-row
- * float4 staging, the full gradient per workgroup), 2 = from 8192 rows on (tests), 0 = the direct kernel everywhere.  Same sums in
- * another order; returns the previous on / off setting. */
-int cmr_set_linear_wgrad_variant(int lds_staged);
 /* nn.Conv2d weight [Cout][Cin][3][3] -> operand layouts of the forward kernels (w9 [9][Co'][Ci'] and the Winograd
  * U fragments); transpose = 1 packs the data-gradient convolution W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx].  bf16_frag
  * (optional) receives the bf16 A fragments of cmr_conv3x3_bf16_nhwc_f32 for cout groups of 32 * bf16_nt. */
@@ -551,10 +518,11 @@ int cmr_dataset_circle_select_f64(const int64_t* pc_mask, const double* xy, cons
  * table, optional fused 2x2 average pool at stride 1) with the products on v_mfma_f32_32x32x16_bf16 (operands rounded to
  * bf16, fp32 accumulate).  wfrag: bf16 A fragments [Cout/(32 nt)][9][Cin/16][nt][64][8]
  * (cmr_agent_amd/models/_pack.py:conv_bf16_frags).  Served shapes: stride 1: (Cin 64, nt 1|2), (Cin 128, nt 1); stride 2:
- * (Cin 64, nt 1|2); anything else returns CMR_EUNSUPPORTED. */
+ * (Cin 64, nt 1|2); anything else returns CMR_EUNSUPPORTED.  cu_budget: CUs the persistent two-team / matrix-class kernels may occupy
+ * (0 = all), as for cmr_conv3x3_wino_nhwc_f32. */
 int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                               const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
-                              hipStream_t stream);
+                              int cu_budget, hipStream_t stream);
 
 /* ---- geometric-model update: backward pieces (reference Train_Geo.py:166-174) ---------------------- */
 /* The training forward of MultiHeadModel is the op-level composition of the inference entry points above with BatchNorm
@@ -650,7 +618,7 @@ int cmr_iter_apply_f32(const float* matrix_i, const float* pc, float* pc_out, in
  * bit-neutral: the residual enters the fp32 epilogue rounded to bf16.  Otherwise CMR_EUNSUPPORTED (-3). */
 int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                             const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope,
-                            int pool, hipStream_t stream);
+                            int pool, int cu_budget, hipStream_t stream);
 
 /* ---- dropout (train mode; the reference trains MultiHeadModel with p = 0.1 in 141 nn.Dropout modules) --------------------------
  * Counter-based masks: element idx of site `site` is kept iff mix64(seed[0], site, idx) >= p 2^32 (csrc/cmr_common.h:cmr_keep); seed is

@@ -1,0 +1,52 @@
+/* A/B switches of libcmr_hip_ab.so -- NOT part of the product ABI.
+ *
+ * cmr_agent_amd/lib/libcmr_hip_ab.so is the same source tree compiled with -DCMR_AB_SWITCHES: it exports everything include/cmr_hip.h
+ * declares PLUS the process-global kernel-variant switches below, which tests use to compare two kernels bit for bit and tools/*_bench.py
+ * to time them.  The product (cmr_agent_amd/*, bench.py, Train_*.py, Test_Agent.py) loads libcmr_hip.so, which has none of these
+ * symbols and no mutable state: its dispatch thresholds are compile-time constants (tests/test_abi.py asserts both).  Every switch
+ * returns the previous setting unless stated otherwise. */
+#ifndef CMR_HIP_AB_H
+#define CMR_HIP_AB_H
+#include "cmr_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Debug / benchmark switch: 0 routes the contiguous [rows][64] -> [rows][64 | 32] calls of cmr_linear_f32 through the generic
+ * weight-stationary kernel instead of the row-streaming fast path (bit-identical results); returns the previous setting. */
+int cmr_set_linear_row64(int on);
+
+/* The same kind of switch for the register-weights kernel (K = 64, n_out <= 64, one source, at least min_rows rows; min_rows <= 0 keeps the
+ * threshold): bit-identical to the weight-stationary kernel.  Returns the previous on / off setting. */
+int cmr_set_linear_wreg(int on, int64_t min_rows);
+
+/* Process-wide switch between the two Winograd kernels for maps of >= 200 tiles (1 = wave-specialised persistent kernel,
+ * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
+int cmr_set_wino_variant(int wave_specialised);
+
+/* Process-wide switch of the bf16 convolution's kernel choice for 128-cout layers without residual / table operand (stride 1,
+ * Cin = 64 | 128): matrix_class = 1 (default) routes maps of at least min_tiles 8x32-pixel tiles (x Cout / 128; min_tiles <= 0 keeps the
+ * current threshold) to the register-tiled kernel that streams the weight fragments from L2 (conv3x3_bf16_mm_kernel), 0 keeps the
+ * two-team kernel everywhere.  Same products, accumulated per 64-channel chunk: results agree to fp32 rounding of the sums.  A/B
+ * measurements and tests only.  Returns CMR_OK. */
+int cmr_set_conv_bf16_variant(int matrix_class, int min_tiles);
+
+/* Process-wide switch between the two softmax-attention kernels (1 = v_mfma_f32_16x16x4_f32 for Q K^T and P V, the default;
+ * 0 = one query per 4 lanes on the vector ALUs): A/B measurements and tests only.  Returns the previous setting. */
+int cmr_set_mha_variant(int mfma);
+
+/* A/B switch: 1 (default) = the LDS-staged kernel for Cin 64 / 128 on maps of >= 4096 pixels (a ring of input rows in LDS, every
+ * tap an LDS address), 0 = the direct kernel everywhere (operands by dword loads).  Same sums in a different order (results agree
+ * to fp32 rounding); returns the previous setting. */
+int cmr_set_wgrad_variant(int lds_staged);
+
+/* A/B switch: 1 (default) = row maps of >= 65 536 rows with n, k multiples of 32 up to 128 take the LDS-staged kernel (whole-row
+ * float4 staging, the full gradient per workgroup), 2 = from 8192 rows on (tests), 0 = the direct kernel everywhere.  Same sums in
+ * another order; returns the previous on / off setting. */
+int cmr_set_linear_wgrad_variant(int lds_staged);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -60,14 +60,54 @@ UNIT = ("pc_geo_feat", "img_geo_feat", "pc_is_in_cam_scores", "img_overlap_pred"
 DISCRETE = ("node2proxy", "pc_overlap_pred")
 
 
-def compare(named, ref, verbose=False, atol=1e-4, sparse_outliers=None):
+def ill_conditioned_rows(named, ref, batch, spec, atol=1e-4):
+    """The one allowance of the headline-batch test, restricted to where tests/test_conditioning_cpu.py locates its cause.
+    spec = dict(pair, node_key, point_keys, max_nodes, hard): in pair `pair` at most `max_nodes` node columns of `node_key` ([B, C, M]) may
+    exceed atol (none by more than `hard`, units of the tensor's scale); the suspect set is every node of that pair above atol / 5 (the
+    conditioning test: the well-conditioned rows sit at 1e-6, nothing in between); the per-point tensors `point_keys` ([B, C, N] / [B, N])
+    may exceed atol only at points of that pair ASSIGNED to a suspect node (pt2node) -- every other pair, node and point meets atol.
+    Returns (error strings, keys it has judged)."""
+    errs, pair = [], spec["pair"]
+    k = spec["node_key"]
+    g, r = named[k].double(), ref[k].double()
+    scale = max(float(r.abs().max()), 1.0)
+    d = (g - r).abs() / scale                                           # [B, C, M]
+    per_node = d.amax(1)                                                # [B, M]
+    others = per_node.clone()
+    others[pair] = 0.0
+    if float(others.max()) > atol:
+        errs.append("%s: pair %d / node %d is %.3e off (only pair %d may hold outliers)" % (k, int(others.argmax()) // per_node.shape[1],
+                                                                                           int(others.argmax()) % per_node.shape[1], float(others.max()), pair))
+    over = per_node[pair] > atol
+    suspect = per_node[pair] > atol / 5
+    if int(over.sum()) > spec["max_nodes"] or int(suspect.sum()) > 2 * spec["max_nodes"] or float(per_node[pair].max()) > spec["hard"]:
+        errs.append("%s: pair %d has %d node rows above %.0e (%d above %.0e), worst %.3e" % (k, pair, int(over.sum()), atol, int(suspect.sum()), atol / 5,
+                                                                                                float(per_node[pair].max())))
+    p2n = batch["pt2node"][pair].long().cpu()
+    point_suspect = suspect[p2n]                                        # [N]
+    for k in spec["point_keys"]:
+        g, r = named[k].double(), ref[k].double()
+        scale = 1.0 if k in UNIT else max(float(r.abs().max()), 1.0)
+        d = (g - r).abs() / scale
+        per_pt = d if d.dim() == 2 else d.amax(1)                       # [B, N]
+        clean = per_pt.clone()
+        clean[pair][point_suspect] = 0.0
+        if float(clean.max()) > atol:
+            errs.append("%s: %.3e off at a point that is not assigned to an ill-conditioned node of pair %d" % (k, float(clean.max()), pair))
+        if float(per_pt.max()) > spec["hard"]:
+            errs.append("%s: worst %.3e > %.0e" % (k, float(per_pt.max()), spec["hard"]))
+    return errs, (spec["node_key"],) + tuple(spec["point_keys"])
+
+
+def compare(named, ref, verbose=False, atol=1e-4, sparse_outliers=None, skip=()):
     """named / ref: dict name -> cpu tensor.  Returns list of error strings.
     sparse_outliers: {key: (max fraction of entries above atol * scale, hard bound in units of scale)} for tensors known to contain a
-    few ill-conditioned rows (where the fp32 ORACLE itself is that far from its float64 evaluation: tests/test_conditioning_cpu.py)."""
+    few ill-conditioned rows (where the fp32 ORACLE itself is that far from its float64 evaluation: tests/test_conditioning_cpu.py).
+    skip: keys judged elsewhere (ill_conditioned_rows)."""
     errs = []
     sparse_outliers = sparse_outliers or {}
     for k, r in ref.items():
-        if k not in named:
+        if k not in named or k in skip:
             continue
         g = named[k]
         if tuple(g.shape) != tuple(r.shape):
@@ -105,7 +145,7 @@ def compare(named, ref, verbose=False, atol=1e-4, sparse_outliers=None):
     return errs
 
 
-def run_case(case, check_golden=True, verbose=False, sparse_outliers=None):
+def run_case(case, check_golden=True, verbose=False, sparse_outliers=None, ill_conditioned=None):
     cfg = C.e2e_config(case)
     geo, agent, geo_sd, agent_sd = build_models(cfg)
     batch = C.e2e_batch(case)
@@ -113,7 +153,10 @@ def run_case(case, check_golden=True, verbose=False, sparse_outliers=None):
     ref = C.e2e_oracle(case, geo_sd, agent_sd, batch)
     if verbose:
         print("product vs oracle (%s)" % case)
-    errs = compare(got, ref, verbose, sparse_outliers=sparse_outliers)
+    errs, judged = ([], ())
+    if ill_conditioned is not None:
+        errs, judged = ill_conditioned_rows(got, ref, batch, ill_conditioned)
+    errs += compare(got, ref, verbose, sparse_outliers=sparse_outliers, skip=judged)
     assert not errs, "HIP path vs oracle:\n  " + "\n  ".join(errs)
     if check_golden:
         fx = G.load_case(case)

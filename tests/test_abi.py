@@ -33,6 +33,35 @@ def test_library_exports_only_declared_entry_points(lib):
     assert exported == set(lib.parse_header()), exported ^ set(lib.parse_header())
 
 
+def test_product_abi_has_no_process_global_switches(lib):
+    """SURVEY.md 8b / VERDICT r03 #8: the product library keeps no launch policy or kernel-variant state.  include/cmr_hip.h declares no
+    cmr_set_* entry point and libcmr_hip.so exports none (CU budget / time slices of the persistent convolutions are arguments of the
+    call); the product's Python never names one; its only writable data are per-kernel caches of granted LDS sizes."""
+    assert not [n for n in lib.parse_header() if n.startswith("cmr_set_")]
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "cmr_set_" not in out
+    prod = [os.path.join(ROOT, f) for f in ("bench.py", "Train_Agent.py", "Train_Geo.py", "Test_Agent.py", "__graft_entry__.py")]
+    for d, _, files in os.walk(os.path.join(ROOT, "cmr_agent_amd")):
+        prod += [os.path.join(d, f) for f in files if f.endswith(".py")]
+    for f in prod:
+        src = open(f).read()
+        if f.endswith("_lib.py"):
+            src = re.sub(r'""".*?"""', "", src, flags=re.S)         # its docstrings describe the A/B library
+        assert not re.search(r"\.cmr_set_\w+\(", src) and "use_ab(" not in src.replace("def use_ab(", ""), f
+        assert f.endswith("_lib.py") or ("load_ab" not in src and "_lib.ab(" not in src), f
+
+
+def test_ab_library_is_the_product_plus_the_switches(lib):
+    """cmr_agent_amd/lib/libcmr_hip_ab.so (tests / tools only): every product entry point + exactly the switches of include/cmr_hip_ab.h."""
+    assert os.path.exists(lib.AB_LIB_PATH)
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.AB_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (cmr_\w+)", out))
+    switches = set(lib.parse_header(lib.AB_HEADER_PATH))
+    assert switches and all(n.startswith("cmr_set_") for n in switches), switches
+    assert exported == set(lib.parse_header()) | switches, exported ^ (set(lib.parse_header()) | switches)
+    lib.load_ab()
+
+
 def test_workspace_queries_run_on_cpu(lib):
     l = lib.load()
     assert l.cmr_la_reduce_workspace_bytes(2, 1000) == 2 * 2 * 576 * 4

@@ -68,7 +68,6 @@ def test_conv3x3_bf16_matrix_class_kernel(B, H, W, cin, cout, pool, in16, out16)
     + half a bf16 ulp when the output is stored as bf16) and against the two-team kernel (same products, other summation order)."""
     from cmr_agent_amd import ops, _lib
     from cmr_agent_amd.models._pack import conv_bf16_frags
-    lib = _lib.load()
     x = rnd(B, cin, H, W, seed=11)
     if in16:
         x = x.to(torch.bfloat16).float()
@@ -82,13 +81,14 @@ def test_conv3x3_bf16_matrix_class_kernel(B, H, W, cin, cout, pool, in16, out16)
         xd = xd.to(torch.bfloat16)
     frags = conv_bf16_frags(w.to(DEV))
     run = lambda: ops.conv3x3_bf16(xd, frags, b.to(DEV), cout, 0.2, pool=pool, out_bf16=out16)
-    try:
-        assert lib.cmr_set_conv_bf16_variant(1, 1) == 0
-        got = run()
-        assert lib.cmr_set_conv_bf16_variant(0, 0) == 0
-        old = run()
-    finally:
-        lib.cmr_set_conv_bf16_variant(1, 128)
+    with _lib.ab() as lib:                                       # the A/B library: same sources + the variant switches
+        try:
+            assert lib.cmr_set_conv_bf16_variant(1, 1) == 0
+            got = run()
+            assert lib.cmr_set_conv_bf16_variant(0, 0) == 0
+            old = run()
+        finally:
+            lib.cmr_set_conv_bf16_variant(1, 128)
     assert got is not None and got.dtype == (torch.bfloat16 if out16 else torch.float32)
     g = got.float().permute(0, 3, 1, 2).cpu().double()
     scale = float(want.abs().max())
@@ -572,7 +572,7 @@ def test_bf16_stored_tower_instances_and_mini_resnet():
 
 
 def test_conv_cu_budget_changes_nothing_but_the_grid():
-    """cmr_set_conv_cu_budget: the persistent convolution kernels (wave-specialised Winograd, two-team bf16) on 64 / 160 CUs give the
+    """`cu_budget` argument of the convolution entry points: the persistent convolution kernels (wave-specialised Winograd, two-team bf16) on 64 / 160 CUs give the
     bit-identical result of the full-chip launch (the tile -> workgroup assignment changes, the arithmetic per tile does not)."""
     from cmr_agent_amd import ops
     from cmr_agent_amd.models._pack import conv_bf16_frags, winograd_u
@@ -593,7 +593,7 @@ def test_conv_cu_budget_changes_nothing_but_the_grid():
 
 
 def test_conv_slices_change_nothing_but_the_grid():
-    """cmr_set_conv_slices: the wave-specialised Winograd kernel launched as 2 / 5 / 64 workgroups per CU (never fewer than 8 tiles per
+    """`slices` argument of cmr_conv3x3_wino_nhwc_f32: the wave-specialised Winograd kernel launched as 2 / 5 / 64 workgroups per CU (never fewer than 8 tiles per
     workgroup) gives the bit-identical result of the one-workgroup-per-CU launch, with and without a CU budget."""
     from cmr_agent_amd import ops
     from cmr_agent_amd.models._pack import winograd_u

@@ -83,3 +83,37 @@ def test_two_rank_agent_update_rccl(tmp_path):
     res = _run_ranks(tmp_path, "nccl", False)
     _check(res)
     assert res[0]["allreduce_ms"] > 0
+
+
+def test_rccl_executes_at_world_size_one(tmp_path):
+    """everything about the RCCL leg that a one-GPU box can prove.  One rank started through the launcher's child path
+    (torch.distributed.run, nproc 1), `Ranks(force=True)` -> init_process_group("nccl", device_id=...) at world size 1, one
+    FlatBucket.all_reduce of REAL agent gradients (librccl loads on gfx950, the communicator comes up under the dmabuf IPC setting, the
+    collective runs on the device and leaves the bucket as it was), then the usual steps with the all-reduce inside optimizer_step."""
+    from cmr_agent_amd.utils import launch
+    cmd = launch.rank_command(os.path.join(ROOT, "tests", "dp_worker.py"), [str(tmp_path), "nccl", "0", str(STEPS), "force"], 1)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = torch.load(os.path.join(str(tmp_path), "rank0.pt"))
+    assert r["forced"] and r["backend"] == "nccl" and r["ranks"] == 1 and r["world_of_all_reduce"] == 1
+    assert r["bucket_abs_sum"] > 0 and r["bucket_unchanged"]
+    assert r["direct_allreduce_ms"] > 0 and r["allreduce_ms"] > 0
+    assert r["rccl_version"]
+    # the forced collective changes nothing: same parameters as a run without any process group
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train import AgentUpdate
+    from cmr_agent_amd.utils import hashfill
+    from cmr_agent_amd.utils.checkpoint import load_checked
+    specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+    cfg = C.train_config("agent_train_small", device="cuda")
+    agent = CMRAgent(cfg)
+    load_checked(agent, hashfill.make_state_dict(specs["agent"], C.AGENT_TAG))
+    up = AgentUpdate(agent.to("cuda"), cfg)
+    shard = {k: v.cuda() for k, v in C.train_inputs("agent_train_small")[0].items()}
+    up.forward_backward(shard)          # the worker's extra forward / backward moved the BatchNorm running statistics once more
+    for _ in range(STEPS):
+        up.step(shard)
+    torch.cuda.synchronize()
+    assert torch.equal(up.bucket.params.cpu(), r["params"])

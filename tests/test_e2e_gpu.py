@@ -30,12 +30,14 @@ def test_registration_iteration_headline_shape_at_the_benchmark_batch():
     (features, losses, per-step logits / values, actions and poses), at the tolerances of the small cases -- with one allowance: pair 5 of
     this batch has 8 of its 1 280 nodes on which the third pixel-to-node linear-attention layer is ill-conditioned (a LayerNorm over a
     nearly constant message row): the fp32 ORACLE is 2.1e-4 of the feature scale away from its own float64 evaluation on exactly those
-    rows (tests/test_conditioning_cpu.py pins that), and so is any fp32 path.  The node-side tensors downstream of that layer may hold
-    <= 0.1 % of their entries above the 1e-4 tolerance, none above 1e-3 of the scale; everything else -- image side, the other 7 pairs,
-    every agent step's logits, actions and poses -- meets the usual bars (tools/e2e_per_sample.py, tools/decoder_trace.py)."""
+    rows (tests/test_conditioning_cpu.py pins that), and so is any fp32 path.  The allowance is restricted to exactly that: in PAIR 5 at
+    most 16 node rows of `fused_node_feat` may exceed the 1e-4 tolerance (none above 1e-3 of the scale), and the per-point outputs of the
+    heads may exceed it only at points of pair 5 ASSIGNED to such a node (parity_e2e.ill_conditioned_rows); every other pair, node and
+    point, the image side, every agent step's logits, actions and poses meet the usual bars (tools/e2e_per_sample.py,
+    tools/decoder_trace.py)."""
     import parity_e2e
-    allow = {k: (1e-3, 1e-3) for k in ("fused_node_feat", "pc_overlap_logits", "pc_geo_feat", "pc_is_in_cam_scores")}
-    parity_e2e.run_case("e2e_config1_b8", check_golden=False, verbose=True, sparse_outliers=allow)
+    spec = dict(pair=5, node_key="fused_node_feat", point_keys=("pc_overlap_logits", "pc_geo_feat", "pc_is_in_cam_scores"), max_nodes=16, hard=1e-3)
+    parity_e2e.run_case("e2e_config1_b8", check_golden=False, verbose=True, ill_conditioned=spec)
 
 
 def test_registration_iteration_nuscenes_config3_shape():

@@ -182,7 +182,6 @@ def test_wave_specialised_winograd_kernel_equals_the_four_wave_kernel(B, H, W, c
     the direct kernel within the Winograd rounding."""
     import math
     from cmr_agent_amd import _lib, ops
-    lib = _lib.load()
     g = torch.Generator().manual_seed(H + cin)
     x = (torch.rand(B, H, W, cin, generator=g) - 0.5).to(DEV)
     w9 = ((torch.rand(9, cout, cin, generator=g) - 0.5) / math.sqrt(cin)).to(DEV)
@@ -192,14 +191,15 @@ def test_wave_specialised_winograd_kernel_equals_the_four_wave_kernel(B, H, W, c
     r = (torch.rand(B, H, W, cout, generator=g) - 0.5).to(DEV) if res else None
     p = (torch.rand(H, W, cout, generator=g) - 0.5).to(DEV) if post else None
     assert ((W + 15) // 16) * ((H + 7) // 8) * B * (cout // 64) >= 200
-    old = lib.cmr_set_wino_variant(0)
-    try:
-        y4 = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
-        lib.cmr_set_wino_variant(1)
-        y8 = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
-        y8b = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
-    finally:
-        lib.cmr_set_wino_variant(old)
+    with _lib.ab() as lib:                                       # the A/B library: same sources + the variant switches
+        old = lib.cmr_set_wino_variant(0)
+        try:
+            y4 = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
+            lib.cmr_set_wino_variant(1)
+            y8 = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)
+        finally:
+            lib.cmr_set_wino_variant(old)
+    y8b = ops.conv3x3_wino(x, u, b, cout, 0.2, res=r, post=p, pool=pool)          # the product library's (only) dispatch
     assert torch.equal(y4, y8) and torch.equal(y8, y8b)
     ops.WINOGRAD = False
     try:

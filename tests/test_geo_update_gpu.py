@@ -12,8 +12,11 @@ their own scale (0.08, see _check_grads); the whole gradient vector must have co
 step is chaotic in the same sense (Adam's first steps move every weight by lr * sign(g), so an entry whose gradient is at noise
 level lands 2 lr away on either side: 31 % of the entries of the oracle itself differ by more than 2e-5 after two steps under
 that 1e-6 perturbation).  So the second step is checked TEACHER-FORCED -- a fresh HIP model loaded with the oracle's state after
-step one must reproduce the oracle's step-two losses and gradients to the same bars as step one -- and the free-running
-trajectory is only required to stay inside the envelope (every weight within 4.4 lr, losses within 3e-4 relative)."""
+step one must reproduce the oracle's step-two losses and gradients to the same bars as step one.  The PARAMETERS are checked
+after the first Adam step, where the statement is sharp: every weight whose oracle gradient is above the noise level of its
+tensor (twice the gradient error measured on that tensor) must be within 2e-5 of the oracle's -- all of them, no fraction
+allowance; the others are bounded by 2.2 lr.  After the free-running second step at least 60 % of the weights must still be
+within 2e-5 (the oracle under a 1e-6 input perturbation keeps 69 %) and every weight within the 4.4 lr envelope."""
 import json
 import os
 
@@ -126,7 +129,36 @@ def test_geo_update_matches_oracle_and_reference_fixture():
     # ---- two free-running optimizer steps
     model2 = _model(cfg, geo_sd)
     up2 = GeoUpdate(model2, cfg, dropout=False)
-    hist = [{k: float(v) for k, v in up2.step(_to_dev(b)).items()} for b in batches]
+    hist = [{k: float(v) for k, v in up2.step(_to_dev(batches[0])).items()}]
+    torch.cuda.synchronize()
+    # After ONE Adam step from the shared start (m = (1 - b1) g, v = (1 - b2) g^2: the step is lr * g / (|g| + eps), i.e. lr * sign(g) unless
+    # |g| is of the order of eps) a weight can only differ from the oracle's if the SIGN of its effective gradient (clipped gradient + weight
+    # decay) differs or |g| ~ eps.  Entries whose oracle gradient exceeds twice the error measured on their tensor in step 0 above are
+    # sign-stable: ALL of them must agree to 2e-5 (no fraction allowance).  The rest -- entries at the noise level of their tensor, incl. the
+    # conv biases in front of a BatchNorm whose true gradient is zero (listed) -- land lr * 2 apart on either side and are only bounded.
+    sd1 = {k: x.detach().cpu() for k, x in model2.state_dict().items()}
+    named = dict(model2.named_parameters(remove_duplicate=False))
+    stable_n, total_n, zero_grad = 0, 0, []
+    for k, g_o in og.items():
+        if not named[k].requires_grad:
+            continue
+        g_o = g_o.double()
+        g_h = lg[k].detach().cpu().double().reshape(g_o.shape)
+        d_k = float((g_h - g_o).abs().max())
+        if float(g_o.abs().max()) <= 1e-6 * gmax:             # (true gradient zero: a bias in front of a BatchNorm)
+            zero_grad.append(k)
+        g_eff = g_o.clamp(-1.0, 1.0) + cfg.weight_decay * sd0[k].double()
+        stable = g_eff.abs() > 2.0 * d_k + 1e-6
+        dp = (sd1[k].double() - osd1[k].double()).abs()
+        assert float(dp.max()) <= 2.2 * cfg.lr, (k, float(dp.max()))
+        if bool(stable.any()):
+            worst = float(dp[stable].max())
+            assert worst <= 2e-5, "%s: a sign-stable entry is %.3e from the oracle after one Adam step" % (k, worst)
+        stable_n, total_n = stable_n + int(stable.sum()), total_n + stable.numel()
+    print("  one Adam step: %.1f %% of %d weights sign-stable, all within 2e-5; zero-gradient tensors: %s"
+          % (100.0 * stable_n / total_n, total_n, ", ".join(zero_grad[:40])))
+    assert stable_n >= 0.3 * total_n, (stable_n, total_n)
+    hist.append({k: float(v) for k, v in up2.step(_to_dev(batches[1])).items()})
     torch.cuda.synchronize()
     osd, ohist = TO.geo_adam_train(sd0, batches, cfg, True)
     for i in range(len(batches)):
@@ -136,16 +168,22 @@ def test_geo_update_matches_oracle_and_reference_fixture():
             assert abs(hist[i][k] - want) <= 3e-4 * max(1.0, abs(want)), (i, k, hist[i][k], want)
     sd2 = {k: x.detach().cpu() for k, x in model2.state_dict().items()}
     lr = cfg.lr
-    moved = 0.0
+    moved, close_n, all_n = 0.0, 0, 0
     for k in osd:
-        d = float((sd2[k].double() - osd[k].double()).abs().max())
+        dd = (sd2[k].double() - osd[k].double()).abs()
+        d = float(dd.max())
         if k.endswith("running_var"):
             assert d <= 2e-3 * max(1.0, float(osd[k].abs().max())), (k, d)
         elif k.endswith("running_mean"):
             assert d <= 4.4 * lr + 2e-3 * float(osd[k].abs().max()), (k, d)
-        else:
-            assert d <= 4.4 * lr, (k, d)
+        elif not k.endswith("num_batches_tracked"):
+            assert d <= 4.4 * lr, (k, d)                        # the envelope: two steps of at most ~1.1 lr each, on either side
+            close_n, all_n = close_n + int((dd <= 2e-5).sum()), all_n + dd.numel()
             moved = max(moved, float((sd2[k].double() - sd0[k].double()).abs().max()))
+    # the free-running second step is chaotic in the sense of the module docstring: the ORACLE itself, fed inputs perturbed by 1e-6, keeps
+    # 69 % of its weights within 2e-5 after two steps; the HIP path measured 71.4 %
+    print("  two free-running steps: %.1f %% of %d weights within 2e-5 of the oracle" % (100.0 * close_n / all_n, all_n))
+    assert close_n >= 0.6 * all_n, (close_n, all_n)
     assert moved >= 1.5 * lr                                   # and the optimizer did move the weights
     # ---- the inference path sees the new weights: updated model in eval mode == a fresh module with its state dict
     model2.eval()

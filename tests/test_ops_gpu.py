@@ -59,11 +59,12 @@ def test_linear_row_streaming_fast_path(ops, rows, n_out, act, res):
     r = rnd(rows, n_out, seed=8) if res else None
     d = lambda t: None if t is None else t.to(DEV)
     got = ops.linear(d(x), d(w), d(b), res=d(r), act=act, act_param=0.2)
-    old = _lib.load().cmr_set_linear_row64(0)
-    try:
-        want = ops.linear(d(x), d(w), d(b), res=d(r), act=act, act_param=0.2)
-    finally:
-        _lib.load().cmr_set_linear_row64(old)
+    with _lib.ab() as lib:                                       # the A/B library: same sources + the variant switches
+        old = lib.cmr_set_linear_row64(0)
+        try:
+            want = ops.linear(d(x), d(w), d(b), res=d(r), act=act, act_param=0.2)
+        finally:
+            lib.cmr_set_linear_row64(old)
     assert old == 1 and torch.equal(got, want)
     ref = x.double() @ w.double().T + b.double() + (r.double() if res else 0)
     ref = {0: lambda v: v, 1: torch.relu, 2: lambda v: F.leaky_relu(v, 0.2), 3: F.gelu, 4: lambda v: F.elu(v) + 1}[act](ref)
@@ -169,18 +170,18 @@ def test_linear_register_weights_kernel_is_bit_identical(ops, rows, n, act, res,
     """linear_wreg_kernel (K = 64 row maps above 65 536 rows: the weight matrix in registers, no LDS reads in the tile loop) must give the
     bits of the weight-stationary kernel it replaces (same products, same order), and those of the oracle formula to 1e-5."""
     from cmr_agent_amd import _lib
-    lib = _lib.load()
     x, w, b = rnd(rows, 64, seed=211), rnd(n, 64, seed=212) / 6, rnd(n, seed=213)
     r = rnd(res_mod if res_mod else rows, n, seed=214) if res else None
     d = lambda t: None if t is None else t.to(DEV)
     kw = dict(res=d(r), res_mod=res_mod, act=act, act_param=0.2)
-    old = lib.cmr_set_linear_wreg(1, 0)
-    try:
-        new = ops.linear(d(x), d(w), d(b), **kw)
-        lib.cmr_set_linear_wreg(0, 0)
-        ws = ops.linear(d(x), d(w), d(b), **kw)
-    finally:
-        lib.cmr_set_linear_wreg(old, 0)
+    with _lib.ab() as lib:                                       # the A/B library: same sources + the variant switches
+        old = lib.cmr_set_linear_wreg(1, 0)
+        try:
+            new = ops.linear(d(x), d(w), d(b), **kw)
+            lib.cmr_set_linear_wreg(0, 0)
+            ws = ops.linear(d(x), d(w), d(b), **kw)
+        finally:
+            lib.cmr_set_linear_wreg(old, 0)
     assert torch.equal(new, ws)
     y = x.double() @ w.double().t() + b.double()
     if r is not None:
@@ -210,11 +211,12 @@ def test_mha(ops, B, Tq, Tk, variant):
     """Both kernels of cmr_mha_f32: Q K^T and P V on v_mfma_f32_16x16x4_f32 with an online softmax (the default), and the
     two-pass vector-ALU kernel."""
     from cmr_agent_amd import _lib
-    old = _lib.load().cmr_set_mha_variant(variant)
-    try:
-        _mha_case(ops, B, Tq, Tk)
-    finally:
-        _lib.load().cmr_set_mha_variant(old)
+    with _lib.ab() as lib:                                       # the A/B library: same sources + the variant switches
+        old = lib.cmr_set_mha_variant(variant)
+        try:
+            _mha_case(ops, B, Tq, Tk)
+        finally:
+            lib.cmr_set_mha_variant(old)
 
 
 @pytest.mark.parametrize("B,Tq,Tk", [(1, 1400, 1400), (2, 100, 513), (1, 33, 1024), (2, 418, 418)])

@@ -96,12 +96,13 @@ def test_conv3x3_weight_gradient_lds_staged_kernel(ops, B, H, W, cin, cout):
     dw = torch.empty(cout * cin * 9, device=DEV)
     ops.conv3x3_wgrad(xd, dyd, dw)
     close(dw.view(cout, cin, 3, 3), w.grad, 3e-5, "conv wgrad (LDS-staged)")
-    old = _lib.load().cmr_set_wgrad_variant(0)
-    try:
-        dw0 = torch.empty_like(dw)
-        ops.conv3x3_wgrad(xd, dyd, dw0)
-    finally:
-        _lib.load().cmr_set_wgrad_variant(old)
+    with _lib.ab() as lib:                                       # the A/B library: same sources + the variant switches
+        old = lib.cmr_set_wgrad_variant(0)
+        try:
+            dw0 = torch.empty_like(dw)
+            ops.conv3x3_wgrad(xd, dyd, dw0)
+        finally:
+            lib.cmr_set_wgrad_variant(old)
     assert old == 1
     close(dw, dw0, 2e-5, "LDS-staged vs direct kernel")
     assert not torch.equal(dw, dw0) or B * H * W < 4096          # a different kernel did run (other summation order)
@@ -150,12 +151,13 @@ def test_linear_weight_gradient_lds_staged_kernel(ops, rows, n, k, bias):
     dw0 = rnd(n, k, seed=43)
     outs = []
     for variant in (2, 0):                                       # 2 = staged kernel from 8192 rows on (default: from 65 536)
-        old = _lib.load().cmr_set_linear_wgrad_variant(variant)
-        try:
-            dw, db = d(dw0).clone(), torch.zeros(n, device=DEV)
-            ops.linear_wgrad(dyd, xd, dw, dw.stride(0), accumulate=True, db=db if bias else None)
-        finally:
-            _lib.load().cmr_set_linear_wgrad_variant(1)
+        with _lib.ab() as lib:
+            lib.cmr_set_linear_wgrad_variant(variant)
+            try:
+                dw, db = d(dw0).clone(), torch.zeros(n, device=DEV)
+                ops.linear_wgrad(dyd, xd, dw, dw.stride(0), accumulate=True, db=db if bias else None)
+            finally:
+                lib.cmr_set_linear_wgrad_variant(1)
         outs.append((dw.cpu(), db.cpu()))
     scale = float(want.abs().max())
     for dw, db in outs:
@@ -568,6 +570,38 @@ def test_forty_updates_on_one_minibatch_fit_it():
     last = last.cpu()
     assert torch.isfinite(last).all()
     assert float(last[1]) < 0.3 and float(last[0]) < 0.1 * float(first[0]), (first.tolist(), last.tolist())
+
+
+def test_forty_updates_in_bf16_mode_follow_the_fp32_trajectory():
+    """bf16 training quality beyond two steps (BASELINE configs[2]'s mode: forward, data- and weight-gradient convolutions on the bf16
+    cores): the same 40 updates on the same minibatch from the same initialisation, once in fp32 and once in bf16 mode.  The bf16 run must
+    fit the minibatch like the fp32 run (same bars as test_forty_updates_on_one_minibatch_fit_it), its loss curve must stay within 5 % of
+    the fp32 curve's starting scale at every step, and its FINAL total loss within 5 % of the fp32 run's (plus 1e-3 absolute: the
+    trajectories end at ~0.2 after a ~5.1 start)."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train import AgentUpdate
+    case = "agent_train_small"
+    cfg = C.train_config(case, device=DEV)
+    batch = _to_dev(C.train_inputs(case)[0])
+    curves = {}
+    for mode in ("fp32", "bf16"):
+        torch.manual_seed(0)
+        agent = CMRAgent(cfg).to(DEV)
+        up = AgentUpdate(agent, cfg)
+        ops.CONV_BF16 = mode == "bf16"
+        try:
+            curves[mode] = torch.stack([up.step(batch) for _ in range(40)]).cpu()
+        finally:
+            ops.CONV_BF16 = False
+    f, b = curves["fp32"], curves["bf16"]
+    assert torch.isfinite(b).all()
+    assert float(b[-1, 1]) < 0.3 and float(b[-1, 0]) < 0.1 * float(b[0, 0]), (b[0].tolist(), b[-1].tolist())
+    dev_curve = float((b[:, 0] - f[:, 0]).abs().max())
+    print("  bf16 vs fp32 over 40 updates: first %.4f / %.4f, last %.4f / %.4f, max |d loss| %.4f" % (
+        float(b[0, 0]), float(f[0, 0]), float(b[-1, 0]), float(f[-1, 0]), dev_curve))
+    assert dev_curve <= 0.05 * float(f[0, 0]), dev_curve
+    assert abs(float(b[-1, 0]) - float(f[-1, 0])) <= 0.05 * abs(float(f[-1, 0])) + 1e-3, (float(b[-1, 0]), float(f[-1, 0]))
 
 
 def test_buffer_ordering_quirk_on_device():

@@ -23,10 +23,18 @@ def main():
     with torch.enable_grad():
         ol, og, _ = TO.agent_forward_backward({k: x.clone() for k, x in sd0.items()}, batch, cfg_c, True)
     gmax = max(float(g.norm()) for g in og.values())
-    for label, conv, wg in (("fp32", False, False), ("bf16 convolutions, fp32 weight gradients", True, False), ("bf16 convolutions and weight gradients", True, True)):
+    # (label, bf16 mode, bf16 weight gradients, bf16 forward, bf16 backward, earliest data-gradient convolutions kept in fp32)
+    for label, conv, wg, fw, bw, early in (("fp32", False, False, True, True, 0),
+                                           ("bf16 convolutions, fp32 weight gradients", True, False, True, True, 0),
+                                           ("bf16 convolutions and weight gradients", True, True, True, True, 0),
+                                           ("bf16 FORWARD only (data and weight gradients fp32)", True, True, True, False, 0),
+                                           ("bf16 BACKWARD only (forward fp32)", True, True, False, True, 0),
+                                           ("bf16, the two earliest data gradients in fp32", True, True, True, True, 2),
+                                           ("bf16, the four earliest data gradients in fp32", True, True, True, True, 4)):
         agent = CMRAgent(cfg_d)
         load_checked(agent, hashfill.make_state_dict(specs["agent"], C.AGENT_TAG))
         up = AgentUpdate(agent.to(dev), cfg_d)
+        up.bf16_forward, up.bf16_backward, up.fp32_early_dgrads = fw, bw, early
         ops.CONV_BF16, ops.WGRAD_BF16 = conv, wg
         try:
             up.forward_backward({k: x.to(dev) for k, x in batch.items()})

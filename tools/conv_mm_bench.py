@@ -14,7 +14,7 @@ SHAPES = [(8, 88, 304, 128, 128), (8, 88, 304, 64, 128), (8, 44, 152, 128, 128),
 def main():
     from cmr_agent_amd import ops, _lib
     from cmr_agent_amd.models._pack import conv_bf16_frags
-    lib = _lib.load()
+    lib = _lib.use_ab()          # the A/B library (kernel-variant switches)
     for B, H, W, cin, cout in SHAPES:
         w = torch.randn(cout, cin, 3, 3, device="cuda") / math.sqrt(9 * cin)
         b = torch.randn(cout, device="cuda")

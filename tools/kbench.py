@@ -96,9 +96,9 @@ def bench_vit(rows_x, rows_y, B, reps):
     q, kv = ops.ln64_linear(x, wq, bq, g, b, 1e-6, y, wkv, bkv)
     t3 = timeit(lambda: ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, rows_x // B, rows_y // B), reps)
     from cmr_agent_amd import _lib
-    old = _lib.load().cmr_set_mha_variant(0)
+    old = _lib.use_ab().cmr_set_mha_variant(0)
     t3v = timeit(lambda: ops.mha(q, kv[:, 0:64], kv[:, 64:128], B, rows_x // B, rows_y // B), reps)
-    _lib.load().cmr_set_mha_variant(old)
+    _lib.use_ab().cmr_set_mha_variant(old)
     t4 = timeit(lambda: ops.vit_out_ffn(q, x, wo, bo, (g, b), 1e-6, w1, b1, w2, b2), reps)
     print("vit block rows %d / %d: ln+qkv %.1f us  ln+q,kv %.1f us  mha %.1f us (vector-ALU kernel %.1f us)  out+ffn %.1f us" % (rows_x, rows_y, t1, t2, t3, t3v, t4))
     from cmr_agent_amd.models._pack import frag_pack_bf16 as fb

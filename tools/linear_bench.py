@@ -17,15 +17,15 @@ def main():
         out = torch.empty(rows, n_out, device=dev)
         by = 4.0 * rows * (64 + n_out * (2 if res else 1))
         t = {}
-        _lib.load().cmr_set_linear_wreg(0, 0)
+        _lib.use_ab().cmr_set_linear_wreg(0, 0)
         for on in (1, 0):
-            _lib.load().cmr_set_linear_row64(on)
+            _lib.use_ab().cmr_set_linear_row64(on)
             t[on] = timeit(lambda: ops.linear(x, w, b, res=r, act=act, act_param=0.2, out=out), 20)
-        _lib.load().cmr_set_linear_row64(0)
-        _lib.load().cmr_set_linear_wreg(1, 1)
+        _lib.use_ab().cmr_set_linear_row64(0)
+        _lib.use_ab().cmr_set_linear_wreg(1, 1)
         t[2] = timeit(lambda: ops.linear(x, w, b, res=r, act=act, act_param=0.2, out=out), 20)
-        _lib.load().cmr_set_linear_row64(1)
-        _lib.load().cmr_set_linear_wreg(1, 65537)
+        _lib.use_ab().cmr_set_linear_row64(1)
+        _lib.use_ab().cmr_set_linear_wreg(1, 65537)
         print("linear %6d x 64 -> %2d act %d res %d : row-streaming %6.1f us = %5.2f TB/s | generic %6.1f us = %5.2f TB/s | register weights %6.1f us = %5.2f TB/s   (%.1f MB algorithmic)" % (
             rows, n_out, act, res, t[1], by / t[1] / 1e6, t[0], by / t[0] / 1e6, t[2], by / t[2] / 1e6, by / 1e6))
 

@@ -15,9 +15,9 @@ def main():
         dw, db = torch.empty(n, k, device=dev), torch.empty(n, device=dev)
         t = {}
         for v in (1, 0):
-            _lib.load().cmr_set_linear_wgrad_variant(v)
+            _lib.use_ab().cmr_set_linear_wgrad_variant(v)
             t[v] = timeit(lambda: ops.linear_wgrad(dy, x, dw, k, db=db), 10)
-        _lib.load().cmr_set_linear_wgrad_variant(1)
+        _lib.use_ab().cmr_set_linear_wgrad_variant(1)
         by = 4.0 * rows * (n + k)
         print("linear_wgrad %7d x (%3d, %3d): LDS-staged %6.1f us = %5.2f TB/s, %5.1f TFLOP/s | direct %6.1f us = %5.2f TB/s" % (
             rows, n, k, t[1], by / t[1] / 1e6, 2.0 * rows * n * k / t[1] / 1e6, t[0], by / t[0] / 1e6))

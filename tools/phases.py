@@ -28,7 +28,7 @@ def main():
     from cmr_agent_amd import _lib
     for a in sys.argv:
         if a.startswith("cus="):
-            _lib.load().cmr_set_conv_cu_budget(int(a[4:]))
+            ops._policy.cu_budget = int(a[4:])          # `cu_budget` argument of every convolution call from here on
     dev = torch.device("cuda", 0); w = BM.WORKLOAD
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
     geo, agent, _ = BM.load_models(cfg, dev)

@@ -6,7 +6,7 @@ from cmr_agent_amd import ops, _lib
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 524288
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 wreg = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-_lib.load().cmr_set_linear_wreg(wreg, 1)
+_lib.use_ab().cmr_set_linear_wreg(wreg, 1)
 x, w, b = torch.randn(rows, 64, device="cuda"), torch.randn(n, 64, device="cuda") * 0.1, torch.randn(n, device="cuda")
 out = torch.empty(rows, n, device="cuda")
 for _ in range(6):

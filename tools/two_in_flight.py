@@ -20,7 +20,7 @@ def main():
     a = ap.parse_args()
     ops.CONV_BF16 = a.dtype == "bf16"
     from cmr_agent_amd import _lib
-    _lib.load().cmr_set_wino_variant(a.wino)
+    _lib.use_ab().cmr_set_wino_variant(a.wino)
     dev = torch.device("cuda", 0); w = BM.WORKLOAD
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device=dev, action_num=w["steps"])
     geo, agent, _ = BM.load_models(cfg, dev)

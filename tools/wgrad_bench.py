@@ -14,9 +14,9 @@ def main():
         fl = 2.0 * 9 * ci * co * B * H * W
         t = {}
         for v in (1, 0):
-            _lib.load().cmr_set_wgrad_variant(v)
+            _lib.use_ab().cmr_set_wgrad_variant(v)
             t[v] = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw), 10)
-        _lib.load().cmr_set_wgrad_variant(1)
+        _lib.use_ab().cmr_set_wgrad_variant(1)
         ops.CONV_BF16 = True
         tb = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw), 10)
         ops.CONV_BF16 = False

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cmr_agent_amd import ops, _lib
 from kbench import timeit
 DEV = "cuda"
-lib = _lib.load()
+lib = _lib.use_ab()          # the A/B library (kernel-variant switches)
 torch.manual_seed(0)
 for (B, H, W, ci, co, res, post, pool) in [(8, 352, 1216, 64, 64, True, False, 1), (8, 176, 608, 64, 64, True, False, 1), (8, 88, 304, 128, 128, True, False, 1),
                                            (8, 88, 304, 128, 64, False, True, 1), (8, 88, 304, 64, 64, True, False, 1), (3, 301, 407, 64, 128, False, False, 1),
