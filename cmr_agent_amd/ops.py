@@ -1191,11 +1191,99 @@ def mha_dropout(q, k, v, B, Tq, Tk, p, seed, site):
     return out
 
 
-def mha_dropout_bwd(q, k, v, o, dout, B, Tq, Tk, p, seed, site):
-    dq, dk, dv = (torch.empty((B * Tq, 64), dtype=f32, device=q.device), torch.empty((B * Tk, 64), dtype=f32, device=q.device),
-                  torch.empty((B * Tk, 64), dtype=f32, device=q.device))
+def mha_dropout_bwd(q, k, v, o, dout, B, Tq, Tk, p, seed, site, dq=None, dk=None, dv=None):
+    """dq / dk / dv: optional row views to write into (e.g. the column blocks of one [rows, 192] buffer)."""
+    mk = lambda t, r: torch.empty((r, 64), dtype=f32, device=q.device) if t is None else _rows(t)
+    dq, dk, dv = mk(dq, B * Tq), mk(dk, B * Tk), mk(dv, B * Tk)
     ws = torch.empty((B * Tq * 16,), dtype=f32, device=q.device)
     _lib.call("cmr_mha_dropout_bwd_f32", _p(_rows(q)), _ld(q), _p(_rows(k)), _ld(k), _p(_rows(v)), _ld(v), _p(_rows(o)), _ld(o), _p(_rows(dout)),
               _ld(dout), _p(dq), _ld(dq), 0, _p(dk), _ld(dk), 0, _p(dv), _ld(dv), 0, _p(ws), ws.numel() * 4, B, Tq, Tk, float(p), _p(seed),
               int(site), _stream())
     return dq, dk, dv
+
+
+# ---- train-mode transformer block in fused launches (csrc/vit_train.hip, csrc/wgrad_group.hip; include/cmr_hip.h) --------------------
+
+def pack_frags(src, dst, table, nslots, max_elements):
+    """dst <- MFMA-fragment-ordered copies of matrix slots of the flat parameter buffer src (table: train/fragpack.py)."""
+    _lib.call("cmr_pack_frags_f32", _p(src), _p(dst), _p(table), int(nslots), int(max_elements), _stream())
+    return dst
+
+
+def _drop_args(p_proj, p_mlp, seed, sites):
+    if seed is None:
+        return 0.0, 0.0, None, 0, 0, 0
+    if seed.dtype != torch.int64 or not seed.is_cuda:
+        raise ValueError("dropout seed must be an int64 device tensor")
+    return float(p_proj), float(p_mlp), seed.data_ptr(), int(sites[0]), int(sites[1]), int(sites[2])
+
+
+def vit_out_ffn16_train(ctx, x, wo_f16, bo, ln, eps, w1_f16, b1, w2_f16, b2, p_proj=0.0, p_mlp=0.0, seed=None, sites=(0, 0, 0)):
+    """Train-mode tail of a transformer block -> (out, x1); sites = dropout site numbers (proj, act, fc2)."""
+    rows = x.shape[0]
+    out = torch.empty((rows, 64), dtype=f32, device=x.device)
+    x1 = torch.empty((rows, 64), dtype=f32, device=x.device)
+    pp, pm, sp, s0, s1, s2 = _drop_args(p_proj, p_mlp, seed, sites)
+    _lib.call("cmr_vit_out_ffn16_train_f32", _p(_rows(ctx)), _ld(ctx), _p(_rows(x)), _ld(x), _p(wo_f16), _p(bo), _p(ln[0]), _p(ln[1]), float(eps),
+              _p(w1_f16), _p(b1), _p(w2_f16), _p(b2), _p(out), _ld(out), _p(x1), _ld(x1), rows, pp, pm, sp, s0, s1, s2, _stream())
+    return out, x1
+
+
+def vit_ffn_bwd16(dout, x1, ln, eps, w1_f16, b1, w2t_f16, w1t_f16, wot_f16, p_proj=0.0, p_mlp=0.0, seed=None, sites=(0, 0, 0)):
+    """Backward of vit_out_ffn16_train from d out -> dict(dx1, dctx, gs, du, h, dm, da, lnpart)."""
+    rows, dev = x1.shape[0], x1.device
+    mk = lambda c: torch.empty((rows, c), dtype=f32, device=dev)
+    r = dict(dx1=mk(64), dctx=mk(64), gs=mk(1024), du=mk(1024), h=mk(64), dm=mk(64), da=mk(64),
+             lnpart=torch.empty(((rows + 15) // 16, 128), dtype=f32, device=dev))
+    pp, pm, sp, s0, s1, s2 = _drop_args(p_proj, p_mlp, seed, sites)
+    _lib.call("cmr_vit_ffn_bwd16_f32", _p(_rows(dout)), _ld(dout), _p(_rows(x1)), _ld(x1), _p(ln[0]), _p(ln[1]), float(eps), _p(w1_f16), _p(b1),
+              _p(w2t_f16), _p(w1t_f16), _p(wot_f16), _p(r["dx1"]), 64, _p(r["dctx"]), 64, _p(r["gs"]), _p(r["du"]), _p(r["h"]), _p(r["dm"]),
+              _p(r["da"]), _p(r["lnpart"]), rows, pp, pm, sp, s0, s1, s2, _stream())
+    return r
+
+
+def vit_lnqkv_bwd(d_x, wt_f_x, x, res, gamma, beta, eps, d_y=None, wt_f_y=None, y=None):
+    """Backward of LayerNorm + q / k / v projections -> (dx, xn, dy, yn, lnpart); d_x [rows_x, 64 | 192], d_y [rows_y, 128] (cross block)."""
+    dev = x.device
+    rx = x.shape[0]
+    dx, xn = torch.empty((rx, 64), dtype=f32, device=dev), torch.empty((rx, 64), dtype=f32, device=dev)
+    tiles = (rx + 31) // 32
+    dy = yn = None
+    ry = 0
+    if d_y is not None:
+        ry = y.shape[0]
+        dy, yn = torch.empty((ry, 64), dtype=f32, device=dev), torch.empty((ry, 64), dtype=f32, device=dev)
+        tiles += (ry + 31) // 32
+    lnpart = torch.empty((tiles, 128), dtype=f32, device=dev)
+    _lib.call("cmr_vit_lnqkv_bwd_f32", _p(_rows(d_x)), _ld(d_x), d_x.shape[1], _p(wt_f_x), _p(_rows(x)), _ld(x), _p(res), _ld(res) if res is not None else 0,
+              _p(dx), 64, _p(xn), 64, rx, _p(d_y), _ld(d_y) if d_y is not None else 0, d_y.shape[1] if d_y is not None else 0, _p(wt_f_y),
+              _p(y), _ld(y) if y is not None else 0, _p(dy), 64, _p(yn), 64, ry, _p(gamma), _p(beta), float(eps), _p(lnpart), _stream())
+    return dx, xn, dy, yn, lnpart
+
+
+def wgrad_group(problems, vectors=()):
+    """problems: [(dy, x, dw, accumulate, db | None, accumulate_db)] with dy [rows, n], x [rows, k] row views and dw [n, k] / db [n] views of
+    the gradient bucket; vectors: [(part [nparts, 2 len], out_a [len], out_b [len], accumulate)].  One call, two kernels."""
+    import numpy as np
+    if not 0 < len(problems) + len(vectors) or len(problems) > 8 or len(vectors) > 4:
+        raise ValueError("wgrad_group: at most 8 problems and 4 vector jobs per call")
+    desc = []
+    for dy, x, dw, acc, db, accb in problems:
+        _rows(dy), _rows(x)
+        n, k = dw.shape
+        if dy.shape[0] != x.shape[0] or dy.shape[1] < n or x.shape[1] < k or dw.stride(1) != 1:
+            raise ValueError("wgrad_group: operand shapes %s / %s vs gradient %s" % (tuple(dy.shape), tuple(x.shape), tuple(dw.shape)))
+        desc += [dy.data_ptr(), _ld(dy), n, x.data_ptr(), _ld(x), k, dy.shape[0], dw.data_ptr(), dw.stride(0), int(bool(acc)),
+                 db.data_ptr() if db is not None else 0, int(bool(accb))]
+    for part, oa, ob, acc in vectors:
+        if part.dim() != 2 or not part.is_contiguous() or part.shape[1] != 2 * oa.numel() or ob.numel() != oa.numel():
+            raise ValueError("wgrad_group: vector job wants part [nparts, 2 len]")
+        desc += [part.data_ptr(), part.shape[0], oa.numel(), oa.data_ptr(), ob.data_ptr(), int(bool(acc))]
+    d = np.asarray(desc, dtype=np.int64)
+    nb = _lib.load().cmr_wgrad_group_workspace_bytes(d.ctypes.data, len(problems), len(vectors))
+    if nb < 0:
+        raise ValueError("wgrad_group: bad descriptor")
+    dev = (problems[0][0] if problems else vectors[0][0]).device
+    ws = _ws(nb, dev)
+    _lib.call("cmr_wgrad_group_f32", d.ctypes.data, len(problems), len(vectors), _p(ws), nb, _stream(),
+              work_extra={"_group": [(dy.shape[0], dw.shape[0], dw.shape[1]) for dy, _, dw, _, _, _ in problems]})

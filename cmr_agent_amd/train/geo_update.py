@@ -20,6 +20,7 @@ import torch.nn as nn
 from .. import ops
 from ..models.PointViT import PointGeometry
 from .flatbucket import FlatBucket
+from .fragpack import FragPack
 from .optim import FlatOptimizer
 from .tape import Tape, Var
 
@@ -45,6 +46,14 @@ class GeoUpdate:
         self._pos2d = {}
         self._pos1d = {}
         self._graph = None
+        # operands of the fused train-mode layer kernels, re-packed from the bucket once per step (train/fragpack.py)
+        enc = model.encoder_decoder.encoder
+        blocks = (list(enc.img_transformer.sa_encoder_layers) + list(enc.pt_transformer.sa_encoder_layers) + list(enc.p2i_ca_layers)
+                  + list(enc.i2p_ca_layers) + list(enc.img_sa_layers) + list(enc.pt_sa_layers))
+        try:
+            self.frags = FragPack(self.bucket, blocks)
+        except ValueError:
+            self.frags = None                                     # other widths: the op-by-op composition
         # dropout: one int64 seed on the device, advanced once per step OUTSIDE the captured graph (the kernels read it through a pointer,
         # so replays draw fresh masks); ranks start from different seeds
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -74,8 +83,15 @@ class GeoUpdate:
             y = t.add_const(y, post, post.shape[0])
         return y, d2
 
+    FUSED_VIT = True        # transformer blocks on the fused train-mode kernels (Tape.vit_block); False: one launch per reference op
+
     def _vit_block(self, t, x, y, blk, B, tx, ty):
         """ImageViT.py:144-158 (y None) / IMGPCEncoder.py:90-102 (cross: both inputs through the SAME attention_norm)."""
+        if self.FUSED_VIT and self.frags is not None:
+            return t.vit_block(x, y, blk, B, tx, ty, self.frags)
+        return self._vit_block_ops(t, x, y, blk, B, tx, ty)
+
+    def _vit_block_ops(self, t, x, y, blk, B, tx, ty):
         at = blk.attn
         xn = t.layernorm(x, blk.attention_norm, blk.LN_EPS)
         yn = xn if y is None else t.layernorm(y, blk.attention_norm, blk.LN_EPS)
@@ -270,6 +286,8 @@ class GeoUpdate:
         self.bucket.check_attached()
         self.bucket.grads.zero_()                           # every used slice is overwritten; frozen / unused ones must read 0
         t = Tape(self.bucket, self.drop_seed)
+        if self.FUSED_VIT and self.frags is not None:
+            self.frags.refresh()
         o = self._forward(t, data)
         B, N, h, w = o["B"], o["N"], o["h"], o["w"]
         dev = self.bucket.params.device

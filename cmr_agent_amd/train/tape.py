@@ -362,6 +362,87 @@ class Tape:
         self.nodes.append(bwd)
         return y
 
+    # ---- fused layers ---------------------------------------------------------------------------------------------------------
+    def vit_block(self, x, y, blk, B, tx, ty, frags):
+        """Pre-LN transformer block (ImageViT.py:144-158; y: the cross block of IMGPCEncoder.py:90-102, both inputs through the SAME
+        attention_norm) as ONE tape op on the fused train-mode kernels: 3 forward launches, 4 backward calls (csrc/vit_train.hip).  Same
+        arithmetic, same dropout sites in the same order (attention probabilities, projection, MLP activation, MLP output) as the
+        op-by-op composition in GeoUpdate._vit_block_ops."""
+        at, ffn = blk.attn, blk.ffn
+        f = frags.of(blk)
+        eps = blk.LN_EPS
+        g1, b1n = self.W(blk.attention_norm.weight), self.W(blk.attention_norm.bias)
+        g2, b2n = self.W(blk.ffn_norm.weight), self.W(blk.ffn_norm.bias)
+        seed = self.drop_seed
+        p_attn, p_proj, p_mlp = (at.attn_dropout.p, at.proj_dropout.p, ffn.dropout.p) if seed is not None else (0.0, 0.0, 0.0)
+
+        def site(p):
+            if p <= 0.0:
+                return 0
+            s_ = self._site
+            self._site += 1
+            return s_
+        s_attn, s_proj = site(p_attn), site(p_proj)
+        s_act, s_fc2 = site(p_mlp), site(p_mlp)
+        sites = (s_proj, s_act, s_fc2)
+        tk = tx if y is None else ty
+        if y is None:
+            qkv = ops.ln64_linear(x.v, f["qkv_f"], f["qkv_b"], g1, b1n, eps)
+            q, k, v = qkv[:, 0:64], qkv[:, 64:128], qkv[:, 128:192]
+        else:
+            q, kv = ops.ln64_linear(x.v, f["q_f"], f["q_b"], g1, b1n, eps, y.v, f["kv_f"], f["kv_b"])
+            k, v = kv[:, 0:64], kv[:, 64:128]
+        if p_attn > 0.0:
+            ctx = ops.mha_dropout(q, k, v, B, tx, tk, p_attn, seed, s_attn)
+        else:
+            ctx = ops.mha(q, k, v, B, tx, tk, libm_exp=True)
+        drop_seed = seed if (p_proj > 0.0 or p_mlp > 0.0) else None
+        out, x1 = ops.vit_out_ffn16_train(ctx, x.v, f["wo_f"], self.W(at.out.bias), (g2, b2n), eps, f["w1_f"], self.W(ffn.fc1.bias), f["w2_f"],
+                                          self.W(ffn.fc2.bias), p_proj, p_mlp, drop_seed, sites)
+        yv = Var(out)
+
+        def bwd():
+            if yv.g is None:
+                return
+            dev = out.device
+            r = ops.vit_ffn_bwd16(yv.g, x1, (g2, b2n), eps, f["w1_f"], self.W(ffn.fc1.bias), f["w2T_f"], f["w1T_f"], f["woT_f"], p_proj, p_mlp,
+                                  drop_seed, sites)
+            R = x.v.shape[0]
+            if y is None:
+                dqkv = torch.empty((R, 192), dtype=f32, device=dev)
+                dq, dk, dv = dqkv[:, 0:64], dqkv[:, 64:128], dqkv[:, 128:192]
+            else:
+                dq = torch.empty((R, 64), dtype=f32, device=dev)
+                dkv = torch.empty((y.v.shape[0], 128), dtype=f32, device=dev)
+                dk, dv = dkv[:, 0:64], dkv[:, 64:128]
+            if p_attn > 0.0:
+                ops.mha_dropout_bwd(q, k, v, ctx, r["dctx"], B, tx, tk, p_attn, seed, s_attn, dq=dq, dk=dk, dv=dv)
+            else:
+                ops.mha_bwd(q, k, v, ctx, r["dctx"], B, tx, tk, dq=dq, dk=dk, dv=dv)
+            if y is None:
+                dx, xn, _, _, ln1 = ops.vit_lnqkv_bwd(dqkv, f["qkvT_f"], x.v, r["dx1"], g1, b1n, eps)
+                yn = xn
+            else:
+                dx, xn, dy, yn, ln1 = ops.vit_lnqkv_bwd(dq, f["qT_f"], x.v, r["dx1"], g1, b1n, eps, dkv, f["kvT_f"], y.v)
+                self.give(y, dy, owned=True)
+            self.give(x, dx, owned=True)
+            probs = []
+            for dyv, xv, lin in ((r["dm"], r["gs"], ffn.fc2), (r["du"], r["h"], ffn.fc1), (r["da"], ctx, at.out), (dq, xn, at.query),
+                                 (dk, yn, at.key), (dv, yn, at.value)):
+                gw, acc = self.G(lin.weight)
+                gb, accb = self.G(lin.bias)
+                probs.append((dyv, xv, gw, acc, gb, accb))
+            vecs = []
+            for part, ln in ((r["lnpart"], blk.ffn_norm), (ln1, blk.attention_norm)):
+                gg, accg = self.G(ln.weight)
+                gb, accb = self.G(ln.bias)
+                if accg != accb:
+                    raise RuntimeError("vit_block: weight and bias of one LayerNorm must be used together")
+                vecs.append((part, gg, gb, accg))
+            ops.wgrad_group(probs, vecs)
+        self.nodes.append(bwd)
+        return yv
+
     # ---- convolutions: x is the row view of a contiguous NHWC map (B, H, W given) -----------------------------------------
     def conv3x3(self, x, dims, conv, stride=1):
         """nn.Conv2d(3x3, padding 1, stride 1|2) with bias, no activation, Cin in {64, 128} -> (Var, (B, Ho, Wo))."""

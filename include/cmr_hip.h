@@ -636,6 +636,54 @@ int cmr_mha_dropout_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t
                             int64_t lddk, int acc_dk, float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq,
                             int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream);
 
+/* ---- train-mode transformer block in fused launches (round 4; reference models/ImageViT.py:61-158, PointViT.py:96-183,
+ * IMGPCEncoder.py:14-102 under model.train(), Train_Geo.py:166-174).  Replaces, per block and step, 16 forward and ~20 backward calls of
+ * the op-level entry points above by 3 + 4: cmr_ln64_linear_f32, cmr_mha_dropout_f32, cmr_vit_out_ffn16_train_f32 forward;
+ * cmr_vit_ffn_bwd16_f32, cmr_mha_dropout_bwd_f32, cmr_vit_lnqkv_bwd_f32, cmr_wgrad_group_f32 backward.  Dropout masks are those of
+ * cmr_dropout_f32 (same (seed, site, row * width + column) -> same mask), p = 0 or seed null: no dropout. ---- */
+/* Weights from the flat parameter bucket `src` into MFMA fragment order in `dst`, every slot of a step in ONE launch.  table: device
+ * [nslots][10] int64 {src offset, n, k (shape of this slot's block of the packed matrix W'), row stride of the stored matrix, dst offset of
+ * W' (multiple of 4), kind, transpose (the block is the transpose of the stored [k][n] matrix), elements (n k; kind 2: n rounded up to 4),
+ * ktot (columns of the whole W'), koff (first column of the block inside W'; row blocks go through the dst offset)}; kind 0 = 32x32x2
+ * fragments (_pack.frag_pack), 1 = 16x16x4 fragments (_pack.frag_pack16), 2 = plain copy of n floats.  max_elements = the largest
+ * `elements`.  A stacked matrix ([Wq; Wk; Wv], or its transpose for the data gradient) is several slots writing one W'. */
+int cmr_pack_frags_f32(const float* src, float* dst, const int64_t* table, int nslots, int64_t max_elements, hipStream_t stream);
+/* x1 = x + drop_proj(ctx Wo^T + bo);  out = x1 + drop_fc2(W2 drop_act(gelu(W1 LN(x1) + b1)) + b2)   (ImageViT.py:103-108, 128-133, 150-157).
+ * cmr_vit_out_ffn16_f32 with the three nn.Dropout sites applied in place and x1 written for the backward.  Weights: frag16 fragments. */
+int cmr_vit_out_ffn16_train_f32(const float* ctx, int64_t ldc, const float* x, int64_t ldx, const float* wo_f16, const float* bo,
+                                const float* ln_g, const float* ln_b, float eps, const float* w1_f16, const float* b1,
+                                const float* w2_f16, const float* b2, float* out, int64_t ldo, float* x1, int64_t ldx1, int64_t rows,
+                                float p_proj, float p_mlp, const int64_t* seed, int64_t site_proj, int64_t site_act, int64_t site_fc2,
+                                hipStream_t stream);
+/* Backward of that launch from d out: recomputes LN(x1), the fc1 pre-activations and the masks from x1;
+ *   dm = drop_fc2(d out);  d hidden = dm W2;  du = drop_act(d hidden) gelu'(u);  d LN = du W1;  d x1 = d out + LayerNorm_bwd(d LN);
+ *   da = drop_proj(d x1);  d ctx = da Wo.
+ * Writes d x1, d ctx and the operands of the weight gradients: gs [rows][1024] (hidden activations as fc2 saw them), du [rows][1024],
+ * h = LN(x1) [rows][64], dm [rows][64], da [rows][64]; lnpart [ceil(rows / 16)][128] = per-tile sums of (d gamma | d beta) of ffn_norm
+ * (summed by cmr_wgrad_group_f32).  w2t / w1t / wot: frag16 fragments of W2^T, W1^T, Wo^T (cmr_pack_frags_f32, transpose = 1). */
+int cmr_vit_ffn_bwd16_f32(const float* dout, int64_t lddo, const float* x1, int64_t ldx1, const float* ln_g, const float* ln_b, float eps,
+                          const float* w1_f16, const float* b1, const float* w2t_f16, const float* w1t_f16, const float* wot_f16,
+                          float* dx1, int64_t lddx1, float* dctx, int64_t lddc, float* gs, float* du, float* h, float* dm, float* da,
+                          float* lnpart, int64_t rows, float p_proj, float p_mlp, const int64_t* seed, int64_t site_proj,
+                          int64_t site_act, int64_t site_fc2, hipStream_t stream);
+/* Backward of attention_norm + the q / k / v projections for up to two row sets in one launch (self block: x with d = [dq | dk | dv],
+ * k = 192; cross block: x with dq, k = 64, and y with [dk | dv], k = 128; IMGPCEncoder.py:93-94: both through the SAME LayerNorm):
+ *   d LN(x) = d W_cat (W_cat = the projections' weights stacked, passed as frag32 fragments of W_cat^T);  dx = LayerNorm_bwd(d LN(x)) (+ res,
+ * the gradient arriving on the residual stream; x set only).  Also writes LN(x) / LN(y) (operands of the projections' weight gradients)
+ * and lnpart [tiles_x + tiles_y][128] (32-row tiles; per-tile sums of d gamma | d beta). */
+int cmr_vit_lnqkv_bwd_f32(const float* d_x, int64_t ldd_x, int k_x, const float* wt_f_x, const float* x, int64_t ldx, const float* res,
+                          int64_t ldres, float* dx, int64_t lddx, float* xn, int64_t ldxn, int64_t rows_x, const float* d_y,
+                          int64_t ldd_y, int k_y, const float* wt_f_y, const float* y, int64_t ldy, float* dy, int64_t lddy, float* yn,
+                          int64_t ldyn, int64_t rows_y, const float* gamma, const float* beta, float eps, float* lnpart,
+                          hipStream_t stream);
+/* Weight / bias gradients of up to 8 row-map linears (dw [n][k] (+)= dy^T x, db (+)= column sums of dy: cmr_linear_wgrad_f32's contract)
+ * and up to 4 "vector jobs" (out_a | out_b [len] (+)= sums over nparts rows of part [nparts][2 len]: the LayerNorm parameter gradients the
+ * row kernels left per tile) in ONE call of two kernels.  desc is a HOST array: nprob x 12 int64 {dy, lddy, n, x, ldx, k, rows, dw, lddw,
+ * accumulate, db (0: none), accumulate_db}, then nvec x 6 int64 {part, nparts, len, out_a, out_b, accumulate}; pointers as integers.
+ * Deterministic (fixed slices, fixed summation order, no atomics). */
+int64_t cmr_wgrad_group_workspace_bytes(const int64_t* desc, int nprob, int nvec);
+int cmr_wgrad_group_f32(const int64_t* desc, int nprob, int nvec, void* ws, int64_t ws_bytes, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
