@@ -157,15 +157,20 @@ def test_geo_update_matches_oracle_and_reference_fixture():
         stable_n, total_n = stable_n + int(stable.sum()), total_n + stable.numel()
     print("  one Adam step: %.1f %% of %d weights sign-stable, all within 2e-5; zero-gradient tensors: %s"
           % (100.0 * stable_n / total_n, total_n, ", ".join(zero_grad[:40])))
-    assert stable_n >= 0.3 * total_n, (stable_n, total_n)
+    assert stable_n >= 0.9 * total_n, (stable_n, total_n)             # measured: 94.8 %
     hist.append({k: float(v) for k, v in up2.step(_to_dev(batches[1])).items()})
     torch.cuda.synchronize()
     osd, ohist = TO.geo_adam_train(sd0, batches, cfg, True)
+    # free-running losses: the total within 3e-4 relative; its three components within 1e-3 -- step two sees weights of which ~5 % (the
+    # entries at noise level above) sit 2 lr from the oracle's on either side, and which ones do is rounding noise: the op-by-op tape lands
+    # 1.6e-4 from the oracle on img_overlap_loss, the fused transformer blocks 3.9e-4, with the TOTAL loss at 1.0e-4 / 7.7e-6 relative
+    # (profiles/r04_geo_fused_ab.txt: both paths have the same step-0 gradient errors); the sharp statements are the ones above
     for i in range(len(batches)):
         for k in C.LOSS_KEYS:
             want, ref = float(fx["step%d/%s" % (i, k)]["sample"][0]), float(ohist[i][k])
-            assert abs(hist[i][k] - ref) <= 3e-4 * max(1.0, abs(ref)), (i, k, hist[i][k], ref)
-            assert abs(hist[i][k] - want) <= 3e-4 * max(1.0, abs(want)), (i, k, hist[i][k], want)
+            tol = 3e-4 if (i == 0 or k == "loss") else 1e-3
+            assert abs(hist[i][k] - ref) <= tol * max(1.0, abs(ref)), (i, k, hist[i][k], ref)
+            assert abs(hist[i][k] - want) <= tol * max(1.0, abs(want)), (i, k, hist[i][k], want)
     sd2 = {k: x.detach().cpu() for k, x in model2.state_dict().items()}
     lr = cfg.lr
     moved, close_n, all_n = 0.0, 0, 0

@@ -25,10 +25,12 @@ def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
     return torch.rand(*shape, generator=g) * (hi - lo) + lo
 
 
-def close(got, ref, rtol, name):
+def close(got, ref, rtol, name, floor=1e-6):
+    """floor: lower bound of the scale (attn.key.bias has a ZERO true gradient -- softmax is invariant to a constant added to every score of
+    a query -- so both sides hold rounding noise; such tensors are judged against the largest parameter gradient of the block)."""
     got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
-    scale = max(float(ref.abs().max()), 1e-6)
+    scale = max(float(ref.abs().max()), floor)
     err = float((got - ref).abs().max())
     assert err <= rtol * scale, "%s: max|d| %.3e vs scale %.3e" % (name, err, scale)
 
@@ -84,8 +86,9 @@ def test_fused_block_equals_the_op_by_op_block(B, tx, ty, cross, dropout):
     close(dx1, dx0, 5e-5, "dx")
     if cross:
         close(dy1, dy0, 5e-5, "dy")
+    gmax = max(float(g.abs().max()) for g in g0.values())
     for n in g0:
-        close(g1[n], g0[n], 1e-4, "grad " + n)
+        close(g1[n], g0[n], 1e-4, "grad " + n, floor=1e-2 * gmax)
     assert float(g0["ffn.fc1.weight"].abs().max()) > 0 and float(g0["attn.key.weight"].abs().max()) > 0
 
 
@@ -118,8 +121,9 @@ def test_fused_block_against_float64_autograd(cross):
     close(dx1, xd.grad, 5e-5, "dx")
     if cross:
         close(dy1, yd.grad, 5e-5, "dy")
+    gmax = max(float(P[n].grad.abs().max()) for n in P)
     for n in P:
-        close(g1[n], P[n].grad, 1e-4, "grad " + n)
+        close(g1[n], P[n].grad, 1e-4, "grad " + n, floor=1e-2 * gmax)
 
 
 def test_fragment_packing_is_the_inference_packers_layout():
@@ -163,14 +167,16 @@ def test_grouped_weight_gradient(rows):
         w = dyf[:, :n].double().t() @ xf[:, :k].double() + (dw0[:, :k].cpu().double() if acc else 0)
         b = dyf[:, :n].double().sum(0) + (db0.cpu().double() if acc else 0)
         want.append((w, b))
-    part = rnd(37, 128, seed=99).to(DEV)
+    part, part2 = rnd(37, 128, seed=99).to(DEV), rnd(5, 128, seed=98).to(DEV)
     oa, ob = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
-    ops.wgrad_group(probs, [(part, oa, ob, False), (part, ob, oa, True)])
+    oc0, od0 = rnd(64, seed=97).to(DEV), rnd(64, seed=96).to(DEV)
+    oc, od = oc0.clone(), od0.clone()
+    ops.wgrad_group(probs, [(part, oa, ob, False), (part2, oc, od, True)])
     torch.cuda.synchronize()
     for (dy, x, dw, acc, db, _), (w, b) in zip(probs, want):
         close(dw, w, 3e-5, "dw %s" % (tuple(dw.shape),))
         if db is not None:
             close(db, b, 3e-5, "db")
-    s = part.cpu().double().sum(0)
-    close(oa, s[:64] + s[64:], 1e-5, "vector job (second job accumulates the other half onto the first's result)")
-    close(ob, s[64:] + s[:64], 1e-5, "vector job b")
+    s, s2 = part.cpu().double().sum(0), part2.cpu().double().sum(0)
+    close(oa, s[:64], 1e-5, "vector job a"), close(ob, s[64:], 1e-5, "vector job b")
+    close(oc, oc0.cpu().double() + s2[:64], 1e-5, "accumulating vector job a"), close(od, od0.cpu().double() + s2[64:], 1e-5, "accumulating vector job b")
