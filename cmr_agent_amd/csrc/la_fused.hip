@@ -64,8 +64,19 @@ struct LaQueryArgs {
   float* out; int64_t ldo;
   uint32_t rows, L; int B;
   float s, eps, ln_eps;
+  // train mode (TRAIN instance only): what the backward needs, written once per row -- qf = elu(Wq x) + 1, msg (the attention message),
+  // mm = Wm msg (input of LayerNorm 1), d1 = drop(LN1(mm)), hid = drop(relu(W0 [x | d1])) [rows][128], o = drop(W3 hid) (input of
+  // LayerNorm 2) -- and the three nn.Dropout sites of LinearAttention.py:28-34 / :61-70 (counter-based masks of cmr_dropout_f32)
+  float *sv_qf, *sv_msg, *sv_mm, *sv_d1, *sv_hid, *sv_o;
+  const int64_t* seed; uint64_t site_att, site_hid, site_out;
+  uint32_t thr; float ks;
 };
 
+__device__ __forceinline__ float la_drop_mul(uint64_t key, uint64_t idx, uint32_t thr, float ks) {
+  return (uint32_t)cmr_mix64(key ^ idx) >= thr ? ks : 0.f;
+}
+
+template <bool TRAIN>
 __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wq = smem;                              // [64][68]
@@ -113,6 +124,14 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
     *reinterpret_cast<f32x4*>(&Kv[e * 4]) = *reinterpret_cast<const f32x4*>(a.kv + e * 4);
   __syncthreads();
 
+  uint64_t key_att = 0, key_hid = 0, key_out = 0;
+  const bool drop = TRAIN && a.seed != nullptr;
+  if (drop) {
+    const uint64_t sd = (uint64_t)a.seed[0];
+    key_att = cmr_mix64(sd + a.site_att * 0x9E3779B97F4A7C15ull);
+    key_hid = cmr_mix64(sd + a.site_hid * 0x9E3779B97F4A7C15ull);
+    key_out = cmr_mix64(sd + a.site_out * 0x9E3779B97F4A7C15ull);
+  }
   const uint32_t ntiles = (a.rows + 31) / 32;
   for (uint32_t tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
     const uint32_t row = tile * 32 + l31;
@@ -136,6 +155,7 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
         float qo[4], qp[4];                      // this lane's 4 dims of the head (4h..4h+3), the partner's 4
 #pragma unroll
         for (int e = 0; e < 4; ++e) qo[e] = la_elu1(msg[t][4 * qd + e]);
+        if (TRAIN) *reinterpret_cast<f32x4*>(a.sv_qf + (int64_t)row * LA_D + 8 * hd + 4 * h) = f32x4{qo[0], qo[1], qo[2], qo[3]};
 #pragma unroll
         for (int e = 0; e < 4; ++e) qp[e] = la_xhalf(qo[e]);
         // dims in natural order d = 0..7: lane half 0 owns 0..3, half 1 owns 4..7
@@ -161,10 +181,30 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
         for (int e = 0; e < 4; ++e) msg[t][4 * qd + e] = num[e] * z * a.s;
       }
 
-    // ---- merge + LayerNorm 1
+    // ---- merge + LayerNorm 1 (+ dropout)
     f32x16 mrg[2];
     cmr_chain_gemm<2, 8, LA_LD64>(Wm, l31, h, mrg, [&](int kg, int j) { return msg[kg / 4][4 * (kg % 4) + j]; });
+    if (TRAIN) {                                 // (the save buffers hold whole tiles: rows past the end are written, never read)
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const int t = kg / 4, qd = kg % 4;
+        *reinterpret_cast<f32x4*>(a.sv_msg + (int64_t)row * LA_D + 8 * kg + 4 * h) = f32x4{msg[t][4 * qd], msg[t][4 * qd + 1], msg[t][4 * qd + 2], msg[t][4 * qd + 3]};
+        *reinterpret_cast<f32x4*>(a.sv_mm + (int64_t)row * LA_D + 8 * kg + 4 * h) = f32x4{mrg[t][4 * qd], mrg[t][4 * qd + 1], mrg[t][4 * qd + 2], mrg[t][4 * qd + 3]};
+      }
+    }
     la_layernorm(mrg, Ln, Ln + LA_D, h, a.ln_eps);
+    if (TRAIN) {
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const int t = kg / 4, qd = kg % 4;
+        if (drop) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) mrg[t][4 * qd + e] *= la_drop_mul(key_att, (uint64_t)row * LA_D + 8 * kg + 4 * h + e, a.thr, a.ks);
+        }
+        *reinterpret_cast<f32x4*>(a.sv_d1 + (int64_t)row * LA_D + 8 * kg + 4 * h) = f32x4{mrg[t][4 * qd], mrg[t][4 * qd + 1], mrg[t][4 * qd + 2], mrg[t][4 * qd + 3]};
+        __builtin_amdgcn_sched_barrier(0);     // one k-group at a time: interleaved, the 64-bit mask arithmetic of all of them spills
+      }
+    }
 
     // ---- mlp: 128 -> 128 (ReLU) -> 64 on cat[x, message], LayerNorm 2, residual
     f32x16 hid[4];
@@ -175,8 +215,32 @@ __global__ __launch_bounds__(512) void la_query_layer_kernel(const LaQueryArgs a
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) hid[t][r] = hid[t][r] > 0.f ? hid[t][r] : 0.f;
+    if (TRAIN) {
+#pragma unroll
+      for (int kg = 0; kg < 16; ++kg) {
+        const int t = kg / 4, qd = kg % 4;
+        if (drop) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hid[t][4 * qd + e] *= la_drop_mul(key_hid, (uint64_t)row * LA_HID + 8 * kg + 4 * h + e, a.thr, a.ks);
+        }
+        *reinterpret_cast<f32x4*>(a.sv_hid + (int64_t)row * LA_HID + 8 * kg + 4 * h) = f32x4{hid[t][4 * qd], hid[t][4 * qd + 1], hid[t][4 * qd + 2], hid[t][4 * qd + 3]};
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     f32x16 o[2];
     cmr_chain_gemm<2, 16, LA_LD128>(W3, l31, h, o, [&](int kg, int j) { return hid[kg / 4][4 * (kg % 4) + j]; });
+    if (TRAIN) {
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        const int t = kg / 4, qd = kg % 4;
+        if (drop) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[t][4 * qd + e] *= la_drop_mul(key_out, (uint64_t)row * LA_D + 8 * kg + 4 * h + e, a.thr, a.ks);
+        }
+        *reinterpret_cast<f32x4*>(a.sv_o + (int64_t)row * LA_D + 8 * kg + 4 * h) = f32x4{o[t][4 * qd], o[t][4 * qd + 1], o[t][4 * qd + 2], o[t][4 * qd + 3]};
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     la_layernorm(o, Ln + 2 * LA_D, Ln + 3 * LA_D, h, a.ln_eps);
 
     f32x4 ov[8];
@@ -206,6 +270,7 @@ struct LaStateArgs {
   const float *wk, *wv;                // [64][64]
   float* part;                         // [B][nslab * 8][576]
   uint32_t S; int tiles_per_wave; float s;
+  float *sv_kf, *sv_v;                 // SAVE instance: kf = elu(Wk y) + 1 and v = Wv y [B * S][64] for the backward (cmr_la_bwd_f32)
 };
 
 // BF16 (the bf16 mode of BASELINE configs[2] / [3]): the two projections run on v_mfma_f32_32x32x16_bf16 (16 instructions per 32-row tile
@@ -225,7 +290,7 @@ __device__ __forceinline__ la_bf16x8 la_pack8(const f32x4& lo, const f32x4& hi) 
   return __builtin_bit_cast(la_bf16x8, w);
 }
 
-template <bool BF16>
+template <bool BF16, bool SAVE = false>
 __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs a) {
   // fp32: [64][LA_LD64] floats per matrix; bf16: [64] rows of LA_WPS bytes
   __shared__ __attribute__((aligned(16))) float Wk[BF16 ? LA_D * LA_WPS / 4 : LA_D * LA_LD64];
@@ -326,7 +391,13 @@ __global__ __launch_bounds__(512) void la_state_partial_kernel(const LaStateArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float k = la_elu1(kk[t][r]);
-        if (partial && tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h >= a.S) k = 0.f;
+        const uint32_t srow = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (partial && srow >= a.S) k = 0.f;
+        if (SAVE && srow < a.S) {                  // lane = channel 32 t + l31: 32 consecutive floats per row and lane half
+          const int64_t o = ((int64_t)b * a.S + srow) * LA_D + 32 * t + l31;
+          a.sv_kf[o] = k;
+          a.sv_v[o] = vv[t][r];
+        }
         kk[t][r] = k;
         ksum[t] += k;
       }
@@ -399,14 +470,17 @@ extern "C" int64_t cmr_la_kv_state_workspace_bytes(int B, int S) {
 }
 
 static int la_kv_state_launch(bool bf16, const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, void* workspace,
-                              int64_t workspace_bytes, int B, int S, hipStream_t stream) {
-  CMR_REQUIRE(y && wk && wv && kvsum && workspace && B > 0 && B <= 65535 && S > 0);
+                              int64_t workspace_bytes, int B, int S, hipStream_t stream, float* sv_kf = nullptr, float* sv_v = nullptr) {
+  CMR_REQUIRE(y && wk && wv && kvsum && workspace && B > 0 && B <= 65535 && S > 0 && (sv_kf == nullptr) == (sv_v == nullptr));
   CMR_REQUIRE(ldy % 4 == 0 && cmr_aligned16(y) && cmr_aligned16(wk) && cmr_aligned16(wv));
   CMR_REQUIRE(workspace_bytes >= cmr_la_kv_state_workspace_bytes(B, S));
   const int nslab = la_state_nslab(S);
-  const LaStateArgs a{y, ldy, wk, wv, (float*)workspace, (uint32_t)S, la_state_tiles_per_wave(S), (float)S};
-  if (bf16) hipLaunchKernelGGL(la_state_partial_kernel<true>, dim3(nslab, B), dim3(512), 0, stream, a);
-  else hipLaunchKernelGGL(la_state_partial_kernel<false>, dim3(nslab, B), dim3(512), 0, stream, a);
+  const LaStateArgs a{y, ldy, wk, wv, (float*)workspace, (uint32_t)S, la_state_tiles_per_wave(S), (float)S, sv_kf, sv_v};
+  if (sv_kf) {
+    if (bf16) return CMR_EUNSUPPORTED;
+    hipLaunchKernelGGL((la_state_partial_kernel<false, true>), dim3(nslab, B), dim3(512), 0, stream, a);
+  } else if (bf16) hipLaunchKernelGGL((la_state_partial_kernel<true>), dim3(nslab, B), dim3(512), 0, stream, a);
+  else hipLaunchKernelGGL((la_state_partial_kernel<false>), dim3(nslab, B), dim3(512), 0, stream, a);
   hipLaunchKernelGGL(la_state_final_kernel, dim3(LA_STATE / 64, B), dim3(1024), 0, stream, (const float*)workspace, kvsum,
                      nslab * 8, (float)S);
   return cmr_launch_status();
@@ -415,6 +489,13 @@ static int la_kv_state_launch(bool bf16, const float* y, int64_t ldy, const floa
 extern "C" int cmr_la_kv_state_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum,
                                    void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
   return la_kv_state_launch(false, y, ldy, wk, wv, kvsum, workspace, workspace_bytes, B, S, stream);
+}
+
+/* train mode: the same state + the projected source rows the backward needs */
+extern "C" int cmr_la_kv_state_train_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, float* kf, float* v,
+                                         void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream) {
+  CMR_REQUIRE(kf && v);
+  return la_kv_state_launch(false, y, ldy, wk, wv, kvsum, workspace, workspace_bytes, B, S, stream, kf, v);
 }
 
 extern "C" int cmr_la_kv_state_bf16_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum,
@@ -434,13 +515,46 @@ extern "C" int cmr_la_query_layer_f32(const float* x, int64_t ldx, const float* 
                       sizeof(float);
   if (smem > 160 * 1024) return CMR_EUNSUPPORTED;          // the per-batch states no longer fit beside the weights
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(la_query_layer_kernel), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(la_query_layer_kernel<false>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   const uint32_t rows = (uint32_t)((int64_t)B * L);
   const uint32_t ntiles = (rows + 31) / 32;
   uint32_t grid = (ntiles + 7) / 8;
   if (grid > 256) grid = 256;                              // one persistent workgroup per CU (LDS bound)
-  const LaQueryArgs a{x, ldx, kvsum, wq, wmerge, w_mlp0, w_mlp3, ln1_g, ln1_b, ln2_g, ln2_b, out, ldo, rows, (uint32_t)L, B,
-                      (float)S, eps, ln_eps};
-  hipLaunchKernelGGL(la_query_layer_kernel, dim3(grid), dim3(512), smem, stream, a);
+  LaQueryArgs a{};
+  a.x = x; a.ldx = ldx; a.kv = kvsum; a.wq = wq; a.wm = wmerge; a.w0 = w_mlp0; a.w3 = w_mlp3; a.g1 = ln1_g; a.b1 = ln1_b; a.g2 = ln2_g; a.b2 = ln2_b;
+  a.out = out; a.ldo = ldo; a.rows = rows; a.L = (uint32_t)L; a.B = B; a.s = (float)S; a.eps = eps; a.ln_eps = ln_eps;
+  hipLaunchKernelGGL(la_query_layer_kernel<false>, dim3(grid), dim3(512), smem, stream, a);
+  return cmr_launch_status();
+}
+
+/* train mode: LinearAttention.forward under model.train() (LinearAttention.py:38-73 with its three nn.Dropout(0.1) active), query side;
+ * saves [B L][64] qf, msg, mm, d1, o and [B L][128] hid for cmr_la_mlp_bwd_f32 / cmr_la_bwd_f32 / cmr_wgrad_group_f32.  The six save
+ * buffers must hold WHOLE 32-row tiles (ceil(B L / 32) * 32 rows): rows past the end are written (garbage) so that no store is predicated */
+extern "C" int cmr_la_query_layer_train_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,
+                                            const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
+                                            const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, float* qf, float* msg, float* mm,
+                                            float* d1, float* hid, float* o, int B, int L, int S, float eps, float ln_eps, float p,
+                                            const int64_t* seed, int64_t site_att, int64_t site_hid, int64_t site_out, hipStream_t stream) {
+  CMR_REQUIRE(x && kvsum && wq && wmerge && ln1_g && ln1_b && w_mlp0 && w_mlp3 && ln2_g && ln2_b && out && qf && msg && mm && d1 && hid && o);
+  CMR_REQUIRE(B > 0 && L > 0 && S > 0 && (int64_t)B * L < (int64_t)0x7fffffc0 && p >= 0.f && p < 1.f);
+  CMR_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && cmr_aligned16(x) && cmr_aligned16(out) && cmr_aligned16(kvsum) && cmr_aligned16(wq) &&
+              cmr_aligned16(wmerge) && cmr_aligned16(w_mlp0) && cmr_aligned16(w_mlp3) && cmr_aligned16(qf) && cmr_aligned16(msg) &&
+              cmr_aligned16(mm) && cmr_aligned16(d1) && cmr_aligned16(hid) && cmr_aligned16(o));
+  const size_t smem = (size_t)(2 * LA_D * LA_LD64 + LA_HID * LA_LD128 + LA_D * LA_LD128 + 4 * LA_D + (size_t)B * LA_STATE) * sizeof(float);
+  if (smem > 160 * 1024) return CMR_EUNSUPPORTED;
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(la_query_layer_kernel<true>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  const uint32_t rows = (uint32_t)((int64_t)B * L);
+  const uint32_t ntiles = (rows + 31) / 32;
+  uint32_t grid = (ntiles + 7) / 8;
+  if (grid > 256) grid = 256;
+  LaQueryArgs a{};
+  a.x = x; a.ldx = ldx; a.kv = kvsum; a.wq = wq; a.wm = wmerge; a.w0 = w_mlp0; a.w3 = w_mlp3; a.g1 = ln1_g; a.b1 = ln1_b; a.g2 = ln2_g; a.b2 = ln2_b;
+  a.out = out; a.ldo = ldo; a.rows = rows; a.L = (uint32_t)L; a.B = B; a.s = (float)S; a.eps = eps; a.ln_eps = ln_eps;
+  a.sv_qf = qf; a.sv_msg = msg; a.sv_mm = mm; a.sv_d1 = d1; a.sv_hid = hid; a.sv_o = o;
+  a.seed = (seed && p > 0.f) ? seed : nullptr;
+  a.site_att = (uint64_t)site_att; a.site_hid = (uint64_t)site_hid; a.site_out = (uint64_t)site_out;
+  a.thr = cmr_drop_threshold(p); a.ks = 1.f / (1.f - p);
+  hipLaunchKernelGGL(la_query_layer_kernel<true>, dim3(grid), dim3(512), smem, stream, a);
   return cmr_launch_status();
 }

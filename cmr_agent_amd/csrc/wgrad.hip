@@ -832,10 +832,9 @@ __global__ __launch_bounds__(RED_OUT * LRED_GRP) void linear_wgrad_reduce_kernel
 // ------------------------------------------------------------------------------------------------------------------
 typedef __bf16 wg_bf16;
 
-__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int transpose, float* __restrict__ w9,
-                                                           float* __restrict__ ufrag, wg_bf16* __restrict__ bfrag, int nt) {
+__device__ __forceinline__ void pack_conv3x3_one(const float* __restrict__ w, int Co, int Ci, int transpose, float* __restrict__ w9,
+                                                 float* __restrict__ ufrag, wg_bf16* __restrict__ bfrag, int nt, int i) {
   const int Cop = transpose ? Ci : Co, Cip = transpose ? Co : Ci;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Cop * Cip) return;
   const int o = i / Cip, c = i - o * Cip;
   float g[3][3];
@@ -878,6 +877,20 @@ __global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restri
       ufrag[((((int64_t)(pos * (Cop / 32) + t32) * (Cip / 8) + kg) * 2 + hh) * 32 + l) * 4 + e] = uu[b];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void pack_conv3x3_kernel(const float* __restrict__ w, int Co, int Ci, int transpose, float* __restrict__ w9,
+                                                           float* __restrict__ ufrag, wg_bf16* __restrict__ bfrag, int nt) {
+  pack_conv3x3_one(w, Co, Ci, transpose, w9, ufrag, bfrag, nt, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// every convolution of a training step (both orientations) in ONE launch: table [nslots][8] int64 {src offset, Co, Ci, transpose, w9
+// offset, U offset (-1: none), bf16 offset in bf16 elements (-1: none), nt}; blockIdx.y = slot
+__global__ __launch_bounds__(256) void pack_conv3x3_slots_kernel(const float* __restrict__ src, float* __restrict__ dst, wg_bf16* __restrict__ dst_bf,
+                                                                 const int64_t* __restrict__ table) {
+  const int64_t* e = table + (int64_t)blockIdx.y * 8;
+  pack_conv3x3_one(src + e[0], (int)e[1], (int)e[2], (int)e[3], dst + e[4], e[5] >= 0 ? dst + e[5] : nullptr,
+                   (e[6] >= 0 && dst_bf) ? dst_bf + e[6] : nullptr, (int)e[7], blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 inline int wgrad_slices(int64_t work_items) {
@@ -1151,6 +1164,14 @@ extern "C" int cmr_pack_conv3x3_f32(const float* w, int Cout, int Cin, int trans
   if (bf16_frag) CMR_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0 && (bf16_nt == 1 || bf16_nt == 2) && (transpose ? Cin : Cout) % (32 * bf16_nt) == 0);
   hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, stream, w, Cout, Cin, transpose, w9, ufrag,
                      (wg_bf16*)bf16_frag, bf16_nt);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_pack_conv3x3_slots_f32(const float* src, float* dst, void* dst_bf16, const int64_t* table, int nslots, int64_t max_pairs,
+                                          hipStream_t stream) {
+  CMR_REQUIRE(src && dst && table && nslots > 0 && nslots <= 65535 && max_pairs > 0 && cmr_aligned16(dst));
+  hipLaunchKernelGGL(pack_conv3x3_slots_kernel, dim3((unsigned)((max_pairs + 255) / 256), (unsigned)nslots), dim3(256), 0, stream, src, dst,
+                     (wg_bf16*)dst_bf16, table);
   return cmr_launch_status();
 }
 

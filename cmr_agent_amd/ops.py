@@ -1287,3 +1287,61 @@ def wgrad_group(problems, vectors=()):
     ws = _ws(nb, dev)
     _lib.call("cmr_wgrad_group_f32", d.ctypes.data, len(problems), len(vectors), _p(ws), nb, _stream(),
               work_extra={"_group": [(dy.shape[0], dw.shape[0], dw.shape[1]) for dy, _, dw, _, _, _ in problems]})
+
+
+# ---- train-mode linear-attention layer in fused launches (csrc/la_fused.hip train instances, csrc/la_train.hip) -------------------------
+
+def _tile_rows(rows, C, dev):
+    """[rows, C] view of a buffer that holds whole 32-row tiles (the row kernels store unpredicated)."""
+    return torch.empty(((rows + 31) // 32 * 32, C), dtype=f32, device=dev)[:rows]
+
+
+def la_kv_state_train(y, wk, wv, B, S):
+    """k / v projections + per-(batch, head) state, keeping kf = elu(Wk y) + 1 and v = Wv y -> (kvsum [B, 576], kf, v [B*S, 64])."""
+    ws_bytes = _lib.load().cmr_la_kv_state_workspace_bytes(B, S)
+    ws = torch.empty((ws_bytes // 4,), dtype=f32, device=y.device)
+    kvsum = torch.empty((B, 576), dtype=f32, device=y.device)
+    kf, v = torch.empty((B * S, 64), dtype=f32, device=y.device), torch.empty((B * S, 64), dtype=f32, device=y.device)
+    _lib.call("cmr_la_kv_state_train_f32", _p(_rows(y)), _ld(y), _p(wk), _p(wv), _p(kvsum), _p(kf), _p(v), _p(ws), ws_bytes, B, S, _stream())
+    return kvsum, kf, v
+
+
+def la_query_layer_train(x, kvsum, wq, wmerge, ln1, w0, w3, ln2, B, L, S, eps, ln_eps, p=0.0, seed=None, sites=(0, 0, 0)):
+    """Train-mode query side of a linear-attention layer -> (out, saved dict qf / msg / mm / d1 / hid / o), or None when not served."""
+    rows, dev = B * L, x.device
+    out = torch.empty((rows, 64), dtype=f32, device=dev)
+    sv = {k: _tile_rows(rows, 128 if k == "hid" else 64, dev) for k in ("qf", "msg", "mm", "d1", "hid", "o")}
+    sp = seed.data_ptr() if (seed is not None and p > 0.0) else None
+    rc = _lib.call("cmr_la_query_layer_train_f32", _p(_rows(x)), _ld(x), _p(kvsum), _p(wq), _p(wmerge), _p(ln1[0]), _p(ln1[1]), _p(w0), _p(w3),
+                   _p(ln2[0]), _p(ln2[1]), _p(out), _ld(out), _p(sv["qf"]), _p(sv["msg"]), _p(sv["mm"]), _p(sv["d1"]), _p(sv["hid"]), _p(sv["o"]),
+                   B, L, S, float(eps), float(ln_eps), float(p), sp, int(sites[0]), int(sites[1]), int(sites[2]), _stream(), allow_unsupported=True)
+    return None if rc == _lib.UNSUPPORTED else (out, sv)
+
+
+def la_mlp_bwd(dout, sv, wmerge, w0, w3, g1, g2, ln_eps, p=0.0, seed=None, sites=(0, 0, 0)):
+    """Backward of the MLP half of the query side -> dict d_o, d_hid, d_mm, d_msg, d_xa, lnpart1, lnpart2."""
+    rows, dev = sv["o"].shape[0], dout.device
+    r = {k: _tile_rows(rows, 128 if k == "d_hid" else 64, dev) for k in ("d_o", "d_hid", "d_mm", "d_msg", "d_xa")}
+    nt = (rows + 31) // 32
+    r["lnpart1"], r["lnpart2"] = torch.empty((nt, 128), dtype=f32, device=dev), torch.empty((nt, 128), dtype=f32, device=dev)
+    sp = seed.data_ptr() if (seed is not None and p > 0.0) else None
+    _lib.call("cmr_la_mlp_bwd_f32", _p(_rows(dout)), _ld(dout), _p(sv["o"]), _p(sv["hid"]), _p(sv["mm"]), _p(wmerge), _p(w0), _p(w3), _p(g1), _p(g2),
+              _p(r["d_o"]), _p(r["d_hid"]), _p(r["d_mm"]), _p(r["d_msg"]), _p(r["d_xa"]), _p(r["lnpart1"]), _p(r["lnpart2"]), rows, float(ln_eps),
+              float(p), sp, int(sites[0]), int(sites[1]), int(sites[2]), _stream())
+    return r
+
+
+def la_proj_bwd(problems):
+    """problems: 1 or 2 of dict(rows, dx, terms=[(d, f | None, wt_f, e_out | None)], res=[row maps]) -- see cmr_la_proj_bwd_f32."""
+    import numpy as np
+    desc = []
+    for pr in problems:
+        res = list(pr.get("res", ())) + [None, None]
+        dx = pr["dx"]
+        d = [pr["rows"], len(pr["terms"]), dx.data_ptr(), _ld(dx), _p(res[0]) or 0, _ld(res[0]) if res[0] is not None else 0, _p(res[1]) or 0,
+             _ld(res[1]) if res[1] is not None else 0]
+        for dd, f, wt, eo in list(pr["terms"]) + [(None, None, None, None)] * (3 - len(pr["terms"])):
+            d += [0, 0, 0, 0, 0] if dd is None else [_rows(dd).data_ptr(), _ld(dd), _p(f) or 0, wt.data_ptr(), _p(eo) or 0]
+        desc += d
+    arr = np.asarray(desc, dtype=np.int64)
+    _lib.call("cmr_la_proj_bwd_f32", arr.ctypes.data, len(problems), _stream(), work_extra={"_rows": sum(pr["rows"] * len(pr["terms"]) for pr in problems)})

@@ -16,6 +16,7 @@ import torch
 from .. import ops
 from ..models.ImageResNet import to_nhwc
 from .flatbucket import FlatBucket
+from .fragpack import ConvPack
 from .optim import FlatOptimizer
 
 SLOPE2D = 0.01     # nn.LeakyReLU() default in state_2d_embed and the heads (CMRAgent.py:36)
@@ -55,6 +56,11 @@ class AgentUpdate:
         self.bf16_forward = self.bf16_backward = True
         f = config.embed_dim
         self.f = f
+        c = 2 * f
+        e = agent.state_2d_embed
+        # the eight 3x3 convolutions of the 2-D tower, forward and (all but the first) data-gradient orientation: one packing launch per step
+        self._convpack, self._pass = {}, 0
+        self._convs = [(e[6 * s + 3 * j].weight, c, c, not (s == 0 and j == 0)) for s in range(4) for j in range(2)]
         self.dims3d = [(5, f), (2 * f, f), (2 * f, f), (2 * f, 2 * f)]
 
     # ---------------------------------------------------------------------------------------------------------- helpers
@@ -83,14 +89,15 @@ class AgentUpdate:
         e = ag.state_2d_embed
         c = 2 * self.f
         T = {}                                                     # tape
+        cp = self._packed_convs()
         # ---- 2-D branch: 4 x [conv3x3 + BN + LReLU, conv3x3 + LReLU, pool]
         x = s2
         T["stages"] = []
         for s in range(4):
             ia, ib = 6 * s, 6 * s + 3
             na, nb = "state_2d_embed.%d" % ia, "state_2d_embed.%d" % ib
-            w9a, ua = ops.pack_conv3x3(bk.w(na + ".weight"), c, c)
-            w9b, ub = ops.pack_conv3x3(bk.w(nb + ".weight"), c, c)
+            w9a, ua = cp.get(e[ia].weight)
+            w9b, ub = cp.get(e[ib].weight)
             a = ops.conv3x3(x, w9a, bk.w(na + ".bias"), c, 1, 1.0, u=ua)
             Bq, H, W, _ = a.shape
             ar = a.view(-1, c)
@@ -161,10 +168,25 @@ class AgentUpdate:
         if depth < self.fp32_early_dgrads:
             ops.CONV_BF16 = False
         try:
-            w9t, ut = ops.pack_conv3x3(self.bucket.w(name + ".weight"), c, c, transpose=True)
+            if ops.CONV_BF16 == mode:
+                w9t, ut = self._packed_convs(refresh=False).get(self.agent.get_parameter(name + ".weight"), True)
+            else:                                                   # an fp32 data gradient inside a bf16 update (fp32_early_dgrads)
+                w9t, ut = ops.pack_conv3x3(self.bucket.w(name + ".weight"), c, c, transpose=True)
             return ops.conv3x3(dy, w9t, None, c, 1, 1.0, u=ut)
         finally:
             ops.CONV_BF16 = mode
+
+    def _packed_convs(self, refresh=True):
+        """ConvPack for the current precision mode (the bf16 fragments exist only in a pack built in bf16 mode), packed from the bucket's
+        current weights once per forward / backward pass and mode."""
+        key = bool(ops.CONV_BF16)
+        if key not in self._convpack:
+            self._convpack[key] = [ConvPack(self.bucket, self._convs), -1]
+        ent = self._convpack[key]
+        if ent[1] != self._pass:
+            ent[0].refresh()
+            ent[1] = self._pass
+        return ent[0]
 
     def _backward(self, T, d_outs, B, N):
         bk = self.bucket
@@ -264,6 +286,7 @@ class AgentUpdate:
         else:
             s3 = ops.planar_to_rows(st3.contiguous(), 8)
         mode = ops.CONV_BF16
+        self._pass += 1
         ops.CONV_BF16 = mode and self.bf16_forward
         try:
             T, (o_r, o_t, o_v) = self._forward(s2.contiguous(), s3, B, N)

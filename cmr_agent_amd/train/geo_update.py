@@ -20,7 +20,7 @@ import torch.nn as nn
 from .. import ops
 from ..models.PointViT import PointGeometry
 from .flatbucket import FlatBucket
-from .fragpack import FragPack
+from .fragpack import ConvPack, FragPack
 from .optim import FlatOptimizer
 from .tape import Tape, Var
 
@@ -51,9 +51,20 @@ class GeoUpdate:
         blocks = (list(enc.img_transformer.sa_encoder_layers) + list(enc.pt_transformer.sa_encoder_layers) + list(enc.p2i_ca_layers)
                   + list(enc.i2p_ca_layers) + list(enc.img_sa_layers) + list(enc.pt_sa_layers))
         try:
-            self.frags = FragPack(self.bucket, blocks)
+            ed = model.encoder_decoder
+            las = [m for stack in (ed.pixel_to_node_LA, ed.node_to_pixel_LA, ed.node_self_LA, ed.pixel_self_LA) for m in stack]
+            self.frags = FragPack(self.bucket, blocks, las)
         except ValueError:
             self.frags = None                                     # other widths: the op-by-op composition
+        # every 3x3 convolution the tape routes through Tape.conv3x3 (Cin in {64, 128}; the stem's 3-channel convolutions are row GEMMs)
+        convs = [(m.weight, m.weight.shape[0], m.weight.shape[1], True) for m in model.modules()
+                 if isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.weight.shape[1] % 32 == 0 and id(m.weight) in self.bucket.by_id]
+        seen, uniq = set(), []
+        for c in convs:                                           # the image pyramid is registered under two names: one Parameter
+            if id(c[0]) not in seen:
+                seen.add(id(c[0]))
+                uniq.append(c)
+        self.convpack = ConvPack(self.bucket, uniq) if uniq else None
         # dropout: one int64 seed on the device, advanced once per step OUTSIDE the captured graph (the kernels read it through a pointer,
         # so replays draw fresh masks); ranks start from different seeds
         rank = dist.get_rank() if (dist is not None and dist.is_initialized()) else 0
@@ -146,8 +157,14 @@ class GeoUpdate:
         res = self._vector_attention(t, m, q, k, v, rel, S, None, None, 16)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), feat)
 
+    FUSED_LA = True         # linear-attention layers on the fused train-mode kernels (Tape.la_layer)
+
     def _la(self, t, la, x, y, B, L, S):
         """LinearAttention.py:38-73."""
+        if self.FUSED_LA and self.frags is not None:
+            out = t.la_layer(la, x, y, B, L, S, self.frags)
+            if out is not None:
+                return out
         q = t.act(t.linear(x, la.q_proj.weight), ELU1)
         k = t.act(t.linear(y, la.k_proj.weight), ELU1)
         v = t.linear(y, la.v_proj.weight)
@@ -286,7 +303,10 @@ class GeoUpdate:
         self.bucket.check_attached()
         self.bucket.grads.zero_()                           # every used slice is overwritten; frozen / unused ones must read 0
         t = Tape(self.bucket, self.drop_seed)
-        if self.FUSED_VIT and self.frags is not None:
+        if self.convpack is not None and self.convpack.bf16 == bool(ops.CONV_BF16):
+            self.convpack.refresh()
+            t.convpack = self.convpack
+        if (self.FUSED_VIT or self.FUSED_LA) and self.frags is not None:
             self.frags.refresh()
         o = self._forward(t, data)
         B, N, h, w = o["B"], o["N"], o["h"], o["w"]

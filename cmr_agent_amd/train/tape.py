@@ -35,6 +35,7 @@ class Tape:
         self.drop_seed = drop_seed      # int64 device tensor [1]: dropout is applied iff given; advanced by the owner once per step
         self._site = 0                  # dropout sites are numbered in call order: the same masks whenever the seed is the same
         self.nodes = []
+        self.convpack = None            # train/fragpack.py:ConvPack of the owner (operand layouts of all convolutions, packed once per step)
         self.touched = set()            # parameter ids whose gradient slice has been written in this step
         self._consts = {}
         self._flatT = None
@@ -443,13 +444,80 @@ class Tape:
         self.nodes.append(bwd)
         return yv
 
+    def la_layer(self, la, x, y, B, L, S, frags):
+        """LinearAttention.forward (LinearAttention.py:38-73) in train mode as ONE tape op: 2 forward launches (k / v projections + state;
+        query side incl. the three dropout sites), 4 backward calls (MLP half, attention core, projections, weight gradients).  y may be x
+        (self attention).  Returns None when the library does not serve the shape (caller composes the op-by-op layer)."""
+        seed = self.drop_seed
+        p = la.att_dropout.p if seed is not None else 0.0
+        if seed is not None and not (la.mlp[2].p == p and la.mlp[4].p == p):
+            return None
+        eps, ln_eps = la.eps, la.LN_EPS
+        W = self.W
+        ln1, ln2 = (W(la.norm1.weight), W(la.norm1.bias)), (W(la.norm2.weight), W(la.norm2.bias))
+        site0 = self._site
+        sites = (site0, site0 + 1, site0 + 2) if p > 0.0 else (0, 0, 0)
+        kvsum, kf, v = ops.la_kv_state_train(y.v, W(la.k_proj.weight), W(la.v_proj.weight), B, S)
+        res = ops.la_query_layer_train(x.v, kvsum, W(la.q_proj.weight), W(la.merge.weight), ln1, W(la.mlp[0].weight), W(la.mlp[3].weight), ln2,
+                                       B, L, S, eps, ln_eps, p, seed, sites)
+        if res is None:
+            return None
+        if p > 0.0:
+            self._site += 3
+        out, sv = res
+        yv = Var(out)
+        f = frags.of(la)
+        same = y is x
+
+        def bwd():
+            if yv.g is None:
+                return
+            dev = out.device
+            r = ops.la_mlp_bwd(yv.g, sv, W(la.merge.weight), W(la.mlp[0].weight), W(la.mlp[3].weight), ln1[0], ln2[0], ln_eps, p, seed, sites)
+            dqf, dkf, dv = ops.la_bwd(sv["qf"], kf, v, kvsum, r["d_msg"], B, L, S, eps)
+            rows_x, rows_y = x.v.shape[0], y.v.shape[0]
+            dx = torch.empty((rows_x, 64), dtype=f32, device=dev)
+            q_term = (dqf, sv["qf"], f["qT_f"], dqf)                  # e = d * elu1'(f) overwrites d in place: dy operand of dWq
+            k_term, v_term = (dkf, kf, f["kT_f"], dkf), (dv, None, f["vT_f"], None)
+            if same:
+                ops.la_proj_bwd([dict(rows=rows_x, dx=dx, terms=[q_term, k_term, v_term], res=[r["d_xa"], yv.g])])
+                self.give(x, dx, owned=True)
+            else:
+                dy = torch.empty((rows_y, 64), dtype=f32, device=dev)
+                ops.la_proj_bwd([dict(rows=rows_x, dx=dx, terms=[q_term], res=[r["d_xa"], yv.g]),
+                                 dict(rows=rows_y, dx=dy, terms=[k_term, v_term])])
+                self.give(x, dx, owned=True)
+                self.give(y, dy, owned=True)
+            probs = []
+            g0, acc0 = self.G(la.mlp[0].weight)                       # [128, 128]: columns 0..63 multiply x, 64..127 the message branch
+            for dyv, xv, gw, acc in ((r["d_o"], sv["hid"], None, None), (r["d_hid"], x.v, g0[:, 0:64], acc0), (r["d_hid"], sv["d1"], g0[:, 64:128], acc0),
+                                     (r["d_mm"], sv["msg"], None, None), (dqf, x.v, None, None), (dkf, y.v, None, None), (dv, y.v, None, None)):
+                probs.append((dyv, xv, gw, acc))
+            mods = (la.mlp[3], None, None, la.merge, la.q_proj, la.k_proj, la.v_proj)
+            full = []
+            for (dyv, xv, gw, acc), m in zip(probs, mods):
+                if m is not None:
+                    gw, acc = self.G(m.weight)
+                full.append((dyv, xv, gw, acc, None, False))
+            vecs = []
+            for part, ln in ((r["lnpart1"], la.norm1), (r["lnpart2"], la.norm2)):
+                gg, accg = self.G(ln.weight)
+                gb, accb = self.G(ln.bias)
+                if accg != accb:
+                    raise RuntimeError("la_layer: weight and bias of one LayerNorm must be used together")
+                vecs.append((part, gg, gb, accg))
+            ops.wgrad_group(full, vecs)
+        self.nodes.append(bwd)
+        return yv
+
     # ---- convolutions: x is the row view of a contiguous NHWC map (B, H, W given) -----------------------------------------
     def conv3x3(self, x, dims, conv, stride=1):
         """nn.Conv2d(3x3, padding 1, stride 1|2) with bias, no activation, Cin in {64, 128} -> (Var, (B, Ho, Wo))."""
         B, H, W = dims
         cout, cin = conv.weight.shape[0], conv.weight.shape[1]
         wflat = self.W(conv.weight)
-        w9, u = ops.pack_conv3x3(wflat, cout, cin, want_u=self.WINOGRAD)
+        packed = self.convpack is not None and self.WINOGRAD
+        w9, u = self.convpack.get(conv.weight) if packed else ops.pack_conv3x3(wflat, cout, cin, want_u=self.WINOGRAD)
         xi = x.v.view(B, H, W, cin)
         yv = ops.conv3x3(xi, w9, self.W(conv.bias), cout, stride, 1.0, u=u)
         Ho, Wo = yv.shape[1], yv.shape[2]
@@ -473,7 +541,7 @@ class Tape:
             gb, fin = self.vec_out(conv.bias)
             ops.colsum(y.g, 1, y.g.shape[0], out=gb.view(1, -1))
             fin()
-            w9t, ut = ops.pack_conv3x3(wflat, cout, cin, transpose=True, want_u=self.WINOGRAD)
+            w9t, ut = self.convpack.get(conv.weight, True) if packed else ops.pack_conv3x3(wflat, cout, cin, transpose=True, want_u=self.WINOGRAD)
             if x.g is not None and x.g.is_contiguous():
                 # second consumer of x (a ResidualBlock's input feeds conv a and the shortcut): accumulate in the convolution's epilogue
                 x.g = ops.conv3x3(dy, w9t, None, cin, 1, 1.0, res=x.g.view(B, H, W, cin), u=ut).view(-1, cin)

@@ -636,6 +636,14 @@ int cmr_mha_dropout_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t
                             int64_t lddk, int acc_dk, float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq,
                             int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream);
 
+/* cmr_pack_conv3x3_f32 for EVERY 3x3 convolution of a training step, both orientations, in one launch: table = device [nslots][8] int64
+ * {src offset in the flat parameter buffer, Cout, Cin, transpose, w9 offset in dst, U offset in dst (-1: none), bf16 fragment offset in
+ * dst_bf16 in bf16 elements (-1: none), bf16_nt}; max_pairs = the largest Cout * Cin.  (Train_Geo.py:166-174 / Train_Agent.py:263-305: the
+ * weights move every optimizer step, so the forward kernels' operand layouts are rebuilt per step -- one launch instead of one per
+ * convolution and direction.) */
+int cmr_pack_conv3x3_slots_f32(const float* src, float* dst, void* dst_bf16, const int64_t* table, int nslots, int64_t max_pairs,
+                               hipStream_t stream);
+
 /* ---- train-mode transformer block in fused launches (round 4; reference models/ImageViT.py:61-158, PointViT.py:96-183,
  * IMGPCEncoder.py:14-102 under model.train(), Train_Geo.py:166-174).  Replaces, per block and step, 16 forward and ~20 backward calls of
  * the op-level entry points above by 3 + 4: cmr_ln64_linear_f32, cmr_mha_dropout_f32, cmr_vit_out_ffn16_train_f32 forward;
@@ -683,6 +691,36 @@ int cmr_vit_lnqkv_bwd_f32(const float* d_x, int64_t ldd_x, int k_x, const float*
  * Deterministic (fixed slices, fixed summation order, no atomics). */
 int64_t cmr_wgrad_group_workspace_bytes(const int64_t* desc, int nprob, int nvec);
 int cmr_wgrad_group_f32(const int64_t* desc, int nprob, int nvec, void* ws, int64_t ws_bytes, hipStream_t stream);
+
+/* ---- train-mode linear-attention layer in fused launches (round 4; reference models/LinearAttention.py:38-73 under model.train(),
+ * Train_Geo.py:166-174): 2 forward + 4 backward calls per layer instead of ~16 + ~20 op-level ones. ---- */
+/* cmr_la_kv_state_f32 that also writes kf = elu(Wk y) + 1 and v = Wv y [B S][64] for the backward. */
+int cmr_la_kv_state_train_f32(const float* y, int64_t ldy, const float* wk, const float* wv, float* kvsum, float* kf, float* v,
+                              void* workspace, int64_t workspace_bytes, int B, int S, hipStream_t stream);
+/* cmr_la_query_layer_f32 with the layer's three nn.Dropout(p) sites applied (attention message after LayerNorm 1, MLP hidden activations,
+ * MLP output; masks of cmr_dropout_f32, element index = row * width + column) and the activations the backward needs written once per row:
+ * qf = elu(Wq x) + 1, msg, mm = Wm msg, d1 = drop(LN1(mm)), o = drop(W3 hid) [B L][64] and hid = drop(relu(W0 [x | d1])) [B L][128]; these six
+ * buffers must have room for whole 32-row tiles (ceil(B L / 32) * 32 rows; rows past the end are written, never read). */
+int cmr_la_query_layer_train_f32(const float* x, int64_t ldx, const float* kvsum, const float* wq, const float* wmerge,
+                                 const float* ln1_g, const float* ln1_b, const float* w_mlp0, const float* w_mlp3,
+                                 const float* ln2_g, const float* ln2_b, float* out, int64_t ldo, float* qf, float* msg, float* mm,
+                                 float* d1, float* hid, float* o, int B, int L, int S, float eps, float ln_eps, float p,
+                                 const int64_t* seed, int64_t site_att, int64_t site_hid, int64_t site_out, hipStream_t stream);
+/* Backward of the query side's MLP half from d out (one pass over the rows): LayerNorm-2 backward, output dropout, W3^T, ReLU / hidden
+ * dropout, W0^T, attention dropout, LayerNorm-1 backward, Wm^T.  Writes d_o [rows][64] (gradient at W3's output), d_hid [rows][128] (at
+ * W0's output), d_mm [rows][64] (at Wm's output) -- the dy operands of the three weight gradients --, d_msg [rows][64] (gradient of the
+ * attention message, input of cmr_la_bwd_f32), d_xa [rows][64] (gradient of x through the MLP) and lnpart1 / lnpart2 [ceil(rows / 32)][128]
+ * (per-tile sums of d gamma | d beta of norm1 / norm2, summed by cmr_wgrad_group_f32).  The five row outputs must have room for whole
+ * 32-row tiles (ceil(rows / 32) * 32 rows): rows past the end are written, so that no store is predicated. */
+int cmr_la_mlp_bwd_f32(const float* dout, int64_t lddo, const float* o, const float* hid, const float* mm, const float* wmerge,
+                       const float* w_mlp0, const float* w_mlp3, const float* ln1_g, const float* ln2_g, float* d_o, float* d_hid,
+                       float* d_mm, float* d_msg, float* d_xa, float* lnpart1, float* lnpart2, int64_t rows, float ln_eps, float p,
+                       const int64_t* seed, int64_t site_att, int64_t site_hid, int64_t site_out, hipStream_t stream);
+/* Backward of the q / k / v projections for one or two row sets in one launch: per set dx = sum_i (d_i * elu1'(f_i)) W_i + res0 + res1, where
+ * f_i is the SAVED activation elu(z) + 1 (derivative 1 where f > 1, else f; 0 = no activation) and W_i^T is passed as frag32 fragments
+ * (cmr_pack_frags_f32).  desc: HOST array, 23 int64 per set: rows, nterm (1..3), dx, lddx, res0, ldr0, res1, ldr1, then 3 x {d, ldd, f, wt_f,
+ * e_out}; e_out (0: none; may equal d) receives d_i * elu1'(f_i), the dy operand of W_i's weight gradient. */
+int cmr_la_proj_bwd_f32(const int64_t* desc, int nprob, hipStream_t stream);
 
 #ifdef __cplusplus
 }

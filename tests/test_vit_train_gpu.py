@@ -180,3 +180,96 @@ def test_grouped_weight_gradient(rows):
     s, s2 = part.cpu().double().sum(0), part2.cpu().double().sum(0)
     close(oa, s[:64], 1e-5, "vector job a"), close(ob, s[64:], 1e-5, "vector job b")
     close(oc, oc0.cpu().double() + s2[:64], 1e-5, "accumulating vector job a"), close(od, od0.cpu().double() + s2[64:], 1e-5, "accumulating vector job b")
+
+
+# ---- fused train-mode linear-attention layer (csrc/la_fused.hip train instances, csrc/la_train.hip) ------------------------------------
+
+def _la_module(seed):
+    from cmr_agent_amd.models.LinearAttention import LinearAttention
+    torch.manual_seed(seed)
+    la = LinearAttention(64, 8)
+    with torch.no_grad():
+        for n, p in la.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    return la.to(DEV)
+
+
+def _run_la(la, x, y, dout, B, L, S, fused, seed):
+    from cmr_agent_amd.train.flatbucket import FlatBucket
+    from cmr_agent_amd.train.fragpack import FragPack
+    from cmr_agent_amd.train.geo_update import GeoUpdate
+    from cmr_agent_amd.train.tape import Tape, Var
+    bucket = FlatBucket(la)
+    bucket.grads.zero_()
+    drop = None if seed is None else torch.full((1,), seed, dtype=torch.int64, device=DEV)
+    t = Tape(bucket, drop)
+    xv = Var(x.clone())
+    yv = xv if y is None else Var(y.clone())
+
+    class Host:                                             # what GeoUpdate._la reads from self
+        FUSED_LA = fused
+        frags = FragPack(bucket, [], [la])
+    Host.frags.refresh()
+    out = GeoUpdate._la(Host, t, la, xv, yv, B, L, S)
+    out.g = dout.clone()
+    t.backward()
+    torch.cuda.synchronize()
+    grads = {n: bucket.slots[n].view(bucket.grads).clone() for n, _ in la.named_parameters()}
+    return out.v.clone(), xv.g.clone(), (None if y is None else yv.g.clone()), grads, t._site
+
+
+@pytest.mark.parametrize("selfatt", [False, True], ids=["cross", "self"])
+@pytest.mark.parametrize("dropout", [False, True], ids=["nodrop", "drop"])
+@pytest.mark.parametrize("B,L,S", [(2, 77, 50), (8, 1280, 5120), (1, 33, 31)])
+def test_fused_linear_attention_layer_equals_the_op_by_op_layer(B, L, S, selfatt, dropout):
+    if selfatt:
+        S = L
+    la = _la_module(11)
+    x = rnd(B * L, 64, seed=1).to(DEV)
+    y = None if selfatt else rnd(B * S, 64, seed=2).to(DEV)
+    dout = rnd(B * L, 64, seed=3).to(DEV)
+    seed = 7654321 if dropout else None
+    o1, dx1, dy1, g1, s1 = _run_la(la, x, y, dout, B, L, S, True, seed)
+    o0, dx0, dy0, g0, s0 = _run_la(la, x, y, dout, B, L, S, False, seed)
+    assert s1 == s0 == (3 if dropout else 0)
+    close(o1, o0, 2e-5, "layer output")
+    close(dx1, dx0, 1e-4, "dx")
+    if not selfatt:
+        close(dy1, dy0, 1e-4, "dy")
+    gmax = max(float(g.abs().max()) for g in g0.values())
+    for n in g0:
+        close(g1[n], g0[n], 2e-4, "grad " + n, floor=1e-2 * gmax)
+    assert float(g0["mlp.0.weight"].abs().max()) > 0 and float(g0["k_proj.weight"].abs().max()) > 0
+
+
+@pytest.mark.parametrize("selfatt", [False, True], ids=["cross", "self"])
+def test_fused_linear_attention_layer_against_float64_autograd(selfatt):
+    """LinearAttention.py:38-73 without dropout: elu + 1 feature maps, per-head 8 x 8 state over the source rows, message, merge, LayerNorm,
+    MLP on cat[x, message], LayerNorm, residual."""
+    B, L, S = 2, 45, (45 if selfatt else 70)
+    la = _la_module(13)
+    x = rnd(B * L, 64, seed=21)
+    y = None if selfatt else rnd(B * S, 64, seed=22)
+    dout = rnd(B * L, 64, seed=23)
+    o1, dx1, dy1, g1, _ = _run_la(la, x.to(DEV), None if y is None else y.to(DEV), dout.to(DEV), B, L, S, True, None)
+    P = {n: p.detach().cpu().double().clone().requires_grad_(True) for n, p in la.named_parameters()}
+    xd = x.double().requires_grad_(True)
+    yd = xd if selfatt else y.double().requires_grad_(True)
+    q = (F.elu(xd @ P["q_proj.weight"].t()) + 1).view(B, L, 8, 8)
+    k = (F.elu(yd @ P["k_proj.weight"].t()) + 1).view(B, S, 8, 8)
+    v = (yd @ P["v_proj.weight"].t()).view(B, S, 8, 8) / S
+    kv = torch.einsum("nshd,nshv->nhdv", k, v)
+    z = 1.0 / (torch.einsum("nlhd,nhd->nlh", q, k.sum(1)) + la.eps)
+    msg = (torch.einsum("nlhd,nhdv,nlh->nlhv", q, kv, z) * S).reshape(B * L, 64)
+    msg = F.layer_norm(msg @ P["merge.weight"].t(), (64,), P["norm1.weight"], P["norm1.bias"], la.LN_EPS)
+    hid = F.relu(torch.cat([xd, msg], 1) @ P["mlp.0.weight"].t())
+    out = xd + F.layer_norm(hid @ P["mlp.3.weight"].t(), (64,), P["norm2.weight"], P["norm2.bias"], la.LN_EPS)
+    out.backward(dout.double())
+    close(o1, out, 2e-5, "layer output")
+    close(dx1, xd.grad, 1e-4, "dx")
+    if not selfatt:
+        close(dy1, yd.grad, 1e-4, "dy")
+    gmax = max(float(P[n].grad.abs().max()) for n in P)
+    for n in P:
+        close(g1[n], P[n].grad, 2e-4, "grad " + n, floor=1e-2 * gmax)
