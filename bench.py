@@ -259,6 +259,11 @@ def train_main(args, ctx=None, with_cpu=False):
     g = torch.Generator().manual_seed(ranks.shard_seed(cfg.seed))
     batch = agent_update_batch(MB, h, wd, w["N"], cfg.num_steps, g, dev)
     info = dist_info(ranks, args)
+    with CallTimer() as ct:                 # eager, before the graph is captured: every C-ABI call of one update with its work
+        up.step(batch)
+        torch.cuda.synchronize()
+    if not args.eager:
+        up.enable_graph(batch)          # forward + backward replayed from a hipGraph; all-reduce and Adam launched per step
     for _ in range(args.warmup):
         up.step(batch)
     ranks.barrier()
@@ -278,9 +283,6 @@ def train_main(args, ctx=None, with_cpu=False):
         ranks.dist.all_reduce(lo, op=ranks.dist.ReduceOp.MIN)
         ranks.dist.all_reduce(hi, op=ranks.dist.ReduceOp.MAX)
         sums = [float(lo), float(hi)]
-    with CallTimer() as ct:
-        up.step(batch)
-        torch.cuda.synchronize()
     ranks.barrier()
     line = None
     if ranks.rank == 0:
@@ -311,6 +313,8 @@ def train_main(args, ctx=None, with_cpu=False):
             "allreduce_ms_per_step": ar_ms / args.steps if ranks.dist is not None else 0.0,
             "gradient_bucket_sum_min_max_over_ranks": sums, "gradient_buckets_identical": sums[0] == sums[-1],
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
+            "launches_per_step": sum(d["calls"] for d in ct.table()),
+            "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
             "roofline": train_roofline(ct.table(), 1, families),
             "loss": float(losses[0]), **info}
         if with_cpu and world == 1:

@@ -64,6 +64,13 @@ __device__ __forceinline__ float m16_sum16(float v) {
 }
 
 __device__ __forceinline__ float m16_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+// gelu(v) and its derivative from ONE erf: Phi = 0.5 (1 + erf(v / sqrt 2)); gelu = v Phi (the same bits as m16_gelu: 0.5 v (1 + erf) is
+// evaluated as written); gelu' = Phi + v phi(v)
+__device__ __forceinline__ void m16_gelu_both(float v, float& g, float& dg) {
+  const float e = 1.f + erff(v * 0.70710678118654752440f);
+  g = 0.5f * v * e;
+  dg = 0.5f * e + v * 0.39894228040143267794f * expf(-0.5f * v * v);
+}
 // d/dv gelu(v) = Phi(v) + v phi(v)
 __device__ __forceinline__ float m16_gelu_grad(float v) {
   return 0.5f * (1.f + erff(v * 0.70710678118654752440f)) + v * 0.39894228040143267794f * expf(-0.5f * v * v);

@@ -243,13 +243,15 @@ __global__ __launch_bounds__(512) void vit_ffn_bwd16_kernel(const FfnBwdArgs a) 
     for (int e = 0; e < 4; ++e) {
       const float uu = u[t][e] + bv[e];
       const float sc = DROP ? da.mul((uint64_t)row * 1024 + 128 * wave + 16 * t + 4 * g + e) : 1.f;
-      u[t][e] = m16_gelu(uu) * sc;                     // hidden activation as the forward's fc2 saw it
-      dg[t][e] = dg[t][e] * sc * m16_gelu_grad(uu);    // gradient at the pre-activation
+      float ge, gd;
+      m16_gelu_both(uu, ge, gd);
+      u[t][e] = ge * sc;                               // hidden activation as the forward's fc2 saw it
+      dg[t][e] = dg[t][e] * sc * gd;                   // gradient at the pre-activation
     }
   }
 #pragma unroll
   for (int t = 0; t < 8; ++t) { cmr_pin(u[t]); cmr_pin(dg[t]); }
-  if (valid) {
+  {                                                    // (every row output holds whole 16-row tiles: no predicated stores)
     float* gp = a.gs + (int64_t)row * 1024 + 128 * wave + 4 * g;
     float* up = a.du + (int64_t)row * 1024 + 128 * wave + 4 * g;
 #pragma unroll
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512) void vit_ffn_bwd16_kernel(const FfnBwdArgs a) 
   m16_gemm<4, 4, 4>(a.wot_f, 4, 0, 0, lane, dc, [&](int t, int r) { return dav[t][r]; });
 #pragma unroll
   for (int t = 0; t < 4; ++t) { cmr_pin(dx1[t]); cmr_pin(dc[t]); }
-  if (valid) {
+  {
     const int64_t o = (int64_t)row * 64 + 4 * g;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {

@@ -1030,7 +1030,7 @@ def la_bwd(qf, kf, v, kvsum, dmsg, B, L, S, eps, dqf=None, dkf=None, dv=None, ac
 def segment_softmax_bwd(attn, vp, dout, nseg, scale, order=None, offsets=None, fixed_len=0):
     dattn, dvp = torch.empty_like(attn), torch.empty_like(vp)
     _lib.call("cmr_segment_softmax_bwd_f32", _p(attn), _p(vp), _p(_i32(order)), _p(_i32(offsets)), fixed_len, float(scale), _p(dout), _p(dattn),
-              _p(dvp), nseg, _stream())
+              _p(dvp), nseg, _stream(), work_extra={"_rows": attn.shape[0]})
     return dattn, dvp
 
 
@@ -1206,7 +1206,7 @@ def mha_dropout_bwd(q, k, v, o, dout, B, Tq, Tk, p, seed, site, dq=None, dk=None
 
 def pack_frags(src, dst, table, nslots, max_elements):
     """dst <- MFMA-fragment-ordered copies of matrix slots of the flat parameter buffer src (table: train/fragpack.py)."""
-    _lib.call("cmr_pack_frags_f32", _p(src), _p(dst), _p(table), int(nslots), int(max_elements), _stream())
+    _lib.call("cmr_pack_frags_f32", _p(src), _p(dst), _p(table), int(nslots), int(max_elements), _stream(), work_extra={"_elems": dst.numel()})
     return dst
 
 
@@ -1232,7 +1232,7 @@ def vit_out_ffn16_train(ctx, x, wo_f16, bo, ln, eps, w1_f16, b1, w2_f16, b2, p_p
 def vit_ffn_bwd16(dout, x1, ln, eps, w1_f16, b1, w2t_f16, w1t_f16, wot_f16, p_proj=0.0, p_mlp=0.0, seed=None, sites=(0, 0, 0)):
     """Backward of vit_out_ffn16_train from d out -> dict(dx1, dctx, gs, du, h, dm, da, lnpart)."""
     rows, dev = x1.shape[0], x1.device
-    mk = lambda c: torch.empty((rows, c), dtype=f32, device=dev)
+    mk = lambda c: torch.empty(((rows + 15) // 16 * 16, c), dtype=f32, device=dev)[:rows]      # whole 16-row tiles: the kernel stores unpredicated
     r = dict(dx1=mk(64), dctx=mk(64), gs=mk(1024), du=mk(1024), h=mk(64), dm=mk(64), da=mk(64),
              lnpart=torch.empty(((rows + 15) // 16, 128), dtype=f32, device=dev))
     pp, pm, sp, s0, s1, s2 = _drop_args(p_proj, p_mlp, seed, sites)

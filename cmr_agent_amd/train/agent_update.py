@@ -330,8 +330,47 @@ class AgentUpdate:
         ev[1].synchronize()
         return ev[0].elapsed_time(ev[1])
 
+    GRAPH_KEYS = ("states_2d", "states_3d", "expert_actions_r", "expert_actions_t", "action_r", "action_t", "action_logprob", "state_value_ref",
+                  "advantages")
+
+    def enable_graph(self, batch):
+        """Capture forward + backward of one minibatch shape into a hipGraph (the all-reduce and the optimizer launch stay outside: the bias
+        corrections are launch arguments).  An update is ~200 C-ABI calls of ~285 kernels averaging 18 us: issued from Python the host is as
+        slow as the device (profiles/r04_train_kernel_stats.csv); replayed, the device runs back to back.  `batch`: a minibatch of the
+        shape to train on (its tensors are copied into static buffers; later minibatches are copied into them by step()).  BatchNorm running
+        statistics moved by the warm-up passes are restored.  Same kernels in the same order as the eager step: bit-identical updates."""
+        dev = self.bucket.params.device
+        self._static = {k: batch[k].to(dev).clone() for k in self.GRAPH_KEYS if k in batch}
+        saved = {n: b.detach().clone() for n, b in self.agent.named_buffers()}
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.forward_backward(self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._static_losses, _ = self.forward_backward(self._static)
+        with torch.no_grad():
+            for n, b in self.agent.named_buffers():
+                b.copy_(saved[n])
+        self._graph = graph
+
     def step(self, batch):
         """One optimizer step on one minibatch (Train_Agent.py:263-305).  Returns the loss vector (device tensor [8])."""
+        if getattr(self, "_graph", None) is not None:
+            for k, v in self._static.items():
+                src = batch[k]
+                if tuple(src.shape) != tuple(v.shape):
+                    raise ValueError("AgentUpdate.step: batch tensor %s has shape %s, the captured graph was built for %s" % (k, tuple(src.shape), tuple(v.shape)))
+                v.copy_(src, non_blocking=True)
+            self._graph.replay()
+            losses = self._static_losses
+            if self._nbt:
+                torch._foreach_add_(self._nbt, 1)
+            self.optimizer_step()
+            return losses
         losses, _ = self.forward_backward(batch)
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)

@@ -140,7 +140,7 @@ class ConvPack:
         from .. import _lib
         _lib.call("cmr_pack_conv3x3_slots_f32", self.bucket.params.data_ptr(), self.buf.data_ptr(),
                   self.buf_bf.data_ptr() if self.buf_bf is not None else None, self.table.data_ptr(), self.nslots, self.max_pairs,
-                  torch.cuda.current_stream().cuda_stream)
+                  torch.cuda.current_stream().cuda_stream, work_extra={"_pairs": self.buf.numel() // 25})
 
     def get(self, param, transpose=False):
         """-> (w9 [9, Co', Ci'], U [16, Co', Ci'] or None) as ops.pack_conv3x3 returns them (u.bf16 set in bf16 mode)."""

@@ -277,8 +277,11 @@ class GeoUpdate:
             pix = self._la(t, ed.pixel_self_LA[i], pix, pix, B, L, L)
         # ---- heads
         outs = {}
+        # both heads start from the same cat[point features | features of the point's node] (MultiHeadModel.py:61-63, :227-229 build it once
+        # per head): built once here, the two heads' gradients meet in its Var (the second one rides in a data-gradient GEMM's epilogue)
+        xh_in = t.cat(x_feat, t.gather(nod, geo.gidx, csr))
         for name, head in (("overlap", model.overlap_head), ("geo", model.geo_head)):
-            xh = t.cat(x_feat, t.gather(nod, geo.gidx, csr))
+            xh = xh_in
             for layer in head.point_fuse_convs:
                 xh = self._cbr1d(t, xh, layer)
             pcs = getattr(head, head._pc_name)

@@ -18,6 +18,18 @@ from .. import ops
 f32 = torch.float32
 
 
+_side_streams = {}
+
+
+def _side_stream_of(main):
+    """one side stream per (device, stream the tape runs on): reused across steps (a hipGraph capture needs the same streams on replays'
+    re-captures, and creating a stream per step leaks them)"""
+    key = (main.device, main.cuda_stream)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=main.device)
+    return _side_streams[key]
+
+
 class Var:
     __slots__ = ("v", "g", "own")
 
@@ -39,12 +51,42 @@ class Tape:
         self.touched = set()            # parameter ids whose gradient slice has been written in this step
         self._consts = {}
         self._flatT = None
+        self._side, self._pending = None, []
 
     # ------------------------------------------------------------------------------------------------------------ engine
+    # the grouped weight gradients of the fused layers on a side stream, off the data-gradient chain: measured and NOT the default
+    # (profiles/r04_ab_side_wgrad.txt: 47.9 ms per geometric update with it against 47.0 without, twice each on one box -- the replayed
+    # step is throughput-bound, its kernels add up to the step time, so a second stream only adds graph edges); CMR_SIDE_WGRAD=1 enables
+    SIDE_WGRAD = __import__("os").environ.get("CMR_SIDE_WGRAD", "0") == "1"
+
     def backward(self):
         for fn in reversed(self.nodes):
             fn()
         self.nodes = []
+        self.join_side()
+
+    def side(self, fn):
+        """Run fn() -- launches whose results nothing reads before the optimizer (weight gradients) -- on the tape's side stream, ordered
+        after everything queued on the current stream so far.  The token / pixel layers of the step are chains of launch-sized kernels
+        that leave most CUs idle; their weight-gradient kernels fill them instead of sitting in the chain.  fn (and with it every tensor
+        it reads) is kept alive until join_side(): the caching allocator must not hand an operand's block to a later main-stream
+        allocation while the side stream may still read it.  Under hipGraph capture the two waits become graph edges (a flat fork from
+        the capture's origin stream: the only shape this runtime captures)."""
+        if not (self.SIDE_WGRAD and torch.cuda.is_available()):
+            fn()
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = _side_stream_of(main)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            fn()
+        self._pending.append(fn)
+
+    def join_side(self):
+        if self._side is not None and self._pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+        self._pending = []
 
     def give(self, var, g, alpha=1.0, owned=False):
         """hand gradient contribution alpha * g to `var`.  owned: g is a fresh buffer nobody else refers to.  A first contribution
@@ -440,7 +482,7 @@ class Tape:
                 if accg != accb:
                     raise RuntimeError("vit_block: weight and bias of one LayerNorm must be used together")
                 vecs.append((part, gg, gb, accg))
-            ops.wgrad_group(probs, vecs)
+            self.side(lambda: ops.wgrad_group(probs, vecs))
         self.nodes.append(bwd)
         return yv
 
@@ -506,7 +548,7 @@ class Tape:
                 if accg != accb:
                     raise RuntimeError("la_layer: weight and bias of one LayerNorm must be used together")
                 vecs.append((part, gg, gb, accg))
-            ops.wgrad_group(full, vecs)
+            self.side(lambda: ops.wgrad_group(full, vecs))
         self.nodes.append(bwd)
         return yv
 

@@ -144,6 +144,59 @@ WORK = {
     "cmr_linear_bwd_rows_f32": lambda a: (4.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (3 * a["n"] + 3 * a["k"]) + 2 * a["n"] * a["k"])),
     "cmr_linear_wgrad_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (a["n"] + a["k"]) + a["n"] * a["k"])),
     "cmr_adam_f32": lambda a: (0, 28 * a["n"]),
+    "cmr_sgd_f32": lambda a: (0, 20 * a["n"]),
+    # ---- every other entry point of the two training steps (round 4: `path` covers all kernel time).  Streaming passes: each distinct input
+    # and output once, no FLOPs credited (HBM-class); the fused layer kernels: the arithmetic of the layer as the reference writes it
+    "cmr_bn_stats_f32": lambda a: (0, F * a["rows"] * a["C"]),
+    "cmr_affine_act_f32": lambda a: (0, F * a["rows"] * a["C"] * (2 + (1 if a["res"] else 0))),
+    "cmr_bn_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["z"] else 0) + (1 if a["add"] else 0))),
+    "cmr_act_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["add"] else 0))),
+    "cmr_pool_act_bwd_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (2 + 1.0 / (a["ph"] * a["pw"]))),
+    "cmr_colsum_f32": lambda a: (0, F * a["B"] * a["N"] * a["C"]),
+    "cmr_colmax_arg_f32": lambda a: (0, F * a["B"] * a["N"] * a["C"]),
+    "cmr_add_at_arg_f32": lambda a: (0, 12 * a["B"] * a["C"]),
+    "cmr_linear_bwd_small_f32": lambda a: (4.0 * a["rows"] * a["n"] * (a["k1"] + a["k2"]),
+                                           F * (a["rows"] * (2 * a["n"] + 2 * (a["k1"] + a["k2"])) + 2 * a["n"] * (a["k1"] + a["k2"]))),
+    "cmr_agent_loss_f32": lambda a: (0, 8 * a["B"] * (a["dr"] + a["dt"]) * a["S"]),
+    "cmr_dropout_f32": lambda a: (0, 2 * F * a["rows"] * a["C"]),
+    "cmr_act_f32": lambda a: (0, 2 * F * a["rows"] * a["C"]),
+    "cmr_act_bwd_x_f32": lambda a: (0, 3 * F * a["rows"] * a["C"]),
+    "cmr_axpy_f32": lambda a: (0, 3 * F * a["rows"] * a["C"]),
+    "cmr_layernorm64_bwd_f32": lambda a: (0, 3 * F * a["rows"] * 64),
+    "cmr_l2norm64_bwd_f32": lambda a: (0, 3 * F * a["rows"] * 64),
+    "cmr_segment_softmax_bwd_f32": lambda a: (0, F * (a["_rows"] * 64 * 4 + a["nseg"] * 64)),
+    # softmax attention with / without dropout on the probabilities; backward: S recomputed, dP, dV, dQ, dK = 5 products
+    "cmr_mha_dropout_f32": lambda a: (4.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (2 * a["Tq"] + 2 * a["Tk"])),
+    "cmr_mha_bwd_f32": lambda a: (10.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (4 * a["Tq"] + 4 * a["Tk"])),
+    "cmr_mha_dropout_bwd_f32": lambda a: (10.0 * a["B"] * a["Tq"] * a["Tk"] * 64, F * 64 * a["B"] * (4 * a["Tq"] + 4 * a["Tk"])),
+    "cmr_la_bwd_f32": lambda a: (2.0 * 576 * a["B"] * (3 * a["L"] + 2 * a["S"]), F * 64 * a["B"] * (3 * a["L"] + 4 * a["S"])),
+    "cmr_circle_loss_bwd_f32": lambda a: (4.0 * a["B"] * a["n"] * a["n"] * 64, 2 * F * a["B"] * a["n"] * 128),
+    "cmr_focal_bwd_f32": lambda a: (0, a["rows"] * 32),
+    "cmr_pack_conv3x3_f32": lambda a: (0, F * a["Cout"] * a["Cin"] * 34),
+    "cmr_pack_conv3x3_slots_f32": lambda a: (0, F * a.get("_pairs", 0) * 34),
+    "cmr_pack_frags_f32": lambda a: (0, 2 * F * a.get("_elems", 0)),
+    "cmr_transpose_slots_f32": lambda a: (0, 2 * F * 1024 * a["total_tiles"]),
+    "cmr_zero_insert2_f32": lambda a: (0, F * a["B"] * a["C"] * (a["Ho"] * a["Wo"] + a["H"] * a["W"])),
+    "cmr_im2col3_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * 40),
+    "cmr_col2im3_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * 40),
+    "cmr_upsample_bwd_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C2"] * (1 + 1.0 / a["scale"] ** 2)),
+    "cmr_patchify_bwd_f32": lambda a: (0, 2 * F * a["B"] * a["H"] * a["W"] * a["C"]),
+    # fused train-mode transformer block (csrc/vit_train.hip): out-projection + MLP forward; its backward (fc1 recomputed, two MLP data
+    # gradients, the out-projection's); LayerNorm + projections backward; grouped weight gradients
+    "cmr_vit_out_ffn16_train_f32": lambda a: (2.0 * a["rows"] * (4096 + 2 * 65536), F * (a["rows"] * 256 + 4096 + 2 * 65536)),
+    "cmr_vit_ffn_bwd16_f32": lambda a: (2.0 * a["rows"] * (3 * 65536 + 4096), F * (a["rows"] * (7 * 64 + 2048) + 3 * 65536 + 4096)),
+    "cmr_vit_lnqkv_bwd_f32": lambda a: (2.0 * 64 * (a["rows_x"] * a["k_x"] + (a["rows_y"] * a["k_y"] if a["d_y"] else 0)),
+                                        F * (a["rows_x"] * (a["k_x"] + 192 + (64 if a["res"] else 0)) + (a["rows_y"] * (a["k_y"] + 192) if a["d_y"] else 0))),
+    "cmr_wgrad_group_f32": lambda a: (sum(2.0 * r * n * k for r, n, k in a.get("_group", ())), F * sum(r * (n + k) + n * k for r, n, k in a.get("_group", ()))),
+    # fused train-mode linear-attention layer (la_fused.hip train instances, la_train.hip)
+    "cmr_la_kv_state_train_f32": lambda a: (2.0 * a["B"] * a["S"] * (2 * 4096 + 576), F * (a["B"] * a["S"] * 192 + 2 * 4096)),
+    "cmr_la_query_layer_train_f32": lambda a: (2.0 * a["B"] * a["L"] * (4096 + 576 + 4096 + 16384 + 8192), F * (a["B"] * a["L"] * (128 + 448) + 2 * 4096 + 16384 + 8192)),
+    "cmr_la_mlp_bwd_f32": lambda a: (2.0 * a["rows"] * (8192 + 16384 + 4096), F * (a["rows"] * 704 + 8192 + 16384 + 4096)),
+    "cmr_la_proj_bwd_f32": lambda a: (2.0 * a["_rows"] * 4096, F * a["_rows"] * 64 * 3),
+    # dataset-side point work: latency-class; priced on the bytes they must move (cloud once, result once)
+    "cmr_fps_f32": lambda a: (0, a["B"] * (16 * a["N"] + 8 * a["npoint"])),
+    "cmr_fps_ws_f32": lambda a: (0, a["B"] * (16 * a["N"] + 8 * a["npoint"])),
+    "cmr_ball_query_f32": lambda a: (0, a["B"] * (16 * a["N"] + a["S"] * (16 + 8 * a["nsample"]))),
 }
 
 # Multiplies the kernel ISSUES on the matrix cores per algorithmic multiply: F(2x2,3x3) Winograd computes 2x2 outputs with 16

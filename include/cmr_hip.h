@@ -668,7 +668,8 @@ int cmr_vit_out_ffn16_train_f32(const float* ctx, int64_t ldc, const float* x, i
  *   da = drop_proj(d x1);  d ctx = da Wo.
  * Writes d x1, d ctx and the operands of the weight gradients: gs [rows][1024] (hidden activations as fc2 saw them), du [rows][1024],
  * h = LN(x1) [rows][64], dm [rows][64], da [rows][64]; lnpart [ceil(rows / 16)][128] = per-tile sums of (d gamma | d beta) of ffn_norm
- * (summed by cmr_wgrad_group_f32).  w2t / w1t / wot: frag16 fragments of W2^T, W1^T, Wo^T (cmr_pack_frags_f32, transpose = 1). */
+ * (summed by cmr_wgrad_group_f32).  w2t / w1t / wot: frag16 fragments of W2^T, W1^T, Wo^T (cmr_pack_frags_f32, transpose = 1).  The
+ * seven row outputs must have room for whole 16-row tiles (ceil(rows / 16) * 16 rows): rows past the end are written, never read. */
 int cmr_vit_ffn_bwd16_f32(const float* dout, int64_t lddo, const float* x1, int64_t ldx1, const float* ln_g, const float* ln_b, float eps,
                           const float* w1_f16, const float* b1, const float* w2t_f16, const float* w1t_f16, const float* wot_f16,
                           float* dx1, int64_t lddx1, float* dctx, int64_t lddc, float* gs, float* du, float* h, float* dm, float* da,

@@ -604,6 +604,36 @@ def test_forty_updates_in_bf16_mode_follow_the_fp32_trajectory():
     assert abs(float(b[-1, 0]) - float(f[-1, 0])) <= 0.05 * abs(float(f[-1, 0])) + 1e-3, (float(b[-1, 0]), float(f[-1, 0]))
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_agent_graph_replay_equals_eager_steps(mode):
+    """AgentUpdate.enable_graph: forward + backward replayed from a hipGraph (all-reduce and the optimizer launch per step) must walk the
+    eager path's trajectory to the bit -- every kernel of the update is deterministic -- over three updates on alternating minibatches; the
+    warm-up passes of the capture leave no trace in the BatchNorm statistics."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.train import AgentUpdate
+    case = "agent_train_small"
+    cfg = C.train_config(case, device=DEV)
+    mbs = [_to_dev(b) for b in C.train_inputs(case)]
+    mbs = [mbs[0], mbs[1], mbs[0]]
+    runs = []
+    ops.CONV_BF16 = mode == "bf16"
+    try:
+        for use_graph in (False, True):
+            agent = _product_agent(cfg)
+            up = AgentUpdate(agent, cfg)
+            if use_graph:
+                up.enable_graph(mbs[0])
+            losses = [up.step(b).cpu().clone() for b in mbs]
+            torch.cuda.synchronize()
+            runs.append((torch.stack(losses), {k: v.detach().clone() for k, v in agent.state_dict().items()}))
+    finally:
+        ops.CONV_BF16 = False
+    (l0, s0), (l1, s1) = runs
+    assert torch.equal(l0, l1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_buffer_ordering_quirk_on_device():
     """Buffer.get_samples() of the product (device tensors) vs the fixture made with the reference's Buffer."""
     from cmr_agent_amd.config import KittiConfiguration
