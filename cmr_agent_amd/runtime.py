@@ -67,8 +67,9 @@ class PipelinedRegistrationGraph:
     back to back each phase leaves the other's resource idle; batches are independent, so the pipeline changes no
     result -- every batch still goes through exactly Test_Agent.py:150-170 -- only WHEN its two phases run.
 
-    Inside the two stages the models' own fork_join branches run sequentially (a fork issued from a forked stream cannot be captured
-    on this ROCm build): the pipeline trades the intra-stage concurrency for the inter-stage one.
+    The agent loop is the fork's MAIN branch: it stays on the capture's origin stream, so its per-step 2-D / 3-D fork is captured as real
+    graph branches; the geo stage is the side branch and runs its own forks sequentially (a fork issued from a forked stream cannot be
+    captured on this ROCm build; utils/streams.sequential_forks makes that explicit).
 
     Per replay the device does one geo forward and one agent loop = the work of one registration step; `run()` returns the final
     pose of the PREVIOUS batch (pipeline depth 2: call `flush()` for the last one).  Throughput, not latency: the latency of one
@@ -154,9 +155,18 @@ class PipelinedRegistrationGraph:
                 return fn()
         return run
 
+    def _geo_side(self):
+        # the geo stage is the SIDE branch of the pipeline's fork: its own forks (towers, fuse, heads) cannot be captured from there
+        # (an edge between two non-origin streams) and run sequentially -- announced, not silent
+        from .utils.streams import sequential_forks
+        with sequential_forks():
+            return self._geo_stage()
+
     def _iteration(self):
         from .utils.streams import fork_join
-        data, pose = fork_join(self._with_budget(self.BUDGET[0], self._geo_stage), self._with_budget(self.BUDGET[1], self._agent_loop),
+        # MAIN branch = the agent loop: it stays on the capture's origin stream, so its per-step 2-D / 3-D fork is captured as real graph
+        # branches (round 3 serialised every fork inside both stages); the geo stage is the side branch
+        data, pose = fork_join(self._with_budget(self.BUDGET[0], self._geo_side), self._with_budget(self.BUDGET[1], self._agent_loop),
                                tag="pipeline")
         for k, v in self._agent_inputs(data).items():       # hand batch i over to the next replay's agent stage
             self.stable[k].copy_(v)

@@ -79,15 +79,15 @@ class GeoUpdate:
             a = t.bn(t.conv3x3_c3(x, dims, cl[0], need_dx=False), cl[1], slope=s)
             sc = t.bn(t.linear(x, blk.shortcut[0].weight, blk.shortcut[0].bias), blk.shortcut[1])
             return t.bn(t.conv3x3_c3(a, dims, cl[3], need_dx=True), cl[4], slope=s, res=sc), dims
-        a, d1 = t.conv3x3(x, dims, cl[0], blk.stride)
+        a, d1 = t.conv3x3(x, dims, cl[0], blk.stride, feeds_bn=True)
         a = t.bn(a, cl[1], slope=s)
-        b, d2 = t.conv3x3(a, d1, cl[3], 1)
+        b, d2 = t.conv3x3(a, d1, cl[3], 1, feeds_bn=True)
         if isinstance(blk.shortcut, nn.Identity):
             sc = x
         elif blk.shortcut[0].kernel_size == (1, 1):
             sc = t.bn(t.linear(x, blk.shortcut[0].weight, blk.shortcut[0].bias), blk.shortcut[1])
         else:
-            sc, _ = t.conv3x3(x, dims, blk.shortcut[0], 2)
+            sc, _ = t.conv3x3(x, dims, blk.shortcut[0], 2, feeds_bn=True)
             sc = t.bn(sc, blk.shortcut[1])
         y = t.bn(b, cl[4], slope=s, res=sc)
         if post is not None:

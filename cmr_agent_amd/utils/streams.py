@@ -18,20 +18,37 @@ import torch
 ENABLED = os.environ.get("CMR_STREAMS", "1") != "0"
 SIDE_PRIORITY = os.environ.get("CMR_SIDE_PRIORITY", "0") == "1"     # side branches on high-priority streams (A/B measurements)
 _pool = {}
-_depth = 0
+_depth = 0          # nesting depth of the fork being issued (0 = not inside any fork)
+_in_side = False    # the code running now was issued by a SIDE branch of some enclosing fork
+_sequential = 0     # > 0: inside a `with sequential_forks():` block
 
 
-def _side_stream(parent, i):
-    """One stream per (stream the fork is issued on, branch index).  Round 1 keyed the pool by the branch index alone, so a fork
-    issued from inside branch 0 of another fork was handed the very stream it was running on (a self-dependency that failed under
-    capture); round 2 keyed it by (depth, index), which still gave the inner forks of two DIFFERENT outer branches the same side
-    stream (false serialisation between siblings, and under capture two unrelated branches joined through one stream).  Keyed by
-    the parent stream, a side stream is only ever shared by successive forks issued from the same stream, which are ordered anyway.
+class NestedForkInCapture(RuntimeError):
+    pass
 
-    Under hipGraph capture a nested fork still runs its branches sequentially (guard in fork_join): with round 2's pool,
-    hipStreamEndCapture died with SIGSEGV on a nested fork (gpurun_out/r02_t2.log).  tools/nested_capture_min.py is the torch-only
-    reproduction of that pattern; DESIGN.md section 6b records what it does on this ROCm / torch build."""
-    key = (parent.device, parent.cuda_stream, i)
+
+class sequential_forks:
+    """with sequential_forks(): every fork_join issued inside runs its branches one after the other on the current stream.  The ONLY way to
+    run code that forks from a side branch of another fork while a hipGraph capture is in progress: on this runtime an event edge between two
+    non-origin streams of a capture kills hipStreamEndCapture, so such a fork cannot be captured -- and it is an error to
+    issue one unannounced (round 3 serialised it silently; a caller could lose its concurrency without noticing)."""
+
+    def __enter__(self):
+        global _sequential
+        _sequential += 1
+
+    def __exit__(self, *a):
+        global _sequential
+        _sequential -= 1
+
+
+def _side_stream(parent, depth, i):
+    """One stream per (stream the fork is issued on, nesting depth of the fork, branch index).  Round 1 keyed the pool by the branch index
+    alone (a nested fork was handed the very stream it was running on), round 2 by (depth, index) (inner forks of two DIFFERENT outer
+    branches shared a side stream), round 3 by (parent stream, index) -- which gives a fork issued from the MAIN branch of another fork
+    (same parent stream, index 0) the outer fork's own side stream, still busy with the outer side branch.  Keyed by all three, a side
+    stream is only ever shared by successive forks of the same depth issued from the same stream, which are ordered anyway."""
+    key = (parent.device, parent.cuda_stream, depth, i)
     if key not in _pool:
         _pool[key] = torch.cuda.Stream(device=parent.device, priority=-1 if SIDE_PRIORITY else 0)
     return _pool[key]
@@ -46,36 +63,50 @@ MAIN_FIRST = set(t for t in os.environ.get("CMR_STREAMS_MAIN_FIRST", "*").split(
 
 
 def fork_join(*fns, tag=""):
-    """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn on the current stream and
-    returns all results (in argument order) after joining.  Sequential on CPU / when disabled.  Forks may nest in eager
-    mode (the side streams of depth d are distinct from those of every other depth); during hipGraph capture an inner
-    fork is sequential (see _side_stream for the recorded failure)."""
-    global _depth
-    if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY):
+    """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn (the MAIN branch) on the current stream and returns all
+    results (in argument order) after joining.  Sequential on CPU / when disabled / inside sequential_forks().
+
+    Nesting.  Eager: forks nest freely (distinct streams per parent stream, depth and branch).  Under hipGraph capture only edges between
+    the capture's origin stream and a side stream survive, so: a fork issued along the chain of MAIN branches (the current stream is still
+    the origin) is captured as real graph branches at any depth -- the agent's 2-D / 3-D fork inside the pipeline's agent stage, the
+    towers' fork inside a main-branch geo stage; a fork issued from a SIDE branch raises NestedForkInCapture unless the caller wrapped that
+    branch in sequential_forks()."""
+    global _depth, _in_side
+    if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY) or _sequential > 0:
         return tuple(f() for f in fns)
-    if _depth > 0 and torch.cuda.is_current_stream_capturing():
-        return tuple(f() for f in fns)                           # (argument order: the order the pipelined runtime was tuned with)
+    if _in_side and torch.cuda.is_current_stream_capturing():
+        raise NestedForkInCapture("fork_join(tag=%r) issued from a side branch of another fork during hipGraph capture: this runtime cannot "
+                                  "capture an edge between two non-origin streams (DESIGN.md 6b); wrap the side branch in "
+                                  "streams.sequential_forks() or issue it as the main branch" % tag)
     main = torch.cuda.current_stream()
-    sides = [_side_stream(main, i) for i in range(len(fns) - 1)]
+    sides = [_side_stream(main, _depth, i) for i in range(len(fns) - 1)]
     if any(s == main for s in sides):
         raise RuntimeError("fork_join: a side stream equals the current stream (called from a foreign stream pool?)")
     for s in sides:
         s.wait_stream(main)
     _depth += 1
+    was_side = _in_side
+
+    def run_sides(out):
+        global _in_side
+        for s, f in zip(sides, fns[:-1]):
+            _in_side = True
+            try:
+                with torch.cuda.stream(s):
+                    out.append(f())
+            finally:
+                _in_side = was_side
+
     try:
         out = []
         if tag and (tag in MAIN_FIRST or ("*" in MAIN_FIRST and tag != "pipeline")):    # the two-stage pipeline keeps geo stage (side) first: 942 vs 849-875 it/s in bf16 mode
             # issue order = the order in which a replayed hipGraph hands the nodes to the device: a main branch of few, long kernels
             # (the image tower) goes first, the many short launches of the side branch are fed while it already runs
             last = fns[-1]()
-            for s, f in zip(sides, fns[:-1]):
-                with torch.cuda.stream(s):
-                    out.append(f())
+            run_sides(out)
             out.append(last)
         else:
-            for s, f in zip(sides, fns[:-1]):
-                with torch.cuda.stream(s):
-                    out.append(f())
+            run_sides(out)
             out.append(fns[-1]())
     finally:
         _depth -= 1
