@@ -761,6 +761,9 @@ def main():
         sub.eager, sub.pipeline = False, False
         sub.steps, sub.warmup = 5, 2
         c3 = register_main(sub, ctx, "c3", None, with_cpu=False, with_pipeline=False, with_alone=False)
+        # the headline workload in bf16 mode (3x3 convolutions, point-side blocks, linear-attention and transformer layers on the bf16 matrix
+        # cores, fp32 accumulate; SURVEY.md 8c's bf16 bars, tests/test_bf16_gpu.py): BESIDE the fp32 headline, never instead of it
+        c1b = register_main(sub, ctx, "c1", "bf16", with_cpu=False, with_pipeline=False, with_alone=False)
         ops.CONV_BF16 = False
         # the training lines run with a REAL process group at world size 1 (RCCL loads, the communicator comes up on this device, the one
         # collective of the update executes as a sum over one rank); if that cannot be set up the lines are still measured, without it
@@ -779,6 +782,7 @@ def main():
         geo160 = geo_train_main(sub, ctx, with_cpu=False)
         if rank == 0:
             line["c3"] = compact(c3)
+            line["c1_bf16"] = compact(c1b)
             line["train"] = compact(train)
             line["train_geo"] = compact(geo5)
             line["train_geo_160x512"] = compact(geo160)
