@@ -136,6 +136,107 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// conv3x3 with STRIDE 2 (pad 1, NHWC; the down-sampling convolutions of a ResidualBlock, ImageResNet.py:9-14, :24-27):
+//   dW[co][ci][ky][kx] = sum_{b,oy,ox} dY[b,oy,ox,co] X[b, 2 oy + ky - 1, 2 ox + kx - 1, ci]
+// Round 2 obtained it from the stride-1 kernel on the zero-inserted gradient (cmr_zero_insert2_f32): a contraction over ALL input pixels of
+// which three quarters multiply zeros -- 252 GFLOP instead of 63 for the 352x1216 64 -> 64 layer.  Here the contraction runs over the OUTPUT
+// pixels: same wave / accumulator layout as conv3x3_wgrad_kernel (A = dY^T, B = X at the tap's input pixel, lane = channel), one dY load and
+// nine X loads per step (consecutive output pixels of a lane are four input columns apart: no column reuse), loads three steps ahead.
+// Padding: only the top row / left column can fall outside (H, W even: 2 oy + 1 <= H - 1).
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCI>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_s2_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                                                   int Cin, int Cout, float* __restrict__ part) {
+  constexpr int NSPLIT = 4 / NCI;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int ci_t = wave % NCI, split = wave / NCI;
+  const int co_t = blockIdx.y;
+  const int Ho = H / 2, Wo = W / 2;
+  const int npix = B * Ho * Wo;                    // output pixels
+  const int npairs = (npix + 1) / 2;
+  const int per_blk = (npairs + gridDim.x - 1) / gridDim.x;
+  const int q0 = min((int)blockIdx.x * per_blk, npairs), q1 = min(q0 + per_blk, npairs);
+  const int per_w = (q1 - q0 + NSPLIT - 1) / NSPLIT;
+  const int w0 = min(q0 + split * per_w, q1), w1 = min(w0 + per_w, q1);
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const float* xb = x + ci_t * 32 + l31;
+  const float* db = dy + co_t * 32 + l31;
+  const int last_out = npix - 1, last_in = B * H * W - 1;
+  const int cin_sh = 31 - __builtin_clz(Cin), cout_sh = 31 - __builtin_clz(Cout);
+
+  // this lane's output pixel of pair q: linear index 2 q + h -> (b, oy, ox); its window's centre in the input: (b H + 2 oy) W + 2 ox
+  int p = 2 * w0 + h;
+  int ox = p % Wo, oyb = p / Wo;                   // oyb = b Ho + oy: the input row of the centre is 2 oyb (H = 2 Ho)
+  int toff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) toff[t] = (t / 3 - 1) * W + (t % 3 - 1);
+  auto load = [&](float& a, float (&v)[9], int pout, int pin) {
+    a = db[(int64_t)(min(pout, last_out) << cout_sh)];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) v[t] = xb[(int64_t)(min(max(pin + toff[t], 0), last_in) << cin_sh)];
+  };
+  constexpr int NSET = 4;                          // consumed now | two loaded earlier | being loaded
+  float sa[NSET], sv[NSET][9];
+  int sp[NSET], sx[NSET], sr[NSET];               // output pixel, ox, b Ho + oy
+  auto advance = [&](int& xq, int& rq) {
+    xq += 2;
+    if (xq >= Wo) { xq -= Wo; ++rq; }             // Wo >= 2: one wrap per step
+  };
+  sp[0] = p; sx[0] = ox; sr[0] = oyb;
+#pragma unroll
+  for (int i = 1; i < NSET - 1; ++i) {
+    sp[i] = sp[i - 1] + 2; sx[i] = sx[i - 1]; sr[i] = sr[i - 1];
+    advance(sx[i], sr[i]);
+  }
+  if (w0 < w1) {
+#pragma unroll
+    for (int i = 0; i < NSET - 1; ++i) load(sa[i], sv[i], sp[i], (2 * sr[i]) * W + 2 * sx[i]);
+  }
+#define CMR_WG2_STEP(C, VALID)                                                             \
+  {                                                                                        \
+    constexpr int L = (C + NSET - 1) % NSET, P = (C + NSET - 2) % NSET;                    \
+    sp[L] = sp[P] + 2; sx[L] = sx[P]; sr[L] = sr[P];                                       \
+    advance(sx[L], sr[L]);                                                                 \
+    load(sa[L], sv[L], sp[L], (2 * sr[L]) * W + 2 * sx[L]);                                \
+    __builtin_amdgcn_sched_barrier(0); /* the loads are issued BEFORE this step's MFMAs */ \
+    const bool live = (VALID) && sp[C] <= last_out;                                        \
+    const float av = live ? sa[C] : 0.f;                                                   \
+    const bool top = (sr[C] % Ho) > 0, left = sx[C] > 0;                                   \
+    _Pragma("unroll") for (int ky = 0; ky < 3; ++ky) {                                     \
+      const bool oky = ky > 0 || top;                                                      \
+      const float vl = (oky && left) ? sv[C][3 * ky] : 0.f;                                \
+      const float vc = oky ? sv[C][3 * ky + 1] : 0.f;                                      \
+      const float vr = oky ? sv[C][3 * ky + 2] : 0.f;                                      \
+      acc[3 * ky] = cmr_mfma32(av, vl, acc[3 * ky]);                                       \
+      acc[3 * ky + 1] = cmr_mfma32(av, vc, acc[3 * ky + 1]);                               \
+      acc[3 * ky + 2] = cmr_mfma32(av, vr, acc[3 * ky + 2]);                               \
+    }                                                                                      \
+  }
+  for (int q = w0; q < w1; q += NSET) {
+    CMR_WG2_STEP(0, true)
+    CMR_WG2_STEP(1, q + 1 < w1)
+    CMR_WG2_STEP(2, q + 2 < w1)
+    CMR_WG2_STEP(3, q + 3 < w1)
+  }
+#undef CMR_WG2_STEP
+  float* out = part + ((int64_t)(blockIdx.x * NSPLIT + split) * 9) * Cout * Cin;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = cmr_mfma_row(r, lane);
+      out[((int64_t)t * Cout + co_t * 32 + row) * Cin + ci_t * 32 + l31] = acc[t][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // The same contraction with the operands staged in LDS (round 3).  conv3x3_wgrad_kernel fetches every operand of every MFMA with a
 // dword load (7 per 9 MFMAs after the column reuse) and every tap of a pixel comes back from L2 once per tap row: 0.44-0.46 of the
 // fp32 matrix peak whatever the prefetch depth.  Here a workgroup walks DOWN a 32-pixel-wide column strip of one image with a ring of
@@ -998,6 +1099,25 @@ extern "C" int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<2>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
   else
     hipLaunchKernelGGL(conv3x3_wgrad_kernel<1>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
+  hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
+                     slices * nsplit, Cout, Cin, dw);
+  return cmr_launch_status();
+}
+
+// stride-2 convolution: x [B][H][W][Cin] (H, W even), dy [B][H/2][W/2][Cout]; workspace = cmr_conv3x3_wgrad_workspace_bytes(B, H/2, W/2, ...)
+extern "C" int cmr_conv3x3_wgrad_s2_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
+                                        int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(x && dy && dw && ws && B > 0 && H >= 2 && W >= 4 && H % 2 == 0 && W % 2 == 0);
+  CMR_REQUIRE((Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (Cin == 32 || Cin == 64 || Cin == 128));
+  CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff * 16 && (int64_t)B * H * W < 0x7fffffff);
+  const int nci = Cin / 32, nsplit = 4 / nci;
+  const int slices = wgrad_slices(((int64_t)B * (H / 2) * (W / 2) + 1) / 2);
+  CMR_REQUIRE(ws_bytes >= (int64_t)slices * nsplit * 9 * Cout * Cin * (int64_t)sizeof(float));
+  float* part = (float*)ws;
+  dim3 grid(slices, Cout / 32);
+  if (nci == 4) hipLaunchKernelGGL(conv3x3_wgrad_s2_kernel<4>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
+  else if (nci == 2) hipLaunchKernelGGL(conv3x3_wgrad_s2_kernel<2>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
+  else hipLaunchKernelGGL(conv3x3_wgrad_s2_kernel<1>, grid, dim3(256), 0, stream, x, dy, B, H, W, Cin, Cout, part);
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
                      slices * nsplit, Cout, Cin, dw);
   return cmr_launch_status();

@@ -887,6 +887,21 @@ def conv3x3_wgrad(x, dy, dw, db=None):
         colsum(dy.view(-1, cout), 1, B * H * W, out=db.view(1, cout))
 
 
+def conv3x3_wgrad_s2(x, dy, dw):
+    """Weight gradient of a stride-2 3x3 convolution: x [B,H,W,Cin], dy [B,H/2,W/2,Cout] (contiguous NHWC) -> dw (flat [Cout,Cin,3,3] view).
+    Returns False when the shape is not served (odd sizes; bf16 mode keeps its own path): the caller zero-inserts and uses conv3x3_wgrad."""
+    B, H, W, cin = x.shape
+    cout = dy.shape[3]
+    if H % 2 or W % 2 or W < 4 or tuple(dy.shape[:3]) != (B, H // 2, W // 2) or cin not in (32, 64, 128) or cout not in (32, 64, 128, 256):
+        return False
+    if (CONV_BF16 and WGRAD_BF16) or not (x.is_contiguous() and dy.is_contiguous()) or dw.numel() != cout * cin * 9:
+        return False
+    nb = _lib.load().cmr_conv3x3_wgrad_workspace_bytes(B, H // 2, W // 2, cin, cout)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_conv3x3_wgrad_s2_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
+    return True
+
+
 def linear_wgrad(dy, x, dw, lddw, n=None, k=None, accumulate=False, db=None, accumulate_db=False):
     """dw[n][k] (+)= dy^T x over the rows, db[n] (+)= column sums of dy (optional); dw is a raw view (pointer + row stride)."""
     _rows(dy), _rows(x)

@@ -578,15 +578,17 @@ class Tape:
             dy = y.g.view(B, Ho, Wo, cout)
             if not dy.is_contiguous():
                 dy = dy.contiguous()
-            if stride == 2:
-                dy = ops.zero_insert2(dy, H, W)                # stride-2 gradients = stride-1 ones of the zero-inserted dy
             gw, acc = self.G(conv.weight)
+            dst = torch.empty(cout * cin * 9, dtype=f32, device=dy.device) if acc else gw[:cout * cin * 9]
+            # stride 2: the weight gradient contracts over the OUTPUT pixels (cmr_conv3x3_wgrad_s2_f32); the data gradient below is the
+            # stride-1 convolution of the zero-inserted dy
+            done = stride == 2 and ops.conv3x3_wgrad_s2(xi, dy, dst)
+            if stride == 2:
+                dy = ops.zero_insert2(dy, H, W)
+            if not done:
+                ops.conv3x3_wgrad(xi, dy, dst)
             if acc:
-                tmp = torch.empty(cout * cin * 9, dtype=f32, device=dy.device)
-                ops.conv3x3_wgrad(xi, dy, tmp)
-                ops.axpy(gw[:cout * cin * 9].view(1, -1), tmp.view(1, -1))
-            else:
-                ops.conv3x3_wgrad(xi, dy, gw[:cout * cin * 9])
+                ops.axpy(gw[:cout * cin * 9].view(1, -1), dst.view(1, -1))
             if feeds_bn and not self.BIAS_GRAD_BEFORE_BN:
                 self.G(conv.bias)                              # touched; stays at the zero the bucket was cleared to
             else:

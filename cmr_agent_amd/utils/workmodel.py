@@ -137,6 +137,8 @@ WORK = {
     # training direction (Train_Agent.py:296-305, Train_Geo.py:166-174): weight gradients as GEMMs over the minibatch's pixels / rows
     "cmr_conv3x3_wgrad_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
                                         F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
+    "cmr_conv3x3_wgrad_s2_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * (a["H"] // 2) * (a["W"] // 2),
+                                           F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"] / 4.0) + 9 * a["Cin"] * a["Cout"])),
     "cmr_conv3x3_wgrad_bf16_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
                                              F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     "cmr_conv3x3_wgrad_bias_bf16_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],

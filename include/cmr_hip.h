@@ -636,6 +636,11 @@ int cmr_mha_dropout_bwd_f32(const float* q, int64_t ldq, const float* k, int64_t
                             int64_t lddk, int acc_dk, float* dv, int64_t lddv, int acc_dv, float* ws, int64_t ws_bytes, int B, int Tq,
                             int Tk, float p, const int64_t* seed, int64_t site, hipStream_t stream);
 
+/* Weight gradient of a STRIDE-2 3x3 convolution (pad 1; ImageResNet.py:9-14, :24-27 under loss.backward()): x [B][H][W][Cin] (H, W even), dy
+ * [B][H/2][W/2][Cout] -> dw [Cout][Cin][3][3].  Contracts over the OUTPUT pixels (cmr_conv3x3_wgrad_f32 on the zero-inserted gradient contracts
+ * over all input pixels, three quarters of which multiply zeros).  Workspace: cmr_conv3x3_wgrad_workspace_bytes(B, H / 2, W / 2, Cin, Cout). */
+int cmr_conv3x3_wgrad_s2_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws, int64_t ws_bytes,
+                             hipStream_t stream);
 /* cmr_pack_conv3x3_f32 for EVERY 3x3 convolution of a training step, both orientations, in one launch: table = device [nslots][8] int64
  * {src offset in the flat parameter buffer, Cout, Cin, transpose, w9 offset in dst, U offset in dst (-1: none), bf16 fragment offset in
  * dst_bf16 in bf16 elements (-1: none), bf16_nt}; max_pairs = the largest Cout * Cin.  (Train_Geo.py:166-174 / Train_Agent.py:263-305: the

@@ -94,6 +94,28 @@ def test_stride2_conv_gradients_through_zero_insertion(ops, B, H, W):
     close(dw.view(64, 64, 3, 3), w.grad, 5e-5, "stride-2 wgrad")
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 12, 20, 64, 64), (1, 2, 4, 64, 64), (3, 10, 38, 64, 128), (1, 64, 96, 128, 64), (2, 6, 6, 32, 32),
+                                            (8, 40, 128, 64, 64)])
+def test_stride2_conv_weight_gradient_over_output_pixels(ops, B, H, W, cin, cout):
+    """cmr_conv3x3_wgrad_s2_f32: the weight gradient of a stride-2 3x3 convolution contracted over the OUTPUT pixels (a quarter of the
+    products of the stride-1 kernel on the zero-inserted gradient), against torch autograd and against that zero-insertion path; odd pixel
+    counts, maps of one output row, top / left padding."""
+    x = rnd(B, cin, H, W, seed=17).requires_grad_(True)
+    w = (rnd(cout, cin, 3, 3, seed=18) / 10).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = rnd(*y.shape, seed=19)
+    y.backward(dy)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = torch.empty(cout * cin * 9, device=DEV)
+    assert ops.conv3x3_wgrad_s2(xd, dyd, dw)
+    close(dw.view(cout, cin, 3, 3), w.grad, 5e-5, "stride-2 wgrad over output pixels")
+    dw0 = torch.empty_like(dw)
+    ops.conv3x3_wgrad(xd, ops.zero_insert2(dyd, H, W), dw0)
+    close(dw, dw0, 3e-5, "vs the zero-insertion path")
+    assert not ops.conv3x3_wgrad_s2(xd[:, :H - 1].contiguous(), dyd, dw)          # odd height: not served, the caller zero-inserts
+
+
 def test_layout_adjoints(ops):
     B, H, W, C, P = 2, 16, 24, 64, 8
     x = rnd(B, H, W, C, seed=11).to(DEV)
