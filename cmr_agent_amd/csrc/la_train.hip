@@ -100,7 +100,7 @@ struct LaMlpBwdArgs {
   const float *wm, *w0, *w3;               // [64][64], [128][128], [64][128]
   const float *g1, *g2;                    // LayerNorm gammas
   float *d_o, *d_hid, *d_mm, *d_msg, *d_xa;   // [rows][64], [rows][128], [rows][64], [rows][64], [rows][64]; each with room for WHOLE 32-row tiles
-  float* lnpart1; float* lnpart2;          // [tiles][128] each
+  float* lnpart1; float* lnpart2;          // [workgroups][128] each: sums of d gamma | d beta over the workgroup's tiles
   uint32_t rows;
   float ln_eps;
   const int64_t* seed; uint64_t site_att, site_hid, site_out;
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(512) void la_mlp_bwd_kernel(const LaMlpBwdArgs a) {
   float* W0 = Wm + LT_D * LT_LD64;               // [128][132]
   float* W3 = W0 + LT_HID * LT_LD128;            // [64][132]
   float* Ln = W3 + LT_D * LT_LD128;              // g1 | g2
+  float* Acc = Ln + 2 * LT_D;                    // [8 waves][2 LayerNorms][128]: this wave's running sums of d gamma | d beta over its tiles
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(512) void la_mlp_bwd_kernel(const LaMlpBwdArgs a) {
     Ln[tid] = a.g1[tid];
     Ln[LT_D + tid] = a.g2[tid];
   }
+  for (int e = tid; e < 8 * 2 * 128; e += 512) Acc[e] = 0.f;
   __syncthreads();
   uint64_t key_att = 0, key_hid = 0, key_out = 0;
   if (DROP) {
@@ -182,12 +184,12 @@ __global__ __launch_bounds__(512) void la_mlp_bwd_kernel(const LaMlpBwdArgs a) {
         pg[kg][e] = lt_sum32(pg[kg][e]);
         pb[kg][e] = lt_sum32(pb[kg][e]);
       }
-    if (l31 == 0) {
-      float* lp = a.lnpart2 + (int64_t)tile * 128 + 4 * h;
+    if (l31 == 0) {                              // lanes 0 and 32: own slot, own channels -- plain read-modify-write, fixed order
+      float* lp = Acc + (wave * 2 + 1) * 128 + 4 * h;
 #pragma unroll
       for (int kg = 0; kg < 8; ++kg) {
-        *reinterpret_cast<f32x4*>(lp + 8 * kg) = pg[kg];
-        *reinterpret_cast<f32x4*>(lp + 64 + 8 * kg) = pb[kg];
+        *reinterpret_cast<f32x4*>(lp + 8 * kg) += pg[kg];
+        *reinterpret_cast<f32x4*>(lp + 64 + 8 * kg) += pb[kg];
       }
     }
     // ---- through the output dropout: gradient at W3's output (operand of dW3)
@@ -259,11 +261,11 @@ __global__ __launch_bounds__(512) void la_mlp_bwd_kernel(const LaMlpBwdArgs a) {
         pb[kg][e] = lt_sum32(pb[kg][e]);
       }
     if (l31 == 0) {
-      float* lp = a.lnpart1 + (int64_t)tile * 128 + 4 * h;
+      float* lp = Acc + (wave * 2 + 0) * 128 + 4 * h;
 #pragma unroll
       for (int kg = 0; kg < 8; ++kg) {
-        *reinterpret_cast<f32x4*>(lp + 8 * kg) = pg[kg];
-        *reinterpret_cast<f32x4*>(lp + 64 + 8 * kg) = pb[kg];
+        *reinterpret_cast<f32x4*>(lp + 8 * kg) += pg[kg];
+        *reinterpret_cast<f32x4*>(lp + 64 + 8 * kg) += pb[kg];
       }
     }
     {                                            // (output buffers hold whole tiles: no predicated stores)
@@ -282,6 +284,15 @@ __global__ __launch_bounds__(512) void la_mlp_bwd_kernel(const LaMlpBwdArgs a) {
         *reinterpret_cast<f32x4*>(p + 8 * kg) = f32x4{dg[t][4 * qd], dg[t][4 * qd + 1], dg[t][4 * qd + 2], dg[t][4 * qd + 3]};
       }
     }
+  }
+  // one partial row per WORKGROUP and LayerNorm (the per-tile rows of a 214 016-row map were 6 688 partials per output for the reduction)
+  __syncthreads();
+  if (tid < 256) {
+    const int ln = tid >> 7, c = tid & 127;
+    float sacc = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) sacc += Acc[(w * 2 + ln) * 128 + c];
+    (ln == 0 ? a.lnpart1 : a.lnpart2)[(int64_t)blockIdx.x * 128 + c] = sacc;
   }
 }
 
@@ -381,7 +392,7 @@ extern "C" int cmr_la_mlp_bwd_f32(const float* dout, int64_t lddo, const float* 
   CMR_REQUIRE(cmr_aligned16(dout) && cmr_aligned16(o) && cmr_aligned16(hid) && cmr_aligned16(mm) && cmr_aligned16(wmerge) && cmr_aligned16(w_mlp0) &&
               cmr_aligned16(w_mlp3) && cmr_aligned16(d_o) && cmr_aligned16(d_hid) && cmr_aligned16(d_mm) && cmr_aligned16(d_msg) && cmr_aligned16(d_xa) &&
               cmr_aligned16(lnpart1) && cmr_aligned16(lnpart2));
-  const size_t smem = (size_t)(LT_D * LT_LD64 + LT_HID * LT_LD128 + LT_D * LT_LD128 + 2 * LT_D) * sizeof(float);
+  const size_t smem = (size_t)(LT_D * LT_LD64 + LT_HID * LT_LD128 + LT_D * LT_LD128 + 2 * LT_D + 8 * 2 * 128) * sizeof(float);
   const bool drop = seed != nullptr && p > 0.f;
   static CmrSmemCache g0{}, g1{};
   if (cmr_grant_smem(reinterpret_cast<const void*>(la_mlp_bwd_kernel<false>), smem, g0) != CMR_OK) return CMR_ELAUNCH;

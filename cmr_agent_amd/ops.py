@@ -1337,7 +1337,7 @@ def la_mlp_bwd(dout, sv, wmerge, w0, w3, g1, g2, ln_eps, p=0.0, seed=None, sites
     """Backward of the MLP half of the query side -> dict d_o, d_hid, d_mm, d_msg, d_xa, lnpart1, lnpart2."""
     rows, dev = sv["o"].shape[0], dout.device
     r = {k: _tile_rows(rows, 128 if k == "d_hid" else 64, dev) for k in ("d_o", "d_hid", "d_mm", "d_msg", "d_xa")}
-    nt = (rows + 31) // 32
+    nt = min(256, ((rows + 31) // 32 + 7) // 8)                  # one partial row per workgroup of the kernel's grid
     r["lnpart1"], r["lnpart2"] = torch.empty((nt, 128), dtype=f32, device=dev), torch.empty((nt, 128), dtype=f32, device=dev)
     sp = seed.data_ptr() if (seed is not None and p > 0.0) else None
     _lib.call("cmr_la_mlp_bwd_f32", _p(_rows(dout)), _ld(dout), _p(sv["o"]), _p(sv["hid"]), _p(sv["mm"]), _p(wmerge), _p(w0), _p(w3), _p(g1), _p(g2),

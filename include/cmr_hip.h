@@ -715,8 +715,8 @@ int cmr_la_query_layer_train_f32(const float* x, int64_t ldx, const float* kvsum
 /* Backward of the query side's MLP half from d out (one pass over the rows): LayerNorm-2 backward, output dropout, W3^T, ReLU / hidden
  * dropout, W0^T, attention dropout, LayerNorm-1 backward, Wm^T.  Writes d_o [rows][64] (gradient at W3's output), d_hid [rows][128] (at
  * W0's output), d_mm [rows][64] (at Wm's output) -- the dy operands of the three weight gradients --, d_msg [rows][64] (gradient of the
- * attention message, input of cmr_la_bwd_f32), d_xa [rows][64] (gradient of x through the MLP) and lnpart1 / lnpart2 [ceil(rows / 32)][128]
- * (per-tile sums of d gamma | d beta of norm1 / norm2, summed by cmr_wgrad_group_f32).  The five row outputs must have room for whole
+ * attention message, input of cmr_la_bwd_f32), d_xa [rows][64] (gradient of x through the MLP) and lnpart1 / lnpart2 [min(256, ceil(rows / 256))][128]
+ * (per-workgroup sums of d gamma | d beta of norm1 / norm2, summed by cmr_wgrad_group_f32).  The five row outputs must have room for whole
  * 32-row tiles (ceil(rows / 32) * 32 rows): rows past the end are written, so that no store is predicated. */
 int cmr_la_mlp_bwd_f32(const float* dout, int64_t lddo, const float* o, const float* hid, const float* mm, const float* wmerge,
                        const float* w_mlp0, const float* w_mlp3, const float* ln1_g, const float* ln2_g, float* d_o, float* d_hid,
