@@ -210,7 +210,8 @@ __global__ __launch_bounds__(64) void bn_bwd_final_kernel(const float* __restric
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, int64_t lddz, const float* __restrict__ z, int64_t ldz,
                                                            float slope, const float* __restrict__ x, int64_t ldx, const float* __restrict__ stat,
                                                            const float* __restrict__ coef, const float* __restrict__ add, int64_t ldadd,
-                                                           float* __restrict__ dx, int64_t lddx, int64_t rows, int C) {
+                                                           float* __restrict__ dx, int64_t lddx, float* __restrict__ dzm, int64_t lddzm,
+                                                           int64_t rows, int C) {
   const int q = C >> 2;
   const int64_t total = rows * q;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : d[e] * slope;
     }
+    if (dzm) st4(dzm + r * lddzm + c, d);          // the gradient at the activation's input: what a residual branch added there receives
     const f32x4 xh = (ld4(x + r * ldx + c) - ld4(stat + c)) * ld4(stat + C + c);
     f32x4 g = ld4(stat + 2 * C + c) * (d - ld4(coef + c) - xh * ld4(coef + C + c));
     if (add) g += ld4(add + r * ldadd + c);
@@ -641,8 +643,9 @@ extern "C" int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scal
 }
 
 extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
-                              const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
-                              int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream) {
+                              const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dzm, int64_t lddzm,
+                              float* dgamma, float* dbeta, int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  if (dzm) CMR_REQUIRE(lddzm % 4 == 0 && cmr_aligned16(dzm));
   CMR_REQUIRE(dz && x && stat && dx && ws && rows > 0 && chan_ok(C));
   CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x) && cmr_aligned16(dx));
   if (z) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z));
@@ -654,7 +657,7 @@ extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat, rows, C, part);
   hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, stream, (const float*)part, nb, rows, C, coef, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat,
-                     (const float*)coef, add, ldadd, dx, lddx, rows, C);
+                     (const float*)coef, add, ldadd, dx, lddx, dzm, lddzm, rows, C);
   return cmr_launch_status();
 }
 

@@ -758,17 +758,20 @@ def affine_act(x, scale=None, shift=None, res=None, rscale=None, rshift=None, sl
     return out
 
 
-def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None):
-    """Backward of [BatchNorm(train) -> LeakyReLU(slope)] (z None: no activation) -> dx [rows, C]."""
+def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None, want_masked=False):
+    """Backward of [BatchNorm(train) -> LeakyReLU(slope)] (z None: no activation) -> dx [rows, C]; want_masked: -> (dx, dz * act'(z)), the
+    second one being the gradient a residual branch added in front of the activation receives."""
     _rows(dz), _rows(x)
     rows, C = x.shape
     if out is None:
         out = torch.empty((rows, C), dtype=f32, device=x.device)
+    dzm = torch.empty((rows, C), dtype=f32, device=x.device) if want_masked else None
     nb = _lib.load().cmr_bn_bwd_workspace_bytes(rows, C)
     ws = _ws(nb, x.device)
     _lib.call("cmr_bn_bwd_f32", _p(dz), _ld(dz), _p(z), _ld(z) if z is not None else 0, float(slope), _p(x), _ld(x), _p(stat), _p(add),
-              _ld(add) if add is not None else 0, _p(out), _ld(out), _p(dgamma), _p(dbeta), rows, C, _p(ws), nb, _stream())
-    return out
+              _ld(add) if add is not None else 0, _p(out), _ld(out), _p(dzm), C if want_masked else 0, _p(dgamma), _p(dbeta), rows, C, _p(ws), nb,
+              _stream())
+    return (out, dzm) if want_masked else out
 
 
 def act_bwd(dz, z, slope, add=None, out=None):

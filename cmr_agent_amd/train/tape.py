@@ -224,9 +224,10 @@ class Tape:
             dg, fin_g = self.vec_out(bn.weight)
             db, fin_b = self.vec_out(bn.bias)
             if res is not None and slope != 1.0:
-                dz = ops.act_bwd(y.g, y.v, slope)                # gradient at the sum: goes to the residual branch and into the BN
+                # the gradient at the sum goes to the residual branch and into the BatchNorm: both from the BatchNorm backward's own
+                # passes (the masked gradient is its second output; round 3 ran an activation-backward sweep in front)
+                dx, dz = ops.bn_bwd(y.g, y.v, slope, x.v, stat, dg, db, want_masked=True)
                 self.give(res, dz, owned=False)
-                dx = ops.bn_bwd(dz, None, 1.0, x.v, stat, dg, db)
             else:
                 if res is not None:
                     self.give(res, y.g)

@@ -151,7 +151,7 @@ WORK = {
     # and output once, no FLOPs credited (HBM-class); the fused layer kernels: the arithmetic of the layer as the reference writes it
     "cmr_bn_stats_f32": lambda a: (0, F * a["rows"] * a["C"]),
     "cmr_affine_act_f32": lambda a: (0, F * a["rows"] * a["C"] * (2 + (1 if a["res"] else 0))),
-    "cmr_bn_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["z"] else 0) + (1 if a["add"] else 0))),
+    "cmr_bn_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["z"] else 0) + (1 if a["add"] else 0) + (1 if a["dzm"] else 0))),
     "cmr_act_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["add"] else 0))),
     "cmr_pool_act_bwd_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (2 + 1.0 / (a["ph"] * a["pw"]))),
     "cmr_colsum_f32": lambda a: (0, F * a["B"] * a["N"] * a["C"]),

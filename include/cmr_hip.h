@@ -409,11 +409,13 @@ int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const fl
                        hipStream_t stream);
 /* Backward of [BatchNorm(train) -> LeakyReLU]: dz = gradient w.r.t. the activation output z (z null: no activation),
  * x = the BatchNorm input, stat from cmr_bn_stats_f32.  dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add),
- * dgamma = sum dy xhat, dbeta = sum dy (written when non-null). */
+ * dgamma = sum dy xhat, dbeta = sum dy (written when non-null).  dzm (optional): receives dy = dz * act'(z), the gradient at the
+ * activation's input -- what a residual branch added in front of the activation gets (`lrelu(BN(x) + res)`, ImageResNet.py:36-40,
+ * PointNN.py:282), from the same pass instead of a separate activation-backward sweep. */
 int64_t cmr_bn_bwd_workspace_bytes(int64_t rows, int C);
 int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
-                   const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dgamma, float* dbeta,
-                   int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream);
+                   const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dzm, int64_t lddzm,
+                   float* dgamma, float* dbeta, int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream);
 /* dy = dz * LeakyReLU'(z) (+ add): activation backward where no BatchNorm sits in front (identity shortcut, PointNN.py:271). */
 int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,
                     float* dy, int64_t lddy, int64_t rows, int C, hipStream_t stream);

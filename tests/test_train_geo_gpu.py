@@ -116,6 +116,23 @@ def test_stride2_conv_weight_gradient_over_output_pixels(ops, B, H, W, cin, cout
     assert not ops.conv3x3_wgrad_s2(xd[:, :H - 1].contiguous(), dyd, dw)          # odd height: not served, the caller zero-inserts
 
 
+@pytest.mark.parametrize("rows,C", [(5000, 64), (777, 128)])
+def test_batchnorm_backward_hands_the_masked_gradient_to_the_residual_branch(ops, rows, C):
+    """`lrelu(BN(x) + res)` (ImageResNet.py:36-40, PointNN.py:282): cmr_bn_bwd_f32 with the activation output z and dzm returns, from its own
+    two passes, both the BatchNorm input gradient and dz * lrelu'(z) for the residual branch -- the same bits as an activation-backward
+    sweep followed by the plain BatchNorm backward."""
+    x, res = rnd(rows, C, seed=31).to(DEV), rnd(rows, C, seed=32).to(DEV)
+    g, b = (rnd(C, seed=33) + 1.5).to(DEV), rnd(C, seed=34).to(DEV)
+    dy = rnd(rows, C, seed=35).to(DEV)
+    stat = ops.bn_stats(x, g, b)
+    z = ops.affine_act(x, stat[2], stat[3], res=res, slope=0.2)
+    dg0, db0, dg1, db1 = (torch.empty(C, device=DEV) for _ in range(4))
+    dz0 = ops.act_bwd(dy, z, 0.2)
+    dx0 = ops.bn_bwd(dz0, None, 1.0, x, stat, dg0, db0)
+    dx1, dz1 = ops.bn_bwd(dy, z, 0.2, x, stat, dg1, db1, want_masked=True)
+    assert torch.equal(dz1, dz0) and torch.equal(dx1, dx0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+
+
 def test_layout_adjoints(ops):
     B, H, W, C, P = 2, 16, 24, 64, 8
     x = rnd(B, H, W, C, seed=11).to(DEV)
