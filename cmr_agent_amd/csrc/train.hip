@@ -661,6 +661,22 @@ extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int
   return cmr_launch_status();
 }
 
+// The reduction half of cmr_bn_bwd_f32 alone: coef [2][C] = (mean(dy), mean(dy xhat)), dgamma / dbeta; the apply half then rides in the
+// prologue of the layer's fused weight / data gradient (cmr_bn_linear_bwd_f32).
+extern "C" int cmr_bn_bwd_coef_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
+                                   const float* stat, float* coef, float* dgamma, float* dbeta, int64_t rows, int C, void* ws,
+                                   int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(dz && x && stat && coef && ws && rows > 0 && chan_ok(C));
+  CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x));
+  if (z) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z));
+  const int nb = red_blocks(rows, C);
+  CMR_REQUIRE(ws_bytes >= (int64_t)nb * 2 * C * (int64_t)sizeof(float));
+  float* part = (float*)ws;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nb), dim3(RED_THREADS), 0, stream, dz, lddz, z, ldz, slope, x, ldx, stat, rows, C, part);
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, stream, (const float*)part, nb, rows, C, coef, dgamma, dbeta);
+  return cmr_launch_status();
+}
+
 extern "C" int64_t cmr_bn_bwd_workspace_bytes(int64_t rows, int C) {
   return (int64_t)(red_blocks(rows, C) + 1) * 2 * C * sizeof(float);
 }

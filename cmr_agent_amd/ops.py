@@ -774,6 +774,47 @@ def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None, w
     return (out, dzm) if want_masked else out
 
 
+def bn_bwd_coef(dz, z, slope, x, stat, dgamma=None, dbeta=None):
+    """The reduction half of bn_bwd alone -> coef [2, C] = (mean(dy), mean(dy xhat)) (and dgamma / dbeta): the apply half rides in
+    bn_linear_bwd's prologue."""
+    _rows(dz), _rows(x)
+    rows, C = x.shape
+    coef = torch.empty((2, C), dtype=f32, device=x.device)
+    nb = _lib.load().cmr_bn_bwd_workspace_bytes(rows, C)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_bn_bwd_coef_f32", _p(dz), _ld(dz), _p(z), _ld(z) if z is not None else 0, float(slope), _p(x), _ld(x), _p(stat), _p(coef),
+              _p(dgamma), _p(dbeta), rows, C, _p(ws), nb, _stream())
+    return coef
+
+
+def bn_linear_bwd_ok(rows, n, k):
+    """shapes cmr_bn_linear_bwd_f32 serves"""
+    return n in (64, 128) and k in (64, 128) and rows >= 32 and rows % 32 == 0
+
+
+def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, res=None, dx=None, want_dx=True, want_masked=False):
+    """Backward of [h = x W^T + b -> BatchNorm(train) -> (+ residual) -> LeakyReLU(slope) = z] in one pass over the row maps: with
+    (stat, coef) from bn_stats / bn_bwd_coef, dw (+)= dh^T x and dx = dh W (+ res; dx may be res itself) where
+    dh = scale (d - c1 - xhat c2), d = dz * act'(z).  stat = coef = None: no BatchNorm (dh = d).  -> (dx or None, d or None: the masked
+    gradient, what a residual branch receives), or False when the shape is not served."""
+    _rows(dz), _rows(x)
+    rows, n = dz.shape
+    k = x.shape[1]
+    if not bn_linear_bwd_ok(rows, n, k) or x.shape[0] != rows or w.shape[0] < n or w.shape[1] != k or w.stride(1) != 1 or dw.stride(1) != 1:
+        return False
+    if stat is not None and (h is None or tuple(h.shape) != (rows, n)):
+        raise ValueError("bn_linear_bwd: BatchNorm input %s vs gradient %s" % (None if h is None else tuple(h.shape), (rows, n)))
+    if want_dx and dx is None:
+        dx = torch.empty((rows, k), dtype=f32, device=x.device)
+    dzm = torch.empty((rows, n), dtype=f32, device=x.device) if want_masked else None
+    nb = _lib.load().cmr_bn_linear_bwd_workspace_bytes(rows, n, k)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_bn_linear_bwd_f32", _p(dz), _ld(dz), _p(z), _ld(z) if z is not None else 0, float(slope), _p(h), _ld(h) if h is not None else 0,
+              _p(stat), _p(coef), _p(dzm), n if want_masked else 0, _p(x), _ld(x), _p(w), w.stride(0), _p(res), _ld(res) if res is not None else 0,
+              _p(dx) if want_dx else None, _ld(dx) if want_dx else 0, rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(ws), nb, _stream())
+    return (dx if want_dx else None), dzm
+
+
 def act_bwd(dz, z, slope, add=None, out=None):
     _rows(dz), _rows(z)
     rows, C = z.shape

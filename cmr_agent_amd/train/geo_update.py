@@ -119,14 +119,14 @@ class GeoUpdate:
 
     def _mini_pointnet(self, t, x, mp):
         for layer in (mp.layer_1, mp.layer_2, mp.layer_3):
-            x = t.bn(t.linear(x, layer[0].weight, layer[0].bias), layer[1], slope=mp.SLOPE)
+            x = t.linear_bn(x, layer[0].weight, layer[0].bias, layer[1], slope=mp.SLOPE)
         return x
 
     def _cbr1d(self, t, x, m):
         """PointNN.py:260-282."""
-        h = t.bn(t.linear(x, m.net[0].weight, m.net[0].bias), m.net[1], slope=m.SLOPE)
-        sc = x if isinstance(m.shortcut, nn.Identity) else t.bn(t.linear(x, m.shortcut[0].weight, m.shortcut[0].bias), m.shortcut[1])
-        return t.bn(t.linear(h, m.net[3].weight, m.net[3].bias), m.net[4], slope=m.SLOPE, res=sc)
+        h = t.linear_bn(x, m.net[0].weight, m.net[0].bias, m.net[1], slope=m.SLOPE)
+        sc = x if isinstance(m.shortcut, nn.Identity) else t.linear_bn(x, m.shortcut[0].weight, m.shortcut[0].bias, m.shortcut[1])
+        return t.linear_bn(h, m.net[3].weight, m.net[3].bias, m.net[4], slope=m.SLOPE, res=sc)
 
     def _vector_attention(self, t, m, q_rows, k, v, rel, nseg, order, offsets, fixed_len):
         d, g = m.fc_delta, m.fc_gamma

@@ -237,6 +237,46 @@ class Tape:
         self.nodes.append(bwd)
         return y
 
+    # [1x1 conv -> BatchNorm -> (+ res) -> LeakyReLU] on a row map as ONE node whose backward is two calls: the BatchNorm reduction
+    # (cmr_bn_bwd_coef_f32) and one pass that applies it on the way into the layer's weight AND data gradient (cmr_bn_linear_bwd_f32):
+    # 4 reads + 1 write of a [rows, 64] map where bn_bwd's apply pass + linear_wgrad + the data-gradient GEMM took 6 + 2.  False = op by op.
+    FUSED_LINEAR_BN = __import__("os").environ.get("CMR_FUSED_LINEAR_BN", "1") == "1"
+    LINEAR_BN_MIN_ROWS = 8192
+
+    def linear_bn(self, x, weight, bias, bn, slope=1.0, res=None):
+        """lrelu_slope(BatchNorm(x W^T + b) (+ res)) in batch-statistics mode (MiniPointNet layers PointNN.py:96-123, the three
+        conv + BatchNorm pairs of ConvBNReLURes1D :260-282)."""
+        rows, k = x.v.shape
+        n = self.W(weight).shape[0]
+        if not (self.FUSED_LINEAR_BN and rows >= self.LINEAR_BN_MIN_ROWS and ops.bn_linear_bwd_ok(rows, n, k) and bn.running_mean.numel() == n):
+            return self.bn(self.linear(x, weight, bias), bn, slope=slope, res=res)
+        W = self.W(weight)
+        h = ops.linear(x.v, W, self.W(bias) if bias is not None else None)
+        stat = ops.bn_stats(h, self.W(bn.weight), self.W(bn.bias), bn.running_mean, bn.running_var, eps=bn.eps,
+                            momentum=bn.momentum if bn.momentum is not None else 0.1)
+        y = Var(ops.affine_act(h, stat[2], stat[3], res=None if res is None else res.v, slope=slope))
+
+        def bwd():
+            if y.g is None:
+                return
+            dg, fin_g = self.vec_out(bn.weight)
+            db, fin_b = self.vec_out(bn.bias)
+            z = None if slope == 1.0 else y.v
+            coef = ops.bn_bwd_coef(y.g, z, slope, h, stat, dg, db)
+            fin_g(), fin_b()
+            gw, acc = self.G(weight)
+            if bias is not None:
+                self.G(bias)                                   # identically zero in front of a BatchNorm: the slot keeps its zero (see conv3x3)
+            masked = res is not None and slope != 1.0
+            inplace = x.g is not None and x.own and x.g.is_contiguous()
+            dx, dzm = ops.bn_linear_bwd(y.g, z, slope, h, stat, coef, x.v, W, gw, acc, res=x.g, dx=x.g if inplace else None,
+                                        want_masked=masked)
+            x.g, x.own = dx, True
+            if res is not None:
+                self.give(res, dzm if masked else y.g, owned=False)
+        self.nodes.append(bwd)
+        return y
+
     def act(self, x, kind, param=0.0):
         y = Var(ops.act(x.v, kind, param))
 

@@ -416,6 +416,22 @@ int64_t cmr_bn_bwd_workspace_bytes(int64_t rows, int C);
 int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
                    const float* stat, const float* add, int64_t ldadd, float* dx, int64_t lddx, float* dzm, int64_t lddzm,
                    float* dgamma, float* dbeta, int64_t rows, int C, void* ws, int64_t ws_bytes, hipStream_t stream);
+/* The reduction half of cmr_bn_bwd_f32 alone (same workspace): coef [2][C] = (mean(dy), mean(dy xhat)), dgamma, dbeta. */
+int cmr_bn_bwd_coef_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,
+                        const float* stat, float* coef, float* dgamma, float* dbeta, int64_t rows, int C, void* ws, int64_t ws_bytes,
+                        hipStream_t stream);
+/* Backward of a train-mode [1x1 conv -> BatchNorm -> LeakyReLU (+ residual)] layer on a big row map in one pass over the maps
+ * (Train_Geo.py:166-174 through PointNN.py:96-123 MiniPointNet / :260-282 ConvBNReLURes1D; Train_Agent.py:296-305 through
+ * CMRAgent.py:25-33): with h = x W^T + b the BatchNorm input, z the layer output and (stat, coef) from cmr_bn_stats_f32 /
+ * cmr_bn_bwd_coef_f32:  d = dz * act'(z) (-> dzm when non-null),  dh = scale (d - c1 - xhat c2),  dw (+)= dh^T x,  dx = dh W (+ res;
+ * dx may alias res; dx null: weight gradient only).  stat = coef = null: no BatchNorm (dh = d).  z null: no activation.
+ * Serves n, k in {64, 128} and rows a multiple of 32; anything else -> CMR_EUNSUPPORTED (compose cmr_bn_bwd_f32,
+ * cmr_linear_wgrad_f32 and cmr_linear_f32 on the transposed weights). */
+int64_t cmr_bn_linear_bwd_workspace_bytes(int64_t rows, int n, int k);
+int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
+                          const float* stat, const float* coef, float* dzm, int64_t lddzm, const float* x, int64_t ldx,
+                          const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows, int n,
+                          int k, float* dw, int64_t lddw, int accumulate, void* ws, int64_t ws_bytes, hipStream_t stream);
 /* dy = dz * LeakyReLU'(z) (+ add): activation backward where no BatchNorm sits in front (identity shortcut, PointNN.py:271). */
 int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,
                     float* dy, int64_t lddy, int64_t rows, int C, hipStream_t stream);

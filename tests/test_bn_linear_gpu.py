@@ -1,0 +1,187 @@
+"""GPU tier: the one-pass backward of a train-mode [1x1 conv -> BatchNorm -> (+ residual) -> LeakyReLU] layer on a row map
+(csrc/bn_linear.hip: cmr_bn_bwd_coef_f32 + cmr_bn_linear_bwd_f32; reference Train_Geo.py:166-174 through models/PointNN.py:96-123
+MiniPointNet and :260-282 ConvBNReLURes1D) against (a) torch float64 autograd of the reference formula and (b) the op-by-op composition it
+replaces (cmr_bn_bwd_f32 + cmr_linear_wgrad_f32 + cmr_linear_f32 on the transposed weights); and Tape.linear_bn against the two tape
+nodes it replaces."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    with torch.enable_grad():
+        yield
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cmr_agent_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.rand(*shape, generator=g) * 2 - 1
+
+
+def close(got, ref, rtol, name):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = max(float(ref.abs().max()), 1e-9)
+    err = float((got - ref).abs().max())
+    assert err <= rtol * scale, "%s: max|d| %.3e vs scale %.3e" % (name, err, scale)
+
+
+def _layer64(x, w, b, gamma, beta, res, slope, mask, eps=1e-5):
+    """float64 autograd of lrelu(BN_train(x W^T + b) (+ res)).  mask: the sign pattern of the fp32 layer output -- of 3e7 outputs a
+    handful lie within fp32 rounding of zero and would take the other branch in float64, a 0.8 dz difference that has nothing to do with the
+    backward under test."""
+    h = x @ w.t() + b
+    mu, var = h.mean(0), h.var(0, unbiased=False)
+    y = (h - mu) / torch.sqrt(var + eps) * gamma + beta
+    if res is not None:
+        y = y + res
+    return y * torch.where(mask, 1.0, slope).double() if slope != 1.0 else y
+
+
+@pytest.mark.parametrize("rows,n,k,slope,with_res,prior,acc", [
+    (8192, 64, 64, 0.2, False, False, False),
+    (16384, 64, 64, 0.2, True, True, True),           # residual branch + x already holds a gradient + accumulating weight gradient
+    (12800, 64, 128, 0.2, False, True, False),
+    (9600, 128, 64, 1.0, False, False, False),         # no activation (the shortcut's BatchNorm)
+    (4096, 128, 128, 0.2, True, False, True),
+    (524288, 64, 64, 0.2, True, True, False),          # the geometric update's point maps
+    (32, 64, 64, 0.01, False, False, False),
+])
+def test_bn_linear_backward_vs_float64_and_op_by_op(ops, rows, n, k, slope, with_res, prior, acc):
+    x, w, b = rnd(rows, k, seed=1), rnd(n, k, seed=2) / 6, rnd(n, seed=3)
+    gamma, beta = 1 + 0.3 * rnd(n, seed=4), 0.2 * rnd(n, seed=5)
+    res = rnd(rows, n, seed=6) if with_res else None
+    dz = rnd(rows, n, seed=7) / rows
+    xg0 = rnd(rows, k, seed=8) / rows if prior else None
+    dw0 = rnd(n, k, seed=9) * 1e-3
+    # ---- HIP forward, op by op
+    d = lambda t: None if t is None else t.to(DEV)
+    xd, wd, bd = d(x), d(w), d(b)
+    h = ops.linear(xd, wd, bd)
+    rm, rv = torch.zeros(n, device=DEV), torch.ones(n, device=DEV)
+    stat = ops.bn_stats(h, d(gamma), d(beta), rm, rv)
+    z = ops.affine_act(h, stat[2], stat[3], res=d(res), slope=slope)
+    # ---- float64 autograd
+    X, Wd = x.double().to(DEV).requires_grad_(True), w.double().to(DEV).requires_grad_(True)
+    G, Bt = gamma.double().to(DEV).requires_grad_(True), beta.double().to(DEV).requires_grad_(True)
+    R = None if res is None else res.double().to(DEV).requires_grad_(True)
+    z64 = _layer64(X, Wd, b.double().to(DEV), G, Bt, R, slope, z > 0)
+    z64.backward(dz.double().to(DEV))
+    want_dx = X.grad + (xg0.double().to(DEV) if prior else 0)
+    want_dw = Wd.grad + (dw0.double().to(DEV) if acc else 0)
+    close(z, z64, 2e-5, "forward")
+    # ---- HIP backward, fused
+    dzd = d(dz)
+    zarg = None if slope == 1.0 else z
+    dg, db = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    coef = ops.bn_bwd_coef(dzd, zarg, slope, h, stat, dg, db)
+    dw = d(dw0).clone()
+    masked = with_res and slope != 1.0
+    xg = d(xg0).clone() if prior else None
+    out = ops.bn_linear_bwd(dzd, zarg, slope, h, stat, coef, xd, wd, dw, acc, res=xg, dx=xg, want_masked=masked)
+    assert out is not False
+    dx, dzm = out
+    if prior:
+        assert dx.data_ptr() == xg.data_ptr()                                # accumulated in place
+    close(dx, want_dx, 2e-4, "dx")
+    close(dw, want_dw, 2e-4, "dw")
+    close(dg, G.grad, 2e-4, "dgamma")
+    close(db, Bt.grad, 2e-4, "dbeta")
+    if masked:
+        close(dzm, R.grad, 1e-6, "masked gradient (residual branch)")
+    # ---- the op-by-op composition: same arithmetic for dh, other summation orders in the two GEMMs
+    dg2, db2 = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    r2 = ops.bn_bwd(dzd, zarg, slope, h, stat, dg2, db2, want_masked=masked)
+    dh = r2[0] if masked else r2
+    dw2 = d(dw0).clone()
+    ops.linear_wgrad_any(dh, xd, dw2, acc)
+    dx2 = ops.linear(dh, wd.t().contiguous(), res=d(xg0) if prior else None)
+    assert torch.equal(dg, dg2) and torch.equal(db, db2)
+    close(dx, dx2, 2e-5, "dx vs op by op")
+    close(dw, dw2, 2e-5, "dw vs op by op")
+    if masked:
+        assert torch.equal(dzm, r2[1])
+
+
+def test_no_batchnorm_variant_and_weight_gradient_only(ops):
+    """stat = coef = None: dh = dz * act'(z) (plain Linear + LeakyReLU); want_dx False: weight gradient only."""
+    rows, n, k, slope = 8192, 64, 64, 0.2
+    x, w, dz = rnd(rows, k, seed=11).to(DEV), (rnd(n, k, seed=12) / 6).to(DEV), (rnd(rows, n, seed=13) / rows).to(DEV)
+    z = F.leaky_relu(x @ w.t(), slope)
+    d64 = dz.double() * torch.where(z > 0, 1.0, slope).double()
+    dw = torch.zeros(n, k, device=DEV)
+    dx, dzm = ops.bn_linear_bwd(dz, z, slope, None, None, None, x, w, dw)
+    close(dx, d64 @ w.double(), 1e-5, "dx")
+    close(dw, d64.t() @ x.double(), 1e-5, "dw")
+    assert dzm is None
+    dw2 = torch.zeros(n, k, device=DEV)
+    dx2, _ = ops.bn_linear_bwd(dz, z, slope, None, None, None, x, w, dw2, want_dx=False)
+    assert dx2 is None and torch.equal(dw, dw2)
+    # no activation at all
+    dw3 = torch.zeros(n, k, device=DEV)
+    dx3, _ = ops.bn_linear_bwd(dz, None, 1.0, None, None, None, x, w, dw3)
+    close(dx3, dz.double() @ w.double(), 1e-5, "dx (linear)")
+    close(dw3, dz.double().t() @ x.double(), 1e-5, "dw (linear)")
+
+
+def test_unserved_shapes_are_declined(ops):
+    x, w, dz = torch.zeros(8200, 64, device=DEV), torch.zeros(64, 64, device=DEV), torch.zeros(8200, 64, device=DEV)
+    assert ops.bn_linear_bwd(dz, None, 1.0, None, None, None, x, w, torch.zeros(64, 64, device=DEV)) is False      # rows not a multiple of 32
+    x, w, dz = torch.zeros(8192, 32, device=DEV), torch.zeros(64, 32, device=DEV), torch.zeros(8192, 64, device=DEV)
+    assert ops.bn_linear_bwd(dz, None, 1.0, None, None, None, x, w, torch.zeros(64, 32, device=DEV)) is False      # k = 32
+
+
+def _stack(seed):
+    from cmr_agent_amd.models.PointNN import ConvBNReLURes1D, MiniPointNet
+    torch.manual_seed(seed)
+    m = torch.nn.ModuleList([MiniPointNet(128, 64), ConvBNReLURes1D(64, 64), ConvBNReLURes1D(128, 64)])
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    return m.to(DEV)
+
+
+def _run_stack(m, x, dout, fused):
+    from cmr_agent_amd.train.flatbucket import FlatBucket
+    from cmr_agent_amd.train.geo_update import GeoUpdate
+    from cmr_agent_amd.train.tape import Tape, Var
+    bucket = FlatBucket(m)
+    bucket.grads.zero_()
+    t = Tape(bucket, None)
+    t.FUSED_LINEAR_BN = fused
+    xv = Var(x.clone())
+    g = GeoUpdate.__new__(GeoUpdate)
+    y = g._mini_pointnet(t, xv, m[0])                 # 128 -> 64 -> 64 -> 64
+    y = g._cbr1d(t, y, m[1])                          # identity shortcut
+    y = g._cbr1d(t, t.cat(y, y), m[2])                # 128 -> 64 with a conv + BatchNorm shortcut
+    y.g = dout.clone()
+    t.backward()
+    torch.cuda.synchronize()
+    return y.v, xv.g, bucket.grads.clone(), {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+
+
+def test_tape_linear_bn_equals_the_two_nodes_it_replaces():
+    """MiniPointNet + both ConvBNReLURes1D forms through Tape.linear_bn (fused backward) and through Tape.linear + Tape.bn: same forward
+    bits (the forward launches are the same), gradients to fp32 rounding, running statistics identical."""
+    rows = 16384
+    x, dout = rnd(rows, 128, seed=21).to(DEV), (rnd(rows, 64, seed=22) / rows).to(DEV)
+    m1, m2 = _stack(5), _stack(5)
+    y1, dx1, g1, rs1 = _run_stack(m1, x, dout, True)
+    y2, dx2, g2, rs2 = _run_stack(m2, x, dout, False)
+    assert torch.equal(y1, y2)
+    for k in rs1:
+        assert torch.equal(rs1[k], rs2[k]), k
+    close(dx1, dx2, 5e-5, "dx")
+    # biases in front of a BatchNorm: exactly zero on the fused path, rounding noise op by op -> judged against the whole bucket's scale
+    close(g1, g2, 5e-5, "parameter gradients")
