@@ -39,7 +39,7 @@ struct BlbArgs {
   int64_t rows;
 };
 
-template <int NT, int KT, bool BN>
+template <int NT, int KT, bool BN, bool DEEP>
 __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   constexpr int N = 32 * NT, K = 32 * KT, DS = N + 36, XS = K + 36, R = 32;
   constexpr int TPW = NT * KT / 4;               // weight-gradient tiles per wave
@@ -149,44 +149,76 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     }
     if (!want_dx) return;
     // data gradient of rows 16 rh + j16, input channels kbase + 16 q + 4 g16 .. + 3
+    // (the two row halves side by side: 2 KQ independent accumulator chains instead of KQ)
+    f32x4 dacc[2][KQ];
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh) {
-      f32x4 dacc[KQ];
+    for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) dacc[q] = has_res ? rv[rh * KQ + q] : f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* drow = dl + (16 * rh + j16) * DS + g16;
+      for (int q = 0; q < KQ; ++q) dacc[rh][q] = has_res ? rv[rh * KQ + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* drow = dl + j16 * DS + g16;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const float b = drow[4 * s];
+    for (int s = 0; s < NS; ++s) {
+      const float b0 = drow[4 * s], b1 = drow[16 * DS + 4 * s];
 #pragma unroll
-        for (int q = 0; q < KQ; ++q) dacc[q] = m16_mfma(wa[q][s], b, dacc[q]);
+      for (int q = 0; q < KQ; ++q) {
+        dacc[0][q] = m16_mfma(wa[q][s], b0, dacc[0][q]);
+        dacc[1][q] = m16_mfma(wa[q][s], b1, dacc[1][q]);
       }
+    }
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
-        *reinterpret_cast<f32x4*>(a.dx + (blk * R + 16 * rh + j16) * a.lddx + kbase + 16 * q + 4 * g16) = dacc[q];
-    }
+        *reinterpret_cast<f32x4*>(a.dx + (blk * R + 16 * rh + j16) * a.lddx + kbase + 16 * q + 4 * g16) = dacc[rh][q];
   };
 
   const int64_t g = gridDim.x;
   auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
   int64_t blk = blockIdx.x;
-  Stage st;
   f32x4 rcur[2 * KQ];
-  load_block(clampb(blk), st);
-  store_block(blk, 0, st);
+  if (DEEP) {
+    // two blocks ahead in registers (blk + g in sa, blk + 2 g in sb; blk itself in LDS), the body unrolled twice so that the two register
+    // sets swap roles without moves
+    Stage sa, sb;
+    load_block(clampb(blk), sa);
+    store_block(blk, 0, sa);
 #pragma unroll
-  for (int i = 0; i < 2 * KQ; ++i) rcur[i] = st.r[i];
-  __syncthreads();
-  int buf = 0;
-  for (; blk < nblocks; blk += g) {
-    const int64_t nb = blk + g;
-    load_block(clampb(nb), st);                    // next block of this workgroup: in flight under the MFMAs
-    multiply(blk, buf, rcur);
-    if (nb < nblocks) store_block(nb, buf ^ 1, st);      // (uniform) the other buffer: last read one iteration ago, behind a barrier
+    for (int i = 0; i < 2 * KQ; ++i) rcur[i] = sa.r[i];
+    load_block(clampb(blk + g), sa);
+    __syncthreads();
+    for (; blk < nblocks; blk += 2 * g) {
+      load_block(clampb(blk + 2 * g), sb);
+      multiply(blk, 0, rcur);
+      if (blk + g < nblocks) store_block(blk + g, 1, sa);        // (uniform)
+#pragma unroll
+      for (int i = 0; i < 2 * KQ; ++i) rcur[i] = sa.r[i];
+      __syncthreads();
+      if (blk + g >= nblocks) break;
+      load_block(clampb(blk + 3 * g), sa);
+      multiply(blk + g, 1, rcur);
+      if (blk + 2 * g < nblocks) store_block(blk + 2 * g, 0, sb);
+#pragma unroll
+      for (int i = 0; i < 2 * KQ; ++i) rcur[i] = sb.r[i];
+      __syncthreads();
+    }
+  } else {
+    Stage st;
+    load_block(clampb(blk), st);
+    store_block(blk, 0, st);
 #pragma unroll
     for (int i = 0; i < 2 * KQ; ++i) rcur[i] = st.r[i];
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    for (; blk < nblocks; blk += g) {
+      const int64_t nb = blk + g;
+      load_block(clampb(nb), st);                    // next block of this workgroup: in flight under the MFMAs
+      multiply(blk, buf, rcur);
+      if (nb < nblocks) store_block(nb, buf ^ 1, st);      // (uniform) the other buffer: last read one iteration ago, behind a barrier
+#pragma unroll
+      for (int i = 0; i < 2 * KQ; ++i) rcur[i] = st.r[i];
+      __syncthreads();
+      buf ^= 1;
+    }
   }
   float* out = a.part + (int64_t)blockIdx.x * N * K;
 #pragma unroll
@@ -227,6 +259,186 @@ __global__ __launch_bounds__(BR_OUT * BR_GRP) void blb_reduce_kernel(const float
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Forward of the same layer: h = x W^T + b for 64 output channels WITH the BatchNorm statistics of h from the same pass (the separate
+// cmr_bn_stats_f32 sweep read h again), and optionally with the PREVIOUS layer's BatchNorm + LeakyReLU applied to x on the way in (PRO: x
+// is then the previous layer's BatchNorm input, its activated output is never written: PointNN.py:96-123 layer_1 -> layer_2 -> layer_3,
+// :260-282 net[0] -> net[3]).  Same skeleton as the backward: 32-row blocks staged through LDS one block ahead; wave w owns the output
+// channels [16 w, 16 w + 16): W in registers as the A operand of v_mfma_f32_16x16x4_f32, x rows as the B operand; a lane owns 4 channels
+// of one row -> the per-channel sums are per-lane running sums, reduced over the 16 row lanes once at the end.  Sums are taken relative to
+// a per-workgroup pivot (the workgroup's first row) and merged in double with the parallel-variance formula (bn_stats_merge_kernel).
+// ------------------------------------------------------------------------------------------------------------------
+struct BlfArgs {
+  const float* x; int64_t ldx;        // [rows][k]
+  const float* pro;                   // PRO: the previous layer's stat [4][k] (scale at 2 k, shift at 3 k)
+  float pro_slope;
+  const float* w; int64_t ldw;        // [64][k]
+  const float* bias;                  // [64] or null
+  float* h; int64_t ldh;              // [rows][64]
+  float* part;                        // [gridDim.x][3][64]: pivot, sum (h - pivot), sum (h - pivot)^2
+  int64_t rows;
+};
+
+template <int KT, bool PRO>
+__global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
+  constexpr int K = 32 * KT, XS = K + 36, R = 32, NS = K / 4, NLX = KT;
+  extern __shared__ __attribute__((aligned(16))) float blf_smem[];
+  float* Xl = blf_smem;                          // [2][R][XS]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g16 = lane >> 4, j16 = lane & 15;
+  const int64_t nblocks = a.rows / R;
+  const int xc = tid % (K / 4), xr0 = tid / (K / 4);
+  constexpr int XRS = 1024 / K;
+  f32x4 pscale, pshift;
+  if (PRO) {
+    pscale = *reinterpret_cast<const f32x4*>(a.pro + 2 * K + 4 * xc);
+    pshift = *reinterpret_cast<const f32x4*>(a.pro + 3 * K + 4 * xc);
+  }
+  const int cbase = 16 * wave;
+  float wa[NS];                                  // A operand: lane 16 g + i holds W[cbase + i][4 s + g]
+#pragma unroll
+  for (int s = 0; s < NS; ++s) wa[s] = a.w[(int64_t)(cbase + j16) * a.ldw + 4 * s + g16];
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + cbase + 4 * g16);
+
+  auto load_block = [&](int64_t blk, f32x4 (&xv)[NLX]) {
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) xv[i] = *reinterpret_cast<const f32x4*>(a.x + (blk * R + xr0 + XRS * i) * a.ldx + 4 * xc);
+  };
+  auto store_block = [&](int buf, const f32x4 (&xv)[NLX]) {
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      f32x4 v = xv[i];
+      if (PRO) {
+        v = v * pscale + pshift;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.pro_slope;
+      }
+      *reinterpret_cast<f32x4*>(Xl + (buf * R + xr0 + XRS * i) * XS + 4 * xc) = v;
+    }
+  };
+  f32x4 pivot = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  bool first = true;
+  auto multiply = [&](int64_t blk, int buf) {
+    const float* xl = Xl + buf * R * XS;
+    f32x4 acc[2] = {bias4, bias4};                 // the two row halves side by side: two independent accumulator chains
+    const float* xrow = xl + j16 * XS + g16;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float b0 = xrow[4 * s], b1 = xrow[16 * XS + 4 * s];
+      acc[0] = m16_mfma(wa[s], b0, acc[0]);
+      acc[1] = m16_mfma(wa[s], b1, acc[1]);
+    }
+    if (first) {                                   // (uniform) pivot = this workgroup's first row: lane 16 g of each lane group holds it
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pivot[e] = __shfl(acc[0][e], lane & 48, 64);
+      first = false;
+    }
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh) {
+      *reinterpret_cast<f32x4*>(a.h + (blk * R + 16 * rh + j16) * a.ldh + cbase + 4 * g16) = acc[rh];
+      const f32x4 d = acc[rh] - pivot;
+      sum += d;
+      sq += d * d;
+    }
+  };
+  const int64_t g = gridDim.x;
+  auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
+  int64_t blk = blockIdx.x;
+  // Two blocks ahead in registers (blk + g in xa, blk + 2 g in xb; blk itself in LDS): 8 - 16 KB per block and workgroup, so with ONE block
+  // in flight a CU had 32 KB outstanding -- 8 MB on the chip against the ~16 MB that 8 TB/s x 2 us of loaded latency asks for (measured:
+  // 3.7 TB/s).  The body is unrolled twice so that the two register sets swap roles without moves.
+  f32x4 xa[NLX], xb[NLX];
+  load_block(clampb(blk), xa);
+  store_block(0, xa);
+  load_block(clampb(blk + g), xa);
+  __syncthreads();
+  for (; blk < nblocks; blk += 2 * g) {
+    load_block(clampb(blk + 2 * g), xb);
+    multiply(blk, 0);
+    store_block(1, xa);
+    __syncthreads();
+    if (blk + g >= nblocks) break;                 // (uniform)
+    load_block(clampb(blk + 3 * g), xa);
+    multiply(blk + g, 1);
+    store_block(0, xb);
+    __syncthreads();
+  }
+  // reduce over the 16 row lanes (DPP, fixed order); lane 16 g writes channels cbase + 4 g .. + 3
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    sum[e] = m16_sum16(sum[e]);
+    sq[e] = m16_sum16(sq[e]);
+  }
+  if (j16 == 0) {
+    float* p = a.part + (int64_t)blockIdx.x * 192 + cbase + 4 * g16;
+    *reinterpret_cast<f32x4*>(p) = pivot;
+    *reinterpret_cast<f32x4*>(p + 64) = sum;
+    *reinterpret_cast<f32x4*>(p + 128) = sq;
+  }
+}
+
+__device__ __forceinline__ double blf_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// one wave per channel: merge the workgroups' (pivot, sum, sum of squares) over their row counts in double (parallel variance), then what
+// cmr_bn_stats_f32's final step does: stat = (mean, rstd, scale, shift), running statistics.  Workgroup w of G held the blocks w, w + G, ...
+__global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restrict__ part, int G, int64_t nblocks, int64_t rows, float eps,
+                                                            float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                            float* __restrict__ stat) {
+  constexpr int C = 64;
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double tot = 0.0;
+  for (int w = lane; w < G; w += 64) {
+    const double n = 32.0 * (double)((nblocks - w + G - 1) / G);
+    tot += n * (double)part[(int64_t)w * 192 + c] + (double)part[(int64_t)w * 192 + 64 + c];
+  }
+  const double mean = blf_wave_sum(tot) / (double)rows;
+  double m2 = 0.0;
+  for (int w = lane; w < G; w += 64) {
+    const double n = 32.0 * (double)((nblocks - w + G - 1) / G);
+    const double s = (double)part[(int64_t)w * 192 + 64 + c], ss = (double)part[(int64_t)w * 192 + 128 + c];
+    const double mw = (double)part[(int64_t)w * 192 + c] + s / n;
+    m2 += (ss - s * s / n) + n * (mw - mean) * (mw - mean);
+  }
+  m2 = blf_wave_sum(m2);
+  if (lane != 0) return;
+  const double n = (double)rows;
+  double var = m2 / n;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float scale = gm * rstd;
+  stat[c] = (float)mean;
+  stat[C + c] = rstd;
+  stat[2 * C + c] = scale;
+  stat[3 * C + c] = bt - (float)mean * scale;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+inline int blf_groups(int64_t rows, int k) {
+  const int64_t nblocks = rows / 32;
+  int64_t groups = 256 * (k == 64 ? 4 : 3);
+  if (groups > nblocks / 8) groups = nblocks / 8 > 0 ? nblocks / 8 : 1;      // >= 8 row blocks per workgroup: the W fragments and the pipeline fill are paid once
+  return (int)groups;
+}
+
+template <int KT, bool PRO>
+int blf_launch(const BlfArgs& a, int groups, hipStream_t stream) {
+  const size_t smem = (size_t)2 * 32 * (32 * KT + 36) * sizeof(float);
+  hipLaunchKernelGGL((bn_linear_fwd_kernel<KT, PRO>), dim3(groups), dim3(256), smem, stream, a);
+  return CMR_OK;
+}
+
 inline int blb_groups(int64_t rows, int n, int k) {
   const int64_t nblocks = rows / 32;
   const size_t smem = (size_t)2 * 32 * (n + k + 72) * sizeof(float);
@@ -238,12 +450,16 @@ inline int blb_groups(int64_t rows, int n, int k) {
   return (int)groups;
 }
 
+#ifndef CMR_BLB_DEEP
+#define CMR_BLB_DEEP 0
+#endif
 template <int NT, int KT, bool BN>
 int blb_launch(const BlbArgs& a, int groups, hipStream_t stream) {
+  constexpr bool DEEP = CMR_BLB_DEEP != 0 && NT == 2 && KT == 2;
   const size_t smem = (size_t)2 * 32 * (32 * NT + 32 * KT + 72) * sizeof(float);
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
-  hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN>), dim3(groups), dim3(256), smem, stream, a);
+  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN, DEEP>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN, DEEP>), dim3(groups), dim3(256), smem, stream, a);
   return CMR_OK;
 }
 
@@ -293,5 +509,35 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   const int64_t outs = (int64_t)n * k;
   hipLaunchKernelGGL(blb_reduce_kernel, dim3((unsigned)((outs + BR_OUT - 1) / BR_OUT)), dim3(BR_OUT * BR_GRP), 0, stream, (const float*)ws, groups,
                      n, k, dw, lddw, accumulate);
+  return cmr_launch_status();
+}
+
+extern "C" int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int k) {
+  if (!(k == 64 || k == 128) || rows < 32 || rows % 32) return 0;
+  return (int64_t)blf_groups(rows, k) * 192 * (int64_t)sizeof(float);
+}
+
+// h [rows][64] = x' W^T + bias with x' = x, or (pro_stat non-null) x' = lrelu_{pro_slope}(x * pro_stat[2] + pro_stat[3]): the previous
+// layer's BatchNorm + LeakyReLU applied on the way in; and stat [4][64] = the batch statistics of h as cmr_bn_stats_f32 returns them
+// (running statistics updated when given).  Serves k in {64, 128}, rows a multiple of 32; else CMR_EUNSUPPORTED.
+extern "C" int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
+                                     const float* bias, float* h, int64_t ldh, int64_t rows, float eps, float momentum, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float* stat, void* ws, int64_t ws_bytes,
+                                     hipStream_t stream) {
+  CMR_REQUIRE(x && w && h && stat && ws && rows > 0 && k > 0);
+  if (!(k == 64 || k == 128) || rows < 32 || rows % 32) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(ldx % 4 == 0 && ldh % 4 == 0 && ldx >= k && ldh >= 64 && ldw >= k && cmr_aligned16(x) && cmr_aligned16(h));
+  CMR_REQUIRE((!bias || cmr_aligned16(bias)) && (!pro_stat || cmr_aligned16(pro_stat)));
+  CMR_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  const int groups = blf_groups(rows, k);
+  CMR_REQUIRE(ws_bytes >= (int64_t)groups * 192 * (int64_t)sizeof(float));
+  const BlfArgs a{x, ldx, pro_stat, pro_slope, w, ldw, bias, h, ldh, (float*)ws, rows};
+  if (k == 64) {
+    if (pro_stat) blf_launch<2, true>(a, groups, stream); else blf_launch<2, false>(a, groups, stream);
+  } else {
+    if (pro_stat) blf_launch<4, true>(a, groups, stream); else blf_launch<4, false>(a, groups, stream);
+  }
+  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(64), dim3(64), 0, stream, (const float*)ws, groups, rows / 32, rows, eps, momentum, gamma, beta,
+                     running_mean, running_var, stat);
   return cmr_launch_status();
 }

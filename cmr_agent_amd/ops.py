@@ -774,6 +774,29 @@ def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None, w
     return (out, dzm) if want_masked else out
 
 
+def linear_bn_fwd_ok(rows, n, k):
+    return n == 64 and k in (64, 128) and rows >= 32 and rows % 32 == 0
+
+
+def linear_bn_fwd(x, w, bias, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, pro=None, pro_slope=1.0):
+    """-> (h [rows, 64] = x' W^T + bias, stat [4, 64] = bn_stats(h)) in one pass; pro = the previous layer's stat [4, k]: x' =
+    lrelu_{pro_slope}(x * pro[2] + pro[3]) (x is then that layer's BatchNorm input).  False when the shape is not served."""
+    _rows(x)
+    rows, k = x.shape
+    n = gamma.numel()
+    if not linear_bn_fwd_ok(rows, n, k) or w.shape[0] < n or w.shape[1] != k or w.stride(1) != 1:
+        return False
+    if pro is not None and tuple(pro.shape) != (4, k):
+        raise ValueError("linear_bn_fwd: prologue statistics %s for an input of width %d" % (tuple(pro.shape), k))
+    h = torch.empty((rows, n), dtype=f32, device=x.device)
+    stat = torch.empty((4, n), dtype=f32, device=x.device)
+    nb = _lib.load().cmr_linear_bn_fwd_workspace_bytes(rows, k)
+    ws = _ws(nb, x.device)
+    _lib.call("cmr_linear_bn_fwd_f32", _p(x), _ld(x), k, _p(pro), float(pro_slope), _p(w), w.stride(0), _p(bias), _p(h), n, rows, float(eps),
+              float(momentum), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(stat), _p(ws), nb, _stream())
+    return h, stat
+
+
 def bn_bwd_coef(dz, z, slope, x, stat, dgamma=None, dbeta=None):
     """The reduction half of bn_bwd alone -> coef [2, C] = (mean(dy), mean(dy xhat)) (and dgamma / dbeta): the apply half rides in
     bn_linear_bwd's prologue."""

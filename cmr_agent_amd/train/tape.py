@@ -241,6 +241,7 @@ class Tape:
     # (cmr_bn_bwd_coef_f32) and one pass that applies it on the way into the layer's weight AND data gradient (cmr_bn_linear_bwd_f32):
     # 4 reads + 1 write of a [rows, 64] map where bn_bwd's apply pass + linear_wgrad + the data-gradient GEMM took 6 + 2.  False = op by op.
     FUSED_LINEAR_BN = __import__("os").environ.get("CMR_FUSED_LINEAR_BN", "1") == "1"
+    FUSED_LINEAR_BN_FWD = __import__("os").environ.get("CMR_FUSED_LINEAR_BN_FWD", "1") == "1"
     LINEAR_BN_MIN_ROWS = 8192
 
     def linear_bn(self, x, weight, bias, bn, slope=1.0, res=None):
@@ -248,12 +249,19 @@ class Tape:
         conv + BatchNorm pairs of ConvBNReLURes1D :260-282)."""
         rows, k = x.v.shape
         n = self.W(weight).shape[0]
-        if not (self.FUSED_LINEAR_BN and rows >= self.LINEAR_BN_MIN_ROWS and ops.bn_linear_bwd_ok(rows, n, k) and bn.running_mean.numel() == n):
+        if not ((self.FUSED_LINEAR_BN or self.FUSED_LINEAR_BN_FWD) and rows >= self.LINEAR_BN_MIN_ROWS and ops.bn_linear_bwd_ok(rows, n, k) and
+                bn.running_mean.numel() == n):
             return self.bn(self.linear(x, weight, bias), bn, slope=slope, res=res)
+        fused_bwd = self.FUSED_LINEAR_BN
         W = self.W(weight)
-        h = ops.linear(x.v, W, self.W(bias) if bias is not None else None)
-        stat = ops.bn_stats(h, self.W(bn.weight), self.W(bn.bias), bn.running_mean, bn.running_var, eps=bn.eps,
-                            momentum=bn.momentum if bn.momentum is not None else 0.1)
+        mom = bn.momentum if bn.momentum is not None else 0.1
+        fwd = ops.linear_bn_fwd(x.v, W, self.W(bias) if bias is not None else None, self.W(bn.weight), self.W(bn.bias), bn.running_mean,
+                                bn.running_var, eps=bn.eps, momentum=mom) if self.FUSED_LINEAR_BN_FWD else False
+        if fwd is not False:
+            h, stat = fwd                                   # the statistics come out of the GEMM's own pass
+        else:
+            h = ops.linear(x.v, W, self.W(bias) if bias is not None else None)
+            stat = ops.bn_stats(h, self.W(bn.weight), self.W(bn.bias), bn.running_mean, bn.running_var, eps=bn.eps, momentum=mom)
         y = Var(ops.affine_act(h, stat[2], stat[3], res=None if res is None else res.v, slope=slope))
 
         def bwd():
@@ -262,15 +270,21 @@ class Tape:
             dg, fin_g = self.vec_out(bn.weight)
             db, fin_b = self.vec_out(bn.bias)
             z = None if slope == 1.0 else y.v
-            coef = ops.bn_bwd_coef(y.g, z, slope, h, stat, dg, db)
-            fin_g(), fin_b()
+            masked = res is not None and slope != 1.0
+            inplace = x.g is not None and x.own and x.g.is_contiguous()
             gw, acc = self.G(weight)
             if bias is not None:
                 self.G(bias)                                   # identically zero in front of a BatchNorm: the slot keeps its zero (see conv3x3)
-            masked = res is not None and slope != 1.0
-            inplace = x.g is not None and x.own and x.g.is_contiguous()
-            dx, dzm = ops.bn_linear_bwd(y.g, z, slope, h, stat, coef, x.v, W, gw, acc, res=x.g, dx=x.g if inplace else None,
-                                        want_masked=masked)
+            if fused_bwd:
+                coef = ops.bn_bwd_coef(y.g, z, slope, h, stat, dg, db)
+                dx, dzm = ops.bn_linear_bwd(y.g, z, slope, h, stat, coef, x.v, W, gw, acc, res=x.g, dx=x.g if inplace else None,
+                                            want_masked=masked)
+            else:                                              # the same arithmetic, one launch per step of it
+                r = ops.bn_bwd(y.g, z, slope, h, stat, dg, db, want_masked=masked)
+                dh, dzm = r if masked else (r, None)
+                ops.linear_wgrad_any(dh, x.v, gw, acc)
+                dx = ops.linear(dh, self.WT(weight), res=x.g, out=x.g if inplace else None)
+            fin_g(), fin_b()
             x.g, x.own = dx, True
             if res is not None:
                 self.give(res, dzm if masked else y.g, owned=False)

@@ -113,6 +113,43 @@ def test_bn_linear_backward_vs_float64_and_op_by_op(ops, rows, n, k, slope, with
         assert torch.equal(dzm, r2[1])
 
 
+@pytest.mark.parametrize("rows,k,pro", [(8192, 64, False), (12800, 128, False), (524288, 64, True), (16384, 128, True), (32, 64, False), (96, 64, True)])
+def test_linear_with_statistics_in_one_pass(ops, rows, k, pro):
+    """cmr_linear_bn_fwd_f32: h = x' W^T + b and the batch statistics of h from the same pass (per-workgroup pivots merged in double) against
+    float64, and against cmr_linear_f32 + cmr_bn_stats_f32; pro: the previous layer's BatchNorm + LeakyReLU applied to x on the way in."""
+    n = 64
+    x, w, b = rnd(rows, k, seed=31) + 0.5, rnd(n, k, seed=32) / 6, rnd(n, seed=33) * 3          # channel means well away from zero
+    gamma, beta = (1 + 0.3 * rnd(n, seed=34)).to(DEV), (0.2 * rnd(n, seed=35)).to(DEV)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    rm0, rv0 = rnd(n, seed=36).to(DEV), (1.5 + 0.5 * rnd(n, seed=37)).to(DEV)
+    prostat, slope = None, 1.0
+    xin = xd
+    if pro:
+        prostat = torch.stack([torch.zeros(k), torch.ones(k), 1 + 0.5 * rnd(k, seed=38), 0.3 * rnd(k, seed=39)]).to(DEV).contiguous()
+        slope = 0.2
+        xin = ops.affine_act(xd, prostat[2], prostat[3], slope=slope)
+    rm, rv = rm0.clone(), rv0.clone()
+    out = ops.linear_bn_fwd(xd, wd, bd, gamma, beta, rm, rv, eps=1e-5, momentum=0.1, pro=prostat, pro_slope=slope)
+    assert out is not False
+    h, stat = out
+    h64 = xin.double() @ wd.double().t() + bd.double()
+    close(h, h64, 2e-6, "h")
+    mean, var = h64.mean(0), h64.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    close(stat[0], mean, 2e-6, "mean")
+    close(stat[1], rstd, 5e-6, "rstd")
+    close(stat[2], gamma.double() * rstd, 5e-6, "scale")
+    close(stat[3], beta.double() - mean * gamma.double() * rstd, 2e-5, "shift")
+    close(rm, 0.9 * rm0.double() + 0.1 * mean, 2e-6, "running_mean")
+    close(rv, 0.9 * rv0.double() + 0.1 * var * rows / max(rows - 1, 1), 5e-6, "running_var")
+    # the two launches it replaces
+    h2 = ops.linear(xin, wd, bd)
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    stat2 = ops.bn_stats(h2, gamma, beta, rm2, rv2, eps=1e-5, momentum=0.1)
+    close(h, h2, 2e-6, "h vs cmr_linear_f32")
+    close(stat, stat2, 2e-5, "stat vs cmr_bn_stats_f32")
+
+
 def test_no_batchnorm_variant_and_weight_gradient_only(ops):
     """stat = coef = None: dh = dz * act'(z) (plain Linear + LeakyReLU); want_dx False: weight gradient only."""
     rows, n, k, slope = 8192, 64, 64, 0.2
@@ -152,14 +189,14 @@ def _stack(seed):
     return m.to(DEV)
 
 
-def _run_stack(m, x, dout, fused):
+def _run_stack(m, x, dout, fused_fwd, fused_bwd):
     from cmr_agent_amd.train.flatbucket import FlatBucket
     from cmr_agent_amd.train.geo_update import GeoUpdate
     from cmr_agent_amd.train.tape import Tape, Var
     bucket = FlatBucket(m)
     bucket.grads.zero_()
     t = Tape(bucket, None)
-    t.FUSED_LINEAR_BN = fused
+    t.FUSED_LINEAR_BN_FWD, t.FUSED_LINEAR_BN = fused_fwd, fused_bwd
     xv = Var(x.clone())
     g = GeoUpdate.__new__(GeoUpdate)
     y = g._mini_pointnet(t, xv, m[0])                 # 128 -> 64 -> 64 -> 64
@@ -168,20 +205,28 @@ def _run_stack(m, x, dout, fused):
     y.g = dout.clone()
     t.backward()
     torch.cuda.synchronize()
-    return y.v, xv.g, bucket.grads.clone(), {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+    grads = {k: bucket.gp(p).clone() for k, p in m.named_parameters()}
+    return y.v, xv.g, grads, {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
 
 
 def test_tape_linear_bn_equals_the_two_nodes_it_replaces():
-    """MiniPointNet + both ConvBNReLURes1D forms through Tape.linear_bn (fused backward) and through Tape.linear + Tape.bn: same forward
-    bits (the forward launches are the same), gradients to fp32 rounding, running statistics identical."""
+    """MiniPointNet + both ConvBNReLURes1D forms through Tape.linear_bn against Tape.linear + Tape.bn.  (a) Fused forward vs the two
+    launches: outputs and running statistics to fp32 rounding.  (b) On the SAME forward (so that no activation within rounding of zero takes
+    the other LeakyReLU branch -- one such flip moves a weight gradient, a random-sign sum over 16 384 rows, by ~1/128 of its size), the
+    fused backward vs bn_bwd + linear_wgrad + the data-gradient GEMM: every gradient to fp32 rounding."""
     rows = 16384
     x, dout = rnd(rows, 128, seed=21).to(DEV), (rnd(rows, 64, seed=22) / rows).to(DEV)
-    m1, m2 = _stack(5), _stack(5)
-    y1, dx1, g1, rs1 = _run_stack(m1, x, dout, True)
-    y2, dx2, g2, rs2 = _run_stack(m2, x, dout, False)
-    assert torch.equal(y1, y2)
+    y0, _, _, rs0 = _run_stack(_stack(5), x, dout, False, False)
+    y1, dx1, g1, rs1 = _run_stack(_stack(5), x, dout, True, True)
+    y2, dx2, g2, rs2 = _run_stack(_stack(5), x, dout, True, False)
+    close(y1, y0, 2e-5, "forward")
     for k in rs1:
-        assert torch.equal(rs1[k], rs2[k]), k
-    close(dx1, dx2, 5e-5, "dx")
-    # biases in front of a BatchNorm: exactly zero on the fused path, rounding noise op by op -> judged against the whole bucket's scale
-    close(g1, g2, 5e-5, "parameter gradients")
+        close(rs1[k], rs0[k], 1e-5, k)
+    assert torch.equal(y1, y2)
+    close(dx1, dx2, 2e-5, "dx")
+    gmax = max(float(v.abs().max()) for v in g2.values())
+    for k in g2:
+        err = float((g1[k] - g2[k]).abs().max())
+        assert err <= 2e-5 * gmax, "%s: max|d| %.3e vs largest gradient %.3e" % (k, err, gmax)
+        if g2[k].dim() == 1 and k.endswith(("0.bias", "3.bias")):
+            assert float(g1[k].abs().max()) == 0.0, k             # a Conv1d bias in front of a BatchNorm: true gradient zero, not computed

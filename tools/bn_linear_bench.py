@@ -37,6 +37,16 @@ def main():
         def new():
             cc = ops.bn_bwd_coef(dz, z, 0.2, h, stat, dg, db)
             ops.bn_linear_bwd(dz, z, 0.2, h, stat, cc, x, w, dw, res=xg, dx=dx)
+        if n == 64:
+            gm, bt = torch.ones(n, device=dev), torch.zeros(n, device=dev)
+            t_f_old = timeit(lambda: ops.bn_stats(ops.linear(x, w), gm, bt), 10)
+            t_f_new = timeit(lambda: ops.linear_bn_fwd(x, w, None, gm, bt), 10)
+            t_f_pro = timeit(lambda: ops.linear_bn_fwd(x, w, None, gm, bt, pro=torch.ones(4, k, device=dev), pro_slope=0.2), 10) if False else float("nan")
+            pro = torch.ones(4, k, device=dev)
+            t_f_pro = timeit(lambda: ops.linear_bn_fwd(x, w, None, gm, bt, pro=pro, pro_slope=0.2), 10)
+            t_aff = timeit(lambda: ops.affine_act(h, stat[2], stat[3], slope=0.2), 10)
+            print("rows %6d  %3d <- %3d forward: linear + bn_stats %6.1f us | one pass %6.1f us (%.2f TB/s), with prologue %6.1f us | affine_act %6.1f us" % (
+                rows, n, k, t_f_old, t_f_new, 4.0 * rows * (n + k) / t_f_new / 1e6, t_f_pro, t_aff))
         t_old, t_coef, t_fused, t_new = timeit(old, 10), timeit(coef, 10), timeit(fused, 10), timeit(new, 10)
         by = 4.0 * rows * (3 * n + k * (2 + (1 if res else 0)))
         print("rows %6d  %3d <- %3d res %d : op by op %7.1f us | coef %6.1f + fused %6.1f = %7.1f us (fused pass: %.2f TB/s algorithmic, %.1f TF/s)" % (
