@@ -37,10 +37,23 @@ struct BlbArgs {
   float* dx; int64_t lddx;              // optional
   float* part;                          // [gridDim.x][n][k]
   int64_t rows;
+  // XL: x is the PREVIOUS layer's BatchNorm input; this layer's operand is lrelu_{xslope}(x * xstat[2] + xstat[3]) (never stored), and the
+  // BatchNorm-backward sums of the previous layer (sum d', sum d' xhat' with d' = dx * act', over this workgroup's rows) go to xpart
+  const float* xstat;                   // [4][k]
+  float xslope;
+  float* xpart;                         // [gridDim.x][2][k]
 };
 
-template <int NT, int KT, bool BN, bool DEEP>
+__device__ __forceinline__ f32x4 blb_fma4(f32x4 a, f32x4 b, f32x4 c) {
+  return f32x4{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]), __builtin_fmaf(a[3], b[3], c[3])};
+}
+
+// ZH: the activation mask is the sign of this layer's own pre-activation h * scale + shift (the layer's output was never stored: it was
+// consumed through the next layer's prologue); XL: see BlbArgs.  Pre-activations are formed with the SAME fused multiply-add in the forward
+// prologue (bn_linear_fwd_kernel), here and in the mask, so that a value within rounding of zero takes the same branch everywhere.
+template <int NT, int KT, bool BN, bool DEEP, bool ZH, bool XL>
 __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
+  static_assert(BN || !(ZH || XL), "lazy operands belong to BatchNorm layers");
   constexpr int N = 32 * NT, K = 32 * KT, DS = N + 36, XS = K + 36, R = 32;
   constexpr int TPW = NT * KT / 4;               // weight-gradient tiles per wave
   constexpr int KQ = K / 64;                     // data gradient: 16-channel tiles per wave
@@ -60,11 +73,12 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   const int xc = tid % (K / 4), xr0 = tid / (K / 4);
   constexpr int DRS = 1024 / N, XRS = 1024 / K;
 
-  f32x4 mean, rstd, scale, c1, c2;
+  f32x4 mean, rstd, scale, shift, c1, c2;
   if (BN) {
     mean = *reinterpret_cast<const f32x4*>(a.stat + 4 * dc);
     rstd = *reinterpret_cast<const f32x4*>(a.stat + N + 4 * dc);
     scale = *reinterpret_cast<const f32x4*>(a.stat + 2 * N + 4 * dc);
+    if (ZH) shift = *reinterpret_cast<const f32x4*>(a.stat + 3 * N + 4 * dc);
     c1 = *reinterpret_cast<const f32x4*>(a.coef + 4 * dc);
     c2 = *reinterpret_cast<const f32x4*>(a.coef + N + 4 * dc);
   }
@@ -83,6 +97,28 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  // XL: the previous layer's affine for the weight-gradient operand (lane = channel 32 kt + l31 of tile t) and, in the data gradient's
+  // layout (channels kbase + 16 q + 4 g16 .. + 3), its affine and its normalisation; running sums of its BatchNorm backward
+  float xs_w[TPW], xb_w[TPW];
+  f32x4 xs_d[KQ], xb_d[KQ], xm_d[KQ], xr_d[KQ], s1[KQ], s2[KQ];
+  if (XL) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int kt = (wave * TPW + t) % KT;
+      xs_w[t] = a.xstat[2 * K + 32 * kt + l31];
+      xb_w[t] = a.xstat[3 * K + 32 * kt + l31];
+    }
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      const int c = kbase + 16 * q + 4 * g16;
+      xm_d[q] = *reinterpret_cast<const f32x4*>(a.xstat + c);
+      xr_d[q] = *reinterpret_cast<const f32x4*>(a.xstat + K + c);
+      xs_d[q] = *reinterpret_cast<const f32x4*>(a.xstat + 2 * K + c);
+      xb_d[q] = *reinterpret_cast<const f32x4*>(a.xstat + 3 * K + c);
+      s1[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      s2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
   struct Stage {
     f32x4 d[NLD], m[NLD], hv[NLD], x[NLX], r[2 * KQ];
@@ -95,7 +131,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     for (int i = 0; i < NLD; ++i) {
       const int64_t row = r0 + dr0 + DRS * i;
       s.d[i] = *reinterpret_cast<const f32x4*>(a.dz + row * a.lddz + 4 * dc);
-      s.m[i] = *reinterpret_cast<const f32x4*>(a.z + row * a.ldz + 4 * dc);
+      if (!ZH) s.m[i] = *reinterpret_cast<const f32x4*>(a.z + row * a.ldz + 4 * dc);
       if (BN) s.hv[i] = *reinterpret_cast<const f32x4*>(a.h + row * a.ldh + 4 * dc);
     }
 #pragma unroll
@@ -118,8 +154,9 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     for (int i = 0; i < NLD; ++i) {
       const int r = dr0 + DRS * i;
       f32x4 d = s.d[i];
+      const f32x4 m = ZH ? blb_fma4(s.hv[i], scale, shift) : s.m[i];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) d[e] = s.m[i][e] > 0.f ? d[e] : d[e] * a.slope;
+      for (int e = 0; e < 4; ++e) d[e] = m[e] > 0.f ? d[e] : d[e] * a.slope;
       if (a.dzm) *reinterpret_cast<f32x4*>(a.dzm + (r0 + r) * a.lddzm + 4 * dc) = d;
       if (BN) {
         const f32x4 xh = (s.hv[i] - mean) * rstd;
@@ -144,7 +181,12 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
-        acc[t] = cmr_mfma32(dl[rr * DS + 32 * nt + l31], xl[rr * XS + 32 * kt + l31], acc[t]);
+        float b = xl[rr * XS + 32 * kt + l31];
+        if (XL) {
+          b = __builtin_fmaf(b, xs_w[t], xb_w[t]);
+          b = b > 0.f ? b : b * a.xslope;
+        }
+        acc[t] = cmr_mfma32(dl[rr * DS + 32 * nt + l31], b, acc[t]);
       }
     }
     if (!want_dx) return;
@@ -168,8 +210,19 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
 #pragma unroll
     for (int rh = 0; rh < 2; ++rh)
 #pragma unroll
-      for (int q = 0; q < KQ; ++q)
+      for (int q = 0; q < KQ; ++q) {
         *reinterpret_cast<f32x4*>(a.dx + (blk * R + 16 * rh + j16) * a.lddx + kbase + 16 * q + 4 * g16) = dacc[rh][q];
+        if (XL) {
+          // dx is the gradient at the previous layer's (never stored) output: its BatchNorm-backward sums from the raw BatchNorm input in LDS
+          const f32x4 raw = *reinterpret_cast<const f32x4*>(xl + (16 * rh + j16) * XS + kbase + 16 * q + 4 * g16);
+          const f32x4 pre = blb_fma4(raw, xs_d[q], xb_d[q]);
+          f32x4 dp = dacc[rh][q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dp[e] = pre[e] > 0.f ? dp[e] : dp[e] * a.xslope;
+          s1[q] += dp;
+          s2[q] += dp * ((raw - xm_d[q]) * xr_d[q]);
+        }
+      }
   };
 
   const int64_t g = gridDim.x;
@@ -227,6 +280,44 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[(int64_t)(nt * 32 + cmr_mfma_row(r, lane)) * K + kt * 32 + l31] = acc[t][r];
   }
+  if (XL) {
+    // the 16 row lanes of a lane group hold the same channels: fixed-order DPP sum, lane 16 g writes (bn_bwd_partial_kernel's layout)
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[q][e] = m16_sum16(s1[q][e]);
+        s2[q][e] = m16_sum16(s2[q][e]);
+      }
+      if (j16 == 0) {
+        float* p = a.xpart + (int64_t)blockIdx.x * 2 * K + kbase + 16 * q + 4 * g16;
+        *reinterpret_cast<f32x4*>(p) = s1[q];
+        *reinterpret_cast<f32x4*>(p + K) = s2[q];
+      }
+    }
+  }
+}
+
+// coef[0][c] = sum d / rows, coef[1][c] = sum d xhat / rows, dgamma = sum d xhat, dbeta = sum d: one wave per channel over the workgroups'
+// partials, in double (train.hip: bn_bwd_final_kernel's arithmetic)
+__global__ __launch_bounds__(64) void blb_coef_final_kernel(const float* __restrict__ part, int nblk, int64_t rows, int C, float* __restrict__ coef,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, sx = 0.0;
+  for (int b = lane; b < nblk; b += 64) {
+    s += (double)part[(int64_t)b * 2 * C + c];
+    sx += (double)part[(int64_t)b * 2 * C + C + c];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    sx += __shfl_xor(sx, o, 64);
+  }
+  if (lane != 0) return;
+  coef[c] = (float)(s / (double)rows);
+  coef[C + c] = (float)(sx / (double)rows);
+  if (dbeta) dbeta[c] = (float)s;
+  if (dgamma) dgamma[c] = (float)sx;
 }
 
 // dw[i] (+)= sum over the workgroups' partials, in double, fixed order (32 slice groups x 8 loads in flight)
@@ -311,7 +402,8 @@ __global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
     for (int i = 0; i < NLX; ++i) {
       f32x4 v = xv[i];
       if (PRO) {
-        v = v * pscale + pshift;
+        v = f32x4{__builtin_fmaf(v[0], pscale[0], pshift[0]), __builtin_fmaf(v[1], pscale[1], pshift[1]), __builtin_fmaf(v[2], pscale[2], pshift[2]),
+                  __builtin_fmaf(v[3], pscale[3], pshift[3])};          // (the same fused multiply-add as the backward's recomputation)
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.pro_slope;
       }
@@ -451,64 +543,83 @@ inline int blb_groups(int64_t rows, int n, int k) {
 }
 
 #ifndef CMR_BLB_DEEP
-#define CMR_BLB_DEEP 0
+#define CMR_BLB_DEEP 0        // two blocks ahead in registers: measured slower at 64 x 64 (174 VGPRs = 2 workgroups per CU: 147 us against 135)
 #endif
-template <int NT, int KT, bool BN>
+template <int NT, int KT, bool BN, bool ZH, bool XL>
 int blb_launch(const BlbArgs& a, int groups, hipStream_t stream) {
-  constexpr bool DEEP = CMR_BLB_DEEP != 0 && NT == 2 && KT == 2;
+  constexpr bool DEEP = CMR_BLB_DEEP != 0 && NT == 2 && KT == 2 && !XL;
   const size_t smem = (size_t)2 * 32 * (32 * NT + 32 * KT + 72) * sizeof(float);
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN, DEEP>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
-  hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN, DEEP>), dim3(groups), dim3(256), smem, stream, a);
+  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL>), dim3(groups), dim3(256), smem, stream, a);
   return CMR_OK;
+}
+
+template <int NT, int KT>
+int blb_dispatch(const BlbArgs& a, bool bn, bool zh, bool xl, int groups, hipStream_t stream) {
+  if (!bn) return blb_launch<NT, KT, false, false, false>(a, groups, stream);
+  if (xl) {
+    if constexpr (NT == 2) {                       // the lazily fed layers of the reference all have 64 outputs
+      return zh ? blb_launch<NT, KT, true, true, true>(a, groups, stream) : blb_launch<NT, KT, true, false, true>(a, groups, stream);
+    } else {
+      return CMR_EUNSUPPORTED;
+    }
+  }
+  return zh ? blb_launch<NT, KT, true, true, false>(a, groups, stream) : blb_launch<NT, KT, true, false, false>(a, groups, stream);
 }
 
 inline bool blb_shape_ok(int64_t rows, int n, int k) { return (n == 64 || n == 128) && (k == 64 || k == 128) && rows >= 32 && rows % 32 == 0; }
 
 }  // namespace
 
+// dW partials [groups][n][k] + (lazy x operand) the previous layer's BatchNorm-backward partials [groups][2][k]
 extern "C" int64_t cmr_bn_linear_bwd_workspace_bytes(int64_t rows, int n, int k) {
   if (!blb_shape_ok(rows, n, k)) return 0;
-  return (int64_t)blb_groups(rows, n, k) * n * k * (int64_t)sizeof(float);
+  return (int64_t)blb_groups(rows, n, k) * ((int64_t)n * k + 2 * k) * (int64_t)sizeof(float);
 }
 
-// stat / coef null: no BatchNorm (dh = dz * act'(z)).  dx null: weight gradient only.  Returns CMR_EUNSUPPORTED for shapes it does not
-// serve (n, k in {64, 128}, rows a multiple of 32): the caller composes cmr_bn_bwd_f32 / cmr_linear_wgrad_f32 / cmr_linear_f32.
+// stat / coef null: no BatchNorm (dh = dz * act'(z)).  dx null: weight gradient only.
+// mask_from_h: the layer's output z was never stored (it was consumed through the next layer's prologue, cmr_linear_bn_fwd_f32): the
+//   activation mask is the sign of h * stat[2] + stat[3]; z is ignored.
+// xstat non-null: x is the PREVIOUS layer's BatchNorm input and this layer's operand is lrelu_{xslope}(x * xstat[2] + xstat[3]); dx is
+//   then the gradient at that (never stored) activation, and the previous layer's BatchNorm-backward reduction comes out of the same
+//   pass: xcoef [2][k] (what cmr_bn_bwd_coef_f32 would return for it), xdgamma, xdbeta [k] (written when non-null).
+// Returns CMR_EUNSUPPORTED for shapes it does not serve (n, k in {64, 128}, rows a multiple of 32; xstat: n = 64): the caller composes
+// cmr_bn_bwd_f32 / cmr_linear_wgrad_f32 / cmr_linear_f32.
 extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
-                                     const float* stat, const float* coef, float* dzm, int64_t lddzm, const float* x, int64_t ldx,
+                                     const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
+                                     int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
                                      const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
                                      int n, int k, float* dw, int64_t lddw, int accumulate, void* ws, int64_t ws_bytes,
                                      hipStream_t stream) {
   CMR_REQUIRE(dz && x && w && dw && ws && rows > 0 && n > 0 && k > 0);
-  if (!blb_shape_ok(rows, n, k)) return CMR_EUNSUPPORTED;
-  const bool bn = stat != nullptr;
-  CMR_REQUIRE((stat == nullptr) == (coef == nullptr) && (!bn || h));
+  if (!blb_shape_ok(rows, n, k) || (xstat && n != 64)) return CMR_EUNSUPPORTED;
+  const bool bn = stat != nullptr, zh = mask_from_h != 0, xl = xstat != nullptr;
+  CMR_REQUIRE((stat == nullptr) == (coef == nullptr) && (!bn || h) && (bn || !(zh || xl)));
   CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x) && lddz >= n && ldx >= k && ldw >= k && lddw >= k);
-  if (z) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z) && ldz >= n);
+  if (z && !zh) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z) && ldz >= n);
   if (bn) CMR_REQUIRE(ldh % 4 == 0 && cmr_aligned16(h) && ldh >= n && cmr_aligned16(stat) && cmr_aligned16(coef));
   if (dzm) CMR_REQUIRE(lddzm % 4 == 0 && cmr_aligned16(dzm) && lddzm >= n);
   if (dx) CMR_REQUIRE(lddx % 4 == 0 && cmr_aligned16(dx) && lddx >= k);
   if (res) CMR_REQUIRE(dx && ldres % 4 == 0 && cmr_aligned16(res) && ldres >= k);
+  if (xl) CMR_REQUIRE(dx && xcoef && cmr_aligned16(xstat));
   const int groups = blb_groups(rows, n, k);
-  CMR_REQUIRE(ws_bytes >= (int64_t)groups * n * k * (int64_t)sizeof(float));
+  CMR_REQUIRE(ws_bytes >= (int64_t)groups * ((int64_t)n * k + (xl ? 2 * k : 0)) * (int64_t)sizeof(float));
+  float* xpart = (float*)ws + (int64_t)groups * n * k;
   // no activation: the mask operand is dz itself with slope 1 (d = dz either way; the second read of the line hits the cache)
-  const BlbArgs a{dz, lddz, z ? z : dz, z ? ldz : lddz, z ? slope : 1.f, h, ldh, stat, coef, dzm, lddzm, x, ldx, w, ldw, res, ldres, dx, lddx, (float*)ws, rows};
+  const bool no_act = !zh && !z;
+  const BlbArgs a{dz, lddz, no_act ? dz : z, no_act ? lddz : ldz, no_act ? 1.f : slope, h, ldh, stat, coef, dzm, lddzm, x, ldx, w, ldw, res, ldres,
+                  dx, lddx, (float*)ws, rows, xstat, xslope, xpart};
   int rc;
-  if (bn) {
-    if (n == 64 && k == 64) rc = blb_launch<2, 2, true>(a, groups, stream);
-    else if (n == 64 && k == 128) rc = blb_launch<2, 4, true>(a, groups, stream);
-    else if (n == 128 && k == 64) rc = blb_launch<4, 2, true>(a, groups, stream);
-    else rc = blb_launch<4, 4, true>(a, groups, stream);
-  } else {
-    if (n == 64 && k == 64) rc = blb_launch<2, 2, false>(a, groups, stream);
-    else if (n == 64 && k == 128) rc = blb_launch<2, 4, false>(a, groups, stream);
-    else if (n == 128 && k == 64) rc = blb_launch<4, 2, false>(a, groups, stream);
-    else rc = blb_launch<4, 4, false>(a, groups, stream);
-  }
+  if (n == 64 && k == 64) rc = blb_dispatch<2, 2>(a, bn, zh, xl, groups, stream);
+  else if (n == 64 && k == 128) rc = blb_dispatch<2, 4>(a, bn, zh, xl, groups, stream);
+  else if (n == 128 && k == 64) rc = blb_dispatch<4, 2>(a, bn, zh, xl, groups, stream);
+  else rc = blb_dispatch<4, 4>(a, bn, zh, xl, groups, stream);
   if (rc != CMR_OK) return rc;
   const int64_t outs = (int64_t)n * k;
   hipLaunchKernelGGL(blb_reduce_kernel, dim3((unsigned)((outs + BR_OUT - 1) / BR_OUT)), dim3(BR_OUT * BR_GRP), 0, stream, (const float*)ws, groups,
                      n, k, dw, lddw, accumulate);
+  if (xl) hipLaunchKernelGGL(blb_coef_final_kernel, dim3(k), dim3(64), 0, stream, (const float*)xpart, groups, rows, k, xcoef, xdgamma, xdbeta);
   return cmr_launch_status();
 }
 

@@ -120,7 +120,12 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
     const int64_t r = i / q;
     const int c = (int)(i - r * q) * 4;
     f32x4 v = ld4(x + r * ldx + c);
-    if (scale) v = v * ld4(scale + c) + ld4(shift + c);
+    if (scale) {
+      // explicitly fused: the lazily evaluated layers (csrc/bn_linear.hip) recompute this pre-activation and must land on the same side of zero
+      const f32x4 sc = ld4(scale + c), sh = ld4(shift + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(v[e], sc[e], sh[e]);
+    }
     if (res) {
       f32x4 t = ld4(res + r * ldres + c);
       if (rscale) t = t * ld4(rscale + c) + ld4(rshift + c);

@@ -815,26 +815,39 @@ def bn_linear_bwd_ok(rows, n, k):
     return n in (64, 128) and k in (64, 128) and rows >= 32 and rows % 32 == 0
 
 
-def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, res=None, dx=None, want_dx=True, want_masked=False):
-    """Backward of [h = x W^T + b -> BatchNorm(train) -> (+ residual) -> LeakyReLU(slope) = z] in one pass over the row maps: with
-    (stat, coef) from bn_stats / bn_bwd_coef, dw (+)= dh^T x and dx = dh W (+ res; dx may be res itself) where
-    dh = scale (d - c1 - xhat c2), d = dz * act'(z).  stat = coef = None: no BatchNorm (dh = d).  -> (dx or None, d or None: the masked
-    gradient, what a residual branch receives), or False when the shape is not served."""
+def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, res=None, dx=None, want_dx=True, want_masked=False,
+                  mask_from_h=False, xstat=None, xslope=1.0, xdgamma=None, xdbeta=None):
+    """Backward of [h = x' W^T + b -> BatchNorm(train) -> (+ residual) -> LeakyReLU(slope) = z] in one pass over the row maps: with
+    (stat, coef) from bn_stats / bn_bwd_coef, dw (+)= dh^T x' and dx = dh W (+ res; dx may be res itself) where
+    dh = scale (d - c1 - xhat c2), d = dz * act'(z).  stat = coef = None: no BatchNorm (dh = d).
+    mask_from_h: z was never stored (z ignored): act' from the sign of h * stat[2] + stat[3].
+    xstat [4, k]: x is the previous layer's BatchNorm input, x' = lrelu_{xslope}(x * xstat[2] + xstat[3]); dx is then the gradient at x'
+    and the third result is the previous layer's coef [2, k] (its dgamma / dbeta written into xdgamma / xdbeta).
+    -> (dx or None, d or None: the masked gradient a residual branch receives[, xcoef]), or False when the shape is not served."""
     _rows(dz), _rows(x)
     rows, n = dz.shape
     k = x.shape[1]
     if not bn_linear_bwd_ok(rows, n, k) or x.shape[0] != rows or w.shape[0] < n or w.shape[1] != k or w.stride(1) != 1 or dw.stride(1) != 1:
         return False
+    if xstat is not None and n != 64:
+        return False
     if stat is not None and (h is None or tuple(h.shape) != (rows, n)):
         raise ValueError("bn_linear_bwd: BatchNorm input %s vs gradient %s" % (None if h is None else tuple(h.shape), (rows, n)))
+    if xstat is not None and (tuple(xstat.shape) != (4, k) or not want_dx or stat is None):
+        raise ValueError("bn_linear_bwd: a lazy operand needs its statistics [4, %d], a BatchNorm layer and the data gradient" % k)
     if want_dx and dx is None:
         dx = torch.empty((rows, k), dtype=f32, device=x.device)
     dzm = torch.empty((rows, n), dtype=f32, device=x.device) if want_masked else None
+    xcoef = torch.empty((2, k), dtype=f32, device=x.device) if xstat is not None else None
     nb = _lib.load().cmr_bn_linear_bwd_workspace_bytes(rows, n, k)
     ws = _ws(nb, x.device)
-    _lib.call("cmr_bn_linear_bwd_f32", _p(dz), _ld(dz), _p(z), _ld(z) if z is not None else 0, float(slope), _p(h), _ld(h) if h is not None else 0,
-              _p(stat), _p(coef), _p(dzm), n if want_masked else 0, _p(x), _ld(x), _p(w), w.stride(0), _p(res), _ld(res) if res is not None else 0,
+    zz = None if mask_from_h else z
+    _lib.call("cmr_bn_linear_bwd_f32", _p(dz), _ld(dz), _p(zz), _ld(zz) if zz is not None else 0, float(slope), _p(h), _ld(h) if h is not None else 0,
+              _p(stat), _p(coef), int(bool(mask_from_h)), _p(dzm), n if want_masked else 0, _p(x), _ld(x), _p(xstat), float(xslope), _p(xcoef),
+              _p(xdgamma), _p(xdbeta), _p(w), w.stride(0), _p(res), _ld(res) if res is not None else 0,
               _p(dx) if want_dx else None, _ld(dx) if want_dx else 0, rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(ws), nb, _stream())
+    if xstat is not None:
+        return dx, dzm, xcoef
     return (dx if want_dx else None), dzm
 
 

@@ -118,15 +118,16 @@ class GeoUpdate:
         return t.add(m, x1)
 
     def _mini_pointnet(self, t, x, mp):
-        for layer in (mp.layer_1, mp.layer_2, mp.layer_3):
-            x = t.linear_bn(x, layer[0].weight, layer[0].bias, layer[1], slope=mp.SLOPE)
-        return x
+        layers = [(l[0].weight, l[0].bias, l[1], mp.SLOPE) for l in (mp.layer_1, mp.layer_2, mp.layer_3)]
+        if x.v.shape[1] not in (64, 128):                        # the raw cloud's 4-wide first layer stays on its own
+            x = t.linear_bn(x, *layers[0][:3], slope=mp.SLOPE)
+            layers = layers[1:]
+        return t.linear_bn_chain(x, layers)
 
     def _cbr1d(self, t, x, m):
         """PointNN.py:260-282."""
-        h = t.linear_bn(x, m.net[0].weight, m.net[0].bias, m.net[1], slope=m.SLOPE)
         sc = x if isinstance(m.shortcut, nn.Identity) else t.linear_bn(x, m.shortcut[0].weight, m.shortcut[0].bias, m.shortcut[1])
-        return t.linear_bn(h, m.net[3].weight, m.net[3].bias, m.net[4], slope=m.SLOPE, res=sc)
+        return t.linear_bn_chain(x, [(m.net[0].weight, m.net[0].bias, m.net[1], m.SLOPE), (m.net[3].weight, m.net[3].bias, m.net[4], m.SLOPE)], res=sc)
 
     def _vector_attention(self, t, m, q_rows, k, v, rel, nseg, order, offsets, fixed_len):
         d, g = m.fc_delta, m.fc_gamma

@@ -156,7 +156,7 @@ WORK = {
     "cmr_bn_bwd_coef_f32": lambda a: (0, F * a["rows"] * a["C"] * (2 + (1 if a["z"] else 0))),
     # fused layer backward: the two GEMMs of the layer (weight + data gradient), every distinct map once
     "cmr_bn_linear_bwd_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"] * (2 if a["dx"] else 1),
-                                        F * (a["rows"] * (a["n"] * (1 + (1 if a["z"] else 0) + (1 if a["stat"] else 0) + (1 if a["dzm"] else 0)) +
+                                        F * (a["rows"] * (a["n"] * (1 + (1 if (a["z"] and not a["mask_from_h"]) else 0) + (1 if a["stat"] else 0) + (1 if a["dzm"] else 0)) +
                                                           a["k"] * (1 + (1 if a["res"] else 0) + (1 if a["dx"] else 0))) + 2 * a["n"] * a["k"])),
     "cmr_act_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["add"] else 0))),
     "cmr_pool_act_bwd_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (2 + 1.0 / (a["ph"] * a["pw"]))),

@@ -189,14 +189,14 @@ def _stack(seed):
     return m.to(DEV)
 
 
-def _run_stack(m, x, dout, fused_fwd, fused_bwd):
+def _run_stack(m, x, dout, fused_fwd, fused_bwd, lazy=False):
     from cmr_agent_amd.train.flatbucket import FlatBucket
     from cmr_agent_amd.train.geo_update import GeoUpdate
     from cmr_agent_amd.train.tape import Tape, Var
     bucket = FlatBucket(m)
     bucket.grads.zero_()
     t = Tape(bucket, None)
-    t.FUSED_LINEAR_BN_FWD, t.FUSED_LINEAR_BN = fused_fwd, fused_bwd
+    t.FUSED_LINEAR_BN_FWD, t.FUSED_LINEAR_BN, t.LAZY_CHAIN = fused_fwd, fused_bwd, lazy
     xv = Var(x.clone())
     g = GeoUpdate.__new__(GeoUpdate)
     y = g._mini_pointnet(t, xv, m[0])                 # 128 -> 64 -> 64 -> 64
@@ -230,3 +230,66 @@ def test_tape_linear_bn_equals_the_two_nodes_it_replaces():
         assert err <= 2e-5 * gmax, "%s: max|d| %.3e vs largest gradient %.3e" % (k, err, gmax)
         if g2[k].dim() == 1 and k.endswith(("0.bias", "3.bias")):
             assert float(g1[k].abs().max()) == 0.0, k             # a Conv1d bias in front of a BatchNorm: true gradient zero, not computed
+
+
+def test_lazy_chain_equals_the_stored_activations():
+    """Tape.linear_bn_chain with the inner activations never stored (prologue in the next layer's forward; recomputed operand, mask from
+    the layer's own BatchNorm input and the previous layer's BatchNorm reduction from the next layer's backward pass) against the same layers
+    with every activation stored: the pre-activations are formed by the same fused multiply-add everywhere, so the forward is bit-identical
+    and no activation changes branch; gradients to fp32 rounding (the reductions run in another order)."""
+    rows = 16384
+    x, dout = rnd(rows, 128, seed=21).to(DEV), (rnd(rows, 64, seed=22) / rows).to(DEV)
+    y1, dx1, g1, rs1 = _run_stack(_stack(5), x, dout, True, True, lazy=True)
+    y2, dx2, g2, rs2 = _run_stack(_stack(5), x, dout, True, True, lazy=False)
+    assert torch.equal(y1, y2)
+    for k in rs1:
+        assert torch.equal(rs1[k], rs2[k]), k
+    close(dx1, dx2, 2e-5, "dx")
+    gmax = max(float(v.abs().max()) for v in g2.values())
+    for k in g2:
+        err = float((g1[k] - g2[k]).abs().max())
+        assert err <= 2e-5 * gmax, "%s: max|d| %.3e vs largest gradient %.3e" % (k, err, gmax)
+
+
+@pytest.mark.parametrize("rows,k,last", [(8192, 64, True), (16384, 64, False), (12800, 128, True), (524288, 64, False)])
+def test_lazy_operand_backward_vs_float64(ops, rows, k, last):
+    """cmr_bn_linear_bwd_f32 with xstat (operand recomputed from the previous layer's BatchNorm input, that layer's reduction returned) and
+    mask_from_h, against float64 autograd of the two layers."""
+    n, s0, s1 = 64, 0.2, 0.2
+    h0 = (rnd(rows, k, seed=41) * 2 + 0.3).to(DEV)                        # the previous layer's BatchNorm input
+    g0, b0 = (1 + 0.3 * rnd(k, seed=42)).to(DEV), (0.2 * rnd(k, seed=43)).to(DEV)
+    w, b = (rnd(n, k, seed=44) / 6).to(DEV), rnd(n, seed=45).to(DEV)
+    g1, b1 = (1 + 0.3 * rnd(n, seed=46)).to(DEV), (0.2 * rnd(n, seed=47)).to(DEV)
+    dz = (rnd(rows, n, seed=48) / rows).to(DEV)
+    stat0 = ops.bn_stats(h0, g0, b0)
+    h1, stat1 = ops.linear_bn_fwd(h0, w, b, g1, b1, pro=stat0, pro_slope=s0)
+    z1 = ops.affine_act(h1, stat1[2], stat1[3], slope=s1)
+    z0 = ops.affine_act(h0, stat0[2], stat0[3], slope=s0)                 # what the lazy path never stores: only the reference uses it
+    # float64: two layers, masks from the fp32 activations
+    H0, W64 = h0.double().requires_grad_(True), w.double().requires_grad_(True)
+    G0, B0, G1, B1 = (t.double().requires_grad_(True) for t in (g0, b0, g1, b1))
+    def bn64(h, g, bb):
+        return (h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5) * g + bb
+    a0 = bn64(H0, G0, B0) * torch.where(z0 > 0, 1.0, s0).double()
+    a1 = bn64(a0 @ W64.t() + b.double(), G1, B1) * torch.where(z1 > 0, 1.0, s1).double()
+    a1.backward(dz.double())
+    # HIP: the upper layer's fused pass
+    dg1, db1, dg0, db0 = (torch.empty(c, device=DEV) for c in (n, n, k, k))
+    dw = torch.zeros(n, k, device=DEV)
+    if last:
+        coef1 = ops.bn_bwd_coef(dz, z1, s1, h1, stat1, dg1, db1)
+        dx, _, xcoef = ops.bn_linear_bwd(dz, z1, s1, h1, stat1, coef1, h0, w, dw, xstat=stat0, xslope=s0, xdgamma=dg0, xdbeta=db0)
+    else:
+        coef1 = ops.bn_bwd_coef(dz, z1, s1, h1, stat1, dg1, db1)
+        dx, _, xcoef = ops.bn_linear_bwd(dz, None, s1, h1, stat1, coef1, h0, w, dw, mask_from_h=True, xstat=stat0, xslope=s0, xdgamma=dg0, xdbeta=db0)
+    close(dw, W64.grad, 2e-4, "dw")
+    close(dg1, G1.grad, 2e-4, "dgamma (this layer)")
+    close(dg0, G0.grad, 2e-4, "dgamma (previous layer, from the fused pass)")
+    close(db0, B0.grad, 2e-4, "dbeta (previous layer, from the fused pass)")
+    # the previous layer's reduction equals what the stand-alone pass returns for the same gradient
+    ref_dg, ref_db = torch.empty(k, device=DEV), torch.empty(k, device=DEV)
+    ref = ops.bn_bwd_coef(dx, z0, s0, h0, stat0, ref_dg, ref_db)
+    close(xcoef, ref, 2e-5, "coef of the previous layer")
+    # and the gradient at the previous layer's BatchNorm input
+    dh0 = ops.bn_bwd(dx, z0, s0, h0, stat0)
+    close(dh0, H0.grad, 2e-4, "gradient at the previous layer's BatchNorm input")
