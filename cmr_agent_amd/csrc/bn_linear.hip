@@ -36,6 +36,7 @@ struct BlbArgs {
   const float* res; int64_t ldres;      // optional: added to dx (dx may alias it)
   float* dx; int64_t lddx;              // optional
   float* part;                          // [gridDim.x][n][k]
+  float* part_b;                        // optional [gridDim.x][n]: column sums of dh (the bias gradient of a layer without BatchNorm)
   int64_t rows;
   // XL: x is the PREVIOUS layer's BatchNorm input; this layer's operand is lrelu_{xslope}(x * xstat[2] + xstat[3]) (never stored), and the
   // BatchNorm-backward sums of the previous layer (sum d', sum d' xhat' with d' = dx * act', over this workgroup's rows) go to xpart
@@ -97,6 +98,9 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum[TPW];                               // column sums of dh over this lane's rows of channel 32 nt + l31 (kept for the kt == 0 tiles)
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) bsum[t] = 0.f;
   // XL: the previous layer's affine for the weight-gradient operand (lane = channel 32 kt + l31 of tile t) and, in the data gradient's
   // layout (channels kbase + 16 q + 4 g16 .. + 3), its affine and its normalisation; running sums of its BatchNorm backward
   float xs_w[TPW], xb_w[TPW];
@@ -186,7 +190,9 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
           b = __builtin_fmaf(b, xs_w[t], xb_w[t]);
           b = b > 0.f ? b : b * a.xslope;
         }
-        acc[t] = cmr_mfma32(dl[rr * DS + 32 * nt + l31], b, acc[t]);
+        const float av = dl[rr * DS + 32 * nt + l31];
+        bsum[t] += av;
+        acc[t] = cmr_mfma32(av, b, acc[t]);
       }
     }
     if (!want_dx) return;
@@ -279,6 +285,10 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[(int64_t)(nt * 32 + cmr_mfma_row(r, lane)) * K + kt * 32 + l31] = acc[t][r];
+    if (a.part_b) {
+      const float bs = bsum[t] + cmr_xhalf(bsum[t]);          // the two lane halves held the rows r and r + 8 of every step
+      if (kt == 0 && h == 0) a.part_b[(int64_t)blockIdx.x * N + nt * 32 + l31] = bs;
+    }
   }
   if (XL) {
     // the 16 row lanes of a lane group hold the same channels: fixed-order DPP sum, lane 16 g writes (bn_bwd_partial_kernel's layout)
@@ -322,31 +332,38 @@ __global__ __launch_bounds__(64) void blb_coef_final_kernel(const float* __restr
 
 // dw[i] (+)= sum over the workgroups' partials, in double, fixed order (32 slice groups x 8 loads in flight)
 constexpr int BR_OUT = 32, BR_GRP = 32, BR_U = 8;
-__global__ __launch_bounds__(BR_OUT * BR_GRP) void blb_reduce_kernel(const float* __restrict__ part, int nslices, int n, int k,
-                                                                     float* __restrict__ dw, int64_t lddw, int accumulate) {
+// outputs [0, n k): dw entries; [n k, n k + n): db entries (when part_b)
+__global__ __launch_bounds__(BR_OUT * BR_GRP) void blb_reduce_kernel(const float* __restrict__ part, const float* __restrict__ part_b, int nslices,
+                                                                     int n, int k, float* __restrict__ dw, int64_t lddw, int accumulate,
+                                                                     float* __restrict__ db, int accumulate_db) {
   __shared__ double sm[BR_GRP][BR_OUT];
   const int o = threadIdx.x % BR_OUT, gq = threadIdx.x / BR_OUT;
-  const int64_t nk = (int64_t)n * k;
+  const int64_t nk = (int64_t)n * k, total = nk + (part_b ? n : 0);
   const int64_t i = (int64_t)blockIdx.x * BR_OUT + o;
-  const float* p = part + (i < nk ? i : 0);
+  const float* p = i < nk ? part + i : (i < total ? part_b + (i - nk) : part);
+  const int64_t stride = i < nk ? nk : n;
   double s = 0.0;
   for (int j0 = gq; j0 < nslices; j0 += BR_GRP * BR_U) {
     float v[BR_U];
 #pragma unroll
     for (int u = 0; u < BR_U; ++u) {
       const int j = j0 + u * BR_GRP;
-      v[u] = p[(int64_t)(j < nslices ? j : j0) * nk];
+      v[u] = p[(int64_t)(j < nslices ? j : j0) * stride];
     }
 #pragma unroll
     for (int u = 0; u < BR_U; ++u) s += j0 + u * BR_GRP < nslices ? (double)v[u] : 0.0;
   }
   sm[gq][o] = s;
   __syncthreads();
-  if (gq == 0 && i < nk) {
+  if (gq == 0 && i < total) {
 #pragma unroll
     for (int j = 1; j < BR_GRP; ++j) s += sm[j][o];
-    float* d = dw + (i / k) * lddw + (i % k);
-    *d = accumulate ? *d + (float)s : (float)s;
+    if (i < nk) {
+      float* d = dw + (i / k) * lddw + (i % k);
+      *d = accumulate ? *d + (float)s : (float)s;
+    } else {
+      db[i - nk] = accumulate_db ? db[i - nk] + (float)s : (float)s;
+    }
   }
 }
 
@@ -575,10 +592,11 @@ inline bool blb_shape_ok(int64_t rows, int n, int k) { return (n == 64 || n == 1
 // dW partials [groups][n][k] + (lazy x operand) the previous layer's BatchNorm-backward partials [groups][2][k]
 extern "C" int64_t cmr_bn_linear_bwd_workspace_bytes(int64_t rows, int n, int k) {
   if (!blb_shape_ok(rows, n, k)) return 0;
-  return (int64_t)blb_groups(rows, n, k) * ((int64_t)n * k + 2 * k) * (int64_t)sizeof(float);
+  return (int64_t)blb_groups(rows, n, k) * ((int64_t)n * k + 2 * k + n) * (int64_t)sizeof(float);
 }
 
-// stat / coef null: no BatchNorm (dh = dz * act'(z)).  dx null: weight gradient only.
+// stat / coef null: no BatchNorm (dh = dz * act'(z)).  dx null: weight gradient only.  db non-null: (+)= the column sums of dh, the bias
+// gradient of a layer without BatchNorm (in front of a BatchNorm it is identically zero).
 // mask_from_h: the layer's output z was never stored (it was consumed through the next layer's prologue, cmr_linear_bn_fwd_f32): the
 //   activation mask is the sign of h * stat[2] + stat[3]; z is ignored.
 // xstat non-null: x is the PREVIOUS layer's BatchNorm input and this layer's operand is lrelu_{xslope}(x * xstat[2] + xstat[3]); dx is
@@ -590,8 +608,8 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
                                      const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
                                      int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
                                      const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
-                                     int n, int k, float* dw, int64_t lddw, int accumulate, void* ws, int64_t ws_bytes,
-                                     hipStream_t stream) {
+                                     int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db, void* ws,
+                                     int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(dz && x && w && dw && ws && rows > 0 && n > 0 && k > 0);
   if (!blb_shape_ok(rows, n, k) || (xstat && n != 64)) return CMR_EUNSUPPORTED;
   const bool bn = stat != nullptr, zh = mask_from_h != 0, xl = xstat != nullptr;
@@ -604,21 +622,22 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   if (res) CMR_REQUIRE(dx && ldres % 4 == 0 && cmr_aligned16(res) && ldres >= k);
   if (xl) CMR_REQUIRE(dx && xcoef && cmr_aligned16(xstat));
   const int groups = blb_groups(rows, n, k);
-  CMR_REQUIRE(ws_bytes >= (int64_t)groups * ((int64_t)n * k + (xl ? 2 * k : 0)) * (int64_t)sizeof(float));
+  CMR_REQUIRE(ws_bytes >= (int64_t)groups * ((int64_t)n * k + 2 * k + n) * (int64_t)sizeof(float));
   float* xpart = (float*)ws + (int64_t)groups * n * k;
+  float* part_b = db ? xpart + (int64_t)groups * 2 * k : nullptr;
   // no activation: the mask operand is dz itself with slope 1 (d = dz either way; the second read of the line hits the cache)
   const bool no_act = !zh && !z;
   const BlbArgs a{dz, lddz, no_act ? dz : z, no_act ? lddz : ldz, no_act ? 1.f : slope, h, ldh, stat, coef, dzm, lddzm, x, ldx, w, ldw, res, ldres,
-                  dx, lddx, (float*)ws, rows, xstat, xslope, xpart};
+                  dx, lddx, (float*)ws, part_b, rows, xstat, xslope, xpart};
   int rc;
   if (n == 64 && k == 64) rc = blb_dispatch<2, 2>(a, bn, zh, xl, groups, stream);
   else if (n == 64 && k == 128) rc = blb_dispatch<2, 4>(a, bn, zh, xl, groups, stream);
   else if (n == 128 && k == 64) rc = blb_dispatch<4, 2>(a, bn, zh, xl, groups, stream);
   else rc = blb_dispatch<4, 4>(a, bn, zh, xl, groups, stream);
   if (rc != CMR_OK) return rc;
-  const int64_t outs = (int64_t)n * k;
-  hipLaunchKernelGGL(blb_reduce_kernel, dim3((unsigned)((outs + BR_OUT - 1) / BR_OUT)), dim3(BR_OUT * BR_GRP), 0, stream, (const float*)ws, groups,
-                     n, k, dw, lddw, accumulate);
+  const int64_t outs = (int64_t)n * k + (db ? n : 0);
+  hipLaunchKernelGGL(blb_reduce_kernel, dim3((unsigned)((outs + BR_OUT - 1) / BR_OUT)), dim3(BR_OUT * BR_GRP), 0, stream, (const float*)ws,
+                     (const float*)part_b, groups, n, k, dw, lddw, accumulate, db, accumulate_db);
   if (xl) hipLaunchKernelGGL(blb_coef_final_kernel, dim3(k), dim3(64), 0, stream, (const float*)xpart, groups, rows, k, xcoef, xdgamma, xdbeta);
   return cmr_launch_status();
 }

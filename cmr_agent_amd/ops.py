@@ -816,10 +816,10 @@ def bn_linear_bwd_ok(rows, n, k):
 
 
 def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, res=None, dx=None, want_dx=True, want_masked=False,
-                  mask_from_h=False, xstat=None, xslope=1.0, xdgamma=None, xdbeta=None):
+                  mask_from_h=False, xstat=None, xslope=1.0, xdgamma=None, xdbeta=None, db=None, accumulate_db=False):
     """Backward of [h = x' W^T + b -> BatchNorm(train) -> (+ residual) -> LeakyReLU(slope) = z] in one pass over the row maps: with
     (stat, coef) from bn_stats / bn_bwd_coef, dw (+)= dh^T x' and dx = dh W (+ res; dx may be res itself) where
-    dh = scale (d - c1 - xhat c2), d = dz * act'(z).  stat = coef = None: no BatchNorm (dh = d).
+    dh = scale (d - c1 - xhat c2), d = dz * act'(z).  stat = coef = None: no BatchNorm (dh = d); db (+)= column sums of dh.
     mask_from_h: z was never stored (z ignored): act' from the sign of h * stat[2] + stat[3].
     xstat [4, k]: x is the previous layer's BatchNorm input, x' = lrelu_{xslope}(x * xstat[2] + xstat[3]); dx is then the gradient at x'
     and the third result is the previous layer's coef [2, k] (its dgamma / dbeta written into xdgamma / xdbeta).
@@ -845,7 +845,8 @@ def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, re
     _lib.call("cmr_bn_linear_bwd_f32", _p(dz), _ld(dz), _p(zz), _ld(zz) if zz is not None else 0, float(slope), _p(h), _ld(h) if h is not None else 0,
               _p(stat), _p(coef), int(bool(mask_from_h)), _p(dzm), n if want_masked else 0, _p(x), _ld(x), _p(xstat), float(xslope), _p(xcoef),
               _p(xdgamma), _p(xdbeta), _p(w), w.stride(0), _p(res), _ld(res) if res is not None else 0,
-              _p(dx) if want_dx else None, _ld(dx) if want_dx else 0, rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(ws), nb, _stream())
+              _p(dx) if want_dx else None, _ld(dx) if want_dx else 0, rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(db),
+              int(accumulate_db), _p(ws), nb, _stream())
     if xstat is not None:
         return dx, dzm, xcoef
     return (dx if want_dx else None), dzm

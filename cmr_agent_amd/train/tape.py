@@ -178,6 +178,14 @@ class Tape:
                 else:
                     x.g, x.own = dx, True
                 return
+            if self.FUSED_LINEAR_BN and x.v.shape[0] >= self.LINEAR_BN_MIN_ROWS:
+                # big row maps (the vector-attention and head linears over the points): activation backward, weight + bias gradient and data
+                # gradient in one pass over the maps (cmr_bn_linear_bwd_f32 without a BatchNorm) instead of act_bwd + linear_wgrad + linear
+                r = ops.bn_linear_bwd(y.g, None if act == ops.ACT_NONE else y.v, 0.0 if act == ops.ACT_RELU else slope, None, None, None, x.v, W,
+                                      gw, acc, res=x.g, dx=x.g if inplace else None, db=gbv, accumulate_db=accb)
+                if r is not False:
+                    x.g, x.own = r[0], True
+                    return
             dy = y.g if act == ops.ACT_NONE else ops.act_bwd(y.g, y.v, 0.0 if act == ops.ACT_RELU else slope)
             if bias is not None:
                 ops.linear_wgrad_any(dy, x.v, gw, acc, db=gbv, accumulate_db=accb)

@@ -164,6 +164,23 @@ def test_no_batchnorm_variant_and_weight_gradient_only(ops):
     dw2 = torch.zeros(n, k, device=DEV)
     dx2, _ = ops.bn_linear_bwd(dz, z, slope, None, None, None, x, w, dw2, want_dx=False)
     assert dx2 is None and torch.equal(dw, dw2)
+    # bias gradient = column sums of dh, written or accumulated
+    db, dw4 = torch.full((n,), 7.0, device=DEV), torch.zeros(n, k, device=DEV)
+    ops.bn_linear_bwd(dz, z, slope, None, None, None, x, w, dw4, db=db)
+    close(db, d64.sum(0), 1e-5, "db")
+    assert torch.equal(dw4, dw)
+    db2 = torch.full((n,), 0.5, device=DEV)
+    ops.bn_linear_bwd(dz, z, slope, None, None, None, x, w, dw4, db=db2, accumulate_db=True)
+    close(db2, d64.sum(0) + 0.5, 1e-6, "db accumulated")
+    # 128 outputs / 128 inputs with a bias
+    x8, w8, dz8 = rnd(4096, 128, seed=14).to(DEV), (rnd(128, 128, seed=15) / 8).to(DEV), (rnd(4096, 128, seed=16) / 4096).to(DEV)
+    z8 = torch.relu(x8 @ w8.t())
+    d8 = dz8.double() * (z8 > 0).double()
+    dw8, db8 = torch.zeros(128, 128, device=DEV), torch.zeros(128, device=DEV)
+    dx8, _ = ops.bn_linear_bwd(dz8, z8, 0.0, None, None, None, x8, w8, dw8, db=db8)
+    close(dx8, d8 @ w8.double(), 1e-5, "dx (128 x 128, ReLU)")
+    close(dw8, d8.t() @ x8.double(), 1e-5, "dw (128 x 128, ReLU)")
+    close(db8, d8.sum(0), 1e-5, "db (128 x 128, ReLU)")
     # no activation at all
     dw3 = torch.zeros(n, k, device=DEV)
     dx3, _ = ops.bn_linear_bwd(dz, None, 1.0, None, None, None, x, w, dw3)
