@@ -14,6 +14,7 @@ streaming kernels of csrc/train.hip.  There is no CPU path."""
 import torch
 
 from .. import ops
+from ..utils.streams import fork_join
 from ..models.ImageResNet import to_nhwc
 from .flatbucket import FlatBucket
 from .fragpack import ConvPack
@@ -90,6 +91,34 @@ class AgentUpdate:
         c = 2 * self.f
         T = {}                                                     # tape
         cp = self._packed_convs()
+        # The two towers are independent until the heads: the 3-D branch (HBM-bound row passes over the B N points) runs on a side stream
+        # underneath the 2-D branch (3x3 convolutions on 40 x 128 maps that leave most CUs idle), forward and backward
+        (L3, e3d), _ = self._fork(lambda: self._forward_3d(s3, B, N), lambda: self._forward_2d(T, s2, B, cp))
+        T["L3"] = L3
+        T["e3d"] = e3d
+        bk = self.bucket
+        # ---- heads on cat([embed_2d, embed_3d])
+        T["heads"] = {}
+        outs = []
+        for name in ("policy_r", "policy_t", "value"):
+            h1 = ops.linear(T["e2d"], bk.w(name + ".0.weight"), bk.w(name + ".0.bias"), x2=T["e3d"], act=ops.ACT_LRELU, act_param=SLOPE2D)
+            h2 = ops.linear(h1, bk.w(name + ".2.weight"), bk.w(name + ".2.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
+            o = ops.linear(h2, bk.w(name + ".4.weight"), bk.w(name + ".4.bias"))
+            T["heads"][name] = (h1, h2, o)
+            outs.append(o)
+        return T, outs
+
+    FORK_BRANCHES = __import__("os").environ.get("CMR_AGENT_UPDATE_FORK", "1") == "1"
+
+    def _fork(self, side, main):
+        if self.FORK_BRANCHES:
+            return fork_join(side, main, tag="agent_update")
+        return side(), main()
+
+    def _forward_2d(self, T, s2, B, cp):
+        bk, ag = self.bucket, self.agent
+        e = ag.state_2d_embed
+        c = 2 * self.f
         # ---- 2-D branch: 4 x [conv3x3 + BN + LReLU, conv3x3 + LReLU, pool]
         x = s2
         T["stages"] = []
@@ -115,6 +144,9 @@ class AgentUpdate:
         T["pooled"] = pooled
         T["t1"] = ops.linear(pooled, bk.w("state_2d_embed.24.weight"), bk.w("state_2d_embed.24.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
         T["e2d"] = ops.linear(T["t1"], bk.w("state_2d_embed.26.weight"), bk.w("state_2d_embed.26.bias"))
+
+    def _forward_3d(self, s3, B, N):
+        bk, ag = self.bucket, self.agent
         # ---- 3-D branch: 4 x ConvBNReLURes1D + per-sample max, broadcast-concatenated to every point (never materialised
         # in front of a GEMM: it is the second source x2[r / N])
         L3 = []
@@ -141,18 +173,7 @@ class AgentUpdate:
             rec.update(out=out, gmax=gmax, arg=arg)
             L3.append(rec)
             feat, g = out, gmax
-        T["L3"] = L3
-        T["e3d"] = g
-        # ---- heads on cat([embed_2d, embed_3d])
-        T["heads"] = {}
-        outs = []
-        for name in ("policy_r", "policy_t", "value"):
-            h1 = ops.linear(T["e2d"], bk.w(name + ".0.weight"), bk.w(name + ".0.bias"), x2=T["e3d"], act=ops.ACT_LRELU, act_param=SLOPE2D)
-            h2 = ops.linear(h1, bk.w(name + ".2.weight"), bk.w(name + ".2.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
-            o = ops.linear(h2, bk.w(name + ".4.weight"), bk.w(name + ".4.bias"))
-            T["heads"][name] = (h1, h2, o)
-            outs.append(o)
-        return T, outs
+        return L3, g
 
     # --------------------------------------------------------------------------------------------------------- backward
     def _lin_small_bwd(self, name, x1, dy, y=None, x2=None, dx1=None, dx2=None, acc=False):
@@ -201,6 +222,11 @@ class AgentUpdate:
             self._lin_small_bwd(name + ".4", h2, d_outs[i], dx1=dh2)
             self._lin_small_bwd(name + ".2", h1, dh2, y=h2, dx1=dh1)
             self._lin_small_bwd(name + ".0", T["e2d"], dh1, y=h1, x2=T["e3d"], dx1=de2d, dx2=de3d, acc=i > 0)
+        self._fork(lambda: self._backward_3d(T, de3d, B, N), lambda: self._backward_2d(T, de2d, B))
+
+    def _backward_2d(self, T, de2d, B):
+        bk = self.bucket
+        c = 2 * self.f
         # ---- 2-D tail and tower
         dt1 = torch.empty_like(T["t1"])
         dpooled = torch.empty_like(T["pooled"])
@@ -218,6 +244,11 @@ class AgentUpdate:
             ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"), db=bk.g(st["na"] + ".bias"))
             if s > 0:
                 g = self._dgrad(da, st["na"], c, 2 * s - 1)
+
+    def _backward_3d(self, T, de3d, B, N):
+        bk = self.bucket
+        dev = bk.params.device
+        f = self.f
         # ---- 3-D branch
         R = B * N
         dg = de3d                                                   # gradient w.r.t. the per-sample max of the current block
