@@ -43,6 +43,8 @@ struct BlbArgs {
   const float* xstat;                   // [4][k]
   float xslope;
   float* xpart;                         // [gridDim.x][2][k]
+  int64_t seg_blocks;                   // row blocks per segment (rows / 32 when the map is one segment)
+  int seg_groups;                       // workgroups per segment (gridDim.x = segments * seg_groups)
 };
 
 __device__ __forceinline__ f32x4 blb_fma4(f32x4 a, f32x4 b, f32x4 c) {
@@ -66,7 +68,6 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31, g16 = lane >> 4, j16 = lane & 15;
-  const int64_t nblocks = a.rows / R;
   const bool want_dx = a.dx != nullptr;
 
   // staging coordinates: element e = tid + 256 i of a [32][W/4] block of float4 -> row e / (W/4), float4 column e % (W/4) (constant per thread)
@@ -231,9 +232,14 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
       }
   };
 
-  const int64_t g = gridDim.x;
+  // Workgroup -> row blocks.  The map is cut into segments of seg_blocks blocks (one segment = the whole map unless the caller wants
+  // per-segment column sums of dh, e.g. per SAMPLE: CMRAgent.py:95-99 broadcasts a per-sample vector to every point, whose gradient is
+  // that sum); seg_groups workgroups stride through each segment.
+  const int64_t g = a.seg_groups;
+  const int64_t seg = blockIdx.x / a.seg_groups;
+  const int64_t nblocks = (seg + 1) * a.seg_blocks;            // (end of this workgroup's segment)
   auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
-  int64_t blk = blockIdx.x;
+  int64_t blk = seg * a.seg_blocks + blockIdx.x % a.seg_groups;
   f32x4 rcur[2 * KQ];
   if (DEEP) {
     // two blocks ahead in registers (blk + g in sa, blk + 2 g in sb; blk itself in LDS), the body unrolled twice so that the two register
@@ -456,8 +462,9 @@ __global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
   auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
   int64_t blk = blockIdx.x;
   // Two blocks ahead in registers (blk + g in xa, blk + 2 g in xb; blk itself in LDS): 8 - 16 KB per block and workgroup, so with ONE block
-  // in flight a CU had 32 KB outstanding -- 8 MB on the chip against the ~16 MB that 8 TB/s x 2 us of loaded latency asks for (measured:
-  // 3.7 TB/s).  The body is unrolled twice so that the two register sets swap roles without moves.
+  // in flight a CU has 32 KB outstanding -- 8 MB on the chip against the ~16 MB that 8 TB/s x 2 us of loaded latency asks for.  (Measured
+  // the same 71 - 73 us either way in back-to-back launches; 57 us = 4.7 TB/s alone.)  The body is unrolled twice so that the two register
+  // sets swap roles without moves.
   f32x4 xa[NLX], xb[NLX];
   load_block(clampb(blk), xa);
   store_block(0, xa);
@@ -548,6 +555,15 @@ int blf_launch(const BlfArgs& a, int groups, hipStream_t stream) {
   return CMR_OK;
 }
 
+// cs[seg][c] = sum over the segment's workgroups of part_b[.][c] (double, fixed order): per-segment column sums of dh
+__global__ __launch_bounds__(64) void blb_seg_reduce_kernel(const float* __restrict__ part_b, int seg_groups, int n, float* __restrict__ cs) {
+  const int seg = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
+  if (c >= n) return;
+  double s = 0.0;
+  for (int w = 0; w < seg_groups; ++w) s += (double)part_b[((int64_t)seg * seg_groups + w) * n + c];
+  cs[(int64_t)seg * n + c] = (float)s;
+}
+
 inline int blb_groups(int64_t rows, int n, int k) {
   const int64_t nblocks = rows / 32;
   const size_t smem = (size_t)2 * 32 * (n + k + 72) * sizeof(float);
@@ -592,11 +608,13 @@ inline bool blb_shape_ok(int64_t rows, int n, int k) { return (n == 64 || n == 1
 // dW partials [groups][n][k] + (lazy x operand) the previous layer's BatchNorm-backward partials [groups][2][k]
 extern "C" int64_t cmr_bn_linear_bwd_workspace_bytes(int64_t rows, int n, int k) {
   if (!blb_shape_ok(rows, n, k)) return 0;
-  return (int64_t)blb_groups(rows, n, k) * ((int64_t)n * k + 2 * k + n) * (int64_t)sizeof(float);
+  return (int64_t)(blb_groups(rows, n, k) + 256) * ((int64_t)n * k + 2 * k + n) * (int64_t)sizeof(float);       // (+ 256: a segmented launch rounds the grid)
 }
 
 // stat / coef null: no BatchNorm (dh = dz * act'(z)).  dx null: weight gradient only.  db non-null: (+)= the column sums of dh, the bias
 // gradient of a layer without BatchNorm (in front of a BatchNorm it is identically zero).
+// seg_db non-null: the map is seg_rows-row segments (samples) and seg_db [rows / seg_rows][n] receives the column sums of dh per segment (the
+//   gradient of a per-sample vector broadcast to the segment's rows, CMRAgent.py:95-99).
 // mask_from_h: the layer's output z was never stored (it was consumed through the next layer's prologue, cmr_linear_bn_fwd_f32): the
 //   activation mask is the sign of h * stat[2] + stat[3]; z is ignored.
 // xstat non-null: x is the PREVIOUS layer's BatchNorm input and this layer's operand is lrelu_{xslope}(x * xstat[2] + xstat[3]); dx is
@@ -608,10 +626,11 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
                                      const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
                                      int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
                                      const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
-                                     int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db, void* ws,
-                                     int64_t ws_bytes, hipStream_t stream) {
+                                     int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db,
+                                     int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(dz && x && w && dw && ws && rows > 0 && n > 0 && k > 0);
   if (!blb_shape_ok(rows, n, k) || (xstat && n != 64)) return CMR_EUNSUPPORTED;
+  if (seg_db && (seg_rows < 128 || seg_rows % 32 || rows % seg_rows)) return CMR_EUNSUPPORTED;
   const bool bn = stat != nullptr, zh = mask_from_h != 0, xl = xstat != nullptr;
   CMR_REQUIRE((stat == nullptr) == (coef == nullptr) && (!bn || h) && (bn || !(zh || xl)));
   CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x) && lddz >= n && ldx >= k && ldw >= k && lddw >= k);
@@ -621,14 +640,26 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   if (dx) CMR_REQUIRE(lddx % 4 == 0 && cmr_aligned16(dx) && lddx >= k);
   if (res) CMR_REQUIRE(dx && ldres % 4 == 0 && cmr_aligned16(res) && ldres >= k);
   if (xl) CMR_REQUIRE(dx && xcoef && cmr_aligned16(xstat));
-  const int groups = blb_groups(rows, n, k);
+  int groups = blb_groups(rows, n, k);
+  int64_t seg_blocks = rows / 32;
+  int seg_groups = groups;
+  if (seg_db) {                                  // per-segment column sums: a whole number of workgroups per segment, >= 4 blocks each
+    const int64_t nseg = rows / seg_rows;
+    seg_blocks = seg_rows / 32;
+    int64_t gps = (groups + nseg - 1) / nseg;
+    if (gps > seg_blocks / 4) gps = seg_blocks / 4;
+    if (gps < 1) gps = 1;
+    CMR_REQUIRE(nseg * gps <= groups + 256);
+    seg_groups = (int)gps;
+    groups = (int)(nseg * gps);
+  }
   CMR_REQUIRE(ws_bytes >= (int64_t)groups * ((int64_t)n * k + 2 * k + n) * (int64_t)sizeof(float));
   float* xpart = (float*)ws + (int64_t)groups * n * k;
-  float* part_b = db ? xpart + (int64_t)groups * 2 * k : nullptr;
+  float* part_b = (db || seg_db) ? xpart + (int64_t)groups * 2 * k : nullptr;
   // no activation: the mask operand is dz itself with slope 1 (d = dz either way; the second read of the line hits the cache)
   const bool no_act = !zh && !z;
   const BlbArgs a{dz, lddz, no_act ? dz : z, no_act ? lddz : ldz, no_act ? 1.f : slope, h, ldh, stat, coef, dzm, lddzm, x, ldx, w, ldw, res, ldres,
-                  dx, lddx, (float*)ws, part_b, rows, xstat, xslope, xpart};
+                  dx, lddx, (float*)ws, part_b, rows, xstat, xslope, xpart, seg_blocks, seg_groups};
   int rc;
   if (n == 64 && k == 64) rc = blb_dispatch<2, 2>(a, bn, zh, xl, groups, stream);
   else if (n == 64 && k == 128) rc = blb_dispatch<2, 4>(a, bn, zh, xl, groups, stream);
@@ -637,7 +668,10 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   if (rc != CMR_OK) return rc;
   const int64_t outs = (int64_t)n * k + (db ? n : 0);
   hipLaunchKernelGGL(blb_reduce_kernel, dim3((unsigned)((outs + BR_OUT - 1) / BR_OUT)), dim3(BR_OUT * BR_GRP), 0, stream, (const float*)ws,
-                     (const float*)part_b, groups, n, k, dw, lddw, accumulate, db, accumulate_db);
+                     (const float*)(db ? part_b : nullptr), groups, n, k, dw, lddw, accumulate, db, accumulate_db);
+  if (seg_db)
+    hipLaunchKernelGGL(blb_seg_reduce_kernel, dim3((unsigned)(rows / seg_rows), (unsigned)((n + 63) / 64)), dim3(64), 0, stream, (const float*)part_b,
+                       seg_groups, n, seg_db);
   if (xl) hipLaunchKernelGGL(blb_coef_final_kernel, dim3(k), dim3(64), 0, stream, (const float*)xpart, groups, rows, k, xcoef, xdgamma, xdbeta);
   return cmr_launch_status();
 }

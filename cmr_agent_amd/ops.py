@@ -816,14 +816,15 @@ def bn_linear_bwd_ok(rows, n, k):
 
 
 def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, res=None, dx=None, want_dx=True, want_masked=False,
-                  mask_from_h=False, xstat=None, xslope=1.0, xdgamma=None, xdbeta=None, db=None, accumulate_db=False):
+                  mask_from_h=False, xstat=None, xslope=1.0, xdgamma=None, xdbeta=None, db=None, accumulate_db=False, seg_rows=0):
     """Backward of [h = x' W^T + b -> BatchNorm(train) -> (+ residual) -> LeakyReLU(slope) = z] in one pass over the row maps: with
     (stat, coef) from bn_stats / bn_bwd_coef, dw (+)= dh^T x' and dx = dh W (+ res; dx may be res itself) where
     dh = scale (d - c1 - xhat c2), d = dz * act'(z).  stat = coef = None: no BatchNorm (dh = d); db (+)= column sums of dh.
     mask_from_h: z was never stored (z ignored): act' from the sign of h * stat[2] + stat[3].
     xstat [4, k]: x is the previous layer's BatchNorm input, x' = lrelu_{xslope}(x * xstat[2] + xstat[3]); dx is then the gradient at x'
     and the third result is the previous layer's coef [2, k] (its dgamma / dbeta written into xdgamma / xdbeta).
-    -> (dx or None, d or None: the masked gradient a residual branch receives[, xcoef]), or False when the shape is not served."""
+    seg_rows: the map is seg_rows-row segments (samples); third result = the column sums of dh per segment [rows / seg_rows, n].
+    -> (dx or None, d or None: the masked gradient a residual branch receives[, xcoef | segment sums]), or False when the shape is not served."""
     _rows(dz), _rows(x)
     rows, n = dz.shape
     k = x.shape[1]
@@ -839,6 +840,9 @@ def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, re
         dx = torch.empty((rows, k), dtype=f32, device=x.device)
     dzm = torch.empty((rows, n), dtype=f32, device=x.device) if want_masked else None
     xcoef = torch.empty((2, k), dtype=f32, device=x.device) if xstat is not None else None
+    if seg_rows and (seg_rows < 128 or seg_rows % 32 or rows % seg_rows):
+        return False
+    seg_db = torch.empty((rows // seg_rows, n), dtype=f32, device=x.device) if seg_rows else None
     nb = _lib.load().cmr_bn_linear_bwd_workspace_bytes(rows, n, k)
     ws = _ws(nb, x.device)
     zz = None if mask_from_h else z
@@ -846,9 +850,11 @@ def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, re
               _p(stat), _p(coef), int(bool(mask_from_h)), _p(dzm), n if want_masked else 0, _p(x), _ld(x), _p(xstat), float(xslope), _p(xcoef),
               _p(xdgamma), _p(xdbeta), _p(w), w.stride(0), _p(res), _ld(res) if res is not None else 0,
               _p(dx) if want_dx else None, _ld(dx) if want_dx else 0, rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(db),
-              int(accumulate_db), _p(ws), nb, _stream())
+              int(accumulate_db), int(seg_rows), _p(seg_db), _p(ws), nb, _stream())
     if xstat is not None:
         return dx, dzm, xcoef
+    if seg_rows:
+        return (dx if want_dx else None), dzm, seg_db
     return (dx if want_dx else None), dzm
 
 

@@ -259,6 +259,9 @@ class AgentUpdate:
             if dfeat is None:
                 dfeat = torch.zeros((R, cout), dtype=torch.float32, device=dev)
             ops.add_at_arg(dfeat, r["arg"], dg, B, N)                                         # backward of torch.max(dim=2)
+            if i > 0 and self.FUSED_3D and N % 32 == 0 and N >= 128:
+                dfeat, dg = self._block3d_bwd_fused(r, dfeat, B, N)
+                continue
             dsum = ops.act_bwd(dfeat, r["out"], SLOPE3D)                                      # final LeakyReLU
             dh2raw = self._bn_bwd(dsum, None, 1.0, r["h2raw"], r["st2"], p + "net.4")
             gw2 = bk.g(p + "net.3.weight")
@@ -297,6 +300,43 @@ class AgentUpdate:
                 # identity shortcut: the streamed half of d cat = dsum goes to the rows as the residual of the GEMM
                 dprev = ops.linear(dh1raw, w1t[:f], res=dsum[:, :f])
             dfeat, dg = dprev, dgprev
+
+    FUSED_3D = __import__("os").environ.get("CMR_AGENT_FUSED_3D", "1") == "1"
+
+    def _block3d_bwd_fused(self, r, dfeat, B, N):
+        """Backward of one ConvBNReLURes1D block of the 3-D branch on cat([feat, broadcast max]) (blocks 1..3: 128-wide input) with one pass
+        over the row maps per conv + BatchNorm pair (cmr_bn_bwd_coef_f32 + cmr_bn_linear_bwd_f32: BatchNorm apply, weight and data gradient
+        together; the final LeakyReLU's backward rides in the first pair, the per-sample column sums that the broadcast half needs come
+        out of the pair's own pass) instead of act_bwd / bn_bwd / linear_wgrad / colsum / the data-gradient GEMM each sweeping them.
+        -> (gradient at the previous block's rows, gradient at its per-sample max)."""
+        bk, f = self.bucket, self.f
+        dev = bk.params.device
+        p, cin, cout = r["p"], r["cin"], r["cout"]
+        ident = cin == cout
+        fprev, gprev = r["x"], r["g"]
+        # net[3] + BatchNorm + the block's final LeakyReLU: dsum = the gradient at the sum (what the shortcut receives)
+        w2, gw2 = bk.w(p + "net.3.weight"), bk.g(p + "net.3.weight")
+        coef2 = ops.bn_bwd_coef(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], bk.g(p + "net.4.weight"), bk.g(p + "net.4.bias"))
+        dh1, dsum = ops.bn_linear_bwd(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], coef2, r["h1"], w2, gw2, db=bk.g(p + "net.3.bias"),
+                                      want_masked=True)
+        # net[0] + BatchNorm + LeakyReLU: streamed half of the input in the pass, broadcast half from the per-sample column sums
+        w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
+        coef1 = ops.bn_bwd_coef(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], bk.g(p + "net.1.weight"), bk.g(p + "net.1.bias"))
+        dprev, _, cs1 = ops.bn_linear_bwd(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], coef1, fprev, w1[:, :f], gw1[:, :f],
+                                          res=dsum[:, :f] if ident else None, seg_rows=N)
+        dgprev = torch.empty((B, f), dtype=torch.float32, device=dev)
+        if ident:           # identity shortcut on the concatenation: the broadcast half of d cat = dsum, summed per sample
+            ops.colsum(dsum[:, f:], B, N, out=dgprev)
+        ops.linear_bwd_small(gprev, cs1, w1[:, f:], w1.shape[1], w1.shape[0], dw=gw1[:, f:], lddw=gw1.shape[1],
+                             db=bk.g(p + "net.0.bias"), dx1=dgprev, acc_dx=ident)
+        if not ident:
+            ws, gws = bk.w(p + "shortcut.0.weight"), bk.g(p + "shortcut.0.weight")
+            coefs = ops.bn_bwd_coef(dsum, None, 1.0, r["scraw"], r["stsc"], bk.g(p + "shortcut.1.weight"), bk.g(p + "shortcut.1.bias"))
+            dprev, _, cs2 = ops.bn_linear_bwd(dsum, None, 1.0, r["scraw"], r["stsc"], coefs, fprev, ws[:, :f], gws[:, :f], res=dprev, dx=dprev,
+                                              seg_rows=N)
+            ops.linear_bwd_small(gprev, cs2, ws[:, f:], ws.shape[1], ws.shape[0], dw=gws[:, f:], lddw=gws.shape[1],
+                                 db=bk.g(p + "shortcut.0.bias"), dx1=dgprev, acc_dx=True)
+        return dprev, dgprev
 
     # ------------------------------------------------------------------------------------------------------------- API
     def forward_backward(self, *args, **kw):

@@ -425,7 +425,8 @@ int cmr_bn_bwd_coef_f32(const float* dz, int64_t lddz, const float* z, int64_t l
  * CMRAgent.py:25-33): with h = x W^T + b the BatchNorm input, z the layer output and (stat, coef) from cmr_bn_stats_f32 /
  * cmr_bn_bwd_coef_f32:  d = dz * act'(z) (-> dzm when non-null),  dh = scale (d - c1 - xhat c2),  dw (+)= dh^T x,  dx = dh W (+ res;
  * dx may alias res; dx null: weight gradient only).  stat = coef = null: no BatchNorm (dh = d).  z null: no activation.  db non-null:
- * (+)= column sums of dh (the bias gradient of a layer without BatchNorm).
+ * (+)= column sums of dh (the bias gradient of a layer without BatchNorm).  seg_db non-null: seg_db [rows / seg_rows][n] = the column sums
+ * of dh per seg_rows-row segment (per sample: the gradient of a per-sample vector broadcast to its points, CMRAgent.py:95-99).
  * mask_from_h: z was never stored (the next layer consumed it through cmr_linear_bn_fwd_f32's prologue): act' from the sign of
  * h * stat[2] + stat[3].  xstat non-null: x is the PREVIOUS layer's BatchNorm input, the operand is lrelu_{xslope}(x * xstat[2] +
  * xstat[3]), dx is the gradient at that never-stored activation and the previous layer's BatchNorm-backward reduction comes out of the
@@ -437,7 +438,8 @@ int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t
                           const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x, int64_t ldx,
                           const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta, const float* w, int64_t ldw,
                           const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows, int n, int k, float* dw, int64_t lddw,
-                          int accumulate, float* db, int accumulate_db, void* ws, int64_t ws_bytes, hipStream_t stream);
+                          int accumulate, float* db, int accumulate_db, int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes,
+                          hipStream_t stream);
 /* Forward of the same layer with its statistics from the same pass: h [rows][64] = x' W^T + bias and stat [4][64] = the batch statistics
  * of h exactly as cmr_bn_stats_f32 defines them (mean, rstd, scale, shift; running statistics updated when given).  pro_stat non-null:
  * x' = lrelu_{pro_slope}(x * pro_stat[2 k ..] + pro_stat[3 k ..]) -- x is then the PREVIOUS layer's BatchNorm input and that layer's

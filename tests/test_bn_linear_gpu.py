@@ -310,3 +310,27 @@ def test_lazy_operand_backward_vs_float64(ops, rows, k, last):
     # and the gradient at the previous layer's BatchNorm input
     dh0 = ops.bn_bwd(dx, z0, s0, h0, stat0)
     close(dh0, H0.grad, 2e-4, "gradient at the previous layer's BatchNorm input")
+
+
+def test_per_segment_column_sums(ops):
+    """seg_rows: the map is B samples of N rows; the third result is the column sum of dh per sample (the gradient of a per-sample vector
+    broadcast to the sample's rows) -- against the stand-alone apply pass + cmr_colsum_f32, and the other results unchanged."""
+    B, N, n, k, slope = 10, 16384, 128, 64, 0.2
+    rows = B * N
+    x, w = rnd(rows, k, seed=51).to(DEV), (rnd(n, 2 * k, seed=52) / 6).to(DEV)          # the streamed half of a 128-wide layer: W[:, :64]
+    h = ops.linear(x, w[:, :k].contiguous())
+    stat = ops.bn_stats(h, torch.ones(n, device=DEV), torch.zeros(n, device=DEV))
+    z = ops.affine_act(h, stat[2], stat[3], slope=slope)
+    dz = (rnd(rows, n, seed=53) / rows).to(DEV)
+    dg, db = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    coef = ops.bn_bwd_coef(dz, z, slope, h, stat, dg, db)
+    dw = torch.zeros(n, 2 * k, device=DEV)
+    res = (rnd(rows, 2 * k, seed=54) / rows).to(DEV)
+    dx, _, cs = ops.bn_linear_bwd(dz, z, slope, h, stat, coef, x, w[:, :k], dw[:, :k], res=res[:, :k], seg_rows=N)
+    dw0 = torch.zeros(n, k, device=DEV)
+    dx0, _ = ops.bn_linear_bwd(dz, z, slope, h, stat, coef, x, w[:, :k].contiguous(), dw0, res=res[:, :k].contiguous())
+    close(dx, dx0, 1e-6, "dx (segmented launch)")
+    close(dw[:, :k], dw0, 2e-5, "dw (segmented launch)")
+    assert float(dw[:, k:].abs().max()) == 0.0
+    dh = ops.bn_bwd(dz, z, slope, h, stat)
+    close(cs, dh.double().view(B, N, n).sum(1), 2e-5, "per-sample column sums")
