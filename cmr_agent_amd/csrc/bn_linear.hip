@@ -54,14 +54,18 @@ __device__ __forceinline__ f32x4 blb_fma4(f32x4 a, f32x4 b, f32x4 c) {
 // ZH: the activation mask is the sign of this layer's own pre-activation h * scale + shift (the layer's output was never stored: it was
 // consumed through the next layer's prologue); XL: see BlbArgs.  Pre-activations are formed with the SAME fused multiply-add in the forward
 // prologue (bn_linear_fwd_kernel), here and in the mask, so that a value within rounding of zero takes the same branch everywhere.
+constexpr int BLB_R(int nt) { return nt == 4 ? 16 : 32; }      // rows per block
+
 template <int NT, int KT, bool BN, bool DEEP, bool ZH, bool XL>
 __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   static_assert(BN || !(ZH || XL), "lazy operands belong to BatchNorm layers");
-  constexpr int N = 32 * NT, K = 32 * KT, DS = N + 36, XS = K + 36, R = 32;
+  // 128 outputs: 16-row blocks -- the LDS tiles and the staging registers halve, so that three workgroups share a CU (with 32 rows: 84 KB
+  // of LDS and 220 registers = ONE workgroup per CU, nothing to hide its load latency behind)
+  constexpr int N = 32 * NT, K = 32 * KT, DS = N + 36, XS = K + 36, R = BLB_R(NT), RH = R / 16;
   constexpr int TPW = NT * KT / 4;               // weight-gradient tiles per wave
   constexpr int KQ = K / 64;                     // data gradient: 16-channel tiles per wave
   constexpr int NS = N / 4;                      // data gradient: contraction steps
-  constexpr int NLD = NT, NLX = KT;              // float4 per thread and block: 32 rows x N / 4 = 256 NT
+  constexpr int NLD = NT * R / 32, NLX = KT * R / 32;      // float4 per thread and block: R rows x N / 4 = 256 NLD
   extern __shared__ __attribute__((aligned(16))) float blb_smem[];
   float* Dl = blb_smem;                          // [2][R][DS]  dh
   float* Xl = blb_smem + 2 * R * DS;             // [2][R][XS]  x
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   }
 
   struct Stage {
-    f32x4 d[NLD], m[NLD], hv[NLD], x[NLX], r[2 * KQ];
+    f32x4 d[NLD], m[NLD], hv[NLD], x[NLX], r[RH * KQ];
   };
   const bool has_res = a.res != nullptr;
 
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     }
     if (want_dx && has_res) {
 #pragma unroll
-      for (int rh = 0; rh < 2; ++rh)
+      for (int rh = 0; rh < RH; ++rh)
 #pragma unroll
         for (int q = 0; q < KQ; ++q)
           s.r[rh * KQ + q] = *reinterpret_cast<const f32x4*>(a.res + (r0 + 16 * rh + j16) * a.ldres + kbase + 16 * q + 4 * g16);
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     }
   };
 
-  auto multiply = [&](int64_t blk, int buf, const f32x4 (&rv)[2 * KQ]) {
+  auto multiply = [&](int64_t blk, int buf, const f32x4 (&rv)[RH * KQ]) {
     const float* dl = Dl + buf * R * DS;
     const float* xl = Xl + buf * R * XS;
     // weight gradient: step j contracts the rows rr = (j & 7) + 16 (j >> 3) and rr + 8 (lane halves)
@@ -198,24 +202,24 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     }
     if (!want_dx) return;
     // data gradient of rows 16 rh + j16, input channels kbase + 16 q + 4 g16 .. + 3
-    // (the two row halves side by side: 2 KQ independent accumulator chains instead of KQ)
-    f32x4 dacc[2][KQ];
+    // (the row halves side by side: RH KQ independent accumulator chains instead of KQ)
+    f32x4 dacc[RH][KQ];
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh)
+    for (int rh = 0; rh < RH; ++rh)
 #pragma unroll
       for (int q = 0; q < KQ; ++q) dacc[rh][q] = has_res ? rv[rh * KQ + q] : f32x4{0.f, 0.f, 0.f, 0.f};
     const float* drow = dl + j16 * DS + g16;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float b0 = drow[4 * s], b1 = drow[16 * DS + 4 * s];
 #pragma unroll
-      for (int q = 0; q < KQ; ++q) {
-        dacc[0][q] = m16_mfma(wa[q][s], b0, dacc[0][q]);
-        dacc[1][q] = m16_mfma(wa[q][s], b1, dacc[1][q]);
+      for (int rh = 0; rh < RH; ++rh) {
+        const float b = drow[16 * rh * DS + 4 * s];
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) dacc[rh][q] = m16_mfma(wa[q][s], b, dacc[rh][q]);
       }
     }
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh)
+    for (int rh = 0; rh < RH; ++rh)
 #pragma unroll
       for (int q = 0; q < KQ; ++q) {
         *reinterpret_cast<f32x4*>(a.dx + (blk * R + 16 * rh + j16) * a.lddx + kbase + 16 * q + 4 * g16) = dacc[rh][q];
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   const int64_t nblocks = (seg + 1) * a.seg_blocks;            // (end of this workgroup's segment)
   auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
   int64_t blk = seg * a.seg_blocks + blockIdx.x % a.seg_groups;
-  f32x4 rcur[2 * KQ];
+  f32x4 rcur[RH * KQ];
   if (DEEP) {
     // two blocks ahead in registers (blk + g in sa, blk + 2 g in sb; blk itself in LDS), the body unrolled twice so that the two register
     // sets swap roles without moves
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     load_block(clampb(blk), sa);
     store_block(blk, 0, sa);
 #pragma unroll
-    for (int i = 0; i < 2 * KQ; ++i) rcur[i] = sa.r[i];
+    for (int i = 0; i < RH * KQ; ++i) rcur[i] = sa.r[i];
     load_block(clampb(blk + g), sa);
     __syncthreads();
     for (; blk < nblocks; blk += 2 * g) {
@@ -256,14 +260,14 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
       multiply(blk, 0, rcur);
       if (blk + g < nblocks) store_block(blk + g, 1, sa);        // (uniform)
 #pragma unroll
-      for (int i = 0; i < 2 * KQ; ++i) rcur[i] = sa.r[i];
+      for (int i = 0; i < RH * KQ; ++i) rcur[i] = sa.r[i];
       __syncthreads();
       if (blk + g >= nblocks) break;
       load_block(clampb(blk + 3 * g), sa);
       multiply(blk + g, 1, rcur);
       if (blk + 2 * g < nblocks) store_block(blk + 2 * g, 0, sb);
 #pragma unroll
-      for (int i = 0; i < 2 * KQ; ++i) rcur[i] = sb.r[i];
+      for (int i = 0; i < RH * KQ; ++i) rcur[i] = sb.r[i];
       __syncthreads();
     }
   } else {
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
     load_block(clampb(blk), st);
     store_block(blk, 0, st);
 #pragma unroll
-    for (int i = 0; i < 2 * KQ; ++i) rcur[i] = st.r[i];
+    for (int i = 0; i < RH * KQ; ++i) rcur[i] = st.r[i];
     __syncthreads();
     int buf = 0;
     for (; blk < nblocks; blk += g) {
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
       multiply(blk, buf, rcur);
       if (nb < nblocks) store_block(nb, buf ^ 1, st);      // (uniform) the other buffer: last read one iteration ago, behind a barrier
 #pragma unroll
-      for (int i = 0; i < 2 * KQ; ++i) rcur[i] = st.r[i];
+      for (int i = 0; i < RH * KQ; ++i) rcur[i] = st.r[i];
       __syncthreads();
       buf ^= 1;
     }
@@ -565,10 +569,12 @@ __global__ __launch_bounds__(64) void blb_seg_reduce_kernel(const float* __restr
 }
 
 inline int blb_groups(int64_t rows, int n, int k) {
-  const int64_t nblocks = rows / 32;
-  const size_t smem = (size_t)2 * 32 * (n + k + 72) * sizeof(float);
+  const int R = BLB_R(n / 32);
+  const int64_t nblocks = rows / R;
+  const size_t smem = (size_t)2 * R * (n + k + 72) * sizeof(float);
   int per_cu = (int)((size_t)160 * 1024 / smem);
   if (per_cu > 3) per_cu = 3;
+  if (n == 128 && per_cu > 2) per_cu = 2;        // (registers allow two; every workgroup also costs a 4 n k byte partial that the reduction reads back)
   if (per_cu < 1) per_cu = 1;
   int64_t groups = 256 * per_cu;
   if (groups > nblocks / 8) groups = nblocks / 8 > 0 ? nblocks / 8 : 1;      // >= 8 row blocks per workgroup
@@ -581,7 +587,7 @@ inline int blb_groups(int64_t rows, int n, int k) {
 template <int NT, int KT, bool BN, bool ZH, bool XL>
 int blb_launch(const BlbArgs& a, int groups, hipStream_t stream) {
   constexpr bool DEEP = CMR_BLB_DEEP != 0 && NT == 2 && KT == 2 && !XL;
-  const size_t smem = (size_t)2 * 32 * (32 * NT + 32 * KT + 72) * sizeof(float);
+  const size_t smem = (size_t)2 * BLB_R(NT) * (32 * NT + 32 * KT + 72) * sizeof(float);
   static CmrSmemCache granted{};
   if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL>), dim3(groups), dim3(256), smem, stream, a);
@@ -641,11 +647,12 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   if (res) CMR_REQUIRE(dx && ldres % 4 == 0 && cmr_aligned16(res) && ldres >= k);
   if (xl) CMR_REQUIRE(dx && xcoef && cmr_aligned16(xstat));
   int groups = blb_groups(rows, n, k);
-  int64_t seg_blocks = rows / 32;
+  const int R = BLB_R(n / 32);
+  int64_t seg_blocks = rows / R;
   int seg_groups = groups;
   if (seg_db) {                                  // per-segment column sums: a whole number of workgroups per segment, >= 4 blocks each
     const int64_t nseg = rows / seg_rows;
-    seg_blocks = seg_rows / 32;
+    seg_blocks = seg_rows / R;
     int64_t gps = (groups + nseg - 1) / nseg;
     if (gps > seg_blocks / 4) gps = seg_blocks / 4;
     if (gps < 1) gps = 1;

@@ -1,5 +1,5 @@
 """Launch census of ONE GeoUpdate step (Train_Geo.py:166-174) at --num-pt points: C-ABI calls by entry point (count, summed HIP-event ms), eager,
-side streams off.  python tools/geo_launches.py [num_pt]"""
+side streams off.  python tools/geo_launches.py [num_pt [HxW]]"""
 import os, sys, json, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,7 +16,11 @@ from cmr_agent_amd.utils.workmodel import CallTimer
 def main():
     dev = torch.device("cuda", 0)
     npt = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-    cfg = KittiConfiguration(device=dev, num_pt=npt)
+    kw = {}
+    if len(sys.argv) > 2:                                   # HxW, e.g. 352x1216
+        H, W = (int(v) for v in sys.argv[2].lower().split("x"))
+        kw = dict(cropped_img_H=H, cropped_img_W=W)
+    cfg = KittiConfiguration(device=dev, num_pt=npt, **kw)
     spec = json.load(open(os.path.join(BM.ROOT, "tests", "golden", "specs.json")))
     model = MultiHeadModel(cfg); load_checked(model, hashfill.make_state_dict(spec["geo"], BM.GEO_TAG)); model = model.to(dev)
     up = GeoUpdate(model, cfg)
