@@ -15,11 +15,11 @@ FLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Icmr_agent_amd/csrc
 
 all: $(LIB) $(LIBAB)
 
-build/%.o: cmr_agent_amd/csrc/%.hip cmr_agent_amd/csrc/cmr_common.h cmr_agent_amd/csrc/cmr_chain.h
+build/%.o: cmr_agent_amd/csrc/%.hip $(wildcard cmr_agent_amd/csrc/*.h)
 	@mkdir -p build
 	$(HIPCC) $(FLAGS) -c $< -o $@
 
-build/ab_%.o: cmr_agent_amd/csrc/%.hip cmr_agent_amd/csrc/cmr_common.h cmr_agent_amd/csrc/cmr_chain.h
+build/ab_%.o: cmr_agent_amd/csrc/%.hip $(wildcard cmr_agent_amd/csrc/*.h)
 	@mkdir -p build
 	$(HIPCC) $(FLAGS) -DCMR_AB_SWITCHES -c $< -o $@
 

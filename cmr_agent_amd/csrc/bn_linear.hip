@@ -390,22 +390,24 @@ struct BlfArgs {
   const float* x; int64_t ldx;        // [rows][k]
   const float* pro;                   // PRO: the previous layer's stat [4][k] (scale at 2 k, shift at 3 k)
   float pro_slope;
-  const float* w; int64_t ldw;        // [64][k]
-  const float* bias;                  // [64] or null
-  float* h; int64_t ldh;              // [rows][64]
-  float* part;                        // [gridDim.x][3][64]: pivot, sum (h - pivot), sum (h - pivot)^2
+  const float* w; int64_t ldw;        // [n][k]
+  const float* bias; int64_t bias_stride;   // [n] or null; bias_stride != 0: one bias row PER SEGMENT (bias + segment * bias_stride)
+  float* h; int64_t ldh;              // [rows][n]
+  float* part;                        // [gridDim.x][3][n]: pivot, sum (h - pivot), sum (h - pivot)^2
   int64_t rows;
+  int64_t seg_blocks;                 // row blocks per segment (rows / 32 when the map is one segment)
+  int seg_groups;                     // workgroups per segment
 };
 
-template <int KT, bool PRO>
+// NQ = n / 64: 16-channel tiles per wave (wave w owns the output channels [16 NQ w, 16 NQ (w + 1)))
+template <int NQ, int KT, bool PRO>
 __global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
-  constexpr int K = 32 * KT, XS = K + 36, R = 32, NS = K / 4, NLX = KT;
+  constexpr int N = 64 * NQ, K = 32 * KT, XS = K + 36, R = 32, NS = K / 4, NLX = KT;
   extern __shared__ __attribute__((aligned(16))) float blf_smem[];
   float* Xl = blf_smem;                          // [2][R][XS]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g16 = lane >> 4, j16 = lane & 15;
-  const int64_t nblocks = a.rows / R;
   const int xc = tid % (K / 4), xr0 = tid / (K / 4);
   constexpr int XRS = 1024 / K;
   f32x4 pscale, pshift;
@@ -413,12 +415,21 @@ __global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
     pscale = *reinterpret_cast<const f32x4*>(a.pro + 2 * K + 4 * xc);
     pshift = *reinterpret_cast<const f32x4*>(a.pro + 3 * K + 4 * xc);
   }
-  const int cbase = 16 * wave;
-  float wa[NS];                                  // A operand: lane 16 g + i holds W[cbase + i][4 s + g]
+  // workgroup -> row blocks: seg_groups workgroups stride through each segment of seg_blocks blocks (one segment = the whole map unless the
+  // bias is per segment, e.g. per SAMPLE: the broadcast half of cat([feat, max]) folded into the bias, CMRAgent.py:95-99)
+  const int64_t g = a.seg_groups;
+  const int64_t seg = blockIdx.x / a.seg_groups;
+  const int64_t nblocks = (seg + 1) * a.seg_blocks;
+  const int cbase = 16 * NQ * wave;
+  float wa[NQ][NS];                              // A operand: lane 16 g + i holds W[cbase + 16 q + i][4 s + g]
+  f32x4 bias4[NQ];
 #pragma unroll
-  for (int s = 0; s < NS; ++s) wa[s] = a.w[(int64_t)(cbase + j16) * a.ldw + 4 * s + g16];
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + cbase + 4 * g16);
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wa[q][s] = a.w[(int64_t)(cbase + 16 * q + j16) * a.ldw + 4 * s + g16];
+    bias4[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias4[q] = *reinterpret_cast<const f32x4*>(a.bias + seg * a.bias_stride + cbase + 16 * q + 4 * g16);
+  }
 
   auto load_block = [&](int64_t blk, f32x4 (&xv)[NLX]) {
 #pragma unroll
@@ -437,34 +448,49 @@ __global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
       *reinterpret_cast<f32x4*>(Xl + (buf * R + xr0 + XRS * i) * XS + 4 * xc) = v;
     }
   };
-  f32x4 pivot = {0.f, 0.f, 0.f, 0.f}, sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  f32x4 pivot[NQ], sum[NQ], sq[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) pivot[q] = sum[q] = sq[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   bool first = true;
   auto multiply = [&](int64_t blk, int buf) {
     const float* xl = Xl + buf * R * XS;
-    f32x4 acc[2] = {bias4, bias4};                 // the two row halves side by side: two independent accumulator chains
+    f32x4 acc[2][NQ];                              // the two row halves side by side: 2 NQ independent accumulator chains
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[0][q] = acc[1][q] = bias4[q];
     const float* xrow = xl + j16 * XS + g16;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const float b0 = xrow[4 * s], b1 = xrow[16 * XS + 4 * s];
-      acc[0] = m16_mfma(wa[s], b0, acc[0]);
-      acc[1] = m16_mfma(wa[s], b1, acc[1]);
-    }
-    if (first) {                                   // (uniform) pivot = this workgroup's first row: lane 16 g of each lane group holds it
 #pragma unroll
-      for (int e = 0; e < 4; ++e) pivot[e] = __shfl(acc[0][e], lane & 48, 64);
-      first = false;
+      for (int q = 0; q < NQ; ++q) {
+        acc[0][q] = m16_mfma(wa[q][s], b0, acc[0][q]);
+        acc[1][q] = m16_mfma(wa[q][s], b1, acc[1][q]);
+      }
     }
+    // pivot = this workgroup's first row (lane 16 g of each lane group holds it).  Branch-free on purpose: with `if (first)` here hipcc put
+    // the branch between the last MFMA and the v_accvgpr_read of its result, and on the taken path (every block but the first) only an
+    // s_nop 0 separated the two -- acc[1][NQ-1][3] was read before the matrix core had written it (seen as wrong statistics of exactly the
+    // channels 16 (2 w + 1) + 4 g + 3 at n = 128, with every h correct)
 #pragma unroll
-    for (int rh = 0; rh < 2; ++rh) {
-      *reinterpret_cast<f32x4*>(a.h + (blk * R + 16 * rh + j16) * a.ldh + cbase + 4 * g16) = acc[rh];
-      const f32x4 d = acc[rh] - pivot;
-      sum += d;
-      sq += d * d;
-    }
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float p0 = __shfl(acc[0][q][e], lane & 48, 64);
+        pivot[q][e] = first ? p0 : pivot[q][e];
+      }
+    first = false;
+#pragma unroll
+    for (int rh = 0; rh < 2; ++rh)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        *reinterpret_cast<f32x4*>(a.h + (blk * R + 16 * rh + j16) * a.ldh + cbase + 16 * q + 4 * g16) = acc[rh][q];
+        const f32x4 d = acc[rh][q] - pivot[q];
+        sum[q] += d;
+        sq[q] += d * d;
+      }
   };
-  const int64_t g = gridDim.x;
   auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
-  int64_t blk = blockIdx.x;
+  int64_t blk = seg * a.seg_blocks + blockIdx.x % a.seg_groups;
   // Two blocks ahead in registers (blk + g in xa, blk + 2 g in xb; blk itself in LDS): 8 - 16 KB per block and workgroup, so with ONE block
   // in flight a CU has 32 KB outstanding -- 8 MB on the chip against the ~16 MB that 8 TB/s x 2 us of loaded latency asks for.  (Measured
   // the same 71 - 73 us either way in back-to-back launches; 57 us = 4.7 TB/s alone.)  The body is unrolled twice so that the two register
@@ -485,17 +511,20 @@ __global__ __launch_bounds__(256) void bn_linear_fwd_kernel(const BlfArgs a) {
     store_block(0, xb);
     __syncthreads();
   }
-  // reduce over the 16 row lanes (DPP, fixed order); lane 16 g writes channels cbase + 4 g .. + 3
+  // reduce over the 16 row lanes (DPP, fixed order); lane 16 g writes channels cbase + 16 q + 4 g .. + 3
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    sum[e] = m16_sum16(sum[e]);
-    sq[e] = m16_sum16(sq[e]);
-  }
-  if (j16 == 0) {
-    float* p = a.part + (int64_t)blockIdx.x * 192 + cbase + 4 * g16;
-    *reinterpret_cast<f32x4*>(p) = pivot;
-    *reinterpret_cast<f32x4*>(p + 64) = sum;
-    *reinterpret_cast<f32x4*>(p + 128) = sq;
+  for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sum[q][e] = m16_sum16(sum[q][e]);
+      sq[q][e] = m16_sum16(sq[q][e]);
+    }
+    if (j16 == 0) {
+      float* p = a.part + (int64_t)blockIdx.x * 3 * N + cbase + 16 * q + 4 * g16;
+      *reinterpret_cast<f32x4*>(p) = pivot[q];
+      *reinterpret_cast<f32x4*>(p + N) = sum[q];
+      *reinterpret_cast<f32x4*>(p + 2 * N) = sq[q];
+    }
   }
 }
 
@@ -506,24 +535,24 @@ __device__ __forceinline__ double blf_wave_sum(double v) {
 }
 
 // one wave per channel: merge the workgroups' (pivot, sum, sum of squares) over their row counts in double (parallel variance), then what
-// cmr_bn_stats_f32's final step does: stat = (mean, rstd, scale, shift), running statistics.  Workgroup w of G held the blocks w, w + G, ...
-__global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restrict__ part, int G, int64_t nblocks, int64_t rows, float eps,
-                                                            float momentum, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                            float* __restrict__ stat) {
-  constexpr int C = 64;
+// cmr_bn_stats_f32's final step does: stat = (mean, rstd, scale, shift), running statistics.  Workgroup w = (segment, i) of seg_groups per
+// segment held the blocks i, i + seg_groups, ... of its segment's seg_blocks.
+__global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restrict__ part, int G, int seg_groups, int64_t seg_blocks, int64_t rows,
+                                                            int C, float eps, float momentum, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float* __restrict__ stat) {
   const int c = blockIdx.x, lane = threadIdx.x;
   double tot = 0.0;
   for (int w = lane; w < G; w += 64) {
-    const double n = 32.0 * (double)((nblocks - w + G - 1) / G);
-    tot += n * (double)part[(int64_t)w * 192 + c] + (double)part[(int64_t)w * 192 + 64 + c];
+    const double n = 32.0 * (double)((seg_blocks - w % seg_groups + seg_groups - 1) / seg_groups);
+    tot += n * (double)part[(int64_t)w * 3 * C + c] + (double)part[(int64_t)w * 3 * C + C + c];
   }
   const double mean = blf_wave_sum(tot) / (double)rows;
   double m2 = 0.0;
   for (int w = lane; w < G; w += 64) {
-    const double n = 32.0 * (double)((nblocks - w + G - 1) / G);
-    const double s = (double)part[(int64_t)w * 192 + 64 + c], ss = (double)part[(int64_t)w * 192 + 128 + c];
-    const double mw = (double)part[(int64_t)w * 192 + c] + s / n;
+    const double n = 32.0 * (double)((seg_blocks - w % seg_groups + seg_groups - 1) / seg_groups);
+    const double s = (double)part[(int64_t)w * 3 * C + C + c], ss = (double)part[(int64_t)w * 3 * C + 2 * C + c];
+    const double mw = (double)part[(int64_t)w * 3 * C + c] + s / n;
     m2 += (ss - s * s / n) + n * (mw - mean) * (mw - mean);
   }
   m2 = blf_wave_sum(m2);
@@ -545,17 +574,17 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
   }
 }
 
-inline int blf_groups(int64_t rows, int k) {
+inline int blf_groups(int64_t rows, int n, int k) {
   const int64_t nblocks = rows / 32;
-  int64_t groups = 256 * (k == 64 ? 4 : 3);
+  int64_t groups = 256 * ((k == 64 && n == 64) ? 4 : (n == 64 || k == 64 ? 3 : 2));
   if (groups > nblocks / 8) groups = nblocks / 8 > 0 ? nblocks / 8 : 1;      // >= 8 row blocks per workgroup: the W fragments and the pipeline fill are paid once
   return (int)groups;
 }
 
-template <int KT, bool PRO>
+template <int NQ, int KT, bool PRO>
 int blf_launch(const BlfArgs& a, int groups, hipStream_t stream) {
   const size_t smem = (size_t)2 * 32 * (32 * KT + 36) * sizeof(float);
-  hipLaunchKernelGGL((bn_linear_fwd_kernel<KT, PRO>), dim3(groups), dim3(256), smem, stream, a);
+  hipLaunchKernelGGL((bn_linear_fwd_kernel<NQ, KT, PRO>), dim3(groups), dim3(256), smem, stream, a);
   return CMR_OK;
 }
 
@@ -683,32 +712,52 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   return cmr_launch_status();
 }
 
-extern "C" int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int k) {
-  if (!(k == 64 || k == 128) || rows < 32 || rows % 32) return 0;
-  return (int64_t)blf_groups(rows, k) * 192 * (int64_t)sizeof(float);
+extern "C" int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int n, int k) {
+  if (!(k == 64 || k == 128) || !(n == 64 || n == 128) || rows < 32 || rows % 32) return 0;
+  return (int64_t)(blf_groups(rows, n, k) + 256) * 3 * n * (int64_t)sizeof(float);
 }
 
-// h [rows][64] = x' W^T + bias with x' = x, or (pro_stat non-null) x' = lrelu_{pro_slope}(x * pro_stat[2] + pro_stat[3]): the previous
-// layer's BatchNorm + LeakyReLU applied on the way in; and stat [4][64] = the batch statistics of h as cmr_bn_stats_f32 returns them
-// (running statistics updated when given).  Serves k in {64, 128}, rows a multiple of 32; else CMR_EUNSUPPORTED.
+// h [rows][n] = x' W^T + bias with x' = x, or (pro_stat non-null) x' = lrelu_{pro_slope}(x * pro_stat[2] + pro_stat[3]): the previous
+// layer's BatchNorm + LeakyReLU applied on the way in; and stat [4][n] = the batch statistics of h as cmr_bn_stats_f32 returns them
+// (running statistics updated when given).  bias_seg_rows > 0: bias is [rows / bias_seg_rows][n] (row stride bias_stride), one row per
+// segment of bias_seg_rows rows -- a per-SAMPLE vector, e.g. the broadcast half of cat([feat, max]) times its weights (CMRAgent.py:95-99).
+// Serves n, k in {64, 128}, rows a multiple of 32; else CMR_EUNSUPPORTED.
 extern "C" int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
-                                     const float* bias, float* h, int64_t ldh, int64_t rows, float eps, float momentum, const float* gamma,
-                                     const float* beta, float* running_mean, float* running_var, float* stat, void* ws, int64_t ws_bytes,
-                                     hipStream_t stream) {
-  CMR_REQUIRE(x && w && h && stat && ws && rows > 0 && k > 0);
-  if (!(k == 64 || k == 128) || rows < 32 || rows % 32) return CMR_EUNSUPPORTED;
-  CMR_REQUIRE(ldx % 4 == 0 && ldh % 4 == 0 && ldx >= k && ldh >= 64 && ldw >= k && cmr_aligned16(x) && cmr_aligned16(h));
+                                     const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n,
+                                     float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float* stat, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(x && w && h && stat && ws && rows > 0 && k > 0 && n > 0);
+  if (!(k == 64 || k == 128) || !(n == 64 || n == 128) || rows < 32 || rows % 32) return CMR_EUNSUPPORTED;
+  if (bias_seg_rows > 0 && (bias_seg_rows < 128 || bias_seg_rows % 32 || rows % bias_seg_rows)) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(ldx % 4 == 0 && ldh % 4 == 0 && ldx >= k && ldh >= n && ldw >= k && cmr_aligned16(x) && cmr_aligned16(h));
   CMR_REQUIRE((!bias || cmr_aligned16(bias)) && (!pro_stat || cmr_aligned16(pro_stat)));
+  CMR_REQUIRE(bias_seg_rows <= 0 || (bias && bias_stride >= n && bias_stride % 4 == 0));
   CMR_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
-  const int groups = blf_groups(rows, k);
-  CMR_REQUIRE(ws_bytes >= (int64_t)groups * 192 * (int64_t)sizeof(float));
-  const BlfArgs a{x, ldx, pro_stat, pro_slope, w, ldw, bias, h, ldh, (float*)ws, rows};
-  if (k == 64) {
-    if (pro_stat) blf_launch<2, true>(a, groups, stream); else blf_launch<2, false>(a, groups, stream);
-  } else {
-    if (pro_stat) blf_launch<4, true>(a, groups, stream); else blf_launch<4, false>(a, groups, stream);
+  int groups = blf_groups(rows, n, k);
+  int64_t seg_blocks = rows / 32;
+  int seg_groups = groups;
+  if (bias_seg_rows > 0) {
+    const int64_t nseg = rows / bias_seg_rows;
+    seg_blocks = bias_seg_rows / 32;
+    int64_t gps = (groups + nseg - 1) / nseg;
+    if (gps > seg_blocks / 4) gps = seg_blocks / 4;
+    if (gps < 1) gps = 1;
+    CMR_REQUIRE(nseg * gps <= groups + 256);
+    seg_groups = (int)gps;
+    groups = (int)(nseg * gps);
   }
-  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(64), dim3(64), 0, stream, (const float*)ws, groups, rows / 32, rows, eps, momentum, gamma, beta,
-                     running_mean, running_var, stat);
+  CMR_REQUIRE(ws_bytes >= (int64_t)groups * 3 * n * (int64_t)sizeof(float));
+  const BlfArgs a{x, ldx, pro_stat, pro_slope, w, ldw, bias, bias_seg_rows > 0 ? bias_stride : 0, h, ldh, (float*)ws, rows, seg_blocks, seg_groups};
+  if (n == 64 && k == 64) {
+    if (pro_stat) blf_launch<1, 2, true>(a, groups, stream); else blf_launch<1, 2, false>(a, groups, stream);
+  } else if (n == 64) {
+    if (pro_stat) blf_launch<1, 4, true>(a, groups, stream); else blf_launch<1, 4, false>(a, groups, stream);
+  } else if (k == 64) {
+    if (pro_stat) blf_launch<2, 2, true>(a, groups, stream); else blf_launch<2, 2, false>(a, groups, stream);
+  } else {
+    if (pro_stat) blf_launch<2, 4, true>(a, groups, stream); else blf_launch<2, 4, false>(a, groups, stream);
+  }
+  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(n), dim3(64), 0, stream, (const float*)ws, groups, seg_groups, seg_blocks, rows, n, eps, momentum,
+                     gamma, beta, running_mean, running_var, stat);
   return cmr_launch_status();
 }

@@ -60,6 +60,10 @@ __device__ __forceinline__ float m16_sum16(float v) {
   v += m16_dppf<0x4E>(v);       // quad_perm:[2,3,0,1]
   v += m16_dppf<0x141>(v);      // row_half_mirror
   v += m16_dppf<0x140>(v);      // row_mirror
+  // The result must exist BEFORE any divergent branch that follows (typically `if (lane % 16 == 0) store`): hipcc sinks a DPP chain whose
+  // only use sits in such a branch into it, where the disabled lanes then read as 0 (bound_ctrl) -- seen as wrong sums of exactly the last
+  // element reduced in front of the branch (bn_linear_fwd_kernel<2, *>).  The empty asm is a use in the dominating block.
+  asm volatile("" : "+v"(v));
   return v;
 }
 

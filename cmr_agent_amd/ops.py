@@ -61,21 +61,22 @@ def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, ac
     if x2 is not None:
         _rows(x2, "x2")
         k2 = x2.shape[1]
-    if kw != k1 + k2 or not w.is_contiguous():
-        raise ValueError("weight shape %s does not match k1+k2=%d" % (tuple(w.shape), k1 + k2))
+    if kw != k1 + k2 or w.stride(1) != 1 or w.stride(0) < kw:
+        raise ValueError("weight shape %s / strides %s do not match k1+k2=%d" % (tuple(w.shape), w.stride(), k1 + k2))
+    ldw = w.stride(0) if n_out > 1 else kw                     # a column block of a wider matrix (W[:, lo:hi]) is read in place
     if out is None:
         out = torch.empty((rows, n_out), dtype=f32, device=x1.device)
     _rows(out, "out")
     if res is not None:
         _rows(res, "res")
-    if CONV_BF16 and LINEAR_BF16 and x2 is None and rows >= LINEAR_BF16_MIN_ROWS and k1 in (32, 64, 128) and n_out <= 128 and n_out % 4 == 0:
+    if CONV_BF16 and LINEAR_BF16 and x2 is None and ldw == kw and rows >= LINEAR_BF16_MIN_ROWS and k1 in (32, 64, 128) and n_out <= 128 and n_out % 4 == 0:
         # bf16 mode: the big row maps stream through the bf16 cores (the fp32 kernel is bound by its MFMA chain at these shapes)
         rc = _lib.call("cmr_linear_rows_bf16_f32", _p(x1), _ld(x1), k1, _p(w), kw, _p(bias), _p(res), _ld(res) if res is not None else 0,
                        int(res_mod), _p(out), _ld(out), rows, n_out, act, float(act_param), _stream(), allow_unsupported=True)
         if rc != _lib.UNSUPPORTED:
             return out
     _lib.call("cmr_linear_f32", _p(x1), _ld(x1), k1, _p(x2), _ld(x2) if x2 is not None else 0, k2, _p(_i32(idx2)),
-              int(div2), _p(w), kw, _p(bias), _p(res), _ld(res) if res is not None else 0, int(res_mod), _p(out),
+              int(div2), _p(w), ldw, _p(bias), _p(res), _ld(res) if res is not None else 0, int(res_mod), _p(out),
               _ld(out), rows, n_out, act, float(act_param), _stream())
     return out
 
@@ -775,25 +776,31 @@ def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None, w
 
 
 def linear_bn_fwd_ok(rows, n, k):
-    return n == 64 and k in (64, 128) and rows >= 32 and rows % 32 == 0
+    return n in (64, 128) and k in (64, 128) and rows >= 32 and rows % 32 == 0
 
 
-def linear_bn_fwd(x, w, bias, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, pro=None, pro_slope=1.0):
-    """-> (h [rows, 64] = x' W^T + bias, stat [4, 64] = bn_stats(h)) in one pass; pro = the previous layer's stat [4, k]: x' =
-    lrelu_{pro_slope}(x * pro[2] + pro[3]) (x is then that layer's BatchNorm input).  False when the shape is not served."""
+def linear_bn_fwd(x, w, bias, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1, pro=None, pro_slope=1.0, bias_seg_rows=0):
+    """-> (h [rows, n] = x' W^T + bias, stat [4, n] = bn_stats(h)) in one pass; pro = the previous layer's stat [4, k]: x' =
+    lrelu_{pro_slope}(x * pro[2] + pro[3]) (x is then that layer's BatchNorm input).  bias_seg_rows: bias is [rows / bias_seg_rows, n], one
+    row per segment (sample).  False when the shape is not served."""
     _rows(x)
     rows, k = x.shape
     n = gamma.numel()
     if not linear_bn_fwd_ok(rows, n, k) or w.shape[0] < n or w.shape[1] != k or w.stride(1) != 1:
         return False
+    if bias_seg_rows and (bias_seg_rows < 128 or bias_seg_rows % 32 or rows % bias_seg_rows):
+        return False
+    if bias_seg_rows and (bias is None or tuple(bias.shape) != (rows // bias_seg_rows, n) or bias.stride(1) != 1):
+        raise ValueError("linear_bn_fwd: per-segment bias must be [%d, %d]" % (rows // bias_seg_rows, n))
     if pro is not None and tuple(pro.shape) != (4, k):
         raise ValueError("linear_bn_fwd: prologue statistics %s for an input of width %d" % (tuple(pro.shape), k))
     h = torch.empty((rows, n), dtype=f32, device=x.device)
     stat = torch.empty((4, n), dtype=f32, device=x.device)
-    nb = _lib.load().cmr_linear_bn_fwd_workspace_bytes(rows, k)
+    nb = _lib.load().cmr_linear_bn_fwd_workspace_bytes(rows, n, k)
     ws = _ws(nb, x.device)
-    _lib.call("cmr_linear_bn_fwd_f32", _p(x), _ld(x), k, _p(pro), float(pro_slope), _p(w), w.stride(0), _p(bias), _p(h), n, rows, float(eps),
-              float(momentum), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(stat), _p(ws), nb, _stream())
+    _lib.call("cmr_linear_bn_fwd_f32", _p(x), _ld(x), k, _p(pro), float(pro_slope), _p(w), w.stride(0), _p(bias), int(bias_seg_rows),
+              bias.stride(0) if bias_seg_rows else 0, _p(h), n, rows, n, float(eps), float(momentum), _p(gamma), _p(beta), _p(running_mean),
+              _p(running_var), _p(stat), _p(ws), nb, _stream())
     return h, stat
 
 

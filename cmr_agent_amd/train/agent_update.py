@@ -76,6 +76,26 @@ class AgentUpdate:
             bn.running_var.copy_(rv[:c])
         return stat
 
+    def _linear_bn(self, x, lin, bn, bnp, gmax, N, src, fused=None):
+        """-> (x' W^T + b, BatchNorm statistics of it) for the conv `lin` + BatchNorm `bnp` pair of a 3-D block.  gmax [B, f] given: the
+        input is cat([x, broadcast gmax]) and the pair runs as ONE pass (cmr_linear_bn_fwd_f32) over the streamed half W[:, :f] with the
+        per-sample bias gmax W[:, f:]^T + b; `fused` (no second source): the same pass on the whole input."""
+        bk = self.bucket
+        w, b = bk.w(lin + ".weight"), bk.w(lin + ".bias")
+        if gmax is not None or fused:
+            gamma, beta = bk.w(bnp + ".weight"), bk.w(bnp + ".bias")
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            if gmax is not None:
+                f = x.shape[1]
+                r = ops.linear_bn_fwd(x, w[:, :f], ops.linear(gmax, w[:, f:], b), gamma, beta, bn.running_mean, bn.running_var, eps=bn.eps,
+                                      momentum=mom, bias_seg_rows=N)
+            else:
+                r = ops.linear_bn_fwd(x, w, b, gamma, beta, bn.running_mean, bn.running_var, eps=bn.eps, momentum=mom)
+            if r is not False:
+                return r
+        h = ops.linear(x, w, b, **src)
+        return h, self._bn(h, bn, bnp)
+
     def _bn_bwd(self, dz, z, slope, x, stat, prefix, add=None):
         return ops.bn_bwd(dz, z, slope, x, stat, self.bucket.g(prefix + ".weight"), self.bucket.g(prefix + ".bias"), add=add)
 
@@ -155,15 +175,15 @@ class AgentUpdate:
             p = "state_3d_embed.%d." % i
             m = ag.state_3d_embed[i]
             src = dict(x2=g, div2=N) if g is not None else {}
-            h1raw = ops.linear(feat, bk.w(p + "net.0.weight"), bk.w(p + "net.0.bias"), **src)
-            st1 = self._bn(h1raw, m.net[1], p + "net.1")
+            fused = g is not None and self.FUSED_3D and N % 32 == 0 and N >= 128
+            # (fused: the GEMM and the BatchNorm statistics of its output in one pass; the broadcast half of the input, cat([feat, max]),
+            # enters as a per-sample bias max W[:, f:]^T + b computed by a skinny GEMM)
+            h1raw, st1 = self._linear_bn(feat, p + "net.0", m.net[1], p + "net.1", g if fused else None, N, src)
             h1 = ops.affine_act(h1raw, st1[2], st1[3], slope=SLOPE3D)
-            h2raw = ops.linear(h1, bk.w(p + "net.3.weight"), bk.w(p + "net.3.bias"))
-            st2 = self._bn(h2raw, m.net[4], p + "net.4")
+            h2raw, st2 = self._linear_bn(h1, p + "net.3", m.net[4], p + "net.4", None, N, {}, fused)
             rec = dict(x=feat, g=g, h1raw=h1raw, st1=st1, h1=h1, h2raw=h2raw, st2=st2, cin=cin, cout=cout, p=p)
             if cin != cout:
-                scraw = ops.linear(feat, bk.w(p + "shortcut.0.weight"), bk.w(p + "shortcut.0.bias"), **src)
-                stsc = self._bn(scraw, m.shortcut[1], p + "shortcut.1")
+                scraw, stsc = self._linear_bn(feat, p + "shortcut.0", m.shortcut[1], p + "shortcut.1", g if fused else None, N, src)
                 out = ops.affine_act(h2raw, st2[2], st2[3], res=scraw, rscale=stsc[2], rshift=stsc[3], slope=SLOPE3D)
                 rec.update(scraw=scraw, stsc=stsc)
             else:

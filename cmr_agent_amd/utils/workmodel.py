@@ -152,7 +152,7 @@ WORK = {
     "cmr_bn_stats_f32": lambda a: (0, F * a["rows"] * a["C"]),
     "cmr_affine_act_f32": lambda a: (0, F * a["rows"] * a["C"] * (2 + (1 if a["res"] else 0))),
     "cmr_bn_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["z"] else 0) + (1 if a["add"] else 0) + (1 if a["dzm"] else 0))),
-    "cmr_linear_bn_fwd_f32": lambda a: (2.0 * a["rows"] * 64 * a["k"], F * (a["rows"] * (a["k"] + 64) + 64 * a["k"])),
+    "cmr_linear_bn_fwd_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (a["k"] + a["n"]) + a["n"] * a["k"])),
     "cmr_bn_bwd_coef_f32": lambda a: (0, F * a["rows"] * a["C"] * (2 + (1 if a["z"] else 0))),
     # fused layer backward: the two GEMMs of the layer (weight + data gradient), every distinct map once
     "cmr_bn_linear_bwd_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"] * (2 if a["dx"] else 1),

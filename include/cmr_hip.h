@@ -440,16 +440,18 @@ int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t
                           const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows, int n, int k, float* dw, int64_t lddw,
                           int accumulate, float* db, int accumulate_db, int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes,
                           hipStream_t stream);
-/* Forward of the same layer with its statistics from the same pass: h [rows][64] = x' W^T + bias and stat [4][64] = the batch statistics
+/* Forward of the same layer with its statistics from the same pass: h [rows][n] = x' W^T + bias and stat [4][n] = the batch statistics
  * of h exactly as cmr_bn_stats_f32 defines them (mean, rstd, scale, shift; running statistics updated when given).  pro_stat non-null:
  * x' = lrelu_{pro_slope}(x * pro_stat[2 k ..] + pro_stat[3 k ..]) -- x is then the PREVIOUS layer's BatchNorm input and that layer's
- * activated output is never written (PointNN.py:96-123 layer_1 -> layer_2 -> layer_3, :260-282 net[0] -> net[3]).  k in {64, 128}, rows a
- * multiple of 32; else CMR_EUNSUPPORTED (compose cmr_linear_f32 + cmr_bn_stats_f32). */
-int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int k);
+ * activated output is never written (PointNN.py:96-123 layer_1 -> layer_2 -> layer_3, :260-282 net[0] -> net[3]).  bias_seg_rows > 0:
+ * bias is [rows / bias_seg_rows][n] with row stride bias_stride, one row per segment (sample) of bias_seg_rows rows: the broadcast half of
+ * cat([feat, max]) times its weights (CMRAgent.py:95-99).  n, k in {64, 128}, rows a multiple of 32; else CMR_EUNSUPPORTED (compose
+ * cmr_linear_f32 + cmr_bn_stats_f32). */
+int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int n, int k);
 int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
-                          const float* bias, float* h, int64_t ldh, int64_t rows, float eps, float momentum, const float* gamma,
-                          const float* beta, float* running_mean, float* running_var, float* stat, void* ws, int64_t ws_bytes,
-                          hipStream_t stream);
+                          const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n, float eps,
+                          float momentum, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
+                          void* ws, int64_t ws_bytes, hipStream_t stream);
 /* dy = dz * LeakyReLU'(z) (+ add): activation backward where no BatchNorm sits in front (identity shortcut, PointNN.py:271). */
 int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,
                     float* dy, int64_t lddy, int64_t rows, int C, hipStream_t stream);

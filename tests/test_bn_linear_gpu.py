@@ -113,11 +113,11 @@ def test_bn_linear_backward_vs_float64_and_op_by_op(ops, rows, n, k, slope, with
         assert torch.equal(dzm, r2[1])
 
 
-@pytest.mark.parametrize("rows,k,pro", [(8192, 64, False), (12800, 128, False), (524288, 64, True), (16384, 128, True), (32, 64, False), (96, 64, True)])
-def test_linear_with_statistics_in_one_pass(ops, rows, k, pro):
+@pytest.mark.parametrize("rows,k,pro,n", [(8192, 64, False, 64), (12800, 128, False, 64), (524288, 64, True, 64), (16384, 128, True, 64), (32, 64, False, 64),
+                                          (96, 64, True, 64), (16384, 64, False, 128), (163840, 128, True, 128), (4096, 128, False, 128)])
+def test_linear_with_statistics_in_one_pass(ops, rows, k, pro, n):
     """cmr_linear_bn_fwd_f32: h = x' W^T + b and the batch statistics of h from the same pass (per-workgroup pivots merged in double) against
     float64, and against cmr_linear_f32 + cmr_bn_stats_f32; pro: the previous layer's BatchNorm + LeakyReLU applied to x on the way in."""
-    n = 64
     x, w, b = rnd(rows, k, seed=31) + 0.5, rnd(n, k, seed=32) / 6, rnd(n, seed=33) * 3          # channel means well away from zero
     gamma, beta = (1 + 0.3 * rnd(n, seed=34)).to(DEV), (0.2 * rnd(n, seed=35)).to(DEV)
     xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
@@ -334,3 +334,19 @@ def test_per_segment_column_sums(ops):
     assert float(dw[:, k:].abs().max()) == 0.0
     dh = ops.bn_bwd(dz, z, slope, h, stat)
     close(cs, dh.double().view(B, N, n).sum(1), 2e-5, "per-sample column sums")
+
+
+def test_per_sample_bias_is_the_broadcast_half_of_the_input(ops):
+    """cat([feat, broadcast(max)]) W^T + b  =  feat W[:, :f]^T + (max W[:, f:]^T + b)[sample]: the one-pass forward with a per-segment bias
+    against cmr_linear_f32 with its second (broadcast) source, statistics against cmr_bn_stats_f32."""
+    B, N, f, n = 10, 16384, 64, 128
+    feat, g = rnd(B * N, f, seed=61).to(DEV), rnd(B, f, seed=62).to(DEV)
+    w, b = (rnd(n, 2 * f, seed=63) / 8).to(DEV), rnd(n, seed=64).to(DEV)
+    gamma, beta = (1 + 0.3 * rnd(n, seed=65)).to(DEV), (0.2 * rnd(n, seed=66)).to(DEV)
+    ref = ops.linear(feat, w, b, x2=g, div2=N)
+    stat_ref = ops.bn_stats(ref, gamma, beta)
+    bias = ops.linear(g, w[:, f:], b)                                   # a column block of the weight matrix, read in place
+    close(bias, g.double() @ w[:, f:].double().t() + b.double(), 2e-6, "per-sample bias")
+    h, stat = ops.linear_bn_fwd(feat, w[:, :f], bias, gamma, beta, bias_seg_rows=N)
+    close(h, ref, 3e-6, "h")
+    close(stat, stat_ref, 2e-5, "stat")
