@@ -174,7 +174,20 @@ def _median_timed(fn, passes, budget_s):
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md); ridge 2500 / 8 = 312 FLOP/B
 
 
-def train_roofline(table, steps, families, step_ms=None):
+def _profiled_traffic(doms, profile):
+    """HBM bytes per C-ABI call of the dominant family from a committed rocprofv3 PMC profile (tools/_pmc_train.sh), or None when the
+    profile does not hold every entry point of the family that ran."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, profile)))
+    except (OSError, ValueError):
+        return None
+    if any(d["name"] not in pmc for d in doms):
+        return None
+    calls = sum(d["calls"] for d in doms)
+    return sum(pmc[d["name"]]["hbm_bytes_per_call"] * d["calls"] for d in doms) / max(calls, 1)
+
+
+def train_roofline(table, steps, families, step_ms=None, traffic_profile=None):
     """roofline object of a training step from a CallTimer table.  families: [(label, entry-point names, matrix peak in TFLOP/s)];
     the DOMINANT one is the family with the largest summed HIP-event time, priced on ISSUED work (Winograd launches at 16/36 of
     their algorithmic multiplies) against its own roof: matrix peak when its FLOP/B exceeds the ridge of that peak, else 8 TB/s on
@@ -212,6 +225,13 @@ def train_roofline(table, steps, families, step_ms=None):
         ach = by / (ms * 1e-3) / 1e9
         out.update(bound="hbm", achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
                    algorithmic_bytes_per_launch=by / max(calls, 1), flop_per_byte=fl / by if by else 0.0)
+    if traffic_profile:
+        tr = _profiled_traffic(doms, traffic_profile)
+        if tr is not None:
+            out.update(traffic=tr, traffic_unit="HBM bytes per C-ABI call of the dominant entry point(s) (rocprofv3 PMC, %s)" % traffic_profile,
+                       traffic_source="committed profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/_pmc_train.sh), "
+                                      "not a property of this run",
+                       algorithmic_bytes_per_call=by / max(calls, 1))
     return out
 
 
@@ -303,9 +323,11 @@ def train_main(args, ctx=None, with_cpu=False):
                     ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
                      ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc"), BF16_MFMA_PEAK_TFLOPS),
                     ("conv3x3_wgrad_bf16_kernel: 3x3 weight gradients on v_mfma_f32_32x32x16_bf16 (rows transposed into LDS, fp32 accumulate)",
-                     ("cmr_conv3x3_wgrad_bf16_f32",), BF16_MFMA_PEAK_TFLOPS),
-                    ("linear_ws_kernel / linear_wgrad_kernel: the 1x1 stacks of the 3-D branch, forward + data gradient + weight gradient "
-                     "(fp32 MFMA, row-streaming)", ("cmr_linear_f32", "cmr_linear_wgrad_f32"), FP32_MFMA_PEAK_TFLOPS)]
+                     ("cmr_conv3x3_wgrad_bf16_f32", "cmr_conv3x3_wgrad_bias_bf16_f32"), BF16_MFMA_PEAK_TFLOPS),
+                    ("bn_linear_bwd_kernel: BatchNorm apply + weight gradient + data gradient of the 3-D branch's conv + BatchNorm pairs in one "
+                     "pass over the row maps (fp32 MFMA)", ("cmr_bn_linear_bwd_f32",), FP32_MFMA_PEAK_TFLOPS),
+                    ("linear_ws_kernel / bn_linear_fwd_kernel / linear_wgrad_kernel: the remaining row GEMMs of the 3-D branch (fp32 MFMA, "
+                     "row-streaming)", ("cmr_linear_f32", "cmr_linear_wgrad_f32", "cmr_linear_bn_fwd_f32"), FP32_MFMA_PEAK_TFLOPS)]
         line = {
             "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
             "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
@@ -321,7 +343,7 @@ def train_main(args, ctx=None, with_cpu=False):
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
             "launches_per_step": sum(d["calls"] for d in ct.table()),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
-            "roofline": train_roofline(ct.table(), 1, families, 1e3 * elapsed / args.steps),
+            "roofline": train_roofline(ct.table(), 1, families, 1e3 * elapsed / args.steps, traffic_profile="profiles/r04_pmc_train.json"),
             "loss": float(losses[0]), **info}
         if with_cpu and world == 1:
             line["cpu_baseline"] = agent_update_cpu_baseline(spec, w, MB)
@@ -450,7 +472,8 @@ def geo_train_main(args, ctx=None, with_cpu=False):
             "allreduce_ms_per_step": ar_ms / args.steps if ranks.dist is not None else 0.0,
             "launches_per_step": sum(d["calls"] for d in table),
             "roofline": train_roofline(table, 1, [("%s (the entry point with the largest summed time of the step)" % dom["name"],
-                                                   (dom["name"],), FP32_MFMA_PEAK_TFLOPS)], 1e3 * elapsed / args.steps),
+                                                   (dom["name"],), FP32_MFMA_PEAK_TFLOPS)], 1e3 * elapsed / args.steps,
+                                       traffic_profile="profiles/r04_pmc_train_geo.json" if (H, W, cfg.num_pt) == (160, 512, 65536) else None),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
             "loss": loss, **info}
         if prologue is not None:
@@ -696,6 +719,7 @@ def compact(line):
     out = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in line}
     out["workload"] = line["config"]["workload"]
     out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "path", "path_step", "path_modelled_share_of_kernel_time", "traffic",
+                                         "traffic_unit", "traffic_source", "algorithmic_bytes_per_call", "algorithmic_bytes_per_launch",
                                          "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
                                          "families_ms_per_step", "flop_per_byte") if k in r}
     for k in ("cpu_baseline", "launches_per_step", "launch_mode", "prologue_ms", "prologue", "allreduce_ms_per_step", "rccl_ranks", "rccl_version",
