@@ -592,8 +592,17 @@ int blf_launch(const BlfArgs& a, int groups, hipStream_t stream) {
 __global__ __launch_bounds__(64) void blb_seg_reduce_kernel(const float* __restrict__ part_b, int seg_groups, int n, float* __restrict__ cs) {
   const int seg = blockIdx.x, c = blockIdx.y * 64 + threadIdx.x;
   if (c >= n) return;
+  const float* p = part_b + (int64_t)seg * seg_groups * n + c;
   double s = 0.0;
-  for (int w = 0; w < seg_groups; ++w) s += (double)part_b[((int64_t)seg * seg_groups + w) * n + c];
+  int w = 0;
+  for (; w + 8 <= seg_groups; w += 8) {          // eight independent loads in flight (one dependent load per workgroup took 18 us for 76)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(w + u) * n];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  for (; w < seg_groups; ++w) s += (double)p[(int64_t)w * n];
   cs[(int64_t)seg * n + c] = (float)s;
 }
 
