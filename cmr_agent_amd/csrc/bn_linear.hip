@@ -542,22 +542,27 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, float* __restrict__ stat) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  double tot = 0.0;
+  // ONE pass over the partials: with d_w = mean - p_w,  M2 = sum_w [ss_w - 2 d_w s_w + n_w d_w^2]
+  //   = sum ss - 2 mean sum s + 2 sum p s + mean^2 sum n - 2 mean sum n p + sum n p^2   (double: the terms are <= rows * mean^2 ~ 1e8, M2 ~ 1e6)
+  double s_s = 0.0, s_ss = 0.0, s_ps = 0.0, s_np = 0.0, s_npp = 0.0;
   for (int w = lane; w < G; w += 64) {
     const double n = 32.0 * (double)((seg_blocks - w % seg_groups + seg_groups - 1) / seg_groups);
-    tot += n * (double)part[(int64_t)w * 3 * C + c] + (double)part[(int64_t)w * 3 * C + C + c];
+    const double p = (double)part[(int64_t)w * 3 * C + c], s = (double)part[(int64_t)w * 3 * C + C + c];
+    s_s += s;
+    s_ss += (double)part[(int64_t)w * 3 * C + 2 * C + c];
+    s_ps += p * s;
+    s_np += n * p;
+    s_npp += n * p * p;
   }
-  const double mean = blf_wave_sum(tot) / (double)rows;
-  double m2 = 0.0;
-  for (int w = lane; w < G; w += 64) {
-    const double n = 32.0 * (double)((seg_blocks - w % seg_groups + seg_groups - 1) / seg_groups);
-    const double s = (double)part[(int64_t)w * 3 * C + C + c], ss = (double)part[(int64_t)w * 3 * C + 2 * C + c];
-    const double mw = (double)part[(int64_t)w * 3 * C + c] + s / n;
-    m2 += (ss - s * s / n) + n * (mw - mean) * (mw - mean);
-  }
-  m2 = blf_wave_sum(m2);
+  s_s = blf_wave_sum(s_s);
+  s_ss = blf_wave_sum(s_ss);
+  s_ps = blf_wave_sum(s_ps);
+  s_np = blf_wave_sum(s_np);
+  s_npp = blf_wave_sum(s_npp);
   if (lane != 0) return;
   const double n = (double)rows;
+  const double mean = (s_np + s_s) / n;
+  const double m2 = s_ss - 2.0 * mean * s_s + 2.0 * s_ps + mean * mean * n - 2.0 * mean * s_np + s_npp;
   double var = m2 / n;
   var = var > 0.0 ? var : 0.0;
   const float rstd = (float)(1.0 / sqrt(var + (double)eps));
