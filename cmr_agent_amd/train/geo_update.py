@@ -211,7 +211,17 @@ class GeoUpdate:
         img = data["img"].to(dev).contiguous()
         pc, node, idx = data["pc"].to(dev), data["node"].to(dev), data["pt2node"].to(dev)
         B, _, H, W = img.shape
-        # ---- image tower
+        # the two towers share nothing until the coarse matcher: the point tower runs on a side stream underneath the image tower, forward
+        # and backward (Tape.fork)
+        (geo, x_feat, node_feat, pt_proxy, n2p_global, n2p_csr), (f2, d2, img_proxy, T) = t.fork(
+            lambda: self._point_tower(t, pc, node, idx, B), lambda: self._image_tower(t, img, B, H, W), tag="geo_update")
+        h, w = d2[1], d2[2]
+        N, M, Q = geo.N, geo.M, cfg.num_proxy
+        csr = (geo.offsets, geo.order)
+        return self._forward_rest(t, geo, csr, x_feat, node_feat, pt_proxy, n2p_global, n2p_csr, f2, d2, img_proxy, T, B, N, M, Q, h, w)
+
+    def _image_tower(self, t, img, B, H, W):
+        enc = self.model.encoder_decoder.encoder
         x4 = Var(ops.planar_to_rows(img.view(B, 3, H * W), 4))                               # [B*H*W, 4] rgb0
         rl = enc.img_transformer.embeddings.mini_resnet.residual_learning
         x, d = self._resblock(t, x4, (B, H, W), rl[0])
@@ -220,11 +230,15 @@ class GeoUpdate:
         f1, d1 = self._resblock(t, x, d, rl[3])
         x, d = self._resblock(t, f1, d1, rl[4])
         f2, d2 = self._resblock(t, x, d, rl[5])
-        h, w = d2[1], d2[2]
         img_proxy, T = self._patch_embed(t, enc.img_transformer.embeddings, f2, d2)
         for blk in enc.img_transformer.sa_encoder_layers:
             img_proxy = self._vit_block(t, img_proxy, None, blk, B, T, T)
-        # ---- point tower
+        return f2, d2, img_proxy, T
+
+    def _point_tower(self, t, pc, node, idx, B):
+        cfg = self.cfg
+        enc = self.model.encoder_decoder.encoder
+        dev = self.bucket.params.device
         geo = PointGeometry(pc, node, idx)
         N, M, Q = geo.N, geo.M, cfg.num_proxy
         pe = enc.pt_transformer.embeddings
@@ -252,46 +266,77 @@ class GeoUpdate:
         pt_proxy = self._group_pt(t, pe.group_transformer_proxy, geo.node4, node_feat, proxy4, proxy_feat, n2p_global, *n2p_csr)
         for blk in enc.pt_transformer.sa_encoder_layers:
             pt_proxy = self._vit_block(t, pt_proxy, None, blk, B, Q, Q)
+        return geo, x_feat, node_feat, pt_proxy, n2p_global, n2p_csr
+
+    def _forward_rest(self, t, geo, csr, x_feat, node_feat, pt_proxy, n2p_global, n2p_csr, f2, d2, img_proxy, T, B, N, M, Q, h, w):
+        cfg, model = self.cfg, self.model
+        ed = model.encoder_decoder
+        enc = ed.encoder
+        dev = self.bucket.params.device
         # ---- coarse matcher
         for i in range(cfg.num_ca_layer_coarse):
             img_proxy = self._vit_block(t, img_proxy, pt_proxy, enc.p2i_ca_layers[i], B, T, Q)
             pt_proxy = self._vit_block(t, pt_proxy, img_proxy, enc.i2p_ca_layers[i], B, Q, T)
-            img_proxy = self._vit_block(t, img_proxy, None, enc.img_sa_layers[i], B, T, T)
-            pt_proxy = self._vit_block(t, pt_proxy, None, enc.pt_sa_layers[i], B, Q, Q)
+            # the two self-attention blocks of an iteration are independent (launch-sized kernels: two chains fill more CUs than one)
+            ip, pp = img_proxy, pt_proxy
+            pt_proxy, img_proxy = t.fork(lambda: self._vit_block(t, pp, None, enc.pt_sa_layers[i], B, Q, Q),
+                                         lambda: self._vit_block(t, ip, None, enc.img_sa_layers[i], B, T, T), tag="geo_update")
         # ---- decoder: proxies -> nodes / pixels, fuse convs, linear attention
-        nod = t.cat(node_feat, t.gather(pt_proxy, n2p_global, n2p_csr))
-        for layer in list(ed.node_fuse_convs)[:-1]:
-            nod = self._cbr1d(t, nod, layer)
-        nod = t.dropout(nod, ed.node_fuse_convs[-1].p)           # IMGPCEnDecoder.py:38
-        pix = t.upsample_concat(f2, img_proxy, d2, cfg.patch_size)
         key = (h, w)
         if key not in self._pos2d:
             self._pos2d[key] = ed._pos_table(h, w, dev).view(h * w, -1).contiguous()
-        for i, layer in enumerate(list(ed.img_fuse_convs)[:-1]):
-            pix, _ = self._resblock(t, pix, d2, layer, post=self._pos2d[key] if i == 0 else None)
-        pix = t.dropout(pix, ed.img_fuse_convs[-1].p)            # IMGPCEnDecoder.py:54
+
+        def node_fuse():
+            nod = t.cat(node_feat, t.gather(pt_proxy, n2p_global, n2p_csr))
+            for layer in list(ed.node_fuse_convs)[:-1]:
+                nod = self._cbr1d(t, nod, layer)
+            return t.dropout(nod, ed.node_fuse_convs[-1].p)           # IMGPCEnDecoder.py:38
+
+        def pixel_fuse():
+            pix = t.upsample_concat(f2, img_proxy, d2, cfg.patch_size)
+            for i, layer in enumerate(list(ed.img_fuse_convs)[:-1]):
+                pix, _ = self._resblock(t, pix, d2, layer, post=self._pos2d[key] if i == 0 else None)
+            return t.dropout(pix, ed.img_fuse_convs[-1].p)            # IMGPCEnDecoder.py:54
+
+        # (sequential order: node side, then pixel side -- the node side is therefore the MAIN branch here so that the dropout sites keep
+        # their numbers)
+        pix, nod = t.fork(pixel_fuse, node_fuse, tag="geo_update")
         L = h * w
         for i in range(cfg.linear_attention_num):
             nod = self._la(t, ed.pixel_to_node_LA[i], nod, pix, B, M, L)
             pix = self._la(t, ed.node_to_pixel_LA[i], pix, nod, B, L, M)
-            nod = self._la(t, ed.node_self_LA[i], nod, nod, B, M, M)
-            pix = self._la(t, ed.pixel_self_LA[i], pix, pix, B, L, L)
+            n1, p1 = nod, pix                                     # the two self-attention layers of an iteration share nothing
+            pix, nod = t.fork(lambda: self._la(t, ed.pixel_self_LA[i], p1, p1, B, L, L), lambda: self._la(t, ed.node_self_LA[i], n1, n1, B, M, M),
+                              tag="geo_update")
         # ---- heads
         outs = {}
         # both heads start from the same cat[point features | features of the point's node] (MultiHeadModel.py:61-63, :227-229 build it once
         # per head): built once here, the two heads' gradients meet in its Var (the second one rides in a data-gradient GEMM's epilogue)
         xh_in = t.cat(x_feat, t.gather(nod, geo.gidx, csr))
-        for name, head in (("overlap", model.overlap_head), ("geo", model.geo_head)):
-            xh = xh_in
-            for layer in head.point_fuse_convs:
-                xh = self._cbr1d(t, xh, layer)
-            pcs = getattr(head, head._pc_name)
-            pts = t.linear(t.linear(xh, pcs[0].weight, pcs[0].bias, act=LRELU, slope=0.2), pcs[2].weight, pcs[2].bias)
-            yh = pix
-            for layer in head.img_res_convs:
-                yh, _ = self._resblock(t, yh, d2, layer)
-            ims = getattr(head, head._img_name)
-            pxs = t.linear(t.linear(yh, ims[0].weight, ims[0].bias, act=LRELU, slope=0.2), ims[2].weight, ims[2].bias)
+        heads = (("overlap", model.overlap_head), ("geo", model.geo_head))
+
+        def point_branches():                                    # 524 288-row stacks: HBM-bound
+            res = []
+            for _, head in heads:
+                xh = xh_in
+                for layer in head.point_fuse_convs:
+                    xh = self._cbr1d(t, xh, layer)
+                pcs = getattr(head, head._pc_name)
+                res.append(t.linear(t.linear(xh, pcs[0].weight, pcs[0].bias, act=LRELU, slope=0.2), pcs[2].weight, pcs[2].bias))
+            return res
+
+        def pixel_branches():                                    # 3x3 convolutions on the pixel map
+            res = []
+            for _, head in heads:
+                yh = pix
+                for layer in head.img_res_convs:
+                    yh, _ = self._resblock(t, yh, d2, layer)
+                ims = getattr(head, head._img_name)
+                res.append(t.linear(t.linear(yh, ims[0].weight, ims[0].bias, act=LRELU, slope=0.2), ims[2].weight, ims[2].bias))
+            return res
+
+        pts_all, pxs_all = t.fork(point_branches, pixel_branches, tag="geo_update")
+        for (name, _), pts, pxs in zip(heads, pts_all, pxs_all):
             outs[name] = (pts, pxs)
         pc_geo, img_geo = t.l2norm(outs["geo"][0]), t.l2norm(outs["geo"][1])
         return dict(B=B, N=N, h=h, w=w, pc_logits=outs["overlap"][0], img_logits=outs["overlap"][1], pc_geo=pc_geo, img_geo=img_geo)

@@ -65,6 +65,47 @@ class Tape:
         self.nodes = []
         self.join_side()
 
+    # Independent sub-graphs of a step (the image tower and the point tower; the point branch and the pixel branch of the heads) on two
+    # streams, forward AND backward: the point side is row passes bound by HBM, the image side 3x3 convolutions bound by the matrix cores --
+    # what the agent update's 2-D / 3-D fork gives (train/agent_update.py).  CMR_TAPE_FORK=0 runs them one after the other.
+    FORK = __import__("os").environ.get("CMR_TAPE_FORK", "1") == "1"
+
+    def fork(self, side_fn, main_fn, tag="tape"):
+        """-> (side_fn(), main_fn()): main_fn's ops are issued first (host order = the sequential order main, side: dropout sites keep their
+        numbers), side_fn's on a side stream; the two may share no Var.  The backward closures each of them records run as ONE node that
+        forks the same way.  Under hipGraph capture this is a flat fork from the capture's origin stream."""
+        from ..utils.streams import fork_join
+        outer = self.nodes
+
+        def run(fn):
+            self.nodes = []
+            try:
+                out = fn()
+                return out, self.nodes
+            finally:
+                self.nodes = outer
+
+        if not self.FORK:
+            (m, mn), (sd, sn) = run(main_fn), run(side_fn)
+            outer.extend(mn)
+            outer.extend(sn)
+            return sd, m
+        (sd, sn), (m, mn) = fork_join(lambda: run(side_fn), lambda: run(main_fn), tag=tag)
+
+        def back(nodes):
+            for fn in reversed(nodes):
+                fn()
+
+        def bwd():
+            # shared per-step state that is built lazily must exist BEFORE the streams part: the transposed weight copy (WT) made by the
+            # first branch that asks would be read by the other one without an edge between the two streams
+            if self._flatT is None:
+                self._flatT = self.bucket.transposed()
+            fork_join(lambda: back(sn), lambda: back(mn), tag=tag)
+
+        outer.append(bwd)
+        return sd, m
+
     def side(self, fn):
         """Run fn() -- launches whose results nothing reads before the optimizer (weight gradients) -- on the tape's side stream, ordered
         after everything queued on the current stream so far.  The token / pixel layers of the step are chains of launch-sized kernels
@@ -122,6 +163,10 @@ class Tape:
         key = (C, float(value))
         if key not in self._consts:
             self._consts[key] = torch.full((C,), float(value), dtype=f32, device=device)
+            # the cache outlives the step and is read from whichever stream asks next (Tape.fork): make the fill visible to all of them once
+            # (first use only; never during a capture -- the warm-up steps of enable_graph have created every constant by then)
+            if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.synchronize()
         return self._consts[key]
 
     # parameters ---------------------------------------------------------------------------------------------------------
