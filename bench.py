@@ -437,16 +437,40 @@ def geo_train_main(args, ctx=None, with_cpu=False):
         torch.cuda.synchronize()
     if not args.eager:
         up.enable_graph(batch)          # forward + backward replayed from a hipGraph; all-reduce and Adam launched per step
-    for _ in range(args.warmup):
-        up.step(batch if prologue is None else prologue(batch))
+    ahead = prologue is not None and getattr(args, "prologue_ahead", False)
+    if ahead:
+        # The loader's point work of step i + 1 runs on a side stream underneath step i, as the reference's DataLoader workers run
+        # underneath its training step (dataset/KittiDataset.py: FarthestSampler / cKDTree in __getitem__): every timed step still issues
+        # one prologue (for the next batch) and consumes one (issued during the step before); all of them finish inside the timed region.
+        main_s, side_s = torch.cuda.current_stream(), torch.cuda.Stream()
+
+        def launch_ahead():
+            side_s.wait_stream(main_s)                  # (the buffers of the prologue before this one have been consumed)
+            with torch.cuda.stream(side_s):
+                return prologue(dict(batch))
+
+        nxt = launch_ahead()
+        for _ in range(args.warmup):
+            main_s.wait_stream(side_s)
+            cur, nxt = nxt, launch_ahead()
+            up.step(cur)
+    else:
+        for _ in range(args.warmup):
+            up.step(batch if prologue is None else prologue(batch))
     ranks.barrier()
     ar_ms, pro_ms, t0 = 0.0, 0.0, time.perf_counter()
     for _ in range(args.steps):
-        losses = up.step(batch if prologue is None else prologue(batch))
+        if ahead:
+            main_s.wait_stream(side_s)
+            pro_ms += prologue.ms()                     # (the prologue this step consumes; its events are re-recorded by the next launch)
+            cur, nxt = nxt, launch_ahead()
+            losses = up.step(cur)
+        else:
+            losses = up.step(batch if prologue is None else prologue(batch))
+            if prologue is not None:
+                pro_ms += prologue.ms()
         if ranks.dist is not None:
             ar_ms += up.allreduce_ms()
-        if prologue is not None:
-            pro_ms += prologue.ms()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
     loss = float(losses["loss"])
@@ -478,7 +502,10 @@ def geo_train_main(args, ctx=None, with_cpu=False):
             "loss": loss, **info}
         if prologue is not None:
             line["prologue_ms"] = pro_ms / args.steps
-            line["prologue"] = "HIP events around planar_to_rows + fps + gather + nearest + ball_query + transpose of every timed step (inside ms_per_step)"
+            line["prologue"] = ("HIP events around planar_to_rows + fps + gather + nearest + ball_query + transpose of every timed step (inside ms_per_step)" +
+                                ("; issued one step ahead on a side stream (the next batch's point work under the current step, as the reference's "
+                                 "DataLoader workers): one prologue issued and one consumed per timed step" if ahead else ""))
+            line["prologue_overlap"] = bool(ahead)
         if with_cpu and world == 1:
             line["cpu_baseline"] = geo_update_cpu_baseline(spec, cfg.num_pt, B, H, W)
     del up, model, batch
@@ -722,7 +749,7 @@ def compact(line):
                                          "traffic_unit", "traffic_source", "algorithmic_bytes_per_call", "algorithmic_bytes_per_launch",
                                          "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
                                          "families_ms_per_step", "flop_per_byte") if k in r}
-    for k in ("cpu_baseline", "launches_per_step", "launch_mode", "prologue_ms", "prologue", "allreduce_ms_per_step", "rccl_ranks", "rccl_version",
+    for k in ("cpu_baseline", "launches_per_step", "launch_mode", "prologue_ms", "prologue", "prologue_overlap", "allreduce_ms_per_step", "rccl_ranks", "rccl_version",
               "rccl_note", "collective_ranks", "per_gpu", "agent_steps_per_s"):
         if k in line:
             out[k] = line[k]
@@ -759,6 +786,9 @@ def main():
     ap.add_argument("--img", default=None, help="train-geo: image crop HxW (default KittiConfig's 160x512; SURVEY.md 8d C5 = 352x1216)")
     ap.add_argument("--prologue", action="store_true", help="train-geo: node sampling (FPS over all points), nearest node and a ball query on the "
                     "device inside every timed step (SURVEY.md 8d C5), reported as prologue_ms")
+    ap.add_argument("--prologue-ahead", action="store_true", help="train-geo --prologue: issue the NEXT step's point prologue on a side stream "
+                    "underneath the current step (default: in front of its step on the same stream; measured 82.0 -> 80.4 ms at C5, the "
+                    "prologue itself stretching from 5.6 to 15 ms under the step's kernels: profiles/r04_ab_prologue.txt)")
     ap.add_argument("--share-gpu", action="store_true", help="every rank on device 0 (one-GPU box): exercises launcher, barrier / MAX "
                     "protocol and the bucket all-reduce on real HIP gradients; needs --dist-backend gloo")
     args = ap.parse_args()
