@@ -266,6 +266,35 @@ def test_graph_replay_equals_eager_steps():
         assert torch.equal(s0[k], s1[k]), k
 
 
+def test_two_stream_step_is_bit_identical_to_the_one_stream_step():
+    """Tape.fork issues the independent sub-graphs of the step (towers, the matcher's self-attention pairs, decoder fuse stacks, self
+    linear-attention pairs, the heads' point / pixel branches) on two streams, forward and backward.  Every kernel is deterministic and each
+    branch keeps its launch order, so losses, every gradient and the running statistics must equal the one-stream step bit for bit -- with
+    dropout ON (the sites keep their numbers because the main branch is issued first, in the sequential order)."""
+    from cmr_agent_amd.train import GeoUpdate
+    from cmr_agent_amd.train.tape import Tape
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batch = _to_dev(C.geo_train_batches()[0])
+    runs = []
+    old = Tape.FORK
+    try:
+        for fork in (True, False):
+            Tape.FORK = fork
+            model = _model(cfg, geo_sd)
+            up = GeoUpdate(model, cfg, dropout=True)
+            losses = {k: float(v) for k, v in up.forward_backward(batch).items()}
+            torch.cuda.synchronize()
+            runs.append((losses, up.bucket.grads.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    finally:
+        Tape.FORK = old
+    (l1, g1, r1), (l0, g0, r0) = runs
+    assert l1 == l0
+    assert torch.equal(g1, g0)
+    for k in r0:
+        assert torch.equal(r1[k], r0[k]), k
+
+
 def test_geo_update_at_the_configs4_shape_vs_oracle():
     """One forward / backward of the geometric model at BASELINE configs[4]'s shape (KittiConfig training crop 160x512, 65 536 points
     per cloud, 512 circle-loss pairs; 2 pairs instead of the 8 of a step so that the host autograd stays within seconds) against
