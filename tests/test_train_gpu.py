@@ -604,6 +604,37 @@ def test_forty_updates_in_bf16_mode_follow_the_fp32_trajectory():
     assert abs(float(b[-1, 0]) - float(f[-1, 0])) <= 0.05 * abs(float(f[-1, 0])) + 1e-3, (float(b[-1, 0]), float(f[-1, 0]))
 
 
+def test_agent_update_variants_at_the_benchmark_shape():
+    """AgentUpdate at the benchmark shape (fp32), three ways: (a) 3-D branch on a side stream (FORK_BRANCHES) vs on one stream: every kernel is
+    deterministic and each branch keeps its order -> bit-identical losses and gradients; (b) the 3-D branch's conv + BatchNorm pairs through
+    the one-pass forward / backward (FUSED_3D: cmr_linear_bn_fwd_f32 with per-sample bias rows, cmr_bn_bwd_coef_f32 + cmr_bn_linear_bwd_f32
+    with per-sample column sums) vs one launch per op: same arithmetic in other summation orders -> losses to 1e-5, every gradient tensor
+    within 2e-4 of the model's largest gradient entry."""
+    from cmr_agent_amd.train import AgentUpdate
+    case = "agent_train_full"
+    cfg_d = C.train_config(case, device=DEV)
+    batch = _to_dev(C.train_inputs(case)[0])
+    runs = {}
+    old = AgentUpdate.FORK_BRANCHES, AgentUpdate.FUSED_3D
+    try:
+        for name, fork, fused in (("fork+fused", True, True), ("fused", False, True), ("plain", False, False)):
+            AgentUpdate.FORK_BRANCHES, AgentUpdate.FUSED_3D = fork, fused
+            up = AgentUpdate(_product_agent(cfg_d), cfg_d)
+            losses, _ = up.forward_backward(batch)
+            torch.cuda.synchronize()
+            runs[name] = (losses.clone(), up.bucket.grads.clone(), {k: g.clone() for k, g in up.bucket.logical_grads().items()})
+    finally:
+        AgentUpdate.FORK_BRANCHES, AgentUpdate.FUSED_3D = old
+    assert torch.equal(runs["fork+fused"][0], runs["fused"][0]) and torch.equal(runs["fork+fused"][1], runs["fused"][1])
+    lf, _, gf = runs["fused"]
+    lp, _, gp = runs["plain"]
+    assert float((lf - lp).abs().max()) <= 1e-5 * max(1.0, float(lp.abs().max()))
+    gmax = max(float(g.abs().max()) for g in gp.values())
+    for k in gp:
+        err = float((gf[k] - gp[k]).abs().max())
+        assert err <= 2e-4 * gmax, "%s: max|d| %.3e vs largest gradient %.3e" % (k, err, gmax)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_agent_graph_replay_equals_eager_steps(mode):
     """AgentUpdate.enable_graph: forward + backward replayed from a hipGraph (all-reduce and the optimizer launch per step) must walk the
