@@ -536,19 +536,22 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
 
 // Farthest point sampling for clouds that do not fit one workgroup's registers (> 16 384 points; BASELINE configs[4] = 65 536):
 // G workgroups of 256 threads per cloud, each keeping its slice (coordinates + running min-distance, PER points per thread)
-// in registers.  A round = local arg-max (wave shuffles + LDS), then ONE 64-bit atomic max per workgroup on the round's word
-// (key = distance bits << 32 | ~index: distances are >= 0, so the unsigned order of the bits is the float order, and among
-// equal distances the lowest index wins, like torch.max), an arrival counter, and a bounded spin until all G workgroups of
-// the cloud have arrived.  Every round has its own word (zeroed by the entry point), so nothing is ever reset; the words are
-// turned into plain indices by fps_unpack_kernel afterwards.  The G workgroups of a cloud must be co-resident (the entry point
-// sizes G so that B * G <= 256); a workgroup that waits longer than FPS_SPIN polls raises the error word and leaves, and
-// everybody who sees the error word leaves too: the grid always drains.
+// in registers.  A round = local arg-max (wave shuffles + LDS), then every workgroup PUBLISHES its candidate as one 64-bit word in
+// its own slot of the round (key = distance bits << 32 | ~index: distances are >= 0, so the unsigned order of the bits is the float
+// order, and among equal distances the lowest index wins, like torch.max; a workgroup without a candidate publishes 1, which loses
+// against every key) and the first wave of every workgroup polls the round's G slots -- one 8 G-byte load -- until none is zero, then
+// takes the maximum itself.  Two dependent memory round trips per round (the poll that sees the last slot, the winner's coordinates)
+// where the first version had five (atomic max on a shared word, release increment of an arrival counter, poll of the counter, load
+// of the word, coordinates): 3.8 -> 2.x us per round at 8 x 65 536 points.  Every round has its own slots (zeroed by the entry point),
+// so nothing is ever reset; fps_unpack_kernel turns them into plain indices afterwards.  The G workgroups of a cloud must be
+// co-resident (the entry point sizes G so that B * G <= 256); a workgroup that polls longer than FPS_SPIN times raises the error
+// word and leaves, and everybody who sees the error word leaves too: the grid always drains.
 constexpr int FPS_CT = 256;
 constexpr unsigned FPS_SPIN = 1u << 22;
 template <int PER>
 __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restrict__ xyz4, const int64_t* __restrict__ start,
-                                                          unsigned long long* __restrict__ win /*[B][npoint]*/,
-                                                          unsigned* __restrict__ cnt /*[B] arrivals, then [B] error flags*/, int B, int G,
+                                                          unsigned long long* __restrict__ win /*[B][npoint][G]*/,
+                                                          unsigned* __restrict__ cnt /*[B] unused, then [B] error flags*/, int B, int G,
                                                           int N, int npoint, unsigned spin_limit) {
   __shared__ float red_d[4];
   __shared__ int red_i[4];
@@ -567,10 +570,10 @@ __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restric
     px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
     dist[j] = i < hi ? 1e10f : -1.f;
   }
-  unsigned long long* wb = win + (int64_t)b * npoint;
+  unsigned long long* wb = win + (int64_t)b * npoint * G;
   unsigned* err = cnt + B + b;
   int far = fps_start(start[b], N);
-  if (w == 0 && tid == 0) wb[0] = (unsigned long long)far;        // round 0's word holds the start index as it is
+  if (w == 0 && tid == 0) wb[0] = (unsigned long long)far;        // round 0's first slot holds the start index as it is
   for (int it = 0; it + 1 < npoint; ++it) {
     const f32x4 c = *reinterpret_cast<const f32x4*>(xb + (int64_t)far * 4);
     float bd = -1.f;
@@ -590,32 +593,38 @@ __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restric
     }
     if (lane == 0) { red_d[wave] = bd; red_i[wave] = bi; }
     __syncthreads();
-    if (tid == 0) {
+    if (wave == 0) {                                            // (uniform per wave) the first wave publishes and polls
+      unsigned long long* slots = wb + (int64_t)(it + 1) * G;
+      if (lane == 0) {
 #pragma unroll
-      for (int k = 1; k < 4; ++k)
-        if (red_d[k] > bd || (red_d[k] == bd && red_i[k] < bi)) { bd = red_d[k]; bi = red_i[k]; }
-      if (bd >= 0.f) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi);
-        __hip_atomic_fetch_max(&wb[it + 1], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = 1; k < 4; ++k)
+          if (red_d[k] > bd || (red_d[k] == bd && red_i[k] < bi)) { bd = red_d[k]; bi = red_i[k]; }
+        const unsigned long long key =
+            bd >= 0.f ? ((unsigned long long)__float_as_uint(bd) << 32) | (unsigned long long)(0xffffffffu - (unsigned)bi) : 1ull;
+        __hip_atomic_store(&slots[w], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __hip_atomic_fetch_add(&cnt[b], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned want = (unsigned)G * (unsigned)(it + 1);
       unsigned spins = 0;
       bool bad = spin_limit == 0u;                              // 0 = "fail at once" (tests of the repair path)
-      while (!bad && __hip_atomic_load(&cnt[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      unsigned long long k = 1ull;
+      while (!bad) {
+        k = lane < G ? __hip_atomic_load(&slots[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1ull;
+        if (__builtin_amdgcn_ballot_w64(k == 0ull) == 0ull) break;                     // every slot of the round is filled
         if (++spins > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = true; break; }
         __builtin_amdgcn_s_sleep(1);
       }
-      unsigned long long k = 0ull;
-      if (!bad) {
-        k = __hip_atomic_load(&wb[it + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad = k == 0ull;                                        // no workgroup had a candidate this round: not a valid index either
+      if (lane >= G) k = 0ull;
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {                        // G <= 16 slots: maximum over lanes 0 .. 15
+        const unsigned long long o = __shfl_xor(k, m);
+        k = o > k ? o : k;
       }
-      if (bad) {
-        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        far_s = -1;
-      } else {
-        far_s = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+      if (lane == 0) {
+        if (bad || k <= 1ull) {                                 // (k <= 1: no workgroup had a candidate this round: not a valid index either)
+          __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          far_s = -1;
+        } else {
+          far_s = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
+        }
       }
     }
     __syncthreads();
@@ -625,11 +634,13 @@ __global__ __launch_bounds__(FPS_CT) void fps_coop_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(256) void fps_unpack_kernel(const unsigned long long* __restrict__ win, const unsigned* __restrict__ cnt,
-                                                         int64_t* __restrict__ out, int B, int npoint) {
+                                                         int64_t* __restrict__ out, int B, int npoint, int G) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)B * npoint) return;
   const int b = (int)(i / npoint), it = (int)(i % npoint);
-  const unsigned long long k = win[i];
+  unsigned long long k = win[i * G];                            // round 0: the start index in the first slot; else the maximum of the round's slots
+  if (it > 0)
+    for (int w = 1; w < G; ++w) k = win[i * G + w] > k ? win[i * G + w] : k;
   int64_t v = it == 0 ? (int64_t)k : (int64_t)(0xffffffffu - (unsigned)(k & 0xffffffffull));
   if (cnt[B + b] != 0u) v = -1;                                 // a cloud whose workgroups could not meet: fps_repair_kernel rewrites it
   out[i] = v;
@@ -908,8 +919,8 @@ extern "C" int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out
 }
 
 
-// Cooperative variant for N > 16 384 (and any N the caller prefers): G workgroups per cloud.  ws: [B][npoint] 64-bit round words,
-// then [2 B] 32-bit counters / status words, then [B][N] floats for the repair pass.  A cloud whose workgroups did not all become
+// Cooperative variant for N > 16 384 (and any N the caller prefers): G workgroups per cloud.  ws: [B][npoint][G] 64-bit round slots
+// (room for 16 per round), then [2 B] 32-bit status words, then [B][N] floats for the repair pass.  A cloud whose workgroups did not all become
 // resident within the spin bound is recomputed by fps_repair_kernel in the same call: out never holds the -1 of a failed cloud.
 static int fps_groups(int B, int N) {
   int g = 256 / B;                                              // all B * G workgroups resident at once, one per CU
@@ -920,8 +931,9 @@ static int fps_groups(int B, int N) {
   return g < 1 ? 1 : g;
 }
 
-// workspace: [B][npoint] 64-bit round words | [B] arrival counters | [B] status words (0 ok, 2 repaired) | pad | [B][N] floats (repair)
-static int64_t fps_words_bytes(int B, int npoint) { return ((int64_t)B * npoint * 8 + (int64_t)2 * B * 4 + 15) / 16 * 16; }
+// workspace: [B][npoint][16] 64-bit round slots | [B] (unused) | [B] status words (0 ok, 2 repaired) | pad | [B][N] floats (repair)
+constexpr int FPS_GMAX = 16;                                   // slots per round in the workspace (G <= 16)
+static int64_t fps_words_bytes(int B, int npoint) { return ((int64_t)B * npoint * FPS_GMAX * 8 + (int64_t)2 * B * 4 + 15) / 16 * 16; }
 
 extern "C" int64_t cmr_fps_workspace_bytes(int B, int N, int npoint) {
   return fps_words_bytes(B, npoint) + (int64_t)B * N * 4;
@@ -932,12 +944,12 @@ static int fps_ws_launch(const float* xyz4, const int64_t* start, int64_t* out, 
   CMR_REQUIRE(xyz4 && start && out && ws && B > 0 && N > 0 && npoint > 0 && cmr_aligned16(xyz4) && (reinterpret_cast<uintptr_t>(ws) & 7u) == 0);
   CMR_REQUIRE(ws_bytes >= cmr_fps_workspace_bytes(B, N, npoint));
   const int G = fps_groups(B, N);
-  CMR_REQUIRE((int64_t)B * G <= 256);                            // co-residency of every cloud's workgroups
+  CMR_REQUIRE((int64_t)B * G <= 256 && G <= FPS_GMAX);           // co-residency of every cloud's workgroups; slots per round
   const int per = ((N + G - 1) / G + FPS_CT - 1) / FPS_CT;
   CMR_REQUIRE(per <= 64);
   if (hipMemsetAsync(ws, 0, (size_t)fps_words_bytes(B, npoint), stream) != hipSuccess) return CMR_ELAUNCH;
-  unsigned long long* win = (unsigned long long*)ws;
-  unsigned* cnt = (unsigned*)(win + (int64_t)B * npoint);
+  unsigned long long* win = (unsigned long long*)ws;             // [B][npoint][G] (the workspace holds FPS_GMAX slots per round)
+  unsigned* cnt = (unsigned*)(win + (int64_t)B * npoint * FPS_GMAX);
   float* distws = (float*)((char*)ws + fps_words_bytes(B, npoint));
 #define FPS_COOP(P) \
   hipLaunchKernelGGL((fps_coop_kernel<P>), dim3(B * G), dim3(FPS_CT), 0, stream, xyz4, start, win, cnt, B, G, N, npoint, spin_limit)
@@ -948,7 +960,7 @@ static int fps_ws_launch(const float* xyz4, const int64_t* start, int64_t* out, 
   else FPS_COOP(64);
 #undef FPS_COOP
   hipLaunchKernelGGL(fps_unpack_kernel, dim3((unsigned)(((int64_t)B * npoint + 255) / 256)), dim3(256), 0, stream, (const unsigned long long*)win,
-                     (const unsigned*)cnt, out, B, npoint);
+                     (const unsigned*)cnt, out, B, npoint, G);
   // clouds whose workgroups did not meet are redone by ONE workgroup each (a no-op launch of B workgroups otherwise)
   hipLaunchKernelGGL(fps_repair_kernel, dim3(B), dim3(FPS_T), 0, stream, xyz4, start, cnt, distws, out, B, N, npoint);
   return cmr_launch_status();

@@ -583,7 +583,8 @@ def fps(xyz4, start, B, N, npoint, coop=None, spin_limit=None, status=None):
         else:
             _lib.call("cmr_fps_ws_spin_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _p(ws), nb, int(spin_limit), _stream())
         if status is not None:
-            status.append(ws.view(torch.int32)[2 * B * npoint + B:2 * B * npoint + 2 * B])
+            words = 2 * B * npoint * 16                     # int32 words of the [B][npoint][16] 64-bit round slots (csrc/points.hip: FPS_GMAX)
+            status.append(ws.view(torch.int32)[words + B:words + 2 * B])
     else:
         _lib.call("cmr_fps_f32", _p(xyz4), _p(start), _p(out), B, N, npoint, _stream())
     return out
