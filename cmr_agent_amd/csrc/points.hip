@@ -924,7 +924,7 @@ extern "C" int cmr_fps_f32(const float* xyz4, const int64_t* start, int64_t* out
 // resident within the spin bound is recomputed by fps_repair_kernel in the same call: out never holds the -1 of a failed cloud.
 static int fps_groups(int B, int N) {
   int g = 256 / B;                                              // all B * G workgroups resident at once, one per CU
-  const int cap = B <= 4 ? 16 : 8;                              // measured at 65 536 points: 16 groups 2.9 us / round at B = 1, 8 groups 3.8 at B = 8
+  const int cap = 16;                                           // measured at 65 536 points: 16 groups 2.5 us / round at B = 1, 2.3 at B = 8 (8 groups: 2.7)
   if (g > cap) g = cap;
   const int need = (N + 64 * FPS_CT - 1) / (64 * FPS_CT);       // <= 64 points per thread
   if (g < need) g = need;
