@@ -350,3 +350,18 @@ def test_per_sample_bias_is_the_broadcast_half_of_the_input(ops):
     h, stat = ops.linear_bn_fwd(feat, w[:, :f], bias, gamma, beta, bias_seg_rows=N)
     close(h, ref, 3e-6, "h")
     close(stat, stat_ref, 2e-5, "stat")
+
+
+def test_statistics_survive_channel_means_far_from_zero(ops):
+    """Channel means of +-300 at a standard deviation of 0.3 (E[h^2] - E[h]^2 in fp32 would lose every digit): the per-workgroup pivots keep
+    the partial sums at the scale of the deviations and the merge runs in double -- mean to 1e-7 of its size, rstd to 1e-4."""
+    rows, n, k = 131072, 64, 64
+    x, w = rnd(rows, k, seed=71), rnd(n, k, seed=72) / 10
+    b = (rnd(n, seed=73) * 300).round()
+    gamma, beta = torch.ones(n, device=DEV), torch.zeros(n, device=DEV)
+    h, stat = ops.linear_bn_fwd(x.to(DEV), w.to(DEV), b.to(DEV), gamma, beta)
+    h64 = h.double()                                            # the statistics of the fp32 h the kernel wrote
+    mean, var = h64.mean(0), h64.var(0, unbiased=False)
+    assert float(var.min()) > 0.01 and float(mean.abs().max()) > 250
+    close(stat[0], mean, 2e-7, "mean")
+    close(stat[1], 1.0 / torch.sqrt(var + 1e-5), 1e-4, "rstd")
