@@ -137,6 +137,36 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict
   }
 }
 
+// The elementwise glue of a vector-attention layer (models/PointNN.py:151-170, 219-226) in one pass each way:
+//   forward   a_in = q - k + pos,  vp = v + pos            (three torch additions: 9 map passes -> 6)
+//   backward  dk = -da_in,  dpos = da_in + dvp             (dq = da_in and dv = dvp are the incoming buffers themselves)
+__global__ __launch_bounds__(256) void vecattn_mix_kernel(const float* __restrict__ q, int64_t ldq, const float* __restrict__ k, int64_t ldk,
+                                                          const float* __restrict__ v, int64_t ldv, const float* __restrict__ pos, int64_t ldp,
+                                                          float* __restrict__ a_in, float* __restrict__ vp, int64_t rows, int C) {
+  const int qd = C >> 2;
+  const int64_t total = rows * qd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / qd;
+    const int c = (int)(i - r * qd) * 4;
+    const f32x4 p = ld4(pos + r * ldp + c);
+    st4(a_in + r * C + c, ld4(q + r * ldq + c) - ld4(k + r * ldk + c) + p);
+    st4(vp + r * C + c, ld4(v + r * ldv + c) + p);
+  }
+}
+
+__global__ __launch_bounds__(256) void vecattn_mix_bwd_kernel(const float* __restrict__ da, int64_t ldda, const float* __restrict__ dvp, int64_t lddv,
+                                                              float* __restrict__ dk, float* __restrict__ dpos, int64_t rows, int C) {
+  const int qd = C >> 2;
+  const int64_t total = rows * qd;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / qd;
+    const int c = (int)(i - r * qd) * 4;
+    const f32x4 a = ld4(da + r * ldda + c);
+    st4(dk + r * C + c, f32x4{0.f, 0.f, 0.f, 0.f} - a);
+    st4(dpos + r * C + c, a + ld4(dvp + r * lddv + c));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // BatchNorm, training mode: backward
 // ------------------------------------------------------------------------------------------------------------------
@@ -684,6 +714,24 @@ extern "C" int cmr_bn_bwd_coef_f32(const float* dz, int64_t lddz, const float* z
 
 extern "C" int64_t cmr_bn_bwd_workspace_bytes(int64_t rows, int C) {
   return (int64_t)(red_blocks(rows, C) + 1) * 2 * C * sizeof(float);
+}
+
+extern "C" int cmr_vecattn_mix_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* pos,
+                                   int64_t ldp, float* a_in, float* vp, int64_t rows, int C, hipStream_t stream) {
+  CMR_REQUIRE(q && k && v && pos && a_in && vp && rows >= 0 && C > 0 && C % 4 == 0 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldp % 4 == 0);
+  CMR_REQUIRE(cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(pos) && cmr_aligned16(a_in) && cmr_aligned16(vp));
+  if (rows == 0) return CMR_OK;
+  hipLaunchKernelGGL(vecattn_mix_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, q, ldq, k, ldk, v, ldv, pos, ldp, a_in, vp, rows, C);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_vecattn_mix_bwd_f32(const float* da, int64_t ldda, const float* dvp, int64_t lddv, float* dk, float* dpos, int64_t rows,
+                                       int C, hipStream_t stream) {
+  CMR_REQUIRE(da && dvp && dk && dpos && rows >= 0 && C > 0 && C % 4 == 0 && ldda % 4 == 0 && lddv % 4 == 0);
+  CMR_REQUIRE(cmr_aligned16(da) && cmr_aligned16(dvp) && cmr_aligned16(dk) && cmr_aligned16(dpos));
+  if (rows == 0) return CMR_OK;
+  hipLaunchKernelGGL(vecattn_mix_bwd_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, da, ldda, dvp, lddv, dk, dpos, rows, C);
+  return cmr_launch_status();
 }
 
 extern "C" int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,

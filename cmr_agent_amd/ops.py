@@ -866,6 +866,27 @@ def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, re
     return (dx if want_dx else None), dzm
 
 
+def vecattn_mix(q, k, v, pos):
+    """-> (q - k + pos, v + pos) in one pass (the elementwise glue of a vector-attention layer)."""
+    for t in (q, k, v, pos):
+        _rows(t)
+    rows, C = q.shape
+    a_in = torch.empty((rows, C), dtype=f32, device=q.device)
+    vp = torch.empty((rows, C), dtype=f32, device=q.device)
+    _lib.call("cmr_vecattn_mix_f32", _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(pos), _ld(pos), _p(a_in), _p(vp), rows, C, _stream())
+    return a_in, vp
+
+
+def vecattn_mix_bwd(da, dvp):
+    """-> (dk = -da, dpos = da + dvp)."""
+    _rows(da), _rows(dvp)
+    rows, C = da.shape
+    dk = torch.empty((rows, C), dtype=f32, device=da.device)
+    dpos = torch.empty((rows, C), dtype=f32, device=da.device)
+    _lib.call("cmr_vecattn_mix_bwd_f32", _p(da), _ld(da), _p(dvp), _ld(dvp), _p(dk), _p(dpos), rows, C, _stream())
+    return dk, dpos
+
+
 def act_bwd(dz, z, slope, add=None, out=None):
     _rows(dz), _rows(z)
     rows, C = z.shape

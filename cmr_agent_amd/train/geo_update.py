@@ -129,12 +129,17 @@ class GeoUpdate:
         sc = x if isinstance(m.shortcut, nn.Identity) else t.linear_bn(x, m.shortcut[0].weight, m.shortcut[0].bias, m.shortcut[1])
         return t.linear_bn_chain(x, [(m.net[0].weight, m.net[0].bias, m.net[1], m.SLOPE), (m.net[3].weight, m.net[3].bias, m.net[4], m.SLOPE)], res=sc)
 
+    FUSED_MIX = __import__("os").environ.get("CMR_FUSED_MIX", "1") == "1"     # q - k + pos and v + pos in one pass each way (Tape.vecattn_mix)
+
     def _vector_attention(self, t, m, q_rows, k, v, rel, nseg, order, offsets, fixed_len):
         d, g = m.fc_delta, m.fc_gamma
         pos = t.linear(t.linear(rel, d[0].weight, d[0].bias, act=RELU), d[2].weight, d[2].bias)
-        a_in = t.add(t.add(q_rows, k, -1.0), pos)
+        if self.FUSED_MIX:
+            a_in, vp = t.vecattn_mix(q_rows, k, v, pos)
+        else:
+            a_in, vp = t.add(t.add(q_rows, k, -1.0), pos), t.add(v, pos)
         a = t.linear(t.linear(a_in, g[0].weight, g[0].bias, act=RELU), g[2].weight, g[2].bias)
-        return t.segment_softmax(a, t.add(v, pos), nseg, 0.125, order=order, offsets=offsets, fixed_len=fixed_len)
+        return t.segment_softmax(a, vp, nseg, 0.125, order=order, offsets=offsets, fixed_len=fixed_len)
 
     def _group_pt(self, t, m, xyz4, feat, node4, node_feat, gidx, offsets, order):
         """PointNN.py:149-185."""

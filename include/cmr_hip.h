@@ -452,6 +452,13 @@ int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_s
                           const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n, float eps,
                           float momentum, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
                           void* ws, int64_t ws_bytes, hipStream_t stream);
+/* The elementwise glue of a vector-attention layer in training (PointNN.py:151-170, 219-226: `fc_gamma(q - k + pos)`, `v + pos`) in one pass
+ * each way: a_in = q - k + pos, vp = v + pos (contiguous [rows][C] outputs);  backward dk = -da_in, dpos = da_in + dvp (dq and dv are the
+ * incoming gradients themselves). */
+int cmr_vecattn_mix_f32(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* pos, int64_t ldp,
+                        float* a_in, float* vp, int64_t rows, int C, hipStream_t stream);
+int cmr_vecattn_mix_bwd_f32(const float* da, int64_t ldda, const float* dvp, int64_t lddv, float* dk, float* dpos, int64_t rows, int C,
+                            hipStream_t stream);
 /* dy = dz * LeakyReLU'(z) (+ add): activation backward where no BatchNorm sits in front (identity shortcut, PointNN.py:271). */
 int cmr_act_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* add, int64_t ldadd,
                     float* dy, int64_t lddy, int64_t rows, int C, hipStream_t stream);

@@ -295,6 +295,28 @@ def test_two_stream_step_is_bit_identical_to_the_one_stream_step():
         assert torch.equal(r1[k], r0[k]), k
 
 
+def test_vector_attention_glue_in_one_pass_is_bit_identical():
+    """Tape.vecattn_mix (q - k + pos and v + pos in one pass; dk = -da, dpos = da + dvp in one pass) performs the three additions' arithmetic
+    in the same order: losses and every gradient equal the three-addition tape bit for bit."""
+    from cmr_agent_amd.train import GeoUpdate
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batch = _to_dev(C.geo_train_batches()[0])
+    runs = []
+    old = GeoUpdate.FUSED_MIX
+    try:
+        for fused in (True, False):
+            GeoUpdate.FUSED_MIX = fused
+            up = GeoUpdate(_model(cfg, geo_sd), cfg, dropout=False)
+            losses = {k: float(v) for k, v in up.forward_backward(batch).items()}
+            torch.cuda.synchronize()
+            runs.append((losses, up.bucket.grads.clone()))
+    finally:
+        GeoUpdate.FUSED_MIX = old
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+
+
 def test_geo_update_at_the_configs4_shape_vs_oracle():
     """One forward / backward of the geometric model at BASELINE configs[4]'s shape (KittiConfig training crop 160x512, 65 536 points
     per cloud, 512 circle-loss pairs; 2 pairs instead of the 8 of a step so that the host autograd stays within seconds) against
