@@ -148,7 +148,7 @@ class GeoUpdate:
         q = t.gather(t.linear(xx, m.w_qs.weight), gidx, (offsets, order))
         k, v = t.linear(x, m.w_ks.weight), t.linear(x, m.w_vs.weight)
         R, S = feat.v.shape[0], node_feat.v.shape[0]
-        rel = Var(ops.rel_pos(xyz4, node4, R, ib=gidx))
+        rel = Var(ops.rel_pos(xyz4, node4, R, ib=gidx), const=True)
         res = self._vector_attention(t, m, q, k, v, rel, S, order, offsets, 0)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), node_feat)
 
@@ -159,7 +159,7 @@ class GeoUpdate:
         k = t.gather(t.linear(x, m.w_ks.weight), knn, knn_csr)
         v = t.gather(t.linear(x, m.w_vs.weight), knn, knn_csr)
         S = feat.v.shape[0]
-        rel = Var(ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn))
+        rel = Var(ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn), const=True)
         res = self._vector_attention(t, m, q, k, v, rel, S, None, None, 16)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), feat)
 
@@ -227,7 +227,7 @@ class GeoUpdate:
 
     def _image_tower(self, t, img, B, H, W):
         enc = self.model.encoder_decoder.encoder
-        x4 = Var(ops.planar_to_rows(img.view(B, 3, H * W), 4))                               # [B*H*W, 4] rgb0
+        x4 = Var(ops.planar_to_rows(img.view(B, 3, H * W), 4), const=True)                   # [B*H*W, 4] rgb0
         rl = enc.img_transformer.embeddings.mini_resnet.residual_learning
         x, d = self._resblock(t, x4, (B, H, W), rl[0])
         f0, d0 = self._resblock(t, x, d, rl[1])
@@ -247,7 +247,7 @@ class GeoUpdate:
         geo = PointGeometry(pc, node, idx)
         N, M, Q = geo.N, geo.M, cfg.num_proxy
         pe = enc.pt_transformer.embeddings
-        pc4, node4 = Var(geo.pc4), Var(geo.node4)
+        pc4, node4 = Var(geo.pc4, const=True), Var(geo.node4, const=True)      # coordinates: no gradient
         csr = (geo.offsets, geo.order)
         x_feat = self._mini_pointnet(t, pc4, pe.raw_point_mlp)
         node_feat = self._mini_pointnet(t, node4, pe.raw_point_mlp)

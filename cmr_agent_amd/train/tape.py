@@ -31,12 +31,13 @@ def _side_stream_of(main):
 
 
 class Var:
-    __slots__ = ("v", "g", "own")
+    __slots__ = ("v", "g", "own", "const")
 
-    def __init__(self, v):
+    def __init__(self, v, const=False):
         self.v = v          # value, 2-D rows
         self.g = None       # gradient (same shape), set by consumers' backward closures
         self.own = False    # g is a buffer of this Var alone (may be accumulated into in place); False: shared with another Var
+        self.const = const  # an input of the step (coordinates, relative positions): nobody reads its gradient, layers skip computing it
 
 
 class Tape:
@@ -236,6 +237,8 @@ class Tape:
                 ops.linear_wgrad_any(dy, x.v, gw, acc, db=gbv, accumulate_db=accb)
             else:
                 ops.linear_wgrad_any(dy, x.v, gw, acc)
+            if x.const:                                        # (the 3-wide relative positions of the vector attention: a pass over dy for nothing)
+                return
             if x.g is None:
                 self.give(x, ops.linear(dy, self.WT(weight)), owned=True)
             else:
