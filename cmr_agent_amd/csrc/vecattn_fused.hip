@@ -22,12 +22,17 @@ struct VaArgs {
   const float* pa4; const int32_t* ia; uint32_t diva; const float* pb4; const int32_t* ib;
   const float *wd0, *bd0, *wd2, *bd2, *wg0, *bg0, *wg2, *bg2;
   float* a_out; float* vp_out; uint32_t rows;
+  // training (TRAIN; rows a multiple of 32): v from its own map instead of kv + 64, and the three activations the layer-by-layer
+  // backward reads -- relu(fc_delta[0]), q - k + pos, relu(fc_gamma[0]) -- stored beside the outputs
+  const float* v2; int64_t ldv2;
+  float *hd_out, *t_out, *g1_out;
 };
 
 __device__ __attribute__((aligned(16))) int32_t va_izero[4] = {0, 0, 0, 0};   // NOT const (see cmr_common.h: cmr_pin)
 
-template <bool COMPUTE_KV>
+template <bool COMPUTE_KV, bool TRAIN = false>
 __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
+  static_assert(!(COMPUTE_KV && TRAIN), "the training variant takes k and v from memory");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wd0 = smem;                          // [64][12]  (K = 3 padded to 8)
   float* Wd2 = Wd0 + 64 * VA_LD8;             // [64][68]
@@ -96,7 +101,8 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
 #pragma unroll
       for (int kg = 0; kg < 8; ++kg) {
         const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + kg * 8);
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(kp + 64 + kg * 8);
+        const f32x4 v4 = TRAIN ? *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)r * a.ldv2 + 4 * h + kg * 8)
+                               : *reinterpret_cast<const f32x4*>(kp + 64 + kg * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kk[kg / 4][4 * (kg % 4) + e] = k4[e]; vv[kg / 4][4 * (kg % 4) + e] = v4[e]; }
       }
@@ -123,6 +129,25 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
     cmr_chain_bias<2>(g1, Bs + 192, h, true);
     cmr_chain_gemm<2, 8, VA_LD>(Wg2, l31, h, ao, [&](int kg, int j) { return g1[kg / 4][4 * (kg % 4) + j]; });
     cmr_chain_bias<2>(ao, Bs + 256, h, false);
+    if (TRAIN) {                                 // (rows % 32 == 0: unconditional stores, the three saved activations first)
+      float* hp = a.hd_out + (int64_t)row * 64 + 4 * h;
+      float* tp = a.t_out + (int64_t)row * 64 + 4 * h;
+      float* gp = a.g1_out + (int64_t)row * 64 + 4 * h;
+#pragma unroll
+      for (int kg = 0; kg < 8; ++kg) {
+        f32x4 sh, st, sg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sh[e] = hd[kg / 4][4 * (kg % 4) + e];
+          st[e] = t[kg / 4][4 * (kg % 4) + e];
+          sg[e] = g1[kg / 4][4 * (kg % 4) + e];
+        }
+        cmr_pin(sh); cmr_pin(st); cmr_pin(sg);
+        *reinterpret_cast<f32x4*>(hp + kg * 8) = sh;
+        *reinterpret_cast<f32x4*>(tp + kg * 8) = st;
+        *reinterpret_cast<f32x4*>(gp + kg * 8) = sg;
+      }
+    }
     f32x4 oa[8], ov[8];
 #pragma unroll
     for (int kg = 0; kg < 8; ++kg)
@@ -145,16 +170,16 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
   }
 }
 
-template <bool COMPUTE_KV>
+template <bool COMPUTE_KV, bool TRAIN = false>
 int launch_va(const VaArgs& a, hipStream_t stream) {
   const size_t smem = (size_t)(64 * VA_LD8 + 3 * 64 * VA_LD + 5 * 64 + (COMPUTE_KV ? 192 * VA_LD : 0)) * sizeof(float);
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(vecattn_front_kernel<COMPUTE_KV>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(vecattn_front_kernel<COMPUTE_KV, TRAIN>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   const uint32_t ntiles = (a.rows + 31) / 32;
   uint32_t grid = (ntiles + 7) / 8;
   const uint32_t cap = COMPUTE_KV ? 256 : 512;          // persistent: 1 (109 KB) or 2 (57 KB) workgroups per CU
   if (grid > cap) grid = cap;
-  hipLaunchKernelGGL(vecattn_front_kernel<COMPUTE_KV>, dim3(grid), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((vecattn_front_kernel<COMPUTE_KV, TRAIN>), dim3(grid), dim3(512), smem, stream, a);
   return cmr_launch_status();
 }
 
@@ -171,11 +196,33 @@ extern "C" int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float
   CMR_REQUIRE((iq || divq >= 1) && (ia || diva >= 1) && cmr_aligned16(a_out) && cmr_aligned16(vp_out));
   CMR_REQUIRE(cmr_aligned16(wd0) && cmr_aligned16(wd2) && cmr_aligned16(wg0) && cmr_aligned16(wg2));
   VaArgs a{feat, ldf, w10, b10, wkv, kv, ldkv, ik, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
-           (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows};
+           (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows,
+           nullptr, 0, nullptr, nullptr, nullptr};
   if (feat) {
     CMR_REQUIRE(w10 && b10 && wkv && ldf % 4 == 0 && cmr_aligned16(feat) && cmr_aligned16(w10) && cmr_aligned16(wkv));
     return launch_va<true>(a, stream);
   }
   CMR_REQUIRE(kv && ldkv % 4 == 0 && cmr_aligned16(kv));
   return launch_va<false>(a, stream);
+}
+
+// Training forward of the same front (reference under model.train(); Train_Geo.py:166-174): k [rows][64] and v [rows][64] from their own maps
+// (k_ik / rows as above), and beside a_out / vp_out the three activations the layer-by-layer backward reads: hd = relu(fc_delta[0]),
+// t = q - k + pos, g1 = relu(fc_gamma[0]), all [rows][64].  rows must be a multiple of 32.
+extern "C" int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const float* v, int64_t ldv, const float* q, int64_t ldq,
+                                           const int32_t* iq, int64_t divq, const float* pa4, const int32_t* ia, int64_t diva, const float* pb4,
+                                           const int32_t* ib, const float* wd0, const float* bd0, const float* wd2, const float* bd2,
+                                           const float* wg0, const float* bg0, const float* wg2, const float* bg2, float* a_out,
+                                           float* vp_out, float* hd_out, float* t_out, float* g1_out, int64_t rows, hipStream_t stream) {
+  CMR_REQUIRE(k && v && q && pa4 && pb4 && ib && wd0 && bd0 && wd2 && bd2 && wg0 && bg0 && wg2 && bg2 && a_out && vp_out && hd_out && t_out && g1_out);
+  if (rows <= 0 || rows % 32 || rows >= (int64_t)0x7fffffc0) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && cmr_aligned16(q) && cmr_aligned16(k) && cmr_aligned16(v) && cmr_aligned16(pa4) &&
+              cmr_aligned16(pb4));
+  CMR_REQUIRE((iq || divq >= 1) && (ia || diva >= 1) && cmr_aligned16(a_out) && cmr_aligned16(vp_out) && cmr_aligned16(hd_out) &&
+              cmr_aligned16(t_out) && cmr_aligned16(g1_out));
+  CMR_REQUIRE(cmr_aligned16(wd0) && cmr_aligned16(wd2) && cmr_aligned16(wg0) && cmr_aligned16(wg2));
+  VaArgs a{nullptr, 0, nullptr, nullptr, nullptr, k, ldk, nullptr, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
+           (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows,
+           v, ldv, hd_out, t_out, g1_out};
+  return launch_va<false, true>(a, stream);
 }

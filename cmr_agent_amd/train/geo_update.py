@@ -130,37 +130,44 @@ class GeoUpdate:
         return t.linear_bn_chain(x, [(m.net[0].weight, m.net[0].bias, m.net[1], m.SLOPE), (m.net[3].weight, m.net[3].bias, m.net[4], m.SLOPE)], res=sc)
 
     FUSED_MIX = __import__("os").environ.get("CMR_FUSED_MIX", "1") == "1"     # q - k + pos and v + pos in one pass each way (Tape.vecattn_mix)
+    FUSED_FRONT = __import__("os").environ.get("CMR_FUSED_FRONT", "1") == "1" # the whole per-row front forward in one launch (Tape.vecattn_front)
 
-    def _vector_attention(self, t, m, q_rows, k, v, rel, nseg, order, offsets, fixed_len):
+    def _vector_attention(self, t, m, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva, nseg, order, offsets, fixed_len):
+        """qn [S, 64]: the queries per node, gathered by q_idx (the row's node) -- inside the fused forward, or by Tape.gather."""
         d, g = m.fc_delta, m.fc_gamma
-        pos = t.linear(t.linear(rel, d[0].weight, d[0].bias, act=RELU), d[2].weight, d[2].bias)
-        if self.FUSED_MIX:
-            a_in, vp = t.vecattn_mix(q_rows, k, v, pos)
+        r = t.vecattn_front(d, g, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva=diva) if self.FUSED_FRONT else None
+        if r is None:
+            q_rows = t.gather(qn, q_idx, q_csr)
+            pos = t.linear(t.linear(rel, d[0].weight, d[0].bias, act=RELU), d[2].weight, d[2].bias)
+            if self.FUSED_MIX:
+                a_in, vp = t.vecattn_mix(q_rows, k, v, pos)
+            else:
+                a_in, vp = t.add(t.add(q_rows, k, -1.0), pos), t.add(v, pos)
+            a = t.linear(t.linear(a_in, g[0].weight, g[0].bias, act=RELU), g[2].weight, g[2].bias)
         else:
-            a_in, vp = t.add(t.add(q_rows, k, -1.0), pos), t.add(v, pos)
-        a = t.linear(t.linear(a_in, g[0].weight, g[0].bias, act=RELU), g[2].weight, g[2].bias)
+            a, vp = r
         return t.segment_softmax(a, vp, nseg, 0.125, order=order, offsets=offsets, fixed_len=fixed_len)
 
     def _group_pt(self, t, m, xyz4, feat, node4, node_feat, gidx, offsets, order):
         """PointNN.py:149-185."""
         x = t.linear(feat, m.fc1_0.weight, m.fc1_0.bias)
         xx = t.linear(node_feat, m.fc1_1.weight, m.fc1_1.bias)
-        q = t.gather(t.linear(xx, m.w_qs.weight), gidx, (offsets, order))
+        qn = t.linear(xx, m.w_qs.weight)
         k, v = t.linear(x, m.w_ks.weight), t.linear(x, m.w_vs.weight)
         R, S = feat.v.shape[0], node_feat.v.shape[0]
         rel = Var(ops.rel_pos(xyz4, node4, R, ib=gidx), const=True)
-        res = self._vector_attention(t, m, q, k, v, rel, S, order, offsets, 0)
+        res = self._vector_attention(t, m, qn, gidx, (offsets, order), k, v, rel, xyz4, node4, gidx, 1, S, order, offsets, 0)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), node_feat)
 
     def _knn_pt(self, t, m, node4, feat, knn, knn_csr, rep, rep_csr):
         """PointNN.py:209-232: neighbourhoods of 16, rows ordered [node][neighbour]."""
         x = t.linear(feat, m.fc1.weight, m.fc1.bias)
-        q = t.gather(t.linear(x, m.w_qs.weight), rep, rep_csr)
+        qn = t.linear(x, m.w_qs.weight)
         k = t.gather(t.linear(x, m.w_ks.weight), knn, knn_csr)
         v = t.gather(t.linear(x, m.w_vs.weight), knn, knn_csr)
         S = feat.v.shape[0]
         rel = Var(ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn), const=True)
-        res = self._vector_attention(t, m, q, k, v, rel, S, None, None, 16)
+        res = self._vector_attention(t, m, qn, rep, rep_csr, k, v, rel, node4, node4, knn, 16, S, None, None, 16)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), feat)
 
     FUSED_LA = True         # linear-attention layers on the fused train-mode kernels (Tape.la_layer)

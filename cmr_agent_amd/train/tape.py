@@ -198,7 +198,9 @@ class Tape:
         return tmp, lambda: ops.axpy(g.view(1, -1), tmp.view(1, -1))
 
     # ------------------------------------------------------------------------------------------------------------ ops
-    def linear(self, x, weight, bias=None, const_res=None, res_mod=0, act=ops.ACT_NONE, slope=0.0):
+    NOVALUE = object()      # `_value=Tape.NOVALUE`: the op's output is not available (a fused kernel consumed it); its backward must not need it
+
+    def linear(self, x, weight, bias=None, const_res=None, res_mod=0, act=ops.ACT_NONE, slope=0.0, _value=None):
         """y = act(x W^T + b (+ constant residual rows, e.g. a position table)).  weight: nn.Parameter [n, k(, 1(, 1))]; act in
         {none, ReLU, LeakyReLU} (their backward needs only the output)."""
         if act not in (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LRELU):
@@ -207,7 +209,13 @@ class Tape:
         b = self.W(bias) if bias is not None else None
         if x.v.shape[1] != W.shape[1]:
             raise ValueError("linear: input width %d vs stored weight %s" % (x.v.shape[1], tuple(W.shape)))
-        y = Var(ops.linear(x.v, W, b, res=const_res, res_mod=res_mod, act=act, act_param=slope))
+        # _value: the output has been computed by a fused forward kernel (Tape.vecattn_front); only the backward node is recorded
+        if _value is None:
+            y = Var(ops.linear(x.v, W, b, res=const_res, res_mod=res_mod, act=act, act_param=slope))
+        else:
+            if _value is Tape.NOVALUE and act != ops.ACT_NONE:
+                raise ValueError("linear: an activation's backward reads the output")
+            y = Var(None if _value is Tape.NOVALUE else _value)
 
         def bwd():
             if y.g is None:
@@ -451,10 +459,10 @@ class Tape:
         self.nodes.append(bwd)
         return y
 
-    def vecattn_mix(self, q, k, v, pos):
+    def vecattn_mix(self, q, k, v, pos, _values=None):
         """-> (q - k + pos, v + pos): the elementwise glue of a vector-attention layer (PointNN.py:163-166) as one op with one pass each way
         instead of three additions (9 map passes forward, two gradient passes + a negation backward)."""
-        a_v, vp_v = ops.vecattn_mix(q.v, k.v, v.v, pos.v)
+        a_v, vp_v = ops.vecattn_mix(q.v, k.v, v.v, pos.v) if _values is None else _values
         a_in, vp = Var(a_v), Var(vp_v)
 
         def bwd():
@@ -476,6 +484,24 @@ class Tape:
             self.give(pos, dpos, owned=True)
         self.nodes.append(bwd)
         return a_in, vp
+
+    def vecattn_front(self, fc_delta, fc_gamma, q_src, q_idx, q_csr, k, v, rel, pa4, pb4, ib, ia=None, diva=1):
+        """The per-row front of a vector-attention layer (PointNN.py:151-170, 219-226) with the forward in ONE launch
+        (cmr_vecattn_front_train_f32: pos = fc_delta(pa - pb), a = fc_gamma(q_src[q_idx] - k + pos), vp = v + pos; the gathered q, pos and the
+        two hidden maps' pre-store copies never make a separate pass) and the backward exactly the nodes of the op-by-op tape -- the kernel
+        stores the three activations they read.  -> (a, vp) Vars, or None when the shape is not served (caller composes the ops)."""
+        d0, d2, g0, g2 = fc_delta[0], fc_delta[2], fc_gamma[0], fc_gamma[2]
+        pk = lambda lin: (self.W(lin.weight), self.W(lin.bias))
+        out = ops.vecattn_front_train(k.v, v.v, q_src.v, pa4, pb4, ib, pk(d0), pk(d2), pk(g0), pk(g2), iq=q_idx, ia=ia, diva=diva)
+        if out is False:
+            return None
+        a, vp, hd, tt, g1 = out
+        hd_v = self.linear(rel, d0.weight, d0.bias, act=ops.ACT_RELU, _value=hd)
+        pos_v = self.linear(hd_v, d2.weight, d2.bias, _value=Tape.NOVALUE)
+        q_rows = self.gather(q_src, q_idx, q_csr, _value=Tape.NOVALUE)
+        a_in, vp_v = self.vecattn_mix(q_rows, k, v, pos_v, _values=(tt, vp))
+        g1_v = self.linear(a_in, g0.weight, g0.bias, act=ops.ACT_RELU, _value=g1)
+        return self.linear(g1_v, g2.weight, g2.bias, _value=a), vp_v
 
     def add_const(self, x, table, period):
         """y[r] = x[r] + table[r % period] (position tables): constant, gradient passes through."""
@@ -507,9 +533,9 @@ class Tape:
         self.nodes.append(bwd)
         return y
 
-    def gather(self, x, idx, csr):
+    def gather(self, x, idx, csr, _value=None):
         """y[r] = x[idx[r]] (idx int32 global rows); csr = (offsets, order) of idx over x's rows for the scatter-add backward."""
-        y = Var(ops.gather_rows(x.v, idx))
+        y = Var(ops.gather_rows(x.v, idx) if _value is None else (None if _value is Tape.NOVALUE else _value))
 
         def bwd():
             if y.g is None:

@@ -317,6 +317,34 @@ def test_vector_attention_glue_in_one_pass_is_bit_identical():
     assert torch.equal(runs[0][1], runs[1][1])
 
 
+def test_vector_attention_front_in_one_launch_matches_the_layer_by_layer_forward():
+    """Tape.vecattn_front: the per-row front of every vector-attention layer (fc_delta, q - k + pos, fc_gamma, v + pos, the gather of q)
+    forward in ONE launch that also stores the three activations the unchanged layer-by-layer backward reads.  The GEMMs are chained in
+    another summation order, so: losses to 1e-5, the whole gradient vector to cosine 0.999999, every tensor within 1e-3 of the model's
+    largest gradient entry."""
+    from cmr_agent_amd.train import GeoUpdate
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batch = _to_dev(C.geo_train_batches()[0])
+    runs = []
+    old = GeoUpdate.FUSED_FRONT
+    try:
+        for fused in (True, False):
+            GeoUpdate.FUSED_FRONT = fused
+            up = GeoUpdate(_model(cfg, geo_sd), cfg, dropout=False)
+            losses = {k: float(v) for k, v in up.forward_backward(batch).items()}
+            torch.cuda.synchronize()
+            runs.append((losses, up.bucket.grads.double().clone()))
+    finally:
+        GeoUpdate.FUSED_FRONT = old
+    (l1, g1), (l0, g0) = runs
+    for k in SCALARS:
+        assert abs(l1[k] - l0[k]) <= 1e-5 * max(1.0, abs(l0[k])), (k, l1[k], l0[k])
+    cos = float((g1 * g0).sum() / (g1.norm() * g0.norm()))
+    assert cos >= 0.999999, cos
+    assert float((g1 - g0).abs().max()) <= 1e-3 * float(g0.abs().max())
+
+
 def test_geo_update_at_the_configs4_shape_vs_oracle():
     """One forward / backward of the geometric model at BASELINE configs[4]'s shape (KittiConfig training crop 160x512, 65 536 points
     per cloud, 512 circle-loss pairs; 2 pairs instead of the 8 of a step so that the host autograd stays within seconds) against
