@@ -26,13 +26,15 @@ struct VaArgs {
   // backward reads -- relu(fc_delta[0]), q - k + pos, relu(fc_gamma[0]) -- stored beside the outputs
   const float* v2; int64_t ldv2;
   float *hd_out, *t_out, *g1_out;
+  float* x_out;                                  // TRAIN + computed k/v: x = fc1_0(feat) [rows][64], what the k / v projections' backward reads
+  const float* wv2;                              // Wv [64][64] when it does not follow Wk in memory (training: two parameters), else null
 };
 
 __device__ __attribute__((aligned(16))) int32_t va_izero[4] = {0, 0, 0, 0};   // NOT const (see cmr_common.h: cmr_pin)
 
 template <bool COMPUTE_KV, bool TRAIN = false>
 __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
-  static_assert(!(COMPUTE_KV && TRAIN), "the training variant takes k and v from memory");
+
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Wd0 = smem;                          // [64][12]  (K = 3 padded to 8)
   float* Wd2 = Wd0 + 64 * VA_LD8;             // [64][68]
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
   if (COMPUTE_KV)
     for (int e = tid; e < 128 * 16; e += 512) {
       const int n = e >> 4, c = (e & 15) * 4;
-      *reinterpret_cast<f32x4*>(&Wkv[n * VA_LD + c]) = *reinterpret_cast<const f32x4*>(a.wkv + n * 64 + c);
+      const float* src = (n >= 64 && a.wv2) ? a.wv2 + (n - 64) * 64 + c : a.wkv + n * 64 + c;
+      *reinterpret_cast<f32x4*>(&Wkv[n * VA_LD + c]) = *reinterpret_cast<const f32x4*>(src);
     }
   if (tid < 64) {
     Bs[tid] = COMPUTE_KV ? a.b10[tid] : 0.f;
@@ -94,6 +97,17 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
       f32x16 x[2];
       cmr_chain_gemm<2, 8, VA_LD>(W10, l31, h, x, [&](int kg, int j) { return ff[kg][j]; });
       cmr_chain_bias<2>(x, Bs, h, false);
+      if (TRAIN) {
+        float* xp = a.x_out + (int64_t)row * 64 + 4 * h;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+          f32x4 sx;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sx[e] = x[kg / 4][4 * (kg % 4) + e];
+          cmr_pin(sx);
+          *reinterpret_cast<f32x4*>(xp + kg * 8) = sx;
+        }
+      }
       cmr_chain_gemm<2, 8, VA_LD>(Wkv, l31, h, kk, [&](int kg, int j) { return x[kg / 4][4 * (kg % 4) + j]; });
       cmr_chain_gemm<2, 8, VA_LD>(Wkv + 64 * VA_LD, l31, h, vv, [&](int kg, int j) { return x[kg / 4][4 * (kg % 4) + j]; });
     } else {
@@ -101,8 +115,8 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
 #pragma unroll
       for (int kg = 0; kg < 8; ++kg) {
         const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + kg * 8);
-        const f32x4 v4 = TRAIN ? *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)r * a.ldv2 + 4 * h + kg * 8)
-                               : *reinterpret_cast<const f32x4*>(kp + 64 + kg * 8);
+        const f32x4 v4 = (TRAIN && !COMPUTE_KV) ? *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)r * a.ldv2 + 4 * h + kg * 8)
+                                                : *reinterpret_cast<const f32x4*>(kp + 64 + kg * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kk[kg / 4][4 * (kg % 4) + e] = k4[e]; vv[kg / 4][4 * (kg % 4) + e] = v4[e]; }
       }
@@ -197,7 +211,7 @@ extern "C" int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float
   CMR_REQUIRE(cmr_aligned16(wd0) && cmr_aligned16(wd2) && cmr_aligned16(wg0) && cmr_aligned16(wg2));
   VaArgs a{feat, ldf, w10, b10, wkv, kv, ldkv, ik, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
            (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows,
-           nullptr, 0, nullptr, nullptr, nullptr};
+           nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (feat) {
     CMR_REQUIRE(w10 && b10 && wkv && ldf % 4 == 0 && cmr_aligned16(feat) && cmr_aligned16(w10) && cmr_aligned16(wkv));
     return launch_va<true>(a, stream);
@@ -223,6 +237,27 @@ extern "C" int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const fl
   CMR_REQUIRE(cmr_aligned16(wd0) && cmr_aligned16(wd2) && cmr_aligned16(wg0) && cmr_aligned16(wg2));
   VaArgs a{nullptr, 0, nullptr, nullptr, nullptr, k, ldk, nullptr, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
            (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows,
-           v, ldv, hd_out, t_out, g1_out};
+           v, ldv, hd_out, t_out, g1_out, nullptr, nullptr};
   return launch_va<false, true>(a, stream);
+}
+
+// ... with k and v computed inside as well (group transformer: x = W10 feat + b10, k = Wk x, v = Wv x; Wk, Wv [64][64]): x is
+// stored for the projections' backward, k and v never leave the registers.
+extern "C" int cmr_vecattn_front_kv_train_f32(const float* feat, int64_t ldf, const float* w10, const float* b10, const float* wk,
+                                              const float* wv, const float* q, int64_t ldq, const int32_t* iq, int64_t divq, const float* pa4,
+                                              const int32_t* ia, int64_t diva, const float* pb4, const int32_t* ib, const float* wd0,
+                                              const float* bd0, const float* wd2, const float* bd2, const float* wg0, const float* bg0,
+                                              const float* wg2, const float* bg2, float* a_out, float* vp_out, float* hd_out, float* t_out,
+                                              float* g1_out, float* x_out, int64_t rows, hipStream_t stream) {
+  CMR_REQUIRE(feat && w10 && b10 && wk && wv && q && pa4 && pb4 && ib && wd0 && bd0 && wd2 && bd2 && wg0 && bg0 && wg2 && bg2);
+  CMR_REQUIRE(a_out && vp_out && hd_out && t_out && g1_out && x_out);
+  if (rows <= 0 || rows % 32 || rows >= (int64_t)0x7fffffc0) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(ldq % 4 == 0 && ldf % 4 == 0 && cmr_aligned16(q) && cmr_aligned16(feat) && cmr_aligned16(pa4) && cmr_aligned16(pb4));
+  CMR_REQUIRE((iq || divq >= 1) && (ia || diva >= 1) && cmr_aligned16(a_out) && cmr_aligned16(vp_out) && cmr_aligned16(hd_out) &&
+              cmr_aligned16(t_out) && cmr_aligned16(g1_out) && cmr_aligned16(x_out));
+  CMR_REQUIRE(cmr_aligned16(wd0) && cmr_aligned16(wd2) && cmr_aligned16(wg0) && cmr_aligned16(wg2) && cmr_aligned16(w10) && cmr_aligned16(wk) && cmr_aligned16(wv));
+  VaArgs a{feat, ldf, w10, b10, wk, nullptr, 0, nullptr, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
+           (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows,
+           nullptr, 0, hd_out, t_out, g1_out, x_out, wv};
+  return launch_va<true, true>(a, stream);
 }

@@ -536,6 +536,19 @@ def vecattn_front_train(k, v, q, pa4, pb4, ib, d0, d2, g0, g2, iq=None, divq=1, 
     return tuple(outs)
 
 
+def vecattn_front_kv_train(feat, fc1, wk, wv, q, pa4, pb4, ib, d0, d2, g0, g2, iq=None, divq=1, ia=None, diva=1):
+    """... with x = fc1(feat), k = Wk x, v = Wv x computed inside -> (a, vp, hd, t, g1, x), or False when rows is not a multiple of 32."""
+    _rows(feat), _rows(q)
+    rows = feat.shape[0]
+    if rows % 32 or feat.shape[1] != 64 or q.shape[1] != 64 or tuple(wk.shape) != (64, 64) or tuple(wv.shape) != (64, 64) or not (wk.is_contiguous() and wv.is_contiguous()):
+        return False
+    outs = [torch.empty((rows, 64), dtype=f32, device=feat.device) for _ in range(6)]
+    _lib.call("cmr_vecattn_front_kv_train_f32", _p(feat), _ld(feat), _p(fc1[0]), _p(fc1[1]), _p(wk), _p(wv), _p(q), _ld(q), _p(_i32(iq)), int(divq),
+              _p(pa4), _p(_i32(ia)), int(diva), _p(pb4), _p(_i32(ib)), _p(d0[0]), _p(d0[1]), _p(d2[0]), _p(d2[1]), _p(g0[0]), _p(g0[1]),
+              _p(g2[0]), _p(g2[1]), *[_p(o) for o in outs], rows, _stream())
+    return tuple(outs)
+
+
 def segment_softmax(attn, vp, nseg, scale, order=None, offsets=None, fixed_len=0):
     out = torch.empty((nseg, 64), dtype=f32, device=attn.device)
     _lib.call("cmr_segment_softmax_f32", _p(attn), _p(vp), _p(_i32(order)), _p(_i32(offsets)), fixed_len, float(scale),

@@ -131,6 +131,7 @@ class GeoUpdate:
 
     FUSED_MIX = __import__("os").environ.get("CMR_FUSED_MIX", "1") == "1"     # q - k + pos and v + pos in one pass each way (Tape.vecattn_mix)
     FUSED_FRONT = __import__("os").environ.get("CMR_FUSED_FRONT", "1") == "1" # the whole per-row front forward in one launch (Tape.vecattn_front)
+    FUSED_FRONT_KV = __import__("os").environ.get("CMR_FUSED_FRONT_KV", "1") == "1"   # ... fc1_0 and the k / v projections in it too (group transformers)
 
     def _vector_attention(self, t, m, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva, nseg, order, offsets, fixed_len):
         """qn [S, 64]: the queries per node, gathered by q_idx (the row's node) -- inside the fused forward, or by Tape.gather."""
@@ -150,13 +151,20 @@ class GeoUpdate:
 
     def _group_pt(self, t, m, xyz4, feat, node4, node_feat, gidx, offsets, order):
         """PointNN.py:149-185."""
-        x = t.linear(feat, m.fc1_0.weight, m.fc1_0.bias)
         xx = t.linear(node_feat, m.fc1_1.weight, m.fc1_1.bias)
         qn = t.linear(xx, m.w_qs.weight)
-        k, v = t.linear(x, m.w_ks.weight), t.linear(x, m.w_vs.weight)
         R, S = feat.v.shape[0], node_feat.v.shape[0]
         rel = Var(ops.rel_pos(xyz4, node4, R, ib=gidx), const=True)
-        res = self._vector_attention(t, m, qn, gidx, (offsets, order), k, v, rel, xyz4, node4, gidx, 1, S, order, offsets, 0)
+        r = None
+        if self.FUSED_FRONT and self.FUSED_FRONT_KV:
+            # fc1_0 and the k / v projections inside the front's launch too: x is stored, k and v never exist as maps
+            r = t.vecattn_front_kv(m.fc1_0, m.w_ks, m.w_vs, m.fc_delta, m.fc_gamma, feat, qn, gidx, (offsets, order), rel, xyz4, node4, gidx)
+        if r is not None:
+            res = t.segment_softmax(r[0], r[1], S, 0.125, order=order, offsets=offsets, fixed_len=0)
+        else:
+            x = t.linear(feat, m.fc1_0.weight, m.fc1_0.bias)
+            k, v = t.linear(x, m.w_ks.weight), t.linear(x, m.w_vs.weight)
+            res = self._vector_attention(t, m, qn, gidx, (offsets, order), k, v, rel, xyz4, node4, gidx, 1, S, order, offsets, 0)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), node_feat)
 
     def _knn_pt(self, t, m, node4, feat, knn, knn_csr, rep, rep_csr):

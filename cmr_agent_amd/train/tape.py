@@ -485,6 +485,26 @@ class Tape:
         self.nodes.append(bwd)
         return a_in, vp
 
+    def vecattn_front_kv(self, fc1, w_ks, w_vs, fc_delta, fc_gamma, feat, q_src, q_idx, q_csr, rel, pa4, pb4, ib):
+        """Tape.vecattn_front with x = fc1(feat), k = w_ks(x), v = w_vs(x) computed inside the same launch (group transformer, PointNN.py:
+        151-158): x is stored for the projections' backward, k and v never exist as maps.  -> (a, vp) or None."""
+        d0, d2, g0, g2 = fc_delta[0], fc_delta[2], fc_gamma[0], fc_gamma[2]
+        pk = lambda lin: (self.W(lin.weight), self.W(lin.bias))
+        out = ops.vecattn_front_kv_train(feat.v, pk(fc1), self.W(w_ks.weight), self.W(w_vs.weight), q_src.v, pa4, pb4, ib, pk(d0), pk(d2), pk(g0),
+                                         pk(g2), iq=q_idx)
+        if out is False:
+            return None
+        a, vp, hd, tt, g1, xv = out
+        x = self.linear(feat, fc1.weight, fc1.bias, _value=xv)
+        k = self.linear(x, w_ks.weight, _value=Tape.NOVALUE)
+        v = self.linear(x, w_vs.weight, _value=Tape.NOVALUE)
+        hd_v = self.linear(rel, d0.weight, d0.bias, act=ops.ACT_RELU, _value=hd)
+        pos_v = self.linear(hd_v, d2.weight, d2.bias, _value=Tape.NOVALUE)
+        q_rows = self.gather(q_src, q_idx, q_csr, _value=Tape.NOVALUE)
+        a_in, vp_v = self.vecattn_mix(q_rows, k, v, pos_v, _values=(tt, vp))
+        g1_v = self.linear(a_in, g0.weight, g0.bias, act=ops.ACT_RELU, _value=g1)
+        return self.linear(g1_v, g2.weight, g2.bias, _value=a), vp_v
+
     def vecattn_front(self, fc_delta, fc_gamma, q_src, q_idx, q_csr, k, v, rel, pa4, pb4, ib, ia=None, diva=1):
         """The per-row front of a vector-attention layer (PointNN.py:151-170, 219-226) with the forward in ONE launch
         (cmr_vecattn_front_train_f32: pos = fc_delta(pa - pb), a = fc_gamma(q_src[q_idx] - k + pos), vp = v + pos; the gathered q, pos and the

@@ -159,6 +159,7 @@ WORK = {
                                         F * (a["rows"] * (a["n"] * (1 + (1 if (a["z"] and not a["mask_from_h"]) else 0) + (1 if a["stat"] else 0) + (1 if a["dzm"] else 0)) +
                                                           a["k"] * (1 + (1 if a["res"] else 0) + (1 if a["dx"] else 0))) + 2 * a["n"] * a["k"])),
     "cmr_vecattn_front_train_f32": lambda a: (2.0 * a["rows"] * (8 * 64 + 3 * 64 * 64), F * a["rows"] * (3 * 64 + 8 + 5 * 64)),
+    "cmr_vecattn_front_kv_train_f32": lambda a: (2.0 * a["rows"] * (8 * 64 + 6 * 64 * 64), F * a["rows"] * (2 * 64 + 8 + 6 * 64)),
     "cmr_vecattn_mix_f32": lambda a: (0, 6 * F * a["rows"] * a["C"]),
     "cmr_vecattn_mix_bwd_f32": lambda a: (0, 4 * F * a["rows"] * a["C"]),
     "cmr_act_bwd_f32": lambda a: (0, F * a["rows"] * a["C"] * (3 + (1 if a["add"] else 0))),

@@ -254,6 +254,14 @@ int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const float* v, int
                                 const float* wd0, const float* bd0, const float* wd2, const float* bd2, const float* wg0, const float* bg0,
                                 const float* wg2, const float* bg2, float* a_out, float* vp_out, float* hd_out, float* t_out, float* g1_out,
                                 int64_t rows, hipStream_t stream);
+/* ... and with k, v computed inside as well (group transformer: x = W10 feat + b10, k = Wk x, v = Wv x): x_out [rows][64] is stored for the
+ * projections' backward, k and v never leave the registers. */
+int cmr_vecattn_front_kv_train_f32(const float* feat, int64_t ldf, const float* w10, const float* b10, const float* wk, const float* wv,
+                                   const float* q, int64_t ldq, const int32_t* iq, int64_t divq, const float* pa4, const int32_t* ia,
+                                   int64_t diva, const float* pb4, const int32_t* ib, const float* wd0, const float* bd0, const float* wd2,
+                                   const float* bd2, const float* wg0, const float* bg0, const float* wg2, const float* bg2, float* a_out,
+                                   float* vp_out, float* hd_out, float* t_out, float* g1_out, float* x_out, int64_t rows,
+                                   hipStream_t stream);
 
 /* ---- loss / metric values of the heads (forward only) ---------------------------------------- */
 
