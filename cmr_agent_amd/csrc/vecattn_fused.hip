@@ -115,7 +115,7 @@ __global__ __launch_bounds__(512) void vecattn_front_kernel(const VaArgs a) {
 #pragma unroll
       for (int kg = 0; kg < 8; ++kg) {
         const f32x4 k4 = *reinterpret_cast<const f32x4*>(kp + kg * 8);
-        const f32x4 v4 = (TRAIN && !COMPUTE_KV) ? *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)r * a.ldv2 + 4 * h + kg * 8)
+        const f32x4 v4 = (TRAIN && !COMPUTE_KV) ? *reinterpret_cast<const f32x4*>(a.v2 + (int64_t)(a.ik ? (uint32_t)vk : r) * a.ldv2 + 4 * h + kg * 8)
                                                 : *reinterpret_cast<const f32x4*>(kp + 64 + kg * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { kk[kg / 4][4 * (kg % 4) + e] = k4[e]; vv[kg / 4][4 * (kg % 4) + e] = v4[e]; }
@@ -220,10 +220,10 @@ extern "C" int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float
   return launch_va<false>(a, stream);
 }
 
-// Training forward of the same front (reference under model.train(); Train_Geo.py:166-174): k [rows][64] and v [rows][64] from their own maps
-// (k_ik / rows as above), and beside a_out / vp_out the three activations the layer-by-layer backward reads: hd = relu(fc_delta[0]),
+// Training forward of the same front (reference under model.train(); Train_Geo.py:166-174): k and v [*][64] from their own maps, row r of
+// both = ikv ? ikv[r] : r (kNN transformer: the neighbour's row of the per-node tables), and beside a_out / vp_out the three activations the layer-by-layer backward reads: hd = relu(fc_delta[0]),
 // t = q - k + pos, g1 = relu(fc_gamma[0]), all [rows][64].  rows must be a multiple of 32.
-extern "C" int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const float* v, int64_t ldv, const float* q, int64_t ldq,
+extern "C" int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const float* v, int64_t ldv, const int32_t* ikv, const float* q, int64_t ldq,
                                            const int32_t* iq, int64_t divq, const float* pa4, const int32_t* ia, int64_t diva, const float* pb4,
                                            const int32_t* ib, const float* wd0, const float* bd0, const float* wd2, const float* bd2,
                                            const float* wg0, const float* bg0, const float* wg2, const float* bg2, float* a_out,
@@ -235,7 +235,7 @@ extern "C" int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const fl
   CMR_REQUIRE((iq || divq >= 1) && (ia || diva >= 1) && cmr_aligned16(a_out) && cmr_aligned16(vp_out) && cmr_aligned16(hd_out) &&
               cmr_aligned16(t_out) && cmr_aligned16(g1_out));
   CMR_REQUIRE(cmr_aligned16(wd0) && cmr_aligned16(wd2) && cmr_aligned16(wg0) && cmr_aligned16(wg2));
-  VaArgs a{nullptr, 0, nullptr, nullptr, nullptr, k, ldk, nullptr, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
+  VaArgs a{nullptr, 0, nullptr, nullptr, nullptr, k, ldk, ikv, q, ldq, iq, (uint32_t)(divq < 1 ? 1 : divq), pa4, ia,
            (uint32_t)(diva < 1 ? 1 : diva), pb4, ib, wd0, bd0, wd2, bd2, wg0, bg0, wg2, bg2, a_out, vp_out, (uint32_t)rows,
            v, ldv, hd_out, t_out, g1_out, nullptr, nullptr};
   return launch_va<false, true>(a, stream);

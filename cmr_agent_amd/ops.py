@@ -522,15 +522,15 @@ def vecattn_front(q, pa4, pb4, ib, d0, d2, g0, g2, rows, iq=None, divq=1, ia=Non
     return a, vp
 
 
-def vecattn_front_train(k, v, q, pa4, pb4, ib, d0, d2, g0, g2, iq=None, divq=1, ia=None, diva=1):
+def vecattn_front_train(k, v, q, pa4, pb4, ib, d0, d2, g0, g2, iq=None, divq=1, ia=None, diva=1, ikv=None):
     """Training forward of the vector-attention front in one launch -> (a, vp, hd, t, g1), all [rows, 64] (see cmr_vecattn_front_train_f32),
-    or False when rows is not a multiple of 32."""
+    or False when rows is not a multiple of 32.  ikv: k and v are per-node tables, row ikv[r] of both is the pair's."""
     _rows(k), _rows(v), _rows(q)
-    rows = k.shape[0]
-    if rows % 32 or k.shape[1] != 64 or v.shape[1] != 64 or q.shape[1] != 64:
+    rows = ib.numel()                                       # one row per (point, node) / (node, neighbour) pair
+    if rows % 32 or k.shape[1] != 64 or v.shape[1] != 64 or q.shape[1] != 64 or (ikv is None and (k.shape[0] != rows or v.shape[0] != rows)):
         return False
     outs = [torch.empty((rows, 64), dtype=f32, device=k.device) for _ in range(5)]
-    _lib.call("cmr_vecattn_front_train_f32", _p(k), _ld(k), _p(v), _ld(v), _p(q), _ld(q), _p(_i32(iq)), int(divq), _p(pa4), _p(_i32(ia)),
+    _lib.call("cmr_vecattn_front_train_f32", _p(k), _ld(k), _p(v), _ld(v), _p(_i32(ikv)), _p(q), _ld(q), _p(_i32(iq)), int(divq), _p(pa4), _p(_i32(ia)),
               int(diva), _p(pb4), _p(_i32(ib)), _p(d0[0]), _p(d0[1]), _p(d2[0]), _p(d2[1]), _p(g0[0]), _p(g0[1]), _p(g2[0]), _p(g2[1]),
               *[_p(o) for o in outs], rows, _stream())
     return tuple(outs)

@@ -133,11 +133,14 @@ class GeoUpdate:
     FUSED_FRONT = __import__("os").environ.get("CMR_FUSED_FRONT", "1") == "1" # the whole per-row front forward in one launch (Tape.vecattn_front)
     FUSED_FRONT_KV = __import__("os").environ.get("CMR_FUSED_FRONT_KV", "1") == "1"   # ... fc1_0 and the k / v projections in it too (group transformers)
 
-    def _vector_attention(self, t, m, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva, nseg, order, offsets, fixed_len):
-        """qn [S, 64]: the queries per node, gathered by q_idx (the row's node) -- inside the fused forward, or by Tape.gather."""
+    def _vector_attention(self, t, m, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva, nseg, order, offsets, fixed_len, kv_idx=None, kv_csr=None):
+        """qn [S, 64]: the queries per node, gathered by q_idx (the row's node) -- inside the fused forward, or by Tape.gather; kv_idx: k and v
+        are per-node tables too (kNN transformer), gathered the same way."""
         d, g = m.fc_delta, m.fc_gamma
-        r = t.vecattn_front(d, g, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva=diva) if self.FUSED_FRONT else None
+        r = t.vecattn_front(d, g, qn, q_idx, q_csr, k, v, rel, pa4, pb4, ib, diva=diva, kv_idx=kv_idx, kv_csr=kv_csr) if self.FUSED_FRONT else None
         if r is None:
+            if kv_idx is not None:
+                k, v = t.gather(k, kv_idx, kv_csr), t.gather(v, kv_idx, kv_csr)
             q_rows = t.gather(qn, q_idx, q_csr)
             pos = t.linear(t.linear(rel, d[0].weight, d[0].bias, act=RELU), d[2].weight, d[2].bias)
             if self.FUSED_MIX:
@@ -171,11 +174,10 @@ class GeoUpdate:
         """PointNN.py:209-232: neighbourhoods of 16, rows ordered [node][neighbour]."""
         x = t.linear(feat, m.fc1.weight, m.fc1.bias)
         qn = t.linear(x, m.w_qs.weight)
-        k = t.gather(t.linear(x, m.w_ks.weight), knn, knn_csr)
-        v = t.gather(t.linear(x, m.w_vs.weight), knn, knn_csr)
+        k, v = t.linear(x, m.w_ks.weight), t.linear(x, m.w_vs.weight)          # per-node tables; the neighbour's rows are gathered downstream
         S = feat.v.shape[0]
         rel = Var(ops.rel_pos(node4, node4, S * 16, diva=16, ib=knn), const=True)
-        res = self._vector_attention(t, m, qn, rep, rep_csr, k, v, rel, node4, node4, knn, 16, S, None, None, 16)
+        res = self._vector_attention(t, m, qn, rep, rep_csr, k, v, rel, node4, node4, knn, 16, S, None, None, 16, kv_idx=knn, kv_csr=knn_csr)
         return t.add(t.linear(res, m.fc2.weight, m.fc2.bias), feat)
 
     FUSED_LA = True         # linear-attention layers on the fused train-mode kernels (Tape.la_layer)

@@ -505,17 +505,21 @@ class Tape:
         g1_v = self.linear(a_in, g0.weight, g0.bias, act=ops.ACT_RELU, _value=g1)
         return self.linear(g1_v, g2.weight, g2.bias, _value=a), vp_v
 
-    def vecattn_front(self, fc_delta, fc_gamma, q_src, q_idx, q_csr, k, v, rel, pa4, pb4, ib, ia=None, diva=1):
+    def vecattn_front(self, fc_delta, fc_gamma, q_src, q_idx, q_csr, k, v, rel, pa4, pb4, ib, ia=None, diva=1, kv_idx=None, kv_csr=None):
         """The per-row front of a vector-attention layer (PointNN.py:151-170, 219-226) with the forward in ONE launch
         (cmr_vecattn_front_train_f32: pos = fc_delta(pa - pb), a = fc_gamma(q_src[q_idx] - k + pos), vp = v + pos; the gathered q, pos and the
         two hidden maps' pre-store copies never make a separate pass) and the backward exactly the nodes of the op-by-op tape -- the kernel
-        stores the three activations they read.  -> (a, vp) Vars, or None when the shape is not served (caller composes the ops)."""
+        stores the three activations they read.  kv_idx: k and v are per-node tables and the pair's row of both is kv_idx[r].
+        -> (a, vp) Vars, or None when the shape is not served (caller composes the ops)."""
         d0, d2, g0, g2 = fc_delta[0], fc_delta[2], fc_gamma[0], fc_gamma[2]
         pk = lambda lin: (self.W(lin.weight), self.W(lin.bias))
-        out = ops.vecattn_front_train(k.v, v.v, q_src.v, pa4, pb4, ib, pk(d0), pk(d2), pk(g0), pk(g2), iq=q_idx, ia=ia, diva=diva)
+        out = ops.vecattn_front_train(k.v, v.v, q_src.v, pa4, pb4, ib, pk(d0), pk(d2), pk(g0), pk(g2), iq=q_idx, ia=ia, diva=diva, ikv=kv_idx)
         if out is False:
             return None
         a, vp, hd, tt, g1 = out
+        if kv_idx is not None:                                 # k, v are per-node tables gathered inside the launch (kNN transformer)
+            k = self.gather(k, kv_idx, kv_csr, _value=Tape.NOVALUE)
+            v = self.gather(v, kv_idx, kv_csr, _value=Tape.NOVALUE)
         hd_v = self.linear(rel, d0.weight, d0.bias, act=ops.ACT_RELU, _value=hd)
         pos_v = self.linear(hd_v, d2.weight, d2.bias, _value=Tape.NOVALUE)
         q_rows = self.gather(q_src, q_idx, q_csr, _value=Tape.NOVALUE)

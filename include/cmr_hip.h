@@ -245,11 +245,13 @@ int cmr_vecattn_front_f32(const float* feat, int64_t ldf, const float* w10, cons
                           const float* wd0, const float* bd0, const float* wd2, const float* bd2, const float* wg0,
                           const float* bg0, const float* wg2, const float* bg2, float* a_out, float* vp_out, int64_t rows,
                           hipStream_t stream);
-/* The same front under model.train() (Train_Geo.py:166-174): k and v [rows][64] from their own maps, q gathered as above, and beside
+/* The same front under model.train() (Train_Geo.py:166-174): k and v from their own [*][64] maps (row ikv ? ikv[r] : r of both), q gathered
+ * as above, and beside
  * a_out / vp_out the three activations a layer-by-layer backward reads, all [rows][64]: hd = relu(fc_delta[0]), t = q - k + pos,
  * g1 = relu(fc_gamma[0]).  Replaces four cmr_linear_f32 launches, the gather of q and cmr_vecattn_mix_f32 of a training step.  rows a
  * multiple of 32, else CMR_EUNSUPPORTED. */
-int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const float* v, int64_t ldv, const float* q, int64_t ldq, const int32_t* iq,
+int cmr_vecattn_front_train_f32(const float* k, int64_t ldk, const float* v, int64_t ldv, const int32_t* ikv, const float* q, int64_t ldq,
+                                const int32_t* iq,
                                 int64_t divq, const float* pa4, const int32_t* ia, int64_t diva, const float* pb4, const int32_t* ib,
                                 const float* wd0, const float* bd0, const float* wd2, const float* bd2, const float* wg0, const float* bg0,
                                 const float* wg2, const float* bg2, float* a_out, float* vp_out, float* hd_out, float* t_out, float* g1_out,
