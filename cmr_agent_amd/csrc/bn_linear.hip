@@ -54,14 +54,15 @@ __device__ __forceinline__ f32x4 blb_fma4(f32x4 a, f32x4 b, f32x4 c) {
 // ZH: the activation mask is the sign of this layer's own pre-activation h * scale + shift (the layer's output was never stored: it was
 // consumed through the next layer's prologue); XL: see BlbArgs.  Pre-activations are formed with the SAME fused multiply-add in the forward
 // prologue (bn_linear_fwd_kernel), here and in the mask, so that a value within rounding of zero takes the same branch everywhere.
-constexpr int BLB_R(int nt) { return nt == 4 ? 16 : 32; }      // rows per block
+// rows per block: 32, or 16 (RB) for 128 outputs and for small maps -- at 10 240 rows 32-row blocks leave 40 workgroups on 256 CUs
+inline int blb_rows_per_block(int64_t rows, int n) { return (n == 128 || rows <= 65536) ? 16 : 32; }
 
-template <int NT, int KT, bool BN, bool DEEP, bool ZH, bool XL>
+template <int NT, int KT, bool BN, bool DEEP, bool ZH, bool XL, int RB>
 __global__ __launch_bounds__(256) void bn_linear_bwd_kernel(const BlbArgs a) {
   static_assert(BN || !(ZH || XL), "lazy operands belong to BatchNorm layers");
   // 128 outputs: 16-row blocks -- the LDS tiles and the staging registers halve, so that three workgroups share a CU (with 32 rows: 84 KB
   // of LDS and 220 registers = ONE workgroup per CU, nothing to hide its load latency behind)
-  constexpr int N = 32 * NT, K = 32 * KT, DS = N + 36, XS = K + 36, R = BLB_R(NT), RH = R / 16;
+  constexpr int N = 32 * NT, K = 32 * KT, DS = N + 36, XS = K + 36, R = RB, RH = R / 16;
   constexpr int TPW = NT * KT / 4;               // weight-gradient tiles per wave
   constexpr int KQ = K / 64;                     // data gradient: 16-channel tiles per wave
   constexpr int NS = N / 4;                      // data gradient: contraction steps
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(64) void blb_seg_reduce_kernel(const float* __restr
 }
 
 inline int blb_groups(int64_t rows, int n, int k) {
-  const int R = BLB_R(n / 32);
+  const int R = blb_rows_per_block(rows, n);
   const int64_t nblocks = rows / R;
   const size_t smem = (size_t)2 * R * (n + k + 72) * sizeof(float);
   int per_cu = (int)((size_t)160 * 1024 / smem);
@@ -627,14 +628,24 @@ inline int blb_groups(int64_t rows, int n, int k) {
 #ifndef CMR_BLB_DEEP
 #define CMR_BLB_DEEP 0        // two blocks ahead in registers: measured slower at 64 x 64 (174 VGPRs = 2 workgroups per CU: 147 us against 135)
 #endif
+template <int NT, int KT, bool BN, bool ZH, bool XL, int RB>
+int blb_launch_r(const BlbArgs& a, int groups, hipStream_t stream) {
+  constexpr bool DEEP = CMR_BLB_DEEP != 0 && NT == 2 && KT == 2 && !XL && RB == 32;
+  const size_t smem = (size_t)2 * RB * (32 * NT + 32 * KT + 72) * sizeof(float);
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL, RB>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL, RB>), dim3(groups), dim3(256), smem, stream, a);
+  return CMR_OK;
+}
+
 template <int NT, int KT, bool BN, bool ZH, bool XL>
 int blb_launch(const BlbArgs& a, int groups, hipStream_t stream) {
-  constexpr bool DEEP = CMR_BLB_DEEP != 0 && NT == 2 && KT == 2 && !XL;
-  const size_t smem = (size_t)2 * BLB_R(NT) * (32 * NT + 32 * KT + 72) * sizeof(float);
-  static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
-  hipLaunchKernelGGL((bn_linear_bwd_kernel<NT, KT, BN, DEEP, ZH, XL>), dim3(groups), dim3(256), smem, stream, a);
-  return CMR_OK;
+  if constexpr (NT == 4) {
+    return blb_launch_r<NT, KT, BN, ZH, XL, 16>(a, groups, stream);
+  } else {
+    return blb_rows_per_block(a.rows, 32 * NT) == 16 ? blb_launch_r<NT, KT, BN, ZH, XL, 16>(a, groups, stream)
+                                                     : blb_launch_r<NT, KT, BN, ZH, XL, 32>(a, groups, stream);
+  }
 }
 
 template <int NT, int KT>
@@ -690,7 +701,7 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   if (res) CMR_REQUIRE(dx && ldres % 4 == 0 && cmr_aligned16(res) && ldres >= k);
   if (xl) CMR_REQUIRE(dx && xcoef && cmr_aligned16(xstat));
   int groups = blb_groups(rows, n, k);
-  const int R = BLB_R(n / 32);
+  const int R = blb_rows_per_block(rows, n);
   int64_t seg_blocks = rows / R;
   int seg_groups = groups;
   if (seg_db) {                                  // per-segment column sums: a whole number of workgroups per segment, >= 4 blocks each
