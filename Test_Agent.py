@@ -16,6 +16,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
 
 from bench import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
@@ -37,12 +38,18 @@ def main():
     ap.add_argument('--dataset', type=str, default='kitti', help=" 'kitti' or 'nuscenes' ")
     ap.add_argument('--pairs', type=int, default=4, help="number of synthetic (image, cloud) pairs")
     ap.add_argument('--num-pt', type=int, default=None)
+    ap.add_argument('--img', type=str, default=None, help="HxW network input size (multiples of 32), default from the config")
     ap.add_argument('--geo-ckpt', default=None)
     ap.add_argument('--agent-ckpt', default=None)
+    ap.add_argument('--data-root', default=None, help="dataset root in the reference's on-disk layout (cmr_agent_amd/dataset/loader.py): the 'test' split; "
+                    "default: the synthetic generator")
     args = ap.parse_args()
     dev = torch.device("cuda")
     Cfg = {"kitti": KittiConfiguration, "nuscenes": NuScenesConfiguration}[args.dataset]
-    config = Cfg(num_pt=args.num_pt, device=dev)
+    kw = {}
+    if args.img:
+        kw["cropped_img_H"], kw["cropped_img_W"] = (int(v) for v in args.img.lower().split("x"))
+    config = Cfg(num_pt=args.num_pt, device=dev, data_root=args.data_root, **kw)
     spec = json.load(open(os.path.join(ROOT, "tests", "golden", "specs.json")))
     geo_model, agent = MultiHeadModel(config), CMRAgent(config)
     load_checked(geo_model, torch.load(args.geo_ckpt) if args.geo_ckpt else hashfill.make_state_dict(spec["geo"], "geo4/"))
@@ -51,9 +58,14 @@ def main():
 
     rte, rre = [], []
     with torch.no_grad():
-        for i in range(args.pairs):                                  # batch_size = 1 like the reference loader (:125)
-            data = synthetic.make_batch(1, config.num_pt, config.cropped_img_H, config.cropped_img_W, config.num_node,
-                                        hip_fps(dev), hip_nearest(dev), seed=config.seed + i, n_circle=16, device=dev)
+        if args.data_root:
+            from cmr_agent_amd.dataset import FrameDataset, FrameLoader
+            import itertools
+            frames = itertools.islice(iter(FrameLoader(FrameDataset(args.data_root, config, 'test', device=dev), 1, shuffle=False)), args.pairs)
+        else:
+            frames = (synthetic.make_batch(1, config.num_pt, config.cropped_img_H, config.cropped_img_W, config.num_node,
+                                           hip_fps(dev), hip_nearest(dev), seed=config.seed + i, n_circle=16, device=dev) for i in range(args.pairs))
+        for data in frames:                                          # batch_size = 1 like the reference loader (:125)
             geo_model(data)
             pose_source, pose_target = env.init(data)
             pose_target = env.to_disentangled(pose_target, data['pc'], data=data)

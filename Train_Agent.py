@@ -23,6 +23,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
 
 if __name__ == "__main__":
     # `--gpus N` without a launcher: start the N ranks as a child (python -m torch.distributed.run ...) before anything touches the GPU
@@ -110,6 +111,61 @@ def validate(geo_model, agent, config, val_batches):
     return float(np.mean(err_r)), float(np.mean(err_t))
 
 
+class ModuleApiAgentUpdate:
+    """Train_Agent.py:111-124, 263-305 as the reference writes them, on this build's CMRAgent: the train-mode forward and backward run on the
+    HIP kernels behind ONE autograd node (cmr_agent_amd/train/bridge.py), the loss is composed in torch, torch.optim owns the step."""
+
+    def __init__(self, agent, config, dist):
+        self.agent, self.cfg, self.dist = agent, config, dist
+        if config.optimizer == 'SGD':
+            self.optimizer = torch.optim.SGD(agent.parameters(), lr=config.lr, momentum=config.momentum, weight_decay=config.weight_decay)
+        elif config.optimizer == 'ADAM':
+            self.optimizer = torch.optim.Adam(agent.parameters(), lr=config.lr, betas=(0.9, 0.99), weight_decay=config.weight_decay)
+        else:
+            raise NotImplementedError("optimizer %r" % config.optimizer)
+        agent.train()
+        self.bucket = agent.hip_engine().bucket
+        agent.eval()
+
+    lr = property(lambda self: self.optimizer.param_groups[0]['lr'])
+
+    def set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr
+
+    def allreduce_ms(self):
+        return 0.0
+
+    def step(self, b):
+        import torch.nn.functional as F
+        cfg, agent = self.cfg, self.agent
+        with torch.enable_grad():
+            r_logits, t_logits, value = agent(b["states_2d"], b["states_3d"])                                             # Train_Agent.py:268
+            new_logprob, new_entropy = agent.action_logprob_and_entropy(r_logits, t_logits, b["action_r"], b["action_t"])   # :269
+            S = r_logits.shape[2]
+            clone_loss = (F.cross_entropy(r_logits.reshape(-1, S), b["expert_actions_r"].reshape(-1))                      # :272-278
+                          + F.cross_entropy(t_logits.reshape(-1, S), b["expert_actions_t"].reshape(-1)))
+            zero = torch.zeros((), device=clone_loss.device)
+            policy_loss = value_loss = entropy_loss = ppo_loss = zero
+            loss = clone_loss
+            if cfg.alpha > 0:
+                ratio = torch.exp(new_logprob - b["action_logprob"].reshape(new_logprob.shape))                             # :284
+                adv = b["advantages"].reshape(-1, 1)
+                policy_loss = -torch.min(ratio * adv, ratio.clamp(1 - cfg.CLIP_EPS, 1 + cfg.CLIP_EPS) * adv).mean()          # :286
+                value_loss = (value.view(-1, 1) - b["state_value_ref"].reshape(-1, 1)).pow(2).mean()                        # :289-290
+                entropy_loss = new_entropy.mean()                                                                          # :293
+                ppo_loss = policy_loss + value_loss * cfg.W_VALUE - entropy_loss * cfg.W_ENTROPY                            # :300
+                loss = clone_loss + ppo_loss * cfg.alpha
+            self.optimizer.zero_grad()                                                                                     # :303
+            loss.backward()                                                                                                # :304
+        if self.dist is not None and self.dist.is_initialized():
+            world = self.bucket.all_reduce(self.dist)
+            if world > 1:
+                self.bucket.grads.div_(world)
+        self.optimizer.step()                                                                                              # :305
+        return torch.stack([x.detach().reshape(()) for x in (loss, clone_loss, policy_loss, value_loss, entropy_loss, ppo_loss, zero, zero)])
+
+
 def main():
     ap = argparse.ArgumentParser(description='Image to point Registration (MI355X HIP path)')
     ap.add_argument('--dataset', type=str, default='kitti', help=" 'kitti' or 'nuscenes' ")
@@ -121,6 +177,9 @@ def main():
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--geo-ckpt', default=None)
     ap.add_argument('--out', default=None, help="directory for agent checkpoints (default: config.ckpt_dir)")
+    ap.add_argument('--data-root', default=None, help="dataset root in the reference's on-disk layout (cmr_agent_amd/dataset/loader.py); default: the synthetic generator")
+    ap.add_argument('--module-api', action='store_true', help="update through the nn.Module boundary as the reference's minibatch body is written (agent(...); "
+                    "loss composed in torch; loss.backward(); torch.optim step -- cmr_agent_amd/train/bridge.py) instead of the fused AgentUpdate.step")
     ap.add_argument('--optimizer', choices=("ADAM", "SGD"), default=None, help="overrides config.optimizer")
     ap.add_argument('--lr-scheduler', choices=("StepLR", "ExponentialLR", "CosineAnnealingLR"), default=None, help="overrides config.lr_scheduler")
     ap.add_argument('--gpus', type=int, default=1, help="data-parallel ranks, one per GPU (started here when no launcher did)")
@@ -139,7 +198,7 @@ def main():
     kw = {}
     if args.img:
         kw["cropped_img_H"], kw["cropped_img_W"] = (int(v) for v in args.img.lower().split("x"))
-    config = Cfg(num_pt=args.num_pt, device=dev, **kw)
+    config = Cfg(num_pt=args.num_pt, device=dev, data_root=args.data_root, **kw)
     B = args.batch_size or config.train_batch_size
     if args.optimizer:
         config.optimizer = args.optimizer
@@ -160,7 +219,10 @@ def main():
     elif ranks.rank == 0:
         print("New Training!")
     agent = agent.to(dev)
-    update = AgentUpdate(agent, config, dist=ranks.dist)            # lr / betas (0.9, 0.99) / weight decay as Train_Agent.py:121-127
+    if args.module_api:
+        update = ModuleApiAgentUpdate(agent, config, ranks.dist)    # the reference's minibatch body on the autograd bridge
+    else:
+        update = AgentUpdate(agent, config, dist=ranks.dist)        # lr / betas (0.9, 0.99) / weight decay as Train_Agent.py:121-127
     if ranks.dist is not None:
         ranks.dist.broadcast(update.bucket.params, src=0)
         n = ranks.collective_ranks()                                 # a real all-reduce on device memory over every rank
@@ -170,12 +232,24 @@ def main():
     sample_gen = torch.Generator().manual_seed(config.seed + 17 * ranks.rank)
     torch.manual_seed(config.seed + 1000 * (ranks.rank + 1))         # action sampling differs per rank from here on
 
-    def loader(n, base_seed):
-        for i in range(n):
-            yield synthetic.make_batch(B, config.num_pt, config.cropped_img_H, config.cropped_img_W, config.num_node, hip_fps(dev),
-                                       hip_nearest(dev), seed=base_seed + i, n_circle=16, device=dev)
+    if args.data_root:
+        # the reference's files (KittiDataset.py:258-264): read on the host, every per-point step on the device
+        from cmr_agent_amd.dataset import FrameDataset, FrameLoader
+        train_set, val_set = FrameDataset(args.data_root, config, 'train', device=dev), FrameDataset(args.data_root, config, 'val', device=dev)
 
-    val_batches = list(loader(args.val_batches, 10 ** 6))
+        def loader(n, base_seed, val=False):
+            import itertools
+            import random as _random
+            _random.seed(base_seed)
+            np.random.seed(base_seed % (2 ** 32))
+            return itertools.islice(iter(FrameLoader(val_set if val else train_set, B, shuffle=not val, drop_last=True)), n)
+    else:
+        def loader(n, base_seed, val=False):
+            for i in range(n):
+                yield synthetic.make_batch(B, config.num_pt, config.cropped_img_H, config.cropped_img_W, config.num_node, hip_fps(dev),
+                                           hip_nearest(dev), seed=base_seed + i, n_circle=16, device=dev)
+
+    val_batches = list(loader(args.val_batches, 10 ** 6, val=True))
     out_dir = args.out or os.path.join(config.ckpt_dir, args.dataset + "_IL_" + time.strftime('%m-%d-%H-%M', time.localtime()))
     buffer = Buffer(config)
     buffer.start_trajectory()

@@ -21,6 +21,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
 
 if __name__ == "__main__":
     # `--gpus N` without a launcher: start the N ranks as a child (python -m torch.distributed.run ...) before anything touches the GPU
@@ -34,6 +35,7 @@ from bench import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
 from cmr_agent_amd.models import MultiHeadModel  # noqa: E402
 from cmr_agent_amd.train import GeoUpdate  # noqa: E402
+from cmr_agent_amd.train.geo_update import LOSS_KEYS  # noqa: E402
 from cmr_agent_amd.utils import synthetic  # noqa: E402
 from cmr_agent_amd.utils.checkpoint import load_checked  # noqa: E402
 from cmr_agent_amd.train.optim import LRSchedule  # noqa: E402
@@ -60,6 +62,43 @@ def validate(model, val_batches):
     return {name: float(torch.cat(acc[k]).mean()) for name, k in VAL_SCALARS}
 
 
+class ModuleApiUpdate:
+    """Train_Geo.py:65-78, 166-174 as the reference writes them, on this build's module: torch.optim owns the parameters, the model's
+    train-mode forward and `data['loss'].backward()` run on the HIP tape (cmr_agent_amd/train/bridge.py).  Data parallel: the flat
+    gradient bucket behind the Parameters' .grad views is all-reduced (ONE collective) between backward() and the clipping."""
+
+    def __init__(self, model, config, dist):
+        self.model, self.dist = model, dist
+        if config.optimizer == 'SGD':
+            self.optimizer = torch.optim.SGD(model.parameters(), lr=config.lr, momentum=config.momentum, weight_decay=config.weight_decay)
+        elif config.optimizer == 'ADAM':
+            self.optimizer = torch.optim.Adam(model.parameters(), lr=config.lr, betas=(0.9, 0.99), weight_decay=config.weight_decay)
+        else:
+            raise NotImplementedError("optimizer %r" % config.optimizer)
+        model.train()
+        self.bucket = model.hip_engine().bucket
+        self._graph = None
+
+    lr = property(lambda self: self.optimizer.param_groups[0]['lr'])
+
+    def set_lr(self, lr):
+        for g in self.optimizer.param_groups:
+            g['lr'] = lr
+
+    def step(self, data):
+        data = dict(data)
+        self.optimizer.zero_grad()                                   # Train_Geo.py:166
+        self.model(data)                                             # :168
+        data['loss'].backward()                                      # :171
+        if self.dist is not None and self.dist.is_initialized():
+            world = self.bucket.all_reduce(self.dist)
+            if world > 1:
+                self.bucket.grads.div_(world)
+        torch.nn.utils.clip_grad_value_(self.model.parameters(), 1)  # :172
+        self.optimizer.step()                                        # :174
+        return {k: data[k] for k in LOSS_KEYS}
+
+
 def main():
     ap = argparse.ArgumentParser(description='Image to point Registration (MI355X HIP path)')
     ap.add_argument('--dataset', type=str, default='kitti', help=" 'kitti' or 'nuscenes' ")
@@ -71,6 +110,9 @@ def main():
     ap.add_argument('--img', type=str, default=None, help="HxW network input size (multiples of 32), default from the config")
     ap.add_argument('--batch-size', type=int, default=None)
     ap.add_argument('--out', default=None, help="directory for checkpoints (default: config.ckpt_dir)")
+    ap.add_argument('--data-root', default=None, help="dataset root in the reference's on-disk layout (cmr_agent_amd/dataset/loader.py); default: the synthetic generator")
+    ap.add_argument('--module-api', action='store_true', help="train through the nn.Module boundary as the reference's loop is written (model(data); "
+                    "data['loss'].backward(); clip_grad_value_; torch.optim step -- cmr_agent_amd/train/bridge.py) instead of the fused GeoUpdate.step")
     ap.add_argument('--no-graph', action='store_true', help="launch every kernel of the step from Python instead of replaying a hipGraph")
     ap.add_argument('--optimizer', choices=("ADAM", "SGD"), default=None, help="overrides config.optimizer")
     ap.add_argument('--lr-scheduler', choices=("StepLR", "ExponentialLR", "CosineAnnealingLR"), default=None, help="overrides config.lr_scheduler")
@@ -90,7 +132,7 @@ def main():
     kw = {}
     if args.img:
         kw["cropped_img_H"], kw["cropped_img_W"] = (int(v) for v in args.img.lower().split("x"))
-    config = Cfg(num_pt=args.num_pt, device=dev, **kw)
+    config = Cfg(num_pt=args.num_pt, device=dev, data_root=args.data_root, **kw)
     B = args.batch_size or config.train_batch_size
     if args.optimizer:
         config.optimizer = args.optimizer
@@ -107,19 +149,34 @@ def main():
     elif ranks.rank == 0:
         print("New Training!")
     model = model.to(dev)
-    update = GeoUpdate(model, config, dist=ranks.dist)              # lr / betas (0.9, 0.99) / weight decay as Train_Geo.py:72-78
+    if args.module_api:
+        update = ModuleApiUpdate(model, config, ranks.dist)         # the reference's loop lines on the autograd bridge
+    else:
+        update = GeoUpdate(model, config, dist=ranks.dist)          # lr / betas (0.9, 0.99) / weight decay as Train_Geo.py:72-78
     if ranks.dist is not None:
         ranks.dist.broadcast(update.bucket.params, src=0)
         n = ranks.collective_ranks()                                 # a real all-reduce on device memory over every rank
         if ranks.rank == 0:
             print(json.dumps({"ranks": n, "dist_backend": args.dist_backend, "gradient_bucket_floats": update.bucket.numel}))
 
-    def loader(n, base_seed, bs):
-        for i in range(n):
-            yield synthetic.make_batch(bs, config.num_pt, config.cropped_img_H, config.cropped_img_W, config.num_node, hip_fps(dev),
-                                       hip_nearest(dev), seed=base_seed + i, n_circle=512, device=dev)
+    if args.data_root:
+        # the reference's files (KittiDataset.py:258-264): read on the host, every per-point step on the device
+        from cmr_agent_amd.dataset import FrameDataset, FrameLoader
+        train_set, val_set = FrameDataset(args.data_root, config, 'train', device=dev), FrameDataset(args.data_root, config, 'val', device=dev)
 
-    val_batches = list(loader(args.val_batches, 10 ** 6, config.val_batch_size if args.batch_size is None else B))
+        def loader(n, base_seed, bs, val=False):
+            import itertools
+            import random as _random
+            _random.seed(base_seed)
+            np.random.seed(base_seed % (2 ** 32))
+            return itertools.islice(iter(FrameLoader(val_set if val else train_set, bs, shuffle=not val, drop_last=True)), n)
+    else:
+        def loader(n, base_seed, bs, val=False):
+            for i in range(n):
+                yield synthetic.make_batch(bs, config.num_pt, config.cropped_img_H, config.cropped_img_W, config.num_node, hip_fps(dev),
+                                           hip_nearest(dev), seed=base_seed + i, n_circle=512, device=dev)
+
+    val_batches = list(loader(args.val_batches, 10 ** 6, config.val_batch_size if args.batch_size is None else B, val=True))
     out_dir = args.out or os.path.join(config.ckpt_dir, args.dataset + "_" + str(config.num_pt) + "_" + time.strftime('%m-%d-%H-%M', time.localtime()))
     global_step, pre_fine_loss = 0, 1e7
     model.train()
@@ -138,7 +195,7 @@ def main():
                     os.makedirs(out_dir, exist_ok=True)
                     torch.save({k: v.detach().clone() for k, v in model.state_dict().items()},
                                os.path.join(out_dir, "epoch-%d-loss-%f.pth" % (epoch, x)))
-            if not args.no_graph and update._graph is None:
+            if not args.no_graph and not args.module_api and update._graph is None:
                 update.enable_graph(data)                                                        # forward + backward of this batch shape, captured once
             t0 = time.perf_counter()
             losses = update.step(data)

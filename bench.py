@@ -24,6 +24,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
 
 if __name__ == "__main__":
     # --gpus N without a launcher: this process only starts `python -m torch.distributed.run ... bench.py <same flags>` as a
@@ -155,7 +156,7 @@ def dist_info(ranks, args):
         d["rccl_version"] = ranks.rccl_version()
         if ranks.forced:
             d["rccl_note"] = ("world size 1 with a real process group (Ranks.force_init): librccl loaded, communicator created with "
-                              "device_id on this GPU, every collective of the path executed as a sum over one rank")
+                              "device_id on this GPU, every collective of the path executed as a sum over one rank; HSA_ENABLE_IPC_MODE_LEGACY=%s set before HSA init" % os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
     if args.share_gpu and ranks.world > 1:
         d["share_gpu"] = "all %d ranks on device 0 (protocol rehearsal, not a scaling measurement)" % ranks.world
     return d

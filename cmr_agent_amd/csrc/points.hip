@@ -227,6 +227,67 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz4
   }
 }
 
+// ---- general kNN: queries != candidates, K <= 64 (pointnet_util.py:114-116, 232-234: square_distance + argsort()[:, :, :K]) ------------
+// The same scheme as knn_kernel with the candidates streamed through LDS in tiles (clouds of 65 536 points do not fit): a query is handled
+// by KNN_SPLIT adjacent lanes, lane `sub` scans the candidates sub, sub + 8, ... of every tile (ascending index across tiles) into its own
+// sorted top-KT, then the 8 lists are merged by K rounds of "lexicographic (distance, index) minimum of the heads" = a stable argsort's
+// first K.  A candidate count below K pads with the index 0x7fffffff -> reported as -1 (the reference would raise on such a slice).
+constexpr int KNN_TILE = 2048;
+template <int KT>
+__global__ __launch_bounds__(256) void knn_general_kernel(const float* __restrict__ q4, const float* __restrict__ c4, int64_t* __restrict__ out,
+                                                           int S, int N, int K) {
+  __shared__ __attribute__((aligned(16))) float tile[KNN_TILE * 4];
+  const int b = blockIdx.y;
+  const int sub = threadIdx.x & (KNN_SPLIT - 1);
+  const int q0 = blockIdx.x * (256 / KNN_SPLIT) + threadIdx.x / KNN_SPLIT;
+  const int qi = q0 < S ? q0 : S - 1;
+  const f32x4 qp = *reinterpret_cast<const f32x4*>(q4 + ((int64_t)b * S + qi) * 4);
+  float bd[KT];
+  int bi[KT];
+#pragma unroll
+  for (int j = 0; j < KT; ++j) { bd[j] = INFINITY; bi[j] = 0x7fffffff; }
+  for (int c0 = 0; c0 < N; c0 += KNN_TILE) {
+    const int n = min(KNN_TILE, N - c0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+      *reinterpret_cast<f32x4*>(&tile[i * 4]) = *reinterpret_cast<const f32x4*>(c4 + ((int64_t)b * N + c0 + i) * 4);
+    __syncthreads();
+    for (int c = sub; c < n; c += KNN_SPLIT) {
+      const f32x4 cp = *reinterpret_cast<const f32x4*>(&tile[c * 4]);
+      float d = sqdist3(qp[0], qp[1], qp[2], cp[0], cp[1], cp[2]);
+      if (d < bd[KT - 1]) {     // strict: on ties the smaller index (seen first) stays ahead
+        int id = c0 + c;
+#pragma unroll
+        for (int j = 0; j < KT; ++j) {
+          const bool sw = d < bd[j];
+          const float td = sw ? bd[j] : d; const int ti = sw ? bi[j] : id;
+          bd[j] = sw ? d : bd[j]; bi[j] = sw ? id : bi[j];
+          d = td; id = ti;
+        }
+      }
+    }
+  }
+  int64_t* o = out + ((int64_t)b * S + qi) * K;
+  for (int r = 0; r < K; ++r) {
+    float dm = bd[0];
+    int im = bi[0];
+#pragma unroll
+    for (int x = 1; x < KNN_SPLIT; x <<= 1) {
+      const float od = __shfl_xor(dm, x);
+      const int oi = __shfl_xor(im, x);
+      const bool take = od < dm || (od == dm && oi < im);
+      dm = take ? od : dm;
+      im = take ? oi : im;
+    }
+    if (bi[0] == im && im != 0x7fffffff) {          // this lane's head won: pop it
+#pragma unroll
+      for (int j = 0; j + 1 < KT; ++j) { bd[j] = bd[j + 1]; bi[j] = bi[j + 1]; }
+      bd[KT - 1] = INFINITY; bi[KT - 1] = 0x7fffffff;
+    }
+    if (sub == (r & (KNN_SPLIT - 1)) && q0 < S) o[r] = im == 0x7fffffff ? (int64_t)-1 : (int64_t)im;
+  }
+}
+
 // nearest candidate row for every query row (first index on ties); candidates tiled through LDS
 __global__ __launch_bounds__(256) void nearest_kernel(const float* __restrict__ q4, const float* __restrict__ c4,
                                                       int32_t* __restrict__ out_global, int64_t* __restrict__ out_local,
@@ -307,6 +368,23 @@ __global__ __launch_bounds__(256) void weighted_gather3_kernel(const float* __re
   const float a1 = src[(int64_t)idx[r * 3 + 1] * lds + c] * wgt[r * 3 + 1];
   const float a2 = src[(int64_t)idx[r * 3 + 2] * lds + c] * wgt[r * 3 + 2];
   out[r * ldo + c] = (a0 + a1) + a2;
+}
+
+// backward of weighted_gather3 w.r.t. src: dsrc[t, c] = sum over the entries e = 3 r + j with idx[e] == t of w[e] * dy[r, c], entries taken
+// in ascending e through the CSR (offsets, order) of idx over the target rows: no atomics, the same sum on every run
+__global__ __launch_bounds__(256) void weighted_scatter3_kernel(const float* __restrict__ dy, int64_t ldd, const float* __restrict__ wgt,
+                                                                const int32_t* __restrict__ order, const int32_t* __restrict__ offsets,
+                                                                float* __restrict__ out, int64_t ldo, int64_t nseg, int C) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t t = e / C;
+  if (t >= nseg) return;
+  const int c = (int)(e % C);
+  float acc = 0.f;
+  for (int j = offsets[t]; j < offsets[t + 1]; ++j) {
+    const int en = order[j];
+    acc += wgt[en] * dy[(int64_t)(en / 3) * ldd + c];
+  }
+  out[t * ldo + c] = acc;
 }
 
 // ---- row gathers ------------------------------------------------------------------------------
@@ -837,6 +915,17 @@ extern "C" int cmr_knn16_f32(const float* xyz4, int32_t* out, int B, int M, hipS
   return cmr_launch_status();
 }
 
+extern "C" int cmr_knn_f32(const float* q4, const float* c4, int64_t* out, int B, int S, int N, int K, hipStream_t stream) {
+  CMR_REQUIRE(q4 && c4 && out && B > 0 && B <= 65535 && S > 0 && N > 0 && K >= 1 && K <= 64 && cmr_aligned16(q4) && cmr_aligned16(c4));
+  constexpr int QPW = 256 / KNN_SPLIT;
+  const dim3 grid((S + QPW - 1) / QPW, B), block(256);
+  if (K <= 8) hipLaunchKernelGGL(knn_general_kernel<8>, grid, block, 0, stream, q4, c4, out, S, N, K);
+  else if (K <= 16) hipLaunchKernelGGL(knn_general_kernel<16>, grid, block, 0, stream, q4, c4, out, S, N, K);
+  else if (K <= 32) hipLaunchKernelGGL(knn_general_kernel<32>, grid, block, 0, stream, q4, c4, out, S, N, K);
+  else hipLaunchKernelGGL(knn_general_kernel<64>, grid, block, 0, stream, q4, c4, out, S, N, K);
+  return cmr_launch_status();
+}
+
 extern "C" int cmr_nearest_f32(const float* q4, const float* c4, int32_t* out_global, int64_t* out_local, int B, int Nq,
                                int Nc, hipStream_t stream) {
   CMR_REQUIRE(q4 && c4 && (out_global || out_local) && B > 0 && B <= 65535 && Nq > 0 && Nc > 0);
@@ -856,6 +945,13 @@ extern "C" int cmr_weighted_gather3_f32(const float* src, int64_t lds, const int
                                         int64_t ldo, int64_t rows, int C, hipStream_t stream) {
   CMR_REQUIRE(src && idx && wgt && out && rows > 0 && C > 0);
   hipLaunchKernelGGL(weighted_gather3_kernel, GRID1D(rows * C), dim3(256), 0, stream, src, lds, idx, wgt, out, ldo, rows, C);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_weighted_scatter3_f32(const float* dy, int64_t ldd, const float* wgt, const int32_t* order, const int32_t* offsets, float* out,
+                                         int64_t ldo, int64_t nseg, int C, hipStream_t stream) {
+  CMR_REQUIRE(dy && wgt && order && offsets && out && nseg > 0 && C > 0);
+  hipLaunchKernelGGL(weighted_scatter3_kernel, GRID1D(nseg * C), dim3(256), 0, stream, dy, ldd, wgt, order, offsets, out, ldo, nseg, C);
   return cmr_launch_status();
 }
 

@@ -42,7 +42,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_partial_kernel(const flo
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   const f32x4 pivot = ld4(x + 4 * cq);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
-  int64_t r = r0 + rg;
+  const bool on = rg < RG;                                 // widths whose quad count does not divide 256 (24, 48, ...): the tail threads idle
+  int64_t r = on ? r0 + rg : r1;
   for (; r + 7 * RG < r1; r += 8 * RG) {                 // eight independent row loads in flight per thread, summed in row order
     f32x4 v[8];
 #pragma unroll
@@ -59,8 +60,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_stats_partial_kernel(const flo
     s += v;
     ss += v * v;
   }
-  st4(&sm[(rg * 2 + 0) * C + 4 * cq], s);
-  st4(&sm[(rg * 2 + 1) * C + 4 * cq], ss);
+  if (on) {
+    st4(&sm[(rg * 2 + 0) * C + 4 * cq], s);
+    st4(&sm[(rg * 2 + 1) * C + 4 * cq], ss);
+  }
   __syncthreads();
   for (int i = tid; i < 2 * C; i += RED_THREADS) {
     float a = 0.f;
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   const f32x4 mean = ld4(stat + 4 * cq), rstd = ld4(stat + C + 4 * cq);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
-  int64_t r = r0 + rg;
+  const bool on = rg < RG;
+  int64_t r = on ? r0 + rg : r1;
   for (; r + 3 * RG < r1; r += 4 * RG) {                 // four rows (12 loads) in flight per thread, summed in row order
     f32x4 dv[4], av[4], xv[4];
 #pragma unroll
@@ -213,8 +217,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float
     s += d;
     sx += d * xh;
   }
-  st4(&sm[(rg * 2 + 0) * C + 4 * cq], s);
-  st4(&sm[(rg * 2 + 1) * C + 4 * cq], sx);
+  if (on) {
+    st4(&sm[(rg * 2 + 0) * C + 4 * cq], s);
+    st4(&sm[(rg * 2 + 1) * C + 4 * cq], sx);
+  }
   __syncthreads();
   for (int i = tid; i < 2 * C; i += RED_THREADS) {
     float a = 0.f;
@@ -325,7 +331,8 @@ __global__ __launch_bounds__(RED_THREADS) void col_partial_kernel(const float* _
   int idx[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] = MAXARG ? -INFINITY : 0.f;
-  for (int n = n0 + rg; n < n1; n += RG) {
+  const bool on = rg < RG;
+  for (int n = on ? n0 + rg : n1; n < n1; n += RG) {
     const f32x4 v = ld4(x + ((int64_t)b * N + n) * ldx + 4 * cq);
     if (MAXARG) {
 #pragma unroll
@@ -335,10 +342,12 @@ __global__ __launch_bounds__(RED_THREADS) void col_partial_kernel(const float* _
       acc += v;
     }
   }
+  if (on) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    sv[rg * C + 4 * cq + e] = acc[e];
-    if (MAXARG) si[rg * C + 4 * cq + e] = idx[e];
+    for (int e = 0; e < 4; ++e) {
+      sv[rg * C + 4 * cq + e] = acc[e];
+      if (MAXARG) si[rg * C + 4 * cq + e] = idx[e];
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += RED_THREADS) {
@@ -646,7 +655,7 @@ inline unsigned ew_grid(int64_t items) {
   return (unsigned)g;
 }
 
-inline bool chan_ok(int C) { return C == 4 || C == 8 || C == 16 || C == 32 || C == 64 || C == 128 || C == 256 || C == 512 || C == 1024; }
+inline bool chan_ok(int C) { return C >= 4 && C <= 1024 && C % 4 == 0; }
 
 }  // namespace
 

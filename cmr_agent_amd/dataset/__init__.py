@@ -1,2 +1,3 @@
 """Dataset-side pre-processing on the device."""
 from .frame import preprocess_frame, random_transform  # noqa: F401
+from .loader import FrameDataset, FrameLoader, read_calib  # noqa: F401,E402

@@ -52,7 +52,8 @@ def preprocess_frame(raw, P_Tr, K, P_random, img_hw4, choice=None, perm=None, no
                      n_circle=512):
     """raw: device float32 [>=3, n] velodyne cloud; P_Tr (4x4 or 3x4), K (3x3, already at 1/4 scale of the crop), P_random
     (4x4): host arrays; img_hw4 = (h, w) of the 1/4-scale map; choice: device int64 [N] down-sampling indices or None;
-    perm: device int64 [>= n_circle] permutation of the in-picture points or None (no circle-loss samples);
+    perm: device int64 [>= n_circle] permutation of the in-picture points, a callable count -> such a tensor (the loader: the count is only
+    known after the projection), or None (no circle-loss samples);
     node_candidates: device int64 [8 * num_node] indices into the sampled cloud (KittiDataset.py:356) or None (no nodes).
     Returns the reference's dict entries (device tensors): pc, pc_in_cam_space, pc_mask, img_mask, K, P, (+ circle-loss
     samples, node, pt2node)."""
@@ -77,6 +78,11 @@ def preprocess_frame(raw, P_Tr, K, P_random, img_hw4, choice=None, perm=None, no
     out = dict(pc=pc_out, pc_in_cam_space=pc_cam, pc_mask=pc_mask, img_mask=img_mask,
                K=torch.from_numpy(np.asarray(K, dtype=np.float32)).to(dev),
                P=torch.from_numpy(np.linalg.inv(np.asarray(P_random, dtype=np.float32)).astype(np.float32)).to(dev))
+    if callable(perm):
+        # the permutation is drawn over the in-picture points (KittiDataset.py:339-340): their count is a device result -> one round trip
+        cnt = int(pc_mask.sum().item())
+        n_circle = min(n_circle, cnt)
+        perm = perm(cnt) if n_circle > 0 else None
     if perm is not None:
         if perm.dtype != torch.int64 or perm.numel() < n_circle:
             raise ValueError("perm must hold at least n_circle int64 entries")

@@ -191,7 +191,30 @@ class CMRAgent(Planned):
             s3 = torch.as_strided(state_3d, (B * N, 8), (8, 1))            # view of the env's [B*N,8] rows
         else:
             s3 = ops.planar_to_rows(state_3d.contiguous(), 8)
+        if self.training:
+            return self._forward_train(s2, s3, B, N, split)
         return self.forward_cl(s2, s3, B, N, split)
+
+    # ---- train mode (Train_Agent.py:256-305): the network is ONE autograd node over the HIP kernels (train/bridge.py); the caller composes
+    # the loss from the returned logits / value in torch and steps a torch optimizer
+    def hip_engine(self):
+        br = getattr(self, "_hip_bridge", None)
+        if br is not None:
+            try:
+                br.bucket.check_attached()
+            except RuntimeError:                                 # the module was moved (.to / .cuda) since: rebuild on the new storage
+                br = self._hip_bridge = None
+        if br is None:
+            from ..train.bridge import AgentBridge
+            self._hip_bridge = None
+            br = AgentBridge(self, self.config)
+            self._hip_bridge = br
+        return br
+
+    def _forward_train(self, s2, s3, B, N, split):
+        if s2 is None:                                       # shape-only state_2d: its two halves, concatenated once (training keeps the input)
+            s2 = torch.cat([split[0], split[1]], dim=3)
+        return self.hip_engine().forward(self, s2, s3, B, N)
 
     @staticmethod
     def action_from_logits(r_logits, t_logits, deterministic=False):

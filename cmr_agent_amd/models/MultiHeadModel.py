@@ -6,8 +6,9 @@ state_dict / batch-dict mirror of the reference's models/MultiHeadModel.py (Over
 have the reference's shapes; feature maps are views of channels-last storage.  The row-layout
 buffers the agent loop consumes are kept under data_batch['_cmr'].
 
-Losses (focal / circle, MultiHeadModel.py:49-50,141-178) are training-side; in this inference
-build `loss` entries are only produced by cmr_agent_amd.models.losses when asked for."""
+In `train()` mode `forward` runs the train-mode network (batch-statistics BatchNorm, dropout) on the HIP tape as ONE
+autograd node and composes the focal / circle losses (MultiHeadModel.py:49-50,141-178) over it, so that the reference's
+`model(data); data['loss'].backward(); optimizer.step()` trains this module as it stands (cmr_agent_amd/train/bridge.py)."""
 import torch
 import torch.nn as nn
 
@@ -154,7 +155,37 @@ class MultiHeadModel(Planned):
         out["loss"] = (pc[0] + im[0]) + geo[0]                 # data['loss'] = 0. += overlap losses += geometric loss (:101-102, 269)
         return out
 
+    # ---- train mode (Train_Geo.py:110,166-174): the whole network is ONE autograd node over the HIP tape (train/bridge.py)
+    hip_train_dropout = True       # the reference's 141 nn.Dropout(p = 0.1) sites with counter-based masks; False: p = 0 everywhere
+    hip_train_dropout_seed = None  # None: config.seed
+
+    def hip_engine(self):
+        """The train-mode machinery behind this module (created on first use): `.bucket.params` / `.bucket.grads` are ALL parameters /
+        gradients as one flat buffer each (every Parameter's .data / .grad is a view of its slice)."""
+        br = getattr(self, "_hip_bridge", None)
+        if br is not None:
+            try:
+                br.bucket.check_attached()
+            except RuntimeError:                                 # the module was moved (.to / .cuda) since: rebuild on the new storage
+                br = self._hip_bridge = None
+        if br is None:
+            from ..train.bridge import GeoBridge
+            self._hip_bridge = None
+            br = GeoBridge(self, self.config, dropout=self.hip_train_dropout, dropout_seed=self.hip_train_dropout_seed)
+            self._hip_bridge = br
+        return br
+
+    def _forward_train(self, data_batch):
+        br = self.hip_engine()
+        dev = br.bucket.params.device
+        data_batch.update(br.forward(self, data_batch))
+        data_batch['pc'] = data_batch['pc'].to(dev)                       # IMGPCEncoder.py:162
+        data_batch['matrix_accumulated'] = _eye4(dev).clone()
+        return 0
+
     def forward(self, data_batch):
+        if self.training:
+            return self._forward_train(data_batch)
         cl = self.forward_cl(data_batch)
         B, N, h, w = cl["B"], cl["geo"].N, cl["h"], cl["w"]
         IMGPCEnDecoder.publish(data_batch, cl)

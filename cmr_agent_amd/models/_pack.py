@@ -184,9 +184,9 @@ class Planned(nn.Module):
     def _require_eval(self):
         if self.training:
             raise NotImplementedError(
-                "%s: the HIP path implements inference (eval-mode BatchNorm / no dropout); training-mode forward "
-                "(batch statistics, dropout, backward kernels) is SURVEY.md 8(f1) and not built yet -- call .eval()"
-                % type(self).__name__)
+                "%s: train-mode forward / backward run at the MODEL boundary -- MultiHeadModel.forward and CMRAgent.forward in train() mode "
+                "are one autograd node each over the HIP tape (cmr_agent_amd/train/bridge.py); a sub-module called on its own implements "
+                "inference only (eval-mode BatchNorm, no dropout) -- call .eval()" % type(self).__name__)
 
 
 def device_of(module):

@@ -46,13 +46,24 @@ def query_ball_point(radius, nsample, xyz, new_xyz):
     return ops.ball_query(_rows4(xyz), _rows4(new_xyz), B, N, S, nsample, radius)
 
 
+def knn_point(nsample, xyz, new_xyz):
+    """square_distance(new_xyz, xyz).argsort()[:, :, :nsample] (pointnet_util.py:114-116, 232-234): int64 [B,S,nsample], ascending
+    distance, equal distances in ascending index; one streaming kernel instead of the [B,S,N] matrix and its full sort."""
+    B, N, _ = xyz.shape
+    if nsample > N:
+        raise ValueError("knn grouping of %d neighbours out of %d points" % (nsample, N))
+    return ops.knn(_rows4(new_xyz), _rows4(xyz), B, new_xyz.shape[1], N, nsample)
+
+
+def _group_idx(knn, radius, nsample, xyz, new_xyz):
+    return knn_point(nsample, xyz, new_xyz) if knn else query_ball_point(radius, nsample, xyz, new_xyz)
+
+
 def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=False, start_idx=None):
-    if knn:
-        raise NotImplementedError("knn grouping is not used by any caller of this module")
     B, N, C = xyz.shape
     fps_idx = farthest_point_sample(xyz, npoint, start_idx)
     new_xyz = index_points(xyz, fps_idx)
-    idx = query_ball_point(radius, nsample, xyz, new_xyz)
+    idx = _group_idx(knn, radius, nsample, xyz, new_xyz)
     grouped_xyz = index_points(xyz, idx)
     g4 = ops.rel_pos(_rows4(xyz), _rows4(new_xyz), B * npoint * nsample, ia=_global_i32(idx, N), divb=nsample)
     norm = g4[:, :3].reshape(B, npoint, nsample, 3)
@@ -118,9 +129,8 @@ class PointNetSetAbstraction(Planned):
 
     def forward(self, xyz, points, start_idx=None):
         """xyz [B,N,3], points [B,N,D] or None -> new_xyz [B,S,3], new_points [B,S,D']"""
-        self._require_eval()
-        if self.knn:
-            raise NotImplementedError("knn grouping")
+        if self.training:
+            return self._forward_train(xyz, points, start_idx)
         B, N, _ = xyz.shape
         plan = self.plan()
         D = 0 if points is None else points.shape[2]
@@ -135,7 +145,7 @@ class PointNetSetAbstraction(Planned):
             S, K = self.npoint, self.nsample
             fps_idx = farthest_point_sample(xyz, S, start_idx)
             new_xyz = index_points(xyz, fps_idx)
-            idx = query_ball_point(self.radius, K, xyz, new_xyz)
+            idx = _group_idx(self.knn, self.radius, K, xyz, new_xyz)
             rel, g = _group_rows(xyz, new_xyz, idx)
             feats = None if points is None else ops.gather_rows(points.contiguous().view(B * N, D), g)
         w0, b0 = plan[0]
@@ -153,10 +163,64 @@ class PointNetSetAbstraction(Planned):
         return new_xyz, out.view(B, S, -1)
 
 
+def _ceil4(n):
+    return (n + 3) // 4 * 4
+
+
+def _train_mlp(t, x, convs, bns):
+    """[1x1 conv -> BatchNorm (batch statistics) -> ReLU] per layer over the rows of x (pointnet_util.py:186-189, 242-246, 303-306)."""
+    for conv, bn in zip(convs, bns):
+        x = t.linear_bn(x, conv.weight, conv.bias, bn, slope=0.0)
+    return x
+
+
+def _grouped_input(t, rel, feats, D, xyz_first):
+    """rows [R, ceil4(3 + D)] = cat([xyz offset, features]) (sample_and_group, :127) or cat([features, xyz offset]) (Msg, :240)"""
+    if feats is None:
+        return t.pack_cols([(rel, 0, 3)], 4)
+    parts = [(rel, 0, 3), (feats, 3, D)] if xyz_first else [(feats, 0, D), (rel, D, 3)]
+    return t.pack_cols(parts, _ceil4(3 + D))
+
+
 def _padcols(x, k):
     out = torch.zeros((x.shape[0], k), dtype=x.dtype, device=x.device)
     out[:, :x.shape[1]] = x
     return out
+
+
+def _sa_forward_train(self, xyz, points, start_idx=None):
+    """PointNetSetAbstraction.forward in train() mode (pointnet_util.py:171-193): grouping as in inference, then the grouped MLP with
+    batch-statistics BatchNorm and the max over each group on the HIP tape as one autograd node (train/bridge.py:TapeFn); `points`
+    receives its gradient through autograd, the parameters through the module's flat bucket."""
+    from ..train.bridge import module_bridge
+    B, N, _ = xyz.shape
+    D = 0 if points is None else points.shape[2]
+    with torch.no_grad():
+        if self.group_all:
+            new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
+            S, K = 1, N
+            rel, g, csr = _rows4(xyz), None, None
+        else:
+            S, K = self.npoint, self.nsample
+            new_xyz = index_points(xyz, farthest_point_sample(xyz, S, start_idx))
+            idx = _group_idx(self.knn, self.radius, K, xyz, new_xyz)
+            rel, g = _group_rows(xyz, new_xyz, idx)
+            csr = ops.csr_build(g, B, S * K, N)
+
+    def build(t, *vin):
+        feats = None
+        if vin:
+            feats = vin[0] if g is None else t.gather(vin[0], g, csr)
+        x = _grouped_input(t, rel, feats, D, True)
+        x = _train_mlp(t, x, self.mlp_convs, self.mlp_bns)
+        return [t.groupmax(x, B * S, K)]
+
+    ins = () if points is None else (points.contiguous().view(B * N, D),)
+    out, = module_bridge(self).run(build, *ins)
+    return new_xyz, out[:, :self.mlp_convs[-1].weight.shape[0]].view(B, S, -1)
+
+
+PointNetSetAbstraction._forward_train = _sa_forward_train
 
 
 class PointNetSetAbstractionMsg(Planned):
@@ -178,9 +242,8 @@ class PointNetSetAbstractionMsg(Planned):
         return [_mlp_plan(c, b) for c, b in zip(self.conv_blocks, self.bn_blocks)]
 
     def forward(self, xyz, points, seed_idx=None, start_idx=None):
-        self._require_eval()
-        if self.knn:
-            raise NotImplementedError("knn grouping")
+        if self.training:
+            return self._forward_train(xyz, points, seed_idx, start_idx)
         B, N, _ = xyz.shape
         S = self.npoint
         D = 0 if points is None else points.shape[2]
@@ -191,7 +254,7 @@ class PointNetSetAbstractionMsg(Planned):
         for i, radius in enumerate(self.radius_list):
             K = self.nsample_list[i]
             plan = self.plan()[i]
-            idx = query_ball_point(radius, K, xyz, new_xyz)
+            idx = _group_idx(self.knn, radius, K, xyz, new_xyz)
             rel, g = _group_rows(xyz, new_xyz, idx)
             w0, b0 = plan[0]
             if points is None:
@@ -209,6 +272,40 @@ class PointNetSetAbstractionMsg(Planned):
         return new_xyz, torch.cat(outs, dim=2)
 
 
+def _msg_forward_train(self, xyz, points, seed_idx=None, start_idx=None):
+    """PointNetSetAbstractionMsg.forward in train() mode (pointnet_util.py:217-254): every scale's grouped MLP + max on the tape, ONE
+    autograd node for the module."""
+    from ..train.bridge import module_bridge
+    B, N, _ = xyz.shape
+    S = self.npoint
+    D = 0 if points is None else points.shape[2]
+    with torch.no_grad():
+        new_xyz = index_points(xyz, farthest_point_sample(xyz, S, start_idx) if seed_idx is None else seed_idx)
+        groups = []
+        for i, radius in enumerate(self.radius_list):
+            K = self.nsample_list[i]
+            idx = _group_idx(self.knn, radius, K, xyz, new_xyz)
+            rel, g = _group_rows(xyz, new_xyz, idx)
+            groups.append((K, rel, g, ops.csr_build(g, B, S * K, N)))
+
+    def build(t, *vin):
+        outs = []
+        for i, (K, rel, g, csr) in enumerate(groups):
+            feats = t.gather(vin[0], g, csr) if vin else None
+            x = _grouped_input(t, rel, feats, D, False)
+            x = _train_mlp(t, x, self.conv_blocks[i], self.bn_blocks[i])
+            outs.append(t.groupmax(x, B * S, K))
+        return outs
+
+    ins = () if points is None else (points.contiguous().view(B * N, D),)
+    outs = module_bridge(self).run(build, *ins)
+    widths = [blk[-1].weight.shape[0] for blk in self.conv_blocks]
+    return new_xyz, torch.cat([o[:, :c].view(B, S, c) for o, c in zip(outs, widths)], dim=2)
+
+
+PointNetSetAbstractionMsg._forward_train = _msg_forward_train
+
+
 class PointNetFeaturePropagation(Planned):
     def __init__(self, in_channel, mlp):
         super().__init__()
@@ -224,7 +321,8 @@ class PointNetFeaturePropagation(Planned):
 
     def forward(self, xyz1, xyz2, points1, points2):
         """xyz1 [B,3,N], xyz2 [B,3,S], points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,D',N]"""
-        self._require_eval()
+        if self.training:
+            return self._forward_train(xyz1, xyz2, points1, points2)
         from .PointNN import bcl_from_rows, rows_from_bcl
         B, _, N = xyz1.shape
         S = xyz2.shape[2]
@@ -250,3 +348,38 @@ class PointNetFeaturePropagation(Planned):
             w, b = _pack.pad_rows(_pack.pad_k(w1), b1)
             x = ops.linear(x if x.shape[1] == w.shape[1] else _padcols(x, w.shape[1]), w, b, act=ops.ACT_RELU)[:, :w1.shape[0]]
         return bcl_from_rows(x if x.stride(0) == x.shape[1] else x.contiguous(), B)
+
+
+def _fp_forward_train(self, xyz1, xyz2, points1, points2):
+    """PointNetFeaturePropagation.forward in train() mode (pointnet_util.py:269-308): inverse-distance interpolation, concatenation and the
+    MLP with batch-statistics BatchNorm on the tape; points1 / points2 receive their gradients through autograd."""
+    from ..train.bridge import module_bridge
+    from .PointNN import bcl_from_rows
+    B, _, N = xyz1.shape
+    S = xyz2.shape[2]
+    D1 = 0 if points1 is None else points1.shape[1]
+    D2 = points2.shape[1]
+    if D1 % 4 or D2 % 4:
+        raise NotImplementedError("feature widths must be multiples of 4")
+    with torch.no_grad():
+        if S == 1:
+            rows = torch.arange(B, device=xyz1.device, dtype=torch.int32).repeat_interleave(N).contiguous()
+            csr = ops.csr_build(rows, B, N, 1)
+            idx = wgt = None
+        else:
+            idx, wgt = ops.three_nn(ops.planar_to_rows(xyz1.contiguous(), 4), ops.planar_to_rows(xyz2.contiguous(), 4), B, N, S)
+            csr = ops.csr_build(idx.view(-1), B, 3 * N, S)
+
+    def build(t, *vin):
+        p2 = vin[-1]
+        interp = t.gather(p2, rows, csr) if S == 1 else t.weighted_gather3(p2, idx, wgt, csr)
+        x = interp if D1 == 0 else t.cat(vin[0], interp)
+        return [_train_mlp(t, x, self.mlp_convs, self.mlp_bns)]
+
+    rows_of = lambda p: p.permute(0, 2, 1).contiguous().view(-1, p.shape[1])
+    ins = ((rows_of(points1),) if points1 is not None else ()) + (rows_of(points2),)
+    out, = module_bridge(self).run(build, *ins)
+    return bcl_from_rows(out[:, :self.mlp_convs[-1].weight.shape[0]], B)
+
+
+PointNetFeaturePropagation._forward_train = _fp_forward_train

@@ -485,6 +485,15 @@ def knn16(xyz4, B, M):
     return out
 
 
+def knn(q4, c4, B, S, N, K):
+    """-> int64 [B, S, K]: the K nearest candidates of every query, ascending distance, ties in ascending index."""
+    if not 1 <= K <= 64:
+        raise ValueError("knn: K = %d (the kernel keeps up to 64 neighbours)" % K)
+    out = torch.empty((B, S, K), dtype=torch.int64, device=q4.device)
+    _lib.call("cmr_knn_f32", _p(q4), _p(c4), _p(out), B, S, N, K, _stream())
+    return out
+
+
 def nearest(q4, c4, B, Nq, Nc, want_local=True, want_global=True):
     og = torch.empty((B * Nq,), dtype=torch.int32, device=q4.device) if want_global else None
     ol = torch.empty((B, Nq), dtype=torch.int64, device=q4.device) if want_local else None
@@ -588,6 +597,15 @@ def weighted_gather3(src, idx, wgt):
     rows, C = idx.shape[0], src.shape[1]
     out = torch.empty((rows, C), dtype=f32, device=src.device)
     _lib.call("cmr_weighted_gather3_f32", _p(src), _ld(src), _p(idx), _p(wgt), _p(out), C, rows, C, _stream())
+    return out
+
+
+def weighted_scatter3(dy, wgt, order, offsets, nseg):
+    """backward of weighted_gather3 w.r.t. its source rows -> [nseg, C]"""
+    _rows(dy)
+    C = dy.shape[1]
+    out = torch.empty((nseg, C), dtype=f32, device=dy.device)
+    _lib.call("cmr_weighted_scatter3_f32", _p(dy), _ld(dy), _p(wgt), _p(_i32(order)), _p(_i32(offsets)), _p(out), C, nseg, C, _stream())
     return out
 
 

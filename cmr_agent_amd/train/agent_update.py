@@ -40,15 +40,19 @@ def _pad_running(bn, cpad):
 class AgentUpdate:
     """agent: cmr_agent_amd.models.CMRAgent already on its device.  dist: torch.distributed (or None) for data parallelism."""
 
-    def __init__(self, agent, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, optimizer=None):
+    def __init__(self, agent, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, optimizer=None, with_optimizer=True):
         self.agent, self.cfg, self.dist = agent, config, dist
+        if getattr(agent, "_hip_bridge", None) is not None:
+            raise RuntimeError("AgentUpdate: this agent already trains through the module boundary (train/bridge.py owns its flat bucket); "
+                               "use agent.hip_engine() or build the update on an agent that has not run a train-mode forward")
         self.bucket = FlatBucket(agent)
         # Train_Agent.py:111-124: 'ADAM' (lr, betas (0.9, 0.99), weight decay) or 'SGD' (lr, config.momentum, weight decay)
         # BatchNorm's forward in train() mode advances num_batches_tracked (a state_dict buffer): once per module and step here
         self._nbt = list({id(m): m.num_batches_tracked for m in agent.modules()
                           if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None}.values())
+        # with_optimizer False: the train-mode forward / backward only (train/bridge.py: torch.optim owns the step)
         self.opt = FlatOptimizer(self.bucket, optimizer or getattr(config, "optimizer", "ADAM"), config.lr if lr is None else lr, betas, eps,
-                                 config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0))
+                                 config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0)) if with_optimizer else None
         self.last_allreduce_ms = None
         # bf16 mode (ops.CONV_BF16) only: the data-gradient convolutions of the `fp32_early_dgrads` EARLIEST layers of the 2-D tower (the
         # last ones of the backward chain: conv b of stage 0, conv a of stage 1, ...) stay on the fp32 kernels; and, for diagnosis
@@ -279,7 +283,7 @@ class AgentUpdate:
             if dfeat is None:
                 dfeat = torch.zeros((R, cout), dtype=torch.float32, device=dev)
             ops.add_at_arg(dfeat, r["arg"], dg, B, N)                                         # backward of torch.max(dim=2)
-            if i > 0 and self.FUSED_3D and N % 32 == 0 and N >= 128:
+            if i > 0 and self._fused3d_bwd_ok(r, R, N):
                 dfeat, dg = self._block3d_bwd_fused(r, dfeat, B, N)
                 continue
             dsum = ops.act_bwd(dfeat, r["out"], SLOPE3D)                                      # final LeakyReLU
@@ -322,6 +326,13 @@ class AgentUpdate:
             dfeat, dg = dprev, dgprev
 
     FUSED_3D = __import__("os").environ.get("CMR_AGENT_FUSED_3D", "1") == "1"
+
+    def _fused3d_bwd_ok(self, r, R, N):
+        """every conv + BatchNorm pair of the block has a shape cmr_bn_linear_bwd_f32 serves (embed_dim 64: widths 64 / 128); other widths take
+        the op-by-op backward, as _linear_bn's forward does"""
+        f, cin, cout = self.f, r["cin"], r["cout"]
+        return (self.FUSED_3D and N % 32 == 0 and N >= 128 and ops.bn_linear_bwd_ok(R, cout, cin) and ops.bn_linear_bwd_ok(R, cin, f)
+                and (cin == cout or ops.bn_linear_bwd_ok(R, cout, f)))
 
     def _block3d_bwd_fused(self, r, dfeat, B, N):
         """Backward of one ConvBNReLURes1D block of the 3-D branch on cat([feat, broadcast max]) (blocks 1..3: 128-wide input) with one pass

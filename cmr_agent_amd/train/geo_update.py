@@ -32,16 +32,20 @@ LOSS_KEYS = ("loss", "pc_overlap_loss", "img_overlap_loss", "geometric_loss", "p
 
 class GeoUpdate:
     def __init__(self, model, config, dist=None, lr=None, betas=(0.9, 0.99), eps=1e-8, weight_decay=None, grad_clip=1.0, dropout=True,
-                 dropout_seed=None, optimizer=None):
+                 dropout_seed=None, optimizer=None, with_optimizer=True):
         self.model, self.cfg, self.dist = model, config, dist
+        if getattr(model, "_hip_bridge", None) is not None:
+            raise RuntimeError("GeoUpdate: this model already trains through the module boundary (train/bridge.py owns its flat bucket); "
+                               "use model.hip_engine() or build the update on a model that has not run a train-mode forward")
         self.bucket = FlatBucket(model)
         dev = self.bucket.params.device
         # Train_Geo.py:65-78: 'ADAM' (lr, betas (0.9, 0.99), weight decay) or 'SGD' (lr, config.momentum, weight decay)
         # BatchNorm's forward in train() mode advances num_batches_tracked (a state_dict buffer): once per module and step here
         self._nbt = list({id(m): m.num_batches_tracked for m in model.modules()
                           if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None}.values())
+        # with_optimizer False: the train-mode forward / backward only (train/bridge.py: torch.optim owns the step)
         self.opt = FlatOptimizer(self.bucket, optimizer or getattr(config, "optimizer", "ADAM"), config.lr if lr is None else lr, betas, eps,
-                                 config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0))
+                                 config.weight_decay if weight_decay is None else weight_decay, getattr(config, "momentum", 0.0)) if with_optimizer else None
         self.grad_clip = grad_clip
         self._pos2d = {}
         self._pos1d = {}
@@ -361,7 +365,12 @@ class GeoUpdate:
         for (name, _), pts, pxs in zip(heads, pts_all, pxs_all):
             outs[name] = (pts, pxs)
         pc_geo, img_geo = t.l2norm(outs["geo"][0]), t.l2norm(outs["geo"][1])
-        return dict(B=B, N=N, h=h, w=w, pc_logits=outs["overlap"][0], img_logits=outs["overlap"][1], pc_geo=pc_geo, img_geo=img_geo)
+        # the intermediate maps MultiHeadModel.forward publishes in the batch dict (values only; reference layouts as views)
+        rows = lambda v: v.v.detach().view(B, -1, v.v.shape[1])
+        publish = {"pt_feat": rows(x_feat).permute(0, 2, 1), "node_feat": rows(node_feat).permute(0, 2, 1),
+                   "img_proxy": rows(img_proxy), "pt_proxy": rows(pt_proxy), "img_feat_2": f2.v.detach().view(B, h, w, -1).permute(0, 3, 1, 2),
+                   "fused_img_feat": pix.v.detach().view(B, h, w, -1).permute(0, 3, 1, 2), "fused_node_feat": rows(nod).permute(0, 2, 1)}
+        return dict(B=B, N=N, h=h, w=w, pc_logits=outs["overlap"][0], img_logits=outs["overlap"][1], pc_geo=pc_geo, img_geo=img_geo, publish=publish)
 
     # ----------------------------------------------------------------------------------------------------------------- API
     def forward_backward(self, *args, **kw):

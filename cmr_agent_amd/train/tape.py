@@ -75,7 +75,7 @@ class Tape:
         """-> (side_fn(), main_fn()): main_fn's ops are issued first (host order = the sequential order main, side: dropout sites keep their
         numbers), side_fn's on a side stream; the two may share no Var.  The backward closures each of them records run as ONE node that
         forks the same way.  Under hipGraph capture this is a flat fork from the capture's origin stream."""
-        from ..utils.streams import fork_join
+        from ..utils.streams import fork_join, issues_main_first
         outer = self.nodes
 
         def run(fn):
@@ -86,7 +86,9 @@ class Tape:
             finally:
                 self.nodes = outer
 
-        if not self.FORK:
+        if not self.FORK or not issues_main_first(tag):
+            # (streams off, CMR_STREAMS_ONLY / CMR_STREAMS_MAIN_FIRST excluding the tag, sequential_forks(): fork_join would issue the SIDE branch
+            # first and the dropout sites of the two branches would swap numbers -- same masks in every mode needs the one host order)
             (m, mn), (sd, sn) = run(main_fn), run(side_fn)
             outer.extend(mn)
             outer.extend(sn)
@@ -566,6 +568,55 @@ class Tape:
                 return
             offsets, order = csr
             self.give(x, ops.segment_reduce(y.g, order, offsets, x.v.shape[0], "sum"), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def groupmax(self, x, G, K):
+        """max over the K consecutive rows of each of the G groups (torch.max(grouped, 2)[0] of pointnet_util.py:190, 248) -> [G, C]; the
+        gradient goes to the arg-max row."""
+        xv = x.v if x.v.is_contiguous() else x.v.contiguous()
+        out, arg = ops.colmax_arg(xv, G, K)
+        y = Var(out)
+
+        def bwd():
+            if y.g is None:
+                return
+            dx = torch.zeros(xv.shape, dtype=f32, device=xv.device)
+            ops.add_at_arg(dx, arg, y.g.contiguous(), G, K)
+            self.give(x, dx, owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def weighted_gather3(self, x, idx, wgt, csr):
+        """y[r] = sum_j wgt[r, j] x[idx[r, j]] (inverse-distance interpolation, pointnet_util.py:287-296); csr = (offsets, order) of the
+        3 R entries of idx over x's rows."""
+        y = Var(ops.weighted_gather3(x.v, idx, wgt))
+
+        def bwd():
+            if y.g is None:
+                return
+            offsets, order = csr
+            self.give(x, ops.weighted_scatter3(y.g, wgt, order, offsets, x.v.shape[0]), owned=True)
+        self.nodes.append(bwd)
+        return y
+
+    def pack_cols(self, parts, width):
+        """[R, width] rows holding the given (Var or constant tensor, first column, columns taken) parts, zero elsewhere: the grouped
+        input cat([xyz offset (3), features (D)]) of a set-abstraction MLP laid out for the stored [n4, ceil4(3 + D)] weight."""
+        R = (parts[0][0].v if isinstance(parts[0][0], Var) else parts[0][0]).shape[0]
+        dev = (parts[0][0].v if isinstance(parts[0][0], Var) else parts[0][0]).device
+        buf = torch.zeros((R, width), dtype=f32, device=dev)
+        for src, lo, n in parts:
+            v = src.v if isinstance(src, Var) else src
+            buf[:, lo:lo + n].copy_(v[:, :n])
+        y = Var(buf)
+
+        def bwd():
+            if y.g is None:
+                return
+            for src, lo, n in parts:
+                if isinstance(src, Var) and not src.const:
+                    self.give(src, y.g[:, lo:lo + n])
         self.nodes.append(bwd)
         return y
 

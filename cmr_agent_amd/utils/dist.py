@@ -44,7 +44,8 @@ class Ranks:
         if "MASTER_ADDR" not in os.environ or "MASTER_PORT" not in os.environ:
             from .launch import free_port
             extra = dict(init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # (HSA_ENABLE_IPC_MODE_LEGACY is read when the HSA runtime initialises -- long before this point in a process that has used the GPU:
+        # it is set by the launcher / at the top of the entry scripts, bench.py included, never here; a one-rank communicator needs no IPC)
         self._init(**extra)
         self.forced = True
         return True

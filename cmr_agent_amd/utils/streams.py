@@ -62,6 +62,16 @@ _ONLY = set(t for t in os.environ.get("CMR_STREAMS_ONLY", "").split(",") if t)  
 MAIN_FIRST = set(t for t in os.environ.get("CMR_STREAMS_MAIN_FIRST", "*").split(",") if t)
 
 
+def _main_first(tag):
+    return bool(tag) and (tag in MAIN_FIRST or ("*" in MAIN_FIRST and tag != "pipeline"))
+
+
+def issues_main_first(tag):
+    """fork_join(..., tag=tag) would run its branches on streams with the MAIN branch issued first (callers whose branches draw numbered
+    dropout sites -- train/tape.py:Tape.fork -- need the host order main, side; any other mode they run sequentially in that order)."""
+    return ENABLED and torch.cuda.is_available() and not (_ONLY and tag not in _ONLY) and _sequential == 0 and _main_first(tag)
+
+
 def fork_join(*fns, tag=""):
     """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn (the MAIN branch) on the current stream and returns all
     results (in argument order) after joining.  Sequential on CPU / when disabled / inside sequential_forks().
@@ -99,7 +109,7 @@ def fork_join(*fns, tag=""):
 
     try:
         out = []
-        if tag and (tag in MAIN_FIRST or ("*" in MAIN_FIRST and tag != "pipeline")):    # the two-stage pipeline keeps geo stage (side) first: 942 vs 849-875 it/s in bf16 mode
+        if _main_first(tag):    # the two-stage pipeline keeps geo stage (side) first: 942 vs 849-875 it/s in bf16 mode
             # issue order = the order in which a replayed hipGraph hands the nodes to the device: a main branch of few, long kernels
             # (the image tower) goes first, the many short launches of the side branch are fed while it already runs
             last = fns[-1]()

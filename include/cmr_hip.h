@@ -313,6 +313,11 @@ int cmr_csr_build_i32(const int32_t* key, int32_t* count, int32_t* offsets, int3
 /* 16 nearest nodes of every node, ascending distance.  PointNN.py:215-216 (square_distance + argsort). */
 int cmr_knn16_f32(const float* xyz4, int32_t* out, int B, int M, hipStream_t stream);
 
+/* K nearest candidates (rows c4 [B*N,4]) of every query (rows q4 [B*S,4]), 1 <= K <= 64: out int64 [B,S,K] = LOCAL candidate indices in
+ * ascending distance, equal distances in ascending index -- square_distance(new_xyz, xyz).argsort()[:, :, :K] of pointnet_util.py:114-116
+ * (sample_and_group, knn=True) and :232-234 (PointNetSetAbstractionMsg).  N < K: the missing entries are -1. */
+int cmr_knn_f32(const float* q4, const float* c4, int64_t* out, int B, int S, int N, int K, hipStream_t stream);
+
 /* nearest candidate per query.  PointViT.py:85-87 (node -> proxy), dataset/KittiDataset.py:366-367 (point -> node). */
 int cmr_nearest_f32(const float* q4, const float* c4, int32_t* out_global, int64_t* out_local, int B, int Nq, int Nc,
                     hipStream_t stream);
@@ -365,6 +370,10 @@ int cmr_three_nn_f32(const float* q4, const float* c4, int32_t* idx, float* wgt,
                      hipStream_t stream);
 int cmr_weighted_gather3_f32(const float* src, int64_t lds, const int32_t* idx, const float* wgt, float* out, int64_t ldo,
                              int64_t rows, int C, hipStream_t stream);
+/* its backward w.r.t. src (train-mode PointNetFeaturePropagation): out[t] = sum of wgt[e] * dy[e / 3] over the entries e of idx that name
+ * row t, in ascending e through the CSR (offsets, order) of idx over the nseg source rows (cmr_csr_build_i32): deterministic, no atomics. */
+int cmr_weighted_scatter3_f32(const float* dy, int64_t ldd, const float* wgt, const int32_t* order, const int32_t* offsets, float* out,
+                              int64_t ldo, int64_t nseg, int C, hipStream_t stream);
 
 /* per-batch max / mean over rows.  CMRAgent.py:95 (torch.max over points), environment.py:46,88 (pc.mean). */
 int64_t cmr_colreduce_workspace_bytes(int B, int N, int C);

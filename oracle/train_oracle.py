@@ -140,7 +140,7 @@ def _tie_aliases(sd):
     return {k: sd[canonical_key(k)] if canonical_key(k) in sd else v for k, v in sd.items()}
 
 
-def geo_forward_backward(sd, data, cfg, bn_training=True):
+def geo_forward_backward(sd, data, cfg, bn_training=True, loss_fn=None):
     """`model.train(); model(data); data['loss'].backward()` of Train_Geo.py:166-171 with every nn.Dropout at p = 0 (the
     reference's dropout draws are not reproducible across implementations; parity is defined without them):
     forward of cmr_oracle.multi_head_model with batch statistics, loss = focal + focal + circle (MultiHeadModel.py:98-102,
@@ -155,7 +155,11 @@ def geo_forward_backward(sd, data, cfg, bn_training=True):
     try:
         with torch.enable_grad():
             out = O.multi_head_model(work, data, cfg, with_loss=True)
-            out["loss"].backward()
+            if loss_fn is None:
+                out["loss"].backward()
+            else:                                           # a caller-composed objective over the published tensors (tests/test_bridge_gpu.py)
+                out["custom_loss"] = loss_fn(out)
+                out["custom_loss"].backward()
     finally:
         O.BN_TRAINING = prev
     g = lambda p: p.grad if p.grad is not None else torch.zeros_like(p)

@@ -93,6 +93,19 @@ OP_CASES = {
         oracle=lambda sd, i: dict(zip(("new_xyz", "new_points"),
                                       O.set_abstraction_msg(O.Weights(sd), i["xyz"], i["points"], 32, [0.3, 0.6],
                                                             [8, 16], i["start"])))),
+    # knn=True grouping (pointnet_util.py:114-116, 232-234): square_distance + argsort()[:, :, :K]
+    "pointnet_util_knn": dict(
+        inputs=_pnu_inputs,
+        oracle=lambda sd, i: _pnu_knn_oracle(i)),
+    "set_abstraction_knn": dict(
+        inputs=_pnu_inputs,
+        oracle=lambda sd, i: dict(zip(("new_xyz", "new_points"),
+                                      O.set_abstraction(O.Weights(sd), i["xyz"], i["points"], 32, 0.4, 16, i["start"], knn=True)))),
+    "set_abstraction_msg_knn": dict(
+        inputs=_pnu_inputs,
+        oracle=lambda sd, i: dict(zip(("new_xyz", "new_points"),
+                                      O.set_abstraction_msg(O.Weights(sd), i["xyz"], i["points"], 32, [0.3, 0.6],
+                                                            [8, 16], i["start"], knn=True)))),
     "feature_propagation": dict(
         inputs=lambda: dict(xyz1=u("fp/x1", (2, 3, 200)), xyz2=u("fp/x2", (2, 3, 40)), p1=u("fp/p1", (2, 8, 200)),
                             p2=u("fp/p2", (2, 16, 40))),
@@ -109,6 +122,52 @@ def _pnu_oracle(i):
     nx, g, _, _ = O.sample_and_group(32, 0.4, 16, xyz, pts, i["start"])
     return dict(fps=fps, new_xyz=new_xyz, ball=ball, sqdist=sq, sg_xyz=nx, sg_points=g,
                 gathered=O.index_points(pts, ball))
+
+
+def _pnu_knn_oracle(i):
+    xyz, pts = i["xyz"], i["points"]
+    new_xyz = O.index_points(xyz, O.farthest_point_sample(xyz, 64, i["start"]))
+    sq = O.square_distance(new_xyz, xyz)
+    nx, g, _, _ = O.sample_and_group(32, 0.4, 16, xyz, pts, i["start"], knn=True)
+    return dict(knn5=sq.argsort()[:, :, :5], knn16=sq.argsort()[:, :, :16], knn40=sq.argsort()[:, :, :40], knn64=sq.argsort()[:, :, :64],
+                sg_xyz=nx, sg_points=g)
+
+
+# train()-mode PointNet++ modules (pointnet_util.py:156-308 under autograd): constructor arguments per case; inputs = _pnu_inputs /
+# the feature_propagation inputs; the scalar differentiated is sum(output * PN2_LOSS_W) with hash-filled weights
+PN2_TRAIN_CASES = {
+    "sa": ("sa", (32, 0.4, 16, 3 + 8, [16, 32], False), dict(knn=False)),
+    "sa_knn": ("sa", (32, 0.4, 16, 3 + 8, [16, 32], False), dict(knn=True)),
+    "sa_all": ("sa", (None, None, None, 3 + 8, [16, 32], True), dict()),
+    "msg": ("msg", (32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]]), dict(knn=False)),
+    "msg_knn": ("msg", (32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]]), dict(knn=True)),
+    "fp": ("fp", (8 + 16, [32, 16]), dict()),
+    "fp_s1": ("fp", (8 + 16, [32, 16]), dict()),
+}
+PN2_TRAIN_FIXTURE = "pointnet2_train"
+
+
+def pn2_train_inputs(name):
+    if name.startswith("fp"):
+        s = 1 if name == "fp_s1" else 40
+        return dict(xyz1=u("fp/x1", (2, 3, 200)), xyz2=u("fp/x2", (2, 3, 40))[:, :, :s].contiguous(), p1=u("fp/p1", (2, 8, 200)),
+                    p2=u("fp/p2", (2, 16, 40))[:, :, :s].contiguous())
+    return _pnu_inputs()
+
+
+def pn2_loss_weight(name, shape):
+    return u("pn2w/" + name, tuple(shape), -1, 1)
+
+
+def pn2_oracle_forward(name, sd, i):
+    """the oracle's forward of a PN2_TRAIN_CASES module (batch statistics when O.BN_TRAINING) -> output tensor"""
+    kind, args, kw = PN2_TRAIN_CASES[name]
+    w = O.Weights(sd)
+    if kind == "sa":
+        return O.set_abstraction(w, i["xyz"], i["points"], args[0], args[1], args[2], i["start"], group_all=args[5], knn=kw.get("knn", False))[1]
+    if kind == "msg":
+        return O.set_abstraction_msg(w, i["xyz"], i["points"], args[0], args[1], args[2], i["start"], knn=kw.get("knn", False))[1]
+    return O.feature_propagation(w, i["xyz1"], i["xyz2"], i["p1"], i["p2"])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -306,7 +365,7 @@ def buffer_inputs():
 # dataset-side geometry of one frame (KittiDataset.py:258-423)
 # ----------------------------------------------------------------------------------------------
 FRAME = dict(n_raw=6000, num_pt=4096, num_node=128, H=160, W=512, img_h=376, img_w=1241)
-TRAIN_FIXTURES = TRAIN_FIXTURES + ("kitti_frame", GEO_TRAIN_FIXTURE)
+TRAIN_FIXTURES = TRAIN_FIXTURES + ("kitti_frame", GEO_TRAIN_FIXTURE, PN2_TRAIN_FIXTURE)
 # calib.txt rows of a KITTI odometry sequence (P2 and Tr; public calibration numbers, data not code)
 FRAME_P2 = [7.188560000000e+02, 0.0, 6.071928000000e+02, 4.538225000000e+01, 0.0, 7.188560000000e+02, 1.852157000000e+02,
             -1.130887000000e-01, 0.0, 0.0, 1.0, 3.779761000000e-03]

@@ -58,6 +58,14 @@ def ref_op_modules(ns):
         return dict(fps=fps, new_xyz=new_xyz, ball=ball, sqdist=U.square_distance(new_xyz, xyz), sg_xyz=nx,
                     sg_points=g, gathered=U.index_points(pts, ball))
 
+    def pnu_knn_ref(_, i):
+        xyz, pts = i["xyz"], i["points"]
+        new_xyz = U.index_points(xyz, _ref_fps(U, xyz, 64, i["start"]))
+        order = U.square_distance(new_xyz, xyz).argsort()
+        _seed_start(i["start"])
+        nx, g = U.sample_and_group(32, 0.4, 16, xyz, pts, knn=True)
+        return dict(knn5=order[:, :, :5], knn16=order[:, :, :16], knn40=order[:, :, :40], knn64=order[:, :, :64], sg_xyz=nx, sg_points=g)
+
     def sa_ref(m, i):
         _seed_start(i["start"])
         a, b = m(i["xyz"], i["points"])
@@ -91,6 +99,9 @@ def ref_op_modules(ns):
         "pointnet_util": (torch.nn.Identity(), pnu_ref),
         "set_abstraction": (U.PointNetSetAbstraction(32, 0.4, 16, 3 + 8, [16, 32], False), sa_ref),
         "set_abstraction_msg": (U.PointNetSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]]), sa_ref),
+        "pointnet_util_knn": (torch.nn.Identity(), pnu_knn_ref),
+        "set_abstraction_knn": (U.PointNetSetAbstraction(32, 0.4, 16, 3 + 8, [16, 32], False, knn=True), sa_ref),
+        "set_abstraction_msg_knn": (U.PointNetSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]], knn=True), sa_ref),
         "feature_propagation": (U.PointNetFeaturePropagation(8 + 16, [32, 16]),
                                 lambda m, i: dict(y=m(i["xyz1"], i["xyz2"], i["p1"], i["p2"]))),
     }

@@ -150,6 +150,67 @@ def run_geo(ns, report):
     print(C.GEO_TRAIN_FIXTURE, report[C.GEO_TRAIN_FIXTURE])
 
 
+def run_pointnet2(ns, report):
+    """The reference's PointNetSetAbstraction / ...Msg / FeaturePropagation (models/pointnet_util.py:156-308) in train() mode under torch
+    autograd: output, gradient of sum(output * W) w.r.t. every parameter and the feature inputs, running statistics after the forward."""
+    U = ns.pnu
+    named, rep = {}, {}
+    start, orig = {}, torch.randint
+
+    def randint(low, high=None, size=None, **kw):           # the FPS start index (pointnet_util.py:62) = the case's explicit one
+        if "v" in start and size is not None and tuple(size) == tuple(start["v"].shape):
+            return start.pop("v")
+        return orig(low, high, size, **kw)
+    torch.randint = randint
+    try:
+        for name, (kind, args, kw) in C.PN2_TRAIN_CASES.items():
+            ctor = {"sa": U.PointNetSetAbstraction, "msg": U.PointNetSetAbstractionMsg, "fp": U.PointNetFeaturePropagation}[kind]
+            m = ctor(*args, **kw)
+            hashfill.fill_state_dict(m.state_dict(), "pn2/" + name + "/")
+            sd0 = {k: v.detach().clone() for k, v in m.state_dict().items() if not k.endswith("num_batches_tracked")}
+            m.train()
+            i = C.pn2_train_inputs(name)
+            feats = [k for k in ("points", "p1", "p2") if k in i]
+            for k in feats:
+                i[k] = i[k].clone().requires_grad_(True)
+            if kind == "fp":
+                out = m(i["xyz1"], i["xyz2"], i["p1"], i["p2"])
+            else:
+                start["v"] = i["start"].clone()
+                out = m(i["xyz"], i["points"])[1]
+            w = C.pn2_loss_weight(name, out.shape)
+            (out * w).sum().backward()
+            named[name + "/out"] = out.detach()
+            for k in feats:
+                named["%s/d_%s" % (name, k)] = i[k].grad.detach()
+            for k, p in m.named_parameters():
+                named["%s/grad/%s" % (name, k)] = p.grad.detach()
+            for k, b in m.named_buffers():
+                if not k.endswith("num_batches_tracked"):
+                    named["%s/buf/%s" % (name, k)] = b.detach().clone()
+            # oracle cross-check (autograd of the functional restatement, batch statistics)
+            leaves = {k: (v.clone().requires_grad_(True) if not k.endswith(("running_mean", "running_var")) else v.clone()) for k, v in sd0.items()}
+            j = C.pn2_train_inputs(name)
+            for k in feats:
+                j[k] = j[k].clone().requires_grad_(True)
+            prev, TO.O.BN_TRAINING = TO.O.BN_TRAINING, True
+            try:
+                oo = C.pn2_oracle_forward(name, leaves, j)
+            finally:
+                TO.O.BN_TRAINING = prev
+            (oo * w).sum().backward()
+            gs = max(float(p.grad.abs().max()) for _, p in m.named_parameters())
+            rep[name] = dict(out=float((oo - out).abs().max()),
+                             grad_over_max=float(max((leaves[k].grad - p.grad).abs().max() for k, p in m.named_parameters())) / gs,
+                             d_in=float(max((j[k].grad - i[k].grad).abs().max() for k in feats)),
+                             running=float(max((leaves[k] - b).abs().max() for k, b in m.named_buffers() if not k.endswith("num_batches_tracked"))))
+    finally:
+        torch.randint = orig
+    report[C.PN2_TRAIN_FIXTURE] = rep
+    G.save_case(C.PN2_TRAIN_FIXTURE, named)
+    print(C.PN2_TRAIN_FIXTURE, rep)
+
+
 def run_buffer(ns, report):
     cfg = ns.config.KittiConfiguration()
     ns.buffer.DEVICE = torch.device("cpu")
@@ -179,6 +240,7 @@ def main():
         run_agent(ns, case, False, report)
     run_buffer(ns, report)
     run_geo(ns, report)
+    run_pointnet2(ns, report)
     rp = os.path.join(G.OUT_DIR, "oracle_vs_reference.json")
     rep = json.load(open(rp))
     rep.update(report)

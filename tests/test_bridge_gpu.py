@@ -1,0 +1,345 @@
+"""GPU tier: the TRAINING side of the nn.Module boundary (cmr_agent_amd/train/bridge.py).  The loop lines of the reference's
+training scripts run here as this build's own code, unchanged in form:
+
+  Train_Geo.py:110,166-174    model.train(); optimizer.zero_grad(); model(data); data['loss'].backward();
+                              clip_grad_value_(model.parameters(), 1); optimizer.step()          (torch.optim.Adam)
+  Train_Agent.py:256-305      agent.train(); ...; r, t, v = agent(states_2d, states_3d); BC + PPO + value + entropy composed in torch;
+                              optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+and must (a) leave the gradient bucket bit-identical to GeoUpdate.forward_backward / AgentUpdate on the same batch, (b) meet the
+reference-generated fixtures (geo_train_small, agent_train_small_trainbn) at the bars of test_geo_update_gpu.py /
+test_train_gpu.py, (c) differentiate a loss the caller composes differently (changed weights, an extra term) like the oracle's
+autograd of the same expression."""
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases as C
+import golden_util as G
+from cmr_agent_amd.utils import hashfill
+from oracle import train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SPECS = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
+SCALARS = C.LOSS_KEYS + C.METRIC_KEYS
+
+
+@pytest.fixture(autouse=True)
+def _grad_enabled():
+    with torch.enable_grad():
+        yield
+
+
+def _to_dev(b):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in b.items()}
+
+
+def _geo_model(cfg, sd):
+    from cmr_agent_amd.models import MultiHeadModel
+    from cmr_agent_amd.utils.checkpoint import load_checked
+    m = MultiHeadModel(cfg)
+    load_checked(m, sd)
+    m = m.to(DEV)
+    m.hip_train_dropout = False                 # parity is defined without the dropout draws
+    return m
+
+
+def _agent(cfg):
+    from cmr_agent_amd.models import CMRAgent
+    a = CMRAgent(cfg)
+    a.load_state_dict(hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG))
+    return a.to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------------------------ geo model
+def test_train_geo_loop_lines_run_on_the_hip_tape():
+    """Train_Geo.py:166-174 verbatim against GeoUpdate on a twin model: bit-identical losses and gradient bucket after backward(), the same
+    two-step trajectory as the fused clip + Adam launch (torch's Adam and cmr_adam_f32 differ by rounding only), the reference fixture met."""
+    from cmr_agent_amd.train import GeoUpdate
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batches = [_to_dev(b) for b in C.geo_train_batches()]
+    fx = G.load_case(C.GEO_TRAIN_FIXTURE)
+    twin = _geo_model(cfg, geo_sd)
+    up = GeoUpdate(twin, cfg, dropout=False)
+    ref_losses = up.forward_backward(dict(batches[0]))
+    ref_grads = up.bucket.grads.clone()
+
+    model = _geo_model(cfg, geo_sd)
+    optimizer = torch.optim.Adam(model.parameters(), lr=cfg.lr, betas=(0.9, 0.99), weight_decay=cfg.weight_decay)      # Train_Geo.py:72-78
+    model.train()                                                                                                       # :110
+    hist = []
+    for step, batch in enumerate(batches):
+        data = dict(batch)
+        optimizer.zero_grad()                                                                                           # :166
+        model(data)                                                                                                     # :168
+        loss = data['loss']
+        loss.backward()                                                                                                 # :171
+        if step == 0:
+            eng = model.hip_engine().engine
+            assert torch.equal(eng.bucket.grads, ref_grads), "gradient bucket differs from GeoUpdate.forward_backward"
+            for k in SCALARS:
+                assert float(data[k]) == float(ref_losses[k]), (k, float(data[k]), float(ref_losses[k]))
+            # every Parameter's .grad is the view of its slice: what torch.optim / clip_grad_value_ read IS the bucket
+            for n, p in model.named_parameters():
+                if p.requires_grad:
+                    assert p.grad is not None and p.grad.data_ptr() == eng.bucket.by_id[id(p)].view(eng.bucket.grads).data_ptr(), n
+            # the reference's layouts on the published tensors, with the autograd node attached
+            B, N = batch["pc"].shape[0], batch["pc"].shape[2]
+            assert tuple(data['pc_overlap_logits'].shape) == (B, 2, N) and data['pc_overlap_logits'].grad_fn is not None
+            assert tuple(data['pc_geo_feat'].shape) == (B, 64, N) and data['img_geo_feat'].shape[1] == 64
+            assert data['pc_overlap_pred'].dtype == torch.bool and tuple(data['pc_overlap_pred'].shape) == (B, N)
+        torch.nn.utils.clip_grad_value_(model.parameters(), 1)                                                          # :172
+        optimizer.step()                                                                                                # :174
+        hist.append({k: float(data[k]) for k in SCALARS})
+    torch.cuda.synchronize()
+    # (b) the reference's own numbers for the two steps, at the bars of test_geo_update_matches_oracle_and_reference_fixture
+    for i in range(len(batches)):
+        for k in C.LOSS_KEYS:
+            want = float(fx["step%d/%s" % (i, k)]["sample"][0])
+            tol = (1e-5 if i == 0 else 3e-4) if (i == 0 or k == "loss") else 1e-3
+            assert abs(hist[i][k] - want) <= tol * max(1.0, abs(want)), (i, k, hist[i][k], want)
+    # the same trajectory as the fused path: two GeoUpdate.step on the twin
+    twin2 = _geo_model(cfg, geo_sd)
+    up2 = GeoUpdate(twin2, cfg, dropout=False)
+    for b in batches:
+        up2.step(dict(b))
+    torch.cuda.synchronize()
+    sd_a, sd_b = model.state_dict(), twin2.state_dict()
+    close_n = all_n = 0
+    for k, v in sd_b.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_a[k]) == int(v) == len(batches), k
+            continue
+        d = (sd_a[k].double() - v.double()).abs()
+        if k.endswith(("running_mean", "running_var")):
+            assert float(d.max()) <= 2e-3 * max(1.0, float(v.abs().max())), (k, float(d.max()))
+        else:
+            assert float(d.max()) <= 4.4 * cfg.lr, (k, float(d.max()))
+            close_n, all_n = close_n + int((d <= 2e-6).sum()), all_n + d.numel()
+    # step one is identical up to Adam's rounding; the free-running second step inherits the sign flips of noise-level entries
+    assert close_n >= 0.9 * all_n, (close_n, all_n)
+    # the inference path sees the weights torch's optimizer wrote
+    model.eval()
+    from cmr_agent_amd.models import MultiHeadModel
+    fresh = MultiHeadModel(cfg)
+    fresh.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    fresh = fresh.to(DEV).eval()
+    with torch.no_grad():
+        da, db = dict(batches[0]), dict(batches[0])
+        model(da)
+        fresh(db)
+    for k in ("pc_overlap_logits", "img_geo_feat"):
+        assert float((da[k] - db[k]).abs().max()) <= 1e-6 * max(1.0, float(db[k].abs().max())), k
+
+
+def test_a_loss_composed_by_the_caller_differentiates_like_the_oracle():
+    """Changed loss weights and an extra term on a published tensor (a maintainer's edit of MultiHeadModel.py:98-102, 269): composed in
+    torch over the bridge's outputs, differentiated by the HIP tape, against the oracle's autograd of the same expression."""
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    sd0 = {k: v for k, v in geo_sd.items() if not k.endswith("num_batches_tracked")}
+    batch = C.geo_train_batches()[0]
+
+    def custom(d, mask):
+        extra = F.cross_entropy(d['pc_overlap_logits'], mask)            # plain cross-entropy next to the focal loss
+        reg = d['pc_geo_feat'][:, :8].abs().mean() + d['img_geo_feat'][:, 8:16].pow(2).mean()
+        return 2.0 * d['pc_overlap_loss'] + 0.5 * d['img_overlap_loss'] + 0.25 * d['geometric_loss'] + 0.3 * extra + 0.1 * reg
+
+    model = _geo_model(cfg, geo_sd).train()
+    data = _to_dev(batch)
+    model(data)
+    loss = custom(data, data["pc_mask"])
+    loss.backward()
+    torch.cuda.synchronize()
+    eng = model.hip_engine().engine
+    named = dict(model.named_parameters(remove_duplicate=False))
+    lg = {k: eng.bucket.by_id[id(p)].view(eng.bucket.grads) for k, p in named.items() if p.requires_grad}
+    out, og = TO.geo_forward_backward({k: x.clone() for k, x in sd0.items()}, batch, cfg, True, loss_fn=lambda o: custom(o, batch["pc_mask"]))
+    assert abs(float(loss) - float(out["custom_loss"])) <= 1e-5 * max(1.0, abs(float(out["custom_loss"])))
+    gmax = max(float(g.abs().max()) for g in og.values())
+    dot = nh = no = 0.0
+    for k, g in og.items():
+        h = lg[k].detach().cpu().double().reshape(g.shape)
+        g = g.double()
+        d, m = float((h - g).abs().max()), float(g.abs().max())
+        assert d <= 3e-3 * gmax and not (m > 1e-4 * gmax and d > 0.08 * m), "%s: max|d| %.3e own max %.3e model max %.3e" % (k, d, m, gmax)
+        if TO.canonical_key(k) == k:
+            dot, nh, no = dot + float((h * g).sum()), nh + float((h * h).sum()), no + float((g * g).sum())
+    assert dot / (nh * no) ** 0.5 >= 0.99999
+    # and it is NOT the default loss's gradient
+    model2 = _geo_model(cfg, geo_sd).train()
+    d2 = _to_dev(batch)
+    model2(d2)
+    d2['loss'].backward()
+    g2 = model2.hip_engine().engine.bucket.grads
+    assert float((g2 - eng.bucket.grads).abs().max()) > 1e-2 * float(g2.abs().max())
+
+
+def test_gradients_accumulate_like_autograd_and_a_second_backward_raises():
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batch = _to_dev(C.geo_train_batches()[0])
+    model = _geo_model(cfg, geo_sd).train()
+    saved = {n: b.detach().clone() for n, b in model.named_buffers()}
+    d1 = dict(batch)
+    model(d1)
+    d1['loss'].backward()
+    g1 = model.hip_engine().bucket.grads.clone()
+    with pytest.raises(RuntimeError):
+        d1['loss'].backward()                                   # the tape's buffers are gone
+    with torch.no_grad():
+        for n, b in model.named_buffers():
+            b.copy_(saved[n])                                   # same BatchNorm running statistics -> same forward
+    d2 = dict(batch)
+    model(d2)
+    d2['loss'].backward()                                       # no zero_grad in between: .grad accumulates
+    torch.cuda.synchronize()
+    g2 = model.hip_engine().bucket.grads
+    assert torch.equal(g2, g1 + g1)
+    # zero_grad(set_to_none=False) keeps the views and zeroes the bucket through them
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    opt.zero_grad(set_to_none=False)
+    assert float(model.hip_engine().bucket.grads.abs().max()) == 0.0
+    opt.zero_grad()                                             # set_to_none
+    d3 = dict(batch)
+    with torch.no_grad():
+        for n, b in model.named_buffers():
+            b.copy_(saved[n])
+    model(d3)
+    d3['loss'].backward()
+    assert torch.equal(model.hip_engine().bucket.grads, g1)
+
+
+def test_train_mode_dropout_is_on_by_default_and_reproducible():
+    """model.train() in the reference switches 141 nn.Dropout(p = 0.1) modules on: the bridge applies them (counter-based masks, one seed
+    per forward) unless hip_train_dropout is cleared."""
+    cfg = C.e2e_config(C.GEO_TRAIN_CASE)
+    geo_sd, _ = C.e2e_state_dicts(SPECS)
+    batch = _to_dev(C.geo_train_batches()[0])
+    losses = []
+    for _ in range(2):
+        from cmr_agent_amd.models import MultiHeadModel
+        from cmr_agent_amd.utils.checkpoint import load_checked
+        m = MultiHeadModel(cfg)
+        load_checked(m, geo_sd)
+        m = m.to(DEV).train()
+        a, b = dict(batch), dict(batch)
+        m(a)
+        m(b)
+        losses.append((float(a['loss']), float(b['loss'])))
+    assert losses[0] == losses[1]                               # same seed sequence in a fresh module
+    assert losses[0][0] != losses[0][1]                         # fresh masks every forward
+    off = _geo_model(cfg, geo_sd).train()
+    c = dict(batch)
+    off(c)
+    assert abs(float(c['loss']) - losses[0][0]) > 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------- agent
+def _torch_agent_loss(agent, cfg, batch, r_logits, t_logits, value):
+    """Train_Agent.py:268-302 composed in torch from the logits / value the train-mode agent returned."""
+    new_logprob, new_entropy = agent.action_logprob_and_entropy(r_logits, t_logits, batch["action_r"], batch["action_t"])       # :269
+    S = r_logits.shape[2]
+    clone_loss = (F.cross_entropy(r_logits.reshape(-1, S), batch["expert_actions_r"].reshape(-1))                          # :272-278
+                  + F.cross_entropy(t_logits.reshape(-1, S), batch["expert_actions_t"].reshape(-1)))
+    out = dict(clone_loss=clone_loss, loss=clone_loss)
+    if cfg.alpha > 0:
+        ratio = torch.exp(new_logprob - batch["action_logprob"])                                                            # :284
+        adv = batch["advantages"]
+        policy_loss = -torch.min(ratio * adv, ratio.clamp(1 - cfg.CLIP_EPS, 1 + cfg.CLIP_EPS) * adv).mean()                 # :286
+        value_loss = (value.view(-1, 1) - batch["state_value_ref"]).pow(2).mean()                                          # :289-290
+        entropy_loss = new_entropy.mean()                                                                                   # :293
+        ppo_loss = policy_loss + value_loss * cfg.W_VALUE - entropy_loss * cfg.W_ENTROPY                                     # :300
+        out.update(policy_loss=policy_loss, value_loss=value_loss, entropy_loss=entropy_loss, ppo_loss=ppo_loss, loss=clone_loss + ppo_loss * cfg.alpha)
+    return out
+
+
+def test_train_agent_minibatch_body_runs_on_the_hip_kernels():
+    """Train_Agent.py:263-305 with the loss composed in torch: fixtures of the reference's own module at the bars of
+    test_agent_update_matches_oracle_and_reference_fixture; with the loss kernel's logit gradients fed to autograd the bucket is bit-identical
+    to AgentUpdate's."""
+    from cmr_agent_amd.train import AgentUpdate
+    from cmr_agent_amd import ops
+    case = "agent_train_small"
+    cfg_d, cfg_c = C.train_config(case, device=DEV), C.train_config(case)
+    batches = [_to_dev(b) for b in C.train_inputs(case)]
+    sd0 = {k: v for k, v in hashfill.make_state_dict(SPECS["agent"], C.AGENT_TAG).items() if not k.endswith("num_batches_tracked")}
+    # ---- (a) same logit gradients in -> same bucket out
+    twin = _agent(cfg_d)
+    up = AgentUpdate(twin, cfg_d)
+    _, (r_ref, t_ref, v_ref) = up.forward_backward(batches[0])
+    ref_grads = up.bucket.grads.clone()
+    agent = _agent(cfg_d)
+    agent.train()
+    r, t, v = agent(batches[0]["states_2d"], batches[0]["states_3d"])
+    assert torch.equal(r, r_ref) and torch.equal(t, t_ref) and torch.equal(v, v_ref)
+    assert r.grad_fn is not None and tuple(r.shape) == (r.shape[0], agent.degree_r, cfg_d.num_steps) and tuple(v.shape) == (r.shape[0], 1, 1)
+    b0 = batches[0]
+    B, S, dr, dt = r.shape[0], cfg_d.num_steps, agent.degree_r, agent.degree_t
+    i64 = lambda x: x.to(torch.int64).contiguous()
+    f32c = lambda x, n: x.reshape(B, n).float().contiguous()
+    pad = lambda x, n: F.pad(x.detach().reshape(B, -1), (0, (n + 3) // 4 * 4 - n)).contiguous()
+    _, d_r, d_t, d_v = ops.agent_loss(pad(r, dr * S), pad(t, dt * S), pad(v, 1), i64(b0["expert_actions_r"]), i64(b0["expert_actions_t"]), i64(b0["action_r"]),
+                                      i64(b0["action_t"]), f32c(b0["action_logprob"], dr + dt), f32c(b0["state_value_ref"], 1), f32c(b0["advantages"], 1),
+                                      dr, dt, S, float(cfg_d.alpha), cfg_d.CLIP_EPS, cfg_d.W_VALUE, cfg_d.W_ENTROPY, 1.0)
+    torch.autograd.backward([r, t, v], [d_r[:, :dr * S].reshape(B, dr, S), d_t[:, :dt * S].reshape(B, dt, S), d_v[:, :1].reshape(B, 1, 1)])
+    torch.cuda.synchronize()
+    assert torch.equal(agent.hip_engine().bucket.grads, ref_grads), "gradient bucket differs from AgentUpdate.forward_backward"
+    # ---- (b) the reference's loop body, two minibatches
+    agent = _agent(cfg_d)
+    optimizer = torch.optim.Adam(agent.parameters(), lr=cfg_d.lr, betas=(0.9, 0.99), weight_decay=cfg_d.weight_decay)       # Train_Agent.py:121-124
+    agent.train()                                                                                                         # :256
+    hist, first = [], None
+    for batch in batches:
+        r_logits, t_logits, value = agent(batch["states_2d"], batch["states_3d"])                                         # :268
+        if first is None:
+            first = r_logits.detach().clone()
+        losses = _torch_agent_loss(agent, cfg_d, batch, r_logits, t_logits, value)
+        optimizer.zero_grad()                                                                                             # :303
+        losses["loss"].backward()                                                                                         # :304
+        optimizer.step()                                                                                                  # :305
+        hist.append({k: float(x) for k, x in losses.items()})
+    torch.cuda.synchronize()
+    fx = G.load_case(case + "_trainbn")
+    e = G.compare("r_logits", first.cpu(), fx["r_logits"], 1e-4 * float(abs(fx["r_logits"]["sample"]).max()), 0)
+    assert e is None, e
+    for i in range(len(batches)):
+        for name in ("loss", "clone_loss", "policy_loss", "value_loss", "entropy_loss", "ppo_loss"):
+            want = float(fx["step%d/%s" % (i, name)]["sample"][0])
+            assert abs(hist[i][name] - want) <= 3e-4 * max(1.0, abs(want)), (i, name, hist[i][name], want)
+    # parameters after the two steps against the oracle's torch.optim.Adam trajectory (bars of the fused-update test)
+    osd, _ = TO.adam_train(sd0, C.train_inputs(case), cfg_c, True)
+    sd2 = {k: x.detach().cpu() for k, x in agent.state_dict().items() if not k.endswith("num_batches_tracked")}
+    lr, nst = cfg_c.lr, len(batches)
+    zero_grad_bias = {"state_2d_embed.%d.bias" % i for i in (0, 6, 12, 18)}
+    for i in range(4):
+        zero_grad_bias |= {"state_3d_embed.%d.net.0.bias" % i, "state_3d_embed.%d.net.3.bias" % i, "state_3d_embed.%d.shortcut.0.bias" % i}
+    n_all = n_bad = 0
+    worst = []
+    for k in osd:
+        d = (sd2[k].double() - osd[k].double()).abs()
+        if k in zero_grad_bias or k.endswith("running_mean"):
+            assert float(d.max()) <= 2.2 * lr * nst, (k, float(d.max()))
+        elif k.endswith("running_var"):
+            assert float(d.max()) <= 2e-4 * max(1.0, float(osd[k].abs().max())), (k, float(d.max()))
+        else:
+            assert float(d.max()) <= 2.2 * lr * nst, (k, float(d.max()))
+            n_all += d.numel()
+            n_bad += int((d > 2e-5).sum())
+            worst.append((int((d > 2e-5).sum()), d.numel(), k))
+    worst.sort(reverse=True)
+    assert n_bad <= 1e-3 * n_all, "parameters after two Adam steps: %d of %d differ by more than 2e-5; worst tensors %s" % (n_bad, n_all, worst[:6])
+    # eval mode after training: the inference plans are rebuilt from the weights torch's optimizer wrote
+    agent.eval()
+    fresh = _agent(cfg_d)
+    fresh.load_state_dict({k: x.detach().clone() for k, x in agent.state_dict().items()})
+    fresh.eval()
+    with torch.no_grad():
+        ra, _, _ = agent(batches[0]["states_2d"], batches[0]["states_3d"])
+        rf, _, _ = fresh(batches[0]["states_2d"], batches[0]["states_3d"])
+    assert float((ra - rf).abs().max()) <= 1e-6 * max(1.0, float(rf.abs().max()))

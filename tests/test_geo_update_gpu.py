@@ -276,23 +276,27 @@ def test_two_stream_step_is_bit_identical_to_the_one_stream_step():
     cfg = C.e2e_config(C.GEO_TRAIN_CASE)
     geo_sd, _ = C.e2e_state_dicts(SPECS)
     batch = _to_dev(C.geo_train_batches()[0])
+    from cmr_agent_amd.utils import streams
     runs = []
-    old = Tape.FORK
+    old, old_enabled = Tape.FORK, streams.ENABLED
     try:
-        for fork in (True, False):
-            Tape.FORK = fork
+        # (fork on, streams on), (fork off), (fork on, streams off = CMR_STREAMS=0, the mode of tools/_pmc_train.sh: fork_join itself would
+        # issue the side branch first there -- Tape.fork must keep the main, side order on its own)
+        for fork, enabled in ((True, True), (False, True), (True, False)):
+            Tape.FORK, streams.ENABLED = fork, enabled
             model = _model(cfg, geo_sd)
             up = GeoUpdate(model, cfg, dropout=True)
             losses = {k: float(v) for k, v in up.forward_backward(batch).items()}
             torch.cuda.synchronize()
             runs.append((losses, up.bucket.grads.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
     finally:
-        Tape.FORK = old
-    (l1, g1, r1), (l0, g0, r0) = runs
-    assert l1 == l0
-    assert torch.equal(g1, g0)
-    for k in r0:
-        assert torch.equal(r1[k], r0[k]), k
+        Tape.FORK, streams.ENABLED = old, old_enabled
+    (l1, g1, r1) = runs[0]
+    for (l0, g0, r0) in runs[1:]:
+        assert l1 == l0
+        assert torch.equal(g1, g0)
+        for k in r0:
+            assert torch.equal(r1[k], r0[k]), k
 
 
 def test_vector_attention_glue_in_one_pass_is_bit_identical():

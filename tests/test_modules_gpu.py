@@ -97,6 +97,45 @@ def test_pointnet_util_ops_vs_golden():
     G.assert_case("pointnet_util", out, atol=0, rtol=0)          # bit exact, indices and floats alike
 
 
+def test_pointnet_util_knn_grouping_vs_golden():
+    """knn=True grouping (pointnet_util.py:114-116: square_distance + argsort()[:, :, :K]) on the streaming kNN kernel, K = 5 / 16 / 40 / 64
+    (every template width, a K that is not one of them): indices bit-exact against the reference's full argsort."""
+    from cmr_agent_amd.models import pointnet_util as U
+    i = {k: v.to(DEV) for k, v in C.OP_CASES["pointnet_util_knn"]["inputs"]().items()}
+    xyz, pts = i["xyz"], i["points"]
+    new_xyz = U.index_points(xyz, U.farthest_point_sample(xyz, 64, i["start"]))
+    nx, g = U.sample_and_group(32, 0.4, 16, xyz, pts, knn=True, start_idx=i["start"])
+    out = dict(sg_xyz=nx, sg_points=g)
+    for k in (5, 16, 40, 64):
+        out["knn%d" % k] = U.knn_point(k, xyz, new_xyz)
+    G.assert_case("pointnet_util_knn", out, atol=0, rtol=0)
+
+
+def test_knn_kernel_against_a_full_sort_on_a_large_cloud():
+    """queries != candidates, candidates streamed through LDS in several tiles (N = 5000 > 2048), ragged query count, exact ties (duplicated
+    points: the smaller index first, as a stable sort)."""
+    from cmr_agent_amd import ops
+    g = torch.Generator().manual_seed(7)
+    B, S, N, K = 3, 77, 5000, 24
+    c = torch.rand(B, N, 3, generator=g) * 10 - 5
+    c[:, 1000:1100] = c[:, 2000:2100]                      # exact duplicates
+    q = torch.cat([c[:, 2000:2040], torch.rand(B, S - 40, 3, generator=g) * 10 - 5], dim=1)
+    d = ((q[:, :, None].double() - c[:, None].double()) ** 2).sum(-1)
+    ref = d.argsort(dim=-1, stable=True)[:, :, :K + 1]
+    to4 = lambda x: torch.cat([x, torch.zeros(*x.shape[:2], 1)], dim=2).reshape(-1, 4).contiguous().to(DEV)
+    got = ops.knn(to4(q), to4(c), B, S, N, K).cpu()
+    assert got.dtype == torch.int64 and int(got.min()) >= 0 and int(got.max()) < N
+    dg = d.gather(2, got)                                   # exact (float64) distances of the reported neighbours
+    tol = 4e-6 * d.gather(2, ref[:, :, K - 1:K])           # fp32 rounding of three squared differences around the K-th distance
+    assert bool((dg[:, :, 1:] >= dg[:, :, :-1] - tol).all()), "not in ascending distance"
+    assert bool((dg[:, :, -1:] <= d.gather(2, ref[:, :, K:K + 1]) + tol).all()), "a nearer candidate was missed"
+    assert all(len(set(row.tolist())) == K for row in got.reshape(-1, K)), "duplicate indices"
+    assert float((got == ref[:, :, :K]).float().mean()) > 0.999
+    # exact ties: query j < 40 IS candidate 2000 + j and its duplicate 1000 + j -> distance 0 twice, the smaller index first
+    j = torch.arange(40)
+    assert torch.equal(got[:, :40, 0], (1000 + j).expand(B, 40)) and torch.equal(got[:, :40, 1], (2000 + j).expand(B, 40))
+
+
 def test_posenc_table_vs_golden():
     from cmr_agent_amd.models.IMGPCEnDecoder import position_encoding_sine_2d
     x = C.OP_CASES["posenc_sine_2d"]["inputs"]()["x"]
@@ -119,12 +158,14 @@ def test_dataset_side_ops_on_device():
     assert (local.cpu().numpy()[0] == fx["pt2node"]["sample"]).mean() > 0.999
 
 
-@pytest.mark.parametrize("name", ["set_abstraction", "set_abstraction_msg", "feature_propagation"])
+@pytest.mark.parametrize("name", ["set_abstraction", "set_abstraction_msg", "feature_propagation", "set_abstraction_knn", "set_abstraction_msg_knn"])
 def test_pointnet2_modules_vs_golden(name):
-    """PointNetSetAbstraction / ...Msg / FeaturePropagation (pointnet_util.py:156-308) on the device ops."""
+    """PointNetSetAbstraction / ...Msg / FeaturePropagation (pointnet_util.py:156-308) on the device ops, ball-query and knn grouping."""
     from cmr_agent_amd.models import pointnet_util as U
     ctor = {"set_abstraction": lambda: U.PointNetSetAbstraction(32, 0.4, 16, 3 + 8, [16, 32], False),
             "set_abstraction_msg": lambda: U.PointNetSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]]),
+            "set_abstraction_knn": lambda: U.PointNetSetAbstraction(32, 0.4, 16, 3 + 8, [16, 32], False, knn=True),
+            "set_abstraction_msg_knn": lambda: U.PointNetSetAbstractionMsg(32, [0.3, 0.6], [8, 16], 8, [[16, 32], [16, 24]], knn=True),
             "feature_propagation": lambda: U.PointNetFeaturePropagation(8 + 16, [32, 16])}[name]
     m = ctor()
     sd = hashfill.make_state_dict(SPECS[name], name + "/")
@@ -139,3 +180,61 @@ def test_pointnet2_modules_vs_golden(name):
             a, b = m(i["xyz"], i["points"], start_idx=i["start"])
             out = {"new_xyz": a, "new_points": b}
     G.assert_case(name, out, atol=2e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", list(C.PN2_TRAIN_CASES))
+def test_pointnet2_modules_train_mode_vs_reference_autograd(name):
+    """train() mode of the three PointNet++ modules (pointnet_util.py:156-308 are ordinary trainable nn.Modules): forward with batch
+    statistics, then `(out * W).sum().backward()` through the module as ONE autograd node over the HIP tape -- output, the gradient of
+    every parameter and of the feature inputs, and the running statistics against the fixture generated from the reference's modules
+    under torch autograd (tests/golden/make_golden_train.py:run_pointnet2), ball-query / knn / group_all grouping, S = 1 propagation."""
+    from cmr_agent_amd.models import pointnet_util as U
+    kind, args, kw = C.PN2_TRAIN_CASES[name]
+    m = {"sa": U.PointNetSetAbstraction, "msg": U.PointNetSetAbstractionMsg, "fp": U.PointNetFeaturePropagation}[kind](*args, **kw)
+    hashfill.fill_state_dict(m.state_dict(), "pn2/" + name + "/")
+    m = m.to(DEV).train()
+    i = {k: v.to(DEV) for k, v in C.pn2_train_inputs(name).items()}
+    feats = [k for k in ("points", "p1", "p2") if k in i]
+    with torch.enable_grad():
+        for k in feats:
+            i[k] = i[k].clone().requires_grad_(True)
+        if kind == "fp":
+            out = m(i["xyz1"], i["xyz2"], i["p1"], i["p2"])
+        else:
+            out = m(i["xyz"], i["points"], start_idx=i["start"])[1]
+        w = C.pn2_loss_weight(name, out.shape).to(DEV)
+        (out * w).sum().backward()
+    torch.cuda.synchronize()
+    named = {name + "/out": out.detach()}
+    for k in feats:
+        named["%s/d_%s" % (name, k)] = i[k].grad
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        named["%s/grad/%s" % (name, k)] = p.grad
+    for k, b in m.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            named["%s/buf/%s" % (name, k)] = b
+        else:
+            assert int(b) == 1, k
+    fx = G.load_case(C.PN2_TRAIN_FIXTURE)
+    gmax = max(float(abs(fx[k]["sample"]).max()) for k in fx if k.startswith(name + "/grad/"))
+    errs = []
+    for k, v in named.items():
+        if "/grad/" in k and k.endswith("bias") and ("mlp_convs" in k or "conv_blocks" in k):
+            atol, rtol = 2e-4 * gmax, 0.0               # a bias in front of a BatchNorm: true gradient zero, rounding noise on both sides
+        elif "/grad/" in k or "/d_" in k:
+            atol, rtol = 2e-4 * gmax if "/grad/" in k else 2e-5 * max(1.0, float(abs(fx[k]["sample"]).max())), 1e-3
+        else:
+            atol, rtol = 2e-5, 1e-4
+        e = G.compare(k, v.detach().cpu(), fx[k], atol, rtol)
+        if e:
+            errs.append(e)
+    assert not errs, "\n  ".join(errs)
+    # eval mode afterwards sees the moved running statistics (plans are rebuilt)
+    m.eval()
+    with torch.no_grad():
+        if kind == "fp":
+            y = m(i["xyz1"], i["xyz2"], i["p1"].detach(), i["p2"].detach())
+        else:
+            y = m(i["xyz"], i["points"].detach(), start_idx=i["start"])[1]
+    assert torch.isfinite(y).all() and tuple(y.shape) == tuple(out.shape)

@@ -503,6 +503,38 @@ def test_agent_update_matches_oracle_and_reference_fixture():
     close(r_a, rr, 5e-3, "eval-mode forward after the update vs the oracle's updated weights (running means carry the bias walk)")
 
 
+def test_agent_update_with_an_embed_dim_the_fused_row_map_kernels_do_not_serve():
+    """embed_dim = 32: the 3-D branch's widths are 32 / 64, outside cmr_linear_bn_fwd_f32 / cmr_bn_linear_bwd_f32's {64, 128}.
+    Forward AND backward must fall back to the op-by-op composition (the backward used to unpack a `False`) and still match the oracle's
+    autograd."""
+    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train import AgentUpdate
+    kw = dict(cropped_img_H=128, cropped_img_W=256, num_pt=512, embed_dim=32)
+    cfg_d, cfg_c = KittiConfiguration(device=DEV, **kw), KittiConfiguration(device="cpu", **kw)
+    torch.manual_seed(3)
+    agent = CMRAgent(cfg_c)
+    sd0 = {k: v.detach().clone() for k, v in agent.state_dict().items() if not k.endswith("num_batches_tracked")}
+    B, h, w, N, S = 4, 32, 64, 512, 11
+    g = torch.Generator().manual_seed(11)
+    rnd_ = lambda *s: torch.rand(*s, generator=g)
+    ints = lambda *s: (rnd_(*s) * S).long().clamp(max=S - 1)
+    batch = dict(states_2d=rnd_(B, 64, h, w) * 0.6 - 0.3,
+                 states_3d=torch.cat([rnd_(B, 3, N) * 80 - 40, (rnd_(B, 1, N) > 0.6).float(), (rnd_(B, 1, N) > 0.5).float()], dim=1),
+                 expert_actions_r=ints(B, 1), expert_actions_t=ints(B, 2), action_r=ints(B, 1), action_t=ints(B, 2),
+                 action_logprob=rnd_(B, 3) * 2.4 - 3.6, state_value_ref=rnd_(B, 1) * 2 - 1, advantages=rnd_(B, 1) * 2 - 1)
+    agent = agent.to(DEV)
+    up = AgentUpdate(agent, cfg_d)
+    losses, (r, t, v) = up.forward_backward(_to_dev(batch))
+    torch.cuda.synchronize()
+    ol, og, (orr, ot, ov) = TO.agent_forward_backward({k: x.clone() for k, x in sd0.items()}, batch, cfg_c, True)
+    for got, ref, name in ((r, orr, "r_logits"), (t, ot, "t_logits"), (v, ov, "value")):
+        close(got, ref, 1e-4, name)
+    assert abs(float(losses[0]) - float(ol["loss"])) <= 1e-4 * max(1.0, abs(float(ol["loss"])))
+    bad = _compare_grads(up.bucket.logical_grads(), og, 2e-4)
+    assert not bad, "gradients vs oracle autograd:\n  " + "\n  ".join(bad)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_agent_update_at_the_benchmark_shape_vs_oracle(mode):
     """One forward / backward at the shape `bench.py --mode train` measures (BASELINE configs[2] per GPU: minibatch of 10 observations
