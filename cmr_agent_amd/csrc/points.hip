@@ -191,9 +191,11 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ xyz4
     float d = sqdist3(qp[0], qp[1], qp[2], cp[0], cp[1], cp[2]);
     if (d < bd[K - 1]) {     // strict: on ties the smaller index (seen first) stays ahead
       int id = c;
+      bool ins = false;      // once the new element has gone in, everything behind it SHIFTS (equal neighbours keep their order)
 #pragma unroll
       for (int j = 0; j < K; ++j) {
-        const bool sw = d < bd[j];
+        const bool sw = ins || d < bd[j];
+        ins = sw;
         const float td = sw ? bd[j] : d; const int ti = sw ? bi[j] : id;
         bd[j] = sw ? d : bd[j]; bi[j] = sw ? id : bi[j];
         d = td; id = ti;
@@ -257,9 +259,11 @@ __global__ __launch_bounds__(256) void knn_general_kernel(const float* __restric
       float d = sqdist3(qp[0], qp[1], qp[2], cp[0], cp[1], cp[2]);
       if (d < bd[KT - 1]) {     // strict: on ties the smaller index (seen first) stays ahead
         int id = c0 + c;
+        bool ins = false;       // once the new element has gone in, everything behind it SHIFTS (a carried element that equals its successor must not hop over it)
 #pragma unroll
         for (int j = 0; j < KT; ++j) {
-          const bool sw = d < bd[j];
+          const bool sw = ins || d < bd[j];
+          ins = sw;
           const float td = sw ? bd[j] : d; const int ti = sw ? bi[j] : id;
           bd[j] = sw ? d : bd[j]; bi[j] = sw ? id : bi[j];
           d = td; id = ti;

@@ -130,7 +130,14 @@ def test_knn_kernel_against_a_full_sort_on_a_large_cloud():
     assert bool((dg[:, :, 1:] >= dg[:, :, :-1] - tol).all()), "not in ascending distance"
     assert bool((dg[:, :, -1:] <= d.gather(2, ref[:, :, K:K + 1]) + tol).all()), "a nearer candidate was missed"
     assert all(len(set(row.tolist())) == K for row in got.reshape(-1, K)), "duplicate indices"
-    assert float((got == ref[:, :, :K]).float().mean()) > 0.999
+    # the indices themselves: against the same fp32 arithmetic as the reference's square_distance (fp64 orders ~1 % of the near-ties differently)
+    d32 = ((q[:, :, None] - c[:, None]) ** 2).sum(-1)
+    r32 = d32.argsort(dim=-1, stable=True)[:, :, :K]
+    bad = (got != r32).nonzero()[:12].tolist()
+    msg = "; ".join("b%d q%d k%d: got %d (d %.9g) want %d (d %.9g)" % (b_, q_, k_, int(got[b_, q_, k_]), float(d32[b_, q_, got[b_, q_, k_]]), int(r32[b_, q_, k_]),
+                                                                         float(d32[b_, q_, r32[b_, q_, k_]])) for b_, q_, k_ in bad)
+    assert float((got == r32).float().mean()) > 0.999, msg
+    assert float((got == ref[:, :, :K]).float().mean()) > 0.97
     # exact ties: query j < 40 IS candidate 2000 + j and its duplicate 1000 + j -> distance 0 twice, the smaller index first
     j = torch.arange(40)
     assert torch.equal(got[:, :40, 0], (1000 + j).expand(B, 40)) and torch.equal(got[:, :40, 1], (2000 + j).expand(B, 40))
