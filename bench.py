@@ -601,6 +601,13 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
         # the agent loop of batch i - 1, one hipGraph): a throughput mode, reported BESIDE the headline (whose step is one batch's
         # geo forward + agent loop back to back)
         pipe = None
+        if getattr(args, "replay_only", False):
+            # profiling aid (tools/r05_final.sh): nothing but the warm-up and the timed hipGraph replays runs on the device, so that a
+            # `rocprofv3 --kernel-trace --stats` of this command is the kernel census of the TIMED mode (roofline.frac_in_graph)
+            elapsed = ranks.max_over_ranks(elapsed)
+            return {"metric": "registration iters/sec (replay-only profiling run)", "value": ranks.aggregate_rate(w["B"] * args.steps, elapsed),
+                    "unit": "registration iters/s", "ms_per_step": 1e3 * elapsed / args.steps, "steps": args.steps, "warmup": args.warmup,
+                    "n_gpus": world, "dtype": dtype, "launch_mode": "hipGraph replay only"} if rank == 0 else None
         if not args.eager and not args.pipeline and with_pipeline:
             rgp = PipelinedRegistrationGraph(geo, agent, cfg, batch)
             for _ in range(args.warmup):
@@ -665,7 +672,7 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
                    for d in table if d["modelled"]]
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
         # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes)
-        traffic, traffic_src = None, "profiles/r03_pmc_path.json"
+        traffic, traffic_src = None, ("profiles/r05_pmc_path.json" if os.path.exists(os.path.join(ROOT, "profiles/r05_pmc_path.json")) else "profiles/r03_pmc_path.json")
         try:
             pmc = json.load(open(os.path.join(ROOT, traffic_src)))
             wino = [v for k, v in pmc.items() if "conv3x3_wino" in k]       # the wave-specialised kernel and both 4-wave instances, launch-weighted
@@ -675,6 +682,22 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
             pass
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
         iters = world * w["B"] * args.steps
+        # the dominant kernel INSIDE the timed hipGraph replay: launch-weighted mean duration of the Winograd kernels in the committed
+        # `rocprofv3 --kernel-trace --stats` summary of `bench.py --replay-only` (tools/r05_final.sh), priced with this run's FLOPs per launch
+        in_graph = {}
+        if dtype != "bf16" and workload == "c1":
+            try:
+                import csv
+                src = "profiles/r05_kernel_stats_replay_only.csv"
+                rows = [r for r in csv.DictReader(open(os.path.join(ROOT, src))) if "conv3x3_wino" in r["Name"]]
+                calls, ns = sum(int(r["Calls"]) for r in rows), sum(float(r["TotalDurationNs"]) for r in rows)
+                us = ns / calls / 1e3
+                fl = conv["flops"] / max(conv["launches"], 1)
+                in_graph = {"frac_in_graph": fl * 16.0 / 36.0 / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us_in_graph": us,
+                            "in_graph_source": "%s: %d launches of conv3x3_wino* in the replayed graphs of `bench.py --replay-only`, mean %.1f us; "
+                                               "x this run's %.2f GFLOP per launch x 16/36 / %.1f TFLOP/s" % (src, calls, us, fl / 1e9, FP32_MFMA_PEAK_TFLOPS)}
+            except Exception:
+                pass
         common = {"algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                   "launches_per_step": conv["launches"] / args.steps, "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                   "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9, "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
@@ -709,6 +732,7 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
                             achieved=issued, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=issued / FP32_MFMA_PEAK_TFLOPS,
                             basis="issued MFMA work (16/36 of the algorithmic multiplies)",
                             achieved_algorithmic=achieved, frac_algorithmic=achieved / FP32_MFMA_PEAK_TFLOPS,
+                            **in_graph,
                             traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src,
                             traffic_source="committed profile (the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command kept under "
                                            "profiles/), not a counter read in this run", **common)
@@ -766,6 +790,8 @@ def main():
                     help="register (default): the headline registration iteration; train: the agent's minibatch update; "
                          "train-geo: the geometric model's training step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replay-only", action="store_true", help="register mode: warm-up and the timed hipGraph replays only (no pipelined line, no "
+                    "eager HIP-event passes, no roofline): the command `rocprofv3 --kernel-trace --stats` is run on for roofline.frac_in_graph")
     ap.add_argument("--no-train-lines", action="store_true", help="register mode at 1 GPU: skip the `train` / `train_geo` sub-objects "
                     "(BASELINE.json configs[2] / configs[4] at 1 GPU) of the default line")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c1", help="c1 = the headline (default); c3 = the nuScenes shape")
@@ -807,7 +833,7 @@ def main():
     rank = ranks.rank
     line = register_main(args, ctx, args.workload, args.dtype, with_cpu=not args.no_cpu_baseline, with_pipeline=not args.no_pipeline_line,
                          with_alone=not args.no_alone_pass)
-    if world == 1 and args.workload == "c1" and not args.no_train_lines and args.dtype is None:
+    if world == 1 and args.workload == "c1" and not args.no_train_lines and not args.replay_only and args.dtype is None:
         # The other BASELINE.json configurations at 1 GPU, each with its own roofline, folded into the default line so that the driver's
         # record carries them: configs[3] (`c3`: nuScenes shape, bf16), configs[2] (`train`: per-GPU bf16 agent update), configs[4] as
         # SURVEY.md 8d's C5 (`train_geo`: Train_Geo step at 352x1216 / 65 536 points with the point prologue inside the step) and the same

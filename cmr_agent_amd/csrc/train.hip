@@ -184,6 +184,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float
   const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * per, r1 = r0 + per < rows ? r0 + per : rows;
   const f32x4 mean = ld4(stat + 4 * cq), rstd = ld4(stat + C + 4 * cq);
+  // z null with an activation (slope != 1): the mask is the sign of the BatchNorm output itself, x * scale + shift with the SAME fused
+  // multiply-add as affine_act_kernel (no residual in front of the activation) -- one map read less than reading the stored output
+  const bool mx = !z && slope != 1.f;
+  const f32x4 msc = ld4(stat + 2 * C + 4 * cq), msh = ld4(stat + 3 * C + 4 * cq);
   f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
   const bool on = rg < RG;
   int64_t r = on ? r0 + rg : r1;
@@ -199,6 +203,10 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       f32x4 d = dv[u];
+      if (mx) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) av[u][e] = __builtin_fmaf(xv[u][e], msc[e], msh[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = av[u][e] > 0.f ? d[e] : d[e] * slope;
       const f32x4 xh = (xv[u] - mean) * rstd;
@@ -208,12 +216,18 @@ __global__ __launch_bounds__(RED_THREADS) void bn_bwd_partial_kernel(const float
   }
   for (; r < r1; r += RG) {
     f32x4 d = ld4(dz + r * lddz + 4 * cq);
-    if (z) {
-      const f32x4 a = ld4(z + r * ldz + 4 * cq);
+    const f32x4 xr = ld4(x + r * ldx + 4 * cq);
+    if (z || mx) {
+      f32x4 a;
+      if (z) a = ld4(z + r * ldz + 4 * cq);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = __builtin_fmaf(xr[e], msc[e], msh[e]);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : d[e] * slope;
     }
-    const f32x4 xh = (ld4(x + r * ldx + 4 * cq) - mean) * rstd;
+    const f32x4 xh = (xr - mean) * rstd;
     s += d;
     sx += d * xh;
   }
@@ -259,13 +273,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int64_t r = i / q;
     const int c = (int)(i - r * q) * 4;
     f32x4 d = ld4(dz + r * lddz + c);
+    const f32x4 xr = ld4(x + r * ldx + c);
     if (z) {
       const f32x4 a = ld4(z + r * ldz + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : d[e] * slope;
+    } else if (slope != 1.f) {                     // mask from the BatchNorm output's sign (see bn_bwd_partial_kernel)
+      const f32x4 sc = ld4(stat + 2 * C + c), sh = ld4(stat + 3 * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = __builtin_fmaf(xr[e], sc[e], sh[e]) > 0.f ? d[e] : d[e] * slope;
     }
     if (dzm) st4(dzm + r * lddzm + c, d);          // the gradient at the activation's input: what a residual branch added there receives
-    const f32x4 xh = (ld4(x + r * ldx + c) - ld4(stat + c)) * ld4(stat + C + c);
+    const f32x4 xh = (xr - ld4(stat + c)) * ld4(stat + C + c);
     f32x4 g = ld4(stat + 2 * C + c) * (d - ld4(coef + c) - xh * ld4(coef + C + c));
     if (add) g += ld4(add + r * ldadd + c);
     st4(dx + r * lddx + c, g);

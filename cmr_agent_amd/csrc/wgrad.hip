@@ -405,8 +405,13 @@ __device__ __forceinline__ unsigned wg_pack2(float lo, float hi) {            //
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, b2));
 }
 
-template <int NCI, int NCO, int TW, bool BIAS>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+// OCC = workgroups per CU the register budget is set for.  2 (the Cin = 128 instances, round 5): 144 accumulator registers + < 112 others.
+// One workgroup per CU kept ~80 KB of loads in flight per CU and waited for them 70 % of the time (an image row tile took 4.6 us for 1 150
+// matrix-pipe cycles); two co-resident workgroups double the bytes in flight and multiply while the other waits.  The bias gradient (BIAS)
+// is one more matrix instruction per pixel block against a vector of ones (wave ci tile 0 only: 16 accumulator registers) instead of
+// per-lane fp32 sums over the staged dY rows -- the lane sums alone cost the instance 100 registers of live ranges.
+template <int NCI, int NCO, int TW, bool BIAS, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void conv3x3_wgrad_bf16_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
                                                                  int Cout, int rps, float* __restrict__ part, float* __restrict__ part_b) {
   // TW = 32 | 64 pixels per row tile (64: twice the bytes in flight per barrier interval -- the kernel waits on memory, not on its 18 / 36
   // matrix instructions per row)
@@ -418,6 +423,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
   extern __shared__ __attribute__((aligned(16))) unsigned wgb_smem[];
   unsigned* XT = wgb_smem;                              // [4][CIN][RS]
   unsigned* DT = wgb_smem + 4 * CIN * RS;               // [2][32 NCO][RS]
+  unsigned* DL = DT + 2 * 32 * NCO * RS;                // [2][32 NCO][RS] (BIAS): the bf16 rounding residues of dY, for the fp32-exact column sums
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, l31 = lane & 31;
@@ -435,10 +441,15 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.f;
 
-  // bias gradient (BIAS): every dY element of the launch is staged by exactly ONE lane of ONE workgroup (strips partition the
-  // pixels, blockIdx.y the couts), in fp32 before it is rounded -- the lane keeps the running sums of its channel quad, the workgroup
-  // writes one partial row at the end (cmr_colsum_f32 used to re-read the whole map for it: 25 us per 88x304 layer of the agent update)
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  // bias gradient (BIAS): column sums of dY = dY^T times a vector of ones on the matrix cores (every column of the accumulator tile is the
+  // sum; cmr_colsum_f32 used to re-read the whole map for it: 25 us per 88x304 layer of the agent update).  The bias is the sum of the
+  // UNROUNDED gradients: dY = hi + lo with hi = bf16(dY) (the A operand the wave holds anyway) and lo = bf16(dY - hi) staged next to it --
+  // two instructions per pixel block, error 2^-17 per element.  The waves of ci tile 0 do it (Cin = 64: each for its own pixel blocks).
+  f32x16 accb[NCO];
+#pragma unroll
+  for (int c = 0; c < NCO; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accb[c][r] = 0.f;
   // staging roles: X: lane -> (channel quad xc4, pair slot within the instruction xps, parity h); dY: (quad dc4 of 8 NCO, pair slot dps)
   constexpr int DQ = 8 * NCO, DPI = 32 / DQ;            // dY channel quads; pixel pairs per wave instruction: 4 | 2
   constexpr int NDI = NPAIRD / (4 * DPI);               // dY staging iterations per wave
@@ -495,7 +506,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
 #pragma unroll
       for (int i = 0; i < NDI; ++i) {
         const bool ok = live && r < H && x0 + 2 * dpair(i) + h < W;
-        if (BIAS) bsum += ok ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BIAS) {
+          f32x4 lo;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) lo[e] = src[i][e] - __builtin_bit_cast(float, wg_pack2(0.f, src[i][e]) & 0xffff0000u);
+          store_pairs(DL + (r & 1) * (32 * NCO * RS), dc4, dpair(i), lo, ok);
+        }
         store_pairs(DT + (r & 1) * (32 * NCO * RS), dc4, dpair(i), src[i], ok);
       }
     };
@@ -504,13 +520,26 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
     // of row y + 2 issued at the top of iteration y and stored at its bottom every iteration waited a full memory round trip (2 us
     // per row: 254 us at 10 x 88 x 304).  Two register sets alternate (rows y + 2 / y + 3) under static names, two rows per trip.
     f32x4 xa[NXI], xb2[NXI], da[NDI], dbv[NDI];
-    {
+    if (OCC == 1) {
       f32x4 r0[NXI], r1[NXI], r2[NXI], d0[NDI];
       load_xrow(y0 - 1, r0); load_xrow(y0, r1); load_xrow(y0 + 1, r2);
       load_drow(y0, d0);
       load_xrow(y0 + 2, xa);                             // stays in registers until the bottom of iteration y0
       load_drow(y0 + 1, da);
       store_xrow(y0 - 1, r0); store_xrow(y0, r1); store_xrow(y0 + 1, r2);
+      store_drow(y0, true, d0);
+    } else {                                             // half the register budget: the strip's first rows in two batches
+      {
+        f32x4 r0[NXI], r1[NXI];
+        load_xrow(y0 - 1, r0); load_xrow(y0, r1);
+        store_xrow(y0 - 1, r0); store_xrow(y0, r1);
+      }
+      f32x4 r2[NXI], d0[NDI];
+      load_xrow(y0 + 1, r2);
+      load_drow(y0, d0);
+      load_xrow(y0 + 2, xa);
+      load_drow(y0 + 1, da);
+      store_xrow(y0 + 1, r2);
       store_drow(y0, true, d0);
     }
     __syncthreads();
@@ -528,6 +557,17 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
           uint4 aw;
           aw.x = dr[c * 32 * RS + d0]; aw.y = dr[c * 32 * RS + d0 + 1]; aw.z = dr[c * 32 * RS + d0 + 2]; aw.w = dr[c * 32 * RS + d0 + 3];
           av[c] = __builtin_bit_cast(wg_bf16x8, aw);
+        }
+        if (BIAS && ci_t == 0) {                        // (wave-uniform)
+          const uint4 one8 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          const unsigned* lr = DL + (y & 1) * (32 * NCO * RS) + l31 * RS;
+#pragma unroll
+          for (int c = 0; c < NCO; ++c) {
+            uint4 lw;
+            lw.x = lr[c * 32 * RS + d0]; lw.y = lr[c * 32 * RS + d0 + 1]; lw.z = lr[c * 32 * RS + d0 + 2]; lw.w = lr[c * 32 * RS + d0 + 3];
+            accb[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[c], __builtin_bit_cast(wg_bf16x8, one8), accb[c], 0, 0, 0);
+            accb[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, lw), __builtin_bit_cast(wg_bf16x8, one8), accb[c], 0, 0, 0);
+          }
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -573,22 +613,213 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_bf16_kernel(const float* __
         const int row = cmr_mfma_row(r, lane);
         out[((int64_t)t * Cout + (co_t * NCO + c) * 32 + row) * CIN + ci_t * 32 + l31] = acc[c][t][r];
       }
-  if (BIAS) {                                           // lanes (wave, h, dps) of one channel quad -> one sum, in a fixed order
-    float* red = reinterpret_cast<float*>(wgb_smem);
-    __syncthreads();                                    // the last row tile's operands have been read
-    *reinterpret_cast<f32x4*>(red + 4 * tid) = bsum;
-    __syncthreads();
-    if (tid < 32 * NCO) {
-      const int quad = tid >> 2, e = tid & 3;
-      float t = 0.f;
+  if (BIAS && ci_t == 0 && l31 == 0) {                  // column 0 of the ones product: lanes 0 and 32 hold its 32 rows
 #pragma unroll
-      for (int w = 0; w < 4; ++w)
+    for (int c = 0; c < NCO; ++c)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
+      for (int r = 0; r < 16; ++r)
+        part_b[(int64_t)(blockIdx.x * NSPLIT + split) * Cout + (co_t * NCO + c) * 32 + cmr_mfma_row(r, lane)] = accb[c][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 weight gradient, second generation (round 5; Cin = 128, Cout % 64 == 0, maps of >= 32 768 pixels): the operands are transposed
+// by the LDS hardware on the way OUT (ds_read_b64_tr_b16) instead of by the lanes on the way in.
+//
+// conv3x3_wgrad_bf16_kernel above spends its time in the staging pass: per 4-channel load two cross-lane swaps, two packs and two scattered
+// ds_write_b32 (4- to 8-way bank conflicts at the odd row stride the transposed image needs) -- ~2 500 issue cycles per row tile and wave
+// against 576 cycles of matrix instructions (0.19 of the bf16 matrix rate standing alone, profiles/r05_wgrad_bench.txt).  Here the rows go
+// to LDS as they lie in memory, [pixel][channel] in bf16 (one v_cvt_pk pair and ONE conflict-free ds_write_b64 per load), and an operand
+// -- 8 consecutive pixels of one channel per lane -- is two ds_read_b64_tr_b16: the instruction hands lane i of a 16-lane group column i
+// of a 4-row x 16-column block.  Image = 256-byte pixel rows, 16-byte chunk c of pixel p at chunk c ^ (((p & 3) << 2) | ((p >> 2) & 3)):
+// conflict-free for the writes and the transposed reads (cdna_hip_programming.md T10, image (b)).
+//
+// Workgroup = 8 waves = 4 ci tiles x 2 cout tiles (64 couts x 128 cins x 9 taps in 144 accumulator registers per wave, two waves per
+// SIMD): the input rows are staged once per 64 couts (twice per launch at Cout = 128; the two workgroups of a strip sit on the same XCD
+// and walk in step, so the second read is an L2 hit) and all 512 lanes share the staging.  dY rows carry their bf16 rounding residues in
+// the upper 64 channels of the same 256-byte pixel row: the bias gradient is two more matrix instructions against a vector of ones
+// (hi + lo: the sum of the unrounded gradients to 2^-17).  Column strips, ring of four input rows, persistent workgroups, rows requested
+// two iterations ahead, partial layout and reduction exactly as above.
+// ------------------------------------------------------------------------------------------------------------------
+typedef short wg_s4 __attribute__((ext_vector_type(4)));
+constexpr int WT2_TW = 32, WT2_NPX = WT2_TW + 4;       // 34 halo pixels + 2 of slack (the last transposed read of a row runs two pixels past it)
+constexpr int WT2_XROW = WT2_NPX * 256;                // bytes per ring slot
+constexpr int WT2_DROW = WT2_TW * 256;                 // bytes per dY row image (64 channels hi | 64 channels lo)
+constexpr int WT2_SMEM = 4 * WT2_XROW + 2 * WT2_DROW;  // 53 248 B
+
+__device__ __forceinline__ int wt2_off(int pixel, int chunk) { return 256 * pixel + 16 * (chunk ^ (((pixel & 3) << 2) | ((pixel >> 2) & 3))); }
+__device__ __forceinline__ uint2 wt2_tr(const unsigned char* base, int byte_off) {
+  const wg_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s4*)(base + byte_off));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <bool BIAS>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_tr_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                                                       int Cout, int rps, int groups, float* __restrict__ part, float* __restrict__ part_b) {
+  constexpr int CIN = 128, TW = WT2_TW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wt2_smem[];
+  unsigned char* XI = wt2_smem;                         // [4][36 px][256 B]
+  unsigned char* DI = wt2_smem + 4 * WT2_XROW;          // [2][32 px][256 B]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci_t = wave & 3, co_h = wave >> 2;
+  // workgroup -> (strip group, cout pair): the cout pairs of one group get consecutive slots of ONE XCD (ids are dealt to the XCDs round robin)
+  const int ncp = Cout / 64;
+  int group, co_p;
+  if ((groups & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    co_p = j % ncp;
+    group = (j / ncp) * 8 + xcd;
+  } else {
+    co_p = blockIdx.x % ncp;
+    group = blockIdx.x / ncp;
+  }
+  const int ntx = (W + TW - 1) / TW, nys = (H + rps - 1) / rps;
+  const int nstrips = B * ntx * nys;
+  const int64_t img_px = (int64_t)H * W;
+
+  f32x16 acc[9], accb;
 #pragma unroll
-          for (int d = 0; d < DPI; ++d) t += red[4 * (w * 64 + hh * 32 + d * DQ + quad) + e];
-      part_b[(int64_t)blockIdx.x * Cout + co_t * (32 * NCO) + tid] = t;
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+
+  // transposed-read addresses of this lane: 16-lane group g = lane >> 4 covers channels 16 (g & 1) .. + 15 of the wave's 32-channel tile and
+  // the pixel half h = g >> 1; lane 4 q + p of the group supplies the address of block row q, columns 4 p .. 4 p + 3
+  const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3, h = g16 >> 1;
+  const int xchunk = 4 * ci_t + 2 * (g16 & 1) + (p4 >> 1);            // 16-byte chunk of the input row image
+  const int dchunk = 4 * co_h + 2 * (g16 & 1) + (p4 >> 1);            // ... of the dY row image (hi half; lo = + 8)
+  const int sub8 = 8 * (p4 & 1);
+  // the swizzled byte offsets of this lane's transposed reads do not change from row to row: [pixel block][4-pixel group]
+  int ox[2][3], od[2][2], ol[2][2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int pd = 16 * pb + 8 * h + q4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ox[pb][j] = wt2_off(pd + 4 * j, xchunk) + sub8; asm volatile("" : "+v"(ox[pb][j])); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      od[pb][j] = wt2_off(pd + 4 * j, dchunk) + sub8; asm volatile("" : "+v"(od[pb][j]));
+      ol[pb][j] = wt2_off(pd + 4 * j, dchunk + 8) + sub8; asm volatile("" : "+v"(ol[pb][j]));
     }
+  }
+  // staging roles: X: thread -> (halo pixel, channel quad); 34 x 32 = 1 088 quads over 512 threads: 3 passes (the tail re-writes its last quad)
+  const int xq = tid & 31;                                           // channel quad of the X loads
+  const int xp0 = tid >> 5;                                          // halo pixel of pass 0 (pass i: + 16 i)
+  const int dq = tid & 15, dp = tid >> 4;                            // dY: 32 pixels x 16 channel quads (this pair's 64 couts) = 512 loads
+
+  for (int strip = group; strip < nstrips; strip += groups) {
+    const int ys = strip % nys, xt = (strip / nys) % ntx, b = strip / (nys * ntx);
+    const int y0 = ys * rps, y1 = min(H, y0 + rps), x0 = xt * TW;
+    const float* xb = x + (int64_t)b * img_px * CIN;
+    const float* db = dy + (int64_t)b * img_px * Cout + co_p * 64;
+    auto xpix = [&](int i) { return min(xp0 + 16 * i, TW + 1); };
+    auto load_xrow = [&](int r, f32x4 (&dst)[3]) {
+      const int rc = min(max(r, 0), H - 1);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int xc = min(max(x0 - 1 + xpix(i), 0), W - 1);
+        dst[i] = *reinterpret_cast<const f32x4*>(xb + (unsigned)((rc * W + xc) * CIN + 4 * xq));
+      }
+    };
+    auto store_xrow = [&](int r, const f32x4 (&src)[3]) {
+      unsigned char* slot = XI + ((r + 1) & 3) * WT2_XROW;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int px = xpix(i), xx = x0 - 1 + px;
+        const bool ok = r >= 0 && r < H && xx >= 0 && xx < W;
+        const f32x4 v = ok ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<uint2*>(slot + wt2_off(px, xq >> 1) + 8 * (xq & 1)) = uint2{wg_pack2(v[0], v[1]), wg_pack2(v[2], v[3])};
+      }
+    };
+    auto load_drow = [&](int r, f32x4& dst) {
+      const int rc = min(r, H - 1), xc = min(x0 + dp, W - 1);
+      dst = *reinterpret_cast<const f32x4*>(db + (unsigned)((rc * W + xc) * Cout + 4 * dq));
+    };
+    auto store_drow = [&](int r, bool live, const f32x4& src) {
+      unsigned char* img = DI + (r & 1) * WT2_DROW;
+      const bool ok = live && r < H && x0 + dp < W;
+      const f32x4 v = ok ? src : f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned w0 = wg_pack2(v[0], v[1]), w1 = wg_pack2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(img + wt2_off(dp, dq >> 1) + 8 * (dq & 1)) = uint2{w0, w1};
+      if (BIAS) {                                         // residues dY - bf16(dY), in the upper 64 channels of the same pixel row
+        const float l0 = v[0] - __builtin_bit_cast(float, w0 << 16), l1 = v[1] - __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const float l2 = v[2] - __builtin_bit_cast(float, w1 << 16), l3 = v[3] - __builtin_bit_cast(float, w1 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(img + wt2_off(dp, 8 + (dq >> 1)) + 8 * (dq & 1)) = uint2{wg_pack2(l0, l1), wg_pack2(l2, l3)};
+      }
+    };
+
+    f32x4 xa[3], xb2[3], da, dbv;
+    {
+      {
+        f32x4 r0[3], r1[3];
+        load_xrow(y0 - 1, r0); load_xrow(y0, r1);
+        store_xrow(y0 - 1, r0); store_xrow(y0, r1);
+      }
+      f32x4 r2[3], d0;
+      load_xrow(y0 + 1, r2);
+      load_drow(y0, d0);
+      load_xrow(y0 + 2, xa);
+      load_drow(y0 + 1, da);
+      store_xrow(y0 + 1, r2);
+      store_drow(y0, true, d0);
+    }
+    __syncthreads();
+    auto multiply_row = [&](int y) __attribute__((always_inline)) {
+      const unsigned char* dimg = DI + (y & 1) * WT2_DROW;
+#pragma unroll
+      for (int pb = 0; pb < TW / 16; ++pb) {
+        const uint2 a0 = wt2_tr(dimg, od[pb][0]), a1 = wt2_tr(dimg, od[pb][1]);
+        const wg_bf16x8 av = __builtin_bit_cast(wg_bf16x8, uint4{a0.x, a0.y, a1.x, a1.y});
+        if (BIAS && ci_t == 0) {                          // (wave-uniform)
+          const uint4 one8 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          const uint2 l0 = wt2_tr(dimg, ol[pb][0]), l1 = wt2_tr(dimg, ol[pb][1]);
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, one8), accb, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(wg_bf16x8, uint4{l0.x, l0.y, l1.x, l1.y}), __builtin_bit_cast(wg_bf16x8, one8), accb, 0, 0, 0);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const unsigned char* ximg = XI + ((y + ky) & 3) * WT2_XROW;
+          // halo pixels 16 pb + 8 h .. + 11 of this lane's channel: three 4-pixel reads; tap kx takes pixels + kx .. + kx + 7
+          const uint2 r0 = wt2_tr(ximg, ox[pb][0]), r1 = wt2_tr(ximg, ox[pb][1]), r2 = wt2_tr(ximg, ox[pb][2]);
+          const uint4 b0 = {r0.x, r0.y, r1.x, r1.y};
+          const uint4 b1 = {__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                            __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)};
+          const uint4 b2 = {r0.y, r1.x, r1.y, r2.x};
+          acc[3 * ky] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b0), acc[3 * ky], 0, 0, 0);
+          acc[3 * ky + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b1), acc[3 * ky + 1], 0, 0, 0);
+          acc[3 * ky + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(wg_bf16x8, b2), acc[3 * ky + 2], 0, 0, 0);
+        }
+      }
+    };
+    for (int y = y0; y < y1; y += 2) {
+      load_xrow(y + 3, xb2);
+      load_drow(y + 2, dbv);
+      multiply_row(y);
+      store_xrow(y + 2, xa);
+      store_drow(y + 1, y + 1 < y1, da);
+      __syncthreads();
+      if (y + 1 >= y1) break;                           // (uniform)
+      load_xrow(y + 4, xa);
+      load_drow(y + 3, da);
+      multiply_row(y + 1);
+      store_xrow(y + 3, xb2);
+      store_drow(y + 2, y + 2 < y1, dbv);
+      __syncthreads();
+    }
+  }
+  const int l31 = lane & 31;
+  float* out = part + (int64_t)group * 9 * Cout * CIN;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      out[((int64_t)t * Cout + (co_p * 2 + co_h) * 32 + cmr_mfma_row(r, lane)) * CIN + ci_t * 32 + l31] = acc[t][r];
+  if (BIAS && ci_t == 0 && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part_b[(int64_t)group * Cout + (co_p * 2 + co_h) * 32 + cmr_mfma_row(r, lane)] = accb[r];
   }
 }
 
@@ -1030,6 +1261,14 @@ inline WgLdsPlan wgrad_lds_plan(int B, int H, int W, int Cin, int Cout) {
   return p;
 }
 
+// bf16 weight gradient: maps of at least this many pixels take the transposed-read kernel (below, the fixed costs of either kernel -- partial
+// write-back, reduction -- dominate and the first-generation kernel's finer slices win)
+constexpr int64_t WGB_TR_MIN_PX = 32768;
+#ifdef CMR_AB_SWITCHES
+static int g_wgrad_tr = 1;
+#else
+static constexpr int g_wgrad_tr = 1;
+#endif
 #ifdef CMR_AB_SWITCHES
 static int g_lwgrad_lds = 1;
 #else
@@ -1046,6 +1285,11 @@ extern "C" int cmr_set_linear_wgrad_variant(int lds_staged) {
   return old;
 }
 
+extern "C" int cmr_set_wgrad_bf16_variant(int transposed_reads) {
+  const int old = g_wgrad_tr;
+  g_wgrad_tr = transposed_reads ? 1 : 0;
+  return old;
+}
 extern "C" int cmr_set_wgrad_variant(int lds_staged) {
   const int old = g_wgrad_lds;
   g_wgrad_lds = lds_staged ? 1 : 0;
@@ -1136,13 +1380,42 @@ extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, 
   CMR_REQUIRE((Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (Cin == 64 || Cin == 128));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff);       // 32-bit element offsets within an image batch
   const int nci = Cin / 32, nsplit = 4 / nci;
+  if (Cin == 128 && Cout % 64 == 0 && (int64_t)B * H * W >= WGB_TR_MIN_PX && g_wgrad_tr) {
+    // second-generation kernel (hardware-transposed operand reads, 64 couts per 8-wave workgroup): one persistent workgroup per CU
+    const int ncp = Cout / 64;
+    int groups = 256 / ncp;
+    const int ntx = (W + WT2_TW - 1) / WT2_TW;
+    int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)8 * groups));
+    if (rps < 4) rps = 4;
+    if (rps > H) rps = H;
+    const int64_t nstrips = (int64_t)B * ntx * ((H + rps - 1) / rps);
+    if (groups > nstrips) groups = (int)nstrips;
+    const int64_t part_floats = (int64_t)groups * 9 * Cout * Cin;
+    CMR_REQUIRE(ws_bytes >= (part_floats + (db ? (int64_t)groups * Cout : 0)) * (int64_t)sizeof(float));
+    float* part = (float*)ws;
+    float* part_b = db ? part + part_floats : nullptr;
+    static CmrSmemCache granted_b{}, granted_n{};
+    if (db) {
+      if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_tr_kernel<true>), WT2_SMEM, granted_b) != CMR_OK) return CMR_ELAUNCH;
+      hipLaunchKernelGGL(conv3x3_wgrad_bf16_tr_kernel<true>, dim3(groups * ncp), dim3(512), WT2_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
+    } else {
+      if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_tr_kernel<false>), WT2_SMEM, granted_n) != CMR_OK) return CMR_ELAUNCH;
+      hipLaunchKernelGGL(conv3x3_wgrad_bf16_tr_kernel<false>, dim3(groups * ncp), dim3(512), WT2_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
+    }
+    hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part, groups, Cout, Cin, dw);
+    if (db) hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, stream, (const float*)part_b, groups, Cout, db);
+    return cmr_launch_status();
+  }
   // persistent workgroups, one per CU (288 accumulator registers per wave at two cout tiles), over all cout groups; ~8 column strips
   // of >= 4 rows per workgroup
-  const int tw = ((W + 63) / 64 * 64 <= (W + 31) / 32 * 32) ? 64 : 32;     // 64-pixel row tiles unless they pad the width more than 32-pixel ones (152 -> 192 vs 160)
+  // Cin = 128: 32-pixel row tiles and two workgroups per CU (see the kernel's OCC note); Cin = 64: 64-pixel row tiles unless they pad the
+  // width more than 32-pixel ones (152 -> 192 vs 160)
+  const int occ = nci == 4 ? 2 : 1;
+  const int tw = occ == 2 ? 32 : (((W + 63) / 64 * 64 <= (W + 31) / 32 * 32) ? 64 : 32);
   // two cout tiles per workgroup (288 accumulator registers) spill at Cin = 128 and with 64-pixel tiles (measured slower): narrow Cin = 64 maps only
   // (with the bias sums the two-tile instance spills 176 registers: one tile then)
   const int nco = (nci == 2 && tw == 32 && Cout % 64 == 0 && !db) ? 2 : 1;
-  int groups = 256 / (Cout / (32 * nco));
+  int groups = 256 * occ / (Cout / (32 * nco));
   const int ntx = (W + tw - 1) / tw;
   int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)8 * groups));
   if (rps < 4) rps = 4;
@@ -1151,32 +1424,30 @@ extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, 
   if (groups > nstrips) groups = (int)nstrips;
   if (groups > 512) groups = 512;                        // workspace bound of cmr_conv3x3_wgrad_workspace_bytes
   const int64_t part_floats = (int64_t)groups * nsplit * 9 * Cout * Cin;
-  CMR_REQUIRE(ws_bytes >= (part_floats + (db ? (int64_t)groups * Cout : 0)) * (int64_t)sizeof(float));
+  CMR_REQUIRE(ws_bytes >= (part_floats + (db ? (int64_t)groups * nsplit * Cout : 0)) * (int64_t)sizeof(float));
   const int rs = tw / 2 + 5;
-  const size_t smem = ((size_t)4 * Cin * rs + 2 * 32 * nco * rs) * sizeof(unsigned);
+  const size_t smem = ((size_t)4 * Cin * rs + (db ? 4 : 2) * 32 * nco * rs) * sizeof(unsigned);
   float* part = (float*)ws;
   float* part_b = db ? part + part_floats : nullptr;
   dim3 grid(groups, Cout / (32 * nco));
-#define CMR_WGB_LAUNCH(NCI_, NCO_, TW_, BIAS_)                                                                                        \
+#define CMR_WGB_LAUNCH(NCI_, NCO_, TW_, BIAS_, OCC_)                                                                                  \
   {                                                                                                                                   \
     static CmrSmemCache granted{};                                                                                                    \
-    if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_, BIAS_>), smem, granted) != CMR_OK) return CMR_ELAUNCH; \
-    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_, BIAS_>), grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, rps, part, part_b);   \
+    if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_, BIAS_, OCC_>), smem, granted) != CMR_OK) return CMR_ELAUNCH; \
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16_kernel<NCI_, NCO_, TW_, BIAS_, OCC_>), grid, dim3(256), smem, stream, x, dy, B, H, W, Cout, rps, part, part_b);   \
   }
   if (db) {
-    if (nci == 4 && tw == 64) CMR_WGB_LAUNCH(4, 1, 64, true)
-    else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32, true)
-    else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64, true)
-    else CMR_WGB_LAUNCH(2, 1, 32, true)
-  } else if (nci == 4 && tw == 64) CMR_WGB_LAUNCH(4, 1, 64, false)
-  else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32, false)
-  else if (nco == 2) CMR_WGB_LAUNCH(2, 2, 32, false)
-  else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64, false)
-  else CMR_WGB_LAUNCH(2, 1, 32, false)
+    if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32, true, 2)
+    else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64, true, 1)
+    else CMR_WGB_LAUNCH(2, 1, 32, true, 1)
+  } else if (nci == 4) CMR_WGB_LAUNCH(4, 1, 32, false, 2)
+  else if (nco == 2) CMR_WGB_LAUNCH(2, 2, 32, false, 1)
+  else if (tw == 64) CMR_WGB_LAUNCH(2, 1, 64, false, 1)
+  else CMR_WGB_LAUNCH(2, 1, 32, false, 1)
 #undef CMR_WGB_LAUNCH
   hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part,
                      groups * nsplit, Cout, Cin, dw);
-  if (db) hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, stream, (const float*)part_b, groups, Cout, db);
+  if (db) hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, stream, (const float*)part_b, groups * nsplit, Cout, db);
   return cmr_launch_status();
 }
 

@@ -806,8 +806,9 @@ def affine_act(x, scale=None, shift=None, res=None, rscale=None, rshift=None, sl
 
 
 def bn_bwd(dz, z, slope, x, stat, dgamma=None, dbeta=None, add=None, out=None, want_masked=False):
-    """Backward of [BatchNorm(train) -> LeakyReLU(slope)] (z None: no activation) -> dx [rows, C]; want_masked: -> (dx, dz * act'(z)), the
-    second one being the gradient a residual branch added in front of the activation receives."""
+    """Backward of [BatchNorm(train) -> LeakyReLU(slope)] -> dx [rows, C].  z None: slope 1 = no activation, any other slope = the mask is
+    recomputed from x and stat (the activation sat directly on the BatchNorm output); want_masked: -> (dx, dz * act'(z)), the second one
+    being the gradient a residual branch added in front of the activation receives."""
     _rows(dz), _rows(x)
     rows, C = x.shape
     if out is None:

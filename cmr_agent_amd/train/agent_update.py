@@ -264,7 +264,8 @@ class AgentUpdate:
             dc = ops.pool_act_bwd(g.contiguous(), st["d"], ph, pw, SLOPE2D)                 # through the pool and conv b's LeakyReLU
             ops.conv3x3_wgrad(st["z"], dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"))
             dz = self._dgrad(dc, st["nb"], c, 2 * s)
-            da = self._bn_bwd(dz.view(-1, c), st["z"].view(-1, c), SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
+            # (activation mask from the sign of the BatchNorm output, recomputed from `a`: the stored z is not read again)
+            da = self._bn_bwd(dz.view(-1, c), None, SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
             ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"), db=bk.g(st["na"] + ".bias"))
             if s > 0:
                 g = self._dgrad(da, st["na"], c, 2 * s - 1)
@@ -291,7 +292,7 @@ class AgentUpdate:
             gw2 = bk.g(p + "net.3.weight")
             ops.linear_wgrad(dh2raw, r["h1"], gw2, gw2.shape[1], db=bk.g(p + "net.3.bias"))       # bias gradient = column sums of dh2raw, same launch
             dh1 = ops.linear(dh2raw, self._wT(p + "net.3.weight"))
-            dh1raw = self._bn_bwd(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], p + "net.1")
+            dh1raw = self._bn_bwd(dh1, None, SLOPE3D, r["h1raw"], r["st1"], p + "net.1")
             w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
             if i == 0:
                 ops.linear_wgrad(dh1raw, r["x"], gw1, gw1.shape[1], db=bk.g(p + "net.0.bias"))

@@ -71,6 +71,11 @@ class Tape:
     # what the agent update's 2-D / 3-D fork gives (train/agent_update.py).  CMR_TAPE_FORK=0 runs them one after the other.
     FORK = __import__("os").environ.get("CMR_TAPE_FORK", "1") == "1"
 
+    # CUs the MAIN branch's persistent convolution kernels may occupy while a side branch runs next to it (0 = all).  At the C5 shape the
+    # image tower's launches fill every CU for ~600 us at a time and the point chain's 5 us reductions queue behind them; a reservation
+    # trades image-side throughput for the short chain's latency.  Measured; CMR_TAPE_MAIN_CUS sets it.
+    MAIN_CUS = int(__import__("os").environ.get("CMR_TAPE_MAIN_CUS", "0"))
+
     def fork(self, side_fn, main_fn, tag="tape"):
         """-> (side_fn(), main_fn()): main_fn's ops are issued first (host order = the sequential order main, side: dropout sites keep their
         numbers), side_fn's on a side stream; the two may share no Var.  The backward closures each of them records run as ONE node that
@@ -93,7 +98,16 @@ class Tape:
             outer.extend(mn)
             outer.extend(sn)
             return sd, m
-        (sd, sn), (m, mn) = fork_join(lambda: run(side_fn), lambda: run(main_fn), tag=tag)
+        def budgeted(fn):
+            if not self.MAIN_CUS:
+                return fn
+
+            def g():
+                with ops.conv_cu_budget(self.MAIN_CUS):
+                    return fn()
+            return g
+
+        (sd, sn), (m, mn) = fork_join(lambda: run(side_fn), budgeted(lambda: run(main_fn)), tag=tag)
 
         def back(nodes):
             for fn in reversed(nodes):
@@ -104,7 +118,7 @@ class Tape:
             # first branch that asks would be read by the other one without an edge between the two streams
             if self._flatT is None:
                 self._flatT = self.bucket.transposed()
-            fork_join(lambda: back(sn), lambda: back(mn), tag=tag)
+            fork_join(lambda: back(sn), budgeted(lambda: back(mn)), tag=tag)
 
         outer.append(bwd)
         return sd, m
@@ -297,7 +311,8 @@ class Tape:
             else:
                 if res is not None:
                     self.give(res, y.g)
-                dx = ops.bn_bwd(y.g, None if slope == 1.0 else y.v, slope, x.v, stat, dg, db)
+                # (no residual: the activation's mask is the sign of the BatchNorm output, recomputed from x -- y is not read again)
+                dx = ops.bn_bwd(y.g, None if (slope == 1.0 or res is None) else y.v, slope, x.v, stat, dg, db)
             fin_g(), fin_b()
             self.give(x, dx, owned=True)
         self.nodes.append(bwd)

@@ -435,8 +435,10 @@ int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C, float eps
 int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const float* shift, const float* res, int64_t ldres,
                        const float* rscale, const float* rshift, float* y, int64_t ldy, int64_t rows, int C, float slope,
                        hipStream_t stream);
-/* Backward of [BatchNorm(train) -> LeakyReLU]: dz = gradient w.r.t. the activation output z (z null: no activation),
- * x = the BatchNorm input, stat from cmr_bn_stats_f32.  dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add),
+/* Backward of [BatchNorm(train) -> LeakyReLU]: dz = gradient w.r.t. the activation output z, x = the BatchNorm input, stat from
+ * cmr_bn_stats_f32.  z null: slope 1 = no activation; slope != 1 = the activation sat directly on the BatchNorm output (no residual in
+ * between) and its mask is taken from the sign of x * scale + shift, recomputed with cmr_affine_act_f32's own fused multiply-add (the
+ * stored output is then not read: one map pass less in each of the two sweeps).  dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add),
  * dgamma = sum dy xhat, dbeta = sum dy (written when non-null).  dzm (optional): receives dy = dz * act'(z), the gradient at the
  * activation's input -- what a residual branch added in front of the activation gets (`lrelu(BN(x) + res)`, ImageResNet.py:36-40,
  * PointNN.py:282), from the same pass instead of a separate activation-backward sweep. */

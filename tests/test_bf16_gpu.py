@@ -134,7 +134,10 @@ def test_registration_iteration_bf16_convolutions_meet_the_bf16_bars(case):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 12, 20, 128, 128), (4, 32, 48, 128, 128), (3, 37, 51, 128, 64), (2, 44, 152, 64, 128), (1, 9, 13, 64, 64),
-                                            (2, 5, 2, 128, 32), (10, 22, 76, 128, 128)])
+                                            (2, 5, 2, 128, 32), (10, 22, 76, 128, 128),
+                                            # >= 32 768 pixels at Cin 128: the transposed-read kernel (ds_read_b64_tr_b16): ragged width (130 = 4 tiles + 2
+                                            # pixels), one cout pair and two, strips that end mid-image, an odd row count
+                                            (4, 64, 130, 128, 128), (5, 45, 152, 128, 64), (3, 88, 160, 128, 256)])
 def test_conv3x3_weight_gradient_bf16(B, H, W, cin, cout):
     """cmr_conv3x3_wgrad_bf16_f32 (v_mfma_f32_32x32x16_bf16, rows transposed into LDS as (even, odd) pixel pairs): exact against torch on
     bf16-ROUNDED operands in float64 up to fp32 accumulation order, and within bf16 rounding of the fp32 gradient; ragged widths, odd

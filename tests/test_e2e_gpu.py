@@ -274,8 +274,9 @@ def test_entry_points_with_the_module_api_and_on_disk_frames(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.path.join(root, "tests"))
     data = tmp_path / "kitti"
-    _write_dataset(str(data), seqs=(0, 9), frames=4, with_image_3=False, n_raw=3000, img_hw=(200, 340))     # half size 100 x 170 >= the 96 x 160 crop
-    common = ["--img", "96x160", "--num-pt", "2048", "--batch-size", "2", "--data-root", str(data)]
+    _write_dataset(str(data), seqs=(0, 9), frames=8, with_image_3=False, n_raw=6000, img_hw=(200, 340))     # half size 100 x 170 >= the 96 x 160 crop
+    # (num_pt >= 8 num_node = 10 240: the node candidates are drawn without replacement, KittiDataset.py:356; the 6 000-point clouds are tiled, :186-190)
+    common = ["--img", "96x160", "--num-pt", "10240", "--batch-size", "2", "--data-root", str(data)]
     out = tmp_path / "geo"
     r = subprocess.run([sys.executable, os.path.join(root, "Train_Geo.py"), "--batches", "2", "--epochs", "2", "--val-interval", "2", "--module-api",
                         "--out", str(out)] + common, capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -286,7 +287,7 @@ def test_entry_points_with_the_module_api_and_on_disk_frames(tmp_path):
     assert len(train) == 4 and len(val) == 2
     assert all(l["train_loss/loss"] == l["train_loss/loss"] and abs(l["train_loss/loss"]) < 1e4 for l in train)
     assert val[1]["val_loss/loss"] != val[0]["val_loss/loss"]                     # torch.optim moved the weights the inference path reads
-    assert "4 samples in train set..." in r.stdout and "4 samples in val set..." in r.stdout
+    assert "8 samples in train set..." in r.stdout and "8 samples in val set..." in r.stdout
     out = tmp_path / "agent"
     r = subprocess.run([sys.executable, os.path.join(root, "Train_Agent.py"), "--batches", "4", "--module-api", "--out", str(out)] + common,
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
@@ -295,7 +296,7 @@ def test_entry_points_with_the_module_api_and_on_disk_frames(tmp_path):
     upd = [l for l in logs if "train_loss/BC_Loss" in l]
     assert len(upd) == 1 and upd[0]["minibatches"] == 8
     assert all(abs(upd[0][k]) < 1e4 for k in ("train_loss/BC_Loss", "train_loss/PPO_Loss"))
-    r = subprocess.run([sys.executable, os.path.join(root, "Test_Agent.py"), "--pairs", "2", "--img", "96x160", "--num-pt", "2048", "--data-root", str(data)],
+    r = subprocess.run([sys.executable, os.path.join(root, "Test_Agent.py"), "--pairs", "2", "--img", "96x160", "--num-pt", "10240", "--data-root", str(data)],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "Registration Recall:" in r.stdout
