@@ -125,7 +125,140 @@ __global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same tail with the weights stored TRANSPOSED, [in][out4] (round 5).  In the kernel above a wave produces output channels one
+// weight row at a time and reduces each dot product over its 64 lanes (six xor-shuffle steps per row: 96 cross-lane operations per batch
+// of 16 rows, two batches per 256-wide layer) -- 35 us per agent step on the serial chain of a registration for 1.3 MFLOP.  Here lane l of
+// every wave owns the outputs 4 l .. 4 l + 3 and wave w the input slice [w k / 16, (w + 1) k / 16): each lane issues ALL its weight loads
+// (k / 16 <= 16 float4, coalesced over the outputs: a wave reads whole 1 KB rows of W^T) before the first multiply -- one memory round trip
+// per layer, no cross-lane operation at all -- and the 16 slices meet in LDS (16 x 256 partial sums, one add chain per output in a fixed
+// order).  The global average pool reads its sample as float4 channel quads, 13 - 14 pixels per thread, all in flight.
+// ------------------------------------------------------------------------------------------------------------------
+struct AtHead { const float *w0t, *b0, *w1t, *b1, *w2t, *b2; int n0, n1, n2, ld2; float* out; int ldo; int64_t* act; int degree; };
+struct AtArgs {
+  const float* x; int npix;
+  const float *w24t, *b24, *w26t, *b26;
+  const float* e3d;
+  AtHead h[3];
+  float slope;
+  int num_steps;
+};
+
+// y[0 .. n_out) = act(b + x W^T) with wt = W^T stored [k][ldw] (ldw % 4 == 0, zero padded columns), x in LDS, k % 16 == 0, k <= 256,
+// n_out <= 256.  part: LDS scratch [16][256].  All 1 024 threads call it; y may be LDS or global.
+__device__ __forceinline__ void at_gemv(const float* __restrict__ wt, int ldw, const float* __restrict__ bias, const float* xin, int k, int n_out,
+                                        float* yout, bool lrelu, float slope, float (*part)[256], int wave, int lane) {
+  const int ks = k >> 4;                               // input slice of this wave: ks <= 16 rows of W^T
+  const int c = 4 * lane;
+  const bool on = c < ldw;
+  f32x4 wv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int kk = wave * ks + (i < ks ? i : ks - 1);
+    wv[i] = *reinterpret_cast<const f32x4*>(wt + (int64_t)kk * ldw + (on ? c : 0));
+  }
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float xv = i < ks ? xin[wave * ks + i] : 0.f;     // LDS broadcast
+    s += wv[i] * xv;
+  }
+  *reinterpret_cast<f32x4*>(&part[wave][c]) = s;
+  __syncthreads();
+  const int tid = wave * 64 + lane;
+  if (tid < n_out) {
+    float t = part[0][tid];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) t += part[w][tid];
+    t += bias[tid];
+    yout[tid] = lrelu ? (t > 0.f ? t : t * slope) : t;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void agent_heads_t_kernel(const AtArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[16][256];
+  __shared__ __attribute__((aligned(16))) float va[AH_C], vb[AH_C], state[AH_STATE], h0[AH_MAXW], h1[AH_MAXW];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // ---- AvgPool2d((H, W)): thread = (channel quad q of 32, pixel group g of 32); every load of the thread in flight at once
+  {
+    const int q = tid & 31, g = tid >> 5;
+    const float* xp = a.x + (int64_t)b * a.npix * AH_C + 4 * q;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int p0 = g; p0 < a.npix; p0 += 32 * 16) {
+      f32x4 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int p = p0 + 32 * i;
+        v[i] = *reinterpret_cast<const f32x4*>(xp + (int64_t)(p < a.npix ? p : p0) * AH_C);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s += p0 + 32 * i < a.npix ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // 32 pixel groups x 128 channels of partial sums through the [16][256] scratch viewed as [32][128]
+    float* red = &part[0][0];
+    *reinterpret_cast<f32x4*>(red + g * AH_C + 4 * q) = s;
+    __syncthreads();
+    if (tid < AH_C) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) t += red[i * AH_C + tid];
+      va[tid] = t / (float)a.npix;
+    }
+    if (tid >= AH_C && tid < 2 * AH_C) state[tid] = a.e3d[(int64_t)b * AH_C + tid - AH_C];
+    __syncthreads();
+  }
+  at_gemv(a.w24t, AH_C, a.b24, va, AH_C, AH_C, vb, true, a.slope, part, wave, lane);
+  at_gemv(a.w26t, AH_C, a.b26, vb, AH_C, AH_C, state, false, a.slope, part, wave, lane);
+  const AtHead& hd = a.h[blockIdx.y];
+  at_gemv(hd.w0t, hd.n0, hd.b0, state, AH_STATE, hd.n0, h0, true, a.slope, part, wave, lane);
+  at_gemv(hd.w1t, hd.n1, hd.b1, h0, hd.n0, hd.n1, h1, true, a.slope, part, wave, lane);
+  at_gemv(hd.w2t, hd.ld2, hd.b2, h1, hd.n1, hd.n2, hd.out + (int64_t)b * hd.ldo, false, a.slope, part, wave, lane);
+  if (hd.act != nullptr && a.num_steps > 0) {                 // (the logits were written before at_gemv's closing barrier)
+    const int d = hd.degree;
+    if (tid < d) {
+      const float* p = hd.out + (int64_t)b * hd.ldo + tid * a.num_steps;
+      float best = p[0];
+      int bi = 0;
+      for (int i = 1; i < a.num_steps; ++i) {
+        const float v = p[i];
+        if (v > best) { best = v; bi = i; }
+      }
+      hd.act[(int64_t)b * d + tid] = bi;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int cmr_agent_heads_t_f32(const float* x, int B, int npix, const float* w24t, const float* b24, const float* w26t, const float* b26,
+                                     const float* e3d,
+                                     const float* r_w0t, const float* r_b0, const float* r_w1t, const float* r_b1, const float* r_w2t, const float* r_b2,
+                                     int r_n0, int r_n1, int r_n2, float* r_out, int r_ldo,
+                                     const float* t_w0t, const float* t_b0, const float* t_w1t, const float* t_b1, const float* t_w2t, const float* t_b2,
+                                     int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
+                                     const float* v_w0t, const float* v_b0, const float* v_w1t, const float* v_b1, const float* v_w2t, const float* v_b2,
+                                     int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                                     int num_steps, int degree_r, int degree_t, int64_t* r_act, int64_t* t_act, float slope, hipStream_t stream) {
+  CMR_REQUIRE(x && w24t && b24 && w26t && b26 && e3d && B > 0 && npix > 0);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w24t) && cmr_aligned16(w26t));
+  AtArgs a{};
+  a.x = x; a.npix = npix; a.w24t = w24t; a.b24 = b24; a.w26t = w26t; a.b26 = b26; a.e3d = e3d; a.slope = slope;
+  CMR_REQUIRE((!r_act && !t_act) || (num_steps > 0 && degree_r > 0 && degree_t > 0 && degree_r * num_steps <= r_n2 && degree_t * num_steps <= t_n2));
+  a.num_steps = (r_act || t_act) ? num_steps : 0;
+  a.h[0] = AtHead{r_w0t, r_b0, r_w1t, r_b1, r_w2t, r_b2, r_n0, r_n1, r_n2, (r_n2 + 3) / 4 * 4, r_out, r_ldo, r_act, degree_r};
+  a.h[1] = AtHead{t_w0t, t_b0, t_w1t, t_b1, t_w2t, t_b2, t_n0, t_n1, t_n2, (t_n2 + 3) / 4 * 4, t_out, t_ldo, t_act, degree_t};
+  a.h[2] = AtHead{v_w0t, v_b0, v_w1t, v_b1, v_w2t, v_b2, v_n0, v_n1, v_n2, (v_n2 + 3) / 4 * 4, v_out, v_ldo, nullptr, 0};
+  for (int i = 0; i < 3; ++i) {
+    const AtHead& h = a.h[i];
+    CMR_REQUIRE(h.w0t && h.w1t && h.w2t && h.b0 && h.b1 && h.b2 && h.out && h.n2 > 0 && h.n2 <= 256 && h.ldo >= h.n2);
+    CMR_REQUIRE(h.n0 > 0 && h.n0 <= AH_MAXW && h.n0 % 16 == 0 && h.n1 > 0 && h.n1 <= AH_MAXW && h.n1 % 16 == 0);
+    CMR_REQUIRE(cmr_aligned16(h.w0t) && cmr_aligned16(h.w1t) && cmr_aligned16(h.w2t));
+  }
+  hipLaunchKernelGGL(agent_heads_t_kernel, dim3(B, 3), dim3(AH_THREADS), 0, stream, a);
+  return cmr_launch_status();
+}
 
 extern "C" int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const float* b24, const float* w26,
                                    const float* b26, const float* e3d,

@@ -59,9 +59,15 @@ class CMRAgent(Planned):
         p["conv0_img"] = _pack.conv9(e[0], e[1], cin_slice=slice(0, f))
         p["conv0_proj"] = _pack.conv9(e[0], e[1], cin_slice=slice(f, 2 * f))
         p["c24"], p["c26"] = _pack.lin(e[24]), _pack.lin(e[26])
+        tr = lambda wb: (wb[0].t().contiguous(), wb[1])          # W^T [in, out4]: operand of cmr_agent_heads_t_f32
+        p["c24t"], p["c26t"] = tr(p["c24"]), tr(p["c26"])
         for name in ("policy_r", "policy_t", "value"):
             m = getattr(self, name)
             p[name] = [_pack.lin(m[0]), _pack.lin(m[2]), _pack.lin(m[4])]
+            p[name + "_t"] = [tr(x) for x in p[name]]
+        # the transposed-weight tail serves hidden widths that are multiples of 16 up to 256 and a 128-wide 2-D embedding (embed_dim 64)
+        p["tail_t"] = 2 * self.config.embed_dim == 128 and all(p[n][0][0].shape[0] % 16 == 0 and p[n][1][0].shape[0] % 16 == 0 and p[n][0][0].shape[0] <= 256
+                                       and p[n][1][0].shape[0] <= 256 and p[n][0][0].shape[1] == 256 for n in ("policy_r", "policy_t", "value"))
         # 3-D branch, layers 1..3: the input is cat([feat, broadcast(global max)]) (CMRAgent.py:95-99).  Split every
         # weight that multiplies it into the streamed half (feat) and the per-sample half (max), which becomes a
         # per-batch bias computed by a skinny GEMM each step.
@@ -102,6 +108,7 @@ class CMRAgent(Planned):
         return g
 
     FUSED_TAIL = True
+    TAIL_T = True           # ... on the transposed-weight kernel (cmr_agent_heads_t_f32); False: the row-per-wave kernel
 
     def _embed_2d(self, state2d, B, split):
         p = self.plan()
@@ -158,8 +165,12 @@ class CMRAgent(Planned):
             # AvgPool2d((H, W)) + the two 1x1 convs + the three heads: one launch (13 otherwise)
             # ... and the deterministic actions (argmax per group of num_steps logits): attached to the logits, picked up by
             # action_from_logits(deterministic=True) instead of two more launches per step
-            out, acts = ops.agent_heads(xr, B, kh * kw, p["c24"], p["c26"], e3d, heads, SLOPE,
-                                        actions=(self.config.num_steps, self.degree_r, self.degree_t))
+            if self.TAIL_T and p["tail_t"]:
+                out, acts = ops.agent_heads_t(xr, B, kh * kw, p["c24t"], p["c26t"], e3d, [p[name + "_t"] for name in ("policy_r", "policy_t", "value")],
+                                              SLOPE, actions=(self.config.num_steps, self.degree_r, self.degree_t))
+            else:
+                out, acts = ops.agent_heads(xr, B, kh * kw, p["c24"], p["c26"], e3d, heads, SLOPE,
+                                            actions=(self.config.num_steps, self.degree_r, self.degree_t))
         else:
             acts = None
             x = ops.colmean(xr, B, kh * kw)                  # AvgPool2d((H, W)) = per-sample channel mean

@@ -384,6 +384,26 @@ def agent_heads(x, B, npix, c24, c26, e3d, heads, slope, actions=None):
     return outs, (ar, at)
 
 
+def agent_heads_t(x, B, npix, c24t, c26t, e3d, heads_t, slope, actions=None):
+    """agent_heads with every weight TRANSPOSED at plan time: c24t / c26t / heads_t[i][j] are (W^T [in, out4], bias [out4]) pairs
+    (models/CMRAgent.py:_build_plan); one memory round trip per layer instead of per batch of weight rows + cross-lane reductions."""
+    outs, args = [], []
+    for (w0, b0), (w1, b1), (w2, b2) in heads_t:
+        o = torch.empty((B, w2.shape[1]), dtype=f32, device=x.device)
+        outs.append(o)
+        args += [_p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), w0.shape[1], w1.shape[1], w2.shape[1], _p(o), o.stride(0)]
+    if actions is None:
+        _lib.call("cmr_agent_heads_t_f32", _p(_rows(x)), B, npix, _p(c24t[0]), _p(c24t[1]), _p(c26t[0]), _p(c26t[1]), _p(e3d), *args,
+                  0, 0, 0, None, None, float(slope), _stream())
+        return outs
+    S, dr, dt = actions
+    ar = torch.empty((B, dr), dtype=torch.int64, device=x.device)
+    at = torch.empty((B, dt), dtype=torch.int64, device=x.device)
+    _lib.call("cmr_agent_heads_t_f32", _p(_rows(x)), B, npix, _p(c24t[0]), _p(c24t[1]), _p(c26t[0]), _p(c26t[1]), _p(e3d), *args,
+              int(S), int(dr), int(dt), _p(ar), _p(at), float(slope), _stream())
+    return outs, (ar, at)
+
+
 def ln64_linear(x, wf_x, bias_x, gamma, beta, eps, y=None, wf_y=None, bias_y=None):
     """LayerNorm(64) + projection of x rows (and, with the same norm, of y rows) in one launch; weights are
     fragment-packed (_pack.frag_pack).  Returns out_x [rows_x, n_x] (and out_y [rows_y, n_y])."""

@@ -170,6 +170,19 @@ int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const
                         int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
                         int num_steps, int degree_r, int degree_t, int64_t* r_act, int64_t* t_act,
                         float slope, hipStream_t stream);
+/* The same tail with every weight matrix stored TRANSPOSED: W^T [in][out4] (out4 = the output width padded to a multiple of 4 with zero
+ * columns; hidden widths n0, n1 multiples of 16): a lane owns four outputs and a wave a slice of the inputs, so that a layer is one memory
+ * round trip and no cross-lane reduction (35 -> ~15 us per agent step on the serial chain of a registration).  Same arguments otherwise;
+ * results agree with cmr_agent_heads_f32 to fp32 rounding of the sums (other summation order). */
+int cmr_agent_heads_t_f32(const float* x, int B, int npix, const float* w24t, const float* b24, const float* w26t, const float* b26,
+                          const float* e3d,
+                          const float* r_w0t, const float* r_b0, const float* r_w1t, const float* r_b1, const float* r_w2t, const float* r_b2,
+                          int r_n0, int r_n1, int r_n2, float* r_out, int r_ldo,
+                          const float* t_w0t, const float* t_b0, const float* t_w1t, const float* t_b1, const float* t_w2t, const float* t_b2,
+                          int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
+                          const float* v_w0t, const float* v_b0, const float* v_w1t, const float* v_b1, const float* v_w2t, const float* v_b2,
+                          int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                          int num_steps, int degree_r, int degree_t, int64_t* r_act, int64_t* t_act, float slope, hipStream_t stream);
 
 /* Pre-LN transformer block (ImageViT.py:61-158 = PointViT.py:96-183 = IMGPCEncoder.py:14-102) in three launches.
  * Weights marked _f are MFMA A fragments: W [n_out][k] stored as [n_out/32][k/8][64 lanes][4] with lane 32h+l holding

@@ -300,3 +300,44 @@ def test_entry_points_with_the_module_api_and_on_disk_frames(tmp_path):
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     assert "Registration Recall:" in r.stdout
+
+
+@pytest.mark.parametrize("shape", ["kitti_headline", "small_six_dof"])
+def test_agent_tail_on_transposed_weights(shape):
+    """cmr_agent_heads_t_f32 (weights stored [in][out4]: a layer is one memory round trip, no cross-lane reduction) against the
+    row-per-wave kernel and a float64 torch restatement of CMRAgent.py:52-56, 101-116: global pool, two 1x1 convs, the three heads, and the
+    deterministic actions (CMRAgent.py:118-123) -- same logits to fp32 rounding of the sums, identical actions."""
+    import cases as C
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.config import KittiConfiguration
+    from cmr_agent_amd.models import CMRAgent
+    if shape == "kitti_headline":
+        cfg, B = KittiConfiguration(cropped_img_H=352, cropped_img_W=1216, num_pt=1024, device="cuda"), 8
+    else:
+        cfg, B = KittiConfiguration(cropped_img_H=96, cropped_img_W=160, num_pt=1024, device="cuda", is_6_DoF=True), 3
+    torch.manual_seed(5)
+    agent = CMRAgent(cfg).to("cuda").eval()
+    p = agent.plan()
+    assert p["tail_t"]
+    kh, kw = cfg.image_H // 8, cfg.image_W // 8
+    g = torch.Generator().manual_seed(9)
+    x = (torch.rand(B * kh * kw, 128, generator=g) - 0.3).to("cuda")
+    e3d = (torch.rand(B, 128, generator=g) - 0.5).to("cuda")
+    names = ("policy_r", "policy_t", "value")
+    acts = (cfg.num_steps, agent.degree_r, agent.degree_t)
+    out_t, (ar_t, at_t) = ops.agent_heads_t(x, B, kh * kw, p["c24t"], p["c26t"], e3d, [p[n + "_t"] for n in names], 0.01, actions=acts)
+    out_r, (ar_r, at_r) = ops.agent_heads(x, B, kh * kw, p["c24"], p["c26"], e3d, [p[n] for n in names], 0.01, actions=acts)
+    torch.cuda.synchronize()
+    lr = lambda v: torch.where(v > 0, v, 0.01 * v)
+    xm = x.double().view(B, kh * kw, 128).mean(1)
+    e2 = lr(xm @ p["c24"][0].double().t() + p["c24"][1].double()) @ p["c26"][0].double().t() + p["c26"][1].double()
+    st = torch.cat([e2, e3d.double()], 1)
+    for i, n in enumerate(names):
+        (w0, b0), (w1, b1), (w2, b2) = p[n]
+        want = lr(lr(st @ w0.double().t() + b0.double()) @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+        scale = float(want.abs().max())
+        assert float((out_t[i].double() - want).abs().max()) <= 2e-6 * max(1.0, scale), (n, float((out_t[i].double() - want).abs().max()))
+        assert float((out_t[i] - out_r[i]).abs().max()) <= 2e-6 * max(1.0, scale), n
+    assert torch.equal(ar_t, ar_r) and torch.equal(at_t, at_r)
+    S = cfg.num_steps
+    assert torch.equal(ar_t, out_t[0][:, :agent.degree_r * S].view(B, agent.degree_r, S).argmax(-1))
