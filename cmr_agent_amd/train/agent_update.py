@@ -353,9 +353,10 @@ class AgentUpdate:
                                       want_masked=True)
         # net[0] + BatchNorm + LeakyReLU: streamed half of the input in the pass, broadcast half from the per-sample column sums
         w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
-        coef1 = ops.bn_bwd_coef(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], bk.g(p + "net.1.weight"), bk.g(p + "net.1.bias"))
-        dprev, _, cs1 = ops.bn_linear_bwd(dh1, r["h1"], SLOPE3D, r["h1raw"], r["st1"], coef1, fprev, w1[:, :f], gw1[:, :f],
-                                          res=dsum[:, :f] if ident else None, seg_rows=N)
+        # (h1 = lrelu(BN(h1raw)) without a residual: both passes take the mask from the sign of the BatchNorm output, h1 is not read again)
+        coef1 = ops.bn_bwd_coef(dh1, None, SLOPE3D, r["h1raw"], r["st1"], bk.g(p + "net.1.weight"), bk.g(p + "net.1.bias"))
+        dprev, _, cs1 = ops.bn_linear_bwd(dh1, None, SLOPE3D, r["h1raw"], r["st1"], coef1, fprev, w1[:, :f], gw1[:, :f],
+                                          res=dsum[:, :f] if ident else None, seg_rows=N, mask_from_h=True)
         dgprev = torch.empty((B, f), dtype=torch.float32, device=dev)
         if ident:           # identity shortcut on the concatenation: the broadcast half of d cat = dsum, summed per sample
             ops.colsum(dsum[:, f:], B, N, out=dgprev)

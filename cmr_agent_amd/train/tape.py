@@ -350,7 +350,9 @@ class Tape:
                 return
             dg, fin_g = self.vec_out(bn.weight)
             db, fin_b = self.vec_out(bn.bias)
-            z = None if slope == 1.0 else y.v
+            # (no residual in front of the activation: the mask comes from the sign of the BatchNorm output, recomputed from h: y is not read)
+            from_h = res is None and slope != 1.0
+            z = None if (slope == 1.0 or from_h) else y.v
             masked = res is not None and slope != 1.0
             inplace = x.g is not None and x.own and x.g.is_contiguous()
             gw, acc = self.G(weight)
@@ -359,7 +361,7 @@ class Tape:
             if fused_bwd:
                 coef = ops.bn_bwd_coef(y.g, z, slope, h, stat, dg, db)
                 dx, dzm = ops.bn_linear_bwd(y.g, z, slope, h, stat, coef, x.v, W, gw, acc, res=x.g, dx=x.g if inplace else None,
-                                            want_masked=masked)
+                                            want_masked=masked, mask_from_h=from_h)
             else:                                              # the same arithmetic, one launch per step of it
                 r = ops.bn_bwd(y.g, z, slope, h, stat, dg, db, want_masked=masked)
                 dh, dzm = r if masked else (r, None)
@@ -421,19 +423,21 @@ class Tape:
                 if last:
                     dg, fin_g = self.vec_out(bn.weight)
                     db, fin_b = self.vec_out(bn.bias)
-                    z = None if slope == 1.0 else y.v
+                    # (no residual in front of the activation: its mask is the sign of the BatchNorm output, recomputed from h -- y is not read)
+                    from_h = res is None and slope != 1.0
+                    z = None if (slope == 1.0 or from_h) else y.v
                     coef = ops.bn_bwd_coef(dz, z, slope, hs[i], stats[i], dg, db)
                     fin_g(), fin_b()
                 gw, acc = self.G(w)
                 if b is not None:
                     self.G(b)                                  # identically zero in front of a BatchNorm (see conv3x3)
                 masked = last and res is not None and slope != 1.0
-                common = dict(want_masked=masked, mask_from_h=not last)
+                common = dict(want_masked=masked, mask_from_h=(not last) or (res is None and slope != 1.0))
                 if i > 0:
                     pbn = layers[i - 1][2]
                     pdg, pfin_g = self.vec_out(pbn.weight)
                     pdb, pfin_b = self.vec_out(pbn.bias)
-                    dx, dzm, xcoef = ops.bn_linear_bwd(dz, y.v if last and slope != 1.0 else None, slope, hs[i], stats[i], coef, hs[i - 1], self.W(w),
+                    dx, dzm, xcoef = ops.bn_linear_bwd(dz, y.v if last and slope != 1.0 and res is not None else None, slope, hs[i], stats[i], coef, hs[i - 1], self.W(w),
                                                        gw, acc, xstat=stats[i - 1], xslope=layers[i - 1][3], xdgamma=pdg, xdbeta=pdb, **common)
                     pfin_g(), pfin_b()
                     if last and res is not None:
