@@ -175,6 +175,13 @@ def _median_timed(fn, passes, budget_s):
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense v_mfma_f32_32x32x16_bf16 (MI355X_MICROARCH.md); ridge 2500 / 8 = 312 FLOP/B
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that committed one (relative path), or None."""
+    import glob
+    fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return os.path.relpath(fs[-1], ROOT) if fs else None
+
+
 def _profiled_traffic(doms, profile):
     """HBM bytes per C-ABI call of the dominant family from a committed rocprofv3 PMC profile (tools/_pmc_train.sh), or None when the
     profile does not hold every entry point of the family that ran."""
@@ -344,7 +351,11 @@ def train_main(args, ctx=None, with_cpu=False):
             "conv_tflops_algorithmic": flops / (elapsed / args.steps) / 1e12,
             "launches_per_step": sum(d["calls"] for d in ct.table()),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
-            "roofline": train_roofline(ct.table(), 1, families, 1e3 * elapsed / args.steps, traffic_profile="profiles/r04_pmc_train.json"),
+            # every modelled entry point of the step competes for `dominant`: the named families above, and each remaining entry point on its own
+            "roofline": train_roofline(ct.table(), 1, families + [("%s (entry point)" % d["name"], (d["name"],),
+                                                                     BF16_MFMA_PEAK_TFLOPS if "bf16" in d["name"] else FP32_MFMA_PEAK_TFLOPS)
+                                                                    for d in ct.table() if d["modelled"] and not any(d["name"] in f[1] for f in families)],
+                                       1e3 * elapsed / args.steps, traffic_profile=_latest_profile("pmc_train.json")),
             "loss": float(losses[0]), **info}
         if with_cpu and world == 1:
             line["cpu_baseline"] = agent_update_cpu_baseline(spec, w, MB)
@@ -498,7 +509,8 @@ def geo_train_main(args, ctx=None, with_cpu=False):
             "launches_per_step": sum(d["calls"] for d in table),
             "roofline": train_roofline(table, 1, [("%s (the entry point with the largest summed time of the step)" % dom["name"],
                                                    (dom["name"],), FP32_MFMA_PEAK_TFLOPS)], 1e3 * elapsed / args.steps,
-                                       traffic_profile="profiles/r04_pmc_train_geo.json" if (H, W, cfg.num_pt) == (160, 512, 65536) else None),
+                                       traffic_profile=_latest_profile("pmc_train_geo.json") if (H, W, cfg.num_pt) == (160, 512, 65536) else
+                                       (_latest_profile("pmc_train_geo_c5.json") if (H, W, cfg.num_pt) == (352, 1216, 65536) else None)),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",
             "loss": loss, **info}
         if prologue is not None:

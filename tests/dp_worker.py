@@ -25,6 +25,7 @@ from cmr_agent_amd.utils.dist import Ranks  # noqa: E402
 def main():
     out, backend, share, steps = sys.argv[1], sys.argv[2], sys.argv[3] == "1", int(sys.argv[4])
     force = len(sys.argv) > 5 and sys.argv[5] == "force"
+    module_api = len(sys.argv) > 5 and sys.argv[5] == "module_api"
     dev = Ranks.local_device(share)
     ranks = Ranks(backend=backend, device=dev, force=force)
     specs = json.load(open(os.path.join(G.GOLDEN_DIR, "specs.json")))
@@ -33,6 +34,8 @@ def main():
     agent = CMRAgent(cfg)
     load_checked(agent, hashfill.make_state_dict(specs["agent"], C.AGENT_TAG))
     agent = agent.to(dev)
+    if module_api:
+        return module_api_main(out, ranks, agent, cfg, case, dev, steps)
     up = AgentUpdate(agent, cfg, dist=ranks.dist)
     n = ranks.collective_ranks()
     batches = C.train_inputs(case)
@@ -56,6 +59,34 @@ def main():
     torch.cuda.synchronize()
     torch.save({"params": up.bucket.params.cpu(), "grads": up.bucket.grads.cpu(), "losses": torch.stack(losses), "ranks": n,
                 "allreduce_ms": up.allreduce_ms(), **extra}, os.path.join(out, "rank%d.pt" % ranks.rank))
+    ranks.close()
+
+
+def module_api_main(out, ranks, agent, cfg, case, dev, steps):
+    """The same data-parallel steps through the nn.Module boundary (train/bridge.py): agent.train(); forward; the loss of Train_Agent.py:268-302
+    composed in torch; backward(); ONE all-reduce of the flat gradient bucket behind the Parameters' .grad views, divided by the world size;
+    torch.optim.Adam."""
+    from test_bridge_gpu import _torch_agent_loss
+    n = ranks.collective_ranks()
+    batches = C.train_inputs(case)
+    shard = {k: v.to(dev) for k, v in batches[ranks.rank % len(batches)].items()}
+    optimizer = torch.optim.Adam(agent.parameters(), lr=cfg.lr, betas=(0.9, 0.99), weight_decay=cfg.weight_decay)
+    agent.train()
+    losses = []
+    with torch.enable_grad():
+        for _ in range(steps):
+            r, t, v = agent(shard["states_2d"], shard["states_3d"])
+            loss = _torch_agent_loss(agent, cfg, shard, r, t, v)["loss"]
+            optimizer.zero_grad()
+            loss.backward()
+            bucket = agent.hip_engine().bucket
+            world = bucket.all_reduce(ranks.dist)
+            bucket.grads.div_(world)
+            optimizer.step()
+            losses.append(loss.detach().cpu())
+    torch.cuda.synchronize()
+    bucket = agent.hip_engine().bucket
+    torch.save({"params": bucket.params.cpu(), "grads": bucket.grads.cpu(), "losses": torch.stack(losses), "ranks": n}, os.path.join(out, "rank%d.pt" % ranks.rank))
     ranks.close()
 
 

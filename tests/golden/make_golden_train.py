@@ -206,7 +206,7 @@ def run_pointnet2(ns, report):
                              running=float(max((leaves[k] - b).abs().max() for k, b in m.named_buffers() if not k.endswith("num_batches_tracked"))))
     finally:
         torch.randint = orig
-    report[C.PN2_TRAIN_FIXTURE] = rep
+    report[C.PN2_TRAIN_FIXTURE] = {"%s/%s" % (name, k): v for name, d in rep.items() for k, v in d.items()}
     G.save_case(C.PN2_TRAIN_FIXTURE, named)
     print(C.PN2_TRAIN_FIXTURE, rep)
 

@@ -24,9 +24,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 2
 
 
-def _run_ranks(tmp_path, backend, share):
+def _run_ranks(tmp_path, backend, share, mode=None):
     from cmr_agent_amd.utils import launch
-    cmd = launch.rank_command(os.path.join(ROOT, "tests", "dp_worker.py"), [str(tmp_path), backend, "1" if share else "0", str(STEPS)], 2)
+    cmd = launch.rank_command(os.path.join(ROOT, "tests", "dp_worker.py"), [str(tmp_path), backend, "1" if share else "0", str(STEPS)] + ([mode] if mode else []), 2)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
@@ -76,6 +76,36 @@ def _check(res):
 
 def test_two_rank_agent_update_gloo_shared_gpu(tmp_path):
     _check(_run_ranks(tmp_path, "gloo", True))
+
+
+def test_two_rank_module_api_update_gloo_shared_gpu(tmp_path):
+    """Data parallelism THROUGH the nn.Module boundary (Train_Agent.py --module-api; cmr_agent_amd/train/bridge.py): two ranks run agent.train();
+    forward; the reference's loss composed in torch; backward(); one all-reduce of the flat gradient bucket behind the Parameters' .grad views;
+    torch.optim.Adam.  A real collective saw both ranks; the ranks end with bit-identical parameter and gradient buckets on different shards; and
+    those equal what ONE process gets that computes both shards' gradients through the same bridge, averages them and steps torch's Adam."""
+    import torch.nn.functional as F  # noqa: F401
+    from test_bridge_gpu import _agent, _torch_agent_loss
+    res = _run_ranks(tmp_path, "gloo", True, "module_api")
+    assert res[0]["ranks"] == 2 and res[1]["ranks"] == 2
+    assert torch.equal(res[0]["params"], res[1]["params"]) and torch.equal(res[0]["grads"], res[1]["grads"])
+    assert not torch.equal(res[0]["losses"], res[1]["losses"])
+    cfg = C.train_config("agent_train_small", device="cuda")
+    batches = [{k: v.cuda() for k, v in b.items()} for b in C.train_inputs("agent_train_small")]
+    agents = [_agent(cfg).train() for _ in range(2)]
+    opts = [torch.optim.Adam(a.parameters(), lr=cfg.lr, betas=(0.9, 0.99), weight_decay=cfg.weight_decay) for a in agents]
+    with torch.enable_grad():
+        for _ in range(STEPS):
+            for a, o, b in zip(agents, opts, batches):
+                r, t, v = a(b["states_2d"], b["states_3d"])
+                loss = _torch_agent_loss(a, cfg, b, r, t, v)["loss"]
+                o.zero_grad()
+                loss.backward()
+            total = agents[0].hip_engine().bucket.grads + agents[1].hip_engine().bucket.grads
+            for a, o in zip(agents, opts):
+                a.hip_engine().bucket.grads.copy_(total).div_(2)
+                o.step()
+    torch.cuda.synchronize()
+    assert torch.equal(agents[0].hip_engine().bucket.params.cpu(), res[0]["params"])
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank")

@@ -7,8 +7,13 @@ ENTRIES = {   # entry point -> (main kernel, other kernels of the same call)
     "cmr_bn_linear_bwd_f32": ("bn_linear_bwd_kernel", ("blb_reduce_kernel", "blb_coef_final_kernel", "blb_seg_reduce_kernel")),
     "cmr_linear_bn_fwd_f32": ("bn_linear_fwd_kernel", ("bn_stats_merge_kernel",)),
     "cmr_conv3x3_wino_nhwc_f32": ("conv3x3_wino_ws_kernel", ("conv3x3_wino_kernel",)),
-    "cmr_conv3x3_wgrad_f32": ("conv3x3_wgrad_reduce_kernel", ("conv3x3_wgrad_kernel", "conv3x3_wgrad_lds_kernel")),      # (one reduction per call)
+    "cmr_conv3x3_wgrad_f32": ("conv3x3_wgrad_reduce_kernel", ("conv3x3_wgrad_kernel", "conv3x3_wgrad_lds_kernel", "conv3x3_wgrad_s2_kernel")),      # (one reduction per call)
     "cmr_affine_act_f32": ("affine_act_kernel", ()),
+    # round 5: the bf16 agent update's convolution / weight-gradient entry points and the BatchNorm sweeps
+    "cmr_conv3x3_wgrad_bias_bf16_f32": ("conv3x3_wgrad_reduce_kernel", ("conv3x3_wgrad_bf16_tr_kernel", "conv3x3_wgrad_bf16_kernel", "conv_bias_reduce_kernel")),
+    "cmr_conv3x3_bf16_nhwc_f32": ("conv3x3_bf16_", ()),
+    "cmr_bn_bwd_f32": ("bn_bwd_apply_kernel", ("bn_bwd_partial_kernel", "bn_bwd_final_kernel")),
+    "cmr_bn_stats_f32": ("bn_stats_final_kernel", ("bn_stats_partial_kernel",)),
 }
 
 
@@ -39,6 +44,10 @@ for entry, (main, others) in ENTRIES.items():
         return n, v
     nf, f = tot(fe, (main,) + others)
     nw, w = tot(wr, (main,) + others)
+    # the two 3x3 weight-gradient entry points share their reduction kernel: an entry point counts only when one of its OWN kernels ran
+    own = [o for o in others if "reduce" not in o and "final" not in o]
+    if "wgrad" in entry and own and not any(any(o in k for o in own) for k in fe):
+        continue
     if nf and nw:
         out[entry] = {"calls_profiled": nf, "fetch_bytes_per_call": 2 * 1024 * f / nf, "write_bytes_per_call": 1024 * w / nw,
                       "hbm_bytes_per_call": 2 * 1024 * f / nf + 1024 * w / nw}
