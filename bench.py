@@ -330,12 +330,13 @@ def train_main(args, ctx=None, with_cpu=False):
                      ("cmr_conv3x3_wgrad_f32",), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
                      ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc"), BF16_MFMA_PEAK_TFLOPS),
-                    ("conv3x3_wgrad_bf16_kernel: 3x3 weight gradients on v_mfma_f32_32x32x16_bf16 (rows transposed into LDS, fp32 accumulate)",
+                    ("conv3x3_wgrad_bf16_tr_kernel / conv3x3_wgrad_bf16_kernel: 3x3 weight gradients on v_mfma_f32_32x32x16_bf16 (operands through "
+                     "ds_read_b64_tr_b16 on maps of >= 32 768 pixels, rows transposed into LDS below; fp32 accumulate)",
                      ("cmr_conv3x3_wgrad_bf16_f32", "cmr_conv3x3_wgrad_bias_bf16_f32"), BF16_MFMA_PEAK_TFLOPS),
                     ("bn_linear_bwd_kernel: BatchNorm apply + weight gradient + data gradient of the 3-D branch's conv + BatchNorm pairs in one "
                      "pass over the row maps (fp32 MFMA)", ("cmr_bn_linear_bwd_f32",), FP32_MFMA_PEAK_TFLOPS),
-                    ("linear_ws_kernel / bn_linear_fwd_kernel / linear_wgrad_kernel: the remaining row GEMMs of the 3-D branch (fp32 MFMA, "
-                     "row-streaming)", ("cmr_linear_f32", "cmr_linear_wgrad_f32", "cmr_linear_bn_fwd_f32"), FP32_MFMA_PEAK_TFLOPS)]
+                    ("bn_linear_fwd_kernel: conv + BatchNorm statistics of the 3-D branch's row maps in one pass (fp32 MFMA)",
+                     ("cmr_linear_bn_fwd_f32",), FP32_MFMA_PEAK_TFLOPS)]
         line = {
             "metric": "agent update samples/sec (Train_Agent.py minibatch update at 88x304 observations, 16384 pts)",
             "value": world * MB * args.steps / elapsed, "unit": "buffered observations/s", "n_gpus": world, "steps": args.steps,
