@@ -183,9 +183,23 @@ class AgentUpdate:
             # (fused: the GEMM and the BatchNorm statistics of its output in one pass; the broadcast half of the input, cat([feat, max]),
             # enters as a per-sample bias max W[:, f:]^T + b computed by a skinny GEMM)
             h1raw, st1 = self._linear_bn(feat, p + "net.0", m.net[1], p + "net.1", g if fused else None, N, src)
-            h1 = ops.affine_act(h1raw, st1[2], st1[3], slope=SLOPE3D)
-            h2raw, st2 = self._linear_bn(h1, p + "net.3", m.net[4], p + "net.4", None, N, {}, fused)
-            rec = dict(x=feat, g=g, h1raw=h1raw, st1=st1, h1=h1, h2raw=h2raw, st2=st2, cin=cin, cout=cout, p=p)
+            # lazy: net[3] takes lrelu(BN(h1raw)) through its own staging pass (cmr_linear_bn_fwd_f32's prologue) and its backward through
+            # cmr_bn_linear_bwd_f32's lazy operand -- h1 is never written (the cmr_affine_act_f32 pass and, in the backward, net[1]'s
+            # cmr_bn_bwd_coef_f32 pass over the map go away); shapes: what the lazy operand serves (64 outputs)
+            lazy = bool(fused and self.LAZY_3D and (cout, cin) in self.LAZY_SHAPES and ops.linear_bn_fwd_ok(h1raw.shape[0], cout, cin))
+            h1 = r2 = None
+            if lazy:
+                bk2, bn2 = self.bucket, m.net[4]
+                r2 = ops.linear_bn_fwd(h1raw, bk2.w(p + "net.3.weight"), bk2.w(p + "net.3.bias"), bk2.w(p + "net.4.weight"), bk2.w(p + "net.4.bias"),
+                                       bn2.running_mean, bn2.running_var, eps=bn2.eps, momentum=bn2.momentum if bn2.momentum is not None else 0.1,
+                                       pro=st1, pro_slope=SLOPE3D)
+                lazy = r2 is not False
+            if lazy:
+                h2raw, st2 = r2
+            else:
+                h1 = ops.affine_act(h1raw, st1[2], st1[3], slope=SLOPE3D)
+                h2raw, st2 = self._linear_bn(h1, p + "net.3", m.net[4], p + "net.4", None, N, {}, fused)
+            rec = dict(x=feat, g=g, h1raw=h1raw, st1=st1, h1=h1, h2raw=h2raw, st2=st2, cin=cin, cout=cout, p=p, lazy=lazy)
             if cin != cout:
                 scraw, stsc = self._linear_bn(feat, p + "shortcut.0", m.shortcut[1], p + "shortcut.1", g if fused else None, N, src)
                 out = ops.affine_act(h2raw, st2[2], st2[3], res=scraw, rscale=stsc[2], rshift=stsc[3], slope=SLOPE3D)
@@ -290,7 +304,8 @@ class AgentUpdate:
             dsum = ops.act_bwd(dfeat, r["out"], SLOPE3D)                                      # final LeakyReLU
             dh2raw = self._bn_bwd(dsum, None, 1.0, r["h2raw"], r["st2"], p + "net.4")
             gw2 = bk.g(p + "net.3.weight")
-            ops.linear_wgrad(dh2raw, r["h1"], gw2, gw2.shape[1], db=bk.g(p + "net.3.bias"))       # bias gradient = column sums of dh2raw, same launch
+            h1 = r["h1"] if r["h1"] is not None else ops.affine_act(r["h1raw"], r["st1"][2], r["st1"][3], slope=SLOPE3D)   # (lazy forward)
+            ops.linear_wgrad(dh2raw, h1, gw2, gw2.shape[1], db=bk.g(p + "net.3.bias"))            # bias gradient = column sums of dh2raw, same launch
             dh1 = ops.linear(dh2raw, self._wT(p + "net.3.weight"))
             dh1raw = self._bn_bwd(dh1, None, SLOPE3D, r["h1raw"], r["st1"], p + "net.1")
             w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
@@ -327,6 +342,8 @@ class AgentUpdate:
             dfeat, dg = dprev, dgprev
 
     FUSED_3D = __import__("os").environ.get("CMR_AGENT_FUSED_3D", "1") == "1"
+    LAZY_3D = __import__("os").environ.get("CMR_AGENT_LAZY_3D", "1") == "1"
+    LAZY_SHAPES = ((64, 64), (64, 128))               # (n, k) cmr_bn_linear_bwd_f32's lazy operand serves (train/tape.py: LAZY_OPERAND_SHAPES)
 
     def _fused3d_bwd_ok(self, r, R, N):
         """every conv + BatchNorm pair of the block has a shape cmr_bn_linear_bwd_f32 serves (embed_dim 64: widths 64 / 128); other widths take
@@ -349,12 +366,19 @@ class AgentUpdate:
         # net[3] + BatchNorm + the block's final LeakyReLU: dsum = the gradient at the sum (what the shortcut receives)
         w2, gw2 = bk.w(p + "net.3.weight"), bk.g(p + "net.3.weight")
         coef2 = ops.bn_bwd_coef(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], bk.g(p + "net.4.weight"), bk.g(p + "net.4.bias"))
-        dh1, dsum = ops.bn_linear_bwd(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], coef2, r["h1"], w2, gw2, db=bk.g(p + "net.3.bias"),
-                                      want_masked=True)
-        # net[0] + BatchNorm + LeakyReLU: streamed half of the input in the pass, broadcast half from the per-sample column sums
         w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
-        # (h1 = lrelu(BN(h1raw)) without a residual: both passes take the mask from the sign of the BatchNorm output, h1 is not read again)
-        coef1 = ops.bn_bwd_coef(dh1, None, SLOPE3D, r["h1raw"], r["st1"], bk.g(p + "net.1.weight"), bk.g(p + "net.1.bias"))
+        if r["lazy"]:
+            # h1 was never stored: the pass recomputes it from h1raw for the weight gradient and returns net[1]'s BatchNorm-backward
+            # reduction (coef1, dgamma, dbeta) with the data gradient
+            dh1, dsum, coef1 = ops.bn_linear_bwd(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], coef2, r["h1raw"], w2, gw2, db=bk.g(p + "net.3.bias"),
+                                                 want_masked=True, xstat=r["st1"], xslope=SLOPE3D, xdgamma=bk.g(p + "net.1.weight"),
+                                                 xdbeta=bk.g(p + "net.1.bias"))
+        else:
+            dh1, dsum = ops.bn_linear_bwd(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], coef2, r["h1"], w2, gw2, db=bk.g(p + "net.3.bias"),
+                                          want_masked=True)
+            # net[0] + BatchNorm + LeakyReLU: streamed half of the input in the pass, broadcast half from the per-sample column sums
+            # (h1 = lrelu(BN(h1raw)) without a residual: both passes take the mask from the sign of the BatchNorm output, h1 is not read again)
+            coef1 = ops.bn_bwd_coef(dh1, None, SLOPE3D, r["h1raw"], r["st1"], bk.g(p + "net.1.weight"), bk.g(p + "net.1.bias"))
         dprev, _, cs1 = ops.bn_linear_bwd(dh1, None, SLOPE3D, r["h1raw"], r["st1"], coef1, fprev, w1[:, :f], gw1[:, :f],
                                           res=dsum[:, :f] if ident else None, seg_rows=N, mask_from_h=True)
         dgprev = torch.empty((B, f), dtype=torch.float32, device=dev)
