@@ -380,10 +380,19 @@ __device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmc
 
 // dbg: compile-time ablation mask used while tuning (see launch_wino_ws); the library instantiates 0 only, where every
 // `dbg & ...` test folds away.
-template <int dbg>
-__global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs a, const int tiles_x, const int tiles_y, const int ntiles) {
+// MW = MFMA waves per SIMD.  1: waves 0-3 multiply (4 positions x 2 cout tiles = 128 accumulator registers each), waves 4-7 help:
+// 8 waves x 256 registers.  2: waves 0-7 multiply -- wave m owns position row m & 3 and cout tile m >> 2 (64 accumulator registers,
+// the same products in the same order: bit-identical results) -- and waves 8-11 help: 12 waves x 168 registers.  Two MFMA waves share
+// a SIMD's matrix pipe, so one wave's wait for its U fragments is the other's issue slot; the price is that both waves of a SIMD read
+// and transform the same patch rows (LDS reads and VALU x 2) and that 168 registers make the helpers spill.  MEASURED (round 5,
+// tools/wino_mw_ab.py, profiles/r05_wino_mw_ab.txt): bit-identical and 10 - 25 % slower at every shape of the step (352x1216 64->64:
+// 1 112 -> 1 432 us; 88x304 128->128: 257 -> 293 us) -- the single MFMA wave was not starved (it issues 80 % of the launch's cycles at
+// the ~1.93 GHz the chip sustains under this load), so MW = 1 stays the library's choice; MW = 2 is kept for the A/B.
+template <int dbg, int MW>
+__global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(const WinoArgs a, const int tiles_x, const int tiles_y, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = 2;
+  constexpr int NT = 2 / MW;                         // cout tiles per MFMA wave
+  constexpr int NMW = 4 * MW;                        // MFMA waves
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nco = a.Cout / 64;
@@ -403,12 +412,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
     return r;
   };
 
-  if (wave < 4) {
+  if (wave < NMW) {
     // =========================================== MFMA waves ===========================================
     const int h = lane >> 5, l31 = lane & 31;
-    const int ra = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
-    const int rb = wave == 3 ? 3 : (wave == 2 ? 1 : 2);
-    const float sgn = wave == 1 ? 1.f : -1.f;
+    const int wr = wave & 3, nsel = (wave >> 2) * NT;  // position row, first cout tile of this wave
+    const int ra = wr == 0 ? 0 : (wr == 2 ? 2 : 1);
+    const int rb = wr == 3 ? 3 : (wr == 2 ? 1 : 2);
+    const float sgn = wr == 1 ? 1.f : -1.f;
     const int ty = l31 >> 3, tx = l31 & 7;
     int pa[4], pb[4];
 #pragma unroll
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
     const int lane_off = lane * 16;
     const int utile = (a.Cin / 8) * 1024;             // bytes between cout tiles
     const int upos = a.Cout * a.Cin * 4;              // bytes between positions
-    const int uwave = 4 * wave * upos;                // position (wave, 0)
+    const int uwave = 4 * wr * upos + nsel * utile;   // position (wr, 0), this wave's first cout tile
     auto load_u = [&](int soff) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ursrc, lane_off, soff, 0)); };
     int ub = uwave + (decode(blockIdx.x).co0 / 32) * utile;
     f32x4 wc[4][NT];
@@ -531,19 +541,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
               t0[e] = (acc[0][n][r] + acc[1][n][r]) + acc[2][n][r];
               t1[e] = (acc[1][n][r] - acc[2][n][r]) - acc[3][n][r];
             }
-            *reinterpret_cast<f32x4*>(&Ts[((wave * 2 + 0) * 32 + l31) * WS_T_ROW + n * 32 + 8 * rq + 4 * h]) = t0;
-            *reinterpret_cast<f32x4*>(&Ts[((wave * 2 + 1) * 32 + l31) * WS_T_ROW + n * 32 + 8 * rq + 4 * h]) = t1;
+            *reinterpret_cast<f32x4*>(&Ts[((wr * 2 + 0) * 32 + l31) * WS_T_ROW + (nsel + n) * 32 + 8 * rq + 4 * h]) = t0;
+            *reinterpret_cast<f32x4*>(&Ts[((wr * 2 + 1) * 32 + l31) * WS_T_ROW + (nsel + n) * 32 + 8 * rq + 4 * h]) = t1;
           }
       }
       ub = ubn;
     }
     if ((dbg & 64) && lane == 0) {                       // timing build only: a.post is the stamp buffer [workgroup][wave][2]
-      float* o = const_cast<float*>(a.post) + ((int)blockIdx.x * 8 + wave) * 2;
+      float* o = const_cast<float*>(a.post) + ((int)blockIdx.x * (NMW + 4) + wave) * 2;
       o[0] = (float)tm_busy; o[1] = (float)tm_wait;
     }
   } else {
     // ============================================ helpers ============================================
-    const int hw = wave - 4;
+    const int hw = wave - NMW;
     const int Ho = a.H, Wo = a.W;
     // The helpers are the younger wave of every SIMD's pair and would get the VALU issue slots the MFMA wave leaves over (their
     // epilogue then takes longer than a chunk of MFMAs and the MFMA waves wait at the barrier: 12-20 % of the launch by s_memtime
@@ -760,9 +770,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
       cur = nxt;
     }
     if ((dbg & 64) && lane == 0) {
-      float* o = const_cast<float*>(a.post) + ((int)blockIdx.x * 8 + wave) * 2;
+      float* o = const_cast<float*>(a.post) + ((int)blockIdx.x * (NMW + 4) + wave) * 2;
       o[0] = (float)tm_busy; o[1] = (float)tm_wait;
-      float* q = const_cast<float*>(a.post) + 2 * 8 * gridDim.x + ((int)blockIdx.x * 4 + hw) * 4;
+      float* q = const_cast<float*>(a.post) + 2 * (NMW + 4) * gridDim.x + ((int)blockIdx.x * 4 + hw) * 4;
       q[0] = (float)tm_vm; q[1] = (float)tm_dma; q[2] = (float)tm_epi; q[3] = (float)tm_st;
     }
   }
@@ -771,11 +781,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_ws_kernel(const WinoArgs 
 #ifndef CMR_WS_DBG
 #define CMR_WS_DBG 0
 #endif
-template <int DBG>
+#ifndef CMR_WINO_MW
+#define CMR_WINO_MW 1
+#endif
+#ifdef CMR_AB_SWITCHES
+static int g_wino_mw = CMR_WINO_MW;                  // cmr_set_wino_mfma_waves: A/B measurements, libcmr_hip_ab.so only
+#else
+static constexpr int g_wino_mw = CMR_WINO_MW;
+#endif
+template <int DBG, int MW>
 int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, int cu_budget, int slices, hipStream_t stream) {
   constexpr int smem = WS_SMEM_FLOATS * (int)sizeof(float);
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel<DBG>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel<DBG, MW>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -793,14 +811,15 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
     want = (int64_t)cus * sl;
   }
   const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
-  hipLaunchKernelGGL(conv3x3_wino_ws_kernel<DBG>, dim3(grid), dim3(512), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
+  hipLaunchKernelGGL((conv3x3_wino_ws_kernel<DBG, MW>), dim3(grid), dim3(256 * (MW + 1)), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
   return cmr_launch_status();
 }
 int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, int cu_budget, int slices, hipStream_t stream) {
   // DBG bits (compile-time ablations used while tuning: 1 no stores, 2 no epilogue, 4 no T hand-over, 8 no U loads, 16 no LDS
   // prefetch, 32 no MFMAs, 128 every tile stored over the same few tiles (stores without HBM write traffic), 64 s_memtime stamps of busy / barrier-wait cycles per wave into the buffer passed as `post`) are not
   // instantiated in the shipped library: tools/ab_build.sh cmr_agent_amd/csrc/conv_wino.hip <tag> -DCMR_WS_DBG=<mask>
-  return launch_wino_ws_t<CMR_WS_DBG>(a, tiles_x, tiles_y, ntiles, cu_budget, slices, stream);
+  if (g_wino_mw == 2) return launch_wino_ws_t<CMR_WS_DBG, 2>(a, tiles_x, tiles_y, ntiles, cu_budget, slices, stream);
+  return launch_wino_ws_t<CMR_WS_DBG, 1>(a, tiles_x, tiles_y, ntiles, cu_budget, slices, stream);
 }
 
 template <int NT>
@@ -821,6 +840,11 @@ int launch_wino(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, hip
 // Both are ARGUMENTS of the call: the library keeps no launch policy of its own (round 3 had process-global setters here).
 #ifdef CMR_AB_SWITCHES
 static int CMR_WINO_WS = 1;      // wave-specialised persistent kernel for large maps (cmr_set_wino_variant: A/B measurements, libcmr_hip_ab.so only)
+extern "C" int cmr_set_wino_mfma_waves(int per_simd) {
+  const int old = g_wino_mw;
+  g_wino_mw = per_simd == 2 ? 2 : 1;
+  return old;
+}
 extern "C" int cmr_set_wino_variant(int wave_specialised) {
   const int old = CMR_WINO_WS;
   CMR_WINO_WS = wave_specialised & 1;

@@ -25,6 +25,11 @@ int cmr_set_linear_wreg(int on, int64_t min_rows);
  * the default; 0 = 4-wave workgroups for every map): A/B measurements and tests only.  Returns the previous setting. */
 int cmr_set_wino_variant(int wave_specialised);
 
+/* MFMA waves per SIMD of the wave-specialised Winograd kernel: 1 = 8-wave workgroups (4 multiply, 4 help: the default), 2 = 12-wave
+ * workgroups (8 multiply -- position row x cout tile -- 4 help; round-5 experiment, 10 - 25 % SLOWER: profiles/r05_wino_mw_ab.txt).  Same
+ * products in the same order: bit-identical results.  A/B measurements and tests only.  Returns the previous setting. */
+int cmr_set_wino_mfma_waves(int per_simd);
+
 /* Process-wide switch of the bf16 convolution's kernel choice for 128-cout layers without residual / table operand (stride 1,
  * Cin = 64 | 128): matrix_class = 1 (default) routes maps of at least min_tiles 8x32-pixel tiles (x Cout / 128; min_tiles <= 0 keeps the
  * current threshold) to the register-tiled kernel that streams the weight fragments from L2 (conv3x3_bf16_mm_kernel), 0 keeps the
