@@ -77,15 +77,25 @@ def rollout(geo_model, agent, config, data, buffer):
     return float(torch.cat(rewards).mean())
 
 
-def minibatches(samples, generator):
+def minibatches(samples, generator, into=None):
     """TensorDataset + DataLoader(batch_size=10, shuffle=True, drop_last=False) of Train_Agent.py:258-261, as index gathers
-    on the device.  The buffered observations are channels-last storage; gathering on the permuted view keeps them so."""
+    on the device.  The buffered observations are channels-last storage; gathering on the permuted view keeps them so.
+    into: a callable returning the update's static input buffers (AgentUpdate.static_batch) or None -- full minibatches are then gathered
+    straight into them (the captured graph reads them in place); the last, shorter minibatch gets tensors of its own."""
     n = samples[0].shape[0]
     perm = torch.randperm(n, generator=generator).to(samples[0].device)
     s2 = samples[0].permute(0, 2, 3, 1)
     nhwc = s2.is_contiguous()
     for i in range(0, n, MINIBATCH):
         idx = perm[i:i + MINIBATCH]
+        static = into() if into is not None and idx.numel() == MINIBATCH else None
+        if static is not None and nhwc and all(static[k].dtype == t.dtype and static[k].shape[1:] == t.shape[1:] and static[k].is_contiguous()
+                                                for k, t in zip(SAMPLE_KEYS[1:], samples[1:])) and static["states_2d"].permute(0, 2, 3, 1).is_contiguous():
+            for k, t in zip(SAMPLE_KEYS[1:], samples[1:]):
+                torch.index_select(t, 0, idx, out=static[k])
+            torch.index_select(s2, 0, idx, out=static["states_2d"].permute(0, 2, 3, 1))
+            yield static
+            continue
         batch = {k: t.index_select(0, idx) for k, t in zip(SAMPLE_KEYS[1:], samples[1:])}
         batch["states_2d"] = s2.index_select(0, idx).permute(0, 3, 1, 2) if nhwc else samples[0].index_select(0, idx)
         yield batch
@@ -178,6 +188,8 @@ def main():
     ap.add_argument('--geo-ckpt', default=None)
     ap.add_argument('--out', default=None, help="directory for agent checkpoints (default: config.ckpt_dir)")
     ap.add_argument('--data-root', default=None, help="dataset root in the reference's on-disk layout (cmr_agent_amd/dataset/loader.py); default: the synthetic generator")
+    ap.add_argument('--eager', action='store_true', help="issue every update launch from Python (default: forward + backward of a full minibatch captured "
+                                                         "into one hipGraph, minibatches gathered straight into its input buffers)")
     ap.add_argument('--module-api', action='store_true', help="update through the nn.Module boundary as the reference's minibatch body is written (agent(...); "
                     "loss composed in torch; loss.backward(); torch.optim step -- cmr_agent_amd/train/bridge.py) instead of the fused AgentUpdate.step")
     ap.add_argument('--optimizer', choices=("ADAM", "SGD"), default=None, help="overrides config.optimizer")
@@ -255,6 +267,7 @@ def main():
     buffer.start_trajectory()
     best_r = best_t = float("inf")
     global_step = 0
+    graph_mode, static_inputs = not (args.eager or args.module_api), None
     for epoch in range(args.epochs):
         if ranks.rank == 0:
             print("Learning rate: ", update.lr)
@@ -274,8 +287,11 @@ def main():
                 samples = buffer.get_samples()
                 loss_bc, loss_ppo, t0 = [], [], time.perf_counter()
                 nmb = 0
-                for batch in minibatches(samples, sample_gen):
-                    losses = update.step(batch)
+                for batch in minibatches(samples, sample_gen, into=static_inputs):
+                    if graph_mode and static_inputs is None and batch["states_2d"].shape[0] == MINIBATCH:
+                        update.enable_graph(batch)               # forward + backward of a full minibatch replayed from one hipGraph from here on
+                        static_inputs = update.static_batch
+                    losses = update.step(batch, eager_if_other_shape=True) if graph_mode else update.step(batch)
                     loss_bc.append(losses[1:2])
                     loss_ppo.append(losses[5:6])
                     nmb += 1
@@ -284,6 +300,7 @@ def main():
                 if ranks.rank == 0:
                     print(json.dumps({"step": global_step, "train_loss/BC_Loss": lb, "train_loss/PPO_Loss": lp,
                                       "train_loss/reward": mean_reward, "minibatches": nmb, "update_s": round(dt, 4),
+                                      "update_mode": "module api" if args.module_api else ("hipGraph" if static_inputs is not None else "eager"),
                                       "allreduce_ms_last": round(update.allreduce_ms(), 4)}))
                 buffer.clear()
                 agent.eval()

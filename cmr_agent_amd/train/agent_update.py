@@ -485,16 +485,33 @@ class AgentUpdate:
                 b.copy_(saved[n])
         self._graph = graph
 
-    def step(self, batch):
-        """One optimizer step on one minibatch (Train_Agent.py:263-305).  Returns the loss vector (device tensor [8])."""
+    def static_batch(self):
+        """The input buffers the captured graph reads (enable_graph): a producer that gathers its minibatch straight into them
+        (`torch.index_select(..., out=...)`, Train_Agent.py:minibatches) and hands this dict to step() pays no second copy."""
+        if getattr(self, "_graph", None) is None:
+            raise RuntimeError("AgentUpdate.static_batch: no captured graph (enable_graph first)")
+        return self._static
+
+    def step(self, batch, eager_if_other_shape=False):
+        """One optimizer step on one minibatch (Train_Agent.py:263-305).  Returns the loss vector (device tensor [8]).
+        With a captured graph: tensors that ARE the graph's input buffers (static_batch()) are not copied; a minibatch of another shape
+        (the last, shorter one of an epoch: DataLoader(drop_last=False)) raises, or runs eagerly when eager_if_other_shape."""
+        if getattr(self, "_graph", None) is not None and eager_if_other_shape and any(
+                tuple(batch[k].shape) != tuple(v.shape) for k, v in self._static.items()):
+            losses, _ = self.forward_backward(batch)
+            if self._nbt:
+                torch._foreach_add_(self._nbt, 1)
+            self.optimizer_step()
+            return losses
         if getattr(self, "_graph", None) is not None:
             for k, v in self._static.items():
                 src = batch[k]
                 if tuple(src.shape) != tuple(v.shape):
                     raise ValueError("AgentUpdate.step: batch tensor %s has shape %s, the captured graph was built for %s" % (k, tuple(src.shape), tuple(v.shape)))
-                v.copy_(src, non_blocking=True)
+                if src.data_ptr() != v.data_ptr() or src.stride() != v.stride():
+                    v.copy_(src, non_blocking=True)
             self._graph.replay()
-            losses = self._static_losses
+            losses = self._static_losses.clone()        # (the graph's own output buffer is overwritten by the next replay)
             if self._nbt:
                 torch._foreach_add_(self._nbt, 1)
             self.optimizer_step()

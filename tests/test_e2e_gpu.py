@@ -227,6 +227,18 @@ def test_entry_point_scripts_run_end_to_end(tmp_path):
     upd = [l for l in logs if "train_loss/BC_Loss" in l]
     assert len(upd) == 1 and upd[0]["minibatches"] == 8                 # 4 trajectories x 10 steps x 2 pairs / 10
     assert all(abs(upd[0][k]) < 1e4 for k in ("train_loss/BC_Loss", "train_loss/PPO_Loss"))
+    assert upd[0]["update_mode"] == "hipGraph"
+    # the same run with every launch issued from Python: the captured update (minibatches gathered straight into the graph's input
+    # buffers) is the same kernels in the same order.  Two runs of EITHER mode differ in the 5th digit (the rollouts' scatter uses
+    # atomics), so the comparison is to 2e-3, far below what a stale or aliased input / loss buffer would show (1.97 vs 2.78 when
+    # step() still returned the graph's own loss buffer)
+    r2 = subprocess.run([sys.executable, os.path.join(root, "Train_Agent.py"), "--batches", "4", "--img", "96x160", "--num-pt", "2048",
+                         "--batch-size", "2", "--eager", "--out", str(tmp_path / "ckpt_eager")], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    upd2 = [l for l in (json.loads(l) for l in r2.stdout.splitlines() if l.startswith("{")) if "train_loss/BC_Loss" in l]
+    assert len(upd2) == 1 and upd2[0]["update_mode"] == "eager"
+    for k in ("train_loss/BC_Loss", "train_loss/PPO_Loss", "train_loss/reward"):
+        assert abs(upd2[0][k] - upd[0][k]) <= 2e-3 * max(1.0, abs(upd[0][k])), (k, upd[0][k], upd2[0][k])
     ck = [f for f in os.listdir(out) if f.endswith(".pth")]
     assert ck
     sd = torch.load(os.path.join(out, ck[0]), map_location="cpu")
