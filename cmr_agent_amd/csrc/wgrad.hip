@@ -823,6 +823,320 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_tr_kernel(const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Third generation (round 5): the same operands, images and matrix instructions as the kernel above -- and the same sums in the same order,
+// bit for bit -- with the two things its timeline showed (8.6 strips x [2 dependent HBM round trips to fill the pipeline + 8 rows at one
+// row per HALF an HBM latency, the register prefetch being two rows deep]: 138 us for 0.48 us of matrix work per row) taken out:
+//   * rows arrive by LDS-DMA (global_load_lds_dwordx4, no registers): a ring of WT3_D raw fp32 rows (34 pixels x 128 channels of x and 32
+//     pixels x 64 channels of dY, 25 KB) filled WT3_D - 1 iterations ahead of their use, across strip boundaries -- the stream of rows of
+//     a workgroup's strips is ONE pipeline that is filled once per launch.  Zero padding comes from the DMA's per-lane source address (a
+//     zero page), so the conversion pass (raw fp32 -> the swizzled bf16 images, LDS to LDS through the VALU) has no bounds logic at all;
+//   * one INPUT row per iteration: the staged x row r meets the dY rows r + 1, r, r - 1 (kernel rows 0, 1, 2) whose operand fragments stay
+//     in registers for three iterations (24 registers -- the register prefetch they replace was 32), so an iteration reads 5 fragments per
+//     16-pixel block from LDS instead of 11 and needs ONE x row and ONE dY row image (two slots each) instead of a ring of four.
+// The DMA is issued through inline asm (M0 written in the same statement): hipcc drains the builtin's DMA with vmcnt(0) in front of every
+// LDS read of the same wave, which would serialise the ring; the waits here are counted (every wave issues exactly WT3_NDMA per row).
+// One raw s_barrier per row: [wait: row i + 1 landed] barrier [issue row i + D] [convert row i + 1 between the matrix instructions of row i].
+// MEASURED (round 5, tools/wgrad_dma_ablate.py -> profiles/r05_wgrad_dma_ablate.txt, PMC profiles/r05_pmc_wgrad_bf16_gen3.txt): bit-identical
+// on the same strips and 15 - 25 % SLOWER than the second generation (10 x 88 x 304 x 128 -> 128 with the bias gradient: 160 - 185 us against
+// 144 - 161 us on the same boxes), although it fetches less from HBM (299 MB against 379 MB: longer strips).  The ablations: without the DMA
+// the same launch takes 80 us, the DMA and its conversion alone 101 us, the conversion is hidden (- 5 us without it), the matrix instructions
+// nearly (- 14 us), the transposed reads are not (- 37 us); the launch moves 563 MB from L2 into LDS (both workgroups of a cout pair stage
+// the whole x row: 9 x 128 x 64 accumulators are what a CU's registers hold) at 2.2 TB/s of HBM traffic with the waves waiting 0.43 of
+// their cycles -- neither HBM nor the matrix pipe (busy 0.18) is the limit, the one-barrier-per-row lockstep of DMA wait, conversion and
+// multiplication is.  The library keeps the second generation (CMR_WGRAD_BF16_GEN 1); this kernel is built into the A/B library only.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int WT3_D = 5;                                  // raw rows in the ring
+constexpr int WT3_NDMA = 4;                               // DMA instructions per wave and row (3 of x, 1 of dY)
+constexpr int WT3_XRAW = (WT2_TW + 2) * 512;              // 17 408 B: 34 pixels x 128 channels fp32
+constexpr int WT3_DRAW = WT2_TW * 256;                    //  8 192 B: 32 pixels x 64 channels fp32
+constexpr int WT3_RAW = WT3_XRAW + WT3_DRAW;
+constexpr int WT3_XI = WT3_D * WT3_RAW;                   // bf16 x row images [2][WT2_XROW]
+constexpr int WT3_DI = WT3_XI + 2 * WT2_XROW;             // bf16 dY row images [2][WT2_DROW] (hi | lo)
+constexpr int WT3_SMEM = WT3_DI + 2 * WT2_DROW;           // 162 816 B of the 163 840
+__device__ __attribute__((aligned(16))) float wt3_zero[4] = {0.f, 0.f, 0.f, 0.f};     // NOT const (loads of a const zero page fold into branches)
+
+__device__ __forceinline__ void wt3_glds16(const float* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+// ABL: compile-time ablation mask (timing only, results meaningless; instantiated in the A/B library alone): 1 no DMA, 2 no conversion
+// pass, 4 no transposed reads (operands left as they are), 8 no matrix instructions
+template <bool BIAS, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
+                                                                        int Cout, int rps, int groups, float* __restrict__ part, float* __restrict__ part_b) {
+  constexpr int CIN = 128, TW = WT2_TW, D = WT3_D;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wt3_smem[];
+  if (ABL == 32) return;                                  // (ablation: the launch alone)
+  const unsigned lds0 = (unsigned)(size_t)wt3_smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci_t = wave & 3, co_h = wave >> 2;
+  const int ncp = Cout / 64;
+  int group, co_p;
+  if ((groups & 7) == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    co_p = j % ncp;
+    group = (j / ncp) * 8 + xcd;
+  } else {
+    co_p = blockIdx.x % ncp;
+    group = blockIdx.x / ncp;
+  }
+  const int ntx = (W + TW - 1) / TW, nys = (H + rps - 1) / rps;
+  const int nstrips = B * ntx * nys;
+  const int64_t img_px = (int64_t)H * W;
+
+  f32x16 acc[9], accb;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+
+  // transposed-read addresses (as in the kernel above)
+  const int g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3, h = g16 >> 1;
+  const int xchunk = 4 * ci_t + 2 * (g16 & 1) + (p4 >> 1);
+  const int dchunk = 4 * co_h + 2 * (g16 & 1) + (p4 >> 1);
+  const int sub8 = 8 * (p4 & 1);
+  int ox[2][3], od[2][2], ol[2][2];
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const int pd = 16 * pb + 8 * h + q4;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { ox[pb][j] = wt2_off(pd + 4 * j, xchunk) + sub8; asm volatile("" : "+v"(ox[pb][j])); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      od[pb][j] = wt2_off(pd + 4 * j, dchunk) + sub8; asm volatile("" : "+v"(od[pb][j]));
+      ol[pb][j] = wt2_off(pd + 4 * j, dchunk + 8) + sub8; asm volatile("" : "+v"(ol[pb][j]));
+    }
+  }
+  // conversion roles: x: thread -> (halo pixel xp0 + 16 i, channel quad xq); dY: thread -> (pixel dp, channel quad dq)
+  const int xq = tid & 31, xp0 = tid >> 5;
+  const int dq = tid & 15, dp = tid >> 4;
+  // DMA roles: x block k = raw bytes [1024 k, + 1024) = halo pixels 2 k, 2 k + 1 (lane: pixel 2 k + (lane >> 5), 16-byte chunk lane & 31);
+  // wave w issues blocks w, w + 8 and min(w + 16, 16) (17 blocks: the waves 1..7 repeat block 16 -- the same bytes to the same place -- so
+  // that every wave has the same number of DMA instructions in flight); dY block w = pixels 4 w .. 4 w + 3 (lane: pixel 4 w + (lane >> 4),
+  // chunk lane & 15)
+  int xk[3];
+  xk[0] = wave; xk[1] = wave + 8; xk[2] = wave + 16 < 17 ? wave + 16 : 16;
+  const int xlp = lane >> 5, xlc = lane & 31;
+  const int dlp = 4 * wave + (lane >> 4), dlc = lane & 15;
+
+  // The stream of row jobs of this workgroup: strip after strip, x rows y0 - 1 .. y1 of each (job = x row r + dY row r + 1).  ONE cursor
+  // (the DMA's); the per-lane column parts of the source addresses change with the strip only.  The conversion and the multiplication need
+  // no position at all: padding and rows outside a strip's range arrive as ZEROS (the zero page), so every job runs the same straight-line
+  // body -- a strip's first and last job multiply two zero fragments each (exact zeros onto the accumulators: + 25 % matrix instructions
+  // against eight strip-dependent branches per row; an empty loop of the branchy form took 0.55 us per row, profiles/r05_wgrad_dma_ablate.txt).
+  int cs = group, cr = 0, cy0 = 0, cy1 = 0, cb = 0;      // cursor: strip, x row, output rows [cy0, cy1), sample
+  int xoff[3], doff = 0;                                  // per lane: byte offset of the lane's 16 bytes within an x row / dY row, < 0: outside
+  auto open_strip = [&](int strip) {
+    cs = strip;
+    if (strip < nstrips) {
+      const int ys = strip % nys, xt = (strip / nys) % ntx;
+      cb = strip / (nys * ntx);
+      cy0 = ys * rps;
+      cy1 = min(H, cy0 + rps);
+      cr = cy0 - 1;
+      const int x0 = xt * TW;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int xx = x0 - 1 + 2 * xk[i] + xlp;
+        xoff[i] = xx >= 0 && xx < W ? (xx * CIN + 4 * xlc) * 4 : -1;
+      }
+      const int xx = x0 + dlp;
+      doff = xx < W ? (xx * Cout + co_p * 64 + 4 * dlc) * 4 : -1;
+    }
+  };
+  int njobs = 0;
+  for (int st = group; st < nstrips; st += groups) {
+    const int y0 = (st % nys) * rps;
+    njobs += min(H, y0 + rps) - y0 + 2;
+  }
+  auto issue = [&](int slot) {
+    if (ABL & 1) return;
+    const bool live = cs < nstrips;
+    const unsigned base = lds0 + (unsigned)(slot * WT3_RAW);
+    const bool rowx = live && cr >= 0 && cr < H;
+    const char* xb = reinterpret_cast<const char*>(x + ((int64_t)cb * img_px + (int64_t)(rowx ? cr : 0) * W) * CIN);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float* src = rowx && xoff[i] >= 0 ? reinterpret_cast<const float*>(xb + (unsigned)xoff[i]) : wt3_zero;
+      wt3_glds16(src, __builtin_amdgcn_readfirstlane(base + 1024u * (unsigned)xk[i]));
+    }
+    const int rd = cr + 1;
+    const bool rowd = live && rd >= cy0 && rd < cy1;
+    const char* db = reinterpret_cast<const char*>(dy + ((int64_t)cb * img_px + (int64_t)(rowd ? rd : 0) * W) * Cout);
+    const float* src = rowd && doff >= 0 ? reinterpret_cast<const float*>(db + (unsigned)doff) : wt3_zero;
+    wt3_glds16(src, __builtin_amdgcn_readfirstlane(base + (unsigned)WT3_XRAW + 1024u * (unsigned)wave));
+    // next job
+    if (live) {
+      if (cr < cy1) ++cr;
+      else open_strip(cs + groups);
+    }
+  };
+  // the bias gradient's matrix instructions (dY fragment x ones: hi and lo image of both 16-pixel blocks = 4 per row and cout tile) are
+  // dealt to the four ci waves of the cout tile, one each and row -- all of them in the waves ci_t = 0 they made SIMD 0 the slowest of the
+  // four by 8 of 44 instructions per row.  Wave ci_t: block ci_t >> 1, image ci_t & 1; its own partial sum (slice 4 group + ci_t).
+  int obias[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) obias[j] = (ci_t & 1) ? ol[ci_t >> 1][j] : od[ci_t >> 1][j];
+  uint4 ap1[2], a0[2], am1[2];                           // dY fragments of the rows r + 1, r, r - 1 (per 16-pixel block)
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) ap1[pb] = a0[pb] = am1[pb] = uint4{0u, 0u, 0u, 0u};
+  uint2 abl_keep = {0x3f803f80u, 0x3f803f80u};
+  auto trr = [&](const unsigned char* base, int off) __attribute__((always_inline)) -> uint2 {
+    if (ABL & 4) { asm volatile("" : "+v"(abl_keep.x), "+v"(abl_keep.y)); return abl_keep; }
+    return wt2_tr(base, off);
+  };
+  auto mm = [&](wg_bf16x8 a, wg_bf16x8 b, f32x16 c) __attribute__((always_inline)) -> f32x16 {
+    if (ABL & 8) { asm volatile("" : "+v"(a), "+v"(b)); return c; }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  };
+  // One row job: multiply row j from the images `img` while row j + 1 is converted from raw slot `slot` into the other images.  ONE
+  // straight-line block (the conversion's LDS reads and writes and its VALU work sit between the matrix instructions in program order, so
+  // that they issue under them; the two are independent: other images, other slot).
+  auto row = [&](int slot, int img) __attribute__((always_inline)) {
+    const unsigned char* ximg = wt3_smem + WT3_XI + img * WT2_XROW;
+    const unsigned char* dimg = wt3_smem + WT3_DI + img * WT2_DROW;
+    const unsigned char* raw = wt3_smem + slot * WT3_RAW;
+    unsigned char* xi = wt3_smem + WT3_XI + (img ^ 1) * WT2_XROW;
+    unsigned char* di = wt3_smem + WT3_DI + (img ^ 1) * WT2_DROW;
+    // ---- block 0 operands, the bias fragment, the raw row
+    uint2 f0 = trr(dimg, od[0][0]), f1 = trr(dimg, od[0][1]);
+    uint2 r0 = trr(ximg, ox[0][0]), r1 = trr(ximg, ox[0][1]), r2 = trr(ximg, ox[0][2]);
+    uint2 g0, g1;
+    if (BIAS) { g0 = trr(dimg, obias[0]); g1 = trr(dimg, obias[1]); }
+    f32x4 v[2], d;
+    if (!(ABL & 2)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = *reinterpret_cast<const f32x4*>(raw + (xp0 + 16 * i) * 512 + xq * 16);
+      d = *reinterpret_cast<const f32x4*>(raw + WT3_XRAW + dp * 256 + dq * 16);
+    }
+    ap1[0] = uint4{f0.x, f0.y, f1.x, f1.y};
+    {
+      const uint4 b0 = {r0.x, r0.y, r1.x, r1.y};
+      const uint4 b1 = {__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                        __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)};
+      const uint4 b2 = {r0.y, r1.x, r1.y, r2.x};
+      const wg_bf16x8 B0 = __builtin_bit_cast(wg_bf16x8, b0), B1 = __builtin_bit_cast(wg_bf16x8, b1), B2 = __builtin_bit_cast(wg_bf16x8, b2);
+      const wg_bf16x8 A0 = __builtin_bit_cast(wg_bf16x8, ap1[0]), A1 = __builtin_bit_cast(wg_bf16x8, a0[0]), A2 = __builtin_bit_cast(wg_bf16x8, am1[0]);
+      acc[0] = mm(A0, B0, acc[0]);                              // kernel row 0: output row r + 1
+      acc[1] = mm(A0, B1, acc[1]);
+      acc[2] = mm(A0, B2, acc[2]);
+      acc[3] = mm(A1, B0, acc[3]);                              // kernel row 1: output row r
+      acc[4] = mm(A1, B1, acc[4]);
+      acc[5] = mm(A1, B2, acc[5]);
+      acc[6] = mm(A2, B0, acc[6]);                              // kernel row 2: output row r - 1
+      acc[7] = mm(A2, B1, acc[7]);
+      acc[8] = mm(A2, B2, acc[8]);
+    }
+    // ---- block 1 operands; the converted row goes out
+    f0 = trr(dimg, od[1][0]); f1 = trr(dimg, od[1][1]);
+    r0 = trr(ximg, ox[1][0]); r1 = trr(ximg, ox[1][1]); r2 = trr(ximg, ox[1][2]);
+    if (!(ABL & 2)) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<uint2*>(xi + wt2_off(xp0 + 16 * i, xq >> 1) + 8 * (xq & 1)) = uint2{wg_pack2(v[i][0], v[i][1]), wg_pack2(v[i][2], v[i][3])};
+      const unsigned w0 = wg_pack2(d[0], d[1]), w1 = wg_pack2(d[2], d[3]);
+      *reinterpret_cast<uint2*>(di + wt2_off(dp, dq >> 1) + 8 * (dq & 1)) = uint2{w0, w1};
+      if (BIAS) {
+        const float l0 = d[0] - __builtin_bit_cast(float, w0 << 16), l1 = d[1] - __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const float l2 = d[2] - __builtin_bit_cast(float, w1 << 16), l3 = d[3] - __builtin_bit_cast(float, w1 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(di + wt2_off(dp, 8 + (dq >> 1)) + 8 * (dq & 1)) = uint2{wg_pack2(l0, l1), wg_pack2(l2, l3)};
+      }
+    }
+    ap1[1] = uint4{f0.x, f0.y, f1.x, f1.y};
+    if (BIAS) {
+      const uint4 one8 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+      accb = mm(__builtin_bit_cast(wg_bf16x8, uint4{g0.x, g0.y, g1.x, g1.y}), __builtin_bit_cast(wg_bf16x8, one8), accb);
+    }
+    {
+      const uint4 b0 = {r0.x, r0.y, r1.x, r1.y};
+      const uint4 b1 = {__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                        __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)};
+      const uint4 b2 = {r0.y, r1.x, r1.y, r2.x};
+      const wg_bf16x8 B0 = __builtin_bit_cast(wg_bf16x8, b0), B1 = __builtin_bit_cast(wg_bf16x8, b1), B2 = __builtin_bit_cast(wg_bf16x8, b2);
+      const wg_bf16x8 A0 = __builtin_bit_cast(wg_bf16x8, ap1[1]), A1 = __builtin_bit_cast(wg_bf16x8, a0[1]), A2 = __builtin_bit_cast(wg_bf16x8, am1[1]);
+      acc[0] = mm(A0, B0, acc[0]);
+      acc[1] = mm(A0, B1, acc[1]);
+      acc[2] = mm(A0, B2, acc[2]);
+      acc[3] = mm(A1, B0, acc[3]);
+      acc[4] = mm(A1, B1, acc[4]);
+      acc[5] = mm(A1, B2, acc[5]);
+      acc[6] = mm(A2, B0, acc[6]);
+      acc[7] = mm(A2, B1, acc[7]);
+      acc[8] = mm(A2, B2, acc[8]);
+    }
+#pragma unroll
+    for (int pb = 0; pb < 2; ++pb) { am1[pb] = a0[pb]; a0[pb] = ap1[pb]; }
+    // halo pixels 32, 33 of the converted row: the 64 quads left over after two passes of 512 threads (wave 0; uniform branch, kept out of
+    // the block above)
+    if (wave == 0 && !(ABL & 2)) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(raw + (xp0 + 32) * 512 + xq * 16);
+      *reinterpret_cast<uint2*>(xi + wt2_off(xp0 + 32, xq >> 1) + 8 * (xq & 1)) = uint2{wg_pack2(t[0], t[1]), wg_pack2(t[2], t[3])};
+    }
+  };
+  // row 0 of the stream: conversion alone (into images 0)
+  auto convert0 = [&]() {
+    const unsigned char* raw = wt3_smem;
+    unsigned char* xi = wt3_smem + WT3_XI;
+    unsigned char* di = wt3_smem + WT3_DI;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (i == 2 && wave != 0) break;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(raw + (xp0 + 16 * i) * 512 + xq * 16);
+      *reinterpret_cast<uint2*>(xi + wt2_off(xp0 + 16 * i, xq >> 1) + 8 * (xq & 1)) = uint2{wg_pack2(t[0], t[1]), wg_pack2(t[2], t[3])};
+    }
+    const f32x4 d = *reinterpret_cast<const f32x4*>(raw + WT3_XRAW + dp * 256 + dq * 16);
+    const unsigned w0 = wg_pack2(d[0], d[1]), w1 = wg_pack2(d[2], d[3]);
+    *reinterpret_cast<uint2*>(di + wt2_off(dp, dq >> 1) + 8 * (dq & 1)) = uint2{w0, w1};
+    if (BIAS) {
+      const float l0 = d[0] - __builtin_bit_cast(float, w0 << 16), l1 = d[1] - __builtin_bit_cast(float, w0 & 0xffff0000u);
+      const float l2 = d[2] - __builtin_bit_cast(float, w1 << 16), l3 = d[3] - __builtin_bit_cast(float, w1 & 0xffff0000u);
+      *reinterpret_cast<uint2*>(di + wt2_off(dp, 8 + (dq >> 1)) + 8 * (dq & 1)) = uint2{wg_pack2(l0, l1), wg_pack2(l2, l3)};
+    }
+  };
+
+  open_strip(group);
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d);                 // rows 0 .. D - 1 of the stream
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(WT3_NDMA * (D - 1)) : "memory");            // row 0 landed, in every wave
+  if (!(ABL & 2)) convert0();
+  int slot = 0;                                         // raw slot of row j
+  for (int j = 0; j < njobs; ++j) {
+    // row j + 1 landed (rows j + 2 .. j + D - 1 stay in flight); this wave's image writes of the last iteration are complete
+    if (!(ABL & 64)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(WT3_NDMA * (D - 2)) : "memory");
+    issue(slot);                                        // row j + D into the slot row j left (converted in the last iteration)
+    slot = slot + 1 == D ? 0 : slot + 1;
+    row(slot, j & 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the ring's last (dummy) rows: nothing of this workgroup's LDS may still be written
+  const int l31 = lane & 31;
+  float* out = part + (int64_t)group * 9 * Cout * CIN;
+  if (ABL & 16) {                                       // (ablation: one store per accumulator tile instead of 16)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float v = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v += acc[t][r];
+      out[((int64_t)t * Cout + (co_p * 2 + co_h) * 32 + cmr_mfma_row(0, lane)) * CIN + ci_t * 32 + l31] = v;
+    }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      out[((int64_t)t * Cout + (co_p * 2 + co_h) * 32 + cmr_mfma_row(r, lane)) * CIN + ci_t * 32 + l31] = acc[t][r];
+  if (BIAS && l31 == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part_b[(int64_t)(4 * group + ci_t) * Cout + (co_p * 2 + co_h) * 32 + cmr_mfma_row(r, lane)] = accb[r];
+  }
+}
+
 // db[c] = sum over the workgroup partials of the kernel above: 32 channels x 32 slice groups per workgroup, double accumulation, fixed order
 __global__ __launch_bounds__(1024) void conv_bias_reduce_kernel(const float* __restrict__ part_b, int nslices, int Cout, float* __restrict__ db) {
   __shared__ double sm[32][32];
@@ -1264,10 +1578,24 @@ inline WgLdsPlan wgrad_lds_plan(int B, int H, int W, int Cin, int Cout) {
 // bf16 weight gradient: maps of at least this many pixels take the transposed-read kernel (below, the fixed costs of either kernel -- partial
 // write-back, reduction -- dominate and the first-generation kernel's finer slices win)
 constexpr int64_t WGB_TR_MIN_PX = 32768;
+#ifndef CMR_WGRAD_BF16_GEN
+#define CMR_WGRAD_BF16_GEN 1            // 0: first generation everywhere, 1: transposed reads (rows through registers: the library's choice),
+                                        // 2: + rows by LDS-DMA (A/B library only: measured 15 - 25 % slower, see the kernel's header)
+#endif
+#ifndef CMR_WGRAD_BF16_SPW
+#define CMR_WGRAD_BF16_SPW 4            // generation 3: strips per workgroup the row count of a strip is sized for
+#endif
 #ifdef CMR_AB_SWITCHES
-static int g_wgrad_tr = 1;
+static int g_wgrad_tr = CMR_WGRAD_BF16_GEN;
+static int g_wgrad_spw = CMR_WGRAD_BF16_SPW;
+extern "C" int cmr_set_wgrad_bf16_strips(int per_workgroup) {
+  const int old = g_wgrad_spw;
+  if (per_workgroup > 0) g_wgrad_spw = per_workgroup;
+  return old;
+}
 #else
-static constexpr int g_wgrad_tr = 1;
+static constexpr int g_wgrad_tr = CMR_WGRAD_BF16_GEN;
+static constexpr int g_wgrad_spw = CMR_WGRAD_BF16_SPW;
 #endif
 #ifdef CMR_AB_SWITCHES
 static int g_lwgrad_lds = 1;
@@ -1287,7 +1615,7 @@ extern "C" int cmr_set_linear_wgrad_variant(int lds_staged) {
 
 extern "C" int cmr_set_wgrad_bf16_variant(int transposed_reads) {
   const int old = g_wgrad_tr;
-  g_wgrad_tr = transposed_reads ? 1 : 0;
+  g_wgrad_tr = transposed_reads < 0 ? 0 : (transposed_reads > 2 && transposed_reads < 16 ? 2 : transposed_reads);      // 16 + mask: ablations
   return old;
 }
 extern "C" int cmr_set_wgrad_variant(int lds_staged) {
@@ -1385,16 +1713,57 @@ extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, 
     const int ncp = Cout / 64;
     int groups = 256 / ncp;
     const int ntx = (W + WT2_TW - 1) / WT2_TW;
-    int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)8 * groups));
+    const bool gen3 = g_wgrad_tr >= 2;
+    // strips per workgroup: ~8 (generation 2), ~4 of twice the rows (generation 3: every strip costs it two rows of zero fragments)
+    int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)(gen3 ? g_wgrad_spw : 8) * groups));
     if (rps < 4) rps = 4;
     if (rps > H) rps = H;
     const int64_t nstrips = (int64_t)B * ntx * ((H + rps - 1) / rps);
     if (groups > nstrips) groups = (int)nstrips;
     const int64_t part_floats = (int64_t)groups * 9 * Cout * Cin;
-    CMR_REQUIRE(ws_bytes >= (part_floats + (db ? (int64_t)groups * Cout : 0)) * (int64_t)sizeof(float));
+    const int bslices = gen3 ? 4 * groups : groups;          // bias partials: generation 3 keeps one per ci wave
+    CMR_REQUIRE(ws_bytes >= (part_floats + (db ? (int64_t)bslices * Cout : 0)) * (int64_t)sizeof(float));
     float* part = (float*)ws;
     float* part_b = db ? part + part_floats : nullptr;
-    static CmrSmemCache granted_b{}, granted_n{};
+    static CmrSmemCache granted_b{}, granted_n{}, granted_b3{}, granted_n3{};
+#ifdef CMR_AB_SWITCHES
+    if (g_wgrad_tr >= 16) {                               // ablations of the third-generation kernel (tools/wgrad_dma_ablate.py)
+      static CmrSmemCache g_abl[32]{};
+      const void* f[32] = {
+          (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 0>, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 1>, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 2>,
+          (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 3>, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 4>, nullptr, nullptr, nullptr,
+          (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 8>, nullptr, nullptr, nullptr, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 12>, nullptr, nullptr,
+          (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 15>, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 16>,
+          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+          (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 31>};
+      int m = g_wgrad_tr - 16;
+      const void* f32_ = (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 32>;
+      const void* f95_ = (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 95>;
+      static CmrSmemCache g32{}, g95{};
+      if (m == 32 || m == 95) {
+        if (!db || cmr_grant_smem(m == 32 ? f32_ : f95_, WT3_SMEM, m == 32 ? g32 : g95) != CMR_OK) return CMR_ELAUNCH;
+        void* args2[] = {(void*)&x, (void*)&dy, (void*)&B, (void*)&H, (void*)&W, (void*)&Cout, (void*)&rps, (void*)&groups, (void*)&part, (void*)&part_b};
+        if (hipLaunchKernel(m == 32 ? f32_ : f95_, dim3(groups * ncp), dim3(512), args2, WT3_SMEM, stream) != hipSuccess) return CMR_ELAUNCH;
+        return cmr_launch_status();
+      }
+      if (m < 0 || m > 31 || !f[m] || !db) return CMR_EINVAL;
+      if (cmr_grant_smem(f[m], WT3_SMEM, g_abl[m]) != CMR_OK) return CMR_ELAUNCH;
+      void* args[] = {(void*)&x, (void*)&dy, (void*)&B, (void*)&H, (void*)&W, (void*)&Cout, (void*)&rps, (void*)&groups, (void*)&part, (void*)&part_b};
+      if (hipLaunchKernel(f[m], dim3(groups * ncp), dim3(512), args, WT3_SMEM, stream) != hipSuccess) return CMR_ELAUNCH;
+      return cmr_launch_status();
+    }
+#endif
+#ifdef CMR_AB_SWITCHES
+    if (g_wgrad_tr == 2) {
+      if (db) {
+        if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_dma_kernel<true>), WT3_SMEM, granted_b3) != CMR_OK) return CMR_ELAUNCH;
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_dma_kernel<true>, dim3(groups * ncp), dim3(512), WT3_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
+      } else {
+        if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_dma_kernel<false>), WT3_SMEM, granted_n3) != CMR_OK) return CMR_ELAUNCH;
+        hipLaunchKernelGGL(conv3x3_wgrad_bf16_dma_kernel<false>, dim3(groups * ncp), dim3(512), WT3_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
+      }
+    } else
+#endif
     if (db) {
       if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_tr_kernel<true>), WT2_SMEM, granted_b) != CMR_OK) return CMR_ELAUNCH;
       hipLaunchKernelGGL(conv3x3_wgrad_bf16_tr_kernel<true>, dim3(groups * ncp), dim3(512), WT2_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
@@ -1403,7 +1772,7 @@ extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, 
       hipLaunchKernelGGL(conv3x3_wgrad_bf16_tr_kernel<false>, dim3(groups * ncp), dim3(512), WT2_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
     }
     hipLaunchKernelGGL(conv3x3_wgrad_reduce_kernel, dim3((9 * Cout * Cin + RED_OUT - 1) / RED_OUT), dim3(256), 0, stream, (const float*)part, groups, Cout, Cin, dw);
-    if (db) hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, stream, (const float*)part_b, groups, Cout, db);
+    if (db) hipLaunchKernelGGL(conv_bias_reduce_kernel, dim3((Cout + 31) / 32), dim3(1024), 0, stream, (const float*)part_b, bslices, Cout, db);
     return cmr_launch_status();
   }
   // persistent workgroups, one per CU (288 accumulator registers per wave at two cout tiles), over all cout groups; ~8 column strips

@@ -46,10 +46,17 @@ int cmr_set_mha_variant(int mfma);
  * to fp32 rounding); returns the previous setting. */
 int cmr_set_wgrad_variant(int lds_staged);
 
-/* A/B switch of the bf16 3x3 weight gradient: 1 (default) = Cin 128 / Cout % 64 == 0 maps of >= 32 768 pixels take the second-generation
- * kernel (rows staged as they lie in memory, operands through ds_read_b64_tr_b16, 64 couts per 8-wave workgroup), 0 = the first-generation
- * kernel everywhere (rows transposed by the lanes on the way into LDS).  Same products, other summation order; returns the previous setting. */
-int cmr_set_wgrad_bf16_variant(int transposed_reads);
+/* A/B switch of the bf16 3x3 weight gradient on Cin 128 / Cout % 64 == 0 maps of >= 32 768 pixels: 1 (default, the product library's only
+ * choice) = second generation (rows staged through registers as they lie in memory, operands through ds_read_b64_tr_b16, 64 couts per
+ * 8-wave workgroup), 2 = third generation (rows by LDS-DMA into a raw ring, one input row per iteration; on the same strips bit-identical
+ * to 1; round-5 experiment, measured slower: profiles/r05_wgrad_dma_ablate.txt), 16 + mask = its timing-only ablations, 0 = the
+ * first-generation kernel everywhere (rows transposed by the lanes on the way into LDS; same products, other summation order).
+ * Returns the previous setting. */
+int cmr_set_wgrad_bf16_variant(int generation);
+
+/* Third-generation bf16 weight gradient: strips per workgroup the row count of a strip is sized for (default 4; <= 0 keeps the
+ * setting).  Other strips = other partial sums: results agree to fp32 rounding.  Returns the previous setting. */
+int cmr_set_wgrad_bf16_strips(int per_workgroup);
 
 /* A/B switch: 1 (default) = row maps of >= 65 536 rows with n, k multiples of 32 up to 128 take the LDS-staged kernel (whole-row
  * float4 staging, the full gradient per workgroup), 2 = from 8192 rows on (tests), 0 = the direct kernel everywhere.  Same sums in

@@ -172,6 +172,37 @@ def test_conv3x3_weight_gradient_bf16(B, H, W, cin, cout):
     assert err <= 2e-5 * float(dy.double().abs().sum(dim=(0, 2, 3)).max()), err
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(4, 64, 130, 128, 128), (5, 45, 152, 128, 64), (3, 88, 160, 128, 256), (10, 88, 304, 128, 128)])
+def test_conv3x3_weight_gradient_bf16_rows_by_lds_dma_is_bit_identical(B, H, W, cin, cout):
+    """The third-generation kernel (rows by LDS-DMA into a raw ring, one input row per iteration with the dY fragments of three rows kept
+    in registers) forms the same products and adds them in the same order as the second-generation one (rows through registers, one
+    output row per iteration): on the same strips the weight gradient is equal to the last bit, incl. ragged widths, strips that end
+    mid-image and the agent update's own map."""
+    from cmr_agent_amd import ops, _lib
+    x, dy = rnd(B, H, W, cin, seed=41).to(DEV), rnd(B, H, W, cout, seed=42).to(DEV)
+    out = {}
+    ops.CONV_BF16 = True
+    try:
+        with _lib.ab() as lib:
+            old = lib.cmr_set_wgrad_bf16_variant(1)
+            old_spw = lib.cmr_set_wgrad_bf16_strips(8)          # the second generation's strips: the same partial sums
+            try:
+                for gen in (1, 2):
+                    lib.cmr_set_wgrad_bf16_variant(gen)
+                    dw, db, dw0 = torch.empty(cout * cin * 9, device=DEV), torch.empty(cout, device=DEV), torch.empty(cout * cin * 9, device=DEV)
+                    ops.conv3x3_wgrad(x, dy, dw, db=db)
+                    ops.conv3x3_wgrad(x, dy, dw0)
+                    out[gen] = (dw, db, dw0)
+            finally:
+                lib.cmr_set_wgrad_bf16_variant(old)
+                lib.cmr_set_wgrad_bf16_strips(old_spw)
+    finally:
+        ops.CONV_BF16 = False
+    assert torch.equal(out[1][0], out[2][0]) and torch.equal(out[1][2], out[2][2]), float((out[1][0] - out[2][0]).abs().max())
+    # the bias gradient's four matrix instructions per row are dealt to four waves (four partial sums instead of one): fp32 rounding apart
+    assert float((out[1][1] - out[2][1]).abs().max()) <= 2e-6 * float(dy.abs().sum(dim=(0, 1, 2)).max())
+
+
 def test_configs3_batch_of_four_in_bf16_is_sample_independent_and_rigid():
     """BASELINE configs[3] runs 4 pairs per GPU in bf16.  No oracle at that size in seconds, so size-independent properties: every pair of
     the batch of 4 gets the result it gets alone (no cross-sample coupling anywhere on the inference path: eval-mode BatchNorm, per-sample

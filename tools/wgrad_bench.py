@@ -21,15 +21,17 @@ def main():
         tb = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw), 10)
         dbias = torch.empty(co, device=dev)
         tbb = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, db=dbias), 10)
-        tb1 = None
-        if ci == 128 and B * H * W >= 32768:               # the first-generation kernel on the same map (A/B switch)
+        tb1 = tb2 = None
+        if ci == 128 and B * H * W >= 32768:               # the first- and second-generation kernels on the same map (A/B switch)
             old = _lib.use_ab().cmr_set_wgrad_bf16_variant(0)
             tb1 = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, db=dbias), 10)
+            _lib.use_ab().cmr_set_wgrad_bf16_variant(1)
+            tb2 = timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, db=dbias), 10)
             _lib.use_ab().cmr_set_wgrad_bf16_variant(old)
         ops.CONV_BF16 = False
         by = 4.0 * B * H * W * (ci + co)
         print("wgrad %2d x %3dx%-3d %3d->%-3d : LDS-staged %7.1f us = %5.1f TFLOP/s (%.2f of peak) | direct %7.1f us = %5.1f TFLOP/s | bf16 %7.1f us = %6.1f TFLOP/s, %4.2f TB/s; with the bias gradient %7.1f us" % (
-            B, H, W, ci, co, t[1], fl / t[1] / 1e6, fl / t[1] / 1e6 / 157.3, t[0], fl / t[0] / 1e6, tb, fl / tb / 1e6, by / tb / 1e6, tbb) + ("" if tb1 is None else " (first-generation kernel: %7.1f us)" % tb1))
+            B, H, W, ci, co, t[1], fl / t[1] / 1e6, fl / t[1] / 1e6 / 157.3, t[0], fl / t[0] / 1e6, tb, fl / tb / 1e6, by / tb / 1e6, tbb) + ("" if tb1 is None else " (first-generation kernel: %7.1f us, second: %7.1f us)" % (tb1, tb2)))
 
 if __name__ == "__main__":
     main()
