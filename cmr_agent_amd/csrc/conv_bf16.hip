@@ -38,6 +38,9 @@ struct B16Args {
   int res_bf16;          // the residual operand is a bf16 NHWC map (bf16-STORED towers: the block input of a ResidualBlock, round 3)
   int wnt;               // cout tiles per group in the fragment layout of wfrag (the matrix-class kernel walks it by 32-cout tile)
   int cu_budget;         // host only: CUs the persistent kernels may occupy (0 = all); an argument of the entry points
+  // input prologue of the matrix-class kernel (training, cmr_conv3x3_bf16_pro_nhwc_f32): x is the PREVIOUS layer's BatchNorm input and the
+  // operand is lrelu_{in_slope}(x * in_scale + in_shift) per input channel, formed in the fp32 -> bf16 staging pass (zero padding after it)
+  const float* in_scale; const float* in_shift; float in_slope;
 };
 
 __device__ __attribute__((aligned(16))) float b16_zero16[4] = {0.f, 0.f, 0.f, 0.f};
@@ -678,9 +681,10 @@ int launch_tt(B16Args a, hipStream_t stream) {
 //     the other LDS buffer.  Their long-latency loads live in their own vmcnt queues -- in ONE wave they would sit between the ring
 //     loads and every ring wait would also wait for HBM.
 // One barrier per (tile, chunk) unit, met by all eight waves.  Results: same products as the kernels above, accumulated chunk-major.
-template <int CIN, bool POOL, int IO>      // IO: bit 0 = bf16 input, bit 1 = bf16 output
+template <int CIN, bool POOL, int IO, bool PRO = false>      // IO: bit 0 = bf16 input, bit 1 = bf16 output; PRO: BatchNorm + LeakyReLU of the input in the staging pass
 __global__ __launch_bounds__(512) void conv3x3_bf16_mm_kernel(const B16Args a) {
   constexpr bool IN16 = (IO & 1) != 0, OUT16 = (IO & 2) != 0;
+  static_assert(!PRO || !IN16, "the input prologue works on fp32 activations");
   constexpr int KC = CIN / 64, KSG = CIN / 16, KT = 36 * KC;
   constexpr int TH = 8, TW = 32, HR = TH + 2, HC = TW + 2, NPIX = HR * HC;
   constexpr int PS = 64 * 2 + 16;
@@ -715,6 +719,16 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_mm_kernel(const B16Args a) {
     constexpr int NLOAD = (NPIECE + 255) / 256;
     constexpr int ES = IN16 ? 2 : 4;
     f32x4 pv[NLOAD];
+    // PRO: a staging thread's 16-byte piece is the same channel quad of every pixel it handles (256 % PPP == 0): the affine of the unit's
+    // 64-channel chunk sits in registers.  The same fused multiply-add and the same select as cmr_affine_act_f32: the operand is bit for
+    // bit what that pass would have stored
+    f32x4 psc0, psh0, psc1, psh1;                       // (named registers: an indexed pair became a stack object)
+    if constexpr (PRO) {
+      psc0 = *reinterpret_cast<const f32x4*>(a.in_scale + 4 * (ht % PPP));
+      psh0 = *reinterpret_cast<const f32x4*>(a.in_shift + 4 * (ht % PPP));
+      psc1 = *reinterpret_cast<const f32x4*>(a.in_scale + (KC - 1) * 64 + 4 * (ht % PPP));
+      psh1 = *reinterpret_cast<const f32x4*>(a.in_shift + (KC - 1) * 64 + 4 * (ht % PPP));
+    }
     auto issue_loads = [&](int u) __attribute__((always_inline)) {
       const Tile t = decode(s0 + (u / KC) * step);
       const int kc = u % KC;
@@ -746,7 +760,16 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_mm_kernel(const B16Args a) {
             w.x &= keep; w.y &= keep; w.z &= keep; w.w &= keep;
             *reinterpret_cast<uint4*>(Xs + p * PS + c * 16) = w;
           } else {
-            uint2 w = b16_pack4(pv[i]);
+            f32x4 v = pv[i];
+            if constexpr (PRO) {
+              const bool hi = KC == 2 && (u % KC) != 0;                       // (uniform) the unit's 64-channel chunk
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                v[q] = __builtin_fmaf(v[q], hi ? psc1[q] : psc0[q], hi ? psh1[q] : psh0[q]);
+                v[q] = fmaxf(v[q], v[q] * a.in_slope);              // = the select for 0 <= slope <= 1 (the entry point checks), one instruction less
+              }
+            }
+            uint2 w = b16_pack4(v);
             w.x &= keep; w.y &= keep;
             *reinterpret_cast<uint2*>(Xs + p * PS + c * 8) = w;
           }
@@ -911,11 +934,11 @@ __global__ __launch_bounds__(512) void conv3x3_bf16_mm_kernel(const B16Args a) {
   }
 }
 
-template <int CIN, bool POOL, int IO>
+template <int CIN, bool POOL, int IO, bool PRO = false>
 int launch_mm_p(B16Args a, hipStream_t stream) {
   constexpr int smem = 2 * 10 * 34 * 144 + 512;
   static CmrSmemCache granted{};
-  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_mm_kernel<CIN, POOL, IO>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_bf16_mm_kernel<CIN, POOL, IO, PRO>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
   a.tiles_x = (a.W + 31) / 32;
   a.tiles_y = (a.H + 7) / 8;
   a.bias_mul = a.bias ? 1 : 0;
@@ -925,7 +948,7 @@ int launch_mm_p(B16Args a, hipStream_t stream) {
   int per_group = cus / ngroups;                        // one persistent workgroup per CU
   if (per_group < 1) per_group = 1;
   if (per_group > nsp) per_group = (int)nsp;
-  hipLaunchKernelGGL((conv3x3_bf16_mm_kernel<CIN, POOL, IO>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((conv3x3_bf16_mm_kernel<CIN, POOL, IO, PRO>), dim3(ngroups * per_group), dim3(512), smem, stream, a);
   return cmr_launch_status();
 }
 
@@ -1003,6 +1026,26 @@ extern "C" int cmr_conv3x3_bf16_nhwc_f32(const float* x, int B, int H, int W, in
                                          const float* res, const float* post, float* y, int Cout, int stride, float slope, int pool,
                                          int cu_budget, hipStream_t stream) {
   return conv3x3_bf16_dispatch(x, 0, B, H, W, Cin, wfrag, nt, bias, res, 0, post, y, 0, Cout, stride, slope, pool, cu_budget, stream);
+}
+
+// Training forward of [BatchNorm -> LeakyReLU(in_slope) -> 3x3 conv (+ bias, LeakyReLU(slope))] without the activated map in memory: x is the
+// BatchNorm INPUT (fp32 NHWC), in_scale / in_shift [Cin] its folded affine (stat[2], stat[3] of cmr_bn_stats_f32); the operand
+// lrelu(x * in_scale + in_shift) is formed while the halo is converted to bf16 (padding stays zero) -- bit for bit the operand the
+// convolution reads from the map cmr_affine_act_f32 would have written.  Served by the matrix-class kernel only (Cin = 128, Cout % 128 == 0,
+// maps of >= 128 8x32-pixel tiles x Cout / 128); CMR_EUNSUPPORTED otherwise: the caller materialises the activation.
+extern "C" int cmr_conv3x3_bf16_pro_nhwc_f32(const float* x, const float* in_scale, const float* in_shift, float in_slope, int B, int H, int W,
+                                             int Cin, const void* wfrag, int nt, const float* bias, float* y, int Cout, float slope, int cu_budget,
+                                             hipStream_t stream) {
+  CMR_REQUIRE(x && in_scale && in_shift && wfrag && y && B > 0 && H > 0 && W > 0 && Cout > 0);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(in_scale) && cmr_aligned16(in_shift) && cmr_aligned16(wfrag) && cmr_aligned16(y) &&
+              (!bias || cmr_aligned16(bias)));
+  CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < 0x7fffffff);
+  if (!(in_slope >= 0.f && in_slope <= 1.f)) return CMR_EUNSUPPORTED;
+  if (!(CMR_B16_MM && Cin == 128 && nt == 1 && Cout % 128 == 0 &&
+        (int64_t)B * ((H + 7) / 8) * ((W + 31) / 32) * (Cout / 128) >= CMR_B16_MM_MIN_TILES))
+    return CMR_EUNSUPPORTED;
+  B16Args a{x, B, H, W, wfrag, bias, nullptr, nullptr, y, Cout, slope, 1, 0, 0, 0, 0, 0, 0, 0, nt, cu_budget, in_scale, in_shift, in_slope};
+  return launch_mm_p<128, false, 0, true>(a, stream);
 }
 
 extern "C" int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,

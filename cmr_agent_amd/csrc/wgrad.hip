@@ -653,11 +653,22 @@ __device__ __forceinline__ uint2 wt2_tr(const unsigned char* base, int byte_off)
   return __builtin_bit_cast(uint2, v);
 }
 
-template <bool BIAS>
+// XPRO: x is a BatchNorm INPUT and the operand is lrelu_{xslope}(x * xscale + xshift) per channel (the activation was never stored:
+// cmr_conv3x3_bf16_pro_nhwc_f32 formed it the same way in the forward); the affine sits in LDS behind the images, the staging pass applies
+// it with the fused multiply-add and the select of cmr_affine_act_f32 -- bit for bit the operand read from the stored map.
+template <bool BIAS, bool XPRO = false>
 __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_tr_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W,
-                                                                       int Cout, int rps, int groups, float* __restrict__ part, float* __restrict__ part_b) {
+                                                                       int Cout, int rps, int groups, float* __restrict__ part, float* __restrict__ part_b,
+                                                                       const float* __restrict__ xscale = nullptr, const float* __restrict__ xshift = nullptr,
+                                                                       float xslope = 1.f) {
   constexpr int CIN = 128, TW = WT2_TW;
   extern __shared__ __attribute__((aligned(16))) unsigned char wt2_smem[];
+  float* xaff = reinterpret_cast<float*>(wt2_smem + WT2_SMEM);            // XPRO: [2][128] scale | shift
+  if (XPRO) {
+    if (threadIdx.x < 128) xaff[threadIdx.x] = xscale[threadIdx.x];
+    else if (threadIdx.x < 256) xaff[threadIdx.x] = xshift[threadIdx.x - 128];
+    __syncthreads();
+  }
   unsigned char* XI = wt2_smem;                         // [4][36 px][256 B]
   unsigned char* DI = wt2_smem + 4 * WT2_XROW;          // [2][32 px][256 B]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -730,7 +741,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_tr_kernel(const flo
       for (int i = 0; i < 3; ++i) {
         const int px = xpix(i), xx = x0 - 1 + px;
         const bool ok = r >= 0 && r < H && xx >= 0 && xx < W;
-        const f32x4 v = ok ? src[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 t = src[i];
+        if (XPRO) {
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(xaff + 4 * xq), sh = *reinterpret_cast<const f32x4*>(xaff + 128 + 4 * xq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            t[e] = __builtin_fmaf(t[e], sc[e], sh[e]);
+            t[e] = fmaxf(t[e], t[e] * xslope);                  // = the select for 0 <= slope <= 1 (checked by the entry point)
+          }
+        }
+        const f32x4 v = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<uint2*>(slot + wt2_off(px, xq >> 1) + 8 * (xq & 1)) = uint2{wg_pack2(v[0], v[1]), wg_pack2(v[2], v[3])};
       }
     };
@@ -1702,12 +1722,30 @@ extern "C" int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B
   return cmr_conv3x3_wgrad_bias_bf16_f32(x, dy, B, H, W, Cin, Cout, dw, nullptr, ws, ws_bytes, stream);
 }
 
+static int wgrad_bias_bf16(const float* x, const float* xscale, const float* xshift, float xslope, const float* dy, int B, int H, int W, int Cin,
+                           int Cout, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t stream);
 extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, float* db,
                                                void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return wgrad_bias_bf16(x, nullptr, nullptr, 1.f, dy, B, H, W, Cin, Cout, dw, db, ws, ws_bytes, stream);
+}
+// The same with x given as a BatchNorm INPUT: the operand is lrelu_{xslope}(x * xscale + xshift) per input channel, formed in the staging
+// pass (the layer's forward ran cmr_conv3x3_bf16_pro_nhwc_f32 and never stored the activation).  Served where the second-generation
+// kernel runs (Cin = 128, Cout % 64 == 0, >= 32 768 pixels); CMR_EUNSUPPORTED otherwise.
+extern "C" int cmr_conv3x3_wgrad_bias_bf16_pro_f32(const float* x, const float* xscale, const float* xshift, float xslope, const float* dy, int B,
+                                                   int H, int W, int Cin, int Cout, float* dw, float* db, void* ws, int64_t ws_bytes,
+                                                   hipStream_t stream) {
+  CMR_REQUIRE(xscale && xshift && cmr_aligned16(xscale) && cmr_aligned16(xshift));
+  if (!(xslope >= 0.f && xslope <= 1.f)) return CMR_EUNSUPPORTED;
+  return wgrad_bias_bf16(x, xscale, xshift, xslope, dy, B, H, W, Cin, Cout, dw, db, ws, ws_bytes, stream);
+}
+
+static int wgrad_bias_bf16(const float* x, const float* xscale, const float* xshift, float xslope, const float* dy, int B, int H, int W, int Cin,
+                           int Cout, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(x && dy && dw && ws && B > 0 && H > 0 && W >= 2);
   CMR_REQUIRE((Cout == 32 || Cout == 64 || Cout == 128 || Cout == 256) && (Cin == 64 || Cin == 128));
   CMR_REQUIRE((int64_t)B * H * W * (Cin > Cout ? Cin : Cout) < (int64_t)0x7fffffff);       // 32-bit element offsets within an image batch
   const int nci = Cin / 32, nsplit = 4 / nci;
+  if (xscale && !(Cin == 128 && Cout % 64 == 0 && (int64_t)B * H * W >= WGB_TR_MIN_PX && g_wgrad_tr == 1)) return CMR_EUNSUPPORTED;
   if (Cin == 128 && Cout % 64 == 0 && (int64_t)B * H * W >= WGB_TR_MIN_PX && g_wgrad_tr) {
     // second-generation kernel (hardware-transposed operand reads, 64 couts per 8-wave workgroup): one persistent workgroup per CU
     const int ncp = Cout / 64;
@@ -1764,7 +1802,19 @@ extern "C" int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, 
       }
     } else
 #endif
-    if (db) {
+    if (xscale) {
+      static CmrSmemCache granted_bp{}, granted_np{};
+      constexpr int smem = WT2_SMEM + 1024;
+      if (db) {
+        if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_tr_kernel<true, true>), smem, granted_bp) != CMR_OK) return CMR_ELAUNCH;
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_tr_kernel<true, true>), dim3(groups * ncp), dim3(512), smem, stream, x, dy, B, H, W, Cout, rps, groups, part,
+                           part_b, xscale, xshift, xslope);
+      } else {
+        if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_tr_kernel<false, true>), smem, granted_np) != CMR_OK) return CMR_ELAUNCH;
+        hipLaunchKernelGGL((conv3x3_wgrad_bf16_tr_kernel<false, true>), dim3(groups * ncp), dim3(512), smem, stream, x, dy, B, H, W, Cout, rps, groups, part,
+                           part_b, xscale, xshift, xslope);
+      }
+    } else if (db) {
       if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wgrad_bf16_tr_kernel<true>), WT2_SMEM, granted_b) != CMR_OK) return CMR_ELAUNCH;
       hipLaunchKernelGGL(conv3x3_wgrad_bf16_tr_kernel<true>, dim3(groups * ncp), dim3(512), WT2_SMEM, stream, x, dy, B, H, W, Cout, rps, groups, part, part_b);
     } else {

@@ -226,6 +226,20 @@ def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, s
     return None
 
 
+def conv3x3_bn_pro(x, in_scale, in_shift, in_slope, bias, cout, slope, u):
+    """conv3x3(lrelu_{in_slope}(x * in_scale + in_shift)) + bias, LeakyReLU(slope), with the affine + activation applied in the convolution's
+    staging pass (bf16 mode, matrix-class kernel): bit-identical to affine_act + conv3x3.  None where not served."""
+    B, H, W, cin = x.shape
+    fr = getattr(u, "bf16", None)
+    if not (CONV_BF16 and fr is not None and x.dtype == f32 and x.is_contiguous() and cin == 128 and in_scale.numel() == cin and in_shift.numel() == cin):
+        return None
+    wf, nt = fr
+    y = torch.empty((B, H, W, cout), dtype=f32, device=x.device)
+    rc = _lib.call("cmr_conv3x3_bf16_pro_nhwc_f32", _p(x), _p(in_scale), _p(in_shift), float(in_slope), B, H, W, cin, _p(wf), nt, _p(bias), _p(y),
+                   cout, float(slope), _cu_budget(), _stream(), allow_unsupported=True)
+    return None if rc == _lib.UNSUPPORTED else y
+
+
 def conv3x3(x, w9, bias, cout, stride=1, slope=1.0, res=None, post=None, out=None, pool=1, u=None, out_bf16=False):
     """x [B,H,W,Cin] contiguous NHWC; w9 [9,Cout,Cin]; returns [B,Ho,Wo,Cout] (or the 2x2 average-pooled
     map when pool=2: fused into the conv epilogue where the tiled kernel runs, a second kernel otherwise).
@@ -1048,15 +1062,24 @@ def transpose_slots(src, dst, table, nslots, total_tiles):
 WGRAD_BF16 = True        # with CONV_BF16: 3x3 weight gradients on the bf16 cores as well (False: fp32 weight gradients, round 2's behaviour)
 
 
-def conv3x3_wgrad(x, dy, dw, db=None):
+def conv3x3_wgrad(x, dy, dw, db=None, xpro=None):
     """x [B,H,W,Cin], dy [B,H,W,Cout] (contiguous NHWC) -> dw (flat view of [Cout,Cin,3,3] in the gradient bucket); db [Cout] (optional):
-    the bias gradient, from the same launch on the bf16 path, by a column sum over dy otherwise."""
+    the bias gradient, from the same launch on the bf16 path, by a column sum over dy otherwise.
+    xpro = (scale, shift, slope): x is a BatchNorm input and the operand is lrelu_slope(x * scale + shift) (conv3x3_bn_pro's forward); returns
+    False when that form is not served (the caller materialises the activation)."""
     B, H, W, cin = x.shape
     cout = dy.shape[3]
     if not (x.is_contiguous() and dy.is_contiguous()) or dw.numel() != cout * cin * 9:
         raise ValueError("conv3x3_wgrad: bad operand layout")
     nb = _lib.load().cmr_conv3x3_wgrad_workspace_bytes(B, H, W, cin, cout)
     ws = _ws(nb, x.device)
+    if xpro is not None:
+        if not (CONV_BF16 and WGRAD_BF16 and cin == 128):
+            return False
+        sc, sh, sl = xpro
+        rc = _lib.call("cmr_conv3x3_wgrad_bias_bf16_pro_f32", _p(x), _p(sc), _p(sh), float(sl), _p(dy), B, H, W, cin, cout, _p(dw), _p(db), _p(ws), nb,
+                       _stream(), allow_unsupported=True)
+        return rc != _lib.UNSUPPORTED
     # bf16 training mode: the weight gradient on the bf16 matrix cores too (operands rounded to bf16, fp32 accumulate), like the forward
     # and data-gradient convolutions
     if CONV_BF16 and WGRAD_BF16 and cin in (64, 128):

@@ -155,8 +155,13 @@ class AgentUpdate:
             Bq, H, W, _ = a.shape
             ar = a.view(-1, c)
             stat = self._bn(ar, e[ia + 1], "state_2d_embed.%d" % (ia + 1))
-            z = ops.affine_act(ar, stat[2], stat[3], slope=SLOPE2D).view(Bq, H, W, c)
-            d = ops.conv3x3(z, w9b, bk.w(nb + ".bias"), c, 1, SLOPE2D, u=ub)
+            # bf16 mode, big maps: BatchNorm + LeakyReLU applied in conv b's own staging pass (and in its weight gradient's) -- the activated
+            # map is never written; bit-identical to the two-pass form (cmr_conv3x3_bf16_pro_nhwc_f32)
+            d = ops.conv3x3_bn_pro(a, stat[2], stat[3], SLOPE2D, bk.w(nb + ".bias"), c, SLOPE2D, ub) if self.LAZY_2D else None
+            z = None
+            if d is None:
+                z = ops.affine_act(ar, stat[2], stat[3], slope=SLOPE2D).view(Bq, H, W, c)
+                d = ops.conv3x3(z, w9b, bk.w(nb + ".bias"), c, 1, SLOPE2D, u=ub)
             T["stages"].append(dict(xin=x, a=a, z=z, d=d, stat=stat, na=na, nb=nb, nbn="state_2d_embed.%d" % (ia + 1), H=H, W=W))
             if s < 3:
                 x = ops.avgpool(d, 2, 2)
@@ -276,7 +281,13 @@ class AgentUpdate:
             H, W = st["H"], st["W"]
             ph, pw = (2, 2) if s < 3 else (H, W)
             dc = ops.pool_act_bwd(g.contiguous(), st["d"], ph, pw, SLOPE2D)                 # through the pool and conv b's LeakyReLU
-            ops.conv3x3_wgrad(st["z"], dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"))
+            z = st["z"]
+            if z is None:                                # lazy forward: the operand from the BatchNorm input, or (shape not served) rebuilt
+                if not ops.conv3x3_wgrad(st["a"], dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"),
+                                         xpro=(st["stat"][2], st["stat"][3], SLOPE2D)):
+                    z = ops.affine_act(st["a"].view(-1, c), st["stat"][2], st["stat"][3], slope=SLOPE2D).view(st["a"].shape)
+            if z is not None:
+                ops.conv3x3_wgrad(z, dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"))
             dz = self._dgrad(dc, st["nb"], c, 2 * s)
             # (activation mask from the sign of the BatchNorm output, recomputed from `a`: the stored z is not read again)
             da = self._bn_bwd(dz.view(-1, c), None, SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
@@ -343,6 +354,7 @@ class AgentUpdate:
 
     FUSED_3D = __import__("os").environ.get("CMR_AGENT_FUSED_3D", "1") == "1"
     LAZY_3D = __import__("os").environ.get("CMR_AGENT_LAZY_3D", "1") == "1"
+    LAZY_2D = __import__("os").environ.get("CMR_AGENT_LAZY_2D", "1") == "1"
     LAZY_SHAPES = ((64, 64), (64, 128))               # (n, k) cmr_bn_linear_bwd_f32's lazy operand serves (train/tape.py: LAZY_OPERAND_SHAPES)
 
     def _fused3d_bwd_ok(self, r, R, N):

@@ -569,6 +569,13 @@ int cmr_conv3x3_wgrad_bf16_f32(const float* x, const float* dy, int B, int H, in
  * sums per channel -- replaces a cmr_colsum_f32 pass over dy.  db null: identical to the entry point above. */
 int cmr_conv3x3_wgrad_bias_bf16_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, float* db, void* ws,
                                     int64_t ws_bytes, hipStream_t stream);
+/* The same with x given as the INPUT of a train-mode BatchNorm whose LeakyReLU(xslope) output was the convolution's operand and was never
+ * stored (forward: cmr_conv3x3_bf16_pro_nhwc_f32; models/CMRAgent.py:34-56 conv -> BatchNorm -> LeakyReLU -> conv under Train_Agent.py:296-305):
+ * the operand lrelu(x * xscale + xshift) (xscale, xshift [Cin] = stat[2], stat[3] of cmr_bn_stats_f32) is formed in the staging pass with the
+ * arithmetic of cmr_affine_act_f32 -- bit-identical gradients to the call above on the stored map.  Cin = 128, Cout % 64 == 0, maps of
+ * >= 32 768 pixels; CMR_EUNSUPPORTED (-3) otherwise. */
+int cmr_conv3x3_wgrad_bias_bf16_pro_f32(const float* x, const float* xscale, const float* xshift, float xslope, const float* dy, int B, int H,
+                                        int W, int Cin, int Cout, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t stream);
 int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                           int64_t ws_bytes, hipStream_t stream);
 /* nn.Conv1d(k=1) / nn.Linear weight and bias gradient over a row map: dw [n][k] (+)= dy^T x, db [n] (+)= column sums of dy
@@ -707,6 +714,16 @@ int cmr_iter_apply_f32(const float* matrix_i, const float* pc, float* pc_out, in
 int cmr_conv3x3_bf16io_nhwc(const void* x, int x_bf16, int B, int H, int W, int Cin, const void* wfrag, int nt, const float* bias,
                             const void* res, int res_bf16, const float* post, void* y, int y_bf16, int Cout, int stride, float slope,
                             int pool, int cu_budget, hipStream_t stream);
+/* Train-mode [BatchNorm -> LeakyReLU(in_slope) -> 3x3 convolution (+ bias, LeakyReLU(slope))] with the BatchNorm applied in the
+ * convolution's own staging pass (models/CMRAgent.py:34-56 under Train_Agent.py:296-305; ImageResNet.py:5-40): x [B][H][W][Cin] is the
+ * BatchNorm INPUT, in_scale / in_shift [Cin] its folded affine (stat[2], stat[3] of cmr_bn_stats_f32); the operand
+ * lrelu(x * in_scale + in_shift) is formed while the halo is converted to bf16 (zero padding applied after it) with the fused
+ * multiply-add and the select of cmr_affine_act_f32: bit for bit the result of cmr_affine_act_f32 + cmr_conv3x3_bf16_nhwc_f32, without the
+ * activated map's write and read.  Stride 1, Cin = 128, Cout % 128 == 0, no residual / table / pool, maps of >= 128 8x32-pixel tiles
+ * (x Cout / 128): the matrix-class kernel; CMR_EUNSUPPORTED (-3) otherwise (the caller materialises the activation). */
+int cmr_conv3x3_bf16_pro_nhwc_f32(const float* x, const float* in_scale, const float* in_shift, float in_slope, int B, int H, int W, int Cin,
+                                  const void* wfrag, int nt, const float* bias, float* y, int Cout, float slope, int cu_budget,
+                                  hipStream_t stream);
 
 /* ---- dropout (train mode; the reference trains MultiHeadModel with p = 0.1 in 141 nn.Dropout modules) --------------------------
  * Counter-based masks: element idx of site `site` is kept iff mix64(seed[0], site, idx) >= p 2^32 (csrc/cmr_common.h:cmr_keep); seed is

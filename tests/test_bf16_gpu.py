@@ -203,6 +203,40 @@ def test_conv3x3_weight_gradient_bf16_rows_by_lds_dma_is_bit_identical(B, H, W, 
     assert float((out[1][1] - out[2][1]).abs().max()) <= 2e-6 * float(dy.abs().sum(dim=(0, 1, 2)).max())
 
 
+@pytest.mark.parametrize("B,H,W,cout", [(10, 88, 304, 128), (10, 44, 152, 128), (4, 67, 130, 256)])
+def test_batchnorm_applied_in_the_convolutions_staging_pass_is_bit_identical(B, H, W, cout):
+    """Train-mode conv -> BatchNorm -> LeakyReLU -> conv (models/CMRAgent.py:34-56): the second convolution and its weight gradient take the
+    BatchNorm INPUT and apply the affine + LeakyReLU while they stage their operand (cmr_conv3x3_bf16_pro_nhwc_f32,
+    cmr_conv3x3_wgrad_bias_bf16_pro_f32) -- the same bits as cmr_affine_act_f32 followed by the plain entry points, at the agent update's
+    two big maps and a ragged one (partial tiles on both edges, two cout groups)."""
+    import math
+    from cmr_agent_amd import ops
+    cin = 128
+    x = rnd(B, H, W, cin, seed=51).to(DEV)
+    scale = (0.5 + torch.rand(cin, generator=torch.Generator().manual_seed(3))).to(DEV)
+    shift = (torch.randn(cin, generator=torch.Generator().manual_seed(4)) * 0.3).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=torch.Generator().manual_seed(5)) / math.sqrt(9 * cin)).to(DEV)
+    bias = torch.randn(cout, generator=torch.Generator().manual_seed(6)).to(DEV)
+    dy = rnd(B, H, W, cout, seed=52).to(DEV)
+    ops.CONV_BF16 = True
+    try:
+        w9, u = ops.pack_conv3x3(w.reshape(-1), cout, cin)
+        z = ops.affine_act(x.view(-1, cin), scale, shift, slope=0.01).view(B, H, W, cin)
+        want = ops.conv3x3(z, w9, bias, cout, 1, 0.01, u=u)
+        got = ops.conv3x3_bn_pro(x, scale, shift, 0.01, bias, cout, 0.01, u)
+        assert got is not None and torch.equal(got, want), float((got - want).abs().max())
+        dw0, db0, dw1, db1 = (torch.empty(n, device=DEV) for n in (cout * cin * 9, cout, cout * cin * 9, cout))
+        ops.conv3x3_wgrad(z, dy, dw0, db=db0)
+        assert ops.conv3x3_wgrad(x, dy, dw1, db=db1, xpro=(scale, shift, 0.01))
+        assert torch.equal(dw0, dw1) and torch.equal(db0, db1), float((dw0 - dw1).abs().max())
+        # a map the lazy forms do not serve: the caller is told (and materialises the activation)
+        xs = rnd(2, 12, 20, cin, seed=53).to(DEV)
+        assert ops.conv3x3_bn_pro(xs, scale, shift, 0.01, bias, cout, 0.01, u) is None
+        assert ops.conv3x3_wgrad(xs, rnd(2, 12, 20, cout, seed=54).to(DEV), dw1, db=db1, xpro=(scale, shift, 0.01)) is False
+    finally:
+        ops.CONV_BF16 = False
+
+
 def test_configs3_batch_of_four_in_bf16_is_sample_independent_and_rigid():
     """BASELINE configs[3] runs 4 pairs per GPU in bf16.  No oracle at that size in seconds, so size-independent properties: every pair of
     the batch of 4 gets the result it gets alone (no cross-sample coupling anywhere on the inference path: eval-mode BatchNorm, per-sample
