@@ -144,19 +144,27 @@ struct AtArgs {
   int num_steps;
 };
 
-// y[0 .. n_out) = act(b + x W^T) with wt = W^T stored [k][ldw] (ldw % 4 == 0, zero padded columns), x in LDS, k % 16 == 0, k <= 256,
-// n_out <= 256.  part: LDS scratch [16][256].  All 1 024 threads call it; y may be LDS or global.
-__device__ __forceinline__ void at_gemv(const float* __restrict__ wt, int ldw, const float* __restrict__ bias, const float* xin, int k, int n_out,
-                                        float* yout, bool lrelu, float slope, float (*part)[256], int wave, int lane) {
+// One layer y[0 .. n_out) = act(b + x W^T), wt = W^T stored [k][ldw] (ldw % 4 == 0, zero padded columns), x in LDS, k % 16 == 0, k <= 256,
+// n_out <= 256, in two halves so that the NEXT layer's weight loads fly while this one's partial sums meet in LDS:
+//   at_issue: this lane's <= 16 float4 of its wave's input slice -> registers (one memory round trip per layer, nothing waits for it here)
+//   at_apply: multiply with the loaded slice, partial sums -> LDS scratch [16][256], THEN `next()` (the following layer's at_issue: the
+//             registers are free again), barrier, one add chain per output in wave order, activation, barrier.
+__device__ __forceinline__ void at_issue(const float* __restrict__ wt, int ldw, int k, f32x4 (&wv)[16], int wave, int lane) {
   const int ks = k >> 4;                               // input slice of this wave: ks <= 16 rows of W^T
   const int c = 4 * lane;
   const bool on = c < ldw;
-  f32x4 wv[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int kk = wave * ks + (i < ks ? i : ks - 1);
     wv[i] = *reinterpret_cast<const f32x4*>(wt + (int64_t)kk * ldw + (on ? c : 0));
   }
+}
+
+template <typename Next>
+__device__ __forceinline__ void at_apply(f32x4 (&wv)[16], const float* __restrict__ bias, const float* xin, int k, int n_out, float* yout, bool lrelu,
+                                         float slope, float (*part)[256], int wave, int lane, Next next) {
+  const int ks = k >> 4;
+  const int c = 4 * lane;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -164,6 +172,7 @@ __device__ __forceinline__ void at_gemv(const float* __restrict__ wt, int ldw, c
     s += wv[i] * xv;
   }
   *reinterpret_cast<f32x4*>(&part[wave][c]) = s;
+  next();
   __syncthreads();
   const int tid = wave * 64 + lane;
   if (tid < n_out) {
@@ -181,20 +190,23 @@ __global__ __launch_bounds__(1024) void agent_heads_t_kernel(const AtArgs a) {
   __shared__ __attribute__((aligned(16))) float va[AH_C], vb[AH_C], state[AH_STATE], h0[AH_MAXW], h1[AH_MAXW];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // ---- AvgPool2d((H, W)): thread = (channel quad q of 32, pixel group g of 32); every load of the thread in flight at once
+  const AtHead& hd = a.h[blockIdx.y];
+  f32x4 wv[16];
+  at_issue(a.w24t, AH_C, AH_C, wv, wave, lane);          // the first layer's weights are on their way while the map is pooled
+  // ---- AvgPool2d((H, W)): thread = (channel quad q of 32, pixel group g of 32); 8 loads of the thread in flight at once
   {
     const int q = tid & 31, g = tid >> 5;
     const float* xp = a.x + (int64_t)b * a.npix * AH_C + 4 * q;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    for (int p0 = g; p0 < a.npix; p0 += 32 * 16) {
-      f32x4 v[16];
+    for (int p0 = g; p0 < a.npix; p0 += 32 * 8) {
+      f32x4 v[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 8; ++i) {
         const int p = p0 + 32 * i;
         v[i] = *reinterpret_cast<const f32x4*>(xp + (int64_t)(p < a.npix ? p : p0) * AH_C);
       }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s += p0 + 32 * i < a.npix ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < 8; ++i) s += p0 + 32 * i < a.npix ? v[i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // 32 pixel groups x 128 channels of partial sums through the [16][256] scratch viewed as [32][128]
     float* red = &part[0][0];
@@ -209,13 +221,12 @@ __global__ __launch_bounds__(1024) void agent_heads_t_kernel(const AtArgs a) {
     if (tid >= AH_C && tid < 2 * AH_C) state[tid] = a.e3d[(int64_t)b * AH_C + tid - AH_C];
     __syncthreads();
   }
-  at_gemv(a.w24t, AH_C, a.b24, va, AH_C, AH_C, vb, true, a.slope, part, wave, lane);
-  at_gemv(a.w26t, AH_C, a.b26, vb, AH_C, AH_C, state, false, a.slope, part, wave, lane);
-  const AtHead& hd = a.h[blockIdx.y];
-  at_gemv(hd.w0t, hd.n0, hd.b0, state, AH_STATE, hd.n0, h0, true, a.slope, part, wave, lane);
-  at_gemv(hd.w1t, hd.n1, hd.b1, h0, hd.n0, hd.n1, h1, true, a.slope, part, wave, lane);
-  at_gemv(hd.w2t, hd.ld2, hd.b2, h1, hd.n1, hd.n2, hd.out + (int64_t)b * hd.ldo, false, a.slope, part, wave, lane);
-  if (hd.act != nullptr && a.num_steps > 0) {                 // (the logits were written before at_gemv's closing barrier)
+  at_apply(wv, a.b24, va, AH_C, AH_C, vb, true, a.slope, part, wave, lane, [&] { at_issue(a.w26t, AH_C, AH_C, wv, wave, lane); });
+  at_apply(wv, a.b26, vb, AH_C, AH_C, state, false, a.slope, part, wave, lane, [&] { at_issue(hd.w0t, hd.n0, AH_STATE, wv, wave, lane); });
+  at_apply(wv, hd.b0, state, AH_STATE, hd.n0, h0, true, a.slope, part, wave, lane, [&] { at_issue(hd.w1t, hd.n1, hd.n0, wv, wave, lane); });
+  at_apply(wv, hd.b1, h0, hd.n0, hd.n1, h1, true, a.slope, part, wave, lane, [&] { at_issue(hd.w2t, hd.ld2, hd.n1, wv, wave, lane); });
+  at_apply(wv, hd.b2, h1, hd.n1, hd.n2, hd.out + (int64_t)b * hd.ldo, false, a.slope, part, wave, lane, [] {});
+  if (hd.act != nullptr && a.num_steps > 0) {                 // (the logits were written before at_apply's closing barrier)
     const int d = hd.degree;
     if (tid < d) {
       const float* p = hd.out + (int64_t)b * hd.ldo + tid * a.num_steps;
