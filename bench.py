@@ -329,10 +329,10 @@ def train_main(args, ctx=None, with_cpu=False):
                     ("conv3x3_wgrad_kernel: 3x3 weight gradients as a GEMM over the minibatch's pixels (fp32 MFMA)",
                      ("cmr_conv3x3_wgrad_f32",), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
-                     ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc"), BF16_MFMA_PEAK_TFLOPS),
+                     ("cmr_conv3x3_bf16_nhwc_f32", "cmr_conv3x3_bf16io_nhwc", "cmr_conv3x3_bf16_pro_nhwc_f32"), BF16_MFMA_PEAK_TFLOPS),
                     ("conv3x3_wgrad_bf16_tr_kernel / conv3x3_wgrad_bf16_kernel: 3x3 weight gradients on v_mfma_f32_32x32x16_bf16 (operands through "
                      "ds_read_b64_tr_b16 on maps of >= 32 768 pixels, rows transposed into LDS below; fp32 accumulate)",
-                     ("cmr_conv3x3_wgrad_bf16_f32", "cmr_conv3x3_wgrad_bias_bf16_f32"), BF16_MFMA_PEAK_TFLOPS),
+                     ("cmr_conv3x3_wgrad_bf16_f32", "cmr_conv3x3_wgrad_bias_bf16_f32", "cmr_conv3x3_wgrad_bias_bf16_pro_f32"), BF16_MFMA_PEAK_TFLOPS),
                     ("bn_linear_bwd_kernel: BatchNorm apply + weight gradient + data gradient of the 3-D branch's conv + BatchNorm pairs in one "
                      "pass over the row maps (fp32 MFMA)", ("cmr_bn_linear_bwd_f32",), FP32_MFMA_PEAK_TFLOPS),
                     ("bn_linear_fwd_kernel: conv + BatchNorm statistics of the 3-D branch's row maps in one pass (fp32 MFMA)",

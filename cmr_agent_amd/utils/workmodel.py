@@ -75,6 +75,9 @@ WORK = {
     "cmr_conv3x3_s2_nhwc_f32": lambda a: _conv(a, 2),
     "cmr_conv3x3_bf16_nhwc_f32": _conv,
     "cmr_conv3x3_bf16io_nhwc": _conv_io,
+    # BatchNorm + LeakyReLU in the staging pass: the BatchNorm input in, the convolution's output out (the activated map is never in memory)
+    "cmr_conv3x3_bf16_pro_nhwc_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
+                                                F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     # ResidualBlock(3 -> 64): conv3x3 3->3, conv3x3 3->64, 1x1 shortcut 3->64
     "cmr_stem_block_f32": lambda a: (2.0 * (81 + 1728 + 192) * a["B"] * a["H"] * a["W"], a["B"] * a["H"] * a["W"] * (F * 3 + (2 if a.get("out_bf16") else F) * 64)),
     "cmr_avgpool_nhwc_f32": lambda a: (0, F * a["B"] * a["H"] * a["W"] * a["C"] * (1 + 1.0 / (a["kh"] * a["kw"]))),
@@ -143,6 +146,8 @@ WORK = {
                                              F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     "cmr_conv3x3_wgrad_bias_bf16_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
                                                   F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
+    "cmr_conv3x3_wgrad_bias_bf16_pro_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
+                                                      F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     "cmr_linear_bwd_rows_f32": lambda a: (4.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (3 * a["n"] + 3 * a["k"]) + 2 * a["n"] * a["k"])),
     "cmr_linear_wgrad_f32": lambda a: (2.0 * a["rows"] * a["n"] * a["k"], F * (a["rows"] * (a["n"] + a["k"]) + a["n"] * a["k"])),
     "cmr_adam_f32": lambda a: (0, 28 * a["n"]),
