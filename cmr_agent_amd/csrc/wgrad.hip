@@ -983,13 +983,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const fl
     const char* xb = reinterpret_cast<const char*>(x + ((int64_t)cb * img_px + (int64_t)(rowx ? cr : 0) * W) * CIN);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-      const float* src = rowx && xoff[i] >= 0 ? reinterpret_cast<const float*>(xb + (unsigned)xoff[i]) : wt3_zero;
+      const float* src = !(ABL & 256) && rowx && xoff[i] >= 0 ? reinterpret_cast<const float*>(xb + (unsigned)xoff[i]) : wt3_zero;      // (256: every DMA from the zero page)
       wt3_glds16(src, __builtin_amdgcn_readfirstlane(base + 1024u * (unsigned)xk[i]));
     }
     const int rd = cr + 1;
     const bool rowd = live && rd >= cy0 && rd < cy1;
     const char* db = reinterpret_cast<const char*>(dy + ((int64_t)cb * img_px + (int64_t)(rowd ? rd : 0) * W) * Cout);
-    const float* src = rowd && doff >= 0 ? reinterpret_cast<const float*>(db + (unsigned)doff) : wt3_zero;
+    const float* src = !(ABL & 256) && rowd && doff >= 0 ? reinterpret_cast<const float*>(db + (unsigned)doff) : wt3_zero;
     wt3_glds16(src, __builtin_amdgcn_readfirstlane(base + (unsigned)WT3_XRAW + 1024u * (unsigned)wave));
     // next job
     if (live) {
@@ -1128,7 +1128,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wgrad_bf16_dma_kernel(const fl
   int slot = 0;                                         // raw slot of row j
   for (int j = 0; j < njobs; ++j) {
     // row j + 1 landed (rows j + 2 .. j + D - 1 stay in flight); this wave's image writes of the last iteration are complete
-    if (!(ABL & 64)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(WT3_NDMA * (D - 2)) : "memory");
+    if (ABL & 128) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (ablation: the barrier without the wait for the DMA)
+    else if (!(ABL & 64)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(WT3_NDMA * (D - 2)) : "memory");
     issue(slot);                                        // row j + D into the slot row j left (converted in the last iteration)
     slot = slot + 1 == D ? 0 : slot + 1;
     row(slot, j & 1);
@@ -1775,13 +1776,14 @@ static int wgrad_bias_bf16(const float* x, const float* xscale, const float* xsh
           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
           (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 31>};
       int m = g_wgrad_tr - 16;
-      const void* f32_ = (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 32>;
-      const void* f95_ = (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 95>;
-      static CmrSmemCache g32{}, g95{};
-      if (m == 32 || m == 95) {
-        if (!db || cmr_grant_smem(m == 32 ? f32_ : f95_, WT3_SMEM, m == 32 ? g32 : g95) != CMR_OK) return CMR_ELAUNCH;
+      const void* fx[4] = {(const void*)conv3x3_wgrad_bf16_dma_kernel<true, 32>, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 95>,
+                           (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 128>, (const void*)conv3x3_wgrad_bf16_dma_kernel<true, 256>};
+      static CmrSmemCache gx[4]{};
+      const int xi = m == 32 ? 0 : (m == 95 ? 1 : (m == 128 ? 2 : (m == 256 ? 3 : -1)));
+      if (xi >= 0) {
+        if (!db || cmr_grant_smem(fx[xi], WT3_SMEM, gx[xi]) != CMR_OK) return CMR_ELAUNCH;
         void* args2[] = {(void*)&x, (void*)&dy, (void*)&B, (void*)&H, (void*)&W, (void*)&Cout, (void*)&rps, (void*)&groups, (void*)&part, (void*)&part_b};
-        if (hipLaunchKernel(m == 32 ? f32_ : f95_, dim3(groups * ncp), dim3(512), args2, WT3_SMEM, stream) != hipSuccess) return CMR_ELAUNCH;
+        if (hipLaunchKernel(fx[xi], dim3(groups * ncp), dim3(512), args2, WT3_SMEM, stream) != hipSuccess) return CMR_ELAUNCH;
         return cmr_launch_status();
       }
       if (m < 0 || m > 31 || !f[m] || !db) return CMR_EINVAL;

@@ -14,7 +14,8 @@ dw, db = torch.empty(co * ci * 9, device="cuda"), torch.empty(co, device="cuda")
 ops.CONV_BF16 = True
 names = {0: "everything", 1: "no DMA (rows never arrive)", 2: "no conversion pass", 3: "no DMA, no conversion: multiply only", 4: "no transposed reads",
          8: "no matrix instructions", 12: "no reads, no matrix instructions: staging only", 15: "loop + barrier only", 16: "everything, 1 / 16 of the partial-sum stores",
-         31: "loop + barrier, 1 / 16 of the stores", 95: "loop without the barrier, 1 / 16 of the stores", 32: "the launch alone (kernel returns at once)"}
+         31: "loop + barrier, 1 / 16 of the stores", 95: "loop without the barrier, 1 / 16 of the stores", 32: "the launch alone (kernel returns at once)",
+         128: "everything, barrier without the wait for the DMA (stale rows)", 256: "everything, every DMA from the zero page (no HBM / L2 stream)"}
 for spw in (8, 6, 4, 3, 2):
     lib.cmr_set_wgrad_bf16_variant(2)
     lib.cmr_set_wgrad_bf16_strips(spw)
