@@ -1606,17 +1606,23 @@ constexpr int64_t WGB_TR_MIN_PX = 32768;
 #ifndef CMR_WGRAD_BF16_SPW
 #define CMR_WGRAD_BF16_SPW 4            // generation 3: strips per workgroup the row count of a strip is sized for
 #endif
+#ifndef CMR_WGRAD_BF16_SPW2
+#define CMR_WGRAD_BF16_SPW2 8           // generation 2: the same (every strip refills its two-row prefetch: fewer, longer strips against balance)
+#endif
 #ifdef CMR_AB_SWITCHES
 static int g_wgrad_tr = CMR_WGRAD_BF16_GEN;
 static int g_wgrad_spw = CMR_WGRAD_BF16_SPW;
-extern "C" int cmr_set_wgrad_bf16_strips(int per_workgroup) {
+static int g_wgrad_spw2 = CMR_WGRAD_BF16_SPW2;
+extern "C" int cmr_set_wgrad_bf16_strips(int per_workgroup) {      // > 0: third generation; < 0: second generation (- per_workgroup)
   const int old = g_wgrad_spw;
   if (per_workgroup > 0) g_wgrad_spw = per_workgroup;
+  if (per_workgroup < 0) g_wgrad_spw2 = -per_workgroup;
   return old;
 }
 #else
 static constexpr int g_wgrad_tr = CMR_WGRAD_BF16_GEN;
 static constexpr int g_wgrad_spw = CMR_WGRAD_BF16_SPW;
+static constexpr int g_wgrad_spw2 = CMR_WGRAD_BF16_SPW2;
 #endif
 #ifdef CMR_AB_SWITCHES
 static int g_lwgrad_lds = 1;
@@ -1754,7 +1760,7 @@ static int wgrad_bias_bf16(const float* x, const float* xscale, const float* xsh
     const int ntx = (W + WT2_TW - 1) / WT2_TW;
     const bool gen3 = g_wgrad_tr >= 2;
     // strips per workgroup: ~8 (generation 2), ~4 of twice the rows (generation 3: every strip costs it two rows of zero fragments)
-    int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)(gen3 ? g_wgrad_spw : 8) * groups));
+    int rps = (int)(((int64_t)B * ntx * H) / ((int64_t)(gen3 ? g_wgrad_spw : g_wgrad_spw2) * groups));
     if (rps < 4) rps = 4;
     if (rps > H) rps = H;
     const int64_t nstrips = (int64_t)B * ntx * ((H + rps - 1) / rps);

@@ -54,8 +54,9 @@ int cmr_set_wgrad_variant(int lds_staged);
  * Returns the previous setting. */
 int cmr_set_wgrad_bf16_variant(int generation);
 
-/* Third-generation bf16 weight gradient: strips per workgroup the row count of a strip is sized for (default 4; <= 0 keeps the
- * setting).  Other strips = other partial sums: results agree to fp32 rounding.  Returns the previous setting. */
+/* bf16 weight gradient: strips per workgroup the row count of a strip is sized for -- per_workgroup > 0: third generation (default 4),
+ * < 0: second generation (- per_workgroup; default 8; 4 measured 4 % faster alone and no different in the update: profiles/r05_wgrad_dma_ablate.txt),
+ * 0 keeps both.  Other strips = other partial sums: results agree to fp32 rounding.  Returns the third generation's previous setting. */
 int cmr_set_wgrad_bf16_strips(int per_workgroup);
 
 /* A/B switch: 1 (default) = row maps of >= 65 536 rows with n, k multiples of 32 up to 128 take the LDS-staged kernel (whole-row

@@ -185,7 +185,8 @@ def test_conv3x3_weight_gradient_bf16_rows_by_lds_dma_is_bit_identical(B, H, W, 
     try:
         with _lib.ab() as lib:
             old = lib.cmr_set_wgrad_bf16_variant(1)
-            old_spw = lib.cmr_set_wgrad_bf16_strips(8)          # the second generation's strips: the same partial sums
+            old_spw = lib.cmr_set_wgrad_bf16_strips(8)          # the second generation's strips (its default: 8 per workgroup): the same partial sums
+            lib.cmr_set_wgrad_bf16_strips(-8)
             try:
                 for gen in (1, 2):
                     lib.cmr_set_wgrad_bf16_variant(gen)

@@ -21,7 +21,11 @@ for spw in (8, 6, 4, 3, 2):
     lib.cmr_set_wgrad_bf16_strips(spw)
     print("generation 3 sized for %d strips per workgroup: %7.1f us (with the reduction launches)" % (spw, timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, db=db), 20)), flush=True)
 lib.cmr_set_wgrad_bf16_strips(4)
-for rep in range(2):
+for spw in (8, 6, 5, 4, 3, 2, 8):
+    lib.cmr_set_wgrad_bf16_variant(1)
+    lib.cmr_set_wgrad_bf16_strips(-spw)
+    print("generation 2 sized for %d strips per workgroup: %7.1f us (with the reduction launches)" % (spw, timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, db=db), 20)), flush=True)
+for rep in range(1):
     for gen in (1, 2):
         lib.cmr_set_wgrad_bf16_variant(gen)
         print("generation %d: %7.1f us (with the reduction launches)" % (gen + 1, timeit(lambda: ops.conv3x3_wgrad(x, dy, dw, db=db), 20)), flush=True)
