@@ -325,7 +325,7 @@ def train_main(args, ctx=None, with_cpu=False):
         conv_f = sum(2.0 * 9 * 128 * 128 * MB * (h >> s) * (wd >> s) * 2 for s in range(4))
         flops = conv_f * 3 - 2.0 * 9 * 128 * 128 * MB * h * wd
         families = [("conv3x3_wino_ws_kernel: forward + data-gradient 3x3 convolutions (Winograd F(2x2,3x3), fp32 MFMA)",
-                     ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_nhwc_f32"), FP32_MFMA_PEAK_TFLOPS),
+                     ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wino_stats_nhwc_f32", "cmr_conv3x3_nhwc_f32"), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_wgrad_kernel: 3x3 weight gradients as a GEMM over the minibatch's pixels (fp32 MFMA)",
                      ("cmr_conv3x3_wgrad_f32",), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
@@ -491,7 +491,15 @@ def geo_train_main(args, ctx=None, with_cpu=False):
     line = None
     if ranks.rank == 0:
         table = ct.table()
-        dom = max((d for d in table if d["modelled"]), key=lambda d: d["ms"])
+        # entry points that launch the same kernel count as one candidate (the Winograd convolution with and without the BatchNorm sums)
+        same = [("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wino_stats_nhwc_f32")]
+        group = lambda n: next((g for g in same if n in g), (n,))
+        tot = {}
+        for d in table:
+            if d["modelled"]:
+                tot[group(d["name"])] = tot.get(group(d["name"]), 0.0) + d["ms"]
+        dom_names = max(tot, key=tot.get)
+        dom = {"name": " / ".join(n for n in dom_names if any(d["name"] == n for d in table))}
         line = {
             "metric": "geometric-model update pairs/sec (Train_Geo.py step, %dx%d image, %d points%s)" % (
                 H, W, cfg.num_pt, ", node sampling + nearest node + ball query on the device inside the step" if prologue is not None else ""),
@@ -509,7 +517,7 @@ def geo_train_main(args, ctx=None, with_cpu=False):
             "allreduce_ms_per_step": ar_ms / args.steps if ranks.dist is not None else 0.0,
             "launches_per_step": sum(d["calls"] for d in table),
             "roofline": train_roofline(table, 1, [("%s (the entry point with the largest summed time of the step)" % dom["name"],
-                                                   (dom["name"],), FP32_MFMA_PEAK_TFLOPS)], 1e3 * elapsed / args.steps,
+                                                   dom_names, FP32_MFMA_PEAK_TFLOPS)], 1e3 * elapsed / args.steps,
                                        traffic_profile=_latest_profile("pmc_train_geo.json") if (H, W, cfg.num_pt) == (160, 512, 65536) else
                                        (_latest_profile("pmc_train_geo_c5.json") if (H, W, cfg.num_pt) == (352, 1216, 65536) else None)),
             "launch_mode": "eager" if args.eager else "hipGraph replay of forward + backward",

@@ -28,6 +28,10 @@ struct WinoArgs {
   const float* u;      // G g G^T (BN folded) as A fragments [16][Cout/32][Cin/8][64][4]
   const float* bias; const float* res; const float* post;
   float* y; int Cout; float slope; int pool;
+  // training (cmr_conv3x3_wino_stats_nhwc_f32; wave-specialised kernel, Cout = 64): per-helper-wave sums of the RAW convolution output
+  // (before the bias) and of its square over the wave's pixels, [workgroup][4 helper waves][2][64] -- the BatchNorm statistics of the
+  // layer without a pass over its output (pivot = the bias)
+  float* stats;
 };
 
 constexpr int WT_TH = 8, WT_TW = 16;          // output tile
@@ -608,6 +612,7 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
     Tile prev = decode(blockIdx.x), cur = prev;
     dma_halo(cur, 0, smem);                              // chunk (0, 0); completed by the wait in front of the first barrier
     f32x4 yv[2][2][2];                                   // [item][a][b]
+    f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};   // a.stats: sums of this lane's channel quad over its pixels
     int g = 0, pend = 0;
     [[maybe_unused]] uint64_t tm_busy = 0, tm_wait = 0, tm_vm = 0, tm_dma = 0, tm_epi = 0, tm_st = 0, tm_mark = (dbg & 64) ? __builtin_amdgcn_s_memtime() : 0;
     for (int k = 0; k <= nk; ++k) {
@@ -676,6 +681,22 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
               yv[ii][0][bb] = (tw[0] + tw[1]) + tw[2];
               yv[ii][1][bb] = (tw[1] - tw[2]) - tw[3];
             }
+          if (a.stats) {                                   // (uniform) the helpers wait 25 - 50 % of a launch at the barrier: these adds are free
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+              for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                  const bool ok = full || (pdy[ii] + aa < ly && pdx[ii] + bb < lx);
+                  const f32x4 r = yv[ii][aa][bb];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    st_s[e] += ok ? r[e] : 0.f;
+                    st_q[e] += ok ? r[e] * r[e] : 0.f;
+                  }
+                }
+          }
           if (a.pool == 2) {
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
@@ -775,6 +796,21 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
       float* q = const_cast<float*>(a.post) + 2 * (NMW + 4) * gridDim.x + ((int)blockIdx.x * 4 + hw) * 4;
       q[0] = (float)tm_vm; q[1] = (float)tm_dma; q[2] = (float)tm_epi; q[3] = (float)tm_st;
     }
+    if (a.stats) {
+      // lanes l, l + 16, l + 32, l + 48 of a helper wave hold the same channel quad (cq4 = lane & 15): fixed-order sum, lane < 16 writes
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st_s[e] += cmr_xor16(st_s[e]);
+        st_s[e] += cmr_xhalf(st_s[e]);
+        st_q[e] += cmr_xor16(st_q[e]);
+        st_q[e] += cmr_xhalf(st_q[e]);
+      }
+      if (lane < 16) {
+        float* o = a.stats + ((int64_t)blockIdx.x * 4 + hw) * 128 + 4 * lane;
+        *reinterpret_cast<f32x4*>(o) = st_s;
+        *reinterpret_cast<f32x4*>(o + 64) = st_q;
+      }
+    }
   }
 }
 
@@ -789,11 +825,18 @@ static int g_wino_mw = CMR_WINO_MW;                  // cmr_set_wino_mfma_waves:
 #else
 static constexpr int g_wino_mw = CMR_WINO_MW;
 #endif
+// workgroups of a wave-specialised launch (= partial-sum slots of a statistics launch / 4)
+inline unsigned wino_ws_grid(int64_t ntiles, int cu_budget, int slices);
 template <int DBG, int MW>
 int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, int cu_budget, int slices, hipStream_t stream) {
   constexpr int smem = WS_SMEM_FLOATS * (int)sizeof(float);
   static CmrSmemCache granted{};
   if (cmr_grant_smem(reinterpret_cast<const void*>(conv3x3_wino_ws_kernel<DBG, MW>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  const unsigned grid = wino_ws_grid(ntiles, cu_budget, slices);
+  hipLaunchKernelGGL((conv3x3_wino_ws_kernel<DBG, MW>), dim3(grid), dim3(256 * (MW + 1)), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
+  return cmr_launch_status();
+}
+inline unsigned wino_ws_grid(int64_t ntiles, int cu_budget, int slices) {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -810,9 +853,7 @@ int launch_wino_ws_t(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles
     while (sl > 1 && ntiles / ((int64_t)cus * sl) < 8) --sl;
     want = (int64_t)cus * sl;
   }
-  const unsigned grid = (unsigned)(ntiles < want ? ntiles : want);
-  hipLaunchKernelGGL((conv3x3_wino_ws_kernel<DBG, MW>), dim3(grid), dim3(256 * (MW + 1)), smem, stream, a, tiles_x, tiles_y, (int)ntiles);
-  return cmr_launch_status();
+  return (unsigned)(ntiles < want ? ntiles : want);
 }
 int launch_wino_ws(const WinoArgs& a, int tiles_x, int tiles_y, int64_t ntiles, int cu_budget, int slices, hipStream_t stream) {
   // DBG bits (compile-time ablations used while tuning: 1 no stores, 2 no epilogue, 4 no T hand-over, 8 no U loads, 16 no LDS
@@ -853,6 +894,29 @@ extern "C" int cmr_set_wino_variant(int wave_specialised) {
 #else
 static constexpr int CMR_WINO_WS = 1;
 #endif
+
+// Training forward of a convolution that feeds a batch-statistics BatchNorm: y = conv(x) + bias (no residual / table / activation / pool) AND
+// the sums the BatchNorm needs, from the helpers' epilogue of the wave-specialised kernel: part [parts][2][64] = per helper wave the sums of
+// (y - bias) and (y - bias)^2 over its pixels.  parts = cmr_conv3x3_wino_stats_parts(...) (0: not served -- Cout = 64, Cin >= 64 and maps
+// of >= 200 8x16 tiles are; the caller then runs the plain entry point and cmr_bn_stats_f32).  cmr_bn_stats_from_sums_f32 finishes.
+extern "C" int64_t cmr_conv3x3_wino_stats_parts(int B, int H, int W, int Cin, int Cout, int cu_budget, int slices) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cout != 64 || Cin % 32 != 0 || Cin < 64 || !CMR_WINO_WS) return 0;
+  const int tiles_x = (W + WT_TW - 1) / WT_TW, tiles_y = (H + WT_TH - 1) / WT_TH;
+  const int64_t ntiles64 = (int64_t)tiles_x * tiles_y * B;
+  if (ntiles64 < 200 || 2 * ntiles64 >= 0x7fffffff) return 0;
+  return (int64_t)wino_ws_grid(ntiles64, cu_budget, slices) * 4;
+}
+
+extern "C" int cmr_conv3x3_wino_stats_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias, float* y, int Cout,
+                                               int cu_budget, int slices, float* part, int64_t parts, hipStream_t stream) {
+  CMR_REQUIRE(x && u && y && part && cmr_aligned16(x) && cmr_aligned16(u) && cmr_aligned16(y) && cmr_aligned16(part) && (!bias || cmr_aligned16(bias)));
+  const int64_t want = cmr_conv3x3_wino_stats_parts(B, H, W, Cin, Cout, cu_budget, slices);
+  if (want == 0) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(parts == want);
+  const int tiles_x = (W + WT_TW - 1) / WT_TW, tiles_y = (H + WT_TH - 1) / WT_TH;
+  const WinoArgs a{x, B, H, W, Cin, u, bias, nullptr, nullptr, y, Cout, 1.f, 1, part};
+  return launch_wino_ws(a, tiles_x, tiles_y, (int64_t)tiles_x * tiles_y * B, cu_budget, slices, stream);
+}
 
 extern "C" int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                                          const float* res, const float* post, float* y, int Cout, float slope, int pool,

@@ -693,6 +693,63 @@ extern "C" int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C
   return cmr_launch_status();
 }
 
+// BatchNorm statistics from partial sums a producer left: part [parts][2][C] = sums of (x - pivot) and (x - pivot)^2 over disjoint row sets
+// that cover all `rows` rows (cmr_conv3x3_wino_stats_nhwc_f32: pivot = the convolution's bias).  One wave per channel, double, fixed order;
+// stat and the running statistics exactly as cmr_bn_stats_f32 leaves them.
+__global__ __launch_bounds__(64) void bn_stats_from_sums_kernel(const float* __restrict__ part, int64_t parts, int64_t rows, int C,
+                                                                const float* __restrict__ pivot, float eps, float momentum,
+                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                float* __restrict__ stat) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, ss = 0.0;
+  for (int64_t b0 = lane; b0 < parts; b0 += 64 * 8) {
+    float v0[8], v1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t b = b0 + 64 * u < parts ? b0 + 64 * u : b0;
+      v0[u] = part[b * 2 * C + c];
+      v1[u] = part[b * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (b0 + 64 * u < parts) {
+        s += (double)v0[u];
+        ss += (double)v1[u];
+      }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if (lane != 0) return;
+  const double n = (double)rows;
+  const double pm = s / n;
+  double var = ss / n - pm * pm;
+  var = var > 0.0 ? var : 0.0;
+  const double mean = (pivot ? (double)pivot[c] : 0.0) + pm;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float g = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float scale = g * rstd;
+  stat[c] = (float)mean;
+  stat[C + c] = rstd;
+  stat[2 * C + c] = scale;
+  stat[3 * C + c] = bt - (float)mean * scale;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+extern "C" int cmr_bn_stats_from_sums_f32(const float* part, int64_t parts, int64_t rows, int C, const float* pivot, float eps, float momentum,
+                                          const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
+                                          hipStream_t stream) {
+  CMR_REQUIRE(part && stat && parts > 0 && rows > 0 && C > 0 && C <= 1024);
+  CMR_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  hipLaunchKernelGGL(bn_stats_from_sums_kernel, dim3(C), dim3(64), 0, stream, part, parts, rows, C, pivot, eps, momentum, gamma, beta,
+                     running_mean, running_var, stat);
+  return cmr_launch_status();
+}
+
 extern "C" int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const float* shift, const float* res, int64_t ldres,
                                   const float* rscale, const float* rshift, float* y, int64_t ldy, int64_t rows, int C, float slope,
                                   hipStream_t stream) {

@@ -196,6 +196,31 @@ def conv3x3_wino(x, u, bias, cout, slope=1.0, res=None, post=None, pool=1):
     return y
 
 
+def conv3x3_wino_stats(x, u, bias, cout):
+    """conv3x3 (stride 1, + bias, nothing else) through the wave-specialised Winograd kernel WITH the BatchNorm sums of its output from the
+    kernel's own epilogue -> (y [B,H,W,Cout], part [parts, 2, Cout]) for bn_stats_from_sums (pivot = bias), or None where not served."""
+    B, H, W, cin = x.shape
+    if not (WINOGRAD and u is not None and x.dtype == f32 and x.is_contiguous() and tuple(u.shape) == (16, cout, cin)):
+        return None
+    parts = int(_lib.load().cmr_conv3x3_wino_stats_parts(B, H, W, cin, cout, _cu_budget(), _slices()))
+    if parts <= 0:
+        return None
+    y = torch.empty((B, H, W, cout), dtype=f32, device=x.device)
+    part = torch.empty((parts, 2, cout), dtype=f32, device=x.device)
+    _lib.call("cmr_conv3x3_wino_stats_nhwc_f32", _p(x), B, H, W, cin, _p(u), _p(bias), _p(y), cout, _cu_budget(), _slices(), _p(part), parts, _stream())
+    return y, part
+
+
+def bn_stats_from_sums(part, rows, pivot, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
+    """-> stat [4, C] (mean, rstd, scale, shift) from a producer's partial sums [parts, 2, C] of (x - pivot), (x - pivot)^2 (conv3x3_wino_stats);
+    running statistics updated as bn_stats does."""
+    parts, _, C = part.shape
+    stat = torch.empty((4, C), dtype=f32, device=part.device)
+    _lib.call("cmr_bn_stats_from_sums_f32", _p(part), parts, int(rows), C, _p(pivot), float(eps), float(momentum), _p(gamma), _p(beta),
+              _p(running_mean), _p(running_var), _p(stat), _stream())
+    return stat
+
+
 def conv3x3_bf16(x, frags, bias, cout, slope=1.0, res=None, post=None, pool=1, stride=1, out_bf16=False):
     """3x3 convolution (stride 1 | 2) on the bf16 matrix cores; frags = (bf16 fragment tensor, nt) from _pack.conv_bf16_frags.  x is fp32 or
     bf16 NHWC (a bf16 x is the output of another bf16 convolution); out_bf16: store the result as bf16 (for a following bf16 convolution:

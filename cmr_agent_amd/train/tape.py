@@ -31,7 +31,7 @@ def _side_stream_of(main):
 
 
 class Var:
-    __slots__ = ("v", "g", "own", "const")
+    __slots__ = ("v", "g", "own", "const", "bn_sums")      # bn_sums: (partial sums, pivot) of a convolution output that feeds a BatchNorm
 
     def __init__(self, v, const=False):
         self.v = v          # value, 2-D rows
@@ -292,7 +292,12 @@ class Tape:
             rv = torch.ones(C, dtype=f32, device=x.v.device)
             rm[:c] = bn.running_mean
             rv[:c] = bn.running_var
-        stat = ops.bn_stats(x.v, gamma, beta, rm, rv, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
+        sums = getattr(x, "bn_sums", None)                     # conv3x3(feeds_bn=True): the sums came out of the convolution's epilogue
+        if sums is not None and c == C:
+            stat = ops.bn_stats_from_sums(sums[0], x.v.shape[0], sums[1], gamma, beta, rm, rv, eps=bn.eps,
+                                          momentum=bn.momentum if bn.momentum is not None else 0.1)
+        else:
+            stat = ops.bn_stats(x.v, gamma, beta, rm, rv, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
         if c != C:
             bn.running_mean.copy_(rm[:c])
             bn.running_var.copy_(rv[:c])
@@ -380,6 +385,7 @@ class Tape:
     # fused pass recomputes its operand from h_i, and -- holding h_i and the gradient at layer i's output at the same time -- also returns
     # layer i's BatchNorm-backward reduction (no cmr_bn_bwd_coef_f32 pass for it); layer i takes its activation mask from its own h_i.
     # Per inner layer: forward 3 map passes instead of 5, backward 4 instead of 8.
+    CONV_STATS = __import__("os").environ.get("CMR_CONV_STATS", "1") == "1"      # BatchNorm sums from the producing convolution's epilogue
     LAZY_CHAIN = __import__("os").environ.get("CMR_LAZY_CHAIN", "1") == "1"
     LAZY_OPERAND_SHAPES = ((64, 64), (64, 128))       # (n, k) of a layer that may take its operand from the previous layer's BatchNorm input
 
@@ -900,9 +906,19 @@ class Tape:
         packed = self.convpack is not None and self.WINOGRAD
         w9, u = self.convpack.get(conv.weight) if packed else ops.pack_conv3x3(wflat, cout, cin, want_u=self.WINOGRAD)
         xi = x.v.view(B, H, W, cin)
-        yv = ops.conv3x3(xi, w9, self.W(conv.bias), cout, stride, 1.0, u=u)
+        sums = None
+        if feeds_bn and stride == 1 and self.CONV_STATS and not ops.CONV_BF16 and u is not None:
+            # the BatchNorm's sums from the convolution's own epilogue (wave-specialised Winograd kernel, 64 couts): no pass over the output
+            r = ops.conv3x3_wino_stats(xi, u, self.W(conv.bias), cout)
+            if r is not None:
+                yv, part = r
+                sums = (part, self.W(conv.bias))
+        if sums is None:
+            yv = ops.conv3x3(xi, w9, self.W(conv.bias), cout, stride, 1.0, u=u)
         Ho, Wo = yv.shape[1], yv.shape[2]
         y = Var(yv.view(-1, cout))
+        if sums is not None:
+            y.bn_sums = sums
 
         def bwd():
             if y.g is None:

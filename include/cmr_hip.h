@@ -90,6 +90,16 @@ int cmr_conv3x3_nhwc_f32(const float* x, int B, int H, int W, int Cin, const flo
 int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias,
                               const float* res, const float* post, float* y, int Cout, float slope, int pool,
                               int cu_budget, int slices, hipStream_t stream);
+/* Training forward of a 3x3 convolution that feeds a batch-statistics BatchNorm (models/ImageResNet.py:5-40 under Train_Geo.py:166-174):
+ * y = conv(x) + bias as the call above with slope 1, no residual / table / pool, AND the sums the BatchNorm needs, accumulated by the helper
+ * waves of the wave-specialised kernel while they finish the output tiles (they wait 25 - 50 % of a launch): part [parts][2][64] = per helper
+ * wave the sums of (y - bias) and (y - bias)^2 over its pixels -- the separate cmr_bn_stats_f32 pass over y goes away.
+ * parts = cmr_conv3x3_wino_stats_parts(...): 0 when this form is not served (Cout = 64, Cin >= 64, maps of >= 200 8x16-pixel tiles are): the
+ * caller runs the plain entry point and cmr_bn_stats_f32.  cmr_bn_stats_from_sums_f32(part, parts, B H W, 64, bias, ...) finishes the
+ * statistics. */
+int64_t cmr_conv3x3_wino_stats_parts(int B, int H, int W, int Cin, int Cout, int cu_budget, int slices);
+int cmr_conv3x3_wino_stats_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias, float* y, int Cout,
+                                    int cu_budget, int slices, float* part, int64_t parts, hipStream_t stream);
 /* Stride-2 3x3 convolution (the two strided convolutions of a down-sampling ResidualBlock, ImageResNet.py:9-14, :24-27) with the weights
  * as MFMA A fragments [9 taps][Cout/32][Cin/8][64 lanes][4] read straight from L2 (cmr_agent_amd/models/_pack.py:conv_s2_frags): same
  * arithmetic and epilogue as cmr_conv3x3_nhwc_f32 at stride 2 (bias, residual, LeakyReLU), two barriers per 16-channel halo chunk instead
@@ -443,6 +453,11 @@ int64_t cmr_bn_workspace_bytes(int64_t rows, int C);
 int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C, float eps, float momentum, const float* gamma,
                      const float* beta, float* running_mean, float* running_var, float* stat, void* ws, int64_t ws_bytes,
                      hipStream_t stream);
+/* BatchNorm statistics from partial sums a producer left (cmr_conv3x3_wino_stats_nhwc_f32): part [parts][2][C] = sums of (x - pivot[c]) and
+ * (x - pivot[c])^2 over disjoint row sets covering all `rows` rows (pivot null = 0); stat [4][C] and the running statistics exactly as
+ * cmr_bn_stats_f32 leaves them. */
+int cmr_bn_stats_from_sums_f32(const float* part, int64_t parts, int64_t rows, int C, const float* pivot, float eps, float momentum,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat, hipStream_t stream);
 /* y = LeakyReLU_slope(x * scale + shift + (res * rscale + rshift | res)): BatchNorm application + activation, and the
  * `final_relu(net(x) + shortcut(x))` of ConvBNReLURes1D (PointNN.py:282).  Null scale / rscale = identity; slope 1 = none. */
 int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const float* shift, const float* res, int64_t ldres,

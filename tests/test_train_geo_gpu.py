@@ -254,3 +254,42 @@ def test_focal_and_circle_loss_backward(ops):
         close(d_img, img.grad.permute(0, 2, 3, 1), 2e-4, "circle d img (n=%d)" % n)
         pc.grad = None
         img.grad = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cin", [(8, 160, 512, 64), (2, 88, 304, 128), (3, 67, 130, 64)])
+def test_batchnorm_statistics_from_the_convolutions_epilogue(B, H, W, cin):
+    """cmr_conv3x3_wino_stats_nhwc_f32 + cmr_bn_stats_from_sums_f32 (train-mode conv -> BatchNorm, models/ImageResNet.py:5-40): the
+    convolution's output is bit-identical to the plain Winograd entry point's, and the statistics (mean, rstd, folded scale / shift, running
+    mean / variance) agree with cmr_bn_stats_f32 on that output and with float64 torch -- full tiles, a two-chunk and a four-chunk input, a
+    ragged map whose edge tiles hold pixels outside the image."""
+    import math
+    import torch
+    from cmr_agent_amd import ops
+    DEV = "cuda"
+    cout = 64
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(B, H, W, cin, generator=g) * 2 - 0.3).to(DEV)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin)).to(DEV)
+    bias = (torch.randn(cout, generator=g) * 0.5).to(DEV)
+    gamma, beta = (0.5 + torch.rand(cout, generator=g)).to(DEV), (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    w9, u = ops.pack_conv3x3(w.reshape(-1), cout, cin)
+    r = ops.conv3x3_wino_stats(x, u, bias, cout)
+    assert r is not None
+    y, part = r
+    want = ops.conv3x3_wino(x, u, bias, cout, 1.0)
+    assert torch.equal(y, want)
+    rm0, rv0 = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    stat = ops.bn_stats_from_sums(part, B * H * W, bias, gamma, beta, rm1, rv1, eps=1e-5, momentum=0.1)
+    ref = ops.bn_stats(want.view(-1, cout), gamma, beta, rm0, rv0, eps=1e-5, momentum=0.1)
+    yd = want.view(-1, cout).double()
+    mean, var = yd.mean(0), yd.var(0, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert float((stat[0].double() - mean).abs().max()) <= 2e-6 * float(mean.abs().max() + yd.std())
+    assert float((stat[1].double() / rstd - 1).abs().max()) <= 5e-6
+    assert float((stat - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((rm1 - rm0).abs().max()) <= 1e-6 and float((rv1 / rv0 - 1).abs().max()) <= 1e-5
+    # a map the statistics form does not serve: the caller is told
+    xs = torch.randn(1, 16, 32, cin, device=DEV)
+    assert ops.conv3x3_wino_stats(xs, u, bias, cout) is None
