@@ -325,7 +325,7 @@ def train_main(args, ctx=None, with_cpu=False):
         conv_f = sum(2.0 * 9 * 128 * 128 * MB * (h >> s) * (wd >> s) * 2 for s in range(4))
         flops = conv_f * 3 - 2.0 * 9 * 128 * 128 * MB * h * wd
         families = [("conv3x3_wino_ws_kernel: forward + data-gradient 3x3 convolutions (Winograd F(2x2,3x3), fp32 MFMA)",
-                     ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wino_stats_nhwc_f32", "cmr_conv3x3_nhwc_f32"), FP32_MFMA_PEAK_TFLOPS),
+                     ("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wino_stats_nhwc_f32", "cmr_conv3x3_wino_bnbwd_nhwc_f32", "cmr_conv3x3_nhwc_f32"), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_wgrad_kernel: 3x3 weight gradients as a GEMM over the minibatch's pixels (fp32 MFMA)",
                      ("cmr_conv3x3_wgrad_f32",), FP32_MFMA_PEAK_TFLOPS),
                     ("conv3x3_bf16_tt_kernel: forward + data-gradient 3x3 convolutions on v_mfma_f32_32x32x16_bf16 (fp32 maps in HBM)",
@@ -492,7 +492,7 @@ def geo_train_main(args, ctx=None, with_cpu=False):
     if ranks.rank == 0:
         table = ct.table()
         # entry points that launch the same kernel count as one candidate (the Winograd convolution with and without the BatchNorm sums)
-        same = [("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wino_stats_nhwc_f32")]
+        same = [("cmr_conv3x3_wino_nhwc_f32", "cmr_conv3x3_wino_stats_nhwc_f32", "cmr_conv3x3_wino_bnbwd_nhwc_f32")]
         group = lambda n: next((g for g in same if n in g), (n,))
         tot = {}
         for d in table:

@@ -32,6 +32,10 @@ struct WinoArgs {
   // (before the bias) and of its square over the wave's pixels, [workgroup][4 helper waves][2][64] -- the BatchNorm statistics of the
   // layer without a pass over its output (pivot = the bias)
   float* stats;
+  // ... or (bn_x non-null: this launch is a DATA GRADIENT whose output dz is the gradient at lrelu_{bn_slope}(BatchNorm(bn_x))) the two sums
+  // of that BatchNorm's backward reduction, sum d and sum d xhat with d = dz * act'(.), xhat = (bn_x - mean) rstd (cmr_bn_bwd_f32's first
+  // pass): bn_x [B][H][W][64] is read like a residual (and NOT added), bn_stat = the layer's stat [4][64]
+  const float* bn_x; const float* bn_stat; float bn_slope;
 };
 
 constexpr int WT_TH = 8, WT_TW = 16;          // output tile
@@ -392,6 +396,16 @@ __device__ __forceinline__ void ws_barrier_lds() { asm volatile("s_waitcnt lgkmc
 // tools/wino_mw_ab.py, profiles/r05_wino_mw_ab.txt): bit-identical and 10 - 25 % slower at every shape of the step (352x1216 64->64:
 // 1 112 -> 1 432 us; 88x304 128->128: 257 -> 293 us) -- the single MFMA wave was not starved (it issues 80 % of the launch's cycles at
 // the ~1.93 GHz the chip sustains under this load), so MW = 1 stays the library's choice; MW = 2 is kept for the A/B.
+#ifndef CMR_WS_STATS
+#define CMR_WS_STATS 1        // BatchNorm sums in the helpers' epilogue (0 / CMR_WS_BNBWD 0: compiled out, for same-box A/B builds)
+#endif
+#ifndef CMR_WS_BNBWD
+#define CMR_WS_BNBWD 0        // the BatchNorm-BACKWARD sums in a data gradient's epilogue: built, parity-tested and measured (round 5, same box,
+                              // tools/wino_ws_bench.py on -D builds): 16 more live registers in the helpers make EVERY launch of the kernel
+                              // 0.5 - 1 % slower on the 64 -> 64 full-resolution maps (1 114 -> 1 123 us) while the update gains 0.06 ms of
+                              // 76; compiled out (cmr_conv3x3_wino_bnbwd_nhwc_f32 answers -3), -DCMR_WS_BNBWD=1 brings it back
+#endif
+constexpr bool WS_STATS = CMR_WS_STATS != 0, WS_BNBWD = CMR_WS_STATS != 0 && CMR_WS_BNBWD != 0;
 template <int dbg, int MW>
 __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(const WinoArgs a, const int tiles_x, const int tiles_y, const int ntiles) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -613,6 +627,13 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
     dma_halo(cur, 0, smem);                              // chunk (0, 0); completed by the wait in front of the first barrier
     f32x4 yv[2][2][2];                                   // [item][a][b]
     f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};   // a.stats: sums of this lane's channel quad over its pixels
+    f32x4 bmean, brstd, bmsc, bmsh;                      // a.bn_x: the BatchNorm of this lane's channel quad (Cout = 64: one cout group)
+    if (WS_BNBWD && a.bn_x) {
+      bmean = *reinterpret_cast<const f32x4*>(a.bn_stat + 4 * cq4);
+      brstd = *reinterpret_cast<const f32x4*>(a.bn_stat + 64 + 4 * cq4);
+      bmsc = *reinterpret_cast<const f32x4*>(a.bn_stat + 128 + 4 * cq4);
+      bmsh = *reinterpret_cast<const f32x4*>(a.bn_stat + 192 + 4 * cq4);
+    }
     int g = 0, pend = 0;
     [[maybe_unused]] uint64_t tm_busy = 0, tm_wait = 0, tm_vm = 0, tm_dma = 0, tm_epi = 0, tm_st = 0, tm_mark = (dbg & 64) ? __builtin_amdgcn_s_memtime() : 0;
     for (int k = 0; k <= nk; ++k) {
@@ -650,8 +671,8 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
           const int ly = Ho - prev.oy0, lx = Wo - prev.ox0;
           const bool full = ly >= WT_TH && lx >= WT_TW;
           if (a.pool == 1) {
-            if (a.res) {
-              const char* rb = reinterpret_cast<const char*>(a.res + pix0 * a.Cout + prev.co0);
+            if (a.res || (WS_BNBWD && a.bn_x)) {                         // (bn_x: the BatchNorm input takes the residual's registers; it is not added below)
+              const char* rb = reinterpret_cast<const char*>(((WS_BNBWD && a.bn_x) ? a.bn_x : a.res) + pix0 * a.Cout + prev.co0);
 #pragma unroll
               for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -681,7 +702,7 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
               yv[ii][0][bb] = (tw[0] + tw[1]) + tw[2];
               yv[ii][1][bb] = (tw[1] - tw[2]) - tw[3];
             }
-          if (a.stats) {                                   // (uniform) the helpers wait 25 - 50 % of a launch at the barrier: these adds are free
+          if (WS_STATS && a.stats) {                       // (uniform) the helpers wait 25 - 50 % of a launch at the barrier: these adds are free
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -690,10 +711,22 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
                 for (int bb = 0; bb < 2; ++bb) {
                   const bool ok = full || (pdy[ii] + aa < ly && pdx[ii] + bb < lx);
                   const f32x4 r = yv[ii][aa][bb];
+                  if (WS_BNBWD && a.bn_x) {                // (uniform) BatchNorm-backward sums: the arithmetic of bn_bwd_partial_kernel
+                    const f32x4 xv = rs[ii][aa][bb];
 #pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    st_s[e] += ok ? r[e] : 0.f;
-                    st_q[e] += ok ? r[e] * r[e] : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                      const float pre = __builtin_fmaf(xv[e], bmsc[e], bmsh[e]);
+                      const float d = pre > 0.f ? r[e] : r[e] * a.bn_slope;
+                      const float xh = (xv[e] - bmean[e]) * brstd[e];
+                      st_s[e] += ok ? d : 0.f;
+                      st_q[e] += ok ? d * xh : 0.f;
+                    }
+                  } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                      st_s[e] += ok ? r[e] : 0.f;
+                      st_q[e] += ok ? r[e] * r[e] : 0.f;
+                    }
                   }
                 }
           }
@@ -722,7 +755,7 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb) {
                   f32x4 v = yv[ii][aa][bb] + bsv;
-                  v += rs[ii][aa][bb];
+                  if (!(WS_BNBWD && a.bn_x)) v += rs[ii][aa][bb];
 #pragma unroll
                   for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * a.slope);
                   yv[ii][aa][bb] = v;
@@ -796,7 +829,7 @@ __global__ __launch_bounds__(256 * (MW + 1), 1) void conv3x3_wino_ws_kernel(cons
       float* q = const_cast<float*>(a.post) + 2 * (NMW + 4) * gridDim.x + ((int)blockIdx.x * 4 + hw) * 4;
       q[0] = (float)tm_vm; q[1] = (float)tm_dma; q[2] = (float)tm_epi; q[3] = (float)tm_st;
     }
-    if (a.stats) {
+    if (WS_STATS && a.stats) {
       // lanes l, l + 16, l + 32, l + 48 of a helper wave hold the same channel quad (cq4 = lane & 15): fixed-order sum, lane < 16 writes
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -915,6 +948,25 @@ extern "C" int cmr_conv3x3_wino_stats_nhwc_f32(const float* x, int B, int H, int
   CMR_REQUIRE(parts == want);
   const int tiles_x = (W + WT_TW - 1) / WT_TW, tiles_y = (H + WT_TH - 1) / WT_TH;
   const WinoArgs a{x, B, H, W, Cin, u, bias, nullptr, nullptr, y, Cout, 1.f, 1, part};
+  return launch_wino_ws(a, tiles_x, tiles_y, (int64_t)tiles_x * tiles_y * B, cu_budget, slices, stream);
+}
+
+// Data gradient of a stride-1 3x3 convolution whose INPUT was lrelu_{bn_slope}(BatchNorm(bn_x)) and had no other consumer
+// (ImageResNet.py:9-14 conv -> BatchNorm -> LeakyReLU -> conv): dx = conv(dy, u) (u = the transposed / flipped weights' G g G^T, no bias, no
+// activation) AND the two sums of that BatchNorm's backward reduction over the pixels each helper wave finishes -- part [parts][2][64] as
+// cmr_conv3x3_wino_stats_nhwc_f32 lays it out, the arithmetic of cmr_bn_bwd_f32's first pass (mask from the sign of bn_x * stat[2] + stat[3]).
+// cmr_bn_bwd_from_sums_f32 finishes the BatchNorm backward without that pass over (dx, bn_x).  Same shapes as the statistics launch.
+extern "C" int cmr_conv3x3_wino_bnbwd_nhwc_f32(const float* dy, int B, int H, int W, int Cin, const float* u, float* dx, int Cout, const float* bn_x,
+                                               const float* bn_stat, float bn_slope, int cu_budget, int slices, float* part, int64_t parts,
+                                               hipStream_t stream) {
+  CMR_REQUIRE(dy && u && dx && bn_x && bn_stat && part && cmr_aligned16(dy) && cmr_aligned16(u) && cmr_aligned16(dx) && cmr_aligned16(bn_x) &&
+              cmr_aligned16(bn_stat) && cmr_aligned16(part));
+  if (!WS_BNBWD) return CMR_EUNSUPPORTED;              // (compiled out by default: see CMR_WS_BNBWD)
+  const int64_t want = cmr_conv3x3_wino_stats_parts(B, H, W, Cin, Cout, cu_budget, slices);
+  if (want == 0) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(parts == want);
+  const int tiles_x = (W + WT_TW - 1) / WT_TW, tiles_y = (H + WT_TH - 1) / WT_TH;
+  const WinoArgs a{dy, B, H, W, Cin, u, nullptr, nullptr, nullptr, dx, Cout, 1.f, 1, part, bn_x, bn_stat, bn_slope};
   return launch_wino_ws(a, tiles_x, tiles_y, (int64_t)tiles_x * tiles_y * B, cu_budget, slices, stream);
 }
 

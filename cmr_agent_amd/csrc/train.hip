@@ -781,6 +781,22 @@ extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int
   return cmr_launch_status();
 }
 
+// cmr_bn_bwd_f32 with the reduction's partial sums ALREADY formed by the producer of dz (cmr_conv3x3_wino_bnbwd_nhwc_f32: part [parts][2][C]
+// = sums of d and d xhat over disjoint pixel sets): the final reduction + the apply pass; the activation mask from the sign of
+// x * stat[2] + stat[3] (no residual in front of the activation).  ws: 2 C floats.
+extern "C" int cmr_bn_bwd_from_sums_f32(const float* dz, int64_t lddz, float slope, const float* x, int64_t ldx, const float* stat, const float* part,
+                                        int64_t parts, float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, void* ws,
+                                        int64_t ws_bytes, hipStream_t stream) {
+  CMR_REQUIRE(dz && x && stat && part && dx && ws && rows > 0 && parts > 0 && parts < 0x7fffffff && chan_ok(C));
+  CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x) && cmr_aligned16(dx));
+  CMR_REQUIRE(ws_bytes >= (int64_t)2 * C * (int64_t)sizeof(float));
+  float* coef = (float*)ws;
+  hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, stream, part, (int)parts, rows, C, coef, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(rows * (C / 4))), dim3(256), 0, stream, dz, lddz, (const float*)nullptr, (int64_t)0, slope, x, ldx,
+                     stat, (const float*)coef, (const float*)nullptr, (int64_t)0, dx, lddx, (float*)nullptr, (int64_t)0, rows, C);
+  return cmr_launch_status();
+}
+
 // The reduction half of cmr_bn_bwd_f32 alone: coef [2][C] = (mean(dy), mean(dy xhat)), dgamma / dbeta; the apply half then rides in the
 // prologue of the layer's fused weight / data gradient (cmr_bn_linear_bwd_f32).
 extern "C" int cmr_bn_bwd_coef_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* x, int64_t ldx,

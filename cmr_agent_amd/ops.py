@@ -211,6 +211,35 @@ def conv3x3_wino_stats(x, u, bias, cout):
     return y, part
 
 
+def conv3x3_wino_bnbwd(dy, u, cout, bn_x, stat, slope):
+    """Data gradient conv3x3(dy; u) of a convolution whose input was lrelu_slope(BatchNorm(bn_x)) (stat = that layer's [4, cout]) WITH the two
+    sums of the BatchNorm's backward reduction from the kernel's epilogue -> (dx [B,H,W,cout], part [parts, 2, cout]) for bn_bwd_from_sums,
+    or None where not served."""
+    B, H, W, cin = dy.shape
+    if not (WINOGRAD and u is not None and dy.is_contiguous() and bn_x.is_contiguous() and tuple(u.shape) == (16, cout, cin)
+            and tuple(bn_x.shape) == (B, H, W, cout) and tuple(stat.shape) == (4, cout) and 0.0 <= slope <= 1.0):
+        return None
+    parts = int(_lib.load().cmr_conv3x3_wino_stats_parts(B, H, W, cin, cout, _cu_budget(), _slices()))
+    if parts <= 0:
+        return None
+    dx = torch.empty((B, H, W, cout), dtype=f32, device=dy.device)
+    part = torch.empty((parts, 2, cout), dtype=f32, device=dy.device)
+    rc = _lib.call("cmr_conv3x3_wino_bnbwd_nhwc_f32", _p(dy), B, H, W, cin, _p(u), _p(dx), cout, _p(bn_x), _p(stat), float(slope), _cu_budget(),
+                   _slices(), _p(part), parts, _stream(), allow_unsupported=True)
+    return None if rc == _lib.UNSUPPORTED else (dx, part)          # (the library is built without this form by default: CMR_WS_BNBWD)
+
+
+def bn_bwd_from_sums(dz, slope, x, stat, part, dgamma=None, dbeta=None):
+    """bn_bwd(dz, None, slope, x, stat) with the reduction's partial sums given (conv3x3_wino_bnbwd) -> dx [rows, C]."""
+    _rows(dz), _rows(x)
+    rows, C = x.shape
+    out = torch.empty((rows, C), dtype=f32, device=x.device)
+    ws = _ws(8 * C, x.device)
+    _lib.call("cmr_bn_bwd_from_sums_f32", _p(dz), _ld(dz), float(slope), _p(x), _ld(x), _p(stat), _p(part), part.shape[0], _p(out), _ld(out),
+              _p(dgamma), _p(dbeta), rows, C, _p(ws), 8 * C, _stream())
+    return out
+
+
 def bn_stats_from_sums(part, rows, pivot, gamma, beta, running_mean=None, running_var=None, eps=1e-5, momentum=0.1):
     """-> stat [4, C] (mean, rstd, scale, shift) from a producer's partial sums [parts, 2, C] of (x - pivot), (x - pivot)^2 (conv3x3_wino_stats);
     running statistics updated as bn_stats does."""

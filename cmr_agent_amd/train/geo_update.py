@@ -85,7 +85,7 @@ class GeoUpdate:
             return t.bn(t.conv3x3_c3(a, dims, cl[3], need_dx=True), cl[4], slope=s, res=sc), dims
         a, d1 = t.conv3x3(x, dims, cl[0], blk.stride, feeds_bn=True)
         a = t.bn(a, cl[1], slope=s)
-        b, d2 = t.conv3x3(a, d1, cl[3], 1, feeds_bn=True)
+        b, d2 = t.conv3x3(a, d1, cl[3], 1, feeds_bn=True, input_from_bn=True)     # (a = lrelu(BatchNorm(.)) has no other consumer)
         if isinstance(blk.shortcut, nn.Identity):
             sc = x
         elif blk.shortcut[0].kernel_size == (1, 1):

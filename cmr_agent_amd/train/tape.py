@@ -31,7 +31,9 @@ def _side_stream_of(main):
 
 
 class Var:
-    __slots__ = ("v", "g", "own", "const", "bn_sums")      # bn_sums: (partial sums, pivot) of a convolution output that feeds a BatchNorm
+    __slots__ = ("v", "g", "own", "const", "bn_sums", "bn_ctx", "g_sums")
+    # bn_sums: (partial sums, pivot) of a convolution output that feeds a BatchNorm; bn_ctx: (BatchNorm input, stat, slope) of a BatchNorm +
+    # LeakyReLU output; g_sums: (partial sums of the BatchNorm-backward reduction, the gradient tensor they belong to)
 
     def __init__(self, v, const=False):
         self.v = v          # value, 2-D rows
@@ -302,12 +304,21 @@ class Tape:
             bn.running_mean.copy_(rm[:c])
             bn.running_var.copy_(rv[:c])
         y = Var(ops.affine_act(x.v, stat[2], stat[3], res=None if res is None else res.v, slope=slope))
+        if res is None and 0.0 <= slope < 1.0 and c == C:
+            y.bn_ctx = (x.v, stat, slope)
 
         def bwd():
             if y.g is None:
                 return
             dg, fin_g = self.vec_out(bn.weight)
             db, fin_b = self.vec_out(bn.bias)
+            gs = getattr(y, "g_sums", None)
+            if gs is not None and gs[1] is y.g and res is None:
+                # the one consumer's data gradient left the reduction's sums with y.g (conv3x3 input_from_bn): no first pass over (y.g, x)
+                dx = ops.bn_bwd_from_sums(y.g, slope, x.v, stat, gs[0], dg, db)
+                fin_g(), fin_b()
+                self.give(x, dx, owned=True)
+                return
             if res is not None and slope != 1.0:
                 # the gradient at the sum goes to the residual branch and into the BatchNorm: both from the BatchNorm backward's own
                 # passes (the masked gradient is its second output; round 3 ran an activation-backward sweep in front)
@@ -386,6 +397,7 @@ class Tape:
     # layer i's BatchNorm-backward reduction (no cmr_bn_bwd_coef_f32 pass for it); layer i takes its activation mask from its own h_i.
     # Per inner layer: forward 3 map passes instead of 5, backward 4 instead of 8.
     CONV_STATS = __import__("os").environ.get("CMR_CONV_STATS", "1") == "1"      # BatchNorm sums from the producing convolution's epilogue
+    CONV_BNBWD = __import__("os").environ.get("CMR_CONV_BNBWD", "0") == "1"      # ... and the BatchNorm-backward sums from the data gradient's (needs a -DCMR_WS_BNBWD=1 library: measured not worth its registers)
     LAZY_CHAIN = __import__("os").environ.get("CMR_LAZY_CHAIN", "1") == "1"
     LAZY_OPERAND_SHAPES = ((64, 64), (64, 128))       # (n, k) of a layer that may take its operand from the previous layer's BatchNorm input
 
@@ -893,7 +905,7 @@ class Tape:
     # ---- convolutions: x is the row view of a contiguous NHWC map (B, H, W given) -----------------------------------------
     BIAS_GRAD_BEFORE_BN = False     # True: compute the (identically zero) bias gradient of a convolution that feeds a BatchNorm anyway
 
-    def conv3x3(self, x, dims, conv, stride=1, feeds_bn=False):
+    def conv3x3(self, x, dims, conv, stride=1, feeds_bn=False, input_from_bn=False):
         """nn.Conv2d(3x3, padding 1, stride 1|2) with bias, no activation, Cin in {64, 128} -> (Var, (B, Ho, Wo)).
         feeds_bn: the output goes straight into a batch-statistics BatchNorm.  The gradient of the bias is then IDENTICALLY zero -- the
         BatchNorm backward returns a gradient whose per-channel sum over the rows vanishes (sum_r dx = gamma rstd (sum dz - N mean(dz) -
@@ -949,7 +961,16 @@ class Tape:
                 x.g = ops.conv3x3(dy, w9t, None, cin, 1, 1.0, res=x.g.view(B, H, W, cin), u=ut).view(-1, cin)
                 x.own = True
             else:
-                self.give(x, ops.conv3x3(dy, w9t, None, cin, 1, 1.0, u=ut).view(-1, cin), owned=True)
+                # input_from_bn: x = lrelu(BatchNorm(.)) feeds THIS convolution only -- the BatchNorm's backward reduction rides in the data
+                # gradient's epilogue (the sums travel with the gradient tensor)
+                ctx = getattr(x, "bn_ctx", None) if (input_from_bn and stride == 1 and self.CONV_BNBWD and not ops.CONV_BF16 and x.g is None) else None
+                r = ops.conv3x3_wino_bnbwd(dy, ut, cin, ctx[0].view(B, H, W, cin), ctx[1], ctx[2]) if (ctx is not None and ut is not None) else None
+                if r is not None:
+                    dxr = r[0].view(-1, cin)
+                    self.give(x, dxr, owned=True)
+                    x.g_sums = (r[1], dxr)
+                else:
+                    self.give(x, ops.conv3x3(dy, w9t, None, cin, 1, 1.0, u=ut).view(-1, cin), owned=True)
         self.nodes.append(bwd)
         return y, (B, Ho, Wo)
 

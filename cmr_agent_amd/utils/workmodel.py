@@ -76,6 +76,10 @@ WORK = {
     "cmr_conv3x3_wino_stats_nhwc_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
                                                   F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     "cmr_bn_stats_from_sums_f32": lambda a: (0, F * a["parts"] * 2 * a["C"]),
+    # data gradient + the BatchNorm-backward sums: reads dy and the BatchNorm input, writes dx
+    "cmr_conv3x3_wino_bnbwd_nhwc_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
+                                                  F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + 2 * a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
+    "cmr_bn_bwd_from_sums_f32": lambda a: (0, F * a["rows"] * a["C"] * 3),
     "cmr_conv3x3_s2_nhwc_f32": lambda a: _conv(a, 2),
     "cmr_conv3x3_bf16_nhwc_f32": _conv,
     "cmr_conv3x3_bf16io_nhwc": _conv_io,
@@ -223,7 +227,7 @@ WORK = {
 # Multiplies the kernel ISSUES on the matrix cores per algorithmic multiply: F(2x2,3x3) Winograd computes 2x2 outputs with 16
 # products instead of 36.  `roofline.frac` prices the dominant kernel on issued work (<= 1 by construction); the algorithmic
 # figure stays beside it as frac_algorithmic.
-ISSUED = {"cmr_conv3x3_wino_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_stats_nhwc_f32": 16.0 / 36.0}
+ISSUED = {"cmr_conv3x3_wino_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_stats_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_bnbwd_nhwc_f32": 16.0 / 36.0}
 
 
 def work(name, args, extra=None):

@@ -100,6 +100,16 @@ int cmr_conv3x3_wino_nhwc_f32(const float* x, int B, int H, int W, int Cin, cons
 int64_t cmr_conv3x3_wino_stats_parts(int B, int H, int W, int Cin, int Cout, int cu_budget, int slices);
 int cmr_conv3x3_wino_stats_nhwc_f32(const float* x, int B, int H, int W, int Cin, const float* u, const float* bias, float* y, int Cout,
                                     int cu_budget, int slices, float* part, int64_t parts, hipStream_t stream);
+/* Data gradient of a stride-1 3x3 convolution whose INPUT was lrelu_{bn_slope}(BatchNorm(bn_x)) with no other consumer (ImageResNet.py:9-14
+ * conv -> BatchNorm -> LeakyReLU -> conv under Train_Geo.py:166-174): dx [B][H][W][Cout] = conv(dy; u) (u from the transposed / flipped
+ * weights, no bias) AND, from the same helper waves, the two sums of that BatchNorm's backward reduction over the pixels they finish --
+ * part [parts][2][64] = sum d, sum d xhat with d = dx * act'(bn_x * stat[2] + stat[3]), xhat = (bn_x - stat[0]) stat[1]: what
+ * cmr_bn_bwd_f32's first pass over (dx, bn_x) computes.  bn_x [B][H][W][Cout], bn_stat [4][Cout]; shapes and parts as the statistics
+ * launch above (0 <= bn_slope <= 1).  cmr_bn_bwd_from_sums_f32 finishes the BatchNorm backward.  COMPILED OUT by default (answers -3;
+ * csrc/conv_wino.hip CMR_WS_BNBWD: its registers cost every launch of the kernel more than the update gains). */
+int cmr_conv3x3_wino_bnbwd_nhwc_f32(const float* dy, int B, int H, int W, int Cin, const float* u, float* dx, int Cout, const float* bn_x,
+                                    const float* bn_stat, float bn_slope, int cu_budget, int slices, float* part, int64_t parts,
+                                    hipStream_t stream);
 /* Stride-2 3x3 convolution (the two strided convolutions of a down-sampling ResidualBlock, ImageResNet.py:9-14, :24-27) with the weights
  * as MFMA A fragments [9 taps][Cout/32][Cin/8][64 lanes][4] read straight from L2 (cmr_agent_amd/models/_pack.py:conv_s2_frags): same
  * arithmetic and epilogue as cmr_conv3x3_nhwc_f32 at stride 2 (bias, residual, LeakyReLU), two barriers per 16-channel halo chunk instead
@@ -456,6 +466,11 @@ int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C, float eps
 /* BatchNorm statistics from partial sums a producer left (cmr_conv3x3_wino_stats_nhwc_f32): part [parts][2][C] = sums of (x - pivot[c]) and
  * (x - pivot[c])^2 over disjoint row sets covering all `rows` rows (pivot null = 0); stat [4][C] and the running statistics exactly as
  * cmr_bn_stats_f32 leaves them. */
+/* cmr_bn_bwd_f32 (z null: mask from the sign of x * stat[2] + stat[3]; no add / masked output) with the reduction's partial sums given:
+ * part [parts][2][C] as cmr_conv3x3_wino_bnbwd_nhwc_f32 leaves them.  ws: 2 C floats. */
+int cmr_bn_bwd_from_sums_f32(const float* dz, int64_t lddz, float slope, const float* x, int64_t ldx, const float* stat, const float* part,
+                             int64_t parts, float* dx, int64_t lddx, float* dgamma, float* dbeta, int64_t rows, int C, void* ws, int64_t ws_bytes,
+                             hipStream_t stream);
 int cmr_bn_stats_from_sums_f32(const float* part, int64_t parts, int64_t rows, int C, const float* pivot, float eps, float momentum,
                                const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat, hipStream_t stream);
 /* y = LeakyReLU_slope(x * scale + shift + (res * rscale + rshift | res)): BatchNorm application + activation, and the

@@ -293,3 +293,35 @@ def test_batchnorm_statistics_from_the_convolutions_epilogue(B, H, W, cin):
     # a map the statistics form does not serve: the caller is told
     xs = torch.randn(1, 16, 32, cin, device=DEV)
     assert ops.conv3x3_wino_stats(xs, u, bias, cout) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cdy", [(8, 160, 512, 64), (2, 88, 304, 128), (3, 67, 130, 64)])
+def test_batchnorm_backward_sums_from_the_data_gradients_epilogue(B, H, W, cdy):
+    """cmr_conv3x3_wino_bnbwd_nhwc_f32 + cmr_bn_bwd_from_sums_f32 (conv -> BatchNorm -> LeakyReLU -> conv, ImageResNet.py:9-14, backward): the
+    data gradient is bit-identical to the plain Winograd launch's, and the BatchNorm backward finished from the epilogue's sums agrees
+    with cmr_bn_bwd_f32 on the same operands (dx, dgamma, dbeta) -- full tiles, a four-chunk gradient, a ragged map."""
+    import math
+    import torch
+    from cmr_agent_amd import ops
+    DEV = "cuda"
+    c = 64
+    g = torch.Generator().manual_seed(11)
+    dy = torch.randn(B, H, W, cdy, generator=g).to(DEV)
+    wt = (torch.randn(c, cdy, 3, 3, generator=g) / math.sqrt(9 * cdy)).to(DEV)        # the data-gradient orientation: cdy -> c
+    w9, u = ops.pack_conv3x3(wt.reshape(-1), c, cdy)
+    a = (torch.randn(B, H, W, c, generator=g) * 1.3 + 0.2).to(DEV)                     # the BatchNorm input
+    gamma, beta = (0.5 + torch.rand(c, generator=g)).to(DEV), (torch.randn(c, generator=g) * 0.1).to(DEV)
+    stat = ops.bn_stats(a.view(-1, c), gamma, beta, None, None, eps=1e-5)
+    r = ops.conv3x3_wino_bnbwd(dy, u, c, a, stat, 0.2)
+    if r is None:
+        pytest.skip("the library is built without the BatchNorm-backward sums (CMR_WS_BNBWD = 0, the default: csrc/conv_wino.hip)")
+    dz, part = r
+    want_dz = ops.conv3x3_wino(dy, u, None, c, 1.0)
+    assert torch.equal(dz, want_dz)
+    dg0, db0, dg1, db1 = (torch.empty(c, device=DEV) for _ in range(4))
+    ref = ops.bn_bwd(want_dz.view(-1, c), None, 0.2, a.view(-1, c), stat, dg0, db0)
+    got = ops.bn_bwd_from_sums(dz.view(-1, c), 0.2, a.view(-1, c), stat, part, dg1, db1)
+    sc = float(ref.abs().max())
+    assert float((got - ref).abs().max()) <= 2e-5 * sc, float((got - ref).abs().max()) / sc
+    assert float((dg1 - dg0).abs().max()) <= 2e-5 * float(dg0.abs().max()) and float((db1 - db0).abs().max()) <= 2e-5 * float(db0.abs().max() + 1e-3)

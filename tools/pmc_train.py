@@ -8,6 +8,7 @@ ENTRIES = {   # entry point -> (main kernel, other kernels of the same call)
     "cmr_linear_bn_fwd_f32": ("bn_linear_fwd_kernel", ("bn_stats_merge_kernel",)),
     "cmr_conv3x3_wino_nhwc_f32": ("conv3x3_wino_ws_kernel", ("conv3x3_wino_kernel",)),
     "cmr_conv3x3_wino_stats_nhwc_f32": ("conv3x3_wino_ws_kernel", ("conv3x3_wino_kernel",)),      # (the same kernel: the launches with the BatchNorm sums are not told apart)
+    "cmr_conv3x3_wino_bnbwd_nhwc_f32": ("conv3x3_wino_ws_kernel", ("conv3x3_wino_kernel",)),
     "cmr_conv3x3_wgrad_f32": ("conv3x3_wgrad_reduce_kernel", ("conv3x3_wgrad_kernel", "conv3x3_wgrad_lds_kernel", "conv3x3_wgrad_s2_kernel")),      # (one reduction per call)
     "cmr_affine_act_f32": ("affine_act_kernel", ()),
     # round 5: the bf16 agent update's convolution / weight-gradient entry points and the BatchNorm sweeps
