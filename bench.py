@@ -162,6 +162,15 @@ def dist_info(ranks, args):
     return d
 
 
+def rank_facts(ranks, seed):
+    """Called by EVERY rank after the timed region (N > 1): one row per rank through a real all_gather -- its shard seed (base seed + rank:
+    every rank registers / trains on its own pairs) and its peak HBM allocation."""
+    if ranks.world <= 1:
+        return {"peak_hbm_gib_per_rank": [round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)]}
+    rows = sorted(ranks.gather_scalars([ranks.rank, ranks.shard_seed(seed), torch.cuda.max_memory_allocated() / 2 ** 30]))
+    return {"shard_seeds": [int(r[1]) for r in rows], "peak_hbm_gib_per_rank": [round(r[2], 2) for r in rows]}
+
+
 def _median_timed(fn, passes, budget_s):
     """fn() timed up to `passes` times while the budget lasts (at least once) -> (median seconds, [seconds])."""
     times, t_start = [], time.perf_counter()
@@ -308,6 +317,7 @@ def train_main(args, ctx=None, with_cpu=False):
             ar_ms += up.allreduce_ms()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    info.update(rank_facts(ranks, cfg.seed))
     assert torch.isfinite(losses).all()
     bucket_sum = float(up.bucket.grads.double().sum())     # identical on every rank after the all-reduce
     sums = [bucket_sum]
@@ -486,6 +496,7 @@ def geo_train_main(args, ctx=None, with_cpu=False):
             ar_ms += up.allreduce_ms()
     ranks.barrier()
     elapsed = ranks.max_over_ranks(time.perf_counter() - t0)
+    info.update(rank_facts(ranks, cfg.seed))
     loss = float(losses["loss"])
     assert loss == loss
     line = None
@@ -660,6 +671,7 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
     assert torch.isfinite(pose).all()
     elapsed = ranks.max_over_ranks(elapsed)
     info = dist_info(ranks, args)
+    info.update(rank_facts(ranks, cfg.seed))
     line = None
 
     if rank == 0:

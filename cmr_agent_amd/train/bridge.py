@@ -52,14 +52,23 @@ def _attach_grads(bucket, module, keep):
 
 def _kept_grads(bucket, module):
     """The caller did not zero the gradients (or zeroed them in place): what the bucket holds is part of the answer.  -> a copy of the
-    bucket, or None when every .grad is None (optimizer.zero_grad() of torch >= 2.0, the reference's call)."""
-    own = False
+    bucket in which only the slices whose `.grad` is STILL the bucket view survive, or None when no parameter kept its view
+    (optimizer.zero_grad() of torch >= 2.0, the reference's call).  Per slot, not per bucket: an optimizer over a subset of the
+    parameters (head-only fine-tuning, two optimizers, `p.grad = None` by hand) drops some views and keeps others; a parameter whose
+    `.grad` is None starts from zero, as autograd would, whatever its slice of the bucket still holds from the last backward."""
+    kept, dropped = [], []
     for p in module.parameters():
         s = bucket.by_id.get(id(p))
-        if s is not None and p.grad is not None and p.grad.data_ptr() == s.view(bucket.grads).data_ptr():
-            own = True
-            break
-    return bucket.grads.clone() if own else None
+        if s is None:
+            continue
+        v = s.view(bucket.grads)
+        (kept if p.grad is not None and p.grad.data_ptr() == v.data_ptr() else dropped).append(s)
+    if not kept:
+        return None
+    keep = bucket.grads.clone()
+    for s in dropped:
+        s.view(keep).zero_()
+    return keep
 
 
 class _Consumed:

@@ -97,6 +97,16 @@ class Ranks:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_scalars(self, values):
+        """[world][len(values)] list: every rank's row of float64 scalars through ONE all_gather on device memory (bench.py reports each
+        rank's shard seed and peak HBM with it -- evidence that N ranks drew N different shards)."""
+        row = torch.tensor([float(v) for v in values], dtype=torch.float64, device=self.device if self.device is not None else "cpu")
+        if self.dist is None:
+            return [row.tolist()]
+        out = [torch.empty_like(row) for _ in range(self.world)]
+        self.dist.all_gather(out, row)
+        return [o.tolist() for o in out]
+
     def aggregate_rate(self, units_per_rank, elapsed_max):
         """whole-job throughput: units all ranks processed / max-over-ranks time."""
         return self.world * units_per_rank / elapsed_max

@@ -179,3 +179,63 @@ def test_geo_model_bucket_all_reduce():
     for r in (a, b):
         assert r[4] and r[5] and r[6] and r[7]
         assert r[8] == r[9]                                        # one slot per distinct trainable Parameter
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# world 4 and world 8: the agent's flat bucket through ONE all-reduce; what the driver's 4- / 8-GPU runs do per step
+# ----------------------------------------------------------------------------------------------------------------------
+def _wide_bucket_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import cases as C
+    from cmr_agent_amd.models import CMRAgent
+    from cmr_agent_amd.train.flatbucket import FlatBucket
+    from cmr_agent_amd.utils.dist import Ranks
+    torch.set_num_threads(1)
+    r = Ranks(backend="gloo", device=torch.device("cpu"))
+    torch.manual_seed(5)
+    bucket = FlatBucket(CMRAgent(C.train_config("agent_train_small")))
+    g = torch.Generator().manual_seed(r.shard_seed(2023))
+    # (a) gradients on a 2^-12 grid in [-8, 8): every partial sum of <= 8 ranks is exact in fp32, so ANY reduction order (gloo's ring
+    #     sums each chunk in a different rank rotation) must equal the sum taken in rank order, to the bit
+    exact = torch.randint(-2 ** 15, 2 ** 15, (bucket.numel,), generator=g).float() / 4096.0
+    bucket.grads.copy_(exact)
+    n = bucket.all_reduce(r.dist)
+    summed_exact = bucket.grads.clone()
+    # (b) free fp32 gradients: the ranks must still agree with each other bit for bit (that is what keeps their Adam states in step)
+    free = torch.randn(bucket.numel, generator=g)
+    bucket.grads.copy_(free)
+    bucket.all_reduce(r.dist)
+    rows = r.gather_scalars([r.rank, r.shard_seed(2023)])
+    out[rank] = (n, exact.numpy(), summed_exact.numpy(), free.numpy(), bucket.grads.clone().numpy(), rows)
+    r.close()
+
+
+def _wide(world):
+    port = _free_port()
+    with mp.Manager() as m:
+        out = m.dict()
+        mp.spawn(_wide_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    import numpy as np
+    assert sorted(res) == list(range(world))
+    in_rank_order = res[0][1].copy()
+    for k in range(1, world):
+        in_rank_order = in_rank_order + res[k][1]                     # fp32, rank 0 + rank 1 + ...
+    free64 = sum(res[k][3].astype(np.float64) for k in range(world))
+    for k in range(world):
+        assert res[k][0] == world
+        assert (res[k][2] == in_rank_order).all()                     # = the single-process sum in rank order
+        assert (res[k][4] == res[0][4]).all()                         # bit-identical on every rank
+        assert np.abs(res[k][4] - free64).max() <= 4e-6               # and the fp32 sum of `world` normal deviates
+        assert res[k][5] == [[float(j), 2023.0 + j] for j in range(world)]   # all_gather: one row per rank, distinct shard seeds
+    assert len({float(res[k][1].sum()) for k in range(world)}) == world       # the ranks did draw different gradients
+
+
+def test_bucket_all_reduce_at_world_four():
+    _wide(4)
+
+
+def test_bucket_all_reduce_at_world_eight():
+    _wide(8)

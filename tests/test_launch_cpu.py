@@ -47,11 +47,11 @@ def test_requested_gpus_and_command():
     assert cmd[-5:] == ["/x/bench.py", "--gpus", "2", "--steps", "5"]
 
 
-def _run(tmp_path, extra):
+def _run(tmp_path, extra, gpus=2):
     script = tmp_path / "ranks.py"
     script.write_text(RANK_SCRIPT % ROOT)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    return subprocess.run([sys.executable, str(script), "--gpus", "2"] + extra, capture_output=True, text=True, env=env, timeout=300)
+    return subprocess.run([sys.executable, str(script), "--gpus", str(gpus)] + extra, capture_output=True, text=True, env=env, timeout=300)
 
 
 def test_parent_starts_two_ranks_and_relays_one_json_line(tmp_path):
@@ -62,6 +62,18 @@ def test_parent_starts_two_ranks_and_relays_one_json_line(tmp_path):
     d = json.loads(lines[0])
     assert d == {"world": 2, "collective_ranks": 2, "tmax": 2.0, "argv": ["--gpus", "2", "--steps", "7"]}
     assert "rank 1 chatter" in p.stderr                                # everything else is relayed to stderr
+
+
+def test_parent_starts_eight_ranks_as_the_drivers_scaling_run_does(tmp_path):
+    """World 8 (the card-side rehearsal stops at 6 ranks: the GPU pool's process guard): rendezvous on 127.0.0.1, a collective over
+    8 ranks, MAX over ranks, ONE JSON line on stdout, every rank's chatter on stderr, exit code 0."""
+    p = _run(tmp_path, ["--steps", "2"], gpus=8)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    assert json.loads(lines[0]) == {"world": 8, "collective_ranks": 8, "tmax": 8.0, "argv": ["--gpus", "8", "--steps", "2"]}
+    for r in range(8):
+        assert "rank %d chatter" % r in p.stderr
 
 
 def test_parent_exits_with_the_ranks_failure(tmp_path):
