@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
 
-from bench import hip_fps, hip_nearest  # noqa: E402
+from cmr_agent_amd.dataset.sampling import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
 from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402

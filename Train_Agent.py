@@ -33,7 +33,7 @@ if __name__ == "__main__":
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from bench import hip_fps, hip_nearest  # noqa: E402
+from cmr_agent_amd.dataset.sampling import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
 from cmr_agent_amd.environment import environment as env  # noqa: E402
 from cmr_agent_amd.environment.buffer import Buffer  # noqa: E402

@@ -38,6 +38,7 @@ import torch  # noqa: E402
 from cmr_agent_amd import ops  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402
 from cmr_agent_amd.environment import environment as env  # noqa: E402
+from cmr_agent_amd.dataset.sampling import hip_fps, hip_nearest  # noqa: E402,F401  (tools/ and tests/ still reach them through bench)
 from cmr_agent_amd.models import CMRAgent, MultiHeadModel  # noqa: E402
 from cmr_agent_amd.runtime import PipelinedRegistrationGraph, RegistrationGraph  # noqa: E402
 from cmr_agent_amd.utils import hashfill, synthetic  # noqa: E402
@@ -58,25 +59,6 @@ WORKLOADS = {
 WORKLOAD = WORKLOADS["c1"]
 GEO_TAG, AGENT_TAG = "geo4/", "agent/"
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-
-
-def hip_fps(dev):
-    def fn(pts_3n, k, init_idx):
-        x = torch.from_numpy(np.ascontiguousarray(pts_3n, dtype=np.float32)).unsqueeze(0).to(dev)
-        rows = ops.planar_to_rows(x, 4)
-        idx = ops.fps(rows, torch.tensor([init_idx], device=dev), 1, x.shape[2], k)
-        i = idx[0].cpu().numpy()
-        return pts_3n[:, i], i
-    return fn
-
-
-def hip_nearest(dev):
-    def fn(pc_3n, node_3m):
-        p = ops.planar_to_rows(torch.from_numpy(np.ascontiguousarray(pc_3n, dtype=np.float32)).unsqueeze(0).to(dev), 4)
-        n = ops.planar_to_rows(torch.from_numpy(np.ascontiguousarray(node_3m, dtype=np.float32)).unsqueeze(0).to(dev), 4)
-        _, local = ops.nearest(p, n, 1, pc_3n.shape[1], node_3m.shape[1], want_global=False)
-        return local[0].cpu().numpy()
-    return fn
 
 
 def load_models(cfg, dev):
@@ -191,9 +173,32 @@ def _latest_profile(suffix):
     return os.path.relpath(fs[-1], ROOT) if fs else None
 
 
+def profile_fresh(profile):
+    """(True, None) when the committed profile's sidecar (tools/profile_meta.py: <profile>.meta.json) lists sources that all still hash to
+    what they were when the profile was taken; (False, reason) otherwise -- a profile without a sidecar counts as stale.  The GPU box
+    has no .git: the check is by file content."""
+    import hashlib
+    try:
+        meta = json.load(open(os.path.join(ROOT, profile + ".meta.json")))
+    except (OSError, ValueError):
+        return False, "no freshness sidecar (%s.meta.json)" % profile
+    changed = []
+    for path, h in meta.get("sources", {}).items():
+        try:
+            if hashlib.sha256(open(os.path.join(ROOT, path), "rb").read()).hexdigest() != h:
+                changed.append(path)
+        except OSError:
+            changed.append(path)
+    if changed:
+        return False, "changed since the profile was taken: " + ", ".join(changed)
+    return True, None
+
+
 def _profiled_traffic(doms, profile):
     """HBM bytes per C-ABI call of the dominant family from a committed rocprofv3 PMC profile (tools/_pmc_train.sh), or None when the
     profile does not hold every entry point of the family that ran."""
+    if not profile_fresh(profile)[0]:
+        return None
     try:
         pmc = json.load(open(os.path.join(ROOT, profile)))
     except (OSError, ValueError):
@@ -704,33 +709,45 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
                         gflop_per_step=round(d["flops"] / args.steps / 1e9, 2), mb_per_step=round(d["bytes"] / args.steps / 1e6, 1))
                    for d in table if d["modelled"]]
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and
-        # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes)
-        traffic, traffic_src = None, ("profiles/r05_pmc_path.json" if os.path.exists(os.path.join(ROOT, "profiles/r05_pmc_path.json")) else "profiles/r03_pmc_path.json")
-        try:
-            pmc = json.load(open(os.path.join(ROOT, traffic_src)))
-            wino = [v for k, v in pmc.items() if "conv3x3_wino" in k]       # the wave-specialised kernel and both 4-wave instances, launch-weighted
-            traffic = (sum((v["hbm_fetch_bytes"] + v["hbm_write_bytes"]) * v["launches_per_iteration"] for v in wino)
-                       / sum(v["launches_per_iteration"] for v in wino))
-        except Exception:
-            pass
+        # WRITE_SIZE in separate runs of this script; KiB units; FETCH_SIZE doubled on gfx950 as the guide prescribes) -- read only while
+        # the profile is FRESH (profile_fresh: the kernel's source and the step's shape-defining files unchanged since it was taken)
+        traffic, traffic_src, traffic_note = None, _latest_profile("pmc_path.json"), None
+        if traffic_src is not None:
+            ok, why = profile_fresh(traffic_src)
+            if ok:
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, traffic_src)))
+                    wino = [v for k, v in pmc.items() if "conv3x3_wino" in k]       # the wave-specialised kernel and both 4-wave instances, launch-weighted
+                    traffic = (sum((v["hbm_fetch_bytes"] + v["hbm_write_bytes"]) * v["launches_per_iteration"] for v in wino)
+                               / sum(v["launches_per_iteration"] for v in wino))
+                except Exception as e:          # noqa: BLE001
+                    traffic_note = "unreadable: %s" % e
+            else:
+                traffic_note = "stale profile, not reported (%s)" % why
         achieved = conv["flops"] / (conv["ms"] * 1e-3) / 1e12
         iters = world * w["B"] * args.steps
         # the dominant kernel INSIDE the timed hipGraph replay: launch-weighted mean duration of the Winograd kernels in the committed
-        # `rocprofv3 --kernel-trace --stats` summary of `bench.py --replay-only` (tools/r05_final.sh), priced with this run's FLOPs per launch
-        in_graph = {}
+        # `rocprofv3 --kernel-trace --stats` summary of `bench.py --replay-only` (tools/r06_final.sh), priced with this run's FLOPs per launch.
+        # This is the headline `roofline.frac` -- while the profile is fresh; otherwise the eager figure leads and says so.
+        in_graph, in_graph_note = None, None
         if dtype != "bf16" and workload == "c1":
-            try:
-                import csv
-                src = "profiles/r05_kernel_stats_replay_only.csv"
-                rows = [r for r in csv.DictReader(open(os.path.join(ROOT, src))) if "conv3x3_wino" in r["Name"]]
-                calls, ns = sum(int(r["Calls"]) for r in rows), sum(float(r["TotalDurationNs"]) for r in rows)
-                us = ns / calls / 1e3
-                fl = conv["flops"] / max(conv["launches"], 1)
-                in_graph = {"frac_in_graph": fl * 16.0 / 36.0 / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "avg_launch_us_in_graph": us,
-                            "in_graph_source": "%s: %d launches of conv3x3_wino* in the replayed graphs of `bench.py --replay-only`, mean %.1f us; "
-                                               "x this run's %.2f GFLOP per launch x 16/36 / %.1f TFLOP/s" % (src, calls, us, fl / 1e9, FP32_MFMA_PEAK_TFLOPS)}
-            except Exception:
-                pass
+            src = _latest_profile("kernel_stats_replay_only.csv")
+            ok, why = profile_fresh(src) if src else (False, "no profiles/rNN_kernel_stats_replay_only.csv")
+            if ok:
+                try:
+                    import csv
+                    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, src))) if "conv3x3_wino" in r["Name"]]
+                    calls, ns = sum(int(r["Calls"]) for r in rows), sum(float(r["TotalDurationNs"]) for r in rows)
+                    us = ns / calls / 1e3
+                    fl = conv["flops"] / max(conv["launches"], 1)
+                    in_graph = {"frac": fl * 16.0 / 36.0 / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "us": us,
+                                "achieved": fl * 16.0 / 36.0 / (us * 1e-6) / 1e12,
+                                "source": "%s: %d launches of conv3x3_wino* in the replayed graphs of `bench.py --replay-only`, mean %.1f us; "
+                                          "x this run's %.2f GFLOP per launch x 16/36 / %.1f TFLOP/s" % (src, calls, us, fl / 1e9, FP32_MFMA_PEAK_TFLOPS)}
+                except Exception as e:          # noqa: BLE001
+                    in_graph_note = "unreadable: %s" % e
+            else:
+                in_graph_note = "stale profile, not reported (%s)" % why
         common = {"algorithmic_bytes_per_launch": conv["bytes"] / max(conv["launches"], 1),
                   "launches_per_step": conv["launches"] / args.steps, "avg_launch_us": 1e3 * conv["ms"] / max(conv["launches"], 1),
                   "algorithmic_gflop_per_step": conv["flops"] / args.steps / 1e9, "algorithmic_mb_per_step": conv["bytes"] / args.steps / 1e6,
@@ -761,14 +778,29 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
             # 2*9*Cin*Cout flop per output pixel) over its HIP-event time -- a position under the fp32 MFMA roof, <= 1 by construction;
             # the algorithmic figure (what a direct convolution would have to sustain) stays beside it
             issued = achieved * 16.0 / 36.0
+            eager = dict(achieved_eager=issued, frac_eager=issued / FP32_MFMA_PEAK_TFLOPS,
+                         avg_launch_us_eager=1e3 * conv["ms"] / max(conv["launches"], 1),
+                         eager_note="the same kernels in the separate eager pass (HIP events around every C-ABI call of this run)")
+            if in_graph is not None:
+                # the TIMED mode leads: the kernel as it runs inside the replayed graphs of the timed region
+                lead = dict(achieved=in_graph["achieved"], frac=in_graph["frac"], avg_launch_us_in_graph=in_graph["us"],
+                            frac_in_graph=in_graph["frac"], frac_source=in_graph["source"],
+                            frac_basis="issued MFMA work (16/36 of the algorithmic multiplies) over the kernel's mean duration INSIDE the timed "
+                                       "hipGraph replays (committed rocprofv3 kernel statistics of `bench.py --replay-only`, fresh by content hash)")
+                alg = in_graph["achieved"] * 36.0 / 16.0
+            else:
+                lead = dict(achieved=issued, frac=issued / FP32_MFMA_PEAK_TFLOPS, frac_in_graph=None, frac_in_graph_note=in_graph_note,
+                            frac_basis="issued MFMA work (16/36 of the algorithmic multiplies) over the HIP-event time of the EAGER pass: no fresh "
+                                       "in-graph profile to read")
+                alg = achieved
             roofline = dict(kernel="conv3x3_wino_ws_kernel / conv3x3_wino_kernel (NHWC 3x3 stride-1, fused Winograd F(2x2,3x3), v_mfma_f32_32x32x2_f32)", bound="mfma",
-                            achieved=issued, peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac=issued / FP32_MFMA_PEAK_TFLOPS,
-                            basis="issued MFMA work (16/36 of the algorithmic multiplies)",
-                            achieved_algorithmic=achieved, frac_algorithmic=achieved / FP32_MFMA_PEAK_TFLOPS,
-                            **in_graph,
-                            traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src,
+                            peak=FP32_MFMA_PEAK_TFLOPS, unit="TFLOP/s", **lead, **eager,
+                            achieved_algorithmic=alg, frac_algorithmic=alg / FP32_MFMA_PEAK_TFLOPS,
+                            traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC, %s)" % traffic_src, traffic_note=traffic_note,
                             traffic_source="committed profile (the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command kept under "
-                                           "profiles/), not a counter read in this run", **common)
+                                           "profiles/, fresh by content hash), not a counter read in this run", **common)
+            if in_graph is not None:
+                roofline["avg_launch_us"] = in_graph["us"]          # the duration `frac` is computed from; the eager mean is avg_launch_us_eager
         line = {
             "metric": "registration iters/sec (%s %dx%d img + %d pts, 1 geo forward + %d agent steps)" % (
                 "KITTI" if w["cfg"] == "kitti" else "nuScenes", w["H"], w["W"], w["N"], w["steps"]),

@@ -696,7 +696,7 @@ extern "C" int cmr_bn_stats_f32(const float* x, int64_t ldx, int64_t rows, int C
 // BatchNorm statistics from partial sums a producer left: part [parts][2][C] = sums of (x - pivot) and (x - pivot)^2 over disjoint row sets
 // that cover all `rows` rows (cmr_conv3x3_wino_stats_nhwc_f32: pivot = the convolution's bias).  One wave per channel, double, fixed order;
 // stat and the running statistics exactly as cmr_bn_stats_f32 leaves them.
-__global__ __launch_bounds__(64) void bn_stats_from_sums_kernel(const float* __restrict__ part, int64_t parts, int64_t rows, int C,
+static __global__ __launch_bounds__(64) void bn_stats_from_sums_kernel(const float* __restrict__ part, int64_t parts, int64_t rows, int C,
                                                                 const float* __restrict__ pivot, float eps, float momentum,
                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
@@ -769,6 +769,7 @@ extern "C" int cmr_bn_bwd_f32(const float* dz, int64_t lddz, const float* z, int
   CMR_REQUIRE(dz && x && stat && dx && ws && rows > 0 && chan_ok(C));
   CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x) && cmr_aligned16(dx));
   if (z) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z));
+  else CMR_REQUIRE(slope >= 0.f && slope <= 1.f);      // mask recomputed from x: equals the forward's only for a LeakyReLU slope in [0, 1]
   if (add) CMR_REQUIRE(ldadd % 4 == 0 && cmr_aligned16(add));
   const int nb = red_blocks(rows, C);
   CMR_REQUIRE(ws_bytes >= (int64_t)(nb + 1) * 2 * C * (int64_t)sizeof(float));
@@ -805,6 +806,7 @@ extern "C" int cmr_bn_bwd_coef_f32(const float* dz, int64_t lddz, const float* z
   CMR_REQUIRE(dz && x && stat && coef && ws && rows > 0 && chan_ok(C));
   CMR_REQUIRE(lddz % 4 == 0 && ldx % 4 == 0 && cmr_aligned16(dz) && cmr_aligned16(x));
   if (z) CMR_REQUIRE(ldz % 4 == 0 && cmr_aligned16(z));
+  else CMR_REQUIRE(slope >= 0.f && slope <= 1.f);
   const int nb = red_blocks(rows, C);
   CMR_REQUIRE(ws_bytes >= (int64_t)nb * 2 * C * (int64_t)sizeof(float));
   float* part = (float*)ws;
@@ -864,7 +866,7 @@ static inline int col_blocks(int N, int C) {
 extern "C" int64_t cmr_colarg_workspace_bytes(int B, int N, int C) { return (int64_t)B * col_blocks(N, C) * C * 8; }
 
 extern "C" int cmr_colsum_f32(const float* x, int64_t ldx, float* out, void* ws, int64_t ws_bytes, int B, int N, int C, hipStream_t stream) {
-  CMR_REQUIRE(x && out && ws && B > 0 && N > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));
+  CMR_REQUIRE(x && out && ws && B > 0 && B <= 65535 && N > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));   // B = gridDim.y
   const int nb = col_blocks(N, C);
   CMR_REQUIRE(ws_bytes >= (int64_t)B * nb * C * 4);
   hipLaunchKernelGGL(col_partial_kernel<false>, dim3(nb, B), dim3(RED_THREADS), 0, stream, x, ldx, N, C, (float*)ws, (int32_t*)nullptr);
@@ -875,7 +877,7 @@ extern "C" int cmr_colsum_f32(const float* x, int64_t ldx, float* out, void* ws,
 
 extern "C" int cmr_colmax_arg_f32(const float* x, int64_t ldx, float* out, int32_t* arg, void* ws, int64_t ws_bytes, int B, int N, int C,
                                   hipStream_t stream) {
-  CMR_REQUIRE(x && out && arg && ws && B > 0 && N > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));
+  CMR_REQUIRE(x && out && arg && ws && B > 0 && B <= 65535 && N > 0 && chan_ok(C) && ldx % 4 == 0 && cmr_aligned16(x));   // B = gridDim.y
   const int nb = col_blocks(N, C);
   CMR_REQUIRE(ws_bytes >= (int64_t)B * nb * C * 8);
   float* pv = (float*)ws;

@@ -54,7 +54,8 @@ def preprocess_frame(raw, P_Tr, K, P_random, img_hw4, choice=None, perm=None, no
     (4x4): host arrays; img_hw4 = (h, w) of the 1/4-scale map; choice: device int64 [N] down-sampling indices or None;
     perm: device int64 [>= n_circle] permutation of the in-picture points, a callable count -> such a tensor (the loader: the count is only
     known after the projection), or None (no circle-loss samples);
-    node_candidates: device int64 [8 * num_node] indices into the sampled cloud (KittiDataset.py:356) or None (no nodes).
+    node_candidates: device int64 [8 * num_node] indices into the sampled cloud (KittiDataset.py:356), a callable () -> (such a tensor,
+    fps_start) invoked AFTER perm (the loader: keeps the reference's order of np.random draws), or None (no nodes).
     Returns the reference's dict entries (device tensors): pc, pc_in_cam_space, pc_mask, img_mask, K, P, (+ circle-loss
     samples, node, pt2node)."""
     if raw.dtype != torch.float32 or raw.dim() != 2 or raw.shape[0] < 3 or not raw.is_contiguous():
@@ -94,6 +95,8 @@ def preprocess_frame(raw, P_Tr, K, P_random, img_hw4, choice=None, perm=None, no
         _lib.call("cmr_dataset_circle_select_f64", pc_mask.data_ptr(), xy.data_ptr(), perm.contiguous().data_ptr(), n_circle, N,
                   ws.data_ptr(), count.data_ptr(), idx.data_ptr(), xyf.data_ptr(), xyi.data_ptr(), _stream())
         out.update(pc_idx_for_circle_loss=idx, pc_xy_float_for_circle_loss=xyf, pc_xy_int_for_circle_loss=xyi, in_picture_count=count)
+    if callable(node_candidates):
+        node_candidates, fps_start = node_candidates()
     if node_candidates is not None:
         # KittiDataset.py:356-367: FPS of num_node nodes among the candidate subset, then the nearest node of every point
         rows = ops.planar_to_rows(pc_out.unsqueeze(0), 4)                                  # [N, 4] xyz0

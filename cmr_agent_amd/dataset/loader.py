@@ -13,8 +13,12 @@ permutation :340, random pose :349, node candidates :356, FPS start :117) -- and
 the sample dict (KittiDataset.py:400-423: same keys, shapes and dtypes) comes back as device tensors.
 
 Image side: the half-size bilinear resize (:290-293) and the crop (:296-304) run on the device with torch's half-pixel bilinear filter
-(the geometry of cv2.INTER_LINEAR; OpenCV's fixed-point rounding is not reproduced: +-1 grey level), the colour jitter of training mode
-(:312, torchvision ColorJitter) is not reproduced -- neither is part of the hot path, and neither library exists in this image."""
+(the geometry of cv2.INTER_LINEAR; OpenCV's fixed-point rounding is not reproduced: +-1 grey level).  The colour jitter of training
+mode (:209-218, :312: torchvision ColorJitter, brightness / contrast / saturation in 0.8..1.2, hue in +-0.1, the four in a random order)
+runs on the device as `color_jitter` below: torchvision's published arithmetic on the 0..255 grid with a rounding after every
+adjustment; its draws come from torch's global generator in torchvision's order (randperm(4), then one uniform per factor).  Neither
+OpenCV nor torchvision exists in this image, so both image steps are restatements WITHOUT a reference-generated fixture (the per-point
+side of the sample dict is pinned by tests/golden/dataset_ops.npz)."""
 import os
 import random
 
@@ -22,6 +26,59 @@ import numpy as np
 import torch
 
 from .frame import camera_matrix, preprocess_frame, random_transform
+
+
+def _gray(x):
+    return 0.2989 * x[0:1] + 0.587 * x[1:2] + 0.114 * x[2:3]
+
+
+def _shift_hue(x, f):
+    """torchvision adjust_hue on a [3, H, W] image in 0..1: RGB -> HSV, h <- (h + f) mod 1, HSV -> RGB."""
+    r, g, b = x[0], x[1], x[2]
+    maxc, minc = x.max(dim=0)[0], x.min(dim=0)[0]
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    crd = torch.where(eqc, ones, cr)
+    rc, gc, bc = (maxc - r) / crd, (maxc - g) / crd, (maxc - b) / crd
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = torch.fmod((hr + hg + hb) / 6.0 + 1.0, 1.0)
+    h = torch.remainder(h + f, 1.0)
+    v = maxc
+    i = torch.floor(h * 6.0)
+    fr = h * 6.0 - i
+    i = i.to(torch.int64) % 6
+    p, q, t = v * (1.0 - s), v * (1.0 - s * fr), v * (1.0 - s * (1.0 - fr))
+    pick = lambda c: torch.stack(c, dim=0).gather(0, i.unsqueeze(0))[0]      # noqa: E731
+    return torch.stack((pick((v, q, p, p, t, v)), pick((t, v, v, q, p, p)), pick((p, p, t, v, v, q))), dim=0).clamp_(0.0, 1.0)
+
+
+def color_jitter(img255, brightness=(0.8, 1.2), contrast=(0.8, 1.2), saturation=(0.8, 1.2), hue=(-0.1, 0.1), draws=None):
+    """KittiDataset.augment_img (:209-218) on a device image [3, H, W] holding grey levels 0..255 (float): torchvision ColorJitter --
+    order = randperm(4), then one uniform factor each for brightness, contrast, saturation, hue (ColorJitter.get_params, torch's global
+    generator); brightness / contrast / saturation blend the image with zero / its mean grey level / its grey image
+    (f x + (1 - f) other, clamped), hue shifts the HSV angle.  The reference runs on a uint8 PIL image: every adjustment lands on the
+    0..255 grid again (rounded here).  draws: (order list, b, c, s, h) to replay a known jitter; -> (image, draws)."""
+    if draws is None:
+        order = torch.randperm(4).tolist()
+        b, c, s, h = (float(torch.empty(1).uniform_(lo, hi)) for lo, hi in (brightness, contrast, saturation, hue))
+    else:
+        order, b, c, s, h = draws
+    x = img255 / 255.0
+    grid = lambda y: (y * 255.0).round().clamp_(0.0, 255.0) / 255.0          # noqa: E731
+    for k in order:
+        if k == 0:
+            x = grid(x * b)
+        elif k == 1:
+            x = grid(c * x + (1.0 - c) * (_gray(x) * 255.0).round().div(255.0).mean())
+        elif k == 2:
+            x = grid(s * x + (1.0 - s) * _gray(x))
+        else:
+            x = grid(_shift_hue(x, h))
+    return x * 255.0, (order, b, c, s, h)
 
 
 def read_calib(root):
@@ -75,6 +132,7 @@ class FrameDataset:
         self.calib = read_calib(root)
         self.frames = self._list_frames()
         self.last_draws = None
+        self.last_jitter = None
         print("%d samples in %s set..." % (len(self.frames), mode))                # :154
 
     def _list_frames(self):
@@ -129,13 +187,18 @@ class FrameDataset:
                     t=np.array(t), choice=choice.astype(np.int64))
 
     # ----------------------------------------------------------------------------------------------------------- device side
-    def image_tensor(self, img, resized, crop):
-        """uint8 [H, W, 3] -> float32 [3, img_H, img_W] in 0..1 on the device: half-size bilinear resize, crop, / 255 (:290-304, :401)."""
+    def image_tensor(self, img, resized, crop, jitter=False):
+        """uint8 [H, W, 3] -> float32 [3, img_H, img_W] in 0..1 on the device: half-size bilinear resize, crop, (train mode: colour
+        jitter, :311-312), / 255 (:290-304, :401)."""
         x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device).permute(2, 0, 1).unsqueeze(0).float()
         x = torch.nn.functional.interpolate(x, size=resized, mode="bilinear", align_corners=False, antialias=False)
         x = x.round().clamp_(0, 255)
         dx, dy = crop
-        return (x[0, :, dy:dy + self.img_H, dx:dx + self.img_W] / 255.0).contiguous()
+        x = x[0, :, dy:dy + self.img_H, dx:dx + self.img_W]
+        self.last_jitter = None
+        if jitter:
+            x, self.last_jitter = color_jitter(x)
+        return (x / 255.0).contiguous()
 
     def __getitem__(self, index):
         f = self.read_frame(index)
@@ -148,15 +211,19 @@ class FrameDataset:
             draws["perm"] = p
             return torch.from_numpy(p.astype(np.int64)).to(dev)
 
-        cand = np.random.choice(self.num_pt, self.num_node * 8, replace=False)     # :356 (drawn after the pose in the reference; only the order
-        fps_start = np.random.randint(3)                                           # of the np.random stream differs) ; :117 start in {0, 1, 2}
-        draws.update(cand=cand, fps_start=int(fps_start))
+        def nodes():                                                               # :356 candidates, :117 FPS start in {0, 1, 2}: drawn AFTER the
+            cand = np.random.choice(self.num_pt, self.num_node * 8, replace=False)  # circle-loss permutation (:340), as in the reference's np.random stream
+            fps_start = int(np.random.randint(3))
+            draws.update(cand=cand, fps_start=fps_start)
+            return torch.from_numpy(cand.astype(np.int64)).to(dev), fps_start
+
+        # the image first: the reference jitters (:312, torch's generator) before it draws the permutation (np.random), the candidates and the pose
+        img = self.image_tensor(f["img"], f["resized"], f["crop"], jitter=self.mode == "train")
         out = preprocess_frame(torch.from_numpy(f["raw"]).to(dev), f["P_Tr"], f["K"], f["P_random"], hw4,
-                               choice=torch.from_numpy(f["choice"]).to(dev), perm=perm,
-                               node_candidates=torch.from_numpy(cand.astype(np.int64)).to(dev), fps_start=int(fps_start),
+                               choice=torch.from_numpy(f["choice"]).to(dev), perm=perm, node_candidates=nodes,
                                num_node=self.num_node, n_circle=self.n_circle)
         out.pop("in_picture_count", None)
-        out["img"] = self.image_tensor(f["img"], f["resized"], f["crop"])
+        out["img"] = img
         out["angles"] = torch.from_numpy(f["angles"])
         out["translation"] = torch.from_numpy(f["t"])
         self.last_draws = draws

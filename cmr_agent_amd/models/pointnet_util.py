@@ -1,10 +1,32 @@
 """Device versions of the reference's models/pointnet_util.py ops with the module's call
 signatures ([B,N,3] channels-last coordinates, int64 indices): square_distance :19-33,
 index_points :36-47, farthest_point_sample :50-70 (explicit start index instead of the global
-RNG draw at :62), query_ball_point :73-93, sample_and_group :96-133."""
+RNG draw at :62), query_ball_point :73-93, sample_and_group :96-133, sample_and_group_all :136-153, and the
+two host helpers pc_normalize :12-17 / timeit :8-10."""
+from time import time
+
+import numpy as np
 import torch
 
 from .. import ops
+
+
+def timeit(tag, t):
+    """pointnet_util.py:8-10."""
+    print("{}: {}s".format(tag, time() - t))
+    return time()
+
+
+def pc_normalize(pc):
+    """pointnet_util.py:12-17: centre an [N, C] cloud on its mean and scale its farthest point onto the unit sphere.  numpy in, numpy out
+    (the reference's host helper); a torch tensor stays a tensor on its device."""
+    if isinstance(pc, torch.Tensor):
+        pc = pc - pc.mean(dim=0)
+        return pc / torch.sqrt((pc ** 2).sum(dim=1)).max()
+    centroid = np.mean(pc, axis=0)
+    pc = pc - centroid
+    m = np.max(np.sqrt(np.sum(pc ** 2, axis=1)))
+    return pc / m
 
 
 def _rows4(xyz):
@@ -71,6 +93,18 @@ def sample_and_group(npoint, radius, nsample, xyz, points, returnfps=False, knn=
     if returnfps:
         return new_xyz, new_points, grouped_xyz, fps_idx
     return new_xyz, new_points
+
+
+def sample_and_group_all(xyz, points):
+    """pointnet_util.py:136-153: the whole cloud as ONE group around the origin -- xyz [B, N, 3], points [B, N, D] or None ->
+    (new_xyz zeros [B, 1, 3], new_points [B, 1, N, 3 + D]: the raw coordinates in front of the features).  Views and one concatenation:
+    no kernel of its own (PointNetSetAbstraction(group_all=True) builds the same rows in its plan)."""
+    B, N, C = xyz.shape
+    new_xyz = torch.zeros(B, 1, C, device=xyz.device)
+    grouped_xyz = xyz.view(B, 1, N, C)
+    if points is not None:
+        return new_xyz, torch.cat([grouped_xyz, points.view(B, 1, N, -1)], dim=-1)
+    return new_xyz, grouped_xyz
 
 
 # ---------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@ from . import _lib
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_ELU1 = 0, 1, 2, 3, 4
 f32 = torch.float32
+GRID_Y_MAX = 65535          # groups / samples that ride in gridDim.y: entry points refuse more (CMR_EINVAL), callers chunk
 
 
 def _stream():
@@ -1053,13 +1054,19 @@ def colsum(x, B, N, out=None):
 
 
 def colmax_arg(x, B, N):
+    """max and arg-max row over the N consecutive rows of each of the B groups of x [B N, C] -> ([B, C] f32, [B, C] i32 row within the
+    group).  The groups ride in gridDim.y (<= 65535): more groups (a train-mode set abstraction with B * npoint >= 65536 centroids,
+    pointnet_util.py:190) go in chunks."""
     _rows(x)
     C = x.shape[1]
-    nb = _lib.load().cmr_colarg_workspace_bytes(B, N, C)
-    ws = _ws(nb, x.device)
     out = torch.empty((B, C), dtype=f32, device=x.device)
     arg = torch.empty((B, C), dtype=torch.int32, device=x.device)
-    _lib.call("cmr_colmax_arg_f32", _p(x), _ld(x), _p(out), _p(arg), _p(ws), nb, B, N, C, _stream())
+    for b0 in range(0, B, GRID_Y_MAX):
+        b = min(GRID_Y_MAX, B - b0)
+        nb = _lib.load().cmr_colarg_workspace_bytes(b, N, C)
+        ws = _ws(nb, x.device)
+        xs = x[b0 * N:(b0 + b) * N]
+        _lib.call("cmr_colmax_arg_f32", _p(xs), _ld(xs), _p(out[b0:b0 + b]), _p(arg[b0:b0 + b]), _p(ws), nb, b, N, C, _stream())
     return out, arg
 
 

@@ -481,7 +481,8 @@ int cmr_affine_act_f32(const float* x, int64_t ldx, const float* scale, const fl
 /* Backward of [BatchNorm(train) -> LeakyReLU]: dz = gradient w.r.t. the activation output z, x = the BatchNorm input, stat from
  * cmr_bn_stats_f32.  z null: slope 1 = no activation; slope != 1 = the activation sat directly on the BatchNorm output (no residual in
  * between) and its mask is taken from the sign of x * scale + shift, recomputed with cmr_affine_act_f32's own fused multiply-add (the
- * stored output is then not read: one map pass less in each of the two sweeps).  dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add),
+ * stored output is then not read: one map pass less in each of the two sweeps; CMR_EINVAL unless 0 <= slope <= 1, the range in which that
+ * sign is the forward's mask -- a caller with a residual in front of the activation MUST pass z).  dx = gamma rstd (dy - mean(dy) - xhat mean(dy xhat)) (+ add),
  * dgamma = sum dy xhat, dbeta = sum dy (written when non-null).  dzm (optional): receives dy = dz * act'(z), the gradient at the
  * activation's input -- what a residual branch added in front of the activation gets (`lrelu(BN(x) + res)`, ImageResNet.py:36-40,
  * PointNN.py:282), from the same pass instead of a separate activation-backward sweep. */

@@ -135,3 +135,68 @@ def test_frame_dataset_sample_dict_on_device(tmp_path):
     batches = list(loader)
     assert len(batches) == 3 and tuple(batches[0]["pc"].shape) == (2, 3, F["num_pt"]) and tuple(batches[0]["img"].shape) == (2, 3, F["H"], F["W"])
     assert batches[0]["pt2node"].dtype == torch.int64 and tuple(batches[0]["node"].shape) == (2, 3, F["num_node"])
+    # train mode (:311-312): the colour jitter runs on the device, its draws are recorded, and replaying them on the un-jittered crop gives
+    # the sample's image
+    from cmr_agent_amd.dataset.loader import color_jitter
+    root_t = str(tmp_path / "train")
+    os.makedirs(root_t)
+    _write_dataset(root_t, seqs=(0,), frames=2)
+    dt = FrameDataset(root_t, cfg, "train", device="cuda")
+    random.seed(3)
+    np.random.seed(3)
+    torch.manual_seed(3)
+    st = dt[1]
+    assert dt.last_jitter is not None and sorted(dt.last_jitter[0]) == [0, 1, 2, 3]
+    f = dt.read_frame(1)
+    plain = dt.image_tensor(f["img"], f["resized"], dt.last_draws["crop"], jitter=False)
+    replay, _ = color_jitter(plain * 255.0, draws=dt.last_jitter)
+    assert torch.equal(st["img"], (replay / 255.0).contiguous()) and not torch.equal(st["img"], plain)
+    assert 0.0 <= float(st["img"].min()) and float(st["img"].max()) <= 1.0
+
+
+def test_color_jitter_against_pil_enhancers():
+    """KittiDataset.augment_img (:209-218) hands a PIL image to torchvision's ColorJitter, whose PIL branch is ImageEnhance.Brightness /
+    Contrast / Color and an 8-bit HSV hue rotation.  torchvision is not in this image; PIL is: each adjustment of the device restatement
+    against PIL's own enhancer on the same uint8 image (+-1 grey level: PIL truncates where the restatement rounds; the hue path goes
+    through PIL's 8-bit HSV, so a few levels more), and the composition order / draw order of ColorJitter.get_params."""
+    from PIL import Image, ImageEnhance
+    from cmr_agent_amd.dataset.loader import color_jitter
+    rng = np.random.RandomState(3)
+    yy, xx = np.mgrid[0:48, 0:64]
+    img = np.stack([(xx * 4) % 256, (yy * 5 + xx) % 256, (255 - xx * 3 - yy) % 256], axis=2).astype(np.uint8)
+    img[8:24, 8:40] = rng.randint(0, 256, (16, 32, 3))
+    pil = Image.fromarray(img)
+    x = torch.from_numpy(img).permute(2, 0, 1).float()
+
+    def mine(order, b=1.0, c=1.0, s=1.0, h=0.0):
+        y, d = color_jitter(x, draws=(order, b, c, s, h))
+        assert d == (order, b, c, s, h)
+        return y.permute(1, 2, 0).numpy()
+
+    assert np.array_equal(mine([0, 1, 2, 3]), img.astype(np.float32))                      # unit factors, zero hue shift: the identity
+    for f in (0.8, 1.13, 1.2):
+        d = np.abs(mine([0], b=f) - np.asarray(ImageEnhance.Brightness(pil).enhance(f), dtype=np.float32))
+        assert d.max() <= 1.0, ("brightness", f, d.max())
+        d = np.abs(mine([1], c=f) - np.asarray(ImageEnhance.Contrast(pil).enhance(f), dtype=np.float32))
+        assert d.max() <= 1.0, ("contrast", f, d.max())
+        d = np.abs(mine([2], s=f) - np.asarray(ImageEnhance.Color(pil).enhance(f), dtype=np.float32))
+        assert d.max() <= 2.0 and d.mean() <= 0.6, ("saturation", f, d.max(), d.mean())
+    for f in (-0.1, 0.04, 0.1):
+        hh, ss, vv = pil.convert("HSV").split()
+        nh = np.array(hh, dtype=np.uint8)
+        nh = (nh.astype(np.int32) + int(np.uint8(np.int32(f * 255)))).astype(np.uint8)      # uint8 wrap-around, as F_pil.adjust_hue
+        ref = np.asarray(Image.merge("HSV", (Image.fromarray(nh, "L"), ss, vv)).convert("RGB"), dtype=np.float32)
+        d = np.abs(mine([3], h=f) - ref)
+        assert d.mean() <= 2.0 and np.percentile(d, 99) <= 8.0, ("hue", f, d.mean(), d.max())
+    # composition: the adjustments apply in the drawn order, each on the previous one's 0..255 result
+    two = mine([2, 0], b=0.9, s=1.15)
+    step = color_jitter(color_jitter(x, draws=([2], 1.0, 1.0, 1.15, 0.0))[0], draws=([0], 0.9, 1.0, 1.0, 0.0))[0].permute(1, 2, 0).numpy()
+    assert np.array_equal(two, step)
+    # draws: randperm(4) first, then brightness, contrast, saturation, hue from torch's global generator (ColorJitter.get_params)
+    torch.manual_seed(7)
+    _, d = color_jitter(x)
+    torch.manual_seed(7)
+    order = torch.randperm(4).tolist()
+    fac = [float(torch.empty(1).uniform_(lo, hi)) for lo, hi in ((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))]
+    assert d == (order, *fac)
+    assert 0.8 <= d[1] <= 1.2 and -0.1 <= d[4] <= 0.1

@@ -249,6 +249,16 @@ def test_column_reductions_pool_backward(ops):
     xr = x.view(B, N, Cc).clone().requires_grad_(True)
     xr.max(dim=1)[0].backward(g)
     close(dx, xr.grad.view(B * N, Cc), 0, "max backward")
+    # more groups than gridDim.y holds (a train-mode set abstraction over 16 x 4096 + centroids, pointnet_util.py:190): chunked by the host
+    # side, refused by the entry point itself
+    NG, K = 65535 + 700, 8
+    xg = rnd(NG * K, 8, seed=35)
+    mg, ag = ops.colmax_arg(xg.to(DEV), NG, K)
+    rg = xg.view(NG, K, 8).max(dim=1)
+    assert torch.equal(mg.cpu(), rg[0]) and torch.equal(ag.cpu().long(), rg[1])
+    from cmr_agent_amd import _lib
+    with pytest.raises(Exception):
+        _lib.call("cmr_colsum_f32", xg.to(DEV).data_ptr(), 8, mg.data_ptr(), mg.data_ptr(), 1 << 30, NG, K, 8, 0)
     # [LeakyReLU -> AvgPool] backward, 2x2 and global
     for ph, pw in ((2, 2), (6, 10)):
         c = rnd(2, 128, 6, 10, seed=33).requires_grad_(True)
