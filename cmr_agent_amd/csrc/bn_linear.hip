@@ -51,6 +51,31 @@ __device__ __forceinline__ f32x4 blb_fma4(f32x4 a, f32x4 b, f32x4 c) {
   return f32x4{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1]), __builtin_fmaf(a[2], b[2], c[2]), __builtin_fmaf(a[3], b[3], c[3])};
 }
 
+// ---- helpers of the bf16-product variants further down ----
+typedef __bf16 bl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bl_s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bl_pack2(float lo, float hi) {            // (bf16(lo) | bf16(hi) << 16), round to nearest even
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo, hi}, b2));
+}
+__device__ __forceinline__ int bl_off(int row, int chunk) { return 256 * row + 16 * (chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ uint2 bl_tr(const unsigned char* base, int byte_off) {
+  const bl_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bl_s4*)(base + byte_off));
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ bl_bf16x8 bl_tr8(const unsigned char* base, int off0, int off1) {
+  const uint2 a0 = bl_tr(base, off0), a1 = bl_tr(base, off1);
+  return __builtin_bit_cast(bl_bf16x8, uint4{a0.x, a0.y, a1.x, a1.y});
+}
+// sum over the 32 lanes that share lane >> 5 (the 32 rows of a block in the transposed product's layout): DPP row sum, then the partner row
+__device__ __forceinline__ float bl_sum32(float v) {
+  v = m16_sum16(v);
+  v += cmr_xor16(v);
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 // ZH: the activation mask is the sign of this layer's own pre-activation h * scale + shift (the layer's output was never stored: it was
 // consumed through the next layer's prologue); XL: see BlbArgs.  Pre-activations are formed with the SAME fused multiply-add in the forward
 // prologue (bn_linear_fwd_kernel), here and in the mask, so that a value within rounding of zero takes the same branch everywhere.
@@ -580,6 +605,231 @@ __global__ __launch_bounds__(64) void bn_stats_merge_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 products, forward (round 6): h = x' W^T + b with the batch statistics of h from the same pass, products on
+// v_mfma_f32_32x32x16_bf16.  With 1/16 of the matrix time the layer is a stream, and the stream needs no workgroup: a WAVE owns 32-row
+// tiles (lane = row, the pattern of linear_rows_bf16_kernel: 4.9 - 5.6 TB/s, profiles/r03_stream_patterns.txt), no barrier in the loop.
+// Transposed product D[channel][row]: weights = A operand (bf16 fragments in LDS, written once per workgroup, fragment order: conflict-free
+// ds_read_b128), rows = B operand (converted on the fly, PRO: the previous layer's BatchNorm + LeakyReLU applied first, its affine in
+// LDS); a lane ends with 2 x 16 channels of ONE row -> float4 stores, per-lane running sums of (h - pivot) and (h - pivot)^2 (pivot = the
+// wave's first row), reduced over the 32 row lanes once at the end.  A workgroup serves 64 output channels (blockIdx.y: the other 64 of a
+// 128-wide layer; its x reads are L2 hits); partials [waves][4][n] = (pivot, sum, sum of squares, row count) merged in double.
+// The bias (per segment when bias_stride != 0) sits in a per-wave LDS slot and is the accumulators' initial value.
+// ------------------------------------------------------------------------------------------------------------------
+template <int KS, bool PRO>
+__global__ __launch_bounds__(256, 2) void bn_linear_fwd_bf16_kernel(const BlfArgs a, int n_total) {
+  constexpr int K = 16 * KS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char blg_smem[];
+  bl_bf16x8* Wf = reinterpret_cast<bl_bf16x8*>(blg_smem);                  // [2][KS][64 lanes]
+  float* paff = reinterpret_cast<float*>(blg_smem + 2 * KS * 1024);        // PRO: [2][K] scale | shift
+  float* bslot = paff + 2 * K;                                             // [4 waves][64]  bias
+  float* pslot = bslot + 256;                                              // [4 waves][64]  pivot
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int cb = 64 * blockIdx.y;
+  // weight fragments: lane (cout cb + 32 t + l31, half h), step ks holds W[cout][16 ks + 8 h .. + 7]
+  for (int f = wave; f < 2 * KS; f += 4) {
+    const int t = f / KS, ks = f % KS;
+    const float* wr = a.w + (int64_t)(cb + 32 * t + l31) * a.ldw + 16 * ks + 8 * h;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(wr), hi = *reinterpret_cast<const f32x4*>(wr + 4);
+    Wf[f * 64 + lane] = __builtin_bit_cast(bl_bf16x8, uint4{bl_pack2(lo[0], lo[1]), bl_pack2(lo[2], lo[3]), bl_pack2(hi[0], hi[1]), bl_pack2(hi[2], hi[3])});
+  }
+  if (PRO) {
+    for (int i = tid; i < 2 * K; i += 256) paff[i] = a.pro[2 * K + i];
+  }
+  float* myb = bslot + 64 * wave;
+  float* myp = pslot + 64 * wave;
+  myb[lane] = 0.f;
+  myp[lane] = 0.f;
+  __syncthreads();
+  const int64_t ntiles = a.rows / 32, tstride = (int64_t)gridDim.x * 4;
+  auto load_tile = [&](int64_t tile, f32x4 (&dst)[2 * KS]) __attribute__((always_inline)) {
+    const int64_t row = (tile < ntiles ? tile : ntiles - 1) * 32 + l31;
+    const float* xp = a.x + row * a.ldx + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      dst[2 * ks] = *reinterpret_cast<const f32x4*>(xp + 16 * ks);
+      dst[2 * ks + 1] = *reinterpret_cast<const f32x4*>(xp + 16 * ks + 4);
+    }
+  };
+  f32x4 raw[2 * KS];
+  float sum[2][16], sq[2][16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum[t][r] = sq[t][r] = 0.f;
+  bool first = true;
+  int64_t cur_seg = -1, count = 0;
+  int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  load_tile(tile, raw);
+#pragma clang loop unroll(disable)
+  for (; tile < ntiles; tile += tstride) {
+    // the LDS operands (affine, weight fragments) are loop invariant: without an opaque offset hipcc hoists all of them out of the tile
+    // loop -- 128 + 64 registers of invariants, i.e. spills
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const float* paff_ = paff + opq;
+    const bl_bf16x8* Wf_ = Wf + opq;
+    if (a.bias) {
+      const int64_t seg = a.bias_stride ? tile / a.seg_blocks : 0;          // (wave-uniform)
+      if (seg != cur_seg) {
+        cur_seg = seg;
+        myb[lane] = a.bias[seg * a.bias_stride + cb + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(myb + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[t][4 * q + e] = bq[e];
+      }
+    // one contraction step at a time: convert this step's 8 channels of the row (PRO: the previous layer's BatchNorm + LeakyReLU first), two
+    // matrix instructions; the raw registers are dead behind the last step and take the NEXT tile's rows, which travel under the epilogue
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f32x4 lo = raw[2 * ks], hi = raw[2 * ks + 1];
+      if (PRO) {
+        const int c = 16 * ks + 8 * h;
+        lo = blb_fma4(lo, *reinterpret_cast<const f32x4*>(paff_ + c), *reinterpret_cast<const f32x4*>(paff_ + K + c));
+        hi = blb_fma4(hi, *reinterpret_cast<const f32x4*>(paff_ + c + 4), *reinterpret_cast<const f32x4*>(paff_ + K + c + 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          lo[e] = lo[e] > 0.f ? lo[e] : lo[e] * a.pro_slope;
+          hi[e] = hi[e] > 0.f ? hi[e] : hi[e] * a.pro_slope;
+        }
+      }
+      const bl_bf16x8 xb = __builtin_bit_cast(bl_bf16x8, uint4{bl_pack2(lo[0], lo[1]), bl_pack2(lo[2], lo[3]), bl_pack2(hi[0], hi[1]), bl_pack2(hi[2], hi[3])});
+#pragma unroll
+      for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Wf_[(t * KS + ks) * 64 + lane], xb, acc[t], 0, 0, 0);
+      if (ks & 1) __builtin_amdgcn_sched_barrier(0);              // (keeps the steps in order: hoisting every operand read costs ~100 registers)
+    }
+    load_tile(tile + tstride, raw);
+    __builtin_amdgcn_sched_barrier(0);
+    float* hp = a.h + (tile * 32 + l31) * a.ldh + cb + 4 * h;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f32x4*>(hp + 32 * t + 8 * q) = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+    // pivot = row 0 of the wave's first tile (lanes 0 / 32 hold it for their channels): kept in the wave's LDS slot, read back as float4
+    if (first) {                                                 // (wave-uniform)
+      if (l31 == 0) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<f32x4*>(myp + 32 * t + 8 * q + 4 * h) = f32x4{acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      first = false;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(myp + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = acc[t][4 * q + e] - pv[e];
+          sum[t][4 * q + e] += d;
+          sq[t][4 * q + e] = __builtin_fmaf(d, d, sq[t][4 * q + e]);
+        }
+      }
+    count += 32;
+  }
+  // reduce over the 32 row lanes of each half (fixed order); lanes 0 and 32 write their channels cb + 32 t + 8 q + 4 h + e.  Partials are
+  // stored [4][n][G] (G = waves of the launch): the merge reads a channel's G values of one kind from consecutive addresses
+  const int64_t G = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + wave;
+  float* pp = a.part + (int64_t)(cb + 4 * h) * G + gw;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float s_ = bl_sum32(sum[t][r]), q_ = bl_sum32(sq[t][r]);
+      if (l31 == 0) {
+        const int c = 32 * t + 8 * (r >> 2) + (r & 3);
+        pp[c * G] = myp[c + 4 * h];
+        pp[((int64_t)n_total + c) * G] = s_;
+        pp[((int64_t)2 * n_total + c) * G] = q_;
+        pp[((int64_t)3 * n_total + c) * G] = (float)count;
+      }
+    }
+}
+
+// one 256-thread workgroup per channel: merge the waves' (pivot, sum, sum of squares, count) in double (parallel variance; every load of a
+// thread independent of the others, consecutive threads on consecutive addresses), then what cmr_bn_stats_f32's final step does: stat =
+// (mean, rstd, scale, shift), running statistics.  part [4][C][G].
+__global__ __launch_bounds__(256) void bn_stats_merge_cnt_kernel(const float* __restrict__ part, int G, int64_t rows, int C, float eps, float momentum,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float* __restrict__ stat) {
+  __shared__ double sm[4][5];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* pv = part + (int64_t)c * G;
+  const int64_t kind = (int64_t)C * G;
+  double s_s = 0.0, s_ss = 0.0, s_ps = 0.0, s_np = 0.0, s_npp = 0.0;
+  for (int w = tid; w < G; w += 256) {
+    const double p = (double)pv[w], s = (double)pv[kind + w], n = (double)pv[3 * kind + w];
+    s_s += s;
+    s_ss += (double)pv[2 * kind + w];
+    s_ps += p * s;
+    s_np += n * p;
+    s_npp += n * p * p;
+  }
+  s_s = blf_wave_sum(s_s);
+  s_ss = blf_wave_sum(s_ss);
+  s_ps = blf_wave_sum(s_ps);
+  s_np = blf_wave_sum(s_np);
+  s_npp = blf_wave_sum(s_npp);
+  if (lane == 0) {
+    sm[wave][0] = s_s; sm[wave][1] = s_ss; sm[wave][2] = s_ps; sm[wave][3] = s_np; sm[wave][4] = s_npp;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  s_s = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+  s_ss = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+  s_ps = sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2];
+  s_np = sm[0][3] + sm[1][3] + sm[2][3] + sm[3][3];
+  s_npp = sm[0][4] + sm[1][4] + sm[2][4] + sm[3][4];
+  const double n = (double)rows;
+  const double mean = (s_np + s_s) / n;
+  const double m2 = s_ss - 2.0 * mean * s_s + 2.0 * s_ps + mean * mean * n - 2.0 * mean * s_np + s_npp;
+  double var = m2 / n;
+  var = var > 0.0 ? var : 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float gm = gamma ? gamma[c] : 1.f, bt = beta ? beta[c] : 0.f;
+  const float scale = gm * rstd;
+  stat[c] = (float)mean;
+  stat[C + c] = rstd;
+  stat[2 * C + c] = scale;
+  stat[3 * C + c] = bt - (float)mean * scale;
+  if (running_mean) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    const double unbiased = rows > 1 ? var * n / (n - 1.0) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+#ifndef CMR_BLG_WG_PER_CU
+#define CMR_BLG_WG_PER_CU 2
+#endif
+#ifndef CMR_BLG_MIN_TILES
+#define CMR_BLG_MIN_TILES 4
+#endif
+inline int blg_groups(int64_t rows) {
+  const int64_t ntiles = rows / 32;
+  int64_t groups = 256 * CMR_BLG_WG_PER_CU;
+  if (groups * 4 * CMR_BLG_MIN_TILES > ntiles) groups = (ntiles + 4 * CMR_BLG_MIN_TILES - 1) / (4 * CMR_BLG_MIN_TILES);     // tiles per wave: the weight fragments and the pipeline fill are paid once
+  return (int)(groups < 1 ? 1 : groups);
+}
+
 inline int blf_groups(int64_t rows, int n, int k) {
   const int64_t nblocks = rows / 32;
   int64_t groups = 256 * ((k == 64 && n == 64) ? 4 : (n == 64 || k == 64 ? 3 : 2));
@@ -661,6 +911,310 @@ int blb_dispatch(const BlbArgs& a, bool bn, bool zh, bool xl, int groups, hipStr
   return zh ? blb_launch<NT, KT, true, true, false>(a, groups, stream) : blb_launch<NT, KT, true, false, false>(a, groups, stream);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// bf16 products (round 6; VERDICT r05 #1a): the same layer backward for the bf16 mode of the agent update (BASELINE configs[2]:
+// Train_Agent.py:296-305 through CMRAgent.py:25-33, 92-101).  At 18 FLOP/B the fp32 kernel above sits ON the fp32 matrix ridge (matrix
+// pipe busy 0.47 of the launch, profiles/r04_pmc_bn_linear.txt); with the products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) the
+// matrix work of a 32-row block is 4 - 12 instructions per wave and the layer is a stream.  Same skeleton (4 waves walk 32-row blocks with a
+// static stride, whole rows fetched with float4 loads one block ahead, (dz, z, h) -> dh in fp32 on the way into LDS), but the LDS tiles
+// are bf16 (RNE) in ONE image that serves both products: 256-byte rows, 16-byte chunk c of row r at chunk c ^ (((r & 3) << 2) | ((r >> 2) & 3))
+// (cdna_hip_programming.md T10, image (b): conflict-free for the 8-byte staging writes, the ds_read_b128 row reads and the transposed reads)
+//   weight gradient  dW[n][k] += sum_r dh[r][n] x'[r][k]: contraction over ROWS -- both operands are 8 consecutive rows of one channel per
+//     lane = two ds_read_b64_tr_b16 each (the LDS hardware transposes on the way out); wave w owns the tiles w TPW .. + TPW - 1 (one nt:
+//     the dh operand is shared);
+//   data gradient    dx^T[k][r] = sum_n W^T[k][n] dh[r][n]: wave w < K / 32 owns input channels [32 w, 32 w + 32); W^T as bf16 fragments in
+//     registers (A operand), dh rows by ds_read_b128 (B operand); a lane ends with 4 x 4 consecutive channels of ONE row: float4 stores,
+//     the residual and (XL) the previous layer's raw BatchNorm input prefetched in the same pattern.
+// Column sums of dh (bias gradient / per-segment sums) are taken by the staging threads from the UNROUNDED fp32 dh; everything that is not
+// a product (masks, BatchNorm backward arithmetic, the XL sums, partial sums, reductions) stays fp32 / double as above.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BLH_R = 32, BLH_IMG = BLH_R * 256;          // rows per block; bytes per image buffer
+// dh enters both products as TWO bf16 terms, hi = bf16(dh) and lo = bf16(dh - hi) (16 mantissa bits instead of 8: two matrix instructions per
+// product step instead of one, still 1/8 of the fp32 matrix time).  With single-term dh the 40-update trajectory of
+// tests/test_train_gpu.py ended 10 % off the fp32 run (bar 5 %); x' and W stay single bf16 terms.
+#ifndef CMR_BLH_HILO
+#define CMR_BLH_HILO 1
+#endif
+
+template <int NT, int KT, bool BN, bool ZH, bool XL>
+__global__ __launch_bounds__(256, (XL || NT == 4 || KT == 4) ? 2 : 3) void bn_linear_bwd_bf16_kernel(const BlbArgs a) {
+  static_assert(BN || !(ZH || XL), "lazy operands belong to BatchNorm layers");
+  constexpr int N = 32 * NT, K = 32 * KT, R = BLH_R, TPW = NT * KT / 4, NS = N / 16;
+  constexpr int NLD = NT, NLX = KT, DRS = 1024 / N, XRS = 1024 / K;
+  constexpr bool HL = CMR_BLH_HILO != 0;
+  // the lo terms of dh: N = 64 -- in the unused half of dh's own 256-byte rows (chunk + 8, i.e. tile + 2 / step + 4); N = 128 -- an image of their own
+  constexpr bool LOIMG = HL && N == 128;
+  constexpr int NIMG = LOIMG ? 6 : 4, LO_T = (HL && !LOIMG) ? 2 : 0, LO_KS = (HL && !LOIMG) ? 4 : 0;
+  extern __shared__ __attribute__((aligned(16))) unsigned char blh_smem[];
+  unsigned char* DI = blh_smem;                                   // [2][32 rows][256 B]  dh  (bf16)
+  unsigned char* XI = blh_smem + 2 * BLH_IMG;                     // [2][32 rows][256 B]  x'  (bf16)
+  unsigned char* DLI = LOIMG ? blh_smem + 4 * BLH_IMG : DI;       // [2][32 rows][256 B]  lo terms of dh
+  float* caff = reinterpret_cast<float*>(blh_smem + NIMG * BLH_IMG); // BN: [6][N] mean, rstd, scale, shift, c1, c2 (read per block: registers are scarcer)
+  float* xaff = caff + 6 * N;                                     // XL: the previous layer's stat [4][K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, l31 = lane & 31, g16 = lane >> 4, q4 = (lane >> 2) & 3, p4 = lane & 3;
+  const bool want_dx = a.dx != nullptr;
+  const bool dg = want_dx && wave < KT;                           // (wave-uniform) this wave owns input channels [32 wave, 32 wave + 32)
+  const bool has_res = a.res != nullptr;
+  const bool want_b = a.part_b != nullptr;
+
+  const int dc = tid % (N / 4), dr0 = tid / (N / 4);
+  const int xc = tid % (K / 4), xr0 = tid / (K / 4);
+  if (BN) {
+    for (int i = tid; i < 4 * N; i += 256) caff[i] = a.stat[i];
+    for (int i = tid; i < 2 * N; i += 256) caff[4 * N + i] = a.coef[i];
+  }
+  if (XL) {
+    for (int i = tid; i < 4 * K; i += 256) xaff[i] = a.xstat[i];
+  }
+  if (BN || XL) __syncthreads();
+  // data gradient: W^T as the A operand -- lane (channel 32 wave + l31, half h), step ks: W[16 ks + 8 h .. + 7][channel]
+  bl_bf16x8 wa[NS];
+  if (dg) {
+    const float* wp = a.w + 32 * wave + l31;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = wp[(int64_t)(16 * ks + 8 * h + e) * a.ldw];
+      wa[ks] = __builtin_bit_cast(bl_bf16x8, uint4{bl_pack2(v[0], v[1]), bl_pack2(v[2], v[3]), bl_pack2(v[4], v[5]), bl_pack2(v[6], v[7])});
+    }
+  }
+  // transposed-read offsets of this lane (they do not change from block to block): 16-lane group g16 covers channels 16 (g16 & 1) .. + 15 of
+  // a 32-channel tile and the row half h = g16 >> 1; lane 4 q + p of the group supplies the address of block row q, columns 4 p .. 4 p + 3.
+  // With row = 16 s + 8 h + 4 j + q4 the swizzle of bl_off splits: chunk (4 T + cq) ^ (((row & 3) << 2) | ((row >> 2) & 3)) =
+  // 4 (T ^ q4) + (cq ^ ((2 h + j) & 3)) -- four row bases per lane and one 64-byte tile term per tile instead of a register per (tile, s, j)
+  const int nt_w = (wave * TPW) / KT;
+  int trb[2][2], tqx[TPW];
+  {
+    const int sub8 = 8 * (p4 & 1), cq = 2 * (g16 & 1) + (p4 >> 1);
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) trb[s_][j] = 256 * (16 * s_ + 8 * h + 4 * j + q4) + 16 * (cq ^ ((2 * h + j) & 3)) + sub8;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) tqx[t] = 64 * (((wave * TPW + t) % KT) ^ q4);
+  }
+  const int tqd = 64 * (nt_w ^ q4), tql = 64 * ((nt_w + LO_T) ^ q4);
+  // row reads of the data gradient's B operand: chunk (2 ks + h) of row l31 -> 256 l31 + 32 (ks ^ (sw >> 1)) + 16 (h ^ (sw & 1))
+  const int swr = ((l31 & 3) << 2) | ((l31 >> 2) & 3);
+  const int rdb = 256 * l31 + 16 * (h ^ (swr & 1)), rdx = swr >> 1;
+  // N = 128: the W^T fragments live in LDS (fragment order, one ds_read_b128 per matrix instruction) -- 32 registers the kernel does not have
+  constexpr bool WLDS = NS == 8;
+  bl_bf16x8* wfr = reinterpret_cast<bl_bf16x8*>(blh_smem + NIMG * BLH_IMG + (6 * N + (XL ? 4 * K : 0)) * sizeof(float)) + wave * NS * 64;
+  if (WLDS && dg) {
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) wfr[ks * 64 + lane] = wa[ks];
+  }
+
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  f32x4 bs = {0.f, 0.f, 0.f, 0.f};                               // column sums of (fp32) dh over this thread's rows, channels 4 dc .. + 3
+  f32x4 s1[4], s2[4];                                            // XL: the previous layer's BatchNorm-backward sums (channels 32 wave + 8 q + 4 h .. + 3)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s1[q] = s2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Stage {
+    f32x4 d[NLD], m[NLD], hv[NLD], x[NLX];
+  };
+  // the residual and (XL) the raw BatchNorm input of the previous layer in the data gradient's OUTPUT layout (row l31, channels 32 wave + 8 q
+  // + 4 h .. + 3): requested at the top of a block's iteration, used behind its matrix instructions (the raw input was fetched by this
+  // workgroup one iteration earlier for the image: an L2 hit)
+  auto load_out_layout = [&](int64_t blk, f32x4 (&rv)[4], f32x4 (&xv)[4]) {
+    if (!dg) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (has_res) rv[q] = *reinterpret_cast<const f32x4*>(a.res + (blk * R + l31) * a.ldres + 32 * wave + 8 * q + 4 * h);
+      if (XL) xv[q] = *reinterpret_cast<const f32x4*>(a.x + (blk * R + l31) * a.ldx + 32 * wave + 8 * q + 4 * h);
+    }
+  };
+  auto load_block = [&](int64_t blk, Stage& s) {
+    const int64_t r0 = blk * R;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int64_t row = r0 + dr0 + DRS * i;
+      s.d[i] = *reinterpret_cast<const f32x4*>(a.dz + row * a.lddz + 4 * dc);
+      if (!ZH) s.m[i] = *reinterpret_cast<const f32x4*>(a.z + row * a.ldz + 4 * dc);
+      if (BN) s.hv[i] = *reinterpret_cast<const f32x4*>(a.h + row * a.ldh + 4 * dc);
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) s.x[i] = *reinterpret_cast<const f32x4*>(a.x + (r0 + xr0 + XRS * i) * a.ldx + 4 * xc);
+  };
+  auto store_block = [&](int64_t blk, int buf, const Stage& s) {
+    const int64_t r0 = blk * R;
+    unsigned char* di = DI + buf * BLH_IMG;
+    unsigned char* xi = XI + buf * BLH_IMG;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int r = dr0 + DRS * i;
+      f32x4 d = s.d[i];
+      const f32x4 scale = BN ? *reinterpret_cast<const f32x4*>(caff + 2 * N + 4 * dc) : f32x4{1.f, 1.f, 1.f, 1.f};
+      const f32x4 m = ZH ? blb_fma4(s.hv[i], scale, *reinterpret_cast<const f32x4*>(caff + 3 * N + 4 * dc)) : s.m[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = m[e] > 0.f ? d[e] : d[e] * a.slope;
+      if (a.dzm) *reinterpret_cast<f32x4*>(a.dzm + (r0 + r) * a.lddzm + 4 * dc) = d;
+      if (BN) {
+        const f32x4 xh = (s.hv[i] - *reinterpret_cast<const f32x4*>(caff + 4 * dc)) * *reinterpret_cast<const f32x4*>(caff + N + 4 * dc);
+        d = scale * (d - *reinterpret_cast<const f32x4*>(caff + 4 * N + 4 * dc) - xh * *reinterpret_cast<const f32x4*>(caff + 5 * N + 4 * dc));
+      }
+      if (want_b) bs += d;
+      const unsigned w0 = bl_pack2(d[0], d[1]), w1 = bl_pack2(d[2], d[3]);
+      *reinterpret_cast<uint2*>(di + bl_off(r, dc >> 1) + 8 * (dc & 1)) = uint2{w0, w1};
+      if (HL) {                                              // residues dh - bf16(dh), rounded to bf16 again
+        const float l0 = d[0] - __builtin_bit_cast(float, w0 << 16), l1 = d[1] - __builtin_bit_cast(float, w0 & 0xffff0000u);
+        const float l2 = d[2] - __builtin_bit_cast(float, w1 << 16), l3 = d[3] - __builtin_bit_cast(float, w1 & 0xffff0000u);
+        *reinterpret_cast<uint2*>(DLI + buf * BLH_IMG + bl_off(r, (dc >> 1) + 2 * LO_KS) + 8 * (dc & 1)) = uint2{bl_pack2(l0, l1), bl_pack2(l2, l3)};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NLX; ++i) {
+      const int r = xr0 + XRS * i;
+      f32x4 v = s.x[i];
+      if (XL) {
+        v = blb_fma4(v, *reinterpret_cast<const f32x4*>(xaff + 2 * K + 4 * xc), *reinterpret_cast<const f32x4*>(xaff + 3 * K + 4 * xc));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * a.xslope;
+      }
+      *reinterpret_cast<uint2*>(xi + bl_off(r, xc >> 1) + 8 * (xc & 1)) = uint2{bl_pack2(v[0], v[1]), bl_pack2(v[2], v[3])};
+    }
+  };
+  auto multiply = [&](int64_t blk, int buf, const f32x4 (&rv)[4], const f32x4 (&xv)[4]) {
+    const unsigned char* di = DI + buf * BLH_IMG;
+    const unsigned char* xi = XI + buf * BLH_IMG;
+    const unsigned char* dli = DLI + buf * BLH_IMG;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bl_bf16x8 av = bl_tr8(di, trb[s][0] + tqd, trb[s][1] + tqd);
+      bl_bf16x8 al;
+      if (HL) al = bl_tr8(dli, trb[s][0] + tql, trb[s][1] + tql);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        const bl_bf16x8 bv = bl_tr8(xi, trb[s][0] + tqx[t], trb[s][1] + tqx[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+        if (HL) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bv, acc[t], 0, 0, 0);
+      }
+    }
+    if (!dg) return;
+    f32x16 dacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) dacc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NS; ++ks) {
+      const bl_bf16x8 wv = WLDS ? wfr[ks * 64 + lane] : wa[ks];
+      dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, *reinterpret_cast<const bl_bf16x8*>(di + rdb + 32 * (ks ^ rdx)), dacc, 0, 0, 0);
+      if (HL) dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, *reinterpret_cast<const bl_bf16x8*>(dli + rdb + 32 * ((ks + LO_KS) ^ rdx)), dacc, 0, 0, 0);
+    }
+    float* dxp = a.dx + (blk * R + l31) * a.lddx + 32 * wave + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 o = {dacc[4 * q], dacc[4 * q + 1], dacc[4 * q + 2], dacc[4 * q + 3]};
+      if (has_res) o += rv[q];
+      *reinterpret_cast<f32x4*>(dxp + 8 * q) = o;
+      if (XL) {
+        // dx is the gradient at the previous layer's (never stored) output: its BatchNorm-backward sums from the raw BatchNorm input
+        const int c = 32 * wave + 8 * q + 4 * h;
+        const f32x4 raw = xv[q];
+        const f32x4 pre = blb_fma4(raw, *reinterpret_cast<const f32x4*>(xaff + 2 * K + c), *reinterpret_cast<const f32x4*>(xaff + 3 * K + c));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pre[e] > 0.f ? o[e] : o[e] * a.xslope;
+        s1[q] += o;
+        s2[q] += o * ((raw - *reinterpret_cast<const f32x4*>(xaff + c)) * *reinterpret_cast<const f32x4*>(xaff + K + c));
+      }
+    }
+  };
+
+  const int64_t g = a.seg_groups;
+  const int64_t seg = blockIdx.x / a.seg_groups;
+  const int64_t nblocks = (seg + 1) * a.seg_blocks;
+  auto clampb = [&](int64_t b) { return b < nblocks ? b : nblocks - 1; };
+  int64_t blk = seg * a.seg_blocks + blockIdx.x % a.seg_groups;
+  {
+    Stage st;
+    load_block(clampb(blk), st);
+    store_block(blk, 0, st);
+    __syncthreads();
+    int buf = 0;
+    for (; blk < nblocks; blk += g) {
+      const int64_t nb = blk + g;
+      f32x4 rcur[4], xcur[4];
+      load_out_layout(blk, rcur, xcur);
+      load_block(clampb(nb), st);                    // next block of this workgroup: in flight under this block's products and stores
+      multiply(blk, buf, rcur, xcur);
+      if (nb < nblocks) store_block(nb, buf ^ 1, st);      // (uniform) the other buffer: last read one iteration ago, behind a barrier
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  float* out = a.part + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tile = wave * TPW + t, nt = tile / KT, kt = tile % KT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[(int64_t)(nt * 32 + cmr_mfma_row(r, lane)) * K + kt * 32 + l31] = acc[t][r];
+  }
+  if (XL && dg) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1[q][e] = bl_sum32(s1[q][e]);
+        s2[q][e] = bl_sum32(s2[q][e]);
+      }
+      if (l31 == 0) {
+        float* p = a.xpart + (int64_t)blockIdx.x * 2 * K + 32 * wave + 8 * q + 4 * h;
+        *reinterpret_cast<f32x4*>(p) = s1[q];
+        *reinterpret_cast<f32x4*>(p + K) = s2[q];
+      }
+    }
+  }
+  if (want_b) {
+    // the row groups of the staging layout meet in LDS (over the images: the loop's last barrier is behind every read of them), fixed order
+    float* scr = reinterpret_cast<float*>(blh_smem);
+    *reinterpret_cast<f32x4*>(scr + dr0 * N + 4 * dc) = bs;
+    __syncthreads();
+    if (tid < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int rg = 0; rg < DRS; ++rg) t += scr[rg * N + tid];
+      a.part_b[(int64_t)blockIdx.x * N + tid] = t;
+    }
+  }
+}
+
+inline int blh_groups(int64_t rows) {
+  const int64_t nblocks = rows / BLH_R;
+  int64_t groups = 256 * 4;                                     // 34 KB of LDS and <= 128 registers: four workgroups per CU
+  if (groups > nblocks / 8) groups = nblocks / 8 > 0 ? nblocks / 8 : 1;      // >= 8 row blocks per workgroup
+  return (int)groups;
+}
+
+template <int NT, int KT, bool BN, bool ZH, bool XL>
+int blh_launch(const BlbArgs& a, int groups, hipStream_t stream) {
+  const size_t smem = (size_t)((CMR_BLH_HILO != 0 && NT == 4) ? 6 : 4) * BLH_IMG + (size_t)6 * 32 * NT * sizeof(float) + (XL ? (size_t)4 * 32 * KT * sizeof(float) : 0) +
+                      (NT == 4 ? (size_t)4 * 8 * 1024 : 0);                  // (N = 128: the four waves' W^T fragments)
+  static CmrSmemCache granted{};
+  if (cmr_grant_smem(reinterpret_cast<const void*>(bn_linear_bwd_bf16_kernel<NT, KT, BN, ZH, XL>), smem, granted) != CMR_OK) return CMR_ELAUNCH;
+  hipLaunchKernelGGL((bn_linear_bwd_bf16_kernel<NT, KT, BN, ZH, XL>), dim3(groups), dim3(256), smem, stream, a);
+  return CMR_OK;
+}
+
+template <int NT, int KT>
+int blh_dispatch(const BlbArgs& a, bool bn, bool zh, bool xl, int groups, hipStream_t stream) {
+  if (!bn) return blh_launch<NT, KT, false, false, false>(a, groups, stream);
+  if (xl) {
+    if constexpr (NT == 2) {
+      return zh ? blh_launch<NT, KT, true, true, true>(a, groups, stream) : blh_launch<NT, KT, true, false, true>(a, groups, stream);
+    } else {
+      return CMR_EUNSUPPORTED;
+    }
+  }
+  return zh ? blh_launch<NT, KT, true, true, false>(a, groups, stream) : blh_launch<NT, KT, true, false, false>(a, groups, stream);
+}
+
 inline bool blb_shape_ok(int64_t rows, int n, int k) { return (n == 64 || n == 128) && (k == 64 || k == 128) && rows >= 32 && rows % 32 == 0; }
 
 }  // namespace
@@ -682,12 +1236,12 @@ extern "C" int64_t cmr_bn_linear_bwd_workspace_bytes(int64_t rows, int n, int k)
 //   pass: xcoef [2][k] (what cmr_bn_bwd_coef_f32 would return for it), xdgamma, xdbeta [k] (written when non-null).
 // Returns CMR_EUNSUPPORTED for shapes it does not serve (n, k in {64, 128}, rows a multiple of 32; xstat: n = 64): the caller composes
 // cmr_bn_bwd_f32 / cmr_linear_wgrad_f32 / cmr_linear_f32.
-extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
-                                     const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
-                                     int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
-                                     const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
-                                     int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db,
-                                     int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes, hipStream_t stream) {
+static int blb_entry(bool bf16, const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
+                     const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
+                     int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
+                     const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
+                     int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db,
+                     int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(dz && x && w && dw && ws && rows > 0 && n > 0 && k > 0);
   if (!blb_shape_ok(rows, n, k) || (xstat && n != 64)) return CMR_EUNSUPPORTED;
   if (seg_db && (seg_rows < 128 || seg_rows % 32 || rows % seg_rows)) return CMR_EUNSUPPORTED;
@@ -700,8 +1254,9 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   if (dx) CMR_REQUIRE(lddx % 4 == 0 && cmr_aligned16(dx) && lddx >= k);
   if (res) CMR_REQUIRE(dx && ldres % 4 == 0 && cmr_aligned16(res) && ldres >= k);
   if (xl) CMR_REQUIRE(dx && xcoef && cmr_aligned16(xstat));
-  int groups = blb_groups(rows, n, k);
-  const int R = blb_rows_per_block(rows, n);
+  if (xl && bf16) CMR_REQUIRE(xslope >= 0.f && ldx % 4 == 0);
+  int groups = bf16 ? blh_groups(rows) : blb_groups(rows, n, k);
+  const int R = bf16 ? BLH_R : blb_rows_per_block(rows, n);
   int64_t seg_blocks = rows / R;
   int seg_groups = groups;
   if (seg_db) {                                  // per-segment column sums: a whole number of workgroups per segment, >= 4 blocks each
@@ -722,7 +1277,12 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   const BlbArgs a{dz, lddz, no_act ? dz : z, no_act ? lddz : ldz, no_act ? 1.f : slope, h, ldh, stat, coef, dzm, lddzm, x, ldx, w, ldw, res, ldres,
                   dx, lddx, (float*)ws, part_b, rows, xstat, xslope, xpart, seg_blocks, seg_groups};
   int rc;
-  if (n == 64 && k == 64) rc = blb_dispatch<2, 2>(a, bn, zh, xl, groups, stream);
+  if (bf16) {
+    if (n == 64 && k == 64) rc = blh_dispatch<2, 2>(a, bn, zh, xl, groups, stream);
+    else if (n == 64 && k == 128) rc = blh_dispatch<2, 4>(a, bn, zh, xl, groups, stream);
+    else if (n == 128 && k == 64) rc = blh_dispatch<4, 2>(a, bn, zh, xl, groups, stream);
+    else rc = blh_dispatch<4, 4>(a, bn, zh, xl, groups, stream);
+  } else if (n == 64 && k == 64) rc = blb_dispatch<2, 2>(a, bn, zh, xl, groups, stream);
   else if (n == 64 && k == 128) rc = blb_dispatch<2, 4>(a, bn, zh, xl, groups, stream);
   else if (n == 128 && k == 64) rc = blb_dispatch<4, 2>(a, bn, zh, xl, groups, stream);
   else rc = blb_dispatch<4, 4>(a, bn, zh, xl, groups, stream);
@@ -737,6 +1297,34 @@ extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float*
   return cmr_launch_status();
 }
 
+extern "C" int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
+                                     const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
+                                     int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
+                                     const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
+                                     int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db,
+                                     int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return blb_entry(false, dz, lddz, z, ldz, slope, h, ldh, stat, coef, mask_from_h, dzm, lddzm, x, ldx, xstat, xslope, xcoef, xdgamma, xdbeta, w, ldw,
+                   res, ldres, dx, lddx, rows, n, k, dw, lddw, accumulate, db, accumulate_db, seg_rows, seg_db, ws, ws_bytes, stream);
+}
+
+// The same layer backward with the two products (dW = dh^T x', dx = dh W) on the bf16 matrix cores, fp32 accumulate: operands rounded to
+// bf16 (RNE) on the way into LDS, everything else (masks, BatchNorm-backward arithmetic, column / segment sums, the lazy operand's sums,
+// partial sums and their reduction) as cmr_bn_linear_bwd_f32.  Same arguments, shapes and return codes.
+extern "C" int64_t cmr_bn_linear_bwd_bf16_workspace_bytes(int64_t rows, int n, int k) {
+  if (!blb_shape_ok(rows, n, k)) return 0;
+  return (int64_t)(blh_groups(rows) + 256) * ((int64_t)n * k + 2 * k + n) * (int64_t)sizeof(float);
+}
+
+extern "C" int cmr_bn_linear_bwd_bf16_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
+                                          const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x,
+                                          int64_t ldx, const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta,
+                                          const float* w, int64_t ldw, const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows,
+                                          int n, int k, float* dw, int64_t lddw, int accumulate, float* db, int accumulate_db,
+                                          int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return blb_entry(true, dz, lddz, z, ldz, slope, h, ldh, stat, coef, mask_from_h, dzm, lddzm, x, ldx, xstat, xslope, xcoef, xdgamma, xdbeta, w, ldw,
+                   res, ldres, dx, lddx, rows, n, k, dw, lddw, accumulate, db, accumulate_db, seg_rows, seg_db, ws, ws_bytes, stream);
+}
+
 extern "C" int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int n, int k) {
   if (!(k == 64 || k == 128) || !(n == 64 || n == 128) || rows < 32 || rows % 32) return 0;
   return (int64_t)(blf_groups(rows, n, k) + 256) * 3 * n * (int64_t)sizeof(float);
@@ -747,10 +1335,10 @@ extern "C" int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int n, int k)
 // (running statistics updated when given).  bias_seg_rows > 0: bias is [rows / bias_seg_rows][n] (row stride bias_stride), one row per
 // segment of bias_seg_rows rows -- a per-SAMPLE vector, e.g. the broadcast half of cat([feat, max]) times its weights (CMRAgent.py:95-99).
 // Serves n, k in {64, 128}, rows a multiple of 32; else CMR_EUNSUPPORTED.
-extern "C" int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
-                                     const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n,
-                                     float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
-                                     float* running_var, float* stat, void* ws, int64_t ws_bytes, hipStream_t stream) {
+static int blf_entry(bool bf16, const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
+                     const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n,
+                     float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float* stat, void* ws, int64_t ws_bytes, hipStream_t stream) {
   CMR_REQUIRE(x && w && h && stat && ws && rows > 0 && k > 0 && n > 0);
   if (!(k == 64 || k == 128) || !(n == 64 || n == 128) || rows < 32 || rows % 32) return CMR_EUNSUPPORTED;
   if (bias_seg_rows > 0 && (bias_seg_rows < 128 || bias_seg_rows % 32 || rows % bias_seg_rows)) return CMR_EUNSUPPORTED;
@@ -758,6 +1346,25 @@ extern "C" int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const f
   CMR_REQUIRE((!bias || cmr_aligned16(bias)) && (!pro_stat || cmr_aligned16(pro_stat)));
   CMR_REQUIRE(bias_seg_rows <= 0 || (bias && bias_stride >= n && bias_stride % 4 == 0));
   CMR_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+  if (bf16) {
+    CMR_REQUIRE(ldw % 4 == 0 && cmr_aligned16(w));
+    const int groups = blg_groups(rows);
+    CMR_REQUIRE(ws_bytes >= (int64_t)groups * 4 * 4 * n * (int64_t)sizeof(float));
+    const BlfArgs a{x, ldx, pro_stat, pro_slope, w, ldw, bias, bias_seg_rows > 0 ? bias_stride : 0, h, ldh, (float*)ws, rows,
+                    bias_seg_rows > 0 ? bias_seg_rows / 32 : rows / 32, groups};
+    const dim3 grid((unsigned)groups, (unsigned)(n / 64));
+    const size_t smem = (size_t)2 * (k / 16) * 1024 + (size_t)(2 * k + 512) * sizeof(float);
+    if (k == 64) {
+      if (pro_stat) hipLaunchKernelGGL((bn_linear_fwd_bf16_kernel<4, true>), grid, dim3(256), smem, stream, a, n);
+      else hipLaunchKernelGGL((bn_linear_fwd_bf16_kernel<4, false>), grid, dim3(256), smem, stream, a, n);
+    } else {
+      if (pro_stat) hipLaunchKernelGGL((bn_linear_fwd_bf16_kernel<8, true>), grid, dim3(256), smem, stream, a, n);
+      else hipLaunchKernelGGL((bn_linear_fwd_bf16_kernel<8, false>), grid, dim3(256), smem, stream, a, n);
+    }
+    hipLaunchKernelGGL(bn_stats_merge_cnt_kernel, dim3(n), dim3(256), 0, stream, (const float*)ws, groups * 4, rows, n, eps, momentum, gamma, beta,
+                       running_mean, running_var, stat);
+    return cmr_launch_status();
+  }
   int groups = blf_groups(rows, n, k);
   int64_t seg_blocks = rows / 32;
   int seg_groups = groups;
@@ -785,4 +1392,27 @@ extern "C" int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const f
   hipLaunchKernelGGL(bn_stats_merge_kernel, dim3(n), dim3(64), 0, stream, (const float*)ws, groups, seg_groups, seg_blocks, rows, n, eps, momentum,
                      gamma, beta, running_mean, running_var, stat);
   return cmr_launch_status();
+}
+
+extern "C" int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
+                                     const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n,
+                                     float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float* stat, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return blf_entry(false, x, ldx, k, pro_stat, pro_slope, w, ldw, bias, bias_seg_rows, bias_stride, h, ldh, rows, n, eps, momentum, gamma, beta,
+                   running_mean, running_var, stat, ws, ws_bytes, stream);
+}
+
+// The same layer forward with its product on the bf16 matrix cores (fp32 accumulate; x' and W rounded to bf16, round-to-nearest-even): h,
+// the statistics of that h and the running statistics as cmr_linear_bn_fwd_f32 leaves them.  Same arguments and shapes; own workspace size.
+extern "C" int64_t cmr_linear_bn_fwd_bf16_workspace_bytes(int64_t rows, int n, int k) {
+  if (!(k == 64 || k == 128) || !(n == 64 || n == 128) || rows < 32 || rows % 32) return 0;
+  return (int64_t)blg_groups(rows) * 4 * 4 * n * (int64_t)sizeof(float);
+}
+
+extern "C" int cmr_linear_bn_fwd_bf16_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
+                                          const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows,
+                                          int n, float eps, float momentum, const float* gamma, const float* beta, float* running_mean,
+                                          float* running_var, float* stat, void* ws, int64_t ws_bytes, hipStream_t stream) {
+  return blf_entry(true, x, ldx, k, pro_stat, pro_slope, w, ldw, bias, bias_seg_rows, bias_stride, h, ldh, rows, n, eps, momentum, gamma, beta,
+                   running_mean, running_var, stat, ws, ws_bytes, stream);
 }

@@ -39,6 +39,17 @@ def _i32(t):
 
 LINEAR_BF16 = os.environ.get("CMR_LINEAR_BF16", "1") != "0"            # with CONV_BF16: contiguous row maps of at least LINEAR_BF16_MIN_ROWS rows through cmr_linear_rows_bf16_f32
 LINEAR_BF16_MIN_ROWS = 16384
+# with CONV_BF16: the train-mode [linear + BatchNorm] layers on the big row maps (cmr_linear_bn_fwd_f32 / cmr_bn_linear_bwd_f32) CAN take their
+# products on the bf16 matrix cores too (cmr_linear_bn_fwd_bf16_f32 / cmr_bn_linear_bwd_bf16_f32; fp32 maps, statistics and accumulation;
+# independent of fp32_linears(), which keeps the plain row GEMMs of the training updates in fp32).  Both are OFF in the product, by measurement
+# (round 6):
+#   forward  -- not faster than the fp32 kernel (both stream at ~2.5 TB/s alone, profiles/r06_bn_linear_bf16_bench.txt) and its logit shift
+#               moves the 2-D tower's weakest gradient cosine from 0.976 to 0.969, under the 0.97 bar of tests/test_train_gpu.py;
+#   backward -- 1.2 - 1.6 x faster alone (65 / 43 us against 102 / 52 us), -0.1 ms of the 3.4 ms update, gradients at cosine 0.99999 with
+#               the fp32 ones (profiles/r06_bnl_grad_cosines.txt) -- but the 40-update trajectory test ends at a total loss of 0.216 against
+#               the fp32 run's 0.192 (bar: 5 %; fp32-equivalent summation orders spread that final loss by +- 2 %): the bar decides.
+BN_LINEAR_BF16_FWD = os.environ.get("CMR_BN_LINEAR_BF16_FWD", "0") != "0"
+BN_LINEAR_BF16_BWD = os.environ.get("CMR_BN_LINEAR_BF16_BWD", "0") != "0"
 
 
 class fp32_linears:
@@ -932,9 +943,10 @@ def linear_bn_fwd(x, w, bias, gamma, beta, running_mean=None, running_var=None, 
         raise ValueError("linear_bn_fwd: prologue statistics %s for an input of width %d" % (tuple(pro.shape), k))
     h = torch.empty((rows, n), dtype=f32, device=x.device)
     stat = torch.empty((4, n), dtype=f32, device=x.device)
-    nb = _lib.load().cmr_linear_bn_fwd_workspace_bytes(rows, n, k)
+    bf = bool(CONV_BF16 and BN_LINEAR_BF16_FWD and w.stride(0) % 4 == 0 and w.data_ptr() % 16 == 0)
+    nb = getattr(_lib.load(), "cmr_linear_bn_fwd_bf16_workspace_bytes" if bf else "cmr_linear_bn_fwd_workspace_bytes")(rows, n, k)
     ws = _ws(nb, x.device)
-    _lib.call("cmr_linear_bn_fwd_f32", _p(x), _ld(x), k, _p(pro), float(pro_slope), _p(w), w.stride(0), _p(bias), int(bias_seg_rows),
+    _lib.call("cmr_linear_bn_fwd_bf16_f32" if bf else "cmr_linear_bn_fwd_f32", _p(x), _ld(x), k, _p(pro), float(pro_slope), _p(w), w.stride(0), _p(bias), int(bias_seg_rows),
               bias.stride(0) if bias_seg_rows else 0, _p(h), n, rows, n, float(eps), float(momentum), _p(gamma), _p(beta), _p(running_mean),
               _p(running_var), _p(stat), _p(ws), nb, _stream())
     return h, stat
@@ -986,10 +998,11 @@ def bn_linear_bwd(dz, z, slope, h, stat, coef, x, w, dw, accumulate_dw=False, re
     if seg_rows and (seg_rows < 128 or seg_rows % 32 or rows % seg_rows):
         return False
     seg_db = torch.empty((rows // seg_rows, n), dtype=f32, device=x.device) if seg_rows else None
-    nb = _lib.load().cmr_bn_linear_bwd_workspace_bytes(rows, n, k)
+    bf = bool(CONV_BF16 and BN_LINEAR_BF16_BWD)
+    nb = getattr(_lib.load(), "cmr_bn_linear_bwd_bf16_workspace_bytes" if bf else "cmr_bn_linear_bwd_workspace_bytes")(rows, n, k)
     ws = _ws(nb, x.device)
     zz = None if mask_from_h else z
-    _lib.call("cmr_bn_linear_bwd_f32", _p(dz), _ld(dz), _p(zz), _ld(zz) if zz is not None else 0, float(slope), _p(h), _ld(h) if h is not None else 0,
+    _lib.call("cmr_bn_linear_bwd_bf16_f32" if bf else "cmr_bn_linear_bwd_f32", _p(dz), _ld(dz), _p(zz), _ld(zz) if zz is not None else 0, float(slope), _p(h), _ld(h) if h is not None else 0,
               _p(stat), _p(coef), int(bool(mask_from_h)), _p(dzm), n if want_masked else 0, _p(x), _ld(x), _p(xstat), float(xslope), _p(xcoef),
               _p(xdgamma), _p(xdbeta), _p(w), w.stride(0), _p(res), _ld(res) if res is not None else 0,
               _p(dx) if want_dx else None, _ld(dx) if want_dx else 0, rows, n, k, _p(dw), dw.stride(0), int(accumulate_dw), _p(db),

@@ -11,6 +11,7 @@ import torch
 from .environment import environment as env
 
 INPUT_KEYS = ("img", "pc", "node", "pt2node", "K", "P")
+SEGMENTED_GRAPH = __import__("os").environ.get("CMR_SEGMENTED_GRAPH_REG", "0") == "1"
 
 
 class RegistrationGraph:
@@ -25,8 +26,15 @@ class RegistrationGraph:
                 self._iteration()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.static_pose, self.static_data = self._iteration()
+        if SEGMENTED_GRAPH:
+            # a program of single-chain graphs on several streams instead of one graph that holds every branch (utils/seggraph.py)
+            from .utils.seggraph import SegmentedGraph
+            self.graph = SegmentedGraph()
+            with torch.no_grad():
+                self.static_pose, self.static_data = self.graph.capture(self._iteration)
+        else:
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.static_pose, self.static_data = self._iteration()
 
     def _iteration(self):
         data = dict(self.static_in)

@@ -14,11 +14,13 @@ streaming kernels of csrc/train.hip.  There is no CPU path."""
 import torch
 
 from .. import ops
-from ..utils.streams import fork_join
+from ..utils.streams import _exhaust, fork_join_interleaved
 from ..models.ImageResNet import to_nhwc
 from .flatbucket import FlatBucket
 from .fragpack import ConvPack
 from .optim import FlatOptimizer
+
+SEGMENTED_GRAPH = __import__("os").environ.get("CMR_SEGMENTED_GRAPH", "0") == "1"      # enable_graph: utils/seggraph.py instead of one multi-branch hipGraph
 
 SLOPE2D = 0.01     # nn.LeakyReLU() default in state_2d_embed and the heads (CMRAgent.py:36)
 SLOPE3D = 0.2      # ConvBNReLURes1D (PointNN.py:267)
@@ -117,7 +119,7 @@ class AgentUpdate:
         cp = self._packed_convs()
         # The two towers are independent until the heads: the 3-D branch (HBM-bound row passes over the B N points) runs on a side stream
         # underneath the 2-D branch (3x3 convolutions on 40 x 128 maps that leave most CUs idle), forward and backward
-        (L3, e3d), _ = self._fork(lambda: self._forward_3d(s3, B, N), lambda: self._forward_2d(T, s2, B, cp))
+        (L3, e3d), _ = self._fork(lambda: self._forward_3d(s3, B, N), lambda: self._forward_2d(T, s2, B, cp))      # (generators: issued interleaved)
         T["L3"] = L3
         T["e3d"] = e3d
         bk = self.bucket
@@ -135,15 +137,19 @@ class AgentUpdate:
     FORK_BRANCHES = __import__("os").environ.get("CMR_AGENT_UPDATE_FORK", "1") == "1"
 
     def _fork(self, side, main):
+        """side / main: functions returning the branch GENERATORS (first yield = their number of launch groups, then one yield per group):
+        the two towers are issued alternately on two streams (utils/streams.py:fork_join_interleaved), so that the replayed graph feeds both
+        queues from the fork on instead of one branch after the other."""
         if self.FORK_BRANCHES:
-            return fork_join(side, main, tag="agent_update")
-        return side(), main()
+            return fork_join_interleaved(side, main, tag="agent_update")
+        return _exhaust(side()), _exhaust(main())
 
     def _forward_2d(self, T, s2, B, cp):
         bk, ag = self.bucket, self.agent
         e = ag.state_2d_embed
         c = 2 * self.f
         # ---- 2-D branch: 4 x [conv3x3 + BN + LReLU, conv3x3 + LReLU, pool]
+        yield 4 * 3 + 1                                            # (launch groups that follow)
         x = s2
         T["stages"] = []
         for s in range(4):
@@ -155,6 +161,7 @@ class AgentUpdate:
             Bq, H, W, _ = a.shape
             ar = a.view(-1, c)
             stat = self._bn(ar, e[ia + 1], "state_2d_embed.%d" % (ia + 1))
+            yield
             # bf16 mode, big maps: BatchNorm + LeakyReLU applied in conv b's own staging pass (and in its weight gradient's) -- the activated
             # map is never written; bit-identical to the two-pass form (cmr_conv3x3_bf16_pro_nhwc_f32)
             d = ops.conv3x3_bn_pro(a, stat[2], stat[3], SLOPE2D, bk.w(nb + ".bias"), c, SLOPE2D, ub) if self.LAZY_2D else None
@@ -163,6 +170,7 @@ class AgentUpdate:
                 z = ops.affine_act(ar, stat[2], stat[3], slope=SLOPE2D).view(Bq, H, W, c)
                 d = ops.conv3x3(z, w9b, bk.w(nb + ".bias"), c, 1, SLOPE2D, u=ub)
             T["stages"].append(dict(xin=x, a=a, z=z, d=d, stat=stat, na=na, nb=nb, nbn="state_2d_embed.%d" % (ia + 1), H=H, W=W))
+            yield
             if s < 3:
                 x = ops.avgpool(d, 2, 2)
             else:
@@ -170,6 +178,7 @@ class AgentUpdate:
                 if (H, W) != (kh, kw):
                     raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (H, W, kh, kw))
                 pooled = ops.colmean(d.view(-1, c), B, H * W)                                        # AvgPool2d((H, W))
+            yield
         T["pooled"] = pooled
         T["t1"] = ops.linear(pooled, bk.w("state_2d_embed.24.weight"), bk.w("state_2d_embed.24.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
         T["e2d"] = ops.linear(T["t1"], bk.w("state_2d_embed.26.weight"), bk.w("state_2d_embed.26.bias"))
@@ -180,6 +189,7 @@ class AgentUpdate:
         # in front of a GEMM: it is the second source x2[r / N])
         L3 = []
         feat, g = s3, None
+        yield 4 * len(self.dims3d)                                 # (launch groups that follow)
         for i, (cin, cout) in enumerate(self.dims3d):
             p = "state_3d_embed.%d." % i
             m = ag.state_3d_embed[i]
@@ -188,6 +198,7 @@ class AgentUpdate:
             # (fused: the GEMM and the BatchNorm statistics of its output in one pass; the broadcast half of the input, cat([feat, max]),
             # enters as a per-sample bias max W[:, f:]^T + b computed by a skinny GEMM)
             h1raw, st1 = self._linear_bn(feat, p + "net.0", m.net[1], p + "net.1", g if fused else None, N, src)
+            yield
             # lazy: net[3] takes lrelu(BN(h1raw)) through its own staging pass (cmr_linear_bn_fwd_f32's prologue) and its backward through
             # cmr_bn_linear_bwd_f32's lazy operand -- h1 is never written (the cmr_affine_act_f32 pass and, in the backward, net[1]'s
             # cmr_bn_bwd_coef_f32 pass over the map go away); shapes: what the lazy operand serves (64 outputs)
@@ -205,6 +216,7 @@ class AgentUpdate:
                 h1 = ops.affine_act(h1raw, st1[2], st1[3], slope=SLOPE3D)
                 h2raw, st2 = self._linear_bn(h1, p + "net.3", m.net[4], p + "net.4", None, N, {}, fused)
             rec = dict(x=feat, g=g, h1raw=h1raw, st1=st1, h1=h1, h2raw=h2raw, st2=st2, cin=cin, cout=cout, p=p, lazy=lazy)
+            yield
             if cin != cout:
                 scraw, stsc = self._linear_bn(feat, p + "shortcut.0", m.shortcut[1], p + "shortcut.1", g if fused else None, N, src)
                 out = ops.affine_act(h2raw, st2[2], st2[3], res=scraw, rscale=stsc[2], rshift=stsc[3], slope=SLOPE3D)
@@ -212,10 +224,12 @@ class AgentUpdate:
             else:
                 xcat = ops.concat_rows(feat, g, None, N)                                           # identity shortcut on cat([feat, max])
                 out = ops.affine_act(h2raw, st2[2], st2[3], res=xcat, slope=SLOPE3D)
+            yield
             gmax, arg = ops.colmax_arg(out, B, N)
             rec.update(out=out, gmax=gmax, arg=arg)
             L3.append(rec)
             feat, g = out, gmax
+            yield
         return L3, g
 
     # --------------------------------------------------------------------------------------------------------- backward
@@ -265,17 +279,19 @@ class AgentUpdate:
             self._lin_small_bwd(name + ".4", h2, d_outs[i], dx1=dh2)
             self._lin_small_bwd(name + ".2", h1, dh2, y=h2, dx1=dh1)
             self._lin_small_bwd(name + ".0", T["e2d"], dh1, y=h1, x2=T["e3d"], dx1=de2d, dx2=de3d, acc=i > 0)
-        self._fork(lambda: self._backward_3d(T, de3d, B, N), lambda: self._backward_2d(T, de2d, B))
+        self._fork(lambda: self._backward_3d(T, de3d, B, N), lambda: self._backward_2d(T, de2d, B))      # (generators: issued interleaved)
 
     def _backward_2d(self, T, de2d, B):
         bk = self.bucket
         c = 2 * self.f
         # ---- 2-D tail and tower
+        yield 1 + 4 * 4                                            # (launch groups that follow)
         dt1 = torch.empty_like(T["t1"])
         dpooled = torch.empty_like(T["pooled"])
         self._lin_small_bwd("state_2d_embed.26", T["t1"], de2d, dx1=dt1)
         self._lin_small_bwd("state_2d_embed.24", T["pooled"], dt1, y=T["t1"], dx1=dpooled)
         g = dpooled
+        yield
         for s in (3, 2, 1, 0):
             st = T["stages"][s]
             H, W = st["H"], st["W"]
@@ -288,12 +304,16 @@ class AgentUpdate:
                     z = ops.affine_act(st["a"].view(-1, c), st["stat"][2], st["stat"][3], slope=SLOPE2D).view(st["a"].shape)
             if z is not None:
                 ops.conv3x3_wgrad(z, dc, bk.g(st["nb"] + ".weight"), db=bk.g(st["nb"] + ".bias"))
+            yield
             dz = self._dgrad(dc, st["nb"], c, 2 * s)
             # (activation mask from the sign of the BatchNorm output, recomputed from `a`: the stored z is not read again)
             da = self._bn_bwd(dz.view(-1, c), None, SLOPE2D, st["a"].view(-1, c), st["stat"], st["nbn"]).view(B, H, W, c)
+            yield
             ops.conv3x3_wgrad(st["xin"], da, bk.g(st["na"] + ".weight"), db=bk.g(st["na"] + ".bias"))
+            yield
             if s > 0:
                 g = self._dgrad(da, st["na"], c, 2 * s - 1)
+            yield
 
     def _backward_3d(self, T, de3d, B, N):
         bk = self.bucket
@@ -303,6 +323,7 @@ class AgentUpdate:
         R = B * N
         dg = de3d                                                   # gradient w.r.t. the per-sample max of the current block
         dfeat = None                                                # gradient w.r.t. the block output rows from the NEXT block
+        yield 4 * len(T["L3"])                                      # (launch groups that follow: four per block)
         for i in (3, 2, 1, 0):
             r = T["L3"][i]
             p, cin, cout = r["p"], r["cin"], r["cout"]
@@ -310,21 +331,25 @@ class AgentUpdate:
                 dfeat = torch.zeros((R, cout), dtype=torch.float32, device=dev)
             ops.add_at_arg(dfeat, r["arg"], dg, B, N)                                         # backward of torch.max(dim=2)
             if i > 0 and self._fused3d_bwd_ok(r, R, N):
-                dfeat, dg = self._block3d_bwd_fused(r, dfeat, B, N)
+                dfeat, dg = yield from self._block3d_bwd_fused(r, dfeat, B, N)
                 continue
             dsum = ops.act_bwd(dfeat, r["out"], SLOPE3D)                                      # final LeakyReLU
             dh2raw = self._bn_bwd(dsum, None, 1.0, r["h2raw"], r["st2"], p + "net.4")
+            yield
             gw2 = bk.g(p + "net.3.weight")
             h1 = r["h1"] if r["h1"] is not None else ops.affine_act(r["h1raw"], r["st1"][2], r["st1"][3], slope=SLOPE3D)   # (lazy forward)
             ops.linear_wgrad(dh2raw, h1, gw2, gw2.shape[1], db=bk.g(p + "net.3.bias"))            # bias gradient = column sums of dh2raw, same launch
             dh1 = ops.linear(dh2raw, self._wT(p + "net.3.weight"))
+            yield
             dh1raw = self._bn_bwd(dh1, None, SLOPE3D, r["h1raw"], r["st1"], p + "net.1")
+            yield
             w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
             if i == 0:
                 ops.linear_wgrad(dh1raw, r["x"], gw1, gw1.shape[1], db=bk.g(p + "net.0.bias"))
                 dsc = self._bn_bwd(dsum, None, 1.0, r["scraw"], r["stsc"], p + "shortcut.1")
                 gws = bk.g(p + "shortcut.0.weight")
                 ops.linear_wgrad(dsc, r["x"], gws, gws.shape[1], db=bk.g(p + "shortcut.0.bias"))
+                yield
                 break
             # input of this block = cat([feat_prev (f), broadcast max_prev (f)]): streamed half -> row GEMMs, broadcast half ->
             # per-sample column sums through the small-rows kernel
@@ -351,6 +376,7 @@ class AgentUpdate:
                 # identity shortcut: the streamed half of d cat = dsum goes to the rows as the residual of the GEMM
                 dprev = ops.linear(dh1raw, w1t[:f], res=dsum[:, :f])
             dfeat, dg = dprev, dgprev
+            yield
 
     FUSED_3D = __import__("os").environ.get("CMR_AGENT_FUSED_3D", "1") == "1"
     LAZY_3D = __import__("os").environ.get("CMR_AGENT_LAZY_3D", "1") == "1"
@@ -378,6 +404,7 @@ class AgentUpdate:
         # net[3] + BatchNorm + the block's final LeakyReLU: dsum = the gradient at the sum (what the shortcut receives)
         w2, gw2 = bk.w(p + "net.3.weight"), bk.g(p + "net.3.weight")
         coef2 = ops.bn_bwd_coef(dfeat, r["out"], SLOPE3D, r["h2raw"], r["st2"], bk.g(p + "net.4.weight"), bk.g(p + "net.4.bias"))
+        yield
         w1, gw1 = bk.w(p + "net.0.weight"), bk.g(p + "net.0.weight")
         if r["lazy"]:
             # h1 was never stored: the pass recomputes it from h1raw for the weight gradient and returns net[1]'s BatchNorm-backward
@@ -391,6 +418,7 @@ class AgentUpdate:
             # net[0] + BatchNorm + LeakyReLU: streamed half of the input in the pass, broadcast half from the per-sample column sums
             # (h1 = lrelu(BN(h1raw)) without a residual: both passes take the mask from the sign of the BatchNorm output, h1 is not read again)
             coef1 = ops.bn_bwd_coef(dh1, None, SLOPE3D, r["h1raw"], r["st1"], bk.g(p + "net.1.weight"), bk.g(p + "net.1.bias"))
+        yield
         dprev, _, cs1 = ops.bn_linear_bwd(dh1, None, SLOPE3D, r["h1raw"], r["st1"], coef1, fprev, w1[:, :f], gw1[:, :f],
                                           res=dsum[:, :f] if ident else None, seg_rows=N, mask_from_h=True)
         dgprev = torch.empty((B, f), dtype=torch.float32, device=dev)
@@ -398,6 +426,7 @@ class AgentUpdate:
             ops.colsum(dsum[:, f:], B, N, out=dgprev)
         ops.linear_bwd_small(gprev, cs1, w1[:, f:], w1.shape[1], w1.shape[0], dw=gw1[:, f:], lddw=gw1.shape[1],
                              db=bk.g(p + "net.0.bias"), dx1=dgprev, acc_dx=ident)
+        yield
         if not ident:
             ws, gws = bk.w(p + "shortcut.0.weight"), bk.g(p + "shortcut.0.weight")
             coefs = ops.bn_bwd_coef(dsum, None, 1.0, r["scraw"], r["stsc"], bk.g(p + "shortcut.1.weight"), bk.g(p + "shortcut.1.bias"))
@@ -405,6 +434,7 @@ class AgentUpdate:
                                               seg_rows=N)
             ops.linear_bwd_small(gprev, cs2, ws[:, f:], ws.shape[1], ws.shape[0], dw=gws[:, f:], lddw=gws.shape[1],
                                  db=bk.g(p + "shortcut.0.bias"), dx1=dgprev, acc_dx=True)
+        yield
         return dprev, dgprev
 
     # ------------------------------------------------------------------------------------------------------------- API
@@ -489,9 +519,16 @@ class AgentUpdate:
                 self.forward_backward(self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            self._static_losses, _ = self.forward_backward(self._static)
+        if SEGMENTED_GRAPH:
+            # a program of single-chain graphs on two streams: the two towers really run side by side (utils/seggraph.py -- a graph that
+            # holds both branches is replayed one branch after the other on this runtime)
+            from ..utils.seggraph import SegmentedGraph
+            graph = SegmentedGraph()
+            self._static_losses, _ = graph.capture(lambda: self.forward_backward(self._static))
+        else:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._static_losses, _ = self.forward_backward(self._static)
         with torch.no_grad():
             for n, b in self.agent.named_buffers():
                 b.copy_(saved[n])

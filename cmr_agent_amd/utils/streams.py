@@ -72,6 +72,25 @@ def issues_main_first(tag):
     return ENABLED and torch.cuda.is_available() and not (_ONLY and tag not in _ONLY) and _sequential == 0 and _main_first(tag)
 
 
+def _segmented():
+    """the SegmentedGraph capture in progress (utils/seggraph.py), or None"""
+    from . import seggraph
+    return seggraph.active()
+
+
+def _segmented_fork(sg, fns, tag):
+    """a fork under a segmented capture: the capture is cut here, every branch is captured as its own single-chain graph(s) on its own
+    stream -- at any nesting depth, from any branch"""
+    global _depth
+    main = torch.cuda.current_stream()
+    sides = [_side_stream(main, _depth, i) for i in range(len(fns) - 1)]
+    _depth += 1
+    try:
+        return sg.fork(fns, sides, main_first=_main_first(tag))
+    finally:
+        _depth -= 1
+
+
 def fork_join(*fns, tag=""):
     """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn (the MAIN branch) on the current stream and returns all
     results (in argument order) after joining.  Sequential on CPU / when disabled / inside sequential_forks().
@@ -84,6 +103,9 @@ def fork_join(*fns, tag=""):
     global _depth, _in_side
     if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY) or _sequential > 0:
         return tuple(f() for f in fns)
+    sg = _segmented()
+    if sg is not None:
+        return _segmented_fork(sg, fns, tag)
     if _in_side and torch.cuda.is_current_stream_capturing():
         raise NestedForkInCapture("fork_join(tag=%r) issued from a side branch of another fork during hipGraph capture: this runtime cannot "
                                   "capture an edge between two non-origin streams (DESIGN.md 6b); wrap the side branch in "
@@ -123,3 +145,80 @@ def fork_join(*fns, tag=""):
     for s in sides:
         main.wait_stream(s)
     return tuple(out)
+
+
+def _exhaust(gen):
+    """run a branch generator to its end on the current stream -> its return value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as e:
+        return e.value
+
+
+INTERLEAVE = os.environ.get("CMR_STREAMS_INTERLEAVE", "1") != "0"
+
+
+def fork_join_interleaved(side_fn, main_fn, tag=""):
+    """fork_join for two branches written as GENERATORS: the first `yield` hands back the number of yields that follow (the branch's plan,
+    no launch yet), every later `yield` ends a group of launches.  The branches are issued ALTERNATELY -- always the one that is behind in
+    its own plan -- each on its own stream (side_fn on a side stream, main_fn on the current one) -> (side result, main result).
+
+    Why: a replayed hipGraph hands its nodes to the device in the order they were captured, at a few microseconds per node from the host.
+    Captured branch after branch (fork_join above), the second branch's first kernel reaches its queue only after ALL of the first
+    branch's nodes: in the agent update the 3-D tower started 0.45 ms after the fork and the device held exactly one kernel for 70 % of
+    the step (profiles/r06_train_timeline_before.txt).  Captured interleaved, both queues are fed from the start.  Same kernels, same
+    operands, same order within each branch: results are bit-identical to the sequential issue.
+    Sequential (side, then main) on CPU / when streams are disabled / inside sequential_forks()."""
+    global _depth, _in_side
+    if not ENABLED or not torch.cuda.is_available() or (_ONLY and tag not in _ONLY) or _sequential > 0:
+        return _exhaust(side_fn()), _exhaust(main_fn())
+    sg = _segmented()
+    if sg is not None:          # segmented capture: every branch becomes its own chain of graphs (nothing to interleave)
+        return _segmented_fork(sg, (lambda: _exhaust(side_fn()), lambda: _exhaust(main_fn())), tag)
+    if _in_side and torch.cuda.is_current_stream_capturing():
+        raise NestedForkInCapture("fork_join_interleaved(tag=%r) issued from a side branch of another fork during hipGraph capture (DESIGN.md 6b)" % tag)
+    main = torch.cuda.current_stream()
+    side = _side_stream(main, _depth, 0)
+    if side == main:
+        raise RuntimeError("fork_join_interleaved: the side stream equals the current stream")
+    side.wait_stream(main)
+    _depth += 1
+    was_side = _in_side
+    try:
+        gs, gm = side_fn(), main_fn()
+        if not INTERLEAVE:                      # A/B: branch after branch, main first (what fork_join does)
+            rm = _exhaust(gm)
+            _in_side = True
+            try:
+                with torch.cuda.stream(side):
+                    rs = _exhaust(gs)
+            finally:
+                _in_side = was_side
+        else:
+            ts, tm = max(int(next(gs)), 1), max(int(next(gm)), 1)
+            ds = dm = 0
+            rs = rm = None
+            live_s = live_m = True
+            while live_s or live_m:
+                if live_s and (not live_m or ds * tm <= dm * ts):          # the side branch is not ahead in its plan: its turn
+                    _in_side = True
+                    try:
+                        with torch.cuda.stream(side):
+                            try:
+                                next(gs)
+                                ds += 1
+                            except StopIteration as e:
+                                rs, live_s = e.value, False
+                    finally:
+                        _in_side = was_side
+                else:
+                    try:
+                        next(gm)
+                        dm += 1
+                    except StopIteration as e:
+                        rm, live_m = e.value, False
+    finally:
+        _depth -= 1
+    main.wait_stream(side)
+    return rs, rm

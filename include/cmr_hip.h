@@ -514,6 +514,18 @@ int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t
                           const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows, int n, int k, float* dw, int64_t lddw,
                           int accumulate, float* db, int accumulate_db, int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes,
                           hipStream_t stream);
+/* The same layer backward with its two products (dw = dh^T x', dx = dh W) on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate; operands rounded to bf16, round-to-nearest-even, on the way into LDS) for the bf16 mode of the agent update (BASELINE
+ * configs[2]; Train_Agent.py:296-305 through CMRAgent.py:25-33, 92-101).  Maps stay fp32 in HBM; masks, the BatchNorm-backward arithmetic,
+ * db / seg_db (sums of the UNROUNDED dh), the lazy operand's sums, partial sums and their reduction exactly as cmr_bn_linear_bwd_f32.
+ * Same arguments, shapes served and return codes; its own workspace size. */
+int64_t cmr_bn_linear_bwd_bf16_workspace_bytes(int64_t rows, int n, int k);
+int cmr_bn_linear_bwd_bf16_f32(const float* dz, int64_t lddz, const float* z, int64_t ldz, float slope, const float* h, int64_t ldh,
+                          const float* stat, const float* coef, int mask_from_h, float* dzm, int64_t lddzm, const float* x, int64_t ldx,
+                          const float* xstat, float xslope, float* xcoef, float* xdgamma, float* xdbeta, const float* w, int64_t ldw,
+                          const float* res, int64_t ldres, float* dx, int64_t lddx, int64_t rows, int n, int k, float* dw, int64_t lddw,
+                          int accumulate, float* db, int accumulate_db, int64_t seg_rows, float* seg_db, void* ws, int64_t ws_bytes,
+                          hipStream_t stream);
 /* Forward of the same layer with its statistics from the same pass: h [rows][n] = x' W^T + bias and stat [4][n] = the batch statistics
  * of h exactly as cmr_bn_stats_f32 defines them (mean, rstd, scale, shift; running statistics updated when given).  pro_stat non-null:
  * x' = lrelu_{pro_slope}(x * pro_stat[2 k ..] + pro_stat[3 k ..]) -- x is then the PREVIOUS layer's BatchNorm input and that layer's
@@ -523,6 +535,15 @@ int cmr_bn_linear_bwd_f32(const float* dz, int64_t lddz, const float* z, int64_t
  * cmr_linear_f32 + cmr_bn_stats_f32). */
 int64_t cmr_linear_bn_fwd_workspace_bytes(int64_t rows, int n, int k);
 int cmr_linear_bn_fwd_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
+                          const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n, float eps,
+                          float momentum, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
+                          void* ws, int64_t ws_bytes, hipStream_t stream);
+/* The same layer forward with its product on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate; x' and W rounded to bf16,
+ * round-to-nearest-even) for the bf16 mode of the agent update (BASELINE configs[2]; CMRAgent.py:25-33, 92-101 under Train_Agent.py:296-305):
+ * h stays fp32 in HBM, stat = the batch statistics of THAT h (per-wave pivoted sums merged in double), running statistics as
+ * cmr_linear_bn_fwd_f32 leaves them.  Same arguments and shapes served (+ w 16-byte aligned, ldw % 4 == 0); its own workspace size. */
+int64_t cmr_linear_bn_fwd_bf16_workspace_bytes(int64_t rows, int n, int k);
+int cmr_linear_bn_fwd_bf16_f32(const float* x, int64_t ldx, int k, const float* pro_stat, float pro_slope, const float* w, int64_t ldw,
                           const float* bias, int64_t bias_seg_rows, int64_t bias_stride, float* h, int64_t ldh, int64_t rows, int n, float eps,
                           float momentum, const float* gamma, const float* beta, float* running_mean, float* running_var, float* stat,
                           void* ws, int64_t ws_bytes, hipStream_t stream);
