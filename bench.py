@@ -767,8 +767,30 @@ def register_main(args, ctx, workload="c1", dtype=None, with_cpu=True, with_pipe
         if dtype == "bf16":
             # the bf16 convolution is HBM-class: 73.7 kFLOP per 512 B (64 -> 64) against a bf16 ridge of ~310 FLOP/B
             gbs = conv["bytes"] / (conv["ms"] * 1e-3) / 1e9
-            roofline = dict(kernel="conv3x3_bf16_tt_kernel / conv3x3_bf16_kernel (NHWC 3x3 direct: two-team stride-1 kernel, one-team stride-2 kernel; v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 activations in HBM)", bound="hbm",
-                            achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=None,
+            # HBM bytes per launch of the bf16 convolutions from the committed per-map PMC table of THIS workload (tools/_pmc_path_bf16.sh:
+            # FETCH_SIZE / WRITE_SIZE passes of one eager iteration joined launch by launch with the map each runs on), fresh by content hash
+            b16_traffic, b16_note, b16_maps = None, None, None
+            b16_src = _latest_profile("pmc_bf16_%s.json" % workload)
+            if b16_src is not None:
+                ok, why = profile_fresh(b16_src)
+                if ok:
+                    try:
+                        t = json.load(open(os.path.join(ROOT, b16_src)))
+                        if t["launches_per_iteration"] * args.steps == conv["launches"]:
+                            b16_traffic = t["hbm_bytes_per_launch"]
+                            b16_maps = [{k: m[k] for k in ("map", "cin", "cout", "stride", "pool", "launches", "us_alone", "frac_hbm", "frac_bf16_mfma",
+                                                           "traffic_over_algorithmic", "share_of_conv_time")} for m in t["maps"][:8]]
+                        else:
+                            b16_note = "profile holds %d launches per iteration, this run issued %g" % (t["launches_per_iteration"], conv["launches"] / args.steps)
+                    except Exception as e:          # noqa: BLE001
+                        b16_note = "unreadable: %s" % e
+                else:
+                    b16_note = "stale profile, not reported (%s)" % why
+            roofline = dict(kernel="conv3x3_bf16_tt_kernel / conv3x3_bf16_mm_kernel (NHWC 3x3 direct: two-team kernel for the 64-channel maps and stride 2, register-tiled matrix-class kernel for 128 -> 128; v_mfma_f32_32x32x16_bf16, fp32 accumulate)", bound="hbm",
+                            achieved=gbs, peak=8000.0, unit="GB/s", frac=gbs / 8000.0, traffic=b16_traffic,
+                            traffic_unit="HBM bytes per launch, mean over the iteration's bf16 convolution launches (rocprofv3 PMC, %s)" % b16_src,
+                            traffic_note=b16_note, traffic_source="committed profile (tools/_pmc_path_bf16.sh), fresh by content hash; not a counter read in this run",
+                            per_map=b16_maps,
                             mfma_tflops=achieved, mfma_frac_of_bf16_peak=achieved / 2500.0,
                             path_note="ideal times of `path`: entry points whose products run on the bf16 cores are priced at the bf16 "
                                       "matrix peak (2.5 PFLOP/s dense, ridge 312 FLOP/B -- most of them are HBM-class there), the rest at "
@@ -836,7 +858,7 @@ def compact(line):
     out = {k: line[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in line}
     out["workload"] = line["config"]["workload"]
     out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_algorithmic", "path", "path_step", "path_modelled_share_of_kernel_time", "traffic",
-                                         "traffic_unit", "traffic_source", "algorithmic_bytes_per_call", "algorithmic_bytes_per_launch",
+                                         "traffic_unit", "traffic_source", "traffic_note", "per_map", "algorithmic_bytes_per_call", "algorithmic_bytes_per_launch",
                                          "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
                                          "families_ms_per_step", "flop_per_byte") if k in r}
     for k in ("cpu_baseline", "launches_per_step", "launch_mode", "prologue_ms", "prologue", "prologue_overlap", "allreduce_ms_per_step", "rccl_ranks", "rccl_version",
