@@ -1133,6 +1133,8 @@ def transpose_slots(src, dst, table, nslots, total_tiles):
     return dst
 
 
+WGRAD_WINO = os.environ.get("CMR_WGRAD_WINO", "1") != "0"     # fp32 64 -> 64 stride-1 weight gradients in the Winograd domain (cmr_conv3x3_wgrad_wino_f32)
+WGRAD_WINO_MIN_PIXELS = 16384                                 # below: too few stages per workgroup to fill the two-buffer pipeline
 WGRAD_BF16 = True        # with CONV_BF16: 3x3 weight gradients on the bf16 cores as well (False: fp32 weight gradients, round 2's behaviour)
 
 
@@ -1161,7 +1163,14 @@ def conv3x3_wgrad(x, dy, dw, db=None, xpro=None):
             raise ValueError("conv3x3_wgrad: db must be a contiguous [Cout] view")
         _lib.call("cmr_conv3x3_wgrad_bias_bf16_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(db), _p(ws), nb, _stream())
         return
-    _lib.call("cmr_conv3x3_wgrad_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
+    rc = _lib.UNSUPPORTED
+    if WGRAD_WINO and cin == 64 and cout == 64 and H % 2 == 0 and W % 2 == 0 and B * H * W >= WGRAD_WINO_MIN_PIXELS:
+        # fp32, 64 -> 64: the weight gradient in the Winograd domain (16/36 of the direct sum's multiplies, like the forward)
+        nbw = _lib.load().cmr_conv3x3_wgrad_wino_workspace_bytes(B, H, W, cin, cout)
+        rc = _lib.call("cmr_conv3x3_wgrad_wino_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(_ws(nbw, x.device)), nbw, _stream(),
+                       allow_unsupported=True)
+    if rc == _lib.UNSUPPORTED:
+        _lib.call("cmr_conv3x3_wgrad_f32", _p(x), _p(dy), B, H, W, cin, cout, _p(dw), _p(ws), nb, _stream())
     if db is not None:
         colsum(dy.view(-1, cout), 1, B * H * W, out=db.view(1, cout))
 

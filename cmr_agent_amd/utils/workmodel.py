@@ -148,6 +148,9 @@ WORK = {
     # training direction (Train_Agent.py:296-305, Train_Geo.py:166-174): weight gradients as GEMMs over the minibatch's pixels / rows
     "cmr_conv3x3_wgrad_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
                                         F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
+    # the same gradient in the Winograd domain (algorithmic work of the direct sum; the kernel issues 16/36 of it: ISSUED)
+    "cmr_conv3x3_wgrad_wino_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
+                                             F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"]) + 9 * a["Cin"] * a["Cout"])),
     "cmr_conv3x3_wgrad_s2_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * (a["H"] // 2) * (a["W"] // 2),
                                            F * (a["B"] * a["H"] * a["W"] * (a["Cin"] + a["Cout"] / 4.0) + 9 * a["Cin"] * a["Cout"])),
     "cmr_conv3x3_wgrad_bf16_f32": lambda a: (2.0 * 9 * a["Cin"] * a["Cout"] * a["B"] * a["H"] * a["W"],
@@ -227,7 +230,8 @@ WORK = {
 # Multiplies the kernel ISSUES on the matrix cores per algorithmic multiply: F(2x2,3x3) Winograd computes 2x2 outputs with 16
 # products instead of 36.  `roofline.frac` prices the dominant kernel on issued work (<= 1 by construction); the algorithmic
 # figure stays beside it as frac_algorithmic.
-ISSUED = {"cmr_conv3x3_wino_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_stats_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_bnbwd_nhwc_f32": 16.0 / 36.0}
+ISSUED = {"cmr_conv3x3_wino_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_stats_nhwc_f32": 16.0 / 36.0, "cmr_conv3x3_wino_bnbwd_nhwc_f32": 16.0 / 36.0,
+          "cmr_conv3x3_wgrad_wino_f32": 16.0 / 36.0}
 
 
 def work(name, args, extra=None):

@@ -630,6 +630,15 @@ int cmr_conv3x3_wgrad_bias_bf16_pro_f32(const float* x, const float* xscale, con
                                         int W, int Cin, int Cout, float* dw, float* db, void* ws, int64_t ws_bytes, hipStream_t stream);
 int cmr_conv3x3_wgrad_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
                           int64_t ws_bytes, hipStream_t stream);
+/* The same gradient in the Winograd domain (round 6; Train_Geo.py:166-174 through models/ImageResNet.py:5-40: the forward and data-gradient
+ * convolutions run on F(2x2,3x3), this is the transpose of that identity): dw = sum over the 2x2 output tiles of G^T[(A dy A^T) (.) (B^T x B)]G
+ * -- 16 position GEMMs over the tiles (16 of the 36 multiplies of the direct sum) on v_mfma_f32_32x32x2_f32, fp32 accumulate, partial sums
+ * reduced in double in a fixed order, the fold with G once per launch.  Served: Cin = Cout = 64, H and W even; CMR_EUNSUPPORTED (-3)
+ * otherwise (the caller uses cmr_conv3x3_wgrad_f32).  Error against the float64 sum: 1.5 x the direct fp32 kernel's at K = 856 064 tiles
+ * (tools/wino_wgrad_check.py). */
+int64_t cmr_conv3x3_wgrad_wino_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int cmr_conv3x3_wgrad_wino_f32(const float* x, const float* dy, int B, int H, int W, int Cin, int Cout, float* dw, void* ws,
+                               int64_t ws_bytes, hipStream_t stream);
 /* nn.Conv1d(k=1) / nn.Linear weight and bias gradient over a row map: dw [n][k] (+)= dy^T x, db [n] (+)= column sums of dy
  * (db optional), any n, k: one launch over (row slices) x (n blocks of 128) x (k blocks of 128) + one deterministic
  * reduction of the slices. */

@@ -135,6 +135,48 @@ def test_conv3x3_weight_and_data_gradients(ops, B, H, W, cin, cout):
     close(dx2.permute(0, 3, 1, 2), x.grad, 5e-5, "conv dgrad (direct kernel)")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 96, 128), (1, 2, 16), (3, 10, 44), (1, 64, 2), (2, 30, 18), (4, 88, 304)])
+def test_conv3x3_weight_gradient_in_the_winograd_domain(ops, B, H, W):
+    """cmr_conv3x3_wgrad_wino_f32 (64 -> 64, even maps): dw = sum_tiles G^T[(A dy A^T)(.)(B^T x B)]G against the float64 gradient of
+    F.conv2d and against the direct kernel; maps whose tile rows do not fill the 8-tile stages (W/2 = 22, 9, 1), a single tile row, maps
+    smaller than one workgroup's pipeline, and a map that spreads over all persistent workgroups.  Non-zero channel means (what the
+    input transform's differences must cope with).  Odd sizes / other widths: -3, the wrapper falls back to the direct kernel."""
+    from cmr_agent_amd import _lib
+    cin = cout = 64
+    x = (rnd(B, cin, H, W, seed=21) + 0.4).double().requires_grad_(True)
+    w = (rnd(cout, cin, 3, 3, seed=22).double() / 10).requires_grad_(True)
+    dy = rnd(B, cout, H, W, seed=23).double()
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    xd = x.detach().float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    nb = _lib.load().cmr_conv3x3_wgrad_wino_workspace_bytes(B, H, W, cin, cout)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dw = torch.full((cout * cin * 9,), float("nan"), device=DEV)
+    _lib.call("cmr_conv3x3_wgrad_wino_f32", xd.data_ptr(), dyd.data_ptr(), B, H, W, cin, cout, dw.data_ptr(), ws.data_ptr(), nb,
+              torch.cuda.current_stream().cuda_stream)
+    close(dw.view(cout, cin, 3, 3), w.grad, 2e-5, "Winograd-domain weight gradient vs float64")
+    old = ops.WGRAD_WINO
+    ops.WGRAD_WINO = False
+    try:
+        dw0 = torch.empty_like(dw)
+        ops.conv3x3_wgrad(xd, dyd, dw0)
+    finally:
+        ops.WGRAD_WINO = old
+    close(dw0.view(cout, cin, 3, 3), w.grad, 2e-5, "direct weight gradient vs float64")
+    e_w = float((dw.view(cout, cin, 3, 3).cpu().double() - w.grad).abs().max())
+    e_d = float((dw0.view(cout, cin, 3, 3).cpu().double() - w.grad).abs().max())
+    assert e_w <= 3.0 * e_d + 1e-6 * float(w.grad.abs().max()), (e_w, e_d)
+    dw2 = torch.empty_like(dw)                                                   # deterministic: the same bits on a second launch
+    _lib.call("cmr_conv3x3_wgrad_wino_f32", xd.data_ptr(), dyd.data_ptr(), B, H, W, cin, cout, dw2.data_ptr(), ws.data_ptr(), nb,
+              torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(dw, dw2)
+    # not served -> -3 (no launch): odd width, other channel counts
+    assert _lib.call("cmr_conv3x3_wgrad_wino_f32", xd.data_ptr(), dyd.data_ptr(), B, H, W - 1, cin, cout, dw2.data_ptr(), ws.data_ptr(), nb,
+                     torch.cuda.current_stream().cuda_stream, allow_unsupported=True) == _lib.UNSUPPORTED
+    assert _lib.call("cmr_conv3x3_wgrad_wino_f32", xd.data_ptr(), dyd.data_ptr(), B, H, W // 2, 128, cout, dw2.data_ptr(), ws.data_ptr(), nb,
+                     torch.cuda.current_stream().cuda_stream, allow_unsupported=True) == _lib.UNSUPPORTED
+
+
 @pytest.mark.parametrize("rows,n,k,bias", [(8192, 64, 64, True), (40961, 64, 64, False), (20000, 128, 64, True), (9000, 64, 128, True), (8200, 128, 128, True),
                                            (163840, 64, 64, True), (10007, 32, 64, True), (12000, 64, 32, False), (8193, 128, 32, True)])
 def test_linear_weight_gradient_lds_staged_kernel(ops, rows, n, k, bias):
