@@ -319,6 +319,97 @@ __global__ __launch_bounds__(1024) void colmax_direct_kernel(const float* __rest
   }
 }
 
+// Round 6: the glue between two blocks of the agent's 3-D branch in ONE launch (CMRAgent.py:92-101: x = cat([feat, max over the points
+// broadcast back]) in front of every ConvBNReLURes1D after the first).  The block kernel leaves per-tile maxima; the next block wants the
+// broadcast half folded into per-sample biases  b1b = g W1[:, f:]^T + b1  and  b2b = g Wsc[:, f:]^T + b2.  That was three launches on the
+// serial chain of every agent step (colmax_direct_kernel + 2 x linear_skinny_kernel: 30 - 45 us of a 280 - 370 us chain); here a
+// 1024-thread workgroup per sample reduces its 64-channel maxima exactly as colmax_direct_kernel does (max is order independent) and then
+// forms both bias rows the way linear_skinny_kernel does -- lane l < 16 multiplies the 4 consecutive k = 4 l .. 4 l + 3, a wave owns 4
+// outputs, xor-shuffle reduction over the 64 lanes, bias added last.  The maxima are the same bits; the products agree with the three
+// launches to the last place or two (the compiler pairs the four products of a lane differently in the 8-row kernel), 64-term fp32 sums.
+__global__ __launch_bounds__(1024) void colmax_bias2_kernel(const float* __restrict__ part, int tiles_per_batch, const float* __restrict__ w1,
+                                                            const float* __restrict__ b1, int n1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, int n2, float* __restrict__ gout,
+                                                            float* __restrict__ y1, float* __restrict__ y2) {
+  constexpr int C = 64;
+  __shared__ f32x4 red[64][16];
+  __shared__ __attribute__((aligned(16))) float gs[C];
+  const int b = blockIdx.x, q = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const float* p = part + (int64_t)b * tiles_per_batch * C + 4 * q;
+  f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  for (int t0 = g; t0 < tiles_per_batch; t0 += 64 * 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + 64 * i;
+      v[i] = *reinterpret_cast<const f32x4*>(p + (int64_t)(t < tiles_per_batch ? t : t0) * C);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[i][e]);
+  }
+  red[g][q] = m;
+  __syncthreads();
+  if (g < 8) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      const f32x4 o = red[g + 8 * i][q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], o[e]);
+    }
+    red[g][q] = m;
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+      const f32x4 o = red[i][q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], o[e]);
+    }
+    *reinterpret_cast<f32x4*>(gs + 4 * q) = m;
+    if (gout) *reinterpret_cast<f32x4*>(gout + (int64_t)b * C + 4 * q) = m;
+  }
+  __syncthreads();
+  // the two skinny products: outputs [0, n1) of (w1, b1) then [0, n2) of (w2, b2); wave = 4 consecutive outputs per pass
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = lane * 4;
+  const bool kin = k < C;
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(gs + (kin ? k : 0));
+  const int ntot = n1 + n2;
+  for (int n0 = wave * 4; n0 < ntot; n0 += 64) {
+    // (n1 % 4 == 0: the four outputs of a wave belong to one of the two products)
+    const bool first = n0 < n1;
+    const float* w = first ? w1 : w2;
+    const float* bias = first ? b1 : b2;
+    float* y = first ? y1 + (int64_t)b * n1 : y2 + (int64_t)b * n2;
+    const int nn = first ? n0 : n0 - n1, nlim = first ? n1 : n2;
+    float acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const int n = nn + o < nlim ? nn + o : 0;
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (int64_t)n * C + (kin ? k : 0));
+      // one multiply + three fused multiply-adds, spelled out so that the result does not depend on the compiler's contraction choice
+      float a = 0.f;
+      if (kin) a += fmaf(wv[3], xv[3], fmaf(wv[2], xv[2], fmaf(wv[1], xv[1], wv[0] * xv[0])));
+      acc[o] = a;
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      float v = acc[o];
+#pragma unroll
+      for (int mm = 32; mm >= 1; mm >>= 1) v += __shfl_xor(v, mm);
+      acc[o] = v;
+    }
+    if (lane < 4 && nn + lane < nlim) {
+      float v = lane == 0 ? acc[0] : (lane == 1 ? acc[1] : (lane == 2 ? acc[2] : acc[3]));
+      v += bias[nn + lane];
+      y[nn + lane] = v;
+    }
+  }
+}
+
 template <int KX, int CH, int CO, bool CONV_SC>
 int launch_cbr(const CbrArgs& a, hipStream_t stream) {
   constexpr int T1 = (CH + 31) / 32;
@@ -374,5 +465,17 @@ extern "C" int cmr_colmax_partials_f32(const float* part, float* out, int B, int
   int z = (tiles_per_batch + 31) / 32;             // >= 32 tiles per chunk: 8 loads per thread
   z = z < 1 ? 1 : (z > 64 ? 64 : z);
   hipLaunchKernelGGL(colmax_partials_kernel, dim3(B, (C + 63) / 64, z), dim3(256), 0, stream, part, out, tiles_per_batch, C);
+  return cmr_launch_status();
+}
+
+// colmax of the block kernel's per-tile maxima (C = 64) + the two per-sample bias rows of the NEXT block in one launch (see
+// colmax_bias2_kernel): g [B][64] (optional output), y1 [B][n1] = g w1^T + b1, y2 [B][n2] = g w2^T + b2; w1 [n1][64], w2 [n2][64] contiguous,
+// n1 % 4 == 0, n2 % 4 == 0.  Other widths: CMR_EUNSUPPORTED (cmr_colmax_partials_f32 + cmr_linear_f32).
+extern "C" int cmr_colmax_bias2_f32(const float* part, int B, int tiles_per_batch, int C, const float* w1, const float* b1, int n1,
+                                    const float* w2, const float* b2, int n2, float* g, float* y1, float* y2, hipStream_t stream) {
+  CMR_REQUIRE(part && w1 && b1 && w2 && b2 && y1 && y2 && B > 0 && B <= 65535 && tiles_per_batch > 0 && n1 > 0 && n2 > 0);
+  if (C != 64 || n1 % 4 || n2 % 4) return CMR_EUNSUPPORTED;
+  CMR_REQUIRE(cmr_aligned16(part) && cmr_aligned16(w1) && cmr_aligned16(w2) && (!g || cmr_aligned16(g)));
+  hipLaunchKernelGGL(colmax_bias2_kernel, dim3(B), dim3(1024), 0, stream, part, tiles_per_batch, w1, b1, n1, w2, b2, n2, g, y1, y2);
   return cmr_launch_status();
 }

@@ -92,20 +92,27 @@ class CMRAgent(Planned):
         layers = self.state_3d_embed
         q0 = layers[0].plan()
         r = ops.cbr_block(state3d_rows, q0["l1"][0], q0["l1"][1], q0["l2"][0], q0["b2f"], q0["sc"][0], 0.2,
-                          rows_per_batch=N, want_colmax=True)
+                          rows_per_batch=N, want_colmax="partials")
         if r is None:
             return None
-        feat, g = r
+        feat, part = r
         for i, ent in enumerate(p["s3d"]):
-            b1b = ops.linear(g, ent["w1b"], ent["b1"])                   # [B, 2f] per-sample hidden bias
-            b2b = ops.linear(g, ent["wscb"], ent["b2"])                  # [B, co] per-sample output bias
+            # the block kernel leaves per-tile maxima; ONE launch finishes the max over the points and folds the broadcast half of the next
+            # block's input into its per-sample biases (three launches -- column max + two skinny GEMMs -- on the serial chain before round 6)
+            glue = ops.colmax_bias2(part, B, N // 32, ent["w1b"], ent["b1"], ent["wscb"], ent["b2"])
+            if glue is not None:
+                b1b, b2b = glue[0], glue[1]
+            else:
+                g = ops.colmax_partials(part, B, N // 32)
+                b1b = ops.linear(g, ent["w1b"], ent["b1"])               # [B, 2f] per-sample hidden bias
+                b2b = ops.linear(g, ent["wscb"], ent["b2"])              # [B, co] per-sample output bias
             last = i == 2
             r = ops.cbr_block(feat, ent["w1a"], b1b, ent["w2"], b2b, ent["wsca"], 0.2, rows_per_batch=N,
-                              want_y=not last, want_colmax=True)
+                              want_y=not last, want_colmax="partials")
             if r is None:
                 return None
-            feat, g = r
-        return g
+            feat, part = r
+        return ops.colmax_partials(part, B, N // 32)
 
     FUSED_TAIL = True
     TAIL_T = True           # ... on the transposed-weight kernel (cmr_agent_heads_t_f32); False: the row-per-wave kernel

@@ -118,10 +118,41 @@ def cbr_block(x1, w1, b1, w2, b2, wsc, slope, x2=None, idx2=None, div2=1, rows_p
     if rc == _lib.UNSUPPORTED:
         return None
     cm = None
+    if want_colmax == "partials":                # the per-tile maxima themselves: colmax_bias2 / colmax_partials finish them
+        return y, part
     if want_colmax:
-        cm = torch.empty((B, co), dtype=f32, device=x1.device)
-        _lib.call("cmr_colmax_partials_f32", _p(part), _p(cm), B, rpb // 32, co, _stream())
+        cm = colmax_partials(part, B, rpb // 32)
     return y, cm
+
+
+def colmax_partials(part, B, tiles_per_batch):
+    """part [B * tiles_per_batch, C] per-tile maxima of a block kernel -> [B, C]."""
+    co = part.shape[1]
+    cm = torch.empty((B, co), dtype=f32, device=part.device)
+    _lib.call("cmr_colmax_partials_f32", _p(part), _p(cm), B, int(tiles_per_batch), co, _stream())
+    return cm
+
+
+# fp32 mode only, by measurement (profiles/r06_ab_glue.txt, same box, alternating): headline 19.54 -> 19.43 ms per registration with the glue
+# launch, but the bf16-mode lines LOSE 1.5 % (c3 12.42 -> 12.60 ms, c1 in bf16 mode 8.93 -> 9.06 ms): under the bf16 convolutions the three
+# small launches (25 + 2 x 9 us in the graph) find room next to the persistent workgroups sooner than one 1024-thread workgroup per sample does.
+# CMR_COLMAX_BIAS2=0 / 1 forces it off / on in both modes.
+COLMAX_BIAS2 = os.environ.get("CMR_COLMAX_BIAS2", "fp32")
+
+
+def colmax_bias2(part, B, tiles_per_batch, w1, b1, w2, b2, want_g=False):
+    """The glue between two blocks of the agent's 3-D branch in one launch: column maxima g [B, 64] of the per-tile maxima `part`, and the
+    per-sample bias rows g w1^T + b1 [B, n1], g w2^T + b2 [B, n2] of the next block.  -> (y1, y2, g or None), or None when not served."""
+    C = part.shape[1]
+    n1, n2 = w1.shape[0], w2.shape[0]
+    if COLMAX_BIAS2 == "0" or (COLMAX_BIAS2 == "fp32" and CONV_BF16) or C != 64 or n1 % 4 or n2 % 4 or not (w1.is_contiguous() and w2.is_contiguous()) or w1.shape[1] != C or w2.shape[1] != C:
+        return None
+    y1 = torch.empty((B, n1), dtype=f32, device=part.device)
+    y2 = torch.empty((B, n2), dtype=f32, device=part.device)
+    g = torch.empty((B, C), dtype=f32, device=part.device) if want_g else None
+    rc = _lib.call("cmr_colmax_bias2_f32", _p(part), B, int(tiles_per_batch), C, _p(w1), _p(b1), n1, _p(w2), _p(b2), n2, _p(g), _p(y1), _p(y2), _stream(),
+                   allow_unsupported=True)
+    return None if rc == _lib.UNSUPPORTED else (y1, y2, g)
 
 
 def layernorm64(x, gamma, beta, eps, res=None, out=None):

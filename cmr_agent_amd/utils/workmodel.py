@@ -69,6 +69,8 @@ WORK = {
     "cmr_cbr_block_f32": _cbr,
     "cmr_cbr_block_bf16_f32": _cbr,
     "cmr_colmax_partials_f32": lambda a: (0, F * a["B"] * a["tiles_per_batch"] * a["C"]),
+    "cmr_colmax_bias2_f32": lambda a: (2.0 * a["B"] * a["C"] * (a["n1"] + a["n2"]),
+                                       F * (a["B"] * a["tiles_per_batch"] * a["C"] + (a["C"] + 1 + a["B"]) * (a["n1"] + a["n2"]))),
     "cmr_layernorm64_f32": lambda a: (0, F * a["rows"] * 64 * (3 if a["res"] else 2)),
     "cmr_conv3x3_nhwc_f32": _conv,
     "cmr_conv3x3_wino_nhwc_f32": lambda a: _conv(a, 1),

@@ -63,6 +63,13 @@ int cmr_cbr_block_bf16_f32(const float* x1, int64_t ld1, int k1, const float* x2
                            const float* w2, const float* b2, int64_t b2_stride, const float* wsc, float* y, int64_t ldy,
                            float* colmax_part, int64_t rows, int64_t rows_per_batch, float slope, hipStream_t stream);
 int cmr_colmax_partials_f32(const float* part, float* out, int B, int tiles_per_batch, int C, hipStream_t stream);
+/* The glue between two ConvBNReLURes1D blocks of the agent's 3-D branch in one launch (CMRAgent.py:92-101: cat([feat, max over the points])
+ * in front of every block after the first): g [B][64] = column maxima of the block kernel's per-tile maxima (as cmr_colmax_partials_f32; g
+ * optional), y1 [B][n1] = g w1^T + b1 and y2 [B][n2] = g w2^T + b2 -- the broadcast half of the next block's input folded into its per-sample
+ * biases (w1 [n1][64], w2 [n2][64] contiguous; 64-term fp32 sums in the lane order of the skinny cmr_linear_f32 path: the same maxima, products
+ * within a unit or two in the last place of the three launches it replaces).  C = 64, n1 % 4 == 0, n2 % 4 == 0; CMR_EUNSUPPORTED (-3) otherwise. */
+int cmr_colmax_bias2_f32(const float* part, int B, int tiles_per_batch, int C, const float* w1, const float* b1, int n1, const float* w2,
+                         const float* b2, int n2, float* g, float* y1, float* y2, hipStream_t stream);
 
 /* y = LayerNorm_64(x) * gamma + beta (+ res).  ImageViT.py:139-140, IMGPCEncoder.py:86-87 (eps 1e-6),
  * LinearAttention.py:33-34,64,69,71 (eps 1e-5, residual x + norm2(.)). */

@@ -615,6 +615,32 @@ def test_colmax_of_block_partials(ops, B, tiles, C):
     assert torch.equal(out.cpu(), part.view(B, tiles, C).max(1)[0])
 
 
+@pytest.mark.parametrize("B,tiles,n1,n2", [(8, 512, 128, 64), (4, 1024, 128, 128), (3, 37, 128, 64), (1, 1, 8, 4), (10, 700, 64, 128)])
+def test_colmax_and_both_bias_rows_in_one_launch(ops, B, tiles, n1, n2):
+    """cmr_colmax_bias2_f32 (the glue between two blocks of the agent's 3-D branch, CMRAgent.py:92-101) against the three launches it
+    replaces -- cmr_colmax_partials_f32 + two skinny cmr_linear_f32: the maxima bit for bit, the bias rows to a few units in the last place
+    (64-term fp32 sums, lanes and reduction in the same order; the compiler pairs a lane's four products differently in the two kernels) --
+    and against float64; -inf partials of empty tiles, an all-negative column; widths it does not serve return None."""
+    part = rnd(B * tiles, 64, seed=80 + tiles, lo=-9, hi=3)
+    part[:, 1] = -part[:, 1].abs() - 1.0
+    if tiles > 2:
+        part[1] = float("-inf")
+    w1, b1 = rnd(n1, 64, seed=81) / 8, rnd(n1, seed=82)
+    w2, b2 = rnd(n2, 64, seed=83) / 8, rnd(n2, seed=84)
+    d = lambda t: t.to(DEV)
+    pd, w1d, b1d, w2d, b2d = d(part), d(w1), d(b1), d(w2), d(b2)
+    got = ops.colmax_bias2(pd, B, tiles, w1d, b1d, w2d, b2d, want_g=True)
+    assert got is not None
+    y1, y2, g = got
+    g0 = ops.colmax_partials(pd, B, tiles)
+    assert torch.equal(g, g0) and torch.equal(g0.cpu(), part.view(B, tiles, 64).max(1)[0])
+    close(y1, ops.linear(g0, w1d, b1d), 5e-7, "bias row 1 vs the skinny GEMM")
+    close(y2, ops.linear(g0, w2d, b2d), 5e-7, "bias row 2 vs the skinny GEMM")
+    close(y1, g0.cpu().double() @ w1.double().t() + b1.double(), 2e-6, "bias row 1")
+    close(y2, g0.cpu().double() @ w2.double().t() + b2.double(), 2e-6, "bias row 2")
+    assert ops.colmax_bias2(d(rnd(B * tiles, 128, seed=85)), B, tiles, d(rnd(n1, 128, seed=86)), b1d, d(rnd(n2, 128, seed=87)), b2d) is None
+
+
 @pytest.mark.parametrize("kx,ch,co,conv", [(64, 128, 64, True), (64, 128, 128, False), (8, 8, 64, True), (64, 64, 64, False)])
 def test_cbr_block_column_maxima_are_the_maxima_of_its_rows(ops, kx, ch, co, conv):
     """The fp32 block's per-tile maxima (DPP reduction over the 32 rows of a tile in the matrix-core result layout) folded per

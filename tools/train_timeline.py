@@ -1,6 +1,7 @@
 """Timeline of ONE replayed agent update from a rocprofv3 kernel trace of `bench.py --mode train` (steps delimited by adam_kernel): per queue
 busy time and gaps, time with 0 / 1 / >= 2 kernels resident, the kernels that run alone, and the ordered kernel list.
-python tools/train_timeline.py <trace dir> [step index from the end, default 2] > timeline.txt"""
+python tools/train_timeline.py <trace dir> [step index from the end, default 2] [marker kernel, default adam_kernel; stem_a_kernel for a
+registration trace] > timeline.txt"""
 import collections
 import csv
 import glob
@@ -18,9 +19,10 @@ def short(n):
     return (m.group(1) + (m.group(2) or ''))[:60]
 
 
-marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+marker = sys.argv[3] if len(sys.argv) > 3 else 'adam_kernel'      # a step ENDS with adam_kernel; any other marker (stem_a_kernel) STARTS one
+marks = [i for i, r in enumerate(rows) if marker in r['Kernel_Name']]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-a, b = marks[-k - 1] + 1, marks[-k] + 1
+a, b = (marks[-k - 1] + 1, marks[-k] + 1) if marker == 'adam_kernel' else (marks[-k - 1], marks[-k])
 seg = rows[a:b]
 t0 = int(seg[0]['Start_Timestamp'])
 wall = max(int(r['End_Timestamp']) for r in seg) - t0
