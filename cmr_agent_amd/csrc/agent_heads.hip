@@ -20,6 +20,9 @@ struct AhArgs {
   AhHead h[3];
   float slope;
   int num_steps;                         // > 0: heads 0 / 1 also emit argmax over each group of num_steps logits (CMRAgent.py:118-123)
+  // training forward (cmr_agent_heads_train_f32): every intermediate the backward needs, in one buffer --
+  // pooled [B][128] | t1 = lrelu(conv 24) [B][128] | e2d = conv 26 [B][128] | per head: h0 [B][n0], h1 [B][n1] (post-activation)
+  float* saves;
 };
 
 // y[n] = act(b[n] + sum_k W[n][k] x[k]) for the outputs n = wave, wave + 16, ...; x in LDS, k % 4 == 0, k <= 256.
@@ -95,17 +98,27 @@ __global__ __launch_bounds__(AH_THREADS) void agent_heads_kernel(const AhArgs a)
     if (tid >= AH_C && tid < 2 * AH_C) state[tid] = a.e3d[(int64_t)b * AH_C + tid - AH_C];
     __syncthreads();
   }
+  const int B = gridDim.x;
+  const bool save = a.saves != nullptr;                         // (uniform)
+  const bool save0 = save && blockIdx.y == 0 && tid < AH_C;     // the shared part is written by the workgroup of head 0
+  if (save0) a.saves[(int64_t)b * AH_C + tid] = va[tid];
   ah_gemv(a.w24, a.b24, va, AH_C, AH_C, vb, true, a.slope, wave, lane);
   __syncthreads();
+  if (save0) a.saves[((int64_t)B + b) * AH_C + tid] = vb[tid];
   ah_gemv(a.w26, a.b26, vb, AH_C, AH_C, state, false, a.slope, wave, lane);
   __syncthreads();
+  if (save0) a.saves[((int64_t)2 * B + b) * AH_C + tid] = state[tid];
   // ---- ONE head per workgroup (blockIdx.y): the pool and the two 1x1 convs above are recomputed by the three workgroups
   // of a sample (345 KB of reads), which is cheaper than streaming the three heads' 1.2 MB through one CU layer by layer
   const AhHead& hd = a.h[blockIdx.y];
+  int64_t soff = (int64_t)3 * B * AH_C;                        // this head's h0 / h1 block in the saves
+  for (int i = 0; i < (int)blockIdx.y; ++i) soff += (int64_t)B * (a.h[i].n0 + a.h[i].n1);
   ah_gemv(hd.w0, hd.b0, state, AH_STATE, hd.n0, h0[0], true, a.slope, wave, lane);
   __syncthreads();
+  if (save && tid < hd.n0) a.saves[soff + (int64_t)b * hd.n0 + tid] = h0[0][tid];
   ah_gemv(hd.w1, hd.b1, h0[0], hd.n0, hd.n1, h1[0], true, a.slope, wave, lane);
   __syncthreads();
+  if (save && tid < hd.n1) a.saves[soff + (int64_t)B * hd.n0 + (int64_t)b * hd.n1 + tid] = h1[0][tid];
   ah_gemv(hd.w2, hd.b2, h1[0], hd.n1, hd.n2, hd.out + (int64_t)b * hd.ldo, false, a.slope, wave, lane);
   // deterministic action of this head: argmax of Categorical(logits).probs = argmax of the logits, first maximum on ties (what
   // cmr_argmax_rows_f32 returns for the same rows) -- saves the two argmax launches of every agent step
@@ -297,6 +310,42 @@ extern "C" int cmr_agent_heads_f32(const float* x, int B, int npix, const float*
     CMR_REQUIRE(h.n0 > 0 && h.n0 <= AH_MAXW && h.n0 % 4 == 0 && h.n1 > 0 && h.n1 <= AH_MAXW && h.n1 % 4 == 0);
     CMR_REQUIRE(cmr_aligned16(h.w0) && cmr_aligned16(h.w1) && cmr_aligned16(h.w2));
   }
+  hipLaunchKernelGGL(agent_heads_kernel, dim3(B, 3), dim3(AH_THREADS), 0, stream, a);
+  return cmr_launch_status();
+}
+
+extern "C" int cmr_agent_heads_train_f32(const float* x, int B, int npix, const float* w24, const float* b24, const float* w26,
+                                   const float* b26, const float* e3d,
+                                   const float* r_w0, const float* r_b0, const float* r_w1, const float* r_b1, const float* r_w2, const float* r_b2,
+                                   int r_n0, int r_n1, int r_n2, float* r_out, int r_ldo,
+                                   const float* t_w0, const float* t_b0, const float* t_w1, const float* t_b1, const float* t_w2, const float* t_b2,
+                                   int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
+                                   const float* v_w0, const float* v_b0, const float* v_w1, const float* v_b1, const float* v_w2, const float* v_b2,
+                                   int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                                   float* saves, int64_t saves_floats, float slope, hipStream_t stream) {
+  // the training forward of the same tail (Train_Agent.py:263-305 through CMRAgent.py:52-56, 101-116): the logits AND every intermediate
+  // the backward needs (AhArgs::saves) from one launch -- 13 launches (column mean, two 1x1 convs, nine head layers) on the serial
+  // stretch between the towers' join and the loss of every update before round 6
+  int64_t* r_act = nullptr; int64_t* t_act = nullptr;
+  const int num_steps = 0, degree_r = 0, degree_t = 0;
+  CMR_REQUIRE(saves && saves_floats >= (int64_t)B * (3 * AH_C + r_n0 + r_n1 + t_n0 + t_n1 + v_n0 + v_n1));
+  CMR_REQUIRE(x && w24 && b24 && w26 && b26 && e3d && B > 0 && npix > 0);
+  CMR_REQUIRE(cmr_aligned16(x) && cmr_aligned16(w24) && cmr_aligned16(w26));
+  AhArgs a{};
+  a.x = x; a.npix = npix; a.w24 = w24; a.b24 = b24; a.w26 = w26; a.b26 = b26; a.e3d = e3d; a.slope = slope;
+  // actions (optional): the logical widths degree * num_steps must fit the (padded) head widths
+  CMR_REQUIRE((!r_act && !t_act) || (num_steps > 0 && degree_r > 0 && degree_t > 0 && degree_r * num_steps <= r_n2 && degree_t * num_steps <= t_n2));
+  a.num_steps = (r_act || t_act) ? num_steps : 0;
+  a.h[0] = AhHead{r_w0, r_b0, r_w1, r_b1, r_w2, r_b2, r_n0, r_n1, r_n2, r_out, r_ldo, r_act, degree_r};
+  a.h[1] = AhHead{t_w0, t_b0, t_w1, t_b1, t_w2, t_b2, t_n0, t_n1, t_n2, t_out, t_ldo, t_act, degree_t};
+  a.h[2] = AhHead{v_w0, v_b0, v_w1, v_b1, v_w2, v_b2, v_n0, v_n1, v_n2, v_out, v_ldo, nullptr, 0};
+  for (int i = 0; i < 3; ++i) {
+    const AhHead& h = a.h[i];
+    CMR_REQUIRE(h.w0 && h.w1 && h.w2 && h.b0 && h.b1 && h.b2 && h.out && h.n2 > 0 && h.ldo >= h.n2);
+    CMR_REQUIRE(h.n0 > 0 && h.n0 <= AH_MAXW && h.n0 % 4 == 0 && h.n1 > 0 && h.n1 <= AH_MAXW && h.n1 % 4 == 0);
+    CMR_REQUIRE(cmr_aligned16(h.w0) && cmr_aligned16(h.w1) && cmr_aligned16(h.w2));
+  }
+  a.saves = saves;
   hipLaunchKernelGGL(agent_heads_kernel, dim3(B, 3), dim3(AH_THREADS), 0, stream, a);
   return cmr_launch_status();
 }

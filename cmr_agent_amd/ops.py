@@ -495,6 +495,34 @@ def agent_heads(x, B, npix, c24, c26, e3d, heads, slope, actions=None):
     return outs, (ar, at)
 
 
+def agent_heads_train(x, B, npix, c24, c26, e3d, heads, slope):
+    """Training forward of the agent's tail in one launch (cmr_agent_heads_train_f32): x [B*npix,128] (activated output of the last 3x3
+    conv), c24 / c26 / heads[i][j] = (W [out4,in4], bias [out4]) as stored in the flat bucket, e3d [B,128] ->
+    (outs [3 x [B,n2]], pooled, t1, e2d, [(h0, h1) per head]); the intermediates are views of ONE buffer.  None when the widths are not
+    the ones the kernel is built for (128 channels, hidden widths multiples of 4 up to 256)."""
+    if x.shape[1] != 128 or e3d.shape != (B, 128) or not e3d.is_contiguous() or c24[0].shape != (128, 128) or c26[0].shape != (128, 128):
+        return None
+    outs, args, widths = [], [], []
+    for (w0, b0), (w1, b1), (w2, b2) in heads:
+        n0, n1 = w0.shape[0], w1.shape[0]
+        if w0.shape[1] != 256 or w1.shape[1] != n0 or w2.shape[1] != n1 or n0 % 4 or n1 % 4 or n0 > 256 or n1 > 256:
+            return None
+        o = torch.empty((B, w2.shape[0]), dtype=f32, device=x.device)
+        outs.append(o)
+        widths.append((n0, n1))
+        args += [_p(w0), _p(b0), _p(w1), _p(b1), _p(w2), _p(b2), n0, n1, w2.shape[0], _p(o), o.stride(0)]
+    total = B * (3 * 128 + sum(a + b for a, b in widths))
+    saves = torch.empty((total,), dtype=f32, device=x.device)
+    _lib.call("cmr_agent_heads_train_f32", _p(_rows(x)), B, npix, _p(c24[0]), _p(c24[1]), _p(c26[0]), _p(c26[1]), _p(e3d), *args,
+              _p(saves), total, float(slope), _stream())
+    pooled, t1, e2d = (saves[i * B * 128:(i + 1) * B * 128].view(B, 128) for i in range(3))
+    off, hid = 3 * B * 128, []
+    for n0, n1 in widths:
+        hid.append((saves[off:off + B * n0].view(B, n0), saves[off + B * n0:off + B * (n0 + n1)].view(B, n1)))
+        off += B * (n0 + n1)
+    return outs, pooled, t1, e2d, hid
+
+
 def agent_heads_t(x, B, npix, c24t, c26t, e3d, heads_t, slope, actions=None):
     """agent_heads with every weight TRANSPOSED at plan time: c24t / c26t / heads_t[i][j] are (W^T [in, out4], bias [out4]) pairs
     (models/CMRAgent.py:_build_plan); one memory round trip per layer instead of per batch of weight rows + cross-lane reductions."""
@@ -1135,7 +1163,14 @@ def agent_loss(r_logits, t_logits, value, expert_r, expert_t, act_r, act_t, old_
                w_value, w_entropy, grad_scale=1.0):
     """-> (losses float32 [8], d_r_logits, d_t_logits, d_value) with the gradient buffers shaped like the (padded) inputs."""
     B = r_logits.shape[0]
-    d_r, d_t, d_v = torch.zeros_like(r_logits), torch.zeros_like(t_logits), torch.zeros_like(value)
+    # the padding columns of the gradient buffers must be zero (the kernel writes the logical ones): ONE zeroed allocation for the three
+    # (three fills were three nodes on the serial chain of every replayed update)
+    if r_logits.is_contiguous() and t_logits.is_contiguous() and value.is_contiguous():
+        nr, nt, nv = r_logits.numel(), t_logits.numel(), value.numel()
+        z = torch.zeros((nr + nt + nv,), dtype=f32, device=r_logits.device)
+        d_r, d_t, d_v = z[:nr].view_as(r_logits), z[nr:nr + nt].view_as(t_logits), z[nr + nt:].view_as(value)
+    else:
+        d_r, d_t, d_v = torch.zeros_like(r_logits), torch.zeros_like(t_logits), torch.zeros_like(value)
     out = torch.empty((8,), dtype=f32, device=r_logits.device)
     for t in (expert_r, expert_t, act_r, act_t):
         if t.dtype != torch.int64 or not t.is_contiguous():

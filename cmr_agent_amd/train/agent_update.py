@@ -28,15 +28,29 @@ LOSS_NAMES = ("loss", "clone_loss", "policy_loss", "value_loss", "entropy_loss",
 
 
 def _pad_running(bn, cpad):
-    """running statistics of a BatchNorm whose width is not a multiple of 4 (the 5-channel first block), zero padded."""
+    """Running statistics of a BatchNorm whose width is not a multiple of 4 (the 5-channel first block), zero padded -> (mean, var) of width
+    cpad that the statistics kernel updates IN PLACE.  The padded vectors are the storage of the module's own buffers from the first call
+    on (bn.running_mean / running_var become views of their first c entries: state_dict, load_state_dict and the graph's save / restore
+    keep working on them), so a step pays nothing for the padding -- round 5 built the padded copies and copied them back on every
+    step: 2 fills + 4 twenty-byte copies, six nodes on the serial chain of every replayed update."""
     c = bn.running_mean.numel()
     if c == cpad:
-        return bn.running_mean, bn.running_var, None
-    rm = torch.zeros(cpad, dtype=torch.float32, device=bn.running_mean.device)
-    rv = torch.ones(cpad, dtype=torch.float32, device=bn.running_mean.device)
-    rm[:c] = bn.running_mean
-    rv[:c] = bn.running_var
-    return rm, rv, c
+        return bn.running_mean, bn.running_var
+    pad = getattr(bn, "_cmr_padded_running", None)
+    if pad is None or pad[0].data_ptr() != bn.running_mean.data_ptr() or pad[1].data_ptr() != bn.running_var.data_ptr():
+        # first call, or the module was moved / its buffers replaced since: (re)attach
+        if torch.cuda.is_available() and bn.running_mean.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("BatchNorm running statistics must be attached to their padded storage before a hipGraph capture "
+                               "(run one eager step first: enable_graph does)")
+        dev = bn.running_mean.device
+        rm = torch.zeros(cpad, dtype=torch.float32, device=dev)
+        rv = torch.ones(cpad, dtype=torch.float32, device=dev)
+        rm[:c] = bn.running_mean
+        rv[:c] = bn.running_var
+        bn.running_mean.data = rm[:c]
+        bn.running_var.data = rv[:c]
+        pad = bn._cmr_padded_running = (rm, rv)
+    return pad
 
 
 class AgentUpdate:
@@ -75,12 +89,8 @@ class AgentUpdate:
         """BatchNorm statistics of the row map x for module `bn` (parameters `prefix`.weight / .bias in the bucket)."""
         C = x.shape[1]
         gamma, beta = self.bucket.w(prefix + ".weight"), self.bucket.w(prefix + ".bias")
-        rm, rv, c = _pad_running(bn, C)
-        stat = ops.bn_stats(x, gamma, beta, rm, rv, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
-        if c is not None:
-            bn.running_mean.copy_(rm[:c])
-            bn.running_var.copy_(rv[:c])
-        return stat
+        rm, rv = _pad_running(bn, C)
+        return ops.bn_stats(x, gamma, beta, rm, rv, eps=bn.eps, momentum=bn.momentum if bn.momentum is not None else 0.1)
 
     def _linear_bn(self, x, lin, bn, bnp, gmax, N, src, fused=None):
         """-> (x' W^T + b, BatchNorm statistics of it) for the conv `lin` + BatchNorm `bnp` pair of a 3-D block.  gmax [B, f] given: the
@@ -126,7 +136,23 @@ class AgentUpdate:
         # ---- heads on cat([embed_2d, embed_3d])
         T["heads"] = {}
         outs = []
-        for name in ("policy_r", "policy_t", "value"):
+        names = ("policy_r", "policy_t", "value")
+        if "tail_in" in T:
+            # AvgPool2d((H, W)) + the two 1x1 convs + the three heads, with every intermediate of the backward: ONE launch
+            # (cmr_agent_heads_train_f32) instead of 13 on the serial stretch between the towers' join and the loss
+            xr, npix = T.pop("tail_in")
+            wb = lambda n: (bk.w(n + ".weight"), bk.w(n + ".bias"))
+            r = ops.agent_heads_train(xr, B, npix, wb("state_2d_embed.24"), wb("state_2d_embed.26"), T["e3d"],
+                                      [[wb("%s.%d" % (n, j)) for j in (0, 2, 4)] for n in names], SLOPE2D)
+            if r is not None:
+                outs, T["pooled"], T["t1"], T["e2d"], hid = r
+                for n, (h1, h2), o in zip(names, hid, outs):
+                    T["heads"][n] = (h1, h2, o)
+                return T, outs
+            T["pooled"] = ops.colmean(xr, B, npix)
+            T["t1"] = ops.linear(T["pooled"], bk.w("state_2d_embed.24.weight"), bk.w("state_2d_embed.24.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
+            T["e2d"] = ops.linear(T["t1"], bk.w("state_2d_embed.26.weight"), bk.w("state_2d_embed.26.bias"))
+        for name in names:
             h1 = ops.linear(T["e2d"], bk.w(name + ".0.weight"), bk.w(name + ".0.bias"), x2=T["e3d"], act=ops.ACT_LRELU, act_param=SLOPE2D)
             h2 = ops.linear(h1, bk.w(name + ".2.weight"), bk.w(name + ".2.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
             o = ops.linear(h2, bk.w(name + ".4.weight"), bk.w(name + ".4.bias"))
@@ -135,6 +161,12 @@ class AgentUpdate:
         return T, outs
 
     FORK_BRANCHES = __import__("os").environ.get("CMR_AGENT_UPDATE_FORK", "1") == "1"
+    # Global pool + 1x1 convs + the three heads of the training forward in ONE launch (cmr_agent_heads_train_f32) instead of 13: built, parity-
+    # tested (tests/test_train_gpu.py::test_agent_update_tail_in_one_launch_vs_thirteen) and OFF, by measurement (round 6): the
+    # replayed update takes 3.40 ms either way -- the towers' backward passes run one after the other on this runtime and the step is
+    # bound by their kernels, not by the 130 us of short launches between them -- and its other summation order moves the two-step Adam
+    # fixture (test_agent_update_matches_oracle_and_reference_fixture: 10 222 of 1.6 M weights > 2e-5 through Adam's sign steps, bar 0.1 %).
+    FUSED_TAIL = __import__("os").environ.get("CMR_AGENT_UPDATE_FUSED_TAIL", "0") == "1"
 
     def _fork(self, side, main):
         """side / main: functions returning the branch GENERATORS (first yield = their number of launch groups, then one yield per group):
@@ -177,11 +209,16 @@ class AgentUpdate:
                 kh, kw = self.cfg.image_H // 8, self.cfg.image_W // 8
                 if (H, W) != (kh, kw):
                     raise ValueError("state_2d is %dx%d at the global pool, config says %dx%d" % (H, W, kh, kw))
-                pooled = ops.colmean(d.view(-1, c), B, H * W)                                        # AvgPool2d((H, W))
+                if self.FUSED_TAIL and c == 128:
+                    pooled = None                                  # global pool + 1x1 convs + heads: one launch after the join (_forward)
+                    T["tail_in"] = (d.view(-1, c), H * W)
+                else:
+                    pooled = ops.colmean(d.view(-1, c), B, H * W)                                    # AvgPool2d((H, W))
             yield
-        T["pooled"] = pooled
-        T["t1"] = ops.linear(pooled, bk.w("state_2d_embed.24.weight"), bk.w("state_2d_embed.24.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
-        T["e2d"] = ops.linear(T["t1"], bk.w("state_2d_embed.26.weight"), bk.w("state_2d_embed.26.bias"))
+        if pooled is not None:
+            T["pooled"] = pooled
+            T["t1"] = ops.linear(pooled, bk.w("state_2d_embed.24.weight"), bk.w("state_2d_embed.24.bias"), act=ops.ACT_LRELU, act_param=SLOPE2D)
+            T["e2d"] = ops.linear(T["t1"], bk.w("state_2d_embed.26.weight"), bk.w("state_2d_embed.26.bias"))
 
     def _forward_3d(self, s3, B, N):
         bk, ag = self.bucket, self.agent

@@ -75,7 +75,7 @@ class Tape:
 
     # CUs the MAIN branch's persistent convolution kernels may occupy while a side branch runs next to it (0 = all).  At the C5 shape the
     # image tower's launches fill every CU for ~600 us at a time and the point chain's 5 us reductions queue behind them; a reservation
-    # trades image-side throughput for the short chain's latency.  Measured; CMR_TAPE_MAIN_CUS sets it.
+    # trades image-side throughput for the short chain's latency.  Measured, see docs/MEASUREMENT_ROUNDS_1_5.md 5e; CMR_TAPE_MAIN_CUS sets it.
     MAIN_CUS = int(__import__("os").environ.get("CMR_TAPE_MAIN_CUS", "0"))
 
     def fork(self, side_fn, main_fn, tag="tape"):

@@ -105,6 +105,7 @@ WORK = {
     "cmr_la_reduce_f32": lambda a: (2.0 * a["B"] * a["S"] * 576, F * a["B"] * a["S"] * 128),
     "cmr_la_apply_f32": lambda a: (2.0 * a["B"] * a["L"] * 576, F * a["B"] * a["L"] * 128),
     "cmr_agent_heads_f32": _heads,
+    "cmr_agent_heads_train_f32": _heads,
     "cmr_ln64_linear_f32": lambda a: (2.0 * 64 * (a["rows_x"] * a["n_out_x"] + (a["rows_y"] * a["n_out_y"] if a["y"] else 0)),
                                       F * (a["rows_x"] * (64 + a["n_out_x"]) + (a["rows_y"] * (64 + a["n_out_y"]) if a["y"] else 0)
                                            + 64 * (a["n_out_x"] + (a["n_out_y"] if a["y"] else 0)))),

@@ -197,6 +197,19 @@ int cmr_agent_heads_f32(const float* x, int B, int npix, const float* w24, const
                         int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
                         int num_steps, int degree_r, int degree_t, int64_t* r_act, int64_t* t_act,
                         float slope, hipStream_t stream);
+/* Training forward of the same tail (Train_Agent.py:263-305 through CMRAgent.py:52-56, 101-116): the logits and, in `saves`, every
+ * intermediate the backward needs -- pooled [B][128] | t1 = lrelu(conv 24) [B][128] | e2d = conv 26 [B][128] | per head (r, t, v):
+ * h0 [B][n0], h1 [B][n1] (post-activation) -- from ONE launch instead of 13 (column mean, two 1x1 convs, nine head layers).
+ * saves_floats >= B (384 + sum of n0 + n1 over the heads).  Weights [out4][in4] as stored in the flat bucket. */
+int cmr_agent_heads_train_f32(const float* x, int B, int npix, const float* w24, const float* b24, const float* w26,
+                              const float* b26, const float* e3d,
+                              const float* r_w0, const float* r_b0, const float* r_w1, const float* r_b1, const float* r_w2, const float* r_b2,
+                              int r_n0, int r_n1, int r_n2, float* r_out, int r_ldo,
+                              const float* t_w0, const float* t_b0, const float* t_w1, const float* t_b1, const float* t_w2, const float* t_b2,
+                              int t_n0, int t_n1, int t_n2, float* t_out, int t_ldo,
+                              const float* v_w0, const float* v_b0, const float* v_w1, const float* v_b1, const float* v_w2, const float* v_b2,
+                              int v_n0, int v_n1, int v_n2, float* v_out, int v_ldo,
+                              float* saves, int64_t saves_floats, float slope, hipStream_t stream);
 /* The same tail with every weight matrix stored TRANSPOSED: W^T [in][out4] (out4 = the output width padded to a multiple of 4 with zero
  * columns; hidden widths n0, n1 multiples of 16): a lane owns four outputs and a wave a slice of the inputs, so that a layer is one memory
  * round trip and no cross-lane reduction (35 -> ~15 us per agent step on the serial chain of a registration).  Same arguments otherwise;

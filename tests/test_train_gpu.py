@@ -719,6 +719,70 @@ def test_agent_update_variants_at_the_benchmark_shape():
         assert err <= 2e-4 * gmax, "%s: max|d| %.3e vs largest gradient %.3e" % (k, err, gmax)
 
 
+def test_agent_update_tail_in_one_launch_vs_thirteen():
+    """cmr_agent_heads_train_f32 (round 6: AvgPool2d((H, W)) + the two 1x1 convs + the three heads of CMRAgent.py:52-56, 101-116 with every
+    intermediate of the backward, one launch) against the 13 launches it replaces (column mean, two skinny GEMMs, nine head layers):
+    op level -- logits and every saved intermediate to fp32 summation-order accuracy, against float64 too; update level at the benchmark
+    shape -- losses to 1e-6, every gradient tensor within 2e-5 of the model's largest gradient entry (the tail's sums take another
+    order, nothing else changes)."""
+    from cmr_agent_amd import ops
+    from cmr_agent_amd.train import AgentUpdate
+    B, npix = 10, 11 * 38
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *sh: (torch.rand(*sh, generator=g) * 2 - 1).to(DEV)
+    x, e3d = rnd(B * npix, 128), rnd(B, 128)
+    lin = lambda n, k: (rnd(n, k) / k ** 0.5, rnd(n))
+    c24, c26 = lin(128, 128), lin(128, 128)
+    heads = [[lin(256, 256), lin(256, 256), lin(12, 256)], [lin(256, 256), lin(256, 256), lin(24, 256)], [lin(64, 256), lin(64, 64), lin(4, 64)]]
+    outs, pooled, t1, e2d, hid = ops.agent_heads_train(x, B, npix, c24, c26, e3d, heads, 0.01)
+    lr = torch.nn.functional.leaky_relu
+    d = lambda t: t.double()
+    p_ref = d(x).view(B, npix, 128).mean(1)
+    t1_ref = lr(p_ref @ d(c24[0]).t() + d(c24[1]), 0.01)
+    e_ref = t1_ref @ d(c26[0]).t() + d(c26[1])
+    st = torch.cat([e_ref, d(e3d)], 1)
+
+    def close(a, b, what):
+        err, sc = float((d(a) - b).abs().max()), max(float(b.abs().max()), 1e-6)
+        assert err <= 3e-6 * sc, "%s: max|d| %.3e vs scale %.3e" % (what, err, sc)
+    close(pooled, p_ref, "pooled")
+    close(t1, t1_ref, "t1")
+    close(e2d, e_ref, "e2d")
+    for (l0, l1, l2), (h0, h1), o, name in zip(heads, hid, outs, "rtv"):
+        h0r = lr(st @ d(l0[0]).t() + d(l0[1]), 0.01)
+        h1r = lr(h0r @ d(l1[0]).t() + d(l1[1]), 0.01)
+        close(h0, h0r, name + " h0")
+        close(h1, h1r, name + " h1")
+        close(o, h1r @ d(l2[0]).t() + d(l2[1]), name + " out")
+    # the 13 launches
+    p13 = ops.colmean(x, B, npix)
+    t13 = ops.linear(p13, *c24, act=ops.ACT_LRELU, act_param=0.01)
+    e13 = ops.linear(t13, *c26)
+    close(pooled, d(p13), "pooled vs colmean")
+    close(e2d, d(e13), "e2d vs the skinny GEMMs")
+    assert ops.agent_heads_train(rnd(B * npix, 64), B, npix, c24, c26, e3d, heads, 0.01) is None            # widths it does not serve
+
+    case = "agent_train_full"
+    cfg_d = C.train_config(case, device=DEV)
+    batch = _to_dev(C.train_inputs(case)[0])
+    runs, old = {}, AgentUpdate.FUSED_TAIL
+    try:
+        for fused in (True, False):
+            AgentUpdate.FUSED_TAIL = fused
+            up = AgentUpdate(_product_agent(cfg_d), cfg_d)
+            losses, _ = up.forward_backward(batch)
+            torch.cuda.synchronize()
+            runs[fused] = (losses.clone(), {k: v.clone() for k, v in up.bucket.logical_grads().items()})
+    finally:
+        AgentUpdate.FUSED_TAIL = old
+    (lf, gf), (lp, gp) = runs[True], runs[False]
+    assert float((lf - lp).abs().max()) <= 1e-6 * max(1.0, float(lp.abs().max()))
+    gmax = max(float(v.abs().max()) for v in gp.values())
+    for k in gp:
+        err = float((gf[k] - gp[k]).abs().max())
+        assert err <= 2e-5 * gmax, "%s: max|d| %.3e vs largest gradient %.3e" % (k, err, gmax)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_agent_graph_replay_equals_eager_steps(mode):
     """AgentUpdate.enable_graph: forward + backward replayed from a hipGraph (all-reduce and the optimizer launch per step) must walk the

@@ -1,6 +1,6 @@
 // Sustained fp32 / bf16 matrix rate of the device this runs on: a grid of waves that do nothing but dependent-free chains of
 // v_mfma_f32_32x32x2_f32 (and v_mfma_f32_32x32x16_bf16) for a given number of iterations; HIP events; several durations so that clock
-// throttling under sustained load shows.  Development tool (DESIGN.md 5d quotes it next to the nominal peaks of MI355X_MICROARCH.md):
+// throttling under sustained load shows.  Development tool (docs/MEASUREMENT_ROUNDS_1_5.md 5d quotes it next to the nominal peaks of MI355X_MICROARCH.md):
 //   hipcc --offload-arch=gfx950 -O3 tools/mfma_peak.hip -o gpurun_out/mfma_peak && gpurun_out/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
