@@ -11,12 +11,13 @@ import json
 import os
 import sys
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
+os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "1")        # HIP runtime: cross-queue waits resolved on the host; replayed registration / agent update - 2 to - 3 % (bench.py, profiles/r06_ab_cpuwait.txt)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 from cmr_agent_amd.dataset.sampling import hip_fps, hip_nearest  # noqa: E402
 from cmr_agent_amd.config import KittiConfiguration, NuScenesConfiguration  # noqa: E402

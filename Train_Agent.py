@@ -24,6 +24,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
+os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "1")        # HIP runtime: cross-queue waits resolved on the host; replayed registration / agent update - 2 to - 3 % (bench.py, profiles/r06_ab_cpuwait.txt)
 
 if __name__ == "__main__":
     # `--gpus N` without a launcher: start the N ranks as a child (python -m torch.distributed.run ...) before anything touches the GPU

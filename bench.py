@@ -25,6 +25,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL on this host driver): read at HSA init, so set before any GPU call
+# ROC_CPU_WAIT_FOR_SIGNAL=1 (HIP runtime: cross-queue waits are resolved on the host instead of with barrier packets in the queues; read when
+# the runtime initialises).  Measured round 6, same box, alternating, two repetitions each (profiles/r06_ab_cpuwait.txt): replayed
+# registration 19.44 -> 19.05 ms (fp32 headline), 8.75 -> 8.51 (bf16 mode), 12.04 -> 11.83 (c3); agent update 3.35 -> 3.26 ms; the geometric
+# update LOSES (31.7 -> 33.2 ms) -- so every mode but train-geo sets it (Test_Agent.py / Train_Agent.py too, Train_Geo.py does not), and
+# the default line measures its two train_geo sub-objects in a child process without it (geo_lines_in_child).  setdefault: the caller's
+# own setting wins.
+if "train-geo" not in sys.argv[1:]:
+    os.environ.setdefault("ROC_CPU_WAIT_FOR_SIGNAL", "1")
 
 if __name__ == "__main__":
     # --gpus N without a launcher: this process only starts `python -m torch.distributed.run ... bench.py <same flags>` as a
@@ -100,7 +108,9 @@ def cpu_baseline(spec, budget_s=24.0, pairs=2, passes=3):
     noise); the median is reported, scaled to pairs / s."""
     from oracle import cmr_oracle as O
     w = WORKLOAD
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))     # past ~32 threads torch's small CPU ops only get slower
+    # 32 threads: measured on the GPU box's host (profiles/r06_cpu_threads.txt, tools/r06_cpu_threads.sh: the same sample at 16 / 32 / 64
+    # threads); CMR_CPU_BASELINE_THREADS overrides
+    torch.set_num_threads(int(os.environ.get("CMR_CPU_BASELINE_THREADS", min(os.cpu_count() or 1, 32))))
     cfg = KittiConfiguration(cropped_img_H=w["H"], cropped_img_W=w["W"], num_pt=w["N"], device="cpu",
                              action_num=w["steps"])
     geo_sd = hashfill.make_state_dict(spec["geo"], GEO_TAG)
@@ -862,9 +872,39 @@ def compact(line):
                                          "launches_per_step", "avg_launch_us", "dominant_ms_per_step", "kernel_ms_per_step",
                                          "families_ms_per_step", "flop_per_byte") if k in r}
     for k in ("cpu_baseline", "launches_per_step", "launch_mode", "prologue_ms", "prologue", "prologue_overlap", "allreduce_ms_per_step", "rccl_ranks", "rccl_version",
-              "rccl_note", "collective_ranks", "per_gpu", "agent_steps_per_s"):
+              "rccl_note", "collective_ranks", "per_gpu", "agent_steps_per_s", "measured_in"):
         if k in line:
             out[k] = line[k]
+    return out
+
+
+def geo_lines_in_child(args):
+    """The two `train_geo` sub-objects of the default line from CHILD processes (`bench.py --mode train-geo ...`, fresh HIP runtime without
+    ROC_CPU_WAIT_FOR_SIGNAL -- see the top of this file): -> (C5 line, 160x512 line), or None when a child fails (the caller then measures
+    them in this process, slower by what the flag costs that step, and says so).  A child is a new program started by this one, never an
+    exec of it; the parent's device memory has been released (empty_cache) before."""
+    import subprocess
+    env_c = dict(os.environ, ROC_CPU_WAIT_FOR_SIGNAL="0")
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "LOCAL_RANK", "WORLD_SIZE", "GROUP_RANK", "LOCAL_WORLD_SIZE"):
+        env_c.pop(k, None)                        # world size 1: the child brings its own one-rank process group up (--force-dist)
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "train-geo", "--num-pt", "65536", "--steps", "5", "--warmup", "2"]
+    if args.dist_backend == "nccl" and not args.no_force_dist:
+        base.append("--force-dist")
+    out = []
+    for extra, cpu in ((["--img", "352x1216", "--prologue"], not args.no_cpu_baseline), ([], False)):
+        cmd = base + extra + ([] if cpu else ["--no-cpu-baseline"])
+        try:
+            r = subprocess.run(cmd, env=env_c, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                sys.stderr.write("bench.py: train-geo child failed (rc %s): %s\n" % (r.returncode, r.stderr[-500:]))
+                return None
+            d = json.loads(lines[-1])
+            d["measured_in"] = "child process `%s` (ROC_CPU_WAIT_FOR_SIGNAL=0: the flag the other modes run with costs this step 4 - 5 %%)" % " ".join(cmd[1:])
+            out.append(d)
+        except Exception as e:                  # noqa: BLE001
+            sys.stderr.write("bench.py: train-geo child: %s: %s\n" % (type(e).__name__, e))
+            return None
     return out
 
 
@@ -945,9 +985,13 @@ def main():
         ops.CONV_BF16 = False
         torch.cuda.empty_cache()
         sub.steps, sub.warmup, sub.dtype, sub.num_pt, sub.img, sub.prologue = 5, 2, "f32", 65536, "352x1216", True
-        geo5 = geo_train_main(sub, ctx, with_cpu=not args.no_cpu_baseline)
-        sub.img, sub.prologue = None, False
-        geo160 = geo_train_main(sub, ctx, with_cpu=False)
+        kids = geo_lines_in_child(args) if (os.environ.get("ROC_CPU_WAIT_FOR_SIGNAL") == "1" and rank == 0) else None
+        if kids is not None:
+            geo5, geo160 = kids
+        else:
+            geo5 = geo_train_main(sub, ctx, with_cpu=not args.no_cpu_baseline)
+            sub.img, sub.prologue = None, False
+            geo160 = geo_train_main(sub, ctx, with_cpu=False)
         if rank == 0:
             line["c3"] = compact(c3)
             line["c1_bf16"] = compact(c1b)

@@ -2,10 +2,13 @@
 on T image proxies x Q point proxies.  API / state_dict mirror of the reference's
 models/IMGPCEncoder.py (:105-164).  Inputs stay on the device of the module's parameters
 (the reference hard-codes .cuda(), :130-134)."""
+import torch
 import torch.nn as nn
 
 from .. import ops
-from ..utils.streams import fork_join
+from ..utils.streams import fork_join, in_side_branch as streams_in_side_branch
+import os
+TOWERS_SWAPPED = os.environ.get("CMR_TOWERS_SWAPPED", "0") == "1"
 from ._pack import Planned, device_of
 from ._vit import Attention, Block, Mlp  # noqa: F401
 from .ImageViT import ImageTransformer
@@ -61,7 +64,13 @@ class IMGPCEncoder(Planned):
                     return self.img_transformer.forward_cl(img)
             return self.img_transformer.forward_cl(img)
 
-        (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat), (img_proxy, T, f2, f1, f0) = fork_join(point_tower, image_tower, tag="towers")
+        if TOWERS_SWAPPED and torch.cuda.is_available() and not streams_in_side_branch():
+            # round 6: the IMAGE tower (14 long launches) as the side branch, issued first, the point tower (~100 short launches) on the
+            # current stream: a replayed graph hands out the first-captured stream's nodes before the other's
+            (img_proxy, T, f2, f1, f0), (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat) = fork_join(image_tower, point_tower, tag="towers",
+                                                                                                       main_first=False)
+        else:
+            (geo, pt_proxy, n2p, n2p_global, pt_feat, node_feat), (img_proxy, T, f2, f1, f0) = fork_join(point_tower, image_tower, tag="towers")
         for i in range(self.config.num_ca_layer_coarse):
             img_proxy = self.p2i_ca_layers[i].rows(img_proxy, pt_proxy, B, T, Q)
             pt_proxy = self.i2p_ca_layers[i].rows(pt_proxy, img_proxy, B, Q, T)

@@ -65,6 +65,14 @@ class fp32_linears:
         LINEAR_BF16 = self.old
 
 
+_AB_SKIP_LINEAR = os.environ.get("CMR_AB_SKIP_LINEAR", "0") == "1"
+_AB_ZERO = {}
+if _AB_SKIP_LINEAR:
+    import sys as _sys
+    print("cmr_agent_amd.ops: CMR_AB_SKIP_LINEAR=1 -- row GEMMs are NOT computed (timing experiment); every result of this process is invalid",
+          file=_sys.stderr)
+
+
 def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, act=ACT_NONE, act_param=0.0, out=None):
     _rows(x1, "x1")
     rows, k1 = x1.shape
@@ -81,6 +89,13 @@ def linear(x1, w, bias=None, x2=None, idx2=None, div2=1, res=None, res_mod=0, ac
     _rows(out, "out")
     if res is not None:
         _rows(res, "res")
+    if _AB_SKIP_LINEAR:
+        # MEASUREMENT ONLY (tools/r06_ab_skip_linear.sh): the row GEMM is not launched, the output is a zero map made once
+        # per shape -- what a registration step would take if this whole kernel family cost nothing.  Results are meaningless.
+        key = (rows, n_out, x1.device)
+        if key not in _AB_ZERO:
+            _AB_ZERO[key] = torch.zeros((rows, n_out), dtype=f32, device=x1.device)
+        return _AB_ZERO[key]
     if CONV_BF16 and LINEAR_BF16 and x2 is None and ldw == kw and rows >= LINEAR_BF16_MIN_ROWS and k1 in (32, 64, 128) and n_out <= 128 and n_out % 4 == 0:
         # bf16 mode: the big row maps stream through the bf16 cores (the fp32 kernel is bound by its MFMA chain at these shapes)
         rc = _lib.call("cmr_linear_rows_bf16_f32", _p(x1), _ld(x1), k1, _p(w), kw, _p(bias), _p(res), _ld(res) if res is not None else 0,

@@ -91,7 +91,7 @@ def _segmented_fork(sg, fns, tag):
         _depth -= 1
 
 
-def fork_join(*fns, tag=""):
+def fork_join(*fns, tag="", main_first=None):
     """fork_join(f0, ..., fn): runs f0 .. f(n-1) on side streams concurrently with fn (the MAIN branch) on the current stream and returns all
     results (in argument order) after joining.  Sequential on CPU / when disabled / inside sequential_forks().
 
@@ -131,7 +131,7 @@ def fork_join(*fns, tag=""):
 
     try:
         out = []
-        if _main_first(tag):    # the two-stage pipeline keeps geo stage (side) first: 942 vs 849-875 it/s in bf16 mode
+        if _main_first(tag) if main_first is None else main_first:    # the two-stage pipeline keeps geo stage (side) first: 942 vs 849-875 it/s in bf16 mode
             # issue order = the order in which a replayed hipGraph hands the nodes to the device: a main branch of few, long kernels
             # (the image tower) goes first, the many short launches of the side branch are fed while it already runs
             last = fns[-1]()
@@ -145,6 +145,11 @@ def fork_join(*fns, tag=""):
     for s in sides:
         main.wait_stream(s)
     return tuple(out)
+
+
+def in_side_branch():
+    """the code running now was issued by a side branch of an enclosing fork (a fork issued here cannot be captured: DESIGN.md 6b)"""
+    return _in_side
 
 
 def _exhaust(gen):

@@ -146,10 +146,11 @@ def test_frame_dataset_sample_dict_on_device(tmp_path):
     np.random.seed(3)
     torch.manual_seed(3)
     st = dt[1]
-    assert dt.last_jitter is not None and sorted(dt.last_jitter[0]) == [0, 1, 2, 3]
+    jit, crop = dt.last_jitter, dt.last_draws["crop"]                  # (image_tensor(jitter=False) below clears last_jitter; read_frame draws anew)
+    assert jit is not None and sorted(jit[0]) == [0, 1, 2, 3]
     f = dt.read_frame(1)
-    plain = dt.image_tensor(f["img"], f["resized"], dt.last_draws["crop"], jitter=False)
-    replay, _ = color_jitter(plain * 255.0, draws=dt.last_jitter)
+    plain = dt.image_tensor(f["img"], f["resized"], crop, jitter=False)
+    replay, _ = color_jitter((plain * 255.0).round(), draws=jit)         # (the 0..255 grid the sample's image was jittered on)
     assert torch.equal(st["img"], (replay / 255.0).contiguous()) and not torch.equal(st["img"], plain)
     assert 0.0 <= float(st["img"].min()) and float(st["img"].max()) <= 1.0
 
