@@ -163,8 +163,8 @@ class AgentUpdate:
     FORK_BRANCHES = __import__("os").environ.get("CMR_AGENT_UPDATE_FORK", "1") == "1"
     # Global pool + 1x1 convs + the three heads of the training forward in ONE launch (cmr_agent_heads_train_f32) instead of 13: built, parity-
     # tested (tests/test_train_gpu.py::test_agent_update_tail_in_one_launch_vs_thirteen) and OFF, by measurement (round 6): the
-    # replayed update takes 3.40 ms either way -- the towers' backward passes run one after the other on this runtime and the step is
-    # bound by their kernels, not by the 130 us of short launches between them -- and its other summation order moves the two-step Adam
+    # replayed update takes 3.40 ms either way -- the step is bound by the towers' HBM-bound kernels, not by the 130 us of short launches
+    # between them -- and its other summation order moves the two-step Adam
     # fixture (test_agent_update_matches_oracle_and_reference_fixture: 10 222 of 1.6 M weights > 2e-5 through Adam's sign steps, bar 0.1 %).
     FUSED_TAIL = __import__("os").environ.get("CMR_AGENT_UPDATE_FUSED_TAIL", "0") == "1"
 

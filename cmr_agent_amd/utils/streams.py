@@ -172,7 +172,8 @@ def fork_join_interleaved(side_fn, main_fn, tag=""):
     Why: a replayed hipGraph hands its nodes to the device in the order they were captured, at a few microseconds per node from the host.
     Captured branch after branch (fork_join above), the second branch's first kernel reaches its queue only after ALL of the first
     branch's nodes: in the agent update the 3-D tower started 0.45 ms after the fork and the device held exactly one kernel for 70 % of
-    the step (profiles/r06_train_timeline_before.txt).  Captured interleaved, both queues are fed from the start.  Same kernels, same
+    the step (profiles/r06_train_timeline_before.txt -- a rocprofv3 trace, and tracing itself delays the branch issued second: DESIGN.md 5).  Captured
+    interleaved, both queues are fed from the start; unprofiled the update moves from 3.40 to 3.38 ms.  Same kernels, same
     operands, same order within each branch: results are bit-identical to the sequential issue.
     Sequential (side, then main) on CPU / when streams are disabled / inside sequential_forks()."""
     global _depth, _in_side

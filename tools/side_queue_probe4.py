@@ -52,4 +52,21 @@ for n_main, order in CFGS:
             g.replay()
             torch.cuda.synchronize()
             time.sleep(0.003)
-        print("config n_main=%d order=%s" % (n_main, order), flush=True)
+        # WITHOUT a profiler the question "do the two chains overlap" is answered by the replay's duration (HIP events around it) against
+        # the two chains alone: origin only (n_side = 0) and side only (n_main = 0)
+        def timed(gr):
+            ts = []
+            for _ in range(7):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                gr.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            return sorted(ts)[3]
+        both = timed(g)
+        only_main = timed(build(n_main, order, n_side=0))
+        only_side = timed(build(0, order))
+        print("config n_main=%d order=%s: replay %.1f us; origin chain alone %.1f us, side chain alone %.1f us (sum %.1f, max %.1f)" % (
+            n_main, order, both, only_main, only_side, only_main + only_side, max(only_main, only_side)), flush=True)
